@@ -1,0 +1,1191 @@
+/*
+ * mdk_oracle.c -- CPU ORACLE for the `MethylDackel extract` hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and the `cpu_baseline` leg of bench.py may build, link or run it.
+ * The shipped path (methyldackel_amd/) never includes, links or executes anything here.
+ *
+ * What it is: a plain-C, single-threaded, deliberately literal restatement of the
+ * reference algorithm (MethylDackel 0.6.1, /root/reference) for `extract`:
+ *   - option surface / validation / return codes      extract.c:706-1069,1343-1514
+ *   - chunk scheduler + adjustBounds                   extract.c:325-378, common.c:466-493
+ *   - read admission (filter_func) + trimming          common.c:137-208,407-463
+ *   - mappability filter (BBM input)                   common.c:210-335, extract.c:1236-1339
+ *   - conversion-efficiency filter                     common.c:338-404
+ *   - mate-overlap quality resolution                  overlaps.c:27-147
+ *   - per-column pileup loop, variant filter, merge    extract.c:399-510
+ *   - text emitters                                    extract.c:39-99,207-222,562-569
+ * plus a restatement of the behaviour of the third-party engine the reference sits on
+ * (htslib >= 1.11, NOT vendored in the reference and NOT installed in this image): BGZF/BAM
+ * decode, region iteration (sam_itr_queryi), the bam_plp/bam_mplp pileup buffer with its
+ * constructor/destructor callbacks, bam_aux_get/bam_aux2i, faidx_fetch_seq, hts_parse_reg.
+ * Those are restated from the htslib API contract and its published algorithm.
+ *
+ * PARITY STATUS: "weakly pinned".  The reference cannot be compiled here (htslib and
+ * libBigWig are absent, no network), so the only pins are the reference's own test
+ * expectations (tests/test.py: 15 CLI runs asserting output LINE COUNTS on the fixture
+ * BAMs that are copied, as data, under tests/golden/).  tests/test_oracle_reference_vectors.py
+ * replays all 15.  14 agree; case 8 (--nOT 50,50,40,40 -> reference asserts 12 lines) yields
+ * 11 lines here, and by hand-execution of common.c:174-208 + overlaps.c:54-119 -- documented in
+ * DESIGN.md.  No byte-level golden output exists in the reference.
+ *
+ * Not supported (reference gets them only via libraries absent here): CRAM input, bigWig (-M).
+ * BED (-l/--keepStrand) is outside the accelerated path and not restated.
+ *
+ * Style note: this file follows the reference's control flow one step at a time (a real pileup
+ * buffer swept column by column, reads copied into it, qualities rewritten in place).  The
+ * product does none of that -- it is a read-parallel scatter on the GPU -- which is what makes
+ * comparing the two meaningful.
+ */
+#define _GNU_SOURCE
+#include <assert.h>
+#include <errno.h>
+#include <getopt.h>
+#include <inttypes.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#define ORACLE_VERSION "0.6.1"
+#define RUNOFFSET 99
+#define BBM_VERSION 1
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+static void *xmalloc(size_t n) { void *p = malloc(n ? n : 1); if(!p) { fprintf(stderr, "oracle: out of memory\n"); exit(2); } return p; }
+static void *xrealloc(void *q, size_t n) { void *p = realloc(q, n ? n : 1); if(!p) { fprintf(stderr, "oracle: out of memory\n"); exit(2); } return p; }
+static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+typedef struct { char *s; size_t l, m; } kstr;
+static void kputs_(kstr *k, const char *s) {
+    size_t n = strlen(s);
+    if(k->l + n + 1 > k->m) { k->m = (k->l + n + 1) * 2; k->s = xrealloc(k->s, k->m); }
+    memcpy(k->s + k->l, s, n + 1); k->l += n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* BAM file, fully inflated in memory (BGZF: concatenated gzip members, SAM spec 4.1)           */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t tid, pos, l_qseq, mtid, mpos;
+    uint16_t flag, n_cigar;
+    uint8_t mapq, l_qname;
+    const char *qname;
+    const uint8_t *cigar, *seq, *qual, *aux;   /* cigar is unaligned little-endian u32[] */
+    int32_t aux_len;
+    int32_t rlen;                              /* raw reference length of the CIGAR */
+} brec;
+
+typedef struct {
+    uint8_t *data; size_t len;
+    int32_t n_targets; char **target_name; uint32_t *target_len;
+    brec *rec; size_t n_rec;
+    size_t *tid_lo, *tid_hi;                   /* record index range per tid (sorted input) */
+    int32_t max_rlen;
+} bamfile;
+
+static uint32_t cig_op(const uint8_t *c, int i) { return rd32(c + 4 * i) & 0xf; }
+static uint32_t cig_len(const uint8_t *c, int i) { return rd32(c + 4 * i) >> 4; }
+
+/* bam_cigar2rlen: M,D,N,=,X consume the reference */
+static int32_t cigar2rlen(const uint8_t *c, int n) {
+    int32_t l = 0; int i;
+    for(i = 0; i < n; i++) { uint32_t op = cig_op(c, i); if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += cig_len(c, i); }
+    return l;
+}
+/* bam_endpos(): pos + rlen, with rlen==0 treated as 1 */
+static int32_t rec_endpos(const brec *r) { return r->pos + (r->rlen > 0 ? r->rlen : 1); }
+
+static int bam_load(const char *fn, bamfile *bf) {
+    FILE *f = fopen(fn, "rb");
+    uint8_t *raw; size_t rawlen, o = 0, cap = 1 << 20, i;
+    memset(bf, 0, sizeof(*bf));
+    if(!f) return -1;
+    fseek(f, 0, SEEK_END); rawlen = ftell(f); fseek(f, 0, SEEK_SET);
+    raw = xmalloc(rawlen);
+    if(fread(raw, 1, rawlen, f) != rawlen) { fclose(f); free(raw); return -1; }
+    fclose(f);
+    bf->data = xmalloc(cap);
+    while(o + 18 <= rawlen) {
+        uint16_t xlen, bsize = 0; size_t x; int have = 0; uint32_t isize; z_stream zs;
+        if(raw[o] != 0x1f || raw[o + 1] != 0x8b || raw[o + 2] != 8 || !(raw[o + 3] & 4)) { free(raw); return -2; }
+        xlen = rd16(raw + o + 10);
+        for(x = o + 12; x + 4 <= o + 12 + xlen;) {      /* find the 'BC' extra subfield */
+            uint16_t slen = rd16(raw + x + 2);
+            if(raw[x] == 'B' && raw[x + 1] == 'C' && slen == 2) { bsize = rd16(raw + x + 4); have = 1; }
+            x += 4 + slen;
+        }
+        if(!have || o + bsize + 1 > rawlen) { free(raw); return -2; }
+        isize = rd32(raw + o + bsize + 1 - 4);
+        if(bf->len + isize > cap) { while(bf->len + isize > cap) cap *= 2; bf->data = xrealloc(bf->data, cap); }
+        if(isize) {
+            memset(&zs, 0, sizeof(zs));
+            zs.next_in = raw + o + 12 + xlen; zs.avail_in = bsize + 1 - 12 - xlen - 8;
+            zs.next_out = bf->data + bf->len; zs.avail_out = isize;
+            if(inflateInit2(&zs, -15) != Z_OK) { free(raw); return -2; }
+            if(inflate(&zs, Z_FINISH) != Z_STREAM_END) { inflateEnd(&zs); free(raw); return -2; }
+            inflateEnd(&zs);
+            bf->len += isize;
+        }
+        o += (size_t)bsize + 1;
+    }
+    free(raw);
+    /* header */
+    if(bf->len < 12 || memcmp(bf->data, "BAM\1", 4)) return -3;
+    o = 8 + rd32(bf->data + 4);
+    bf->n_targets = (int32_t)rd32(bf->data + o); o += 4;
+    bf->target_name = xmalloc(sizeof(char *) * bf->n_targets);
+    bf->target_len = xmalloc(sizeof(uint32_t) * bf->n_targets);
+    for(i = 0; i < (size_t)bf->n_targets; i++) {
+        uint32_t ln = rd32(bf->data + o);
+        bf->target_name[i] = (char *)(bf->data + o + 4);
+        bf->target_len[i] = rd32(bf->data + o + 4 + ln);
+        o += 8 + ln;
+    }
+    /* records */
+    cap = 1024; bf->rec = xmalloc(cap * sizeof(brec));
+    while(o + 4 <= bf->len) {
+        uint32_t bs = rd32(bf->data + o); const uint8_t *r = bf->data + o + 4; brec *b;
+        if(o + 4 + bs > bf->len) return -3;
+        if(bf->n_rec == cap) { cap *= 2; bf->rec = xrealloc(bf->rec, cap * sizeof(brec)); }
+        b = &bf->rec[bf->n_rec++];
+        b->tid = (int32_t)rd32(r); b->pos = (int32_t)rd32(r + 4);
+        b->l_qname = r[8]; b->mapq = r[9];
+        b->n_cigar = rd16(r + 12); b->flag = rd16(r + 14);
+        b->l_qseq = (int32_t)rd32(r + 16); b->mtid = (int32_t)rd32(r + 20); b->mpos = (int32_t)rd32(r + 24);
+        b->qname = (const char *)(r + 32);
+        b->cigar = r + 32 + b->l_qname;
+        b->seq = b->cigar + 4 * b->n_cigar;
+        b->qual = b->seq + (b->l_qseq + 1) / 2;
+        b->aux = b->qual + b->l_qseq;
+        b->aux_len = (int32_t)((r + bs) - b->aux);
+        if(b->aux_len < 0) return -3;
+        b->rlen = cigar2rlen(b->cigar, b->n_cigar);
+        if(b->rlen > bf->max_rlen) bf->max_rlen = b->rlen;
+        o += 4 + (size_t)bs;
+    }
+    /* per-tid ranges; the pileup needs coordinate-sorted input (htslib errors out otherwise) */
+    bf->tid_lo = xmalloc(sizeof(size_t) * (bf->n_targets + 1));
+    bf->tid_hi = xmalloc(sizeof(size_t) * (bf->n_targets + 1));
+    for(i = 0; i < (size_t)bf->n_targets; i++) bf->tid_lo[i] = bf->tid_hi[i] = 0;
+    for(i = 0; i < bf->n_rec; i++) {
+        brec *b = &bf->rec[i];
+        if(b->tid < 0 || b->tid >= bf->n_targets) continue;
+        if(bf->tid_hi[b->tid] == 0 && bf->tid_lo[b->tid] == 0) bf->tid_lo[b->tid] = i;
+        else if(bf->tid_hi[b->tid] != i) { fprintf(stderr, "oracle: BAM is not coordinate sorted (contigs interleaved)\n"); return -4; }
+        if(i > bf->tid_lo[b->tid] && bf->rec[i - 1].pos > b->pos) { fprintf(stderr, "oracle: BAM is not coordinate sorted\n"); return -4; }
+        bf->tid_hi[b->tid] = i + 1;
+    }
+    return 0;
+}
+
+/* region iterator == sam_itr_queryi(idx, tid, beg, end) + sam_itr_next (extract.c:379, common.c:413):
+ * file order, same tid, pos < end, bam_endpos > beg. */
+typedef struct { const bamfile *bf; int32_t tid, beg, end; size_t cur, hi; } regitr;
+static void regitr_init(regitr *it, const bamfile *bf, int32_t tid, int32_t beg, int32_t end) {
+    size_t lo = bf->tid_lo[tid], hi = bf->tid_hi[tid]; int64_t want = (int64_t)beg - bf->max_rlen - 1;
+    it->bf = bf; it->tid = tid; it->beg = beg; it->end = end; it->hi = hi;
+    /* first record with pos >= beg - max_rlen - 1 (binary search; sorted within tid) */
+    { size_t a = lo, b = hi; while(a < b) { size_t m = a + (b - a) / 2; if((int64_t)bf->rec[m].pos < want) a = m + 1; else b = m; } it->cur = a; }
+}
+static const brec *regitr_next(regitr *it) {
+    while(it->cur < it->hi) {
+        const brec *r = &it->bf->rec[it->cur];
+        if(r->pos >= it->end) { it->cur = it->hi; return NULL; }
+        it->cur++;
+        if(rec_endpos(r) > it->beg) return r;
+    }
+    return NULL;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* FASTA (faidx semantics: name up to first whitespace, letters kept verbatim incl. case)       */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int n; char **name; char **seq; int64_t *len; } fasta;
+static int fasta_load(const char *fn, fasta *fa) {
+    FILE *f = fopen(fn, "rb"); char *line = NULL; size_t cap = 0; ssize_t n; int64_t m = 0;
+    memset(fa, 0, sizeof(*fa));
+    if(!f) return -1;
+    while((n = getline(&line, &cap, f)) >= 0) {
+        if(line[0] == '>') {
+            char *e = line + 1; while(*e && *e != ' ' && *e != '\t' && *e != '\n' && *e != '\r') e++;
+            *e = 0;
+            fa->name = xrealloc(fa->name, sizeof(char *) * (fa->n + 1));
+            fa->seq = xrealloc(fa->seq, sizeof(char *) * (fa->n + 1));
+            fa->len = xrealloc(fa->len, sizeof(int64_t) * (fa->n + 1));
+            fa->name[fa->n] = strdup(line + 1); fa->seq[fa->n] = NULL; fa->len[fa->n] = 0; fa->n++; m = 0;
+        } else if(fa->n) {
+            ssize_t i; int k = fa->n - 1;
+            for(i = 0; i < n; i++) {
+                unsigned char c = (unsigned char)line[i];
+                if(c <= ' ' || c > '~') continue;                    /* isgraph() as in faidx */
+                if(fa->len[k] + 1 > m) { m = m ? m * 2 : 1024; fa->seq[k] = xrealloc(fa->seq[k], m); }
+                fa->seq[k][fa->len[k]++] = (char)c;
+            }
+        }
+    }
+    free(line); fclose(f);
+    return 0;
+}
+/* faidx_fetch_seq(fai, name, beg, end_inclusive, &len): clamped to the contig; len=-2 unknown name */
+static char *fetch_seq(const fasta *fa, const char *name, int64_t beg, int64_t end, int *len) {
+    int i; int64_t L; char *s;
+    for(i = 0; i < fa->n; i++) if(!strcmp(fa->name[i], name)) break;
+    if(i == fa->n) { *len = -2; return NULL; }
+    L = fa->len[i];
+    if(end < beg) beg = end;
+    if(beg < 0) beg = 0; else if(L <= beg) beg = L;
+    if(end < 0) end = 0; else if(L <= end) end = L - 1;
+    end += 1;                                       /* half-open now */
+    if(end < beg) end = beg;
+    s = xmalloc((size_t)(end - beg) + 1);
+    memcpy(s, fa->seq[i] + beg, (size_t)(end - beg)); s[end - beg] = 0;
+    *len = (int)(end - beg);
+    return s;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Config (MethylDackel.h:90-126)                                                               */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int keepCpG, keepCHG, keepCHH;
+    int minMapq, minPhred, keepDupes, minDepth;
+    int keepDiscordant, keepSingleton, ignoreFlags, requireFlags;
+    int merge, methylKit, minOppositeDepth;
+    int ignoreNH;
+    double maxVariantFrac;
+    int fraction, counts, logit;
+    int cytosine_report;
+    FILE *output_fp[3];
+    char *reg;
+    float minConversionEfficiency;
+    char *BBMName;
+    char **chromNames; uint32_t chromCount; uint32_t *chromLengths;
+    char filterMappability;
+    float mappabilityCutoff;
+    int minMappableBases;
+    char **bw_data;
+    int bounds[16], absoluteBounds[16];
+    int nThreads;
+    unsigned long chunkSize;
+} Config;
+
+/* per-chunk context == mplp_data (MethylDackel.h:139-149) */
+typedef struct { Config *config; const bamfile *bf; regitr iter; int lseq; char *seq; uint32_t offset; } mplp_data;
+
+/* working copy of a record: what htslib hands around as bam1_t (seq/qual are mutable) */
+typedef struct {
+    const brec *r;
+    uint8_t *seq, *qual;       /* private copies */
+} bam1;
+#define seqi(s, i) ((s)[(i) >> 1] >> ((~(i) & 1) << 2) & 0xf)
+
+/* ------------------------------------------------------------------------------------------ */
+/* aux access: bam_aux_get returns a pointer to the TYPE byte (common.c:85-87 relies on it)     */
+/* ------------------------------------------------------------------------------------------ */
+static const uint8_t *aux_get(const brec *r, const char tag[2]) {
+    const uint8_t *s = r->aux, *e = r->aux + r->aux_len;
+    while(e - s >= 3) {
+        const uint8_t *t = s + 2; uint8_t ty = *t; const uint8_t *v = t + 1; size_t sz;
+        int hit = (s[0] == (uint8_t)tag[0] && s[1] == (uint8_t)tag[1]);
+        switch(ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'd': sz = 8; break;
+        case 'Z': case 'H': { const uint8_t *z = memchr(v, 0, (size_t)(e - v)); if(!z) return NULL; sz = (size_t)(z - v) + 1; break; }
+        case 'B': { uint32_t n; size_t es; if(e - v < 5) return NULL; n = rd32(v + 1);
+                    switch(v[0]) { case 'c': case 'C': es = 1; break; case 's': case 'S': es = 2; break; case 'i': case 'I': case 'f': es = 4; break; default: return NULL; }
+                    sz = 5 + es * (size_t)n; break; }
+        default: return NULL;
+        }
+        if((size_t)(e - v) < sz) return NULL;
+        if(hit) return t;
+        s = v + sz;
+    }
+    return NULL;
+}
+static int64_t aux2i(const uint8_t *t) {   /* bam_aux2i: integer types only, else 0 */
+    switch(*t) {
+    case 'c': return (int8_t)t[1];
+    case 'C': return t[1];
+    case 's': return (int16_t)rd16(t + 1);
+    case 'S': return rd16(t + 1);
+    case 'i': return (int32_t)rd32(t + 1);
+    case 'I': return rd32(t + 1);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* common.c restated                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+static int isCpG(char *seq, int pos, int seqlen) {            /* common.c:49-61 */
+    if(pos >= seqlen) return 0;
+    if(seq[pos] == 'C' || seq[pos] == 'c') {
+        if(pos + 1 == seqlen) return 0;
+        if(seq[pos + 1] == 'G' || seq[pos + 1] == 'g') return 1;
+        return 0;
+    } else if(seq[pos] == 'G' || seq[pos] == 'g') {
+        if(pos == 0) return 0;
+        if(seq[pos - 1] == 'C' || seq[pos - 1] == 'c') return -1;
+        return 0;
+    }
+    return 0;
+}
+static int isCHG(char *seq, int pos, int seqlen) {            /* common.c:63-75 */
+    if(pos >= seqlen) return 0;
+    if(seq[pos] == 'C' || seq[pos] == 'c') {
+        if(pos + 2 >= seqlen) return 0;
+        if(seq[pos + 2] == 'G' || seq[pos + 2] == 'g') return 1;
+        return 0;
+    } else if(seq[pos] == 'G' || seq[pos] == 'g') {
+        if(pos <= 1) return 0;
+        if(seq[pos - 2] == 'C' || seq[pos - 2] == 'c') return -1;
+        return 0;
+    }
+    return 0;
+}
+static int isCHH(char *seq, int pos, int seqlen) {            /* common.c:77-82 */
+    if(pos >= seqlen) return 0;
+    if(seq[pos] == 'C' || seq[pos] == 'c') return 1;
+    else if(seq[pos] == 'G' || seq[pos] == 'g') return -1;
+    return 0;
+}
+
+static int getStrand(const brec *b) {                          /* common.c:84-116 */
+    const uint8_t *XG = aux_get(b, "XG");
+    if(XG != NULL && XG[1] != 'C' && XG[1] != 'G') XG = NULL;
+    if(XG == NULL) {
+        if(b->flag & 0x1) {
+            if((b->flag & 0x50) == 0x50) return 2;
+            else if(b->flag & 0x40) return 1;
+            else if((b->flag & 0x90) == 0x90) return 1;
+            else if(b->flag & 0x80) return 2;
+            return 0;
+        } else {
+            if(b->flag & 0x10) return 2;
+            return 1;
+        }
+    } else {
+        if(XG[1] == 'C') {
+            if((b->flag & 0x51) == 0x41) return 1;
+            else if((b->flag & 0x51) == 0x51) return 3;
+            else if((b->flag & 0x91) == 0x81) return 3;
+            else if((b->flag & 0x91) == 0x91) return 1;
+            else if(b->flag & 0x10) return 3;
+            else return 1;
+        } else {
+            if((b->flag & 0x51) == 0x41) return 4;
+            else if((b->flag & 0x51) == 0x51) return 2;
+            else if((b->flag & 0x91) == 0x81) return 2;
+            else if((b->flag & 0x91) == 0x91) return 4;
+            else if(b->flag & 0x10) return 2;
+            else return 4;
+        }
+    }
+}
+
+/* common.c:118-134 (and its twin getMethylState, 338-354) */
+static int methState(Config *config, const bam1 *b, int qpos) {
+    uint8_t base = seqi(b->seq, qpos);
+    int strand = getStrand(b->r);
+    if(strand == 0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
+    if(b->qual[qpos] < config->minPhred) return 0;
+    if(base == 2 && (strand == 1 || strand == 3)) return 1;
+    else if(base == 8 && (strand == 1 || strand == 3)) return -1;
+    else if(base == 4 && (strand == 2 || strand == 4)) return 1;
+    else if(base == 1 && (strand == 2 || strand == 4)) return -1;
+    return 0;
+}
+
+static void maskBase(bam1 *b, int i) { b->qual[i] = 0; if(i & 1) b->seq[i >> 1] |= 0xf; else b->seq[i >> 1] |= 0xf0; }
+
+static void trimAlignment(bam1 *b, int bounds[16]) {           /* common.c:137-172 */
+    int strand = getStrand(b->r) - 1, i, lb, rb, l = b->r->l_qseq;
+    if(strand < 0) return;   /* reference indexes bounds[-4..] here (UB); such reads abort later anyway */
+    if(b->r->flag & 0x80) { lb = bounds[4 * strand + 2]; rb = bounds[4 * strand + 3]; }
+    else { lb = bounds[4 * strand]; rb = bounds[4 * strand + 1]; }
+    lb = (lb < l) ? lb : l;
+    if(lb) for(i = 0; i < lb; i++) maskBase(b, i);
+    if(rb) for(i = rb; i < l; i++) maskBase(b, i);
+}
+static void trimAbsoluteAlignment(bam1 *b, int bounds[16]) {   /* common.c:174-208 */
+    int strand = getStrand(b->r) - 1, i, lb, rb, l = b->r->l_qseq;
+    if(strand < 0) return;
+    if(b->r->flag & 0x80) { lb = bounds[4 * strand + 2]; rb = bounds[4 * strand + 3]; }
+    else { lb = bounds[4 * strand]; rb = bounds[4 * strand + 1]; }
+    lb = (lb < l) ? lb : l;
+    rb = (rb < l) ? rb : l;
+    if(lb) for(i = 0; i < lb; i++) maskBase(b, i);
+    if(rb) for(i = 0; i < rb; i++) maskBase(b, l - 1 - i);
+}
+
+/* common.c:210-275 */
+static unsigned char *getMappabilityValue(Config *config, const char *chrom_n, uint32_t start, uint32_t end) {
+    char chromFound = 0; uint32_t chrom = (uint32_t)-1; int i;
+    unsigned char *data; int index, offset, arrlen = 0;
+    for(i = 0; i < (int)config->chromCount; i++) if(!strcmp(config->chromNames[i], chrom_n)) { chrom = i; chromFound = 1; break; }
+    data = xmalloc((size_t)(end - start));
+    index = (int)(start / 8); offset = (int)(start % 8);
+    if(chromFound) { arrlen = config->chromLengths[chrom] / 8; if(config->chromLengths[chrom] % 8 > 0) arrlen++; }
+    for(i = 0; i < (int)(end - start); i++) {
+        unsigned char byte, mask;
+        if(chromFound) { if(index >= arrlen) byte = 0; else byte = (unsigned char)config->bw_data[chrom][index]; }
+        else byte = 0;
+        mask = (unsigned char)(1 << offset);
+        data[i] = (unsigned char)((byte & mask) >> offset);
+        if(offset == 7) { index++; offset = 0; } else offset++;
+    }
+    return data;
+}
+/* common.c:277-335 */
+static char check_mappability(mplp_data *ldata, const brec *b) {
+    int read1_start, read1_end, read2_start, read2_end, i, num_mappable_reads = 0;
+    signed char num_mappable_bases = 0;       /* `char` on x86-64 */
+    unsigned char *vals;
+    if((b->flag & 0x40) || ((b->flag & 0x10) && (b->flag & 0x80))) {
+        read1_start = b->pos; read1_end = b->pos + b->l_qseq;
+        read2_start = b->mpos; read2_end = b->mpos + b->l_qseq;
+    } else {
+        read2_start = b->pos; read2_end = b->pos + b->l_qseq;
+        read1_start = b->mpos; read1_end = b->mpos + b->l_qseq;
+    }
+    vals = getMappabilityValue(ldata->config, ldata->bf->target_name[b->tid], (uint32_t)read1_start, (uint32_t)read1_end);
+    for(i = 0; i < read1_end - read1_start; i++) {
+        if(vals[i] > 0) num_mappable_bases = (signed char)(num_mappable_bases + 1);
+        if(num_mappable_bases >= ldata->config->minMappableBases) { num_mappable_reads++; break; }
+    }
+    free(vals);
+    vals = getMappabilityValue(ldata->config, ldata->bf->target_name[b->tid], (uint32_t)read2_start, (uint32_t)read2_end);
+    num_mappable_bases = 0;
+    for(i = 0; i < read2_end - read2_start; i++) {
+        if(vals[i] > 0) num_mappable_bases = (signed char)(num_mappable_bases + 1);
+        if(num_mappable_bases >= ldata->config->minMappableBases) { num_mappable_reads++; break; }
+    }
+    free(vals);
+    return (char)num_mappable_reads;
+}
+
+static float computeEfficiency(unsigned int nMethyl, unsigned int nUMethyl) {   /* common.c:356-359 */
+    if(nMethyl + nUMethyl == 0) return 1.0;
+    return nUMethyl / ((float)(nMethyl + nUMethyl));
+}
+/* common.c:361-404.  NB the reference reads ldata->seq at a negative index when the read starts
+ * left of the chunk window (undefined behaviour); here such positions are treated as "no context". */
+static float computeConversionEfficiency(bam1 *b, mplp_data *ldata) {
+    unsigned int nMethyl = 0, nUMethyl = 0;
+    uint32_t i, j, seqEnd = ldata->offset + ldata->lseq, op, opLen;
+    int state, pos = b->r->pos, seqPos = 0;
+    for(i = 0; i < b->r->n_cigar; i++) {
+        op = cig_op(b->r->cigar, i); opLen = cig_len(b->r->cigar, i);
+        switch(op) {
+        case 0: case 7: case 8:
+            for(j = 0; j < opLen; j++, seqPos++) {
+                int64_t wi = (int64_t)pos + j - ldata->offset;
+                if((uint32_t)(pos + j) >= seqEnd) return computeEfficiency(nMethyl, nUMethyl);
+                if(wi < 0) continue;
+                if(isCpG(ldata->seq, (int)wi, ldata->lseq)) continue;
+                else if(isCHG(ldata->seq, (int)wi, ldata->lseq) || isCHH(ldata->seq, (int)wi, ldata->lseq)) {
+                    state = methState(ldata->config, b, seqPos);
+                    if(state > 0) nMethyl++; else if(state < 0) nUMethyl++;
+                }
+            }
+            break;
+        case 1: case 4: seqPos += opLen; break;
+        case 2: case 3: pos += opLen; break;
+        }
+    }
+    return computeEfficiency(nMethyl, nUMethyl);
+}
+
+/* filter_func (common.c:407-463): pulls the next ADMITTED record of the region into *b.
+ * returns 0 on success, -1 at end.  b->seq/b->qual are (re)filled private copies. */
+static int filter_func(mplp_data *ldata, bam1 *b) {
+    const brec *r; Config *c = ldata->config;
+    while(1) {
+        r = regitr_next(&ldata->iter);
+        if(!r) return -1;
+        if(r->tid == -1 || (r->flag & 0x4)) continue;
+        if(r->mapq < c->minMapq) continue;
+        if(r->flag & c->ignoreFlags) continue;
+        if(c->requireFlags && (r->flag & c->requireFlags) != c->requireFlags) continue;
+        if(!c->keepDupes && (r->flag & 0x400)) continue;
+        if(!c->ignoreNH) {
+            const uint8_t *p = aux_get(r, "NH");
+            if(p != NULL) { int NH = (int)aux2i(p); if(NH > 1) continue; }
+        }
+        if(c->filterMappability && check_mappability(ldata, r) == 0) continue;
+        if(!c->keepSingleton && (r->flag & 0x9) == 0x9) continue;
+        if(!c->keepDiscordant && (r->flag & 0x3) == 0x1) continue;
+        /* common.c:431 sets 0x2 on the private copy; nothing downstream in extract looks at it */
+        b->r = r;
+        b->seq = xrealloc(b->seq, (size_t)(r->l_qseq + 1) / 2 + 1);
+        b->qual = xrealloc(b->qual, (size_t)r->l_qseq + 1);
+        memcpy(b->seq, r->seq, (size_t)(r->l_qseq + 1) / 2);
+        memcpy(b->qual, r->qual, (size_t)r->l_qseq);
+        if(c->minConversionEfficiency > 0.0) {
+            if(computeConversionEfficiency(b, ldata) < c->minConversionEfficiency) continue;
+        }
+        trimAlignment(b, c->bounds);
+        trimAbsoluteAlignment(b, c->absoluteBounds);
+        return 0;
+    }
+}
+
+/* adjustBounds (common.c:466-493) */
+static void adjustBounds(const bamfile *bf, const fasta *fa, uint32_t *localTid, uint32_t *localPos, uint32_t *localEnd) {
+    uint32_t start, end, tmp; int seqlen; char *seq;
+    end = *localEnd + 1;
+    if(*localEnd > 0) start = *localEnd - 1; else start = 0;
+    seq = fetch_seq(fa, bf->target_name[*localTid], (int)start, (int)end, &seqlen);
+    if(seqlen > 1) {
+        if(seqlen > 2 && (seq[0] & 0x5F) == 'C' && (seq[2] & 0x5F) == 'G') *localEnd += 2;
+        else if((seq[1] & 0x5F) == 'G') *localEnd += 1;
+    }
+    free(seq);
+    if(*localPos > *localEnd) { tmp = *localPos; *localPos = *localEnd; *localEnd = tmp; }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* overlaps.c restated.  The qname dictionary is a tiny chained hash keyed on the qname string  */
+/* ------------------------------------------------------------------------------------------ */
+struct lbnode;
+typedef struct oent { const char *key; struct lbnode *val; struct oent *next; } oent;
+typedef struct { oent **b; size_t nb; } ohash_t;
+static size_t ohash_fn(const char *s) { size_t h = 1469598103934665603ULL; for(; *s; s++) h = (h ^ (uint8_t)*s) * 1099511628211ULL; return h; }
+static ohash_t *initOlapHash(void) { ohash_t *h = xmalloc(sizeof(*h)); h->nb = 1 << 16; h->b = calloc(h->nb, sizeof(oent *)); return h; }
+static void destroyOlapHash(ohash_t *h) { size_t i; for(i = 0; i < h->nb; i++) { oent *e = h->b[i]; while(e) { oent *n = e->next; free(e); e = n; } } free(h->b); free(h); }
+static oent **ohash_find(ohash_t *h, const char *k) { oent **p = &h->b[ohash_fn(k) & (h->nb - 1)]; while(*p && strcmp((*p)->key, k)) p = &(*p)->next; return p; }
+
+typedef struct lbnode {       /* one buffered read of the pileup (htslib lbnode_t) */
+    bam1 b; int32_t beg, end; struct lbnode *next;
+} lbnode;
+
+static int32_t *calculate_positions(const brec *read) {        /* overlaps.c:27-52 */
+    int32_t *positions = xmalloc(sizeof(int32_t) * (size_t)(read->l_qseq + 1));
+    int i, j, offset = 0, op, op_len; int32_t previous_position = read->pos;
+    for(i = 0; i < read->n_cigar; i++) {
+        op = cig_op(read->cigar, i); op_len = cig_len(read->cigar, i);
+        for(j = 0; j < op_len; j++) {
+            if(op == 0 || op == 7 || op == 8) { if(offset < read->l_qseq) positions[offset] = previous_position; previous_position++; offset++; }
+            else if(op == 1 || op == 4) { if(offset < read->l_qseq) positions[offset] = -1; offset++; }
+            else if(op == 2 || op == 3) previous_position++;
+            else if(op == 5) { }
+            else fprintf(stderr, "[calculate_positions] We encountered a CIGAR operation that we're not ready to deal with in %s\n", read->qname);
+        }
+    }
+    /* a CIGAR that covers fewer query bases than l_qseq leaves the tail uninitialised in the
+     * reference; treat as unaligned */
+    for(; offset < read->l_qseq; offset++) positions[offset] = -1;
+    return positions;
+}
+
+static void cust_tweak_overlap_quality(bam1 *a, bam1 *b) {     /* overlaps.c:54-119 */
+    int ia = 0, ib = 0; int32_t na = a->r->l_qseq, nb = b->r->l_qseq;
+    int32_t *posa = calculate_positions(a->r), *posb = calculate_positions(b->r);
+    uint8_t *a_qual = a->qual, *b_qual = b->qual, *a_seq = a->seq, *b_seq = b->seq;
+    int sa = getStrand(a->r), sb = getStrand(b->r);
+    if(((sa - sb) & 1) == 1) goto quit;
+    while(ia < na && posa[ia] < 0) ia++;
+    while(ib < nb && posb[ib] < 0) ib++;
+    if(ia == na || ib == nb) goto quit;
+    if(posa[ia] < posb[ib]) { while(ia < na && posa[ia] < posb[ib]) ia++; }
+    else { while(ib < nb && posb[ib] < posa[ia]) ib++; }
+    if(ia == na || ib == nb) goto quit;
+    while(ia < na && ib < nb) {
+        if(posa[ia] < posb[ib] || posa[ia] < 0) { ia++; continue; }
+        if(posb[ib] < posa[ia] || posb[ib] < 0) { ib++; continue; }
+        if(seqi(a_seq, ia) != seqi(b_seq, ib)) {
+            if(a_qual[ia] > b_qual[ib] && seqi(a_seq, ia) != 15) { a_qual[ia] -= b_qual[ib]; b_qual[ib] = 0; }
+            else if(b_qual[ib] > a_qual[ia] && seqi(b_seq, ib) != 15) { b_qual[ib] -= a_qual[ia]; a_qual[ia] = 0; }
+            else { a_qual[ia] = 0; b_qual[ib] = 0; }
+        } else {
+            /* `a_qual[ia] += 0.2*a_qual[ia]` : uint8 <- double; >=256 wraps mod 256 with gcc/x86-64 */
+            if(a_qual[ia] > b_qual[ib]) { a_qual[ia] = (uint8_t)(int)(a_qual[ia] + 0.2 * a_qual[ia]); b_qual[ib] = 0; }
+            else { b_qual[ib] = (uint8_t)(int)(b_qual[ib] + 0.2 * b_qual[ib]); a_qual[ia] = 0; }
+        }
+        ia++; ib++;
+    }
+quit:
+    free(posa); free(posb);
+}
+
+static void custom_overlap_constructor(ohash_t *oh, lbnode *nb) {   /* overlaps.c:121-139 */
+    oent **p = ohash_find(oh, nb->b.r->qname);
+    if(!(nb->b.r->flag & 0x1) || ((nb->b.r->flag & 12) > 0)) return;
+    if(*p == NULL) { oent *e = xmalloc(sizeof(*e)); e->key = nb->b.r->qname; e->val = nb; e->next = NULL; *p = e; }
+    else { oent *e = *p; cust_tweak_overlap_quality(&e->val->b, &nb->b); *p = e->next; free(e); }
+}
+static void custom_overlap_destructor(ohash_t *oh, lbnode *nb) {    /* overlaps.c:141-147 */
+    oent **p = ohash_find(oh, nb->b.r->qname);
+    if(*p) { oent *e = *p; *p = e->next; free(e); }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* htslib pileup buffer restated (bam_plp_push / bam_plp64_next / bam_plp64_auto, one input,    */
+/* maxcnt = INT_MAX, no htslib-side overlap detection: extract.c:394-399).                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { const bam1 *b; int32_t qpos; int is_del, is_refskip; } pileup1;
+typedef struct {
+    mplp_data *data; ohash_t *oh;
+    lbnode *head, *tail;           /* tail is the spare node, as in htslib */
+    int32_t tid, pos, max_tid, max_pos; int is_eof;
+    pileup1 *plp; int max_plp;
+    bam1 scratch;
+} plp_t;
+
+static lbnode *node_new(void) { lbnode *n = calloc(1, sizeof(*n)); if(!n) exit(2); return n; }
+static void node_free(lbnode *n) { free(n->b.seq); free(n->b.qual); free(n); }
+
+static void plp_init(plp_t *it, mplp_data *data, ohash_t *oh) {
+    memset(it, 0, sizeof(*it)); it->data = data; it->oh = oh;
+    it->head = it->tail = node_new(); it->max_tid = it->max_pos = -1;
+}
+static void plp_destroy(plp_t *it) {
+    lbnode *p = it->head;
+    while(p != it->tail) { lbnode *n = p->next; custom_overlap_destructor(it->oh, p); node_free(p); p = n; }
+    node_free(it->tail); free(it->plp); free(it->scratch.seq); free(it->scratch.qual);
+}
+/* resolve_cigar2: where does column `pos` fall in this read? */
+static void resolve_cigar(pileup1 *p, const brec *r, int32_t pos) {
+    int32_t x = r->pos, y = 0; int k;
+    p->qpos = 0; p->is_del = p->is_refskip = 0;
+    for(k = 0; k < r->n_cigar; k++) {
+        int op = cig_op(r->cigar, k); int32_t l = (int32_t)cig_len(r->cigar, k);
+        if(op == 0 || op == 7 || op == 8) { if(pos < x + l) { p->qpos = y + (pos - x); return; } x += l; y += l; }
+        else if(op == 2 || op == 3) { if(pos < x + l) { p->qpos = y; p->is_del = 1; p->is_refskip = (op == 3); return; } x += l; }
+        else if(op == 1 || op == 4) y += l;
+    }
+    p->is_del = 1;   /* unreachable for beg <= pos < end */
+}
+static void plp_push(plp_t *it, const bam1 *b) {
+    if(b) {
+        lbnode *t = it->tail;
+        /* bam_copy1 */
+        t->b.r = b->r;
+        t->b.seq = xrealloc(t->b.seq, (size_t)(b->r->l_qseq + 1) / 2 + 1);
+        t->b.qual = xrealloc(t->b.qual, (size_t)b->r->l_qseq + 1);
+        memcpy(t->b.seq, b->seq, (size_t)(b->r->l_qseq + 1) / 2);
+        memcpy(t->b.qual, b->qual, (size_t)b->r->l_qseq);
+        t->beg = b->r->pos; t->end = b->r->pos + b->r->rlen;      /* raw rlen, not bam_endpos */
+        it->max_tid = b->r->tid; it->max_pos = t->beg;
+        if(t->end > it->pos || b->r->tid > it->tid) {
+            lbnode *next = node_new();
+            custom_overlap_constructor(it->oh, t);
+            t->next = next; it->tail = next;
+        }
+    } else it->is_eof = 1;
+}
+static pileup1 *plp_next(plp_t *it, int *_tid, int32_t *_pos, int *_n_plp) {
+    *_n_plp = 0;
+    if(it->is_eof && it->head == it->tail) return NULL;
+    while(it->is_eof || it->max_tid > it->tid || (it->max_tid == it->tid && it->max_pos > it->pos)) {
+        int n_plp = 0; lbnode **pptr = &it->head;
+        while(*pptr != it->tail) {
+            lbnode *p = *pptr;
+            if(p->b.r->tid < it->tid || (p->b.r->tid == it->tid && p->end <= it->pos)) {
+                custom_overlap_destructor(it->oh, p);
+                *pptr = p->next; node_free(p);
+            } else {
+                if(p->b.r->tid == it->tid && p->beg <= it->pos) {
+                    if(n_plp == it->max_plp) { it->max_plp = it->max_plp ? it->max_plp << 1 : 256; it->plp = xrealloc(it->plp, sizeof(pileup1) * it->max_plp); }
+                    it->plp[n_plp].b = &p->b;
+                    resolve_cigar(&it->plp[n_plp], p->b.r, it->pos);
+                    n_plp++;
+                }
+                pptr = &(*pptr)->next;
+            }
+        }
+        *_n_plp = n_plp; *_tid = it->tid; *_pos = it->pos;
+        if(it->head != it->tail && it->tid < it->head->b.r->tid) { it->tid = it->head->b.r->tid; it->pos = it->head->beg; }
+        else if(it->head != it->tail && it->pos < it->head->beg) it->pos = it->head->beg;
+        else ++it->pos;
+        if(n_plp) return it->plp;
+        if(it->is_eof && it->head == it->tail) break;
+    }
+    return NULL;
+}
+static pileup1 *plp_auto(plp_t *it, int *_tid, int32_t *_pos, int *_n_plp) {
+    pileup1 *plp;
+    if((plp = plp_next(it, _tid, _pos, _n_plp)) != NULL) return plp;
+    *_n_plp = 0;
+    if(it->is_eof) return NULL;
+    while(filter_func(it->data, &it->scratch) >= 0) {
+        plp_push(it, &it->scratch);
+        if((plp = plp_next(it, _tid, _pos, _n_plp)) != NULL) return plp;
+    }
+    plp_push(it, NULL);
+    if((plp = plp_next(it, _tid, _pos, _n_plp)) != NULL) return plp;
+    return NULL;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* extract.c restated                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+static double logit(double p) { return log(p) - log(1 - p); }
+struct lastCall { int32_t tid, pos; uint32_t nmethyl, nunmethyl; };
+static const char *TriNucleotideContexts[25] = {"CAA", "CAC", "CAG", "CAT", "CAN", "CCA", "CCC", "CCG", "CCT", "CCN",
+    "CGA", "CGC", "CGG", "CGT", "CGN", "CTA", "CTC", "CTG", "CTT", "CTN", "CNA", "CNC", "CNG", "CNT", "CNN"};
+
+static void writeCall(kstr *ks, Config *config, const char *chrom, int32_t pos, int32_t width, uint32_t nmethyl, uint32_t nunmethyl, char base, const char *context, const char *tnc) {
+    char str[10000]; char strand = (base == 'C' || base == 'c') ? 'F' : 'R';
+    if((int64_t)(uint32_t)(nmethyl + nunmethyl) < config->minDepth && !config->cytosine_report) return;
+    if(!config->fraction && !config->logit && !config->counts && !config->methylKit && !config->cytosine_report) {
+        snprintf(str, 10000, "%s\t%i\t%i\t%i\t%" PRIu32 "\t%" PRIu32 "\n", chrom, pos, pos + width, (int)(100.0 * ((double)nmethyl) / (nmethyl + nunmethyl)), nmethyl, nunmethyl);
+    } else if(config->fraction) {
+        snprintf(str, 10000, "%s\t%i\t%i\t%f\n", chrom, pos, pos + width, ((double)nmethyl) / (nmethyl + nunmethyl));
+    } else if(config->counts) {
+        snprintf(str, 10000, "%s\t%i\t%i\t%i\n", chrom, pos, pos + width, nmethyl + nunmethyl);
+    } else if(config->logit) {
+        snprintf(str, 10000, "%s\t%i\t%i\t%f\n", chrom, pos, pos + width, logit(((double)nmethyl) / (nmethyl + nunmethyl)));
+    } else if(config->methylKit) {
+        snprintf(str, 10000, "%s.%i\t%s\t%i\t%c\t%i\t%6.2f\t%6.2f\n", chrom, pos + 1, chrom, pos + 1, strand, nmethyl + nunmethyl,
+                 100.0 * ((double)nmethyl) / (nmethyl + nunmethyl), 100.0 * ((double)nunmethyl) / (nmethyl + nunmethyl));
+    } else {
+        strand = (base == 'C' || base == 'c') ? '+' : '-';
+        snprintf(str, 10000, "%s\t%i\t%c\t%" PRIu32 "\t%" PRIu32 "\tC%s\t%s\n", chrom, pos + 1, strand, nmethyl, nunmethyl, context, tnc);
+    }
+    kputs_(ks, str);
+}
+static char revcomp(char b) {
+    switch(b) { case 'A': case 'a': return 'T'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; case 'T': case 't': return 'A'; default: return 'N'; }
+}
+static int tri_idx(char base) { switch(base) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } }
+static int getTriNucContext(char *seq, uint32_t offset, int seqlen, int direction) {   /* extract.c:120-180 */
+    int rv = 0; char base;
+    if((direction > 0 && (int64_t)offset + 2 >= seqlen) || (direction < 0 && offset <= 1)) rv = 4;
+    else { base = seq[(int64_t)offset + 2 * direction]; if(direction < 0) base = revcomp(base); rv = tri_idx(base); }
+    if((direction > 0 && (int64_t)offset + 1 >= seqlen) || (direction < 0 && offset == 0)) rv += 20;
+    else { base = seq[(int64_t)offset + direction]; if(direction < 0) base = revcomp(base); rv += 5 * tri_idx(base); }
+    return rv;
+}
+static void writeBlank(kstr **ks, Config *config, const char *chrom, int32_t pos, uint32_t localPos2, uint32_t *lastPos, char *seq, int seqlen) {
+    int triNucContext = 0, direction = 0; char context[3] = "HG";
+    if(pos == -1) return;
+    for(; (int64_t)*lastPos < pos; (*lastPos)++) {
+        if((direction = isCpG(seq, *lastPos - localPos2, seqlen)) != 0) { if(!config->keepCpG) continue; context[0] = 'G'; context[1] = 0; }
+        else if((direction = isCHG(seq, *lastPos - localPos2, seqlen)) != 0) { if(!config->keepCHG) continue; context[0] = 'H'; context[1] = 'G'; }
+        else if((direction = isCHH(seq, *lastPos - localPos2, seqlen)) != 0) { if(!config->keepCHH) continue; context[0] = 'H'; context[1] = 'H'; }
+        else continue;
+        triNucContext = getTriNucContext(seq, *lastPos - localPos2, seqlen, direction);
+        writeCall(ks[0], config, chrom, *lastPos, 1, 0, 0, (direction > 0) ? 'C' : 'G', context, TriNucleotideContexts[triNucContext]);
+    }
+}
+static void processLast(kstr *ks, Config *config, struct lastCall *last, const bamfile *hdr, int32_t tid, int32_t pos, int width, uint32_t nmethyl, uint32_t nunmethyl, char base) {
+    if(last->tid == tid && last->pos == pos) {
+        nmethyl += last->nmethyl; nunmethyl += last->nunmethyl;
+        writeCall(ks, config, hdr->target_name[tid], pos, width, nmethyl, nunmethyl, base, NULL, NULL);
+        last->tid = -1;
+    } else {
+        if(last->tid != -1) writeCall(ks, config, hdr->target_name[last->tid], last->pos, width, last->nmethyl, last->nunmethyl, base, NULL, NULL);
+        last->tid = tid; last->pos = pos; last->nmethyl = nmethyl; last->nunmethyl = nunmethyl;
+    }
+}
+static int isVariant(Config *config, const pileup1 *plp, uint32_t *coverage, int strand) {   /* extract.c:225-239 */
+    uint8_t base = seqi(plp->b->seq, plp->qpos);
+    if(plp->b->qual[plp->qpos] < config->minPhred) return 0;
+    *coverage += 1;
+    if(strand & 1) { if(base != 4 && base != 15) return 1; else return 0; }
+    else { if(base != 2 && base != 15) return 1; else return 0; }
+}
+
+/* globals of main.c:7-15 */
+static uint32_t globalTid, globalPos, globalEnd, bin_;
+static uint64_t globalnVariantPositions;
+static FILE *dump_fp;    /* MDK_ORACLE_DUMP: per-column raw counters, used by the kernel-level parity tests */
+
+static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {   /* extract.c:247-560 */
+    int tid = 0, i, seqlen, type, rv, n_plp, strand, direction, tnc;
+    int32_t pos = 0;
+    uint32_t nmethyl = 0, nunmethyl = 0, nOff = 0, nVariant = 0;
+    uint32_t localPos = 0, localEnd = 0, localTid = 0, localPos2 = 0, lastPos = 0;
+    uint64_t nVariantPositions = 0;
+    pileup1 *plp; char *seq = NULL, base = 'A'; char context[3] = "HG";
+    struct lastCall lastCpG_, lastCHG_, *lastCpG = NULL, *lastCHG = NULL;
+    kstr os_[3], *os[3]; mplp_data data;
+    memset(os_, 0, sizeof(os_)); os[0] = &os_[0]; os[1] = &os_[1]; os[2] = &os_[2];
+    for(i = 0; i < 3; i++) { os_[i].m = 1024; os_[i].s = xmalloc(1024); os_[i].s[0] = 0; }
+    if(config->merge) {
+        if(config->keepCpG) { lastCpG = &lastCpG_; lastCpG->tid = -1; }
+        if(config->keepCHG) { lastCHG = &lastCHG_; lastCHG->tid = -1; }
+    }
+    memset(&data, 0, sizeof(data)); data.config = config; data.bf = bf;
+
+    while(1) {
+        plp_t iter; ohash_t *oh;
+        bin_++;
+        localTid = globalTid; localPos = globalPos;
+        localEnd = (uint32_t)(localPos + config->chunkSize);
+        if(localTid >= (uint32_t)bf->n_targets) break;
+        if(globalEnd && localEnd > globalEnd) localEnd = globalEnd;
+        adjustBounds(bf, fa, &localTid, &localPos, &localEnd);
+        globalPos = localEnd;
+        if(globalEnd > 0 && globalPos >= globalEnd) globalTid = (uint32_t)-1;
+        if(localTid < (uint32_t)bf->n_targets && globalTid != (uint32_t)-1) {
+            if(globalPos >= bf->target_len[localTid]) { localEnd = bf->target_len[localTid]; globalTid++; globalPos = 0; }
+        }
+        localPos2 = 0; if(localPos > 1) localPos2 = localPos - 2;
+        lastPos = localPos;
+        if(localTid >= (uint32_t)bf->n_targets) break;
+        if(globalEnd && localPos >= globalEnd) break;
+        regitr_init(&data.iter, bf, (int32_t)localTid, (int32_t)localPos, (int32_t)localEnd);
+        seq = fetch_seq(fa, bf->target_name[localTid], (int)localPos2, (int)(localEnd + 10), &seqlen);
+        if(seqlen < 0) {
+            fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", seqlen, bf->target_name[localTid], localPos2, localEnd);
+            fprintf(stderr, "Note that the output will be truncated!\n");
+            continue;
+        }
+        data.seq = seq; data.offset = localPos2; data.lseq = seqlen;
+        oh = initOlapHash();
+        plp_init(&iter, &data, oh);
+
+        while((plp = plp_auto(&iter, &tid, &pos, &n_plp)) != NULL) {
+            if((uint32_t)pos < localPos || (uint32_t)pos >= localEnd) continue;
+            if((direction = isCpG(seq, pos - localPos2, seqlen))) { if(!config->keepCpG) continue; type = 0; }
+            else if((direction = isCHG(seq, pos - localPos2, seqlen))) { if(!config->keepCHG) continue; type = 1; }
+            else if((direction = isCHH(seq, pos - localPos2, seqlen))) { if(!config->keepCHH) continue; type = 2; }
+            else continue;
+
+            nmethyl = nunmethyl = nVariant = nOff = 0;
+            base = seq[pos - localPos2];
+            for(i = 0; i < n_plp; i++) {
+                if(plp[i].is_del) continue;
+                if(plp[i].is_refskip) continue;
+                strand = getStrand(plp[i].b->r);
+                if(strand & 1) { if(base != 'C' && base != 'c') { nVariant += isVariant(config, plp + i, &nOff, strand); continue; } }
+                else { if(base != 'G' && base != 'g') { nVariant += isVariant(config, plp + i, &nOff, strand); continue; } }
+                rv = methState(config, plp[i].b, plp[i].qpos);
+                if(rv > 0) nmethyl++; else if(rv < 0) nunmethyl++;
+            }
+            if(dump_fp && (nmethyl + nunmethyl > 0 || nOff > 0))
+                fprintf(dump_fp, "%d\t%d\t%d\t%d\t%u\t%u\t%u\t%u\n", tid, pos, type, (base == 'G' || base == 'g'), nmethyl, nunmethyl, nOff, nVariant);
+
+            if(config->minOppositeDepth > 0 && nOff >= (uint32_t)config->minOppositeDepth && ((double)nVariant) / ((double)nOff) >= config->maxVariantFrac) {
+                nVariantPositions++;
+                if(config->merge) {
+                    if(type == 0 && lastCpG->tid == tid && lastCpG->pos == pos - 1 && (base == 'G' || base == 'g')) { lastCpG->nmethyl = 0; lastCpG->nunmethyl = 0; }
+                    else if(type == 1 && lastCHG->tid == tid && lastCHG->pos == pos - 2 && (base == 'G' || base == 'g')) { lastCHG->nmethyl = 0; lastCHG->nunmethyl = 0; }
+                }
+                continue;
+            }
+            if(nmethyl + nunmethyl == 0 && config->cytosine_report == 0) continue;
+            if(!config->merge || type == 2) {
+                if(config->cytosine_report) {
+                    writeBlank(os, config, bf->target_name[localTid], pos, localPos2, &lastPos, seq, seqlen);
+                    if(type == 0) { context[0] = 'G'; context[1] = 0; }
+                    else if(type == 1) { context[0] = 'H'; context[1] = 'G'; }
+                    else { context[0] = 'H'; context[1] = 'H'; }
+                    tnc = getTriNucContext(seq, pos - localPos2, seqlen, direction);
+                    writeCall(os[0], config, bf->target_name[tid], pos, 1, nmethyl, nunmethyl, base, context, TriNucleotideContexts[tnc]);
+                } else writeCall(os[type], config, bf->target_name[tid], pos, 1, nmethyl, nunmethyl, base, NULL, NULL);
+            } else {
+                if(type == 0) { if(base == 'G' || base == 'g') pos--; processLast(os[0], config, lastCpG, bf, tid, pos, 2, nmethyl, nunmethyl, base); }
+                else { if(base == 'G' || base == 'g') pos -= 2; processLast(os[1], config, lastCHG, bf, tid, pos, 3, nmethyl, nunmethyl, base); }
+            }
+            lastPos = pos + 1;
+        }
+        plp_destroy(&iter);
+
+        nmethyl = 0; nunmethyl = 0;
+        if(config->merge) {
+            if(config->keepCpG && lastCpG->tid != -1) { processLast(os[0], config, lastCpG, bf, tid, pos, 2, nmethyl, nunmethyl, base); lastCpG->tid = -1; }
+            if(config->keepCHG && lastCHG->tid != -1) { processLast(os[1], config, lastCHG, bf, tid, pos, 3, nmethyl, nunmethyl, base); lastCHG->tid = -1; }
+        } else if(config->cytosine_report) {
+            writeBlank(os, config, bf->target_name[localTid], localEnd, localPos2, &lastPos, seq, seqlen);
+        }
+        free(seq);
+        /* ordered flush (extract.c:514-535); single worker => already in order */
+        if(config->cytosine_report) { if(os[0]->l) { fputs(os[0]->s, config->output_fp[0]); os[0]->l = 0; os[0]->s[0] = 0; } }
+        else {
+            if(config->keepCpG && os[0]->l) { fputs(os[0]->s, config->output_fp[0]); os[0]->l = 0; os[0]->s[0] = 0; }
+            if(config->keepCHG && os[1]->l) { fputs(os[1]->s, config->output_fp[1]); os[1]->l = 0; os[1]->s[0] = 0; }
+            if(config->keepCHH && os[2]->l) { fputs(os[2]->s, config->output_fp[2]); os[2]->l = 0; os[2]->s[0] = 0; }
+        }
+        destroyOlapHash(oh);
+    }
+    for(i = 0; i < 3; i++) free(os_[i].s);
+    if(nVariantPositions > 0) globalnVariantPositions += nVariantPositions;
+}
+
+static void printHeader(FILE *of, const char *context, char *opref, Config config) {   /* extract.c:562-569 */
+    fprintf(of, "track type=\"bedGraph\" description=\"%s %s", opref, context);
+    if(config.merge) fprintf(of, " merged");
+    if(config.fraction) fprintf(of, " methylation fractions\"\n");
+    else if(config.counts) fprintf(of, " methylation counts\"\n");
+    else if(config.logit) fprintf(of, " logit transformed methylation fractions\"\n");
+    else fprintf(of, " methylation levels\"\n");
+}
+
+static void parseBounds(char *s2, int *vals, int mult) {       /* common.c:11-43 */
+    char *p, *s = strdup(s2), *end; int i, v; long tempV;
+    p = strtok(s, ",");
+    if(!p) { fprintf(stderr, "Invalid bounds string, %s\n", s2); free(s); return; }
+    tempV = strtol(p, &end, 10);
+    if((errno == ERANGE && (tempV == LONG_MAX || tempV == LONG_MIN)) || (errno != 0 && tempV == 0) || end == p) v = -1;
+    else if(tempV > INT_MAX || tempV < LONG_MIN) v = -1; else v = (int)tempV;
+    if(v >= 0) vals[4 * mult] = v; else { fprintf(stderr, "Invalid bounds string, %s\n", s2); free(s); return; }
+    for(i = 1; i < 4; i++) {
+        p = strtok(NULL, ",");
+        if(!p) { fprintf(stderr, "Invalid bounds string, %s\n", s2); free(s); return; }   /* reference segfaults here */
+        tempV = strtol(p, &end, 10);
+        if((errno == ERANGE && (tempV == LONG_MAX || tempV == LONG_MIN)) || (errno != 0 && tempV == 0) || end == p) v = -1;
+        else if(tempV > INT_MAX || tempV < LONG_MIN) v = -1; else v = (int)tempV;
+        if(v >= 0) vals[4 * mult + i] = v; else { fprintf(stderr, "Invalid bounds string, %s\n", s2); free(s); return; }
+    }
+    free(s);
+}
+
+/* hts_parse_reg (htslib): "chr", "chr:beg", "chr:beg-", "chr:beg-end", "chr:-end"; commas allowed */
+static const char *parse_reg(const char *s, int *beg, int *end) {
+    const char *colon = strrchr(s, ':'), *p; int64_t b = 0, e = 0; int nd;
+    if(!colon) { *beg = 0; *end = INT_MAX; return s + strlen(s); }
+    p = colon + 1;
+    if(*p == '-') { /* chr:-100 == chr:1-100 */
+        p++; nd = 0; while((*p >= '0' && *p <= '9') || *p == ',') { if(*p != ',') { e = e * 10 + (*p - '0'); nd++; } p++; }
+        if(*p || !nd) return NULL;
+        *beg = 0; *end = e > INT_MAX ? INT_MAX : (int)e; return colon;
+    }
+    nd = 0; while((*p >= '0' && *p <= '9') || *p == ',') { if(*p != ',') { b = b * 10 + (*p - '0'); nd++; } p++; }
+    b -= 1;
+    if(b < 0) { if(nd && *p == '-') return NULL; *beg = 0; *end = INT_MAX; if(*p) return NULL; return colon; }
+    if(*p == 0) e = INT_MAX;
+    else if(*p == '-') { p++; while((*p >= '0' && *p <= '9') || *p == ',') { if(*p != ',') e = e * 10 + (*p - '0'); p++; } if(*p) return NULL; }
+    else return NULL;
+    if(e == 0) e = INT_MAX;
+    if(e > INT_MAX) e = INT_MAX;
+    if(b >= e) return NULL;
+    *beg = (int)b; *end = (int)e; return colon;
+}
+
+static int bbm_error(void) { printf("fatal: malformed BBM file\n"); return -9; }
+
+static void extract_usage(void) {
+    fprintf(stderr, "\nUsage: MethylDackel extract [OPTIONS] <ref.fa> <sorted_alignments.bam>\n");
+    fprintf(stderr, "(mdk_oracle: CPU oracle of the reference's option surface; see the reference for the option text)\n");
+}
+
+static int extract_main(int argc, char *argv[]) {              /* extract.c:706-1514 */
+    char *opref = NULL, *oname, *p; int c, i; Config config; bamfile bf; fasta fa;
+    FILE *BBM_ptr = NULL; char *BWName = NULL; int outputBB = 0, noBAM = 0; char *bedName = NULL;
+    const char *FastaName, *BAMName;
+    static struct option lopts[] = {
+        {"opref", 1, NULL, 'o'}, {"fraction", 0, NULL, 'f'}, {"counts", 0, NULL, 'c'}, {"logit", 0, NULL, 'm'},
+        {"minDepth", 1, NULL, 'd'}, {"noCpG", 0, NULL, 1}, {"CHG", 0, NULL, 2}, {"CHH", 0, NULL, 3},
+        {"keepDupes", 0, NULL, 4}, {"keepSingleton", 0, NULL, 5}, {"keepDiscordant", 0, NULL, 6},
+        {"OT", 1, NULL, 7}, {"OB", 1, NULL, 8}, {"CTOT", 1, NULL, 9}, {"CTOB", 1, NULL, 10},
+        {"mergeContext", 0, NULL, 11}, {"methylKit", 0, NULL, 12},
+        {"nOT", 1, NULL, 13}, {"nOB", 1, NULL, 14}, {"nCTOT", 1, NULL, 15}, {"nCTOB", 1, NULL, 16},
+        {"minOppositeDepth", 1, NULL, 17}, {"maxVariantFrac", 1, NULL, 18}, {"chunkSize", 1, NULL, 19},
+        {"keepStrand", 0, NULL, 20}, {"cytosine_report", 0, NULL, 21}, {"minConversionEfficiency", 1, NULL, 22},
+        {"ignoreNH", 0, NULL, 23}, {"ignoreFlags", 1, NULL, 'F'}, {"requireFlags", 1, NULL, 'R'},
+        {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {"mappability", 1, NULL, 'M'},
+        {"mappabilityThreshold", 1, NULL, 't'}, {"minMappableBases", 1, NULL, 'b'},
+        {"outputBBMFile", 1, NULL, 'O'}, {"outputBBMFileName", 1, NULL, 'N'}, {"mappabilityBBM", 1, NULL, 'B'},
+        {0, 0, NULL, 0}};
+
+    globalTid = globalPos = globalEnd = bin_ = 0; globalnVariantPositions = 0;
+    memset(&config, 0, sizeof(config));
+    config.mappabilityCutoff = 0.01; config.minMappableBases = 15;
+    config.keepCpG = 1; config.minMapq = 10; config.minPhred = 5; config.minDepth = 1;
+    config.ignoreFlags = 0xF00; config.nThreads = 1; config.chunkSize = 1000000;
+
+    optind = 1;
+    while((c = getopt_long(argc, argv, "hvq:p:r:l:o:D:f:c:m:d:F:R:@:M:t:b:ON:B:", lopts, NULL)) >= 0) {
+        switch(c) {
+        case 'h': extract_usage(); return 0;
+        case 'v': printf("%s (using HTSlib version %s)\n", ORACLE_VERSION, "none: mdk_oracle"); return 0;
+        case 'o': opref = strdup(optarg); break;
+        case 'D': break;
+        case 'd': config.minDepth = atoi(optarg); if(config.minDepth < 1) { fprintf(stderr, "Error, the minimum depth must be at least 1!\n"); return 1; } break;
+        case 'r': config.reg = optarg; break;
+        case 'l': bedName = optarg; break;
+        case 1: config.keepCpG = 0; break;
+        case 2: config.keepCHG = 1; break;
+        case 3: config.keepCHH = 1; break;
+        case 4: config.keepDupes = 1; break;
+        case 5: config.keepSingleton = 1; break;
+        case 6: config.keepDiscordant = 1; break;
+        case 7: parseBounds(optarg, config.bounds, 0); break;
+        case 8: parseBounds(optarg, config.bounds, 1); break;
+        case 9: parseBounds(optarg, config.bounds, 2); break;
+        case 10: parseBounds(optarg, config.bounds, 3); break;
+        case 11: config.merge = 1; break;
+        case 12: config.methylKit = 1; break;
+        case 13: parseBounds(optarg, config.absoluteBounds, 0); break;
+        case 14: parseBounds(optarg, config.absoluteBounds, 1); break;
+        case 15: parseBounds(optarg, config.absoluteBounds, 2); break;
+        case 16: parseBounds(optarg, config.absoluteBounds, 3); break;
+        case 17: config.minOppositeDepth = atoi(optarg); break;
+        case 18: config.maxVariantFrac = atof(optarg); break;
+        case 19: config.chunkSize = strtoul(optarg, NULL, 10); if(config.chunkSize < 1) { fprintf(stderr, "Error: The chunk size must be at least 1!\n"); return 1; } break;
+        case 20: break;
+        case 21: config.cytosine_report = 1; break;
+        case 22: config.minConversionEfficiency = atof(optarg); break;
+        case 23: config.ignoreNH = 1; break;
+        case 'M': BWName = optarg; break;
+        case 't': config.mappabilityCutoff = atof(optarg); break;
+        case 'b': config.minMappableBases = atoi(optarg); break;
+        case 'O': outputBB = 1; break;
+        case 'N': outputBB = 1; break;
+        case 'B': config.BBMName = optarg; break;
+        case 'F': config.ignoreFlags = atoi(optarg); break;
+        case 'R': config.requireFlags = atoi(optarg); break;
+        case 'q': config.minMapq = atoi(optarg); break;
+        case 'p': config.minPhred = atoi(optarg); break;
+        case 'm': config.logit = 1; break;
+        case 'f': config.fraction = 1; break;
+        case 'c': config.counts = 1; break;
+        case '@': config.nThreads = atoi(optarg); break;
+        case '?': default: fprintf(stderr, "Invalid option '%c'\n", c); extract_usage(); return 1;
+        }
+    }
+    if(outputBB && !BWName) { fprintf(stderr, "You must specify a bigWig file when attempting to create a BBM file!\n"); extract_usage(); return -1; }
+    if(argc == 1) { extract_usage(); return 0; }
+    if(argc - optind < 2) {
+        if(outputBB) noBAM = 1;
+        else { fprintf(stderr, "You must supply a reference genome in fasta format and an input BAM file!!!\n"); extract_usage(); return -1; }
+    }
+    if(config.minPhred < 1) { fprintf(stderr, "-p %i is invalid. resetting to 1, which is the lowest possible value.\n", config.minPhred); config.minPhred = 1; }
+    if(config.minMapq < 0) { fprintf(stderr, "-q %i is invalid. Resetting to 0, which is the lowest possible value.\n", config.minMapq); config.minMapq = 0; }
+    if(config.keepDupes > 0 && (config.ignoreFlags & 0x400)) config.ignoreFlags -= 0x400;
+    if(config.fraction + config.counts + config.logit + config.methylKit + config.cytosine_report > 1) {
+        fprintf(stderr, "More than one of --fraction, --counts, --methylKit, --cytosine_report and --logit were specified. These are mutually exclusive.\n");
+        extract_usage(); return 1;
+    }
+    if(config.methylKit + config.merge == 2) { fprintf(stderr, "--mergeContext and --methylKit are mutually exclusive.\n"); extract_usage(); return 1; }
+    if(config.cytosine_report + config.merge == 2) { fprintf(stderr, "--mergeContext and --cytosine_report are mutually exclusive.\n"); extract_usage(); return 1; }
+    if(config.fraction + config.counts + config.logit > 1) { fprintf(stderr, "You may specify AT MOST one of -c/--counts, -f/--fraction, or -m/--logit.\n"); return -6; }
+    if(!(config.keepCpG + config.keepCHG + config.keepCHH)) {
+        fprintf(stderr, "You haven't specified any metrics to output!\nEither don't use the --noCpG option or specify --CHG and/or --CHH.\n");
+        return -1;
+    }
+    if(BWName || noBAM) { fprintf(stderr, "mdk_oracle: bigWig input (-M/-O/-N) needs libBigWig, which is not available; use -B <file.bbm>\n"); return -4; }
+    if(bedName) { fprintf(stderr, "mdk_oracle: -l/--keepStrand are outside the restated path\n"); return 1; }
+
+    FastaName = argv[optind]; BAMName = argv[optind + 1];
+    if((i = bam_load(BAMName, &bf)) != 0) { fprintf(stderr, "Couldn't open %s for reading!\n", BAMName); return -4; }
+    if(config.BBMName && (BBM_ptr = fopen(config.BBMName, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", config.BBMName); return -8; }
+
+    if(BBM_ptr) {                                              /* extract.c:1236-1339 */
+        signed char readlen; unsigned char bbm_version = 0; int chromID = 0;
+        config.filterMappability = 1;
+        fprintf(stderr, "loading mappability data from %s\n", config.BBMName);
+        readlen = (signed char)fread(&bbm_version, sizeof(char), 1, BBM_ptr);
+        if(bbm_version != BBM_VERSION) { fprintf(stderr, "fatal: %s has wrong BBM version or is malformed\n", config.BBMName); return -10; }
+        readlen = (signed char)fread(&config.chromCount, sizeof(config.chromCount), 1, BBM_ptr);
+        config.chromNames = xmalloc(config.chromCount * sizeof(char *));
+        config.chromLengths = xmalloc(config.chromCount * sizeof(uint32_t));
+        if(readlen <= 0) return bbm_error();
+        config.bw_data = xmalloc(config.chromCount * sizeof(char *));
+        while(chromID < (int)config.chromCount) {
+            uint16_t nameLen = 0; char nullterm = 1; uint32_t bpos = 0; int arrlen;
+            readlen = (signed char)fread(&nameLen, sizeof(uint16_t), 1, BBM_ptr);
+            config.chromNames[chromID] = xmalloc((size_t)nameLen + 1);
+            for(i = 0; i < nameLen; i++) readlen = (signed char)fread(&(config.chromNames[chromID][i]), sizeof(char), 1, BBM_ptr);
+            config.chromNames[chromID][nameLen] = 0;
+            readlen = (signed char)fread(&nullterm, sizeof(char), 1, BBM_ptr);
+            if(nullterm) return bbm_error();
+            readlen = (signed char)fread(&(config.chromLengths[chromID]), sizeof(uint32_t), 1, BBM_ptr);
+            arrlen = config.chromLengths[chromID] / 8; if(config.chromLengths[chromID] % 8 > 0) arrlen++;
+            config.bw_data[chromID] = xmalloc((size_t)arrlen + 1);
+            while(bpos < config.chromLengths[chromID]) {
+                int index = bpos / 8; char offset = bpos % 8, aboveCutoff; unsigned char val = 0; uint16_t runlen = 0;
+                if(offset == 0) config.bw_data[chromID][index] = 0;
+                if(fread(&val, sizeof(val), 1, BBM_ptr) != 1) return bbm_error();   /* reference would loop forever on a truncated file */
+                if(val > 100) {
+                    if(val == 255) { readlen = (signed char)fread(&runlen, sizeof(uint16_t), 1, BBM_ptr); readlen = (signed char)fread(&val, sizeof(val), 1, BBM_ptr); }
+                    else { runlen = val - RUNOFFSET; readlen = (signed char)fread(&val, sizeof(val), 1, BBM_ptr); }
+                    aboveCutoff = (char)(val >= config.mappabilityCutoff * 100.0);
+                    for(i = 0; i < runlen; i++) {
+                        int tempindex = (bpos + i) / 8; char tempoffset = (bpos + i) % 8;
+                        if(tempindex >= arrlen) break;         /* reference writes out of bounds on an over-long run */
+                        if(tempoffset == 0) config.bw_data[chromID][tempindex] = 0;
+                        config.bw_data[chromID][tempindex] = config.bw_data[chromID][tempindex] | (aboveCutoff << tempoffset);
+                    }
+                    bpos += runlen;
+                    if(runlen == 0) return bbm_error();        /* reference would loop forever */
+                } else {
+                    aboveCutoff = (char)(val >= config.mappabilityCutoff * 100.0);
+                    config.bw_data[chromID][index] = config.bw_data[chromID][index] | (aboveCutoff << offset);
+                    bpos++;
+                }
+            }
+            chromID++;
+        }
+        (void)readlen;
+        fclose(BBM_ptr);
+    }
+
+    if(fasta_load(FastaName, &fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", FastaName); return -4; }
+
+    /* output files (extract.c:1343-1439) */
+    if(opref == NULL) {
+        opref = strdup(argv[optind + 1]);
+        p = strrchr(opref, '.'); if(p != NULL) *p = '\0';
+        fprintf(stderr, "writing to prefix:'%s'\n", opref);
+    }
+    oname = xmalloc(strlen(opref) + 32);
+    if(config.cytosine_report) {
+        sprintf(oname, "%s.cytosine_report.txt", opref);
+        config.output_fp[0] = fopen(oname, "w"); config.output_fp[1] = config.output_fp[0]; config.output_fp[2] = config.output_fp[0];
+        if(!config.output_fp[0]) return -3;
+    }
+    {
+        static const char *ctx[3] = {"CpG", "CHG", "CHH"}; int keep[3]; keep[0] = config.keepCpG; keep[1] = config.keepCHG; keep[2] = config.keepCHH;
+        for(i = 0; i < 3; i++) {
+            if(!keep[i] || config.cytosine_report) continue;
+            if(config.fraction) sprintf(oname, "%s_%s.meth.bedGraph", opref, ctx[i]);
+            else if(config.counts) sprintf(oname, "%s_%s.counts.bedGraph", opref, ctx[i]);
+            else if(config.logit) sprintf(oname, "%s_%s.logit.bedGraph", opref, ctx[i]);
+            else if(config.methylKit) sprintf(oname, "%s_%s.methylKit", opref, ctx[i]);
+            else sprintf(oname, "%s_%s.bedGraph", opref, ctx[i]);
+            config.output_fp[i] = fopen(oname, "w");
+            if(config.output_fp[i] == NULL) { fprintf(stderr, "Couldn't open the output %s metrics file for writing! Insufficient permissions?\n", ctx[i]); return -3; }
+            if(config.methylKit) fprintf(config.output_fp[i], "chrBase\tchr\tbase\tstrand\tcoverage\tfreqC\tfreqT\n");
+            else printHeader(config.output_fp[i], ctx[i], opref, config);
+        }
+    }
+    if(config.reg) {                                           /* extract.c:1441-1468 */
+        const char *foo; char *bar; int s = 0, e = 0;
+        foo = parse_reg(config.reg, &s, &e);
+        if(foo == NULL) { fprintf(stderr, "Could not parse the specified region!\n"); return -4; }
+        bar = xmalloc((size_t)(foo - config.reg) + 1);
+        strncpy(bar, config.reg, (size_t)(foo - config.reg)); bar[foo - config.reg] = 0;
+        globalTid = (uint32_t)-1;
+        for(i = 0; i < bf.n_targets; i++) if(!strcmp(bf.target_name[i], bar)) { globalTid = (uint32_t)i; break; }
+        if(globalTid == (uint32_t)-1) { fprintf(stderr, "%s did not match a known chromosome/contig name!\n", config.reg); return -6; }
+        if(s > 0) globalPos = (uint32_t)s;
+        if(e > 0) globalEnd = (uint32_t)e;
+        if(globalEnd > bf.target_len[globalTid]) globalEnd = bf.target_len[globalTid];
+        free(bar);
+    }
+    if(getenv("MDK_ORACLE_DUMP")) dump_fp = fopen(getenv("MDK_ORACLE_DUMP"), "w");
+
+    extractCalls(&config, &bf, &fa);
+
+    if(dump_fp) { fclose(dump_fp); dump_fp = NULL; }
+    if(globalnVariantPositions) printf("%" PRIu64 " positions were excluded due to likely being variants.\n", globalnVariantPositions);
+    if(config.cytosine_report) fclose(config.output_fp[0]);
+    if(config.keepCpG && !config.cytosine_report) fclose(config.output_fp[0]);
+    if(config.keepCHG && !config.cytosine_report) fclose(config.output_fp[1]);
+    if(config.keepCHH && !config.cytosine_report) fclose(config.output_fp[2]);
+    free(opref); free(oname);
+    return 0;
+}
+
+#ifndef MDK_ORACLE_NO_MAIN
+int main(int argc, char *argv[]) {                             /* main.c:39-62 */
+    if(argc == 1) { fprintf(stderr, "mdk_oracle: CPU oracle for `MethylDackel extract`\nUsage: mdk_oracle extract [options] ref.fa aln.bam\n"); return 0; }
+    if(strcmp(argv[1], "-v") == 0 || strcmp(argv[1], "--version") == 0) { printf("%s (using HTSlib version %s)\n", ORACLE_VERSION, "none: mdk_oracle"); return 0; }
+    if(strcmp(argv[1], "extract") == 0) return extract_main(argc - 1, argv + 1);
+    fprintf(stderr, "Unknown command!\n");
+    return -1;
+}
+#endif

@@ -1,0 +1,290 @@
+/*
+ * mdk_synth.c -- seeded synthetic WGBS data generator (FASTA + coordinate-sorted BAM [+ BBM]).
+ *
+ * Test/bench infrastructure: produces the inputs named by BASELINE.json's configs (SURVEY.md
+ * section 8d): first-order Markov reference with depleted CpG, soft-masked runs and N runs;
+ * directional paired-end bisulfite reads (OT pairs 99/147, OB pairs 83/163) with per-site
+ * methylation levels, substitution errors, indels, soft clips, ref-skips, flag/MAPQ/NH noise,
+ * optional Bismark-style XG tags (incl. CTOT/CTOB), optional secondary/supplementary records.
+ * Everything is driven by xorshift64* streams so a (seed, args) pair is reproducible anywhere.
+ *
+ * usage: mdk_synth -o PREFIX [-L len[,len...]] [-c coverage] [-l readlen] [-s seed] [-z level]
+ *                  [--bismark] [--extras] [--clean] [--bbm] [--single]
+ * writes PREFIX.fa, PREFIX.bam (and PREFIX.bbm with --bbm) and prints totals as JSON on stdout.
+ */
+#define _GNU_SOURCE
+#include <getopt.h>
+#include <inttypes.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+typedef struct { uint64_t s; } rng_t;
+static uint64_t rnd(rng_t *r) { uint64_t x = r->s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; r->s = x; return x * 2685821657736338717ULL; }
+static double rndu(rng_t *r) { return (rnd(r) >> 11) * (1.0 / 9007199254740992.0); }
+static int rndi(rng_t *r, int n) { return (int)(rndu(r) * n); }
+static double rndn(rng_t *r) { double u = rndu(r), v = rndu(r); if(u < 1e-300) u = 1e-300; return sqrt(-2 * log(u)) * cos(6.283185307179586 * v); }
+static uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+
+typedef struct { uint8_t *p; size_t l, m; } buf_t;
+static void bput(buf_t *b, const void *d, size_t n) { if(b->l + n > b->m) { b->m = (b->l + n) * 2 + 64; b->p = realloc(b->p, b->m); } memcpy(b->p + b->l, d, n); b->l += n; }
+static void b32(buf_t *b, uint32_t v) { uint8_t x[4] = {v, v >> 8, v >> 16, v >> 24}; bput(b, x, 4); }
+static void b16(buf_t *b, uint16_t v) { uint8_t x[2] = {(uint8_t)v, (uint8_t)(v >> 8)}; bput(b, x, 2); }
+static void b8(buf_t *b, uint8_t v) { bput(b, &v, 1); }
+
+/* ---- BGZF writer ---- */
+typedef struct { FILE *f; uint8_t blk[65280]; int n; int level; } bgzf_t;
+static void bgzf_flush(bgzf_t *z) {
+    uint8_t out[70000]; z_stream zs; uint32_t crc; int clen; uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
+    if(!z->n) return;
+    memset(&zs, 0, sizeof(zs));
+    deflateInit2(&zs, z->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = z->blk; zs.avail_in = z->n; zs.next_out = out; zs.avail_out = sizeof(out);
+    deflate(&zs, Z_FINISH); clen = (int)zs.total_out; deflateEnd(&zs);
+    crc = crc32(crc32(0, NULL, 0), z->blk, z->n);
+    { int bsize = clen + 25; hdr[16] = bsize & 0xff; hdr[17] = bsize >> 8; }
+    fwrite(hdr, 1, 18, z->f); fwrite(out, 1, clen, z->f);
+    { uint8_t t[8] = {crc, crc >> 8, crc >> 16, crc >> 24, (uint8_t)z->n, (uint8_t)(z->n >> 8), (uint8_t)(z->n >> 16), (uint8_t)(z->n >> 24)}; fwrite(t, 1, 8, z->f); }
+    z->n = 0;
+}
+static void bgzf_write(bgzf_t *z, const void *d, size_t n) {
+    const uint8_t *p = d;
+    while(n) { size_t k = sizeof(z->blk) - z->n; if(k > n) k = n; memcpy(z->blk + z->n, p, k); z->n += k; p += k; n -= k; if(z->n == (int)sizeof(z->blk)) bgzf_flush(z); }
+}
+static void bgzf_close(bgzf_t *z) {
+    static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bgzf_flush(z); fwrite(eof, 1, 28, z->f); fclose(z->f);
+}
+
+/* ---- reference ---- */
+typedef struct { char *name; char *seq; int64_t len; float *beta; /* per C/G-of-CpG methylation level, keyed on the C position */ } contig_t;
+
+static void make_contig(contig_t *c, rng_t *r) {
+    int64_t i; char prev = 'A'; const double gc = 0.41, cpg_oe = 0.25;
+    c->seq = malloc(c->len + 1); c->beta = calloc(c->len + 1, sizeof(float));
+    for(i = 0; i < c->len; i++) {
+        double u = rndu(r); char b;
+        double pC = gc / 2, pG = gc / 2, pA = (1 - gc) / 2;
+        if(prev == 'C') { double ng = pG * cpg_oe, d = pG - ng; pG = ng; pA += d / 2; /* T takes the rest */ }
+        if(u < pA) b = 'A'; else if(u < pA + pC) b = 'C'; else if(u < pA + pC + pG) b = 'G'; else b = 'T';
+        c->seq[i] = b; prev = b;
+    }
+    c->seq[c->len] = 0;
+    /* N runs: 0.5 % of bases in runs of <= 100 */
+    { int64_t target = c->len / 200, done = 0; while(done < target && c->len > 400) { int64_t s = (int64_t)(rndu(r) * (c->len - 100)); int l = 1 + rndi(r, 100); for(i = 0; i < l; i++) c->seq[s + i] = 'N'; done += l; } }
+    /* soft-masked (lower-case) runs: ~10 % */
+    { int64_t target = c->len / 10, done = 0; while(done < target && c->len > 2000) { int64_t s = (int64_t)(rndu(r) * (c->len - 1000)); int l = 50 + rndi(r, 950); for(i = 0; i < l; i++) if(c->seq[s + i] != 'N') c->seq[s + i] |= 0x20; done += l; } }
+    for(i = 0; i + 1 < c->len; i++) if((c->seq[i] & 0x5f) == 'C' && (c->seq[i + 1] & 0x5f) == 'G') c->beta[i] = (rndu(r) < 0.8) ? (float)(0.65 + 0.3 * rndu(r)) : (float)(0.02 + 0.16 * rndu(r));
+}
+
+/* ---- reads ---- */
+typedef struct { int32_t tid, pos; uint64_t ord; uint8_t *d; uint32_t n; } rec_t;
+static int rec_cmp(const void *a, const void *b) {
+    const rec_t *x = a, *y = b;
+    if(x->tid != y->tid) return x->tid < y->tid ? -1 : 1;
+    if(x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+    return x->ord < y->ord ? -1 : (x->ord > y->ord);
+}
+static int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if(beg >> 14 == end >> 14) return ((1 << 15) - 1) / 7 + (beg >> 14);
+    if(beg >> 17 == end >> 17) return ((1 << 12) - 1) / 7 + (beg >> 17);
+    if(beg >> 20 == end >> 20) return ((1 << 9) - 1) / 7 + (beg >> 20);
+    if(beg >> 23 == end >> 23) return ((1 << 6) - 1) / 7 + (beg >> 23);
+    if(beg >> 26 == end >> 26) return ((1 << 3) - 1) / 7 + (beg >> 26);
+    return 0;
+}
+static const uint8_t nt16[256] = {['A'] = 1, ['C'] = 2, ['G'] = 4, ['T'] = 8, ['N'] = 15, ['a'] = 1, ['c'] = 2, ['g'] = 4, ['t'] = 8, ['n'] = 15};
+
+typedef struct { int clean, bismark, extras, single; int readlen; } opts_t;
+typedef struct { uint32_t op[8]; int n; int rspan, qlen; } cig_t;
+
+/* choose a CIGAR for a read of `L` query bases */
+static void make_cigar(cig_t *c, int L, rng_t *r, const opts_t *o) {
+    double u = rndu(r); int a, b;
+    c->n = 0;
+    if(o->clean || L < 40) { c->op[c->n++] = (uint32_t)L << 4 | 0; }
+    else if(u < 0.01) { b = 1 + rndi(r, 3); a = 10 + rndi(r, L - 20 - b); c->op[c->n++] = a << 4 | 0; c->op[c->n++] = b << 4 | 1; c->op[c->n++] = (L - a - b) << 4 | 0; }
+    else if(u < 0.02) { b = 1 + rndi(r, 3); a = 10 + rndi(r, L - 20); c->op[c->n++] = a << 4 | 0; c->op[c->n++] = b << 4 | 2; c->op[c->n++] = (L - a) << 4 | 0; }
+    else if(u < 0.045) { b = 5 + rndi(r, 16); c->op[c->n++] = b << 4 | 4; c->op[c->n++] = (L - b) << 4 | 0; }
+    else if(u < 0.07) { b = 5 + rndi(r, 16); c->op[c->n++] = (L - b) << 4 | 0; c->op[c->n++] = b << 4 | 4; }
+    else if(u < 0.071) { b = 100 + rndi(r, 900); a = 20 + rndi(r, L - 40); c->op[c->n++] = a << 4 | 0; c->op[c->n++] = b << 4 | 3; c->op[c->n++] = (L - a) << 4 | 0; }
+    else if(u < 0.072) { a = 10 + rndi(r, L - 30); c->op[c->n++] = a << 4 | 7; c->op[c->n++] = 5 << 4 | 8; c->op[c->n++] = (L - a - 5) << 4 | 0; }   /* = and X ops */
+    else if(u < 0.073) { b = 3 + rndi(r, 8); c->op[c->n++] = 7 << 4 | 5; c->op[c->n++] = b << 4 | 4; c->op[c->n++] = (L - b) << 4 | 0; }                 /* hard + soft clip */
+    else c->op[c->n++] = (uint32_t)L << 4 | 0;
+    c->rspan = c->qlen = 0;
+    for(a = 0; a < c->n; a++) { int op = c->op[a] & 15, l = c->op[a] >> 4; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) c->rspan += l; if(op == 0 || op == 1 || op == 4 || op == 7 || op == 8) c->qlen += l; }
+}
+
+/* strand: 1 OT, 2 OB, 3 CTOT, 4 CTOB -- which conversion the read carries (odd: C->T, even: G->A) */
+static void emit_read(buf_t *out, const contig_t *ct, int tid, int64_t pos, const cig_t *cg, int flag, int mapq, int32_t mpos, int32_t tlen,
+                      const char *qname, int strand, uint64_t fragkey, rng_t *r, const opts_t *o, int nh, int mtid) {
+    static const int qlev[4] = {2, 12, 23, 37}; int L = cg->qlen, i, k, q = 0; int64_t p = pos;
+    uint8_t *seq = calloc((L + 1) / 2 + 1, 1), *qual = malloc(L + 1); size_t start = out->l; uint32_t bs;
+    for(k = 0; k < cg->n; k++) {
+        int op = cg->op[k] & 15, l = cg->op[k] >> 4;
+        for(i = 0; i < l; i++) {
+            uint8_t code; double u;
+            if(op == 0 || op == 7 || op == 8) {
+                char rb = (p >= 0 && p < ct->len) ? ct->seq[p] : 'N'; char ub = rb & 0x5f; char sb = ub;
+                /* methylation state is a property of the fragment, so both mates agree on it */
+                if((strand & 1) && ub == 'C') {
+                    double beta = ((p + 1 < ct->len) && (ct->seq[p + 1] & 0x5f) == 'G') ? ct->beta[p] : 0.01;
+                    double h = (mix64(fragkey ^ (uint64_t)p * 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0);
+                    if(h >= beta) sb = 'T';
+                } else if(!(strand & 1) && ub == 'G') {
+                    double beta = (p > 0 && (ct->seq[p - 1] & 0x5f) == 'C') ? ct->beta[p - 1] : 0.01;
+                    double h = (mix64(fragkey ^ (uint64_t)p * 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0);
+                    if(h >= beta) sb = 'A';
+                }
+                if(!o->clean && rndu(r) < 0.005) sb = "ACGT"[rndi(r, 4)];
+                if(op == 8 && sb != 'N') sb = (sb == 'A') ? 'C' : 'A';
+                code = nt16[(uint8_t)sb]; p++;
+            } else if(op == 1 || op == 4) code = nt16[(uint8_t)"ACGT"[rndi(r, 4)]];
+            else { if(op == 2 || op == 3) p++; continue; }
+            u = rndu(r);
+            qual[q] = (uint8_t)(o->clean ? 37 : qlev[u < 0.02 ? 0 : u < 0.07 ? 1 : u < 0.20 ? 2 : 3]);
+            seq[q >> 1] |= (q & 1) ? code : (uint8_t)(code << 4);
+            q++;
+        }
+    }
+    b32(out, 0);                                  /* block_size placeholder */
+    b32(out, (uint32_t)tid); b32(out, (uint32_t)pos);
+    b8(out, (uint8_t)(strlen(qname) + 1)); b8(out, (uint8_t)mapq); b16(out, (uint16_t)reg2bin(pos, pos + (cg->rspan ? cg->rspan : 1)));
+    b16(out, (uint16_t)cg->n); b16(out, (uint16_t)flag); b32(out, (uint32_t)L);
+    b32(out, (uint32_t)mtid); b32(out, (uint32_t)mpos); b32(out, (uint32_t)tlen);
+    bput(out, qname, strlen(qname) + 1);
+    for(k = 0; k < cg->n; k++) b32(out, cg->op[k]);
+    bput(out, seq, (L + 1) / 2); bput(out, qual, L);
+    /* aux */
+    bput(out, "NMC", 3); b8(out, (uint8_t)rndi(r, 4));
+    if(!o->clean && rndu(r) < 0.3) { bput(out, "MDZ", 3); bput(out, "150", 4); }
+    if(o->bismark) { bput(out, "XRZ", 3); bput(out, (flag & 0x80) ? "GA" : "CT", 3); bput(out, "XGZ", 3); bput(out, (strand == 1 || strand == 3) ? "CT" : "GA", 3); }
+    if(!o->clean && rndu(r) < 0.02) { bput(out, "XGi", 3); b32(out, (uint32_t)rndi(r, 3)); }      /* non-Bismark XG: must be ignored */
+    if(nh == 1) { bput(out, "NHC", 3); b8(out, 1); } else if(nh == 2) { bput(out, "NHi", 3); b32(out, 2); }
+    if(!o->clean && rndu(r) < 0.05) { bput(out, "ZBB", 3); b8(out, 'S'); b32(out, 3); b16(out, 1); b16(out, 2); b16(out, 3); }
+    bs = (uint32_t)(out->l - start - 4);
+    out->p[start] = bs; out->p[start + 1] = bs >> 8; out->p[start + 2] = bs >> 16; out->p[start + 3] = bs >> 24;
+    free(seq); free(qual);
+}
+
+int main(int argc, char **argv) {
+    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {0, 0, 0, 0}};
+    const char *prefix = NULL, *lens = "1000000"; double cov = 30; uint64_t seed = 0x5EED0001ULL; int level = 1, c, want_bbm = 0;
+    opts_t o = {0, 0, 0, 0, 150}; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
+    buf_t pool = {0, 0, 0}; size_t *offs = NULL; char fn[4096]; uint64_t ord = 0, npairs_total = 0, nbases = 0;
+    while((c = getopt_long(argc, argv, "o:L:c:l:s:z:", lo, NULL)) >= 0) {
+        switch(c) {
+        case 'o': prefix = optarg; break; case 'L': lens = optarg; break; case 'c': cov = atof(optarg); break;
+        case 'l': o.readlen = atoi(optarg); break; case 's': seed = strtoull(optarg, NULL, 0); break; case 'z': level = atoi(optarg); break;
+        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break;
+        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [--bismark] [--extras] [--clean] [--bbm] [--single]\n"); return 1;
+        }
+    }
+    if(!prefix) { fprintf(stderr, "mdk_synth: -o PREFIX is required\n"); return 1; }
+    rg.s = seed ? seed : 1; rr.s = mix64(seed + 1) | 1;
+    { char *s = strdup(lens), *p = strtok(s, ","); while(p) { ct = realloc(ct, sizeof(*ct) * (nct + 1)); memset(&ct[nct], 0, sizeof(*ct)); ct[nct].len = atoll(p); asprintf(&ct[nct].name, nct ? "chrS%d" : "chrS1", nct + 1); nct++; p = strtok(NULL, ","); } free(s); }
+    snprintf(fn, sizeof(fn), "%s.fa", prefix);
+    { FILE *f = fopen(fn, "w"); if(!f) { perror(fn); return 1; }
+      for(t = 0; t < nct; t++) { int64_t j; make_contig(&ct[t], &rg); fprintf(f, ">%s synthetic seed=%" PRIu64 "\n", ct[t].name, seed); for(j = 0; j < ct[t].len; j += 60) { fwrite(ct[t].seq + j, 1, (ct[t].len - j) < 60 ? (ct[t].len - j) : 60, f); fputc('\n', f); } }
+      fclose(f); }
+
+    for(t = 0; t < nct; t++) {
+        int64_t L = ct[t].len; uint64_t npairs = (uint64_t)(L * cov / (2.0 * o.readlen)), pi;
+        if(L < 2 * o.readlen) continue;
+        for(pi = 0; pi < npairs; pi++) {
+            int flen = (int)(300 + 50 * rndn(&rr)), ob, mapq, nh, fl1, fl2, strand1, strand2, single = o.single; int64_t fs; cig_t c1, c2; char qn[64]; uint64_t fragkey;
+            int64_t p1, p2; double u; int extraflag = 0, discord = 0, singleton = 0;
+            if(flen < o.readlen) flen = o.readlen; if(flen > 4 * o.readlen) flen = 4 * o.readlen; if(flen > L) flen = (int)L;
+            fs = (int64_t)(rndu(&rr) * (L - flen + 1));
+            ob = rndu(&rr) < 0.5;
+            make_cigar(&c1, o.readlen, &rr, &o); make_cigar(&c2, o.readlen, &rr, &o);
+            snprintf(qn, sizeof(qn), "f%d_%" PRIu64, t, pi);
+            fragkey = mix64(seed ^ ((uint64_t)t << 48) ^ pi);
+            mapq = 40 + rndi(&rr, 21); nh = 0; fl1 = 0; fl2 = 0;
+            if(!o.clean) {
+                if(rndu(&rr) < 0.02) mapq = rndi(&rr, 10);
+                u = rndu(&rr); if(u < 0.10) nh = 1; else if(u < 0.11) nh = 2;
+                u = rndu(&rr); if(u < 0.03) extraflag = 0x400; else if(u < 0.04) extraflag = 0x200;
+                if(rndu(&rr) < 0.01) discord = 1;
+                if(rndu(&rr) < 0.005) singleton = 1;
+            }
+            /* left read at fs, right read ends at fs+flen */
+            p1 = fs; p2 = fs + flen - c2.rspan; if(p2 < 0) p2 = 0; if(p2 + c2.rspan > L) p2 = L - c2.rspan; if(p1 + c1.rspan > L) p1 = L - c1.rspan;
+            if(p2 < p1) p2 = p1;
+            if(single) {
+                int rev = ob; strand1 = ob ? 2 : 1; fl1 = (rev ? 0x10 : 0) | extraflag;
+                if(o.bismark && rndu(&rr) < 0.1) { strand1 = ob ? 4 : 3; fl1 ^= 0x10; }
+                if(nrec + 1 > mrec) { mrec = mrec ? mrec * 2 : 1 << 16; offs = realloc(offs, mrec * sizeof(size_t)); recs = realloc(recs, mrec * sizeof(rec_t)); }
+                offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p1, &c1, fl1, mapq, -1, 0, qn, strand1, fragkey, &rr, &o, nh, -1);
+                recs[nrec].tid = t; recs[nrec].pos = (int32_t)p1; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++; nbases += c1.qlen; npairs_total++;
+                continue;
+            }
+            if(!ob) { fl1 = 0x1 | 0x2 | 0x20 | 0x40; fl2 = 0x1 | 0x2 | 0x10 | 0x80; strand1 = strand2 = 1; }       /* 99 / 147 */
+            else { fl1 = 0x1 | 0x2 | 0x20 | 0x80; fl2 = 0x1 | 0x2 | 0x10 | 0x40; strand1 = strand2 = 2; }       /* 163 / 83 */
+            if(o.bismark && rndu(&rr) < 0.1) {      /* non-directional: CTOT / CTOB pairs (read#1/#2 roles swapped) */
+                fl1 ^= 0xC0; fl2 ^= 0xC0; strand1 = strand2 = ob ? 4 : 3;
+            }
+            if(discord) { fl1 &= ~0x2; fl2 &= ~0x2; }
+            fl1 |= extraflag; fl2 |= extraflag;
+            if(nrec + 4 > mrec) { mrec = mrec ? mrec * 2 : 1 << 16; offs = realloc(offs, mrec * sizeof(size_t)); recs = realloc(recs, mrec * sizeof(rec_t)); }
+            if(singleton) {                          /* mate unmapped: keep only the left read */
+                fl1 = (fl1 | 0x8) & ~0x2 & ~0x20;
+                offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p1, &c1, fl1, mapq, (int32_t)p1, 0, qn, strand1, fragkey, &rr, &o, nh, t);
+                recs[nrec].tid = t; recs[nrec].pos = (int32_t)p1; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++; nbases += c1.qlen; npairs_total++;
+                continue;
+            }
+            offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p1, &c1, fl1, mapq, (int32_t)p2, (int32_t)(p2 + c2.rspan - p1), qn, strand1, fragkey, &rr, &o, nh, t);
+            recs[nrec].tid = t; recs[nrec].pos = (int32_t)p1; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++;
+            offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p2, &c2, fl2, mapq, (int32_t)p1, -(int32_t)(p2 + c2.rspan - p1), qn, strand2, fragkey, &rr, &o, nh, t);
+            recs[nrec].tid = t; recs[nrec].pos = (int32_t)p2; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++;
+            nbases += c1.qlen + c2.qlen; npairs_total++;
+            if(o.extras && rndu(&rr) < 0.02) {       /* a secondary or supplementary record sharing the qname */
+                cig_t c3; int64_t p3; int f3 = fl1 | (rndu(&rr) < 0.5 ? 0x100 : 0x800);
+                make_cigar(&c3, o.readlen, &rr, &o); p3 = fs + rndi(&rr, flen); if(p3 + c3.rspan > L) p3 = L - c3.rspan; if(p3 < 0) p3 = 0;
+                offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p3, &c3, f3, mapq, (int32_t)p2, 0, qn, strand1, fragkey, &rr, &o, nh, t);
+                recs[nrec].tid = t; recs[nrec].pos = (int32_t)p3; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++;
+            }
+        }
+    }
+    for(i = 0; i < nrec; i++) recs[i].d = pool.p + offs[i];
+    qsort(recs, nrec, sizeof(rec_t), rec_cmp);
+
+    snprintf(fn, sizeof(fn), "%s.bam", prefix);
+    { bgzf_t z; buf_t h = {0, 0, 0}; char txt[65536]; int n = 0;
+      z.f = fopen(fn, "wb"); z.n = 0; z.level = level; if(!z.f) { perror(fn); return 1; }
+      n += snprintf(txt + n, sizeof(txt) - n, "@HD\tVN:1.6\tSO:coordinate\n");
+      for(t = 0; t < nct; t++) n += snprintf(txt + n, sizeof(txt) - n, "@SQ\tSN:%s\tLN:%" PRId64 "\n", ct[t].name, ct[t].len);
+      n += snprintf(txt + n, sizeof(txt) - n, "@PG\tID:mdk_synth\tPN:mdk_synth\tCL:seed=%" PRIu64 "\n", seed);
+      bput(&h, "BAM\1", 4); b32(&h, (uint32_t)n); bput(&h, txt, n); b32(&h, (uint32_t)nct);
+      for(t = 0; t < nct; t++) { b32(&h, (uint32_t)strlen(ct[t].name) + 1); bput(&h, ct[t].name, strlen(ct[t].name) + 1); b32(&h, (uint32_t)ct[t].len); }
+      bgzf_write(&z, h.p, h.l); bgzf_flush(&z);
+      for(i = 0; i < nrec; i++) bgzf_write(&z, recs[i].d, recs[i].n);
+      bgzf_close(&z); free(h.p); }
+
+    if(want_bbm) {     /* synthetic mappability: values {0,50,100}; ~10 % of bases in low runs */
+        FILE *f; uint8_t ver = 1; uint32_t nc = (uint32_t)nct;
+        snprintf(fn, sizeof(fn), "%s.bbm", prefix); f = fopen(fn, "wb"); if(!f) { perror(fn); return 1; }
+        fwrite(&ver, 1, 1, f); fwrite(&nc, 4, 1, f);
+        for(t = 0; t < nct; t++) {
+            uint16_t nl = (uint16_t)strlen(ct[t].name); uint8_t z0 = 0; uint32_t cl = (uint32_t)ct[t].len; int64_t p = 0;
+            fwrite(&nl, 2, 1, f); fwrite(ct[t].name, 1, nl, f); fwrite(&z0, 1, 1, f); fwrite(&cl, 4, 1, f);
+            while(p < ct[t].len) {
+                int64_t run = (rndu(&rg) < 0.5) ? 1 + rndi(&rg, 3000) : 1 + rndi(&rg, 300); uint8_t val = (rndu(&rg) < 0.25) ? (rndu(&rg) < 0.5 ? 0 : 50) : 100;
+                if(run > ct[t].len - p) run = ct[t].len - p;
+                p += run;
+                while(run > 0) {
+                    if(run == 1) { fwrite(&val, 1, 1, f); run = 0; }
+                    else if(run <= 155) { uint8_t rl = (uint8_t)(run + 99); fwrite(&rl, 1, 1, f); fwrite(&val, 1, 1, f); run = 0; }
+                    else { uint8_t fl = 255; uint16_t rl = (uint16_t)(run > 65535 ? 65535 : run); fwrite(&fl, 1, 1, f); fwrite(&rl, 2, 1, f); fwrite(&val, 1, 1, f); run -= rl; }
+                }
+            }
+        }
+        fclose(f);
+    }
+    printf("{\"prefix\": \"%s\", \"contigs\": %d, \"records\": %zu, \"pairs\": %" PRIu64 ", \"query_bases\": %" PRIu64 ", \"seed\": %" PRIu64 "}\n", prefix, nct, nrec, npairs_total, nbases, seed);
+    return 0;
+}
