@@ -1,0 +1,32 @@
+# Build of the MI355X `MethylDackel extract` path: device library (hipcc, gfx950), host library (gcc),
+# the `MethylDackel` command, plus the test/bench infrastructure (oracle, synthetic generator).
+HIPCC  ?= hipcc
+CC     ?= gcc
+ARCH   ?= gfx950
+B      := methyldackel_amd/_build
+CFLAGS ?= -O2 -g -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -fPIC -pthread
+HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_extract.c
+
+all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
+
+$(B)/libmdk_hip.so: methyldackel_amd/csrc/mdk_hip.hip include/mdk_hip.h
+	@mkdir -p $(B)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude -o $@ methyldackel_amd/csrc/mdk_hip.hip
+
+$(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h include/mdk_extract.h include/mdk_hip.h $(B)/libmdk_hip.so
+	$(CC) $(CFLAGS) -shared -Iinclude -o $@ $(HOSTSRC) -L$(B) -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
+
+$(B)/MethylDackel: methyldackel_amd/csrc/host/main.c $(B)/libmdk_extract.so
+	$(CC) $(CFLAGS) -Iinclude -o $@ methyldackel_amd/csrc/host/main.c -L$(B) -lmdk_extract -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
+
+tools: tools/_build/mdk_synth
+tools/_build/mdk_synth: tools/mdk_synth.c
+	@mkdir -p tools/_build
+	$(CC) -O2 -g -o $@ tools/mdk_synth.c -lz -lm
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(B) tools/_build oracle/_build
+.PHONY: all tools oracle clean

@@ -1,0 +1,63 @@
+/*
+ * mdk_extract.h -- C ABI of the host side of the MI355X `extract` path (libmdk_extract.so).
+ *
+ * Drop-in symbol (what the reference's main.c:18,49-50 binds):
+ *     int extract_main(int argc, char *argv[]);            reference: extract.c:706
+ * Same argv contract (argv[0] == "extract"), option surface, validation order, messages, output
+ * file naming/format and return codes as the reference; the per-chunk work (extractCalls,
+ * extract.c:247-560) runs on the GPU through include/mdk_hip.h.  There is no CPU fallback: without
+ * a usable device extract_main prints the HIP error and returns -20.
+ *
+ * The staged API below exposes the same pipeline one reference chunk at a time (used by the
+ * parity tests, bench.py and the multi-GPU sharded driver).
+ */
+#ifndef MDK_EXTRACT_H
+#define MDK_EXTRACT_H
+#include <stdint.h>
+#include "mdk_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDK_RC_NODEVICE (-20)   /* GPU path unavailable */
+#define MDK_RC_DEVICE   (-21)   /* a device operation failed mid-run */
+
+int extract_main(int argc, char *argv[]);
+
+typedef struct mdk_plan mdk_plan;
+
+/* One chunk of the reference's schedule (extract.c:325-350 + adjustBounds) with its admitted reads packed
+ * for the device.  `batch` arrays are owned by the plan and stay valid until the second-next
+ * mdk_plan_next_chunk call (two rotating pinned buffers). */
+typedef struct {
+    uint32_t index;            /* localBin: output order */
+    int32_t  tid;
+    int64_t  beg, end;         /* [localPos, localEnd) */
+    int32_t  skipped;          /* 1: contig missing from the FASTA -> the reference skips the chunk */
+    md_read_batch batch;
+    uint64_t n_records_seen;   /* BAM records examined for this chunk (before admission) */
+} mdk_chunk;
+
+/* Parse an `extract` command line (argv[0] = "extract"), open inputs.  rc follows extract_main:
+ * *out is NULL with rc==0 when the command line only asked for help/version. */
+int  mdk_plan_open(int argc, char *argv[], mdk_plan **out);
+void mdk_plan_close(mdk_plan *p);
+/* device configuration implied by the options */
+void mdk_plan_dev_cfg(const mdk_plan *p, md_dev_cfg *cfg);
+/* upload the contig a chunk needs (no-op if already resident on that device handle) */
+int  mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid);
+/* 1: chunk produced; 0: schedule finished; <0: error */
+int  mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c);
+/* host post-pass for one chunk (variant filter, --mergeContext, formats; extract.c:443-510), appended to
+ * the plan's output files.  Chunks must be emitted in index order. */
+int  mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *sites);
+/* print the variant-position line (extract.c:1489), close outputs */
+int  mdk_plan_finish(mdk_plan *p);
+int  mdk_plan_n_targets(const mdk_plan *p);
+const char *mdk_plan_target_name(const mdk_plan *p, int32_t tid);
+int64_t mdk_plan_target_len(const mdk_plan *p, int32_t tid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,266 @@
+"""methyldackel_amd -- MI355X-native `MethylDackel extract` hot path.
+
+The product is native code: ``csrc/mdk_hip.hip`` (HIP kernels + device C-ABI, ``include/mdk_hip.h``) and
+``csrc/host/*.c`` (C host: BGZF/BAM decode, admission, pairing, chunk schedule, text emitters;
+``include/mdk_extract.h``).  This package is only the ctypes view of those two C-ABIs that the tests, bench.py
+and the multi-GPU driver use; it contains no compute and no fallback -- importing works anywhere, but every
+device call fails loudly when ``libmdk_hip.so`` is missing or no GPU is visible.
+
+Reference interface mirrored: ``extract_main(argc, argv)`` (reference extract.c:706) and the per-chunk
+pipeline of ``extractCalls`` (reference extract.c:247-560).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+REPO = ROOT.parent
+BUILD = ROOT / "_build"
+LIB_HIP = BUILD / "libmdk_hip.so"
+LIB_EXTRACT = BUILD / "libmdk_extract.so"
+CLI = BUILD / "MethylDackel"
+
+MDK_ERR = {-1: "HIP call failed", -2: "no device", -3: "bad argument", -4: "reference not uploaded",
+           -5: "strand 0 read reached a call", -6: "out of memory"}
+
+
+class MdkError(RuntimeError):
+    pass
+
+
+class md_dev_cfg(C.Structure):
+    _fields_ = [("keepCpG", C.c_int32), ("keepCHG", C.c_int32), ("keepCHH", C.c_int32), ("minPhred", C.c_int32),
+                ("minOppositeDepth", C.c_int32), ("bounds", C.c_int32 * 16), ("absoluteBounds", C.c_int32 * 16),
+                ("tile", C.c_int32), ("n_slots", C.c_int32)]
+
+
+class md_read_hdr(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("off4", C.c_uint32), ("l_qseq", C.c_uint32), ("n_cigar", C.c_uint16),
+                ("strand", C.c_uint8), ("flags", C.c_uint8)]
+
+
+class md_read_batch(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("n_reads", C.c_int32),
+                ("hdr", C.POINTER(md_read_hdr)), ("rend", C.POINTER(C.c_int32)), ("mate", C.POINTER(C.c_int32)),
+                ("blob", C.POINTER(C.c_uint8)), ("blob_bytes", C.c_uint64)]
+
+
+class md_sites(C.Structure):
+    _fields_ = [("n_sites", C.c_int64), ("pos", C.POINTER(C.c_uint32)), ("nmeth", C.POINTER(C.c_uint32)),
+                ("nunmeth", C.POINTER(C.c_uint32)), ("noff", C.POINTER(C.c_uint32)), ("nvar", C.POINTER(C.c_uint32)),
+                ("meta", C.POINTER(C.c_uint8))]
+
+
+class md_bench_result(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_pileup", C.c_float), ("algo_bytes", C.c_uint64), ("n_sites", C.c_uint64)]
+
+
+class mdk_chunk(C.Structure):
+    _fields_ = [("index", C.c_uint32), ("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("skipped", C.c_int32),
+                ("batch", md_read_batch), ("n_records_seen", C.c_uint64)]
+
+
+HIP_SYMBOLS = ["md_dev_count", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference",
+               "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_sites_to_device",
+               "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free"]
+EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
+                   "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_n_targets", "mdk_plan_target_name",
+                   "mdk_plan_target_len"]
+
+_hip = None
+_ext = None
+
+
+def build(verbose: bool = False) -> None:
+    """Compile everything in-tree (hipcc --offload-arch=gfx950 for the kernels, gcc for the host)."""
+    r = subprocess.run(["make", "-C", str(REPO), "all"], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise MdkError("build failed")
+
+
+def lib_hip():
+    global _hip
+    if _hip is None:
+        if not LIB_HIP.exists():
+            raise MdkError(f"{LIB_HIP} is missing: the HIP extension was not built (run `make` / __graft_entry__.build()); there is no fallback")
+        L = C.CDLL(str(LIB_HIP), mode=C.RTLD_GLOBAL)
+        L.md_dev_last_error.restype = C.c_char_p
+        L.md_dev_open.argtypes = [C.c_int, C.POINTER(md_dev_cfg), C.POINTER(C.c_void_p)]
+        L.md_dev_close.argtypes = [C.c_void_p]
+        L.md_dev_tile.argtypes = [C.c_void_p]
+        L.md_dev_set_reference.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
+        for f in ("md_dev_upload", "md_dev_submit"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.POINTER(md_read_batch)]
+        L.md_dev_launch.argtypes = [C.c_void_p, C.c_int]
+        L.md_dev_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_sites)]
+        L.md_dev_sync.argtypes = [C.c_void_p]
+        L.md_dev_sites_to_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int64]
+        L.md_dev_sites_to_device.restype = C.c_int64
+        L.md_dev_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
+        L.md_dev_debug_effective.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.md_host_alloc.restype = C.c_void_p
+        L.md_host_alloc.argtypes = [C.c_uint64]
+        L.md_host_free.argtypes = [C.c_void_p]
+        _hip = L
+    return _hip
+
+
+def lib_extract():
+    global _ext
+    if _ext is None:
+        lib_hip()
+        if not LIB_EXTRACT.exists():
+            raise MdkError(f"{LIB_EXTRACT} is missing (run `make`)")
+        L = C.CDLL(str(LIB_EXTRACT))
+        L.extract_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.mdk_plan_open.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+        L.mdk_plan_close.argtypes = [C.c_void_p]
+        L.mdk_plan_dev_cfg.argtypes = [C.c_void_p, C.POINTER(md_dev_cfg)]
+        L.mdk_plan_ensure_reference.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.mdk_plan_next_chunk.argtypes = [C.c_void_p, C.POINTER(mdk_chunk)]
+        L.mdk_plan_emit.argtypes = [C.c_void_p, C.POINTER(mdk_chunk), C.POINTER(md_sites)]
+        L.mdk_plan_finish.argtypes = [C.c_void_p]
+        L.mdk_plan_n_targets.argtypes = [C.c_void_p]
+        L.mdk_plan_target_name.argtypes = [C.c_void_p, C.c_int32]
+        L.mdk_plan_target_name.restype = C.c_char_p
+        L.mdk_plan_target_len.argtypes = [C.c_void_p, C.c_int32]
+        L.mdk_plan_target_len.restype = C.c_int64
+        _ext = L
+    return _ext
+
+
+def _argv(args):
+    arr = (C.c_char_p * (len(args) + 1))()
+    for i, a in enumerate(args):
+        arr[i] = os.fsencode(str(a))
+    return arr
+
+
+class Device:
+    """One GPU handle (md_dev_open).  Raises MdkError when no device / no HIP library: there is no CPU path."""
+
+    def __init__(self, cfg: md_dev_cfg, device: int = 0):
+        L = lib_hip()
+        self.h = C.c_void_p()
+        rc = L.md_dev_open(device, C.byref(cfg), C.byref(self.h))
+        if rc:
+            raise MdkError(f"md_dev_open failed ({rc}): {L.md_dev_last_error().decode()}")
+        self.L = L
+
+    def _chk(self, rc, what):
+        if rc:
+            raise MdkError(f"{what} failed ({rc}): {self.L.md_dev_last_error().decode()}")
+
+    def set_reference(self, tid: int, seq: bytes):
+        self._chk(self.L.md_dev_set_reference(self.h, tid, seq, len(seq)), "md_dev_set_reference")
+
+    def submit(self, slot: int, batch: md_read_batch):
+        self._chk(self.L.md_dev_submit(self.h, slot, C.byref(batch)), "md_dev_submit")
+
+    def upload(self, slot: int, batch: md_read_batch):
+        self._chk(self.L.md_dev_upload(self.h, slot, C.byref(batch)), "md_dev_upload")
+
+    def launch(self, slot: int):
+        self._chk(self.L.md_dev_launch(self.h, slot), "md_dev_launch")
+
+    def download(self, slot: int) -> md_sites:
+        s = md_sites()
+        self._chk(self.L.md_dev_download(self.h, slot, C.byref(s)), "md_dev_download")
+        return s
+
+    def bench(self, slot: int, warmup: int, iters: int) -> md_bench_result:
+        r = md_bench_result()
+        self._chk(self.L.md_dev_bench(self.h, slot, warmup, iters, C.byref(r)), "md_dev_bench")
+        return r
+
+    def sync(self):
+        self._chk(self.L.md_dev_sync(self.h), "md_dev_sync")
+
+    def close(self):
+        if self.h:
+            self.L.md_dev_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """The host pipeline of one `extract` command line, a chunk at a time (mdk_plan_*)."""
+
+    def __init__(self, args):
+        L = lib_extract()
+        self.L = L
+        self.args = ["extract"] + [str(a) for a in args]
+        self._argv = _argv(self.args)
+        self.p = C.c_void_p()
+        self.rc = L.mdk_plan_open(len(self.args), self._argv, C.byref(self.p))
+        if self.rc or not self.p:
+            raise MdkError(f"mdk_plan_open returned {self.rc}")
+
+    def dev_cfg(self) -> md_dev_cfg:
+        cfg = md_dev_cfg()
+        self.L.mdk_plan_dev_cfg(self.p, C.byref(cfg))
+        return cfg
+
+    def next_chunk(self):
+        c = mdk_chunk()
+        rc = self.L.mdk_plan_next_chunk(self.p, C.byref(c))
+        if rc < 0:
+            raise MdkError(f"mdk_plan_next_chunk failed ({rc})")
+        return c if rc == 1 else None
+
+    def ensure_reference(self, dev: Device, tid: int):
+        rc = self.L.mdk_plan_ensure_reference(self.p, dev.h, tid)
+        if rc:
+            raise MdkError(f"mdk_plan_ensure_reference failed ({rc}): {lib_hip().md_dev_last_error().decode()}")
+
+    def emit(self, chunk: mdk_chunk, sites: md_sites):
+        rc = self.L.mdk_plan_emit(self.p, C.byref(chunk), C.byref(sites))
+        if rc:
+            raise MdkError(f"mdk_plan_emit failed ({rc})")
+
+    def finish(self):
+        self.L.mdk_plan_finish(self.p)
+
+    def target_name(self, tid: int) -> str:
+        return self.L.mdk_plan_target_name(self.p, tid).decode()
+
+    def close(self):
+        if self.p:
+            self.L.mdk_plan_close(self.p)
+            self.p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sites_to_rows(s: md_sites):
+    """md_sites -> list of (pos, type, isG, nmeth, nunmeth, noff, nvar) tuples (for tests)."""
+    n = s.n_sites
+    rows = []
+    for i in range(n):
+        rows.append((s.pos[i], s.meta[i] >> 1, s.meta[i] & 1, s.nmeth[i], s.nunmeth[i],
+                     s.noff[i] if s.noff else 0, s.nvar[i] if s.nvar else 0))
+    return rows
+
+
+def run_cli(args, cwd=None, env=None):
+    """Run the `MethylDackel extract` command of this build; returns CompletedProcess."""
+    if not CLI.exists():
+        raise MdkError(f"{CLI} is missing (run `make`)")
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    return subprocess.run([str(CLI), "extract"] + [str(a) for a in args], cwd=cwd, env=e, capture_output=True, text=True)

@@ -1,0 +1,20 @@
+/* main.c -- `MethylDackel` command of the MI355X build.  Only `extract` is accelerated (and built); the
+ * reference's dispatcher is main.c:39-62. */
+#include <stdio.h>
+#include <string.h>
+#include "mdk_extract.h"
+
+static void usage_main(void) {
+    fprintf(stderr, "MethylDackel (methyldackel_amd, MI355X build of the `extract` path)\n"
+                    "Usage: MethylDackel <command> [options]\n\nCommands:\n"
+                    "    extract  Extract methylation metrics from an alignment file in BAM format (GPU).\n"
+                    "    mbias | mergeContext | perRead   not part of this build; use the reference MethylDackel.\n");
+}
+int main(int argc, char *argv[]) {
+    if(argc == 1) { usage_main(); return 0; }
+    if(!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage_main(); return 0; }
+    if(!strcmp(argv[1], "-v") || !strcmp(argv[1], "--version")) { printf("0.6.1 (using HTSlib version none; methyldackel_amd MI355X build)\n"); return 0; }
+    if(!strcmp(argv[1], "extract")) return extract_main(argc - 1, argv + 1);
+    if(!strcmp(argv[1], "mbias") || !strcmp(argv[1], "mergeContext") || !strcmp(argv[1], "perRead")) { fprintf(stderr, "`%s` is not part of the MI355X build.\n", argv[1]); return -1; }
+    fprintf(stderr, "Unknown command!\n"); usage_main(); return -1;
+}

@@ -1,0 +1,834 @@
+/*
+ * mdk_extract.c -- host side of the MI355X `MethylDackel extract` path.
+ *
+ * Division of labour:
+ *   host  : BGZF inflate + BAM record framing (mdk_io.c), read admission (the flag/tag/MAPQ tests of
+ *           filter_func, common.c:416-444), strand determination (getStrand, common.c:84-116), the
+ *           qname pairing that htslib's constructor/destructor callbacks perform (overlaps.c:121-147),
+ *           packing into the SoA batch of include/mdk_hip.h, the reference's chunk schedule
+ *           (extract.c:325-350, common.c:466-493) and the text post-pass (extract.c:443-510, 39-99).
+ *   device: everything per base -- trimming, overlap resolution, context classification, counting.
+ * There is no CPU implementation of the per-base work in this library.
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <getopt.h>
+#include <inttypes.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mdk_extract.h"
+#include "mdk_io.h"
+
+#define MDK_VERSION "0.6.1"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* options (the reference's Config, MethylDackel.h:90-126; defaults extract.c:715-753)               */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int ctx_on[3];                 /* CpG, CHG, CHH */
+    int min_mapq, min_phred, keep_dupes, min_depth, keep_discordant, keep_singleton;
+    int ignore_flags, require_flags, merge, methylkit, min_opp_depth, ignore_nh;
+    double max_variant_frac;
+    int fraction, counts, logit, cytosine_report;
+    float min_conv_eff, map_cutoff; int min_mappable;
+    int rel_bounds[16], abs_bounds[16];
+    int n_threads; unsigned long chunk_size;
+    char *region, *opref, *bbm_name, *bw_name, *bed_name, *out_bbm_name;
+    int output_bb, no_bam, keep_strand;
+    const char *fasta_name, *bam_name;
+} opts_t;
+
+/* text buffer */
+typedef struct { char *s; size_t l, m; } sbuf;
+static void sb_put(sbuf *b, const char *s, size_t n) {
+    if(b->l + n + 1 > b->m) { b->m = (b->l + n + 1) * 2; b->s = realloc(b->s, b->m); }
+    memcpy(b->s + b->l, s, n); b->l += n; b->s[b->l] = 0;
+}
+
+/* pinned, growable batch arrays */
+typedef struct {
+    md_read_hdr *hdr; int32_t *rend, *mate; uint8_t *blob;
+    size_t cap_reads, cap_blob, n, blob_len;
+    char *qn; size_t qn_len, qn_cap; uint32_t *qn_off; size_t qn_off_cap;
+} batchbuf;
+
+/* qname table entry for the pairing pass */
+typedef struct { uint64_t h; uint32_t qoff; int32_t pending; int32_t nlive; int32_t live[4]; int32_t *more; int32_t nmore, capmore; int used; } qent;
+
+struct mdk_plan {
+    opts_t o;
+    mdk_bam *bam; mdk_fasta fa; int *fa_of_tid;
+    /* schedule cursor (main.c:10-13 globals) */
+    uint32_t g_tid, g_pos, g_end, bin;
+    uint64_t n_variant_positions;
+    /* stream state */
+    int32_t last_tid, last_pos;
+    uint8_t *carry; size_t carry_len, carry_cap; int32_t carry_tid;
+    uint8_t *carry2; size_t carry2_len, carry2_cap;
+    batchbuf bb[2]; int cur_bb;
+    uint16_t *bflag[2]; size_t bflag_cap[2];
+    qent *qt; size_t qt_cap;
+    /* mappability */
+    int map_on; uint32_t map_n; char **map_names; uint32_t *map_len; uint8_t **map_bits; int *map_of_tid;
+    /* outputs */
+    FILE *out[3]; sbuf ob[3];
+    uint32_t next_emit;
+    int32_t lastcpg_tid, lastcpg_pos, lastchg_tid, lastchg_pos; uint32_t lastcpg_m, lastcpg_u, lastchg_m, lastchg_u;
+    /* device references already uploaded: (dev handle, tid) pairs */
+    md_dev **ref_dev; int32_t *ref_tid; int n_ref, cap_ref;
+};
+
+/* ------------------------------------------------------------------------------------------------ */
+/* usage text                                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+static void usage(void) {
+    fputs("\nUsage: MethylDackel extract [OPTIONS] <ref.fa> <sorted_alignments.bam>\n", stderr);
+    fputs("\nOptions (MI355X build; same option surface as MethylDackel 0.6.1):\n"
+" -q INT, -p INT, -d INT, -D INT(ignored), -r STR, -l FILE(*), -o/--opref STR, -@ INT,\n"
+" -F/--ignoreFlags INT, -R/--requireFlags INT, --chunkSize INT, --mergeContext,\n"
+" --keepDupes, --keepSingleton, --keepDiscordant, --noCpG, --CHG, --CHH,\n"
+" --fraction, --counts, --logit, --methylKit, --cytosine_report, --ignoreNH,\n"
+" --minOppositeDepth INT, --maxVariantFrac FLOAT, --minConversionEfficiency FLOAT,\n"
+" --OT/--OB/--CTOT/--CTOB INT,INT,INT,INT, --nOT/--nOB/--nCTOT/--nCTOB INT,INT,INT,INT,\n"
+" -B/--mappabilityBBM FILE, -t/--mappabilityThreshold FLOAT, -b/--minMappableBases INT,\n"
+" -M/--mappability FILE(*), -O, -N FILE(*), --keepStrand(*), --version\n"
+" (*) needs libraries/paths outside this build: bigWig input and BED-driven extraction.\n"
+"\nNote that --fraction, --counts, and --logit are mutually exclusive!\n", stderr);
+}
+
+/* 4 comma-separated non-negative ints (the reference's parseBounds, common.c:11-43) */
+static void parse_bounds(const char *arg, int *dst) {
+    char *dup = strdup(arg), *tok, *end, *save = NULL; int k; int tmp[4];
+    for(k = 0, tok = strtok_r(dup, ",", &save); k < 4; k++, tok = strtok_r(NULL, ",", &save)) {
+        long v;
+        if(!tok) break;
+        v = strtol(tok, &end, 10);
+        if((errno == ERANGE && (v == LONG_MAX || v == LONG_MIN)) || (errno != 0 && v == 0) || end == tok || v > INT_MAX || v < 0) break;
+        tmp[k] = (int)v;
+        dst[k] = tmp[k];             /* the reference stores values as it goes, so a bad later field keeps the earlier ones */
+    }
+    if(k < 4) fprintf(stderr, "Invalid bounds string, %s\n", arg);
+    free(dup);
+}
+
+/* "chr", "chr:beg", "chr:beg-", "chr:beg-end", "chr:-end" (htslib hts_parse_reg as used at extract.c:1446) */
+static const char *parse_region(const char *s, int *beg, int *end) {
+    const char *colon = strrchr(s, ':'), *p; long long b = 0, e = 0; int nd = 0;
+    if(!colon) { *beg = 0; *end = INT_MAX; return s + strlen(s); }
+    p = colon + 1;
+    if(*p == '-') {
+        for(p++; (*p >= '0' && *p <= '9') || *p == ','; p++) if(*p != ',') { e = e * 10 + (*p - '0'); nd++; }
+        if(*p || !nd) return NULL;
+        *beg = 0; *end = e > INT_MAX ? INT_MAX : (int)e; return colon;
+    }
+    for(; (*p >= '0' && *p <= '9') || *p == ','; p++) if(*p != ',') { b = b * 10 + (*p - '0'); nd++; }
+    b -= 1;
+    if(b < 0) { if((nd && *p == '-') || *p) return NULL; *beg = 0; *end = INT_MAX; return colon; }
+    if(*p == 0) e = INT_MAX;
+    else if(*p == '-') { for(p++; (*p >= '0' && *p <= '9') || *p == ','; p++) if(*p != ',') e = e * 10 + (*p - '0'); if(*p) return NULL; }
+    else return NULL;
+    if(e == 0 || e > INT_MAX) e = INT_MAX;
+    if(b >= e) return NULL;
+    *beg = (int)b; *end = (int)e; return colon;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* BBM mappability (BBM_Specification.md; loader semantics of extract.c:1236-1339)                   */
+/* ------------------------------------------------------------------------------------------------ */
+static int load_bbm(mdk_plan *p, FILE *f) {
+    uint8_t ver = 0; uint32_t nchrom = 0, c;
+    fprintf(stderr, "loading mappability data from %s\n", p->o.bbm_name);
+    if(fread(&ver, 1, 1, f) != 1 || ver != 1) { fprintf(stderr, "fatal: %s has wrong BBM version or is malformed\n", p->o.bbm_name); return -10; }
+    if(fread(&nchrom, 4, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; }
+    p->map_n = nchrom; p->map_names = calloc(nchrom + 1, sizeof(char *)); p->map_len = calloc(nchrom + 1, 4); p->map_bits = calloc(nchrom + 1, sizeof(uint8_t *));
+    for(c = 0; c < nchrom; c++) {
+        uint16_t nl = 0; uint8_t z = 1; uint32_t len = 0, at = 0; size_t nbytes; double cut = p->o.map_cutoff * 100.0;
+        if(fread(&nl, 2, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; }
+        p->map_names[c] = calloc((size_t)nl + 1, 1);
+        if(nl && fread(p->map_names[c], 1, nl, f) != nl) { printf("fatal: malformed BBM file\n"); return -9; }
+        if(fread(&z, 1, 1, f) != 1 || z) { printf("fatal: malformed BBM file\n"); return -9; }
+        if(fread(&len, 4, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; }
+        p->map_len[c] = len; nbytes = (size_t)len / 8 + ((len % 8) ? 1 : 0);
+        p->map_bits[c] = calloc(nbytes + 8, 1);
+        while(at < len) {
+            uint8_t v; uint32_t run = 1; int above;
+            if(fread(&v, 1, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; }
+            if(v > 100) {
+                if(v == 255) { uint16_t r16 = 0; if(fread(&r16, 2, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; } run = r16; }
+                else run = (uint32_t)v - 99u;
+                if(fread(&v, 1, 1, f) != 1 || run == 0) { printf("fatal: malformed BBM file\n"); return -9; }
+            }
+            above = ((double)v >= cut);
+            if(above) { uint32_t k, stop = (at + run < len) ? at + run : len; for(k = at; k < stop; k++) p->map_bits[c][k >> 3] |= (uint8_t)(1u << (k & 7)); }
+            at += run;
+        }
+    }
+    p->map_on = 1;
+    return 0;
+}
+/* number of set bits in [start, start+l) of chromosome c; bits outside the stored array are 0 */
+static int64_t map_popcount(const mdk_plan *p, int c, int64_t start, int64_t l) {
+    int64_t nbits = ((int64_t)p->map_len[c] / 8 + ((p->map_len[c] % 8) ? 1 : 0)) * 8, end = start + l, cnt = 0, k;
+    if(start < 0 || c < 0) return 0;          /* a negative start is a huge uint32 in the reference: past the array */
+    if(end > nbits) end = nbits;
+    for(k = start; k < end && (k & 7); k++) cnt += (p->map_bits[c][k >> 3] >> (k & 7)) & 1;
+    for(; k + 8 <= end; k += 8) cnt += __builtin_popcount(p->map_bits[c][k >> 3]);
+    for(; k < end; k++) cnt += (p->map_bits[c][k >> 3] >> (k & 7)) & 1;
+    return cnt;
+}
+/* one window of check_mappability (common.c:305-316): the running counter is a signed char */
+static int map_window_passes(const mdk_plan *p, int c, int64_t start, int l) {
+    int need = p->o.min_mappable;
+    if(l <= 0) return 0;
+    if(need <= 0) return 1;
+    if(need > 127) return 0;
+    return map_popcount(p, c, start, l) >= need;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* plan open / option surface                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+enum { O_NOCPG = 1, O_CHG, O_CHH, O_KEEPDUPES, O_KEEPSINGLETON, O_KEEPDISCORDANT, O_OT, O_OB, O_CTOT, O_CTOB, O_MERGE, O_METHYLKIT,
+       O_NOT, O_NOB, O_NCTOT, O_NCTOB, O_MINOPP, O_MAXVARFRAC, O_CHUNKSIZE, O_KEEPSTRAND, O_CYTREPORT, O_MINCONVEFF, O_IGNORENH };
+
+static void plan_free(mdk_plan *p);
+
+int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
+    static const struct option longopts[] = {
+        {"opref", required_argument, 0, 'o'}, {"fraction", no_argument, 0, 'f'}, {"counts", no_argument, 0, 'c'}, {"logit", no_argument, 0, 'm'},
+        {"minDepth", required_argument, 0, 'd'}, {"noCpG", no_argument, 0, O_NOCPG}, {"CHG", no_argument, 0, O_CHG}, {"CHH", no_argument, 0, O_CHH},
+        {"keepDupes", no_argument, 0, O_KEEPDUPES}, {"keepSingleton", no_argument, 0, O_KEEPSINGLETON}, {"keepDiscordant", no_argument, 0, O_KEEPDISCORDANT},
+        {"OT", required_argument, 0, O_OT}, {"OB", required_argument, 0, O_OB}, {"CTOT", required_argument, 0, O_CTOT}, {"CTOB", required_argument, 0, O_CTOB},
+        {"mergeContext", no_argument, 0, O_MERGE}, {"methylKit", no_argument, 0, O_METHYLKIT},
+        {"nOT", required_argument, 0, O_NOT}, {"nOB", required_argument, 0, O_NOB}, {"nCTOT", required_argument, 0, O_NCTOT}, {"nCTOB", required_argument, 0, O_NCTOB},
+        {"minOppositeDepth", required_argument, 0, O_MINOPP}, {"maxVariantFrac", required_argument, 0, O_MAXVARFRAC}, {"chunkSize", required_argument, 0, O_CHUNKSIZE},
+        {"keepStrand", no_argument, 0, O_KEEPSTRAND}, {"cytosine_report", no_argument, 0, O_CYTREPORT}, {"minConversionEfficiency", required_argument, 0, O_MINCONVEFF},
+        {"ignoreNH", no_argument, 0, O_IGNORENH}, {"ignoreFlags", required_argument, 0, 'F'}, {"requireFlags", required_argument, 0, 'R'},
+        {"help", no_argument, 0, 'h'}, {"version", no_argument, 0, 'v'}, {"mappability", required_argument, 0, 'M'},
+        {"mappabilityThreshold", required_argument, 0, 't'}, {"minMappableBases", required_argument, 0, 'b'},
+        {"outputBBMFile", required_argument, 0, 'O'}, {"outputBBMFileName", required_argument, 0, 'N'}, {"mappabilityBBM", required_argument, 0, 'B'},
+        {0, 0, 0, 0}};
+    mdk_plan *p; opts_t *o; int c, i; char *oname; FILE *bbm = NULL;
+    *out = NULL;
+    p = calloc(1, sizeof(*p)); if(!p) return -5;
+    o = &p->o;
+    o->ctx_on[0] = 1; o->min_mapq = 10; o->min_phred = 5; o->min_depth = 1; o->ignore_flags = 0xF00;
+    o->n_threads = 1; o->chunk_size = 1000000; o->map_cutoff = 0.01f; o->min_mappable = 15;
+    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1; p->lastcpg_tid = -1; p->lastchg_tid = -1;
+
+    optind = 1;     /* the reference relies on a fresh process; being a library we reset getopt */
+    /* NB -f, -c and -m take an argument in the short-option string although --fraction/--counts/--logit do not
+     * (extract.c:796 vs 757-759); kept as is, it is part of the option surface. */
+    while((c = getopt_long(argc, argv, "hvq:p:r:l:o:D:f:c:m:d:F:R:@:M:t:b:ON:B:", longopts, NULL)) >= 0) {
+        switch(c) {
+        case 'h': usage(); plan_free(p); return 0;
+        case 'v': printf("%s (using HTSlib version %s)\n", MDK_VERSION, "none; methyldackel_amd MI355X build"); plan_free(p); return 0;
+        case 'o': free(o->opref); o->opref = strdup(optarg); break;
+        case 'D': break;
+        case 'd': o->min_depth = atoi(optarg); if(o->min_depth < 1) { fprintf(stderr, "Error, the minimum depth must be at least 1!\n"); plan_free(p); return 1; } break;
+        case 'r': o->region = optarg; break;
+        case 'l': o->bed_name = optarg; break;
+        case O_NOCPG: o->ctx_on[0] = 0; break;
+        case O_CHG: o->ctx_on[1] = 1; break;
+        case O_CHH: o->ctx_on[2] = 1; break;
+        case O_KEEPDUPES: o->keep_dupes = 1; break;
+        case O_KEEPSINGLETON: o->keep_singleton = 1; break;
+        case O_KEEPDISCORDANT: o->keep_discordant = 1; break;
+        case O_OT: case O_OB: case O_CTOT: case O_CTOB: parse_bounds(optarg, o->rel_bounds + 4 * (c - O_OT)); break;
+        case O_NOT: case O_NOB: case O_NCTOT: case O_NCTOB: parse_bounds(optarg, o->abs_bounds + 4 * (c - O_NOT)); break;
+        case O_MERGE: o->merge = 1; break;
+        case O_METHYLKIT: o->methylkit = 1; break;
+        case O_MINOPP: o->min_opp_depth = atoi(optarg); break;
+        case O_MAXVARFRAC: o->max_variant_frac = atof(optarg); break;
+        case O_CHUNKSIZE: o->chunk_size = strtoul(optarg, NULL, 10); if(o->chunk_size < 1) { fprintf(stderr, "Error: The chunk size must be at least 1!\n"); plan_free(p); return 1; } break;
+        case O_KEEPSTRAND: o->keep_strand = 1; break;
+        case O_CYTREPORT: o->cytosine_report = 1; break;
+        case O_MINCONVEFF: o->min_conv_eff = (float)atof(optarg); break;
+        case O_IGNORENH: o->ignore_nh = 1; break;
+        case 'M': o->bw_name = optarg; break;
+        case 't': o->map_cutoff = (float)atof(optarg); break;
+        case 'b': o->min_mappable = atoi(optarg); break;
+        case 'O': o->output_bb = 1; break;
+        case 'N': o->output_bb = 1; o->out_bbm_name = optarg; break;
+        case 'B': o->bbm_name = optarg; break;
+        case 'F': o->ignore_flags = atoi(optarg); break;     /* atoi: "0xD00" parses as 0, as in the reference */
+        case 'R': o->require_flags = atoi(optarg); break;
+        case 'q': o->min_mapq = atoi(optarg); break;
+        case 'p': o->min_phred = atoi(optarg); break;
+        case 'm': o->logit = 1; break;
+        case 'f': o->fraction = 1; break;
+        case 'c': o->counts = 1; break;
+        case '@': o->n_threads = atoi(optarg); break;
+        default: fprintf(stderr, "Invalid option '%c'\n", c); usage(); plan_free(p); return 1;
+        }
+    }
+    if(o->output_bb && !o->bw_name) { fprintf(stderr, "You must specify a bigWig file when attempting to create a BBM file!\n"); usage(); plan_free(p); return -1; }
+    if(argc == 1) { usage(); plan_free(p); return 0; }
+    if(argc - optind < 2) {
+        if(o->output_bb) o->no_bam = 1;
+        else { fprintf(stderr, "You must supply a reference genome in fasta format and an input BAM file!!!\n"); usage(); plan_free(p); return -1; }
+    }
+    if(o->min_phred < 1) { fprintf(stderr, "-p %i is invalid. resetting to 1, which is the lowest possible value.\n", o->min_phred); o->min_phred = 1; }
+    if(o->min_mapq < 0) { fprintf(stderr, "-q %i is invalid. Resetting to 0, which is the lowest possible value.\n", o->min_mapq); o->min_mapq = 0; }
+    if(o->keep_dupes > 0 && (o->ignore_flags & 0x400)) o->ignore_flags -= 0x400;
+    if(o->fraction + o->counts + o->logit + o->methylkit + o->cytosine_report > 1) {
+        fprintf(stderr, "More than one of --fraction, --counts, --methylKit, --cytosine_report and --logit were specified. These are mutually exclusive.\n");
+        usage(); plan_free(p); return 1;
+    }
+    if(o->methylkit + o->merge == 2) { fprintf(stderr, "--mergeContext and --methylKit are mutually exclusive.\n"); usage(); plan_free(p); return 1; }
+    if(o->cytosine_report + o->merge == 2) { fprintf(stderr, "--mergeContext and --cytosine_report are mutually exclusive.\n"); usage(); plan_free(p); return 1; }
+    if(o->fraction + o->counts + o->logit > 1) { fprintf(stderr, "You may specify AT MOST one of -c/--counts, -f/--fraction, or -m/--logit.\n"); plan_free(p); return -6; }
+    if(!(o->ctx_on[0] + o->ctx_on[1] + o->ctx_on[2])) {
+        fprintf(stderr, "You haven't specified any metrics to output!\nEither don't use the --noCpG option or specify --CHG and/or --CHH.\n");
+        plan_free(p); return -1;
+    }
+    if(o->bw_name || o->no_bam) { fprintf(stderr, "Couldn't open %s for reading! (bigWig input needs libBigWig, which this build does not have; convert to .bbm and use -B)\n", o->bw_name ? o->bw_name : "bigWig"); plan_free(p); return -4; }
+    if(o->bed_name) { fprintf(stderr, "There was an error while reading in your BED file! (-l/--keepStrand are not part of the MI355X extract path yet)\n"); plan_free(p); return 1; }
+
+    o->fasta_name = argv[optind]; o->bam_name = argv[optind + 1];
+    if(o->n_threads < 1) o->n_threads = 1;
+    p->bam = mdk_bam_open(o->bam_name, o->n_threads);
+    if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
+    if(o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); plan_free(p); return -8; }
+    if(bbm) { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { plan_free(p); return rc; } }
+    if(mdk_fasta_load(o->fasta_name, &p->fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", o->fasta_name); plan_free(p); return -4; }
+    p->fa_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
+    for(i = 0; i < p->bam->n_targets; i++) p->fa_of_tid[i] = mdk_fasta_find(&p->fa, p->bam->target_name[i]);
+    if(p->map_on) {
+        p->map_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
+        for(i = 0; i < p->bam->n_targets; i++) { uint32_t k; p->map_of_tid[i] = -1; for(k = 0; k < p->map_n; k++) if(!strcmp(p->map_names[k], p->bam->target_name[i])) { p->map_of_tid[i] = (int)k; break; } }
+    }
+
+    /* output files and headers (extract.c:1343-1439) */
+    if(!o->opref) {
+        char *dot; o->opref = strdup(o->bam_name); dot = strrchr(o->opref, '.'); if(dot) *dot = 0;
+        fprintf(stderr, "writing to prefix:'%s'\n", o->opref);
+    }
+    oname = malloc(strlen(o->opref) + 40);
+    if(o->cytosine_report) {
+        sprintf(oname, "%s.cytosine_report.txt", o->opref);
+        p->out[0] = fopen(oname, "w"); p->out[1] = p->out[2] = p->out[0];
+        if(!p->out[0]) { fprintf(stderr, "Couldn't open the output CpG metrics file for writing! Insufficient permissions?\n"); free(oname); plan_free(p); return -3; }
+    } else {
+        static const char *cn[3] = {"CpG", "CHG", "CHH"};
+        for(i = 0; i < 3; i++) {
+            const char *ext = o->fraction ? ".meth.bedGraph" : o->counts ? ".counts.bedGraph" : o->logit ? ".logit.bedGraph" : o->methylkit ? ".methylKit" : ".bedGraph";
+            if(!o->ctx_on[i]) continue;
+            sprintf(oname, "%s_%s%s", o->opref, cn[i], ext);
+            p->out[i] = fopen(oname, "w");
+            if(!p->out[i]) { fprintf(stderr, "Couldn't open the output %s metrics file for writing! Insufficient permissions?\n", cn[i]); free(oname); plan_free(p); return -3; }
+            if(o->methylkit) fputs("chrBase\tchr\tbase\tstrand\tcoverage\tfreqC\tfreqT\n", p->out[i]);
+            else fprintf(p->out[i], "track type=\"bedGraph\" description=\"%s %s%s%s\"\n", o->opref, cn[i], o->merge ? " merged" : "",
+                         o->fraction ? " methylation fractions" : o->counts ? " methylation counts" : o->logit ? " logit transformed methylation fractions" : " methylation levels");
+        }
+    }
+    free(oname);
+    /* -r (extract.c:1441-1468) */
+    if(o->region) {
+        int s = 0, e = 0, t; const char *colon = parse_region(o->region, &s, &e); char *name;
+        if(!colon) { fprintf(stderr, "Could not parse the specified region!\n"); plan_free(p); return -4; }
+        name = strndup(o->region, (size_t)(colon - o->region));
+        for(t = 0; t < p->bam->n_targets; t++) if(!strcmp(p->bam->target_name[t], name)) break;
+        free(name);
+        if(t == p->bam->n_targets) { fprintf(stderr, "%s did not match a known chromosome/contig name!\n", o->region); plan_free(p); return -6; }
+        p->g_tid = (uint32_t)t;
+        if(s > 0) p->g_pos = (uint32_t)s;
+        if(e > 0) p->g_end = (uint32_t)e;
+        if(p->g_end > p->bam->target_len[t]) p->g_end = p->bam->target_len[t];
+    }
+    *out = p;
+    return 0;
+}
+
+static void bb_free(batchbuf *b) { md_host_free(b->hdr); md_host_free(b->rend); md_host_free(b->mate); md_host_free(b->blob); free(b->qn); free(b->qn_off); memset(b, 0, sizeof(*b)); }
+static void plan_free(mdk_plan *p) {
+    uint32_t k; int i;
+    if(!p) return;
+    if(p->bam) mdk_bam_close(p->bam);
+    mdk_fasta_free(&p->fa); free(p->fa_of_tid); free(p->map_of_tid);
+    for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); }
+    free(p->map_names); free(p->map_len); free(p->map_bits);
+    free(p->carry); free(p->carry2); free(p->bflag[0]); free(p->bflag[1]);
+    if(p->bb[0].hdr || p->bb[1].hdr) { bb_free(&p->bb[0]); bb_free(&p->bb[1]); }
+    if(p->qt) { size_t q; for(q = 0; q < p->qt_cap; q++) free(p->qt[q].more); free(p->qt); }
+    if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); }
+    else for(i = 0; i < 3; i++) if(p->out[i]) fclose(p->out[i]);
+    for(i = 0; i < 3; i++) free(p->ob[i].s);
+    free(p->o.opref); free(p->ref_dev); free(p->ref_tid);
+    free(p);
+}
+void mdk_plan_close(mdk_plan *p) { plan_free(p); }
+
+int mdk_plan_n_targets(const mdk_plan *p) { return p->bam->n_targets; }
+const char *mdk_plan_target_name(const mdk_plan *p, int32_t tid) { return (tid >= 0 && tid < p->bam->n_targets) ? p->bam->target_name[tid] : NULL; }
+int64_t mdk_plan_target_len(const mdk_plan *p, int32_t tid) { return (tid >= 0 && tid < p->bam->n_targets) ? (int64_t)p->bam->target_len[tid] : -1; }
+
+void mdk_plan_dev_cfg(const mdk_plan *p, md_dev_cfg *cfg) {
+    int i;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->keepCpG = p->o.ctx_on[0]; cfg->keepCHG = p->o.ctx_on[1]; cfg->keepCHH = p->o.ctx_on[2];
+    cfg->minPhred = p->o.min_phred; cfg->minOppositeDepth = p->o.min_opp_depth > 0 ? p->o.min_opp_depth : 0;
+    for(i = 0; i < 16; i++) { cfg->bounds[i] = p->o.rel_bounds[i]; cfg->absoluteBounds[i] = p->o.abs_bounds[i]; }
+    cfg->n_slots = 2;
+    if(getenv("MDK_TILE")) cfg->tile = atoi(getenv("MDK_TILE"));
+}
+
+int mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid) {
+    int i, fi;
+    for(i = 0; i < p->n_ref; i++) if(p->ref_dev[i] == dev && p->ref_tid[i] == tid) return 0;
+    if(tid < 0 || tid >= p->bam->n_targets || (fi = p->fa_of_tid[tid]) < 0) return MDK_ERR_NOREF;
+    i = md_dev_set_reference(dev, tid, p->fa.seq[fi], p->fa.len[fi]);
+    if(i) return i;
+    if(p->n_ref == p->cap_ref) { p->cap_ref = p->cap_ref ? p->cap_ref * 2 : 32; p->ref_dev = realloc(p->ref_dev, sizeof(md_dev *) * p->cap_ref); p->ref_tid = realloc(p->ref_tid, sizeof(int32_t) * p->cap_ref); }
+    p->ref_dev[p->n_ref] = dev; p->ref_tid[p->n_ref] = tid; p->n_ref++;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* per-record helpers                                                                                */
+/* ------------------------------------------------------------------------------------------------ */
+static inline uint32_t rd_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static inline int cigar_is_match(int op) { return op == 0 || op == 7 || op == 8; }
+static int32_t cigar_ref_len(const mdk_rec *r) {
+    int32_t l = 0; int k;
+    for(k = 0; k < r->n_cigar; k++) { uint32_t c = rd_u32(r->cigar + 4 * k); int op = c & 15; if(cigar_is_match(op) || op == 2 || op == 3) l += (int32_t)(c >> 4); }
+    return l;
+}
+
+/* one pass over the aux area for the two tags the path looks at.  Pointers are to the TYPE byte of the first
+ * occurrence, like bam_aux_get; a malformed aux area ends the scan (tags after it are "absent"). */
+static void scan_aux(const mdk_rec *r, const uint8_t **nh, const uint8_t **xg) {
+    const uint8_t *s = r->aux, *e = r->aux + r->aux_len;
+    *nh = *xg = NULL;
+    while(e - s >= 3) {
+        const uint8_t *ty = s + 2, *v = s + 3; size_t sz;
+        switch(*ty) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'd': sz = 8; break;
+        case 'Z': case 'H': { const uint8_t *z = memchr(v, 0, (size_t)(e - v)); if(!z) return; sz = (size_t)(z - v) + 1; break; }
+        case 'B': { size_t es; if(e - v < 5) return; switch(v[0]) { case 'c': case 'C': es = 1; break; case 's': case 'S': es = 2; break; case 'i': case 'I': case 'f': es = 4; break; default: return; } sz = 5 + es * (size_t)rd_u32(v + 1); break; }
+        default: return;
+        }
+        if((size_t)(e - v) < sz) return;
+        if(s[0] == 'N' && s[1] == 'H' && !*nh) *nh = ty;
+        else if(s[0] == 'X' && s[1] == 'G' && !*xg) *xg = ty;
+        s = v + sz;
+    }
+}
+static int64_t aux_int(const uint8_t *ty) {
+    switch(*ty) {
+    case 'c': return (int8_t)ty[1]; case 'C': return ty[1];
+    case 's': { int16_t v; memcpy(&v, ty + 1, 2); return v; } case 'S': { uint16_t v; memcpy(&v, ty + 1, 2); return v; }
+    case 'i': { int32_t v; memcpy(&v, ty + 1, 4); return v; } case 'I': { uint32_t v; memcpy(&v, ty + 1, 4); return v; }
+    }
+    return 0;
+}
+/* strand of origin from FLAG and an optional Bismark-style XG tag (common.c:84-116) */
+static int strand_of(uint16_t flag, const uint8_t *xg) {
+    int conv = 0;    /* 0: no usable XG, 'C' / 'G': converted genome */
+    if(xg && (xg[1] == 'C' || xg[1] == 'G')) conv = xg[1];
+    if(!conv) {
+        if(!(flag & 0x1)) return (flag & 0x10) ? 2 : 1;
+        if((flag & 0x50) == 0x50) return 2;
+        if(flag & 0x40) return 1;
+        if((flag & 0x90) == 0x90) return 1;
+        if(flag & 0x80) return 2;
+        return 0;
+    }
+    {   /* orientation classes in the reference's test order (a FLAG with both 0x40 and 0x80 resolves as read #1) */
+        int fwdlike;
+        if((flag & 0x51) == 0x41) fwdlike = 1;            /* read #1 forward */
+        else if((flag & 0x51) == 0x51) fwdlike = 0;       /* read #1 reverse */
+        else if((flag & 0x91) == 0x81) fwdlike = 0;       /* read #2 forward */
+        else if((flag & 0x91) == 0x91) fwdlike = 1;       /* read #2 reverse */
+        else fwdlike = !(flag & 0x10);                    /* single end */
+        if(conv == 'C') return fwdlike ? 1 : 3;
+        return fwdlike ? 4 : 2;
+    }
+}
+
+/* --minConversionEfficiency (common.c:338-404).  `win` is the chunk window [woff, woff+wlen) of contig letters. */
+static int ctx_code(const char *seq, int64_t len, int64_t i) {   /* 0 none, 1 CpG, 2 CHG, 3 CHH (sign = direction not needed here) */
+    char c = seq[i] & 0x5f;
+    if(c == 'C') { if(i + 1 < len && (seq[i + 1] & 0x5f) == 'G') return 1; if(i + 2 < len && (seq[i + 2] & 0x5f) == 'G') return 2; return 3; }
+    if(c == 'G') { if(i > 0 && (seq[i - 1] & 0x5f) == 'C') return 1; if(i > 1 && (seq[i - 2] & 0x5f) == 'C') return 2; return 3; }
+    return 0;
+}
+static float conv_efficiency(const mdk_rec *r, int strand, int min_phred, const char *win, int64_t woff, int64_t wlen) {
+    unsigned nm = 0, nu = 0; int64_t pos = r->pos; int q = 0, k;
+    for(k = 0; k < r->n_cigar; k++) {
+        uint32_t c = rd_u32(r->cigar + 4 * k); int op = c & 15, len = (int)(c >> 4), j;
+        if(cigar_is_match(op)) {
+            for(j = 0; j < len; j++, q++) {
+                int64_t wi = pos + j - woff; int ctx, b;
+                if(pos + j >= woff + wlen) goto done;
+                if(wi < 0) continue;                 /* reference reads before its buffer here (UB) */
+                ctx = ctx_code(win, wlen, wi);
+                if(ctx < 2) continue;                /* CpG and non-C/G positions do not count */
+                if(strand == 0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
+                if(q >= r->l_qseq || r->qual[q] < min_phred) continue;
+                b = (r->seq[q >> 1] >> ((~q & 1) << 2)) & 15;
+                if(strand & 1) { if(b == 2) nm++; else if(b == 8) nu++; }
+                else { if(b == 4) nm++; else if(b == 1) nu++; }
+            }
+            /* NB the reference never advances `pos` after an M run (common.c:373-391); keep that */
+        } else if(op == 1 || op == 4) q += len;
+        else if(op == 2 || op == 3) pos += len;
+    }
+done:
+    if(nm + nu == 0) return 1.0f;
+    return nu / ((float)(nm + nu));
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* batch building                                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+static int bb_reserve(batchbuf *b, size_t more_reads, size_t more_blob, size_t more_qn) {
+    if(b->n + more_reads > b->cap_reads) {
+        size_t nc = (b->n + more_reads) * 2 + 1024;
+        md_read_hdr *h = md_host_alloc(nc * sizeof(md_read_hdr)); int32_t *e = md_host_alloc(nc * 4), *m = md_host_alloc(nc * 4);
+        if(!h || !e || !m) return -1;
+        if(b->n) { memcpy(h, b->hdr, b->n * sizeof(md_read_hdr)); memcpy(e, b->rend, b->n * 4); memcpy(m, b->mate, b->n * 4); }
+        md_host_free(b->hdr); md_host_free(b->rend); md_host_free(b->mate);
+        b->hdr = h; b->rend = e; b->mate = m; b->cap_reads = nc;
+    }
+    if(b->blob_len + more_blob > b->cap_blob) {
+        size_t nc = (b->blob_len + more_blob) * 2 + (1 << 20); uint8_t *d = md_host_alloc(nc);
+        if(!d) return -1;
+        if(b->blob_len) memcpy(d, b->blob, b->blob_len);
+        md_host_free(b->blob); b->blob = d; b->cap_blob = nc;
+    }
+    if(b->qn_len + more_qn > b->qn_cap) { b->qn_cap = (b->qn_len + more_qn) * 2 + 65536; b->qn = realloc(b->qn, b->qn_cap); if(!b->qn) return -1; }
+    if(b->n + more_reads > b->qn_off_cap) { b->qn_off_cap = (b->n + more_reads) * 2 + 1024; b->qn_off = realloc(b->qn_off, b->qn_off_cap * 4); if(!b->qn_off) return -1; }
+    return 0;
+}
+
+static uint64_t hash_str(const char *s) { uint64_t h = 0xcbf29ce484222325ULL; for(; *s; s++) h = (h ^ (uint8_t)*s) * 0x100000001b3ULL; return h ? h : 1; }
+
+/* The qname bookkeeping htslib's pileup does through the constructor/destructor callbacks
+ * (overlaps.c:121-147), evaluated lazily per qname.  A buffered read whose end precedes the position of the
+ * most recently pulled read has been swept out of the pileup buffer, and its destructor erased the qname key. */
+static qent *qt_get(mdk_plan *p, const batchbuf *b, uint32_t qoff) {
+    const char *name = b->qn + qoff; uint64_t h = hash_str(name); size_t mask = p->qt_cap - 1, i = (size_t)h & mask;
+    for(;; i = (i + 1) & mask) {
+        qent *e = &p->qt[i];
+        if(!e->used) { e->used = 1; e->h = h; e->qoff = qoff; e->pending = -1; e->nlive = 0; e->nmore = 0; return e; }
+        if(e->h == h && !strcmp(b->qn + e->qoff, name)) return e;
+    }
+}
+static void qt_prepare(mdk_plan *p, size_t expect) {
+    size_t want = 1024, i;
+    while(want < expect * 2 + 16) want <<= 1;
+    if(want > p->qt_cap) { if(p->qt) for(i = 0; i < p->qt_cap; i++) free(p->qt[i].more); free(p->qt); p->qt = calloc(want, sizeof(qent)); p->qt_cap = want; }
+    else for(i = 0; i < p->qt_cap; i++) { p->qt[i].used = 0; }
+}
+static void pair_reads(mdk_plan *p, batchbuf *b, const uint16_t *bamflag, int32_t tid) {
+    size_t i, n = b->n; int32_t prev_pos = 0; int first = 1;
+    qt_prepare(p, n);
+    for(i = 0; i < n; i++) {
+        int32_t pos = b->hdr[i].pos, end = b->rend[i]; int inserted; qent *e; int k, w, evicted = 0;
+        b->mate[i] = -1;
+        /* bam_plp_push: a read enters the buffer iff its end lies beyond the column about to be emitted */
+        if(first) inserted = (tid > 0) || (end > 0); else inserted = end > prev_pos;
+        if(inserted) {
+            e = qt_get(p, b, b->qn_off[i]);
+            for(k = 0, w = 0; k < e->nlive; k++) { if(!first && e->live[k] < prev_pos) evicted = 1; else e->live[w++] = e->live[k]; }
+            e->nlive = w;
+            for(k = 0, w = 0; k < e->nmore; k++) { if(!first && e->more[k] < prev_pos) evicted = 1; else e->more[w++] = e->more[k]; }
+            e->nmore = w;
+            if(evicted) e->pending = -1;
+            if((bamflag[i] & 0x1) && !(bamflag[i] & 12)) {
+                if(e->pending < 0) e->pending = (int32_t)i;
+                else { int32_t a = e->pending; b->mate[a] = (int32_t)i; b->mate[i] = a; b->hdr[i].flags |= MDK_RF_SECOND; e->pending = -1; }
+            }
+            if(e->nlive < 4) e->live[e->nlive++] = end;
+            else { if(e->nmore == e->capmore) { e->capmore = e->capmore ? e->capmore * 2 : 8; e->more = realloc(e->more, sizeof(int32_t) * e->capmore); } e->more[e->nmore++] = end; }
+        }
+        prev_pos = pos; first = 0;
+    }
+}
+
+
+/* admission (filter_func, common.c:416-444) + packing of one candidate record; returns 1 if admitted */
+static int admit_and_pack(mdk_plan *p, batchbuf *b, int which, const mdk_rec *r, int32_t rlen, const char *win, int64_t woff, int64_t wlen) {
+    const opts_t *o = &p->o; const uint8_t *nh, *xg; int strand; size_t seqb, seqpad, qualpad, need; uint8_t *d; md_read_hdr *h;
+    if(r->tid == -1 || (r->flag & 0x4)) return 0;
+    if(r->mapq < o->min_mapq) return 0;
+    if(r->flag & o->ignore_flags) return 0;
+    if(o->require_flags && (r->flag & o->require_flags) != o->require_flags) return 0;
+    if(!o->keep_dupes && (r->flag & 0x400)) return 0;
+    scan_aux(r, &nh, &xg);
+    if(!o->ignore_nh && nh) { int v = (int)aux_int(nh); if(v > 1) return 0; }
+    if(p->map_on) {
+        int c = p->map_of_tid[r->tid], l = r->l_qseq; int64_t s1, s2;
+        if((r->flag & 0x40) || ((r->flag & 0x10) && (r->flag & 0x80))) { s1 = r->pos; s2 = r->mpos; } else { s2 = r->pos; s1 = r->mpos; }
+        if(!map_window_passes(p, c, s1, l) && !map_window_passes(p, c, s2, l)) return 0;
+    }
+    if(!o->keep_singleton && (r->flag & 0x9) == 0x9) return 0;
+    if(!o->keep_discordant && (r->flag & 0x3) == 0x1) return 0;
+    strand = strand_of(r->flag, xg);
+    if(o->min_conv_eff > 0.0) { if(conv_efficiency(r, strand, o->min_phred, win, woff, wlen) < o->min_conv_eff) return 0; }
+
+    seqb = ((size_t)r->l_qseq + 1) / 2; seqpad = (seqb + 3) & ~(size_t)3; qualpad = ((size_t)r->l_qseq + 3) & ~(size_t)3;
+    need = 4u * r->n_cigar + seqpad + qualpad;
+    if(bb_reserve(b, 1, need, (size_t)r->l_qname + 1)) return -1;
+    if(b->n + 1 > p->bflag_cap[which]) { p->bflag_cap[which] = (b->n + 1) * 2 + 1024; p->bflag[which] = realloc(p->bflag[which], p->bflag_cap[which] * 2); }
+    h = &b->hdr[b->n];
+    h->pos = r->pos; h->off4 = (uint32_t)(b->blob_len >> 2); h->l_qseq = (uint32_t)r->l_qseq; h->n_cigar = r->n_cigar;
+    h->strand = (uint8_t)strand; h->flags = (r->flag & 0x80) ? MDK_RF_READ2 : 0;
+    b->rend[b->n] = r->pos + rlen; b->mate[b->n] = -1; p->bflag[which][b->n] = r->flag;
+    d = b->blob + b->blob_len;
+    memcpy(d, r->cigar, 4u * r->n_cigar); d += 4u * r->n_cigar;
+    memcpy(d, r->seq, seqb); memset(d + seqb, 0, seqpad - seqb); d += seqpad;
+    memcpy(d, r->qual, (size_t)r->l_qseq); memset(d + r->l_qseq, 0, qualpad - (size_t)r->l_qseq);
+    b->blob_len += need;
+    b->qn_off[b->n] = (uint32_t)b->qn_len; memcpy(b->qn + b->qn_len, r->qname, r->l_qname); b->qn[b->qn_len + r->l_qname] = 0; b->qn_len += (size_t)r->l_qname + 1;
+    b->n++;
+    return 1;
+}
+
+static int carry_push(uint8_t **buf, size_t *len, size_t *cap, const mdk_rec *r) {
+    size_t need = *len + 4 + r->raw_len;
+    if(need > *cap) { *cap = need * 2 + 65536; *buf = realloc(*buf, *cap); if(!*buf) return -1; }
+    memcpy(*buf + *len, &r->raw_len, 4); memcpy(*buf + *len + 4, r->raw, r->raw_len); *len = need;
+    return 0;
+}
+
+/* the end of a chunk may not split a CpG / CHG (adjustBounds, common.c:466-493) */
+static uint32_t adjust_end(const mdk_plan *p, uint32_t tid, uint32_t end) {
+    int fi = p->fa_of_tid[tid]; int64_t L, s, e, n; const char *q;
+    if(fi < 0) return end;
+    L = p->fa.len[fi]; s = end > 0 ? (int64_t)end - 1 : 0; e = (int64_t)end + 1;      /* inclusive window [s,e], clamped */
+    if(s >= L) return end;
+    if(e >= L) e = L - 1;
+    n = e - s + 1; q = p->fa.seq[fi] + s;
+    if(n > 1) {
+        if(n > 2 && (q[0] & 0x5f) == 'C' && (q[2] & 0x5f) == 'G') return end + 2;
+        if((q[1] & 0x5f) == 'G') return end + 1;
+    }
+    return end;
+}
+
+int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
+    const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; batchbuf *b; int which, rc, fi; mdk_rec r;
+    const char *win = NULL; int64_t woff = 0, wlen = 0; size_t off;
+    memset(c, 0, sizeof(*c));
+    /* extract.c:325-350 */
+    c->index = p->bin++;
+    tid = p->g_tid; beg = p->g_pos; end = (uint32_t)(beg + o->chunk_size);
+    if(tid >= (uint32_t)bam->n_targets) return 0;
+    if(p->g_end && end > p->g_end) end = p->g_end;
+    end = adjust_end(p, tid, end);
+    if(beg > end) { tmp = beg; beg = end; end = tmp; }
+    p->g_pos = end;
+    if(p->g_end > 0 && p->g_pos >= p->g_end) p->g_tid = (uint32_t)-1;
+    if(p->g_tid != (uint32_t)-1 && p->g_pos >= bam->target_len[tid]) { end = bam->target_len[tid]; p->g_tid++; p->g_pos = 0; }
+    if(p->g_end && beg >= p->g_end) return 0;
+    c->tid = (int32_t)tid; c->beg = beg; c->end = end;
+    which = p->cur_bb; p->cur_bb ^= 1; b = &p->bb[which];
+    b->n = 0; b->blob_len = 0; b->qn_len = 0;
+    fi = p->fa_of_tid[tid];
+    if(fi < 0) {
+        fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", -2, bam->target_name[tid], beg > 1 ? beg - 2 : 0, end);
+        fprintf(stderr, "Note that the output will be truncated!\n");
+        c->skipped = 1;
+    } else {
+        woff = beg > 1 ? (int64_t)beg - 2 : 0; wlen = (int64_t)end + 10 + 1; if(wlen > p->fa.len[fi]) wlen = p->fa.len[fi]; wlen -= woff; if(wlen < 0) wlen = 0;
+        win = p->fa.seq[fi] + woff;
+    }
+    /* reads of this chunk, file order: straddlers carried over from the previous chunk, then the stream */
+    p->carry2_len = 0;
+    if(p->carry_tid == (int32_t)tid) {
+        for(off = 0; off < p->carry_len;) {
+            uint32_t len; int32_t rlen, endp;
+            memcpy(&len, p->carry + off, 4);
+            if(mdk_rec_parse(p->carry + off + 4, len, &r) != 0) return -2;
+            off += 4 + (size_t)len;
+            rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
+            c->n_records_seen++;
+            if(endp > (int32_t)beg && r.pos < (int32_t)end && !c->skipped) { if(admit_and_pack(p, b, which, &r, rlen, win, woff, wlen) < 0) return -5; }
+            if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
+        }
+    }
+    while((rc = mdk_bam_peek(bam, &r)) == 1) {
+        int32_t rlen, endp;
+        if(r.tid >= 0) {
+            if(r.tid < p->last_tid || (r.tid == p->last_tid && r.pos < p->last_pos)) { fprintf(stderr, "[mdk] %s is not coordinate sorted; `extract` needs sorted alignments\n", o->bam_name); return -2; }
+            if(r.tid > (int32_t)tid) break;
+            if(r.tid == (int32_t)tid && r.pos >= (int32_t)end) break;
+            p->last_tid = r.tid; p->last_pos = r.pos;
+        }
+        if(r.tid == (int32_t)tid) {
+            rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
+            c->n_records_seen++;
+            if(endp > (int32_t)beg && !c->skipped) { if(admit_and_pack(p, b, which, &r, rlen, win, woff, wlen) < 0) return -5; }
+            if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
+        }
+        mdk_bam_advance(bam, &r);
+    }
+    if(rc < 0) { fprintf(stderr, "[mdk] error while reading %s: %s\n", o->bam_name, bam->err); return -2; }
+    { uint8_t *t = p->carry; size_t tc = p->carry_cap; p->carry = p->carry2; p->carry_len = p->carry2_len; p->carry_cap = p->carry2_cap; p->carry2 = t; p->carry2_cap = tc; p->carry2_len = 0; p->carry_tid = (int32_t)tid; }
+    if(bb_reserve(b, 1, 16, 16)) return -5;          /* never hand out NULL arrays */
+    pair_reads(p, b, p->bflag[which], (int32_t)tid);
+    c->batch.tid = (int32_t)tid; c->batch.beg = beg; c->batch.end = end; c->batch.n_reads = (int32_t)b->n;
+    c->batch.hdr = b->hdr; c->batch.rend = b->rend; c->batch.mate = b->mate; c->batch.blob = b->blob; c->batch.blob_bytes = b->blob_len;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* text post-pass (extract.c:443-510 driving writeCall/processLast, extract.c:39-99,207-222)          */
+/* ------------------------------------------------------------------------------------------------ */
+static void put_site(mdk_plan *p, sbuf *dst, const char *chrom, int32_t pos, int width, uint32_t m, uint32_t u, int ref_is_c, const char *cctx, const char *tri) {
+    const opts_t *o = &p->o; char line[1024]; int n; uint32_t cov = m + u;
+    if(cov < (uint32_t)o->min_depth && !o->cytosine_report) return;
+    if(o->fraction) n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%f\n", chrom, pos, pos + width, ((double)m) / cov);
+    else if(o->counts) n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%i\n", chrom, pos, pos + width, cov);
+    else if(o->logit) { double f = ((double)m) / cov; n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%f\n", chrom, pos, pos + width, log(f) - log(1 - f)); }
+    else if(o->methylkit) n = snprintf(line, sizeof(line), "%s.%i\t%s\t%i\t%c\t%i\t%6.2f\t%6.2f\n", chrom, pos + 1, chrom, pos + 1, ref_is_c ? 'F' : 'R', cov, 100.0 * ((double)m) / cov, 100.0 * ((double)u) / cov);
+    else if(o->cytosine_report) n = snprintf(line, sizeof(line), "%s\t%i\t%c\t%" PRIu32 "\t%" PRIu32 "\tC%s\t%s\n", chrom, pos + 1, ref_is_c ? '+' : '-', m, u, cctx, tri);
+    else n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%i\t%" PRIu32 "\t%" PRIu32 "\n", chrom, pos, pos + width, (int)(100.0 * ((double)m) / cov), m, u);
+    if(n > 0) sb_put(dst, line, (size_t)n < sizeof(line) ? (size_t)n : sizeof(line) - 1);
+}
+
+/* trinucleotide context string of a C (direction +1) or G (direction -1) at contig index i (extract.c:120-180) */
+static const char *trinuc(const char *seq, int64_t len, int64_t i, int dir, char out[4]) {
+    static const char comp[256] = {['A'] = 'T', ['a'] = 'T', ['C'] = 'G', ['c'] = 'G', ['G'] = 'C', ['g'] = 'C', ['T'] = 'A', ['t'] = 'A'};
+    int k;
+    out[0] = 'C'; out[3] = 0;
+    for(k = 1; k <= 2; k++) {
+        int64_t j = i + (int64_t)k * dir; char ch = 'N';
+        if(j >= 0 && j < len) { ch = seq[j]; if(dir < 0) ch = comp[(uint8_t)ch] ? comp[(uint8_t)ch] : 'N'; else { ch &= 0x5f; if(ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ch = 'N'; } }
+        out[k] = ch;
+    }
+    return out;
+}
+static const char *cctx_name(int type) { return type == 0 ? "G" : type == 1 ? "HG" : "HH"; }
+
+/* zero-coverage rows of --cytosine_report between *from and upto (extract.c:182-205) */
+static void put_blanks(mdk_plan *p, const char *chrom, const char *seq, int64_t len, int64_t *from, int64_t upto) {
+    char tri[4];
+    for(; *from < upto; (*from)++) {
+        int code; int dir, type;
+        if(*from >= len) continue;
+        code = ctx_code(seq, len, *from);
+        if(!code) continue;
+        type = code - 1;
+        if(!p->o.ctx_on[type]) continue;
+        dir = ((seq[*from] & 0x5f) == 'C') ? 1 : -1;
+        put_site(p, &p->ob[0], chrom, (int32_t)*from, 1, 0, 0, dir > 0, cctx_name(type), trinuc(seq, len, *from, dir, tri));
+    }
+}
+
+int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
+    const opts_t *o = &p->o; const char *chrom; int64_t i; int fi; const char *seq = NULL; int64_t slen = 0, blank_from;
+    int k; char tri[4];
+    if(c->index != p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
+    p->next_emit++;
+    if(c->skipped) return 0;
+    chrom = p->bam->target_name[c->tid];
+    fi = p->fa_of_tid[c->tid]; if(fi >= 0) { seq = p->fa.seq[fi]; slen = p->fa.len[fi]; }
+    blank_from = c->beg;
+    for(i = 0; i < s->n_sites; i++) {
+        int32_t pos = (int32_t)s->pos[i]; uint32_t m = s->nmeth[i], u = s->nunmeth[i]; int type = s->meta[i] >> 1, is_g = s->meta[i] & 1;
+        if(o->min_opp_depth > 0 && s->noff) {
+            uint32_t noff = s->noff[i], nvar = s->nvar[i];
+            if(noff >= (uint32_t)o->min_opp_depth && ((double)nvar) / ((double)noff) >= o->max_variant_frac) {
+                p->n_variant_positions++;
+                if(o->merge && is_g) {
+                    if(type == 0 && p->lastcpg_tid == c->tid && p->lastcpg_pos == pos - 1) { p->lastcpg_m = 0; p->lastcpg_u = 0; }
+                    else if(type == 1 && p->lastchg_tid == c->tid && p->lastchg_pos == pos - 2) { p->lastchg_m = 0; p->lastchg_u = 0; }
+                }
+                continue;
+            }
+        }
+        if(m + u == 0 && !o->cytosine_report) continue;
+        if(!o->merge || type == 2) {
+            if(o->cytosine_report) {
+                put_blanks(p, chrom, seq, slen, &blank_from, pos);
+                put_site(p, &p->ob[0], chrom, pos, 1, m, u, !is_g, cctx_name(type), trinuc(seq, slen, pos, is_g ? -1 : 1, tri));
+                blank_from = (int64_t)pos + 1;
+            } else put_site(p, &p->ob[type], chrom, pos, 1, m, u, !is_g, NULL, NULL);
+        } else if(type == 0) {
+            int32_t key = is_g ? pos - 1 : pos;
+            if(p->lastcpg_tid == c->tid && p->lastcpg_pos == key) { put_site(p, &p->ob[0], chrom, key, 2, m + p->lastcpg_m, u + p->lastcpg_u, !is_g, NULL, NULL); p->lastcpg_tid = -1; }
+            else {
+                if(p->lastcpg_tid != -1) put_site(p, &p->ob[0], p->bam->target_name[p->lastcpg_tid], p->lastcpg_pos, 2, p->lastcpg_m, p->lastcpg_u, !is_g, NULL, NULL);
+                p->lastcpg_tid = c->tid; p->lastcpg_pos = key; p->lastcpg_m = m; p->lastcpg_u = u;
+            }
+        } else {
+            int32_t key = is_g ? pos - 2 : pos;
+            if(p->lastchg_tid == c->tid && p->lastchg_pos == key) { put_site(p, &p->ob[1], chrom, key, 3, m + p->lastchg_m, u + p->lastchg_u, !is_g, NULL, NULL); p->lastchg_tid = -1; }
+            else {
+                if(p->lastchg_tid != -1) put_site(p, &p->ob[1], p->bam->target_name[p->lastchg_tid], p->lastchg_pos, 3, p->lastchg_m, p->lastchg_u, !is_g, NULL, NULL);
+                p->lastchg_tid = c->tid; p->lastchg_pos = key; p->lastchg_m = m; p->lastchg_u = u;
+            }
+        }
+    }
+    if(o->merge) {      /* pending sites never cross a chunk boundary (extract.c:496-507) */
+        if(o->ctx_on[0] && p->lastcpg_tid != -1) { put_site(p, &p->ob[0], p->bam->target_name[p->lastcpg_tid], p->lastcpg_pos, 2, p->lastcpg_m, p->lastcpg_u, 1, NULL, NULL); p->lastcpg_tid = -1; }
+        if(o->ctx_on[1] && p->lastchg_tid != -1) { put_site(p, &p->ob[1], p->bam->target_name[p->lastchg_tid], p->lastchg_pos, 3, p->lastchg_m, p->lastchg_u, 1, NULL, NULL); p->lastchg_tid = -1; }
+    } else if(o->cytosine_report) put_blanks(p, chrom, seq, slen, &blank_from, c->end);
+    if(o->cytosine_report) { if(p->ob[0].l) { fputs(p->ob[0].s, p->out[0]); p->ob[0].l = 0; } }
+    else for(k = 0; k < 3; k++) if(o->ctx_on[k] && p->ob[k].l) { fputs(p->ob[k].s, p->out[k]); p->ob[k].l = 0; }
+    return 0;
+}
+
+int mdk_plan_finish(mdk_plan *p) {
+    int i;
+    if(p->n_variant_positions) printf("%" PRIu64 " positions were excluded due to likely being variants.\n", p->n_variant_positions);
+    if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); p->out[0] = p->out[1] = p->out[2] = NULL; }
+    else for(i = 0; i < 3; i++) if(p->out[i]) { fclose(p->out[i]); p->out[i] = NULL; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* the drop-in entry point                                                                           */
+/* ------------------------------------------------------------------------------------------------ */
+int extract_main(int argc, char *argv[]) {
+    mdk_plan *p = NULL; md_dev *dev = NULL; md_dev_cfg cfg; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1, device = 0;
+    rc = mdk_plan_open(argc, argv, &p);
+    if(rc != 0 || !p) return rc;
+    mdk_plan_dev_cfg(p, &cfg);
+    if(getenv("MDK_DEVICE")) device = atoi(getenv("MDK_DEVICE"));
+    rc = md_dev_open(device, &cfg, &dev);
+    if(rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then emit k-1 */
+    while(more || have[0] || have[1]) {
+        int cur = k & 1, prev = cur ^ 1;
+        if(more) {
+            rc = mdk_plan_next_chunk(p, &ch[cur]);
+            if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
+            if(rc == 0) more = 0;
+            else {
+                if(!ch[cur].skipped) {
+                    rc = mdk_plan_ensure_reference(p, dev, ch[cur].tid);
+                    if(!rc) rc = md_dev_submit(dev, cur, &ch[cur].batch);
+                    if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+                }
+                have[cur] = 1;
+            }
+        }
+        if(have[prev]) {
+            md_sites sites; memset(&sites, 0, sizeof(sites));
+            if(!ch[prev].skipped) {
+                rc = md_dev_download(dev, prev, &sites);
+                if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
+                if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+            }
+            if(mdk_plan_emit(p, &ch[prev], &sites)) { ret = MDK_RC_DEVICE; break; }
+            have[prev] = 0;
+        }
+        k++;
+        if(!more && !have[0] && !have[1]) break;
+    }
+    if(ret == 0) mdk_plan_finish(p);
+    md_dev_close(dev);
+    mdk_plan_close(p);
+    return ret;
+}

@@ -1,0 +1,58 @@
+"""Shared test plumbing.  GPU tests are marked `gpu`; everything else runs on a CPU-only box."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+GOLDEN = REPO / "tests" / "golden"
+ORACLE = REPO / "oracle" / "_build" / "mdk_oracle"
+SYNTH = REPO / "tools" / "_build" / "mdk_synth"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    """Everything is built in-tree by `make` (the GPU box receives the prebuilt .so files; make is then a no-op)."""
+    r = subprocess.run(["make", "-C", str(REPO), "all"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return True
+
+
+def run_oracle(args, cwd, dump=None):
+    env = dict(os.environ)
+    if dump:
+        env["MDK_ORACLE_DUMP"] = str(dump)
+    return subprocess.run([str(ORACLE), "extract"] + [str(a) for a in args], cwd=cwd, env=env, capture_output=True, text=True)
+
+
+def synth(prefix, *args):
+    r = subprocess.run([str(SYNTH), "-o", str(prefix)] + [str(a) for a in args], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def read_dump(path):
+    """MDK_ORACLE_DUMP rows -> {(tid,pos): (type,isG,nmeth,nunmeth,noff,nvar)}"""
+    d = {}
+    for line in open(path):
+        t = [int(x) for x in line.split()]
+        d[(t[0], t[1])] = tuple(t[2:])
+    return d
+
+
+@pytest.fixture(scope="session")
+def small_synth(tmp_path_factory):
+    """A 60 kb, 2-contig, 25x noisy paired-end sample + a Bismark-style one, shared by several tests."""
+    d = tmp_path_factory.mktemp("synth")
+    synth(d / "pe", "-L", "40000,20000", "-c", "25", "-s", "11", "--extras", "--bbm")
+    synth(d / "bis", "-L", "30000", "-c", "20", "-s", "12", "--bismark")
+    synth(d / "se", "-L", "20000", "-c", "15", "-s", "13", "--single")
+    return d

@@ -1,0 +1,133 @@
+"""CPU-only checks of the product's HOST side (csrc/host): chunk schedule, admission, strand, qname pairing and
+SoA packing.  The packed batches are evaluated by the slow test-only evaluator (tests/batch_eval.py) and must equal
+the oracle's per-column counters exactly.  No device work happens here."""
+import ctypes as C
+
+import pytest
+
+import methyldackel_amd as mdk
+from batch_eval import eval_batch
+from conftest import GOLDEN, read_dump, run_oracle
+
+
+def host_counts(args):
+    plan = mdk.Plan(args)
+    cfg = plan.dev_cfg()
+    out = {}
+    chunks = []
+    refs = {}
+    while True:
+        c = plan.next_chunk()
+        if c is None:
+            break
+        chunks.append((c.index, c.tid, c.beg, c.end, c.batch.n_reads))
+        if c.skipped:
+            continue
+        name = plan.target_name(c.tid)
+        if name not in refs:
+            refs[name] = read_fasta(args)[name]
+        for p, v in eval_batch(c.batch, refs[name], cfg).items():
+            assert (c.tid, p) not in out
+            out[(c.tid, p)] = v
+    plan.close()
+    return out, chunks
+
+
+_fa_cache = {}
+
+
+def read_fasta(args):
+    fa = [a for a in map(str, args) if a.endswith(".fa")][0]
+    if fa not in _fa_cache:
+        d, name = {}, None
+        for line in open(fa, "rb"):
+            if line.startswith(b">"):
+                name = line[1:].split()[0].decode()
+                d[name] = bytearray()
+            else:
+                d[name] += line.strip()
+        _fa_cache[fa] = {k: bytes(v) for k, v in d.items()}
+    return _fa_cache[fa]
+
+
+def check(tmp_path, args, variant=False):
+    dump = tmp_path / "dump.tsv"
+    r = run_oracle(list(args) + ["-o", tmp_path / "o"], cwd=tmp_path, dump=dump)
+    assert r.returncode == 0, r.stderr
+    want = read_dump(dump)
+    if not variant:
+        want = {k: v[:4] + (0, 0) for k, v in want.items() if v[2] + v[3] > 0}
+    got, chunks = host_counts(list(args) + ["-o", tmp_path / "g"])
+    assert got == want
+    return chunks
+
+
+FIX = [
+    ["cg100.fa", "cg_aln.bam", "-q", "2"],
+    ["cg100.fa", "cg_aln.bam", "-q", "2", "--CHG", "--CHH"],
+    ["cg100.fa", "cg_aln.bam", "-q", "2", "--ignoreFlags", "0xD00"],
+    ["cg100.fa", "cg_aln.bam", "-q", "2", "--nOT", "50,50,40,40"],
+    ["cg100.fa", "cg_aln.bam", "-q", "2", "--OT", "10,90,20,80"],
+    ["cg100.fa", "NH.bam", "-q", "1"],
+    ["cg100.fa", "NH.bam", "-q", "1", "--ignoreNH"],
+    ["chgchh.fa", "chgchh_aln.bam", "-q", "5", "--CHG", "--CHH"],
+    ["chgchh.fa", "chgchh_aln.bam", "-q", "5", "--minConversionEfficiency", "0.9"],
+    ["ct100.fa", "ct_aln.bam", "-q", "2", "--CHH"],
+]
+
+
+@pytest.mark.parametrize("args", FIX, ids=[" ".join(a[1:]) for a in FIX])
+def test_fixture_batches(tmp_path, args):
+    args = [str(GOLDEN / a) if (a.endswith(".fa") or a.endswith(".bam")) else a for a in args]
+    check(tmp_path, args)
+
+
+def test_fixture_variant_counters(tmp_path):
+    args = [str(GOLDEN / "cg100.fa"), str(GOLDEN / "cg_with_variants.bam"), "-p", "1", "-q", "0", "--minOppositeDepth", "3", "--maxVariantFrac", "0.25"]
+    check(tmp_path, args, variant=True)
+
+
+SYN = [
+    ("pe", []),
+    ("pe", ["--CHG", "--CHH", "--chunkSize", "7000"]),
+    ("pe", ["--chunkSize", "100", "-r", "chrS1:5000-9000"]),
+    ("pe", ["-F", "0", "--keepDupes", "--keepSingleton", "--keepDiscordant", "--ignoreNH", "-q", "0", "--chunkSize", "3001"]),
+    ("pe", ["--OT", "6,146,6,146", "--OB", "6,146,6,146", "--nOT", "2,3,4,5", "--CHH"]),
+    ("pe", ["-B", "BBM", "--chunkSize", "9999"]),
+    ("pe", ["-B", "BBM", "-b", "140", "-t", "0.6"]),
+    ("bis", ["--CHG"]),
+    ("bis", ["--CTOT", "5,100,5,100", "--nCTOB", "3,3,3,3", "--CHH", "--chunkSize", "5000"]),
+    ("se", ["--CHG", "--CHH"]),
+]
+
+
+@pytest.mark.parametrize("which,extra", SYN, ids=[f"{w}:{' '.join(e)}" for w, e in SYN])
+def test_synthetic_batches(tmp_path, small_synth, which, extra):
+    extra = [str(small_synth / "pe.bbm") if e == "BBM" else e for e in extra]
+    args = [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")] + extra
+    variant = False
+    check(tmp_path, args, variant)
+
+
+def test_synthetic_variant_mode(tmp_path, small_synth):
+    args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--minOppositeDepth", "2", "--maxVariantFrac", "0.5", "--CHG", "--chunkSize", "8000"]
+    check(tmp_path, args, variant=True)
+
+
+def test_chunk_schedule_matches_reference_rules(tmp_path, small_synth):
+    """chunk ends never split a CpG/CHG (adjustBounds) and chunks tile each contig exactly"""
+    args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--chunkSize", "1000", "-o", str(tmp_path / "x")]
+    _, chunks = host_counts(args)
+    ref = read_fasta(args)
+    by_tid = {}
+    for idx, tid, beg, end, n in chunks:
+        by_tid.setdefault(tid, []).append((beg, end))
+    assert [c[0] for c in chunks] == list(range(len(chunks)))
+    names = ["chrS1", "chrS2"]
+    for tid, iv in by_tid.items():
+        seq = ref[names[tid]].upper()
+        assert iv[0][0] == 0 and iv[-1][1] == len(seq)
+        for (b0, e0), (b1, e1) in zip(iv, iv[1:]):
+            assert e0 == b1
+            assert not (seq[e0 - 1:e0] == b"C" and seq[e0:e0 + 1] == b"G"), "CpG split across chunks"
+            assert not (seq[e0 - 2:e0 - 1] == b"C" and seq[e0:e0 + 1] == b"G"), "CHG split across chunks"
