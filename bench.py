@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X `MethylDackel extract` hot path.
+
+Metric (BASELINE.json): CpG calls/s on the synthetic 1 Mb contig, 30x paired-end WGBS BAM (configs[1], "S1"),
+CpG-only extract.  One "step" = one pass of the device path (pileup + scan + gather kernels) over the admitted reads
+of one S1 interval, inputs already resident in HBM.  With N ranks every rank owns its own S1 interval (weak scaling:
+independent intervals, as the path shards by contig/interval) and, after each step, the per-interval site buffers are
+gathered to rank 0 over RCCL -- the one real exchange step of the path.
+
+Also reported on the same JSON line:
+  roofline     -- pileup kernel: algorithmic bytes (SURVEY.md 8d formula) / HIP-event kernel time vs 8 TB/s HBM
+  cpu_baseline -- the CPU oracle (`oracle/`, single thread, "port") timed on the same S1 BAM on this box's host
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import subprocess
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+S1_SEED = 0x5EED0001
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--length", type=int, default=1_000_000, help="interval length per rank (S1 = 1 Mb)")
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--extra", default="", help="extra extract options, e.g. '--CHG --CHH' (not the headline config)")
+    ap.add_argument("--cpu-runs", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"[bench] WORLD_SIZE={world} overrides --gpus {args.gpus}")
+    n_gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import methyldackel_amd as mdk
+    if rank == 0:
+        mdk.build()
+    if world > 1:
+        dist.barrier()
+
+    work = Path(tempfile.mkdtemp(prefix=f"mdk_bench_r{rank}_"))
+    prefix = work / "S1"
+    synth = subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(prefix), "-L", str(args.length), "-c", str(args.coverage),
+                            "-s", str(S1_SEED + rank)], capture_output=True, text=True, check=True)
+    synth_info = json.loads(synth.stdout)
+    extra = args.extra.split()
+    cmd = [str(prefix) + ".fa", str(prefix) + ".bam", "--chunkSize", str(args.length)] + extra + ["-o", str(work / "gpu")]
+
+    # host side: decode + admit + pack the interval once; it then stays resident in HBM
+    t0 = time.time()
+    plan = mdk.Plan(cmd)
+    cfg = plan.dev_cfg()
+    chunk = plan.next_chunk()
+    t_host = time.time() - t0
+    assert chunk is not None and not chunk.skipped
+    dev = mdk.Device(cfg, device=local_rank)
+    plan.ensure_reference(dev, chunk.tid)
+    dev.upload(0, chunk.batch)
+    dev.launch(0)
+    sites = dev.download(0)
+    n_sites = sites.n_sites
+    cpg_calls = 0
+    all_calls = 0
+    for i in range(n_sites):
+        c = sites.nmeth[i] + sites.nunmeth[i]
+        all_calls += c
+        if (sites.meta[i] >> 1) == 0:
+            cpg_calls += c
+    variant = cfg.minOppositeDepth > 0
+
+    cap = int(n_sites) + 1024
+    t_cnt = torch.empty((5, cap), dtype=torch.int32, device="cuda")
+    t_meta = torch.empty((cap,), dtype=torch.uint8, device="cuda")
+    ptr = lambda row: C.c_void_p(t_cnt[row].data_ptr())
+    L = mdk.lib_hip()
+
+    if world > 1:
+        counts = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([cap], dtype=torch.int64, device="cuda"))
+        gcap = int(max(int(c.item()) for c in counts))
+        send = torch.zeros((5, gcap), dtype=torch.int32, device="cuda")
+        recv = [torch.empty((5, gcap), dtype=torch.int32, device="cuda") for _ in range(world)] if rank == 0 else None
+
+    def step():
+        dev.launch(0)
+        n = L.md_dev_sites_to_device(dev.h, 0, ptr(0), ptr(1), ptr(2), ptr(3) if variant else None, ptr(4) if variant else None,
+                                     C.c_void_p(t_meta.data_ptr()), cap)
+        if n < 0:
+            raise RuntimeError(f"md_dev_sites_to_device failed: {n} {L.md_dev_last_error().decode()}")
+        if world > 1:
+            send[:, :cap].copy_(t_cnt)
+            send[3, 0] = n                      # site count travels with the buffer
+            dist.gather(send, recv, dst=0)
+        return n
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        dev.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    assert n_last == n_sites
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([cpg_calls, all_calls, int(n_sites)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_cpg_calls, total_calls, total_sites = (int(x) for x in tot.tolist())
+    else:
+        total_cpg_calls, total_calls, total_sites = cpg_calls, all_calls, int(n_sites)
+
+    # kernel-level timing with HIP events on the launch stream, inside the library
+    br = dev.bench(0, 5, 50)
+    pile_s = br.ms_pileup / 1e3
+    achieved = br.algo_bytes / pile_s / 1e9 if pile_s > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        value = total_cpg_calls * args.steps / dt
+        result = {
+            "metric": "CpG calls/sec, synthetic 1 Mb contig 30x paired-end WGBS BAM, CpG extract",
+            "value": value, "unit": "CpG calls/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u32", "data": "synthetic",
+            "config": {"workload": "S1: synthetic 1 Mb contig, 30x PE 2x150 WGBS BAM, CpG-only extract (BASELINE.json configs[1])" if not extra and args.length == 1_000_000
+                       else f"synthetic {args.length} bp, {args.coverage}x, extract {' '.join(extra)}",
+                       "interval_bp": args.length, "coverage": args.coverage, "reads_admitted_per_gpu": int(chunk.batch.n_reads),
+                       "records_per_gpu": synth_info["records"], "sites_per_gpu": int(n_sites), "cpg_calls_per_gpu": int(cpg_calls),
+                       "tile": int(L.md_dev_tile(dev.h)), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup, "all_kernels_ms": br.ms_total},
+            "host_prep_s": t_host,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            oracle = REPO / "oracle/_build/mdk_oracle"
+            ocmd = [str(oracle), "extract", str(prefix) + ".fa", str(prefix) + ".bam", "--chunkSize", str(args.length)] + extra + ["-o", str(work / "cpu")]
+            times = []
+            t_all = time.time()
+            for _ in range(args.cpu_runs):
+                t1 = time.perf_counter()
+                subprocess.run(ocmd, check=True, capture_output=True)
+                times.append(time.perf_counter() - t1)
+                if time.time() - t_all > 30:
+                    break
+            med = statistics.median(times)
+            # end-to-end CLI of the product on the same file (includes HIP init, inflate, H2D, D2H, text)
+            t1 = time.perf_counter()
+            rg = mdk.run_cli(cmd[:-1] + [str(work / "cli")])
+            e2e = time.perf_counter() - t1
+            ident = (work / "cli_CpG.bedGraph").read_bytes().split(b"\n", 1)[1] == (work / "cpu_CpG.bedGraph").read_bytes().split(b"\n", 1)[1] if rg.returncode == 0 else False
+            result["cpu_baseline"] = {"value": cpg_calls / med, "unit": "CpG calls/s", "cores": 1, "kind": "port",
+                                      "sample": f"oracle/mdk_oracle extract (single-thread C restatement of the reference, incl. its own BAM inflate+parse) on the same S1 BAM, "
+                                                f"median of {len(times)} runs, {med:.3f} s per run; the reference binary itself cannot be built here (no htslib)",
+                                      "seconds_per_run": med}
+            result["e2e_cli"] = {"seconds": e2e, "identical_to_oracle": bool(ident), "note": "product CLI wall-clock on the same BAM incl. process start, HIP init, inflate, H2D, D2H, text"}
+        print(json.dumps(result), flush=True)
+    dev.close()
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

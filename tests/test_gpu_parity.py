@@ -1,0 +1,200 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C-ABI of the product:
+  * CLI level: `MethylDackel extract` (extract_main -> libmdk_hip.so kernels) must produce byte-identical output files
+    and stdout to the CPU oracle for the same command line;
+  * C-ABI level: md_dev_submit/md_dev_download sites == the oracle's per-column counters.
+Bar: bit-exact (integer counters, text formatted by the same libc)."""
+import ctypes as C
+import filecmp
+import os
+import subprocess
+
+import pytest
+
+import methyldackel_amd as mdk
+from conftest import GOLDEN, read_dump, run_oracle, synth
+
+pytestmark = pytest.mark.gpu
+
+SUFFIXES = ["_CpG.bedGraph", "_CHG.bedGraph", "_CHH.bedGraph", "_CpG.meth.bedGraph", "_CHG.meth.bedGraph", "_CHH.meth.bedGraph",
+            "_CpG.counts.bedGraph", "_CHG.counts.bedGraph", "_CHH.counts.bedGraph", "_CpG.logit.bedGraph", "_CHG.logit.bedGraph",
+            "_CHH.logit.bedGraph", "_CpG.methylKit", "_CHG.methylKit", "_CHH.methylKit", ".cytosine_report.txt"]
+
+
+def compare_cli(tmp_path, args, env=None):
+    """same command line through the oracle and the product; same prefix (in different dirs) so headers agree"""
+    od, gd = tmp_path / "oracle", tmp_path / "gpu"
+    od.mkdir(exist_ok=True), gd.mkdir(exist_ok=True)
+    ro = run_oracle(list(args) + ["-o", "out"], cwd=od)
+    rg = mdk.run_cli(list(args) + ["-o", "out"], cwd=gd, env=env)
+    assert rg.returncode == ro.returncode, (rg.returncode, ro.returncode, rg.stderr[-2000:])
+    assert rg.stdout == ro.stdout
+    seen = 0
+    for s in SUFFIXES:
+        fo, fg = od / ("out" + s), gd / ("out" + s)
+        assert fo.exists() == fg.exists(), s
+        if fo.exists():
+            seen += 1
+            assert filecmp.cmp(fo, fg, shallow=False), f"{s} differs:\n" + diff_head(fo, fg)
+    assert seen > 0
+    return od, gd
+
+
+def diff_head(a, b, n=10):
+    la, lb = open(a).read().splitlines(), open(b).read().splitlines()
+    out = [f"lines: oracle {len(la)} gpu {len(lb)}"]
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            out.append(f"{i}: oracle {x!r} gpu {y!r}")
+            if len(out) > n:
+                break
+    return "\n".join(out)
+
+
+def G(*names):
+    return [str(GOLDEN / n) for n in names]
+
+
+# the reference's own 15 command lines (tests/test.py) + the same fixtures under more of the option surface
+FIXTURE_CMDS = [
+    G("ct100.fa", "ct_aln.bam") + ["-q", "2"],
+    G("cg100.fa", "cg_aln.bam") + ["-q", "2"],
+    G("cg100.fa", "cg_aln.bam") + ["-q", "10"],
+    ["--methylKit", "--CHH", "--CHG"] + G("cg100.fa", "cg_aln.bam") + ["-q", "2"],
+    ["--minDepth", "2"] + G("cg100.fa", "cg_aln.bam") + ["-q", "2"],
+    ["--ignoreFlags", "0xD00"] + G("cg100.fa", "cg_aln.bam") + ["-q", "2"],
+    ["--requireFlags", "0xD00"] + G("cg100.fa", "cg_aln.bam") + ["-q", "2"],
+    ["--nOT", "50,50,40,40"] + G("cg100.fa", "cg_aln.bam") + ["-q", "2"],
+    ["-p", "1", "-q", "0", "--minOppositeDepth", "3", "--maxVariantFrac", "0.25"] + G("cg100.fa", "cg_with_variants.bam"),
+    G("chgchh.fa", "chgchh_aln.bam"),
+    ["-q", "5"] + G("chgchh.fa", "chgchh_aln.bam"),
+    ["-q", "5", "--minConversionEfficiency", "0.9"] + G("chgchh.fa", "chgchh_aln.bam"),
+    ["-q", "5", "--minConversionEfficiency", "1.0"] + G("chgchh.fa", "chgchh_aln.bam"),
+    ["-q", "1"] + G("cg100.fa", "NH.bam"),
+    ["--ignoreNH", "-q", "1"] + G("cg100.fa", "NH.bam"),
+    ["--mergeContext", "--CHG", "-q", "2"] + G("cg100.fa", "cg_aln.bam"),
+    ["--fraction", "-q", "2", "--CHH"] + G("cg100.fa", "cg_aln.bam"),
+    ["--counts", "-q", "2"] + G("cg100.fa", "cg_aln.bam"),
+    ["--logit", "-q", "2", "--ignoreFlags", "0"] + G("cg100.fa", "cg_aln.bam"),
+    ["--cytosine_report", "--CHG", "--CHH", "-q", "2"] + G("cg100.fa", "cg_aln.bam"),
+    ["--mergeContext", "-p", "1", "-q", "0", "--minOppositeDepth", "3", "--maxVariantFrac", "0.25"] + G("cg100.fa", "cg_with_variants.bam"),
+    ["-q", "2", "-r", "chrCG:10-50", "--chunkSize", "7"] + G("cg100.fa", "cg_aln.bam"),
+    ["-q", "5", "--CHG", "--CHH", "--mergeContext", "--chunkSize", "3"] + G("chgchh.fa", "chgchh_aln.bam"),
+]
+
+
+@pytest.mark.parametrize("args", FIXTURE_CMDS, ids=[" ".join(os.path.basename(a) for a in c) for c in FIXTURE_CMDS])
+def test_cli_fixtures_byte_exact(tmp_path, args):
+    compare_cli(tmp_path, args)
+
+
+SYN_CMDS = [
+    ("pe", []),
+    ("pe", ["--CHG", "--CHH", "--chunkSize", "7000"]),
+    ("pe", ["--CHG", "--CHH", "--mergeContext", "--chunkSize", "2500", "-d", "3"]),
+    ("pe", ["--chunkSize", "100", "-r", "chrS1:5000-9000", "--CHH"]),
+    ("pe", ["-F", "0", "--keepDupes", "--keepSingleton", "--keepDiscordant", "--ignoreNH", "-q", "0", "--chunkSize", "3001", "--CHG"]),
+    ("pe", ["--OT", "6,146,6,146", "--OB", "6,146,6,146", "--nOT", "2,3,4,5", "--CHH", "--methylKit"]),
+    ("pe", ["-B", "BBM", "--chunkSize", "9999"]),
+    ("pe", ["--minOppositeDepth", "2", "--maxVariantFrac", "0.5", "--CHG", "--chunkSize", "8000", "--mergeContext"]),
+    ("pe", ["--cytosine_report", "--CHG", "--CHH", "--chunkSize", "6000", "--minOppositeDepth", "2", "--maxVariantFrac", "0.3"]),
+    ("pe", ["--fraction", "-p", "20", "-@", "4"]),
+    ("pe", ["--logit", "--CHH", "--noCpG"]),
+    ("bis", ["--CHG", "--CHH"]),
+    ("bis", ["--CTOT", "5,100,5,100", "--nCTOB", "3,3,3,3", "--CHH", "--chunkSize", "5000"]),
+    ("se", ["--CHG", "--CHH", "--mergeContext"]),
+]
+
+
+@pytest.mark.parametrize("which,extra", SYN_CMDS, ids=[f"{w}:{' '.join(e)}" for w, e in SYN_CMDS])
+@pytest.mark.parametrize("tile", ["256", "1024"])
+def test_cli_synthetic_byte_exact(tmp_path, small_synth, which, extra, tile):
+    extra = [str(small_synth / "pe.bbm") if e == "BBM" else e for e in extra]
+    compare_cli(tmp_path, [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")] + extra, env={"MDK_TILE": tile})
+
+
+def abi_sites(args):
+    plan = mdk.Plan(args)
+    dev = mdk.Device(plan.dev_cfg())
+    got = {}
+    while True:
+        c = plan.next_chunk()
+        if c is None:
+            break
+        if c.skipped:
+            continue
+        plan.ensure_reference(dev, c.tid)
+        dev.submit(0, c.batch)
+        s = dev.download(0)
+        prev = -1
+        for pos, typ, isg, m, u, off, var in mdk.sites_to_rows(s):
+            assert c.beg <= pos < c.end and pos > prev, "sites must be ascending and inside the interval"
+            prev = pos
+            got[(c.tid, pos)] = (typ, isg, m, u, off, var)
+    dev.close()
+    plan.close()
+    return got
+
+
+def test_abi_sites_equal_oracle_counters(tmp_path, small_synth):
+    args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--CHG", "--CHH", "--minOppositeDepth", "1", "--chunkSize", "9000"]
+    dump = tmp_path / "d.tsv"
+    assert run_oracle(args + ["-o", tmp_path / "o"], cwd=tmp_path, dump=dump).returncode == 0
+    assert abi_sites(args + ["-o", tmp_path / "g"]) == read_dump(dump)
+
+
+@pytest.fixture(scope="module")
+def s1(tmp_path_factory):
+    """BASELINE.json configs[1]: synthetic 1 Mb contig, 30x paired-end WGBS"""
+    d = tmp_path_factory.mktemp("s1")
+    synth(d / "S1", "-L", "1000000", "-c", "30", "-s", "0x5EED0001")
+    return d
+
+
+def test_s1_cpg_byte_exact(tmp_path, s1):
+    compare_cli(tmp_path, [str(s1 / "S1.fa"), str(s1 / "S1.bam")])
+
+
+def test_s1_config3_chg_chh_trim_byte_exact(tmp_path, s1):
+    """BASELINE.json configs[2]"""
+    compare_cli(tmp_path, [str(s1 / "S1.fa"), str(s1 / "S1.bam"), "--CHG", "--CHH", "--OT", "6,146,6,146", "--OB", "6,146,6,146"])
+
+
+def test_s1_merge_variant_byte_exact(tmp_path, s1):
+    compare_cli(tmp_path, [str(s1 / "S1.fa"), str(s1 / "S1.bam"), "--mergeContext", "--minOppositeDepth", "5", "--maxVariantFrac", "0.2", "--chunkSize", "250000"])
+
+
+def test_launch_is_idempotent_and_chunking_invariant(tmp_path, s1):
+    """size-independent properties: re-launching a resident batch gives identical sites; total calls do not depend on
+    the chunk size or the tile size"""
+    base = [str(s1 / "S1.fa"), str(s1 / "S1.bam")]
+    a = abi_sites(base + ["-o", tmp_path / "a"])
+    os.environ["MDK_TILE"] = "512"
+    try:
+        b = abi_sites(base + ["--chunkSize", "33333", "-o", tmp_path / "b"])
+    finally:
+        del os.environ["MDK_TILE"]
+    assert a == b
+    plan = mdk.Plan(base + ["-o", tmp_path / "c"])
+    dev = mdk.Device(plan.dev_cfg())
+    c = plan.next_chunk()
+    plan.ensure_reference(dev, c.tid)
+    dev.upload(0, c.batch)
+    dev.launch(0)
+    r1 = mdk.sites_to_rows(dev.download(0))
+    dev.launch(0)
+    r2 = mdk.sites_to_rows(dev.download(0))
+    assert r1 == r2 and len(r1) > 1000
+    dev.close(), plan.close()
+
+
+def test_empty_and_edge_batches(tmp_path):
+    """empty BAM region, reads hanging over both contig ends, zero-length and clipped alignments"""
+    synth(tmp_path / "tiny", "-L", "400,150,3000", "-c", "12", "-s", "5", "-l", "100")
+    compare_cli(tmp_path, [str(tmp_path / "tiny.fa"), str(tmp_path / "tiny.bam"), "--CHG", "--CHH", "--chunkSize", "64"])
+    compare_cli(tmp_path, [str(tmp_path / "tiny.fa"), str(tmp_path / "tiny.bam"), "-r", "chrS2"])
+
+
+def test_no_cpu_fallback_symbols():
+    """the shipped libraries must not link the oracle"""
+    out = subprocess.run(["nm", "-D", str(mdk.LIB_EXTRACT)], capture_output=True, text=True).stdout
+    assert "extract_main" in out and "oracle" not in out.lower()
