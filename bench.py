@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--length", type=int, default=1_000_000, help="interval length per rank (S1 = 1 Mb)")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--extra", default="", help="extra extract options, e.g. '--CHG --CHH' (not the headline config)")
+    ap.add_argument("--synth-args", default="", help="extra mdk_synth options, e.g. '--clean' (not the headline config)")
     ap.add_argument("--cpu-runs", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -71,7 +72,7 @@ def main():
     work = Path(tempfile.mkdtemp(prefix=f"mdk_bench_r{rank}_"))
     prefix = work / "S1"
     synth = subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(prefix), "-L", str(args.length), "-c", str(args.coverage),
-                            "-s", str(S1_SEED + rank)], capture_output=True, text=True, check=True)
+                            "-s", str(S1_SEED + rank)] + args.synth_args.split(), capture_output=True, text=True, check=True)
     synth_info = json.loads(synth.stdout)
     extra = args.extra.split()
     cmd = [str(prefix) + ".fa", str(prefix) + ".bam", "--chunkSize", str(args.length)] + extra + ["-o", str(work / "gpu")]
@@ -92,34 +93,38 @@ def main():
     cpg_calls = 0
     all_calls = 0
     for i in range(n_sites):
-        c = sites.nmeth[i] + sites.nunmeth[i]
+        r = sites.site[i]
+        c = r.nmeth + r.nunmeth
         all_calls += c
-        if (sites.meta[i] >> 1) == 0:
+        if ((r.meta >> 1) & 3) == 0:
             cpg_calls += c
     variant = cfg.minOppositeDepth > 0
-
-    cap = int(n_sites) + 1024
-    t_cnt = torch.empty((5, cap), dtype=torch.int32, device="cuda")
-    t_meta = torch.empty((cap,), dtype=torch.uint8, device="cuda")
-    ptr = lambda row: C.c_void_p(t_cnt[row].data_ptr())
     L = mdk.lib_hip()
 
+    # the kernel writes its result straight into torch tensors (md_dev_bind_output), which is what travels over RCCL
+    n_tiles = dev.wait(0).n_tiles
+    cap = int(n_sites) + 1024
+    t_site = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
+    t_var = torch.zeros((cap, 2), dtype=torch.int32, device="cuda") if variant else None
+    t_seg = torch.zeros((n_tiles + 1, 2), dtype=torch.int32, device="cuda")
+    dev.bind_output(0, C.c_void_p(t_site.data_ptr()), C.c_void_p(t_var.data_ptr()) if variant else None, C.c_void_p(t_seg.data_ptr()), cap, n_tiles + 1)
+
     if world > 1:
-        counts = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-        dist.all_gather(counts, torch.tensor([cap], dtype=torch.int64, device="cuda"))
-        gcap = int(max(int(c.item()) for c in counts))
-        send = torch.zeros((5, gcap), dtype=torch.int32, device="cuda")
-        recv = [torch.empty((5, gcap), dtype=torch.int32, device="cuda") for _ in range(world)] if rank == 0 else None
+        shape = torch.tensor([cap, n_tiles + 1], dtype=torch.int64, device="cuda")
+        shapes = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(shapes, shape)
+        gcap = int(max(int(x[0].item()) for x in shapes)); gtiles = int(max(int(x[1].item()) for x in shapes))
+        send = torch.zeros((gcap * 4 + gtiles * 2 + 2,), dtype=torch.int32, device="cuda")
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
 
     def step():
         dev.launch(0)
-        n = L.md_dev_sites_to_device(dev.h, 0, ptr(0), ptr(1), ptr(2), ptr(3) if variant else None, ptr(4) if variant else None,
-                                     C.c_void_p(t_meta.data_ptr()), cap)
-        if n < 0:
-            raise RuntimeError(f"md_dev_sites_to_device failed: {n} {L.md_dev_last_error().decode()}")
-        if world > 1:
-            send[:, :cap].copy_(t_cnt)
-            send[3, 0] = n                      # site count travels with the buffer
+        n = dev.wait(0).n_sites
+        if world > 1:                           # the exchange step: per-interval site buffers -> rank 0 (RCCL over xGMI)
+            send[: cap * 4].copy_(t_site.view(-1))
+            send[gcap * 4: gcap * 4 + (n_tiles + 1) * 2].copy_(t_seg.view(-1))
+            send[-2] = n
+            send[-1] = n_tiles
             dist.gather(send, recv, dst=0)
         return n
 
@@ -138,6 +143,13 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     assert n_last == n_sites
+    # the bound buffers hold the same sites as the library's own download (segment order -> ascending)
+    chk = t_site.cpu().numpy().view("uint32"); segs = t_seg.cpu().numpy().view("uint32")
+    got = []
+    for t in range(n_tiles):
+        o, c = int(segs[t, 0]), int(segs[t, 1])
+        got.extend(int(x) for x in chk[o:o + c, 0])
+    assert got == [sites.site[i].pos for i in range(n_sites)], "bound-output sites differ from md_dev_download"
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -145,6 +157,8 @@ def main():
         tot = torch.tensor([cpg_calls, all_calls, int(n_sites)], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_cpg_calls, total_calls, total_sites = (int(x) for x in tot.tolist())
+        if rank == 0:                           # rank 0 really received every rank's interval
+            assert all(int(r[-2].item()) > 0 for r in recv)
     else:
         total_cpg_calls, total_calls, total_sites = cpg_calls, all_calls, int(n_sites)
 
@@ -161,11 +175,11 @@ def main():
             "value": value, "unit": "CpG calls/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32", "data": "synthetic",
-            "config": {"workload": "S1: synthetic 1 Mb contig, 30x PE 2x150 WGBS BAM, CpG-only extract (BASELINE.json configs[1])" if not extra and args.length == 1_000_000
+            "config": {"workload": "S1: synthetic 1 Mb contig, 30x PE 2x150 WGBS BAM, CpG-only extract (BASELINE.json configs[1])" if not extra and not args.synth_args and args.length == 1_000_000
                        else f"synthetic {args.length} bp, {args.coverage}x, extract {' '.join(extra)}",
-                       "interval_bp": args.length, "coverage": args.coverage, "reads_admitted_per_gpu": int(chunk.batch.n_reads),
+                       "interval_bp": args.length, "coverage": args.coverage, "reads_admitted_per_gpu": int(chunk.batch.n_reads), "segments_per_gpu": int(chunk.batch.n_segs),
                        "records_per_gpu": synth_info["records"], "sites_per_gpu": int(n_sites), "cpg_calls_per_gpu": int(cpg_calls),
-                       "tile": int(L.md_dev_tile(dev.h)), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else "")},
+                       "tile": int(br.tile), "tiles": int(br.n_tiles), "tiles_staged_in_lds": int(br.n_staged_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup, "all_kernels_ms": br.ms_total},
             "host_prep_s": t_host,

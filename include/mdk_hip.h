@@ -10,7 +10,9 @@
  *                                    bounds[16], absoluteBounds[16]; defaults extract.c:715-753)
  *   md_dev_set_reference          <- faidx_fetch_seq window handed to the column loop (extract.c:381,388-390)
  *   md_read_batch / md_dev_upload <- the reads bam_mplp64_auto pulls through filter_func for one chunk
- *                                    (extract.c:379,394-399; common.c:407-463) *after* admission
+ *                                    (extract.c:379,394-399; common.c:407-463) *after* admission, with the
+ *                                    CIGAR -> (qpos, is_del, is_refskip) resolution htslib does per column
+ *                                    (resolve_cigar2) done once per read on the host
  *   md_dev_launch                 <- the whole per-chunk pileup: trimming (common.c:137-208), mate-overlap
  *                                    resolution (overlaps.c:54-147), context classification
  *                                    (common.c:49-82, extract.c:407-418) and the per-read-base counting
@@ -48,50 +50,69 @@ typedef struct {
     int32_t n_slots;                     /* batches that may be in flight at once; 0 = 2 (double buffering) */
 } md_dev_cfg;
 
-/* One admitted alignment (16 bytes).  The payload of read i lives at blob + 4*off4:
- *   uint32 cigar[n_cigar]            BAM encoding, len<<4|op, ops MIDNSHP=X = 0..8
- *   uint8  seq[(l_qseq+1)/2]         BAM 4-bit codes, high nibble = even query index; padded to a multiple of 4 bytes
- *   uint8  qual[l_qseq]              raw phred bytes; padded to a multiple of 4 bytes
- * Reads are in file (coordinate) order. */
+/* The device sees every admitted alignment as one or more gapless SEGMENTS: the CIGAR is expanded on the host
+ * (reference <-> query map), so the kernel never walks a CIGAR.  A segment is a run of M/=/X bases; it is split
+ * further so that the read it is overlap-resolved against (overlaps.c:54-119) either covers the whole segment with
+ * one of ITS gapless runs, or does not touch it.  32 bytes, coalesced one per lane.
+ * The payload of a read lives at blob + 4*off4:
+ *   uint8 seq[(l_qseq+1)/2]   BAM 4-bit codes, high nibble = even query index; padded to a multiple of 4 bytes
+ *   uint8 qual[l_qseq]        raw phred bytes; padded to a multiple of 4 bytes
+ * Segments are emitted in file (coordinate) order of their reads, ascending within a read. */
 typedef struct {
-    int32_t  pos;        /* 0-based leftmost reference position (bam1_core_t.pos) */
-    uint32_t off4;
-    uint32_t l_qseq;
-    uint16_t n_cigar;
-    uint8_t  strand;     /* getStrand(): 1 OT, 2 OB, 3 CTOT, 4 CTOB, 0 undeterminable (common.c:84-116) */
-    uint8_t  flags;      /* bit0: read #2 (BAM flag 0x80); bit1: this read is the LATER-in-file member of its pair */
-} md_read_hdr;
-#define MDK_RF_READ2  1u
-#define MDK_RF_SECOND 2u
+    int32_t  rpos;       /* reference position of the segment's first base */
+    uint32_t off4;       /* payload of the read the segment belongs to */
+    uint32_t l_qseq;     /* length of that READ (trimming bounds are defined on the whole read, common.c:137-208) */
+    uint32_t q0;         /* query index of the segment's first base */
+    uint16_t len;        /* bases in the segment, >= 1 */
+    uint8_t  sf;         /* MDK_SF_*: strand of origin (getStrand, common.c:84-116) and flags */
+    uint8_t  msf;        /* partner: strand (bits 0-2) and read #2 (bit 3); valid iff sf & MDK_SF_PARTNER */
+    uint32_t m_off4;     /* partner read's payload */
+    uint32_t m_l_qseq;   /* partner read's length */
+    uint32_t m_q0;       /* partner's query index of the base aligned to rpos */
+} md_seg;
+#define MDK_SF_STRAND  7u     /* bits 0-2: 1 OT, 2 OB, 3 CTOT, 4 CTOB, 0 undeterminable */
+#define MDK_SF_READ2   8u     /* read #2 (BAM flag 0x80) */
+#define MDK_SF_SECOND  16u    /* this read is the LATER-in-file member of its pair ('b' of overlaps.c:54) */
+#define MDK_SF_PARTNER 32u    /* m_* valid: the partner covers the whole segment gaplessly */
 
 /* The admitted reads of ONE interval [beg,end) of one contig -- what one chunk of extractCalls sees.
- * Host-owned; must stay valid until md_dev_upload returns (the copy is staged internally). */
+ * Host-owned; must stay valid until the slot is downloaded, waited for or synced (copies are asynchronous). */
 typedef struct {
     int32_t  tid;
     int64_t  beg, end;          /* columns counted: beg <= pos < end (extract.c:400) */
-    int32_t  n_reads;
-    const md_read_hdr *hdr;     /* [n_reads] */
-    const int32_t *rend;        /* [n_reads] pos + raw reference length of the CIGAR (htslib lbnode end) */
-    const int32_t *mate;        /* [n_reads] index of the read this one is overlap-resolved against
-                                   (the pairing custom_overlap_constructor would make, overlaps.c:121-139) or -1 */
+    int32_t  n_segs;
+    const md_seg *seg;          /* [n_segs] */
     const uint8_t *blob;
     uint64_t blob_bytes;
+    int32_t  n_reads;           /* informational: admitted alignments behind the segments */
+    uint64_t algo_bytes;        /* informational: sum over those reads of 16 + 4*n_cigar + ceil(l/2) + l */
 } md_read_batch;
 
 /* Result of one interval: every position with nmeth+nunmeth > 0 (or nOff > 0 when minOppositeDepth > 0),
  * ascending.  Pointers are host memory owned by the library, valid until the slot is reused. */
+typedef struct { uint32_t pos, nmeth, nunmeth, meta; } md_site;   /* meta bit 0: reference base is G/g; bits 1-2: context 0 CpG / 1 CHG / 2 CHH */
+typedef struct { uint32_t noff, nvar; } md_site_var;              /* opposite-strand depth / variant evidence (extract.c:225-239) */
 typedef struct {
     int64_t n_sites;
-    const uint32_t *pos, *nmeth, *nunmeth;
-    const uint32_t *noff, *nvar;     /* NULL unless minOppositeDepth > 0 */
-    const uint8_t  *meta;            /* bits 1-2: context 0 CpG / 1 CHG / 2 CHH; bit 0: reference base is G/g */
+    const md_site *site;
+    const md_site_var *var;          /* NULL unless minOppositeDepth > 0 */
 } md_sites;
 
+/* Device-resident result of one interval, as the kernel leaves it: tile t's sites (ascending) occupy
+ * site[seg[t].off .. seg[t].off + seg[t].cnt); tiles are in position order but their segments are not
+ * (segments are reserved with one atomic per tile).  Used for device-to-device exchange (RCCL gather). */
+typedef struct { uint32_t off, cnt; } md_tile_seg;
 typedef struct {
-    float ms_total;      /* all kernels of one launch, averaged over iters */
-    float ms_pileup;     /* the pileup kernel alone, averaged over iters */
+    int64_t n_sites; int32_t n_tiles;
+    const md_site *d_site; const md_site_var *d_var; const md_tile_seg *d_seg;   /* DEVICE pointers */
+} md_sites_dev;
+
+typedef struct {
+    float ms_total;      /* one launch bracketed by HIP events on the slot's stream (includes lone-launch dispatch latency), mean over iters */
+    float ms_pileup;     /* the pileup kernel: `iters` launches back to back between two HIP events, divided by iters */
     uint64_t algo_bytes; /* algorithmic bytes of one launch (SURVEY.md 8d formula) */
     uint64_t n_sites;
+    int32_t tile, n_tiles, n_staged_tiles, lds_bytes;   /* geometry the launch used */
 } md_bench_result;
 
 int  md_dev_count(void);                                       /* number of HIP devices, <0 on error */
@@ -111,11 +132,16 @@ int  md_dev_submit(md_dev *h, int slot, const md_read_batch *b);
 int  md_dev_download(md_dev *h, int slot, md_sites *out);
 int  md_dev_sync(md_dev *h);
 
-/* Write the sites of a finished slot into caller-provided DEVICE buffers (e.g. torch tensors used for the
- * RCCL gather) instead of library host memory.  cap = capacity in sites of every buffer; noff/nvar may be NULL.
- * Returns the number of sites (>=0) or a negative error; MDK_ERR_ARG if cap is too small. */
-int64_t md_dev_sites_to_device(md_dev *h, int slot, uint32_t *d_pos, uint32_t *d_nmeth, uint32_t *d_nunmeth,
-                               uint32_t *d_noff, uint32_t *d_nvar, uint8_t *d_meta, int64_t cap);
+/* Make the kernels of `slot` write their result into caller-provided DEVICE buffers (e.g. torch tensors that are
+ * then exchanged over RCCL) instead of library memory: d_site[cap_sites] (md_site), d_var[cap_sites] (md_site_var,
+ * may be NULL when minOppositeDepth == 0), d_seg[cap_tiles] (md_tile_seg).  Pass all-NULL to unbind.
+ * md_dev_wait then reports how many sites/tiles were written; MDK_ERR_ARG if a capacity was too small. */
+int  md_dev_bind_output(md_dev *h, int slot, void *d_site, void *d_var, void *d_seg, int64_t cap_sites, int64_t cap_tiles);
+/* wait for the slot's kernels; fills the device view (library or bound buffers) */
+int  md_dev_wait(md_dev *h, int slot, md_sites_dev *out);
+/* host-side helper: put a segmented result (copied to host memory) into ascending order */
+int  md_sites_order(const md_site *site, const md_site_var *var, const md_tile_seg *seg, int32_t n_tiles, int64_t n_sites,
+                    md_site *out_site, md_site_var *out_var);
 
 /* Re-run the kernels of an uploaded slot `iters` times (inputs stay resident in HBM; results are identical
  * every time) and time them with HIP events on the slot's stream. */

@@ -37,25 +37,40 @@ class md_dev_cfg(C.Structure):
                 ("tile", C.c_int32), ("n_slots", C.c_int32)]
 
 
-class md_read_hdr(C.Structure):
-    _fields_ = [("pos", C.c_int32), ("off4", C.c_uint32), ("l_qseq", C.c_uint32), ("n_cigar", C.c_uint16),
-                ("strand", C.c_uint8), ("flags", C.c_uint8)]
+class md_seg(C.Structure):
+    _fields_ = [("rpos", C.c_int32), ("off4", C.c_uint32), ("l_qseq", C.c_uint32), ("q0", C.c_uint32), ("len", C.c_uint16),
+                ("sf", C.c_uint8), ("msf", C.c_uint8), ("m_off4", C.c_uint32), ("m_l_qseq", C.c_uint32), ("m_q0", C.c_uint32)]
 
 
 class md_read_batch(C.Structure):
-    _fields_ = [("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("n_reads", C.c_int32),
-                ("hdr", C.POINTER(md_read_hdr)), ("rend", C.POINTER(C.c_int32)), ("mate", C.POINTER(C.c_int32)),
-                ("blob", C.POINTER(C.c_uint8)), ("blob_bytes", C.c_uint64)]
+    _fields_ = [("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("n_segs", C.c_int32),
+                ("seg", C.POINTER(md_seg)), ("blob", C.POINTER(C.c_uint8)), ("blob_bytes", C.c_uint64),
+                ("n_reads", C.c_int32), ("algo_bytes", C.c_uint64)]
+
+
+class md_site(C.Structure):
+    _fields_ = [("pos", C.c_uint32), ("nmeth", C.c_uint32), ("nunmeth", C.c_uint32), ("meta", C.c_uint32)]
+
+
+class md_site_var(C.Structure):
+    _fields_ = [("noff", C.c_uint32), ("nvar", C.c_uint32)]
+
+
+class md_tile_seg(C.Structure):
+    _fields_ = [("off", C.c_uint32), ("cnt", C.c_uint32)]
 
 
 class md_sites(C.Structure):
-    _fields_ = [("n_sites", C.c_int64), ("pos", C.POINTER(C.c_uint32)), ("nmeth", C.POINTER(C.c_uint32)),
-                ("nunmeth", C.POINTER(C.c_uint32)), ("noff", C.POINTER(C.c_uint32)), ("nvar", C.POINTER(C.c_uint32)),
-                ("meta", C.POINTER(C.c_uint8))]
+    _fields_ = [("n_sites", C.c_int64), ("site", C.POINTER(md_site)), ("var", C.POINTER(md_site_var))]
+
+
+class md_sites_dev(C.Structure):
+    _fields_ = [("n_sites", C.c_int64), ("n_tiles", C.c_int32), ("d_site", C.c_void_p), ("d_var", C.c_void_p), ("d_seg", C.c_void_p)]
 
 
 class md_bench_result(C.Structure):
-    _fields_ = [("ms_total", C.c_float), ("ms_pileup", C.c_float), ("algo_bytes", C.c_uint64), ("n_sites", C.c_uint64)]
+    _fields_ = [("ms_total", C.c_float), ("ms_pileup", C.c_float), ("algo_bytes", C.c_uint64), ("n_sites", C.c_uint64),
+                ("tile", C.c_int32), ("n_tiles", C.c_int32), ("n_staged_tiles", C.c_int32), ("lds_bytes", C.c_int32)]
 
 
 class mdk_chunk(C.Structure):
@@ -64,7 +79,7 @@ class mdk_chunk(C.Structure):
 
 
 HIP_SYMBOLS = ["md_dev_count", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference",
-               "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_sites_to_device",
+               "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_n_targets", "mdk_plan_target_name",
@@ -99,8 +114,9 @@ def lib_hip():
         L.md_dev_launch.argtypes = [C.c_void_p, C.c_int]
         L.md_dev_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_sites)]
         L.md_dev_sync.argtypes = [C.c_void_p]
-        L.md_dev_sites_to_device.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int64]
-        L.md_dev_sites_to_device.restype = C.c_int64
+        L.md_dev_bind_output.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
+        L.md_dev_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_sites_dev)]
+        L.md_sites_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
         L.md_dev_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
         L.md_dev_debug_effective.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.md_host_alloc.restype = C.c_void_p
@@ -172,6 +188,14 @@ class Device:
         s = md_sites()
         self._chk(self.L.md_dev_download(self.h, slot, C.byref(s)), "md_dev_download")
         return s
+
+    def wait(self, slot: int) -> md_sites_dev:
+        s = md_sites_dev()
+        self._chk(self.L.md_dev_wait(self.h, slot, C.byref(s)), "md_dev_wait")
+        return s
+
+    def bind_output(self, slot: int, d_site, d_var, d_seg, cap_sites: int, cap_tiles: int):
+        self._chk(self.L.md_dev_bind_output(self.h, slot, d_site, d_var, d_seg, cap_sites, cap_tiles), "md_dev_bind_output")
 
     def bench(self, slot: int, warmup: int, iters: int) -> md_bench_result:
         r = md_bench_result()
@@ -248,11 +272,10 @@ class Plan:
 
 def sites_to_rows(s: md_sites):
     """md_sites -> list of (pos, type, isG, nmeth, nunmeth, noff, nvar) tuples (for tests)."""
-    n = s.n_sites
     rows = []
-    for i in range(n):
-        rows.append((s.pos[i], s.meta[i] >> 1, s.meta[i] & 1, s.nmeth[i], s.nunmeth[i],
-                     s.noff[i] if s.noff else 0, s.nvar[i] if s.nvar else 0))
+    for i in range(s.n_sites):
+        r = s.site[i]
+        rows.append((r.pos, (r.meta >> 1) & 3, r.meta & 1, r.nmeth, r.nunmeth, s.var[i].noff if s.var else 0, s.var[i].nvar if s.var else 0))
     return rows
 
 

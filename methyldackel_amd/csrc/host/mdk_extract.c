@@ -49,11 +49,16 @@ static void sb_put(sbuf *b, const char *s, size_t n) {
     memcpy(b->s + b->l, s, n); b->l += n; b->s[b->l] = 0;
 }
 
-/* pinned, growable batch arrays */
+/* one admitted read, host-side only (the device gets segments) */
+typedef struct { int32_t pos, rend, mate; uint32_t off4, lq, cig_off, qn_off; uint16_t ncig, bamflag; uint8_t strand, second; } rinfo;
+/* growable batch arrays; blob and seg are pinned (they are what gets uploaded) */
 typedef struct {
-    md_read_hdr *hdr; int32_t *rend, *mate; uint8_t *blob;
-    size_t cap_reads, cap_blob, n, blob_len;
-    char *qn; size_t qn_len, qn_cap; uint32_t *qn_off; size_t qn_off_cap;
+    rinfo *ri; size_t n, cap_ri;
+    uint32_t *cig; size_t cig_len, cig_cap;
+    char *qn; size_t qn_len, qn_cap;
+    uint8_t *blob; size_t blob_len, cap_blob;
+    md_seg *seg; size_t n_seg, cap_seg;
+    uint64_t algo_bytes;
 } batchbuf;
 
 /* qname table entry for the pairing pass */
@@ -70,7 +75,6 @@ struct mdk_plan {
     uint8_t *carry; size_t carry_len, carry_cap; int32_t carry_tid;
     uint8_t *carry2; size_t carry2_len, carry2_cap;
     batchbuf bb[2]; int cur_bb;
-    uint16_t *bflag[2]; size_t bflag_cap[2];
     qent *qt; size_t qt_cap;
     /* mappability */
     int map_on; uint32_t map_n; char **map_names; uint32_t *map_len; uint8_t **map_bits; int *map_of_tid;
@@ -344,7 +348,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     return 0;
 }
 
-static void bb_free(batchbuf *b) { md_host_free(b->hdr); md_host_free(b->rend); md_host_free(b->mate); md_host_free(b->blob); free(b->qn); free(b->qn_off); memset(b, 0, sizeof(*b)); }
+static void bb_free(batchbuf *b) { md_host_free(b->seg); md_host_free(b->blob); free(b->ri); free(b->cig); free(b->qn); memset(b, 0, sizeof(*b)); }
 static void plan_free(mdk_plan *p) {
     uint32_t k; int i;
     if(!p) return;
@@ -352,8 +356,8 @@ static void plan_free(mdk_plan *p) {
     mdk_fasta_free(&p->fa); free(p->fa_of_tid); free(p->map_of_tid);
     for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); }
     free(p->map_names); free(p->map_len); free(p->map_bits);
-    free(p->carry); free(p->carry2); free(p->bflag[0]); free(p->bflag[1]);
-    if(p->bb[0].hdr || p->bb[1].hdr) { bb_free(&p->bb[0]); bb_free(&p->bb[1]); }
+    free(p->carry); free(p->carry2);
+    bb_free(&p->bb[0]); bb_free(&p->bb[1]);
     if(p->qt) { size_t q; for(q = 0; q < p->qt_cap; q++) free(p->qt[q].more); free(p->qt); }
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); }
     else for(i = 0; i < 3; i++) if(p->out[i]) fclose(p->out[i]);
@@ -489,15 +493,8 @@ done:
 /* ------------------------------------------------------------------------------------------------ */
 /* batch building                                                                                    */
 /* ------------------------------------------------------------------------------------------------ */
-static int bb_reserve(batchbuf *b, size_t more_reads, size_t more_blob, size_t more_qn) {
-    if(b->n + more_reads > b->cap_reads) {
-        size_t nc = (b->n + more_reads) * 2 + 1024;
-        md_read_hdr *h = md_host_alloc(nc * sizeof(md_read_hdr)); int32_t *e = md_host_alloc(nc * 4), *m = md_host_alloc(nc * 4);
-        if(!h || !e || !m) return -1;
-        if(b->n) { memcpy(h, b->hdr, b->n * sizeof(md_read_hdr)); memcpy(e, b->rend, b->n * 4); memcpy(m, b->mate, b->n * 4); }
-        md_host_free(b->hdr); md_host_free(b->rend); md_host_free(b->mate);
-        b->hdr = h; b->rend = e; b->mate = m; b->cap_reads = nc;
-    }
+static int bb_reserve(batchbuf *b, size_t more_reads, size_t more_blob, size_t more_qn, size_t more_cig) {
+    if(b->n + more_reads > b->cap_ri) { b->cap_ri = (b->n + more_reads) * 2 + 1024; b->ri = realloc(b->ri, b->cap_ri * sizeof(rinfo)); if(!b->ri) return -1; }
     if(b->blob_len + more_blob > b->cap_blob) {
         size_t nc = (b->blob_len + more_blob) * 2 + (1 << 20); uint8_t *d = md_host_alloc(nc);
         if(!d) return -1;
@@ -505,7 +502,16 @@ static int bb_reserve(batchbuf *b, size_t more_reads, size_t more_blob, size_t m
         md_host_free(b->blob); b->blob = d; b->cap_blob = nc;
     }
     if(b->qn_len + more_qn > b->qn_cap) { b->qn_cap = (b->qn_len + more_qn) * 2 + 65536; b->qn = realloc(b->qn, b->qn_cap); if(!b->qn) return -1; }
-    if(b->n + more_reads > b->qn_off_cap) { b->qn_off_cap = (b->n + more_reads) * 2 + 1024; b->qn_off = realloc(b->qn_off, b->qn_off_cap * 4); if(!b->qn_off) return -1; }
+    if(b->cig_len + more_cig > b->cig_cap) { b->cig_cap = (b->cig_len + more_cig) * 2 + 4096; b->cig = realloc(b->cig, b->cig_cap * 4); if(!b->cig) return -1; }
+    return 0;
+}
+static int seg_reserve(batchbuf *b, size_t more) {
+    if(b->n_seg + more > b->cap_seg) {
+        size_t nc = (b->n_seg + more) * 2 + 4096; md_seg *d = md_host_alloc(nc * sizeof(md_seg));
+        if(!d) return -1;
+        if(b->n_seg) memcpy(d, b->seg, b->n_seg * sizeof(md_seg));
+        md_host_free(b->seg); b->seg = d; b->cap_seg = nc;
+    }
     return 0;
 }
 
@@ -528,24 +534,24 @@ static void qt_prepare(mdk_plan *p, size_t expect) {
     if(want > p->qt_cap) { if(p->qt) for(i = 0; i < p->qt_cap; i++) free(p->qt[i].more); free(p->qt); p->qt = calloc(want, sizeof(qent)); p->qt_cap = want; }
     else for(i = 0; i < p->qt_cap; i++) { p->qt[i].used = 0; }
 }
-static void pair_reads(mdk_plan *p, batchbuf *b, const uint16_t *bamflag, int32_t tid) {
+static void pair_reads(mdk_plan *p, batchbuf *b, int32_t tid) {
     size_t i, n = b->n; int32_t prev_pos = 0; int first = 1;
     qt_prepare(p, n);
     for(i = 0; i < n; i++) {
-        int32_t pos = b->hdr[i].pos, end = b->rend[i]; int inserted; qent *e; int k, w, evicted = 0;
-        b->mate[i] = -1;
+        rinfo *r = &b->ri[i]; int32_t pos = r->pos, end = r->rend; int inserted; qent *e; int k, w, evicted = 0;
+        r->mate = -1; r->second = 0;
         /* bam_plp_push: a read enters the buffer iff its end lies beyond the column about to be emitted */
         if(first) inserted = (tid > 0) || (end > 0); else inserted = end > prev_pos;
         if(inserted) {
-            e = qt_get(p, b, b->qn_off[i]);
+            e = qt_get(p, b, r->qn_off);
             for(k = 0, w = 0; k < e->nlive; k++) { if(!first && e->live[k] < prev_pos) evicted = 1; else e->live[w++] = e->live[k]; }
             e->nlive = w;
             for(k = 0, w = 0; k < e->nmore; k++) { if(!first && e->more[k] < prev_pos) evicted = 1; else e->more[w++] = e->more[k]; }
             e->nmore = w;
             if(evicted) e->pending = -1;
-            if((bamflag[i] & 0x1) && !(bamflag[i] & 12)) {
+            if((r->bamflag & 0x1) && !(r->bamflag & 12)) {
                 if(e->pending < 0) e->pending = (int32_t)i;
-                else { int32_t a = e->pending; b->mate[a] = (int32_t)i; b->mate[i] = a; b->hdr[i].flags |= MDK_RF_SECOND; e->pending = -1; }
+                else { int32_t a = e->pending; b->ri[a].mate = (int32_t)i; r->mate = a; r->second = 1; e->pending = -1; }
             }
             if(e->nlive < 4) e->live[e->nlive++] = end;
             else { if(e->nmore == e->capmore) { e->capmore = e->capmore ? e->capmore * 2 : 8; e->more = realloc(e->more, sizeof(int32_t) * e->capmore); } e->more[e->nmore++] = end; }
@@ -554,10 +560,63 @@ static void pair_reads(mdk_plan *p, batchbuf *b, const uint16_t *bamflag, int32_
     }
 }
 
+/* CIGAR -> gapless runs (reference start, query start, length); what calculate_positions (overlaps.c:27-52) and
+ * htslib's resolve_cigar2 compute base by base */
+typedef struct { int32_t x, y, l; } run_t;
+static int cigar_runs(const uint32_t *cig, int ncig, int32_t pos, int32_t lq, run_t **out, int *cap) {
+    int n = 0, k; int32_t x = pos, y = 0;
+    for(k = 0; k < ncig; k++) {
+        int op = cig[k] & 15; int32_t len = (int32_t)(cig[k] >> 4);
+        if(cigar_is_match(op)) {
+            int32_t l = len; if(y + l > lq) l = lq - y;            /* malformed CIGAR guard */
+            if(l > 0) { if(n == *cap) { *cap = *cap ? *cap * 2 : 16; *out = realloc(*out, sizeof(run_t) * *cap); } (*out)[n].x = x; (*out)[n].y = y; (*out)[n].l = l; n++; }
+            x += len; y += len;
+        } else if(op == 1 || op == 4) y += len;
+        else if(op == 2 || op == 3) x += len;
+    }
+    return n;
+}
+
+/* segments of every read of the chunk: its gapless runs, cut where the overlap partner's runs begin/end */
+static int build_segments(mdk_plan *p, batchbuf *b, int64_t beg, int64_t end) {
+    static __thread run_t *ro = NULL, *rm = NULL; static __thread int co = 0, cm = 0;
+    size_t i;
+    b->n_seg = 0;
+    for(i = 0; i < b->n; i++) {
+        const rinfo *r = &b->ri[i], *m = NULL; int no, nm = 0, a, j = 0;
+        uint8_t sf = (uint8_t)((r->strand & 7) | ((r->bamflag & 0x80) ? MDK_SF_READ2 : 0) | (r->second ? MDK_SF_SECOND : 0)), msf = 0;
+        no = cigar_runs(b->cig + r->cig_off, r->ncig, r->pos, (int32_t)r->lq, &ro, &co);
+        /* only pairs whose strands agree in parity are resolved against each other (overlaps.c:63-65) */
+        if(r->mate >= 0 && (((int)r->strand - (int)b->ri[r->mate].strand) & 1) == 0) {
+            m = &b->ri[r->mate];
+            nm = cigar_runs(b->cig + m->cig_off, m->ncig, m->pos, (int32_t)m->lq, &rm, &cm);
+            msf = (uint8_t)((m->strand & 7) | ((m->bamflag & 0x80) ? MDK_SF_READ2 : 0));
+        }
+        for(a = 0; a < no; a++) {
+            int32_t cur = ro[a].x, stop = ro[a].x + ro[a].l;
+            while(cur < stop) {
+                int32_t pe = stop; int covered = 0; md_seg *g;
+                while(j < nm && rm[j].x + rm[j].l <= cur) j++;        /* partner runs are ascending, so is cur */
+                if(j < nm) { if(rm[j].x <= cur) { covered = 1; if(rm[j].x + rm[j].l < pe) pe = rm[j].x + rm[j].l; } else if(rm[j].x < pe) pe = rm[j].x; }
+                if(pe - cur > 65535) pe = cur + 65535;
+                if(pe > beg && cur < end) {                         /* pieces wholly outside the counted columns are not needed */
+                    if(seg_reserve(b, 1)) return -1;
+                    g = &b->seg[b->n_seg++];
+                    g->rpos = cur; g->off4 = r->off4; g->l_qseq = r->lq; g->q0 = (uint32_t)(ro[a].y + (cur - ro[a].x)); g->len = (uint16_t)(pe - cur);
+                    g->sf = sf; g->msf = 0; g->m_off4 = 0; g->m_l_qseq = 0; g->m_q0 = 0;
+                    if(covered) { g->sf |= MDK_SF_PARTNER; g->msf = msf; g->m_off4 = m->off4; g->m_l_qseq = m->lq; g->m_q0 = (uint32_t)(rm[j].y + (cur - rm[j].x)); }
+                }
+                cur = pe;
+            }
+        }
+    }
+    (void)p;
+    return 0;
+}
 
 /* admission (filter_func, common.c:416-444) + packing of one candidate record; returns 1 if admitted */
-static int admit_and_pack(mdk_plan *p, batchbuf *b, int which, const mdk_rec *r, int32_t rlen, const char *win, int64_t woff, int64_t wlen) {
-    const opts_t *o = &p->o; const uint8_t *nh, *xg; int strand; size_t seqb, seqpad, qualpad, need; uint8_t *d; md_read_hdr *h;
+static int admit_and_pack(mdk_plan *p, batchbuf *b, const mdk_rec *r, int32_t rlen, const char *win, int64_t woff, int64_t wlen) {
+    const opts_t *o = &p->o; const uint8_t *nh, *xg; int strand; size_t seqb, seqpad, qualpad, need; uint8_t *d; rinfo *ri; int k;
     if(r->tid == -1 || (r->flag & 0x4)) return 0;
     if(r->mapq < o->min_mapq) return 0;
     if(r->flag & o->ignore_flags) return 0;
@@ -576,19 +635,19 @@ static int admit_and_pack(mdk_plan *p, batchbuf *b, int which, const mdk_rec *r,
     if(o->min_conv_eff > 0.0) { if(conv_efficiency(r, strand, o->min_phred, win, woff, wlen) < o->min_conv_eff) return 0; }
 
     seqb = ((size_t)r->l_qseq + 1) / 2; seqpad = (seqb + 3) & ~(size_t)3; qualpad = ((size_t)r->l_qseq + 3) & ~(size_t)3;
-    need = 4u * r->n_cigar + seqpad + qualpad;
-    if(bb_reserve(b, 1, need, (size_t)r->l_qname + 1)) return -1;
-    if(b->n + 1 > p->bflag_cap[which]) { p->bflag_cap[which] = (b->n + 1) * 2 + 1024; p->bflag[which] = realloc(p->bflag[which], p->bflag_cap[which] * 2); }
-    h = &b->hdr[b->n];
-    h->pos = r->pos; h->off4 = (uint32_t)(b->blob_len >> 2); h->l_qseq = (uint32_t)r->l_qseq; h->n_cigar = r->n_cigar;
-    h->strand = (uint8_t)strand; h->flags = (r->flag & 0x80) ? MDK_RF_READ2 : 0;
-    b->rend[b->n] = r->pos + rlen; b->mate[b->n] = -1; p->bflag[which][b->n] = r->flag;
+    need = seqpad + qualpad;
+    if(bb_reserve(b, 1, need, (size_t)r->l_qname + 1, r->n_cigar)) return -1;
+    ri = &b->ri[b->n];
+    ri->pos = r->pos; ri->rend = r->pos + rlen; ri->mate = -1; ri->second = 0;
+    ri->off4 = (uint32_t)(b->blob_len >> 2); ri->lq = (uint32_t)r->l_qseq; ri->ncig = r->n_cigar; ri->bamflag = r->flag; ri->strand = (uint8_t)strand;
+    ri->cig_off = (uint32_t)b->cig_len;
+    for(k = 0; k < r->n_cigar; k++) b->cig[b->cig_len++] = rd_u32(r->cigar + 4 * k);
     d = b->blob + b->blob_len;
-    memcpy(d, r->cigar, 4u * r->n_cigar); d += 4u * r->n_cigar;
     memcpy(d, r->seq, seqb); memset(d + seqb, 0, seqpad - seqb); d += seqpad;
     memcpy(d, r->qual, (size_t)r->l_qseq); memset(d + r->l_qseq, 0, qualpad - (size_t)r->l_qseq);
     b->blob_len += need;
-    b->qn_off[b->n] = (uint32_t)b->qn_len; memcpy(b->qn + b->qn_len, r->qname, r->l_qname); b->qn[b->qn_len + r->l_qname] = 0; b->qn_len += (size_t)r->l_qname + 1;
+    ri->qn_off = (uint32_t)b->qn_len; memcpy(b->qn + b->qn_len, r->qname, r->l_qname); b->qn[b->qn_len + r->l_qname] = 0; b->qn_len += (size_t)r->l_qname + 1;
+    b->algo_bytes += 16 + 4ull * r->n_cigar + seqb + (uint64_t)r->l_qseq;
     b->n++;
     return 1;
 }
@@ -618,6 +677,7 @@ static uint32_t adjust_end(const mdk_plan *p, uint32_t tid, uint32_t end) {
 int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
     const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; batchbuf *b; int which, rc, fi; mdk_rec r;
     const char *win = NULL; int64_t woff = 0, wlen = 0; size_t off;
+    (void)which;
     memset(c, 0, sizeof(*c));
     /* extract.c:325-350 */
     c->index = p->bin++;
@@ -632,7 +692,7 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
     if(p->g_end && beg >= p->g_end) return 0;
     c->tid = (int32_t)tid; c->beg = beg; c->end = end;
     which = p->cur_bb; p->cur_bb ^= 1; b = &p->bb[which];
-    b->n = 0; b->blob_len = 0; b->qn_len = 0;
+    b->n = 0; b->blob_len = 0; b->qn_len = 0; b->cig_len = 0; b->n_seg = 0; b->algo_bytes = 0;
     fi = p->fa_of_tid[tid];
     if(fi < 0) {
         fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", -2, bam->target_name[tid], beg > 1 ? beg - 2 : 0, end);
@@ -652,7 +712,7 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
             off += 4 + (size_t)len;
             rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
             c->n_records_seen++;
-            if(endp > (int32_t)beg && r.pos < (int32_t)end && !c->skipped) { if(admit_and_pack(p, b, which, &r, rlen, win, woff, wlen) < 0) return -5; }
+            if(endp > (int32_t)beg && r.pos < (int32_t)end && !c->skipped) { if(admit_and_pack(p, b, &r, rlen, win, woff, wlen) < 0) return -5; }
             if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
         }
     }
@@ -667,17 +727,18 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
         if(r.tid == (int32_t)tid) {
             rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
             c->n_records_seen++;
-            if(endp > (int32_t)beg && !c->skipped) { if(admit_and_pack(p, b, which, &r, rlen, win, woff, wlen) < 0) return -5; }
+            if(endp > (int32_t)beg && !c->skipped) { if(admit_and_pack(p, b, &r, rlen, win, woff, wlen) < 0) return -5; }
             if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
         }
         mdk_bam_advance(bam, &r);
     }
     if(rc < 0) { fprintf(stderr, "[mdk] error while reading %s: %s\n", o->bam_name, bam->err); return -2; }
     { uint8_t *t = p->carry; size_t tc = p->carry_cap; p->carry = p->carry2; p->carry_len = p->carry2_len; p->carry_cap = p->carry2_cap; p->carry2 = t; p->carry2_cap = tc; p->carry2_len = 0; p->carry_tid = (int32_t)tid; }
-    if(bb_reserve(b, 1, 16, 16)) return -5;          /* never hand out NULL arrays */
-    pair_reads(p, b, p->bflag[which], (int32_t)tid);
-    c->batch.tid = (int32_t)tid; c->batch.beg = beg; c->batch.end = end; c->batch.n_reads = (int32_t)b->n;
-    c->batch.hdr = b->hdr; c->batch.rend = b->rend; c->batch.mate = b->mate; c->batch.blob = b->blob; c->batch.blob_bytes = b->blob_len;
+    if(bb_reserve(b, 1, 16, 16, 1) || seg_reserve(b, 1)) return -5;          /* never hand out NULL arrays */
+    pair_reads(p, b, (int32_t)tid);
+    if(build_segments(p, b, beg, end)) return -5;
+    c->batch.tid = (int32_t)tid; c->batch.beg = beg; c->batch.end = end; c->batch.n_segs = (int32_t)b->n_seg; c->batch.seg = b->seg;
+    c->batch.blob = b->blob; c->batch.blob_bytes = b->blob_len; c->batch.n_reads = (int32_t)b->n; c->batch.algo_bytes = b->algo_bytes;
     return 1;
 }
 
@@ -735,9 +796,9 @@ int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
     fi = p->fa_of_tid[c->tid]; if(fi >= 0) { seq = p->fa.seq[fi]; slen = p->fa.len[fi]; }
     blank_from = c->beg;
     for(i = 0; i < s->n_sites; i++) {
-        int32_t pos = (int32_t)s->pos[i]; uint32_t m = s->nmeth[i], u = s->nunmeth[i]; int type = s->meta[i] >> 1, is_g = s->meta[i] & 1;
-        if(o->min_opp_depth > 0 && s->noff) {
-            uint32_t noff = s->noff[i], nvar = s->nvar[i];
+        int32_t pos = (int32_t)s->site[i].pos; uint32_t m = s->site[i].nmeth, u = s->site[i].nunmeth; int type = (s->site[i].meta >> 1) & 3, is_g = s->site[i].meta & 1;
+        if(o->min_opp_depth > 0 && s->var) {
+            uint32_t noff = s->var[i].noff, nvar = s->var[i].nvar;
             if(noff >= (uint32_t)o->min_opp_depth && ((double)nvar) / ((double)noff) >= o->max_variant_frac) {
                 p->n_variant_positions++;
                 if(o->merge && is_g) {

@@ -1,36 +1,49 @@
 // mdk_hip.hip -- MI355X (gfx950 / CDNA4) device library for the `MethylDackel extract` hot path.
 //
 // The reference sweeps a pileup buffer column by column (htslib bam_mplp64_auto driven from
-// extract.c:399-493) and, per column, loops over the reads covering it.  Every per-position output is a
-// plain sum over (read, aligned base) pairs, so on the GPU the same result is computed READ-parallel:
+// extract.c:399-493) and, per column, loops over the reads covering it.  Every per-position output is a plain
+// sum over (read, aligned base) pairs, so on the GPU the same result is computed READ-parallel, per tile of
+// reference positions, entirely inside one kernel launch per interval:
 //
-//   k_pileup  one workgroup per tile of reference positions.  The tile's context codes (common.c:49-82,
-//             precedence extract.c:407-418) are derived from the resident reference into LDS, the tile's
-//             counters live in LDS, and the 4 wavefronts of the workgroup stream the admitted reads that
-//             overlap the tile: one 64-lane wavefront per read, lanes laid along the read's M/=/X run so
-//             that consecutive lanes touch consecutive seq nibbles / qual bytes (coalesced) and consecutive
-//             LDS counters (conflict-free).  Per base: trimming (common.c:137-208) is a predicate on the
-//             query index, mate-overlap resolution (overlaps.c:54-119) is evaluated on the fly against the
-//             mate's base at the same reference position (nothing is written back, so a launch is
-//             idempotent), then getStrand/updateMetrics/isVariant arithmetic (common.c:118-134,
-//             extract.c:225-239,420-441) and an LDS atomic.  Tiles are compacted from LDS with wave ballots
-//             into a per-tile staging segment: no global atomics, deterministic output.
-//   k_scan    exclusive scan of the per-tile site counts.
-//   k_gather  packs the staged segments into ascending-position SoA site arrays.
+//   k_classify  (once per contig) context code of every reference position (common.c:49-82, precedence
+//               extract.c:407-418), 1 byte per base, resident in HBM next to the bases.
+//   k_pileup    one workgroup per tile.
+//                 1. the tile's context codes -> two sorted LDS lists (C positions, G positions) via wave
+//                    ballots; the tile's counters are zeroed in LDS;
+//                 2. every LANE owns one SEGMENT -- a gapless run of aligned bases; the host expands CIGARs once per
+//                    read (include/mdk_hip.h md_seg), so there is no CIGAR walk and no dependent pointer chase on the
+//                    device: a coalesced 32-byte record load, then bases.  The lane walks the slice of the C (OT/CTOT)
+//                    or G (OB/CTOB) list its segment covers, K positions at a time: all seq/qual bytes of the read AND
+//                    of its overlap partner are requested together, then used: trimming (common.c:137-208) is a
+//                    predicate on the query index, the mate overlap is resolved on the fly against the partner's base
+//                    at the same reference position (overlaps.c:54-119; nothing is written back, a launch is
+//                    idempotent), then the getStrand/updateMetrics/isVariant arithmetic (common.c:118-134,
+//                    extract.c:225-239,420-441) and an LDS atomic;
+//                 3. the tile is compacted from LDS with wave ballots and written as 16-byte site records into
+//                    a segment reserved with one atomic per tile.
+//               The workgroup keeps 256 reads in flight and needs ~13 KiB of LDS, so 8 workgroups (32 wavefronts)
+//               fit a CU and the per-read latency chain (header -> bases) is hidden by occupancy.
+//               (Measured and rejected, see DESIGN.md: a wavefront per read -- 192 us on S1, latency bound; staging
+//               each tile's read payload in LDS with LDS-DMA -- 43-62 us, 70 KiB per workgroup kills occupancy.)
 //
-// Integer/byte work, HBM-bound: no MFMA anywhere (see DESIGN.md for the roofline accounting).
+// Integer/byte work, HBM-bound: no MFMA anywhere (DESIGN.md has the roofline accounting).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#include <string.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 #include <algorithm>
 #include "mdk_hip.h"
 
-#define WG 256
+#define WG 512
 #define WAVES (WG / 64)
-#define DEFAULT_TILE 1024
+#define DEFAULT_TILE 2048
+#define PERMAX 4                   // reference positions owned by one thread: tile = WG * per, per <= PERMAX
+#define MAX_TILE (WG * PERMAX)
+#define RING 64                    // site counters: launch i uses counter i%RING and clears the next one
+#define LDS_LIMIT 163840          // 160 KiB per CU / per workgroup on gfx950
+#define DEFAULT_LDS_BUDGET 80896  // two workgroups per CU
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *what, hipError_t e) {
@@ -42,25 +55,21 @@ static int fail(int code, const char *what, hipError_t e) {
 // ------------------------------------------------------------------------------------------------
 // kernel parameters
 // ------------------------------------------------------------------------------------------------
+struct TileEnt { int first, last; };     // segments [first,last) of the batch overlap the tile (one contiguous run: the batch is coordinate sorted)
+
 struct KParams {
-    const md_read_hdr *hdr; const int32_t *mate; const uint8_t *blob;
-    const char *ref; int64_t reflen;
+    const md_seg *seg; const uint8_t *blob;
+    const uint8_t *ctxcode; int64_t reflen;
     int64_t beg, end; int tile, ntiles, nper;
-    const int32_t *tfirst, *tlast;
-    uint32_t *spos, *smeth, *sunmeth, *soff, *svar; uint8_t *smeta; uint32_t *tcnt;
-    int keepCpG, keepCHG, keepCHH, minPhred;
+    const TileEnt *tiles;
+    md_site *site; md_site_var *var; md_tile_seg *tseg; uint32_t *total, *total_next; int64_t cap_sites;
+    int keepmask, minPhred;
     int bounds[16], abounds[16];
     int *err;
+    unsigned long long *dbg;      // optional phase timestamps: 8 words per workgroup (MDK_PHASES=1)
 };
 
-struct RD {               // one read, wave-uniform
-    int pos, ncig, lq, strand, flags, lo, hi;
-    const uint32_t *cig; const uint8_t *seq, *qual;
-};
-
-__device__ __forceinline__ int is_mtype(int op) { return op == 0 || op == 7 || op == 8; }
-
-// kept query-index window [lo,hi) after --OT-style and --nOT-style trimming (common.c:137-208)
+// kept query-index window [lo,hi) of a read after --OT-style and --nOT-style trimming (common.c:137-208)
 __device__ __forceinline__ void trim_window(const KParams &P, int strand, int read2, int lq, int &lo, int &hi) {
     if(strand < 1) { lo = 0; hi = lq; return; }
     int b = 4 * (strand - 1) + (read2 ? 2 : 0);
@@ -72,229 +81,271 @@ __device__ __forceinline__ void trim_window(const KParams &P, int strand, int re
     if(lq - arb < hi) hi = lq - arb;
 }
 
-__device__ __forceinline__ RD load_rd(const KParams &P, int r) {
-    RD d; md_read_hdr h = P.hdr[r];
-    const uint8_t *pay = P.blob + 4ull * h.off4;
-    d.pos = h.pos; d.ncig = h.n_cigar; d.lq = (int)h.l_qseq; d.strand = h.strand; d.flags = h.flags;
-    d.cig = (const uint32_t *)pay;
-    d.seq = pay + 4 * d.ncig;
-    d.qual = d.seq + ((((d.lq + 1) >> 1) + 3) & ~3);
-    trim_window(P, d.strand, d.flags & MDK_RF_READ2, d.lq, d.lo, d.hi);
+struct RD {       // addressing of one read's payload + its trimming window
+    int lq, lo, hi;
+    const uint8_t *seq, *qual;
+};
+__device__ __forceinline__ RD make_rd(const KParams &P, uint32_t off4, uint32_t lq, int strand, int read2) {
+    RD d; d.lq = (int)lq;
+    d.seq = P.blob + 4ull * off4; d.qual = d.seq + ((((d.lq + 1) >> 1) + 3) & ~3);
+    trim_window(P, strand, read2, d.lq, d.lo, d.hi);
     return d;
-}
-
-__device__ __forceinline__ void fetch_bq(const RD &d, int q, int &b, int &ql) {
-    if(q < d.lo || q >= d.hi) { b = 15; ql = 0; return; }     // trimmed: base N, qual 0
-    uint8_t sb = d.seq[q >> 1];
-    b = (q & 1) ? (sb & 15) : (sb >> 4);
-    ql = d.qual[q];
-}
-
-// the mate's (base, qual) at reference position p, if p falls in an M/=/X run of the mate
-__device__ __forceinline__ bool mate_at(const RD &m, int p, int &mb, int &mq) {
-    int x = m.pos, y = 0; bool found = false; int q = 0;
-    for(int k = 0; k < m.ncig; k++) {
-        uint32_t c = m.cig[k]; int op = c & 15, len = (int)(c >> 4);
-        if(is_mtype(op)) { if(!found && p >= x && p < x + len) { q = y + (p - x); found = true; } x += len; y += len; }
-        else if(op == 1 || op == 4) y += len;
-        else if(op == 2 || op == 3) x += len;
-    }
-    if(found && q < m.lq) fetch_bq(m, q, mb, mq); else found = false;
-    return found;
 }
 
 // (uint8_t)(q + 0.2*q) as evaluated by the reference on x86-64 (overlaps.c:103,106): floor(6q/5) mod 256.
 // md_dev_open checks this identity against the C expression for all 256 values.
 __device__ __forceinline__ int boost(int q) { return ((q * 6) / 5) & 255; }
 
-// effective (base, qual) of query base q (reference position p) of read o after trimming and, when the read
-// has an overlap-resolution partner, after cust_tweak_overlap_quality (overlaps.c:81-114)
-__device__ __forceinline__ void effective_bq(const RD &o, bool hasMate, const RD &m, int p, int q, int &b, int &ql) {
-    fetch_bq(o, q, b, ql);
-    if(hasMate) {
-        int mb, mq;
-        if(mate_at(m, p, mb, mq)) {
-            bool second = (o.flags & MDK_RF_SECOND) != 0;      // 'a' = earlier in file, 'b' = later
-            int ba = second ? mb : b, qa = second ? mq : ql, bb = second ? b : mb, qb = second ? ql : mq;
-            if(ba != bb) {
-                if(qa > qb && ba != 15) { qa -= qb; qb = 0; }
-                else if(qb > qa && bb != 15) { qb -= qa; qa = 0; }
-                else { qa = 0; qb = 0; }
-            } else {
-                if(qa > qb) { qa = boost(qa); qb = 0; }
-                else { qb = boost(qb); qa = 0; }
+// cust_tweak_overlap_quality for one matched pair of bases (overlaps.c:90-109); a = earlier in file
+__device__ __forceinline__ int resolve_overlap(bool ownIsSecond, int b, int ql, int mb, int mq) {
+    int ba = ownIsSecond ? mb : b, qa = ownIsSecond ? mq : ql, bb = ownIsSecond ? b : mb, qb = ownIsSecond ? ql : mq;
+    if(ba != bb) {
+        if(qa > qb && ba != 15) { qa -= qb; qb = 0; }
+        else if(qb > qa && bb != 15) { qb -= qa; qa = 0; }
+        else { qa = 0; qb = 0; }
+    } else {
+        if(qa > qb) { qa = boost(qa); qb = 0; } else { qb = boost(qb); qa = 0; }
+    }
+    return ownIsSecond ? qb : qa;
+}
+
+// context code of a reference position: 0 = not C/G, else 1 + 2*type + isG (type 0 CpG, 1 CHG, 2 CHH).
+// (x & 0x5f) folds 'c'->'C', 'g'->'G' and maps no other FASTA letter onto C or G.
+__global__ __launch_bounds__(WG) void k_classify(const char *ref, uint8_t *code, int64_t n) {
+    for(int64_t p = (int64_t)blockIdx.x * WG + threadIdx.x; p < n; p += (int64_t)gridDim.x * WG) {
+        char c = ref[p] & 0x5f; int type, isG, out = 0;
+        if(c == 'C') {
+            isG = 0;
+            if(p + 1 < n && (ref[p + 1] & 0x5f) == 'G') type = 0;
+            else if(p + 2 < n && (ref[p + 2] & 0x5f) == 'G') type = 1;
+            else type = 2;
+            out = 1 + 2 * type + isG;
+        } else if(c == 'G') {
+            isG = 1;
+            if(p > 0 && (ref[p - 1] & 0x5f) == 'C') type = 0;
+            else if(p > 1 && (ref[p - 2] & 0x5f) == 'C') type = 1;
+            else type = 2;
+            out = 1 + 2 * type + isG;
+        }
+        code[p] = (uint8_t)out;
+    }
+}
+
+#define KB 4      // positions per batch: their base/qual bytes (own + partner) are all in flight together
+
+// One segment, one lane.
+template <bool VARIANT>
+__device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int T0, int T1,
+                                         const uint16_t *listC, int nC, const uint16_t *listG, int nG,
+                                         uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv) {
+    const int send = g.rpos + (int)g.len;
+    if(g.rpos >= T1 || send <= T0) return;                        // inside the tile's run but not on the tile
+    const int strand = g.sf & MDK_SF_STRAND;
+    const bool odd = strand & 1, second = (g.sf & MDK_SF_SECOND) != 0, partner = (g.sf & MDK_SF_PARTNER) != 0;
+    const RD o = make_rd(P, g.off4, g.l_qseq, strand, g.sf & MDK_SF_READ2);
+    RD m = o;
+    if(partner) m = make_rd(P, g.m_off4, g.m_l_qseq, g.msf & MDK_SF_STRAND, g.msf & MDK_SF_READ2);
+    const int lo_off = g.rpos > T0 ? g.rpos - T0 : 0, hi_off = (send < T1 ? send : T1) - T0;   // tile offsets covered
+#pragma unroll
+    for(int pass = 0; pass < (VARIANT ? 2 : 1); pass++) {
+        const bool callpass = pass == 0;
+        const bool useC = (odd == callpass);      // calls: OT/CTOT on C, OB/CTOB on G; opposite-strand evidence: the other list
+        const uint16_t *list = useC ? listC : listG; const int n = useC ? nC : nG;
+        int a = 0, b = n;
+        while(a < b) { int mid = (a + b) >> 1; if((int)(list[mid] & 0x1fff) < lo_off) a = mid + 1; else b = mid; }
+        int i = a;
+        while(i < n) {
+            // 1. which positions (no base has been touched yet)
+            int li[KB];
+#pragma unroll
+            for(int k = 0; k < KB; k++) {
+                li[k] = -1;
+                if(i < n) { const int l = list[i] & 0x1fff; if(l < hi_off) { li[k] = l; i++; } else i = n; }
             }
-            ql = second ? qb : qa;
+            if(li[0] < 0) break;
+            // 2. request every byte the batch needs (trimmed bases need none: they read as N with quality 0)
+            uint32_t sb[KB], qb[KB], msb[KB], mqb[KB];
+#pragma unroll
+            for(int k = 0; k < KB; k++) {
+                sb[k] = 0xff; qb[k] = 0; msb[k] = 0xff; mqb[k] = 0;
+                if(li[k] >= 0) {
+                    const int d = T0 + li[k] - g.rpos, q = (int)g.q0 + d, mq = (int)g.m_q0 + d;
+                    if(q >= o.lo && q < o.hi) { sb[k] = o.seq[q >> 1]; qb[k] = o.qual[q]; }
+                    if(partner && mq >= m.lo && mq < m.hi) { msb[k] = m.seq[mq >> 1]; mqb[k] = m.qual[mq]; }
+                }
+            }
+            // 3. use them
+#pragma unroll
+            for(int k = 0; k < KB; k++) {
+                if(li[k] < 0) continue;
+                const int d = T0 + li[k] - g.rpos, q = (int)g.q0 + d, mq = (int)g.m_q0 + d;
+                int bq = (q & 1) ? (sb[k] & 15) : (sb[k] >> 4), ql = (int)qb[k];
+                if(partner) { int mb = (mq & 1) ? (msb[k] & 15) : (msb[k] >> 4); ql = resolve_overlap(second, bq, ql, mb, (int)mqb[k]); }
+                if(callpass) {
+                    if(strand == 0) atomicExch(P.err, 1);                 // reference: assert(strand != 0) (common.c:122-125)
+                    if(ql >= P.minPhred) {
+                        if(odd) { if(bq == 2) atomicAdd(&cm[li[k]], 1u); else if(bq == 8) atomicAdd(&cu[li[k]], 1u); }
+                        else { if(bq == 4) atomicAdd(&cm[li[k]], 1u); else if(bq == 1) atomicAdd(&cu[li[k]], 1u); }
+                    }
+                } else if(VARIANT) {
+                    if(ql >= P.minPhred) {
+                        atomicAdd(&co[li[k]], 1u);
+                        if(odd ? (bq != 4 && bq != 15) : (bq != 2 && bq != 15)) atomicAdd(&cv[li[k]], 1u);
+                    }
+                }
+            }
         }
     }
 }
 
-// context code of reference position p: 0 = not a kept C/G, else 1 + 2*type + isG (type 0 CpG, 1 CHG, 2 CHH)
-__device__ __forceinline__ int context_code(const KParams &P, int64_t p) {
-    char c = P.ref[p] & 0x5f; int type, isG;
-    if(c == 'C') {
-        isG = 0;
-        if(p + 1 < P.reflen && (P.ref[p + 1] & 0x5f) == 'G') type = 0;
-        else if(p + 2 < P.reflen && (P.ref[p + 2] & 0x5f) == 'G') type = 1;
-        else type = 2;
-    } else if(c == 'G') {
-        isG = 1;
-        if(p > 0 && (P.ref[p - 1] & 0x5f) == 'C') type = 0;
-        else if(p > 1 && (P.ref[p - 2] & 0x5f) == 'C') type = 1;
-        else type = 2;
-    } else return 0;
-    if(type == 0 ? !P.keepCpG : type == 1 ? !P.keepCHG : !P.keepCHH) return 0;
-    return 1 + 2 * type + isG;
-}
+// barrier that orders LDS traffic only (does not drain this wave's outstanding global loads)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// NB (P.ref[x] & 0x5f) maps 'c'->'C', 'g'->'G' and no other FASTA letter onto C/G.
+// inclusive scan over the 64 lanes of a wavefront
+__device__ __forceinline__ int wave_scan_incl(int v, int lane) {
+#pragma unroll
+    for(int d = 1; d < 64; d <<= 1) { int n = __shfl_up(v, d); if(lane >= d) v += n; }
+    return v;
+}
 
 template <bool VARIANT>
 __global__ __launch_bounds__(WG) void k_pileup(const KParams P) {
     extern __shared__ __align__(16) uint32_t lds[];
-    const int TILE = P.tile;
+    const int TILE = P.tile, PER = TILE / WG;
     uint32_t *cm = lds, *cu = lds + TILE, *co = lds + 2 * TILE, *cv = lds + 3 * TILE;
-    uint8_t *ctx = (uint8_t *)(lds + (VARIANT ? 4 : 2) * TILE);
+    uint16_t *listC = (uint16_t *)(lds + (VARIANT ? 4 : 2) * TILE), *listG = listC + TILE;
     __shared__ int wsum[WAVES];
+    __shared__ uint32_t sbase;
 
-    // XCD-aware tile assignment: workgroup b runs on XCD b%8 (observed dispatch order); give every XCD a
-    // contiguous run of tiles so that halo reads and mates are shared through one L2.
     const int b = blockIdx.x;
-    const int t = (b & 7) * P.nper + (b >> 3);
+    const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
     if(t >= P.ntiles) return;
     const int64_t T0 = P.beg + (int64_t)t * TILE;
     const int64_t T1 = (T0 + TILE < P.end) ? T0 + TILE : P.end;
     const int tlen = (int)(T1 - T0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if(b == 0 && tid == 0) *P.total_next = 0;    // the counter the NEXT launch on this stream will use
 
-    for(int i = tid; i < TILE; i += WG) {
-        int64_t p = T0 + i;
-        ctx[i] = (i < tlen && p < P.reflen) ? (uint8_t)context_code(P, p) : 0;
-        cm[i] = 0; cu[i] = 0;
-        if(VARIANT) { co[i] = 0; cv[i] = 0; }
+    unsigned long long tr0 = 0, tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
+    if(P.dbg) { tr0 = wall_clock64(); tc0 = clock64(); }
+    // everything this thread needs from HBM before it can start is requested up front, in one round:
+    // the context codes of the PER consecutive positions it owns, and its first segment record
+    const TileEnt te = P.tiles[t];
+    const int first = te.first, last = te.last;
+    int code[PERMAX];
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++) {
+        const int i = tid * PER + j; const int64_t p = T0 + i;
+        code[j] = (j < PER && i < tlen && p < P.reflen) ? P.ctxcode[p] : 0;
+    }
+    md_seg g0; g0.rpos = 0x7fffffff; g0.len = 0;
+    if(first + tid < last) g0 = P.seg[first + tid];
+
+    // phase 1: sorted C / G position lists (wave scan + one cross-wave exchange), counters zeroed
+    int cntC = 0, cntG = 0;
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++) {
+        if(j < PER) {
+            const int i = tid * PER + j;
+            if(code[j] && !((P.keepmask >> ((code[j] - 1) >> 1)) & 1)) code[j] = 0;
+            cm[i] = 0; cu[i] = 0;
+            if(VARIANT) { co[i] = 0; cv[i] = 0; }
+            if(code[j]) { if((code[j] - 1) & 1) cntG++; else cntC++; }
+        }
+    }
+    int nC, nG;
+    {
+        const int packed = cntC | (cntG << 16), incl = wave_scan_incl(packed, lane);
+        if(lane == 63) wsum[wave] = incl;
+        lds_barrier();
+        int pre = incl - packed, tot = 0;
+        for(int w = 0; w < WAVES; w++) { const int c = wsum[w]; if(w < wave) pre += c; tot += c; }
+        nC = tot & 0xffff; nG = tot >> 16;
+        int oc = pre & 0xffff, og = pre >> 16;
+#pragma unroll
+        for(int j = 0; j < PERMAX; j++) {
+            if(j < PER && code[j]) {
+                const uint16_t ent = (uint16_t)((tid * PER + j) | (((code[j] - 1) >> 1) << 13));
+                if((code[j] - 1) & 1) listG[og++] = ent; else listC[oc++] = ent;
+            }
+        }
+        lds_barrier();
+    }
+    if(P.dbg) tc1 = clock64();
+
+    // phase 2: one segment per lane, WG segments per round
+    if(first + tid < last) lane_seg<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
+    for(int r = first + WG + tid; r < last; r += WG) {
+        const md_seg g = P.seg[r];
+        lane_seg<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
+    }
+    if(P.dbg) tc2 = clock64();
+    __syncthreads();
+    if(P.dbg) tc3 = clock64();
+
+    // phase 3: compaction.  Every thread packs the positions it owns; one atomic reserves the tile's segment;
+    // 16-byte site records are written in ascending position order.
+    uint32_t vm[PERMAX], vu[PERMAX], vo[PERMAX], vv[PERMAX]; int cnt = 0;
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++) {
+        vm[j] = vu[j] = vo[j] = vv[j] = 0;
+        const int i = tid * PER + j;
+        if(j < PER && i < tlen && code[j]) { vm[j] = cm[i]; vu[j] = cu[i]; if(VARIANT) { vo[j] = co[i]; vv[j] = cv[i]; } }
+        if((vm[j] + vu[j]) > 0 || vo[j] > 0) cnt++;
+    }
+    const int incl = wave_scan_incl(cnt, lane);
+    if(lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if(tid == 0) {
+        int tot = 0; for(int w = 0; w < WAVES; w++) tot += wsum[w];
+        const uint32_t base = tot ? atomicAdd(P.total, (uint32_t)tot) : 0u;
+        sbase = base;
+        md_tile_seg sg; sg.off = base; sg.cnt = (uint32_t)tot; P.tseg[t] = sg;
     }
     __syncthreads();
-
-    const int first = P.tfirst[t], last = P.tlast[t];
-    for(int r0 = first + wave; r0 < last; r0 += WAVES) {
-        const int r = __builtin_amdgcn_readfirstlane(r0);
-        RD o = load_rd(P, r);
-        if(o.pos >= T1) continue;
-        int mi = P.mate[r]; bool hasMate = mi >= 0; RD m = o;
-        if(hasMate) { m = load_rd(P, mi); if(((o.strand - m.strand) & 1) != 0) hasMate = false; }
-        const bool odd = o.strand & 1;
-        int x = o.pos, y = 0;
-        for(int k = 0; k < o.ncig; k++) {
-            uint32_t c = o.cig[k]; int op = c & 15, len = (int)(c >> 4);
-            if(is_mtype(op)) {
-                int j0 = (T0 > x) ? (int)(T0 - x) : 0;
-                int j1 = ((int64_t)x + len > T1) ? (int)(T1 - x) : len;
-                if(o.lq - y < j1) j1 = o.lq - y;               // malformed CIGAR guard
-                for(int jb = j0; jb < j1; jb += 64) {
-                    int j = jb + lane;
-                    if(j < j1) {
-                        int p = x + j, q = y + j, li = (int)(p - T0);
-                        int cc = ctx[li];
-                        if(cc) {
-                            bool isG = (cc - 1) & 1;
-                            bool callpath = (odd != isG);       // OT/CTOT on a C, OB/CTOB on a G
-                            if(callpath) {
-                                if(o.strand == 0) atomicExch(P.err, 1);   // reference: assert(strand != 0)
-                                int bq, ql; effective_bq(o, hasMate, m, p, q, bq, ql);
-                                if(ql >= P.minPhred) {
-                                    if(odd) { if(bq == 2) atomicAdd(&cm[li], 1u); else if(bq == 8) atomicAdd(&cu[li], 1u); }
-                                    else { if(bq == 4) atomicAdd(&cm[li], 1u); else if(bq == 1) atomicAdd(&cu[li], 1u); }
-                                }
-                            } else if(VARIANT) {
-                                int bq, ql; effective_bq(o, hasMate, m, p, q, bq, ql);
-                                if(ql >= P.minPhred) {
-                                    atomicAdd(&co[li], 1u);
-                                    if(odd ? (bq != 4 && bq != 15) : (bq != 2 && bq != 15)) atomicAdd(&cv[li], 1u);
-                                }
-                            }
-                        }
-                    }
+    {
+        uint32_t o = sbase + (uint32_t)(incl - cnt);
+        for(int w = 0; w < wave; w++) o += (uint32_t)wsum[w];
+#pragma unroll
+        for(int j = 0; j < PERMAX; j++) {
+            if((vm[j] + vu[j]) > 0 || vo[j] > 0) {
+                if((int64_t)o < P.cap_sites) {
+                    md_site rec; rec.pos = (uint32_t)(T0 + tid * PER + j); rec.nmeth = vm[j]; rec.nunmeth = vu[j]; rec.meta = (uint32_t)(code[j] - 1);
+                    P.site[o] = rec;
+                    if(VARIANT) { md_site_var rv; rv.noff = vo[j]; rv.nvar = vv[j]; P.var[o] = rv; }
                 }
-                x += len; y += len;
-            } else if(op == 1 || op == 4) y += len;
-            else if(op == 2 || op == 3) x += len;
-            if(x >= T1) break;
+                o++;
+            }
         }
     }
-    __syncthreads();
-
-    // compaction: positions with any evidence, ascending, into this tile's staging segment
-    int base = 0; const size_t seg = (size_t)t * TILE;
-    for(int s0 = 0; s0 < tlen; s0 += WG) {
-        int i = s0 + tid; bool nz = false; uint32_t vm = 0, vu = 0, vo = 0, vv = 0;
-        if(i < tlen) { vm = cm[i]; vu = cu[i]; if(VARIANT) { vo = co[i]; vv = cv[i]; } nz = (vm + vu) > 0 || vo > 0; }
-        unsigned long long bal = __ballot(nz);
-        int wcnt = __popcll(bal), wpre = __popcll(bal & ((1ull << lane) - 1ull));
-        if(lane == 0) wsum[wave] = wcnt;
-        __syncthreads();
-        int pre = base, tot = 0;
-        for(int w = 0; w < WAVES; w++) { int c = wsum[w]; if(w < wave) pre += c; tot += c; }
-        if(nz) {
-            size_t o = seg + pre + wpre;
-            P.spos[o] = (uint32_t)(T0 + i); P.smeth[o] = vm; P.sunmeth[o] = vu; P.smeta[o] = (uint8_t)(ctx[i] - 1);
-            if(VARIANT) { P.soff[o] = vo; P.svar[o] = vv; }
-        }
-        base += tot;
-        __syncthreads();
-    }
-    if(tid == 0) P.tcnt[t] = (uint32_t)base;
-}
-
-// exclusive scan of tcnt[0..n) -> toff, total; one workgroup of 1024 threads, chunked
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t *tcnt, uint32_t *toff, uint32_t *total, int n) {
-    __shared__ uint32_t part[1024];
-    int tid = threadIdx.x, per = (n + 1023) / 1024, lo = tid * per, hi = lo + per < n ? lo + per : n;
-    uint32_t s = 0;
-    for(int i = lo; i < hi; i++) s += tcnt[i];
-    part[tid] = s; __syncthreads();
-    for(int d = 1; d < 1024; d <<= 1) { uint32_t v = tid >= d ? part[tid - d] : 0; __syncthreads(); part[tid] += v; __syncthreads(); }
-    uint32_t run = part[tid] - s;
-    for(int i = lo; i < hi; i++) { toff[i] = run; run += tcnt[i]; }
-    if(tid == 1023) *total = part[1023];
-}
-
-struct GParams {
-    const uint32_t *spos, *smeth, *sunmeth, *soff, *svar; const uint8_t *smeta;
-    uint32_t *pos, *meth, *unmeth, *off, *var; uint8_t *meta;
-    const uint32_t *tcnt, *toff; int tile, ntiles; int64_t cap;
-};
-__global__ __launch_bounds__(WG) void k_gather(const GParams G) {
-    for(int t = blockIdx.x; t < G.ntiles; t += gridDim.x) {
-        uint32_t n = G.tcnt[t], o = G.toff[t]; size_t seg = (size_t)t * G.tile;
-        for(uint32_t i = threadIdx.x; i < n; i += WG) {
-            if((int64_t)(o + i) >= G.cap) break;
-            G.pos[o + i] = G.spos[seg + i]; G.meth[o + i] = G.smeth[seg + i]; G.unmeth[o + i] = G.sunmeth[seg + i];
-            G.meta[o + i] = G.smeta[seg + i];
-            if(G.off) { G.off[o + i] = G.soff[seg + i]; G.var[o + i] = G.svar[seg + i]; }
+    if(P.dbg) {
+        tc4 = clock64();
+        if(lane == 0) {
+            unsigned long long *d = P.dbg + ((size_t)b * WAVES + wave) * 8;
+            d[0] = tr0; d[1] = wall_clock64(); d[2] = tc1 - tc0; d[3] = tc2 - tc1; d[4] = tc3 - tc2; d[5] = tc4 - tc3; d[6] = (unsigned long long)(last - first); d[7] = (unsigned long long)t;
         }
     }
 }
 
-// test hook: effective base/qual of every query base (one wavefront per read)
-__global__ __launch_bounds__(WG) void k_debug_effective(const KParams P, int n_reads, uint8_t *ob, uint8_t *oq, const uint64_t *ooff) {
+// test hook: effective (post-trim, post-overlap-resolution) base and quality of every base of every segment,
+// one lane per base: out[ooff[s] + j] for base j of segment s
+__global__ __launch_bounds__(WG) void k_debug_effective(const KParams P, int n_segs, uint8_t *ob, uint8_t *oq, const uint64_t *ooff) {
     int lane = threadIdx.x & 63;
-    for(int r0 = blockIdx.x * WAVES + (threadIdx.x >> 6); r0 < n_reads; r0 += gridDim.x * WAVES) {
-        int r = __builtin_amdgcn_readfirstlane(r0);
-        RD o = load_rd(P, r);
-        int mi = P.mate[r]; bool hasMate = mi >= 0; RD m = o;
-        if(hasMate) { m = load_rd(P, mi); if(((o.strand - m.strand) & 1) != 0) hasMate = false; }
-        uint64_t base = ooff[r];
-        int x = o.pos, y = 0;
-        for(int k = 0; k < o.ncig; k++) {
-            uint32_t c = o.cig[k]; int op = c & 15, len = (int)(c >> 4);
-            if(is_mtype(op) || op == 1 || op == 4) {
-                for(int j = lane; j < len && y + j < o.lq; j += 64) {
-                    int bq, ql;
-                    if(is_mtype(op)) effective_bq(o, hasMate, m, x + j, y + j, bq, ql); else fetch_bq(o, y + j, bq, ql);
-                    ob[base + y + j] = (uint8_t)bq; oq[base + y + j] = (uint8_t)ql;
-                }
-                y += len; if(is_mtype(op)) x += len;
-            } else if(op == 2 || op == 3) x += len;
+    for(int s0 = blockIdx.x * WAVES + (threadIdx.x >> 6); s0 < n_segs; s0 += gridDim.x * WAVES) {
+        const int si = __builtin_amdgcn_readfirstlane(s0);
+        const md_seg g = P.seg[si];
+        const int strand = g.sf & MDK_SF_STRAND; const bool second = (g.sf & MDK_SF_SECOND) != 0, partner = (g.sf & MDK_SF_PARTNER) != 0;
+        const RD o = make_rd(P, g.off4, g.l_qseq, strand, g.sf & MDK_SF_READ2);
+        RD m = o; if(partner) m = make_rd(P, g.m_off4, g.m_l_qseq, g.msf & MDK_SF_STRAND, g.msf & MDK_SF_READ2);
+        for(int j = lane; j < (int)g.len; j += 64) {
+            int q = (int)g.q0 + j, mq = (int)g.m_q0 + j, bq = 15, ql = 0;
+            if(q >= o.lo && q < o.hi) { uint32_t sb = o.seq[q >> 1]; bq = (q & 1) ? (sb & 15) : (sb >> 4); ql = o.qual[q]; }
+            if(partner) {
+                int mb = 15, mqv = 0;
+                if(mq >= m.lo && mq < m.hi) { uint32_t sb = m.seq[mq >> 1]; mb = (mq & 1) ? (sb & 15) : (sb >> 4); mqv = m.qual[mq]; }
+                ql = resolve_overlap(second, bq, ql, mb, mqv);
+            }
+            ob[ooff[si] + j] = (uint8_t)bq; oq[ooff[si] + j] = (uint8_t)ql;
         }
     }
 }
@@ -331,21 +382,20 @@ template <typename T> struct HBuf {
 
 struct Slot {
     hipStream_t stream = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
-    DBuf<md_read_hdr> d_hdr; DBuf<int32_t> d_mate; DBuf<uint8_t> d_blob;
-    DBuf<int32_t> d_tfirst, d_tlast; HBuf<int32_t> h_tfirst, h_tlast;
-    DBuf<uint32_t> d_spos, d_smeth, d_sunmeth, d_soff, d_svar; DBuf<uint8_t> d_smeta;
-    DBuf<uint32_t> d_tcnt, d_toff, d_total;
-    DBuf<uint32_t> d_pos, d_meth, d_unmeth, d_off, d_var; DBuf<uint8_t> d_meta;
-    HBuf<uint32_t> h_pos, h_meth, h_unmeth, h_off, h_var, h_total; HBuf<uint8_t> h_meta; HBuf<int> h_err;
-    DBuf<int> d_err;
-    int n_reads = 0, ntiles = 0, tid = -1; int64_t beg = 0, end = 0; uint64_t read_bytes = 0;
-    bool uploaded = false, launched = false;
+    DBuf<md_seg> d_seg_in; DBuf<uint8_t> d_blob;
+    DBuf<TileEnt> d_tiles; HBuf<TileEnt> h_tiles;
+    DBuf<md_site> d_site; DBuf<md_site_var> d_var; DBuf<md_tile_seg> d_seg; DBuf<uint32_t> d_total; DBuf<int> d_err;
+    HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; HBuf<uint32_t> h_total; HBuf<int> h_err;
+    // caller-bound output (device memory owned by the caller)
+    md_site *b_site = nullptr; md_site_var *b_var = nullptr; md_tile_seg *b_seg = nullptr; int64_t b_cap_sites = 0, b_cap_tiles = 0;
+    int n_segs = 0, n_reads = 0, ntiles = 0, tid = -1, tile = 0, paycap = 0, lds_bytes = 0, n_staged = 0; int64_t beg = 0, end = 0; uint64_t read_bytes = 0;
+    bool uploaded = false, launched = false; unsigned ring = 0;
 };
 
 struct md_dev {
-    int device; md_dev_cfg cfg; int tile, n_slots; bool variant;
+    int device; md_dev_cfg cfg; int tile, n_slots, force_global, lds_budget; bool variant, tile_fixed;
     std::vector<Slot> slots;
-    std::vector<char *> ref; std::vector<int64_t> reflen;
+    std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
 };
 
 extern "C" const char *md_dev_last_error(void) { return g_err; }
@@ -355,6 +405,8 @@ extern "C" int md_dev_count(void) {
     if(e != hipSuccess) { fail(MDK_ERR_NODEVICE, "hipGetDeviceCount", e); return MDK_ERR_NODEVICE; }
     return n;
 }
+
+static int fixed_lds(int tile, bool variant) { return tile * ((variant ? 16 : 8) + 4); }
 
 extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     if(!cfg || !out) return fail(MDK_ERR_ARG, "md_dev_open", hipSuccess);
@@ -370,17 +422,25 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     HIPCHK(hipSetDevice(device));
     md_dev *h = new md_dev();
     h->device = device; h->cfg = *cfg;
+    h->tile_fixed = cfg->tile > 0;
     h->tile = cfg->tile > 0 ? cfg->tile : DEFAULT_TILE;
     h->tile = (h->tile + WG - 1) / WG * WG;
-    if(h->tile > 8192) h->tile = 8192;
+    if(h->tile > MAX_TILE) h->tile = MAX_TILE;
     h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2;
     h->variant = cfg->minOppositeDepth > 0;
+    h->force_global = 0; h->lds_budget = 0;
+    while(fixed_lds(h->tile, h->variant) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
+    if(fixed_lds(h->tile, h->variant) > 65536) {    // more than the default dynamic-LDS window: opt in
+        if(h->variant) HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true)));
+        else HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false)));
+    }
     h->slots.resize(h->n_slots);
     for(auto &s : h->slots) {
         HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&s.e0)); HIPCHK(hipEventCreate(&s.e1)); HIPCHK(hipEventCreate(&s.k0)); HIPCHK(hipEventCreate(&s.k1));
-        if(s.d_err.need(1) || s.h_err.need(1) || s.d_total.need(1) || s.h_total.need(1)) return MDK_ERR_NOMEM;
+        if(s.d_err.need(1) || s.h_err.need(1) || s.d_total.need(RING) || s.h_total.need(1)) return MDK_ERR_NOMEM;
         HIPCHK(hipMemset(s.d_err.p, 0, sizeof(int)));
+        HIPCHK(hipMemset(s.d_total.p, 0, sizeof(uint32_t) * RING));
     }
     *out = h;
     return 0;
@@ -391,16 +451,14 @@ extern "C" void md_dev_close(md_dev *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for(auto &s : h->slots) {
-        s.d_hdr.release(); s.d_mate.release(); s.d_blob.release(); s.d_tfirst.release(); s.d_tlast.release(); s.h_tfirst.release(); s.h_tlast.release();
-        s.d_spos.release(); s.d_smeth.release(); s.d_sunmeth.release(); s.d_soff.release(); s.d_svar.release(); s.d_smeta.release();
-        s.d_tcnt.release(); s.d_toff.release(); s.d_total.release();
-        s.d_pos.release(); s.d_meth.release(); s.d_unmeth.release(); s.d_off.release(); s.d_var.release(); s.d_meta.release();
-        s.h_pos.release(); s.h_meth.release(); s.h_unmeth.release(); s.h_off.release(); s.h_var.release(); s.h_total.release(); s.h_meta.release();
-        s.h_err.release(); s.d_err.release();
+        s.d_seg_in.release(); s.d_blob.release(); s.d_tiles.release(); s.h_tiles.release();
+        s.d_site.release(); s.d_var.release(); s.d_seg.release(); s.d_total.release(); s.d_err.release();
+        s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release(); s.h_total.release(); s.h_err.release();
         if(s.e0) (void)hipEventDestroy(s.e0); if(s.e1) (void)hipEventDestroy(s.e1); if(s.k0) (void)hipEventDestroy(s.k0); if(s.k1) (void)hipEventDestroy(s.k1);
         if(s.stream) (void)hipStreamDestroy(s.stream);
     }
     for(char *p : h->ref) if(p) (void)hipFree(p);
+    for(uint8_t *p : h->refcode) if(p) (void)hipFree(p);
     delete h;
 }
 
@@ -409,90 +467,110 @@ extern "C" int md_dev_tile(const md_dev *h) { return h ? h->tile : MDK_ERR_ARG; 
 extern "C" int md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int64_t len) {
     if(!h || tid < 0 || !seq || len < 0) return fail(MDK_ERR_ARG, "md_dev_set_reference", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
-    if((size_t)tid >= h->ref.size()) { h->ref.resize(tid + 1, nullptr); h->reflen.resize(tid + 1, 0); }
+    if((size_t)tid >= h->ref.size()) { h->ref.resize(tid + 1, nullptr); h->refcode.resize(tid + 1, nullptr); h->reflen.resize(tid + 1, 0); }
     if(h->ref[tid]) { (void)hipFree(h->ref[tid]); h->ref[tid] = nullptr; }
-    char *d = nullptr;
+    if(h->refcode[tid]) { (void)hipFree(h->refcode[tid]); h->refcode[tid] = nullptr; }
+    char *d = nullptr; uint8_t *c = nullptr;
     hipError_t e = hipMalloc((void **)&d, (size_t)len + 16);
     if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(reference)", e);
+    e = hipMalloc((void **)&c, (size_t)len + 16);
+    if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_NOMEM, "hipMalloc(reference codes)", e); }
     HIPCHK(hipMemcpy(d, seq, (size_t)len, hipMemcpyHostToDevice));
-    h->ref[tid] = d; h->reflen[tid] = len;
+    if(len > 0) {
+        int64_t blocks = (len + WG - 1) / WG; if(blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(k_classify, dim3((unsigned)blocks), dim3(WG), 0, 0, d, c, len);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+    }
+    h->ref[tid] = d; h->refcode[tid] = c; h->reflen[tid] = len;
     return 0;
 }
 
 static Slot *get_slot(md_dev *h, int slot) { if(!h || slot < 0 || slot >= h->n_slots) { fail(MDK_ERR_ARG, "bad slot", hipSuccess); return nullptr; } return &h->slots[slot]; }
 
-extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
-    Slot *s = get_slot(h, slot);
-    if(!s || !b || b->n_reads < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_upload", hipSuccess);
-    if(b->n_reads && (!b->hdr || !b->rend || !b->mate || !b->blob)) return fail(MDK_ERR_ARG, "md_dev_upload: null array", hipSuccess);
-    if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(g_err, sizeof(g_err), "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(s->stream));          // the slot's previous contents are being replaced
-    const int TILE = h->tile; const int64_t span = b->end - b->beg;
-    const int ntiles = (int)((span + TILE - 1) / TILE);
-    s->n_reads = b->n_reads; s->ntiles = ntiles; s->tid = b->tid; s->beg = b->beg; s->end = b->end;
-    s->uploaded = false; s->launched = false;
-    size_t nr = (size_t)b->n_reads, nt = (size_t)(ntiles > 0 ? ntiles : 1);
-    if(s->d_hdr.need(nr + 1) || s->d_mate.need(nr + 1) || s->d_blob.need((size_t)b->blob_bytes + 16)) return MDK_ERR_NOMEM;
-    if(s->d_tfirst.need(nt) || s->d_tlast.need(nt) || s->h_tfirst.need(nt) || s->h_tlast.need(nt)) return MDK_ERR_NOMEM;
-    if(s->d_tcnt.need(nt) || s->d_toff.need(nt)) return MDK_ERR_NOMEM;
-    size_t stg = (size_t)nt * TILE;
-    if(s->d_spos.need(stg) || s->d_smeth.need(stg) || s->d_sunmeth.need(stg) || s->d_smeta.need(stg)) return MDK_ERR_NOMEM;
-    if(h->variant && (s->d_soff.need(stg) || s->d_svar.need(stg))) return MDK_ERR_NOMEM;
-    // read index range per tile (reads are coordinate sorted, so each tile sees one contiguous run;
-    // reads inside the run that end before the tile are skipped by the kernel)
-    for(int t = 0; t < ntiles; t++) { s->h_tfirst.p[t] = 0x7fffffff; s->h_tlast.p[t] = 0; }
-    uint64_t rbytes = 0;
-    for(int i = 0; i < b->n_reads; i++) {
-        const md_read_hdr &hd = b->hdr[i];
-        rbytes += 16 + 4ull * hd.n_cigar + (hd.l_qseq + 1) / 2 + hd.l_qseq;
-        int64_t lo = hd.pos, hi = b->rend[i];
+// segment run of every tile
+static void build_tiles(const md_read_batch *b, int TILE, TileEnt *te, int ntiles) {
+    for(int t = 0; t < ntiles; t++) { te[t].first = 0x7fffffff; te[t].last = 0; }
+    for(int i = 0; i < b->n_segs; i++) {
+        int64_t lo = b->seg[i].rpos, hi = lo + b->seg[i].len;
         if(hi <= lo || hi <= b->beg || lo >= b->end) continue;
         if(lo < b->beg) lo = b->beg; if(hi > b->end) hi = b->end;
         int t0 = (int)((lo - b->beg) / TILE), t1 = (int)((hi - 1 - b->beg) / TILE);
-        for(int t = t0; t <= t1; t++) { if(s->h_tfirst.p[t] > i) s->h_tfirst.p[t] = i; s->h_tlast.p[t] = i + 1; }
+        for(int t = t0; t <= t1; t++) { if(te[t].first > i) te[t].first = i; te[t].last = i + 1; }
     }
-    for(int t = 0; t < ntiles; t++) if(s->h_tlast.p[t] == 0) s->h_tfirst.p[t] = 0;
-    s->read_bytes = rbytes;
-    if(nr) {
-        HIPCHK(hipMemcpyAsync(s->d_hdr.p, b->hdr, nr * sizeof(md_read_hdr), hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipMemcpyAsync(s->d_mate.p, b->mate, nr * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    for(int t = 0; t < ntiles; t++) if(te[t].last == 0) te[t].first = 0;
+}
+
+extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !b || b->n_segs < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_upload", hipSuccess);
+    if(b->n_segs && (!b->seg || !b->blob)) return fail(MDK_ERR_ARG, "md_dev_upload: null array", hipSuccess);
+    if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(g_err, sizeof(g_err), "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(s->stream));          // the slot's previous contents are being replaced
+    const int64_t span = b->end - b->beg;
+    s->n_segs = b->n_segs; s->n_reads = b->n_reads; s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->uploaded = false; s->launched = false;
+    const int TILE = h->tile;
+    const int ntiles = (int)((span + TILE - 1) / TILE);
+    if(s->h_tiles.need((size_t)(ntiles > 0 ? ntiles : 1))) return MDK_ERR_NOMEM;
+    build_tiles(b, TILE, s->h_tiles.p, ntiles);
+    s->tile = TILE; s->ntiles = ntiles; s->n_staged = 0; s->paycap = 0; s->lds_bytes = fixed_lds(TILE, h->variant);
+    s->read_bytes = b->algo_bytes;
+    size_t ns = (size_t)b->n_segs, nt = (size_t)(ntiles > 0 ? ntiles : 1);
+    if(s->d_seg_in.need(ns + 1) || s->d_blob.need((size_t)b->blob_bytes + 64)) return MDK_ERR_NOMEM;
+    if(s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
+    if(!s->b_site) {
+        if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
+        if(h->variant && s->d_var.need((size_t)span + 16)) return MDK_ERR_NOMEM;
+    }
+    if(ns) {
+        HIPCHK(hipMemcpyAsync(s->d_seg_in.p, b->seg, ns * sizeof(md_seg), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->d_blob.p, b->blob, (size_t)b->blob_bytes, hipMemcpyHostToDevice, s->stream));
     }
-    if(ntiles) {
-        HIPCHK(hipMemcpyAsync(s->d_tfirst.p, s->h_tfirst.p, nt * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipMemcpyAsync(s->d_tlast.p, s->h_tlast.p, nt * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-    }
+    if(ntiles) HIPCHK(hipMemcpyAsync(s->d_tiles.p, s->h_tiles.p, nt * sizeof(TileEnt), hipMemcpyHostToDevice, s->stream));
     s->uploaded = true;
     return 0;
 }
 
-static void fill_kparams(md_dev *h, Slot *s, KParams &P) {
+extern "C" int md_dev_bind_output(md_dev *h, int slot, void *d_site, void *d_var, void *d_seg, int64_t cap_sites, int64_t cap_tiles) {
+    Slot *s = get_slot(h, slot);
+    if(!s) return MDK_ERR_ARG;
+    if(!d_site && !d_seg) { s->b_site = nullptr; s->b_var = nullptr; s->b_seg = nullptr; s->b_cap_sites = s->b_cap_tiles = 0; return 0; }
+    if(!d_site || !d_seg || cap_sites < 0 || cap_tiles < 0 || (h->variant && !d_var)) return fail(MDK_ERR_ARG, "md_dev_bind_output", hipSuccess);
+    s->b_site = (md_site *)d_site; s->b_var = (md_site_var *)d_var; s->b_seg = (md_tile_seg *)d_seg; s->b_cap_sites = cap_sites; s->b_cap_tiles = cap_tiles;
+    return 0;
+}
+
+static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
     memset(&P, 0, sizeof(P));
-    P.hdr = s->d_hdr.p; P.mate = s->d_mate.p; P.blob = s->d_blob.p;
-    P.ref = h->ref[s->tid]; P.reflen = h->reflen[s->tid];
-    P.beg = s->beg; P.end = s->end; P.tile = h->tile; P.ntiles = s->ntiles; P.nper = (s->ntiles + 7) / 8;
-    P.tfirst = s->d_tfirst.p; P.tlast = s->d_tlast.p;
-    P.spos = s->d_spos.p; P.smeth = s->d_smeth.p; P.sunmeth = s->d_sunmeth.p; P.soff = s->d_soff.p; P.svar = s->d_svar.p; P.smeta = s->d_smeta.p;
-    P.tcnt = s->d_tcnt.p;
-    P.keepCpG = h->cfg.keepCpG; P.keepCHG = h->cfg.keepCHG; P.keepCHH = h->cfg.keepCHH; P.minPhred = h->cfg.minPhred;
+    P.seg = s->d_seg_in.p; P.blob = s->d_blob.p;
+    P.ctxcode = h->refcode[s->tid]; P.reflen = h->reflen[s->tid];
+    P.beg = s->beg; P.end = s->end; P.tile = s->tile; P.ntiles = s->ntiles; P.nper = (s->ntiles + 7) / 8;
+    P.tiles = s->d_tiles.p;
+    if(s->b_site) {
+        if(s->b_cap_tiles < s->ntiles) return fail(MDK_ERR_ARG, "bound tile-segment buffer too small", hipSuccess);
+        P.site = s->b_site; P.var = s->b_var; P.tseg = s->b_seg; P.cap_sites = s->b_cap_sites;
+    } else { P.site = s->d_site.p; P.var = s->d_var.p; P.tseg = s->d_seg.p; P.cap_sites = (int64_t)s->d_site.cap; }
+    P.total = s->d_total.p + (s->ring % RING); P.total_next = s->d_total.p + ((s->ring + 1) % RING);
+    P.keepmask = (h->cfg.keepCpG ? 1 : 0) | (h->cfg.keepCHG ? 2 : 0) | (h->cfg.keepCHH ? 4 : 0);
+    P.minPhred = h->cfg.minPhred;
     for(int i = 0; i < 16; i++) { P.bounds[i] = h->cfg.bounds[i]; P.abounds[i] = h->cfg.absoluteBounds[i]; }
     P.err = s->d_err.p;
+    return 0;
 }
 
 static int launch_kernels(md_dev *h, Slot *s, bool time_pileup) {
+    s->ring++;                                          // a fresh (already zero) site counter for this launch
     if(s->ntiles > 0) {
-        KParams P; fill_kparams(h, s, P);
-        size_t lds = (size_t)h->tile * ((h->variant ? 16 : 8) + 1);
+        KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
         int grid = P.nper * 8;
         if(time_pileup) HIPCHK(hipEventRecord(s->k0, s->stream));
-        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), lds, s->stream, P);
-        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), lds, s->stream, P);
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
         if(time_pileup) HIPCHK(hipEventRecord(s->k1, s->stream));
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s->stream, s->d_tcnt.p, s->d_toff.p, s->d_total.p, s->ntiles);
         HIPCHK(hipGetLastError());
     } else {
-        HIPCHK(hipMemsetAsync(s->d_total.p, 0, sizeof(uint32_t), s->stream));
+        HIPCHK(hipMemsetAsync(s->d_total.p, 0, sizeof(uint32_t) * RING, s->stream));
     }
     return 0;
 }
@@ -513,73 +591,67 @@ extern "C" int md_dev_submit(md_dev *h, int slot, const md_read_batch *b) {
     return md_dev_launch(h, slot);
 }
 
-// wait for the pileup+scan, read the total, check the error word
+// wait for the launch, read the total, check the error word
 static int64_t finish_count(md_dev *h, Slot *s) {
     if(!s->launched) { fail(MDK_ERR_ARG, "slot not launched", hipSuccess); return MDK_ERR_ARG; }
-    if(hipMemcpyAsync(s->h_total.p, s->d_total.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H total", hipGetLastError());
+    if(hipMemcpyAsync(s->h_total.p, s->d_total.p + (s->ring % RING), sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H total", hipGetLastError());
     if(hipMemcpyAsync(s->h_err.p, s->d_err.p, sizeof(int), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H err", hipGetLastError());
     hipError_t e = hipStreamSynchronize(s->stream);
     if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
     if(s->h_err.p[0]) { snprintf(g_err, sizeof(g_err), "Can't determine the strand of a read!"); (void)hipMemset(s->d_err.p, 0, sizeof(int)); return MDK_ERR_STRAND0; }
-    return (int64_t)s->h_total.p[0];
+    int64_t n = (int64_t)s->h_total.p[0];
+    int64_t cap = s->b_site ? s->b_cap_sites : (int64_t)s->d_site.cap;
+    if(n > cap) { snprintf(g_err, sizeof(g_err), "site buffer too small: %lld sites, capacity %lld", (long long)n, (long long)cap); return MDK_ERR_ARG; }
+    return n;
 }
 
-static int gather_into(md_dev *h, Slot *s, uint32_t *pos, uint32_t *meth, uint32_t *unmeth, uint32_t *off, uint32_t *var, uint8_t *meta, int64_t cap) {
-    if(s->ntiles <= 0) return 0;
-    GParams G; memset(&G, 0, sizeof(G));
-    G.spos = s->d_spos.p; G.smeth = s->d_smeth.p; G.sunmeth = s->d_sunmeth.p; G.soff = s->d_soff.p; G.svar = s->d_svar.p; G.smeta = s->d_smeta.p;
-    G.pos = pos; G.meth = meth; G.unmeth = unmeth; G.off = h->variant ? off : nullptr; G.var = h->variant ? var : nullptr; G.meta = meta;
-    G.tcnt = s->d_tcnt.p; G.toff = s->d_toff.p; G.tile = h->tile; G.ntiles = s->ntiles; G.cap = cap;
-    int grid = s->ntiles < 4096 ? s->ntiles : 4096;
-    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(WG), 0, s->stream, G);
-    HIPCHK(hipGetLastError());
+extern "C" int md_dev_wait(md_dev *h, int slot, md_sites_dev *out) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !out) return fail(MDK_ERR_ARG, "md_dev_wait", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    memset(out, 0, sizeof(*out));
+    int64_t n = finish_count(h, s);
+    if(n < 0) return (int)n;
+    out->n_sites = n; out->n_tiles = s->ntiles;
+    out->d_site = s->b_site ? s->b_site : s->d_site.p; out->d_var = h->variant ? (s->b_site ? s->b_var : s->d_var.p) : nullptr;
+    out->d_seg = s->b_site ? s->b_seg : s->d_seg.p;
     return 0;
+}
+
+extern "C" int md_sites_order(const md_site *site, const md_site_var *var, const md_tile_seg *seg, int32_t n_tiles, int64_t n_sites, md_site *out_site, md_site_var *out_var) {
+    if(n_sites < 0 || n_tiles < 0 || (n_sites && (!site || !seg || !out_site))) return MDK_ERR_ARG;
+    int64_t o = 0;
+    for(int t = 0; t < n_tiles; t++) {
+        uint32_t c = seg[t].cnt;
+        if(!c) continue;
+        if((int64_t)seg[t].off + c > n_sites || o + c > n_sites) return MDK_ERR_ARG;
+        memcpy(out_site + o, site + seg[t].off, (size_t)c * sizeof(md_site));
+        if(var && out_var) memcpy(out_var + o, var + seg[t].off, (size_t)c * sizeof(md_site_var));
+        o += c;
+    }
+    return o == n_sites ? 0 : MDK_ERR_ARG;
 }
 
 extern "C" int md_dev_download(md_dev *h, int slot, md_sites *out) {
     Slot *s = get_slot(h, slot);
     if(!s || !out) return fail(MDK_ERR_ARG, "md_dev_download", hipSuccess);
-    HIPCHK(hipSetDevice(h->device));
     memset(out, 0, sizeof(*out));
-    int64_t n = finish_count(h, s);
-    if(n < 0) return (int)n;
-    size_t nn = (size_t)n;
-    if(s->d_pos.need(nn + 1) || s->d_meth.need(nn + 1) || s->d_unmeth.need(nn + 1) || s->d_meta.need(nn + 1)) return MDK_ERR_NOMEM;
-    if(s->h_pos.need(nn + 1) || s->h_meth.need(nn + 1) || s->h_unmeth.need(nn + 1) || s->h_meta.need(nn + 1)) return MDK_ERR_NOMEM;
-    if(h->variant && (s->d_off.need(nn + 1) || s->d_var.need(nn + 1) || s->h_off.need(nn + 1) || s->h_var.need(nn + 1))) return MDK_ERR_NOMEM;
-    if(n) {
-        int rc = gather_into(h, s, s->d_pos.p, s->d_meth.p, s->d_unmeth.p, s->d_off.p, s->d_var.p, s->d_meta.p, n);
-        if(rc) return rc;
-        HIPCHK(hipMemcpyAsync(s->h_pos.p, s->d_pos.p, nn * 4, hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(s->h_meth.p, s->d_meth.p, nn * 4, hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(s->h_unmeth.p, s->d_unmeth.p, nn * 4, hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(s->h_meta.p, s->d_meta.p, nn, hipMemcpyDeviceToHost, s->stream));
-        if(h->variant) {
-            HIPCHK(hipMemcpyAsync(s->h_off.p, s->d_off.p, nn * 4, hipMemcpyDeviceToHost, s->stream));
-            HIPCHK(hipMemcpyAsync(s->h_var.p, s->d_var.p, nn * 4, hipMemcpyDeviceToHost, s->stream));
-        }
+    md_sites_dev dv;
+    int rc = md_dev_wait(h, slot, &dv);
+    if(rc) return rc;
+    size_t nn = (size_t)dv.n_sites, nt = (size_t)(s->ntiles > 0 ? s->ntiles : 1);
+    if(s->h_site.need(nn + 1) || s->h_sorted.need(nn + 1) || s->h_seg.need(nt)) return MDK_ERR_NOMEM;
+    if(h->variant && (s->h_var.need(nn + 1) || s->h_vsorted.need(nn + 1))) return MDK_ERR_NOMEM;
+    if(nn) {
+        HIPCHK(hipMemcpyAsync(s->h_site.p, dv.d_site, nn * sizeof(md_site), hipMemcpyDeviceToHost, s->stream));
+        if(h->variant) HIPCHK(hipMemcpyAsync(s->h_var.p, dv.d_var, nn * sizeof(md_site_var), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->h_seg.p, dv.d_seg, (size_t)s->ntiles * sizeof(md_tile_seg), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
+        rc = md_sites_order(s->h_site.p, h->variant ? s->h_var.p : nullptr, s->h_seg.p, s->ntiles, dv.n_sites, s->h_sorted.p, h->variant ? s->h_vsorted.p : nullptr);
+        if(rc) return fail(MDK_ERR_ARG, "md_dev_download: inconsistent tile segments", hipSuccess);
     }
-    out->n_sites = n; out->pos = s->h_pos.p; out->nmeth = s->h_meth.p; out->nunmeth = s->h_unmeth.p; out->meta = s->h_meta.p;
-    out->noff = h->variant ? s->h_off.p : nullptr; out->nvar = h->variant ? s->h_var.p : nullptr;
+    out->n_sites = dv.n_sites; out->site = s->h_sorted.p; out->var = h->variant ? s->h_vsorted.p : nullptr;
     return 0;
-}
-
-extern "C" int64_t md_dev_sites_to_device(md_dev *h, int slot, uint32_t *d_pos, uint32_t *d_nmeth, uint32_t *d_nunmeth, uint32_t *d_noff, uint32_t *d_nvar, uint8_t *d_meta, int64_t cap) {
-    Slot *s = get_slot(h, slot);
-    if(!s || !d_pos || !d_nmeth || !d_nunmeth || !d_meta) return fail(MDK_ERR_ARG, "md_dev_sites_to_device", hipSuccess);
-    if(h->variant && (!d_noff || !d_nvar)) return fail(MDK_ERR_ARG, "md_dev_sites_to_device: noff/nvar required", hipSuccess);
-    if(hipSetDevice(h->device) != hipSuccess) return MDK_ERR_HIP;
-    int64_t n = finish_count(h, s);
-    if(n < 0) return n;
-    if(n > cap) return fail(MDK_ERR_ARG, "md_dev_sites_to_device: capacity too small", hipSuccess);
-    if(n) {
-        int rc = gather_into(h, s, d_pos, d_nmeth, d_nunmeth, d_noff, d_nvar, d_meta, cap);
-        if(rc) return rc;
-        hipError_t e = hipStreamSynchronize(s->stream);
-        if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
-    }
-    return n;
 }
 
 extern "C" int md_dev_sync(md_dev *h) {
@@ -594,33 +666,65 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
     if(!s || !out || !s->uploaded || iters < 1) return fail(MDK_ERR_ARG, "md_dev_bench", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
     memset(out, 0, sizeof(*out));
-    // output buffers sized once, outside the timed region
     int rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
     int64_t n = finish_count(h, s); if(n < 0) return (int)n;
-    size_t nn = (size_t)n + 1;
-    if(s->d_pos.need(nn) || s->d_meth.need(nn) || s->d_unmeth.need(nn) || s->d_meta.need(nn)) return MDK_ERR_NOMEM;
-    if(h->variant && (s->d_off.need(nn) || s->d_var.need(nn))) return MDK_ERR_NOMEM;
-    for(int i = 0; i < warmup; i++) {
-        rc = launch_kernels(h, s, false); if(rc) return rc;
-        rc = gather_into(h, s, s->d_pos.p, s->d_meth.p, s->d_unmeth.p, s->d_off.p, s->d_var.p, s->d_meta.p, n); if(rc) return rc;
-    }
+    for(int i = 0; i < warmup; i++) { rc = launch_kernels(h, s, false); if(rc) return rc; }
     HIPCHK(hipStreamSynchronize(s->stream));
+    // (a) one launch at a time, bracketed by events (includes the dispatch latency of a lone launch)
     double tot = 0, pk = 0;
     for(int i = 0; i < iters; i++) {
-        float a = 0, b = 0;
+        float a = 0;
         HIPCHK(hipEventRecord(s->e0, s->stream));
-        rc = launch_kernels(h, s, true); if(rc) return rc;
-        rc = gather_into(h, s, s->d_pos.p, s->d_meth.p, s->d_unmeth.p, s->d_off.p, s->d_var.p, s->d_meta.p, n); if(rc) return rc;
+        rc = launch_kernels(h, s, false); if(rc) return rc;
         HIPCHK(hipEventRecord(s->e1, s->stream));
         HIPCHK(hipEventSynchronize(s->e1));
         HIPCHK(hipEventElapsedTime(&a, s->e0, s->e1));
-        if(s->ntiles > 0) HIPCHK(hipEventElapsedTime(&b, s->k0, s->k1));
-        tot += a; pk += b;
+        tot += a;
+    }
+    // (b) `iters` launches back to back between two events: the sustained per-launch time of the kernel, which is
+    // what rocprofv3 --kernel-trace reports as its average duration (plus the ~1.5 us kernel-to-kernel boundary)
+    {
+        float b = 0;
+        HIPCHK(hipEventRecord(s->k0, s->stream));
+        for(int i = 0; i < iters; i++) { rc = launch_kernels(h, s, false); if(rc) return rc; }
+        HIPCHK(hipEventRecord(s->k1, s->stream));
+        HIPCHK(hipEventSynchronize(s->k1));
+        HIPCHK(hipEventElapsedTime(&b, s->k0, s->k1));
+        pk = (double)b;
     }
     out->ms_total = (float)(tot / iters); out->ms_pileup = (float)(pk / iters);
+    if(getenv("MDK_PHASES") && s->ntiles > 0) {        // one instrumented launch: where does a workgroup spend its time?
+        KParams P; rc = fill_kparams(h, s, P); if(rc) return rc;
+        int grid = P.nper * 8; size_t nw = (size_t)grid * WAVES * 8;
+        unsigned long long *dd = nullptr; std::vector<unsigned long long> hd(nw);
+        HIPCHK(hipMalloc((void **)&dd, nw * 8)); HIPCHK(hipMemset(dd, 0, nw * 8));
+        s->ring++; rc = fill_kparams(h, s, P); if(rc) return rc;
+        P.dbg = dd;
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipMemcpy(hd.data(), dd, nw * 8, hipMemcpyDeviceToHost)); (void)hipFree(dd);
+        unsigned long long r0 = ~0ull, r1 = 0; double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}; size_t cnt = 0; std::vector<double> starts, ends, life;
+        for(size_t i = 0; i < nw; i += 8) { if(!hd[i]) continue; r0 = std::min(r0, hd[i]); r1 = std::max(r1, hd[i + 1]); }
+        for(size_t i = 0; i < nw; i += 8) {
+            if(!hd[i]) continue;
+            cnt++; starts.push_back((double)(hd[i] - r0) / 100.0); ends.push_back((double)(hd[i + 1] - r0) / 100.0); life.push_back((double)(hd[i + 1] - hd[i]) / 100.0);
+            for(int k = 0; k < 4; k++) { sum[k] += (double)hd[i + 2 + k]; mx[k] = std::max(mx[k], (double)hd[i + 2 + k]); }
+        }
+        std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end()); std::sort(life.begin(), life.end());
+        if(cnt) {
+            fprintf(stderr, "[phases] waves %zu, launch span %.2f us (realtime clock)\n", cnt, (double)(r1 - r0) / 100.0);
+            fprintf(stderr, "[phases] wave start  us: p0 %.2f p50 %.2f p90 %.2f p100 %.2f\n", starts[0], starts[cnt / 2], starts[cnt * 9 / 10], starts[cnt - 1]);
+            fprintf(stderr, "[phases] wave end    us: p0 %.2f p50 %.2f p90 %.2f p100 %.2f\n", ends[0], ends[cnt / 2], ends[cnt * 9 / 10], ends[cnt - 1]);
+            fprintf(stderr, "[phases] wave life   us: p0 %.2f p50 %.2f p90 %.2f p100 %.2f\n", life[0], life[cnt / 2], life[cnt * 9 / 10], life[cnt - 1]);
+            const char *nm[4] = {"lists(+hdr issue)", "reads", "wait at barrier", "compaction"};
+            for(int k = 0; k < 4; k++) fprintf(stderr, "[phases] %-18s mean %8.0f max %8.0f shader clocks\n", nm[k], sum[k] / cnt, mx[k]);
+        }
+    }
     out->n_sites = (uint64_t)n;
     // sum over reads [16 + 4 n_cigar + ceil(l/2) + l] + interval length + 8 per site (+8 with nOff/nVariant)
     out->algo_bytes = s->read_bytes + (uint64_t)(s->end - s->beg) + (uint64_t)n * (h->variant ? 16 : 8);
+    out->tile = s->tile; out->n_tiles = s->ntiles; out->n_staged_tiles = s->n_staged; out->lds_bytes = s->lds_bytes;
     return 0;
 }
 
@@ -628,20 +732,19 @@ extern "C" int md_dev_debug_effective(md_dev *h, int slot, uint8_t *out_base, ui
     Slot *s = get_slot(h, slot);
     if(!s || !s->uploaded || !out_base || !out_qual || !out_off) return fail(MDK_ERR_ARG, "md_dev_debug_effective", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
-    if(s->n_reads == 0) return 0;
+    if(s->n_segs == 0) return 0;
     HIPCHK(hipStreamSynchronize(s->stream));
-    // total bytes = out_off[n-1] + l_qseq of the last read; the caller guarantees the layout, so recompute from it
-    std::vector<md_read_hdr> hdr(s->n_reads);
-    HIPCHK(hipMemcpy(hdr.data(), s->d_hdr.p, sizeof(md_read_hdr) * s->n_reads, hipMemcpyDeviceToHost));
+    std::vector<md_seg> sg(s->n_segs);
+    HIPCHK(hipMemcpy(sg.data(), s->d_seg_in.p, sizeof(md_seg) * s->n_segs, hipMemcpyDeviceToHost));
     uint64_t total = 0;
-    for(int i = 0; i < s->n_reads; i++) total = std::max<uint64_t>(total, out_off[i] + hdr[i].l_qseq);
+    for(int i = 0; i < s->n_segs; i++) total = std::max<uint64_t>(total, out_off[i] + sg[i].len);
     uint8_t *db = nullptr, *dq = nullptr; uint64_t *doff = nullptr;
-    HIPCHK(hipMalloc((void **)&db, total + 1)); HIPCHK(hipMalloc((void **)&dq, total + 1)); HIPCHK(hipMalloc((void **)&doff, sizeof(uint64_t) * s->n_reads));
+    HIPCHK(hipMalloc((void **)&db, total + 1)); HIPCHK(hipMalloc((void **)&dq, total + 1)); HIPCHK(hipMalloc((void **)&doff, sizeof(uint64_t) * s->n_segs));
     HIPCHK(hipMemset(db, 0xff, total + 1)); HIPCHK(hipMemset(dq, 0xff, total + 1));
-    HIPCHK(hipMemcpy(doff, out_off, sizeof(uint64_t) * s->n_reads, hipMemcpyHostToDevice));
-    KParams P; fill_kparams(h, s, P);
-    int grid = (s->n_reads + WAVES - 1) / WAVES; if(grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(k_debug_effective, dim3(grid), dim3(WG), 0, s->stream, P, s->n_reads, db, dq, doff);
+    HIPCHK(hipMemcpy(doff, out_off, sizeof(uint64_t) * s->n_segs, hipMemcpyHostToDevice));
+    KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
+    int grid = (s->n_segs + WAVES - 1) / WAVES; if(grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_debug_effective, dim3(grid), dim3(WG), 0, s->stream, P, s->n_segs, db, dq, doff);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     HIPCHK(hipMemcpy(out_base, db, total, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(out_qual, dq, total, hipMemcpyDeviceToHost));

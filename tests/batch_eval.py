@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE: a slow pure-Python evaluation of one device batch (include/mdk_hip.h md_read_batch).
 
-It restates, for SMALL inputs only, what the HIP kernel computes from a packed batch, so that the host side of the
-product (admission, strand, pairing, packing: csrc/host/mdk_extract.c) can be checked against the oracle on a box
-without a GPU.  It is never imported by the product."""
+It restates, for SMALL inputs only, what the HIP kernel computes from a packed batch of segments, so that the host
+side of the product (admission, strand, pairing, CIGAR expansion, packing: csrc/host/mdk_extract.c) can be checked
+against the oracle on a box without a GPU.  It is never imported by the product."""
 import ctypes as C
 
 
@@ -19,33 +19,17 @@ def _window(cfg, strand, read2, lq):
     return lo, hi
 
 
-class Read:
-    def __init__(self, batch, i, cfg):
-        h = batch.hdr[i]
-        self.pos, self.lq, self.ncig, self.strand, self.flags = h.pos, h.l_qseq, h.n_cigar, h.strand, h.flags
-        base = C.addressof(batch.blob.contents) + 4 * h.off4
-        self.cig = list((C.c_uint32 * self.ncig).from_address(base)) if self.ncig else []
-        seqb = (self.lq + 1) // 2
-        seq = bytes((C.c_uint8 * seqb).from_address(base + 4 * self.ncig)) if seqb else b""
-        qoff = base + 4 * self.ncig + ((seqb + 3) & ~3)
-        self.qual = bytes((C.c_uint8 * self.lq).from_address(qoff)) if self.lq else b""
-        self.bases = [(seq[q >> 1] >> (0 if q & 1 else 4)) & 15 for q in range(self.lq)]
-        self.lo, self.hi = _window(cfg, self.strand, self.flags & 1, self.lq)
-        # reference position -> query index for M/=/X bases
-        self.at = {}
-        x, y = self.pos, 0
-        for c in self.cig:
-            op, ln = c & 15, c >> 4
-            if op in (0, 7, 8):
-                for j in range(ln):
-                    if y + j < self.lq:
-                        self.at[x + j] = y + j
-                x += ln
-                y += ln
-            elif op in (1, 4):
-                y += ln
-            elif op in (2, 3):
-                x += ln
+class Payload:
+    """seq/qual of one read (blob + 4*off4) with its trimming window"""
+    _cache = {}
+
+    def __init__(self, batch, off4, lq, strand, read2, cfg):
+        base = C.addressof(batch.blob.contents) + 4 * off4
+        seqb = (lq + 1) // 2
+        seq = bytes((C.c_uint8 * seqb).from_address(base)) if seqb else b""
+        self.qual = bytes((C.c_uint8 * lq).from_address(base + ((seqb + 3) & ~3))) if lq else b""
+        self.bases = [(seq[q >> 1] >> (0 if q & 1 else 4)) & 15 for q in range(lq)]
+        self.lo, self.hi = _window(cfg, strand, read2, lq)
 
     def bq(self, q):
         if q < self.lo or q >= self.hi:
@@ -55,6 +39,23 @@ class Read:
 
 def boost(q):
     return ((q * 6) // 5) & 255
+
+
+def resolve(second, b, ql, mb, mq):
+    ba, qa, bb, qb = (mb, mq, b, ql) if second else (b, ql, mb, mq)
+    if ba != bb:
+        if qa > qb and ba != 15:
+            qa, qb = qa - qb, 0
+        elif qb > qa and bb != 15:
+            qa, qb = 0, qb - qa
+        else:
+            qa = qb = 0
+    else:
+        if qa > qb:
+            qa, qb = boost(qa), 0
+        else:
+            qa, qb = 0, boost(qb)
+    return qb if second else qa
 
 
 def context(ref, p, keep):
@@ -76,40 +77,40 @@ def context(ref, p, keep):
 def eval_batch(batch, ref: bytes, cfg):
     """-> {pos: (type, isG, nmeth, nunmeth, noff, nvar)} for positions with any evidence"""
     keep = (cfg.keepCpG, cfg.keepCHG, cfg.keepCHH)
-    reads = [Read(batch, i, cfg) for i in range(batch.n_reads)]
     out = {}
-    for i, o in enumerate(reads):
-        mi = batch.mate[i]
-        m = reads[mi] if mi >= 0 and ((o.strand - reads[mi].strand) & 1) == 0 else None
-        for p, q in o.at.items():
+    pay = {}
+
+    def payload(off4, lq, strand, read2):
+        k = (off4, lq, strand, read2)
+        if k not in pay:
+            pay[k] = Payload(batch, off4, lq, strand, read2, cfg)
+        return pay[k]
+
+    prev = None
+    for i in range(batch.n_segs):
+        g = batch.seg[i]
+        strand, read2, second, partner = g.sf & 7, bool(g.sf & 8), bool(g.sf & 16), bool(g.sf & 32)
+        assert g.len >= 1 and g.q0 + g.len <= g.l_qseq
+        o = payload(g.off4, g.l_qseq, strand, read2)
+        m = payload(g.m_off4, g.m_l_qseq, g.msf & 7, bool(g.msf & 8)) if partner else None
+        if partner:
+            assert g.m_q0 + g.len <= g.m_l_qseq
+        odd = strand & 1
+        for j in range(g.len):
+            p = g.rpos + j
             if p < batch.beg or p >= batch.end or p >= len(ref):
                 continue
             ctx = context(ref, p, keep)
             if ctx is None:
                 continue
             t, isg = ctx
-            odd = o.strand & 1
-            b, ql = o.bq(q)
-            if m is not None and p in m.at:
-                mb, mq = m.bq(m.at[p])
-                second = bool(o.flags & 2)
-                ba, qa, bb, qb = (mb, mq, b, ql) if second else (b, ql, mb, mq)
-                if ba != bb:
-                    if qa > qb and ba != 15:
-                        qa, qb = qa - qb, 0
-                    elif qb > qa and bb != 15:
-                        qa, qb = 0, qb - qa
-                    else:
-                        qa = qb = 0
-                else:
-                    if qa > qb:
-                        qa, qb = boost(qa), 0
-                    else:
-                        qa, qb = 0, boost(qb)
-                ql = qb if second else qa
+            b, ql = o.bq(g.q0 + j)
+            if m is not None:
+                mb, mq = m.bq(g.m_q0 + j)
+                ql = resolve(second, b, ql, mb, mq)
             e = out.setdefault(p, [t, isg, 0, 0, 0, 0])
             if bool(odd) != bool(isg):
-                assert o.strand != 0, "strand 0 read reached a call"
+                assert strand != 0, "strand 0 read reached a call"
                 if ql >= cfg.minPhred:
                     if odd:
                         e[2] += b == 2

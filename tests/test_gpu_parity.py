@@ -106,10 +106,13 @@ SYN_CMDS = [
 
 
 @pytest.mark.parametrize("which,extra", SYN_CMDS, ids=[f"{w}:{' '.join(e)}" for w, e in SYN_CMDS])
-@pytest.mark.parametrize("tile", ["256", "1024"])
-def test_cli_synthetic_byte_exact(tmp_path, small_synth, which, extra, tile):
+@pytest.mark.parametrize("env", [{"MDK_TILE": "256"}, {}, {"MDK_TILE": "1024", "MDK_KERNEL": "global"}, {"MDK_TILE": "512", "MDK_LDS_BUDGET": "24000"}],
+                         ids=["tile256-lds", "auto", "tile1024-global", "tile512-mixed"])
+def test_cli_synthetic_byte_exact(tmp_path, small_synth, which, extra, env):
+    """every command line under: LDS-staged tiles (fixed and auto geometry), the global-pointer path, and a budget so
+    small that staged and overflowing tiles mix inside one launch"""
     extra = [str(small_synth / "pe.bbm") if e == "BBM" else e for e in extra]
-    compare_cli(tmp_path, [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")] + extra, env={"MDK_TILE": tile})
+    compare_cli(tmp_path, [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")] + extra, env=env)
 
 
 def abi_sites(args):
