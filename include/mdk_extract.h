@@ -25,6 +25,8 @@ extern "C" {
 int extract_main(int argc, char *argv[]);
 
 typedef struct mdk_plan mdk_plan;
+#define MDK_CHUNK_NOREF   1   /* contig missing from the FASTA -> the reference skips the chunk; nothing is emitted */
+#define MDK_CHUNK_FOREIGN 2   /* interval sharding: another rank owns this chunk; its sites arrive through the gather */
 
 /* One chunk of the reference's schedule (extract.c:325-350 + adjustBounds) with its admitted reads packed
  * for the device.  `batch` arrays are owned by the plan and stay valid until the second-next
@@ -33,7 +35,7 @@ typedef struct {
     uint32_t index;            /* localBin: output order */
     int32_t  tid;
     int64_t  beg, end;         /* [localPos, localEnd) */
-    int32_t  skipped;          /* 1: contig missing from the FASTA -> the reference skips the chunk */
+    int32_t  skipped;          /* MDK_CHUNK_* flags; non-zero: nothing was packed for this chunk */
     md_read_batch batch;
     uint64_t n_records_seen;   /* BAM records examined for this chunk (before admission) */
 } mdk_chunk;
@@ -53,6 +55,9 @@ int  mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c);
 int  mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *sites);
 /* print the variant-position line (extract.c:1489), close outputs */
 int  mdk_plan_finish(mdk_plan *p);
+/* interval sharding over `world` processes (one per GPU): this process admits and packs only the chunks whose index
+ * is congruent to `rank`; every process still walks the whole schedule, so chunk indices agree everywhere. */
+int  mdk_plan_set_shard(mdk_plan *p, int rank, int world);
 int  mdk_plan_n_targets(const mdk_plan *p);
 const char *mdk_plan_target_name(const mdk_plan *p, int32_t tid);
 int64_t mdk_plan_target_len(const mdk_plan *p, int32_t tid);

@@ -23,6 +23,7 @@ LIB_HIP = BUILD / "libmdk_hip.so"
 LIB_EXTRACT = BUILD / "libmdk_extract.so"
 CLI = BUILD / "MethylDackel"
 
+CHUNK_NOREF, CHUNK_FOREIGN = 1, 2
 MDK_ERR = {-1: "HIP call failed", -2: "no device", -3: "bad argument", -4: "reference not uploaded",
            -5: "strand 0 read reached a call", -6: "out of memory"}
 
@@ -82,7 +83,7 @@ HIP_SYMBOLS = ["md_dev_count", "md_dev_open", "md_dev_close", "md_dev_last_error
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
-                   "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_n_targets", "mdk_plan_target_name",
+                   "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len"]
 
 _hip = None
@@ -141,6 +142,7 @@ def lib_extract():
         L.mdk_plan_next_chunk.argtypes = [C.c_void_p, C.POINTER(mdk_chunk)]
         L.mdk_plan_emit.argtypes = [C.c_void_p, C.POINTER(mdk_chunk), C.POINTER(md_sites)]
         L.mdk_plan_finish.argtypes = [C.c_void_p]
+        L.mdk_plan_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.mdk_plan_n_targets.argtypes = [C.c_void_p]
         L.mdk_plan_target_name.argtypes = [C.c_void_p, C.c_int32]
         L.mdk_plan_target_name.restype = C.c_char_p
@@ -234,6 +236,10 @@ class Plan:
         cfg = md_dev_cfg()
         self.L.mdk_plan_dev_cfg(self.p, C.byref(cfg))
         return cfg
+
+    def set_shard(self, rank: int, world: int):
+        if self.L.mdk_plan_set_shard(self.p, rank, world):
+            raise MdkError("mdk_plan_set_shard: bad rank/world")
 
     def next_chunk(self):
         c = mdk_chunk()

@@ -69,6 +69,7 @@ struct mdk_plan {
     mdk_bam *bam; mdk_fasta fa; int *fa_of_tid;
     /* schedule cursor (main.c:10-13 globals) */
     uint32_t g_tid, g_pos, g_end, bin;
+    int shard_rank, shard_world;       /* interval sharding: this process packs chunk k iff k % world == rank */
     uint64_t n_variant_positions;
     /* stream state */
     int32_t last_tid, last_pos;
@@ -222,6 +223,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     o = &p->o;
     o->ctx_on[0] = 1; o->min_mapq = 10; o->min_phred = 5; o->min_depth = 1; o->ignore_flags = 0xF00;
     o->n_threads = 1; o->chunk_size = 1000000; o->map_cutoff = 0.01f; o->min_mappable = 15;
+    p->shard_rank = 0; p->shard_world = 1;
     p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1; p->lastcpg_tid = -1; p->lastchg_tid = -1;
 
     optind = 1;     /* the reference relies on a fresh process; being a library we reset getopt */
@@ -315,7 +317,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     oname = malloc(strlen(o->opref) + 40);
     if(o->cytosine_report) {
         sprintf(oname, "%s.cytosine_report.txt", o->opref);
-        p->out[0] = fopen(oname, "w"); p->out[1] = p->out[2] = p->out[0];
+        p->out[0] = fopen(getenv("MDK_NO_OUTPUT") ? "/dev/null" : oname, "w"); p->out[1] = p->out[2] = p->out[0];
         if(!p->out[0]) { fprintf(stderr, "Couldn't open the output CpG metrics file for writing! Insufficient permissions?\n"); free(oname); plan_free(p); return -3; }
     } else {
         static const char *cn[3] = {"CpG", "CHG", "CHH"};
@@ -323,7 +325,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
             const char *ext = o->fraction ? ".meth.bedGraph" : o->counts ? ".counts.bedGraph" : o->logit ? ".logit.bedGraph" : o->methylkit ? ".methylKit" : ".bedGraph";
             if(!o->ctx_on[i]) continue;
             sprintf(oname, "%s_%s%s", o->opref, cn[i], ext);
-            p->out[i] = fopen(oname, "w");
+            p->out[i] = fopen(getenv("MDK_NO_OUTPUT") ? "/dev/null" : oname, "w");     /* MDK_NO_OUTPUT: non-writer rank of a sharded run */
             if(!p->out[i]) { fprintf(stderr, "Couldn't open the output %s metrics file for writing! Insufficient permissions?\n", cn[i]); free(oname); plan_free(p); return -3; }
             if(o->methylkit) fputs("chrBase\tchr\tbase\tstrand\tcoverage\tfreqC\tfreqT\n", p->out[i]);
             else fprintf(p->out[i], "track type=\"bedGraph\" description=\"%s %s%s%s\"\n", o->opref, cn[i], o->merge ? " merged" : "",
@@ -367,6 +369,11 @@ static void plan_free(mdk_plan *p) {
 }
 void mdk_plan_close(mdk_plan *p) { plan_free(p); }
 
+int mdk_plan_set_shard(mdk_plan *p, int rank, int world) {
+    if(!p || world < 1 || rank < 0 || rank >= world) return -1;
+    p->shard_rank = rank; p->shard_world = world;
+    return 0;
+}
 int mdk_plan_n_targets(const mdk_plan *p) { return p->bam->n_targets; }
 const char *mdk_plan_target_name(const mdk_plan *p, int32_t tid) { return (tid >= 0 && tid < p->bam->n_targets) ? p->bam->target_name[tid] : NULL; }
 int64_t mdk_plan_target_len(const mdk_plan *p, int32_t tid) { return (tid >= 0 && tid < p->bam->n_targets) ? (int64_t)p->bam->target_len[tid] : -1; }
@@ -691,13 +698,14 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
     if(p->g_tid != (uint32_t)-1 && p->g_pos >= bam->target_len[tid]) { end = bam->target_len[tid]; p->g_tid++; p->g_pos = 0; }
     if(p->g_end && beg >= p->g_end) return 0;
     c->tid = (int32_t)tid; c->beg = beg; c->end = end;
+    if(p->shard_world > 1 && (int)(c->index % (uint32_t)p->shard_world) != p->shard_rank) c->skipped |= MDK_CHUNK_FOREIGN;
     which = p->cur_bb; p->cur_bb ^= 1; b = &p->bb[which];
     b->n = 0; b->blob_len = 0; b->qn_len = 0; b->cig_len = 0; b->n_seg = 0; b->algo_bytes = 0;
     fi = p->fa_of_tid[tid];
     if(fi < 0) {
-        fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", -2, bam->target_name[tid], beg > 1 ? beg - 2 : 0, end);
-        fprintf(stderr, "Note that the output will be truncated!\n");
-        c->skipped = 1;
+        if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", -2, bam->target_name[tid], beg > 1 ? beg - 2 : 0, end);
+        if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "Note that the output will be truncated!\n");
+        c->skipped |= MDK_CHUNK_NOREF;
     } else {
         woff = beg > 1 ? (int64_t)beg - 2 : 0; wlen = (int64_t)end + 10 + 1; if(wlen > p->fa.len[fi]) wlen = p->fa.len[fi]; wlen -= woff; if(wlen < 0) wlen = 0;
         win = p->fa.seq[fi] + woff;
@@ -791,7 +799,7 @@ int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
     int k; char tri[4];
     if(c->index != p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
     p->next_emit++;
-    if(c->skipped) return 0;
+    if(c->skipped & MDK_CHUNK_NOREF) return 0;
     chrom = p->bam->target_name[c->tid];
     fi = p->fa_of_tid[c->tid]; if(fi >= 0) { seq = p->fa.seq[fi]; slen = p->fa.len[fi]; }
     blank_from = c->beg;

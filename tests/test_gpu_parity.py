@@ -201,3 +201,44 @@ def test_no_cpu_fallback_symbols():
     """the shipped libraries must not link the oracle"""
     out = subprocess.run(["nm", "-D", str(mdk.LIB_EXTRACT)], capture_output=True, text=True).stdout
     assert "extract_main" in out and "oracle" not in out.lower()
+
+
+def _shard_worker(rank, world, port, args, ret):
+    import sys
+    sys.path.insert(0, str(mdk.REPO))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # two ranks share cuda:0 here, so the exchange goes over gloo
+    from methyldackel_amd import multi
+    devs = {}
+
+    def factory(plan):
+        devs["d"] = mdk.Device(plan.dev_cfg(), device=0)
+        return multi.device_count_fn(devs["d"])
+
+    ret[rank] = multi.extract_sharded(args, factory)
+    devs["d"].close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_byte_exact(tmp_path, small_synth):
+    """interval sharding with real kernels: 2 ranks (both on this box's single GPU), rank 0 writes; output == oracle"""
+    import socket
+    import torch.multiprocessing as mp
+    args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--CHG", "--mergeContext", "--chunkSize", "3000", "--minOppositeDepth", "2", "--maxVariantFrac", "0.4"]
+    od, gd = tmp_path / "oracle", tmp_path / "gpu"
+    od.mkdir(), gd.mkdir()
+    ro = run_oracle(args + ["-o", "out"], cwd=od)
+    assert ro.returncode == 0
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cwd = os.getcwd(); os.chdir(gd)
+    try:
+        mgr = mp.Manager(); ret = mgr.dict()
+        mp.spawn(_shard_worker, args=(2, port, args + ["-o", "out"], ret), nprocs=2, join=True)
+    finally:
+        os.chdir(cwd)
+    assert ret[0] > 0 and ret[1] > 0
+    for f in os.listdir(od):
+        if f.startswith("out"):
+            assert filecmp.cmp(od / f, gd / f, shallow=False), f
