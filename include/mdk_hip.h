@@ -99,11 +99,13 @@ typedef struct {
 } md_sites;
 
 /* Device-resident result of one interval, as the kernel leaves it: tile t's sites (ascending) occupy
- * site[seg[t].off .. seg[t].off + seg[t].cnt); tiles are in position order but their segments are not
- * (segments are reserved with one atomic per tile).  Used for device-to-device exchange (RCCL gather). */
+ * site[seg[t].off .. seg[t].off + seg[t].cnt).  Tiles are in position order but their segments are not: a tile
+ * reserves room for one site per kept context position with a single atomic, so segments appear in completion order
+ * and a segment may be followed by unused slots.  Used for device-to-device exchange (RCCL gather). */
 typedef struct { uint32_t off, cnt; } md_tile_seg;
 typedef struct {
-    int64_t n_sites; int32_t n_tiles;
+    int64_t n_slots;                 /* slots of d_site in use (>= number of sites) */
+    int32_t n_tiles;
     const md_site *d_site; const md_site_var *d_var; const md_tile_seg *d_seg;   /* DEVICE pointers */
 } md_sites_dev;
 
@@ -135,13 +137,15 @@ int  md_dev_sync(md_dev *h);
 /* Make the kernels of `slot` write their result into caller-provided DEVICE buffers (e.g. torch tensors that are
  * then exchanged over RCCL) instead of library memory: d_site[cap_sites] (md_site), d_var[cap_sites] (md_site_var,
  * may be NULL when minOppositeDepth == 0), d_seg[cap_tiles] (md_tile_seg).  Pass all-NULL to unbind.
- * md_dev_wait then reports how many sites/tiles were written; MDK_ERR_ARG if a capacity was too small. */
+ * md_dev_wait then reports how many slots/tiles were used; MDK_ERR_ARG if a capacity was too small (cap_sites must
+ * be at least the number of kept context positions of the interval; the interval length always suffices). */
 int  md_dev_bind_output(md_dev *h, int slot, void *d_site, void *d_var, void *d_seg, int64_t cap_sites, int64_t cap_tiles);
 /* wait for the slot's kernels; fills the device view (library or bound buffers) */
 int  md_dev_wait(md_dev *h, int slot, md_sites_dev *out);
-/* host-side helper: put a segmented result (copied to host memory) into ascending order */
-int  md_sites_order(const md_site *site, const md_site_var *var, const md_tile_seg *seg, int32_t n_tiles, int64_t n_sites,
-                    md_site *out_site, md_site_var *out_var);
+/* host-side helper: put a segmented result (copied to host memory, n_slots slots) into ascending order;
+ * returns the number of sites written to out_site (>= 0) or a negative error */
+int64_t md_sites_order(const md_site *site, const md_site_var *var, const md_tile_seg *seg, int32_t n_tiles, int64_t n_slots,
+                       md_site *out_site, md_site_var *out_var);
 
 /* Re-run the kernels of an uploaded slot `iters` times (inputs stay resident in HBM; results are identical
  * every time) and time them with HIP events on the slot's stream. */

@@ -66,7 +66,7 @@ class md_sites(C.Structure):
 
 
 class md_sites_dev(C.Structure):
-    _fields_ = [("n_sites", C.c_int64), ("n_tiles", C.c_int32), ("d_site", C.c_void_p), ("d_var", C.c_void_p), ("d_seg", C.c_void_p)]
+    _fields_ = [("n_slots", C.c_int64), ("n_tiles", C.c_int32), ("d_site", C.c_void_p), ("d_var", C.c_void_p), ("d_seg", C.c_void_p)]
 
 
 class md_bench_result(C.Structure):
@@ -118,6 +118,7 @@ def lib_hip():
         L.md_dev_bind_output.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]
         L.md_dev_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_sites_dev)]
         L.md_sites_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
+        L.md_sites_order.restype = C.c_int64
         L.md_dev_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
         L.md_dev_debug_effective.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.md_host_alloc.restype = C.c_void_p

@@ -584,14 +584,40 @@ static int cigar_runs(const uint32_t *cig, int ncig, int32_t pos, int32_t lq, ru
     return n;
 }
 
-/* segments of every read of the chunk: its gapless runs, cut where the overlap partner's runs begin/end */
-static int build_segments(mdk_plan *p, batchbuf *b, int64_t beg, int64_t end) {
-    static __thread run_t *ro = NULL, *rm = NULL; static __thread int co = 0, cm = 0;
+/* segments of every read of the chunk: its gapless runs, cut where the overlap partner's runs begin/end.
+ * Segments are emitted in ascending order of their reference start: the later runs of a read (after a deletion or a
+ * long ref-skip) wait in a small heap until the stream of reads has reached their position, so that the segments
+ * overlapping any window of the reference are one tight contiguous run of the array. */
+typedef struct { md_seg *v; size_t n, cap; } segheap;
+static int heap_push(segheap *h, const md_seg *g) {
     size_t i;
-    b->n_seg = 0;
-    for(i = 0; i < b->n; i++) {
-        const rinfo *r = &b->ri[i], *m = NULL; int no, nm = 0, a, j = 0;
-        uint8_t sf = (uint8_t)((r->strand & 7) | ((r->bamflag & 0x80) ? MDK_SF_READ2 : 0) | (r->second ? MDK_SF_SECOND : 0)), msf = 0;
+    if(h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 256; h->v = realloc(h->v, h->cap * sizeof(md_seg)); if(!h->v) return -1; }
+    for(i = h->n++; i > 0 && h->v[(i - 1) / 2].rpos > g->rpos; i = (i - 1) / 2) h->v[i] = h->v[(i - 1) / 2];
+    h->v[i] = *g;
+    return 0;
+}
+static void heap_pop(segheap *h, md_seg *out) {
+    size_t i = 0, c; md_seg last;
+    *out = h->v[0]; last = h->v[--h->n];
+    for(;;) {
+        c = 2 * i + 1; if(c >= h->n) break;
+        if(c + 1 < h->n && h->v[c + 1].rpos < h->v[c].rpos) c++;
+        if(h->v[c].rpos >= last.rpos) break;
+        h->v[i] = h->v[c]; i = c;
+    }
+    if(h->n) h->v[i] = last;
+}
+static int build_segments(mdk_plan *p, batchbuf *b, int64_t beg, int64_t end) {
+    static __thread run_t *ro = NULL, *rm = NULL; static __thread int co = 0, cm = 0; static __thread segheap hp = {NULL, 0, 0};
+    size_t i;
+    b->n_seg = 0; hp.n = 0;
+    for(i = 0; i <= b->n; i++) {
+        const rinfo *r, *m = NULL; int no, nm = 0, a, j = 0; uint8_t sf, msf = 0;
+        /* everything that starts at or before this read's position can go out now */
+        while(hp.n && (i == b->n || hp.v[0].rpos <= b->ri[i].pos)) { if(seg_reserve(b, 1)) return -1; heap_pop(&hp, &b->seg[b->n_seg]); b->n_seg++; }
+        if(i == b->n) break;
+        r = &b->ri[i];
+        sf = (uint8_t)((r->strand & 7) | ((r->bamflag & 0x80) ? MDK_SF_READ2 : 0) | (r->second ? MDK_SF_SECOND : 0));
         no = cigar_runs(b->cig + r->cig_off, r->ncig, r->pos, (int32_t)r->lq, &ro, &co);
         /* only pairs whose strands agree in parity are resolved against each other (overlaps.c:63-65) */
         if(r->mate >= 0 && (((int)r->strand - (int)b->ri[r->mate].strand) & 1) == 0) {
@@ -602,16 +628,16 @@ static int build_segments(mdk_plan *p, batchbuf *b, int64_t beg, int64_t end) {
         for(a = 0; a < no; a++) {
             int32_t cur = ro[a].x, stop = ro[a].x + ro[a].l;
             while(cur < stop) {
-                int32_t pe = stop; int covered = 0; md_seg *g;
+                int32_t pe = stop; int covered = 0; md_seg g;
                 while(j < nm && rm[j].x + rm[j].l <= cur) j++;        /* partner runs are ascending, so is cur */
                 if(j < nm) { if(rm[j].x <= cur) { covered = 1; if(rm[j].x + rm[j].l < pe) pe = rm[j].x + rm[j].l; } else if(rm[j].x < pe) pe = rm[j].x; }
                 if(pe - cur > 65535) pe = cur + 65535;
                 if(pe > beg && cur < end) {                         /* pieces wholly outside the counted columns are not needed */
-                    if(seg_reserve(b, 1)) return -1;
-                    g = &b->seg[b->n_seg++];
-                    g->rpos = cur; g->off4 = r->off4; g->l_qseq = r->lq; g->q0 = (uint32_t)(ro[a].y + (cur - ro[a].x)); g->len = (uint16_t)(pe - cur);
-                    g->sf = sf; g->msf = 0; g->m_off4 = 0; g->m_l_qseq = 0; g->m_q0 = 0;
-                    if(covered) { g->sf |= MDK_SF_PARTNER; g->msf = msf; g->m_off4 = m->off4; g->m_l_qseq = m->lq; g->m_q0 = (uint32_t)(rm[j].y + (cur - rm[j].x)); }
+                    g.rpos = cur; g.off4 = r->off4; g.l_qseq = r->lq; g.q0 = (uint32_t)(ro[a].y + (cur - ro[a].x)); g.len = (uint16_t)(pe - cur);
+                    g.sf = sf; g.msf = 0; g.m_off4 = 0; g.m_l_qseq = 0; g.m_q0 = 0;
+                    if(covered) { g.sf |= MDK_SF_PARTNER; g.msf = msf; g.m_off4 = m->off4; g.m_l_qseq = m->lq; g.m_q0 = (uint32_t)(rm[j].y + (cur - rm[j].x)); }
+                    if(cur <= r->pos) { if(seg_reserve(b, 1)) return -1; b->seg[b->n_seg++] = g; }      /* in order already */
+                    else if(heap_push(&hp, &g)) return -1;
                 }
                 cur = pe;
             }

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(WG) void k_classify(const char *ref, uint8_t *code,
     }
 }
 
-#define KB 4      // positions per batch: their base/qual bytes (own + partner) are all in flight together
+#define KB 2      // positions per batch: their base/qual bytes (own + partner) are all in flight together
 
 // One segment, one lane.
 template <bool VARIANT>
@@ -209,7 +209,7 @@ __device__ __forceinline__ int wave_scan_incl(int v, int lane) {
 }
 
 template <bool VARIANT>
-__global__ __launch_bounds__(WG) void k_pileup(const KParams P) {
+__global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
     extern __shared__ __align__(16) uint32_t lds[];
     const int TILE = P.tile, PER = TILE / WG;
     uint32_t *cm = lds, *cu = lds + TILE, *co = lds + 2 * TILE, *cv = lds + 3 * TILE;
@@ -279,6 +279,11 @@ __global__ __launch_bounds__(WG) void k_pileup(const KParams P) {
         const md_seg g = P.seg[r];
         lane_seg<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
     }
+    // reserve this tile's output segment: at most one site per kept context position (unused slots stay empty,
+    // md_tile_seg.cnt says how many are filled).  Issued by the first thread once its own segments are done, so the
+    // atomic's round trip overlaps the wait for the slower wavefronts, and the tiles' atomics are spread in time.
+    uint32_t reserved = 0;
+    if(tid == 0) reserved = (nC + nG) ? atomicAdd(P.total, (uint32_t)(nC + nG)) : 0u;
     if(P.dbg) tc2 = clock64();
     __syncthreads();
     if(P.dbg) tc3 = clock64();
@@ -295,14 +300,12 @@ __global__ __launch_bounds__(WG) void k_pileup(const KParams P) {
     }
     const int incl = wave_scan_incl(cnt, lane);
     if(lane == 63) wsum[wave] = incl;
+    if(tid == 0) sbase = reserved;
     __syncthreads();
     if(tid == 0) {
         int tot = 0; for(int w = 0; w < WAVES; w++) tot += wsum[w];
-        const uint32_t base = tot ? atomicAdd(P.total, (uint32_t)tot) : 0u;
-        sbase = base;
-        md_tile_seg sg; sg.off = base; sg.cnt = (uint32_t)tot; P.tseg[t] = sg;
+        md_tile_seg sg; sg.off = reserved; sg.cnt = (uint32_t)tot; P.tseg[t] = sg;
     }
-    __syncthreads();
     {
         uint32_t o = sbase + (uint32_t)(incl - cnt);
         for(int w = 0; w < wave; w++) o += (uint32_t)wsum[w];
@@ -612,24 +615,24 @@ extern "C" int md_dev_wait(md_dev *h, int slot, md_sites_dev *out) {
     memset(out, 0, sizeof(*out));
     int64_t n = finish_count(h, s);
     if(n < 0) return (int)n;
-    out->n_sites = n; out->n_tiles = s->ntiles;
+    out->n_slots = n; out->n_tiles = s->ntiles;
     out->d_site = s->b_site ? s->b_site : s->d_site.p; out->d_var = h->variant ? (s->b_site ? s->b_var : s->d_var.p) : nullptr;
     out->d_seg = s->b_site ? s->b_seg : s->d_seg.p;
     return 0;
 }
 
-extern "C" int md_sites_order(const md_site *site, const md_site_var *var, const md_tile_seg *seg, int32_t n_tiles, int64_t n_sites, md_site *out_site, md_site_var *out_var) {
-    if(n_sites < 0 || n_tiles < 0 || (n_sites && (!site || !seg || !out_site))) return MDK_ERR_ARG;
+extern "C" int64_t md_sites_order(const md_site *site, const md_site_var *var, const md_tile_seg *seg, int32_t n_tiles, int64_t n_slots, md_site *out_site, md_site_var *out_var) {
+    if(n_slots < 0 || n_tiles < 0 || (n_slots && (!site || !seg || !out_site))) return MDK_ERR_ARG;
     int64_t o = 0;
     for(int t = 0; t < n_tiles; t++) {
         uint32_t c = seg[t].cnt;
         if(!c) continue;
-        if((int64_t)seg[t].off + c > n_sites || o + c > n_sites) return MDK_ERR_ARG;
+        if((int64_t)seg[t].off + c > n_slots || o + c > n_slots) return MDK_ERR_ARG;
         memcpy(out_site + o, site + seg[t].off, (size_t)c * sizeof(md_site));
         if(var && out_var) memcpy(out_var + o, var + seg[t].off, (size_t)c * sizeof(md_site_var));
         o += c;
     }
-    return o == n_sites ? 0 : MDK_ERR_ARG;
+    return o;
 }
 
 extern "C" int md_dev_download(md_dev *h, int slot, md_sites *out) {
@@ -639,7 +642,8 @@ extern "C" int md_dev_download(md_dev *h, int slot, md_sites *out) {
     md_sites_dev dv;
     int rc = md_dev_wait(h, slot, &dv);
     if(rc) return rc;
-    size_t nn = (size_t)dv.n_sites, nt = (size_t)(s->ntiles > 0 ? s->ntiles : 1);
+    size_t nn = (size_t)dv.n_slots, nt = (size_t)(s->ntiles > 0 ? s->ntiles : 1);
+    int64_t nsites = 0;
     if(s->h_site.need(nn + 1) || s->h_sorted.need(nn + 1) || s->h_seg.need(nt)) return MDK_ERR_NOMEM;
     if(h->variant && (s->h_var.need(nn + 1) || s->h_vsorted.need(nn + 1))) return MDK_ERR_NOMEM;
     if(nn) {
@@ -647,10 +651,10 @@ extern "C" int md_dev_download(md_dev *h, int slot, md_sites *out) {
         if(h->variant) HIPCHK(hipMemcpyAsync(s->h_var.p, dv.d_var, nn * sizeof(md_site_var), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipMemcpyAsync(s->h_seg.p, dv.d_seg, (size_t)s->ntiles * sizeof(md_tile_seg), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
-        rc = md_sites_order(s->h_site.p, h->variant ? s->h_var.p : nullptr, s->h_seg.p, s->ntiles, dv.n_sites, s->h_sorted.p, h->variant ? s->h_vsorted.p : nullptr);
-        if(rc) return fail(MDK_ERR_ARG, "md_dev_download: inconsistent tile segments", hipSuccess);
+        nsites = md_sites_order(s->h_site.p, h->variant ? s->h_var.p : nullptr, s->h_seg.p, s->ntiles, dv.n_slots, s->h_sorted.p, h->variant ? s->h_vsorted.p : nullptr);
+        if(nsites < 0) return fail(MDK_ERR_ARG, "md_dev_download: inconsistent tile segments", hipSuccess);
     }
-    out->n_sites = dv.n_sites; out->site = s->h_sorted.p; out->var = h->variant ? s->h_vsorted.p : nullptr;
+    out->n_sites = nsites; out->site = s->h_sorted.p; out->var = h->variant ? s->h_vsorted.p : nullptr;
     return 0;
 }
 
@@ -667,7 +671,8 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
     HIPCHK(hipSetDevice(h->device));
     memset(out, 0, sizeof(*out));
     int rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
-    int64_t n = finish_count(h, s); if(n < 0) return (int)n;
+    int64_t n;
+    { md_sites tmp; rc = md_dev_download(h, slot, &tmp); if(rc) return rc; n = tmp.n_sites; }
     for(int i = 0; i < warmup; i++) { rc = launch_kernels(h, s, false); if(rc) return rc; }
     HIPCHK(hipStreamSynchronize(s->stream));
     // (a) one launch at a time, bracketed by events (includes the dispatch latency of a lone launch)
