@@ -20,8 +20,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <time.h>
 #include "mdk_extract.h"
 #include "mdk_io.h"
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 #define MDK_VERSION "0.6.1"
 
@@ -75,14 +79,17 @@ struct mdk_plan {
     int32_t last_tid, last_pos;
     uint8_t *carry; size_t carry_len, carry_cap; int32_t carry_tid;
     uint8_t *carry2; size_t carry2_len, carry2_cap;
-    batchbuf bb[2]; int cur_bb;
-    qent *qt; size_t qt_cap;
+    /* chunk pipeline: reader thread -> worker threads -> ordered delivery (see the pipeline section) */
+    struct pslot *slot; int n_slot, n_workers; pthread_t reader_th, *worker_th; int started, quit, pipe_rc, reader_done;
+    pthread_mutex_t mu; pthread_cond_t cv_free, cv_raw, cv_done;
+    uint32_t next_out; int held[2];
     /* mappability */
     int map_on; uint32_t map_n; char **map_names; uint32_t *map_len; uint8_t **map_bits; int *map_of_tid;
     /* outputs */
     FILE *out[3]; sbuf ob[3];
     uint32_t next_emit;
     int32_t lastcpg_tid, lastcpg_pos, lastchg_tid, lastchg_pos; uint32_t lastcpg_m, lastcpg_u, lastchg_m, lastchg_u;
+    double t_collect, t_pair, t_segs, t_emit;      /* MDK_HOST_PROFILE=1: seconds per host stage */
     /* device references already uploaded: (dev handle, tid) pairs */
     md_dev **ref_dev; int32_t *ref_tid; int n_ref, cap_ref;
 };
@@ -201,6 +208,7 @@ enum { O_NOCPG = 1, O_CHG, O_CHH, O_KEEPDUPES, O_KEEPSINGLETON, O_KEEPDISCORDANT
        O_NOT, O_NOB, O_NCTOT, O_NCTOB, O_MINOPP, O_MAXVARFRAC, O_CHUNKSIZE, O_KEEPSTRAND, O_CYTREPORT, O_MINCONVEFF, O_IGNORENH };
 
 static void plan_free(mdk_plan *p);
+static void pipeline_stop(mdk_plan *p);
 
 int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     static const struct option longopts[] = {
@@ -358,9 +366,8 @@ static void plan_free(mdk_plan *p) {
     mdk_fasta_free(&p->fa); free(p->fa_of_tid); free(p->map_of_tid);
     for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); }
     free(p->map_names); free(p->map_len); free(p->map_bits);
+    pipeline_stop(p);
     free(p->carry); free(p->carry2);
-    bb_free(&p->bb[0]); bb_free(&p->bb[1]);
-    if(p->qt) { size_t q; for(q = 0; q < p->qt_cap; q++) free(p->qt[q].more); free(p->qt); }
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); }
     else for(i = 0; i < 3; i++) if(p->out[i]) fclose(p->out[i]);
     for(i = 0; i < 3; i++) free(p->ob[i].s);
@@ -527,30 +534,31 @@ static uint64_t hash_str(const char *s) { uint64_t h = 0xcbf29ce484222325ULL; fo
 /* The qname bookkeeping htslib's pileup does through the constructor/destructor callbacks
  * (overlaps.c:121-147), evaluated lazily per qname.  A buffered read whose end precedes the position of the
  * most recently pulled read has been swept out of the pileup buffer, and its destructor erased the qname key. */
-static qent *qt_get(mdk_plan *p, const batchbuf *b, uint32_t qoff) {
-    const char *name = b->qn + qoff; uint64_t h = hash_str(name); size_t mask = p->qt_cap - 1, i = (size_t)h & mask;
+static __thread qent *t_qt = NULL; static __thread size_t t_qt_cap = 0;      /* one qname table per worker thread */
+static qent *qt_get(const batchbuf *b, uint32_t qoff) {
+    const char *name = b->qn + qoff; uint64_t h = hash_str(name); size_t mask = t_qt_cap - 1, i = (size_t)h & mask;
     for(;; i = (i + 1) & mask) {
-        qent *e = &p->qt[i];
+        qent *e = &t_qt[i];
         if(!e->used) { e->used = 1; e->h = h; e->qoff = qoff; e->pending = -1; e->nlive = 0; e->nmore = 0; return e; }
         if(e->h == h && !strcmp(b->qn + e->qoff, name)) return e;
     }
 }
-static void qt_prepare(mdk_plan *p, size_t expect) {
+static void qt_prepare(size_t expect) {
     size_t want = 1024, i;
     while(want < expect * 2 + 16) want <<= 1;
-    if(want > p->qt_cap) { if(p->qt) for(i = 0; i < p->qt_cap; i++) free(p->qt[i].more); free(p->qt); p->qt = calloc(want, sizeof(qent)); p->qt_cap = want; }
-    else for(i = 0; i < p->qt_cap; i++) { p->qt[i].used = 0; }
+    if(want > t_qt_cap) { if(t_qt) for(i = 0; i < t_qt_cap; i++) free(t_qt[i].more); free(t_qt); t_qt = calloc(want, sizeof(qent)); t_qt_cap = want; }
+    else for(i = 0; i < t_qt_cap; i++) { t_qt[i].used = 0; }
 }
-static void pair_reads(mdk_plan *p, batchbuf *b, int32_t tid) {
+static void pair_reads(batchbuf *b, int32_t tid) {
     size_t i, n = b->n; int32_t prev_pos = 0; int first = 1;
-    qt_prepare(p, n);
+    qt_prepare(n);
     for(i = 0; i < n; i++) {
         rinfo *r = &b->ri[i]; int32_t pos = r->pos, end = r->rend; int inserted; qent *e; int k, w, evicted = 0;
         r->mate = -1; r->second = 0;
         /* bam_plp_push: a read enters the buffer iff its end lies beyond the column about to be emitted */
         if(first) inserted = (tid > 0) || (end > 0); else inserted = end > prev_pos;
         if(inserted) {
-            e = qt_get(p, b, r->qn_off);
+            e = qt_get(b, r->qn_off);
             for(k = 0, w = 0; k < e->nlive; k++) { if(!first && e->live[k] < prev_pos) evicted = 1; else e->live[w++] = e->live[k]; }
             e->nlive = w;
             for(k = 0, w = 0; k < e->nmore; k++) { if(!first && e->more[k] < prev_pos) evicted = 1; else e->more[w++] = e->more[k]; }
@@ -707,11 +715,32 @@ static uint32_t adjust_end(const mdk_plan *p, uint32_t tid, uint32_t end) {
     return end;
 }
 
-int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
-    const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; batchbuf *b; int which, rc, fi; mdk_rec r;
-    const char *win = NULL; int64_t woff = 0, wlen = 0; size_t off;
-    (void)which;
-    memset(c, 0, sizeof(*c));
+/* ------------------------------------------------------------------------------------------------ */
+/* chunk pipeline                                                                                    */
+/*   reader  : walks the reference's chunk schedule over the (block-parallel inflated) BAM stream and copies the      */
+/*             raw records of each chunk -- straddlers carried over from the previous chunk first -- into a slot     */
+/*   workers : admission, packing, pairing, CIGAR expansion of one chunk each (chunks are independent)               */
+/*   consumer: mdk_plan_next_chunk hands the chunks out in schedule order                                            */
+/* ------------------------------------------------------------------------------------------------ */
+enum { S_FREE = 0, S_FILL, S_RAW, S_WORK, S_DONE, S_HELD };
+typedef struct pslot {
+    int state; mdk_chunk c;
+    uint8_t *raw; size_t raw_len, raw_cap;                /* [u32 len][record bytes]... */
+    const char *win; int64_t woff, wlen;
+    batchbuf bb; int rc;
+} pslot;
+
+static int raw_push(pslot *sl, const mdk_rec *r) {
+    size_t need = sl->raw_len + 4 + r->raw_len;
+    if(need > sl->raw_cap) { sl->raw_cap = need * 2 + (1 << 20); sl->raw = realloc(sl->raw, sl->raw_cap); if(!sl->raw) return -1; }
+    memcpy(sl->raw + sl->raw_len, &r->raw_len, 4); memcpy(sl->raw + sl->raw_len + 4, r->raw, r->raw_len); sl->raw_len = need;
+    return 0;
+}
+
+/* schedule step + raw collection for one chunk; 1 = produced, 0 = schedule finished, <0 error */
+static int reader_fill(mdk_plan *p, pslot *sl) {
+    const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; int rc, fi; mdk_rec r; size_t off; mdk_chunk *c = &sl->c;
+    memset(c, 0, sizeof(*c)); sl->raw_len = 0; sl->win = NULL; sl->woff = sl->wlen = 0;
     /* extract.c:325-350 */
     c->index = p->bin++;
     tid = p->g_tid; beg = p->g_pos; end = (uint32_t)(beg + o->chunk_size);
@@ -725,16 +754,14 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
     if(p->g_end && beg >= p->g_end) return 0;
     c->tid = (int32_t)tid; c->beg = beg; c->end = end;
     if(p->shard_world > 1 && (int)(c->index % (uint32_t)p->shard_world) != p->shard_rank) c->skipped |= MDK_CHUNK_FOREIGN;
-    which = p->cur_bb; p->cur_bb ^= 1; b = &p->bb[which];
-    b->n = 0; b->blob_len = 0; b->qn_len = 0; b->cig_len = 0; b->n_seg = 0; b->algo_bytes = 0;
     fi = p->fa_of_tid[tid];
     if(fi < 0) {
         if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", -2, bam->target_name[tid], beg > 1 ? beg - 2 : 0, end);
         if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "Note that the output will be truncated!\n");
         c->skipped |= MDK_CHUNK_NOREF;
     } else {
-        woff = beg > 1 ? (int64_t)beg - 2 : 0; wlen = (int64_t)end + 10 + 1; if(wlen > p->fa.len[fi]) wlen = p->fa.len[fi]; wlen -= woff; if(wlen < 0) wlen = 0;
-        win = p->fa.seq[fi] + woff;
+        sl->woff = beg > 1 ? (int64_t)beg - 2 : 0; sl->wlen = (int64_t)end + 10 + 1; if(sl->wlen > p->fa.len[fi]) sl->wlen = p->fa.len[fi]; sl->wlen -= sl->woff; if(sl->wlen < 0) sl->wlen = 0;
+        sl->win = p->fa.seq[fi] + sl->woff;
     }
     /* reads of this chunk, file order: straddlers carried over from the previous chunk, then the stream */
     p->carry2_len = 0;
@@ -746,7 +773,7 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
             off += 4 + (size_t)len;
             rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
             c->n_records_seen++;
-            if(endp > (int32_t)beg && r.pos < (int32_t)end && !c->skipped) { if(admit_and_pack(p, b, &r, rlen, win, woff, wlen) < 0) return -5; }
+            if(endp > (int32_t)beg && r.pos < (int32_t)end && !c->skipped) { if(raw_push(sl, &r)) return -5; }
             if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
         }
     }
@@ -761,19 +788,129 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
         if(r.tid == (int32_t)tid) {
             rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
             c->n_records_seen++;
-            if(endp > (int32_t)beg && !c->skipped) { if(admit_and_pack(p, b, &r, rlen, win, woff, wlen) < 0) return -5; }
+            if(endp > (int32_t)beg && !c->skipped) { if(raw_push(sl, &r)) return -5; }
             if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
         }
         mdk_bam_advance(bam, &r);
     }
     if(rc < 0) { fprintf(stderr, "[mdk] error while reading %s: %s\n", o->bam_name, bam->err); return -2; }
     { uint8_t *t = p->carry; size_t tc = p->carry_cap; p->carry = p->carry2; p->carry_len = p->carry2_len; p->carry_cap = p->carry2_cap; p->carry2 = t; p->carry2_cap = tc; p->carry2_len = 0; p->carry_tid = (int32_t)tid; }
-    if(bb_reserve(b, 1, 16, 16, 1) || seg_reserve(b, 1)) return -5;          /* never hand out NULL arrays */
-    pair_reads(p, b, (int32_t)tid);
-    if(build_segments(p, b, beg, end)) return -5;
-    c->batch.tid = (int32_t)tid; c->batch.beg = beg; c->batch.end = end; c->batch.n_segs = (int32_t)b->n_seg; c->batch.seg = b->seg;
-    c->batch.blob = b->blob; c->batch.blob_bytes = b->blob_len; c->batch.n_reads = (int32_t)b->n; c->batch.algo_bytes = b->algo_bytes;
     return 1;
+}
+
+/* admission + packing + pairing + segments of one chunk */
+static int worker_process(mdk_plan *p, pslot *sl) {
+    batchbuf *b = &sl->bb; mdk_chunk *c = &sl->c; size_t off; mdk_rec r; double t0 = now_s(), t1, t2;
+    b->n = 0; b->blob_len = 0; b->qn_len = 0; b->cig_len = 0; b->n_seg = 0; b->algo_bytes = 0;
+    for(off = 0; off < sl->raw_len;) {
+        uint32_t len; memcpy(&len, sl->raw + off, 4);
+        if(mdk_rec_parse(sl->raw + off + 4, len, &r) != 0) return -2;
+        off += 4 + (size_t)len;
+        if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen) < 0) return -5;
+    }
+    if(bb_reserve(b, 1, 16, 16, 1) || seg_reserve(b, 1)) return -5;          /* never hand out NULL arrays */
+    t1 = now_s();
+    pair_reads(b, c->tid);
+    t2 = now_s();
+    if(build_segments(p, b, c->beg, c->end)) return -5;
+    c->batch.tid = c->tid; c->batch.beg = c->beg; c->batch.end = c->end; c->batch.n_segs = (int32_t)b->n_seg; c->batch.seg = b->seg;
+    c->batch.blob = b->blob; c->batch.blob_bytes = b->blob_len; c->batch.n_reads = (int32_t)b->n; c->batch.algo_bytes = b->algo_bytes;
+    pthread_mutex_lock(&p->mu); p->t_collect += t1 - t0; p->t_pair += t2 - t1; p->t_segs += now_s() - t2; pthread_mutex_unlock(&p->mu);
+    return 0;
+}
+
+static void *reader_main(void *arg) {
+    mdk_plan *p = arg;
+    for(;;) {
+        pslot *sl = NULL; int i, rc;
+        pthread_mutex_lock(&p->mu);
+        while(!p->quit) { for(i = 0; i < p->n_slot; i++) if(p->slot[i].state == S_FREE) { sl = &p->slot[i]; break; } if(sl) break; pthread_cond_wait(&p->cv_free, &p->mu); }
+        if(p->quit) { pthread_mutex_unlock(&p->mu); break; }
+        sl->state = S_FILL;
+        pthread_mutex_unlock(&p->mu);
+        rc = reader_fill(p, sl);
+        pthread_mutex_lock(&p->mu);
+        if(rc == 1) { sl->state = S_RAW; pthread_cond_signal(&p->cv_raw); }
+        else { sl->state = S_FREE; if(rc < 0) p->pipe_rc = rc; p->reader_done = 1; pthread_cond_broadcast(&p->cv_raw); pthread_cond_broadcast(&p->cv_done); }
+        pthread_mutex_unlock(&p->mu);
+        if(rc != 1) break;
+    }
+    return NULL;
+}
+static void *worker_main(void *arg) {
+    mdk_plan *p = arg;
+    for(;;) {
+        pslot *sl = NULL; int i, rc; uint32_t best = 0;
+        pthread_mutex_lock(&p->mu);
+        for(;;) {
+            sl = NULL;
+            for(i = 0; i < p->n_slot; i++) if(p->slot[i].state == S_RAW && (!sl || p->slot[i].c.index < best)) { sl = &p->slot[i]; best = sl->c.index; }
+            if(sl || p->quit || p->reader_done) break;
+            pthread_cond_wait(&p->cv_raw, &p->mu);
+        }
+        if(!sl) { pthread_mutex_unlock(&p->mu); break; }       /* nothing left and the reader has finished (or we are quitting) */
+        sl->state = S_WORK;
+        pthread_mutex_unlock(&p->mu);
+        rc = worker_process(p, sl);
+        pthread_mutex_lock(&p->mu);
+        sl->rc = rc; sl->state = S_DONE; if(rc < 0 && !p->pipe_rc) p->pipe_rc = rc;
+        pthread_cond_broadcast(&p->cv_done);
+        pthread_mutex_unlock(&p->mu);
+    }
+    if(t_qt) { size_t q; for(q = 0; q < t_qt_cap; q++) free(t_qt[q].more); free(t_qt); t_qt = NULL; t_qt_cap = 0; }
+    return NULL;
+}
+static int pipeline_start(mdk_plan *p) {
+    int i;
+    p->n_workers = p->o.n_threads < 1 ? 1 : p->o.n_threads; if(p->n_workers > 64) p->n_workers = 64;
+    p->n_slot = p->n_workers + 4;
+    p->slot = calloc((size_t)p->n_slot, sizeof(pslot));
+    p->worker_th = calloc((size_t)p->n_workers, sizeof(pthread_t));
+    if(!p->slot || !p->worker_th) return -5;
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_free, NULL); pthread_cond_init(&p->cv_raw, NULL); pthread_cond_init(&p->cv_done, NULL);
+    p->held[0] = p->held[1] = -1; p->next_out = 0; p->started = 1;
+    pthread_create(&p->reader_th, NULL, reader_main, p);
+    for(i = 0; i < p->n_workers; i++) pthread_create(&p->worker_th[i], NULL, worker_main, p);
+    return 0;
+}
+static void pipeline_stop(mdk_plan *p) {
+    int i;
+    if(!p->started) return;
+    pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->cv_free); pthread_cond_broadcast(&p->cv_raw); pthread_cond_broadcast(&p->cv_done); pthread_mutex_unlock(&p->mu);
+    pthread_join(p->reader_th, NULL);
+    for(i = 0; i < p->n_workers; i++) pthread_join(p->worker_th[i], NULL);
+    for(i = 0; i < p->n_slot; i++) { bb_free(&p->slot[i].bb); free(p->slot[i].raw); }
+    free(p->slot); free(p->worker_th); p->slot = NULL; p->started = 0;
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_free); pthread_cond_destroy(&p->cv_raw); pthread_cond_destroy(&p->cv_done);
+}
+
+int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
+    int i, found = -1, rc = 0;
+    if(!p->started && pipeline_start(p)) return -5;
+    pthread_mutex_lock(&p->mu);
+    /* the chunk handed out two calls ago is no longer referenced by the caller: recycle its buffers */
+    if(p->held[1] >= 0) { p->slot[p->held[1]].state = S_FREE; pthread_cond_signal(&p->cv_free); }
+    p->held[1] = p->held[0]; p->held[0] = -1;
+    for(;;) {
+        int active = 0;
+        for(i = 0; i < p->n_slot; i++) {
+            int st = p->slot[i].state;
+            if(st == S_DONE && p->slot[i].c.index == p->next_out) { found = i; break; }
+            if(st == S_FILL || st == S_RAW || st == S_WORK || st == S_DONE) active = 1;
+        }
+        if(found >= 0) break;
+        if(p->pipe_rc < 0) { rc = p->pipe_rc; break; }
+        if(p->reader_done && !active) { rc = 0; break; }
+        pthread_cond_wait(&p->cv_done, &p->mu);
+    }
+    if(found >= 0) {
+        pslot *sl = &p->slot[found];
+        if(sl->rc < 0) rc = sl->rc; else { *c = sl->c; rc = 1; }
+        sl->state = S_HELD; p->held[0] = found; p->next_out++;
+    }
+    pthread_mutex_unlock(&p->mu);
+    if(rc <= 0) memset(c, 0, sizeof(*c));
+    return rc;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -823,6 +960,7 @@ static void put_blanks(mdk_plan *p, const char *chrom, const char *seq, int64_t 
 int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
     const opts_t *o = &p->o; const char *chrom; int64_t i; int fi; const char *seq = NULL; int64_t slen = 0, blank_from;
     int k; char tri[4];
+    double te0 = now_s();
     if(c->index != p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
     p->next_emit++;
     if(c->skipped & MDK_CHUNK_NOREF) return 0;
@@ -871,11 +1009,13 @@ int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
     } else if(o->cytosine_report) put_blanks(p, chrom, seq, slen, &blank_from, c->end);
     if(o->cytosine_report) { if(p->ob[0].l) { fputs(p->ob[0].s, p->out[0]); p->ob[0].l = 0; } }
     else for(k = 0; k < 3; k++) if(o->ctx_on[k] && p->ob[k].l) { fputs(p->ob[k].s, p->out[k]); p->ob[k].l = 0; }
+    p->t_emit += now_s() - te0;
     return 0;
 }
 
 int mdk_plan_finish(mdk_plan *p) {
     int i;
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] inflate+frame+admit+pack %.3fs (inflate alone %.3fs)  pairing %.3fs  segments %.3fs  emit %.3fs\n", p->t_collect, p->bam->t_inflate, p->t_pair, p->t_segs, p->t_emit);
     if(p->n_variant_positions) printf("%" PRIu64 " positions were excluded due to likely being variants.\n", p->n_variant_positions);
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); p->out[0] = p->out[1] = p->out[2] = NULL; }
     else for(i = 0; i < 3; i++) if(p->out[i]) { fclose(p->out[i]); p->out[i] = NULL; }

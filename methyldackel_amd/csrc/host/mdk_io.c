@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <time.h>
+static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 #define CCHUNK (24u << 20)     /* compressed bytes pulled per refill */
 
@@ -77,7 +79,9 @@ static int refill(mdk_bam *b) {
 /* make at least n bytes available at uoff; 1 ok, 0 clean EOF (no bytes left), <0 error */
 static int need(mdk_bam *b, size_t n) {
     while(b->ulen - b->uoff < n) {
+        double t0 = io_now();
         int rc = refill(b);
+        b->t_inflate += io_now() - t0;
         if(rc < 0) return rc;
         if(rc == 1) {
             if(b->ulen - b->uoff >= n) return 1;

@@ -16,6 +16,7 @@ typedef struct {
     int32_t n_targets; char **target_name; uint32_t *target_len;
     char *text; uint32_t l_text;
     uint64_t n_records;
+    double t_inflate;                        /* seconds spent in refill (read + inflate) */
     char err[256];
 } mdk_bam;
 
