@@ -209,6 +209,7 @@ enum { O_NOCPG = 1, O_CHG, O_CHH, O_KEEPDUPES, O_KEEPSINGLETON, O_KEEPDISCORDANT
 
 static void plan_free(mdk_plan *p);
 static void pipeline_stop(mdk_plan *p);
+static int pipeline_start(mdk_plan *p);
 
 int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     static const struct option longopts[] = {
@@ -723,9 +724,12 @@ static uint32_t adjust_end(const mdk_plan *p, uint32_t tid, uint32_t end) {
 /*   consumer: mdk_plan_next_chunk hands the chunks out in schedule order                                            */
 /* ------------------------------------------------------------------------------------------------ */
 enum { S_FREE = 0, S_FILL, S_RAW, S_WORK, S_DONE, S_HELD };
+typedef struct { mdk_slab *slab; size_t beg, end; } rrange;      /* records parsed in place from an inflate slab */
 typedef struct pslot {
     int state; mdk_chunk c;
-    uint8_t *raw; size_t raw_len, raw_cap;                /* [u32 len][record bytes]... */
+    uint8_t *raw; size_t raw_len, raw_cap;                /* copied records (straddlers from earlier chunks): [u32 len][record bytes]... */
+    rrange *rg; int n_rg, cap_rg;                         /* then these ranges of the stream, in order */
+    uint64_t n_stream;                                    /* records in the ranges (for up-front reservation) */
     const char *win; int64_t woff, wlen;
     batchbuf bb; int rc;
 } pslot;
@@ -740,7 +744,7 @@ static int raw_push(pslot *sl, const mdk_rec *r) {
 /* schedule step + raw collection for one chunk; 1 = produced, 0 = schedule finished, <0 error */
 static int reader_fill(mdk_plan *p, pslot *sl) {
     const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; int rc, fi; mdk_rec r; size_t off; mdk_chunk *c = &sl->c;
-    memset(c, 0, sizeof(*c)); sl->raw_len = 0; sl->win = NULL; sl->woff = sl->wlen = 0;
+    memset(c, 0, sizeof(*c)); sl->raw_len = 0; sl->n_rg = 0; sl->n_stream = 0; sl->win = NULL; sl->woff = sl->wlen = 0;
     /* extract.c:325-350 */
     c->index = p->bin++;
     tid = p->g_tid; beg = p->g_pos; end = (uint32_t)(beg + o->chunk_size);
@@ -788,7 +792,15 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
         if(r.tid == (int32_t)tid) {
             rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
             c->n_records_seen++;
-            if(endp > (int32_t)beg && !c->skipped) { if(raw_push(sl, &r)) return -5; }
+            if(endp > (int32_t)beg && !c->skipped) {          /* in place: extend the open range or start a new one */
+                size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
+                if(g && g->slab == cs && g->end == roff) g->end = roff + 4 + r.raw_len;
+                else {
+                    if(sl->n_rg == sl->cap_rg) { sl->cap_rg = sl->cap_rg ? sl->cap_rg * 2 : 16; sl->rg = realloc(sl->rg, sizeof(rrange) * sl->cap_rg); if(!sl->rg) return -5; }
+                    g = &sl->rg[sl->n_rg++]; g->slab = cs; g->beg = roff; g->end = roff + 4 + r.raw_len; mdk_slab_ref(bam, cs);
+                }
+                sl->n_stream++;
+            }
             if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
         }
         mdk_bam_advance(bam, &r);
@@ -801,13 +813,29 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
 /* admission + packing + pairing + segments of one chunk */
 static int worker_process(mdk_plan *p, pslot *sl) {
     batchbuf *b = &sl->bb; mdk_chunk *c = &sl->c; size_t off; mdk_rec r; double t0 = now_s(), t1, t2;
+    int g; size_t bytes = sl->raw_len;
     b->n = 0; b->blob_len = 0; b->qn_len = 0; b->cig_len = 0; b->n_seg = 0; b->algo_bytes = 0;
+    /* one reservation per chunk instead of growing (the blob is pinned memory, which is expensive to allocate): the
+     * payload, names and CIGARs of the admitted reads are all smaller than the raw records they come from */
+    for(g = 0; g < sl->n_rg; g++) bytes += sl->rg[g].end - sl->rg[g].beg;
+    if(bb_reserve(b, (size_t)sl->n_stream + c->n_records_seen + 16, bytes + 4096, bytes / 4 + 4096, bytes / 16 + 4096) || seg_reserve(b, 2 * (size_t)sl->n_stream + 1024)) return -5;
     for(off = 0; off < sl->raw_len;) {
         uint32_t len; memcpy(&len, sl->raw + off, 4);
         if(mdk_rec_parse(sl->raw + off + 4, len, &r) != 0) return -2;
         off += 4 + (size_t)len;
         if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen) < 0) return -5;
     }
+    for(g = 0; g < sl->n_rg; g++) {
+        const uint8_t *base = sl->rg[g].slab->buf;
+        for(off = sl->rg[g].beg; off < sl->rg[g].end;) {
+            uint32_t len; memcpy(&len, base + off, 4);
+            if(mdk_rec_parse(base + off + 4, len, &r) != 0) return -2;
+            off += 4 + (size_t)len;
+            if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen) < 0) return -5;
+        }
+        mdk_slab_unref(p->bam, sl->rg[g].slab);
+    }
+    sl->n_rg = 0;
     if(bb_reserve(b, 1, 16, 16, 1) || seg_reserve(b, 1)) return -5;          /* never hand out NULL arrays */
     t1 = now_s();
     pair_reads(b, c->tid);
@@ -879,7 +907,7 @@ static void pipeline_stop(mdk_plan *p) {
     pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->cv_free); pthread_cond_broadcast(&p->cv_raw); pthread_cond_broadcast(&p->cv_done); pthread_mutex_unlock(&p->mu);
     pthread_join(p->reader_th, NULL);
     for(i = 0; i < p->n_workers; i++) pthread_join(p->worker_th[i], NULL);
-    for(i = 0; i < p->n_slot; i++) { bb_free(&p->slot[i].bb); free(p->slot[i].raw); }
+    for(i = 0; i < p->n_slot; i++) { int g; for(g = 0; g < p->slot[i].n_rg; g++) mdk_slab_unref(p->bam, p->slot[i].rg[g].slab); bb_free(&p->slot[i].bb); free(p->slot[i].raw); free(p->slot[i].rg); }
     free(p->slot); free(p->worker_th); p->slot = NULL; p->started = 0;
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_free); pthread_cond_destroy(&p->cv_raw); pthread_cond_destroy(&p->cv_done);
 }
@@ -1025,14 +1053,22 @@ int mdk_plan_finish(mdk_plan *p) {
 /* ------------------------------------------------------------------------------------------------ */
 /* the drop-in entry point                                                                           */
 /* ------------------------------------------------------------------------------------------------ */
+typedef struct { int device; md_dev_cfg cfg; md_dev *dev; int rc; } devopen_t;
+static void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); return NULL; }
+
 int extract_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; md_dev_cfg cfg; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1, device = 0;
+    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth;
     rc = mdk_plan_open(argc, argv, &p);
     if(rc != 0 || !p) return rc;
-    mdk_plan_dev_cfg(p, &cfg);
-    if(getenv("MDK_DEVICE")) device = atoi(getenv("MDK_DEVICE"));
-    rc = md_dev_open(device, &cfg, &dev);
-    if(rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    /* HIP initialisation takes a few hundred ms: do it while the host pipeline already inflates and packs */
+    memset(&dop, 0, sizeof(dop));
+    mdk_plan_dev_cfg(p, &dop.cfg);
+    if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
+    pthread_create(&dth, NULL, devopen_main, &dop);
+    if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
+    pthread_join(dth, NULL);
+    dev = dop.dev;
+    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then emit k-1 */
     while(more || have[0] || have[1]) {
         int cur = k & 1, prev = cur ^ 1;

@@ -8,7 +8,7 @@
 #include <time.h>
 static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
-#define CCHUNK (24u << 20)     /* compressed bytes pulled per refill */
+#define CCHUNK (8u << 20)      /* compressed bytes inflated into one slab */
 
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -35,59 +35,120 @@ static void *inflate_worker(void *arg) {
     return NULL;
 }
 
-/* pull more compressed data, inflate every complete BGZF member in it, append to ubuf (after compacting) */
-static int refill(mdk_bam *b) {
-    size_t n, off = 0, total = 0; blk_t *blk = NULL; int nb = 0, mb = 0;
-    if(b->uoff) { memmove(b->ubuf, b->ubuf + b->uoff, b->ulen - b->uoff); b->ulen -= b->uoff; b->uoff = 0; }
+/* ---- slabs ---- */
+static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) {          /* inflater side: a free slab with room for need_cap bytes */
+    mdk_slab *s = NULL;
+    pthread_mutex_lock(&b->mu);
+    while(!b->quit) {
+        if(b->n_pool) { s = b->pool[--b->n_pool]; break; }
+        if(b->n_alloc < b->max_alloc) { b->n_alloc++; s = calloc(1, sizeof(*s)); break; }
+        pthread_cond_wait(&b->cv_pool, &b->mu);
+    }
+    pthread_mutex_unlock(&b->mu);
+    if(!s) return NULL;
+    if(s->cap < need_cap) { free(s->buf); s->cap = need_cap + (need_cap >> 3); s->buf = malloc(s->cap); if(!s->buf) { free(s); return NULL; } }
+    s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM;
+    return s;
+}
+void mdk_slab_ref(mdk_bam *b, mdk_slab *s) { pthread_mutex_lock(&b->mu); s->refs++; pthread_mutex_unlock(&b->mu); }
+void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
+    pthread_mutex_lock(&b->mu);
+    if(--s->refs == 0) {
+        if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = realloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); }
+        b->pool[b->n_pool++] = s; pthread_cond_signal(&b->cv_pool);
+    }
+    pthread_mutex_unlock(&b->mu);
+}
+
+/* one slab: pull CCHUNK compressed bytes, inflate every complete BGZF member of them (fanned out to nthreads) */
+static mdk_slab *inflate_slab(mdk_bam *b, int *status) {          /* status: 0 ok, 1 end of file, <0 error */
+    size_t n, off = 0, total = 0; blk_t *blk = NULL; int nb = 0, mb = 0; mdk_slab *s;
+    *status = 0;
     if(!b->file_eof) {
-        if(b->ccap < b->clen + CCHUNK) { b->ccap = b->clen + CCHUNK; b->cbuf = realloc(b->cbuf, b->ccap); if(!b->cbuf) return -1; }
+        if(b->ccap < b->clen + CCHUNK) { b->ccap = b->clen + CCHUNK; b->cbuf = realloc(b->cbuf, b->ccap); if(!b->cbuf) { *status = -1; return NULL; } }
         n = fread(b->cbuf + b->clen, 1, CCHUNK, b->f);
         b->clen += n;
         if(n < CCHUNK) b->file_eof = 1;
     }
     while(off + 18 <= b->clen) {
         const uint8_t *p = b->cbuf + off; uint16_t xlen; uint32_t bsize = 0, isize; size_t x; int have = 0;
-        if(p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { snprintf(b->err, sizeof(b->err), "not a BGZF file (bad gzip member header)"); free(blk); return -2; }
+        if(p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { snprintf(b->err, sizeof(b->err), "not a BGZF file (bad gzip member header)"); free(blk); *status = -2; return NULL; }
         xlen = le16(p + 10);
         if(off + 12 + xlen > b->clen) break;
         for(x = 12; x + 4 <= 12u + xlen;) { uint16_t sl = le16(p + x + 2); if(p[x] == 'B' && p[x + 1] == 'C' && sl == 2) { bsize = le16(p + x + 4) + 1u; have = 1; } x += 4 + sl; }
-        if(!have || bsize < 12u + xlen + 8u) { snprintf(b->err, sizeof(b->err), "BGZF member without a valid BC field"); free(blk); return -2; }
+        if(!have || bsize < 12u + xlen + 8u) { snprintf(b->err, sizeof(b->err), "BGZF member without a valid BC field"); free(blk); *status = -2; return NULL; }
         if(off + bsize > b->clen) break;
         isize = le32(p + bsize - 4);
-        if(nb == mb) { mb = mb ? mb * 2 : 1024; blk = realloc(blk, sizeof(blk_t) * mb); if(!blk) return -1; }
+        if(nb == mb) { mb = mb ? mb * 2 : 1024; blk = realloc(blk, sizeof(blk_t) * mb); if(!blk) { *status = -1; return NULL; } }
         blk[nb].in = p + 12 + xlen; blk[nb].in_len = bsize - 12 - xlen - 8; blk[nb].out = NULL; blk[nb].out_len = isize; nb++;
         total += isize; off += bsize;
     }
-    if(b->ucap < b->ulen + total + 8) { b->ucap = b->ulen + total + (total >> 2) + 4096; b->ubuf = realloc(b->ubuf, b->ucap); if(!b->ubuf) { free(blk); return -1; } }
-    { size_t o = b->ulen; for(int i = 0; i < nb; i++) { blk[i].out = b->ubuf + o; o += blk[i].out_len; } }
-    if(nb) {
+    if(nb == 0) {
+        free(blk);
+        if(b->file_eof) { if(b->clen) { snprintf(b->err, sizeof(b->err), "truncated BGZF member at end of file"); *status = -2; } else *status = 1; return NULL; }
+        snprintf(b->err, sizeof(b->err), "BGZF member larger than the read window"); *status = -2; return NULL;
+    }
+    s = slab_get(b, MDK_SLAB_HEADROOM + total + 64);
+    if(!s) { free(blk); *status = b->quit ? 1 : -1; return NULL; }
+    { size_t o = s->beg; for(int i = 0; i < nb; i++) { blk[i].out = s->buf + o; o += blk[i].out_len; } s->end = o; }
+    {
         inflate_job job; int nt = b->nthreads, i; pthread_t th[64];
         job.blk = blk; job.n = nb; job.next = 0; job.failed = 0; pthread_mutex_init(&job.mu, NULL);
         if(nt > 64) nt = 64; if(nt > (nb + 7) / 8) nt = (nb + 7) / 8; if(nt < 1) nt = 1;
         if(nt == 1) inflate_worker(&job);
         else { for(i = 0; i < nt; i++) pthread_create(&th[i], NULL, inflate_worker, &job); for(i = 0; i < nt; i++) pthread_join(th[i], NULL); }
         pthread_mutex_destroy(&job.mu);
-        if(job.failed) { snprintf(b->err, sizeof(b->err), "BGZF inflate failed (corrupt file?)"); free(blk); return -2; }
+        if(job.failed) { snprintf(b->err, sizeof(b->err), "BGZF inflate failed (corrupt file?)"); free(blk); mdk_slab_unref(b, s); *status = -2; return NULL; }
     }
-    b->ulen += total;
     memmove(b->cbuf, b->cbuf + off, b->clen - off); b->clen -= off;
     free(blk);
-    if(nb == 0 && b->file_eof) { if(b->clen) { snprintf(b->err, sizeof(b->err), "truncated BGZF member at end of file"); return -2; } return 1; }
-    return 0;
+    return s;
 }
 
-/* make at least n bytes available at uoff; 1 ok, 0 clean EOF (no bytes left), <0 error */
+static void *inflater_main(void *arg) {
+    mdk_bam *b = arg;
+    for(;;) {
+        int st; mdk_slab *s = inflate_slab(b, &st);
+        pthread_mutex_lock(&b->mu);
+        if(s) {
+            while(b->q_n == 4 && !b->quit) pthread_cond_wait(&b->cv_pool, &b->mu);
+            if(b->quit) { pthread_mutex_unlock(&b->mu); break; }
+            b->queue[b->q_n++] = s; pthread_cond_broadcast(&b->cv_q);
+            pthread_mutex_unlock(&b->mu);
+            continue;
+        }
+        b->inf_done = st < 0 ? st : 1; pthread_cond_broadcast(&b->cv_q);
+        pthread_mutex_unlock(&b->mu);
+        break;
+    }
+    return NULL;
+}
+
+/* scanner side: next inflated slab (blocking); NULL at end of data or on error (b->inf_done < 0) */
+static mdk_slab *slab_next(mdk_bam *b) {
+    mdk_slab *s = NULL; double t0 = io_now();
+    pthread_mutex_lock(&b->mu);
+    while(!b->q_n && !b->inf_done) pthread_cond_wait(&b->cv_q, &b->mu);
+    if(b->q_n) { s = b->queue[0]; memmove(b->queue, b->queue + 1, sizeof(mdk_slab *) * (size_t)(--b->q_n)); pthread_cond_broadcast(&b->cv_pool); }
+    pthread_mutex_unlock(&b->mu);
+    b->t_inflate += io_now() - t0;
+    return s;
+}
+
+/* make at least n bytes available at the scan position, moving to the next slab when the current one runs out
+ * (the unfinished tail is completed in the next slab's headroom); 1 ok, 0 clean end of data, <0 error */
 static int need(mdk_bam *b, size_t n) {
-    while(b->ulen - b->uoff < n) {
-        double t0 = io_now();
-        int rc = refill(b);
-        b->t_inflate += io_now() - t0;
-        if(rc < 0) return rc;
-        if(rc == 1) {
-            if(b->ulen - b->uoff >= n) return 1;
-            if(b->ulen == b->uoff) return 0;
+    while(!b->cur || b->cur->end - b->off < n) {
+        mdk_slab *s = slab_next(b); size_t left = b->cur ? b->cur->end - b->off : 0;
+        if(!s) {
+            if(b->inf_done < 0) return b->inf_done;
+            if(left == 0) return 0;
             snprintf(b->err, sizeof(b->err), "truncated BAM record at end of file"); return -2;
         }
+        if(left > s->beg) { snprintf(b->err, sizeof(b->err), "BAM record larger than %u bytes", MDK_SLAB_HEADROOM); mdk_slab_unref(b, s); return -2; }
+        if(left) { memcpy(s->buf + s->beg - left, b->cur->buf + b->off, left); s->beg -= left; }
+        if(b->cur) mdk_slab_unref(b, b->cur);
+        b->cur = s; b->off = s->beg;
     }
     return 1;
 }
@@ -98,22 +159,25 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     b->f = fopen(fn, "rb");
     if(!b->f) { free(b); return NULL; }
     b->nthreads = nthreads < 1 ? 1 : nthreads;
-    if((rc = need(b, 12)) <= 0 || memcmp(b->ubuf + b->uoff, "BAM\1", 4)) { mdk_bam_close(b); return NULL; }
-    b->l_text = le32(b->ubuf + b->uoff + 4);
+    b->max_alloc = b->nthreads * 2 + 8;           /* slabs that may exist at once (each worker may pin a few) */
+    pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL);
+    pthread_create(&b->inf_th, NULL, inflater_main, b); b->inf_started = 1;
+    if((rc = need(b, 12)) <= 0 || memcmp(b->cur->buf + b->off, "BAM\1", 4)) { mdk_bam_close(b); return NULL; }
+    b->l_text = le32(b->cur->buf + b->off + 4);
     if(need(b, 12 + (size_t)b->l_text) <= 0) { mdk_bam_close(b); return NULL; }
-    b->text = malloc((size_t)b->l_text + 1); memcpy(b->text, b->ubuf + b->uoff + 8, b->l_text); b->text[b->l_text] = 0;
-    b->n_targets = (int32_t)le32(b->ubuf + b->uoff + 8 + b->l_text);
-    b->uoff += 12 + (size_t)b->l_text;
+    b->text = malloc((size_t)b->l_text + 1); memcpy(b->text, b->cur->buf + b->off + 8, b->l_text); b->text[b->l_text] = 0;
+    b->n_targets = (int32_t)le32(b->cur->buf + b->off + 8 + b->l_text);
+    b->off += 12 + (size_t)b->l_text;
     b->target_name = calloc((size_t)b->n_targets + 1, sizeof(char *)); b->target_len = calloc((size_t)b->n_targets + 1, sizeof(uint32_t));
     for(i = 0; i < (uint32_t)b->n_targets; i++) {
         uint32_t ln;
         if(need(b, 4) <= 0) { mdk_bam_close(b); return NULL; }
-        ln = le32(b->ubuf + b->uoff);
+        ln = le32(b->cur->buf + b->off);
         if(need(b, 8 + (size_t)ln) <= 0) { mdk_bam_close(b); return NULL; }
-        o = b->uoff;
-        b->target_name[i] = malloc((size_t)ln + 1); memcpy(b->target_name[i], b->ubuf + o + 4, ln); b->target_name[i][ln] = 0;
-        b->target_len[i] = le32(b->ubuf + o + 4 + ln);
-        b->uoff += 8 + (size_t)ln;
+        o = b->off;
+        b->target_name[i] = malloc((size_t)ln + 1); memcpy(b->target_name[i], b->cur->buf + o + 4, ln); b->target_name[i][ln] = 0;
+        b->target_len[i] = le32(b->cur->buf + o + 4 + ln);
+        b->off += 8 + (size_t)ln;
     }
     return b;
 }
@@ -121,10 +185,22 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
 void mdk_bam_close(mdk_bam *b) {
     int i;
     if(!b) return;
+    if(b->inf_started) {
+        pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
+        pthread_join(b->inf_th, NULL);
+    }
+    if(b->cur) { free(b->cur->buf); free(b->cur); }
+    for(i = 0; i < b->q_n; i++) { free(b->queue[i]->buf); free(b->queue[i]); }
+    for(i = 0; i < b->n_pool; i++) { free(b->pool[i]->buf); free(b->pool[i]); }
+    free(b->pool);
     if(b->f) fclose(b->f);
     if(b->target_name) for(i = 0; i < b->n_targets; i++) free(b->target_name[i]);
-    free(b->target_name); free(b->target_len); free(b->text); free(b->cbuf); free(b->ubuf); free(b);
+    free(b->target_name); free(b->target_len); free(b->text); free(b->cbuf);
+    pthread_mutex_destroy(&b->mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool);
+    free(b);
 }
+
+mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off) { *off = b->off; return b->cur; }
 
 int mdk_rec_parse(const uint8_t *r, uint32_t len, mdk_rec *o) {
     if(len < 32) return -1;
@@ -144,13 +220,13 @@ int mdk_rec_parse(const uint8_t *r, uint32_t len, mdk_rec *o) {
 int mdk_bam_peek(mdk_bam *b, mdk_rec *r) {
     int rc = need(b, 4); uint32_t bs;
     if(rc <= 0) return rc;
-    bs = le32(b->ubuf + b->uoff);
+    bs = le32(b->cur->buf + b->off);
     rc = need(b, 4 + (size_t)bs);
     if(rc <= 0) { if(rc == 0) { snprintf(b->err, sizeof(b->err), "truncated BAM record at end of file"); return -2; } return rc; }
-    if(mdk_rec_parse(b->ubuf + b->uoff + 4, bs, r) != 0) { snprintf(b->err, sizeof(b->err), "malformed BAM record"); return -2; }
+    if(mdk_rec_parse(b->cur->buf + b->off + 4, bs, r) != 0) { snprintf(b->err, sizeof(b->err), "malformed BAM record"); return -2; }
     return 1;
 }
-void mdk_bam_advance(mdk_bam *b, const mdk_rec *r) { b->uoff += 4 + (size_t)r->raw_len; b->n_records++; }
+void mdk_bam_advance(mdk_bam *b, const mdk_rec *r) { b->off += 4 + (size_t)r->raw_len; b->n_records++; }
 
 /* ---- FASTA ---- */
 int mdk_fasta_load(const char *fn, mdk_fasta *fa) {

@@ -4,19 +4,32 @@
  * (sam_itr_next at common.c:413, faidx_fetch_seq at extract.c:381). */
 #ifndef MDK_IO_H
 #define MDK_IO_H
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 
-typedef struct {
+/* Inflated data travels in reference-counted SLABS so that the chunk workers can parse records in place (no copy):
+ * an inflater thread (which fans the BGZF members of a slab out to a pool of threads) runs ahead of the scanner;
+ * the scanner hands [slab, begin, end) ranges to the chunks; a slab returns to the pool when its last user drops it.
+ * A record cut by a slab boundary is completed in the headroom in front of the next slab's data. */
+#define MDK_SLAB_HEADROOM (16u << 20)
+typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs; } mdk_slab;
+
+typedef struct mdk_bam {
     FILE *f;
     int nthreads;
-    uint8_t *cbuf; size_t ccap, clen;        /* compressed bytes not yet inflated */
-    uint8_t *ubuf; size_t ucap, ulen, uoff;  /* inflated bytes; records are parsed at uoff */
-    int file_eof;
+    /* inflater thread + slab queue/pool */
+    pthread_t inf_th; int inf_started;
+    pthread_mutex_t mu; pthread_cond_t cv_q, cv_pool;
+    mdk_slab *queue[4]; int q_n; int inf_done, quit;
+    mdk_slab **pool; int n_pool, cap_pool, n_alloc, max_alloc;
+    uint8_t *cbuf; size_t ccap, clen; int file_eof;
+    /* scanner position */
+    mdk_slab *cur; size_t off;
     int32_t n_targets; char **target_name; uint32_t *target_len;
     char *text; uint32_t l_text;
     uint64_t n_records;
-    double t_inflate;                        /* seconds spent in refill (read + inflate) */
+    double t_inflate;                        /* seconds the scanner waited for inflated data */
     char err[256];
 } mdk_bam;
 
@@ -30,6 +43,10 @@ typedef struct {
 } mdk_rec;
 
 mdk_bam *mdk_bam_open(const char *fn, int nthreads);
+/* slab holding the record last returned by mdk_bam_peek, and the byte offset of that record's block_size word in it */
+mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off);
+void mdk_slab_ref(mdk_bam *b, mdk_slab *s);
+void mdk_slab_unref(mdk_bam *b, mdk_slab *s);
 void mdk_bam_close(mdk_bam *b);
 /* 1 = record available, 0 = end of file, <0 = error (b->err) */
 int mdk_bam_peek(mdk_bam *b, mdk_rec *r);
