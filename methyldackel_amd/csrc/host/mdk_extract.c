@@ -363,11 +363,11 @@ static void bb_free(batchbuf *b) { md_host_free(b->seg); md_host_free(b->blob); 
 static void plan_free(mdk_plan *p) {
     uint32_t k; int i;
     if(!p) return;
+    pipeline_stop(p);               /* the reader and the workers use the BAM reader, the FASTA and the bitmaps: stop them first */
     if(p->bam) mdk_bam_close(p->bam);
     mdk_fasta_free(&p->fa); free(p->fa_of_tid); free(p->map_of_tid);
     for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); }
     free(p->map_names); free(p->map_len); free(p->map_bits);
-    pipeline_stop(p);
     free(p->carry); free(p->carry2);
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); }
     else for(i = 0; i < 3; i++) if(p->out[i]) fclose(p->out[i]);
@@ -520,6 +520,15 @@ static int bb_reserve(batchbuf *b, size_t more_reads, size_t more_blob, size_t m
     if(b->cig_len + more_cig > b->cig_cap) { b->cig_cap = (b->cig_len + more_cig) * 2 + 4096; b->cig = realloc(b->cig, b->cig_cap * 4); if(!b->cig) return -1; }
     return 0;
 }
+/* one-shot reservation at the start of a chunk (buffers are empty): no doubling, pinned memory is precious */
+static int bb_reserve_exact(batchbuf *b, size_t reads, size_t blob, size_t qn, size_t cig, size_t segs) {
+    if(reads > b->cap_ri) { b->cap_ri = reads + reads / 8; b->ri = realloc(b->ri, b->cap_ri * sizeof(rinfo)); if(!b->ri) return -1; }
+    if(blob > b->cap_blob) { md_host_free(b->blob); b->cap_blob = blob + blob / 8; b->blob = md_host_alloc(b->cap_blob); if(!b->blob) return -1; }
+    if(qn > b->qn_cap) { b->qn_cap = qn + qn / 8; b->qn = realloc(b->qn, b->qn_cap); if(!b->qn) return -1; }
+    if(cig > b->cig_cap) { b->cig_cap = cig + cig / 8; b->cig = realloc(b->cig, b->cig_cap * 4); if(!b->cig) return -1; }
+    if(segs > b->cap_seg) { md_host_free(b->seg); b->cap_seg = segs + segs / 8; b->seg = md_host_alloc(b->cap_seg * sizeof(md_seg)); if(!b->seg) return -1; }
+    return 0;
+}
 static int seg_reserve(batchbuf *b, size_t more) {
     if(b->n_seg + more > b->cap_seg) {
         size_t nc = (b->n_seg + more) * 2 + 4096; md_seg *d = md_host_alloc(nc * sizeof(md_seg));
@@ -535,20 +544,20 @@ static uint64_t hash_str(const char *s) { uint64_t h = 0xcbf29ce484222325ULL; fo
 /* The qname bookkeeping htslib's pileup does through the constructor/destructor callbacks
  * (overlaps.c:121-147), evaluated lazily per qname.  A buffered read whose end precedes the position of the
  * most recently pulled read has been swept out of the pileup buffer, and its destructor erased the qname key. */
-static __thread qent *t_qt = NULL; static __thread size_t t_qt_cap = 0;      /* one qname table per worker thread */
+static __thread qent *t_qt = NULL; static __thread size_t t_qt_cap = 0; static __thread int t_gen = 0;     /* one qname table per worker thread; `used` holds the chunk generation */
 static qent *qt_get(const batchbuf *b, uint32_t qoff) {
     const char *name = b->qn + qoff; uint64_t h = hash_str(name); size_t mask = t_qt_cap - 1, i = (size_t)h & mask;
     for(;; i = (i + 1) & mask) {
         qent *e = &t_qt[i];
-        if(!e->used) { e->used = 1; e->h = h; e->qoff = qoff; e->pending = -1; e->nlive = 0; e->nmore = 0; return e; }
+        if(e->used != t_gen) { e->used = t_gen; e->h = h; e->qoff = qoff; e->pending = -1; e->nlive = 0; e->nmore = 0; return e; }
         if(e->h == h && !strcmp(b->qn + e->qoff, name)) return e;
     }
 }
 static void qt_prepare(size_t expect) {
     size_t want = 1024, i;
     while(want < expect * 2 + 16) want <<= 1;
-    if(want > t_qt_cap) { if(t_qt) for(i = 0; i < t_qt_cap; i++) free(t_qt[i].more); free(t_qt); t_qt = calloc(want, sizeof(qent)); t_qt_cap = want; }
-    else for(i = 0; i < t_qt_cap; i++) { t_qt[i].used = 0; }
+    if(want > t_qt_cap) { if(t_qt) for(i = 0; i < t_qt_cap; i++) free(t_qt[i].more); free(t_qt); t_qt = calloc(want, sizeof(qent)); t_qt_cap = want; t_gen = 0; }
+    if(++t_gen == 0x7fffffff) { for(i = 0; i < t_qt_cap; i++) t_qt[i].used = 0; t_gen = 1; }     /* a new generation empties the table */
 }
 static void pair_reads(batchbuf *b, int32_t tid) {
     size_t i, n = b->n; int32_t prev_pos = 0; int first = 1;
@@ -818,7 +827,7 @@ static int worker_process(mdk_plan *p, pslot *sl) {
     /* one reservation per chunk instead of growing (the blob is pinned memory, which is expensive to allocate): the
      * payload, names and CIGARs of the admitted reads are all smaller than the raw records they come from */
     for(g = 0; g < sl->n_rg; g++) bytes += sl->rg[g].end - sl->rg[g].beg;
-    if(bb_reserve(b, (size_t)sl->n_stream + c->n_records_seen + 16, bytes + 4096, bytes / 4 + 4096, bytes / 16 + 4096) || seg_reserve(b, 2 * (size_t)sl->n_stream + 1024)) return -5;
+    if(bb_reserve_exact(b, (size_t)sl->n_stream + c->n_records_seen + 16, bytes - bytes / 8 + 65536, bytes / 4 + 4096, bytes / 16 + 4096, 2 * (size_t)sl->n_stream + 4096)) return -5;
     for(off = 0; off < sl->raw_len;) {
         uint32_t len; memcpy(&len, sl->raw + off, 4);
         if(mdk_rec_parse(sl->raw + off + 4, len, &r) != 0) return -2;
@@ -890,8 +899,10 @@ static void *worker_main(void *arg) {
 }
 static int pipeline_start(mdk_plan *p) {
     int i;
-    p->n_workers = p->o.n_threads < 1 ? 1 : p->o.n_threads; if(p->n_workers > 64) p->n_workers = 64;
-    p->n_slot = p->n_workers + 4;
+    /* beyond a dozen workers the serial reader is the limit, and every slot pins ~1.2 bytes of host memory per raw BAM
+     * byte of its chunk (expensive to allocate), so the pipeline depth is bounded; -@ still sizes the inflate pool */
+    p->n_workers = p->o.n_threads < 1 ? 1 : p->o.n_threads; if(p->n_workers > 12) p->n_workers = 12;
+    p->n_slot = p->n_workers + 3;
     p->slot = calloc((size_t)p->n_slot, sizeof(pslot));
     p->worker_th = calloc((size_t)p->n_workers, sizeof(pthread_t));
     if(!p->slot || !p->worker_th) return -5;
@@ -905,6 +916,7 @@ static void pipeline_stop(mdk_plan *p) {
     int i;
     if(!p->started) return;
     pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->cv_free); pthread_cond_broadcast(&p->cv_raw); pthread_cond_broadcast(&p->cv_done); pthread_mutex_unlock(&p->mu);
+    mdk_bam_abort(p->bam);          /* wake the reader if it is waiting for inflated data */
     pthread_join(p->reader_th, NULL);
     for(i = 0; i < p->n_workers; i++) pthread_join(p->worker_th[i], NULL);
     for(i = 0; i < p->n_slot; i++) { int g; for(g = 0; g < p->slot[i].n_rg; g++) mdk_slab_unref(p->bam, p->slot[i].rg[g].slab); bb_free(&p->slot[i].bb); free(p->slot[i].raw); free(p->slot[i].rg); }

@@ -200,6 +200,11 @@ void mdk_bam_close(mdk_bam *b) {
     free(b);
 }
 
+void mdk_bam_abort(mdk_bam *b) {
+    if(!b) return;
+    pthread_mutex_lock(&b->mu); b->quit = 1; if(!b->inf_done) b->inf_done = 1; pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_pool); pthread_mutex_unlock(&b->mu);
+}
+
 mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off) { *off = b->off; return b->cur; }
 
 int mdk_rec_parse(const uint8_t *r, uint32_t len, mdk_rec *o) {

@@ -48,6 +48,8 @@ mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off);
 void mdk_slab_ref(mdk_bam *b, mdk_slab *s);
 void mdk_slab_unref(mdk_bam *b, mdk_slab *s);
 void mdk_bam_close(mdk_bam *b);
+/* make every blocked or future read return end-of-data (used to stop a reader thread) */
+void mdk_bam_abort(mdk_bam *b);
 /* 1 = record available, 0 = end of file, <0 = error (b->err) */
 int mdk_bam_peek(mdk_bam *b, mdk_rec *r);
 void mdk_bam_advance(mdk_bam *b, const mdk_rec *r);
