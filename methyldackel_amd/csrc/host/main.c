@@ -1,6 +1,7 @@
 /* main.c -- `MethylDackel` command of the MI355X build.  Only `extract` is accelerated (and built); the
  * reference's dispatcher is main.c:39-62. */
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "mdk_extract.h"
 
@@ -14,7 +15,10 @@ int main(int argc, char *argv[]) {
     if(argc == 1) { usage_main(); return 0; }
     if(!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage_main(); return 0; }
     if(!strcmp(argv[1], "-v") || !strcmp(argv[1], "--version")) { printf("0.6.1 (using HTSlib version none; methyldackel_amd MI355X build)\n"); return 0; }
-    if(!strcmp(argv[1], "extract")) return extract_main(argc - 1, argv + 1);
+    if(!strcmp(argv[1], "extract")) {
+        setenv("MDK_FAST_EXIT", "1", 0);      /* a process about to end need not unpin buffers and shut the runtime down politely */
+        return extract_main(argc - 1, argv + 1);
+    }
     if(!strcmp(argv[1], "mbias") || !strcmp(argv[1], "mergeContext") || !strcmp(argv[1], "perRead")) { fprintf(stderr, "`%s` is not part of the MI355X build.\n", argv[1]); return -1; }
     fprintf(stderr, "Unknown command!\n"); usage_main(); return -1;
 }

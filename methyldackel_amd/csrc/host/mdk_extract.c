@@ -22,6 +22,7 @@
 #include <string.h>
 #include <pthread.h>
 #include <time.h>
+#include <unistd.h>
 #include "mdk_extract.h"
 #include "mdk_io.h"
 
@@ -1070,7 +1071,9 @@ static void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d
 
 int extract_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth;
+    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta;
     rc = mdk_plan_open(argc, argv, &p);
+    t_open = now_s() - T0;
     if(rc != 0 || !p) return rc;
     /* HIP initialisation takes a few hundred ms: do it while the host pipeline already inflates and packs */
     memset(&dop, 0, sizeof(dop));
@@ -1079,19 +1082,24 @@ int extract_main(int argc, char *argv[]) {
     pthread_create(&dth, NULL, devopen_main, &dop);
     if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     pthread_join(dth, NULL);
+    t_dev = now_s() - T0;
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then emit k-1 */
     while(more || have[0] || have[1]) {
         int cur = k & 1, prev = cur ^ 1;
         if(more) {
+            ta = now_s();
             rc = mdk_plan_next_chunk(p, &ch[cur]);
+            w_next += now_s() - ta;
             if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
             if(rc == 0) more = 0;
             else {
                 if(!ch[cur].skipped) {
+                    ta = now_s();
                     rc = mdk_plan_ensure_reference(p, dev, ch[cur].tid);
                     if(!rc) rc = md_dev_submit(dev, cur, &ch[cur].batch);
+                    w_sub += now_s() - ta;
                     if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
                 }
                 have[cur] = 1;
@@ -1100,17 +1108,26 @@ int extract_main(int argc, char *argv[]) {
         if(have[prev]) {
             md_sites sites; memset(&sites, 0, sizeof(sites));
             if(!ch[prev].skipped) {
+                ta = now_s();
                 rc = md_dev_download(dev, prev, &sites);
+                w_down += now_s() - ta;
                 if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
             }
+            ta = now_s();
             if(mdk_plan_emit(p, &ch[prev], &sites)) { ret = MDK_RC_DEVICE; break; }
+            w_emit += now_s() - ta;
             have[prev] = 0;
         }
         k++;
         if(!more && !have[0] && !have[1]) break;
     }
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0);
     if(ret == 0) mdk_plan_finish(p);
+    if(getenv("MDK_FAST_EXIT")) {     /* set by the `MethylDackel` command: the outputs are closed; skip unpinning buffers and the HIP shutdown */
+        fflush(stdout); fflush(stderr);
+        _exit(ret & 0xff);
+    }
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;

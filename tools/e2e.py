@@ -16,5 +16,5 @@ for th in ths:
         dt = time.time() - t; best = dt if best is None else min(best, dt)
     ident = all(filecmp.cmp(f"{d}/o/{f}", f"{d}/g/{f}", shallow=False) for f in os.listdir(f"{d}/o"))
     res[f"gpu_cli_threads_{th}"] = {"seconds": round(best, 3), "rc": r.returncode, "identical": ident, "speedup_vs_oracle": round(res["oracle_s"] / best, 2),
-                                    "host_profile": r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ""}
+                                    "host_profile": [l for l in r.stderr.strip().splitlines() if l.startswith("[mdk")]}
 print(json.dumps(res))
