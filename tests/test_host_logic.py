@@ -131,3 +131,24 @@ def test_chunk_schedule_matches_reference_rules(tmp_path, small_synth):
             assert e0 == b1
             assert not (seq[e0 - 1:e0] == b"C" and seq[e0:e0 + 1] == b"G"), "CpG split across chunks"
             assert not (seq[e0 - 2:e0 - 1] == b"C" and seq[e0:e0 + 1] == b"G"), "CHG split across chunks"
+
+
+import test_gpu_edge_cases as edge
+
+
+@pytest.mark.parametrize("fn", [edge.test_quality_boost_wraps_above_213, edge.test_three_records_per_qname_across_chunks_and_zero_length_alignments,
+                                edge.test_cigar_zoo_and_long_runs, edge.test_tags_flags_and_tiny_contigs], ids=lambda f: f.__name__[5:])
+def test_edge_cases_host_side(tmp_path, monkeypatch, fn):
+    """the adversarial BAMs of tests/test_gpu_edge_cases.py through the host side + slow evaluator, on CPU"""
+    n = [0]
+
+    def run(tmp, args, env=None):
+        d = tmp / f"case{n[0]}"
+        d.mkdir()
+        n[0] += 1
+        check(d, list(args), variant="--minOppositeDepth" in args)
+        return d, d
+
+    monkeypatch.setattr(edge, "compare_cli", run)
+    fn(tmp_path)
+    assert n[0] >= 3
