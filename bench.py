@@ -168,6 +168,19 @@ def main():
     pile_s = br.ms_pileup / 1e3
     achieved = br.algo_bytes / pile_s / 1e9 if pile_s > 0 else 0.0
 
+    # HBM traffic of the kernel cannot be sampled from inside this process; it is taken from the committed rocprofv3 PMC summary
+    # of this same command (profiles/, produced by tools/gpu_round.sh + tools/summarize_prof.py), or left null
+    traffic, traffic_note = None, None
+    try:
+        prof = json.load(open(REPO / "profiles" / "r01_rocprofv3_pmc_summary.json"))
+        hb = prof["hbm_traffic_bytes_per_launch"]
+        if not extra and not args.synth_args and args.length == 1_000_000:
+            traffic = hb["fetch_x2_gfx950_correction"] + hb["write_raw"]
+            traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per k_pileup dispatch (profiles/r01_rocprofv3_pmc_summary.json): FETCH_SIZE KiB x 2 (gfx950 under-count, "
+                            "MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB; raw FETCH_SIZE is %.0f bytes" % hb["fetch_raw"])
+    except Exception:
+        pass
+
     result = None
     if rank == 0:
         value = total_cpg_calls * args.steps / dt
@@ -182,7 +195,7 @@ def main():
                        "records_per_gpu": synth_info["records"], "sites_per_gpu": int(n_sites), "cpg_calls_per_gpu": int(cpg_calls),
                        "tile": int(br.tile), "tiles": int(br.n_tiles), "tiles_staged_in_lds": int(br.n_staged_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup, "all_kernels_ms": br.ms_total},
+                         "traffic": traffic, "traffic_source": traffic_note, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup, "all_kernels_ms": br.ms_total},
             "host_prep_s": t_host,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -42,7 +42,7 @@ typedef struct {
     float min_conv_eff, map_cutoff; int min_mappable;
     int rel_bounds[16], abs_bounds[16];
     int n_threads; unsigned long chunk_size;
-    char *region, *opref, *bbm_name, *bw_name, *bed_name, *out_bbm_name;
+    char *region, *opref, *bbm_name, *bw_name, *bed_name, *out_bbm_name;     /* opref and out_bbm_name are owned */
     int output_bb, no_bam, keep_strand;
     const char *fasta_name, *bam_name;
 } opts_t;
@@ -108,8 +108,8 @@ static void usage(void) {
 " --minOppositeDepth INT, --maxVariantFrac FLOAT, --minConversionEfficiency FLOAT,\n"
 " --OT/--OB/--CTOT/--CTOB INT,INT,INT,INT, --nOT/--nOB/--nCTOT/--nCTOB INT,INT,INT,INT,\n"
 " -B/--mappabilityBBM FILE, -t/--mappabilityThreshold FLOAT, -b/--minMappableBases INT,\n"
-" -M/--mappability FILE(*), -O, -N FILE(*), --keepStrand(*), --version\n"
-" (*) needs libraries/paths outside this build: bigWig input and BED-driven extraction.\n"
+" -M/--mappability FILE, -O, -N FILE, --keepStrand(*), --version\n"
+" (*) BED-driven extraction is not part of this build.\n"
 "\nNote that --fraction, --counts, and --logit are mutually exclusive!\n", stderr);
 }
 
@@ -183,6 +183,50 @@ static int load_bbm(mdk_plan *p, FILE *f) {
     p->map_on = 1;
     return 0;
 }
+/* the 0..100 value the reference stores for one bigWig value (extract.c:1137-1144): (char)(raw*100 + 0.5), NaN -> 0 */
+static unsigned char map_value(float raw) { if(isnan(raw)) return 0; return (unsigned char)(char)((raw * 100) + 0.5); }
+
+/* -M: mappability from a bigWig (extract.c:1071-1233), optionally re-encoded as BBM (-O / -N).  The run-length writer
+ * follows the reference's state machine (runs of 2..155 as [len+99][v], longer as [255][u16 len][v], at most 65535 per run,
+ * a trailing run of exactly 155 in the long form) so that the bytes on disk agree. */
+static int load_bigwig(mdk_plan *p) {
+    opts_t *o = &p->o; mdk_bigwig *bw = mdk_bigwig_open(o->bw_name); FILE *f = NULL; uint32_t c;
+    if(!bw) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bw_name); return -4; }
+    if(o->out_bbm_name) {
+        f = fopen(o->out_bbm_name, "wb");
+        if(!f) { fprintf(stderr, "Couldn't open %s for writing! Insufficient permissions?\n", o->out_bbm_name); mdk_bigwig_close(bw); return -7; }
+        fputc(1, f);
+    }
+    fprintf(stderr, "loading mappability data from %s\n", o->bw_name);
+    if(f) { uint32_t n = bw->n; fwrite(&n, 4, 1, f); fprintf(stderr, "writing .bbm file to %s\n", o->out_bbm_name); }
+    p->map_n = bw->n; p->map_names = calloc(bw->n + 1, sizeof(char *)); p->map_len = calloc(bw->n + 1, 4); p->map_bits = calloc(bw->n + 1, sizeof(uint8_t *));
+    for(c = 0; c < bw->n; c++) {
+        uint32_t len = bw->len[c], j; float *v = mdk_bigwig_values(bw, c); double cut = o->map_cutoff * 100.0;
+        unsigned char last = 255; uint16_t run = 0;
+        if(!v) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bw_name); if(f) fclose(f); mdk_bigwig_close(bw); return -4; }
+        p->map_names[c] = strdup(bw->name[c]); p->map_len[c] = len; p->map_bits[c] = calloc((size_t)len / 8 + 9, 1);
+        if(f) { uint16_t nl = (uint16_t)strlen(bw->name[c]); fwrite(&nl, 2, 1, f); fwrite(bw->name[c], 1, nl, f); fputc(0, f); fwrite(&len, 4, 1, f); }
+        for(j = 0; j < len; j++) {
+            unsigned char val = map_value(v[j]);
+            if(f) {
+                if(val == last && run < 65535) run++;
+                else {
+                    if(run > 1) { if(run < 156) { fputc(run + 99, f); fputc(last, f); } else { fputc(255, f); fwrite(&run, 2, 1, f); fputc(last, f); } run = 0; }
+                    if(j + 1 < len && map_value(v[j + 1]) == val) { last = val; run = 1; }
+                    else { fputc(val, f); last = val; run = 0; }
+                }
+            }
+            if((double)val >= cut) p->map_bits[c][j >> 3] |= (uint8_t)(1u << (j & 7));
+        }
+        if(f && run > 1) { if(run < 155) { fputc(run + 99, f); fputc(last, f); } else { fputc(255, f); fwrite(&run, 2, 1, f); fputc(last, f); } }
+        free(v);
+    }
+    if(f) fclose(f);
+    mdk_bigwig_close(bw);
+    p->map_on = 1;
+    return 0;
+}
+
 /* number of set bits in [start, start+l) of chromosome c; bits outside the stored array are 0 */
 static int64_t map_popcount(const mdk_plan *p, int c, int64_t start, int64_t l) {
     int64_t nbits = ((int64_t)p->map_len[c] / 8 + ((p->map_len[c] % 8) ? 1 : 0)) * 8, end = start + l, cnt = 0, k;
@@ -268,8 +312,8 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         case 'M': o->bw_name = optarg; break;
         case 't': o->map_cutoff = (float)atof(optarg); break;
         case 'b': o->min_mappable = atoi(optarg); break;
-        case 'O': o->output_bb = 1; break;
-        case 'N': o->output_bb = 1; o->out_bbm_name = optarg; break;
+        case 'O': o->output_bb = 1; free(o->out_bbm_name); o->out_bbm_name = NULL; break;
+        case 'N': o->output_bb = 1; free(o->out_bbm_name); o->out_bbm_name = malloc(strlen(optarg) + 5); sprintf(o->out_bbm_name, "%s.bbm", optarg); break;
         case 'B': o->bbm_name = optarg; break;
         case 'F': o->ignore_flags = atoi(optarg); break;     /* atoi: "0xD00" parses as 0, as in the reference */
         case 'R': o->require_flags = atoi(optarg); break;
@@ -281,6 +325,11 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         case '@': o->n_threads = atoi(optarg); break;
         default: fprintf(stderr, "Invalid option '%c'\n", c); usage(); plan_free(p); return 1;
         }
+    }
+    if(o->output_bb && !o->out_bbm_name && o->bw_name) {       /* -O: the bigWig's name with its extension replaced by .bbm */
+        char *dot; o->out_bbm_name = malloc(strlen(o->bw_name) + 5); strcpy(o->out_bbm_name, o->bw_name);
+        dot = strrchr(o->out_bbm_name, '.'); if(dot) *dot = 0;
+        strcat(o->out_bbm_name, ".bbm");
     }
     if(o->output_bb && !o->bw_name) { fprintf(stderr, "You must specify a bigWig file when attempting to create a BBM file!\n"); usage(); plan_free(p); return -1; }
     if(argc == 1) { usage(); plan_free(p); return 0; }
@@ -302,7 +351,11 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         fprintf(stderr, "You haven't specified any metrics to output!\nEither don't use the --noCpG option or specify --CHG and/or --CHH.\n");
         plan_free(p); return -1;
     }
-    if(o->bw_name || o->no_bam) { fprintf(stderr, "Couldn't open %s for reading! (bigWig input needs libBigWig, which this build does not have; convert to .bbm and use -B)\n", o->bw_name ? o->bw_name : "bigWig"); plan_free(p); return -4; }
+    if(o->no_bam) {            /* only the bigWig -> BBM conversion was asked for (extract.c:983-994,1217-1230) */
+        int rc = load_bigwig(p);
+        plan_free(p);
+        return rc;
+    }
     if(o->bed_name) { fprintf(stderr, "There was an error while reading in your BED file! (-l/--keepStrand are not part of the MI355X extract path yet)\n"); plan_free(p); return 1; }
 
     o->fasta_name = argv[optind]; o->bam_name = argv[optind + 1];
@@ -310,7 +363,11 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
     if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
     if(o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); plan_free(p); return -8; }
-    if(bbm) { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { plan_free(p); return rc; } }
+    if(o->bw_name) { int rc = load_bigwig(p); if(rc) { if(bbm) fclose(bbm); plan_free(p); return rc; } }
+    if(bbm) {                  /* as in the reference, a BBM given together with a bigWig replaces the bigWig's bitmaps */
+        if(p->map_on) { uint32_t k; for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); } free(p->map_names); free(p->map_len); free(p->map_bits); p->map_names = NULL; p->map_len = NULL; p->map_bits = NULL; p->map_n = 0; }
+        { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { plan_free(p); return rc; } }
+    }
     if(mdk_fasta_load(o->fasta_name, &p->fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", o->fasta_name); plan_free(p); return -4; }
     p->fa_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
     for(i = 0; i < p->bam->n_targets; i++) p->fa_of_tid[i] = mdk_fasta_find(&p->fa, p->bam->target_name[i]);
@@ -373,7 +430,7 @@ static void plan_free(mdk_plan *p) {
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); }
     else for(i = 0; i < 3; i++) if(p->out[i]) fclose(p->out[i]);
     for(i = 0; i < 3; i++) free(p->ob[i].s);
-    free(p->o.opref); free(p->ref_dev); free(p->ref_tid);
+    free(p->o.opref); free(p->o.out_bbm_name); free(p->ref_dev); free(p->ref_tid);
     free(p);
 }
 void mdk_plan_close(mdk_plan *p) { plan_free(p); }

@@ -61,4 +61,11 @@ int mdk_fasta_load(const char *fn, mdk_fasta *fa);
 void mdk_fasta_free(mdk_fasta *fa);
 int mdk_fasta_find(const mdk_fasta *fa, const char *name);
 
+
+/* bigWig (mappability track for -M) */
+typedef struct { FILE *f; uint64_t chrom_tree, index; uint32_t uncompress; uint32_t n, cap; char **name; uint32_t *len, *id; } mdk_bigwig;
+mdk_bigwig *mdk_bigwig_open(const char *fn);
+void mdk_bigwig_close(mdk_bigwig *bw);
+float *mdk_bigwig_values(mdk_bigwig *bw, uint32_t k);
+
 #endif

@@ -52,7 +52,7 @@ def read_dump(path):
 def small_synth(tmp_path_factory):
     """A 60 kb, 2-contig, 25x noisy paired-end sample + a Bismark-style one, shared by several tests."""
     d = tmp_path_factory.mktemp("synth")
-    synth(d / "pe", "-L", "40000,20000", "-c", "25", "-s", "11", "--extras", "--bbm")
+    synth(d / "pe", "-L", "40000,20000", "-c", "25", "-s", "11", "--extras", "--bbm", "--bw")
     synth(d / "bis", "-L", "30000", "-c", "20", "-s", "12", "--bismark")
     synth(d / "se", "-L", "20000", "-c", "15", "-s", "13", "--single")
     return d

@@ -20,14 +20,15 @@ SUFFIXES = ["_CpG.bedGraph", "_CHG.bedGraph", "_CHH.bedGraph", "_CpG.meth.bedGra
             "_CHH.logit.bedGraph", "_CpG.methylKit", "_CHG.methylKit", "_CHH.methylKit", ".cytosine_report.txt"]
 
 
-def compare_cli(tmp_path, args, env=None):
+def compare_cli(tmp_path, args, env=None, oracle_args=None):
     """same command line through the oracle and the product; same prefix (in different dirs) so headers agree"""
     od, gd = tmp_path / "oracle", tmp_path / "gpu"
     od.mkdir(exist_ok=True), gd.mkdir(exist_ok=True)
-    ro = run_oracle(list(args) + ["-o", "out"], cwd=od)
+    ro = run_oracle(list(oracle_args if oracle_args is not None else args) + ["-o", "out"], cwd=od)
     rg = mdk.run_cli(list(args) + ["-o", "out"], cwd=gd, env=env)
     assert rg.returncode == ro.returncode, (rg.returncode, ro.returncode, rg.stderr[-2000:])
     assert rg.stdout == ro.stdout
+    assert [l for l in rg.stderr.splitlines() if l.startswith("loading mappability")] == [l.replace(".bbm", ".bw") for l in ro.stderr.splitlines() if l.startswith("loading mappability")] or oracle_args is None
     seen = 0
     for s in SUFFIXES:
         fo, fg = od / ("out" + s), gd / ("out" + s)
@@ -95,6 +96,7 @@ SYN_CMDS = [
     ("pe", ["-F", "0", "--keepDupes", "--keepSingleton", "--keepDiscordant", "--ignoreNH", "-q", "0", "--chunkSize", "3001", "--CHG"]),
     ("pe", ["--OT", "6,146,6,146", "--OB", "6,146,6,146", "--nOT", "2,3,4,5", "--CHH", "--methylKit"]),
     ("pe", ["-B", "BBM", "--chunkSize", "9999"]),
+    ("pe", ["-M", "BW", "-t", "0.6", "-b", "100", "--mergeContext", "--CHG"]),
     ("pe", ["--minOppositeDepth", "2", "--maxVariantFrac", "0.5", "--CHG", "--chunkSize", "8000", "--mergeContext"]),
     ("pe", ["--cytosine_report", "--CHG", "--CHH", "--chunkSize", "6000", "--minOppositeDepth", "2", "--maxVariantFrac", "0.3"]),
     ("pe", ["--fraction", "-p", "20", "-@", "4"]),
@@ -111,8 +113,13 @@ SYN_CMDS = [
 def test_cli_synthetic_byte_exact(tmp_path, small_synth, which, extra, env):
     """every command line under: LDS-staged tiles (fixed and auto geometry), the global-pointer path, and a budget so
     small that staged and overflowing tiles mix inside one launch"""
+    args = [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")]
+    if "BW" in extra:       # the oracle has no bigWig reader: it gets the same track as BBM
+        compare_cli(tmp_path, args + [str(small_synth / "pe.bw") if e == "BW" else e for e in extra], env=env,
+                    oracle_args=args + [{"BW": str(small_synth / "pe.bbm"), "-M": "-B"}.get(e, e) for e in extra])
+        return
     extra = [str(small_synth / "pe.bbm") if e == "BBM" else e for e in extra]
-    compare_cli(tmp_path, [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")] + extra, env=env)
+    compare_cli(tmp_path, args + extra, env=env)
 
 
 def abi_sites(args):

@@ -152,3 +152,29 @@ def test_edge_cases_host_side(tmp_path, monkeypatch, fn):
     monkeypatch.setattr(edge, "compare_cli", run)
     fn(tmp_path)
     assert n[0] >= 3
+
+
+def test_bigwig_mappability_equals_bbm(tmp_path, small_synth):
+    """-M <bigWig> (own reader: B+ chromosome tree, R-tree, zlib blocks, NaN where uncovered) admits exactly the reads that
+    -B <BBM of the same values> admits, which the oracle also agrees with"""
+    fa, bam = str(small_synth / "pe.fa"), str(small_synth / "pe.bam")
+    for extra in ([], ["-t", "0.6", "-b", "120"], ["-b", "0"], ["-b", "200"]):
+        a, ca = host_counts([fa, bam, "-M", str(small_synth / "pe.bw"), "--chunkSize", "9000", "-o", str(tmp_path / "a")] + extra)
+        b, cb = host_counts([fa, bam, "-B", str(small_synth / "pe.bbm"), "--chunkSize", "9000", "-o", str(tmp_path / "b")] + extra)
+        assert a == b and ca == cb
+    plain, _ = host_counts([fa, bam, "-o", str(tmp_path / "c")])
+    assert plain != a
+
+
+def test_bigwig_to_bbm_conversion_without_bam(tmp_path, small_synth):
+    """`extract -M x.bw -N out` / `-O` only convert (extract.c:983-994): the BBM written is byte-identical to the generator's
+    encoding of the same track, and no device is needed for it"""
+    import shutil
+    shutil.copy(small_synth / "pe.bw", tmp_path / "m.bw")
+    r = mdk.run_cli(["-M", str(tmp_path / "m.bw"), "-N", str(tmp_path / "named")], cwd=tmp_path)
+    assert r.returncode == 0 and "writing .bbm file to" in r.stderr
+    assert (tmp_path / "named.bbm").read_bytes() == (small_synth / "pe.bbm").read_bytes()
+    r = mdk.run_cli(["-M", str(tmp_path / "m.bw"), "-O"], cwd=tmp_path)
+    assert r.returncode == 0 and (tmp_path / "m.bbm").read_bytes() == (small_synth / "pe.bbm").read_bytes()
+    r = mdk.run_cli(["-O"], cwd=tmp_path)
+    assert r.returncode == 255 and "You must specify a bigWig file" in r.stderr

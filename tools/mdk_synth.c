@@ -172,16 +172,16 @@ static void emit_read(buf_t *out, const contig_t *ct, int tid, int64_t pos, cons
 }
 
 int main(int argc, char **argv) {
-    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {0, 0, 0, 0}};
+    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {0, 0, 0, 0}};
     const char *prefix = NULL, *lens = "1000000"; double cov = 30; uint64_t seed = 0x5EED0001ULL; int level = 1, c, want_bbm = 0;
-    opts_t o = {0, 0, 0, 0, 150}; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
+    opts_t o = {0, 0, 0, 0, 150}; int want_bw = 0; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
     buf_t pool = {0, 0, 0}; size_t *offs = NULL; char fn[4096]; uint64_t ord = 0, npairs_total = 0, nbases = 0;
     while((c = getopt_long(argc, argv, "o:L:c:l:s:z:", lo, NULL)) >= 0) {
         switch(c) {
         case 'o': prefix = optarg; break; case 'L': lens = optarg; break; case 'c': cov = atof(optarg); break;
         case 'l': o.readlen = atoi(optarg); break; case 's': seed = strtoull(optarg, NULL, 0); break; case 'z': level = atoi(optarg); break;
-        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break;
-        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [--bismark] [--extras] [--clean] [--bbm] [--single]\n"); return 1;
+        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break;
+        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [--bismark] [--extras] [--clean] [--bbm] [--bw] [--single]\n"); return 1;
         }
     }
     if(!prefix) { fprintf(stderr, "mdk_synth: -o PREFIX is required\n"); return 1; }
@@ -265,25 +265,79 @@ int main(int argc, char **argv) {
       for(i = 0; i < nrec; i++) bgzf_write(&z, recs[i].d, recs[i].n);
       bgzf_close(&z); free(h.p); }
 
-    if(want_bbm) {     /* synthetic mappability: values {0,50,100}; ~10 % of bases in low runs */
-        FILE *f; uint8_t ver = 1; uint32_t nc = (uint32_t)nct;
-        snprintf(fn, sizeof(fn), "%s.bbm", prefix); f = fopen(fn, "wb"); if(!f) { perror(fn); return 1; }
-        fwrite(&ver, 1, 1, f); fwrite(&nc, 4, 1, f);
+    if(want_bbm || want_bw) {     /* synthetic mappability track: values {0, 0.5, 1.0}; written as BBM and/or bigWig (same values) */
+        typedef struct { int64_t beg, end; uint8_t val; } mrun; mrun **runs = calloc(nct, sizeof(mrun *)); size_t *nr = calloc(nct, sizeof(size_t));
         for(t = 0; t < nct; t++) {
-            uint16_t nl = (uint16_t)strlen(ct[t].name); uint8_t z0 = 0; uint32_t cl = (uint32_t)ct[t].len; int64_t p = 0;
-            fwrite(&nl, 2, 1, f); fwrite(ct[t].name, 1, nl, f); fwrite(&z0, 1, 1, f); fwrite(&cl, 4, 1, f);
+            int64_t p = 0; size_t cap = 0;
             while(p < ct[t].len) {
                 int64_t run = (rndu(&rg) < 0.5) ? 1 + rndi(&rg, 3000) : 1 + rndi(&rg, 300); uint8_t val = (rndu(&rg) < 0.25) ? (rndu(&rg) < 0.5 ? 0 : 50) : 100;
                 if(run > ct[t].len - p) run = ct[t].len - p;
+                if(nr[t] && runs[t][nr[t] - 1].val == val) runs[t][nr[t] - 1].end += run;
+                else { if(nr[t] == cap) { cap = cap ? cap * 2 : 1024; runs[t] = realloc(runs[t], cap * sizeof(mrun)); } runs[t][nr[t]].beg = p; runs[t][nr[t]].end = p + run; runs[t][nr[t]].val = val; nr[t]++; }
                 p += run;
-                while(run > 0) {
-                    if(run == 1) { fwrite(&val, 1, 1, f); run = 0; }
-                    else if(run <= 155) { uint8_t rl = (uint8_t)(run + 99); fwrite(&rl, 1, 1, f); fwrite(&val, 1, 1, f); run = 0; }
-                    else { uint8_t fl = 255; uint16_t rl = (uint16_t)(run > 65535 ? 65535 : run); fwrite(&fl, 1, 1, f); fwrite(&rl, 2, 1, f); fwrite(&val, 1, 1, f); run -= rl; }
-                }
             }
         }
-        fclose(f);
+        if(want_bbm) {
+            FILE *f; uint8_t ver = 1; uint32_t nc = (uint32_t)nct;
+            snprintf(fn, sizeof(fn), "%s.bbm", prefix); f = fopen(fn, "wb"); if(!f) { perror(fn); return 1; }
+            fwrite(&ver, 1, 1, f); fwrite(&nc, 4, 1, f);
+            for(t = 0; t < nct; t++) {
+                uint16_t nl = (uint16_t)strlen(ct[t].name); uint8_t z0 = 0; uint32_t cl = (uint32_t)ct[t].len; size_t k;
+                fwrite(&nl, 2, 1, f); fwrite(ct[t].name, 1, nl, f); fwrite(&z0, 1, 1, f); fwrite(&cl, 4, 1, f);
+                for(k = 0; k < nr[t]; k++) {
+                    int64_t run = runs[t][k].end - runs[t][k].beg; uint8_t val = runs[t][k].val;
+                    while(run > 0) {
+                        if(run == 1) { fwrite(&val, 1, 1, f); run = 0; }
+                        else if(run <= 155) { uint8_t rl = (uint8_t)(run + 99); fwrite(&rl, 1, 1, f); fwrite(&val, 1, 1, f); run = 0; }
+                        else { uint8_t fl = 255; uint16_t rl = (uint16_t)(run > 65535 ? 65535 : run); fwrite(&fl, 1, 1, f); fwrite(&rl, 2, 1, f); fwrite(&val, 1, 1, f); run -= rl; }
+                    }
+                }
+            }
+            fclose(f);
+        }
+        if(want_bw) {      /* bigWig: bedGraph sections of <= 512 items, zlib-compressed, one-level R-tree; value-0 runs are left uncovered (NaN) */
+            FILE *f; buf_t body = {0, 0, 0}, idx = {0, 0, 0}; uint32_t nblocks = 0, keySize = 0, maxraw = 0; uint64_t chromTree, dataOff, indexOff; buf_t hdr = {0, 0, 0};
+            for(t = 0; t < nct; t++) if(strlen(ct[t].name) > keySize) keySize = (uint32_t)strlen(ct[t].name);
+            chromTree = 64 + 40; dataOff = chromTree + 32 + 4 + (uint64_t)nct * (keySize + 8);
+            b32(&body, 0); b32(&body, 0);                      /* section count (u64), patched below */
+            for(t = 0; t < nct; t++) {
+                size_t k = 0;
+                while(k < nr[t]) {
+                    buf_t raw = {0, 0, 0}; uint16_t cnt = 0; uint32_t s0 = 0, e0 = 0; size_t k0 = k; uLongf cl; uint8_t *comp;
+                    b32(&raw, (uint32_t)t); b32(&raw, 0); b32(&raw, 0); b32(&raw, 0); b32(&raw, 0); b8(&raw, 1); b8(&raw, 0); b16(&raw, 0);
+                    for(; k < nr[t] && cnt < 512; k++) {
+                        float v = runs[t][k].val / 100.0f;
+                        if(runs[t][k].val == 0) continue;
+                        if(!cnt) s0 = (uint32_t)runs[t][k].beg;
+                        e0 = (uint32_t)runs[t][k].end;
+                        b32(&raw, (uint32_t)runs[t][k].beg); b32(&raw, (uint32_t)runs[t][k].end); bput(&raw, &v, 4); cnt++;
+                    }
+                    if(!cnt) { free(raw.p); if(k == k0) k++; continue; }
+                    raw.p[4] = s0; raw.p[5] = s0 >> 8; raw.p[6] = s0 >> 16; raw.p[7] = s0 >> 24; raw.p[8] = e0; raw.p[9] = e0 >> 8; raw.p[10] = e0 >> 16; raw.p[11] = e0 >> 24;
+                    raw.p[22] = cnt & 0xff; raw.p[23] = cnt >> 8;
+                    if(raw.l > maxraw) maxraw = (uint32_t)raw.l;
+                    cl = compressBound(raw.l); comp = malloc(cl); compress2(comp, &cl, raw.p, raw.l, 6);
+                    b32(&idx, (uint32_t)t); b32(&idx, s0); b32(&idx, (uint32_t)t); b32(&idx, e0);
+                    { uint64_t off = dataOff + body.l, sz = cl; bput(&idx, &off, 8); bput(&idx, &sz, 8); }
+                    bput(&body, comp, cl); free(comp); free(raw.p); nblocks++;
+                }
+            }
+            if(nblocks > 65535) { fprintf(stderr, "mdk_synth: too many bigWig blocks for a one-level index\n"); return 1; }
+            { uint64_t nb = nblocks; memcpy(body.p, &nb, 8); }
+            indexOff = dataOff + body.l;
+            b32(&hdr, 0x888FFC26u); b16(&hdr, 4); b16(&hdr, 0); bput(&hdr, &chromTree, 8); bput(&hdr, &dataOff, 8); bput(&hdr, &indexOff, 8);
+            b16(&hdr, 0); b16(&hdr, 0); { uint64_t z = 0, ts = 64; bput(&hdr, &z, 8); bput(&hdr, &ts, 8); } b32(&hdr, maxraw); { uint64_t z = 0; bput(&hdr, &z, 8); }
+            { uint8_t summ[40] = {0}; bput(&hdr, summ, 40); }
+            b32(&hdr, 0x78CA8C91u); b32(&hdr, (uint32_t)nct); b32(&hdr, keySize); b32(&hdr, 8); { uint64_t ic = nct, z = 0; bput(&hdr, &ic, 8); bput(&hdr, &z, 8); }
+            b8(&hdr, 1); b8(&hdr, 0); b16(&hdr, (uint16_t)nct);
+            for(t = 0; t < nct; t++) { char key[256] = {0}; strncpy(key, ct[t].name, keySize); bput(&hdr, key, keySize); b32(&hdr, (uint32_t)t); b32(&hdr, (uint32_t)ct[t].len); }
+            snprintf(fn, sizeof(fn), "%s.bw", prefix); f = fopen(fn, "wb"); if(!f) { perror(fn); return 1; }
+            fwrite(hdr.p, 1, hdr.l, f); fwrite(body.p, 1, body.l, f);
+            { buf_t r = {0, 0, 0}; uint64_t ic = nblocks, endoff = indexOff; b32(&r, 0x2468ACE0u); b32(&r, 256); bput(&r, &ic, 8); b32(&r, 0); b32(&r, 0); b32(&r, (uint32_t)nct - 1); b32(&r, (uint32_t)ct[nct - 1].len);
+              bput(&r, &endoff, 8); b32(&r, 512); b32(&r, 0); b8(&r, 1); b8(&r, 0); b16(&r, (uint16_t)nblocks); fwrite(r.p, 1, r.l, f); free(r.p); }
+            fwrite(idx.p, 1, idx.l, f);
+            fclose(f); free(hdr.p); free(body.p); free(idx.p);
+        }
     }
     printf("{\"prefix\": \"%s\", \"contigs\": %d, \"records\": %zu, \"pairs\": %" PRIu64 ", \"query_bases\": %" PRIu64 ", \"seed\": %" PRIu64 "}\n", prefix, nct, nrec, npairs_total, nbases, seed);
     return 0;
