@@ -71,13 +71,13 @@ typedef struct { uint64_t h; uint32_t qoff; int32_t pending; int32_t nlive; int3
 
 struct mdk_plan {
     opts_t o;
-    mdk_bam *bam; mdk_fasta fa; int *fa_of_tid;
+    mdk_bam *bam; mdk_bai *bai; int need_seek; mdk_fasta fa; int *fa_of_tid;
     /* schedule cursor (main.c:10-13 globals) */
     uint32_t g_tid, g_pos, g_end, bin;
     int shard_rank, shard_world;       /* interval sharding: this process packs chunk k iff k % world == rank */
     uint64_t n_variant_positions;
     /* stream state */
-    int32_t last_tid, last_pos;
+    int32_t last_tid, last_pos; int at_eof;
     uint8_t *carry; size_t carry_len, carry_cap; int32_t carry_tid;
     uint8_t *carry2; size_t carry2_len, carry2_cap;
     /* chunk pipeline: reader thread -> worker threads -> ordered delivery (see the pipeline section) */
@@ -362,6 +362,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     if(o->n_threads < 1) o->n_threads = 1;
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
     if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
+    p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */
     if(o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); plan_free(p); return -8; }
     if(o->bw_name) { int rc = load_bigwig(p); if(rc) { if(bbm) fclose(bbm); plan_free(p); return rc; } }
     if(bbm) {                  /* as in the reference, a BBM given together with a bigWig replaces the bigWig's bitmaps */
@@ -412,6 +413,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         if(s > 0) p->g_pos = (uint32_t)s;
         if(e > 0) p->g_end = (uint32_t)e;
         if(p->g_end > p->bam->target_len[t]) p->g_end = p->bam->target_len[t];
+        p->need_seek = 1;
     }
     *out = p;
     return 0;
@@ -423,6 +425,7 @@ static void plan_free(mdk_plan *p) {
     if(!p) return;
     pipeline_stop(p);               /* the reader and the workers use the BAM reader, the FASTA and the bitmaps: stop them first */
     if(p->bam) mdk_bam_close(p->bam);
+    mdk_bai_free(p->bai);
     mdk_fasta_free(&p->fa); free(p->fa_of_tid); free(p->map_of_tid);
     for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); }
     free(p->map_names); free(p->map_len); free(p->map_bits);
@@ -833,6 +836,19 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
     } else {
         sl->woff = beg > 1 ? (int64_t)beg - 2 : 0; sl->wlen = (int64_t)end + 10 + 1; if(sl->wlen > p->fa.len[fi]) sl->wlen = p->fa.len[fi]; sl->wlen -= sl->woff; if(sl->wlen < 0) sl->wlen = 0;
         sl->win = p->fa.seq[fi] + sl->woff;
+    }
+    /* With a .bai the stream is repositioned instead of read through: once at the start of a -r region, and before every
+     * own chunk of a sharded run (foreign chunks are then not read at all, like the reference's per-chunk region query). */
+    if(p->bai && (p->need_seek || p->shard_world > 1)) {
+        p->carry_len = 0; p->carry_tid = -1;
+        if(c->skipped & MDK_CHUNK_FOREIGN) return 1;
+        {
+            uint64_t vo = mdk_bai_start(p->bai, (int32_t)tid, beg);
+            if(!vo) { p->need_seek = p->shard_world > 1; p->at_eof = 1; }
+            else { rc = mdk_bam_seek(bam, vo); if(rc < 0) { fprintf(stderr, "[mdk] error while reading %s: %s\n", o->bam_name, bam->err); return -2; } p->at_eof = rc == 0; }
+            p->last_tid = -1; p->last_pos = -1; p->need_seek = 0;
+        }
+        if(p->at_eof) { if(p->shard_world <= 1) p->need_seek = 1; return 1; }      /* no records for this chunk */
     }
     /* reads of this chunk, file order: straddlers carried over from the previous chunk, then the stream */
     p->carry2_len = 0;

@@ -233,6 +233,75 @@ int mdk_bam_peek(mdk_bam *b, mdk_rec *r) {
 }
 void mdk_bam_advance(mdk_bam *b, const mdk_rec *r) { b->off += 4 + (size_t)r->raw_len; b->n_records++; }
 
+/* ---- BAI + seeking ---- */
+mdk_bai *mdk_bai_load(const char *bam_fn) {
+    char fn[4096]; FILE *f; uint8_t *d; size_t sz, o = 8; mdk_bai *x; int32_t r;
+    snprintf(fn, sizeof(fn), "%s.bai", bam_fn); f = fopen(fn, "rb");
+    if(!f) { size_t l = strlen(bam_fn); if(l > 4 && l + 1 < sizeof(fn)) { memcpy(fn, bam_fn, l - 4); strcpy(fn + l - 4, ".bai"); f = fopen(fn, "rb"); } }
+    if(!f) return NULL;
+    fseek(f, 0, SEEK_END); sz = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
+    d = malloc(sz + 8);
+    if(!d || fread(d, 1, sz, f) != sz || sz < 8 || memcmp(d, "BAI\1", 4)) { fclose(f); free(d); return NULL; }
+    fclose(f);
+    x = calloc(1, sizeof(*x)); x->n_ref = (int32_t)le32(d + 4);
+    x->n_intv = calloc((size_t)x->n_ref + 1, 4); x->ioff = calloc((size_t)x->n_ref + 1, sizeof(uint64_t *)); x->first = calloc((size_t)x->n_ref + 1, 8);
+    for(r = 0; r < x->n_ref; r++) {
+        int32_t nb, b, ni, i; uint64_t first = 0;
+        if(o + 4 > sz) goto bad;
+        nb = (int32_t)le32(d + o); o += 4;
+        for(b = 0; b < nb; b++) {
+            uint32_t bin; int32_t nc, c;
+            if(o + 8 > sz) goto bad;
+            bin = le32(d + o); nc = (int32_t)le32(d + o + 4); o += 8;
+            if(o + 16u * (size_t)nc > sz) goto bad;
+            if(bin != 37450) for(c = 0; c < nc; c++) { uint64_t cb = (uint64_t)le32(d + o + 16 * c) | ((uint64_t)le32(d + o + 16 * c + 4) << 32); if(!first || cb < first) first = cb; }
+            o += 16u * (size_t)nc;
+        }
+        if(o + 4 > sz) goto bad;
+        ni = (int32_t)le32(d + o); o += 4;
+        if(o + 8u * (size_t)ni > sz) goto bad;
+        x->n_intv[r] = ni; x->ioff[r] = malloc(8u * (size_t)(ni + 1)); x->first[r] = first;
+        for(i = 0; i < ni; i++) x->ioff[r][i] = (uint64_t)le32(d + o + 8 * i) | ((uint64_t)le32(d + o + 8 * i + 4) << 32);
+        o += 8u * (size_t)ni;
+    }
+    free(d);
+    return x;
+bad:
+    free(d); mdk_bai_free(x);
+    return NULL;
+}
+void mdk_bai_free(mdk_bai *x) { int32_t r; if(!x) return; for(r = 0; r < x->n_ref; r++) free(x->ioff[r]); free(x->ioff); free(x->n_intv); free(x->first); free(x); }
+uint64_t mdk_bai_start(const mdk_bai *x, int32_t tid, int64_t beg) {
+    int64_t w;
+    if(!x || tid < 0 || tid >= x->n_ref || !x->first[tid]) return 0;
+    w = beg >> 14;
+    if(w >= x->n_intv[tid]) return 0;                 /* nothing overlaps this window or any later one */
+    for(; w >= 0; w--) if(x->ioff[tid][w]) return x->ioff[tid][w];
+    return x->first[tid];
+}
+
+int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
+    int i;
+    if(b->inf_started) {
+        pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
+        pthread_join(b->inf_th, NULL); b->inf_started = 0;
+    }
+    pthread_mutex_lock(&b->mu);
+    for(i = 0; i < b->q_n; i++) { if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = realloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); } b->pool[b->n_pool++] = b->queue[i]; }
+    b->q_n = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
+    pthread_mutex_unlock(&b->mu);
+    if(b->cur) { mdk_slab_unref(b, b->cur); b->cur = NULL; }
+    if(fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET)) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; }
+    pthread_create(&b->inf_th, NULL, inflater_main, b); b->inf_started = 1;
+    if((voffset & 0xffff) || 1) {
+        int rc = need(b, (size_t)(voffset & 0xffff) + 1);
+        if(rc < 0) return rc;
+        if(rc == 0) return 0;                          /* nothing there */
+        b->off += (size_t)(voffset & 0xffff);
+    }
+    return 1;
+}
+
 /* ---- FASTA ---- */
 int mdk_fasta_load(const char *fn, mdk_fasta *fa) {
     FILE *f = fopen(fn, "rb"); size_t sz, i, w; char *d; int cur = -1, cap = 0;

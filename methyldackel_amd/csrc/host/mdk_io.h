@@ -62,6 +62,16 @@ void mdk_fasta_free(mdk_fasta *fa);
 int mdk_fasta_find(const mdk_fasta *fa, const char *name);
 
 
+/* BAI index (SAM spec 5.2): only the 16 kb linear index is kept -- enough to find where to start reading for a
+ * reference window; starting too early is harmless because the caller skips records that end before its window. */
+typedef struct { int32_t n_ref; int32_t *n_intv; uint64_t **ioff; uint64_t *first; } mdk_bai;
+mdk_bai *mdk_bai_load(const char *bam_fn);      /* <bam>.bai or <bam without .bam>.bai; NULL if absent/unreadable */
+void mdk_bai_free(mdk_bai *x);
+/* virtual offset to start reading at for records overlapping [beg, ...) of tid; 0 = that reference has no records at or after beg */
+uint64_t mdk_bai_start(const mdk_bai *x, int32_t tid, int64_t beg);
+/* reposition the record stream at a BGZF virtual offset (compressed offset << 16 | offset in the inflated member) */
+int mdk_bam_seek(mdk_bam *b, uint64_t voffset);
+
 /* bigWig (mappability track for -M) */
 typedef struct { FILE *f; uint64_t chrom_tree, index; uint32_t uncompress; uint32_t n, cap; char **name; uint32_t *len, *id; } mdk_bigwig;
 mdk_bigwig *mdk_bigwig_open(const char *fn);

@@ -178,3 +178,33 @@ def test_bigwig_to_bbm_conversion_without_bam(tmp_path, small_synth):
     assert r.returncode == 0 and (tmp_path / "m.bbm").read_bytes() == (small_synth / "pe.bbm").read_bytes()
     r = mdk.run_cli(["-O"], cwd=tmp_path)
     assert r.returncode == 255 and "You must specify a bigWig file" in r.stderr
+
+
+def test_index_seek_equals_streaming(tmp_path, small_synth, monkeypatch):
+    """with a .bai the reader seeks (once for -r, per own chunk when sharded); without it it reads the file through.
+    Both must pack exactly the same batches."""
+    fa, bam = str(small_synth / "pe.fa"), str(small_synth / "pe.bam")
+    assert (small_synth / "pe.bam.bai").exists()
+
+    def batches(extra, shard=None):
+        plan = mdk.Plan([fa, bam, "-o", str(tmp_path / "x")] + extra)
+        if shard:
+            plan.set_shard(*shard)
+        out = []
+        while (c := plan.next_chunk()) is not None:
+            segs = bytes(C.string_at(c.batch.seg, c.batch.n_segs * 32)) if c.batch.n_segs else b""
+            out.append((c.index, c.tid, c.beg, c.end, c.skipped, c.batch.n_reads, segs, bytes(C.string_at(c.batch.blob, c.batch.blob_bytes))))
+        plan.close()
+        return out
+
+    cases = [(["-r", "chrS1:12000-31000", "--chunkSize", "3000"], None), (["-r", "chrS2:19990", "--chunkSize", "700"], None),
+             (["-r", "chrS1:39990-40000"], None), (["--chunkSize", "5000"], (1, 3)), (["--chunkSize", "5000", "-r", "chrS2:500-15000"], (0, 2))]
+    total = 0
+    for extra, shard in cases:
+        with_index = batches(extra, shard)
+        monkeypatch.setenv("MDK_NO_INDEX", "1")
+        without = batches(extra, shard)
+        monkeypatch.delenv("MDK_NO_INDEX")
+        assert with_index == without, (extra, shard)
+        total += sum(b[5] for b in with_index)
+    assert total > 1000

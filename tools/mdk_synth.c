@@ -36,7 +36,7 @@ static void b16(buf_t *b, uint16_t v) { uint8_t x[2] = {(uint8_t)v, (uint8_t)(v 
 static void b8(buf_t *b, uint8_t v) { bput(b, &v, 1); }
 
 /* ---- BGZF writer ---- */
-typedef struct { FILE *f; uint8_t blk[65280]; int n; int level; } bgzf_t;
+typedef struct { FILE *f; uint8_t blk[65280]; int n; int level; uint64_t fpos; } bgzf_t;
 static void bgzf_flush(bgzf_t *z) {
     uint8_t out[70000]; z_stream zs; uint32_t crc; int clen; uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
     if(!z->n) return;
@@ -46,7 +46,7 @@ static void bgzf_flush(bgzf_t *z) {
     deflate(&zs, Z_FINISH); clen = (int)zs.total_out; deflateEnd(&zs);
     crc = crc32(crc32(0, NULL, 0), z->blk, z->n);
     { int bsize = clen + 25; hdr[16] = bsize & 0xff; hdr[17] = bsize >> 8; }
-    fwrite(hdr, 1, 18, z->f); fwrite(out, 1, clen, z->f);
+    fwrite(hdr, 1, 18, z->f); fwrite(out, 1, clen, z->f); z->fpos += 18 + (uint64_t)clen + 8;
     { uint8_t t[8] = {crc, crc >> 8, crc >> 16, crc >> 24, (uint8_t)z->n, (uint8_t)(z->n >> 8), (uint8_t)(z->n >> 16), (uint8_t)(z->n >> 24)}; fwrite(t, 1, 8, z->f); }
     z->n = 0;
 }
@@ -172,15 +172,15 @@ static void emit_read(buf_t *out, const contig_t *ct, int tid, int64_t pos, cons
 }
 
 int main(int argc, char **argv) {
-    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {0, 0, 0, 0}};
+    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {"no-bai", 0, 0, 7}, {0, 0, 0, 0}};
     const char *prefix = NULL, *lens = "1000000"; double cov = 30; uint64_t seed = 0x5EED0001ULL; int level = 1, c, want_bbm = 0;
-    opts_t o = {0, 0, 0, 0, 150}; int want_bw = 0; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
+    opts_t o = {0, 0, 0, 0, 150}; int want_bw = 0, no_bai = 0; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
     buf_t pool = {0, 0, 0}; size_t *offs = NULL; char fn[4096]; uint64_t ord = 0, npairs_total = 0, nbases = 0;
     while((c = getopt_long(argc, argv, "o:L:c:l:s:z:", lo, NULL)) >= 0) {
         switch(c) {
         case 'o': prefix = optarg; break; case 'L': lens = optarg; break; case 'c': cov = atof(optarg); break;
         case 'l': o.readlen = atoi(optarg); break; case 's': seed = strtoull(optarg, NULL, 0); break; case 'z': level = atoi(optarg); break;
-        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break;
+        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break; case 7: no_bai = 1; break;
         default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [--bismark] [--extras] [--clean] [--bbm] [--bw] [--single]\n"); return 1;
         }
     }
@@ -255,14 +255,43 @@ int main(int argc, char **argv) {
 
     snprintf(fn, sizeof(fn), "%s.bam", prefix);
     { bgzf_t z; buf_t h = {0, 0, 0}; char txt[65536]; int n = 0;
-      z.f = fopen(fn, "wb"); z.n = 0; z.level = level; if(!z.f) { perror(fn); return 1; }
+      z.f = fopen(fn, "wb"); z.n = 0; z.level = level; z.fpos = 0; if(!z.f) { perror(fn); return 1; }
       n += snprintf(txt + n, sizeof(txt) - n, "@HD\tVN:1.6\tSO:coordinate\n");
       for(t = 0; t < nct; t++) n += snprintf(txt + n, sizeof(txt) - n, "@SQ\tSN:%s\tLN:%" PRId64 "\n", ct[t].name, ct[t].len);
       n += snprintf(txt + n, sizeof(txt) - n, "@PG\tID:mdk_synth\tPN:mdk_synth\tCL:seed=%" PRIu64 "\n", seed);
       bput(&h, "BAM\1", 4); b32(&h, (uint32_t)n); bput(&h, txt, n); b32(&h, (uint32_t)nct);
       for(t = 0; t < nct; t++) { b32(&h, (uint32_t)strlen(ct[t].name) + 1); bput(&h, ct[t].name, strlen(ct[t].name) + 1); b32(&h, (uint32_t)ct[t].len); }
       bgzf_write(&z, h.p, h.l); bgzf_flush(&z);
-      for(i = 0; i < nrec; i++) bgzf_write(&z, recs[i].d, recs[i].n);
+      {   /* records + a BAI (linear index per contig, one catch-all bin 0 per contig holding the contig's byte range) */
+          uint64_t **lin = calloc(nct, sizeof(uint64_t *)), *first = calloc(nct, 8), *last = calloc(nct, 8); size_t *nlin = calloc(nct, sizeof(size_t));
+          for(t = 0; t < nct; t++) { nlin[t] = (size_t)((ct[t].len >> 14) + 1); lin[t] = calloc(nlin[t], 8); }
+          for(i = 0; i < nrec; i++) {
+              uint64_t vo; int32_t tid = recs[i].tid, pos = recs[i].pos; int64_t w, w1; uint32_t ncig, k, rl = 0; const uint8_t *r = recs[i].d + 4;
+              if(z.n + 4 > (int)sizeof(z.blk)) bgzf_flush(&z);          /* keep the block_size word inside one member */
+              vo = (z.fpos << 16) | (uint64_t)z.n;
+              ncig = r[12] | (r[13] << 8);
+              for(k = 0; k < ncig; k++) { const uint8_t *c = r + 32 + r[8] + 4 * k; uint32_t cv = c[0] | (c[1] << 8) | (c[2] << 16) | ((uint32_t)c[3] << 24), op = cv & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cv >> 4; }
+              w1 = ((int64_t)pos + (rl ? rl : 1) - 1) >> 14;
+              for(w = pos >> 14; w <= w1 && w < (int64_t)nlin[tid]; w++) if(!lin[tid][w]) lin[tid][w] = vo;
+              if(!first[tid]) first[tid] = vo;
+              bgzf_write(&z, recs[i].d, recs[i].n);
+              last[tid] = (z.fpos << 16) | (uint64_t)z.n;
+          }
+          bgzf_flush(&z);
+          for(t = 0; t < nct; t++) if(first[t]) last[t] = z.fpos << 16;      /* generous end for the catch-all chunk */
+          if(!no_bai) {
+              buf_t x = {0, 0, 0}; FILE *bf;
+              bput(&x, "BAI\1", 4); b32(&x, (uint32_t)nct);
+              for(t = 0; t < nct; t++) {
+                  size_t w; uint64_t prev = 0;
+                  if(first[t]) { b32(&x, 1); b32(&x, 0); b32(&x, 1); bput(&x, &first[t], 8); bput(&x, &last[t], 8); } else b32(&x, 0);
+                  for(w = 0; w < nlin[t]; w++) { if(lin[t][w]) prev = lin[t][w]; else lin[t][w] = prev; }     /* samtools fills gaps with the previous offset */
+                  { size_t n = nlin[t]; while(n && !lin[t][n - 1]) n--; b32(&x, (uint32_t)n); bput(&x, lin[t], 8 * n); }
+              }
+              snprintf(fn, sizeof(fn), "%s.bam.bai", prefix); bf = fopen(fn, "wb"); if(!bf) { perror(fn); return 1; }
+              fwrite(x.p, 1, x.l, bf); fclose(bf); free(x.p);
+          }
+      }
       bgzf_close(&z); free(h.p); }
 
     if(want_bbm || want_bw) {     /* synthetic mappability track: values {0, 0.5, 1.0}; written as BBM and/or bigWig (same values) */
