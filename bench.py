@@ -193,7 +193,7 @@ def main():
                        else f"synthetic {args.length} bp, {args.coverage}x, extract {' '.join(extra)}",
                        "interval_bp": args.length, "coverage": args.coverage, "reads_admitted_per_gpu": int(chunk.batch.n_reads), "segments_per_gpu": int(chunk.batch.n_segs),
                        "records_per_gpu": synth_info["records"], "sites_per_gpu": int(n_sites), "cpg_calls_per_gpu": int(cpg_calls),
-                       "tile": int(br.tile), "tiles": int(br.n_tiles), "tiles_staged_in_lds": int(br.n_staged_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else "")},
+                       "tile": int(br.tile), "tiles": int(br.n_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup, "all_kernels_ms": br.ms_total},
             "host_prep_s": t_host,

@@ -114,7 +114,7 @@ typedef struct {
     float ms_pileup;     /* the pileup kernel: `iters` launches back to back between two HIP events, divided by iters */
     uint64_t algo_bytes; /* algorithmic bytes of one launch (SURVEY.md 8d formula) */
     uint64_t n_sites;
-    int32_t tile, n_tiles, n_staged_tiles, lds_bytes;   /* geometry the launch used */
+    int32_t tile, n_tiles, lds_bytes;   /* geometry the launch used: positions per tile, tiles, LDS bytes per workgroup */
 } md_bench_result;
 
 int  md_dev_count(void);                                       /* number of HIP devices, <0 on error */

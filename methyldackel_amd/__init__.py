@@ -71,7 +71,7 @@ class md_sites_dev(C.Structure):
 
 class md_bench_result(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_pileup", C.c_float), ("algo_bytes", C.c_uint64), ("n_sites", C.c_uint64),
-                ("tile", C.c_int32), ("n_tiles", C.c_int32), ("n_staged_tiles", C.c_int32), ("lds_bytes", C.c_int32)]
+                ("tile", C.c_int32), ("n_tiles", C.c_int32), ("lds_bytes", C.c_int32)]
 
 
 class mdk_chunk(C.Structure):

@@ -43,7 +43,6 @@
 #define MAX_TILE (WG * PERMAX)
 #define RING 64                    // site counters: launch i uses counter i%RING and clears the next one
 #define LDS_LIMIT 163840          // 160 KiB per CU / per workgroup on gfx950
-#define DEFAULT_LDS_BUDGET 80896  // two workgroups per CU
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char *what, hipError_t e) {
@@ -391,12 +390,12 @@ struct Slot {
     HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; HBuf<uint32_t> h_total; HBuf<int> h_err;
     // caller-bound output (device memory owned by the caller)
     md_site *b_site = nullptr; md_site_var *b_var = nullptr; md_tile_seg *b_seg = nullptr; int64_t b_cap_sites = 0, b_cap_tiles = 0;
-    int n_segs = 0, n_reads = 0, ntiles = 0, tid = -1, tile = 0, paycap = 0, lds_bytes = 0, n_staged = 0; int64_t beg = 0, end = 0; uint64_t read_bytes = 0;
+    int n_segs = 0, n_reads = 0, ntiles = 0, tid = -1, tile = 0, lds_bytes = 0; int64_t beg = 0, end = 0; uint64_t read_bytes = 0;
     bool uploaded = false, launched = false; unsigned ring = 0;
 };
 
 struct md_dev {
-    int device; md_dev_cfg cfg; int tile, n_slots, force_global, lds_budget; bool variant, tile_fixed;
+    int device; md_dev_cfg cfg; int tile, n_slots; bool variant;
     std::vector<Slot> slots;
     std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
 };
@@ -425,13 +424,11 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     HIPCHK(hipSetDevice(device));
     md_dev *h = new md_dev();
     h->device = device; h->cfg = *cfg;
-    h->tile_fixed = cfg->tile > 0;
     h->tile = cfg->tile > 0 ? cfg->tile : DEFAULT_TILE;
     h->tile = (h->tile + WG - 1) / WG * WG;
     if(h->tile > MAX_TILE) h->tile = MAX_TILE;
     h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2;
     h->variant = cfg->minOppositeDepth > 0;
-    h->force_global = 0; h->lds_budget = 0;
     while(fixed_lds(h->tile, h->variant) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
     if(fixed_lds(h->tile, h->variant) > 65536) {    // more than the default dynamic-LDS window: opt in
         if(h->variant) HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true)));
@@ -517,7 +514,7 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     const int ntiles = (int)((span + TILE - 1) / TILE);
     if(s->h_tiles.need((size_t)(ntiles > 0 ? ntiles : 1))) return MDK_ERR_NOMEM;
     build_tiles(b, TILE, s->h_tiles.p, ntiles);
-    s->tile = TILE; s->ntiles = ntiles; s->n_staged = 0; s->paycap = 0; s->lds_bytes = fixed_lds(TILE, h->variant);
+    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = fixed_lds(TILE, h->variant);
     s->read_bytes = b->algo_bytes;
     size_t ns = (size_t)b->n_segs, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     if(s->d_seg_in.need(ns + 1) || s->d_blob.need((size_t)b->blob_bytes + 64)) return MDK_ERR_NOMEM;
@@ -729,7 +726,7 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
     out->n_sites = (uint64_t)n;
     // sum over reads [16 + 4 n_cigar + ceil(l/2) + l] + interval length + 8 per site (+8 with nOff/nVariant)
     out->algo_bytes = s->read_bytes + (uint64_t)(s->end - s->beg) + (uint64_t)n * (h->variant ? 16 : 8);
-    out->tile = s->tile; out->n_tiles = s->ntiles; out->n_staged_tiles = s->n_staged; out->lds_bytes = s->lds_bytes;
+    out->tile = s->tile; out->n_tiles = s->ntiles; out->lds_bytes = s->lds_bytes;
     return 0;
 }
 

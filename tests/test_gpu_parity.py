@@ -108,11 +108,10 @@ SYN_CMDS = [
 
 
 @pytest.mark.parametrize("which,extra", SYN_CMDS, ids=[f"{w}:{' '.join(e)}" for w, e in SYN_CMDS])
-@pytest.mark.parametrize("env", [{"MDK_TILE": "256"}, {}, {"MDK_TILE": "1024", "MDK_KERNEL": "global"}, {"MDK_TILE": "512", "MDK_LDS_BUDGET": "24000"}],
-                         ids=["tile256-lds", "auto", "tile1024-global", "tile512-mixed"])
+@pytest.mark.parametrize("env", [{"MDK_TILE": "512"}, {}, {"MDK_TILE": "4096"}], ids=["tile512", "tile2048", "tile4096"])
 def test_cli_synthetic_byte_exact(tmp_path, small_synth, which, extra, env):
-    """every command line under: LDS-staged tiles (fixed and auto geometry), the global-pointer path, and a budget so
-    small that staged and overflowing tiles mix inside one launch"""
+    """every command line under three tile geometries (1, 4 and 8 reference positions per thread; at 512 positions a tile's
+    segment run overflows the 512 lanes of its workgroup, so the multi-round path runs too)"""
     args = [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")]
     if "BW" in extra:       # the oracle has no bigWig reader: it gets the same track as BBM
         compare_cli(tmp_path, args + [str(small_synth / "pe.bw") if e == "BW" else e for e in extra], env=env,
@@ -249,3 +248,51 @@ def test_sharded_two_ranks_byte_exact(tmp_path, small_synth):
     for f in os.listdir(od):
         if f.startswith("out"):
             assert filecmp.cmp(od / f, gd / f, shallow=False), f
+
+
+def test_effective_bases_hook_matches_evaluator(tmp_path, small_synth):
+    """md_dev_debug_effective: the (base, quality) every segment base ends up with after trimming and mate-overlap resolution
+    -- the part of the reference that rewrites reads in place (common.c:137-208, overlaps.c:54-119) -- against the slow
+    Python evaluator, independent of any counting"""
+    import numpy as np
+    from batch_eval import Payload, resolve
+    args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--OT", "4,140,6,130", "--nOB", "2,3,4,5", "--chunkSize", "20000", "-o", str(tmp_path / "x")]
+    plan = mdk.Plan(args)
+    cfg = plan.dev_cfg()
+    dev = mdk.Device(cfg)
+    c = plan.next_chunk()
+    plan.ensure_reference(dev, c.tid)
+    dev.upload(0, c.batch)
+    n = c.batch.n_segs
+    lens = np.array([c.batch.seg[i].len for i in range(n)], dtype=np.uint64)
+    off = np.zeros(n, dtype=np.uint64); off[1:] = np.cumsum(lens)[:-1]
+    total = int(lens.sum())
+    ob = np.zeros(total + 1, dtype=np.uint8); oq = np.zeros(total + 1, dtype=np.uint8)
+    rc = dev.L.md_dev_debug_effective(dev.h, 0, ob.ctypes.data, oq.ctypes.data, off.ctypes.data)
+    assert rc == 0
+    pay, checked, partnered = {}, 0, 0
+    for i in range(0, n, 7):            # every 7th segment is plenty
+        g = c.batch.seg[i]
+        key = (g.off4, g.l_qseq, g.sf & 7, bool(g.sf & 8))
+        o = pay.setdefault(key, Payload(c.batch, g.off4, g.l_qseq, g.sf & 7, bool(g.sf & 8), cfg))
+        m = None
+        if g.sf & 32:
+            mk = (g.m_off4, g.m_l_qseq, g.msf & 7, bool(g.msf & 8))
+            m = pay.setdefault(mk, Payload(c.batch, g.m_off4, g.m_l_qseq, g.msf & 7, bool(g.msf & 8), cfg))
+            partnered += 1
+        for j in range(g.len):
+            b, q = o.bq(g.q0 + j)
+            if m is not None:
+                mb, mq = m.bq(g.m_q0 + j)
+                q = resolve(bool(g.sf & 16), b, q, mb, mq)
+            assert (int(ob[int(off[i]) + j]), int(oq[int(off[i]) + j])) == (b, q), (i, j)
+            checked += 1
+    assert checked > 20000 and partnered > 50
+    dev.close(), plan.close()
+
+
+def test_high_depth_100x_byte_exact(tmp_path):
+    """100x coverage (BASELINE configs[4] depth): several rounds of segments per tile"""
+    synth(tmp_path / "deep", "-L", "150000", "-c", "100", "-s", "41", "--bbm")
+    compare_cli(tmp_path, [str(tmp_path / "deep.fa"), str(tmp_path / "deep.bam"), "--mergeContext", "--CHG", "-B", str(tmp_path / "deep.bbm")])
+    compare_cli(tmp_path, [str(tmp_path / "deep.fa"), str(tmp_path / "deep.bam"), "--CHH", "--minOppositeDepth", "10", "--maxVariantFrac", "0.1"], env={"MDK_TILE": "4096"})

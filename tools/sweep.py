@@ -18,7 +18,7 @@ for t, b in itertools.product(tiles, budgets):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1]); c = d["config"]; rf = d["roofline"]
-        print(f"tile {t:>5} budget {b:>6} -> tile {c['tile']:>5} staged {c['tiles_staged_in_lds']:>5}/{c['tiles']:<5} lds {c['lds_bytes_per_workgroup']:>6} "
+        print(f"tile {t:>5} budget {b:>6} -> tile {c['tile']:>5} tiles {c['tiles']:<5} lds {c['lds_bytes_per_workgroup']:>6} "
               f"ms/step {d['ms_per_step']:.4f} pileup_ms {rf['kernel_ms']:.4f} all_ms {rf['all_kernels_ms']:.4f} frac {rf['frac']:.4f} value {d['value']:.3e}", flush=True)
     except Exception as e:
         print("FAILED", t, b, e, r.stderr[-500:], flush=True)
