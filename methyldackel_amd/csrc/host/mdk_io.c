@@ -41,7 +41,10 @@ static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) {          /* inflater si
     pthread_mutex_lock(&b->mu);
     while(!b->quit) {
         if(b->n_pool) { s = b->pool[--b->n_pool]; break; }
-        if(b->n_alloc < b->max_alloc) { b->n_alloc++; s = calloc(1, sizeof(*s)); break; }
+        /* max_alloc only bounds how far the inflater runs AHEAD: when the scanner has nothing queued it may be collecting a
+         * chunk that spans more slabs than the cap (huge --chunkSize, deep coverage) and every slab it holds stays pinned
+         * until the chunk is complete, so waiting for one to come back would never end */
+        if(b->n_alloc < b->max_alloc || b->q_n == 0) { b->n_alloc++; s = calloc(1, sizeof(*s)); break; }
         pthread_cond_wait(&b->cv_pool, &b->mu);
     }
     pthread_mutex_unlock(&b->mu);
@@ -128,8 +131,10 @@ static void *inflater_main(void *arg) {
 static mdk_slab *slab_next(mdk_bam *b) {
     mdk_slab *s = NULL; double t0 = io_now();
     pthread_mutex_lock(&b->mu);
+    if(!b->q_n) pthread_cond_broadcast(&b->cv_pool);        /* starving: the inflater may take a slab beyond the cap */
     while(!b->q_n && !b->inf_done) pthread_cond_wait(&b->cv_q, &b->mu);
-    if(b->q_n) { s = b->queue[0]; memmove(b->queue, b->queue + 1, sizeof(mdk_slab *) * (size_t)(--b->q_n)); pthread_cond_broadcast(&b->cv_pool); }
+    if(b->q_n) { s = b->queue[0]; memmove(b->queue, b->queue + 1, sizeof(mdk_slab *) * (size_t)(--b->q_n)); }
+    pthread_cond_broadcast(&b->cv_pool);          /* a queue slot is free / the scanner is about to starve: let the inflater go on */
     pthread_mutex_unlock(&b->mu);
     b->t_inflate += io_now() - t0;
     return s;
@@ -159,7 +164,8 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     b->f = fopen(fn, "rb");
     if(!b->f) { free(b); return NULL; }
     b->nthreads = nthreads < 1 ? 1 : nthreads;
-    b->max_alloc = b->nthreads * 2 + 8;           /* slabs that may exist at once (each worker may pin a few) */
+    b->max_alloc = b->nthreads * 2 + 8;           /* how far the inflater may run ahead of the consumers, in slabs */
+    if(getenv("MDK_SLAB_CAP")) b->max_alloc = atoi(getenv("MDK_SLAB_CAP")) > 1 ? atoi(getenv("MDK_SLAB_CAP")) : 2;
     pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL);
     pthread_create(&b->inf_th, NULL, inflater_main, b); b->inf_started = 1;
     if((rc = need(b, 12)) <= 0 || memcmp(b->cur->buf + b->off, "BAM\1", 4)) { mdk_bam_close(b); return NULL; }

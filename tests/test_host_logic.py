@@ -7,7 +7,7 @@ import pytest
 
 import methyldackel_amd as mdk
 from batch_eval import eval_batch
-from conftest import GOLDEN, read_dump, run_oracle
+from conftest import GOLDEN, read_dump, run_oracle, synth
 
 
 def host_counts(args):
@@ -208,3 +208,16 @@ def test_index_seek_equals_streaming(tmp_path, small_synth, monkeypatch):
         assert with_index == without, (extra, shard)
         total += sum(b[5] for b in with_index)
     assert total > 1000
+
+
+@pytest.mark.timeout(180)
+def test_chunk_larger_than_the_slab_pool(tmp_path, monkeypatch):
+    """one chunk spanning more inflate slabs than the reader's look-ahead cap (huge --chunkSize, here a cap of 2 slabs):
+    the slabs a chunk holds stay pinned until it is complete, so the inflater must be allowed past the cap"""
+    monkeypatch.setenv("MDK_SLAB_CAP", "2")
+    synth(tmp_path / "wide", "-L", "1500000", "-c", "40", "-s", "5")
+    plan = mdk.Plan([str(tmp_path / "wide.fa"), str(tmp_path / "wide.bam"), "--chunkSize", "1500000", "-o", str(tmp_path / "x")])
+    c = plan.next_chunk()
+    assert c is not None and c.batch.n_reads > 300000
+    assert plan.next_chunk() is None
+    plan.close()
