@@ -26,6 +26,7 @@ int extract_main(int argc, char *argv[]);
 
 typedef struct mdk_plan mdk_plan;
 #define MDK_CHUNK_NOREF   1   /* contig missing from the FASTA -> the reference skips the chunk; nothing is emitted */
+#define MDK_CHUNK_BED     4   /* -l: no BED region touches the chunk -> the reference passes it over (extract.c:352-369) */
 #define MDK_CHUNK_FOREIGN 2   /* interval sharding: another rank owns this chunk; its sites arrive through the gather */
 
 /* One chunk of the reference's schedule (extract.c:325-350 + adjustBounds) with its admitted reads packed
@@ -59,6 +60,10 @@ int  mdk_plan_finish(mdk_plan *p);
  * is congruent to `rank`; every process still walks the whole schedule, so chunk indices agree everywhere. */
 int  mdk_plan_set_shard(mdk_plan *p, int rank, int world);
 int  mdk_plan_n_targets(const mdk_plan *p);
+/* -l: the disjoint runs (include/mdk_hip.h: md_region) the sites of a contig are restricted to, as handed to
+ * md_dev_set_regions by mdk_plan_ensure_reference; *n = -1 when no BED file was given.  Replaces the cursor walk over
+ * config->bed in extractCalls (extract.c:352-369,402-405; bed.c:22-53). */
+int  mdk_plan_regions(const mdk_plan *p, int32_t tid, const md_region **runs, int64_t *n);
 const char *mdk_plan_target_name(const mdk_plan *p, int32_t tid);
 int64_t mdk_plan_target_len(const mdk_plan *p, int32_t tid);
 

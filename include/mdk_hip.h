@@ -126,6 +126,14 @@ int  md_dev_tile(const md_dev *h);
 /* Upload (once) the bases of a contig; letters verbatim from the FASTA (case matters: C/c, G/g). */
 int  md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int64_t len);
 
+/* -l/--keepStrand: restrict the sites of a contig (whose reference is already uploaded) to these runs -- sorted,
+ * disjoint, half-open, strand 0 = either, 1 = '+' (only OT/CTOT reads are seen there), 2 = '-' (only OB/CTOB reads).
+ * Replaces posOverlapsBED + readStrandOverlapsBED inside the column loop (extract.c:402-405,425; bed.c:46-64).
+ * n = 0 leaves the contig without sites.  Calling it again replaces the previous restriction only where a position
+ * is still a site, so set_reference again first to widen. */
+typedef struct { int32_t start, end, strand; } md_region;
+int  md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs, int64_t n);
+
 /* slot in [0, n_slots): upload is H2D on the slot's stream; launch enqueues the kernels; download waits for
  * the slot and returns the sites.  md_dev_submit = upload + launch. */
 int  md_dev_upload(md_dev *h, int slot, const md_read_batch *b);

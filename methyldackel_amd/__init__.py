@@ -23,7 +23,8 @@ LIB_HIP = BUILD / "libmdk_hip.so"
 LIB_EXTRACT = BUILD / "libmdk_extract.so"
 CLI = BUILD / "MethylDackel"
 
-CHUNK_NOREF, CHUNK_FOREIGN = 1, 2
+CHUNK_NOREF, CHUNK_FOREIGN, CHUNK_BED = 1, 2, 4
+CHUNK_EMPTY = CHUNK_NOREF | CHUNK_BED      # passed over by every rank: nothing is packed and nothing is emitted
 MDK_ERR = {-1: "HIP call failed", -2: "no device", -3: "bad argument", -4: "reference not uploaded",
            -5: "strand 0 read reached a call", -6: "out of memory"}
 
@@ -47,6 +48,10 @@ class md_read_batch(C.Structure):
     _fields_ = [("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("n_segs", C.c_int32),
                 ("seg", C.POINTER(md_seg)), ("blob", C.POINTER(C.c_uint8)), ("blob_bytes", C.c_uint64),
                 ("n_reads", C.c_int32), ("algo_bytes", C.c_uint64)]
+
+
+class md_region(C.Structure):
+    _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("strand", C.c_int32)]
 
 
 class md_site(C.Structure):
@@ -79,12 +84,12 @@ class mdk_chunk(C.Structure):
                 ("batch", md_read_batch), ("n_records_seen", C.c_uint64)]
 
 
-HIP_SYMBOLS = ["md_dev_count", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference",
+HIP_SYMBOLS = ["md_dev_count", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
-                   "mdk_plan_target_len"]
+                   "mdk_plan_target_len", "mdk_plan_regions"]
 
 _hip = None
 _ext = None
@@ -110,6 +115,7 @@ def lib_hip():
         L.md_dev_close.argtypes = [C.c_void_p]
         L.md_dev_tile.argtypes = [C.c_void_p]
         L.md_dev_set_reference.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
+        L.md_dev_set_regions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(md_region), C.c_int64]
         for f in ("md_dev_upload", "md_dev_submit"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.POINTER(md_read_batch)]
         L.md_dev_launch.argtypes = [C.c_void_p, C.c_int]
@@ -149,6 +155,7 @@ def lib_extract():
         L.mdk_plan_target_name.restype = C.c_char_p
         L.mdk_plan_target_len.argtypes = [C.c_void_p, C.c_int32]
         L.mdk_plan_target_len.restype = C.c_int64
+        L.mdk_plan_regions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(md_region)), C.POINTER(C.c_int64)]
         _ext = L
     return _ext
 
@@ -177,6 +184,11 @@ class Device:
 
     def set_reference(self, tid: int, seq: bytes):
         self._chk(self.L.md_dev_set_reference(self.h, tid, seq, len(seq)), "md_dev_set_reference")
+
+    def set_regions(self, tid: int, runs):
+        """runs: [(start, end, strand)], sorted and disjoint (-l/--keepStrand)"""
+        arr = (md_region * max(len(runs), 1))(*[md_region(*r) for r in runs])
+        self._chk(self.L.md_dev_set_regions(self.h, tid, arr, len(runs)), "md_dev_set_regions")
 
     def submit(self, slot: int, batch: md_read_batch):
         self._chk(self.L.md_dev_submit(self.h, slot, C.byref(batch)), "md_dev_submit")
@@ -261,6 +273,13 @@ class Plan:
 
     def finish(self):
         self.L.mdk_plan_finish(self.p)
+
+    def regions(self, tid: int):
+        """None without -l, else the [(start, end, strand)] runs the contig's sites are restricted to"""
+        ptr, n = C.POINTER(md_region)(), C.c_int64()
+        if self.L.mdk_plan_regions(self.p, tid, C.byref(ptr), C.byref(n)):
+            raise MdkError("mdk_plan_regions failed")
+        return None if n.value < 0 else [(ptr[i].start, ptr[i].end, ptr[i].strand) for i in range(n.value)]
 
     def target_name(self, tid: int) -> str:
         return self.L.mdk_plan_target_name(self.p, tid).decode()

@@ -11,6 +11,7 @@
  * There is no CPU implementation of the per-base work in this library.
  */
 #define _GNU_SOURCE
+#include <ctype.h>
 #include <errno.h>
 #include <getopt.h>
 #include <inttypes.h>
@@ -23,6 +24,7 @@
 #include <pthread.h>
 #include <time.h>
 #include <unistd.h>
+#include <zlib.h>
 #include "mdk_extract.h"
 #include "mdk_io.h"
 
@@ -86,6 +88,8 @@ struct mdk_plan {
     uint32_t next_out; int held[2];
     /* mappability */
     int map_on; uint32_t map_n; char **map_names; uint32_t *map_len; uint8_t **map_bits; int *map_of_tid;
+    /* -l: per contig, the disjoint runs a position must fall in (and the strand a read must have there) */
+    int bed_on; md_region **bed_run; int64_t *bed_nrun;
     /* outputs */
     FILE *out[3]; sbuf ob[3];
     uint32_t next_emit;
@@ -101,15 +105,14 @@ struct mdk_plan {
 static void usage(void) {
     fputs("\nUsage: MethylDackel extract [OPTIONS] <ref.fa> <sorted_alignments.bam>\n", stderr);
     fputs("\nOptions (MI355X build; same option surface as MethylDackel 0.6.1):\n"
-" -q INT, -p INT, -d INT, -D INT(ignored), -r STR, -l FILE(*), -o/--opref STR, -@ INT,\n"
+" -q INT, -p INT, -d INT, -D INT(ignored), -r STR, -o/--opref STR, -@ INT,\n"
 " -F/--ignoreFlags INT, -R/--requireFlags INT, --chunkSize INT, --mergeContext,\n"
 " --keepDupes, --keepSingleton, --keepDiscordant, --noCpG, --CHG, --CHH,\n"
 " --fraction, --counts, --logit, --methylKit, --cytosine_report, --ignoreNH,\n"
 " --minOppositeDepth INT, --maxVariantFrac FLOAT, --minConversionEfficiency FLOAT,\n"
 " --OT/--OB/--CTOT/--CTOB INT,INT,INT,INT, --nOT/--nOB/--nCTOT/--nCTOB INT,INT,INT,INT,\n"
 " -B/--mappabilityBBM FILE, -t/--mappabilityThreshold FLOAT, -b/--minMappableBases INT,\n"
-" -M/--mappability FILE, -O, -N FILE, --keepStrand(*), --version\n"
-" (*) BED-driven extraction is not part of this build.\n"
+" -M/--mappability FILE, -O, -N FILE, -l FILE, --keepStrand, --version\n"
 "\nNote that --fraction, --counts, and --logit are mutually exclusive!\n", stderr);
 }
 
@@ -252,6 +255,120 @@ static int map_window_passes(const mdk_plan *p, int c, int64_t start, int l) {
 enum { O_NOCPG = 1, O_CHG, O_CHH, O_KEEPDUPES, O_KEEPSINGLETON, O_KEEPDISCORDANT, O_OT, O_OB, O_CTOT, O_CTOB, O_MERGE, O_METHYLKIT,
        O_NOT, O_NOB, O_NCTOT, O_NCTOB, O_MINOPP, O_MAXVARFRAC, O_CHUNKSIZE, O_KEEPSTRAND, O_CYTREPORT, O_MINCONVEFF, O_IGNORENH };
 
+
+/* ------------------------------------------------------------------------------------------------ */
+/* -l FILE / --keepStrand (bed.c)                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+/* The reference walks its sorted region list with cursors that only move forward (spanOverlapsBED for chunks and
+ * reads, posOverlapsBED for columns; bed.c:22-53).  What those cursors compute is a function of the position alone:
+ * the region that governs position x is the FIRST region, in sorted order, that does not end at or before x; x is
+ * inside iff that region has started.  build_runs() turns the list into that function -- disjoint runs, each with the
+ * strand of its governing region -- once; chunks, reads and (on the device) columns then test against the runs. */
+typedef struct { int32_t tid, start, end; int strand; } bedreg;
+static int bedreg_order(const void *a, const void *b) {      /* sortBED_func, bed.c:66-80 */
+    const bedreg *x = a, *y = b;
+    if(x->tid != y->tid) return x->tid < y->tid ? -1 : 1;
+    if(x->start != y->start) return x->start < y->start ? -1 : 1;
+    if(x->end != y->end) return x->end < y->end ? -1 : 1;
+    return (x->strand > y->strand) - (x->strand < y->strand);
+}
+static size_t skip_field(const char *s, size_t i) { while(s[i] && !isspace((unsigned char)s[i])) i++; return i; }
+static size_t skip_blank(const char *s, size_t i) { while(s[i] && isspace((unsigned char)s[i])) i++; return i; }
+
+/* One line of the BED file, by the rules of parseBED (bed.c:118-219): the name ends at the first white-space character;
+ * the start is read (scanf %d, so leading blanks are tolerated) right after that ONE separator; the start column is
+ * taken to begin there too, so a doubled separator makes the start be read a second time as the end; the strand is the
+ * first character of the third column after the end.  Returns 1 = region, 0 = skipped, -1 = error (message printed). */
+static int bed_line(char *s, size_t l, int lnum, const char *fn, const mdk_bam *bam, int keep_strand, bedreg *r) {
+    size_t a, b, c; int t; char save;
+    if(s[0] == '#') return 0;
+    a = skip_field(s, 0);
+    save = s[a]; s[a] = 0;
+    for(t = 0; t < bam->n_targets; t++) if(!strcmp(s, bam->target_name[t])) break;
+    if(t == bam->n_targets) {
+        if(!strcmp(s, "track") || !strcmp(s, "browser")) return 0;
+        fprintf(stderr, "Couldn't properly parse line number %i in %s.\n", lnum, fn);
+        return -1;
+    }
+    s[a] = save;
+    r->tid = t; r->start = -1; r->end = -1; r->strand = 0;
+    if(a >= l || sscanf(s + a + 1, "%" SCNd32, &r->start) != 1 || r->start == -1) { fprintf(stderr, "Line %" PRId32 " of %s is malformed.\n", (int32_t)lnum, fn); return -1; }
+    b = skip_field(s, a + 1);
+    if(b >= l || sscanf(s + b + 1, "%" SCNd32, &r->end) != 1 || r->end == -1) { fprintf(stderr, "Line %" PRId32 " of %s is malformed.\n", (int32_t)lnum, fn); return -1; }
+    if(r->start >= r->end) { fprintf(stderr, "The position on line %" PRId32 " of %s is incorrect (%" PRId32 " >= %" PRId32 ".\n", (int32_t)lnum, fn, r->start, r->end); return -1; }
+    if(r->start < 0) r->start = 0;
+    if((int64_t)r->end > (int64_t)bam->target_len[t] + 1) r->end = (int32_t)(bam->target_len[t] + 1);
+    if(!keep_strand) return 1;
+    c = skip_field(s, b + 1);                                  /* the end column */
+    c = skip_blank(s, c); if(!s[c]) return 1; c = skip_field(s, c); if(!s[c]) return 1;      /* column 4 */
+    c = skip_blank(s, c); if(!s[c]) return 1; c = skip_field(s, c); if(!s[c]) return 1;      /* column 5 */
+    c = skip_blank(s, c);
+    if(s[c] == '+') r->strand = 1; else if(s[c] == '-') r->strand = 2;
+    return 1;
+}
+
+static void build_runs(mdk_plan *p, const bedreg *reg, size_t n) {
+    size_t i = 0; int32_t nt = p->bam->n_targets, t;
+    p->bed_run = calloc((size_t)nt + 1, sizeof(md_region *)); p->bed_nrun = calloc((size_t)nt + 1, sizeof(int64_t));
+    for(t = 0; t < nt; t++) {
+        size_t j = i, k; int64_t x = 0, m = 0; md_region *run;
+        while(j < n && reg[j].tid == t) j++;
+        run = malloc(sizeof(md_region) * (j - i + 1));
+        for(k = i; k < j; k++) {
+            if((int64_t)reg[k].end <= x) continue;                       /* over before x: never governs anything from here on */
+            run[m].start = reg[k].start > x ? reg[k].start : (int32_t)x; run[m].end = reg[k].end; run[m].strand = reg[k].strand; m++;
+            x = reg[k].end;
+        }
+        p->bed_run[t] = run; p->bed_nrun[t] = m; i = j;
+    }
+}
+/* does [beg, end) touch a run of the contig?  (spanOverlapsBED == 1, bed.c:11-41) */
+static int bed_touches(const mdk_plan *p, int32_t tid, int64_t beg, int64_t end) {
+    const md_region *run = p->bed_run[tid]; int64_t a = 0, b = p->bed_nrun[tid];
+    while(a < b) { int64_t m = (a + b) >> 1; if((int64_t)run[m].end <= beg) a = m + 1; else b = m; }
+    return a < p->bed_nrun[tid] && (int64_t)run[a].start < end;
+}
+
+static int load_bed(mdk_plan *p) {
+    const opts_t *o = &p->o; gzFile f; char *data = NULL, *line = NULL; size_t n = 0, cap = 0, at = 0, nreg = 0, creg = 0; bedreg *reg = NULL; int lnum = 0, rc = 0;
+    if((f = gzopen(o->bed_name, "r")) == NULL) { fprintf(stderr, "Couldn't open %s for reading.\n", o->bed_name); return -1; }
+    for(;;) {
+        int got;
+        if(cap - n < (1u << 16)) { cap = cap ? cap * 2 : 1u << 20; data = realloc(data, cap); if(!data) { gzclose(f); return -1; } }
+        got = gzread(f, data + n, 1u << 16);
+        if(got <= 0) break;
+        n += (size_t)got;
+    }
+    gzclose(f);
+    while(at < n && rc >= 0) {
+        size_t e = at, l; bedreg r;
+        while(e < n && data[e] != '\n') e++;
+        l = e - at; if(l > 1 && data[e - 1] == '\r') l--;
+        if(l == 0) break;                                /* the reference's line loop ends at the first empty line */
+        line = realloc(line, l + 2); memcpy(line, data + at, l); line[l] = line[l + 1] = 0;
+        at = e + 1; lnum++;
+        rc = bed_line(line, strlen(line) < l ? strlen(line) : l, lnum, o->bed_name, p->bam, o->keep_strand, &r);
+        if(rc == 1) {
+            if(nreg == creg) { creg = creg ? creg * 2 : 1024; reg = realloc(reg, sizeof(bedreg) * creg); }
+            reg[nreg++] = r;
+        }
+    }
+    free(line); free(data);
+    if(rc < 0) { free(reg); return -1; }
+    qsort(reg, nreg, sizeof(bedreg), bedreg_order);
+    fprintf(stderr, "Parsed %" PRId32 " regions in %s\n", (int32_t)nreg, o->bed_name);
+    build_runs(p, reg, nreg);
+    free(reg);
+    p->bed_on = 1;
+    return 0;
+}
+int mdk_plan_regions(const mdk_plan *p, int32_t tid, const md_region **runs, int64_t *n) {
+    if(!p || !runs || !n || tid < 0 || tid >= p->bam->n_targets) return -1;
+    if(!p->bed_on) { *runs = NULL; *n = -1; return 0; }
+    *runs = p->bed_run[tid]; *n = p->bed_nrun[tid];
+    return 0;
+}
+
 static void plan_free(mdk_plan *p);
 static void pipeline_stop(mdk_plan *p);
 static int pipeline_start(mdk_plan *p);
@@ -356,7 +473,6 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         plan_free(p);
         return rc;
     }
-    if(o->bed_name) { fprintf(stderr, "There was an error while reading in your BED file! (-l/--keepStrand are not part of the MI355X extract path yet)\n"); plan_free(p); return 1; }
 
     o->fasta_name = argv[optind]; o->bam_name = argv[optind + 1];
     if(o->n_threads < 1) o->n_threads = 1;
@@ -415,6 +531,8 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         if(p->g_end > p->bam->target_len[t]) p->g_end = p->bam->target_len[t];
         p->need_seek = 1;
     }
+    /* -l (extract.c:1469-1477) */
+    if(o->bed_name && load_bed(p) != 0) { fprintf(stderr, "There was an error while reading in your BED file!\n"); plan_free(p); return 1; }
     *out = p;
     return 0;
 }
@@ -424,6 +542,7 @@ static void plan_free(mdk_plan *p) {
     uint32_t k; int i;
     if(!p) return;
     pipeline_stop(p);               /* the reader and the workers use the BAM reader, the FASTA and the bitmaps: stop them first */
+    if(p->bed_run) { for(i = 0; i < p->bam->n_targets; i++) free(p->bed_run[i]); free(p->bed_run); free(p->bed_nrun); }
     if(p->bam) mdk_bam_close(p->bam);
     mdk_bai_free(p->bai);
     mdk_fasta_free(&p->fa); free(p->fa_of_tid); free(p->map_of_tid);
@@ -463,6 +582,7 @@ int mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid) {
     if(tid < 0 || tid >= p->bam->n_targets || (fi = p->fa_of_tid[tid]) < 0) return MDK_ERR_NOREF;
     i = md_dev_set_reference(dev, tid, p->fa.seq[fi], p->fa.len[fi]);
     if(i) return i;
+    if(p->bed_on && (i = md_dev_set_regions(dev, tid, p->bed_run[tid], p->bed_nrun[tid])) != 0) return i;
     if(p->n_ref == p->cap_ref) { p->cap_ref = p->cap_ref ? p->cap_ref * 2 : 32; p->ref_dev = realloc(p->ref_dev, sizeof(md_dev *) * p->cap_ref); p->ref_tid = realloc(p->ref_tid, sizeof(int32_t) * p->cap_ref); }
     p->ref_dev[p->n_ref] = dev; p->ref_tid[p->n_ref] = tid; p->n_ref++;
     return 0;
@@ -743,6 +863,7 @@ static int admit_and_pack(mdk_plan *p, batchbuf *b, const mdk_rec *r, int32_t rl
     }
     if(!o->keep_singleton && (r->flag & 0x9) == 0x9) return 0;
     if(!o->keep_discordant && (r->flag & 0x3) == 0x1) return 0;
+    if(p->bed_on && !bed_touches(p, r->tid, r->pos, (int64_t)r->pos + (rlen > 0 ? rlen : 1))) return 0;      /* common.c:432-439 */
     strand = strand_of(r->flag, xg);
     if(o->min_conv_eff > 0.0) { if(conv_efficiency(r, strand, o->min_phred, win, woff, wlen) < o->min_conv_eff) return 0; }
 
@@ -828,8 +949,13 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
     if(p->g_end && beg >= p->g_end) return 0;
     c->tid = (int32_t)tid; c->beg = beg; c->end = end;
     if(p->shard_world > 1 && (int)(c->index % (uint32_t)p->shard_world) != p->shard_rank) c->skipped |= MDK_CHUNK_FOREIGN;
+    if(p->bed_on && !bed_touches(p, (int32_t)tid, beg, end)) {      /* extract.c:352-369: the chunk is passed over before anything else happens */
+        c->skipped |= MDK_CHUNK_BED;
+        if(p->bai) { p->need_seek = 1; p->carry_len = 0; p->carry_tid = -1; return 1; }      /* do not even read its records */
+    }
     fi = p->fa_of_tid[tid];
-    if(fi < 0) {
+    if(c->skipped & MDK_CHUNK_BED) ;
+    else if(fi < 0) {
         if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", -2, bam->target_name[tid], beg > 1 ? beg - 2 : 0, end);
         if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "Note that the output will be truncated!\n");
         c->skipped |= MDK_CHUNK_NOREF;
@@ -1077,7 +1203,7 @@ int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
     double te0 = now_s();
     if(c->index != p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
     p->next_emit++;
-    if(c->skipped & MDK_CHUNK_NOREF) return 0;
+    if(c->skipped & (MDK_CHUNK_NOREF | MDK_CHUNK_BED)) return 0;
     chrom = p->bam->target_name[c->tid];
     fi = p->fa_of_tid[c->tid]; if(fi >= 0) { seq = p->fa.seq[fi]; slen = p->fa.len[fi]; }
     blank_from = c->beg;

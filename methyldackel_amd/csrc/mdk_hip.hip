@@ -130,6 +130,19 @@ __global__ __launch_bounds__(WG) void k_classify(const char *ref, uint8_t *code,
     }
 }
 
+// -l/--keepStrand (bed.c:46-64, extract.c:402-405,425): restrict a contig's sites to sorted disjoint runs.  A position
+// outside every run stops being a site (code 0); inside a run the run's strand code (0 any, 1 '+', 2 '-') goes into
+// bits 4-5 of the code, where the pileup reads it per position.  One thread per position, binary search over the runs.
+__global__ __launch_bounds__(WG) void k_mask_regions(uint8_t *code, int64_t n, const md_region *runs, int64_t nruns) {
+    for(int64_t p = (int64_t)blockIdx.x * WG + threadIdx.x; p < n; p += (int64_t)gridDim.x * WG) {
+        const int c = code[p] & 15;
+        if(!c) { code[p] = 0; continue; }
+        int64_t a = 0, b = nruns;                     // first run with end > p
+        while(a < b) { const int64_t m = (a + b) >> 1; if((int64_t)runs[m].end <= p) a = m + 1; else b = m; }
+        code[p] = (a < nruns && (int64_t)runs[a].start <= p) ? (uint8_t)(c | ((runs[a].strand & 3) << 4)) : (uint8_t)0;
+    }
+}
+
 #define KB 2      // positions per batch: their base/qual bytes (own + partner) are all in flight together
 
 // One segment, one lane.
@@ -145,6 +158,9 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
     RD m = o;
     if(partner) m = make_rd(P, g.m_off4, g.m_l_qseq, g.msf & MDK_SF_STRAND, g.msf & MDK_SF_READ2);
     const int lo_off = g.rpos > T0 ? g.rpos - T0 : 0, hi_off = (send < T1 ? send : T1) - T0;   // tile offsets covered
+    // --keepStrand: region strand codes (bits 13-14 of a list entry) this read is invisible at (bed.c:56-64):
+    // '+' regions (1) want OT/CTOT, '-' regions (2) want OB/CTOB, a read of unknown strand matches neither
+    const int badrs = strand == 0 ? 6 : (odd ? 4 : 2);
 #pragma unroll
     for(int pass = 0; pass < (VARIANT ? 2 : 1); pass++) {
         const bool callpass = pass == 0;
@@ -159,9 +175,9 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
 #pragma unroll
             for(int k = 0; k < KB; k++) {
                 li[k] = -1;
-                if(i < n) { const int l = list[i] & 0x1fff; if(l < hi_off) { li[k] = l; i++; } else i = n; }
+                if(i < n) { const int e = list[i], l = e & 0x1fff; if(l < hi_off) { li[k] = ((badrs >> (e >> 13)) & 1) ? -2 : l; i++; } else i = n; }
             }
-            if(li[0] < 0) break;
+            if(li[0] == -1) break;
             // 2. request every byte the batch needs (trimmed bases need none: they read as N with quality 0)
             uint32_t sb[KB], qb[KB], msb[KB], mqb[KB];
 #pragma unroll
@@ -246,10 +262,10 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
     for(int j = 0; j < PERMAX; j++) {
         if(j < PER) {
             const int i = tid * PER + j;
-            if(code[j] && !((P.keepmask >> ((code[j] - 1) >> 1)) & 1)) code[j] = 0;
+            if(code[j] && !((P.keepmask >> (((code[j] & 15) - 1) >> 1)) & 1)) code[j] = 0;
             cm[i] = 0; cu[i] = 0;
             if(VARIANT) { co[i] = 0; cv[i] = 0; }
-            if(code[j]) { if((code[j] - 1) & 1) cntG++; else cntC++; }
+            if(code[j]) { if((code[j] - 1) & 1) cntG++; else cntC++; }      // bit 0 of (code-1) = isG (bits 4-5 do not reach it)
         }
     }
     int nC, nG;
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
 #pragma unroll
         for(int j = 0; j < PERMAX; j++) {
             if(j < PER && code[j]) {
-                const uint16_t ent = (uint16_t)((tid * PER + j) | (((code[j] - 1) >> 1) << 13));
+                const uint16_t ent = (uint16_t)((tid * PER + j) | ((code[j] >> 4) << 13));       // offset | region strand code
                 if((code[j] - 1) & 1) listG[og++] = ent; else listC[oc++] = ent;
             }
         }
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
         for(int j = 0; j < PERMAX; j++) {
             if((vm[j] + vu[j]) > 0 || vo[j] > 0) {
                 if((int64_t)o < P.cap_sites) {
-                    md_site rec; rec.pos = (uint32_t)(T0 + tid * PER + j); rec.nmeth = vm[j]; rec.nunmeth = vu[j]; rec.meta = (uint32_t)(code[j] - 1);
+                    md_site rec; rec.pos = (uint32_t)(T0 + tid * PER + j); rec.nmeth = vm[j]; rec.nunmeth = vu[j]; rec.meta = (uint32_t)((code[j] & 15) - 1);
                     P.site[o] = rec;
                     if(VARIANT) { md_site_var rv; rv.noff = vo[j]; rv.nvar = vv[j]; P.var[o] = rv; }
                 }
@@ -483,6 +499,27 @@ extern "C" int md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int
         HIPCHK(hipDeviceSynchronize());
     }
     h->ref[tid] = d; h->refcode[tid] = c; h->reflen[tid] = len;
+    return 0;
+}
+
+extern "C" int md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs, int64_t n) {
+    if(!h || tid < 0 || n < 0 || (n && !runs)) return fail(MDK_ERR_ARG, "md_dev_set_regions", hipSuccess);
+    if((size_t)tid >= h->ref.size() || !h->refcode[tid]) { snprintf(g_err, sizeof(g_err), "reference for tid %d not uploaded", tid); return MDK_ERR_NOREF; }
+    for(int64_t i = 0; i < n; i++)
+        if(runs[i].start < 0 || runs[i].end <= runs[i].start || (i && runs[i].start < runs[i - 1].end) || runs[i].strand < 0 || runs[i].strand > 2)
+            return fail(MDK_ERR_ARG, "md_dev_set_regions: runs must be sorted, disjoint, non-empty, strand in 0..2", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t len = h->reflen[tid];
+    if(len <= 0) return 0;
+    md_region *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, sizeof(md_region) * (size_t)(n ? n : 1));
+    if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(regions)", e);
+    if(n) { e = hipMemcpy(d, runs, sizeof(md_region) * (size_t)n, hipMemcpyHostToDevice); if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_HIP, "hipMemcpy(regions)", e); } }
+    int64_t blocks = (len + WG - 1) / WG; if(blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_mask_regions, dim3((unsigned)blocks), dim3(WG), 0, 0, h->refcode[tid], len, d, n);
+    e = hipGetLastError(); if(e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d);
+    if(e != hipSuccess) return fail(MDK_ERR_HIP, "k_mask_regions", e);
     return 0;
 }
 

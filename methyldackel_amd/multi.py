@@ -76,7 +76,7 @@ def extract_sharded(args, count_fn_factory, device=None):
                 done = True
                 break
             meta.append(c)
-            if not (c.skipped & mdk.CHUNK_FOREIGN) and not (c.skipped & mdk.CHUNK_NOREF):
+            if not (c.skipped & mdk.CHUNK_FOREIGN) and not (c.skipped & mdk.CHUNK_EMPTY):
                 sites, var = count_fn(plan, c)
                 owned = np.concatenate([sites, var], axis=1) if variant else sites
                 mine += 1
@@ -92,7 +92,7 @@ def extract_sharded(args, count_fn_factory, device=None):
         dist.gather(send, recv, dst=0)
         if rank == 0:
             for c in meta:
-                if c.skipped & mdk.CHUNK_NOREF:
+                if c.skipped & mdk.CHUNK_EMPTY:
                     plan.emit(c, mdk.md_sites())
                     continue
                 owner = c.index % world

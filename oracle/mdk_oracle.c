@@ -30,7 +30,7 @@
  * DESIGN.md.  No byte-level golden output exists in the reference.
  *
  * Not supported (reference gets them only via libraries absent here): CRAM input, bigWig (-M).
- * BED (-l/--keepStrand) is outside the accelerated path and not restated.
+ * BED (-l/--keepStrand): bed.c restated below (parseBED, spanOverlapsBED, posOverlapsBED, readStrandOverlapsBED).
  *
  * Style note: this file follows the reference's control flow one step at a time (a real pileup
  * buffer swept column by column, reads copied into it, qualities rewritten in place).  The
@@ -39,6 +39,7 @@
  */
 #define _GNU_SOURCE
 #include <assert.h>
+#include <ctype.h>
 #include <errno.h>
 #include <getopt.h>
 #include <inttypes.h>
@@ -274,10 +275,11 @@ typedef struct {
     int bounds[16], absoluteBounds[16];
     int nThreads;
     unsigned long chunkSize;
+    struct bedRegions_ *bed;
 } Config;
 
 /* per-chunk context == mplp_data (MethylDackel.h:139-149) */
-typedef struct { Config *config; const bamfile *bf; regitr iter; int lseq; char *seq; uint32_t offset; } mplp_data;
+typedef struct { Config *config; const bamfile *bf; regitr iter; int lseq; char *seq; uint32_t offset; int32_t bedIdx; } mplp_data;
 
 /* working copy of a record: what htslib hands around as bam1_t (seq/qual are mutable) */
 typedef struct {
@@ -326,6 +328,131 @@ static int64_t aux2i(const uint8_t *t) {   /* bam_aux2i: integer types only, els
 /* ------------------------------------------------------------------------------------------ */
 /* common.c restated                                                                            */
 /* ------------------------------------------------------------------------------------------ */
+/* ---------------------------------------------------------------- bed.c ---------------------------------------- */
+typedef struct { int32_t tid, start, end; int8_t strand; } bedRegion;          /* MethylDackel.h:24-39 */
+typedef struct bedRegions_ { bedRegion *region; int32_t n, m; } bedRegions;    /* MethylDackel.h:41-52 */
+
+static int64_t compareRegions(int32_t tid0, int32_t start0, int32_t end0, int32_t tid1, int32_t start1, int32_t end1) {   /* bed.c:11-16 */
+    if(tid0 != tid1) return ((int64_t)tid0) - ((int64_t)tid1);
+    if(start0 < start1 && end0 >= start1) return 0;
+    if(start0 >= start1 && start0 < end1) return 0;
+    return ((int64_t)start0) - ((int64_t)start1);
+}
+static int spanOverlapsBED(int32_t tid, int32_t start, int32_t end, bedRegions *regs, int32_t *idx) {   /* bed.c:22-41 */
+    bedRegion *reg = regs->region; int64_t rv = -1; int i;
+    if(compareRegions(reg[*idx].tid, reg[*idx].start, reg[*idx].end - 1, tid, start, end) == 0) return 1;
+    else {
+        for(i = *idx; i < regs->n; i++) {
+            rv = compareRegions(reg[i].tid, reg[i].start, reg[i].end - 1, tid, start, end);
+            if(rv >= 0) { *idx = i; rv = (rv >= 1) ? 0 : 1; break; }
+        }
+        if(rv < 0) rv = -1;
+    }
+    return (int)rv;
+}
+static int posOverlapsBED(int32_t tid, int32_t pos, bedRegions *regions, int32_t idx) {   /* bed.c:46-53 */
+    if(idx >= regions->n) return 0;
+    if(tid != regions->region[idx].tid) return (regions->region[idx].tid < tid) ? -1 : 0;
+    if(pos >= regions->region[idx].end) return -1;
+    if(pos < regions->region[idx].start) return 0;
+    return 1;
+}
+static int getStrand(const brec *b);
+static int readStrandOverlapsBED(const brec *b, bedRegion region) {   /* bed.c:56-64 */
+    int s = getStrand(b);
+    if(region.strand) {
+        if(region.strand == 1 && (s == 1 || s == 3)) return 1;
+        if(region.strand == 2 && (s == 2 || s == 4)) return 1;
+        return 0;
+    }
+    return 1;
+}
+static int sortBED_func(const void *a, const void *b) {   /* bed.c:66-80 */
+    const bedRegion *pa = a, *pb = b;
+    if(pa->tid < pb->tid) return -1;
+    if(pa->tid > pb->tid) return 1;
+    if(pa->start < pb->start) return -1;
+    if(pa->start > pb->start) return 1;
+    if(pa->end < pb->end) return -1;
+    if(pa->end > pb->end) return 1;
+    if(pa->strand < pb->strand) return -1;
+    if(pa->strand > pb->strand) return 1;
+    return 0;
+}
+/* parseBED (bed.c:90-237).  The reference reads lines through htslib's kstream (gz or plain, '\n'-separated, one
+ * trailing '\r' dropped when the line is longer than one character) and stops at the first EMPTY line because its
+ * loop condition is "length > 0".  A line that ends before its start or end column makes the reference read stale
+ * bytes of the kstring buffer (undefined); here the line buffer is followed by NULs, so such a line is "malformed". */
+static bedRegions *parseBED(const char *fn, const bamfile *hdr, int keepStrand) {
+    gzFile fp; char *data = NULL; size_t n = 0, m = 0, o = 0; int32_t lnum = 0, i; bedRegions *regions;
+    char *line = NULL;
+    if((fp = gzopen(fn, "r")) == NULL) { fprintf(stderr, "Couldn't open %s for reading.\n", fn); return NULL; }
+    for(;;) {
+        int got;
+        if(m - n < 65536) { m = m ? 2 * m : 1 << 20; data = xrealloc(data, m); }
+        got = gzread(fp, data + n, 65536);
+        if(got <= 0) break;
+        n += (size_t)got;
+    }
+    gzclose(fp);
+    regions = xmalloc(sizeof(*regions)); regions->n = 0; regions->m = 1000; regions->region = xmalloc(sizeof(bedRegion) * (size_t)regions->m);
+    while(o < n) {      /* ks_getuntil(ks, KS_SEP_LINE, ...) > 0 */
+        size_t e = o, l; char *p1, *p2; bedRegion *r;
+        while(e < n && data[e] != '\n') e++;
+        l = e - o;
+        if(l > 1 && data[e - 1] == '\r') l--;
+        line = xrealloc(line, l + 4); memcpy(line, data + o, l); memset(line + l, 0, 4);
+        o = e + 1;
+        if(l == 0) break;
+        lnum++;
+        p1 = line; p2 = p1;
+        if(*p1 == '\0') continue;
+        if(*p1 == '#') continue;
+        if(regions->m - regions->n < 100) { regions->m += 1000; regions->region = xrealloc(regions->region, sizeof(bedRegion) * (size_t)regions->m); }
+        r = &regions->region[regions->n];
+        r->tid = -1; r->start = -1; r->end = -1; r->strand = 0;
+        while(*p2 && !isspace((unsigned char)*p2)) p2++;
+        if(*p2 != '\0') *p2 = '\0';
+        for(i = 0; i < hdr->n_targets; i++) if(strcmp(p1, hdr->target_name[i]) == 0) { r->tid = i; break; }
+        if(r->tid == -1) { if(strcmp(p1, "track") == 0) continue; if(strcmp(p1, "browser") == 0) continue; }
+        if(r->tid == -1) { fprintf(stderr, "Couldn't properly parse line number %i in %s.\n", lnum, fn); goto err; }
+        p1 = p2 + 1;
+        if(sscanf(p1, "%" SCNd32, &r->start) != 1 || r->start == -1) { fprintf(stderr, "Line %" PRId32 " of %s is malformed.\n", lnum, fn); goto err; }
+        p2++;
+        while(*p2 && !isspace((unsigned char)*p2)) p2++;
+        if(*p2 != '\0') *p2 = '\0';
+        p1 = p2 + 1;
+        if(sscanf(p1, "%" SCNd32, &r->end) != 1 || r->end == -1) { fprintf(stderr, "Line %" PRId32 " of %s is malformed.\n", lnum, fn); goto err; }
+        if(r->start >= r->end) { fprintf(stderr, "The position on line %" PRId32 " of %s is incorrect (%" PRId32 " >= %" PRId32 ".\n", lnum, fn, r->start, r->end); goto err; }
+        if(r->start < 0) r->start = 0;
+        if(r->end > (int64_t)hdr->target_len[r->tid] + 1) r->end = (int32_t)(hdr->target_len[r->tid] + 1);
+        regions->n++;
+        if((size_t)(p2 - line) >= l) continue;
+        p2++;
+        if(keepStrand != 1) continue;
+        while(*p2 && !isspace((unsigned char)*p2)) p2++;
+        while(*p2 && isspace((unsigned char)*p2)) p2++;          /* 4th column */
+        if(*p2 == '\0') continue;
+        while(*p2 && !isspace((unsigned char)*p2)) p2++;
+        if(*p2 == '\0') continue;
+        while(*p2 && isspace((unsigned char)*p2)) p2++;          /* 5th column */
+        if(*p2 == '\0') continue;
+        while(*p2 && !isspace((unsigned char)*p2)) p2++;
+        if(*p2 == '\0') continue;
+        while(*p2 && isspace((unsigned char)*p2)) p2++;          /* strand */
+        if(*p2 == '\0') continue;
+        if(*p2 == '+') regions->region[regions->n - 1].strand = 1;
+        else if(*p2 == '-') regions->region[regions->n - 1].strand = 2;
+    }
+    free(line); free(data);
+    qsort(regions->region, (size_t)regions->n, sizeof(bedRegion), sortBED_func);
+    fprintf(stderr, "Parsed %" PRId32 " regions in %s\n", regions->n, fn);
+    return regions;
+err:
+    free(line); free(data); free(regions->region); free(regions);
+    return NULL;
+}
+
 static int isCpG(char *seq, int pos, int seqlen) {            /* common.c:49-61 */
     if(pos >= seqlen) return 0;
     if(seq[pos] == 'C' || seq[pos] == 'c') {
@@ -525,6 +652,11 @@ static int filter_func(mplp_data *ldata, bam1 *b) {
         if(!c->keepSingleton && (r->flag & 0x9) == 0x9) continue;
         if(!c->keepDiscordant && (r->flag & 0x3) == 0x1) continue;
         /* common.c:431 sets 0x2 on the private copy; nothing downstream in extract looks at it */
+        if(c->bed) {       /* common.c:432-439: prefilter on the read's span, strand independent */
+            int overlap = spanOverlapsBED(r->tid, r->pos, rec_endpos(r), c->bed, &ldata->bedIdx);
+            if(overlap == 0) continue;
+            if(overlap < 0) return -1;
+        }
         b->r = r;
         b->seq = xrealloc(b->seq, (size_t)(r->l_qseq + 1) / 2 + 1);
         b->qual = xrealloc(b->qual, (size_t)r->l_qseq + 1);
@@ -809,7 +941,7 @@ static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {  
     uint64_t nVariantPositions = 0;
     pileup1 *plp; char *seq = NULL, base = 'A'; char context[3] = "HG";
     struct lastCall lastCpG_, lastCHG_, *lastCpG = NULL, *lastCHG = NULL;
-    kstr os_[3], *os[3]; mplp_data data;
+    kstr os_[3], *os[3]; mplp_data data; int32_t bedIdx = 0; int o;
     memset(os_, 0, sizeof(os_)); os[0] = &os_[0]; os[1] = &os_[1]; os[2] = &os_[2];
     for(i = 0; i < 3; i++) { os_[i].m = 1024; os_[i].s = xmalloc(1024); os_[i].s[0] = 0; }
     if(config->merge) {
@@ -831,6 +963,9 @@ static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {  
         if(localTid < (uint32_t)bf->n_targets && globalTid != (uint32_t)-1) {
             if(globalPos >= bf->target_len[localTid]) { localEnd = bf->target_len[localTid]; globalTid++; globalPos = 0; }
         }
+        if(config->bed) {   /* extract.c:352-369: skip chunks that touch no BED region */
+            if(spanOverlapsBED((int32_t)localTid, (int32_t)localPos, (int32_t)localEnd, config->bed, &bedIdx) != 1) continue;
+        }
         localPos2 = 0; if(localPos > 1) localPos2 = localPos - 2;
         lastPos = localPos;
         if(localTid >= (uint32_t)bf->n_targets) break;
@@ -848,6 +983,10 @@ static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {  
 
         while((plp = plp_auto(&iter, &tid, &pos, &n_plp)) != NULL) {
             if((uint32_t)pos < localPos || (uint32_t)pos >= localEnd) continue;
+            if(config->bed) {   /* extract.c:402-405 */
+                while((o = posOverlapsBED(tid, pos, config->bed, bedIdx)) == -1) bedIdx++;
+                if(o == 0) continue;
+            }
             if((direction = isCpG(seq, pos - localPos2, seqlen))) { if(!config->keepCpG) continue; type = 0; }
             else if((direction = isCHG(seq, pos - localPos2, seqlen))) { if(!config->keepCHG) continue; type = 1; }
             else if((direction = isCHH(seq, pos - localPos2, seqlen))) { if(!config->keepCHH) continue; type = 2; }
@@ -858,6 +997,7 @@ static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {  
             for(i = 0; i < n_plp; i++) {
                 if(plp[i].is_del) continue;
                 if(plp[i].is_refskip) continue;
+                if(config->bed) if(!readStrandOverlapsBED(plp[i].b->r, config->bed->region[bedIdx])) continue;   /* extract.c:425 */
                 strand = getStrand(plp[i].b->r);
                 if(strand & 1) { if(base != 'C' && base != 'c') { nVariant += isVariant(config, plp + i, &nOff, strand); continue; } }
                 else { if(base != 'G' && base != 'g') { nVariant += isVariant(config, plp + i, &nOff, strand); continue; } }
@@ -973,7 +1113,7 @@ static void extract_usage(void) {
 
 static int extract_main(int argc, char *argv[]) {              /* extract.c:706-1514 */
     char *opref = NULL, *oname, *p; int c, i; Config config; bamfile bf; fasta fa;
-    FILE *BBM_ptr = NULL; char *BWName = NULL; int outputBB = 0, noBAM = 0; char *bedName = NULL;
+    FILE *BBM_ptr = NULL; char *BWName = NULL; int outputBB = 0, noBAM = 0; char *bedName = NULL; int keepStrand = 0;
     const char *FastaName, *BAMName;
     static struct option lopts[] = {
         {"opref", 1, NULL, 'o'}, {"fraction", 0, NULL, 'f'}, {"counts", 0, NULL, 'c'}, {"logit", 0, NULL, 'm'},
@@ -1025,7 +1165,7 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
         case 17: config.minOppositeDepth = atoi(optarg); break;
         case 18: config.maxVariantFrac = atof(optarg); break;
         case 19: config.chunkSize = strtoul(optarg, NULL, 10); if(config.chunkSize < 1) { fprintf(stderr, "Error: The chunk size must be at least 1!\n"); return 1; } break;
-        case 20: break;
+        case 20: keepStrand = 1; break;
         case 21: config.cytosine_report = 1; break;
         case 22: config.minConversionEfficiency = atof(optarg); break;
         case 23: config.ignoreNH = 1; break;
@@ -1067,7 +1207,6 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
         return -1;
     }
     if(BWName || noBAM) { fprintf(stderr, "mdk_oracle: bigWig input (-M/-O/-N) needs libBigWig, which is not available; use -B <file.bbm>\n"); return -4; }
-    if(bedName) { fprintf(stderr, "mdk_oracle: -l/--keepStrand are outside the restated path\n"); return 1; }
 
     FastaName = argv[optind]; BAMName = argv[optind + 1];
     if((i = bam_load(BAMName, &bf)) != 0) { fprintf(stderr, "Couldn't open %s for reading!\n", BAMName); return -4; }
@@ -1165,6 +1304,10 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
         if(e > 0) globalEnd = (uint32_t)e;
         if(globalEnd > bf.target_len[globalTid]) globalEnd = bf.target_len[globalTid];
         free(bar);
+    }
+    if(bedName) {       /* extract.c:1469-1477 */
+        config.bed = parseBED(bedName, &bf, keepStrand);
+        if(!config.bed) { fprintf(stderr, "There was an error while reading in your BED file!\n"); return 1; }
     }
     if(getenv("MDK_ORACLE_DUMP")) dump_fp = fopen(getenv("MDK_ORACLE_DUMP"), "w");
 

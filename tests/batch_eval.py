@@ -74,8 +74,18 @@ def context(ref, p, keep):
     return t, isg
 
 
-def eval_batch(batch, ref: bytes, cfg):
-    """-> {pos: (type, isG, nmeth, nunmeth, noff, nvar)} for positions with any evidence"""
+def region_of(runs, p):
+    """strand code of the run holding p, or None (runs: sorted disjoint (start, end, strand))"""
+    import bisect
+    i = bisect.bisect_right(runs, (p, 1 << 40, 9)) - 1
+    if i >= 0 and runs[i][0] <= p < runs[i][1]:
+        return runs[i][2]
+    return None
+
+
+def eval_batch(batch, ref: bytes, cfg, runs=None):
+    """-> {pos: (type, isG, nmeth, nunmeth, noff, nvar)} for positions with any evidence.
+    runs: the -l restriction of this contig (Plan.regions), or None"""
     keep = (cfg.keepCpG, cfg.keepCHG, cfg.keepCHH)
     out = {}
     pay = {}
@@ -104,6 +114,10 @@ def eval_batch(batch, ref: bytes, cfg):
             if ctx is None:
                 continue
             t, isg = ctx
+            if runs is not None:
+                rs = region_of(runs, p)
+                if rs is None or (rs == 1 and strand not in (1, 3)) or (rs == 2 and strand not in (2, 4)):
+                    continue
             b, ql = o.bq(g.q0 + j)
             if m is not None:
                 mb, mq = m.bq(g.m_q0 + j)

@@ -26,7 +26,7 @@ def host_counts(args):
         name = plan.target_name(c.tid)
         if name not in refs:
             refs[name] = read_fasta(args)[name]
-        for p, v in eval_batch(c.batch, refs[name], cfg).items():
+        for p, v in eval_batch(c.batch, refs[name], cfg, plan.regions(c.tid)).items():
             assert (c.tid, p) not in out
             out[(c.tid, p)] = v
     plan.close()
