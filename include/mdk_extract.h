@@ -67,6 +67,19 @@ int  mdk_plan_regions(const mdk_plan *p, int32_t tid, const md_region **runs, in
 const char *mdk_plan_target_name(const mdk_plan *p, int32_t tid);
 int64_t mdk_plan_target_len(const mdk_plan *p, int32_t tid);
 
+/* ---- `mbias` (MBias.c; main.c:17,51-52 dispatches to mbias_main) ----
+ * mbias_main: drop-in for the reference symbol (argv[0] = "mbias"); same options, messages, return codes, SVG / --txt
+ * output and "Suggested inclusion options" line; -20/-21 when the GPU is unavailable/fails.
+ * mdk_plan_open_mbias: the same plan object for an `mbias` command line: chunks come out of mdk_plan_next_chunk with
+ * batches built WITHOUT mate pairing (mbias installs no overlap handler, MBias.c:158-161), to be fed to
+ * md_dev_mbias_submit.  mdk_plan_mbias_outputs tells what the command line asked to be written (prefix is NULL with
+ * --noSVG; which = keepCpG + 2 keepCHG + 4 keepCHH as passed to makeSVGs, MBias.c:556).
+ * mdk_mbias_report: makeSVGs + makeTXT (svg.c:300-454) over the histogram the device returns. */
+int  mbias_main(int argc, char *argv[]);
+int  mdk_plan_open_mbias(int argc, char *argv[], mdk_plan **out);
+int  mdk_plan_mbias_outputs(const mdk_plan *p, const char **opref, int *svg, int *txt, int *which);
+int  mdk_mbias_report(const md_mbias *hist, const char *opref, int svg, int txt, int which);
+
 #ifdef __cplusplus
 }
 #endif

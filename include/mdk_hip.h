@@ -134,6 +134,19 @@ int  md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int64_t len);
 typedef struct { int32_t start, end, strand; } md_region;
 int  md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs, int64_t n);
 
+/* mbias (MBias.c:57-230): histogram of calls over (strand, read number, position in read) instead of per-position
+ * counts; the reference keeps it as strandMeth{meth1,unmeth1,meth2,unmeth2}[qpos] per strand (MethylDackel.h:171-176).
+ * count[q*16 + (strand-1)*4 + (read 2 ? 2 : 0) + (unmethylated ? 1 : 0)], 0 <= q < len; strand 1..4 = OT, OB, CTOT, CTOB.
+ * md_dev_mbias_submit = md_dev_upload + the histogram kernel; the batch (built WITHOUT mate pairing: mbias installs no
+ * overlap handler, MBias.c:159) must stay valid until md_dev_slot_sync(slot) or the next submit on that slot returns.
+ * The histogram accumulates over submits in device memory; md_dev_mbias_read waits for all of them and returns it
+ * (memory owned by the handle, valid until the next read/reset/close). */
+typedef struct { int32_t len; const uint32_t *count; } md_mbias;
+int  md_dev_mbias_submit(md_dev *h, int slot, const md_read_batch *b);
+int  md_dev_mbias_read(md_dev *h, md_mbias *out);
+int  md_dev_mbias_reset(md_dev *h);
+int  md_dev_slot_sync(md_dev *h, int slot);
+
 /* slot in [0, n_slots): upload is H2D on the slot's stream; launch enqueues the kernels; download waits for
  * the slot and returns the sites.  md_dev_submit = upload + launch. */
 int  md_dev_upload(md_dev *h, int slot, const md_read_batch *b);

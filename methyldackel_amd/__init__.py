@@ -54,6 +54,10 @@ class md_region(C.Structure):
     _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("strand", C.c_int32)]
 
 
+class md_mbias(C.Structure):
+    _fields_ = [("len", C.c_int32), ("count", C.POINTER(C.c_uint32))]
+
+
 class md_site(C.Structure):
     _fields_ = [("pos", C.c_uint32), ("nmeth", C.c_uint32), ("nunmeth", C.c_uint32), ("meta", C.c_uint32)]
 
@@ -86,10 +90,12 @@ class mdk_chunk(C.Structure):
 
 HIP_SYMBOLS = ["md_dev_count", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
-               "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free"]
+               "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free",
+               "md_dev_mbias_submit", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
-                   "mdk_plan_target_len", "mdk_plan_regions"]
+                   "mdk_plan_target_len", "mdk_plan_regions",
+                   "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report"]
 
 _hip = None
 _ext = None
@@ -127,6 +133,10 @@ def lib_hip():
         L.md_sites_order.restype = C.c_int64
         L.md_dev_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
         L.md_dev_debug_effective.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.md_dev_mbias_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_read_batch)]
+        L.md_dev_mbias_read.argtypes = [C.c_void_p, C.POINTER(md_mbias)]
+        L.md_dev_mbias_reset.argtypes = [C.c_void_p]
+        L.md_dev_slot_sync.argtypes = [C.c_void_p, C.c_int]
         L.md_host_alloc.restype = C.c_void_p
         L.md_host_alloc.argtypes = [C.c_uint64]
         L.md_host_free.argtypes = [C.c_void_p]
@@ -155,6 +165,10 @@ def lib_extract():
         L.mdk_plan_target_name.restype = C.c_char_p
         L.mdk_plan_target_len.argtypes = [C.c_void_p, C.c_int32]
         L.mdk_plan_target_len.restype = C.c_int64
+        L.mbias_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.mdk_plan_open_mbias.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+        L.mdk_plan_mbias_outputs.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mdk_mbias_report.argtypes = [C.POINTER(md_mbias), C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.mdk_plan_regions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(md_region)), C.POINTER(C.c_int64)]
         _ext = L
     return _ext
@@ -217,6 +231,25 @@ class Device:
         self._chk(self.L.md_dev_bench(self.h, slot, warmup, iters, C.byref(r)), "md_dev_bench")
         return r
 
+    def mbias_submit(self, slot: int, batch: md_read_batch):
+        """accumulate the batch's calls into the device histogram; the batch must stay alive until slot_sync(slot)"""
+        self._chk(self.L.md_dev_mbias_submit(self.h, slot, C.byref(batch)), "md_dev_mbias_submit")
+
+    def slot_sync(self, slot: int):
+        self._chk(self.L.md_dev_slot_sync(self.h, slot), "md_dev_slot_sync")
+
+    def mbias_read(self):
+        """-> numpy uint32 array [len, 4 strands, 2 reads, (meth, unmeth)]"""
+        import numpy as np
+        m = md_mbias()
+        self._chk(self.L.md_dev_mbias_read(self.h, C.byref(m)), "md_dev_mbias_read")
+        if m.len <= 0:
+            return np.zeros((0, 4, 2, 2), dtype=np.uint32)
+        return np.ctypeslib.as_array(m.count, shape=(m.len * 16,)).reshape(m.len, 4, 2, 2).copy()
+
+    def mbias_reset(self):
+        self._chk(self.L.md_dev_mbias_reset(self.h), "md_dev_mbias_reset")
+
     def sync(self):
         self._chk(self.L.md_dev_sync(self.h), "md_dev_sync")
 
@@ -235,15 +268,24 @@ class Device:
 class Plan:
     """The host pipeline of one `extract` command line, a chunk at a time (mdk_plan_*)."""
 
-    def __init__(self, args):
+    def __init__(self, args, command: str = "extract"):
         L = lib_extract()
         self.L = L
-        self.args = ["extract"] + [str(a) for a in args]
+        self.command = command
+        self.args = [command] + [str(a) for a in args]
         self._argv = _argv(self.args)
         self.p = C.c_void_p()
-        self.rc = L.mdk_plan_open(len(self.args), self._argv, C.byref(self.p))
+        opener = {"extract": L.mdk_plan_open, "mbias": L.mdk_plan_open_mbias}[command]
+        self.rc = opener(len(self.args), self._argv, C.byref(self.p))
         if self.rc or not self.p:
-            raise MdkError(f"mdk_plan_open returned {self.rc}")
+            raise MdkError(f"{opener.__name__} returned {self.rc}")
+
+    def mbias_outputs(self):
+        """(prefix or None, svg, txt, which) of an mbias plan"""
+        pre, svg, txt, which = C.c_char_p(), C.c_int(), C.c_int(), C.c_int()
+        if self.L.mdk_plan_mbias_outputs(self.p, C.byref(pre), C.byref(svg), C.byref(txt), C.byref(which)):
+            raise MdkError("not an mbias plan")
+        return (pre.value.decode() if pre.value else None), svg.value, txt.value, which.value
 
     def dev_cfg(self) -> md_dev_cfg:
         cfg = md_dev_cfg()
@@ -296,6 +338,15 @@ class Plan:
             pass
 
 
+def mbias_report(hist, opref, svg: bool, txt: bool, which: int) -> int:
+    """makeSVGs/makeTXT of the reference over a [len,4,2,2] uint32 histogram (writes <opref>_<strand>.svg, prints to
+    the process's stdout/stderr)"""
+    import numpy as np
+    a = np.ascontiguousarray(hist, dtype=np.uint32).reshape(-1)
+    m = md_mbias(len(a) // 16, a.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return lib_extract().mdk_mbias_report(C.byref(m), os.fsencode(str(opref)) if opref is not None else None, int(svg), int(txt), which)
+
+
 def sites_to_rows(s: md_sites):
     """md_sites -> list of (pos, type, isG, nmeth, nunmeth, noff, nvar) tuples (for tests)."""
     rows = []
@@ -305,11 +356,11 @@ def sites_to_rows(s: md_sites):
     return rows
 
 
-def run_cli(args, cwd=None, env=None):
-    """Run the `MethylDackel extract` command of this build; returns CompletedProcess."""
+def run_cli(args, cwd=None, env=None, command="extract"):
+    """Run the `MethylDackel extract` (or `mbias`) command of this build; returns CompletedProcess."""
     if not CLI.exists():
         raise MdkError(f"{CLI} is missing (run `make`)")
     e = dict(os.environ)
     if env:
         e.update(env)
-    return subprocess.run([str(CLI), "extract"] + [str(a) for a in args], cwd=cwd, env=e, capture_output=True, text=True)
+    return subprocess.run([str(CLI), command] + [str(a) for a in args], cwd=cwd, env=e, capture_output=True, text=True)

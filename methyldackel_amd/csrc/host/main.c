@@ -1,5 +1,5 @@
-/* main.c -- `MethylDackel` command of the MI355X build.  Only `extract` is accelerated (and built); the
- * reference's dispatcher is main.c:39-62. */
+/* main.c -- `MethylDackel` command of the MI355X build: `extract` and `mbias` (the reference's dispatcher is
+ * main.c:39-62). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -9,7 +9,8 @@ static void usage_main(void) {
     fprintf(stderr, "MethylDackel (methyldackel_amd, MI355X build of the `extract` path)\n"
                     "Usage: MethylDackel <command> [options]\n\nCommands:\n"
                     "    extract  Extract methylation metrics from an alignment file in BAM format (GPU).\n"
-                    "    mbias | mergeContext | perRead   not part of this build; use the reference MethylDackel.\n");
+                    "    mbias    Determine the position-dependent methylation bias in a dataset (GPU).\n"
+                    "    mergeContext | perRead   not part of this build; use the reference MethylDackel.\n");
 }
 int main(int argc, char *argv[]) {
     if(argc == 1) { usage_main(); return 0; }
@@ -19,6 +20,7 @@ int main(int argc, char *argv[]) {
         setenv("MDK_FAST_EXIT", "1", 0);      /* a process about to end need not unpin buffers and shut the runtime down politely */
         return extract_main(argc - 1, argv + 1);
     }
-    if(!strcmp(argv[1], "mbias") || !strcmp(argv[1], "mergeContext") || !strcmp(argv[1], "perRead")) { fprintf(stderr, "`%s` is not part of the MI355X build.\n", argv[1]); return -1; }
+    if(!strcmp(argv[1], "mbias")) { setenv("MDK_FAST_EXIT", "1", 0); return mbias_main(argc - 1, argv + 1); }
+    if(!strcmp(argv[1], "mergeContext") || !strcmp(argv[1], "perRead")) { fprintf(stderr, "`%s` is not part of the MI355X build.\n", argv[1]); return -1; }
     fprintf(stderr, "Unknown command!\n"); usage_main(); return -1;
 }

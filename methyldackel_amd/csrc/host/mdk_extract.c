@@ -46,6 +46,7 @@ typedef struct {
     int n_threads; unsigned long chunk_size;
     char *region, *opref, *bbm_name, *bw_name, *bed_name, *out_bbm_name;     /* opref and out_bbm_name are owned */
     int output_bb, no_bam, keep_strand;
+    int mbias, svg, txt; char *mb_opref;                 /* `mbias` command: no pairing, no outputs of its own (MBias.c) */
     const char *fasta_name, *bam_name;
 } opts_t;
 
@@ -373,6 +374,74 @@ static void plan_free(mdk_plan *p);
 static void pipeline_stop(mdk_plan *p);
 static int pipeline_start(mdk_plan *p);
 
+/* everything after option parsing that `extract` and `mbias` share: inputs, (extract only) mappability and output
+ * files, -r, -l.  Frees the plan and returns the reference's code on failure. */
+static int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional) {
+    opts_t *o = &p->o; int i; char *oname; FILE *bbm = NULL;
+    o->fasta_name = argv[first_positional]; o->bam_name = argv[first_positional + 1];
+    if(o->n_threads < 1) o->n_threads = 1;
+    p->bam = mdk_bam_open(o->bam_name, o->n_threads);
+    if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
+    p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */
+    if(!o->mbias && o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); plan_free(p); return -8; }
+    if(!o->mbias && o->bw_name) { int rc = load_bigwig(p); if(rc) { if(bbm) fclose(bbm); plan_free(p); return rc; } }
+    if(bbm) {                  /* as in the reference, a BBM given together with a bigWig replaces the bigWig's bitmaps */
+        if(p->map_on) { uint32_t k; for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); } free(p->map_names); free(p->map_len); free(p->map_bits); p->map_names = NULL; p->map_len = NULL; p->map_bits = NULL; p->map_n = 0; }
+        { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { plan_free(p); return rc; } }
+    }
+    if(mdk_fasta_load(o->fasta_name, &p->fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", o->fasta_name); plan_free(p); return -4; }
+    p->fa_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
+    for(i = 0; i < p->bam->n_targets; i++) p->fa_of_tid[i] = mdk_fasta_find(&p->fa, p->bam->target_name[i]);
+    if(p->map_on) {
+        p->map_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
+        for(i = 0; i < p->bam->n_targets; i++) { uint32_t k; p->map_of_tid[i] = -1; for(k = 0; k < p->map_n; k++) if(!strcmp(p->map_names[k], p->bam->target_name[i])) { p->map_of_tid[i] = (int)k; break; } }
+    }
+
+    if(o->mbias) goto region;
+    /* output files and headers (extract.c:1343-1439) */
+    if(!o->opref) {
+        char *dot; o->opref = strdup(o->bam_name); dot = strrchr(o->opref, '.'); if(dot) *dot = 0;
+        fprintf(stderr, "writing to prefix:'%s'\n", o->opref);
+    }
+    oname = malloc(strlen(o->opref) + 40);
+    if(o->cytosine_report) {
+        sprintf(oname, "%s.cytosine_report.txt", o->opref);
+        p->out[0] = fopen(getenv("MDK_NO_OUTPUT") ? "/dev/null" : oname, "w"); p->out[1] = p->out[2] = p->out[0];
+        if(!p->out[0]) { fprintf(stderr, "Couldn't open the output CpG metrics file for writing! Insufficient permissions?\n"); free(oname); plan_free(p); return -3; }
+    } else {
+        static const char *cn[3] = {"CpG", "CHG", "CHH"};
+        for(i = 0; i < 3; i++) {
+            const char *ext = o->fraction ? ".meth.bedGraph" : o->counts ? ".counts.bedGraph" : o->logit ? ".logit.bedGraph" : o->methylkit ? ".methylKit" : ".bedGraph";
+            if(!o->ctx_on[i]) continue;
+            sprintf(oname, "%s_%s%s", o->opref, cn[i], ext);
+            p->out[i] = fopen(getenv("MDK_NO_OUTPUT") ? "/dev/null" : oname, "w");     /* MDK_NO_OUTPUT: non-writer rank of a sharded run */
+            if(!p->out[i]) { fprintf(stderr, "Couldn't open the output %s metrics file for writing! Insufficient permissions?\n", cn[i]); free(oname); plan_free(p); return -3; }
+            if(o->methylkit) fputs("chrBase\tchr\tbase\tstrand\tcoverage\tfreqC\tfreqT\n", p->out[i]);
+            else fprintf(p->out[i], "track type=\"bedGraph\" description=\"%s %s%s%s\"\n", o->opref, cn[i], o->merge ? " merged" : "",
+                         o->fraction ? " methylation fractions" : o->counts ? " methylation counts" : o->logit ? " logit transformed methylation fractions" : " methylation levels");
+        }
+    }
+    free(oname);
+region:
+    /* -r (extract.c:1441-1468, MBias.c:497-523) */
+    if(o->region) {
+        int s = 0, e = 0, t; const char *colon = parse_region(o->region, &s, &e); char *name;
+        if(!colon) { fprintf(stderr, "Could not parse the specified region!\n"); plan_free(p); return -4; }
+        name = strndup(o->region, (size_t)(colon - o->region));
+        for(t = 0; t < p->bam->n_targets; t++) if(!strcmp(p->bam->target_name[t], name)) break;
+        free(name);
+        if(t == p->bam->n_targets) { fprintf(stderr, "%s did not match a known chromosome/contig name!\n", o->region); plan_free(p); return -6; }
+        p->g_tid = (uint32_t)t;
+        if(s > 0) p->g_pos = (uint32_t)s;
+        if(e > 0) p->g_end = (uint32_t)e;
+        if(p->g_end > p->bam->target_len[t]) p->g_end = p->bam->target_len[t];
+        p->need_seek = 1;
+    }
+    /* -l (extract.c:1469-1477, MBias.c:524-532) */
+    if(o->bed_name && load_bed(p) != 0) { fprintf(stderr, "There was an error while reading in your BED file!\n"); plan_free(p); return 1; }
+    return 0;
+}
+
 int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     static const struct option longopts[] = {
         {"opref", required_argument, 0, 'o'}, {"fraction", no_argument, 0, 'f'}, {"counts", no_argument, 0, 'c'}, {"logit", no_argument, 0, 'm'},
@@ -388,7 +457,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         {"mappabilityThreshold", required_argument, 0, 't'}, {"minMappableBases", required_argument, 0, 'b'},
         {"outputBBMFile", required_argument, 0, 'O'}, {"outputBBMFileName", required_argument, 0, 'N'}, {"mappabilityBBM", required_argument, 0, 'B'},
         {0, 0, 0, 0}};
-    mdk_plan *p; opts_t *o; int c, i; char *oname; FILE *bbm = NULL;
+    mdk_plan *p; opts_t *o; int c;
     *out = NULL;
     p = calloc(1, sizeof(*p)); if(!p) return -5;
     o = &p->o;
@@ -474,65 +543,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         return rc;
     }
 
-    o->fasta_name = argv[optind]; o->bam_name = argv[optind + 1];
-    if(o->n_threads < 1) o->n_threads = 1;
-    p->bam = mdk_bam_open(o->bam_name, o->n_threads);
-    if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
-    p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */
-    if(o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); plan_free(p); return -8; }
-    if(o->bw_name) { int rc = load_bigwig(p); if(rc) { if(bbm) fclose(bbm); plan_free(p); return rc; } }
-    if(bbm) {                  /* as in the reference, a BBM given together with a bigWig replaces the bigWig's bitmaps */
-        if(p->map_on) { uint32_t k; for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); } free(p->map_names); free(p->map_len); free(p->map_bits); p->map_names = NULL; p->map_len = NULL; p->map_bits = NULL; p->map_n = 0; }
-        { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { plan_free(p); return rc; } }
-    }
-    if(mdk_fasta_load(o->fasta_name, &p->fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", o->fasta_name); plan_free(p); return -4; }
-    p->fa_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
-    for(i = 0; i < p->bam->n_targets; i++) p->fa_of_tid[i] = mdk_fasta_find(&p->fa, p->bam->target_name[i]);
-    if(p->map_on) {
-        p->map_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
-        for(i = 0; i < p->bam->n_targets; i++) { uint32_t k; p->map_of_tid[i] = -1; for(k = 0; k < p->map_n; k++) if(!strcmp(p->map_names[k], p->bam->target_name[i])) { p->map_of_tid[i] = (int)k; break; } }
-    }
-
-    /* output files and headers (extract.c:1343-1439) */
-    if(!o->opref) {
-        char *dot; o->opref = strdup(o->bam_name); dot = strrchr(o->opref, '.'); if(dot) *dot = 0;
-        fprintf(stderr, "writing to prefix:'%s'\n", o->opref);
-    }
-    oname = malloc(strlen(o->opref) + 40);
-    if(o->cytosine_report) {
-        sprintf(oname, "%s.cytosine_report.txt", o->opref);
-        p->out[0] = fopen(getenv("MDK_NO_OUTPUT") ? "/dev/null" : oname, "w"); p->out[1] = p->out[2] = p->out[0];
-        if(!p->out[0]) { fprintf(stderr, "Couldn't open the output CpG metrics file for writing! Insufficient permissions?\n"); free(oname); plan_free(p); return -3; }
-    } else {
-        static const char *cn[3] = {"CpG", "CHG", "CHH"};
-        for(i = 0; i < 3; i++) {
-            const char *ext = o->fraction ? ".meth.bedGraph" : o->counts ? ".counts.bedGraph" : o->logit ? ".logit.bedGraph" : o->methylkit ? ".methylKit" : ".bedGraph";
-            if(!o->ctx_on[i]) continue;
-            sprintf(oname, "%s_%s%s", o->opref, cn[i], ext);
-            p->out[i] = fopen(getenv("MDK_NO_OUTPUT") ? "/dev/null" : oname, "w");     /* MDK_NO_OUTPUT: non-writer rank of a sharded run */
-            if(!p->out[i]) { fprintf(stderr, "Couldn't open the output %s metrics file for writing! Insufficient permissions?\n", cn[i]); free(oname); plan_free(p); return -3; }
-            if(o->methylkit) fputs("chrBase\tchr\tbase\tstrand\tcoverage\tfreqC\tfreqT\n", p->out[i]);
-            else fprintf(p->out[i], "track type=\"bedGraph\" description=\"%s %s%s%s\"\n", o->opref, cn[i], o->merge ? " merged" : "",
-                         o->fraction ? " methylation fractions" : o->counts ? " methylation counts" : o->logit ? " logit transformed methylation fractions" : " methylation levels");
-        }
-    }
-    free(oname);
-    /* -r (extract.c:1441-1468) */
-    if(o->region) {
-        int s = 0, e = 0, t; const char *colon = parse_region(o->region, &s, &e); char *name;
-        if(!colon) { fprintf(stderr, "Could not parse the specified region!\n"); plan_free(p); return -4; }
-        name = strndup(o->region, (size_t)(colon - o->region));
-        for(t = 0; t < p->bam->n_targets; t++) if(!strcmp(p->bam->target_name[t], name)) break;
-        free(name);
-        if(t == p->bam->n_targets) { fprintf(stderr, "%s did not match a known chromosome/contig name!\n", o->region); plan_free(p); return -6; }
-        p->g_tid = (uint32_t)t;
-        if(s > 0) p->g_pos = (uint32_t)s;
-        if(e > 0) p->g_end = (uint32_t)e;
-        if(p->g_end > p->bam->target_len[t]) p->g_end = p->bam->target_len[t];
-        p->need_seek = 1;
-    }
-    /* -l (extract.c:1469-1477) */
-    if(o->bed_name && load_bed(p) != 0) { fprintf(stderr, "There was an error while reading in your BED file!\n"); plan_free(p); return 1; }
+    { int rc = plan_attach_inputs(p, argv, optind); if(rc) return rc; }
     *out = p;
     return 0;
 }
@@ -960,7 +971,11 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
         if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "Note that the output will be truncated!\n");
         c->skipped |= MDK_CHUNK_NOREF;
     } else {
-        sl->woff = beg > 1 ? (int64_t)beg - 2 : 0; sl->wlen = (int64_t)end + 10 + 1; if(sl->wlen > p->fa.len[fi]) sl->wlen = p->fa.len[fi]; sl->wlen -= sl->woff; if(sl->wlen < 0) sl->wlen = 0;
+        if(o->mbias) { sl->woff = beg; sl->wlen = (int64_t)end + 1; }                       /* faidx_fetch_seq(localPos, localEnd), MBias.c:147 */
+        else { sl->woff = beg > 1 ? (int64_t)beg - 2 : 0; sl->wlen = (int64_t)end + 10 + 1; }   /* (localPos2, localEnd+10), extract.c:381 */
+        if(sl->wlen > p->fa.len[fi]) sl->wlen = p->fa.len[fi];
+        sl->wlen -= sl->woff;
+        if(sl->wlen < 0) sl->wlen = 0;
         sl->win = p->fa.seq[fi] + sl->woff;
     }
     /* With a .bai the stream is repositioned instead of read through: once at the start of a -r region, and before every
@@ -1047,7 +1062,7 @@ static int worker_process(mdk_plan *p, pslot *sl) {
     sl->n_rg = 0;
     if(bb_reserve(b, 1, 16, 16, 1) || seg_reserve(b, 1)) return -5;          /* never hand out NULL arrays */
     t1 = now_s();
-    pair_reads(b, c->tid);
+    if(!p->o.mbias) pair_reads(b, c->tid);          /* mbias installs no overlap handler (MBias.c:158-161): every read counts on its own */
     t2 = now_s();
     if(build_segments(p, b, c->beg, c->end)) return -5;
     c->batch.tid = c->tid; c->batch.beg = c->beg; c->batch.end = c->end; c->batch.n_segs = (int32_t)b->n_seg; c->batch.seg = b->seg;
@@ -1327,6 +1342,128 @@ int extract_main(int argc, char *argv[]) {
         fflush(stdout); fflush(stderr);
         _exit(ret & 0xff);
     }
+    md_dev_close(dev);
+    mdk_plan_close(p);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* mbias (MBias.c): the same schedule, admission and segments; the device accumulates a histogram    */
+/* over (strand, read number, position in read) across all chunks, which is read back once.          */
+/* ------------------------------------------------------------------------------------------------ */
+static void mbias_usage(void) {
+    fputs("\nUsage: MethylDackel mbias [OPTIONS] <ref.fa> <sorted_alignments.bam> <output.prefix>\n", stderr);
+    fputs("\nOptions (MI355X build; same option surface as MethylDackel 0.6.1):\n"
+" -q INT, -p INT, -D INT(ignored), -r STR, -l FILE, --keepStrand, -@ INT, --chunkSize INT,\n"
+" --keepDupes, --keepSingleton, --keepDiscordant, -F/--ignoreFlags INT, -R/--requireFlags INT,\n"
+" --ignoreNH, --minConversionEfficiency FLOAT, --txt, --noSVG (implies --txt; no prefix needed),\n"
+" --noCpG, --CHG, --CHH, --nOT/--nOB/--nCTOT/--nCTOB INT,INT,INT,INT, --version\n", stderr);
+}
+
+int mdk_plan_open_mbias(int argc, char *argv[], mdk_plan **out) {
+    enum { M_NOCPG = 1, M_CHG, M_CHH, M_KEEPDUPES, M_KEEPSINGLETON, M_KEEPDISCORDANT, M_TXT, M_NOSVG, M_NOT, M_NOB, M_NCTOT, M_NCTOB,
+           M_CHUNKSIZE, M_KEEPSTRAND, M_MINCONVEFF, M_IGNORENH };
+    static const struct option longopts[] = {            /* MBias.c:330-352 */
+        {"noCpG", no_argument, 0, M_NOCPG}, {"CHG", no_argument, 0, M_CHG}, {"CHH", no_argument, 0, M_CHH}, {"keepDupes", no_argument, 0, M_KEEPDUPES},
+        {"keepSingleton", no_argument, 0, M_KEEPSINGLETON}, {"keepDiscordant", no_argument, 0, M_KEEPDISCORDANT}, {"txt", no_argument, 0, M_TXT},
+        {"noSVG", no_argument, 0, M_NOSVG}, {"nOT", required_argument, 0, M_NOT}, {"nOB", required_argument, 0, M_NOB}, {"nCTOT", required_argument, 0, M_NCTOT},
+        {"nCTOB", required_argument, 0, M_NCTOB}, {"chunkSize", required_argument, 0, M_CHUNKSIZE}, {"keepStrand", no_argument, 0, M_KEEPSTRAND},
+        {"minConversionEfficiency", required_argument, 0, M_MINCONVEFF}, {"ignoreNH", no_argument, 0, M_IGNORENH},
+        {"ignoreFlags", required_argument, 0, 'F'}, {"requireFlags", required_argument, 0, 'R'}, {"help", no_argument, 0, 'h'}, {"version", no_argument, 0, 'v'},
+        {0, 0, 0, 0}};
+    mdk_plan *p; opts_t *o; int c;
+    *out = NULL;
+    p = calloc(1, sizeof(*p)); if(!p) return -5;
+    o = &p->o;
+    o->mbias = 1; o->svg = 1;
+    o->ctx_on[0] = 1; o->min_mapq = 10; o->min_phred = 5; o->min_depth = 1; o->ignore_flags = 0xF00; o->n_threads = 1; o->chunk_size = 1000000;
+    p->shard_rank = 0; p->shard_world = 1;
+    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1; p->lastcpg_tid = -1; p->lastchg_tid = -1;
+    optind = 1;
+    while((c = getopt_long(argc, argv, "hvq:p:r:l:D:F:@:", longopts, NULL)) >= 0) {      /* NB no R: in the short options (MBias.c:353) */
+        switch(c) {
+        case 'h': mbias_usage(); plan_free(p); return 0;
+        case 'v': printf("%s (using HTSlib version %s)\n", MDK_VERSION, "none; methyldackel_amd MI355X build"); plan_free(p); return 0;
+        case 'D': break;
+        case 'r': o->region = optarg; break;
+        case 'l': o->bed_name = optarg; break;
+        case M_NOCPG: o->ctx_on[0] = 0; break;
+        case M_CHG: o->ctx_on[1] = 1; break;
+        case M_CHH: o->ctx_on[2] = 1; break;
+        case M_KEEPDUPES: o->keep_dupes = 1; break;       /* unlike extract, 0x400 stays in ignoreFlags, so this alone changes nothing */
+        case M_KEEPSINGLETON: o->keep_singleton = 1; break;
+        case M_KEEPDISCORDANT: o->keep_discordant = 1; break;
+        case M_TXT: o->txt = 1; break;
+        case M_NOSVG: o->svg = 0; o->txt = 1; break;
+        case M_NOT: case M_NOB: case M_NCTOT: case M_NCTOB: parse_bounds(optarg, o->abs_bounds + 4 * (c - M_NOT)); break;
+        case M_CHUNKSIZE: o->chunk_size = strtoul(optarg, NULL, 10); if(o->chunk_size < 1) { fprintf(stderr, "Error: The chunk size must be at least 1!\n"); plan_free(p); return 1; } break;
+        case M_KEEPSTRAND: o->keep_strand = 1; break;
+        case M_MINCONVEFF: o->min_conv_eff = (float)atof(optarg); break;
+        case M_IGNORENH: o->ignore_nh = 1; break;
+        case 'F': o->ignore_flags = atoi(optarg); break;
+        case 'R': o->require_flags = atoi(optarg); break;
+        case 'q': o->min_mapq = atoi(optarg); break;
+        case 'p': o->min_phred = atoi(optarg); break;
+        case '@': o->n_threads = atoi(optarg); break;
+        default: fprintf(stderr, "Invalid option '%c'\n", c); mbias_usage(); plan_free(p); return 1;
+        }
+    }
+    if(argc == 1) { mbias_usage(); plan_free(p); return 0; }
+    if((o->svg && argc - optind != 3) || (!o->svg && argc - optind < 2)) {
+        fprintf(stderr, "You must supply a reference genome in fasta format, an input BAM file, and an output prefix!!!\n");
+        mbias_usage(); plan_free(p); return -1;
+    }
+    if(o->min_phred < 1) { fprintf(stderr, "-p %i is invalid. resetting to 1, which is the lowest possible value.\n", o->min_phred); o->min_phred = 1; }
+    if(o->min_mapq < 0) { fprintf(stderr, "-q %i is invalid. Resetting to 0, which is the lowest possible value.\n", o->min_mapq); o->min_mapq = 0; }
+    if(!(o->ctx_on[0] + o->ctx_on[1] + o->ctx_on[2])) {
+        fprintf(stderr, "You haven't specified any metrics to output!\nEither don't use the --noCpG option or specify --CHG and/or --CHH.\n");
+        plan_free(p); return -1;
+    }
+    if(o->svg) o->mb_opref = argv[optind + 2];
+    { int rc = plan_attach_inputs(p, argv, optind); if(rc) return rc; }
+    *out = p;
+    return 0;
+}
+int mdk_plan_mbias_outputs(const mdk_plan *p, const char **opref, int *svg, int *txt, int *which) {
+    if(!p || !p->o.mbias) return -1;
+    if(opref) *opref = p->o.mb_opref;
+    if(svg) *svg = p->o.svg;
+    if(txt) *txt = p->o.txt;
+    if(which) *which = p->o.ctx_on[0] + 2 * p->o.ctx_on[1] + 4 * p->o.ctx_on[2];
+    return 0;
+}
+
+int mbias_main(int argc, char *argv[]) {
+    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch; int rc, k = 0, ret = 0; devopen_t dop; pthread_t dth; md_mbias hist;
+    rc = mdk_plan_open_mbias(argc, argv, &p);
+    if(rc != 0 || !p) return rc;
+    memset(&dop, 0, sizeof(dop));
+    mdk_plan_dev_cfg(p, &dop.cfg);
+    if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
+    pthread_create(&dth, NULL, devopen_main, &dop);
+    if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
+    pthread_join(dth, NULL);
+    dev = dop.dev;
+    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `mbias`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    for(;; k++) {
+        /* chunk k goes to slot k&1; the batch handed out two calls ago is recycled by the next call, so its upload must be over */
+        if((rc = md_dev_slot_sync(dev, k & 1)) != 0) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+        rc = mdk_plan_next_chunk(p, &ch);
+        if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
+        if(rc == 0) break;
+        if(ch.skipped & MDK_CHUNK_NOREF) { ret = -4; break; }        /* the reference's worker gives up here and its caller then crashes (MBias.c:150-155,543) */
+        if(ch.skipped) continue;
+        rc = mdk_plan_ensure_reference(p, dev, ch.tid);
+        if(!rc) rc = md_dev_mbias_submit(dev, k & 1, &ch.batch);
+        if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+    }
+    if(ret == 0) {
+        rc = md_dev_mbias_read(dev, &hist);
+        if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
+        if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; }
+        else if(mdk_mbias_report(&hist, p->o.mb_opref, p->o.svg, p->o.txt, p->o.ctx_on[0] + 2 * p->o.ctx_on[1] + 4 * p->o.ctx_on[2])) ret = -3;
+    }
+    if(getenv("MDK_FAST_EXIT")) { fflush(stdout); fflush(stderr); _exit(ret & 0xff); }
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;

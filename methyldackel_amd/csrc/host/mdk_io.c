@@ -97,7 +97,9 @@ static mdk_slab *inflate_slab(mdk_bam *b, int *status) {          /* status: 0 o
     {
         inflate_job job; int nt = b->nthreads, i; pthread_t th[64];
         job.blk = blk; job.n = nb; job.next = 0; job.failed = 0; pthread_mutex_init(&job.mu, NULL);
-        if(nt > 64) nt = 64; if(nt > (nb + 7) / 8) nt = (nb + 7) / 8; if(nt < 1) nt = 1;
+        if(nt > 64) nt = 64;
+        if(nt > (nb + 7) / 8) nt = (nb + 7) / 8;
+        if(nt < 1) nt = 1;
         if(nt == 1) inflate_worker(&job);
         else { for(i = 0; i < nt; i++) pthread_create(&th[i], NULL, inflate_worker, &job); for(i = 0; i < nt; i++) pthread_join(th[i], NULL); }
         pthread_mutex_destroy(&job.mu);

@@ -65,6 +65,7 @@ struct KParams {
     int keepmask, minPhred;
     int bounds[16], abounds[16];
     int *err;
+    int mbias; uint32_t *hist; int hist_lq;     // mbias: window-relative contexts at the chunk edges; histogram rows [q][16]; rows kept in LDS
     unsigned long long *dbg;      // optional phase timestamps: 8 words per workgroup (MDK_PHASES=1)
 };
 
@@ -223,6 +224,55 @@ __device__ __forceinline__ int wave_scan_incl(int v, int lane) {
     return v;
 }
 
+
+// context codes of the PER consecutive positions a thread owns (0 = not a site or context not wanted).
+// mbias classifies inside the chunk's own reference window [beg, end] (MBias.c:147,172-180), so a G in the first two
+// positions cannot see the C before the chunk and a C in the last position cannot see a G two past it.
+__device__ __forceinline__ void load_codes(const KParams &P, int64_t T0, int tlen, int PER, int tid, int (&code)[PERMAX]) {
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++) {
+        const int i = tid * PER + j; const int64_t p = T0 + i;
+        code[j] = (j < PER && i < tlen && p < P.reflen) ? P.ctxcode[p] : 0;
+    }
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++) {
+        if(j < PER && code[j]) {
+            if(P.mbias) {
+                const int64_t p = T0 + tid * PER + j; const int c = (code[j] & 15) - 1, type = c >> 1, isG = c & 1;
+                int nt = type;
+                if(isG) { if(p == P.beg) nt = 2; else if(p == P.beg + 1 && type == 1) nt = 2; }
+                else if(p == P.end - 1 && type == 1) nt = 2;
+                code[j] = (code[j] & ~15) | (1 + 2 * nt + isG);
+            }
+            if(!((P.keepmask >> (((code[j] & 15) - 1) >> 1)) & 1)) code[j] = 0;
+        }
+    }
+}
+
+// sorted C and G position lists of the tile in LDS (wave scan + one cross-wave exchange): entry = tile offset | region strand code << 13
+__device__ __forceinline__ void build_lists(const KParams &P, int PER, int tid, int lane, int wave, const int (&code)[PERMAX],
+                                            uint16_t *listC, uint16_t *listG, int *wsum, int &nC, int &nG) {
+    int cntC = 0, cntG = 0;
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++)
+        if(j < PER && code[j]) { if((code[j] - 1) & 1) cntG++; else cntC++; }      // bit 0 of (code-1) = isG (bits 4-5 do not reach it)
+    const int packed = cntC | (cntG << 16), incl = wave_scan_incl(packed, lane);
+    if(lane == 63) wsum[wave] = incl;
+    lds_barrier();
+    int pre = incl - packed, tot = 0;
+    for(int w = 0; w < WAVES; w++) { const int c = wsum[w]; if(w < wave) pre += c; tot += c; }
+    nC = tot & 0xffff; nG = tot >> 16;
+    int oc = pre & 0xffff, og = pre >> 16;
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++) {
+        if(j < PER && code[j]) {
+            const uint16_t ent = (uint16_t)((tid * PER + j) | ((code[j] >> 4) << 13));
+            if((code[j] - 1) & 1) listG[og++] = ent; else listC[oc++] = ent;
+        }
+    }
+    lds_barrier();
+}
+
 template <bool VARIANT>
 __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
     extern __shared__ __align__(16) uint32_t lds[];
@@ -248,44 +298,21 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
     const TileEnt te = P.tiles[t];
     const int first = te.first, last = te.last;
     int code[PERMAX];
-#pragma unroll
-    for(int j = 0; j < PERMAX; j++) {
-        const int i = tid * PER + j; const int64_t p = T0 + i;
-        code[j] = (j < PER && i < tlen && p < P.reflen) ? P.ctxcode[p] : 0;
-    }
+    load_codes(P, T0, tlen, PER, tid, code);
     md_seg g0; g0.rpos = 0x7fffffff; g0.len = 0;
     if(first + tid < last) g0 = P.seg[first + tid];
 
     // phase 1: sorted C / G position lists (wave scan + one cross-wave exchange), counters zeroed
-    int cntC = 0, cntG = 0;
 #pragma unroll
     for(int j = 0; j < PERMAX; j++) {
         if(j < PER) {
             const int i = tid * PER + j;
-            if(code[j] && !((P.keepmask >> (((code[j] & 15) - 1) >> 1)) & 1)) code[j] = 0;
             cm[i] = 0; cu[i] = 0;
             if(VARIANT) { co[i] = 0; cv[i] = 0; }
-            if(code[j]) { if((code[j] - 1) & 1) cntG++; else cntC++; }      // bit 0 of (code-1) = isG (bits 4-5 do not reach it)
         }
     }
     int nC, nG;
-    {
-        const int packed = cntC | (cntG << 16), incl = wave_scan_incl(packed, lane);
-        if(lane == 63) wsum[wave] = incl;
-        lds_barrier();
-        int pre = incl - packed, tot = 0;
-        for(int w = 0; w < WAVES; w++) { const int c = wsum[w]; if(w < wave) pre += c; tot += c; }
-        nC = tot & 0xffff; nG = tot >> 16;
-        int oc = pre & 0xffff, og = pre >> 16;
-#pragma unroll
-        for(int j = 0; j < PERMAX; j++) {
-            if(j < PER && code[j]) {
-                const uint16_t ent = (uint16_t)((tid * PER + j) | ((code[j] >> 4) << 13));       // offset | region strand code
-                if((code[j] - 1) & 1) listG[og++] = ent; else listC[oc++] = ent;
-            }
-        }
-        lds_barrier();
-    }
+    build_lists(P, PER, tid, lane, wave, code, listC, listG, wsum, nC, nG);
     if(P.dbg) tc1 = clock64();
 
     // phase 2: one segment per lane, WG segments per round
@@ -343,6 +370,73 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
             d[0] = tr0; d[1] = wall_clock64(); d[2] = tc1 - tc0; d[3] = tc2 - tc1; d[4] = tc3 - tc2; d[5] = tc4 - tc3; d[6] = (unsigned long long)(last - first); d[7] = (unsigned long long)t;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mbias (MBias.c:57-230): the same admission, segments, context lists and trimming, but no mate-overlap resolution and
+// no per-position counters: every call lands in a histogram over (strand, read number, position in read).
+// Rows [q][16] with column (strand-1)*4 + (read 2 ? 2 : 0) + (unmethylated ? 1 : 0); the first MB_LQ rows are
+// accumulated in LDS per workgroup and flushed once, longer reads go to the global histogram directly.
+// ------------------------------------------------------------------------------------------------
+#define MB_LQ 512
+
+__device__ __forceinline__ void mbias_seg(const KParams &P, const md_seg &g, int T0, int T1,
+                                          const uint16_t *listC, int nC, const uint16_t *listG, int nG, uint32_t *lh) {
+    const int send = g.rpos + (int)g.len;
+    if(g.rpos >= T1 || send <= T0) return;
+    const int strand = g.sf & MDK_SF_STRAND;
+    const bool odd = strand & 1;
+    const RD o = make_rd(P, g.off4, g.l_qseq, strand, g.sf & MDK_SF_READ2);
+    const int lo_off = g.rpos > T0 ? g.rpos - T0 : 0, hi_off = (send < T1 ? send : T1) - T0;
+    const int badrs = strand == 0 ? 6 : (odd ? 4 : 2);
+    const int col = (strand - 1) * 4 + ((g.sf & MDK_SF_READ2) ? 2 : 0);
+    const uint16_t *list = odd ? listC : listG; const int n = odd ? nC : nG;
+    int a = 0, b = n;
+    while(a < b) { int mid = (a + b) >> 1; if((int)(list[mid] & 0x1fff) < lo_off) a = mid + 1; else b = mid; }
+    for(int i = a; i < n; i++) {
+        const int e = list[i], l = e & 0x1fff;
+        if(l >= hi_off) break;
+        if((badrs >> (e >> 13)) & 1) continue;
+        if(strand == 0) { atomicExch(P.err, 1); return; }          // updateMetrics aborts on such a read (common.c:122-125)
+        const int q = (int)g.q0 + (T0 + l - g.rpos);
+        if(q < o.lo || q >= o.hi) continue;                        // trimmed: N with quality 0, below any -p
+        const uint32_t sb = o.seq[q >> 1]; const int ql = o.qual[q];
+        if(ql < P.minPhred) continue;
+        const int bq = (q & 1) ? (sb & 15) : (sb >> 4);
+        int un;
+        if(odd) { if(bq == 2) un = 0; else if(bq == 8) un = 1; else continue; }
+        else { if(bq == 4) un = 0; else if(bq == 1) un = 1; else continue; }
+        const int idx = q * 16 + col + un;
+        if(q < P.hist_lq) atomicAdd(&lh[idx], 1u); else atomicAdd(&P.hist[idx], 1u);
+    }
+}
+
+__global__ __launch_bounds__(WG, 8) void k_mbias(const KParams P) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const int TILE = P.tile, PER = TILE / WG;
+    uint16_t *listC = (uint16_t *)lds, *listG = listC + TILE;
+    uint32_t *lh = lds + TILE;
+    __shared__ int wsum[WAVES];
+    const int b = blockIdx.x;
+    const int t = (b & 7) * P.nper + (b >> 3);
+    if(t >= P.ntiles) return;
+    const int64_t T0 = P.beg + (int64_t)t * TILE;
+    const int64_t T1 = (T0 + TILE < P.end) ? T0 + TILE : P.end;
+    const int tlen = (int)(T1 - T0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TileEnt te = P.tiles[t];
+    int code[PERMAX];
+    load_codes(P, T0, tlen, PER, tid, code);
+    const int nh = 16 * P.hist_lq;
+    for(int i = tid; i < nh; i += WG) lh[i] = 0;
+    int nC, nG;
+    build_lists(P, PER, tid, lane, wave, code, listC, listG, wsum, nC, nG);
+    for(int r = te.first + tid; r < te.last; r += WG) {
+        const md_seg g = P.seg[r];
+        mbias_seg(P, g, (int)T0, (int)T1, listC, nC, listG, nG, lh);
+    }
+    __syncthreads();
+    for(int i = tid; i < nh; i += WG) { const uint32_t v = lh[i]; if(v) atomicAdd(&P.hist[i], v); }
 }
 
 // test hook: effective (post-trim, post-overlap-resolution) base and quality of every base of every segment,
@@ -414,6 +508,7 @@ struct md_dev {
     int device; md_dev_cfg cfg; int tile, n_slots; bool variant;
     std::vector<Slot> slots;
     std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
+    uint32_t *d_hist = nullptr; int hist_cap = 0, hist_len = 0; std::vector<uint32_t> h_hist;      // mbias: rows [q][16], q < hist_cap
 };
 
 extern "C" const char *md_dev_last_error(void) { return g_err; }
@@ -473,6 +568,7 @@ extern "C" void md_dev_close(md_dev *h) {
         if(s.e0) (void)hipEventDestroy(s.e0); if(s.e1) (void)hipEventDestroy(s.e1); if(s.k0) (void)hipEventDestroy(s.k0); if(s.k1) (void)hipEventDestroy(s.k1);
         if(s.stream) (void)hipStreamDestroy(s.stream);
     }
+    if(h->d_hist) (void)hipFree(h->d_hist);
     for(char *p : h->ref) if(p) (void)hipFree(p);
     for(uint8_t *p : h->refcode) if(p) (void)hipFree(p);
     delete h;
@@ -626,6 +722,73 @@ extern "C" int md_dev_submit(md_dev *h, int slot, const md_read_batch *b) {
     int rc = md_dev_upload(h, slot, b);
     if(rc) return rc;
     return md_dev_launch(h, slot);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mbias entry points
+// ------------------------------------------------------------------------------------------------
+static int hist_reserve(md_dev *h, int rows) {
+    if(rows <= h->hist_cap) return 0;
+    int cap = h->hist_cap ? h->hist_cap : 1024;
+    while(cap < rows) cap *= 2;
+    HIPCHK(hipDeviceSynchronize());                    // launches in flight still add into the old buffer
+    uint32_t *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, (size_t)cap * 16 * sizeof(uint32_t));
+    if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(mbias histogram)", e);
+    HIPCHK(hipMemset(d, 0, (size_t)cap * 16 * sizeof(uint32_t)));
+    if(h->d_hist) { HIPCHK(hipMemcpy(d, h->d_hist, (size_t)h->hist_cap * 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice)); (void)hipFree(h->d_hist); }
+    h->d_hist = d; h->hist_cap = cap;
+    return 0;
+}
+
+extern "C" int md_dev_mbias_submit(md_dev *h, int slot, const md_read_batch *b) {
+    int rc = md_dev_upload(h, slot, b);
+    if(rc) return rc;
+    Slot *s = get_slot(h, slot);
+    int maxlq = 0;
+    for(int i = 0; i < b->n_segs; i++) if((int)b->seg[i].l_qseq > maxlq) maxlq = (int)b->seg[i].l_qseq;
+    if((rc = hist_reserve(h, maxlq > 1 ? maxlq : 1)) != 0) return rc;
+    if(maxlq > h->hist_len) h->hist_len = maxlq;
+    if(s->ntiles <= 0 || b->n_segs == 0) return 0;
+    KParams P; if((rc = fill_kparams(h, s, P)) != 0) return rc;
+    P.mbias = 1; P.hist = h->d_hist;
+    P.hist_lq = maxlq < MB_LQ ? (maxlq + 7) & ~7 : MB_LQ; if(P.hist_lq > h->hist_cap) P.hist_lq = h->hist_cap;
+    const size_t lds = (size_t)s->tile * 4 + (size_t)P.hist_lq * 16 * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_mbias, dim3(P.nper * 8), dim3(WG), lds, s->stream, P);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int md_dev_slot_sync(md_dev *h, int slot) {
+    Slot *s = get_slot(h, slot);
+    if(!s) return MDK_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+extern "C" int md_dev_mbias_read(md_dev *h, md_mbias *out) {
+    if(!h || !out) return fail(MDK_ERR_ARG, "md_dev_mbias_read", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    for(auto &s : h->slots) {
+        int err = 0;
+        HIPCHK(hipMemcpy(&err, s.d_err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if(err) { snprintf(g_err, sizeof(g_err), "Can't determine the strand of a read!"); (void)hipMemset(s.d_err.p, 0, sizeof(int)); return MDK_ERR_STRAND0; }
+    }
+    h->h_hist.assign((size_t)(h->hist_len > 0 ? h->hist_len : 1) * 16, 0u);
+    if(h->hist_len > 0) HIPCHK(hipMemcpy(h->h_hist.data(), h->d_hist, (size_t)h->hist_len * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    out->len = h->hist_len; out->count = h->h_hist.data();
+    return 0;
+}
+
+extern "C" int md_dev_mbias_reset(md_dev *h) {
+    if(!h) return MDK_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipDeviceSynchronize());
+    if(h->d_hist) HIPCHK(hipMemset(h->d_hist, 0, (size_t)h->hist_cap * 16 * sizeof(uint32_t)));
+    h->hist_len = 0;
+    return 0;
 }
 
 // wait for the launch, read the total, check the error word

@@ -782,7 +782,7 @@ static void plp_init(plp_t *it, mplp_data *data, ohash_t *oh) {
 }
 static void plp_destroy(plp_t *it) {
     lbnode *p = it->head;
-    while(p != it->tail) { lbnode *n = p->next; custom_overlap_destructor(it->oh, p); node_free(p); p = n; }
+    while(p != it->tail) { lbnode *n = p->next; if(it->oh) custom_overlap_destructor(it->oh, p); node_free(p); p = n; }
     node_free(it->tail); free(it->plp); free(it->scratch.seq); free(it->scratch.qual);
 }
 /* resolve_cigar2: where does column `pos` fall in this read? */
@@ -810,7 +810,7 @@ static void plp_push(plp_t *it, const bam1 *b) {
         it->max_tid = b->r->tid; it->max_pos = t->beg;
         if(t->end > it->pos || b->r->tid > it->tid) {
             lbnode *next = node_new();
-            custom_overlap_constructor(it->oh, t);
+            if(it->oh) custom_overlap_constructor(it->oh, t);     /* mbias installs no constructor/destructor (MBias.c:158-161) */
             t->next = next; it->tail = next;
         }
     } else it->is_eof = 1;
@@ -823,7 +823,7 @@ static pileup1 *plp_next(plp_t *it, int *_tid, int32_t *_pos, int *_n_plp) {
         while(*pptr != it->tail) {
             lbnode *p = *pptr;
             if(p->b.r->tid < it->tid || (p->b.r->tid == it->tid && p->end <= it->pos)) {
-                custom_overlap_destructor(it->oh, p);
+                if(it->oh) custom_overlap_destructor(it->oh, p);
                 *pptr = p->next; node_free(p);
             } else {
                 if(p->b.r->tid == it->tid && p->beg <= it->pos) {
@@ -1323,11 +1323,467 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
     return 0;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* MBias.c + svg.c restated (`mbias`).  The reference's tests hold no expectation for this       */
+/* command: parity for mbias is UNPINNED by the reference and rests on this restatement alone.  */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int32_t l, m; uint32_t *unmeth1, *unmeth2, *meth1, *meth2; } strandMeth;      /* MethylDackel.h:171-176 */
+#define kroundup32_(x) (--(x), (x) |= (x) >> 1, (x) |= (x) >> 2, (x) |= (x) >> 4, (x) |= (x) >> 8, (x) |= (x) >> 16, ++(x))
+
+static strandMeth *growStrandMeth(strandMeth *s, int32_t l) {   /* MBias.c:16-40 */
+    int32_t m; int i;
+    l++;
+    m = l; kroundup32_(m);
+    if(m < 32) m = 32;
+    s->unmeth1 = xrealloc(s->unmeth1, sizeof(uint32_t) * (size_t)m);
+    s->meth1 = xrealloc(s->meth1, sizeof(uint32_t) * (size_t)m);
+    s->unmeth2 = xrealloc(s->unmeth2, sizeof(uint32_t) * (size_t)m);
+    s->meth2 = xrealloc(s->meth2, sizeof(uint32_t) * (size_t)m);
+    for(i = s->m; i < m; i++) { s->unmeth1[i] = 0; s->meth1[i] = 0; s->unmeth2[i] = 0; s->meth2[i] = 0; }
+    s->m = m;
+    return s;
+}
+static strandMeth *mergeStrandMeth(strandMeth *target, strandMeth *source) {   /* MBias.c:42-55 */
+    int32_t i;
+    if(source->l == 0) return target;
+    if(target->m < source->l) target = growStrandMeth(target, source->m);
+    if(target->l < source->l) target->l = source->l;
+    for(i = 0; i < source->l; i++) {
+        target->unmeth1[i] += source->unmeth1[i]; target->meth1[i] += source->meth1[i];
+        target->unmeth2[i] += source->unmeth2[i]; target->meth2[i] += source->meth2[i];
+    }
+    return target;
+}
+
+/* extractMBias (MBias.c:57-230).  A contig missing from the FASTA makes the reference's worker return NULL, which
+ * mbias_main then dereferences (MBias.c:150-155,543-546); here that is a fatal error. */
+static strandMeth **extractMBias(Config *config, const bamfile *bf, const fasta *fa) {
+    int tid = 0, i, seqlen, rv, n_plp, strand, o = 0; int32_t pos = 0, bedIdx = 0;
+    pileup1 *plp; char *seq = NULL, base;
+    strandMeth **meths = xmalloc(4 * sizeof(strandMeth *));
+    uint32_t localPos = 0, localEnd = 0, localTid = 0; mplp_data data;
+    for(i = 0; i < 4; i++) meths[i] = calloc(1, sizeof(strandMeth));
+    memset(&data, 0, sizeof(data)); data.config = config; data.bf = bf; data.bedIdx = bedIdx;
+
+    while(1) {
+        plp_t iter;
+        localTid = globalTid; localPos = globalPos;
+        localEnd = (uint32_t)(localPos + config->chunkSize);
+        if(localTid >= (uint32_t)bf->n_targets) break;
+        if(globalEnd && localEnd > globalEnd) localEnd = globalEnd;
+        adjustBounds(bf, fa, &localTid, &localPos, &localEnd);
+        globalPos = localEnd;
+        if(globalEnd > 0 && globalPos >= globalEnd) globalTid = (uint32_t)-1;
+        if(localTid < (uint32_t)bf->n_targets && globalTid != (uint32_t)-1) {
+            if(globalPos >= bf->target_len[localTid]) { localEnd = bf->target_len[localTid]; globalTid++; globalPos = 0; }
+        }
+        if(config->bed) { if(spanOverlapsBED((int32_t)localTid, (int32_t)localPos, (int32_t)localEnd, config->bed, &bedIdx) != 1) continue; }
+        if(localTid >= (uint32_t)bf->n_targets) break;
+        if(globalEnd && localPos >= globalEnd) break;
+        regitr_init(&data.iter, bf, (int32_t)localTid, (int32_t)localPos, (int32_t)localEnd);
+        seq = fetch_seq(fa, bf->target_name[localTid], (int)localPos, (int)localEnd, &seqlen);      /* NB no 2-base lead-in, 1 base past the end */
+        if(seqlen < 0) {
+            fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", seqlen, bf->target_name[localTid], localPos, localEnd);
+            fprintf(stderr, "Note that the output will be truncated!\n");
+            exit(3);
+        }
+        data.seq = seq; data.lseq = seqlen; data.offset = localPos;
+        plp_init(&iter, &data, NULL);
+        while((plp = plp_auto(&iter, &tid, &pos, &n_plp)) != NULL) {
+            if((uint32_t)pos < localPos || (uint32_t)pos >= localEnd) continue;
+            if(config->bed) {
+                while((o = posOverlapsBED(tid, pos, config->bed, bedIdx)) == -1) bedIdx++;
+                if(o == 0) continue;
+            }
+            if(isCpG(seq, pos - localPos, seqlen)) { if(!config->keepCpG) continue; }
+            else if(isCHG(seq, pos - localPos, seqlen)) { if(!config->keepCHG) continue; }
+            else if(isCHH(seq, pos - localPos, seqlen)) { if(!config->keepCHH) continue; }
+            else continue;
+            base = seq[pos - localPos];
+            for(i = 0; i < n_plp; i++) {
+                if(plp[i].is_del) continue;
+                if(plp[i].is_refskip) continue;
+                if(config->bed) if(!readStrandOverlapsBED(plp[i].b->r, config->bed->region[bedIdx])) continue;
+                strand = getStrand(plp[i].b->r);
+                if(strand & 1) { if(base != 'C' && base != 'c') continue; }
+                else { if(base != 'G' && base != 'g') continue; }
+                rv = methState(config, plp[i].b, plp[i].qpos);
+                if(rv != 0) {
+                    int32_t qpos = plp[i].qpos; strandMeth *sm;
+                    if(qpos >= meths[strand - 1]->m) meths[strand - 1] = growStrandMeth(meths[strand - 1], qpos);
+                    sm = meths[strand - 1];
+                    if(rv < 0) { if(plp[i].b->r->flag & 0x80) sm->unmeth2[qpos]++; else sm->unmeth1[qpos]++; }
+                    else { if(plp[i].b->r->flag & 0x80) sm->meth2[qpos]++; else sm->meth1[qpos]++; }
+                    if(qpos + 1 > sm->l) sm->l = qpos + 1;
+                }
+            }
+        }
+        free(seq);
+        plp_destroy(&iter);
+    }
+    return meths;
+}
+
+/* svg.c:8-27  Agresti-Coull interval */
+static double CI(uint32_t um, uint32_t m, int which) {
+    double ZZ, Z, N_dot, P_dot, X, N, rv;
+    X = (double)m; N = (double)(m + um);
+    ZZ = 10.8275661707; Z = 3.2905267315;
+    N_dot = N + ZZ;
+    P_dot = (1.0 / N_dot) * (X + 0.5 * ZZ);
+    if(which) { rv = P_dot + Z * sqrt((P_dot / N_dot) * (1 - P_dot)); if(rv > 1.) rv = 1.0; }
+    else { rv = P_dot - Z * sqrt((P_dot / N_dot) * (1 - P_dot)); if(rv < 0.) rv = 0.0; }
+    return rv;
+}
+static double getMaxY(strandMeth *m) {   /* svg.c:29-55 */
+    double maximum = 0.0, val; int i;
+    for(i = 0; i < m->l; i++) {
+        if(m->meth1[i] + m->unmeth1[i]) { val = CI(m->unmeth1[i], m->meth1[i], 1); maximum = (val > maximum) ? val : maximum; }
+        if(m->meth2[i] + m->unmeth2[i]) { val = CI(m->unmeth2[i], m->meth2[i], 1); maximum = (val > maximum) ? val : maximum; }
+    }
+    maximum += 0.03;
+    if(5 * (((int)ceil(100 * maximum)) / 5) - (int)ceil(100 * maximum)) maximum = (1 + ((int)ceil(100 * maximum)) / 5) * 0.05;
+    else maximum = ((int)ceil(100 * maximum) / 5) * 0.05;
+    if(maximum > 0.8) maximum = 1.0;
+    assert(maximum > 0.0);
+    return maximum;
+}
+static double getMinY(strandMeth *m) {   /* svg.c:57-79 */
+    double minimum = 1.0, val; int i;
+    for(i = 0; i < m->l; i++) {
+        if(m->meth1[i] + m->unmeth1[i]) { val = CI(m->unmeth1[i], m->meth1[i], 0); minimum = (val < minimum) ? val : minimum; }
+        if(m->meth2[i] + m->unmeth2[i]) { val = CI(m->unmeth2[i], m->meth2[i], 0); minimum = (val < minimum) ? val : minimum; }
+    }
+    minimum -= 0.03;
+    minimum = 0.01 * (5 * (((int)(100 * minimum)) / 5));
+    if(minimum < 0.2) minimum = 0.0;
+    assert(minimum < 1.0);
+    return minimum;
+}
+static int getMinX(strandMeth *m, int which) {   /* svg.c:81-91 */
+    int i;
+    for(i = 0; i < m->l; i++) {
+        if(which == 1) { if(m->unmeth1[i] + m->meth1[i]) return i; }
+        else { if(m->unmeth2[i] + m->meth2[i]) return i; }
+    }
+    return m->l;
+}
+static int getMaxX(strandMeth *m) {   /* svg.c:93-107; its i>=0 test is always true */
+    int i;
+    for(i = m->l; i > 0; i--) {
+        if(m->unmeth1[i - 1] + m->meth1[i - 1]) break;
+        if(m->unmeth2[i - 1] + m->meth2[i - 1]) break;
+    }
+    if(i % 5) i += 5 - (i % 5);
+    return i;
+}
+static int *getXTicks(int maxX, int *n) {   /* svg.c:109-149: every else-if repeats the first test, so the span is 5 or 10 */
+    int *o, maxN = 7, i, span = 5;
+    *n = maxX / 5;
+    if(*n > maxN) { span = 10; *n = maxX / span; }
+    o = xmalloc((size_t)(*n) * sizeof(int));
+    for(i = 0; i < *n; i++) o[i] = (i + 1) * span;
+    return o;
+}
+static double *getYTicks(double minY, double maxY, int *n) {   /* svg.c:151-164 */
+    double *o, span = maxY - minY; int i;
+    *n = (int)(1 + ceil(span / 0.05));
+    if(span < 0.05) *n = 2;
+    o = xmalloc(sizeof(double) * (size_t)(*n));
+    for(i = 0; i < *n; i++) o[i] = 0.05 * i + minY;
+    return o;
+}
+static double remapY(double orig, double minY, double maxY, int buffer, int dim) { return buffer + dim - ((double)dim) * (orig - minY) / (maxY - minY); }   /* svg.c:166-168 */
+static double remapX(int orig, int maxX, int buffer, int dim) { return buffer + ((double)dim) * orig / ((double)maxX); }   /* svg.c:170-172 */
+
+/* svg.c:174-203.  The loops run to i == m->l inclusive; in the reference that element exists and is zero (the merged
+ * arrays are grown past the per-thread capacity, MBias.c:45), which is what the arrays here guarantee too. */
+static void plotCI(FILE *of, int minX, int maxX, strandMeth *m, int which, const char *col, int buffer, int dim, double minY, double maxY) {
+    uint32_t *meth, *umeth; int32_t i; double val;
+    if(which == 1) { meth = m->meth1; umeth = m->unmeth1; } else { meth = m->meth2; umeth = m->unmeth2; }
+    val = CI(umeth[minX], meth[minX], 0);
+    fprintf(of, "<path d=\"M %f %f\n", remapX(minX + 1, maxX, buffer, dim), remapY(val, minY, maxY, buffer, dim));
+    for(i = minX + 1; i <= m->l; i++) {
+        if(meth[i] || umeth[i]) { val = CI(umeth[i], meth[i], 0); fprintf(of, "  L %f %f\n", remapX(i + 1, maxX, buffer, dim), remapY(val, minY, maxY, buffer, dim)); }
+    }
+    for(i = m->l - 1; i >= 0; i--) {
+        if(meth[i] || umeth[i]) { val = CI(umeth[i], meth[i], 1); fprintf(of, "  L %f %f\n", remapX(i + 1, maxX, buffer, dim), remapY(val, minY, maxY, buffer, dim)); }
+    }
+    fprintf(of, "Z\" fill=\"%s\" fill-opacity=\"0.2\"/>\n", col);
+}
+static void plotVals(FILE *of, int minX, int maxX, strandMeth *m, int which, const char *col, int buffer, int dim, double minY, double maxY) {   /* svg.c:205-228 */
+    uint32_t *meth, *umeth; int32_t i; double val;
+    if(which == 1) { meth = m->meth1; umeth = m->unmeth1; } else { meth = m->meth2; umeth = m->unmeth2; }
+    assert(minX >= 0);
+    val = meth[minX] / ((double)(meth[minX] + umeth[minX]));
+    fprintf(of, "<path d=\"M %f %f\n", remapX(minX + 1, maxX, buffer, dim), remapY(val, minY, maxY, buffer, dim));
+    for(i = minX + 1; i <= m->l; i++) {
+        if(meth[i] || umeth[i]) { val = meth[i] / ((double)(meth[i] + umeth[i])); fprintf(of, "  L %f %f\n", remapX(i + 1, maxX, buffer, dim), remapY(val, minY, maxY, buffer, dim)); }
+    }
+    fprintf(of, "\" stroke=\"%s\" stroke-width=\"2\" fill-opacity=\"0\"/>\n", col);
+}
+static void getThresholds(strandMeth *m, int which, int *lthresh, int *rthresh) {   /* svg.c:239-294 */
+    uint32_t *meth, *umeth; int i, total = 0, middle = m->l / 2;
+    double average = 0.0, minCI = 1.0, maxCI = 0.0, tmp, tmp2;
+    if(which == 1) { meth = m->meth1; umeth = m->unmeth1; } else { meth = m->meth2; umeth = m->unmeth2; }
+    for(i = (int)(0.2 * m->l); i <= (int)(0.8 * m->l); i++) {
+        if(meth[i] || umeth[i]) {
+            total++;
+            average += ((double)meth[i]) / ((double)(meth[i] + umeth[i]));
+            tmp = CI(umeth[i], meth[i], 1); if(minCI > tmp) minCI = tmp;
+            tmp = CI(umeth[i], meth[i], 0); if(maxCI < tmp) maxCI = tmp;
+        }
+    }
+    if(total) average /= total;
+    else { *lthresh = 0; *rthresh = 0; return; }
+    for(i = middle; i >= 0; i--) {
+        if(meth[i] || umeth[i]) {
+            tmp = ((double)meth[i]) / ((double)(meth[i] + umeth[i]));
+            tmp2 = CI(umeth[i], meth[i], 1);
+            if(tmp2 < average && tmp < minCI && fabs(tmp - average) > 0.05) break;
+            tmp2 = CI(umeth[i], meth[i], 0);
+            if(tmp2 > average && tmp > maxCI && fabs(tmp - average) > 0.05) break;
+        }
+    }
+    if(i >= 0) *lthresh = i + 2; else *lthresh = 0;
+    for(i = middle + 1; i < m->l; i++) {
+        if(meth[i] || umeth[i]) {
+            tmp = ((double)meth[i]) / ((double)(meth[i] + umeth[i]));
+            tmp2 = CI(umeth[i], meth[i], 1);
+            if(tmp2 < average && tmp < minCI && fabs(tmp - average) > 0.05) break;
+            tmp2 = CI(umeth[i], meth[i], 0);
+            if(tmp2 > average && tmp > maxCI && fabs(tmp - average) > 0.05) break;
+        }
+    }
+    if(i < m->l) *rthresh = i; else *rthresh = 0;
+}
+static void makeSVGs(char *opref, strandMeth **meths, int which) {   /* svg.c:300-437 */
+    double minY = 1.0, maxY = 0.0; int minX1 = -1, minX2 = -1, maxX = 0, hasRead1 = 0, hasRead2 = 0;
+    int i, j, buffer = 80, dim = 500, nXTicks, nYTicks;
+    char *oname = xmalloc(strlen(opref) + strlen("_CTOT.svg "));
+    const char *titles[4] = {"Original Top", "Original Bottom", "Complementary to the Original Top", "Complementary to the Original Bottom"};
+    const char *abbrevs[4] = {"OT", "OB", "CTOT", "CTOB"};
+    const char *col1 = "rgb(248,118,109)", *col2 = "rgb(0,191,196)";
+    FILE *of; double *yTicks; int *xTicks, lthresh1, lthresh2, rthresh1, rthresh2; int alreadyPrinting = 0, doingLabel = 0;
+    for(i = 0; i < 4; i++) {
+        if(meths[i]->l) {
+            minY = getMinY(meths[i]); maxY = getMaxY(meths[i]);
+            minX1 = getMinX(meths[i], 1); minX2 = getMinX(meths[i], 2);
+            maxX = getMaxX(meths[i]);
+            xTicks = getXTicks(maxX, &nXTicks); yTicks = getYTicks(minY, maxY, &nYTicks);
+            sprintf(oname, "%s_%s.svg", opref, abbrevs[i]);
+            of = fopen(oname, "w");
+            if(!of) { fprintf(stderr, "mdk_oracle: cannot write %s\n", oname); exit(3); }
+            fprintf(of, "<svg height=\"%i\" width=\"%i\"\n", dim + 2 * buffer, dim + 2 * buffer);
+            fprintf(of, "    xmlns=\"http://www.w3.org/2000/svg\"\n");
+            fprintf(of, "    xmlns:xlink=\"http://www.w3.org/1999/xlink\"\n");
+            fprintf(of, "    xmlns:ev=\"http://www.w3.org/2001/xml-events\">\n");
+            fprintf(of, "<title>%s Strand</title>\n", titles[i]);
+            fprintf(of, "<rect x=\"0\" y=\"0\" width=\"%i\" height=\"%i\" fill=\"white\" />\n", dim + 2 * buffer, dim + 2 * buffer);
+            fprintf(of, "<text x=\"%i\" y=\"%i\" text-anchor=\"middle\">%s Strand</text>\n", buffer + (dim >> 1), 20, titles[i]);
+            fprintf(of, "<line x1=\"%i\" y1=\"%i\" x2=\"%i\" y2=\"%i\" stroke=\"black\" />\n", buffer, buffer, buffer, buffer + dim);
+            fprintf(of, "<line x1=\"%i\" y1=\"%i\" x2=\"%i\" y2=\"%i\" stroke=\"black\" />\n", buffer, buffer + dim, buffer + dim, buffer + dim);
+            fprintf(of, "<text x=\"15\" y=\"%i\" transform=\"rotate(270 15, %i)\" text-anchor=\"middle\" dominant-baseline=\"text-before-edge\">", buffer + (dim >> 1), buffer + (dim >> 1));
+            doingLabel = 0;
+            if(which & 1) { doingLabel = 1; fprintf(of, "CpG"); }
+            if(which & 2) { if(doingLabel) fprintf(of, "/CHG"); else fprintf(of, "CHG"); doingLabel = 1; }
+            if(which & 4) { if(doingLabel) fprintf(of, "/CHH"); else fprintf(of, "CHH"); doingLabel = 1; }
+            if(doingLabel) fprintf(of, " ");
+            fprintf(of, "Methylation %%</text>\n");
+            fprintf(of, "<text x=\"%i\" y=\"%i\" text-anchor=\"middle\">Position along mapped read (5'->3' of + strand)</text>\n", buffer + (dim >> 1), buffer + dim + 40);
+            fprintf(of, "<line x1=\"%i\" y1=\"%i\" x2=\"%i\" y2=\"%i\" stroke=\"black\" />\n", buffer, buffer + dim, buffer, buffer + dim + 5);
+            fprintf(of, "<text x=\"%i\" y=\"%i\" text-anchor=\"middle\">%i</text>\n", buffer, buffer + dim + 20, 0);
+            for(j = 0; j < nXTicks; j++) {
+                fprintf(of, "<line x1=\"%f\" y1=\"%i\" x2=\"%f\" y2=\"%i\" stroke-dasharray=\"5 5\" stroke=\"grey\" />\n", remapX(xTicks[j], maxX, buffer, dim), buffer, remapX(xTicks[j], maxX, buffer, dim), buffer + dim);
+                fprintf(of, "<line x1=\"%f\" y1=\"%i\" x2=\"%f\" y2=\"%i\" stroke=\"black\" />\n", remapX(xTicks[j], maxX, buffer, dim), buffer + dim, remapX(xTicks[j], maxX, buffer, dim), buffer + dim + 5);
+                fprintf(of, "<text x=\"%f\" y=\"%i\" text-anchor=\"middle\">%i</text>\n", remapX(xTicks[j], maxX, buffer, dim), buffer + dim + 20, xTicks[j]);
+            }
+            for(j = 0; j < nYTicks; j++) {
+                fprintf(of, "<line x1=\"%i\" y1=\"%f\" x2=\"%i\" y2=\"%f\" stroke=\"black\" />\n", buffer, remapY(yTicks[j], minY, maxY, buffer, dim), buffer - 5, remapY(yTicks[j], minY, maxY, buffer, dim));
+                fprintf(of, "<text x=\"%i\" y=\"%f\" text-anchor=\"middle\" dominant-baseline=\"middle\">%4.2f</text>\n", buffer - 25, remapY(yTicks[j], minY, maxY, buffer, dim), yTicks[j]);
+            }
+            for(j = 0; j < meths[i]->l; j++) {
+                if(meths[i]->unmeth1[j] + meths[i]->meth1[j]) hasRead1 = 1;
+                if(meths[i]->unmeth2[j] + meths[i]->meth2[j]) hasRead2 = 1;
+                if(hasRead1 && hasRead2) break;
+            }
+            if(hasRead1) plotCI(of, minX1, maxX, meths[i], 1, col1, buffer, dim, minY, maxY);
+            if(hasRead2) plotCI(of, minX2, maxX, meths[i], 2, col2, buffer, dim, minY, maxY);
+            if(hasRead1) plotVals(of, minX1, maxX, meths[i], 1, col1, buffer, dim, minY, maxY);
+            if(hasRead2) plotVals(of, minX2, maxX, meths[i], 2, col2, buffer, dim, minY, maxY);
+            getThresholds(meths[i], 1, &lthresh1, &rthresh1);
+            getThresholds(meths[i], 2, &lthresh2, &rthresh2);
+            if(lthresh1 + lthresh2 + rthresh1 + rthresh2) {
+                fprintf(of, "<text x=\"%i\" y=\"%i\" text-anchor=\"end\">--%s %i,%i,%i,%i</text>\n", 2 * buffer + dim - 10, 2 * buffer + dim - 10, abbrevs[i], lthresh1, rthresh1, lthresh2, rthresh2);
+                if(lthresh1) fprintf(of, "<line x1=\"%f\" y1=\"%i\" x2=\"%f\" y2=\"%i\" stroke-dasharray=\"5 1\" stroke=\"%s\" stroke-width=\"1\" />\n", remapX(lthresh1, maxX, buffer, dim), dim + buffer, remapX(lthresh1, maxX, buffer, dim), buffer, col1);
+                if(rthresh1) fprintf(of, "<line x1=\"%f\" y1=\"%i\" x2=\"%f\" y2=\"%i\" stroke-dasharray=\"5 1\" stroke=\"%s\" stroke-width=\"1\" />\n", remapX(rthresh1, maxX, buffer, dim), dim + buffer, remapX(rthresh1, maxX, buffer, dim), buffer, col1);
+                if(lthresh2) fprintf(of, "<line x1=\"%f\" y1=\"%i\" x2=\"%f\" y2=\"%i\" stroke-dasharray=\"5 1\" stroke=\"%s\" stroke-width=\"1\" />\n", remapX(lthresh2, maxX, buffer, dim), dim + buffer, remapX(lthresh2, maxX, buffer, dim), buffer, col2);
+                if(rthresh2) fprintf(of, "<line x1=\"%f\" y1=\"%i\" x2=\"%f\" y2=\"%i\" stroke-dasharray=\"5 1\" stroke=\"%s\" stroke-width=\"1\" />\n", remapX(rthresh2, maxX, buffer, dim), dim + buffer, remapX(rthresh2, maxX, buffer, dim), buffer, col2);
+            }
+            if(hasRead1) {
+                fprintf(of, "<rect x=\"%i\" y=\"%i\" width=\"20\" height=\"20\" fill=\"%s\" />\n", dim + buffer + 10, (dim >> 1) + buffer - 20, col1);
+                fprintf(of, "<text x=\"%i\" y=\"%i\" text-anchor=\"start\" dominant-baseline=\"middle\">#1</text>\n", dim + buffer + 35, (dim >> 1) + buffer - 10);
+            }
+            if(hasRead2) {
+                fprintf(of, "<rect x=\"%i\" y=\"%i\" width=\"20\" height=\"20\" fill=\"%s\" />\n", dim + buffer + 10, (dim >> 1) + buffer, col2);
+                fprintf(of, "<text x=\"%i\" y=\"%i\" text-anchor=\"start\" dominant-baseline=\"middle\">#2</text>\n", dim + buffer + 35, (dim >> 1) + buffer + 10);
+            }
+            fprintf(of, "</svg>\n");
+            if(!alreadyPrinting) fprintf(stderr, "Suggested inclusion options:");
+            fprintf(stderr, " --%s %i,%i,%i,%i", abbrevs[i], lthresh1, rthresh1, lthresh2, rthresh2);
+            alreadyPrinting = 1;
+            fclose(of); free(xTicks); free(yTicks);
+            hasRead1 = 0; hasRead2 = 0;
+        }
+    }
+    if(alreadyPrinting) fprintf(stderr, "\n");
+    free(oname);
+}
+static void makeTXT(strandMeth **m) {   /* svg.c:439-454 */
+    const char *abbrevs[4] = {"OT", "OB", "CTOT", "CTOB"}; int i, j;
+    printf("Strand\tRead\tPosition\tnMethylated\tnUnmethylated\n");
+    for(i = 0; i < 4; i++) {
+        if(m[i]->l) {
+            for(j = 0; j < m[i]->l; j++) {
+                if(m[i]->meth1[j] || m[i]->unmeth1[j]) printf("%s\t1\t%i\t%" PRIu32 "\t%" PRIu32 "\n", abbrevs[i], j + 1, m[i]->meth1[j], m[i]->unmeth1[j]);
+                if(m[i]->meth2[j] || m[i]->unmeth2[j]) printf("%s\t2\t%i\t%" PRIu32 "\t%" PRIu32 "\n", abbrevs[i], j + 1, m[i]->meth2[j], m[i]->unmeth2[j]);
+            }
+        }
+    }
+}
+static void mbias_usage(void) { fprintf(stderr, "\nUsage: mdk_oracle mbias [OPTIONS] <ref.fa> <sorted_alignments.bam> <output.prefix>\n"); }
+
+static int mbias_main(int argc, char *argv[]) {                /* MBias.c:308-573 */
+    char *opref = NULL, *bedName = NULL; int c, i, j, SVG = 1, txt = 0, keepStrand = 0;
+    strandMeth *meths[4], **threadout = NULL; Config config; bamfile bf; fasta fa;
+    static struct option lopts[] = {
+        {"noCpG", 0, NULL, 1}, {"CHG", 0, NULL, 2}, {"CHH", 0, NULL, 3}, {"keepDupes", 0, NULL, 4}, {"keepSingleton", 0, NULL, 5},
+        {"keepDiscordant", 0, NULL, 6}, {"txt", 0, NULL, 7}, {"noSVG", 0, NULL, 8}, {"nOT", 1, NULL, 9}, {"nOB", 1, NULL, 10},
+        {"nCTOT", 1, NULL, 11}, {"nCTOB", 1, NULL, 12}, {"chunkSize", 1, NULL, 13}, {"keepStrand", 0, NULL, 14},
+        {"minConversionEfficiency", 1, NULL, 15}, {"ignoreNH", 0, NULL, 16}, {"ignoreFlags", 1, NULL, 'F'}, {"requireFlags", 1, NULL, 'R'},
+        {"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {0, 0, NULL, 0}};
+    memset(&config, 0, sizeof(config));
+    config.keepCpG = 1; config.keepCHG = 0; config.keepCHH = 0;
+    config.minMapq = 10; config.minPhred = 5; config.keepDupes = 0;
+    config.keepSingleton = 0; config.keepDiscordant = 0;
+    config.filterMappability = 0; config.ignoreNH = 0;
+    config.reg = NULL; config.bed = NULL;
+    config.ignoreFlags = 0xF00; config.requireFlags = 0;
+    config.nThreads = 1; config.chunkSize = 1000000; config.minConversionEfficiency = 0.0;
+    for(i = 0; i < 16; i++) config.bounds[i] = 0;
+    for(i = 0; i < 16; i++) config.absoluteBounds[i] = 0;
+    optind = 1;
+    while((c = getopt_long(argc, argv, "hvq:p:r:l:D:F:@:", lopts, NULL)) >= 0) {
+        switch(c) {
+        case 'h': mbias_usage(); return 0;
+        case 'v': printf("%s (using HTSlib version %s)\n", ORACLE_VERSION, "none: mdk_oracle"); return 0;
+        case 'D': break;
+        case 'r': config.reg = optarg; break;
+        case 'l': bedName = optarg; break;
+        case 1: config.keepCpG = 0; break;
+        case 2: config.keepCHG = 1; break;
+        case 3: config.keepCHH = 1; break;
+        case 4: config.keepDupes = 1; break;
+        case 5: config.keepSingleton = 1; break;
+        case 6: config.keepDiscordant = 1; break;
+        case 7: txt = 1; break;
+        case 8: SVG = 0; txt = 1; break;
+        case 9: parseBounds(optarg, config.absoluteBounds, 0); break;
+        case 10: parseBounds(optarg, config.absoluteBounds, 1); break;
+        case 11: parseBounds(optarg, config.absoluteBounds, 2); break;
+        case 12: parseBounds(optarg, config.absoluteBounds, 3); break;
+        case 13:
+            config.chunkSize = strtoul(optarg, NULL, 10);
+            if(config.chunkSize < 1) { fprintf(stderr, "Error: The chunk size must be at least 1!\n"); return 1; }
+            break;
+        case 14: keepStrand = 1; break;
+        case 15: config.minConversionEfficiency = (float)atof(optarg); break;
+        case 16: config.ignoreNH = 1; break;
+        case 'F': config.ignoreFlags = atoi(optarg); break;
+        case 'R': config.requireFlags = atoi(optarg); break;
+        case 'q': config.minMapq = atoi(optarg); break;
+        case 'p': config.minPhred = atoi(optarg); break;
+        case '@': config.nThreads = atoi(optarg); break;
+        default: fprintf(stderr, "Invalid option '%c'\n", c); mbias_usage(); return 1;
+        }
+    }
+    if(argc == 1) { mbias_usage(); return 0; }
+    if((SVG && argc - optind != 3) || (!SVG && argc - optind < 2)) {
+        fprintf(stderr, "You must supply a reference genome in fasta format, an input BAM file, and an output prefix!!!\n");
+        mbias_usage(); return -1;
+    }
+    if(config.minPhred < 1) { fprintf(stderr, "-p %i is invalid. resetting to 1, which is the lowest possible value.\n", config.minPhred); config.minPhred = 1; }
+    if(config.minMapq < 0) { fprintf(stderr, "-q %i is invalid. Resetting to 0, which is the lowest possible value.\n", config.minMapq); config.minMapq = 0; }
+    if(!(config.keepCpG + config.keepCHG + config.keepCHH)) {
+        fprintf(stderr, "You haven't specified any metrics to output!\nEither don't use the --noCpG option or specify --CHG and/or --CHH.\n");
+        return -1;
+    }
+    if(bam_load(argv[optind + 1], &bf) != 0) { fprintf(stderr, "Couldn't open %s for reading!\n", argv[optind + 1]); return -4; }
+    if(fasta_load(argv[optind], &fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", argv[optind]); return -4; }
+    if(SVG) opref = argv[optind + 2];
+    globalTid = 0; globalPos = 0; globalEnd = 0;
+    if(config.reg) {
+        const char *foo; char *bar; int s = 0, e = 0;
+        foo = parse_reg(config.reg, &s, &e);
+        if(foo == NULL) { fprintf(stderr, "Could not parse the specified region!\n"); return -4; }
+        bar = xmalloc((size_t)(foo - config.reg) + 1);
+        strncpy(bar, config.reg, (size_t)(foo - config.reg)); bar[foo - config.reg] = 0;
+        globalTid = (uint32_t)-1;
+        for(i = 0; i < bf.n_targets; i++) if(!strcmp(bf.target_name[i], bar)) { globalTid = (uint32_t)i; break; }
+        if(globalTid == (uint32_t)-1) { fprintf(stderr, "%s did not match a known chromosome/contig name!\n", config.reg); return -6; }
+        if(s > 0) globalPos = (uint32_t)s;
+        if(e > 0) globalEnd = (uint32_t)e;
+        if(globalEnd > bf.target_len[globalTid]) globalEnd = bf.target_len[globalTid];
+        free(bar);
+    }
+    if(bedName) {
+        config.bed = parseBED(bedName, &bf, keepStrand);
+        if(!config.bed) { fprintf(stderr, "There was an error while reading in your BED file!\n"); return 1; }
+    }
+    for(i = 0; i < 4; i++) meths[i] = calloc(1, sizeof(strandMeth));
+    threadout = extractMBias(&config, &bf, &fa);           /* one worker */
+    for(j = 0; j < 4; j++) {
+        meths[j] = mergeStrandMeth(meths[j], threadout[j]);
+        free(threadout[j]->meth1); free(threadout[j]->unmeth1); free(threadout[j]->meth2); free(threadout[j]->unmeth2); free(threadout[j]);
+    }
+    free(threadout);
+    if(SVG) makeSVGs(opref, meths, config.keepCpG + 2 * config.keepCHG + 4 * config.keepCHH);
+    if(txt) makeTXT(meths);
+    for(i = 0; i < 4; i++) { free(meths[i]->meth1); free(meths[i]->unmeth1); free(meths[i]->meth2); free(meths[i]->unmeth2); free(meths[i]); }
+    return 0;
+}
+
+
+/* test driver: `mdk_oracle mbias-report <prefix> <which>` plots a --txt table read from stdin (makeSVGs + makeTXT on
+ * hand-made histograms; the arrays go through the same per-thread -> merged growth as in mbias_main) */
+static int mbias_report_main(int argc, char *argv[]) {
+    static const char *abbrevs[4] = {"OT", "OB", "CTOT", "CTOB"};
+    strandMeth *meths[4], *src[4]; char line[256], name[16]; int i, r, q; unsigned m, u;
+    if(argc != 3) { fprintf(stderr, "usage: mdk_oracle mbias-report <prefix> <which> < table\n"); return 1; }
+    for(i = 0; i < 4; i++) { meths[i] = calloc(1, sizeof(strandMeth)); src[i] = calloc(1, sizeof(strandMeth)); }
+    while(fgets(line, sizeof(line), stdin)) {
+        if(sscanf(line, "%15s %d %d %u %u", name, &r, &q, &m, &u) != 5) continue;
+        for(i = 0; i < 4; i++) if(!strcmp(name, abbrevs[i])) break;
+        if(i == 4 || q < 1 || (r != 1 && r != 2)) continue;
+        q--;
+        if(q >= src[i]->m) src[i] = growStrandMeth(src[i], q);
+        if(r == 1) { src[i]->meth1[q] = m; src[i]->unmeth1[q] = u; } else { src[i]->meth2[q] = m; src[i]->unmeth2[q] = u; }
+        if(q + 1 > src[i]->l) src[i]->l = q + 1;
+    }
+    for(i = 0; i < 4; i++) meths[i] = mergeStrandMeth(meths[i], src[i]);
+    makeSVGs(argv[1], meths, atoi(argv[2]));
+    makeTXT(meths);
+    return 0;
+}
+
 #ifndef MDK_ORACLE_NO_MAIN
 int main(int argc, char *argv[]) {                             /* main.c:39-62 */
     if(argc == 1) { fprintf(stderr, "mdk_oracle: CPU oracle for `MethylDackel extract`\nUsage: mdk_oracle extract [options] ref.fa aln.bam\n"); return 0; }
     if(strcmp(argv[1], "-v") == 0 || strcmp(argv[1], "--version") == 0) { printf("%s (using HTSlib version %s)\n", ORACLE_VERSION, "none: mdk_oracle"); return 0; }
     if(strcmp(argv[1], "extract") == 0) return extract_main(argc - 1, argv + 1);
+    if(strcmp(argv[1], "mbias") == 0) return mbias_main(argc - 1, argv + 1);
+    if(strcmp(argv[1], "mbias-report") == 0) return mbias_report_main(argc - 1, argv + 1);
     fprintf(stderr, "Unknown command!\n");
     return -1;
 }

@@ -137,3 +137,55 @@ def eval_batch(batch, ref: bytes, cfg, runs=None):
                     e[4] += 1
                     e[5] += (b not in (4, 15)) if odd else (b not in (2, 15))
     return {p: tuple(v) for p, v in out.items() if v[2] + v[3] > 0 or v[4] > 0}
+
+
+def mbias_context(ref, p, beg, end, keep):
+    """context as mbias sees it: classified inside the chunk's own window [beg, min(end, len-1)] (MBias.c:147,172-180)"""
+    lo, hi = beg, min(end, len(ref) - 1)          # inclusive window
+    c = ref[p] & 0x5F
+    if c == 0x43:
+        isg = 0
+        t = 0 if (p + 1 <= hi and ref[p + 1] & 0x5F == 0x47) else 1 if (p + 2 <= hi and ref[p + 2] & 0x5F == 0x47) else 2
+    elif c == 0x47:
+        isg = 1
+        t = 0 if (p - 1 >= lo and ref[p - 1] & 0x5F == 0x43) else 1 if (p - 2 >= lo and ref[p - 2] & 0x5F == 0x43) else 2
+    else:
+        return None
+    return (t, isg) if keep[t] else None
+
+
+def eval_mbias(batch, ref: bytes, cfg, runs=None, hist=None):
+    """adds the batch's calls to hist {(strand, read#, q): [meth, unmeth]} (no mate-overlap handling: MBias.c:158-161)"""
+    keep = (cfg.keepCpG, cfg.keepCHG, cfg.keepCHH)
+    hist = {} if hist is None else hist
+    pay = {}
+    for i in range(batch.n_segs):
+        g = batch.seg[i]
+        strand, read2, partner = g.sf & 7, bool(g.sf & 8), bool(g.sf & 32)
+        assert not partner, "mbias batches must be built without pairing"
+        k = (g.off4, g.l_qseq, strand, read2)
+        if k not in pay:
+            pay[k] = Payload(batch, g.off4, g.l_qseq, strand, read2, cfg)
+        o = pay[k]
+        odd = strand & 1
+        for j in range(g.len):
+            p = g.rpos + j
+            if p < batch.beg or p >= batch.end or p >= len(ref):
+                continue
+            ctx = mbias_context(ref, p, batch.beg, batch.end, keep)
+            if ctx is None or bool(odd) == bool(ctx[1]):
+                continue
+            if runs is not None:
+                rs = region_of(runs, p)
+                if rs is None or (rs == 1 and strand not in (1, 3)) or (rs == 2 and strand not in (2, 4)):
+                    continue
+            assert strand != 0
+            q = g.q0 + j
+            b, ql = o.bq(q)
+            if ql < cfg.minPhred:
+                continue
+            un = {2: 0, 8: 1}.get(b) if odd else {4: 0, 1: 1}.get(b)
+            if un is None:
+                continue
+            hist.setdefault((strand, 2 if read2 else 1, q), [0, 0])[un] += 1
+    return hist
