@@ -123,6 +123,7 @@ static void parse_bounds(const char *arg, int *dst) {
     for(k = 0, tok = strtok_r(dup, ",", &save); k < 4; k++, tok = strtok_r(NULL, ",", &save)) {
         long v;
         if(!tok) break;
+        errno = 0;                   /* the reference tests errno without clearing it (common.c:20-24): a stale errno would reject a literal 0 */
         v = strtol(tok, &end, 10);
         if((errno == ERANGE && (v == LONG_MAX || v == LONG_MIN)) || (errno != 0 && v == 0) || end == tok || v > INT_MAX || v < 0) break;
         tmp[k] = (int)v;

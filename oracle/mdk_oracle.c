@@ -1067,6 +1067,7 @@ static void parseBounds(char *s2, int *vals, int mult) {       /* common.c:11-43
     char *p, *s = strdup(s2), *end; int i, v; long tempV;
     p = strtok(s, ",");
     if(!p) { fprintf(stderr, "Invalid bounds string, %s\n", s2); free(s); return; }
+    errno = 0;      /* NOT in the reference, which tests whatever errno was left by earlier calls; cleared here so that the result is defined */
     tempV = strtol(p, &end, 10);
     if((errno == ERANGE && (tempV == LONG_MAX || tempV == LONG_MIN)) || (errno != 0 && tempV == 0) || end == p) v = -1;
     else if(tempV > INT_MAX || tempV < LONG_MIN) v = -1; else v = (int)tempV;
@@ -1074,6 +1075,7 @@ static void parseBounds(char *s2, int *vals, int mult) {       /* common.c:11-43
     for(i = 1; i < 4; i++) {
         p = strtok(NULL, ",");
         if(!p) { fprintf(stderr, "Invalid bounds string, %s\n", s2); free(s); return; }   /* reference segfaults here */
+        errno = 0;
         tempV = strtol(p, &end, 10);
         if((errno == ERANGE && (tempV == LONG_MAX || tempV == LONG_MIN)) || (errno != 0 && tempV == 0) || end == p) v = -1;
         else if(tempV > INT_MAX || tempV < LONG_MIN) v = -1; else v = (int)tempV;

@@ -103,6 +103,7 @@ SYN_CMDS = [
     ("pe", ["--logit", "--CHH", "--noCpG"]),
     ("bis", ["--CHG", "--CHH"]),
     ("bis", ["--CTOT", "5,100,5,100", "--nCTOB", "3,3,3,3", "--CHH", "--chunkSize", "5000"]),
+    ("pe", ["--OT", "0,0,0,140", "--nOB", "0,9,0,0"]),        # literal zeros: the bounds parser must not depend on a stale errno
     ("se", ["--CHG", "--CHH", "--mergeContext"]),
 ]
 
