@@ -31,6 +31,9 @@
  *
  * Not supported (reference gets them only via libraries absent here): CRAM input, bigWig (-M).
  * BED (-l/--keepStrand): bed.c restated below (parseBED, spanOverlapsBED, posOverlapsBED, readStrandOverlapsBED).
+ * `mbias`: MBias.c:16-573 and svg.c:8-454 restated below (extractMBias, mbias_main, makeSVGs, makeTXT, getThresholds).
+ * PARITY FOR BED AND MBIAS IS UNPINNED: tests/test.py never runs `-l` or `mbias`, so nothing of the reference's own
+ * pins these two; they rest on this restatement alone.
  *
  * Style note: this file follows the reference's control flow one step at a time (a real pileup
  * buffer swept column by column, reads copied into it, qualities rewritten in place).  The
