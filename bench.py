@@ -101,14 +101,17 @@ def main():
     variant = cfg.minOppositeDepth > 0
     L = mdk.lib_hip()
 
-    # the kernel writes its result straight into torch tensors (md_dev_bind_output), which is what travels over RCCL
+    # the kernel writes its result straight into torch tensors (md_dev_bind_output), which is what travels over RCCL.
+    # Two slots, as in extract_main: chunk k is launched while chunk k-1 is collected (two chunks in flight).
     w0 = dev.wait(0)
     n_tiles = w0.n_tiles
     cap = int(w0.n_slots) + 1024             # slots = kept context positions of the interval: fixed by the reference, not by the reads
-    t_site = torch.zeros((cap, 4), dtype=torch.int32, device="cuda")
-    t_var = torch.zeros((cap, 2), dtype=torch.int32, device="cuda") if variant else None
-    t_seg = torch.zeros((n_tiles + 1, 2), dtype=torch.int32, device="cuda")
-    dev.bind_output(0, C.c_void_p(t_site.data_ptr()), C.c_void_p(t_var.data_ptr()) if variant else None, C.c_void_p(t_seg.data_ptr()), cap, n_tiles + 1)
+    dev.upload(1, chunk.batch)
+    t_site = [torch.zeros((cap, 4), dtype=torch.int32, device="cuda") for _ in range(2)]
+    t_var = [torch.zeros((cap, 2), dtype=torch.int32, device="cuda") if variant else None for _ in range(2)]
+    t_seg = [torch.zeros((n_tiles + 1, 2), dtype=torch.int32, device="cuda") for _ in range(2)]
+    for sl in range(2):
+        dev.bind_output(sl, C.c_void_p(t_site[sl].data_ptr()), C.c_void_p(t_var[sl].data_ptr()) if variant else None, C.c_void_p(t_seg[sl].data_ptr()), cap, n_tiles + 1)
 
     if world > 1:
         shape = torch.tensor([cap, n_tiles + 1], dtype=torch.int64, device="cuda")
@@ -118,15 +121,25 @@ def main():
         send = torch.zeros((gcap * 4 + gtiles * 2 + 2,), dtype=torch.int32, device="cuda")
         recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
 
-    def step():
-        dev.launch(0)
-        n = dev.wait(0).n_slots
+    def collect(sl):
+        n = dev.wait(sl).n_slots
         if world > 1:                           # the exchange step: per-interval site buffers -> rank 0 (RCCL over xGMI)
-            send[: cap * 4].copy_(t_site.view(-1))
-            send[gcap * 4: gcap * 4 + (n_tiles + 1) * 2].copy_(t_seg.view(-1))
+            send[: cap * 4].copy_(t_site[sl].view(-1))
+            send[gcap * 4: gcap * 4 + (n_tiles + 1) * 2].copy_(t_seg[sl].view(-1))
             send[-2] = n
             send[-1] = n_tiles
             dist.gather(send, recv, dst=0)
+        return n
+
+    def run(k_steps):
+        """k_steps passes over the batch: every pass is launched AND collected inside the call"""
+        n = 0
+        for k in range(k_steps):
+            dev.launch(k & 1)
+            if k:
+                n = collect((k - 1) & 1)
+        if k_steps:
+            n = collect((k_steps - 1) & 1)
         return n
 
     def fence():
@@ -135,17 +148,16 @@ def main():
         dev.sync()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_last = step()
+    n_last = run(args.steps)
     fence()
     dt = time.perf_counter() - t0
     assert n_last >= n_sites
     # the bound buffers hold the same sites as the library's own download (segment order -> ascending)
-    chk = t_site.cpu().numpy().view("uint32"); segs = t_seg.cpu().numpy().view("uint32")
+    last = (args.steps - 1) & 1 if args.steps else 0
+    chk = t_site[last].cpu().numpy().view("uint32"); segs = t_seg[last].cpu().numpy().view("uint32")
     got = []
     for t in range(n_tiles):
         o, c = int(segs[t, 0]), int(segs[t, 1])
@@ -193,7 +205,8 @@ def main():
                        else f"synthetic {args.length} bp, {args.coverage}x, extract {' '.join(extra)}",
                        "interval_bp": args.length, "coverage": args.coverage, "reads_admitted_per_gpu": int(chunk.batch.n_reads), "segments_per_gpu": int(chunk.batch.n_segs),
                        "records_per_gpu": synth_info["records"], "sites_per_gpu": int(n_sites), "cpg_calls_per_gpu": int(cpg_calls),
-                       "tile": int(br.tile), "tiles": int(br.n_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else "")},
+                       "tile": int(br.tile), "tiles": int(br.n_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else ""),
+                       "in_flight": "2 chunks per GPU (step k is launched while step k-1 is collected, as extract_main does); every step is launched and collected inside the timed region"},
             "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup, "all_kernels_ms": br.ms_total},
             "host_prep_s": t_host,

@@ -1281,6 +1281,15 @@ int mdk_plan_finish(mdk_plan *p) {
 /* ------------------------------------------------------------------------------------------------ */
 /* the drop-in entry point                                                                           */
 /* ------------------------------------------------------------------------------------------------ */
+/* The `MethylDackel` command asks (MDK_FAST_EXIT) to leave with _exit once the outputs are closed, skipping the unpinning
+ * of buffers and the HIP shutdown.  Not under a profiler or another injected tool: those finalise at normal exit. */
+static int fast_exit_wanted(void) {
+    const char *pre = getenv("LD_PRELOAD");
+    if(!getenv("MDK_FAST_EXIT")) return 0;
+    if(getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCPROF_OUTPUT_PATH")) return 0;
+    if(pre && (strstr(pre, "rocprof") || strstr(pre, "roctx") || strstr(pre, "rocm"))) return 0;
+    return 1;
+}
 typedef struct { int device; md_dev_cfg cfg; md_dev *dev; int rc; } devopen_t;
 static void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); return NULL; }
 
@@ -1339,7 +1348,7 @@ int extract_main(int argc, char *argv[]) {
     }
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0);
     if(ret == 0) mdk_plan_finish(p);
-    if(getenv("MDK_FAST_EXIT")) {     /* set by the `MethylDackel` command: the outputs are closed; skip unpinning buffers and the HIP shutdown */
+    if(fast_exit_wanted()) {
         fflush(stdout); fflush(stderr);
         _exit(ret & 0xff);
     }
@@ -1464,7 +1473,7 @@ int mbias_main(int argc, char *argv[]) {
         if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; }
         else if(mdk_mbias_report(&hist, p->o.mb_opref, p->o.svg, p->o.txt, p->o.ctx_on[0] + 2 * p->o.ctx_on[1] + 4 * p->o.ctx_on[2])) ret = -3;
     }
-    if(getenv("MDK_FAST_EXIT")) { fflush(stdout); fflush(stderr); _exit(ret & 0xff); }
+    if(fast_exit_wanted()) { fflush(stdout); fflush(stderr); _exit(ret & 0xff); }
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;
