@@ -39,6 +39,8 @@ typedef struct {
     int32_t  skipped;          /* MDK_CHUNK_* flags; non-zero: nothing was packed for this chunk */
     md_read_batch batch;
     uint64_t n_records_seen;   /* BAM records examined for this chunk (before admission) */
+    md_pr_batch pr;            /* perRead plans: the reads that start in the chunk (batch is unused then) */
+    const void *host;          /* perRead plans: the plan's own record of those reads (names), for mdk_plan_emit_perread */
 } mdk_chunk;
 
 /* Parse an `extract` command line (argv[0] = "extract"), open inputs.  rc follows extract_main:
@@ -79,6 +81,16 @@ int  mbias_main(int argc, char *argv[]);
 int  mdk_plan_open_mbias(int argc, char *argv[], mdk_plan **out);
 int  mdk_plan_mbias_outputs(const mdk_plan *p, const char **opref, int *svg, int *txt, int *which);
 int  mdk_mbias_report(const md_mbias *hist, const char *opref, int svg, int txt, int which);
+
+/* ---- `perRead` (perRead.c; main.c:20,55-56 dispatches to perRead_main) ----
+ * perRead_main: drop-in for the reference symbol (argv[0] = "perRead").  mdk_plan_open_perread: chunks without
+ * adjustBounds, `pr` filled with the alignments that start in the chunk and pass -F/-R/-q (perRead.c:178-183), for
+ * md_dev_perread_submit; a chunk of a contig the FASTA lacks comes out with MDK_CHUNK_NOREF set AND its reads listed
+ * (the reference prints them with zero calls).  mdk_plan_emit_perread writes addRead's lines (perRead.c:16-36) for a
+ * chunk, in chunk order; counts may be NULL for a MDK_CHUNK_NOREF chunk. */
+int  perRead_main(int argc, char *argv[]);
+int  mdk_plan_open_perread(int argc, char *argv[], mdk_plan **out);
+int  mdk_plan_emit_perread(mdk_plan *p, const mdk_chunk *c, const md_pr_count *counts, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -147,6 +147,18 @@ int  md_dev_mbias_read(md_dev *h, md_mbias *out);
 int  md_dev_mbias_reset(md_dev *h);
 int  md_dev_slot_sync(md_dev *h, int slot);
 
+/* perRead (perRead.c): per-read CpG methylation.  One md_pr_read per alignment the command keeps (start inside the chunk,
+ * -F/-R/-q passed), in file order; `cigar` holds the BAM CIGAR words of all reads back to back (cig_off/n_cigar index it);
+ * the payload in `blob` is laid out as for md_read_batch (4*off4: seq nibbles padded to 4 bytes, then qualities).
+ * Replaces processRead (perRead.c:38-94) for every read of a chunk; counts[i] belongs to read[i].
+ * The reference must be resident WITHOUT md_dev_set_regions: perRead uses -l only to pass over whole chunks. */
+typedef struct { int32_t pos; uint32_t off4, l_qseq, cig_off; uint16_t n_cigar; uint8_t strand, reserved; } md_pr_read;
+typedef struct { int32_t tid; int64_t beg, end; int32_t n_reads; const md_pr_read *read; const uint32_t *cigar; uint64_t n_cigar;
+                 const uint8_t *blob; uint64_t blob_bytes; } md_pr_batch;
+typedef struct { uint32_t nmeth, nunmeth; } md_pr_count;
+int  md_dev_perread_submit(md_dev *h, int slot, const md_pr_batch *b);                 /* H2D + kernel + D2H enqueued on the slot's stream */
+int  md_dev_perread_download(md_dev *h, int slot, const md_pr_count **counts, int64_t *n);   /* waits; memory owned by the slot */
+
 /* slot in [0, n_slots): upload is H2D on the slot's stream; launch enqueues the kernels; download waits for
  * the slot and returns the sites.  md_dev_submit = upload + launch. */
 int  md_dev_upload(md_dev *h, int slot, const md_read_batch *b);

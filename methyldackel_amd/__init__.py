@@ -54,6 +54,20 @@ class md_region(C.Structure):
     _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("strand", C.c_int32)]
 
 
+class md_pr_read(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("off4", C.c_uint32), ("l_qseq", C.c_uint32), ("cig_off", C.c_uint32), ("n_cigar", C.c_uint16),
+                ("strand", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class md_pr_batch(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("n_reads", C.c_int32), ("read", C.POINTER(md_pr_read)),
+                ("cigar", C.POINTER(C.c_uint32)), ("n_cigar", C.c_uint64), ("blob", C.POINTER(C.c_uint8)), ("blob_bytes", C.c_uint64)]
+
+
+class md_pr_count(C.Structure):
+    _fields_ = [("nmeth", C.c_uint32), ("nunmeth", C.c_uint32)]
+
+
 class md_mbias(C.Structure):
     _fields_ = [("len", C.c_int32), ("count", C.POINTER(C.c_uint32))]
 
@@ -85,17 +99,19 @@ class md_bench_result(C.Structure):
 
 class mdk_chunk(C.Structure):
     _fields_ = [("index", C.c_uint32), ("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("skipped", C.c_int32),
-                ("batch", md_read_batch), ("n_records_seen", C.c_uint64)]
+                ("batch", md_read_batch), ("n_records_seen", C.c_uint64), ("pr", md_pr_batch), ("host", C.c_void_p)]
 
 
 HIP_SYMBOLS = ["md_dev_count", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free",
-               "md_dev_mbias_submit", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync"]
+               "md_dev_mbias_submit", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
+               "md_dev_perread_submit", "md_dev_perread_download"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len", "mdk_plan_regions",
-                   "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report"]
+                   "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report",
+                   "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread"]
 
 _hip = None
 _ext = None
@@ -137,6 +153,8 @@ def lib_hip():
         L.md_dev_mbias_read.argtypes = [C.c_void_p, C.POINTER(md_mbias)]
         L.md_dev_mbias_reset.argtypes = [C.c_void_p]
         L.md_dev_slot_sync.argtypes = [C.c_void_p, C.c_int]
+        L.md_dev_perread_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_pr_batch)]
+        L.md_dev_perread_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(md_pr_count)), C.POINTER(C.c_int64)]
         L.md_host_alloc.restype = C.c_void_p
         L.md_host_alloc.argtypes = [C.c_uint64]
         L.md_host_free.argtypes = [C.c_void_p]
@@ -169,6 +187,9 @@ def lib_extract():
         L.mdk_plan_open_mbias.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         L.mdk_plan_mbias_outputs.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mdk_mbias_report.argtypes = [C.POINTER(md_mbias), C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.perRead_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.mdk_plan_open_perread.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
+        L.mdk_plan_emit_perread.argtypes = [C.c_void_p, C.POINTER(mdk_chunk), C.POINTER(md_pr_count), C.c_int64]
         L.mdk_plan_regions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(md_region)), C.POINTER(C.c_int64)]
         _ext = L
     return _ext
@@ -247,6 +268,13 @@ class Device:
             return np.zeros((0, 4, 2, 2), dtype=np.uint32)
         return np.ctypeslib.as_array(m.count, shape=(m.len * 16,)).reshape(m.len, 4, 2, 2).copy()
 
+    def perread(self, slot: int, batch: md_pr_batch):
+        """per-read CpG counts of a perRead chunk -> [(nmeth, nunmeth)] (submit + download)"""
+        self._chk(self.L.md_dev_perread_submit(self.h, slot, C.byref(batch)), "md_dev_perread_submit")
+        out, n = C.POINTER(md_pr_count)(), C.c_int64()
+        self._chk(self.L.md_dev_perread_download(self.h, slot, C.byref(out), C.byref(n)), "md_dev_perread_download")
+        return [(out[i].nmeth, out[i].nunmeth) for i in range(n.value)]
+
     def mbias_reset(self):
         self._chk(self.L.md_dev_mbias_reset(self.h), "md_dev_mbias_reset")
 
@@ -275,7 +303,7 @@ class Plan:
         self.args = [command] + [str(a) for a in args]
         self._argv = _argv(self.args)
         self.p = C.c_void_p()
-        opener = {"extract": L.mdk_plan_open, "mbias": L.mdk_plan_open_mbias}[command]
+        opener = {"extract": L.mdk_plan_open, "mbias": L.mdk_plan_open_mbias, "perRead": L.mdk_plan_open_perread}[command]
         self.rc = opener(len(self.args), self._argv, C.byref(self.p))
         if self.rc or not self.p:
             raise MdkError(f"{opener.__name__} returned {self.rc}")
@@ -312,6 +340,16 @@ class Plan:
         rc = self.L.mdk_plan_emit(self.p, C.byref(chunk), C.byref(sites))
         if rc:
             raise MdkError(f"mdk_plan_emit failed ({rc})")
+
+    def emit_perread(self, chunk: mdk_chunk, counts):
+        """counts: [(nmeth, nunmeth)] per read of the chunk, or None for a chunk whose contig the FASTA lacks"""
+        arr, n = None, 0
+        if counts is not None:
+            n = len(counts)
+            arr = (md_pr_count * max(n, 1))(*[md_pr_count(m, u) for m, u in counts])
+        rc = self.L.mdk_plan_emit_perread(self.p, C.byref(chunk), arr, n)
+        if rc:
+            raise MdkError(f"mdk_plan_emit_perread failed ({rc})")
 
     def finish(self):
         self.L.mdk_plan_finish(self.p)

@@ -1,5 +1,5 @@
-/* main.c -- `MethylDackel` command of the MI355X build: `extract` and `mbias` (the reference's dispatcher is
- * main.c:39-62). */
+/* main.c -- `MethylDackel` command of the MI355X build: `extract`, `mbias` and `perRead` (the reference's dispatcher
+ * is main.c:39-62). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -10,7 +10,8 @@ static void usage_main(void) {
                     "Usage: MethylDackel <command> [options]\n\nCommands:\n"
                     "    extract  Extract methylation metrics from an alignment file in BAM format (GPU).\n"
                     "    mbias    Determine the position-dependent methylation bias in a dataset (GPU).\n"
-                    "    mergeContext | perRead   not part of this build; use the reference MethylDackel.\n");
+                    "    perRead  Generate a per-read methylation summary (GPU).\n"
+                    "    mergeContext   not part of this build; use the reference MethylDackel.\n");
 }
 int main(int argc, char *argv[]) {
     if(argc == 1) { usage_main(); return 0; }
@@ -21,6 +22,7 @@ int main(int argc, char *argv[]) {
         return extract_main(argc - 1, argv + 1);
     }
     if(!strcmp(argv[1], "mbias")) { setenv("MDK_FAST_EXIT", "1", 0); return mbias_main(argc - 1, argv + 1); }
-    if(!strcmp(argv[1], "mergeContext") || !strcmp(argv[1], "perRead")) { fprintf(stderr, "`%s` is not part of the MI355X build.\n", argv[1]); return -1; }
+    if(!strcmp(argv[1], "perRead")) { setenv("MDK_FAST_EXIT", "1", 0); return perRead_main(argc - 1, argv + 1); }
+    if(!strcmp(argv[1], "mergeContext")) { fprintf(stderr, "`%s` is not part of the MI355X build.\n", argv[1]); return -1; }
     fprintf(stderr, "Unknown command!\n"); usage_main(); return -1;
 }

@@ -46,6 +46,7 @@ typedef struct {
     int n_threads; unsigned long chunk_size;
     char *region, *opref, *bbm_name, *bw_name, *bed_name, *out_bbm_name;     /* opref and out_bbm_name are owned */
     int output_bb, no_bam, keep_strand;
+    int perread;                                        /* `perRead` command: reads that START in the chunk, flags/MAPQ only (perRead.c) */
     int mbias, svg, txt; char *mb_opref;                 /* `mbias` command: no pairing, no outputs of its own (MBias.c) */
     const char *fasta_name, *bam_name;
 } opts_t;
@@ -66,6 +67,7 @@ typedef struct {
     char *qn; size_t qn_len, qn_cap;
     uint8_t *blob; size_t blob_len, cap_blob;
     md_seg *seg; size_t n_seg, cap_seg;
+    md_pr_read *pr; size_t cap_pr;                      /* perRead: one device record per kept read */
     uint64_t algo_bytes;
 } batchbuf;
 
@@ -91,6 +93,7 @@ struct mdk_plan {
     int map_on; uint32_t map_n; char **map_names; uint32_t *map_len; uint8_t **map_bits; int *map_of_tid;
     /* -l: per contig, the disjoint runs a position must fall in (and the strand a read must have there) */
     int bed_on; md_region **bed_run; int64_t *bed_nrun;
+    FILE *pr_out; int pr_out_owned;                     /* perRead: -o file or stdout */
     /* outputs */
     FILE *out[3]; sbuf ob[3];
     uint32_t next_emit;
@@ -384,8 +387,8 @@ static int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional) {
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
     if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
     p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */
-    if(!o->mbias && o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); plan_free(p); return -8; }
-    if(!o->mbias && o->bw_name) { int rc = load_bigwig(p); if(rc) { if(bbm) fclose(bbm); plan_free(p); return rc; } }
+    if(!o->mbias && !o->perread && o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); plan_free(p); return -8; }
+    if(!o->mbias && !o->perread && o->bw_name) { int rc = load_bigwig(p); if(rc) { if(bbm) fclose(bbm); plan_free(p); return rc; } }
     if(bbm) {                  /* as in the reference, a BBM given together with a bigWig replaces the bigWig's bitmaps */
         if(p->map_on) { uint32_t k; for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); } free(p->map_names); free(p->map_len); free(p->map_bits); p->map_names = NULL; p->map_len = NULL; p->map_bits = NULL; p->map_n = 0; }
         { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { plan_free(p); return rc; } }
@@ -398,7 +401,7 @@ static int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional) {
         for(i = 0; i < p->bam->n_targets; i++) { uint32_t k; p->map_of_tid[i] = -1; for(k = 0; k < p->map_n; k++) if(!strcmp(p->map_names[k], p->bam->target_name[i])) { p->map_of_tid[i] = (int)k; break; } }
     }
 
-    if(o->mbias) goto region;
+    if(o->mbias || o->perread) goto region;
     /* output files and headers (extract.c:1343-1439) */
     if(!o->opref) {
         char *dot; o->opref = strdup(o->bam_name); dot = strrchr(o->opref, '.'); if(dot) *dot = 0;
@@ -549,7 +552,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     return 0;
 }
 
-static void bb_free(batchbuf *b) { md_host_free(b->seg); md_host_free(b->blob); free(b->ri); free(b->cig); free(b->qn); memset(b, 0, sizeof(*b)); }
+static void bb_free(batchbuf *b) { md_host_free(b->seg); md_host_free(b->blob); free(b->ri); free(b->cig); free(b->qn); free(b->pr); memset(b, 0, sizeof(*b)); }
 static void plan_free(mdk_plan *p) {
     uint32_t k; int i;
     if(!p) return;
@@ -563,6 +566,7 @@ static void plan_free(mdk_plan *p) {
     free(p->carry); free(p->carry2);
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); }
     else for(i = 0; i < 3; i++) if(p->out[i]) fclose(p->out[i]);
+    if(p->pr_out && p->pr_out_owned) fclose(p->pr_out);
     for(i = 0; i < 3; i++) free(p->ob[i].s);
     free(p->o.opref); free(p->o.out_bbm_name); free(p->ref_dev); free(p->ref_tid);
     free(p);
@@ -594,7 +598,7 @@ int mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid) {
     if(tid < 0 || tid >= p->bam->n_targets || (fi = p->fa_of_tid[tid]) < 0) return MDK_ERR_NOREF;
     i = md_dev_set_reference(dev, tid, p->fa.seq[fi], p->fa.len[fi]);
     if(i) return i;
-    if(p->bed_on && (i = md_dev_set_regions(dev, tid, p->bed_run[tid], p->bed_nrun[tid])) != 0) return i;
+    if(p->bed_on && !p->o.perread && (i = md_dev_set_regions(dev, tid, p->bed_run[tid], p->bed_nrun[tid])) != 0) return i;     /* perRead uses -l only to pass over chunks (perRead.c:150-166) */
     if(p->n_ref == p->cap_ref) { p->cap_ref = p->cap_ref ? p->cap_ref * 2 : 32; p->ref_dev = realloc(p->ref_dev, sizeof(md_dev *) * p->cap_ref); p->ref_tid = realloc(p->ref_tid, sizeof(int32_t) * p->cap_ref); }
     p->ref_dev[p->n_ref] = dev; p->ref_tid[p->n_ref] = tid; p->n_ref++;
     return 0;
@@ -859,8 +863,17 @@ static int build_segments(mdk_plan *p, batchbuf *b, int64_t beg, int64_t end) {
 }
 
 /* admission (filter_func, common.c:416-444) + packing of one candidate record; returns 1 if admitted */
-static int admit_and_pack(mdk_plan *p, batchbuf *b, const mdk_rec *r, int32_t rlen, const char *win, int64_t woff, int64_t wlen) {
+static int admit_and_pack(mdk_plan *p, batchbuf *b, const mdk_rec *r, int32_t rlen, const char *win, int64_t woff, int64_t wlen, int64_t beg, int64_t end) {
     const opts_t *o = &p->o; const uint8_t *nh, *xg; int strand; size_t seqb, seqpad, qualpad, need; uint8_t *d; rinfo *ri; int k;
+    if(o->perread) {         /* perRead.c:178-183: alignments that start inside the chunk; flag masks and MAPQ only */
+        if(r->pos < beg || r->pos >= end) return 0;
+        if(o->require_flags && (o->require_flags & r->flag) != o->require_flags) return 0;
+        if(o->ignore_flags && (o->ignore_flags & r->flag) != 0) return 0;
+        if(r->mapq < o->min_mapq) return 0;
+        scan_aux(r, &nh, &xg);
+        strand = strand_of(r->flag, xg);
+        goto pack;
+    }
     if(r->tid == -1 || (r->flag & 0x4)) return 0;
     if(r->mapq < o->min_mapq) return 0;
     if(r->flag & o->ignore_flags) return 0;
@@ -878,7 +891,7 @@ static int admit_and_pack(mdk_plan *p, batchbuf *b, const mdk_rec *r, int32_t rl
     if(p->bed_on && !bed_touches(p, r->tid, r->pos, (int64_t)r->pos + (rlen > 0 ? rlen : 1))) return 0;      /* common.c:432-439 */
     strand = strand_of(r->flag, xg);
     if(o->min_conv_eff > 0.0) { if(conv_efficiency(r, strand, o->min_phred, win, woff, wlen) < o->min_conv_eff) return 0; }
-
+pack:
     seqb = ((size_t)r->l_qseq + 1) / 2; seqpad = (seqb + 3) & ~(size_t)3; qualpad = ((size_t)r->l_qseq + 3) & ~(size_t)3;
     need = seqpad + qualpad;
     if(bb_reserve(b, 1, need, (size_t)r->l_qname + 1, r->n_cigar)) return -1;
@@ -946,14 +959,14 @@ static int raw_push(pslot *sl, const mdk_rec *r) {
 
 /* schedule step + raw collection for one chunk; 1 = produced, 0 = schedule finished, <0 error */
 static int reader_fill(mdk_plan *p, pslot *sl) {
-    const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; int rc, fi; mdk_rec r; size_t off; mdk_chunk *c = &sl->c;
+    const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; int rc, fi, collect; mdk_rec r; size_t off; mdk_chunk *c = &sl->c;
     memset(c, 0, sizeof(*c)); sl->raw_len = 0; sl->n_rg = 0; sl->n_stream = 0; sl->win = NULL; sl->woff = sl->wlen = 0;
     /* extract.c:325-350 */
     c->index = p->bin++;
     tid = p->g_tid; beg = p->g_pos; end = (uint32_t)(beg + o->chunk_size);
     if(tid >= (uint32_t)bam->n_targets) return 0;
     if(p->g_end && end > p->g_end) end = p->g_end;
-    end = adjust_end(p, tid, end);
+    if(!o->perread) end = adjust_end(p, tid, end);       /* perRead does not move chunk ends (perRead.c:131-147) */
     if(beg > end) { tmp = beg; beg = end; end = tmp; }
     p->g_pos = end;
     if(p->g_end > 0 && p->g_pos >= p->g_end) p->g_tid = (uint32_t)-1;
@@ -967,6 +980,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
     }
     fi = p->fa_of_tid[tid];
     if(c->skipped & MDK_CHUNK_BED) ;
+    else if(fi < 0 && o->perread) c->skipped |= MDK_CHUNK_NOREF;       /* perRead.c:176 ignores the failed fetch: every read of the chunk comes out with zero calls */
     else if(fi < 0) {
         if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", -2, bam->target_name[tid], beg > 1 ? beg - 2 : 0, end);
         if(!(c->skipped & MDK_CHUNK_FOREIGN)) fprintf(stderr, "Note that the output will be truncated!\n");
@@ -993,6 +1007,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
         if(p->at_eof) { if(p->shard_world <= 1) p->need_seek = 1; return 1; }      /* no records for this chunk */
     }
     /* reads of this chunk, file order: straddlers carried over from the previous chunk, then the stream */
+    collect = !c->skipped || (o->perread && c->skipped == MDK_CHUNK_NOREF);      /* perRead still lists the reads of a contig the FASTA lacks (all zero) */
     p->carry2_len = 0;
     if(p->carry_tid == (int32_t)tid) {
         for(off = 0; off < p->carry_len;) {
@@ -1002,7 +1017,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
             off += 4 + (size_t)len;
             rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
             c->n_records_seen++;
-            if(endp > (int32_t)beg && r.pos < (int32_t)end && !c->skipped) { if(raw_push(sl, &r)) return -5; }
+            if(endp > (int32_t)beg && r.pos < (int32_t)end && collect) { if(raw_push(sl, &r)) return -5; }
             if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
         }
     }
@@ -1017,7 +1032,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
         if(r.tid == (int32_t)tid) {
             rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
             c->n_records_seen++;
-            if(endp > (int32_t)beg && !c->skipped) {          /* in place: extend the open range or start a new one */
+            if(endp > (int32_t)beg && collect) {          /* in place: extend the open range or start a new one */
                 size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
                 if(g && g->slab == cs && g->end == roff) g->end = roff + 4 + r.raw_len;
                 else {
@@ -1048,7 +1063,7 @@ static int worker_process(mdk_plan *p, pslot *sl) {
         uint32_t len; memcpy(&len, sl->raw + off, 4);
         if(mdk_rec_parse(sl->raw + off + 4, len, &r) != 0) return -2;
         off += 4 + (size_t)len;
-        if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen) < 0) return -5;
+        if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen, c->beg, c->end) < 0) return -5;
     }
     for(g = 0; g < sl->n_rg; g++) {
         const uint8_t *base = sl->rg[g].slab->buf;
@@ -1056,13 +1071,25 @@ static int worker_process(mdk_plan *p, pslot *sl) {
             uint32_t len; memcpy(&len, base + off, 4);
             if(mdk_rec_parse(base + off + 4, len, &r) != 0) return -2;
             off += 4 + (size_t)len;
-            if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen) < 0) return -5;
+            if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen, c->beg, c->end) < 0) return -5;
         }
         mdk_slab_unref(p->bam, sl->rg[g].slab);
     }
     sl->n_rg = 0;
     if(bb_reserve(b, 1, 16, 16, 1) || seg_reserve(b, 1)) return -5;          /* never hand out NULL arrays */
     t1 = now_s();
+    if(p->o.perread) {        /* no pairing, no segments: the device walks each read's CIGAR itself */
+        size_t i;
+        if(b->cap_pr < b->n + 1) { b->cap_pr = (b->n + 1) * 2; free(b->pr); b->pr = malloc(sizeof(md_pr_read) * b->cap_pr); if(!b->pr) return -5; }
+        for(i = 0; i < b->n; i++) {
+            const rinfo *ri = &b->ri[i]; md_pr_read *q = &b->pr[i];
+            q->pos = ri->pos; q->off4 = ri->off4; q->l_qseq = ri->lq; q->cig_off = ri->cig_off; q->n_cigar = ri->ncig; q->strand = ri->strand; q->reserved = 0;
+        }
+        c->pr.tid = c->tid; c->pr.beg = c->beg; c->pr.end = c->end; c->pr.n_reads = (int32_t)b->n; c->pr.read = b->pr; c->pr.cigar = b->cig; c->pr.n_cigar = b->cig_len;
+        c->pr.blob = b->blob; c->pr.blob_bytes = b->blob_len; c->host = b;
+        pthread_mutex_lock(&p->mu); p->t_collect += t1 - t0; pthread_mutex_unlock(&p->mu);
+        return 0;
+    }
     if(!p->o.mbias) pair_reads(b, c->tid);          /* mbias installs no overlap handler (MBias.c:158-161): every read counts on its own */
     t2 = now_s();
     if(build_segments(p, b, c->beg, c->end)) return -5;
@@ -1474,6 +1501,135 @@ int mbias_main(int argc, char *argv[]) {
         else if(mdk_mbias_report(&hist, p->o.mb_opref, p->o.svg, p->o.txt, p->o.ctx_on[0] + 2 * p->o.ctx_on[1] + 4 * p->o.ctx_on[2])) ret = -3;
     }
     if(fast_exit_wanted()) { fflush(stdout); fflush(stderr); _exit(ret & 0xff); }
+    md_dev_close(dev);
+    mdk_plan_close(p);
+    return ret;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* perRead (perRead.c): chunks without adjustBounds; the reads that start in a chunk and pass the    */
+/* flag/MAPQ tests go to the device, which walks each CIGAR (k_perread); one text line per read.     */
+/* ------------------------------------------------------------------------------------------------ */
+static void perread_usage(void) {
+    fputs("\nUsage: MethylDackel perRead [OPTIONS] <ref.fa> <input>\n", stderr);
+    fputs("\nOutput columns: read name, chromosome, position, CpG methylation (%), number of informative bases.\n"
+"Options (MI355X build; same option surface as MethylDackel 0.6.1):\n"
+" -q INT, -p INT, -r STR, -l FILE, --keepStrand, -o STR, -F/--ignoreFlags INT (default 0),\n"
+" -R/--requireFlags INT, -@ INT, --chunkSize INT, --version\n", stderr);
+}
+
+int mdk_plan_open_perread(int argc, char *argv[], mdk_plan **out) {
+    static const struct option longopts[] = {            /* perRead.c:300-308; --ignoreNH is in the help text only */
+        {"help", no_argument, 0, 'h'}, {"version", no_argument, 0, 'v'}, {"chunkSize", required_argument, 0, 19}, {"keepStrand", no_argument, 0, 20},
+        {"ignoreFlags", required_argument, 0, 'F'}, {"requireFlags", required_argument, 0, 'R'}, {0, 0, 0, 0}};
+    mdk_plan *p; opts_t *o; int c;
+    *out = NULL;
+    p = calloc(1, sizeof(*p)); if(!p) return -5;
+    o = &p->o;
+    o->perread = 1;
+    o->ctx_on[0] = 1; o->min_mapq = 10; o->min_phred = 5; o->min_depth = 1; o->ignore_flags = 0; o->n_threads = 1; o->chunk_size = 1000000;
+    p->shard_rank = 0; p->shard_world = 1;
+    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1; p->lastcpg_tid = -1; p->lastchg_tid = -1;
+    p->pr_out = stdout;
+    optind = 1;
+    while((c = getopt_long(argc, argv, "hvq:p:o:@:r:l:F:R:", longopts, NULL)) >= 0) {
+        switch(c) {
+        case 'h': perread_usage(); plan_free(p); return 0;
+        case 'v': printf("%s (using HTSlib version %s)\n", MDK_VERSION, "none; methyldackel_amd MI355X build"); plan_free(p); return 0;
+        case 'o':
+            if(p->pr_out_owned) fclose(p->pr_out);
+            if((p->pr_out = fopen(optarg, "w")) == NULL) { fprintf(stderr, "Couldn't open %s for writing\n", optarg); p->pr_out_owned = 0; plan_free(p); return 2; }
+            p->pr_out_owned = 1;
+            break;
+        case 'q': o->min_mapq = atoi(optarg); break;
+        case 'p': o->min_phred = atoi(optarg); break;
+        case '@': o->n_threads = atoi(optarg); break;
+        case 'r': o->region = optarg; break;
+        case 'l': o->bed_name = optarg; break;
+        case 'F': o->ignore_flags = atoi(optarg); break;
+        case 'R': o->require_flags = atoi(optarg); break;
+        case 19: o->chunk_size = strtoul(optarg, NULL, 10); if(o->chunk_size < 1) { fprintf(stderr, "Error: The chunk size must be at least 1!\n"); plan_free(p); return 1; } break;
+        case 20: o->keep_strand = 1; break;
+        default: fprintf(stderr, "Invalid option '%c'\n", c); perread_usage(); plan_free(p); return 1;
+        }
+    }
+    if(argc == 1) { perread_usage(); plan_free(p); return 0; }
+    if(argc - optind != 2) { fprintf(stderr, "You must supply a reference genome in fasta format and a BAM or CRAM file\n"); perread_usage(); plan_free(p); return -1; }
+    if(o->min_phred < 1) { fprintf(stderr, "-p %i is invalid. resetting to 1, which is the lowest possible value.\n", o->min_phred); o->min_phred = 1; }
+    if(o->min_mapq < 0) { fprintf(stderr, "-q %i is invalid. Resetting to 0, which is the lowest possible value.\n", o->min_mapq); o->min_mapq = 0; }
+    /* the reference opens the FASTA first (-2 with the usage text), then the BAM (-4) (perRead.c:386-396) */
+    { FILE *f = fopen(argv[optind], "r"); if(!f) { fprintf(stderr, "Couldn't open the index for %s!\n", argv[optind]); perread_usage(); plan_free(p); return -2; } fclose(f); }
+    { int rc = plan_attach_inputs(p, argv, optind); if(rc) return rc; }
+    *out = p;
+    return 0;
+}
+
+int mdk_plan_emit_perread(mdk_plan *p, const mdk_chunk *c, const md_pr_count *counts, int64_t n) {
+    const batchbuf *b; const char *chrom; int64_t i; char line[10000]; sbuf *ob;
+    if(!p || !c || !p->o.perread) return -1;
+    if(c->index != p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
+    p->next_emit++;
+    if(c->skipped & ~MDK_CHUNK_NOREF) return 0;
+    b = c->host;
+    if(!b || (int64_t)b->n != c->pr.n_reads) return -2;
+    if(counts && n != c->pr.n_reads) return -2;
+    if(!counts && !(c->skipped & MDK_CHUNK_NOREF) && c->pr.n_reads) return -2;
+    chrom = p->bam->target_name[c->tid];
+    ob = &p->ob[0]; ob->l = 0;
+    for(i = 0; i < c->pr.n_reads; i++) {             /* addRead, perRead.c:16-36 */
+        uint32_t m = counts ? counts[i].nmeth : 0, u = counts ? counts[i].nunmeth : 0; int l;
+        const char *qn = b->qn + b->ri[i].qn_off;
+        if(m + u > 0) l = snprintf(line, sizeof(line), "%s\t%s\t%" PRId64 "\t%f\t%" PRIu32 "\n", qn, chrom, (int64_t)b->ri[i].pos, 100. * ((double)m) / (m + u), m + u);
+        else l = snprintf(line, sizeof(line), "%s\t%s\t%" PRId64 "\t0.0\t%" PRIu32 "\n", qn, chrom, (int64_t)b->ri[i].pos, m + u);
+        if(l >= (int)sizeof(line)) l = (int)sizeof(line) - 1;
+        sb_put(ob, line, (size_t)l);
+    }
+    if(ob->l) fputs(ob->s, p->pr_out);
+    ob->l = 0;
+    return 0;
+}
+
+int perRead_main(int argc, char *argv[]) {
+    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth;
+    rc = mdk_plan_open_perread(argc, argv, &p);
+    if(rc != 0 || !p) return rc;
+    memset(&dop, 0, sizeof(dop));
+    mdk_plan_dev_cfg(p, &dop.cfg);
+    if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
+    pthread_create(&dth, NULL, devopen_main, &dop);
+    if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
+    pthread_join(dth, NULL);
+    dev = dop.dev;
+    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `perRead`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    while(more || have[0] || have[1]) {       /* two chunks in flight, as in extract_main */
+        int cur = k & 1, prev = cur ^ 1;
+        if(more) {
+            rc = mdk_plan_next_chunk(p, &ch[cur]);
+            if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
+            if(rc == 0) more = 0;
+            else {
+                if(!ch[cur].skipped && ch[cur].pr.n_reads) {
+                    rc = mdk_plan_ensure_reference(p, dev, ch[cur].tid);
+                    if(!rc) rc = md_dev_perread_submit(dev, cur, &ch[cur].pr);
+                    if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+                }
+                have[cur] = 1;
+            }
+        }
+        if(have[prev]) {
+            const md_pr_count *cnt = NULL; int64_t n = 0;
+            if(!ch[prev].skipped && ch[prev].pr.n_reads) {
+                rc = md_dev_perread_download(dev, prev, &cnt, &n);
+                if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+            }
+            if(mdk_plan_emit_perread(p, &ch[prev], cnt, n)) { ret = MDK_RC_DEVICE; break; }
+            have[prev] = 0;
+        }
+        k++;
+        if(!more && !have[0] && !have[1]) break;
+    }
+    fflush(p->pr_out);
+    if(fast_exit_wanted()) { if(p->pr_out_owned) fclose(p->pr_out); fflush(stdout); fflush(stderr); _exit(ret & 0xff); }
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;

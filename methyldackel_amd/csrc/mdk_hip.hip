@@ -439,6 +439,58 @@ __global__ __launch_bounds__(WG, 8) void k_mbias(const KParams P) {
     for(int i = tid; i < nh; i += WG) { const uint32_t v = lh[i]; if(v) atomicAdd(&P.hist[i], v); }
 }
 
+// ------------------------------------------------------------------------------------------------
+// perRead (perRead.c:38-94): one lane per read walks its CIGAR and counts CpG calls of the read itself.  The walk is the
+// reference's, including what it does after a base below -p: it steps one base on and evaluates that base without
+// looking at its quality or at the CIGAR again, which can run one element past the sequence -- resolved as the BAM
+// record layout resolves it (padding nibble of the last sequence byte, or the high nibble of the first quality byte).
+// CpG context comes from the resident context codes, clipped to the reference window the command fetches for the chunk
+// ([max(beg-2,0), end+10000], perRead.c:176): past its last base nothing is a CpG, and a C in its last base is not one.
+// ------------------------------------------------------------------------------------------------
+struct PRParams {
+    const md_pr_read *read; const uint32_t *cigar; const uint8_t *blob; const uint8_t *ctxcode;
+    int64_t reflen, wend; int n, minPhred; md_pr_count *out;
+};
+__device__ __forceinline__ int pr_cigar_type(uint32_t op) { return (0x3C1A7u >> ((op & 15) << 1)) & 3; }    // M I D N S H P = X (B: 0): bit 0 query, bit 1 reference
+
+__global__ __launch_bounds__(256) void k_perread(const PRParams P) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if(i >= P.n) return;
+    const md_pr_read r = P.read[i];
+    const uint8_t *seq = P.blob + 4ull * r.off4, *qual = seq + ((((r.l_qseq + 1) >> 1) + 3) & ~3u);
+    const uint32_t *cig = P.cigar + r.cig_off;
+    const bool odd = r.strand & 1;
+    uint32_t rp = 0, mp = (uint32_t)r.pos, nm = 0, nu = 0; int k = 0, off = 0;
+    while(rp < r.l_qseq && k < (int)r.n_cigar) {
+        if(off >= (int)(cig[k] >> 4)) { off = 0; k++; }
+        if(k >= (int)r.n_cigar) break;
+        const uint32_t c = cig[k]; const int type = pr_cigar_type(c);
+        if(type & 2) {
+            if(type & 1) {
+                if((int)qual[rp] < P.minPhred) { mp++; rp++; off++; }
+                int dir = 0;
+                if((int64_t)mp <= P.wend && (int64_t)mp < P.reflen) {
+                    const int code = P.ctxcode[mp] & 15;
+                    if(code == 1) dir = ((int64_t)mp == P.wend) ? 0 : 1;       // C of a CpG
+                    else if(code == 2) dir = -1;                                // G of a CpG
+                }
+                if(dir) {
+                    int b;
+                    if(rp < r.l_qseq) b = (seq[rp >> 1] >> ((~rp & 1) << 2)) & 15;
+                    else if(r.l_qseq & 1) b = seq[rp >> 1] & 15;
+                    else b = (qual[0] >> 4) & 15;
+                    if(dir == 1 && odd) { if(b == 2) nm++; else if(b == 8) nu++; }
+                    else if(dir == -1 && !odd) { if(b == 4) nm++; else if(b == 1) nu++; }
+                }
+                mp++; rp++; off++;
+            } else { mp += c >> 4; k++; off = 0; }
+        } else if(type & 1) { rp += c >> 4; k++; off = 0; }
+        else { off = 0; k++; }
+    }
+    md_pr_count o; o.nmeth = nm; o.nunmeth = nu;
+    P.out[i] = o;
+}
+
 // test hook: effective (post-trim, post-overlap-resolution) base and quality of every base of every segment,
 // one lane per base: out[ooff[s] + j] for base j of segment s
 __global__ __launch_bounds__(WG) void k_debug_effective(const KParams P, int n_segs, uint8_t *ob, uint8_t *oq, const uint64_t *ooff) {
@@ -498,6 +550,7 @@ struct Slot {
     DBuf<TileEnt> d_tiles; HBuf<TileEnt> h_tiles;
     DBuf<md_site> d_site; DBuf<md_site_var> d_var; DBuf<md_tile_seg> d_seg; DBuf<uint32_t> d_total; DBuf<int> d_err;
     HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; HBuf<uint32_t> h_total; HBuf<int> h_err;
+    DBuf<md_pr_read> d_pr; DBuf<uint32_t> d_cig; DBuf<md_pr_count> d_prc; HBuf<md_pr_count> h_prc; int pr_n = -1;      // perRead
     // caller-bound output (device memory owned by the caller)
     md_site *b_site = nullptr; md_site_var *b_var = nullptr; md_tile_seg *b_seg = nullptr; int64_t b_cap_sites = 0, b_cap_tiles = 0;
     int n_segs = 0, n_reads = 0, ntiles = 0, tid = -1, tile = 0, lds_bytes = 0; int64_t beg = 0, end = 0; uint64_t read_bytes = 0;
@@ -563,6 +616,7 @@ extern "C" void md_dev_close(md_dev *h) {
     (void)hipDeviceSynchronize();
     for(auto &s : h->slots) {
         s.d_seg_in.release(); s.d_blob.release(); s.d_tiles.release(); s.h_tiles.release();
+        s.d_pr.release(); s.d_cig.release(); s.d_prc.release(); s.h_prc.release();
         s.d_site.release(); s.d_var.release(); s.d_seg.release(); s.d_total.release(); s.d_err.release();
         s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release(); s.h_total.release(); s.h_err.release();
         if(s.e0) (void)hipEventDestroy(s.e0); if(s.e1) (void)hipEventDestroy(s.e1); if(s.k0) (void)hipEventDestroy(s.k0); if(s.k1) (void)hipEventDestroy(s.k1);
@@ -788,6 +842,44 @@ extern "C" int md_dev_mbias_reset(md_dev *h) {
     HIPCHK(hipDeviceSynchronize());
     if(h->d_hist) HIPCHK(hipMemset(h->d_hist, 0, (size_t)h->hist_cap * 16 * sizeof(uint32_t)));
     h->hist_len = 0;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// perRead entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int md_dev_perread_submit(md_dev *h, int slot, const md_pr_batch *b) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !b || b->n_reads < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_perread_submit", hipSuccess);
+    if(b->n_reads && (!b->read || !b->blob || (b->n_cigar && !b->cigar))) return fail(MDK_ERR_ARG, "md_dev_perread_submit: null array", hipSuccess);
+    if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(g_err, sizeof(g_err), "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->pr_n = -1;
+    const size_t n = (size_t)b->n_reads;
+    if(s->d_pr.need(n + 1) || s->d_cig.need((size_t)b->n_cigar + 1) || s->d_blob.need((size_t)b->blob_bytes + 64) || s->d_prc.need(n + 1) || s->h_prc.need(n + 1)) return MDK_ERR_NOMEM;
+    if(n) {
+        HIPCHK(hipMemcpyAsync(s->d_pr.p, b->read, n * sizeof(md_pr_read), hipMemcpyHostToDevice, s->stream));
+        if(b->n_cigar) HIPCHK(hipMemcpyAsync(s->d_cig.p, b->cigar, (size_t)b->n_cigar * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->d_blob.p, b->blob, (size_t)b->blob_bytes, hipMemcpyHostToDevice, s->stream));
+        PRParams P;
+        P.read = s->d_pr.p; P.cigar = s->d_cig.p; P.blob = s->d_blob.p; P.ctxcode = h->refcode[b->tid]; P.reflen = h->reflen[b->tid];
+        P.wend = b->end + 10000; if(P.wend > P.reflen - 1) P.wend = P.reflen - 1;
+        P.n = b->n_reads; P.minPhred = h->cfg.minPhred; P.out = s->d_prc.p;
+        hipLaunchKernelGGL(k_perread, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, P);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->h_prc.p, s->d_prc.p, n * sizeof(md_pr_count), hipMemcpyDeviceToHost, s->stream));
+    }
+    s->pr_n = b->n_reads;
+    return 0;
+}
+
+extern "C" int md_dev_perread_download(md_dev *h, int slot, const md_pr_count **out, int64_t *n) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !out || !n || s->pr_n < 0) return fail(MDK_ERR_ARG, "md_dev_perread_download: nothing submitted on this slot", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    *out = s->h_prc.p; *n = s->pr_n;
     return 0;
 }
 

@@ -32,8 +32,9 @@
  * Not supported (reference gets them only via libraries absent here): CRAM input, bigWig (-M).
  * BED (-l/--keepStrand): bed.c restated below (parseBED, spanOverlapsBED, posOverlapsBED, readStrandOverlapsBED).
  * `mbias`: MBias.c:16-573 and svg.c:8-454 restated below (extractMBias, mbias_main, makeSVGs, makeTXT, getThresholds).
- * PARITY FOR BED AND MBIAS IS UNPINNED: tests/test.py never runs `-l` or `mbias`, so nothing of the reference's own
- * pins these two; they rest on this restatement alone.
+ * `perRead`: perRead.c:16-464 restated below (processRead, perReadMetrics, perRead_main).
+ * PARITY FOR BED, MBIAS AND PERREAD IS UNPINNED: tests/test.py never runs `-l`, `mbias` or `perRead`, so nothing of the reference's own
+ * pins these; they rest on this restatement alone.
  *
  * Style note: this file follows the reference's control flow one step at a time (a real pileup
  * buffer swept column by column, reads copied into it, qualities rewritten in place).  The
@@ -1760,6 +1761,146 @@ static int mbias_main(int argc, char *argv[]) {                /* MBias.c:308-57
 }
 
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* perRead.c restated (`perRead`).  As for mbias, the reference's tests never run it: parity for   */
+/* perRead is UNPINNED by the reference and rests on this restatement.                          */
+/* ------------------------------------------------------------------------------------------ */
+static void addRead(kstr *os, const brec *b, const bamfile *hdr, uint32_t nmethyl, uint32_t nunmethyl) {   /* perRead.c:16-36 */
+    char str[10000];
+    if(nmethyl + nunmethyl > 0) snprintf(str, 10000, "%s\t%s\t%" PRId64 "\t%f\t%" PRIu32 "\n", b->qname, hdr->target_name[b->tid], (int64_t)b->pos, 100. * ((double)nmethyl) / (nmethyl + nunmethyl), nmethyl + nunmethyl);
+    else snprintf(str, 10000, "%s\t%s\t%" PRId64 "\t0.0\t%" PRIu32 "\n", b->qname, hdr->target_name[b->tid], (int64_t)b->pos, nmethyl + nunmethyl);
+    kputs_(os, str);
+}
+static int cigar_type(uint32_t op) { static const int t[16] = {3, 1, 2, 2, 1, 0, 0, 3, 3, 0, 0, 0, 0, 0, 0, 0}; return t[op & 15]; }   /* htslib bam_cigar_type: MIDNSHP=XB */
+/* processRead (perRead.c:38-94), step for step: after a low-quality base it moves one base on and evaluates that one
+ * without looking at its quality or at the CIGAR again.  Two reads past the record's arrays are possible in the
+ * reference and are resolved here by the BAM record layout, which is what the reference would see: the base at index
+ * l_qseq is the padding nibble of the last sequence byte (odd l_qseq) or the high nibble of the first quality byte
+ * (even l_qseq); a CIGAR index of n_cigar (only reachable on malformed records) ends the walk. */
+static void processRead(Config *config, const brec *b, char *seq, uint32_t sequenceStart, int seqLen, uint32_t *nmethyl, uint32_t *nunmethyl) {
+    uint32_t readPosition = 0, mappedPosition = (uint32_t)b->pos;
+    int cigarOPNumber = 0, cigarOPOffset = 0;
+    const uint8_t *readSeq = b->seq, *readQual = b->qual;
+    int strand = getStrand(b), cigarOPType, direction, base;
+    while(readPosition < (uint32_t)b->l_qseq && cigarOPNumber < b->n_cigar) {
+        if(cigarOPOffset >= (int)cig_len(b->cigar, cigarOPNumber)) { cigarOPOffset = 0; cigarOPNumber++; }
+        if(cigarOPNumber >= b->n_cigar) break;
+        cigarOPType = cigar_type(cig_op(b->cigar, cigarOPNumber));
+        if(cigarOPType & 2) {
+            if(cigarOPType & 1) {
+                if(readQual[readPosition] < config->minPhred) { mappedPosition++; readPosition++; cigarOPOffset++; }
+                direction = seq ? isCpG(seq, (int)(mappedPosition - sequenceStart), seqLen) : 0;
+                if(direction) {
+                    if(readPosition < (uint32_t)b->l_qseq) base = (readSeq[readPosition >> 1] >> ((~readPosition & 1) << 2)) & 0xf;
+                    else if(b->l_qseq & 1) base = readSeq[readPosition >> 1] & 0xf;
+                    else base = b->l_qseq ? (readQual[0] >> 4) & 0xf : 0;
+                    if(direction == 1 && (strand & 1) == 1) { if(base == 2) (*nmethyl)++; else if(base == 8) (*nunmethyl)++; }
+                    else if(direction == -1 && (strand & 1) == 0) { if(base == 4) (*nmethyl)++; else if(base == 1) (*nunmethyl)++; }
+                }
+                mappedPosition++; readPosition++; cigarOPOffset++;
+            } else { mappedPosition += cig_len(b->cigar, cigarOPNumber++); cigarOPOffset = 0; continue; }
+        } else if(cigarOPType & 1) { readPosition += cig_len(b->cigar, cigarOPNumber++); cigarOPOffset = 0; continue; }
+        else { cigarOPOffset = 0; cigarOPNumber++; continue; }
+    }
+}
+static void perReadMetrics(Config *config, const bamfile *bf, const fasta *fa) {   /* perRead.c:96-223, one worker */
+    int32_t bedIdx = 0; int seqlen; uint32_t nmethyl = 0, nunmethyl = 0;
+    uint32_t localPos = 0, localEnd = 0, localTid = 0, localPos2 = 0; char *seq = NULL; kstr os_; kstr *os = &os_; regitr iter; const brec *b;
+    memset(&os_, 0, sizeof(os_)); os_.m = 1024; os_.s = xmalloc(1024); os_.s[0] = 0;
+    while(1) {
+        bin_++;
+        localTid = globalTid; localPos = globalPos;
+        localEnd = (uint32_t)(localPos + config->chunkSize);
+        if(localTid >= (uint32_t)bf->n_targets) break;
+        if(globalEnd && localEnd > globalEnd) localEnd = globalEnd;
+        globalPos = localEnd;
+        if(globalEnd > 0 && globalPos >= globalEnd) globalTid = (uint32_t)-1;
+        if(localTid < (uint32_t)bf->n_targets && globalTid != (uint32_t)-1) {
+            if(globalPos >= bf->target_len[localTid]) { localEnd = bf->target_len[localTid]; globalTid++; globalPos = 0; }
+        }
+        if(config->bed) { if(spanOverlapsBED((int32_t)localTid, (int32_t)localPos, (int32_t)localEnd, config->bed, &bedIdx) != 1) continue; }
+        localPos2 = 0; if(localPos > 1) localPos2 = localPos - 2;
+        if(localTid >= (uint32_t)bf->n_targets) break;
+        if(globalEnd && localPos >= globalEnd) break;
+        regitr_init(&iter, bf, (int32_t)localTid, (int32_t)localPos, (int32_t)localEnd);
+        seq = fetch_seq(fa, bf->target_name[localTid], (int)localPos2, (int)(localEnd + 10000), &seqlen);
+        while((b = regitr_next(&iter)) != NULL) {
+            if((uint32_t)b->pos < localPos) continue;
+            if((uint32_t)b->pos >= localEnd) break;
+            nmethyl = 0; nunmethyl = 0;
+            if(config->requireFlags && (config->requireFlags & b->flag) != config->requireFlags) continue;
+            if(config->ignoreFlags && (config->ignoreFlags & b->flag) != 0) continue;
+            if(b->mapq < config->minMapq) continue;
+            processRead(config, b, seq, localPos2, seqlen, &nmethyl, &nunmethyl);
+            addRead(os, b, bf, nmethyl, nunmethyl);
+        }
+        free(seq);
+        if(os->l) fputs(os->s, config->output_fp[0]);
+        os->l = 0; os->s[0] = 0;
+    }
+    free(os_.s);
+}
+static void perRead_usage(void) { fprintf(stderr, "\nUsage: mdk_oracle perRead [OPTIONS] <ref.fa> <input>\n"); }
+static int perRead_main(int argc, char *argv[]) {              /* perRead.c:275-464 */
+    Config config; FILE *ofile = stdout; int i, keepStrand = 0; char *bedName = NULL; bamfile bf; fasta fa; char c;
+    static struct option lopts[] = {{"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {"chunkSize", 1, NULL, 19}, {"keepStrand", 0, NULL, 20},
+                                    {"ignoreFlags", 1, NULL, 'F'}, {"requireFlags", 1, NULL, 'R'}, {0, 0, NULL, 0}};
+    memset(&config, 0, sizeof(config));
+    config.keepCpG = 1; config.minMapq = 10; config.minPhred = 5; config.ignoreFlags = 0; config.requireFlags = 0; config.nThreads = 1; config.chunkSize = 1000000;
+    optind = 1;
+    while((c = (char)getopt_long(argc, argv, "hvq:p:o:@:r:l:F:R:", lopts, NULL)) >= 0) {
+        switch(c) {
+        case 'h': perRead_usage(); return 0;
+        case 'v': printf("%s (using HTSlib version %s)\n", ORACLE_VERSION, "none: mdk_oracle"); return 0;
+        case 'o': if((ofile = fopen(optarg, "w")) == NULL) { fprintf(stderr, "Couldn't open %s for writing\n", optarg); return 2; } break;
+        case 'q': config.minMapq = atoi(optarg); break;
+        case 'p': config.minPhred = atoi(optarg); break;
+        case '@': config.nThreads = atoi(optarg); break;
+        case 'r': config.reg = optarg; break;
+        case 'l': bedName = optarg; break;
+        case 'F': config.ignoreFlags = atoi(optarg); break;
+        case 'R': config.requireFlags = atoi(optarg); break;
+        case 19:
+            config.chunkSize = strtoul(optarg, NULL, 10);
+            if(config.chunkSize < 1) { fprintf(stderr, "Error: The chunk size must be at least 1!\n"); return 1; }
+            break;
+        case 20: keepStrand = 1; break;
+        case 21: config.ignoreNH = 1; break;     /* unreachable: --ignoreNH is in the help text but not in lopts (perRead.c:300-308) */
+        default: fprintf(stderr, "Invalid option '%c'\n", c); perRead_usage(); return 1;
+        }
+    }
+    if(argc == 1) { perRead_usage(); return 0; }
+    if(argc - optind != 2) { fprintf(stderr, "You must supply a reference genome in fasta format and a BAM or CRAM file\n"); perRead_usage(); return -1; }
+    if(config.minPhred < 1) { fprintf(stderr, "-p %i is invalid. resetting to 1, which is the lowest possible value.\n", config.minPhred); config.minPhred = 1; }
+    if(config.minMapq < 0) { fprintf(stderr, "-q %i is invalid. Resetting to 0, which is the lowest possible value.\n", config.minMapq); config.minMapq = 0; }
+    if(fasta_load(argv[optind], &fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", argv[optind]); perRead_usage(); return -2; }
+    if(bam_load(argv[optind + 1], &bf) != 0) { fprintf(stderr, "Couldn't open %s for reading!\n", argv[optind + 1]); return -4; }
+    config.output_fp[0] = ofile;
+    globalTid = 0; globalPos = 0; globalEnd = 0; bin_ = 0;
+    if(config.reg) {
+        const char *foo; char *bar; int s = 0, e = 0;
+        foo = parse_reg(config.reg, &s, &e);
+        if(foo == NULL) { fprintf(stderr, "Could not parse the specified region!\n"); return -4; }
+        bar = xmalloc((size_t)(foo - config.reg) + 1);
+        strncpy(bar, config.reg, (size_t)(foo - config.reg)); bar[foo - config.reg] = 0;
+        globalTid = (uint32_t)-1;
+        for(i = 0; i < bf.n_targets; i++) if(!strcmp(bf.target_name[i], bar)) { globalTid = (uint32_t)i; break; }
+        if(globalTid == (uint32_t)-1) { fprintf(stderr, "%s did not match a known chromosome/contig name!\n", config.reg); return -6; }
+        if(s > 0) globalPos = (uint32_t)s;
+        if(e > 0) globalEnd = (uint32_t)e;
+        if(globalEnd > bf.target_len[globalTid]) globalEnd = bf.target_len[globalTid];
+        free(bar);
+    }
+    if(bedName) {
+        config.bed = parseBED(bedName, &bf, keepStrand);
+        if(!config.bed) { fprintf(stderr, "There was an error while reading in your BED file!\n"); return 1; }
+    }
+    perReadMetrics(&config, &bf, &fa);
+    if(ofile != stdout) fclose(ofile);
+    return 0;
+}
+
 /* test driver: `mdk_oracle mbias-report <prefix> <which>` plots a --txt table read from stdin (makeSVGs + makeTXT on
  * hand-made histograms; the arrays go through the same per-thread -> merged growth as in mbias_main) */
 static int mbias_report_main(int argc, char *argv[]) {
@@ -1788,6 +1929,7 @@ int main(int argc, char *argv[]) {                             /* main.c:39-62 *
     if(strcmp(argv[1], "-v") == 0 || strcmp(argv[1], "--version") == 0) { printf("%s (using HTSlib version %s)\n", ORACLE_VERSION, "none: mdk_oracle"); return 0; }
     if(strcmp(argv[1], "extract") == 0) return extract_main(argc - 1, argv + 1);
     if(strcmp(argv[1], "mbias") == 0) return mbias_main(argc - 1, argv + 1);
+    if(strcmp(argv[1], "perRead") == 0) return perRead_main(argc - 1, argv + 1);
     if(strcmp(argv[1], "mbias-report") == 0) return mbias_report_main(argc - 1, argv + 1);
     fprintf(stderr, "Unknown command!\n");
     return -1;

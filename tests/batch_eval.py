@@ -189,3 +189,61 @@ def eval_mbias(batch, ref: bytes, cfg, runs=None, hist=None):
                 continue
             hist.setdefault((strand, 2 if read2 else 1, q), [0, 0])[un] += 1
     return hist
+
+
+CIGAR_TYPE = [3, 1, 2, 2, 1, 0, 0, 3, 3, 0, 0, 0, 0, 0, 0, 0]      # htslib bam_cigar_type for MIDNSHP=XB
+
+
+def eval_perread(pr, ref: bytes, min_phred):
+    """[(nmeth, nunmeth)] for the reads of a perRead batch (md_pr_batch): processRead of the reference (perRead.c:38-94),
+    with the chunk's reference window [max(beg-2,0), min(end+10000, len-1)] (perRead.c:176)"""
+    wend = min(pr.end + 10000, len(ref) - 1)
+    out = []
+    for i in range(pr.n_reads):
+        r = pr.read[i]
+        base = C.addressof(pr.blob.contents) + 4 * r.off4
+        lq = r.l_qseq
+        seqb = (lq + 1) // 2
+        seq = bytes((C.c_uint8 * max(seqb, 1)).from_address(base))
+        qual = bytes((C.c_uint8 * max(lq, 1)).from_address(base + ((seqb + 3) & ~3)))
+        cig = [pr.cigar[r.cig_off + k] for k in range(r.n_cigar)]
+        odd = r.strand & 1
+        rp, mp, k, off, nm, nu = 0, r.pos, 0, 0, 0, 0
+        while rp < lq and k < len(cig):
+            if off >= cig[k] >> 4:
+                off = 0
+                k += 1
+            if k >= len(cig):
+                break
+            t = CIGAR_TYPE[cig[k] & 15]
+            if t & 2:
+                if t & 1:
+                    if qual[rp] < min_phred:
+                        mp += 1; rp += 1; off += 1
+                    d = 0
+                    if mp <= wend:
+                        c = ref[mp] & 0x5F
+                        if c == 0x43 and mp + 1 <= wend and ref[mp + 1] & 0x5F == 0x47:
+                            d = 1
+                        elif c == 0x47 and mp >= 1 and ref[mp - 1] & 0x5F == 0x43:
+                            d = -1
+                    if d:
+                        if rp < lq:
+                            b = (seq[rp >> 1] >> (0 if rp & 1 else 4)) & 15
+                        elif lq & 1:
+                            b = seq[rp >> 1] & 15
+                        else:
+                            b = (qual[0] >> 4) & 15
+                        if d == 1 and odd:
+                            nm += b == 2; nu += b == 8
+                        elif d == -1 and not odd:
+                            nm += b == 4; nu += b == 1
+                    mp += 1; rp += 1; off += 1
+                else:
+                    mp += cig[k] >> 4; k += 1; off = 0
+            elif t & 1:
+                rp += cig[k] >> 4; k += 1; off = 0
+            else:
+                off = 0; k += 1
+        out.append((nm, nu))
+    return out
