@@ -92,6 +92,9 @@ int  perRead_main(int argc, char *argv[]);
 int  mdk_plan_open_perread(int argc, char *argv[], mdk_plan **out);
 int  mdk_plan_emit_perread(mdk_plan *p, const mdk_chunk *c, const md_pr_count *counts, int64_t n);
 
+/* ---- `mergeContext` (mergeContext.c; main.c:19,53-54): text-to-text host tool, no device work ---- */
+int  mergeContext_main(int argc, char *argv[]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,7 +111,7 @@ EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len", "mdk_plan_regions",
                    "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report",
-                   "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread"]
+                   "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread", "mergeContext_main"]
 
 _hip = None
 _ext = None
@@ -188,6 +188,7 @@ def lib_extract():
         L.mdk_plan_mbias_outputs.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mdk_mbias_report.argtypes = [C.POINTER(md_mbias), C.c_char_p, C.c_int, C.c_int, C.c_int]
         L.perRead_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.mergeContext_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
         L.mdk_plan_open_perread.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         L.mdk_plan_emit_perread.argtypes = [C.c_void_p, C.POINTER(mdk_chunk), C.POINTER(md_pr_count), C.c_int64]
         L.mdk_plan_regions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(md_region)), C.POINTER(C.c_int64)]

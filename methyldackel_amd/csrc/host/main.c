@@ -1,5 +1,5 @@
-/* main.c -- `MethylDackel` command of the MI355X build: `extract`, `mbias` and `perRead` (the reference's dispatcher
- * is main.c:39-62). */
+/* main.c -- `MethylDackel` command of the MI355X build: `extract`, `mbias`, `perRead` on the GPU and the `mergeContext`
+ * text tool (the reference's dispatcher is main.c:39-62). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -11,7 +11,7 @@ static void usage_main(void) {
                     "    extract  Extract methylation metrics from an alignment file in BAM format (GPU).\n"
                     "    mbias    Determine the position-dependent methylation bias in a dataset (GPU).\n"
                     "    perRead  Generate a per-read methylation summary (GPU).\n"
-                    "    mergeContext   not part of this build; use the reference MethylDackel.\n");
+                    "    mergeContext   Combine single Cytosine metrics from 'MethylDackel extract' into per-CpG/CHG metrics.\n");
 }
 int main(int argc, char *argv[]) {
     if(argc == 1) { usage_main(); return 0; }
@@ -23,6 +23,6 @@ int main(int argc, char *argv[]) {
     }
     if(!strcmp(argv[1], "mbias")) { setenv("MDK_FAST_EXIT", "1", 0); return mbias_main(argc - 1, argv + 1); }
     if(!strcmp(argv[1], "perRead")) { setenv("MDK_FAST_EXIT", "1", 0); return perRead_main(argc - 1, argv + 1); }
-    if(!strcmp(argv[1], "mergeContext")) { fprintf(stderr, "`%s` is not part of the MI355X build.\n", argv[1]); return -1; }
+    if(!strcmp(argv[1], "mergeContext")) return mergeContext_main(argc - 1, argv + 1);
     fprintf(stderr, "Unknown command!\n"); usage_main(); return -1;
 }

@@ -1901,6 +1901,97 @@ static int perRead_main(int argc, char *argv[]) {              /* perRead.c:275-
     return 0;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* mergeContext.c restated (`mergeContext`, a text-to-text tool; unpinned by the reference's tests) */
+/* ------------------------------------------------------------------------------------------ */
+struct mcLast { char *chrom; int32_t start, end; uint32_t nmethyl, nunmethyl; };
+static void printRecord(FILE *of, char *chr, int32_t start, int32_t end, uint32_t nmethyl, uint32_t nunmethyl) {   /* mergeContext.c:24-28 */
+    fprintf(of, "%s\t%" PRId32 "\t%" PRId32 "\t%i\t%" PRIu32 "\t%" PRIu32 "\n", chr, start, end, (int)(100.0 * ((double)nmethyl) / (nmethyl + nunmethyl)), nmethyl, nunmethyl);
+}
+static void MergeOrPrint(FILE *of, struct mcLast *last, char *chr, int32_t start, int32_t width, uint32_t nmethyl, uint32_t nunmethyl) {   /* mergeContext.c:30-56 */
+    int32_t end;
+    if(width > 0) end = start + width;
+    else { end = start + 1; start = end + width; }
+    if(last->chrom && strcmp(last->chrom, chr) == 0 && last->start == start && last->end == end) {
+        printRecord(of, chr, start, end, nmethyl + last->nmethyl, nunmethyl + last->nunmethyl);
+        free(last->chrom); free(chr); last->chrom = NULL;
+    } else {
+        if(last->chrom) { printRecord(of, last->chrom, last->start, last->end, last->nmethyl, last->nunmethyl); free(last->chrom); }
+        last->chrom = chr; last->start = start; last->end = end; last->nmethyl = nmethyl; last->nunmethyl = nunmethyl;
+    }
+}
+static int getContext(const fasta *fa, char *chr, int32_t pos, int *width) {   /* mergeContext.c:58-97 */
+    int len = -1, rv = 2, k; int32_t start, end; char *seq, *base;
+    for(k = 0; k < fa->n; k++) if(!strcmp(fa->name[k], chr)) { len = (int)fa->len[k]; break; }      /* faidx_seq_len: -1 if unknown */
+    start = (pos > 2) ? pos - 2 : 0;
+    end = (pos + 2 < len) ? pos + 2 : len - 1;
+    seq = fetch_seq(fa, chr, start, end, &len);
+    if(!seq) return 3;
+    base = seq + (pos - start);
+    if(toupper((unsigned char)*base) == 'C') {
+        if(end - pos) {
+            if(toupper((unsigned char)*(base + 1)) == 'G') { *width = 2; rv = 0; }
+            else if(end - pos == 2) { if(toupper((unsigned char)*(base + 2)) == 'G') { *width = 3; rv = 1; } }
+        }
+    } else {
+        assert(toupper((unsigned char)*base) == 'G');
+        if(pos - start) {
+            if(toupper((unsigned char)*(base - 1)) == 'C') { *width = -2; rv = 0; }
+            else if(pos - start == 2) { if(toupper((unsigned char)*(base - 2)) == 'C') { *width = -3; rv = 1; } }
+        }
+    }
+    free(seq);
+    return rv;
+}
+static void mergeContext(FILE *ifile, const fasta *fa, FILE *ofile) {   /* mergeContext.c:99-160 */
+    struct mcLast *lastCpG = calloc(1, sizeof(*lastCpG)), *lastCHG = calloc(1, sizeof(*lastCHG));
+    char *p, *p2, *chr, *line = NULL; size_t cap = 0; ssize_t got; int type, width = 0; int32_t start, end; uint32_t nmethyl, nunmethyl;
+    while((got = getline(&line, &cap, ifile)) >= 0) {       /* ks_getuntil(KS_SEP_LINE): the line without its terminator */
+        if(got && line[got - 1] == '\n') line[--got] = 0;
+        if(got > 1 && line[got - 1] == '\r') line[--got] = 0;
+        assert(got > 0);
+        if(strncmp(line, "track", 5) == 0) continue;
+        p = strtok(line, "\t"); chr = strdup(p);
+        p = strtok(NULL, "\t"); start = (int32_t)strtoll(p, &p2, 10); assert(p2 != p);
+        p = strtok(NULL, "\t"); end = (int32_t)strtoll(p, &p2, 10); assert(p2 != p);
+        p = strtok(NULL, "\t");
+        p = strtok(NULL, "\t"); nmethyl = (uint32_t)strtoul(p, &p2, 10); assert(p2 != p);
+        p = strtok(NULL, "\n"); nunmethyl = (uint32_t)strtoul(p, &p2, 10); assert(p2 != p);
+        type = getContext(fa, chr, start, &width);
+        if(type == 0) MergeOrPrint(ofile, lastCpG, chr, start, width, nmethyl, nunmethyl);
+        else if(type == 1) MergeOrPrint(ofile, lastCHG, chr, start, width, nmethyl, nunmethyl);
+        else if(type == 2) { printRecord(ofile, chr, start, end, nmethyl, nunmethyl); free(chr); }
+        else { fprintf(stderr, "[mergeContext] Error, %s is an unknown chromosome name!\n", chr); free(chr); break; }
+    }
+    if(lastCpG->chrom) { printRecord(ofile, lastCpG->chrom, lastCpG->start, lastCpG->end, lastCpG->nmethyl, lastCpG->nunmethyl); free(lastCpG->chrom); }
+    if(lastCHG->chrom) { printRecord(ofile, lastCHG->chrom, lastCHG->start, lastCHG->end, lastCHG->nmethyl, lastCHG->nunmethyl); free(lastCHG->chrom); }
+    free(line); free(lastCpG); free(lastCHG);
+}
+static void mergeContext_usage(void) { fprintf(stderr, "\nUsage: mdk_oracle mergeContext [OPTIONS] <ref.fa> <input>\n"); }
+static int mergeContext_main(int argc, char *argv[]) {         /* mergeContext.c:179-236 */
+    fasta fa; FILE *ifile, *ofile = stdout; char c;
+    static struct option lopts[] = {{"help", 0, NULL, 'h'}, {"version", 0, NULL, 'v'}, {0, 0, NULL, 0}};
+    optind = 1;
+    while((c = (char)getopt_long(argc, argv, "hvo:", lopts, NULL)) >= 0) {
+        switch(c) {
+        case 'h': mergeContext_usage(); return 0;
+        case 'v': printf("%s (using HTSlib version %s)\n", ORACLE_VERSION, "none: mdk_oracle"); return 0;
+        case 'o': if((ofile = fopen(optarg, "w")) == NULL) { fprintf(stderr, "Couldn't open %s for writing\n", optarg); return 2; } break;
+        default: fprintf(stderr, "Invalid option '%c'\n", c); mergeContext_usage(); return 1;
+        }
+    }
+    if(argc == 1) { mergeContext_usage(); return 0; }
+    if(argc - optind != 2) { fprintf(stderr, "You must supply a reference genome in fasta format and an input bedGraph files\n"); mergeContext_usage(); return -1; }
+    if(fasta_load(argv[optind], &fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", argv[optind]); mergeContext_usage(); return -2; }
+    if((ifile = fopen(argv[optind + 1], "r")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", argv[optind + 1]); return -3; }
+    fprintf(ofile, "track type=\"bedGraph\" description=\"merged Methylation metrics\"\n");
+    mergeContext(ifile, &fa, ofile);
+    if(ofile != stdout) fclose(ofile);
+    fclose(ifile);
+    return 0;
+}
+
 /* test driver: `mdk_oracle mbias-report <prefix> <which>` plots a --txt table read from stdin (makeSVGs + makeTXT on
  * hand-made histograms; the arrays go through the same per-thread -> merged growth as in mbias_main) */
 static int mbias_report_main(int argc, char *argv[]) {
@@ -1930,6 +2021,7 @@ int main(int argc, char *argv[]) {                             /* main.c:39-62 *
     if(strcmp(argv[1], "extract") == 0) return extract_main(argc - 1, argv + 1);
     if(strcmp(argv[1], "mbias") == 0) return mbias_main(argc - 1, argv + 1);
     if(strcmp(argv[1], "perRead") == 0) return perRead_main(argc - 1, argv + 1);
+    if(strcmp(argv[1], "mergeContext") == 0) return mergeContext_main(argc - 1, argv + 1);
     if(strcmp(argv[1], "mbias-report") == 0) return mbias_report_main(argc - 1, argv + 1);
     fprintf(stderr, "Unknown command!\n");
     return -1;

@@ -10,7 +10,7 @@ from conftest import REPO
 def declared(header):
     txt = open(REPO / "include" / header).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:md_|mdk_|extract_main|mbias_main|perRead_main)\w*)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b((?:md_|mdk_|extract_main|mbias_main|perRead_main|mergeContext_main)\w*)\s*\(", txt)))
 
 
 def exported(lib):
