@@ -1144,7 +1144,8 @@ static int pipeline_start(mdk_plan *p) {
     int i;
     /* beyond a dozen workers the serial reader is the limit, and every slot pins ~1.2 bytes of host memory per raw BAM
      * byte of its chunk (expensive to allocate), so the pipeline depth is bounded; -@ still sizes the inflate pool */
-    p->n_workers = p->o.n_threads < 1 ? 1 : p->o.n_threads; if(p->n_workers > 12) p->n_workers = 12;
+    p->n_workers = p->o.n_threads < 1 ? 1 : p->o.n_threads;
+    { int cap = getenv("MDK_WORKERS") ? atoi(getenv("MDK_WORKERS")) : 12; if(cap < 1) cap = 1; if(p->n_workers > cap) p->n_workers = cap; }
     p->n_slot = p->n_workers + 3;
     p->slot = calloc((size_t)p->n_slot, sizeof(pslot));
     p->worker_th = calloc((size_t)p->n_workers, sizeof(pthread_t));
