@@ -74,6 +74,14 @@ typedef struct {
 /* qname table entry for the pairing pass */
 typedef struct { uint64_t h; uint32_t qoff; int32_t pending; int32_t nlive; int32_t live[4]; int32_t *more; int32_t nmore, capmore; int used; } qent;
 
+/* what formatting one chunk needs and produces: the text per output file, the pending --mergeContext sites (they never
+ * cross a chunk: extract.c:496-507) and the count of positions dropped as likely variants */
+typedef struct {
+    sbuf ob[3];
+    int32_t lastcpg_tid, lastcpg_pos, lastchg_tid, lastchg_pos; uint32_t lastcpg_m, lastcpg_u, lastchg_m, lastchg_u;
+    uint64_t n_variant;
+} emit_ctx;
+
 struct mdk_plan {
     opts_t o;
     mdk_bam *bam; mdk_bai *bai; int need_seek; mdk_fasta fa; int *fa_of_tid;
@@ -95,9 +103,8 @@ struct mdk_plan {
     int bed_on; md_region **bed_run; int64_t *bed_nrun;
     FILE *pr_out; int pr_out_owned;                     /* perRead: -o file or stdout */
     /* outputs */
-    FILE *out[3]; sbuf ob[3];
+    FILE *out[3]; sbuf ob[3]; emit_ctx ec;
     uint32_t next_emit;
-    int32_t lastcpg_tid, lastcpg_pos, lastchg_tid, lastchg_pos; uint32_t lastcpg_m, lastcpg_u, lastchg_m, lastchg_u;
     double t_collect, t_pair, t_segs, t_emit;      /* MDK_HOST_PROFILE=1: seconds per host stage */
     /* device references already uploaded: (dev handle, tid) pairs */
     md_dev **ref_dev; int32_t *ref_tid; int n_ref, cap_ref;
@@ -468,7 +475,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
     o->ctx_on[0] = 1; o->min_mapq = 10; o->min_phred = 5; o->min_depth = 1; o->ignore_flags = 0xF00;
     o->n_threads = 1; o->chunk_size = 1000000; o->map_cutoff = 0.01f; o->min_mappable = 15;
     p->shard_rank = 0; p->shard_world = 1;
-    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1; p->lastcpg_tid = -1; p->lastchg_tid = -1;
+    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1;
 
     optind = 1;     /* the reference relies on a fresh process; being a library we reset getopt */
     /* NB -f, -c and -m take an argument in the short-option string although --fraction/--counts/--logit do not
@@ -567,7 +574,7 @@ static void plan_free(mdk_plan *p) {
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); }
     else for(i = 0; i < 3; i++) if(p->out[i]) fclose(p->out[i]);
     if(p->pr_out && p->pr_out_owned) fclose(p->pr_out);
-    for(i = 0; i < 3; i++) free(p->ob[i].s);
+    for(i = 0; i < 3; i++) { free(p->ob[i].s); free(p->ec.ob[i].s); }
     free(p->o.opref); free(p->o.out_bbm_name); free(p->ref_dev); free(p->ref_tid);
     free(p);
 }
@@ -1227,7 +1234,7 @@ static const char *trinuc(const char *seq, int64_t len, int64_t i, int dir, char
 static const char *cctx_name(int type) { return type == 0 ? "G" : type == 1 ? "HG" : "HH"; }
 
 /* zero-coverage rows of --cytosine_report between *from and upto (extract.c:182-205) */
-static void put_blanks(mdk_plan *p, const char *chrom, const char *seq, int64_t len, int64_t *from, int64_t upto) {
+static void put_blanks(mdk_plan *p, sbuf *dst, const char *chrom, const char *seq, int64_t len, int64_t *from, int64_t upto) {
     char tri[4];
     for(; *from < upto; (*from)++) {
         int code; int dir, type;
@@ -1237,17 +1244,16 @@ static void put_blanks(mdk_plan *p, const char *chrom, const char *seq, int64_t 
         type = code - 1;
         if(!p->o.ctx_on[type]) continue;
         dir = ((seq[*from] & 0x5f) == 'C') ? 1 : -1;
-        put_site(p, &p->ob[0], chrom, (int32_t)*from, 1, 0, 0, dir > 0, cctx_name(type), trinuc(seq, len, *from, dir, tri));
+        put_site(p, dst, chrom, (int32_t)*from, 1, 0, 0, dir > 0, cctx_name(type), trinuc(seq, len, *from, dir, tri));
     }
 }
 
-int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
+/* text of one chunk (variant filter, --mergeContext, formats; extract.c:443-510) into e->ob[]; touches nothing shared */
+static void emit_format(mdk_plan *p, const mdk_chunk *c, const md_sites *s, emit_ctx *e) {
     const opts_t *o = &p->o; const char *chrom; int64_t i; int fi; const char *seq = NULL; int64_t slen = 0, blank_from;
-    int k; char tri[4];
-    double te0 = now_s();
-    if(c->index != p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
-    p->next_emit++;
-    if(c->skipped & (MDK_CHUNK_NOREF | MDK_CHUNK_BED)) return 0;
+    char tri[4];
+    e->ob[0].l = e->ob[1].l = e->ob[2].l = 0; e->n_variant = 0; e->lastcpg_tid = e->lastchg_tid = -1;
+    if(c->skipped & (MDK_CHUNK_NOREF | MDK_CHUNK_BED)) return;
     chrom = p->bam->target_name[c->tid];
     fi = p->fa_of_tid[c->tid]; if(fi >= 0) { seq = p->fa.seq[fi]; slen = p->fa.len[fi]; }
     blank_from = c->beg;
@@ -1256,10 +1262,10 @@ int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
         if(o->min_opp_depth > 0 && s->var) {
             uint32_t noff = s->var[i].noff, nvar = s->var[i].nvar;
             if(noff >= (uint32_t)o->min_opp_depth && ((double)nvar) / ((double)noff) >= o->max_variant_frac) {
-                p->n_variant_positions++;
+                e->n_variant++;
                 if(o->merge && is_g) {
-                    if(type == 0 && p->lastcpg_tid == c->tid && p->lastcpg_pos == pos - 1) { p->lastcpg_m = 0; p->lastcpg_u = 0; }
-                    else if(type == 1 && p->lastchg_tid == c->tid && p->lastchg_pos == pos - 2) { p->lastchg_m = 0; p->lastchg_u = 0; }
+                    if(type == 0 && e->lastcpg_tid == c->tid && e->lastcpg_pos == pos - 1) { e->lastcpg_m = 0; e->lastcpg_u = 0; }
+                    else if(type == 1 && e->lastchg_tid == c->tid && e->lastchg_pos == pos - 2) { e->lastchg_m = 0; e->lastchg_u = 0; }
                 }
                 continue;
             }
@@ -1267,35 +1273,126 @@ int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
         if(m + u == 0 && !o->cytosine_report) continue;
         if(!o->merge || type == 2) {
             if(o->cytosine_report) {
-                put_blanks(p, chrom, seq, slen, &blank_from, pos);
-                put_site(p, &p->ob[0], chrom, pos, 1, m, u, !is_g, cctx_name(type), trinuc(seq, slen, pos, is_g ? -1 : 1, tri));
+                put_blanks(p, &e->ob[0], chrom, seq, slen, &blank_from, pos);
+                put_site(p, &e->ob[0], chrom, pos, 1, m, u, !is_g, cctx_name(type), trinuc(seq, slen, pos, is_g ? -1 : 1, tri));
                 blank_from = (int64_t)pos + 1;
-            } else put_site(p, &p->ob[type], chrom, pos, 1, m, u, !is_g, NULL, NULL);
+            } else put_site(p, &e->ob[type], chrom, pos, 1, m, u, !is_g, NULL, NULL);
         } else if(type == 0) {
             int32_t key = is_g ? pos - 1 : pos;
-            if(p->lastcpg_tid == c->tid && p->lastcpg_pos == key) { put_site(p, &p->ob[0], chrom, key, 2, m + p->lastcpg_m, u + p->lastcpg_u, !is_g, NULL, NULL); p->lastcpg_tid = -1; }
+            if(e->lastcpg_tid == c->tid && e->lastcpg_pos == key) { put_site(p, &e->ob[0], chrom, key, 2, m + e->lastcpg_m, u + e->lastcpg_u, !is_g, NULL, NULL); e->lastcpg_tid = -1; }
             else {
-                if(p->lastcpg_tid != -1) put_site(p, &p->ob[0], p->bam->target_name[p->lastcpg_tid], p->lastcpg_pos, 2, p->lastcpg_m, p->lastcpg_u, !is_g, NULL, NULL);
-                p->lastcpg_tid = c->tid; p->lastcpg_pos = key; p->lastcpg_m = m; p->lastcpg_u = u;
+                if(e->lastcpg_tid != -1) put_site(p, &e->ob[0], p->bam->target_name[e->lastcpg_tid], e->lastcpg_pos, 2, e->lastcpg_m, e->lastcpg_u, !is_g, NULL, NULL);
+                e->lastcpg_tid = c->tid; e->lastcpg_pos = key; e->lastcpg_m = m; e->lastcpg_u = u;
             }
         } else {
             int32_t key = is_g ? pos - 2 : pos;
-            if(p->lastchg_tid == c->tid && p->lastchg_pos == key) { put_site(p, &p->ob[1], chrom, key, 3, m + p->lastchg_m, u + p->lastchg_u, !is_g, NULL, NULL); p->lastchg_tid = -1; }
+            if(e->lastchg_tid == c->tid && e->lastchg_pos == key) { put_site(p, &e->ob[1], chrom, key, 3, m + e->lastchg_m, u + e->lastchg_u, !is_g, NULL, NULL); e->lastchg_tid = -1; }
             else {
-                if(p->lastchg_tid != -1) put_site(p, &p->ob[1], p->bam->target_name[p->lastchg_tid], p->lastchg_pos, 3, p->lastchg_m, p->lastchg_u, !is_g, NULL, NULL);
-                p->lastchg_tid = c->tid; p->lastchg_pos = key; p->lastchg_m = m; p->lastchg_u = u;
+                if(e->lastchg_tid != -1) put_site(p, &e->ob[1], p->bam->target_name[e->lastchg_tid], e->lastchg_pos, 3, e->lastchg_m, e->lastchg_u, !is_g, NULL, NULL);
+                e->lastchg_tid = c->tid; e->lastchg_pos = key; e->lastchg_m = m; e->lastchg_u = u;
             }
         }
     }
     if(o->merge) {      /* pending sites never cross a chunk boundary (extract.c:496-507) */
-        if(o->ctx_on[0] && p->lastcpg_tid != -1) { put_site(p, &p->ob[0], p->bam->target_name[p->lastcpg_tid], p->lastcpg_pos, 2, p->lastcpg_m, p->lastcpg_u, 1, NULL, NULL); p->lastcpg_tid = -1; }
-        if(o->ctx_on[1] && p->lastchg_tid != -1) { put_site(p, &p->ob[1], p->bam->target_name[p->lastchg_tid], p->lastchg_pos, 3, p->lastchg_m, p->lastchg_u, 1, NULL, NULL); p->lastchg_tid = -1; }
-    } else if(o->cytosine_report) put_blanks(p, chrom, seq, slen, &blank_from, c->end);
-    if(o->cytosine_report) { if(p->ob[0].l) { fputs(p->ob[0].s, p->out[0]); p->ob[0].l = 0; } }
-    else for(k = 0; k < 3; k++) if(o->ctx_on[k] && p->ob[k].l) { fputs(p->ob[k].s, p->out[k]); p->ob[k].l = 0; }
+        if(o->ctx_on[0] && e->lastcpg_tid != -1) { put_site(p, &e->ob[0], p->bam->target_name[e->lastcpg_tid], e->lastcpg_pos, 2, e->lastcpg_m, e->lastcpg_u, 1, NULL, NULL); e->lastcpg_tid = -1; }
+        if(o->ctx_on[1] && e->lastchg_tid != -1) { put_site(p, &e->ob[1], p->bam->target_name[e->lastchg_tid], e->lastchg_pos, 3, e->lastchg_m, e->lastchg_u, 1, NULL, NULL); e->lastchg_tid = -1; }
+    } else if(o->cytosine_report) put_blanks(p, &e->ob[0], chrom, seq, slen, &blank_from, c->end);
+}
+/* append a formatted chunk to the output files (ordered flush, extract.c:514-535) */
+static void emit_write(mdk_plan *p, emit_ctx *e) {
+    int k;
+    if(p->o.cytosine_report) { if(e->ob[0].l) fputs(e->ob[0].s, p->out[0]); }
+    else for(k = 0; k < 3; k++) if(p->o.ctx_on[k] && e->ob[k].l) fputs(e->ob[k].s, p->out[k]);
+    p->n_variant_positions += e->n_variant;
+}
+
+int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
+    double te0 = now_s();
+    if(c->index != p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
+    p->next_emit++;
+    emit_format(p, c, s, &p->ec);
+    emit_write(p, &p->ec);
     p->t_emit += now_s() - te0;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* extract_main's emitter: chunks are formatted by a few threads and written in chunk order          */
+/* ------------------------------------------------------------------------------------------------ */
+enum { EJ_FREE = 0, EJ_READY, EJ_BUSY };
+typedef struct { int state; mdk_chunk c; md_sites s; md_site *site; md_site_var *var; int64_t cap; emit_ctx e; } ejob;
+typedef struct {
+    mdk_plan *p; ejob *job; int n_job, n_th; pthread_t *th; pthread_mutex_t mu; pthread_cond_t cv_job, cv_free, cv_turn;
+    uint32_t next_write; int quit; double t_format;
+} emitter;
+static void *emitter_main(void *arg) {
+    emitter *E = arg;
+    for(;;) {
+        ejob *j = NULL; int i; double t0;
+        pthread_mutex_lock(&E->mu);
+        for(;;) {
+            for(i = 0; i < E->n_job; i++) if(E->job[i].state == EJ_READY && (!j || E->job[i].c.index < j->c.index)) j = &E->job[i];
+            if(j || E->quit) break;
+            pthread_cond_wait(&E->cv_job, &E->mu);
+        }
+        if(!j) { pthread_mutex_unlock(&E->mu); break; }
+        j->state = EJ_BUSY;
+        pthread_mutex_unlock(&E->mu);
+        t0 = now_s();
+        emit_format(E->p, &j->c, &j->s, &j->e);
+        pthread_mutex_lock(&E->mu);
+        E->t_format += now_s() - t0;
+        while(E->next_write != j->c.index) pthread_cond_wait(&E->cv_turn, &E->mu);
+        emit_write(E->p, &j->e);                 /* in turn, so under the lock: nobody else may write now anyway */
+        E->next_write++; j->state = EJ_FREE;
+        pthread_cond_broadcast(&E->cv_turn); pthread_cond_signal(&E->cv_free);
+        pthread_mutex_unlock(&E->mu);
+    }
+    return NULL;
+}
+static int emitter_start(emitter *E, mdk_plan *p, int n_th) {
+    int i;
+    memset(E, 0, sizeof(*E));
+    E->p = p; E->n_th = n_th < 1 ? 1 : n_th; E->n_job = E->n_th + 2; E->next_write = p->next_emit;
+    E->job = calloc((size_t)E->n_job, sizeof(ejob)); E->th = calloc((size_t)E->n_th, sizeof(pthread_t));
+    if(!E->job || !E->th) return -5;
+    pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv_job, NULL); pthread_cond_init(&E->cv_free, NULL); pthread_cond_init(&E->cv_turn, NULL);
+    for(i = 0; i < E->n_th; i++) pthread_create(&E->th[i], NULL, emitter_main, E);
+    return 0;
+}
+/* hand a chunk and its sites over (both are copied: the caller's buffers are recycled) */
+static int emitter_push(emitter *E, const mdk_chunk *c, const md_sites *s) {
+    ejob *j = NULL; int i;
+    if(c->index != E->p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
+    E->p->next_emit++;
+    pthread_mutex_lock(&E->mu);
+    for(;;) { for(i = 0; i < E->n_job; i++) if(E->job[i].state == EJ_FREE) { j = &E->job[i]; break; } if(j) break; pthread_cond_wait(&E->cv_free, &E->mu); }
+    j->state = EJ_BUSY;                          /* being filled */
+    pthread_mutex_unlock(&E->mu);
+    j->c = *c; j->s = *s;
+    if(s->n_sites > j->cap) {
+        j->cap = s->n_sites + s->n_sites / 4 + 1024; free(j->site); free(j->var);
+        j->site = malloc(sizeof(md_site) * (size_t)j->cap); j->var = malloc(sizeof(md_site_var) * (size_t)j->cap);
+        if(!j->site || !j->var) return -5;
+    }
+    if(s->n_sites) { memcpy(j->site, s->site, sizeof(md_site) * (size_t)s->n_sites); if(s->var) memcpy(j->var, s->var, sizeof(md_site_var) * (size_t)s->n_sites); }
+    j->s.site = j->site; j->s.var = s->var ? j->var : NULL;
+    pthread_mutex_lock(&E->mu); j->state = EJ_READY; pthread_cond_signal(&E->cv_job); pthread_mutex_unlock(&E->mu);
+    return 0;
+}
+static void emitter_stop(emitter *E) {
+    int i;
+    if(!E->th) return;
+    pthread_mutex_lock(&E->mu);
+    while(E->next_write != E->p->next_emit) pthread_cond_wait(&E->cv_turn, &E->mu);       /* everything handed over has been written */
+    E->quit = 1; pthread_cond_broadcast(&E->cv_job);
+    pthread_mutex_unlock(&E->mu);
+    for(i = 0; i < E->n_th; i++) pthread_join(E->th[i], NULL);
+    for(i = 0; i < E->n_job; i++) { int k; free(E->job[i].site); free(E->job[i].var); for(k = 0; k < 3; k++) free(E->job[i].e.ob[k].s); }
+    E->p->t_emit += E->t_format;
+    free(E->job); free(E->th); E->th = NULL;
+}
+
 
 int mdk_plan_finish(mdk_plan *p) {
     int i;
@@ -1322,7 +1419,7 @@ typedef struct { int device; md_dev_cfg cfg; md_dev *dev; int rc; } devopen_t;
 static void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); return NULL; }
 
 int extract_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth;
+    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; emitter em;
     double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta;
     rc = mdk_plan_open(argc, argv, &p);
     t_open = now_s() - T0;
@@ -1337,7 +1434,8 @@ int extract_main(int argc, char *argv[]) {
     t_dev = now_s() - T0;
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
-    /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then emit k-1 */
+    if(emitter_start(&em, p, p->o.n_threads >= 4 ? 4 : p->o.n_threads)) { md_dev_close(dev); mdk_plan_close(p); return -5; }
+    /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then hand k-1 to the emitter */
     while(more || have[0] || have[1]) {
         int cur = k & 1, prev = cur ^ 1;
         if(more) {
@@ -1367,13 +1465,14 @@ int extract_main(int argc, char *argv[]) {
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
             }
             ta = now_s();
-            if(mdk_plan_emit(p, &ch[prev], &sites)) { ret = MDK_RC_DEVICE; break; }
+            if(emitter_push(&em, &ch[prev], &sites)) { ret = MDK_RC_DEVICE; break; }
             w_emit += now_s() - ta;
             have[prev] = 0;
         }
         k++;
         if(!more && !have[0] && !have[1]) break;
     }
+    { double tw = now_s(); emitter_stop(&em); w_emit += now_s() - tw; }
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0);
     if(ret == 0) mdk_plan_finish(p);
     if(fast_exit_wanted()) {
@@ -1416,7 +1515,7 @@ int mdk_plan_open_mbias(int argc, char *argv[], mdk_plan **out) {
     o->mbias = 1; o->svg = 1;
     o->ctx_on[0] = 1; o->min_mapq = 10; o->min_phred = 5; o->min_depth = 1; o->ignore_flags = 0xF00; o->n_threads = 1; o->chunk_size = 1000000;
     p->shard_rank = 0; p->shard_world = 1;
-    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1; p->lastcpg_tid = -1; p->lastchg_tid = -1;
+    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1;
     optind = 1;
     while((c = getopt_long(argc, argv, "hvq:p:r:l:D:F:@:", longopts, NULL)) >= 0) {      /* NB no R: in the short options (MBias.c:353) */
         switch(c) {
@@ -1530,7 +1629,7 @@ int mdk_plan_open_perread(int argc, char *argv[], mdk_plan **out) {
     o->perread = 1;
     o->ctx_on[0] = 1; o->min_mapq = 10; o->min_phred = 5; o->min_depth = 1; o->ignore_flags = 0; o->n_threads = 1; o->chunk_size = 1000000;
     p->shard_rank = 0; p->shard_world = 1;
-    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1; p->lastcpg_tid = -1; p->lastchg_tid = -1;
+    p->last_tid = -1; p->last_pos = -1; p->carry_tid = -1;
     p->pr_out = stdout;
     optind = 1;
     while((c = getopt_long(argc, argv, "hvq:p:o:@:r:l:F:R:", longopts, NULL)) >= 0) {
