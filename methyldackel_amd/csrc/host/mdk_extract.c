@@ -1434,7 +1434,7 @@ int extract_main(int argc, char *argv[]) {
     t_dev = now_s() - T0;
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
-    if(emitter_start(&em, p, p->o.n_threads >= 4 ? 4 : p->o.n_threads)) { md_dev_close(dev); mdk_plan_close(p); return -5; }
+    if(emitter_start(&em, p, p->o.n_threads >= 8 ? 8 : p->o.n_threads)) { md_dev_close(dev); mdk_plan_close(p); return -5; }
     /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then hand k-1 to the emitter */
     while(more || have[0] || have[1]) {
         int cur = k & 1, prev = cur ^ 1;
