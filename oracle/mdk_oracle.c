@@ -525,9 +525,13 @@ static int getStrand(const brec *b) {                          /* common.c:84-11
 
 /* common.c:118-134 (and its twin getMethylState, 338-354) */
 static int methState(Config *config, const bam1 *b, int qpos) {
-    uint8_t base = seqi(b->seq, qpos);
+    uint8_t base;
     int strand = getStrand(b->r);
     if(strand == 0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
+    /* a record whose CIGAR consumes more query bases than it stores (SEQ '*', l_qseq 0) makes the reference read past its
+     * sequence and quality arrays; such a base is given no letter and quality 0 here */
+    if(qpos >= b->r->l_qseq) return 0;
+    base = seqi(b->seq, qpos);
     if(b->qual[qpos] < config->minPhred) return 0;
     if(base == 2 && (strand == 1 || strand == 3)) return 1;
     else if(base == 8 && (strand == 1 || strand == 3)) return -1;
@@ -925,7 +929,9 @@ static void processLast(kstr *ks, Config *config, struct lastCall *last, const b
     }
 }
 static int isVariant(Config *config, const pileup1 *plp, uint32_t *coverage, int strand) {   /* extract.c:225-239 */
-    uint8_t base = seqi(plp->b->seq, plp->qpos);
+    uint8_t base;
+    if(plp->qpos >= plp->b->r->l_qseq) return 0;          /* as in methState: no stored base */
+    base = seqi(plp->b->seq, plp->qpos);
     if(plp->b->qual[plp->qpos] < config->minPhred) return 0;
     *coverage += 1;
     if(strand & 1) { if(base != 4 && base != 15) return 1; else return 0; }
