@@ -1028,29 +1028,30 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
             if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
         }
     }
-    while((rc = mdk_bam_peek(bam, &r)) == 1) {
-        int32_t rlen, endp;
-        if(r.tid >= 0) {
-            if(r.tid < p->last_tid || (r.tid == p->last_tid && r.pos < p->last_pos)) { fprintf(stderr, "[mdk] %s is not coordinate sorted; `extract` needs sorted alignments\n", o->bam_name); return -2; }
-            if(r.tid > (int32_t)tid) break;
-            if(r.tid == (int32_t)tid && r.pos >= (int32_t)end) break;
-            p->last_tid = r.tid; p->last_pos = r.pos;
+    for(;;) {
+        mdk_rsum q; const uint8_t *raw;
+        rc = mdk_bam_peek_sum(bam, &q, &raw);
+        if(rc != 1) break;
+        if(q.tid >= 0) {
+            if(q.tid < p->last_tid || (q.tid == p->last_tid && q.pos < p->last_pos)) { fprintf(stderr, "[mdk] %s is not coordinate sorted; `extract` needs sorted alignments\n", o->bam_name); return -2; }
+            if(q.tid > (int32_t)tid) break;
+            if(q.tid == (int32_t)tid && q.pos >= (int32_t)end) break;
+            p->last_tid = q.tid; p->last_pos = q.pos;
         }
-        if(r.tid == (int32_t)tid) {
-            rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
+        if(q.tid == (int32_t)tid) {
             c->n_records_seen++;
-            if(endp > (int32_t)beg && collect) {          /* in place: extend the open range or start a new one */
+            if(q.endp > (int32_t)beg && collect) {          /* in place: extend the open range or start a new one */
                 size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
-                if(g && g->slab == cs && g->end == roff) g->end = roff + 4 + r.raw_len;
+                if(g && g->slab == cs && g->end == roff) g->end = roff + 4 + q.len;
                 else {
                     if(sl->n_rg == sl->cap_rg) { sl->cap_rg = sl->cap_rg ? sl->cap_rg * 2 : 16; sl->rg = realloc(sl->rg, sizeof(rrange) * sl->cap_rg); if(!sl->rg) return -5; }
-                    g = &sl->rg[sl->n_rg++]; g->slab = cs; g->beg = roff; g->end = roff + 4 + r.raw_len; mdk_slab_ref(bam, cs);
+                    g = &sl->rg[sl->n_rg++]; g->slab = cs; g->beg = roff; g->end = roff + 4 + q.len; mdk_slab_ref(bam, cs);
                 }
                 sl->n_stream++;
             }
-            if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
+            if((uint32_t)q.endp > end) { r.raw = raw; r.raw_len = q.len; if(carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5; }
         }
-        mdk_bam_advance(bam, &r);
+        mdk_bam_advance_sum(bam, &q);
     }
     if(rc < 0) { fprintf(stderr, "[mdk] error while reading %s: %s\n", o->bam_name, bam->err); return -2; }
     { uint8_t *t = p->carry; size_t tc = p->carry_cap; p->carry = p->carry2; p->carry_len = p->carry2_len; p->carry_cap = p->carry2_cap; p->carry2 = t; p->carry2_cap = tc; p->carry2_len = 0; p->carry_tid = (int32_t)tid; }
@@ -1396,7 +1397,7 @@ static void emitter_stop(emitter *E) {
 
 int mdk_plan_finish(mdk_plan *p) {
     int i;
-    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] inflate+frame+admit+pack %.3fs (inflate alone %.3fs)  pairing %.3fs  segments %.3fs  emit %.3fs\n", p->t_collect, p->bam->t_inflate, p->t_pair, p->t_segs, p->t_emit);
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] inflate+frame+admit+pack %.3fs (inflate alone %.3fs)  pairing %.3fs  segments %.3fs  emit %.3fs; records found in the inflate threads' tables %" PRIu64 ", by walking %" PRIu64 "\n", p->t_collect, p->bam->t_inflate, p->t_pair, p->t_segs, p->t_emit, p->bam->n_fast, p->bam->n_slow);
     if(p->n_variant_positions) printf("%" PRIu64 " positions were excluded due to likely being variants.\n", p->n_variant_positions);
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); p->out[0] = p->out[1] = p->out[2] = NULL; }
     else for(i = 0; i < 3; i++) if(p->out[i]) { fclose(p->out[i]); p->out[i] = NULL; }

@@ -13,22 +13,46 @@ static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-typedef struct { const uint8_t *in; uint32_t in_len; uint8_t *out; uint32_t out_len; } blk_t;
-typedef struct { blk_t *blk; int n; int next; int failed; pthread_mutex_t mu; } inflate_job;
+typedef struct { const uint8_t *in; uint32_t in_len; uint8_t *out; uint32_t out_len; int th; size_t sum0; uint32_t n_sum; int ok; } blk_t;
+typedef struct { mdk_rsum *v; size_t n, cap; } sumbuf;
+typedef struct { blk_t *blk; int n; int next; int failed; int n_th; int next_th; const uint8_t *base; sumbuf sb[64]; pthread_mutex_t mu; } inflate_job;
+
+/* walk one inflated member from its first byte (see mdk_io.h); the notes go to the calling thread's buffer */
+static void note_records(blk_t *b, sumbuf *sb, const uint8_t *base) {
+    const uint8_t *d = b->out; uint32_t L = b->out_len, o = 0;
+    b->sum0 = sb->n; b->n_sum = 0; b->ok = 0;
+    while(o + 4 <= L) {
+        uint32_t bs = le32(d + o), lq, nc, k; const uint8_t *r = d + o + 4, *c; int32_t rl = 0; mdk_rsum *q;
+        if(bs < 32 || (uint64_t)o + 4 + bs > L) return;
+        lq = r[8]; nc = le16(r + 12);
+        if(32u + lq + 4u * nc > bs) return;
+        c = r + 32 + lq;
+        for(k = 0; k < nc; k++) { uint32_t v = le32(c + 4 * k), op = v & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int32_t)(v >> 4); }
+        if(sb->n == sb->cap) { sb->cap = sb->cap ? sb->cap * 2 : 4096; sb->v = realloc(sb->v, sizeof(mdk_rsum) * sb->cap); if(!sb->v) { sb->cap = sb->n = 0; return; } }
+        q = &sb->v[sb->n++];
+        q->off = (uint32_t)(d + o - base); q->len = bs; q->tid = (int32_t)le32(r); q->pos = (int32_t)le32(r + 4); q->endp = q->pos + (rl > 0 ? rl : 1);
+        b->n_sum++;
+        o += 4 + bs;
+    }
+    b->ok = o == L;
+}
 
 static void *inflate_worker(void *arg) {
-    inflate_job *job = arg; z_stream zs; int inited = 0;
+    inflate_job *job = arg; z_stream zs; int inited = 0, me;
+    pthread_mutex_lock(&job->mu); me = job->next_th++; pthread_mutex_unlock(&job->mu);
     for(;;) {
         int i;
         pthread_mutex_lock(&job->mu); i = job->next; job->next += 8; pthread_mutex_unlock(&job->mu);
         if(i >= job->n) break;
         for(int k = i; k < i + 8 && k < job->n; k++) {
             blk_t *b = &job->blk[k];
+            b->th = me; b->sum0 = job->sb[me].n; b->n_sum = 0; b->ok = 1;      /* an empty member (the EOF marker) holds no record and ends where it starts */
             if(!b->out_len) continue;
             if(!inited) { memset(&zs, 0, sizeof(zs)); if(inflateInit2(&zs, -15) != Z_OK) { job->failed = 1; return NULL; } inited = 1; }
             else inflateReset(&zs);
             zs.next_in = (Bytef *)b->in; zs.avail_in = b->in_len; zs.next_out = b->out; zs.avail_out = b->out_len;
-            if(inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) job->failed = 1;
+            if(inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) { job->failed = 1; b->ok = 0; continue; }
+            note_records(b, &job->sb[me], job->base);
         }
     }
     if(inited) inflateEnd(&zs);
@@ -50,7 +74,7 @@ static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) {          /* inflater si
     pthread_mutex_unlock(&b->mu);
     if(!s) return NULL;
     if(s->cap < need_cap) { free(s->buf); s->cap = need_cap + (need_cap >> 3); s->buf = malloc(s->cap); if(!s->buf) { free(s); return NULL; } }
-    s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM;
+    s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM; s->n_mem = 0; s->n_sum = 0;
     return s;
 }
 void mdk_slab_ref(mdk_bam *b, mdk_slab *s) { pthread_mutex_lock(&b->mu); s->refs++; pthread_mutex_unlock(&b->mu); }
@@ -96,13 +120,31 @@ static mdk_slab *inflate_slab(mdk_bam *b, int *status) {          /* status: 0 o
     { size_t o = s->beg; for(int i = 0; i < nb; i++) { blk[i].out = s->buf + o; o += blk[i].out_len; } s->end = o; }
     {
         inflate_job job; int nt = b->nthreads, i; pthread_t th[64];
-        job.blk = blk; job.n = nb; job.next = 0; job.failed = 0; pthread_mutex_init(&job.mu, NULL);
+        memset(&job, 0, sizeof(job));
+        job.blk = blk; job.n = nb; job.next = 0; job.failed = 0; job.base = s->buf; pthread_mutex_init(&job.mu, NULL);
         if(nt > 64) nt = 64;
         if(nt > (nb + 7) / 8) nt = (nb + 7) / 8;
         if(nt < 1) nt = 1;
         if(nt == 1) inflate_worker(&job);
         else { for(i = 0; i < nt; i++) pthread_create(&th[i], NULL, inflate_worker, &job); for(i = 0; i < nt; i++) pthread_join(th[i], NULL); }
         pthread_mutex_destroy(&job.mu);
+        if(!job.failed) {      /* the notes of all members, in stream order, into the slab's table */
+            size_t tot = 0, o = 0;
+            for(i = 0; i < nb; i++) tot += blk[i].n_sum;
+            if(s->cap_sum < tot + 1) { free(s->sum); s->cap_sum = tot + tot / 8 + 1024; s->sum = malloc(sizeof(mdk_rsum) * s->cap_sum); }
+            if(s->cap_mem < nb) { free(s->mem); s->cap_mem = nb + 64; s->mem = malloc(sizeof(mdk_member) * (size_t)s->cap_mem); }
+            s->n_mem = 0; s->n_sum = 0;
+            if(s->sum && s->mem) {
+                for(i = 0; i < nb; i++) {
+                    mdk_member *m = &s->mem[i];
+                    m->off = (uint32_t)(blk[i].out - s->buf); m->n_sum = blk[i].n_sum; m->sum0 = (uint32_t)o; m->ok = blk[i].ok && (blk[i].n_sum == 0 || job.sb[blk[i].th].v != NULL);
+                    if(m->ok && m->n_sum) memcpy(s->sum + o, job.sb[blk[i].th].v + blk[i].sum0, sizeof(mdk_rsum) * m->n_sum);
+                    if(m->ok) o += m->n_sum; else m->n_sum = 0;
+                }
+                s->n_mem = nb; s->n_sum = o;
+            }
+        }
+        for(i = 0; i < 64; i++) free(job.sb[i].v);
         if(job.failed) { snprintf(b->err, sizeof(b->err), "BGZF inflate failed (corrupt file?)"); free(blk); mdk_slab_unref(b, s); *status = -2; return NULL; }
     }
     memmove(b->cbuf, b->cbuf + off, b->clen - off); b->clen -= off;
@@ -155,7 +197,7 @@ static int need(mdk_bam *b, size_t n) {
         if(left > s->beg) { snprintf(b->err, sizeof(b->err), "BAM record larger than %u bytes", MDK_SLAB_HEADROOM); mdk_slab_unref(b, s); return -2; }
         if(left) { memcpy(s->buf + s->beg - left, b->cur->buf + b->off, left); s->beg -= left; }
         if(b->cur) mdk_slab_unref(b, b->cur);
-        b->cur = s; b->off = s->beg;
+        b->cur = s; b->off = s->beg; b->mem_i = 0; b->sum_i = b->sum_end = 0;
     }
     return 1;
 }
@@ -197,9 +239,9 @@ void mdk_bam_close(mdk_bam *b) {
         pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
         pthread_join(b->inf_th, NULL);
     }
-    if(b->cur) { free(b->cur->buf); free(b->cur); }
-    for(i = 0; i < b->q_n; i++) { free(b->queue[i]->buf); free(b->queue[i]); }
-    for(i = 0; i < b->n_pool; i++) { free(b->pool[i]->buf); free(b->pool[i]); }
+    if(b->cur) { free(b->cur->buf); free(b->cur->sum); free(b->cur->mem); free(b->cur); }
+    for(i = 0; i < b->q_n; i++) { free(b->queue[i]->buf); free(b->queue[i]->sum); free(b->queue[i]->mem); free(b->queue[i]); }
+    for(i = 0; i < b->n_pool; i++) { free(b->pool[i]->buf); free(b->pool[i]->sum); free(b->pool[i]->mem); free(b->pool[i]); }
     free(b->pool);
     if(b->f) fclose(b->f);
     if(b->target_name) for(i = 0; i < b->n_targets; i++) free(b->target_name[i]);
@@ -240,6 +282,41 @@ int mdk_bam_peek(mdk_bam *b, mdk_rec *r) {
     return 1;
 }
 void mdk_bam_advance(mdk_bam *b, const mdk_rec *r) { b->off += 4 + (size_t)r->raw_len; b->n_records++; }
+
+int mdk_bam_peek_sum(mdk_bam *b, mdk_rsum *o, const uint8_t **raw) {
+    mdk_rec r; int rc, k;
+    for(;;) {
+        if(b->sum_i < b->sum_end) {                       /* inside an ok member: the inflating thread has been here already */
+            *o = b->cur->sum[b->sum_i]; *raw = b->cur->buf + o->off + 4;
+            return 1;
+        }
+        rc = need(b, 4);
+        if(rc <= 0) return rc;
+        {   /* does an ok member begin exactly here? */
+            mdk_slab *s = b->cur;
+            while(b->mem_i < s->n_mem && s->mem[b->mem_i].off < b->off) b->mem_i++;
+            if(b->mem_i < s->n_mem && s->mem[b->mem_i].off == b->off && s->mem[b->mem_i].ok) {
+                const mdk_member *m = &s->mem[b->mem_i++];
+                if(m->n_sum) { b->sum_i = m->sum0; b->sum_end = (size_t)m->sum0 + m->n_sum; }
+                continue;                                 /* an empty member: the next one starts at the same place */
+            }
+        }
+        break;
+    }
+    rc = mdk_bam_peek(b, &r);
+    if(rc <= 0) return rc;
+    {
+        int32_t rl = 0;
+        for(k = 0; k < r.n_cigar; k++) { uint32_t v = le32(r.cigar + 4 * k), op = v & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int32_t)(v >> 4); }
+        o->off = (uint32_t)(b->off); o->len = r.raw_len; o->tid = r.tid; o->pos = r.pos; o->endp = r.pos + (rl > 0 ? rl : 1);
+    }
+    *raw = r.raw;
+    return 1;
+}
+void mdk_bam_advance_sum(mdk_bam *b, const mdk_rsum *r) {
+    if(b->sum_i < b->sum_end) { b->sum_i++; b->n_fast++; } else b->n_slow++;
+    b->off = (size_t)r->off + 4 + (size_t)r->len; b->n_records++;
+}
 
 /* ---- BAI + seeking ---- */
 mdk_bai *mdk_bai_load(const char *bam_fn) {

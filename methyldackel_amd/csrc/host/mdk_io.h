@@ -13,7 +13,18 @@
  * the scanner hands [slab, begin, end) ranges to the chunks; a slab returns to the pool when its last user drops it.
  * A record cut by a slab boundary is completed in the headroom in front of the next slab's data. */
 #define MDK_SLAB_HEADROOM (16u << 20)
-typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs; } mdk_slab;
+/* Record summaries.  htslib never lets a BAM record straddle two BGZF members (bam_write1 flushes the block first when the
+ * record would not fit), so in the files this path normally sees every member starts on a record boundary.  The thread
+ * that inflates a member therefore also walks it from its first byte while the data is still in its cache, noting each
+ * record's place, contig, start and end; a member whose walk ends exactly at its last byte is `ok`.  When the scanner
+ * reaches the first byte of an ok member at a record boundary, the records of that member are exactly the ones noted
+ * (induction over the members), and it reads them from the table instead of chasing block_size words through memory
+ * that other cores have just written.  Any other file (records split across members) simply never matches and is
+ * scanned the slow way. */
+typedef struct { uint32_t off, len; int32_t tid, pos, endp; } mdk_rsum;          /* off: of the block_size word in the slab; len: block_size */
+typedef struct { uint32_t off, n_sum; uint32_t sum0; int ok; } mdk_member;     /* off: first byte in the slab; records sum[sum0 .. sum0+n_sum) */
+typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs;
+                          mdk_rsum *sum; size_t n_sum, cap_sum; mdk_member *mem; int n_mem, cap_mem; } mdk_slab;
 
 typedef struct mdk_bam {
     FILE *f;
@@ -26,6 +37,8 @@ typedef struct mdk_bam {
     uint8_t *cbuf; size_t ccap, clen; int file_eof;
     /* scanner position */
     mdk_slab *cur; size_t off;
+    int mem_i; size_t sum_i, sum_end;        /* next member to look at; records of the current ok member still to hand out */
+    uint64_t n_fast, n_slow;                 /* records taken from the tables / found by walking */
     int32_t n_targets; char **target_name; uint32_t *target_len;
     char *text; uint32_t l_text;
     uint64_t n_records;
@@ -53,6 +66,9 @@ void mdk_bam_abort(mdk_bam *b);
 /* 1 = record available, 0 = end of file, <0 = error (b->err) */
 int mdk_bam_peek(mdk_bam *b, mdk_rec *r);
 void mdk_bam_advance(mdk_bam *b, const mdk_rec *r);
+/* the same walk for callers that only need a record's place and extent: *raw = first byte after block_size */
+int mdk_bam_peek_sum(mdk_bam *b, mdk_rsum *r, const uint8_t **raw);
+void mdk_bam_advance_sum(mdk_bam *b, const mdk_rsum *r);
 /* decode a raw record (bytes after block_size) */
 int mdk_rec_parse(const uint8_t *raw, uint32_t len, mdk_rec *r);
 

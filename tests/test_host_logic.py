@@ -221,3 +221,26 @@ def test_chunk_larger_than_the_slab_pool(tmp_path, monkeypatch):
     assert c is not None and c.batch.n_reads > 300000
     assert plan.next_chunk() is None
     plan.close()
+
+
+def test_records_split_across_bgzf_members_take_the_walking_path(tmp_path):
+    """htslib never splits a record across BGZF members and the scanner then reads the inflate threads' record tables;
+    a file that does split them (--split-records) must be scanned by walking and give the same batches"""
+    import subprocess, sys
+    synth(tmp_path / "a", "-L", "60000", "-c", "25", "-s", "21")
+    synth(tmp_path / "b", "-L", "60000", "-c", "25", "-s", "21", "--split-records")
+    assert (tmp_path / "a.bam").read_bytes() != (tmp_path / "b.bam").read_bytes()
+    ca = check(tmp_path, [tmp_path / "a.fa", tmp_path / "a.bam", "--CHG", "--chunkSize", "7000"])
+    cb = check(tmp_path, [tmp_path / "b.fa", tmp_path / "b.bam", "--CHG", "--chunkSize", "7000"])
+    assert ca == cb
+    code = ("import sys; sys.path.insert(0, %r); import methyldackel_amd as mdk\n"
+            "p = mdk.Plan(sys.argv[1:])\nwhile p.next_chunk() is not None: pass\np.finish(); p.close()\n" % str(mdk.REPO))
+    def walked(prefix):
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / f"{prefix}.fa"), str(tmp_path / f"{prefix}.bam"), "-o", str(tmp_path / "x")],
+                           capture_output=True, text=True, env=dict(__import__("os").environ, MDK_HOST_PROFILE="1"))
+        line = [l for l in r.stderr.splitlines() if "by walking" in l][0]
+        return int(line.split("tables ")[1].split(",")[0]), int(line.split("by walking ")[1])
+    fast_a, slow_a = walked("a")
+    fast_b, slow_b = walked("b")
+    assert slow_a == 0 and fast_a > 5000
+    assert slow_b > 0.9 * (fast_b + slow_b)

@@ -172,16 +172,16 @@ static void emit_read(buf_t *out, const contig_t *ct, int tid, int64_t pos, cons
 }
 
 int main(int argc, char **argv) {
-    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {"no-bai", 0, 0, 7}, {0, 0, 0, 0}};
+    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {"no-bai", 0, 0, 7}, {"split-records", 0, 0, 8}, {0, 0, 0, 0}};
     const char *prefix = NULL, *lens = "1000000"; double cov = 30; uint64_t seed = 0x5EED0001ULL; int level = 1, c, want_bbm = 0;
-    opts_t o = {0, 0, 0, 0, 150}; int want_bw = 0, no_bai = 0; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
+    opts_t o = {0, 0, 0, 0, 150}; int want_bw = 0, no_bai = 0, split_records = 0; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
     buf_t pool = {0, 0, 0}; size_t *offs = NULL; char fn[4096]; uint64_t ord = 0, npairs_total = 0, nbases = 0;
     while((c = getopt_long(argc, argv, "o:L:c:l:s:z:", lo, NULL)) >= 0) {
         switch(c) {
         case 'o': prefix = optarg; break; case 'L': lens = optarg; break; case 'c': cov = atof(optarg); break;
         case 'l': o.readlen = atoi(optarg); break; case 's': seed = strtoull(optarg, NULL, 0); break; case 'z': level = atoi(optarg); break;
-        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break; case 7: no_bai = 1; break;
-        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [--bismark] [--extras] [--clean] [--bbm] [--bw] [--single]\n"); return 1;
+        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break; case 7: no_bai = 1; break; case 8: split_records = 1; break;
+        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [--bismark] [--extras] [--clean] [--bbm] [--bw] [--single] [--no-bai] [--split-records]\n"); return 1;
         }
     }
     if(!prefix) { fprintf(stderr, "mdk_synth: -o PREFIX is required\n"); return 1; }
@@ -268,6 +268,8 @@ int main(int argc, char **argv) {
           for(i = 0; i < nrec; i++) {
               uint64_t vo; int32_t tid = recs[i].tid, pos = recs[i].pos; int64_t w, w1; uint32_t ncig, k, rl = 0; const uint8_t *r = recs[i].d + 4;
               if(z.n + 4 > (int)sizeof(z.blk)) bgzf_flush(&z);          /* keep the block_size word inside one member */
+              /* as htslib does (bam_write1 -> bgzf_flush_try): a record that fits a member never straddles two */
+              if(!split_records && z.n && recs[i].n <= sizeof(z.blk) && z.n + recs[i].n > sizeof(z.blk)) bgzf_flush(&z);
               vo = (z.fpos << 16) | (uint64_t)z.n;
               ncig = r[12] | (r[13] << 8);
               for(k = 0; k < ncig; k++) { const uint8_t *c = r + 32 + r[8] + 4 * k; uint32_t cv = c[0] | (c[1] << 8) | (c[2] << 16) | ((uint32_t)c[3] << 24), op = cv & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cv >> 4; }
