@@ -87,39 +87,57 @@ void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
     pthread_mutex_unlock(&b->mu);
 }
 
-/* one slab: pull CCHUNK compressed bytes, inflate every complete BGZF member of them (fanned out to nthreads) */
-static mdk_slab *inflate_slab(mdk_bam *b, int *status) {          /* status: 0 ok, 1 end of file, <0 error */
-    size_t n, off = 0, total = 0; blk_t *blk = NULL; int nb = 0, mb = 0; mdk_slab *s;
-    *status = 0;
+/* a piece of the file: the complete BGZF members found in the read window, with the compressed bytes they live in */
+typedef struct { uint8_t *cbuf; blk_t *blk; int nb; size_t total; uint64_t seq; } piece;
+
+/* under io_mu: read CCHUNK more compressed bytes, list every complete member; the unfinished tail moves to a fresh window.
+ * status: 0 a piece was produced, 1 end of file, <0 error */
+static int next_piece(mdk_bam *b, piece *pc) {
+    size_t n, off = 0, total = 0; blk_t *blk = NULL; int nb = 0, mb = 0;
+    memset(pc, 0, sizeof(*pc));
     if(!b->file_eof) {
-        if(b->ccap < b->clen + CCHUNK) { b->ccap = b->clen + CCHUNK; b->cbuf = realloc(b->cbuf, b->ccap); if(!b->cbuf) { *status = -1; return NULL; } }
+        if(b->ccap < b->clen + CCHUNK) { b->ccap = b->clen + CCHUNK; b->cbuf = realloc(b->cbuf, b->ccap); if(!b->cbuf) return -1; }
         n = fread(b->cbuf + b->clen, 1, CCHUNK, b->f);
         b->clen += n;
         if(n < CCHUNK) b->file_eof = 1;
     }
     while(off + 18 <= b->clen) {
         const uint8_t *p = b->cbuf + off; uint16_t xlen; uint32_t bsize = 0, isize; size_t x; int have = 0;
-        if(p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { snprintf(b->err, sizeof(b->err), "not a BGZF file (bad gzip member header)"); free(blk); *status = -2; return NULL; }
+        if(p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { snprintf(b->err, sizeof(b->err), "not a BGZF file (bad gzip member header)"); free(blk); return -2; }
         xlen = le16(p + 10);
         if(off + 12 + xlen > b->clen) break;
         for(x = 12; x + 4 <= 12u + xlen;) { uint16_t sl = le16(p + x + 2); if(p[x] == 'B' && p[x + 1] == 'C' && sl == 2) { bsize = le16(p + x + 4) + 1u; have = 1; } x += 4 + sl; }
-        if(!have || bsize < 12u + xlen + 8u) { snprintf(b->err, sizeof(b->err), "BGZF member without a valid BC field"); free(blk); *status = -2; return NULL; }
+        if(!have || bsize < 12u + xlen + 8u) { snprintf(b->err, sizeof(b->err), "BGZF member without a valid BC field"); free(blk); return -2; }
         if(off + bsize > b->clen) break;
         isize = le32(p + bsize - 4);
-        if(nb == mb) { mb = mb ? mb * 2 : 1024; blk = realloc(blk, sizeof(blk_t) * mb); if(!blk) { *status = -1; return NULL; } }
+        if(nb == mb) { mb = mb ? mb * 2 : 1024; blk = realloc(blk, sizeof(blk_t) * mb); if(!blk) return -1; }
         blk[nb].in = p + 12 + xlen; blk[nb].in_len = bsize - 12 - xlen - 8; blk[nb].out = NULL; blk[nb].out_len = isize; nb++;
         total += isize; off += bsize;
     }
     if(nb == 0) {
         free(blk);
-        if(b->file_eof) { if(b->clen) { snprintf(b->err, sizeof(b->err), "truncated BGZF member at end of file"); *status = -2; } else *status = 1; return NULL; }
-        snprintf(b->err, sizeof(b->err), "BGZF member larger than the read window"); *status = -2; return NULL;
+        if(b->file_eof) { if(b->clen) { snprintf(b->err, sizeof(b->err), "truncated BGZF member at end of file"); return -2; } return 1; }
+        snprintf(b->err, sizeof(b->err), "BGZF member larger than the read window"); return -2;
     }
-    s = slab_get(b, MDK_SLAB_HEADROOM + total + 64);
-    if(!s) { free(blk); *status = b->quit ? 1 : -1; return NULL; }
+    {   /* the piece keeps this window; the tail that belongs to the next member starts a new one */
+        size_t left = b->clen - off; uint8_t *nw = malloc(left + CCHUNK + 64);
+        if(!nw) { free(blk); return -1; }
+        memcpy(nw, b->cbuf + off, left);
+        pc->cbuf = b->cbuf; b->cbuf = nw; b->ccap = left + CCHUNK + 64; b->clen = left;
+    }
+    pc->blk = blk; pc->nb = nb; pc->total = total;
+    return 0;
+}
+
+/* inflate the members of a piece into a slab (fanned out to nthreads) and gather the record tables */
+static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status) {
+    blk_t *blk = pc->blk; int nb = pc->nb; mdk_slab *s;
+    *status = 0;
+    s = slab_get(b, MDK_SLAB_HEADROOM + pc->total + 64);
+    if(!s) { *status = b->quit ? 1 : -1; return NULL; }
     { size_t o = s->beg; for(int i = 0; i < nb; i++) { blk[i].out = s->buf + o; o += blk[i].out_len; } s->end = o; }
     {
-        inflate_job job; int nt = b->nthreads, i; pthread_t th[64];
+        inflate_job job; int nt = nthreads, i; pthread_t th[64];
         memset(&job, 0, sizeof(job));
         job.blk = blk; job.n = nb; job.next = 0; job.failed = 0; job.base = s->buf; pthread_mutex_init(&job.mu, NULL);
         if(nt > 64) nt = 64;
@@ -145,30 +163,53 @@ static mdk_slab *inflate_slab(mdk_bam *b, int *status) {          /* status: 0 o
             }
         }
         for(i = 0; i < 64; i++) free(job.sb[i].v);
-        if(job.failed) { snprintf(b->err, sizeof(b->err), "BGZF inflate failed (corrupt file?)"); free(blk); mdk_slab_unref(b, s); *status = -2; return NULL; }
+        if(job.failed) { pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "BGZF inflate failed (corrupt file?)"); pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, s); *status = -2; return NULL; }
     }
-    memmove(b->cbuf, b->cbuf + off, b->clen - off); b->clen -= off;
-    free(blk);
     return s;
 }
 
 static void *inflater_main(void *arg) {
     mdk_bam *b = arg;
     for(;;) {
-        int st; mdk_slab *s = inflate_slab(b, &st);
+        piece pc; int st; mdk_slab *s = NULL;
+        pthread_mutex_lock(&b->io_mu);
+        if(b->io_status) { pthread_mutex_unlock(&b->io_mu); break; }              /* another team has seen the end (or an error) */
+        st = next_piece(b, &pc);
+        if(st == 0) pc.seq = b->next_seq++; else b->io_status = st;
+        pthread_mutex_unlock(&b->io_mu);
+        if(st == 0) { s = inflate_piece(b, &pc, b->team_threads, &st); free(pc.cbuf); free(pc.blk); }
         pthread_mutex_lock(&b->mu);
         if(s) {
-            while(b->q_n == 4 && !b->quit) pthread_cond_wait(&b->cv_pool, &b->mu);
-            if(b->quit) { pthread_mutex_unlock(&b->mu); break; }
-            b->queue[b->q_n++] = s; pthread_cond_broadcast(&b->cv_q);
+            while(b->push_seq != pc.seq && !b->quit) pthread_cond_wait(&b->cv_turn, &b->mu);
+            while(b->q_n == (int)(sizeof(b->queue) / sizeof(b->queue[0])) && !b->quit) pthread_cond_wait(&b->cv_pool, &b->mu);
+            if(b->quit) { pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, s); break; }
+            b->queue[b->q_n++] = s; b->push_seq++;
+            pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_turn);
             pthread_mutex_unlock(&b->mu);
             continue;
         }
-        b->inf_done = st < 0 ? st : 1; pthread_cond_broadcast(&b->cv_q);
+        /* end of file or an error: report it once everything handed out before has been queued */
+        if(st < 0) { if(!b->inf_done || b->inf_done == 1) b->inf_done = st; pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_turn); pthread_mutex_unlock(&b->mu); break; }
+        while(b->push_seq != b->next_seq && !b->quit && b->inf_done >= 0) pthread_cond_wait(&b->cv_turn, &b->mu);
+        if(!b->inf_done) b->inf_done = 1;
+        pthread_cond_broadcast(&b->cv_q);
         pthread_mutex_unlock(&b->mu);
         break;
     }
     return NULL;
+}
+static void inflaters_start(mdk_bam *b) {
+    int i;
+    b->next_seq = b->push_seq = 0; b->io_status = 0;
+    for(i = 0; i < b->n_teams; i++) pthread_create(&b->inf_th[i], NULL, inflater_main, b);
+    b->inf_started = 1;
+}
+static void inflaters_stop(mdk_bam *b) {
+    int i;
+    if(!b->inf_started) return;
+    pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_turn); pthread_mutex_unlock(&b->mu);
+    for(i = 0; i < b->n_teams; i++) pthread_join(b->inf_th[i], NULL);
+    b->inf_started = 0;
 }
 
 /* scanner side: next inflated slab (blocking); NULL at end of data or on error (b->inf_done < 0) */
@@ -210,8 +251,11 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     b->nthreads = nthreads < 1 ? 1 : nthreads;
     b->max_alloc = b->nthreads * 2 + 8;           /* how far the inflater may run ahead of the consumers, in slabs */
     if(getenv("MDK_SLAB_CAP")) b->max_alloc = atoi(getenv("MDK_SLAB_CAP")) > 1 ? atoi(getenv("MDK_SLAB_CAP")) : 2;
-    pthread_mutex_init(&b->mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL);
-    pthread_create(&b->inf_th, NULL, inflater_main, b); b->inf_started = 1;
+    pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL); pthread_cond_init(&b->cv_turn, NULL);
+    b->n_teams = b->nthreads >= 32 ? 4 : b->nthreads >= 8 ? 2 : 1;
+    if(getenv("MDK_INFLATE_TEAMS")) { b->n_teams = atoi(getenv("MDK_INFLATE_TEAMS")); if(b->n_teams < 1) b->n_teams = 1; if(b->n_teams > 8) b->n_teams = 8; }
+    b->team_threads = (b->nthreads + b->n_teams - 1) / b->n_teams;
+    inflaters_start(b);
     if((rc = need(b, 12)) <= 0 || memcmp(b->cur->buf + b->off, "BAM\1", 4)) { mdk_bam_close(b); return NULL; }
     b->l_text = le32(b->cur->buf + b->off + 4);
     if(need(b, 12 + (size_t)b->l_text) <= 0) { mdk_bam_close(b); return NULL; }
@@ -235,10 +279,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
 void mdk_bam_close(mdk_bam *b) {
     int i;
     if(!b) return;
-    if(b->inf_started) {
-        pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
-        pthread_join(b->inf_th, NULL);
-    }
+    inflaters_stop(b);
     if(b->cur) { free(b->cur->buf); free(b->cur->sum); free(b->cur->mem); free(b->cur); }
     for(i = 0; i < b->q_n; i++) { free(b->queue[i]->buf); free(b->queue[i]->sum); free(b->queue[i]->mem); free(b->queue[i]); }
     for(i = 0; i < b->n_pool; i++) { free(b->pool[i]->buf); free(b->pool[i]->sum); free(b->pool[i]->mem); free(b->pool[i]); }
@@ -246,13 +287,13 @@ void mdk_bam_close(mdk_bam *b) {
     if(b->f) fclose(b->f);
     if(b->target_name) for(i = 0; i < b->n_targets; i++) free(b->target_name[i]);
     free(b->target_name); free(b->target_len); free(b->text); free(b->cbuf);
-    pthread_mutex_destroy(&b->mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool);
+    pthread_mutex_destroy(&b->mu); pthread_mutex_destroy(&b->io_mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool); pthread_cond_destroy(&b->cv_turn);
     free(b);
 }
 
 void mdk_bam_abort(mdk_bam *b) {
     if(!b) return;
-    pthread_mutex_lock(&b->mu); b->quit = 1; if(!b->inf_done) b->inf_done = 1; pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_pool); pthread_mutex_unlock(&b->mu);
+    pthread_mutex_lock(&b->mu); b->quit = 1; if(!b->inf_done) b->inf_done = 1; pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_turn); pthread_mutex_unlock(&b->mu);
 }
 
 mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off) { *off = b->off; return b->cur; }
@@ -367,17 +408,14 @@ uint64_t mdk_bai_start(const mdk_bai *x, int32_t tid, int64_t beg) {
 
 int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
     int i;
-    if(b->inf_started) {
-        pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
-        pthread_join(b->inf_th, NULL); b->inf_started = 0;
-    }
+    inflaters_stop(b);
     pthread_mutex_lock(&b->mu);
     for(i = 0; i < b->q_n; i++) { if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = realloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); } b->pool[b->n_pool++] = b->queue[i]; }
     b->q_n = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
     pthread_mutex_unlock(&b->mu);
     if(b->cur) { mdk_slab_unref(b, b->cur); b->cur = NULL; }
     if(fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET)) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; }
-    pthread_create(&b->inf_th, NULL, inflater_main, b); b->inf_started = 1;
+    inflaters_start(b);
     if((voffset & 0xffff) || 1) {
         int rc = need(b, (size_t)(voffset & 0xffff) + 1);
         if(rc < 0) return rc;

@@ -29,10 +29,13 @@ typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs;
 typedef struct mdk_bam {
     FILE *f;
     int nthreads;
-    /* inflater thread + slab queue/pool */
-    pthread_t inf_th; int inf_started;
-    pthread_mutex_t mu; pthread_cond_t cv_q, cv_pool;
-    mdk_slab *queue[4]; int q_n; int inf_done, quit;
+    /* inflater teams + slab queue/pool.  A team takes the next piece of the file under io_mu (read + member headers: serial
+     * and cheap), inflates it with its share of the threads while another team is already reading the following piece,
+     * and queues the slab when its turn comes (seq order) */
+    pthread_t inf_th[8]; int n_teams, team_threads, inf_started;
+    pthread_mutex_t mu, io_mu; pthread_cond_t cv_q, cv_pool, cv_turn;
+    uint64_t next_seq, push_seq; int io_status;     /* pieces handed out / slabs queued; 0 reading, 1 end of file, <0 error */
+    mdk_slab *queue[8]; int q_n; int inf_done, quit;
     mdk_slab **pool; int n_pool, cap_pool, n_alloc, max_alloc;
     uint8_t *cbuf; size_t ccap, clen; int file_eof;
     /* scanner position */
