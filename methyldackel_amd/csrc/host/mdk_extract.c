@@ -105,7 +105,7 @@ struct mdk_plan {
     /* outputs */
     FILE *out[3]; sbuf ob[3]; emit_ctx ec;
     uint32_t next_emit;
-    double t_collect, t_pair, t_segs, t_emit;      /* MDK_HOST_PROFILE=1: seconds per host stage */
+    double t_collect, t_pair, t_segs, t_emit, t_rfill, t_rwait, t_widle, t_wbusy;      /* MDK_HOST_PROFILE=1: seconds per host stage */
     /* device references already uploaded: (dev handle, tid) pairs */
     md_dev **ref_dev; int32_t *ref_tid; int n_ref, cap_ref;
 };
@@ -1110,14 +1110,16 @@ static int worker_process(mdk_plan *p, pslot *sl) {
 static void *reader_main(void *arg) {
     mdk_plan *p = arg;
     for(;;) {
-        pslot *sl = NULL; int i, rc;
+        pslot *sl = NULL; int i, rc; double t0 = now_s(), t1;
         pthread_mutex_lock(&p->mu);
         while(!p->quit) { for(i = 0; i < p->n_slot; i++) if(p->slot[i].state == S_FREE) { sl = &p->slot[i]; break; } if(sl) break; pthread_cond_wait(&p->cv_free, &p->mu); }
         if(p->quit) { pthread_mutex_unlock(&p->mu); break; }
         sl->state = S_FILL;
         pthread_mutex_unlock(&p->mu);
+        t1 = now_s();
         rc = reader_fill(p, sl);
         pthread_mutex_lock(&p->mu);
+        p->t_rwait += t1 - t0; p->t_rfill += now_s() - t1;
         if(rc == 1) { sl->state = S_RAW; pthread_cond_signal(&p->cv_raw); }
         else { sl->state = S_FREE; if(rc < 0) p->pipe_rc = rc; p->reader_done = 1; pthread_cond_broadcast(&p->cv_raw); pthread_cond_broadcast(&p->cv_done); }
         pthread_mutex_unlock(&p->mu);
@@ -1128,7 +1130,7 @@ static void *reader_main(void *arg) {
 static void *worker_main(void *arg) {
     mdk_plan *p = arg;
     for(;;) {
-        pslot *sl = NULL; int i, rc; uint32_t best = 0;
+        pslot *sl = NULL; int i, rc; uint32_t best = 0; double tw0 = now_s();
         pthread_mutex_lock(&p->mu);
         for(;;) {
             sl = NULL;
@@ -1137,10 +1139,12 @@ static void *worker_main(void *arg) {
             pthread_cond_wait(&p->cv_raw, &p->mu);
         }
         if(!sl) { pthread_mutex_unlock(&p->mu); break; }       /* nothing left and the reader has finished (or we are quitting) */
-        sl->state = S_WORK;
+        sl->state = S_WORK; p->t_widle += now_s() - tw0;
         pthread_mutex_unlock(&p->mu);
+        tw0 = now_s();
         rc = worker_process(p, sl);
         pthread_mutex_lock(&p->mu);
+        p->t_wbusy += now_s() - tw0;
         sl->rc = rc; sl->state = S_DONE; if(rc < 0 && !p->pipe_rc) p->pipe_rc = rc;
         pthread_cond_broadcast(&p->cv_done);
         pthread_mutex_unlock(&p->mu);
@@ -1397,7 +1401,7 @@ static void emitter_stop(emitter *E) {
 
 int mdk_plan_finish(mdk_plan *p) {
     int i;
-    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] inflate+frame+admit+pack %.3fs (inflate alone %.3fs)  pairing %.3fs  segments %.3fs  emit %.3fs; records found in the inflate threads' tables %" PRIu64 ", by walking %" PRIu64 "\n", p->t_collect, p->bam->t_inflate, p->t_pair, p->t_segs, p->t_emit, p->bam->n_fast, p->bam->n_slow);
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] inflate+frame+admit+pack %.3fs (inflate alone %.3fs)  pairing %.3fs  segments %.3fs  emit %.3fs; records found in the inflate threads' tables %" PRIu64 ", by walking %" PRIu64 "; reader: scanning %.3fs, waiting for a free slot %.3fs; workers busy %.3fs idle %.3fs (sum over %d)\n", p->t_collect, p->bam->t_inflate, p->t_pair, p->t_segs, p->t_emit, p->bam->n_fast, p->bam->n_slow, p->t_rfill, p->t_rwait, p->t_wbusy, p->t_widle, p->n_workers);
     if(p->n_variant_positions) printf("%" PRIu64 " positions were excluded due to likely being variants.\n", p->n_variant_positions);
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); p->out[0] = p->out[1] = p->out[2] = NULL; }
     else for(i = 0; i < 3; i++) if(p->out[i]) { fclose(p->out[i]); p->out[i] = NULL; }
