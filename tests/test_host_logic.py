@@ -239,7 +239,7 @@ def test_records_split_across_bgzf_members_take_the_walking_path(tmp_path):
         r = subprocess.run([sys.executable, "-c", code, str(tmp_path / f"{prefix}.fa"), str(tmp_path / f"{prefix}.bam"), "-o", str(tmp_path / "x")],
                            capture_output=True, text=True, env=dict(__import__("os").environ, MDK_HOST_PROFILE="1"))
         line = [l for l in r.stderr.splitlines() if "by walking" in l][0]
-        return int(line.split("tables ")[1].split(",")[0]), int(line.split("by walking ")[1])
+        return int(line.split("tables ")[1].split(",")[0]), int(line.split("by walking ")[1].split(";")[0])
     fast_a, slow_a = walked("a")
     fast_b, slow_b = walked("b")
     assert slow_a == 0 and fast_a > 5000
