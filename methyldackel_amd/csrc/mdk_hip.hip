@@ -42,7 +42,6 @@
 #define PERMAX 4                   // reference positions owned by one thread: tile = WG * per, per <= PERMAX
 #define MAX_TILE (WG * PERMAX)
 #define RING 64                    // site counters: launch i uses counter i%RING and clears the next one
-#define BLOB_PAD 64                // bytes kept free in front of and behind the uploaded read payload
 #define LDS_LIMIT 163840          // 160 KiB per CU / per workgroup on gfx950
 
 static thread_local char g_err[512] = "";
@@ -66,7 +65,6 @@ struct KParams {
     int keepmask, minPhred;
     int bounds[16], abounds[16];
     int *err;
-    int regions;                  // some context code of this contig carries a region strand code (md_dev_set_regions was used)
     int mbias; uint32_t *hist; int hist_lq;     // mbias: window-relative contexts at the chunk edges; histogram rows [q][16]; rows kept in LDS
     unsigned long long *dbg;      // optional phase timestamps: 8 words per workgroup (MDK_PHASES=1)
 };
@@ -146,19 +144,10 @@ __global__ __launch_bounds__(WG) void k_mask_regions(uint8_t *code, int64_t n, c
     }
 }
 
-// Two ways for a lane to go through its segment.
-// KB_SPARSE (CpG-only runs, a handful of positions per segment): look the positions up in the tile's sorted C / G lists and
-// fetch, KB positions at a time, just the bytes they need (own + partner, all in flight together).
-// KB_DENSE (CHG/CHH wanted, ~30 positions of its strand in a 150-base segment): a byte load per position keeps the
-// load unit busy with 64 different cache lines per instruction (70 us on S1 however many are in flight); instead the
-// segment is read in windows of 16 query bases -- 8 sequence bytes and 16 quality bytes per load pair, dword-aligned
-// because the windows are aligned in the read -- and the positions to count come from bitmaps of the tile's C and G
-// context positions in LDS.
-#define KB_SPARSE 2
-#define KB_DENSE 0
+#define KB 2      // positions per batch: their base/qual bytes (own + partner) are all in flight together
 
 // One segment, one lane.
-template <bool VARIANT, int KB>
+template <bool VARIANT>
 __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int T0, int T1,
                                          const uint16_t *listC, int nC, const uint16_t *listG, int nG,
                                          uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv) {
@@ -284,142 +273,14 @@ __device__ __forceinline__ void build_lists(const KParams &P, int PER, int tid, 
     lds_barrier();
 }
 
-
-// ---- window mode (KB_DENSE) ----
-// bitmaps of the tile in LDS: bit i of bm[1 + i/32] = position T0+i; one zero guard word on each side
-#define BMW(tile) ((tile) / 32 + 2)
-__device__ __forceinline__ uint32_t bits16(const uint32_t *bm, int off) {      // bits [off, off+16), off >= -16
-    const int w = (off >> 5) + 1;
-    return __builtin_amdgcn_alignbit(bm[w + 1], bm[w], (uint32_t)(off & 31)) & 0xffffu;
-}
-__device__ __forceinline__ uint32_t swap_nibbles(uint32_t x) { return ((x & 0x0f0f0f0fu) << 4) | ((x >> 4) & 0x0f0f0f0fu); }   // BAM stores the first base of a byte in the high nibble
-__device__ __forceinline__ uint32_t range16(int a, int b) {                    // bits [a, b) of a 16-bit window
-    a = a < 0 ? 0 : a; b = b > 16 ? 16 : b;
-    return a < b ? ((0xffffu >> (16 - (b - a))) << a) : 0u;
-}
-
 template <bool VARIANT>
-__device__ __forceinline__ void lane_seg_dense(const KParams &P, const md_seg &g, int T0, int T1,
-                                               const uint32_t *bmC, const uint32_t *bmG, const uint32_t *bmPlus, const uint32_t *bmMinus,
-                                               uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv) {
-    const int send = g.rpos + (int)g.len;
-    if(g.rpos >= T1 || send <= T0) return;
-    const int strand = g.sf & MDK_SF_STRAND;
-    const bool odd = strand & 1, second = (g.sf & MDK_SF_SECOND) != 0, partner = (g.sf & MDK_SF_PARTNER) != 0;
-    const RD o = make_rd(P, g.off4, g.l_qseq, strand, g.sf & MDK_SF_READ2);
-    RD m = o;
-    if(partner) m = make_rd(P, g.m_off4, g.m_l_qseq, g.msf & MDK_SF_STRAND, g.msf & MDK_SF_READ2);
-    const int lo_pos = g.rpos > T0 ? g.rpos : T0, hi_pos = send < T1 ? send : T1;
-    // query indices of the part of the segment that lies on the tile, and of that the part that survives trimming
-    const int qa = (int)g.q0 + (lo_pos - g.rpos), qb = (int)g.q0 + (hi_pos - g.rpos);
-    const int ca = qa > o.lo ? qa : o.lo, cb = qb < o.hi ? qb : o.hi;       // own base visible
-    const uint32_t *bmOwn = odd ? bmC : bmG, *bmOpp = odd ? bmG : bmC;
-    const uint32_t *bmBad = strand == 0 ? nullptr : (odd ? bmMinus : bmPlus);   // region strand codes this read is invisible at (bed.c:56-64)
-    for(int qs = qa & ~15; qs < qb; qs += 16) {
-        const int boff = (qs - (int)g.q0) + g.rpos - T0;                  // tile offset of query index qs
-        uint32_t own = bits16(bmOwn, boff), opp = VARIANT ? bits16(bmOpp, boff) : 0u;
-        const uint32_t inseg = range16(qa - qs, qb - qs);
-        own &= inseg; opp &= inseg;
-        if(P.regions) {
-            const uint32_t bad = strand == 0 ? (bits16(bmPlus, boff) | bits16(bmMinus, boff)) : bits16(bmBad, boff);
-            own &= ~bad; opp &= ~bad;
-        }
-        if(!(own | opp)) continue;
-        if(own && strand == 0) atomicExch(P.err, 1);                       // reference: assert(strand != 0) (common.c:122-125)
-        const uint32_t vis = range16(ca - qs, cb - qs);                   // trimmed bases read as N with quality 0: they count for nothing
-        // the window's bytes: own sequence (8) and qualities (16), dword aligned; the partner's are not (realigned below)
-        uint32_t s0 = 0xffffffffu, s1 = 0xffffffffu, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-        uint32_t ms0 = 0xffffffffu, ms1 = 0xffffffffu, mq0 = 0, mq1 = 0, mq2 = 0, mq3 = 0;
-        if((own | opp) & vis) {
-            const uint32_t *sp = (const uint32_t *)(o.seq + (qs >> 1)), *qp = (const uint32_t *)(o.qual + qs);
-            s0 = sp[0]; s1 = sp[1]; q0 = qp[0]; q1 = qp[1]; q2 = qp[2]; q3 = qp[3];
-        }
-        uint32_t mvis = 0;
-        if(partner) {
-            const int mqs = (int)g.m_q0 + (qs - (int)g.q0);               // partner query index facing own index qs (may lie before its first base)
-            mvis = range16(m.lo - mqs, m.hi - mqs);
-            if((own | opp) & mvis) {
-                const int nb = mqs >> 1;                                   // byte holding nibble mqs (arithmetic shift: mqs >= -15)
-                const uint32_t *sp = (const uint32_t *)(m.seq + (nb & ~3)), *qp = (const uint32_t *)(m.qual + (mqs & ~3));
-                const uint32_t a0 = swap_nibbles(sp[0]), a1 = swap_nibbles(sp[1]), a2 = swap_nibbles(sp[2]);
-                const uint32_t sh = (uint32_t)(mqs - 2 * (nb & ~3)) * 4u;  // 0..28: nibble of mqs inside the three dwords
-                ms0 = __builtin_amdgcn_alignbit(a1, a0, sh); ms1 = __builtin_amdgcn_alignbit(a2, a1, sh);
-                const uint32_t b0 = qp[0], b1 = qp[1], b2 = qp[2], b3 = qp[3], b4 = qp[4], bs = (uint32_t)(mqs & 3) * 8u;
-                mq0 = __builtin_amdgcn_alignbit(b1, b0, bs); mq1 = __builtin_amdgcn_alignbit(b2, b1, bs); mq2 = __builtin_amdgcn_alignbit(b3, b2, bs); mq3 = __builtin_amdgcn_alignbit(b4, b3, bs);
-            }
-        }
-        s0 = swap_nibbles(s0); s1 = swap_nibbles(s1);
-#pragma unroll
-        for(int j = 0; j < 16; j++) {
-            const uint32_t bit = 1u << j;
-            if(!((own | opp) & bit)) continue;
-            int bq = 15, ql = 0;
-            if(vis & bit) { bq = (int)(((j < 8 ? s0 : s1) >> (4 * (j & 7))) & 15u); ql = (int)(((j < 4 ? q0 : j < 8 ? q1 : j < 12 ? q2 : q3) >> (8 * (j & 3))) & 255u); }
-            if(partner) {
-                int mb = 15, mq = 0;
-                if(mvis & bit) { mb = (int)(((j < 8 ? ms0 : ms1) >> (4 * (j & 7))) & 15u); mq = (int)(((j < 4 ? mq0 : j < 8 ? mq1 : j < 12 ? mq2 : mq3) >> (8 * (j & 3))) & 255u); }
-                ql = resolve_overlap(second, bq, ql, mb, mq);
-            }
-            if(ql < P.minPhred) continue;
-            const int off = boff + j;
-            if(own & bit) {
-                if(odd) { if(bq == 2) atomicAdd(&cm[off], 1u); else if(bq == 8) atomicAdd(&cu[off], 1u); }
-                else { if(bq == 4) atomicAdd(&cm[off], 1u); else if(bq == 1) atomicAdd(&cu[off], 1u); }
-            } else if(VARIANT) {
-                atomicAdd(&co[off], 1u);
-                if(odd ? (bq != 4 && bq != 15) : (bq != 2 && bq != 15)) atomicAdd(&cv[off], 1u);
-            }
-        }
-    }
-}
-
-// the tile's context bitmaps from the per-thread codes; returns the number of kept context positions of the tile
-__device__ __forceinline__ int build_bitmaps(const KParams &P, int TILE, int PER, int tid, int lane, const int (&code)[PERMAX],
-                                             uint32_t *bmC, uint32_t *bmG, uint32_t *bmPlus, uint32_t *bmMinus, int *skept) {
-    const int nw = BMW(TILE);
-    for(int i = tid; i < nw; i += WG) { bmC[i] = 0; bmG[i] = 0; if(P.regions) { bmPlus[i] = 0; bmMinus[i] = 0; } }
-    if(tid == 0) *skept = 0;
-    lds_barrier();
-    uint32_t c = 0, gbits = 0, pl = 0, mi = 0; int kept = 0;
-#pragma unroll
-    for(int j = 0; j < PERMAX; j++) {
-        if(j < PER && code[j]) {
-            kept++;
-            if((code[j] - 1) & 1) gbits |= 1u << j; else c |= 1u << j;
-            const int rs = code[j] >> 4;
-            if(rs == 1) pl |= 1u << j; else if(rs == 2) mi |= 1u << j;
-        }
-    }
-    {   // a thread's PER (<= 4) positions can straddle two words when PER does not divide 32 (tile 1536: PER 3)
-        const int i = tid * PER, w = (i >> 5) + 1, sh = i & 31;
-        const uint64_t c2 = (uint64_t)c << sh, g2 = (uint64_t)gbits << sh, p2 = (uint64_t)pl << sh, m2 = (uint64_t)mi << sh;
-        if((uint32_t)c2) atomicOr(&bmC[w], (uint32_t)c2);
-        if(c2 >> 32) atomicOr(&bmC[w + 1], (uint32_t)(c2 >> 32));
-        if((uint32_t)g2) atomicOr(&bmG[w], (uint32_t)g2);
-        if(g2 >> 32) atomicOr(&bmG[w + 1], (uint32_t)(g2 >> 32));
-        if(P.regions) {
-            if((uint32_t)p2) atomicOr(&bmPlus[w], (uint32_t)p2);
-            if(p2 >> 32) atomicOr(&bmPlus[w + 1], (uint32_t)(p2 >> 32));
-            if((uint32_t)m2) atomicOr(&bmMinus[w], (uint32_t)m2);
-            if(m2 >> 32) atomicOr(&bmMinus[w + 1], (uint32_t)(m2 >> 32));
-        }
-    }
-    for(int d = 32; d > 0; d >>= 1) kept += __shfl_down(kept, d);
-    if(lane == 0 && kept) atomicAdd(skept, kept);
-    lds_barrier();
-    return *skept;
-}
-
-template <bool VARIANT, int KB>
-__global__ __launch_bounds__(WG, KB == KB_SPARSE ? 8 : 4) void k_pileup(const KParams P) {     // sparse: 64 VGPRs, four 512-thread workgroups per CU
+__global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
     extern __shared__ __align__(16) uint32_t lds[];
     const int TILE = P.tile, PER = TILE / WG;
     uint32_t *cm = lds, *cu = lds + TILE, *co = lds + 2 * TILE, *cv = lds + 3 * TILE;
-    uint16_t *listC = (uint16_t *)(lds + (VARIANT ? 4 : 2) * TILE), *listG = listC + TILE;         // KB_SPARSE
-    uint32_t *bmC = lds + (VARIANT ? 4 : 2) * TILE, *bmG = bmC + BMW(TILE), *bmPlus = bmG + BMW(TILE), *bmMinus = bmPlus + BMW(TILE);   // KB_DENSE
+    uint16_t *listC = (uint16_t *)(lds + (VARIANT ? 4 : 2) * TILE), *listG = listC + TILE;
     __shared__ int wsum[WAVES];
     __shared__ uint32_t sbase;
-    __shared__ int skept;
 
     const int b = blockIdx.x;
     const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
@@ -450,24 +311,15 @@ __global__ __launch_bounds__(WG, KB == KB_SPARSE ? 8 : 4) void k_pileup(const KP
             if(VARIANT) { co[i] = 0; cv[i] = 0; }
         }
     }
-    int nC = 0, nG = 0;
-    if(KB == KB_DENSE) nC = build_bitmaps(P, TILE, PER, tid, lane, code, bmC, bmG, bmPlus, bmMinus, &skept);
-    else build_lists(P, PER, tid, lane, wave, code, listC, listG, wsum, nC, nG);
+    int nC, nG;
+    build_lists(P, PER, tid, lane, wave, code, listC, listG, wsum, nC, nG);
     if(P.dbg) tc1 = clock64();
 
     // phase 2: one segment per lane, WG segments per round
-    if(KB == KB_DENSE) {
-        if(first + tid < last) lane_seg_dense<VARIANT>(P, g0, (int)T0, (int)T1, bmC, bmG, bmPlus, bmMinus, cm, cu, co, cv);
-        for(int r = first + WG + tid; r < last; r += WG) {
-            const md_seg g = P.seg[r];
-            lane_seg_dense<VARIANT>(P, g, (int)T0, (int)T1, bmC, bmG, bmPlus, bmMinus, cm, cu, co, cv);
-        }
-    } else {
-        if(first + tid < last) lane_seg<VARIANT, KB == KB_DENSE ? 1 : KB>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
-        for(int r = first + WG + tid; r < last; r += WG) {
-            const md_seg g = P.seg[r];
-            lane_seg<VARIANT, KB == KB_DENSE ? 1 : KB>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
-        }
+    if(first + tid < last) lane_seg<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
+    for(int r = first + WG + tid; r < last; r += WG) {
+        const md_seg g = P.seg[r];
+        lane_seg<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
     }
     // reserve this tile's output segment: at most one site per kept context position (unused slots stay empty,
     // md_tile_seg.cnt says how many are filled).  Issued by the first thread once its own segments are done, so the
@@ -706,9 +558,9 @@ struct Slot {
 };
 
 struct md_dev {
-    int device; md_dev_cfg cfg; int tile, n_slots; bool variant, dense;
+    int device; md_dev_cfg cfg; int tile, n_slots; bool variant;
     std::vector<Slot> slots;
-    std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen; std::vector<char> refregions;
+    std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
     uint32_t *d_hist = nullptr; int hist_cap = 0, hist_len = 0; std::vector<uint32_t> h_hist;      // mbias: rows [q][16], q < hist_cap
 };
 
@@ -720,11 +572,6 @@ extern "C" int md_dev_count(void) {
     return n;
 }
 
-template <bool V, int K> static void launch_pileup(int grid, size_t lds, hipStream_t st, const KParams &P) { hipLaunchKernelGGL((k_pileup<V, K>), dim3(grid), dim3(WG), lds, st, P); }
-static void launch_pileup_any(bool variant, bool dense, int grid, size_t lds, hipStream_t st, const KParams &P) {
-    if(variant) { if(dense) launch_pileup<true, KB_DENSE>(grid, lds, st, P); else launch_pileup<true, KB_SPARSE>(grid, lds, st, P); }
-    else { if(dense) launch_pileup<false, KB_DENSE>(grid, lds, st, P); else launch_pileup<false, KB_SPARSE>(grid, lds, st, P); }
-}
 static int fixed_lds(int tile, bool variant) { return tile * ((variant ? 16 : 8) + 4); }
 
 extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
@@ -746,13 +593,10 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     if(h->tile > MAX_TILE) h->tile = MAX_TILE;
     h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2;
     h->variant = cfg->minOppositeDepth > 0;
-    h->dense = (cfg->keepCHG || cfg->keepCHH) && !getenv("MDK_KB_SPARSE");
     while(fixed_lds(h->tile, h->variant) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
     if(fixed_lds(h->tile, h->variant) > 65536) {    // more than the default dynamic-LDS window: opt in
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true, KB_SPARSE>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true)));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true, KB_DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true)));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false, KB_SPARSE>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false)));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false, KB_DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false)));
+        if(h->variant) HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true)));
+        else HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false)));
     }
     h->slots.resize(h->n_slots);
     for(auto &s : h->slots) {
@@ -789,8 +633,7 @@ extern "C" int md_dev_tile(const md_dev *h) { return h ? h->tile : MDK_ERR_ARG; 
 extern "C" int md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int64_t len) {
     if(!h || tid < 0 || !seq || len < 0) return fail(MDK_ERR_ARG, "md_dev_set_reference", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
-    if((size_t)tid >= h->ref.size()) { h->ref.resize(tid + 1, nullptr); h->refcode.resize(tid + 1, nullptr); h->reflen.resize(tid + 1, 0); h->refregions.resize(tid + 1, 0); }
-    h->refregions[tid] = 0;
+    if((size_t)tid >= h->ref.size()) { h->ref.resize(tid + 1, nullptr); h->refcode.resize(tid + 1, nullptr); h->reflen.resize(tid + 1, 0); }
     if(h->ref[tid]) { (void)hipFree(h->ref[tid]); h->ref[tid] = nullptr; }
     if(h->refcode[tid]) { (void)hipFree(h->refcode[tid]); h->refcode[tid] = nullptr; }
     char *d = nullptr; uint8_t *c = nullptr;
@@ -824,7 +667,6 @@ extern "C" int md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs,
     if(n) { e = hipMemcpy(d, runs, sizeof(md_region) * (size_t)n, hipMemcpyHostToDevice); if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_HIP, "hipMemcpy(regions)", e); } }
     int64_t blocks = (len + WG - 1) / WG; if(blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(k_mask_regions, dim3((unsigned)blocks), dim3(WG), 0, 0, h->refcode[tid], len, d, n);
-    h->refregions[tid] = 1;
     e = hipGetLastError(); if(e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d);
     if(e != hipSuccess) return fail(MDK_ERR_HIP, "k_mask_regions", e);
@@ -862,7 +704,7 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = fixed_lds(TILE, h->variant);
     s->read_bytes = b->algo_bytes;
     size_t ns = (size_t)b->n_segs, nt = (size_t)(ntiles > 0 ? ntiles : 1);
-    if(s->d_seg_in.need(ns + 1) || s->d_blob.need((size_t)b->blob_bytes + 2 * BLOB_PAD)) return MDK_ERR_NOMEM;      /* window loads reach a few bytes in front of and behind a payload */
+    if(s->d_seg_in.need(ns + 1) || s->d_blob.need((size_t)b->blob_bytes + 64)) return MDK_ERR_NOMEM;
     if(s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
     if(!s->b_site) {
         if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
@@ -870,7 +712,7 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     }
     if(ns) {
         HIPCHK(hipMemcpyAsync(s->d_seg_in.p, b->seg, ns * sizeof(md_seg), hipMemcpyHostToDevice, s->stream));
-        HIPCHK(hipMemcpyAsync(s->d_blob.p + BLOB_PAD, b->blob, (size_t)b->blob_bytes, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(hipMemcpyAsync(s->d_blob.p, b->blob, (size_t)b->blob_bytes, hipMemcpyHostToDevice, s->stream));
     }
     if(ntiles) HIPCHK(hipMemcpyAsync(s->d_tiles.p, s->h_tiles.p, nt * sizeof(TileEnt), hipMemcpyHostToDevice, s->stream));
     s->uploaded = true;
@@ -888,8 +730,8 @@ extern "C" int md_dev_bind_output(md_dev *h, int slot, void *d_site, void *d_var
 
 static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
     memset(&P, 0, sizeof(P));
-    P.seg = s->d_seg_in.p; P.blob = s->d_blob.p + BLOB_PAD;
-    P.ctxcode = h->refcode[s->tid]; P.reflen = h->reflen[s->tid]; P.regions = h->refregions[s->tid];
+    P.seg = s->d_seg_in.p; P.blob = s->d_blob.p;
+    P.ctxcode = h->refcode[s->tid]; P.reflen = h->reflen[s->tid];
     P.beg = s->beg; P.end = s->end; P.tile = s->tile; P.ntiles = s->ntiles; P.nper = (s->ntiles + 7) / 8;
     P.tiles = s->d_tiles.p;
     if(s->b_site) {
@@ -910,7 +752,8 @@ static int launch_kernels(md_dev *h, Slot *s, bool time_pileup) {
         KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
         int grid = P.nper * 8;
         if(time_pileup) HIPCHK(hipEventRecord(s->k0, s->stream));
-        launch_pileup_any(h->variant, h->dense, grid, (size_t)s->lds_bytes, s->stream, P);
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
         if(time_pileup) HIPCHK(hipEventRecord(s->k1, s->stream));
         HIPCHK(hipGetLastError());
     } else {
@@ -1151,7 +994,8 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
         HIPCHK(hipMalloc((void **)&dd, nw * 8)); HIPCHK(hipMemset(dd, 0, nw * 8));
         s->ring++; rc = fill_kparams(h, s, P); if(rc) return rc;
         P.dbg = dd;
-        launch_pileup_any(h->variant, h->dense, grid, (size_t)s->lds_bytes, s->stream, P);
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipMemcpy(hd.data(), dd, nw * 8, hipMemcpyDeviceToHost)); (void)hipFree(dd);
         unsigned long long r0 = ~0ull, r1 = 0; double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}; size_t cnt = 0; std::vector<double> starts, ends, life;
