@@ -1,9 +1,45 @@
 /* main.c -- `MethylDackel` command of the MI355X build: `extract`, `mbias`, `perRead` on the GPU and the `mergeContext`
  * text tool (the reference's dispatcher is main.c:39-62). */
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include "mdk_extract.h"
+
+/* The GPU commands run in a child process.  When the work is done and the outputs are closed the child reports its return
+ * code through a pipe and closes its standard streams; this process then ends at once, while the child is left to the
+ * part nobody needs to wait for: the kernel unpinning the staging buffers and tearing down the GPU context (~0.3 s).
+ * A child that dies without reporting (abort, crash) is waited for and its fate is passed on.  MDK_NO_DETACH=1 (or any
+ * profiler in the environment, see fast_exit_wanted in mdk_extract.c) keeps everything in one process. */
+static int run_detached(int (*cmd)(int, char **), int argc, char *argv[]) {
+    int fd[2]; pid_t pid; char num[16];
+    if(getenv("MDK_NO_DETACH") || pipe(fd)) return cmd(argc, argv);
+    fflush(stdout); fflush(stderr);
+    pid = fork();
+    if(pid < 0) { close(fd[0]); close(fd[1]); return cmd(argc, argv); }
+    if(pid == 0) {
+        int rc;
+        close(fd[0]);
+        snprintf(num, sizeof(num), "%d", fd[1]); setenv("MDK_DONE_FD", num, 1);
+        rc = cmd(argc, argv);                                  /* a successful run does not come back (leave_fast) */
+        fflush(stdout); fflush(stderr);
+        if(write(fd[1], &rc, sizeof(rc)) != (ssize_t)sizeof(rc)) _exit(rc & 0xff);
+        _exit(rc & 0xff);
+    } else {
+        int rc = 0, st = 0; ssize_t n;
+        close(fd[1]);
+        do n = read(fd[0], &rc, sizeof(rc)); while(n < 0);
+        if(n == (ssize_t)sizeof(rc)) _exit(rc & 0xff);
+        if(waitpid(pid, &st, 0) == pid) {
+            if(WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); }
+            if(WIFEXITED(st)) _exit(WEXITSTATUS(st));
+        }
+        _exit(255);
+    }
+}
 
 static void usage_main(void) {
     fprintf(stderr, "MethylDackel (methyldackel_amd, MI355X build of the `extract` path)\n"
@@ -19,10 +55,10 @@ int main(int argc, char *argv[]) {
     if(!strcmp(argv[1], "-v") || !strcmp(argv[1], "--version")) { printf("0.6.1 (using HTSlib version none; methyldackel_amd MI355X build)\n"); return 0; }
     if(!strcmp(argv[1], "extract")) {
         setenv("MDK_FAST_EXIT", "1", 0);      /* a process about to end need not unpin buffers and shut the runtime down politely */
-        return extract_main(argc - 1, argv + 1);
+        return run_detached(extract_main, argc - 1, argv + 1);
     }
-    if(!strcmp(argv[1], "mbias")) { setenv("MDK_FAST_EXIT", "1", 0); return mbias_main(argc - 1, argv + 1); }
-    if(!strcmp(argv[1], "perRead")) { setenv("MDK_FAST_EXIT", "1", 0); return perRead_main(argc - 1, argv + 1); }
+    if(!strcmp(argv[1], "mbias")) { setenv("MDK_FAST_EXIT", "1", 0); return run_detached(mbias_main, argc - 1, argv + 1); }
+    if(!strcmp(argv[1], "perRead")) { setenv("MDK_FAST_EXIT", "1", 0); return run_detached(perRead_main, argc - 1, argv + 1); }
     if(!strcmp(argv[1], "mergeContext")) return mergeContext_main(argc - 1, argv + 1);
     fprintf(stderr, "Unknown command!\n"); usage_main(); return -1;
 }

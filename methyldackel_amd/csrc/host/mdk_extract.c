@@ -1420,8 +1420,18 @@ static int fast_exit_wanted(void) {
     if(pre && (strstr(pre, "rocprof") || strstr(pre, "roctx") || strstr(pre, "rocm"))) return 0;
     return 1;
 }
-typedef struct { int device; md_dev_cfg cfg; md_dev *dev; int rc; } devopen_t;
-static void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); return NULL; }
+/* leave now: outputs are flushed and closed.  When the `MethylDackel` command runs the work in a child process (main.c),
+ * MDK_DONE_FD names the pipe on which the parent waits for the result: it is told first, and the standard streams are
+ * closed, so that nobody waits for the kernel to unpin ~1 GB of staging buffers and tear the GPU context down. */
+static void leave_fast(int ret) {
+    const char *fd = getenv("MDK_DONE_FD");
+    fflush(stdout); fflush(stderr);
+    if(fd) { int f = atoi(fd), rc = ret; if(f > 2 && write(f, &rc, sizeof(rc)) == (ssize_t)sizeof(rc)) { close(f); close(0); close(1); close(2); } }
+    _exit(ret & 0xff);
+}
+typedef struct { int device; md_dev_cfg cfg; md_dev *dev; int rc; char err[512]; } devopen_t;
+/* md_dev_last_error is per thread: keep the text of a failed open for the thread that reports it */
+static void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); if(d->rc) snprintf(d->err, sizeof(d->err), "%s", md_dev_last_error()); return NULL; }
 
 int extract_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; emitter em;
@@ -1438,7 +1448,7 @@ int extract_main(int argc, char *argv[]) {
     pthread_join(dth, NULL);
     t_dev = now_s() - T0;
     dev = dop.dev;
-    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     if(emitter_start(&em, p, p->o.n_threads >= 8 ? 8 : p->o.n_threads)) { md_dev_close(dev); mdk_plan_close(p); return -5; }
     /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then hand k-1 to the emitter */
     while(more || have[0] || have[1]) {
@@ -1480,10 +1490,7 @@ int extract_main(int argc, char *argv[]) {
     { double tw = now_s(); emitter_stop(&em); w_emit += now_s() - tw; }
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0);
     if(ret == 0) mdk_plan_finish(p);
-    if(fast_exit_wanted()) {
-        fflush(stdout); fflush(stderr);
-        _exit(ret & 0xff);
-    }
+    if(fast_exit_wanted()) leave_fast(ret);
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;
@@ -1586,7 +1593,7 @@ int mbias_main(int argc, char *argv[]) {
     if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     pthread_join(dth, NULL);
     dev = dop.dev;
-    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `mbias`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `mbias`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     for(;; k++) {
         /* chunk k goes to slot k&1; the batch handed out two calls ago is recycled by the next call, so its upload must be over */
         if((rc = md_dev_slot_sync(dev, k & 1)) != 0) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
@@ -1605,7 +1612,7 @@ int mbias_main(int argc, char *argv[]) {
         if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; }
         else if(mdk_mbias_report(&hist, p->o.mb_opref, p->o.svg, p->o.txt, p->o.ctx_on[0] + 2 * p->o.ctx_on[1] + 4 * p->o.ctx_on[2])) ret = -3;
     }
-    if(fast_exit_wanted()) { fflush(stdout); fflush(stderr); _exit(ret & 0xff); }
+    if(fast_exit_wanted()) leave_fast(ret);
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;
@@ -1705,7 +1712,7 @@ int perRead_main(int argc, char *argv[]) {
     if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     pthread_join(dth, NULL);
     dev = dop.dev;
-    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `perRead`.\n", dop.device, md_dev_last_error()); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `perRead`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     while(more || have[0] || have[1]) {       /* two chunks in flight, as in extract_main */
         int cur = k & 1, prev = cur ^ 1;
         if(more) {
@@ -1734,7 +1741,7 @@ int perRead_main(int argc, char *argv[]) {
         if(!more && !have[0] && !have[1]) break;
     }
     fflush(p->pr_out);
-    if(fast_exit_wanted()) { if(p->pr_out_owned) fclose(p->pr_out); fflush(stdout); fflush(stderr); _exit(ret & 0xff); }
+    if(fast_exit_wanted()) { if(p->pr_out_owned) fclose(p->pr_out); leave_fast(ret); }
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;
