@@ -1430,12 +1430,18 @@ static void leave_fast(int ret) {
     _exit(ret & 0xff);
 }
 typedef struct { int device; md_dev_cfg cfg; md_dev *dev; int rc; char err[512]; } devopen_t;
+/* the HIP runtime takes 0.1-0.4 s to come up: start that before anything else (options, BAM header, FASTA), on its own thread */
+static void *hipwarm_main(void *arg) { (void)arg; (void)md_dev_count(); return NULL; }
+/* only in the command's child process, which always ends with _exit: a library caller whose bad command line makes us return
+ * at once must not find a half-initialised runtime racing its exit handlers */
+static void hip_warm_up(void) { pthread_t th; if(getenv("MDK_DONE_FD") && !pthread_create(&th, NULL, hipwarm_main, NULL)) pthread_detach(th); }
 /* md_dev_last_error is per thread: keep the text of a failed open for the thread that reports it */
 static void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); if(d->rc) snprintf(d->err, sizeof(d->err), "%s", md_dev_last_error()); return NULL; }
 
 int extract_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; emitter em;
     double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta;
+    if(argc > 2) hip_warm_up();
     rc = mdk_plan_open(argc, argv, &p);
     t_open = now_s() - T0;
     if(rc != 0 || !p) return rc;
@@ -1584,6 +1590,7 @@ int mdk_plan_mbias_outputs(const mdk_plan *p, const char **opref, int *svg, int 
 
 int mbias_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch; int rc, k = 0, ret = 0; devopen_t dop; pthread_t dth; md_mbias hist;
+    if(argc > 2) hip_warm_up();
     rc = mdk_plan_open_mbias(argc, argv, &p);
     if(rc != 0 || !p) return rc;
     memset(&dop, 0, sizeof(dop));
@@ -1703,6 +1710,7 @@ int mdk_plan_emit_perread(mdk_plan *p, const mdk_chunk *c, const md_pr_count *co
 
 int perRead_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth;
+    if(argc > 2) hip_warm_up();
     rc = mdk_plan_open_perread(argc, argv, &p);
     if(rc != 0 || !p) return rc;
     memset(&dop, 0, sizeof(dop));
