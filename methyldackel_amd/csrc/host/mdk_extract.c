@@ -1378,7 +1378,7 @@ static int emitter_push(emitter *E, const mdk_chunk *c, const md_sites *s) {
     if(s->n_sites > j->cap) {
         j->cap = s->n_sites + s->n_sites / 4 + 1024; free(j->site); free(j->var);
         j->site = malloc(sizeof(md_site) * (size_t)j->cap); j->var = malloc(sizeof(md_site_var) * (size_t)j->cap);
-        if(!j->site || !j->var) return -5;
+        if(!j->site || !j->var) { fprintf(stderr, "[mdk] out of memory while queueing a chunk for output\n"); abort(); }      /* nothing sensible can be written in order any more */
     }
     if(s->n_sites) { memcpy(j->site, s->site, sizeof(md_site) * (size_t)s->n_sites); if(s->var) memcpy(j->var, s->var, sizeof(md_site_var) * (size_t)s->n_sites); }
     j->s.site = j->site; j->s.var = s->var ? j->var : NULL;
