@@ -58,10 +58,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
+    # MDK_BENCH_BACKEND=gloo is a test mode for boxes with fewer GPUs than ranks (ranks then share devices and the exchange is
+    # staged through host memory); the real multi-GPU run uses "nccl", i.e. RCCL over xGMI
+    backend = os.environ.get("MDK_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    cdev = "cuda" if backend == "nccl" else "cpu"          # where the tensors of the small bookkeeping collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import methyldackel_amd as mdk
     if rank == 0:
@@ -84,7 +92,7 @@ def main():
     chunk = plan.next_chunk()
     t_host = time.time() - t0
     assert chunk is not None and not chunk.skipped
-    dev = mdk.Device(cfg, device=local_rank)
+    dev = mdk.Device(cfg, device=dev_index)
     plan.ensure_reference(dev, chunk.tid)
     dev.upload(0, chunk.batch)
     dev.launch(0)
@@ -113,33 +121,61 @@ def main():
     for sl in range(2):
         dev.bind_output(sl, C.c_void_p(t_site[sl].data_ptr()), C.c_void_p(t_var[sl].data_ptr()) if variant else None, C.c_void_p(t_seg[sl].data_ptr()), cap, n_tiles + 1)
 
+    # N > 1: the exchange step of the sharded path -- per-interval site buffers travel to rank 0 (RCCL gather over xGMI).
+    # The kernels write straight into the send buffer (no staging copy), and the results of GROUP consecutive steps
+    # travel together: fewer, larger collectives, the next group being computed while the previous one is on the links.
+    GROUP = 8
     if world > 1:
-        shape = torch.tensor([cap, n_tiles + 1], dtype=torch.int64, device="cuda")
-        shapes = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(world)]
+        shape = torch.tensor([cap, n_tiles + 1], dtype=torch.int64, device=cdev)
+        shapes = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
         dist.all_gather(shapes, shape)
         gcap = int(max(int(x[0].item()) for x in shapes)); gtiles = int(max(int(x[1].item()) for x in shapes))
-        send = torch.zeros((gcap * 4 + gtiles * 2 + 2,), dtype=torch.int32, device="cuda")
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        E = gcap * 4 + gtiles * 2                                  # int32 words of one step: sites, then tile segments
+        sendbuf = [torch.zeros((GROUP * E,), dtype=torch.int32, device="cuda") for _ in range(2)]
+        if backend == "nccl":
+            recvbuf = [[torch.empty_like(sendbuf[0]) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+        else:
+            recvbuf = [[torch.empty((GROUP * E,), dtype=torch.int32) for _ in range(world)] if rank == 0 else None for _ in range(2)]
+        pending = [None, None]
+        t_dummy_var = t_var
 
-    def collect(sl):
-        n = dev.wait(sl).n_slots
-        if world > 1:                           # the exchange step: per-interval site buffers -> rank 0 (RCCL over xGMI)
-            send[: cap * 4].copy_(t_site[sl].view(-1))
-            send[gcap * 4: gcap * 4 + (n_tiles + 1) * 2].copy_(t_seg[sl].view(-1))
-            send[-2] = n
-            send[-1] = n_tiles
-            dist.gather(send, recv, dst=0)
-        return n
+    def bind_for(k):
+        """step k writes into step-slot k % GROUP of send buffer (k // GROUP) & 1"""
+        if world == 1:
+            return
+        x, e = (k // GROUP) & 1, k % GROUP
+        if e == 0 and pending[x] is not None:                      # this buffer is about to be overwritten: its gather must be over
+            pending[x].wait(); pending[x] = None
+        base = sendbuf[x].data_ptr() + 4 * e * E
+        sl = k & 1
+        dev.bind_output(sl, C.c_void_p(base), C.c_void_p(t_dummy_var[sl].data_ptr()) if variant else None, C.c_void_p(base + 16 * gcap), gcap, gtiles)
+
+    def exchange(k, last):
+        """after step k has been collected: send its group when the group is complete (or the run ends)"""
+        if world == 1 or not (k % GROUP == GROUP - 1 or last):
+            return
+        x = (k // GROUP) & 1
+        if backend == "nccl":
+            pending[x] = dist.gather(sendbuf[x], recvbuf[x], dst=0, async_op=True)
+        else:
+            dist.gather(sendbuf[x].cpu(), recvbuf[x], dst=0)
 
     def run(k_steps):
-        """k_steps passes over the batch: every pass is launched AND collected inside the call"""
+        """k_steps passes over the batch: every pass is launched, collected and (N > 1) exchanged inside the call"""
         n = 0
         for k in range(k_steps):
+            bind_for(k)
             dev.launch(k & 1)
             if k:
-                n = collect((k - 1) & 1)
+                n = dev.wait((k - 1) & 1).n_slots
+                exchange(k - 1, False)
         if k_steps:
-            n = collect((k_steps - 1) & 1)
+            n = dev.wait((k_steps - 1) & 1).n_slots
+            exchange(k_steps - 1, True)
+        if world > 1:
+            for x in range(2):
+                if pending[x] is not None:
+                    pending[x].wait(); pending[x] = None
         return n
 
     def fence():
@@ -157,21 +193,29 @@ def main():
     assert n_last >= n_sites
     # the bound buffers hold the same sites as the library's own download (segment order -> ascending)
     last = (args.steps - 1) & 1 if args.steps else 0
-    chk = t_site[last].cpu().numpy().view("uint32"); segs = t_seg[last].cpu().numpy().view("uint32")
+    if world > 1 and args.steps:
+        kl = args.steps - 1
+        flat = sendbuf[(kl // GROUP) & 1][(kl % GROUP) * E:(kl % GROUP + 1) * E].cpu().numpy().view("uint32")
+        chk = flat[: gcap * 4].reshape(gcap, 4); segs = flat[gcap * 4:].reshape(gtiles, 2)
+    else:
+        chk = t_site[last].cpu().numpy().view("uint32"); segs = t_seg[last].cpu().numpy().view("uint32")
     got = []
     for t in range(n_tiles):
         o, c = int(segs[t, 0]), int(segs[t, 1])
         got.extend(int(x) for x in chk[o:o + c, 0])
     assert got == [sites.site[i].pos for i in range(n_sites)], "bound-output sites differ from md_dev_download"
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([cpg_calls, all_calls, int(n_sites)], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([cpg_calls, all_calls, int(n_sites)], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_cpg_calls, total_calls, total_sites = (int(x) for x in tot.tolist())
-        if rank == 0:                           # rank 0 really received every rank's interval
-            assert all(int(r[-2].item()) > 0 for r in recv)
+        if rank == 0 and args.steps:            # rank 0 really received every rank's interval: the tile segments of the last step hold sites
+            kl = args.steps - 1
+            for r in recvbuf[(kl // GROUP) & 1]:
+                one = r[(kl % GROUP) * E:(kl % GROUP + 1) * E]
+                assert int(one[gcap * 4:].view(-1, 2)[:, 1].sum().item()) > 0
     else:
         total_cpg_calls, total_calls, total_sites = cpg_calls, all_calls, int(n_sites)
 
