@@ -59,7 +59,7 @@ static void sb_put(sbuf *b, const char *s, size_t n) {
 }
 
 /* one admitted read, host-side only (the device gets segments) */
-typedef struct { int32_t pos, rend, mate; uint32_t off4, lq, cig_off, qn_off; uint16_t ncig, bamflag; uint8_t strand, second; } rinfo;
+typedef struct { int32_t pos, rend, mate; uint32_t off4, lq, cig_off, qn_off, qn_hash; uint16_t ncig, bamflag; uint8_t strand, second; } rinfo;
 /* growable batch arrays; blob and seg are pinned (they are what gets uploaded) */
 typedef struct {
     rinfo *ri; size_t n, cap_ri;
@@ -72,7 +72,7 @@ typedef struct {
 } batchbuf;
 
 /* qname table entry for the pairing pass */
-typedef struct { uint64_t h; uint32_t qoff; int32_t pending; int32_t nlive; int32_t live[4]; int32_t *more; int32_t nmore, capmore; int used; } qent;
+typedef struct { uint32_t h, qoff; int32_t pending, used; int32_t live[2]; int32_t nlive; int32_t more; } qent;     /* 32 bytes; more = head of a side list (index + 1) for the rare third and later records of a name */
 
 /* what formatting one chunk needs and produces: the text per output file, the pending --mergeContext sites (they never
  * cross a chunk: extract.c:496-507) and the count of positions dropped as likely variants */
@@ -749,19 +749,21 @@ static uint64_t hash_str(const char *s) { uint64_t h = 0xcbf29ce484222325ULL; fo
  * (overlaps.c:121-147), evaluated lazily per qname.  A buffered read whose end precedes the position of the
  * most recently pulled read has been swept out of the pileup buffer, and its destructor erased the qname key. */
 static __thread qent *t_qt = NULL; static __thread size_t t_qt_cap = 0; static __thread int t_gen = 0;     /* one qname table per worker thread; `used` holds the chunk generation */
-static qent *qt_get(const batchbuf *b, uint32_t qoff) {
-    const char *name = b->qn + qoff; uint64_t h = hash_str(name); size_t mask = t_qt_cap - 1, i = (size_t)h & mask;
+static __thread struct { int32_t end, next; } *t_side; static __thread size_t t_side_n, t_side_cap;      /* live ends beyond the two kept inline */
+static qent *qt_get(const batchbuf *b, uint32_t qoff, uint32_t h) {
+    const char *name = b->qn + qoff; size_t mask = t_qt_cap - 1, i = (size_t)h & mask;
     for(;; i = (i + 1) & mask) {
         qent *e = &t_qt[i];
-        if(e->used != t_gen) { e->used = t_gen; e->h = h; e->qoff = qoff; e->pending = -1; e->nlive = 0; e->nmore = 0; return e; }
+        if(e->used != t_gen) { e->used = t_gen; e->h = h; e->qoff = qoff; e->pending = -1; e->nlive = 0; e->more = 0; return e; }
         if(e->h == h && !strcmp(b->qn + e->qoff, name)) return e;
     }
 }
 static void qt_prepare(size_t expect) {
-    size_t want = 1024, i;
-    while(want < expect * 2 + 16) want <<= 1;
-    if(want > t_qt_cap) { if(t_qt) for(i = 0; i < t_qt_cap; i++) free(t_qt[i].more); free(t_qt); t_qt = calloc(want, sizeof(qent)); t_qt_cap = want; t_gen = 0; }
-    if(++t_gen == 0x7fffffff) { for(i = 0; i < t_qt_cap; i++) t_qt[i].used = 0; t_gen = 1; }     /* a new generation empties the table */
+    size_t want = 1024;
+    while(want < expect + expect / 2 + 16) want <<= 1;
+    if(want > t_qt_cap) { free(t_qt); t_qt = calloc(want, sizeof(qent)); t_qt_cap = want; t_gen = 0; }
+    if(++t_gen == 0x7fffffff) { size_t i; for(i = 0; i < t_qt_cap; i++) t_qt[i].used = 0; t_gen = 1; }     /* a new generation empties the table */
+    t_side_n = 0;
 }
 static void pair_reads(batchbuf *b, int32_t tid) {
     size_t i, n = b->n; int32_t prev_pos = 0; int first = 1;
@@ -772,18 +774,28 @@ static void pair_reads(batchbuf *b, int32_t tid) {
         /* bam_plp_push: a read enters the buffer iff its end lies beyond the column about to be emitted */
         if(first) inserted = (tid > 0) || (end > 0); else inserted = end > prev_pos;
         if(inserted) {
-            e = qt_get(b, r->qn_off);
+            e = qt_get(b, r->qn_off, r->qn_hash);
             for(k = 0, w = 0; k < e->nlive; k++) { if(!first && e->live[k] < prev_pos) evicted = 1; else e->live[w++] = e->live[k]; }
             e->nlive = w;
-            for(k = 0, w = 0; k < e->nmore; k++) { if(!first && e->more[k] < prev_pos) evicted = 1; else e->more[w++] = e->more[k]; }
-            e->nmore = w;
+            if(e->more) {       /* drop the swept-out ends of the side list too, refilling the inline slots from it */
+                int32_t *link = &e->more;
+                while(*link) {
+                    int32_t idx = *link - 1;
+                    if(!first && t_side[idx].end < prev_pos) { evicted = 1; *link = t_side[idx].next; }
+                    else if(e->nlive < 2) { e->live[e->nlive++] = t_side[idx].end; *link = t_side[idx].next; }
+                    else link = &t_side[idx].next;
+                }
+            }
             if(evicted) e->pending = -1;
             if((r->bamflag & 0x1) && !(r->bamflag & 12)) {
                 if(e->pending < 0) e->pending = (int32_t)i;
                 else { int32_t a = e->pending; b->ri[a].mate = (int32_t)i; r->mate = a; r->second = 1; e->pending = -1; }
             }
-            if(e->nlive < 4) e->live[e->nlive++] = end;
-            else { if(e->nmore == e->capmore) { e->capmore = e->capmore ? e->capmore * 2 : 8; e->more = realloc(e->more, sizeof(int32_t) * e->capmore); } e->more[e->nmore++] = end; }
+            if(e->nlive < 2) e->live[e->nlive++] = end;
+            else {
+                if(t_side_n == t_side_cap) { t_side_cap = t_side_cap ? t_side_cap * 2 : 1024; t_side = realloc(t_side, sizeof(*t_side) * t_side_cap); }
+                t_side[t_side_n].end = end; t_side[t_side_n].next = e->more; e->more = (int32_t)++t_side_n;
+            }
         }
         prev_pos = pos; first = 0;
     }
@@ -911,7 +923,9 @@ pack:
     memcpy(d, r->seq, seqb); memset(d + seqb, 0, seqpad - seqb); d += seqpad;
     memcpy(d, r->qual, (size_t)r->l_qseq); memset(d + r->l_qseq, 0, qualpad - (size_t)r->l_qseq);
     b->blob_len += need;
-    ri->qn_off = (uint32_t)b->qn_len; memcpy(b->qn + b->qn_len, r->qname, r->l_qname); b->qn[b->qn_len + r->l_qname] = 0; b->qn_len += (size_t)r->l_qname + 1;
+    ri->qn_off = (uint32_t)b->qn_len; memcpy(b->qn + b->qn_len, r->qname, r->l_qname); b->qn[b->qn_len + r->l_qname] = 0;
+    { uint64_t hh = hash_str(b->qn + b->qn_len); ri->qn_hash = (uint32_t)(hh ^ (hh >> 32)); }        /* while the name is in cache: the pairing pass then only compares names that collide */
+    b->qn_len += (size_t)r->l_qname + 1;
     b->algo_bytes += 16 + 4ull * r->n_cigar + seqb + (uint64_t)r->l_qseq;
     b->n++;
     return 1;
@@ -1149,7 +1163,7 @@ static void *worker_main(void *arg) {
         pthread_cond_broadcast(&p->cv_done);
         pthread_mutex_unlock(&p->mu);
     }
-    if(t_qt) { size_t q; for(q = 0; q < t_qt_cap; q++) free(t_qt[q].more); free(t_qt); t_qt = NULL; t_qt_cap = 0; }
+    free(t_qt); t_qt = NULL; t_qt_cap = 0; free(t_side); t_side = NULL; t_side_cap = t_side_n = 0;
     return NULL;
 }
 static int pipeline_start(mdk_plan *p) {
