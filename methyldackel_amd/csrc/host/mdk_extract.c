@@ -1227,7 +1227,7 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
 /* text post-pass (extract.c:443-510 driving writeCall/processLast, extract.c:39-99,207-222)          */
 /* ------------------------------------------------------------------------------------------------ */
 static void put_site(mdk_plan *p, sbuf *dst, const char *chrom, int32_t pos, int width, uint32_t m, uint32_t u, int ref_is_c, const char *cctx, const char *tri) {
-    const opts_t *o = &p->o; char line[1024]; int n; uint32_t cov = m + u;
+    const opts_t *o = &p->o; char line[10000]; int n; uint32_t cov = m + u;      /* the size of writeCall's buffer (extract.c:40): lines longer than that are cut the same way */
     if(cov < (uint32_t)o->min_depth && !o->cytosine_report) return;
     if(o->fraction) n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%f\n", chrom, pos, pos + width, ((double)m) / cov);
     else if(o->counts) n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%i\n", chrom, pos, pos + width, cov);
