@@ -5,7 +5,7 @@ CC     ?= gcc
 ARCH   ?= gfx950
 B      := methyldackel_amd/_build
 CFLAGS ?= -O2 -g -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -fPIC -pthread
-HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bigwig.c methyldackel_amd/csrc/host/mdk_mbias.c methyldackel_amd/csrc/host/mdk_mergecontext.c methyldackel_amd/csrc/host/mdk_extract.c
+HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bigwig.c methyldackel_amd/csrc/host/mdk_mbias.c methyldackel_amd/csrc/host/mdk_mergecontext.c methyldackel_amd/csrc/host/mdk_plan.c methyldackel_amd/csrc/host/mdk_pipeline.c methyldackel_amd/csrc/host/mdk_emit.c methyldackel_amd/csrc/host/mdk_extract.c methyldackel_amd/csrc/host/mdk_cmd_mbias.c methyldackel_amd/csrc/host/mdk_cmd_perread.c
 
 all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 
@@ -13,7 +13,7 @@ $(B)/libmdk_hip.so: methyldackel_amd/csrc/mdk_hip.hip include/mdk_hip.h
 	@mkdir -p $(B)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude -o $@ methyldackel_amd/csrc/mdk_hip.hip
 
-$(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h include/mdk_extract.h include/mdk_hip.h $(B)/libmdk_hip.so
+$(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldackel_amd/csrc/host/mdk_plan.h include/mdk_extract.h include/mdk_hip.h $(B)/libmdk_hip.so
 	$(CC) $(CFLAGS) -shared -Iinclude -o $@ $(HOSTSRC) -L$(B) -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
 
 $(B)/MethylDackel: methyldackel_amd/csrc/host/main.c $(B)/libmdk_extract.so

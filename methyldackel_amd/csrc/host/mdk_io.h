@@ -7,6 +7,7 @@
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
+#pragma GCC visibility push(hidden)      /* internal to libmdk_extract.so: not part of the C ABI */
 
 /* Inflated data travels in reference-counted SLABS so that the chunk workers can parse records in place (no copy):
  * an inflater thread (which fans the BGZF members of a slab out to a pool of threads) runs ahead of the scanner;
@@ -97,4 +98,5 @@ mdk_bigwig *mdk_bigwig_open(const char *fn);
 void mdk_bigwig_close(mdk_bigwig *bw);
 float *mdk_bigwig_values(mdk_bigwig *bw, uint32_t k);
 
+#pragma GCC visibility pop
 #endif
