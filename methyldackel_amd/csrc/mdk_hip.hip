@@ -32,6 +32,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include <algorithm>
 #include "mdk_hip.h"
@@ -1051,8 +1052,8 @@ extern "C" int md_dev_debug_effective(md_dev *h, int slot, uint8_t *out_base, ui
 // GPU; nothing is computed there).  A 64-byte header in front of the block remembers which kind it is.
 extern "C" void *md_host_alloc(uint64_t bytes) {
     void *p = nullptr; size_t n = (size_t)bytes + 64;
-    static int pinned_ok = -1;
-    if(pinned_ok < 0) { int c = 0; pinned_ok = (hipGetDeviceCount(&c) == hipSuccess && c > 0) ? 1 : 0; }
+    static std::once_flag once; static int pinned_ok = 0;          // several chunk workers may be the first caller at the same time
+    std::call_once(once, [] { int c = 0; pinned_ok = (hipGetDeviceCount(&c) == hipSuccess && c > 0) ? 1 : 0; });
     if(pinned_ok && hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess) { memcpy(p, "MDKPIN", 7); return (char *)p + 64; }
     if(posix_memalign(&p, 4096, n) != 0) return nullptr;
     memcpy(p, "MDKMAL", 7);
