@@ -183,7 +183,7 @@ static void pair_reads(batchbuf *b, int32_t tid) {
             }
             if(e->nlive < 2) e->live[e->nlive++] = end;
             else {
-                if(t_side_n == t_side_cap) { t_side_cap = t_side_cap ? t_side_cap * 2 : 1024; t_side = realloc(t_side, sizeof(*t_side) * t_side_cap); }
+                if(t_side_n == t_side_cap) { t_side_cap = t_side_cap ? t_side_cap * 2 : 1024; t_side = realloc(t_side, sizeof(*t_side) * t_side_cap); if(!t_side) { fprintf(stderr, "[mdk] out of memory\n"); abort(); } }
                 t_side[t_side_n].end = end; t_side[t_side_n].next = e->more; e->more = (int32_t)++t_side_n;
             }
         }
@@ -200,7 +200,7 @@ static int cigar_runs(const uint32_t *cig, int ncig, int32_t pos, int32_t lq, ru
         int op = cig[k] & 15; int32_t len = (int32_t)(cig[k] >> 4);
         if(cigar_is_match(op)) {
             int32_t l = len; if(y + l > lq) l = lq - y;            /* malformed CIGAR guard */
-            if(l > 0) { if(n == *cap) { *cap = *cap ? *cap * 2 : 16; *out = realloc(*out, sizeof(run_t) * *cap); } (*out)[n].x = x; (*out)[n].y = y; (*out)[n].l = l; n++; }
+            if(l > 0) { if(n == *cap) { *cap = *cap ? *cap * 2 : 16; *out = realloc(*out, sizeof(run_t) * *cap); if(!*out) { fprintf(stderr, "[mdk] out of memory\n"); abort(); } } (*out)[n].x = x; (*out)[n].y = y; (*out)[n].l = l; n++; }
             x += len; y += len;
         } else if(op == 1 || op == 4) y += len;
         else if(op == 2 || op == 3) x += len;

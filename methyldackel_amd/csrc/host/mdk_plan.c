@@ -20,7 +20,7 @@ static void usage(void) {
 
 /* 4 comma-separated non-negative ints (the reference's parseBounds, common.c:11-43) */
 MDK_LOCAL void parse_bounds(const char *arg, int *dst) {
-    char *dup = strdup(arg), *tok, *end, *save = NULL; int k; int tmp[4];
+    char *dup = xstrdup(arg), *tok, *end, *save = NULL; int k; int tmp[4];
     for(k = 0, tok = strtok_r(dup, ",", &save); k < 4; k++, tok = strtok_r(NULL, ",", &save)) {
         long v;
         if(!tok) break;
@@ -63,16 +63,16 @@ static int load_bbm(mdk_plan *p, FILE *f) {
     fprintf(stderr, "loading mappability data from %s\n", p->o.bbm_name);
     if(fread(&ver, 1, 1, f) != 1 || ver != 1) { fprintf(stderr, "fatal: %s has wrong BBM version or is malformed\n", p->o.bbm_name); return -10; }
     if(fread(&nchrom, 4, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; }
-    p->map_n = nchrom; p->map_names = calloc(nchrom + 1, sizeof(char *)); p->map_len = calloc(nchrom + 1, 4); p->map_bits = calloc(nchrom + 1, sizeof(uint8_t *));
+    p->map_n = nchrom; p->map_names = xcalloc(nchrom + 1, sizeof(char *)); p->map_len = xcalloc(nchrom + 1, 4); p->map_bits = xcalloc(nchrom + 1, sizeof(uint8_t *));
     for(c = 0; c < nchrom; c++) {
         uint16_t nl = 0; uint8_t z = 1; uint32_t len = 0, at = 0; size_t nbytes; double cut = p->o.map_cutoff * 100.0;
         if(fread(&nl, 2, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; }
-        p->map_names[c] = calloc((size_t)nl + 1, 1);
+        p->map_names[c] = xcalloc((size_t)nl + 1, 1);
         if(nl && fread(p->map_names[c], 1, nl, f) != nl) { printf("fatal: malformed BBM file\n"); return -9; }
         if(fread(&z, 1, 1, f) != 1 || z) { printf("fatal: malformed BBM file\n"); return -9; }
         if(fread(&len, 4, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; }
         p->map_len[c] = len; nbytes = (size_t)len / 8 + ((len % 8) ? 1 : 0);
-        p->map_bits[c] = calloc(nbytes + 8, 1);
+        p->map_bits[c] = xcalloc(nbytes + 8, 1);
         while(at < len) {
             uint8_t v; uint32_t run = 1; int above;
             if(fread(&v, 1, 1, f) != 1) { printf("fatal: malformed BBM file\n"); return -9; }
@@ -105,12 +105,12 @@ static int load_bigwig(mdk_plan *p) {
     }
     fprintf(stderr, "loading mappability data from %s\n", o->bw_name);
     if(f) { uint32_t n = bw->n; fwrite(&n, 4, 1, f); fprintf(stderr, "writing .bbm file to %s\n", o->out_bbm_name); }
-    p->map_n = bw->n; p->map_names = calloc(bw->n + 1, sizeof(char *)); p->map_len = calloc(bw->n + 1, 4); p->map_bits = calloc(bw->n + 1, sizeof(uint8_t *));
+    p->map_n = bw->n; p->map_names = xcalloc(bw->n + 1, sizeof(char *)); p->map_len = xcalloc(bw->n + 1, 4); p->map_bits = xcalloc(bw->n + 1, sizeof(uint8_t *));
     for(c = 0; c < bw->n; c++) {
         uint32_t len = bw->len[c], j; float *v = mdk_bigwig_values(bw, c); double cut = o->map_cutoff * 100.0;
         unsigned char last = 255; uint16_t run = 0;
         if(!v) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bw_name); if(f) fclose(f); mdk_bigwig_close(bw); return -4; }
-        p->map_names[c] = strdup(bw->name[c]); p->map_len[c] = len; p->map_bits[c] = calloc((size_t)len / 8 + 9, 1);
+        p->map_names[c] = xstrdup(bw->name[c]); p->map_len[c] = len; p->map_bits[c] = xcalloc((size_t)len / 8 + 9, 1);
         if(f) { uint16_t nl = (uint16_t)strlen(bw->name[c]); fwrite(&nl, 2, 1, f); fwrite(bw->name[c], 1, nl, f); fputc(0, f); fwrite(&len, 4, 1, f); }
         for(j = 0; j < len; j++) {
             unsigned char val = map_value(v[j]);
@@ -212,11 +212,11 @@ static int bed_line(char *s, size_t l, int lnum, const char *fn, const mdk_bam *
 
 static void build_runs(mdk_plan *p, const bedreg *reg, size_t n) {
     size_t i = 0; int32_t nt = p->bam->n_targets, t;
-    p->bed_run = calloc((size_t)nt + 1, sizeof(md_region *)); p->bed_nrun = calloc((size_t)nt + 1, sizeof(int64_t));
+    p->bed_run = xcalloc((size_t)nt + 1, sizeof(md_region *)); p->bed_nrun = xcalloc((size_t)nt + 1, sizeof(int64_t));
     for(t = 0; t < nt; t++) {
         size_t j = i, k; int64_t x = 0, m = 0; md_region *run;
         while(j < n && reg[j].tid == t) j++;
-        run = malloc(sizeof(md_region) * (j - i + 1));
+        run = xmalloc(sizeof(md_region) * (j - i + 1));
         for(k = i; k < j; k++) {
             if((int64_t)reg[k].end <= x) continue;                       /* over before x: never governs anything from here on */
             run[m].start = reg[k].start > x ? reg[k].start : (int32_t)x; run[m].end = reg[k].end; run[m].strand = reg[k].strand; m++;
@@ -237,7 +237,7 @@ static int load_bed(mdk_plan *p) {
     if((f = gzopen(o->bed_name, "r")) == NULL) { fprintf(stderr, "Couldn't open %s for reading.\n", o->bed_name); return -1; }
     for(;;) {
         int got;
-        if(cap - n < (1u << 16)) { cap = cap ? cap * 2 : 1u << 20; data = realloc(data, cap); if(!data) { gzclose(f); return -1; } }
+        if(cap - n < (1u << 16)) { cap = cap ? cap * 2 : 1u << 20; data = xrealloc(data, cap); if(!data) { gzclose(f); return -1; } }
         got = gzread(f, data + n, 1u << 16);
         if(got <= 0) break;
         n += (size_t)got;
@@ -248,11 +248,11 @@ static int load_bed(mdk_plan *p) {
         while(e < n && data[e] != '\n') e++;
         l = e - at; if(l > 1 && data[e - 1] == '\r') l--;
         if(l == 0) break;                                /* the reference's line loop ends at the first empty line */
-        line = realloc(line, l + 2); memcpy(line, data + at, l); line[l] = line[l + 1] = 0;
+        line = xrealloc(line, l + 2); memcpy(line, data + at, l); line[l] = line[l + 1] = 0;
         at = e + 1; lnum++;
         rc = bed_line(line, strlen(line) < l ? strlen(line) : l, lnum, o->bed_name, p->bam, o->keep_strand, &r);
         if(rc == 1) {
-            if(nreg == creg) { creg = creg ? creg * 2 : 1024; reg = realloc(reg, sizeof(bedreg) * creg); }
+            if(nreg == creg) { creg = creg ? creg * 2 : 1024; reg = xrealloc(reg, sizeof(bedreg) * creg); }
             reg[nreg++] = r;
         }
     }
@@ -289,20 +289,20 @@ MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional
         { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { plan_free(p); return rc; } }
     }
     if(mdk_fasta_load(o->fasta_name, &p->fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", o->fasta_name); plan_free(p); return -4; }
-    p->fa_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
+    p->fa_of_tid = xmalloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
     for(i = 0; i < p->bam->n_targets; i++) p->fa_of_tid[i] = mdk_fasta_find(&p->fa, p->bam->target_name[i]);
     if(p->map_on) {
-        p->map_of_tid = malloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
+        p->map_of_tid = xmalloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
         for(i = 0; i < p->bam->n_targets; i++) { uint32_t k; p->map_of_tid[i] = -1; for(k = 0; k < p->map_n; k++) if(!strcmp(p->map_names[k], p->bam->target_name[i])) { p->map_of_tid[i] = (int)k; break; } }
     }
 
     if(o->mbias || o->perread) goto region;
     /* output files and headers (extract.c:1343-1439) */
     if(!o->opref) {
-        char *dot; o->opref = strdup(o->bam_name); dot = strrchr(o->opref, '.'); if(dot) *dot = 0;
+        char *dot; o->opref = xstrdup(o->bam_name); dot = strrchr(o->opref, '.'); if(dot) *dot = 0;
         fprintf(stderr, "writing to prefix:'%s'\n", o->opref);
     }
-    oname = malloc(strlen(o->opref) + 40);
+    oname = xmalloc(strlen(o->opref) + 40);
     if(o->cytosine_report) {
         sprintf(oname, "%s.cytosine_report.txt", o->opref);
         p->out[0] = fopen(getenv("MDK_NO_OUTPUT") ? "/dev/null" : oname, "w"); p->out[1] = p->out[2] = p->out[0];
@@ -372,7 +372,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         switch(c) {
         case 'h': usage(); plan_free(p); return 0;
         case 'v': printf("%s (using HTSlib version %s)\n", MDK_VERSION, "none; methyldackel_amd MI355X build"); plan_free(p); return 0;
-        case 'o': free(o->opref); o->opref = strdup(optarg); break;
+        case 'o': free(o->opref); o->opref = xstrdup(optarg); break;
         case 'D': break;
         case 'd': o->min_depth = atoi(optarg); if(o->min_depth < 1) { fprintf(stderr, "Error, the minimum depth must be at least 1!\n"); plan_free(p); return 1; } break;
         case 'r': o->region = optarg; break;
@@ -398,7 +398,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         case 't': o->map_cutoff = (float)atof(optarg); break;
         case 'b': o->min_mappable = atoi(optarg); break;
         case 'O': o->output_bb = 1; free(o->out_bbm_name); o->out_bbm_name = NULL; break;
-        case 'N': o->output_bb = 1; free(o->out_bbm_name); o->out_bbm_name = malloc(strlen(optarg) + 5); sprintf(o->out_bbm_name, "%s.bbm", optarg); break;
+        case 'N': o->output_bb = 1; free(o->out_bbm_name); o->out_bbm_name = xmalloc(strlen(optarg) + 5); sprintf(o->out_bbm_name, "%s.bbm", optarg); break;
         case 'B': o->bbm_name = optarg; break;
         case 'F': o->ignore_flags = atoi(optarg); break;     /* atoi: "0xD00" parses as 0, as in the reference */
         case 'R': o->require_flags = atoi(optarg); break;
@@ -412,7 +412,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         }
     }
     if(o->output_bb && !o->out_bbm_name && o->bw_name) {       /* -O: the bigWig's name with its extension replaced by .bbm */
-        char *dot; o->out_bbm_name = malloc(strlen(o->bw_name) + 5); strcpy(o->out_bbm_name, o->bw_name);
+        char *dot; o->out_bbm_name = xmalloc(strlen(o->bw_name) + 5); strcpy(o->out_bbm_name, o->bw_name);
         dot = strrchr(o->out_bbm_name, '.'); if(dot) *dot = 0;
         strcat(o->out_bbm_name, ".bbm");
     }
@@ -494,7 +494,7 @@ int mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid) {
     i = md_dev_set_reference(dev, tid, p->fa.seq[fi], p->fa.len[fi]);
     if(i) return i;
     if(p->bed_on && !p->o.perread && (i = md_dev_set_regions(dev, tid, p->bed_run[tid], p->bed_nrun[tid])) != 0) return i;     /* perRead uses -l only to pass over chunks (perRead.c:150-166) */
-    if(p->n_ref == p->cap_ref) { p->cap_ref = p->cap_ref ? p->cap_ref * 2 : 32; p->ref_dev = realloc(p->ref_dev, sizeof(md_dev *) * p->cap_ref); p->ref_tid = realloc(p->ref_tid, sizeof(int32_t) * p->cap_ref); }
+    if(p->n_ref == p->cap_ref) { p->cap_ref = p->cap_ref ? p->cap_ref * 2 : 32; p->ref_dev = xrealloc(p->ref_dev, sizeof(md_dev *) * p->cap_ref); p->ref_tid = xrealloc(p->ref_tid, sizeof(int32_t) * p->cap_ref); }
     p->ref_dev[p->n_ref] = dev; p->ref_tid[p->n_ref] = tid; p->n_ref++;
     return 0;
 }
