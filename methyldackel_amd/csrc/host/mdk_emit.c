@@ -145,7 +145,7 @@ MDK_LOCAL int emitter_start(emitter *E, mdk_plan *p, int n_th) {
     int i;
     memset(E, 0, sizeof(*E));
     E->p = p; E->n_th = n_th < 1 ? 1 : n_th; E->n_job = E->n_th + 2; E->next_write = p->next_emit;
-    E->job = calloc((size_t)E->n_job, sizeof(ejob)); E->th = calloc((size_t)E->n_th, sizeof(pthread_t));
+    E->job = xcalloc((size_t)E->n_job, sizeof(ejob)); E->th = xcalloc((size_t)E->n_th, sizeof(pthread_t));
     if(!E->job || !E->th) return -5;
     pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv_job, NULL); pthread_cond_init(&E->cv_free, NULL); pthread_cond_init(&E->cv_turn, NULL);
     for(i = 0; i < E->n_th; i++) pthread_create(&E->th[i], NULL, emitter_main, E);

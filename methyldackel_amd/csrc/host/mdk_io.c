@@ -81,7 +81,7 @@ void mdk_slab_ref(mdk_bam *b, mdk_slab *s) { pthread_mutex_lock(&b->mu); s->refs
 void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
     pthread_mutex_lock(&b->mu);
     if(--s->refs == 0) {
-        if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = realloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); }
+        if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = xrealloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); }
         b->pool[b->n_pool++] = s; pthread_cond_signal(&b->cv_pool);
     }
     pthread_mutex_unlock(&b->mu);
@@ -244,7 +244,7 @@ static int need(mdk_bam *b, size_t n) {
 }
 
 mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
-    mdk_bam *b = calloc(1, sizeof(*b)); int rc; uint32_t i; size_t o;
+    mdk_bam *b = xcalloc(1, sizeof(*b)); int rc; uint32_t i; size_t o;
     if(!b) return NULL;
     b->f = fopen(fn, "rb");
     if(!b->f) { free(b); return NULL; }
@@ -259,17 +259,17 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     if((rc = need(b, 12)) <= 0 || memcmp(b->cur->buf + b->off, "BAM\1", 4)) { mdk_bam_close(b); return NULL; }
     b->l_text = le32(b->cur->buf + b->off + 4);
     if(need(b, 12 + (size_t)b->l_text) <= 0) { mdk_bam_close(b); return NULL; }
-    b->text = malloc((size_t)b->l_text + 1); memcpy(b->text, b->cur->buf + b->off + 8, b->l_text); b->text[b->l_text] = 0;
+    b->text = xmalloc((size_t)b->l_text + 1); memcpy(b->text, b->cur->buf + b->off + 8, b->l_text); b->text[b->l_text] = 0;
     b->n_targets = (int32_t)le32(b->cur->buf + b->off + 8 + b->l_text);
     b->off += 12 + (size_t)b->l_text;
-    b->target_name = calloc((size_t)b->n_targets + 1, sizeof(char *)); b->target_len = calloc((size_t)b->n_targets + 1, sizeof(uint32_t));
+    b->target_name = xcalloc((size_t)b->n_targets + 1, sizeof(char *)); b->target_len = xcalloc((size_t)b->n_targets + 1, sizeof(uint32_t));
     for(i = 0; i < (uint32_t)b->n_targets; i++) {
         uint32_t ln;
         if(need(b, 4) <= 0) { mdk_bam_close(b); return NULL; }
         ln = le32(b->cur->buf + b->off);
         if(need(b, 8 + (size_t)ln) <= 0) { mdk_bam_close(b); return NULL; }
         o = b->off;
-        b->target_name[i] = malloc((size_t)ln + 1); memcpy(b->target_name[i], b->cur->buf + o + 4, ln); b->target_name[i][ln] = 0;
+        b->target_name[i] = xmalloc((size_t)ln + 1); memcpy(b->target_name[i], b->cur->buf + o + 4, ln); b->target_name[i][ln] = 0;
         b->target_len[i] = le32(b->cur->buf + o + 4 + ln);
         b->off += 8 + (size_t)ln;
     }
@@ -369,8 +369,8 @@ mdk_bai *mdk_bai_load(const char *bam_fn) {
     d = malloc(sz + 8);
     if(!d || fread(d, 1, sz, f) != sz || sz < 8 || memcmp(d, "BAI\1", 4)) { fclose(f); free(d); return NULL; }
     fclose(f);
-    x = calloc(1, sizeof(*x)); x->n_ref = (int32_t)le32(d + 4);
-    x->n_intv = calloc((size_t)x->n_ref + 1, 4); x->ioff = calloc((size_t)x->n_ref + 1, sizeof(uint64_t *)); x->first = calloc((size_t)x->n_ref + 1, 8);
+    x = xcalloc(1, sizeof(*x)); x->n_ref = (int32_t)le32(d + 4);
+    x->n_intv = xcalloc((size_t)x->n_ref + 1, 4); x->ioff = xcalloc((size_t)x->n_ref + 1, sizeof(uint64_t *)); x->first = xcalloc((size_t)x->n_ref + 1, 8);
     for(r = 0; r < x->n_ref; r++) {
         int32_t nb, b, ni, i; uint64_t first = 0;
         if(o + 4 > sz) goto bad;
@@ -386,7 +386,7 @@ mdk_bai *mdk_bai_load(const char *bam_fn) {
         if(o + 4 > sz) goto bad;
         ni = (int32_t)le32(d + o); o += 4;
         if(o + 8u * (size_t)ni > sz) goto bad;
-        x->n_intv[r] = ni; x->ioff[r] = malloc(8u * (size_t)(ni + 1)); x->first[r] = first;
+        x->n_intv[r] = ni; x->ioff[r] = xmalloc(8u * (size_t)(ni + 1)); x->first[r] = first;
         for(i = 0; i < ni; i++) x->ioff[r][i] = (uint64_t)le32(d + o + 8 * i) | ((uint64_t)le32(d + o + 8 * i + 4) << 32);
         o += 8u * (size_t)ni;
     }
@@ -410,7 +410,7 @@ int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
     int i;
     inflaters_stop(b);
     pthread_mutex_lock(&b->mu);
-    for(i = 0; i < b->q_n; i++) { if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = realloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); } b->pool[b->n_pool++] = b->queue[i]; }
+    for(i = 0; i < b->q_n; i++) { if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = xrealloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); } b->pool[b->n_pool++] = b->queue[i]; }
     b->q_n = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
     pthread_mutex_unlock(&b->mu);
     if(b->cur) { mdk_slab_unref(b, b->cur); b->cur = NULL; }
@@ -442,7 +442,7 @@ int mdk_fasta_load(const char *fn, mdk_fasta *fa) {
             size_t s = i + 1, t = s;
             while(t < e && d[t] != ' ' && d[t] != '\t' && d[t] != '\r') t++;
             if(cur >= 0) fa->len[cur] = (int64_t)(d + w - fa->seq[cur]);
-            if(fa->n == cap) { cap = cap ? cap * 2 : 64; fa->name = realloc(fa->name, sizeof(char *) * cap); fa->seq = realloc(fa->seq, sizeof(char *) * cap); fa->len = realloc(fa->len, sizeof(int64_t) * cap); }
+            if(fa->n == cap) { cap = cap ? cap * 2 : 64; fa->name = xrealloc(fa->name, sizeof(char *) * cap); fa->seq = xrealloc(fa->seq, sizeof(char *) * cap); fa->len = xrealloc(fa->len, sizeof(int64_t) * cap); }
             memmove(d + w, d + s, t - s); fa->name[fa->n] = d + w; w += t - s; d[w++] = 0;
             cur = fa->n++; fa->seq[cur] = d + w; fa->len[cur] = 0;
         } else if(cur >= 0) {

@@ -7,7 +7,17 @@
 #include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #pragma GCC visibility push(hidden)      /* internal to libmdk_extract.so: not part of the C ABI */
+
+/* set-up allocations (options, name tables, bitmaps, region lists): running out of memory there is fatal, as in the reference */
+static inline void *mdk_fatal_oom(void) { fprintf(stderr, "[mdk] out of memory\n"); abort(); return NULL; }
+static inline void *xmalloc(size_t n) { void *q = malloc(n ? n : 1); return q ? q : mdk_fatal_oom(); }
+static inline void *xcalloc(size_t n, size_t m) { void *q = calloc(n ? n : 1, m ? m : 1); return q ? q : mdk_fatal_oom(); }
+static inline void *xrealloc(void *o, size_t n) { void *q = realloc(o, n ? n : 1); return q ? q : mdk_fatal_oom(); }
+static inline char *xstrdup(const char *s) { char *q = strdup(s); return q ? q : (char *)mdk_fatal_oom(); }
+
 
 /* Inflated data travels in reference-counted SLABS so that the chunk workers can parse records in place (no copy):
  * an inflater thread (which fans the BGZF members of a slab out to a pool of threads) runs ahead of the scanner;

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "mdk_extract.h"
+#include "mdk_io.h"
 
 /* calls of one (strand, read number): methylated / unmethylated per position in the read */
 typedef struct { const uint32_t *row; int col; int len; } series;
@@ -104,7 +105,7 @@ static int strand_len(const md_mbias *h, int strand) {
 }
 
 static int svg_of_strand(const char *opref, int strand, const series s[2], int len, int which, int sugg[4]) {
-    char *name = malloc(strlen(opref) + 16); FILE *f; double ymin, ymax, span; int first[2] = {len, len}, has[2] = {0, 0}, xmax, q, r, j, n, step, labelled = 0;
+    char *name = xmalloc(strlen(opref) + 16); FILE *f; double ymin, ymax, span; int first[2] = {len, len}, has[2] = {0, 0}, xmax, q, r, j, n, step, labelled = 0;
     sprintf(name, "%s_%s.svg", opref, ABBREV[strand]);
     f = fopen(name, "w");
     free(name);

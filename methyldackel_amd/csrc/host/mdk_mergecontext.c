@@ -88,7 +88,7 @@ int mergeContext_main(int argc, char *argv[]) {
         unmeth = (uint32_t)strtoul(f[5], &end, 10); if(end == f[5]) malformed("unmethylated count");
         fi = mdk_fasta_find(&fa, f[0]);
         if(fi < 0) { fprintf(stderr, "[mergeContext] Error, %s is an unknown chromosome name!\n", f[0]); break; }
-        chrom = strdup(f[0]);
+        chrom = xstrdup(f[0]);
         type = site_of(fa.seq[fi], fa.len[fi], start, &lo, &hi);
         if(type == 0) meet_or_wait(out, &cpg, chrom, lo, hi, meth, unmeth);
         else if(type == 1) meet_or_wait(out, &chg, chrom, lo, hi, meth, unmeth);

@@ -33,12 +33,6 @@ static inline double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOT
 
 #define MDK_LOCAL __attribute__((visibility("hidden")))
 
-/* set-up allocations (options, name tables, bitmaps, region lists): running out of memory there is fatal, as in the reference */
-static inline void *mdk_fatal_oom(void) { fprintf(stderr, "[mdk] out of memory\n"); abort(); return NULL; }
-static inline void *xmalloc(size_t n) { void *q = malloc(n ? n : 1); return q ? q : mdk_fatal_oom(); }
-static inline void *xcalloc(size_t n, size_t m) { void *q = calloc(n ? n : 1, m ? m : 1); return q ? q : mdk_fatal_oom(); }
-static inline void *xrealloc(void *o, size_t n) { void *q = realloc(o, n ? n : 1); return q ? q : mdk_fatal_oom(); }
-static inline char *xstrdup(const char *s) { char *q = strdup(s); return q ? q : (char *)mdk_fatal_oom(); }
 /* ------------------------------------------------------------------------------------------------ */
 /* options (the reference's Config, MethylDackel.h:90-126; defaults extract.c:715-753)               */
 /* ------------------------------------------------------------------------------------------------ */
