@@ -118,6 +118,9 @@ typedef struct {
 } md_bench_result;
 
 int  md_dev_count(void);                                       /* number of HIP devices, <0 on error */
+/* optional: create the device context and load the kernels ahead of md_dev_open (e.g. on a thread, while options and
+ * input headers are still being read) */
+int  md_dev_warm(int device);
 int  md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out);
 void md_dev_close(md_dev *h);
 const char *md_dev_last_error(void);
@@ -191,6 +194,9 @@ int  md_dev_debug_effective(md_dev *h, int slot, uint8_t *out_base, uint8_t *out
 
 /* Pinned host memory for staging buffers (so the C host never includes HIP headers). */
 void *md_host_alloc(uint64_t bytes);
+/* Pinning costs ~0.3 s per GB up front and again at process exit; a pageable buffer costs ~5 ms per 55 MB upload instead.
+ * on = 0 makes later md_host_alloc calls return pageable memory (the host does this for inputs of a few dozen chunks). */
+void  md_host_set_pinned(int on);
 void  md_host_free(void *p);
 
 #ifdef __cplusplus

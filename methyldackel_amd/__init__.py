@@ -102,9 +102,9 @@ class mdk_chunk(C.Structure):
                 ("batch", md_read_batch), ("n_records_seen", C.c_uint64), ("pr", md_pr_batch), ("host", C.c_void_p)]
 
 
-HIP_SYMBOLS = ["md_dev_count", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
+HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
-               "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free",
+               "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned",
                "md_dev_mbias_submit", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
                "md_dev_perread_submit", "md_dev_perread_download"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",

@@ -34,10 +34,14 @@ MDK_LOCAL void leave_fast(int ret) {
     _exit(ret & 0xff);
 }
 /* the HIP runtime takes 0.1-0.4 s to come up: start that before anything else (options, BAM header, FASTA), on its own thread */
-static void *hipwarm_main(void *arg) { (void)arg; (void)md_dev_count(); return NULL; }
+static void *hipwarm_main(void *arg) { (void)arg; (void)md_dev_warm(getenv("MDK_DEVICE") ? atoi(getenv("MDK_DEVICE")) : 0); return NULL; }
 /* only in the command's child process, which always ends with _exit: a library caller whose bad command line makes us return
  * at once must not find a half-initialised runtime racing its exit handlers */
-MDK_LOCAL void hip_warm_up(void) { pthread_t th; if(getenv("MDK_DONE_FD") && !pthread_create(&th, NULL, hipwarm_main, NULL)) pthread_detach(th); }
+MDK_LOCAL void hip_warm_up(void) {
+    pthread_t th;
+    if(!getenv("MDK_DONE_FD") || pthread_create(&th, NULL, hipwarm_main, NULL)) return;
+    if(getenv("MDK_INIT_FIRST")) pthread_join(th, NULL); else pthread_detach(th);      /* experiment: runtime first, inflate threads afterwards */
+}
 /* md_dev_last_error is per thread: keep the text of a failed open for the thread that reports it */
 MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); if(d->rc) snprintf(d->err, sizeof(d->err), "%s", md_dev_last_error()); return NULL; }
 

@@ -22,6 +22,7 @@
 #include <string.h>
 #include <pthread.h>
 #include <time.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 #include "mdk_extract.h"

@@ -32,6 +32,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <algorithm>
@@ -573,6 +574,19 @@ extern "C" int md_dev_count(void) {
     return n;
 }
 
+// Bring the runtime all the way up for a device -- context, code object -- without needing a configuration yet, so that a
+// caller can overlap it with its own start-up; md_dev_open afterwards finds it done.
+extern "C" int md_dev_warm(int device) {
+    int n = md_dev_count();
+    if(n <= 0 || device < 0 || device >= n) return MDK_ERR_NODEVICE;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(nullptr));
+    hipFuncAttributes fa;
+    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_pileup<false>));
+    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_classify));
+    return 0;
+}
+
 static int fixed_lds(int tile, bool variant) { return tile * ((variant ? 16 : 8) + 4); }
 
 extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
@@ -1050,10 +1064,13 @@ extern "C" int md_dev_debug_effective(md_dev *h, int slot, uint8_t *out_base, ui
 // Staging memory for the host: pinned when a device is present (so hipMemcpyAsync really is asynchronous),
 // ordinary page-aligned memory otherwise (lets the host-side packing logic be exercised on a machine without a
 // GPU; nothing is computed there).  A 64-byte header in front of the block remembers which kind it is.
+static std::atomic<int> g_want_pinned{1};
+extern "C" void md_host_set_pinned(int on) { g_want_pinned.store(on != 0); }
 extern "C" void *md_host_alloc(uint64_t bytes) {
     void *p = nullptr; size_t n = (size_t)bytes + 64;
     static std::once_flag once; static int pinned_ok = 0;          // several chunk workers may be the first caller at the same time
-    std::call_once(once, [] { int c = 0; pinned_ok = (hipGetDeviceCount(&c) == hipSuccess && c > 0) ? 1 : 0; });
+    std::call_once(once, [] { int c = 0; pinned_ok = (!getenv("MDK_NO_PIN") && hipGetDeviceCount(&c) == hipSuccess && c > 0) ? 1 : 0; });
+    if(!g_want_pinned.load()) { if(posix_memalign(&p, 4096, n) != 0) return nullptr; memcpy(p, "MDKMAL", 7); return (char *)p + 64; }
     if(pinned_ok && hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess) { memcpy(p, "MDKPIN", 7); return (char *)p + 64; }
     if(posix_memalign(&p, 4096, n) != 0) return nullptr;
     memcpy(p, "MDKMAL", 7);
