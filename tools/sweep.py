@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Tuning helper (GPU box): run bench.py under a grid of MDK_TILE / MDK_LDS_BUDGET / MDK_KERNEL settings and print one line each."""
+"""Tuning helper (GPU box): run bench.py under a grid of MDK_TILE settings and print one line each.
+usage: tools/sweep.py <tile,tile,...> [unused] ["extra extract options"] ["extra mdk_synth options"]"""
 import itertools, json, os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["256", "512", "768", "1024"]
