@@ -249,7 +249,8 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     b->f = fopen(fn, "rb");
     if(!b->f) { free(b); return NULL; }
     b->nthreads = nthreads < 1 ? 1 : nthreads;
-    b->max_alloc = b->nthreads * 2 + 8;           /* how far the inflater may run ahead of the consumers, in slabs */
+    b->max_alloc = b->nthreads * 2 + 8;           /* how far the inflaters may run ahead of the consumers, in slabs (~48 MB each) */
+    if(b->max_alloc > 48) b->max_alloc = 48;       /* the chunk slots hold ~2 slabs each, the queue 8, the teams 4: more only costs memory */
     if(getenv("MDK_SLAB_CAP")) b->max_alloc = atoi(getenv("MDK_SLAB_CAP")) > 1 ? atoi(getenv("MDK_SLAB_CAP")) : 2;
     pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL); pthread_cond_init(&b->cv_turn, NULL);
     b->n_teams = b->nthreads >= 32 ? 4 : b->nthreads >= 8 ? 2 : 1;
