@@ -54,8 +54,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <pthread.h>
 
 #define ORACLE_VERSION "0.6.1"
+/* Differential-search knob (tests/t8_differential.py): MDK_ORACLE_PERTURB=<n> makes ONE rule deviate
+ * from the reference's code, to find out which single deviation would reproduce an expectation the code contradicts.
+ * 0 (the default) is the reference's behaviour; nothing else is ever used by a parity test. */
+static int g_pt = 0; int g_pt_abs[16];
+enum { PT_ABS_RIGHT_M1 = 1, PT_ABS_LEFT_M1, PT_ABS_RIGHT_P1, PT_ABS_LEFT_P1, PT_ABS_SWAP_R1R2, PT_ABS_AS_RELATIVE, PT_ABS_5PRIME, PT_ABS_QUAL_ONLY,
+       PT_ABS_N_ONLY, PT_TRIM_AFTER_PAIRING, PT_SWAP_A_B, PT_TIE_FIRST, PT_SKIP_N_IN_OVERLAP, PT_NO_OVERLAP, PT_ABS_SKIP_READ1, PT_ABS_SKIP_READ2, PT_ADMIT_QCFAIL, PT_N };
 #define RUNOFFSET 99
 #define BBM_VERSION 1
 
@@ -107,18 +114,59 @@ static int32_t cigar2rlen(const uint8_t *c, int n) {
 /* bam_endpos(): pos + rlen, with rlen==0 treated as 1 */
 static int32_t rec_endpos(const brec *r) { return r->pos + (r->rlen > 0 ? r->rlen : 1); }
 
+/* -@ N: the reference gives every worker its own file handle and region iterator (extract.c:283-295), so BGZF inflate
+ * and record decoding scale with the workers.  This oracle keeps the whole file in memory instead, so the same work is
+ * spread over the N threads up front: members are inflated block-parallel, records are decoded range-parallel. */
+static int g_load_threads = 1;
+typedef struct { const uint8_t *raw; const size_t *moff, *mout; const uint32_t *mlen, *misz, *mhdr; size_t nm; uint8_t *out; int k, n, bad; } inflate_job;
+static void *inflate_main(void *arg) {
+    inflate_job *j = arg; size_t i; z_stream zs;
+    for(i = (size_t)j->k; i < j->nm; i += (size_t)j->n) {
+        if(!j->misz[i]) continue;
+        memset(&zs, 0, sizeof(zs));
+        zs.next_in = (uint8_t *)j->raw + j->moff[i] + j->mhdr[i]; zs.avail_in = j->mlen[i] - j->mhdr[i] - 8;
+        zs.next_out = j->out + j->mout[i]; zs.avail_out = j->misz[i];
+        if(inflateInit2(&zs, -15) != Z_OK) { j->bad = 1; return NULL; }
+        if(inflate(&zs, Z_FINISH) != Z_STREAM_END) { inflateEnd(&zs); j->bad = 1; return NULL; }
+        inflateEnd(&zs);
+    }
+    return NULL;
+}
+typedef struct { bamfile *bf; const size_t *roff; size_t lo, hi; int32_t max_rlen; int bad; } decode_job;
+static void *decode_main(void *arg) {
+    decode_job *j = arg; bamfile *bf = j->bf; size_t i;
+    for(i = j->lo; i < j->hi; i++) {
+        size_t o = j->roff[i]; uint32_t bs = rd32(bf->data + o); const uint8_t *r = bf->data + o + 4; brec *b = &bf->rec[i];
+        b->tid = (int32_t)rd32(r); b->pos = (int32_t)rd32(r + 4);
+        b->l_qname = r[8]; b->mapq = r[9];
+        b->n_cigar = rd16(r + 12); b->flag = rd16(r + 14);
+        b->l_qseq = (int32_t)rd32(r + 16); b->mtid = (int32_t)rd32(r + 20); b->mpos = (int32_t)rd32(r + 24);
+        b->qname = (const char *)(r + 32);
+        b->cigar = r + 32 + b->l_qname;
+        b->seq = b->cigar + 4 * b->n_cigar;
+        b->qual = b->seq + (b->l_qseq + 1) / 2;
+        b->aux = b->qual + b->l_qseq;
+        b->aux_len = (int32_t)((r + bs) - b->aux);
+        if(b->aux_len < 0) { j->bad = 1; return NULL; }
+        b->rlen = cigar2rlen(b->cigar, b->n_cigar);
+        if(b->rlen > j->max_rlen) j->max_rlen = b->rlen;
+    }
+    return NULL;
+}
 static int bam_load(const char *fn, bamfile *bf) {
     FILE *f = fopen(fn, "rb");
-    uint8_t *raw; size_t rawlen, o = 0, cap = 1 << 20, i;
+    uint8_t *raw; size_t rawlen, o = 0, cap, i, nm = 0, mcap = 1024, total = 0, *moff, *mout, *roff; uint32_t *mlen, *misz, *mhdr;
+    int nt = g_load_threads < 1 ? 1 : g_load_threads, k, bad = 0;
     memset(bf, 0, sizeof(*bf));
     if(!f) return -1;
     fseek(f, 0, SEEK_END); rawlen = ftell(f); fseek(f, 0, SEEK_SET);
     raw = xmalloc(rawlen);
     if(fread(raw, 1, rawlen, f) != rawlen) { fclose(f); free(raw); return -1; }
     fclose(f);
-    bf->data = xmalloc(cap);
+    /* member table (BGZF: concatenated gzip members with a 'BC' extra subfield holding the member size) */
+    moff = xmalloc(mcap * sizeof(size_t)); mout = xmalloc(mcap * sizeof(size_t)); mlen = xmalloc(mcap * 4); misz = xmalloc(mcap * 4); mhdr = xmalloc(mcap * 4);
     while(o + 18 <= rawlen) {
-        uint16_t xlen, bsize = 0; size_t x; int have = 0; uint32_t isize; z_stream zs;
+        uint16_t xlen, bsize = 0; size_t x; int have = 0;
         if(raw[o] != 0x1f || raw[o + 1] != 0x8b || raw[o + 2] != 8 || !(raw[o + 3] & 4)) { free(raw); return -2; }
         xlen = rd16(raw + o + 10);
         for(x = o + 12; x + 4 <= o + 12 + xlen;) {      /* find the 'BC' extra subfield */
@@ -127,20 +175,21 @@ static int bam_load(const char *fn, bamfile *bf) {
             x += 4 + slen;
         }
         if(!have || o + bsize + 1 > rawlen) { free(raw); return -2; }
-        isize = rd32(raw + o + bsize + 1 - 4);
-        if(bf->len + isize > cap) { while(bf->len + isize > cap) cap *= 2; bf->data = xrealloc(bf->data, cap); }
-        if(isize) {
-            memset(&zs, 0, sizeof(zs));
-            zs.next_in = raw + o + 12 + xlen; zs.avail_in = bsize + 1 - 12 - xlen - 8;
-            zs.next_out = bf->data + bf->len; zs.avail_out = isize;
-            if(inflateInit2(&zs, -15) != Z_OK) { free(raw); return -2; }
-            if(inflate(&zs, Z_FINISH) != Z_STREAM_END) { inflateEnd(&zs); free(raw); return -2; }
-            inflateEnd(&zs);
-            bf->len += isize;
-        }
+        if(nm == mcap) { mcap *= 2; moff = xrealloc(moff, mcap * sizeof(size_t)); mout = xrealloc(mout, mcap * sizeof(size_t)); mlen = xrealloc(mlen, mcap * 4); misz = xrealloc(misz, mcap * 4); mhdr = xrealloc(mhdr, mcap * 4); }
+        moff[nm] = o; mlen[nm] = (uint32_t)bsize + 1; mhdr[nm] = 12u + xlen; misz[nm] = rd32(raw + o + bsize + 1 - 4); mout[nm] = total; total += misz[nm]; nm++;
         o += (size_t)bsize + 1;
     }
-    free(raw);
+    bf->data = xmalloc(total + 1); bf->len = total;
+    {
+        pthread_t *th = xmalloc(sizeof(pthread_t) * nt); inflate_job *job = xmalloc(sizeof(inflate_job) * nt);
+        for(k = 0; k < nt; k++) { inflate_job j = {raw, moff, mout, mlen, misz, mhdr, nm, bf->data, k, nt, 0}; job[k] = j; if(k) pthread_create(&th[k], NULL, inflate_main, &job[k]); }
+        inflate_main(&job[0]);
+        for(k = 1; k < nt; k++) pthread_join(th[k], NULL);
+        for(k = 0; k < nt; k++) bad |= job[k].bad;
+        free(th); free(job);
+    }
+    free(raw); free(moff); free(mout); free(mlen); free(misz); free(mhdr);
+    if(bad) return -2;
     /* header */
     if(bf->len < 12 || memcmp(bf->data, "BAM\1", 4)) return -3;
     o = 8 + rd32(bf->data + 4);
@@ -153,28 +202,26 @@ static int bam_load(const char *fn, bamfile *bf) {
         bf->target_len[i] = rd32(bf->data + o + 4 + ln);
         o += 8 + ln;
     }
-    /* records */
-    cap = 1024; bf->rec = xmalloc(cap * sizeof(brec));
+    /* records: where they start (a serial walk over the block_size words), then the fields (range-parallel) */
+    cap = 1024; roff = xmalloc(cap * sizeof(size_t));
     while(o + 4 <= bf->len) {
-        uint32_t bs = rd32(bf->data + o); const uint8_t *r = bf->data + o + 4; brec *b;
-        if(o + 4 + bs > bf->len) return -3;
-        if(bf->n_rec == cap) { cap *= 2; bf->rec = xrealloc(bf->rec, cap * sizeof(brec)); }
-        b = &bf->rec[bf->n_rec++];
-        b->tid = (int32_t)rd32(r); b->pos = (int32_t)rd32(r + 4);
-        b->l_qname = r[8]; b->mapq = r[9];
-        b->n_cigar = rd16(r + 12); b->flag = rd16(r + 14);
-        b->l_qseq = (int32_t)rd32(r + 16); b->mtid = (int32_t)rd32(r + 20); b->mpos = (int32_t)rd32(r + 24);
-        b->qname = (const char *)(r + 32);
-        b->cigar = r + 32 + b->l_qname;
-        b->seq = b->cigar + 4 * b->n_cigar;
-        b->qual = b->seq + (b->l_qseq + 1) / 2;
-        b->aux = b->qual + b->l_qseq;
-        b->aux_len = (int32_t)((r + bs) - b->aux);
-        if(b->aux_len < 0) return -3;
-        b->rlen = cigar2rlen(b->cigar, b->n_cigar);
-        if(b->rlen > bf->max_rlen) bf->max_rlen = b->rlen;
+        uint32_t bs = rd32(bf->data + o);
+        if(o + 4 + bs > bf->len || bs < 32) { free(roff); return -3; }
+        if(bf->n_rec == cap) { cap *= 2; roff = xrealloc(roff, cap * sizeof(size_t)); }
+        roff[bf->n_rec++] = o;
         o += 4 + (size_t)bs;
     }
+    bf->rec = xmalloc((bf->n_rec + 1) * sizeof(brec));
+    {
+        pthread_t *th = xmalloc(sizeof(pthread_t) * nt); decode_job *job = xmalloc(sizeof(decode_job) * nt);
+        for(k = 0; k < nt; k++) { decode_job j = {bf, roff, bf->n_rec * (size_t)k / nt, bf->n_rec * (size_t)(k + 1) / nt, 0, 0}; job[k] = j; if(k) pthread_create(&th[k], NULL, decode_main, &job[k]); }
+        decode_main(&job[0]);
+        for(k = 1; k < nt; k++) pthread_join(th[k], NULL);
+        for(k = 0; k < nt; k++) { bad |= job[k].bad; if(job[k].max_rlen > bf->max_rlen) bf->max_rlen = job[k].max_rlen; }
+        free(th); free(job);
+    }
+    free(roff);
+    if(bad) return -3;
     /* per-tid ranges; the pileup needs coordinate-sorted input (htslib errors out otherwise) */
     bf->tid_lo = xmalloc(sizeof(size_t) * (bf->n_targets + 1));
     bf->tid_hi = xmalloc(sizeof(size_t) * (bf->n_targets + 1));
@@ -556,6 +603,22 @@ static void trimAbsoluteAlignment(bam1 *b, int bounds[16]) {   /* common.c:174-2
     if(strand < 0) return;
     if(b->r->flag & 0x80) { lb = bounds[4 * strand + 2]; rb = bounds[4 * strand + 3]; }
     else { lb = bounds[4 * strand]; rb = bounds[4 * strand + 1]; }
+    if(g_pt) {                                            /* differential search only; never taken by a parity test */
+        if(g_pt == PT_ABS_SWAP_R1R2) { if(b->r->flag & 0x80) { lb = bounds[4 * strand]; rb = bounds[4 * strand + 1]; } else { lb = bounds[4 * strand + 2]; rb = bounds[4 * strand + 3]; } }
+        if(g_pt == PT_ABS_SKIP_READ1 && !(b->r->flag & 0x80)) return;
+        if(g_pt == PT_ABS_SKIP_READ2 && (b->r->flag & 0x80)) return;
+        if(g_pt == PT_ABS_RIGHT_M1 && rb > 0) rb--;
+        if(g_pt == PT_ABS_LEFT_M1 && lb > 0) lb--;
+        if(g_pt == PT_ABS_RIGHT_P1 && rb > 0) rb++;
+        if(g_pt == PT_ABS_LEFT_P1 && lb > 0) lb++;
+        if(g_pt == PT_ABS_5PRIME && (b->r->flag & 0x10)) { int t = lb; lb = rb; rb = t; }
+        if(g_pt == PT_ABS_AS_RELATIVE) { lb = (lb < l) ? lb : l; for(i = 0; i < lb; i++) maskBase(b, i); if(rb) for(i = rb; i < l; i++) maskBase(b, i); return; }
+        if(g_pt == PT_ABS_QUAL_ONLY || g_pt == PT_ABS_N_ONLY) {
+            lb = (lb < l) ? lb : l; rb = (rb < l) ? rb : l;
+            for(i = 0; i < l; i++) if(i < lb || i >= l - rb) { if(g_pt == PT_ABS_QUAL_ONLY) b->qual[i] = 0; else { if(i & 1) b->seq[i >> 1] |= 0xf; else b->seq[i >> 1] |= 0xf0; } }
+            return;
+        }
+    }
     lb = (lb < l) ? lb : l;
     rb = (rb < l) ? rb : l;
     if(lb) for(i = 0; i < lb; i++) maskBase(b, i);
@@ -649,7 +712,7 @@ static int filter_func(mplp_data *ldata, bam1 *b) {
         if(!r) return -1;
         if(r->tid == -1 || (r->flag & 0x4)) continue;
         if(r->mapq < c->minMapq) continue;
-        if(r->flag & c->ignoreFlags) continue;
+        if((r->flag & c->ignoreFlags) && !(g_pt == PT_ADMIT_QCFAIL && !(r->flag & c->ignoreFlags & ~0x200))) continue;
         if(c->requireFlags && (r->flag & c->requireFlags) != c->requireFlags) continue;
         if(!c->keepDupes && (r->flag & 0x400)) continue;
         if(!c->ignoreNH) {
@@ -674,7 +737,8 @@ static int filter_func(mplp_data *ldata, bam1 *b) {
             if(computeConversionEfficiency(b, ldata) < c->minConversionEfficiency) continue;
         }
         trimAlignment(b, c->bounds);
-        trimAbsoluteAlignment(b, c->absoluteBounds);
+        if(g_pt != PT_TRIM_AFTER_PAIRING || !(r->flag & 0x1)) trimAbsoluteAlignment(b, c->absoluteBounds);
+        else memcpy(g_pt_abs, c->absoluteBounds, sizeof(g_pt_abs));      /* diagnostic: paired reads are trimmed after the overlap rule instead */
         return 0;
     }
 }
@@ -733,6 +797,7 @@ static void cust_tweak_overlap_quality(bam1 *a, bam1 *b) {     /* overlaps.c:54-
     uint8_t *a_qual = a->qual, *b_qual = b->qual, *a_seq = a->seq, *b_seq = b->seq;
     int sa = getStrand(a->r), sb = getStrand(b->r);
     if(((sa - sb) & 1) == 1) goto quit;
+    if(g_pt == PT_NO_OVERLAP) goto quit;
     while(ia < na && posa[ia] < 0) ia++;
     while(ib < nb && posb[ib] < 0) ib++;
     if(ia == na || ib == nb) goto quit;
@@ -742,6 +807,8 @@ static void cust_tweak_overlap_quality(bam1 *a, bam1 *b) {     /* overlaps.c:54-
     while(ia < na && ib < nb) {
         if(posa[ia] < posb[ib] || posa[ia] < 0) { ia++; continue; }
         if(posb[ib] < posa[ia] || posb[ib] < 0) { ib++; continue; }
+        if(g_pt == PT_SKIP_N_IN_OVERLAP && (seqi(a_seq, ia) == 15 || seqi(b_seq, ib) == 15)) { ia++; ib++; continue; }
+        if(g_pt == PT_TIE_FIRST && seqi(a_seq, ia) == seqi(b_seq, ib) && a_qual[ia] == b_qual[ib]) { a_qual[ia] = (uint8_t)(int)(a_qual[ia] + 0.2 * a_qual[ia]); b_qual[ib] = 0; ia++; ib++; continue; }
         if(seqi(a_seq, ia) != seqi(b_seq, ib)) {
             if(a_qual[ia] > b_qual[ib] && seqi(a_seq, ia) != 15) { a_qual[ia] -= b_qual[ib]; b_qual[ib] = 0; }
             else if(b_qual[ib] > a_qual[ia] && seqi(b_seq, ib) != 15) { b_qual[ib] -= a_qual[ia]; a_qual[ia] = 0; }
@@ -761,7 +828,12 @@ static void custom_overlap_constructor(ohash_t *oh, lbnode *nb) {   /* overlaps.
     oent **p = ohash_find(oh, nb->b.r->qname);
     if(!(nb->b.r->flag & 0x1) || ((nb->b.r->flag & 12) > 0)) return;
     if(*p == NULL) { oent *e = xmalloc(sizeof(*e)); e->key = nb->b.r->qname; e->val = nb; e->next = NULL; *p = e; }
-    else { oent *e = *p; cust_tweak_overlap_quality(&e->val->b, &nb->b); *p = e->next; free(e); }
+    else {
+        oent *e = *p;
+        if(g_pt == PT_SWAP_A_B) cust_tweak_overlap_quality(&nb->b, &e->val->b); else cust_tweak_overlap_quality(&e->val->b, &nb->b);
+        if(g_pt == PT_TRIM_AFTER_PAIRING) { int sv = g_pt; g_pt = 0; trimAbsoluteAlignment(&e->val->b, g_pt_abs); trimAbsoluteAlignment(&nb->b, g_pt_abs); g_pt = sv; }
+        *p = e->next; free(e);
+    }
 }
 static void custom_overlap_destructor(ohash_t *oh, lbnode *nb) {    /* overlaps.c:141-147 */
     oent **p = ohash_find(oh, nb->b.r->qname);
@@ -939,15 +1011,21 @@ static int isVariant(Config *config, const pileup1 *plp, uint32_t *coverage, int
 }
 
 /* globals of main.c:7-15 */
-static uint32_t globalTid, globalPos, globalEnd, bin_;
+static uint32_t globalTid, globalPos, globalEnd, bin_, outputBin;
 static uint64_t globalnVariantPositions;
+static pthread_mutex_t positionMutex = PTHREAD_MUTEX_INITIALIZER, outputMutex = PTHREAD_MUTEX_INITIALIZER;   /* main.c:14-15 */
+static pthread_cond_t outputCv = PTHREAD_COND_INITIALIZER;      /* the reference spins on outputMutex (extract.c:514-520); waiting on a condition gives the same order */
+static void awaitTurn(uint32_t localBin) { pthread_mutex_lock(&outputMutex); while(outputBin != localBin) pthread_cond_wait(&outputCv, &outputMutex); }
+static void passTurn(void) { outputBin++; pthread_cond_broadcast(&outputCv); pthread_mutex_unlock(&outputMutex); }
+typedef struct { Config *config; const bamfile *bf; const fasta *fa; } extractArgs;
 static FILE *dump_fp;    /* MDK_ORACLE_DUMP: per-column raw counters, used by the kernel-level parity tests */
 
-static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {   /* extract.c:247-560 */
+static void *extractCalls(void *arg_) {   /* extract.c:247-560; one call per worker thread (extract.c:1479-1486) */
+    extractArgs *arg = arg_; Config *config = arg->config; const bamfile *bf = arg->bf; const fasta *fa = arg->fa;
     int tid = 0, i, seqlen, type, rv, n_plp, strand, direction, tnc;
     int32_t pos = 0;
     uint32_t nmethyl = 0, nunmethyl = 0, nOff = 0, nVariant = 0;
-    uint32_t localPos = 0, localEnd = 0, localTid = 0, localPos2 = 0, lastPos = 0;
+    uint32_t localPos = 0, localEnd = 0, localTid = 0, localPos2 = 0, lastPos = 0, localBin = 0;
     uint64_t nVariantPositions = 0;
     pileup1 *plp; char *seq = NULL, base = 'A'; char context[3] = "HG";
     struct lastCall lastCpG_, lastCHG_, *lastCpG = NULL, *lastCHG = NULL;
@@ -962,10 +1040,11 @@ static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {  
 
     while(1) {
         plp_t iter; ohash_t *oh;
-        bin_++;
+        pthread_mutex_lock(&positionMutex);                    /* extract.c:325-350: claim the next chunk */
+        localBin = bin_++;
         localTid = globalTid; localPos = globalPos;
         localEnd = (uint32_t)(localPos + config->chunkSize);
-        if(localTid >= (uint32_t)bf->n_targets) break;
+        if(localTid >= (uint32_t)bf->n_targets) { pthread_mutex_unlock(&positionMutex); break; }
         if(globalEnd && localEnd > globalEnd) localEnd = globalEnd;
         adjustBounds(bf, fa, &localTid, &localPos, &localEnd);
         globalPos = localEnd;
@@ -973,8 +1052,9 @@ static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {  
         if(localTid < (uint32_t)bf->n_targets && globalTid != (uint32_t)-1) {
             if(globalPos >= bf->target_len[localTid]) { localEnd = bf->target_len[localTid]; globalTid++; globalPos = 0; }
         }
-        if(config->bed) {   /* extract.c:352-369: skip chunks that touch no BED region */
-            if(spanOverlapsBED((int32_t)localTid, (int32_t)localPos, (int32_t)localEnd, config->bed, &bedIdx) != 1) continue;
+        pthread_mutex_unlock(&positionMutex);
+        if(config->bed) {   /* extract.c:352-369: skip chunks that touch no BED region (the bin is marked as written) */
+            if(spanOverlapsBED((int32_t)localTid, (int32_t)localPos, (int32_t)localEnd, config->bed, &bedIdx) != 1) { awaitTurn(localBin); passTurn(); continue; }
         }
         localPos2 = 0; if(localPos > 1) localPos2 = localPos - 2;
         lastPos = localPos;
@@ -985,6 +1065,7 @@ static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {  
         if(seqlen < 0) {
             fprintf(stderr, "faidx_fetch_seq returned %i while trying to fetch the sequence for tid %s:%" PRIu32 "-%" PRIu32 "!\n", seqlen, bf->target_name[localTid], localPos2, localEnd);
             fprintf(stderr, "Note that the output will be truncated!\n");
+            awaitTurn(localBin); passTurn();        /* the reference `continue`s without releasing its bin (extract.c:382-387): with -@ > 1 every later chunk then waits forever; not reproduced */
             continue;
         }
         data.seq = seq; data.offset = localPos2; data.lseq = seqlen;
@@ -1051,17 +1132,20 @@ static void extractCalls(Config *config, const bamfile *bf, const fasta *fa) {  
             writeBlank(os, config, bf->target_name[localTid], localEnd, localPos2, &lastPos, seq, seqlen);
         }
         free(seq);
-        /* ordered flush (extract.c:514-535); single worker => already in order */
+        /* ordered flush (extract.c:514-535) */
+        awaitTurn(localBin);
         if(config->cytosine_report) { if(os[0]->l) { fputs(os[0]->s, config->output_fp[0]); os[0]->l = 0; os[0]->s[0] = 0; } }
         else {
             if(config->keepCpG && os[0]->l) { fputs(os[0]->s, config->output_fp[0]); os[0]->l = 0; os[0]->s[0] = 0; }
             if(config->keepCHG && os[1]->l) { fputs(os[1]->s, config->output_fp[1]); os[1]->l = 0; os[1]->s[0] = 0; }
             if(config->keepCHH && os[2]->l) { fputs(os[2]->s, config->output_fp[2]); os[2]->l = 0; os[2]->s[0] = 0; }
         }
+        passTurn();
         destroyOlapHash(oh);
     }
     for(i = 0; i < 3; i++) free(os_[i].s);
-    if(nVariantPositions > 0) globalnVariantPositions += nVariantPositions;
+    if(nVariantPositions > 0) { pthread_mutex_lock(&outputMutex); globalnVariantPositions += nVariantPositions; pthread_mutex_unlock(&outputMutex); }
+    return NULL;
 }
 
 static void printHeader(FILE *of, const char *context, char *opref, Config config) {   /* extract.c:562-569 */
@@ -1142,7 +1226,7 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
         {"outputBBMFile", 1, NULL, 'O'}, {"outputBBMFileName", 1, NULL, 'N'}, {"mappabilityBBM", 1, NULL, 'B'},
         {0, 0, NULL, 0}};
 
-    globalTid = globalPos = globalEnd = bin_ = 0; globalnVariantPositions = 0;
+    globalTid = globalPos = globalEnd = bin_ = outputBin = 0; globalnVariantPositions = 0;
     memset(&config, 0, sizeof(config));
     config.mappabilityCutoff = 0.01; config.minMappableBases = 15;
     config.keepCpG = 1; config.minMapq = 10; config.minPhred = 5; config.minDepth = 1;
@@ -1221,6 +1305,7 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
     if(BWName || noBAM) { fprintf(stderr, "mdk_oracle: bigWig input (-M/-O/-N) needs libBigWig, which is not available; use -B <file.bbm>\n"); return -4; }
 
     FastaName = argv[optind]; BAMName = argv[optind + 1];
+    g_load_threads = config.nThreads;
     if((i = bam_load(BAMName, &bf)) != 0) { fprintf(stderr, "Couldn't open %s for reading!\n", BAMName); return -4; }
     if(config.BBMName && (BBM_ptr = fopen(config.BBMName, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", config.BBMName); return -8; }
 
@@ -1323,7 +1408,14 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
     }
     if(getenv("MDK_ORACLE_DUMP")) dump_fp = fopen(getenv("MDK_ORACLE_DUMP"), "w");
 
-    extractCalls(&config, &bf, &fa);
+    {   /* extract.c:1479-1486 */
+        extractArgs ea = {&config, &bf, &fa}; int nt = config.nThreads < 1 ? 1 : config.nThreads; pthread_t *threads = calloc((size_t)nt, sizeof(pthread_t));
+        if(dump_fp) nt = 1;      /* the per-column dump is written as columns are finished: one worker keeps it ordered */
+        for(i = 1; i < nt; i++) pthread_create(threads + i, NULL, extractCalls, &ea);
+        extractCalls(&ea);
+        for(i = 1; i < nt; i++) pthread_join(threads[i], NULL);
+        free(threads);
+    }
 
     if(dump_fp) { fclose(dump_fp); dump_fp = NULL; }
     if(globalnVariantPositions) printf("%" PRIu64 " positions were excluded due to likely being variants.\n", globalnVariantPositions);
@@ -2024,6 +2116,7 @@ static int mbias_report_main(int argc, char *argv[]) {
 int main(int argc, char *argv[]) {                             /* main.c:39-62 */
     if(argc == 1) { fprintf(stderr, "mdk_oracle: CPU oracle for `MethylDackel extract`\nUsage: mdk_oracle extract [options] ref.fa aln.bam\n"); return 0; }
     if(strcmp(argv[1], "-v") == 0 || strcmp(argv[1], "--version") == 0) { printf("%s (using HTSlib version %s)\n", ORACLE_VERSION, "none: mdk_oracle"); return 0; }
+    if(getenv("MDK_ORACLE_PERTURB")) { g_pt = atoi(getenv("MDK_ORACLE_PERTURB")); if(g_pt < 0 || g_pt >= PT_N) g_pt = 0; }
     if(strcmp(argv[1], "extract") == 0) return extract_main(argc - 1, argv + 1);
     if(strcmp(argv[1], "mbias") == 0) return mbias_main(argc - 1, argv + 1);
     if(strcmp(argv[1], "perRead") == 0) return perRead_main(argc - 1, argv + 1);
