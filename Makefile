@@ -9,9 +9,10 @@ HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bi
 
 all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 
-$(B)/libmdk_hip.so: methyldackel_amd/csrc/mdk_hip.hip include/mdk_hip.h
+HIPSRC := methyldackel_amd/csrc/mdk_hip.hip methyldackel_amd/csrc/mdk_comm.hip
+$(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp include/mdk_hip.h
 	@mkdir -p $(B)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude -o $@ methyldackel_amd/csrc/mdk_hip.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude -Imethyldackel_amd/csrc -o $@ $(HIPSRC) -ldl
 
 $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldackel_amd/csrc/host/mdk_plan.h include/mdk_extract.h include/mdk_hip.h $(B)/libmdk_hip.so
 	$(CC) $(CFLAGS) -shared -Iinclude -o $@ $(HOSTSRC) -L$(B) -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
@@ -19,7 +20,10 @@ $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldac
 $(B)/MethylDackel: methyldackel_amd/csrc/host/main.c $(B)/libmdk_extract.so
 	$(CC) $(CFLAGS) -Iinclude -o $@ methyldackel_amd/csrc/host/main.c -L$(B) -lmdk_extract -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
 
-tools: tools/_build/mdk_synth
+tools: tools/_build/mdk_synth tools/_build/mdk_calib
+tools/_build/mdk_calib: tools/mdk_calib.hip
+	@mkdir -p tools/_build
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ tools/mdk_calib.hip
 tools/_build/mdk_synth: tools/mdk_synth.c
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -o $@ tools/mdk_synth.c -lz -lm

@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X `MethylDackel extract` hot path.
 
-Metric (BASELINE.json): CpG calls/s on the synthetic 1 Mb contig, 30x paired-end WGBS BAM (configs[1], "S1"),
-CpG-only extract.  One "step" = one pass of the device path (pileup + scan + gather kernels) over the admitted reads
-of one S1 interval, inputs already resident in HBM.  With N ranks every rank owns its own S1 interval (weak scaling:
-independent intervals, as the path shards by contig/interval) and, after each step, the per-interval site buffers are
-gathered to rank 0 over RCCL -- the one real exchange step of the path.
+Metric (BASELINE.json): CpG calls/s, synthetic 30x paired-end WGBS, CpG-only extract, in 1 Mb chunks (configs[1], "S1").
 
-Also reported on the same JSON line:
-  roofline     -- pileup kernel: algorithmic bytes (SURVEY.md 8d formula) / HIP-event kernel time vs 8 TB/s HBM
-  cpu_baseline -- the CPU oracle (`oracle/`, single thread, "port") timed on the same S1 BAM on this box's host
+Workload.  Every rank holds R (default 16) DIFFERENT S1-sized intervals resident in HBM: the R chunks the reference's
+schedule (1 Mb chunks, extract.c:325-350) cuts out of an R Mb synthetic contig, each about 52 MB of admitted reads, about
+0.8 GB together -- beyond the 256 MiB Infinity Cache, so every launch streams its inputs from HBM.  One STEP is one pass of
+the hot path over a batch of P x R chunks (default P = 256: 4096 chunk launches), i.e. the R resident intervals presented P
+times in rotation.  Inside a step every launch is issued and collected (site count read back) with two launches in flight,
+exactly as extract_main drives the device; with N ranks the kernels write into send buffers and the results of 8
+consecutive launches travel to rank 0 with one ncclSend/ncclRecv exchange (libmdk_hip's md_comm, RCCL over xGMI) while the
+next group is computed.  The loop is libmdk_hip's md_bench_run (C); Python only brackets it.
+
+Also on the JSON line:
+  roofline     -- k_pileup: algorithmic bytes per launch (SURVEY.md 8d formula, averaged over the R intervals) / HIP-event
+                  time per launch while rotating over the R intervals on one stream, vs 8 TB/s
+  cpu_baseline -- the CPU oracle (`oracle/`, "port") end to end on a 32 Mb sample of the same workload with all host
+                  cores (`-@ nproc`: chunk-parallel workers as the reference's, extract.c:1479-1486), and with one thread
+  streamed     -- the same chunks with H2D upload + kernel + D2H of the sites per chunk (pinned staging, two slots)
+  e2e_cli      -- `MethylDackel extract` of this build on the CPU sample's BAM, whole-process wall clock
 """
 import argparse
 import ctypes as C
 import json
 import os
-import statistics
 import subprocess
 import sys
 import tempfile
@@ -27,6 +35,7 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 S1_SEED = 0x5EED0001
+GROUP = 8                    # launches per exchange
 
 
 def log(*a):
@@ -36,14 +45,17 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--length", type=int, default=1_000_000, help="interval length per rank (S1 = 1 Mb)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--resident", type=int, default=16, help="R: resident 1 Mb intervals per rank (R x ~52 MB must exceed the 256 MiB Infinity Cache)")
+    ap.add_argument("--passes", type=int, default=256, help="P: a step presents the R resident intervals P times (P x R chunk launches)")
+    ap.add_argument("--length", type=int, default=1_000_000, help="interval (chunk) length; S1 = 1 Mb")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--extra", default="", help="extra extract options, e.g. '--CHG --CHH' (not the headline config)")
     ap.add_argument("--synth-args", default="", help="extra mdk_synth options, e.g. '--clean' (not the headline config)")
-    ap.add_argument("--cpu-sample-length", type=int, default=32_000_000, help="bp of the same synthetic workload the CPU oracle is timed on (about 10 s of CPU work)")
+    ap.add_argument("--cpu-sample-length", type=int, default=32_000_000, help="bp of the same synthetic workload the CPU oracle is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data-dir", default="", help="keep the synthetic inputs here and reuse them on the next run (profiling passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -58,125 +70,90 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU path)")
-    # MDK_BENCH_BACKEND=gloo is a test mode for boxes with fewer GPUs than ranks (ranks then share devices and the exchange is
-    # staged through host memory); the real multi-GPU run uses "nccl", i.e. RCCL over xGMI
-    backend = os.environ.get("MDK_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
-    cdev = "cuda" if backend == "nccl" else "cpu"          # where the tensors of the small bookkeeping collectives live
     if world > 1:
+        # torch.distributed carries only bookkeeping (the RCCL id, barriers, the max over ranks) over gloo; the data path --
+        # site buffers to rank 0 -- is libmdk_hip's own RCCL communicator, created below
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import methyldackel_amd as mdk
     if rank == 0:
         mdk.build()
     if world > 1:
         dist.barrier()
+    L = mdk.lib_hip()
 
+    R = max(2, args.resident)
     work = Path(tempfile.mkdtemp(prefix=f"mdk_bench_r{rank}_"))
-    prefix = work / "S1"
-    synth = subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(prefix), "-L", str(args.length), "-c", str(args.coverage),
-                            "-s", str(S1_SEED + rank)] + args.synth_args.split(), capture_output=True, text=True, check=True)
-    synth_info = json.loads(synth.stdout)
+    data = Path(args.data_dir) if args.data_dir else work
+    data.mkdir(parents=True, exist_ok=True)
+    prefix = data / f"S1_r{rank}_{R}x{args.length}_{args.coverage}"
+    t0 = time.time()
+    if not (Path(str(prefix) + ".json").exists() and Path(str(prefix) + ".bam").exists()):
+        synth = subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(prefix), "-L", str(args.length * R), "-c", str(args.coverage),
+                                "-s", str(S1_SEED + rank)] + args.synth_args.split(), capture_output=True, text=True, check=True)
+        Path(str(prefix) + ".json").write_text(synth.stdout)
+    synth_info = json.loads(Path(str(prefix) + ".json").read_text())
+    log(f"[bench] rank {rank}: synthetic {R} x {args.length} bp at {args.coverage}x in {time.time() - t0:.1f} s")
     extra = args.extra.split()
-    cmd = [str(prefix) + ".fa", str(prefix) + ".bam", "--chunkSize", str(args.length)] + extra + ["-o", str(work / "gpu")]
+    cmd = [str(prefix) + ".fa", str(prefix) + ".bam", "--chunkSize", str(args.length), "-@", str(min(32, os.cpu_count() or 1))] + extra + ["-o", str(work / "gpu")]
 
-    # host side: decode + admit + pack the interval once; it then stays resident in HBM
+    # host side: decode + admit + pack the R intervals once; they then stay resident in HBM, one per device slot
     t0 = time.time()
     plan = mdk.Plan(cmd)
     cfg = plan.dev_cfg()
-    chunk = plan.next_chunk()
-    t_host = time.time() - t0
-    assert chunk is not None and not chunk.skipped
+    cfg.n_slots = R + 2                      # R resident intervals + two slots for the streamed figure
     dev = mdk.Device(cfg, device=dev_index)
-    plan.ensure_reference(dev, chunk.tid)
-    dev.upload(0, chunk.batch)
-    dev.launch(0)
-    sites = dev.download(0)
-    n_sites = sites.n_sites
-    cpg_calls = 0
-    all_calls = 0
-    for i in range(n_sites):
-        r = sites.site[i]
-        c = r.nmeth + r.nunmeth
-        all_calls += c
-        if ((r.meta >> 1) & 3) == 0:
-            cpg_calls += c
-    variant = cfg.minOppositeDepth > 0
-    L = mdk.lib_hip()
+    reads = segs = n_sites_sum = cpg_calls = all_calls = 0
+    keep_batches = []                        # (host copies of two batches for the streamed figure)
+    n_chunks = 0
+    while n_chunks < R:
+        chunk = plan.next_chunk()
+        assert chunk is not None and not chunk.skipped, "the synthetic contig must give R full chunks"
+        plan.ensure_reference(dev, chunk.tid)
+        dev.upload(n_chunks, chunk.batch)
+        dev.launch(n_chunks)
+        sites = dev.download(n_chunks)        # waits: the pipeline's host buffers may be recycled after this
+        reads += chunk.batch.n_reads; segs += chunk.batch.n_segs; n_sites_sum += sites.n_sites
+        for i in range(sites.n_sites):
+            r = sites.site[i]
+            c = r.nmeth + r.nunmeth
+            all_calls += c
+            if ((r.meta >> 1) & 3) == 0:
+                cpg_calls += c
+        if n_chunks < 2:
+            b = chunk.batch
+            seg_copy = C.create_string_buffer(C.string_at(b.seg, b.n_segs * C.sizeof(mdk.md_seg)), b.n_segs * C.sizeof(mdk.md_seg))
+            blob_copy = C.create_string_buffer(C.string_at(b.blob, b.blob_bytes), b.blob_bytes)
+            keep_batches.append((b.tid, b.beg, b.end, b.n_segs, b.n_reads, b.blob_bytes, b.algo_bytes, seg_copy, blob_copy))
+        n_chunks += 1
+    t_host = time.time() - t0
+    slots = list(range(R))
+    slot_arr = (C.c_int * R)(*slots)
 
-    # the kernel writes its result straight into torch tensors (md_dev_bind_output), which is what travels over RCCL.
-    # Two slots, as in extract_main: chunk k is launched while chunk k-1 is collected (two chunks in flight).
-    w0 = dev.wait(0)
-    n_tiles = w0.n_tiles
-    cap = int(w0.n_slots) + 1024             # slots = kept context positions of the interval: fixed by the reference, not by the reads
-    dev.upload(1, chunk.batch)
-    t_site = [torch.zeros((cap, 4), dtype=torch.int32, device="cuda") for _ in range(2)]
-    t_var = [torch.zeros((cap, 2), dtype=torch.int32, device="cuda") if variant else None for _ in range(2)]
-    t_seg = [torch.zeros((n_tiles + 1, 2), dtype=torch.int32, device="cuda") for _ in range(2)]
-    for sl in range(2):
-        dev.bind_output(sl, C.c_void_p(t_site[sl].data_ptr()), C.c_void_p(t_var[sl].data_ptr()) if variant else None, C.c_void_p(t_seg[sl].data_ptr()), cap, n_tiles + 1)
-
-    # N > 1: the exchange step of the sharded path -- per-interval site buffers travel to rank 0 (RCCL gather over xGMI).
-    # The kernels write straight into the send buffer (no staging copy), and the results of GROUP consecutive steps
-    # travel together: fewer, larger collectives, the next group being computed while the previous one is on the links.
-    GROUP = 8
+    comm = C.c_void_p()
     if world > 1:
-        shape = torch.tensor([cap, n_tiles + 1], dtype=torch.int64, device=cdev)
-        shapes = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
-        dist.all_gather(shapes, shape)
-        gcap = int(max(int(x[0].item()) for x in shapes)); gtiles = int(max(int(x[1].item()) for x in shapes))
-        E = gcap * 4 + gtiles * 2                                  # int32 words of one step: sites, then tile segments
-        sendbuf = [torch.zeros((GROUP * E,), dtype=torch.int32, device="cuda") for _ in range(2)]
-        if backend == "nccl":
-            recvbuf = [[torch.empty_like(sendbuf[0]) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-        else:
-            recvbuf = [[torch.empty((GROUP * E,), dtype=torch.int32) for _ in range(world)] if rank == 0 else None for _ in range(2)]
-        pending = [None, None]
-        t_dummy_var = t_var
+        idbuf = torch.zeros(mdk.COMM_ID_BYTES, dtype=torch.uint8)
+        if rank == 0:
+            raw = C.create_string_buffer(mdk.COMM_ID_BYTES)
+            rc = L.md_comm_unique_id(raw)
+            assert rc == 0, L.md_dev_last_error()
+            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+        dist.broadcast(idbuf, src=0)
+        rc = L.md_comm_open_rank(dev.h, rank, world, bytes(idbuf.numpy().tobytes()), C.byref(comm))
+        assert rc == 0, L.md_dev_last_error()
+    bench = C.c_void_p()
+    rc = L.md_bench_open(dev.h, comm if world > 1 else None, slot_arr, R, GROUP, C.byref(bench))
+    assert rc == 0, L.md_dev_last_error()
 
-    def bind_for(k):
-        """step k writes into step-slot k % GROUP of send buffer (k // GROUP) & 1"""
-        if world == 1:
-            return
-        x, e = (k // GROUP) & 1, k % GROUP
-        if e == 0 and pending[x] is not None:                      # this buffer is about to be overwritten: its gather must be over
-            pending[x].wait(); pending[x] = None
-        base = sendbuf[x].data_ptr() + 4 * e * E
-        sl = k & 1
-        dev.bind_output(sl, C.c_void_p(base), C.c_void_p(t_dummy_var[sl].data_ptr()) if variant else None, C.c_void_p(base + 16 * gcap), gcap, gtiles)
-
-    def exchange(k, last):
-        """after step k has been collected: send its group when the group is complete (or the run ends)"""
-        if world == 1 or not (k % GROUP == GROUP - 1 or last):
-            return
-        x = (k // GROUP) & 1
-        if backend == "nccl":
-            pending[x] = dist.gather(sendbuf[x], recvbuf[x], dst=0, async_op=True)
-        else:
-            dist.gather(sendbuf[x].cpu(), recvbuf[x], dst=0)
+    launches_per_step = args.passes * R
+    res = mdk.md_bench_run_result()
 
     def run(k_steps):
-        """k_steps passes over the batch: every pass is launched, collected and (N > 1) exchanged inside the call"""
-        n = 0
-        for k in range(k_steps):
-            bind_for(k)
-            dev.launch(k & 1)
-            if k:
-                n = dev.wait((k - 1) & 1).n_slots
-                exchange(k - 1, False)
-        if k_steps:
-            n = dev.wait((k_steps - 1) & 1).n_slots
-            exchange(k_steps - 1, True)
-        if world > 1:
-            for x in range(2):
-                if pending[x] is not None:
-                    pending[x].wait(); pending[x] = None
-        return n
+        rc = L.md_bench_run(bench, k_steps * launches_per_step, C.byref(res))
+        assert rc == 0, L.md_dev_last_error()
 
     def fence():
         if world > 1:
@@ -187,107 +164,159 @@ def main():
     run(args.warmup)
     fence()
     t0 = time.perf_counter()
-    n_last = run(args.steps)
+    run(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    assert n_last >= n_sites
-    # the bound buffers hold the same sites as the library's own download (segment order -> ascending)
-    last = (args.steps - 1) & 1 if args.steps else 0
-    if world > 1 and args.steps:
-        kl = args.steps - 1
-        flat = sendbuf[(kl // GROUP) & 1][(kl % GROUP) * E:(kl % GROUP + 1) * E].cpu().numpy().view("uint32")
-        chk = flat[: gcap * 4].reshape(gcap, 4); segs = flat[gcap * 4:].reshape(gtiles, 2)
-    else:
-        chk = t_site[last].cpu().numpy().view("uint32"); segs = t_seg[last].cpu().numpy().view("uint32")
-    got = []
-    for t in range(n_tiles):
-        o, c = int(segs[t, 0]), int(segs[t, 1])
-        got.extend(int(x) for x in chk[o:o + c, 0])
-    assert got == [sites.site[i].pos for i in range(n_sites)], "bound-output sites differ from md_dev_download"
+    if args.steps:
+        rc = L.md_bench_verify(bench)
+        assert rc == 0, L.md_dev_last_error()
+    exchanges, bytes_per_exchange = int(res.exchanges), int(res.bytes_per_exchange)
+    L.md_bench_close(bench)
+
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([cpg_calls, all_calls, int(n_sites)], dtype=torch.int64, device=cdev)
+        tot = torch.tensor([cpg_calls, all_calls, int(n_sites_sum)], dtype=torch.int64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_cpg_calls, total_calls, total_sites = (int(x) for x in tot.tolist())
-        if rank == 0 and args.steps:            # rank 0 really received every rank's interval: the tile segments of the last step hold sites
-            kl = args.steps - 1
-            for r in recvbuf[(kl // GROUP) & 1]:
-                one = r[(kl % GROUP) * E:(kl % GROUP + 1) * E]
-                assert int(one[gcap * 4:].view(-1, 2)[:, 1].sum().item()) > 0
     else:
-        total_cpg_calls, total_calls, total_sites = cpg_calls, all_calls, int(n_sites)
+        total_cpg_calls, total_calls, total_sites = cpg_calls, all_calls, int(n_sites_sum)
 
-    # kernel-level timing with HIP events on the launch stream, inside the library
-    br = dev.bench(0, 5, 50)
+    # kernel-level timing with HIP events on the launch stream, inside the library, rotating over the R resident intervals
+    br = dev.bench_rotate(slots, 2 * R, max(200, 50 * R))
     pile_s = br.ms_pileup / 1e3
     achieved = br.algo_bytes / pile_s / 1e9 if pile_s > 0 else 0.0
+    br1 = dev.bench(0, 5, 200)                 # one interval relaunched on cache-resident data, for comparison with round 1
+
+    # streamed: the same chunk with its H2D upload (pinned staging) and the D2H of its sites, two slots, chunk k+1 uploaded
+    # and launched while chunk k is downloaded
+    streamed = None
+    if world == 1 and len(keep_batches) == 2:
+        pinned, batches = [], []
+        L.md_host_alloc.restype = C.c_void_p
+        for (tid, beg, end, n_segs, n_reads, blob_bytes, algo_bytes, seg_copy, blob_copy) in keep_batches:
+            ps = L.md_host_alloc(C.c_uint64(len(seg_copy))); pb = L.md_host_alloc(C.c_uint64(len(blob_copy)))
+            C.memmove(ps, seg_copy, len(seg_copy)); C.memmove(pb, blob_copy, len(blob_copy))
+            pinned += [ps, pb]
+            b = mdk.md_read_batch(); b.tid = tid; b.beg = beg; b.end = end; b.n_segs = n_segs; b.seg = C.cast(ps, C.POINTER(mdk.md_seg))
+            b.blob = C.cast(pb, C.POINTER(C.c_uint8)); b.blob_bytes = blob_bytes; b.n_reads = n_reads; b.algo_bytes = algo_bytes
+            batches.append(b)
+        n_stream = 200
+        for timed in (False, True):
+            ts = time.perf_counter()
+            dev.submit(R, batches[0])
+            for k in range(1, n_stream if timed else 10):
+                dev.submit(R + (k & 1), batches[k & 1])
+                dev.download(R + ((k - 1) & 1))
+            dev.download(R + ((n_stream if timed else 10) - 1 & 1))
+            t_stream = time.perf_counter() - ts
+        h2d = (len(keep_batches[0][7]) + len(keep_batches[0][8]) + len(keep_batches[1][7]) + len(keep_batches[1][8])) / 2
+        per_chunk_calls = cpg_calls / R
+        streamed = {"ms_per_chunk": t_stream / n_stream * 1e3, "value": per_chunk_calls * n_stream / t_stream, "unit": "CpG calls/s", "h2d_bytes_per_chunk": int(h2d),
+                    "h2d_GBps": h2d * n_stream / t_stream / 1e9,
+                    "note": "per chunk: hipMemcpyAsync of segments + payload from pinned host memory, k_pileup, D2H of the site records; two slots (chunk k+1 is uploaded and launched while chunk k is downloaded)"}
+        for p in pinned:
+            L.md_host_free(C.c_void_p(p))
 
     # HBM traffic of the kernel cannot be sampled from inside this process; it is taken from the committed rocprofv3 PMC summary
-    # of this same command (profiles/, produced by tools/gpu_round.sh + tools/summarize_prof.py), or left null
+    # of this same command (profiles/, produced by tools/gpu_round.sh + tools/summarize_prof.py) with the calibration measured by
+    # tools/mdk_calib (byte gathers of a known line count), or left null
     traffic, traffic_note = None, None
     try:
-        prof = json.load(open(REPO / "profiles" / "r01_rocprofv3_pmc_summary.json"))
+        prof = json.load(open(REPO / "profiles" / "r02_rocprofv3_pmc_summary.json"))
         hb = prof["hbm_traffic_bytes_per_launch"]
         if not extra and not args.synth_args and args.length == 1_000_000:
-            traffic = hb["fetch_x2_gfx950_correction"] + hb["write_raw"]
-            traffic_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per k_pileup dispatch (profiles/r01_rocprofv3_pmc_summary.json): FETCH_SIZE KiB x 2 (gfx950 under-count, "
-                            "MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB; raw FETCH_SIZE is %.0f bytes" % hb["fetch_raw"])
+            traffic = hb["fetch_calibrated"] + hb["write_calibrated"]
+            traffic_note = hb["note"]
     except Exception:
         pass
 
     result = None
     if rank == 0:
-        value = total_cpg_calls * args.steps / dt
+        launches = args.steps * launches_per_step
+        value = (total_cpg_calls / R) * launches / dt if dt > 0 else 0.0        # total_cpg_calls = one pass over every rank's R intervals
+        headline = not extra and not args.synth_args and args.length == 1_000_000
         result = {
             "metric": "CpG calls/sec, synthetic 1 Mb contig 30x paired-end WGBS BAM, CpG extract",
             "value": value, "unit": "CpG calls/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3 if args.steps else 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32", "data": "synthetic",
-            "config": {"workload": "S1: synthetic 1 Mb contig, 30x PE 2x150 WGBS BAM, CpG-only extract (BASELINE.json configs[1])" if not extra and not args.synth_args and args.length == 1_000_000
-                       else f"synthetic {args.length} bp, {args.coverage}x, extract {' '.join(extra)}",
-                       "interval_bp": args.length, "coverage": args.coverage, "reads_admitted_per_gpu": int(chunk.batch.n_reads), "segments_per_gpu": int(chunk.batch.n_segs),
-                       "records_per_gpu": synth_info["records"], "sites_per_gpu": int(n_sites), "cpg_calls_per_gpu": int(cpg_calls),
-                       "tile": int(br.tile), "tiles": int(br.n_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes), "parallelism": f"interval-sharded x{n_gpus}" + (" + RCCL gather of site buffers" if world > 1 else ""),
-                       "in_flight": "2 chunks per GPU (step k is launched while step k-1 is collected, as extract_main does); every step is launched and collected inside the timed region"},
+            "config": {"workload": ("S1: synthetic 30x PE 2x150 WGBS, CpG-only extract in 1 Mb chunks (BASELINE.json configs[1])" if headline
+                                    else f"synthetic {args.length} bp chunks, {args.coverage}x, extract {' '.join(extra)}") +
+                                   f"; per GPU {R} different resident 1 Mb intervals (~{br.algo_bytes * R / 1e6:.0f} MB algorithmic, beyond the 256 MiB Infinity Cache)",
+                       "step": f"one pass over a batch of {args.passes} x {R} = {launches_per_step} chunks per GPU (the {R} resident intervals in rotation)",
+                       "chunk_launches_per_step_per_gpu": launches_per_step, "ms_per_chunk_launch": dt / launches * 1e3 if launches else 0.0,
+                       "interval_bp": args.length, "coverage": args.coverage, "resident_intervals_per_gpu": R,
+                       "reads_admitted_per_interval": reads // R, "segments_per_interval": segs // R, "records_per_gpu": synth_info["records"],
+                       "sites_per_interval": int(n_sites_sum) // R, "cpg_calls_per_interval": int(cpg_calls) // R,
+                       "tile": int(br.tile), "tiles": int(br.n_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes),
+                       "parallelism": f"interval-sharded x{n_gpus}" + (f" + RCCL gather of site buffers to rank 0 ({GROUP} launches per exchange, {bytes_per_exchange} B per exchange and rank)" if world > 1 else ""),
+                       "in_flight": "2 launches per GPU (launch k is issued, then launch k-1 is collected, as extract_main does); every launch is issued and collected inside the timed region"},
             "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_note, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup, "all_kernels_ms": br.ms_total},
+                         "traffic": traffic, "traffic_source": traffic_note, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup,
+                         "measured": f"HIP events around {max(200, 50 * R)} launches rotating over the {R} resident intervals on one stream",
+                         "cache_resident_comparison": {"kernel_ms": br1.ms_pileup, "achieved": br1.algo_bytes / (br1.ms_pileup / 1e3) / 1e9 if br1.ms_pileup > 0 else 0.0,
+                                                       "note": "interval 0 relaunched back to back: its ~52 MB stay in the 256 MiB Infinity Cache (the round-1 measurement)"}},
             "host_prep_s": t_host,
         }
+        if world > 1:
+            result["exchange"] = {"exchanges": exchanges, "bytes_per_exchange_per_rank": bytes_per_exchange, "transport": "ncclSend/ncclRecv group (libmdk_hip md_comm_gather)"}
+        if streamed:
+            result["streamed"] = streamed
         if not args.no_cpu_baseline and world == 1:
-            # CPU baseline on a bounded sample of the same workload: the same generator and parameters at 32 Mb (about 10 s of
-            # single-thread CPU time for the oracle), end to end from the BAM file; the product's CLI is timed on the same file.
-            sp = work / "cpu_sample"
-            subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(sp), "-L", str(args.cpu_sample_length), "-c", str(args.coverage), "-s", str(S1_SEED + 1000)] + args.synth_args.split(),
-                           capture_output=True, text=True, check=True)
+            # CPU baseline on a bounded sample of the same workload: the same generator and parameters at 32 Mb, end to end from
+            # the BAM file; the product's CLI is timed on the same file.
+            sp = data / f"cpu_sample_{args.cpu_sample_length}_{args.coverage}"
+            if not Path(str(sp) + ".bam.bai").exists():
+                subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(sp), "-L", str(args.cpu_sample_length), "-c", str(args.coverage), "-s", str(S1_SEED + 1000)] + args.synth_args.split(),
+                               capture_output=True, text=True, check=True)
             oracle = REPO / "oracle/_build/mdk_oracle"
-            (work / "co").mkdir(); (work / "cg").mkdir()
-            t1 = time.perf_counter()
-            subprocess.run([str(oracle), "extract", str(sp) + ".fa", str(sp) + ".bam"] + extra + ["-o", "out"], check=True, capture_output=True, cwd=work / "co")
-            t_cpu = time.perf_counter() - t1
+            ncores = os.cpu_count() or 1
+            # all cores: the reference's chunk-parallel workers need enough chunks to go round, so the chunk size is chosen to
+            # give every thread about four (outputs do not depend on --chunkSize)
+            chunk_all = max(50_000, args.cpu_sample_length // (4 * ncores))
+            timings = {}
+            for name, thr, ck in (("single", 1, None), ("allcore", ncores, chunk_all)):
+                d = work / f"co_{name}"; d.mkdir()
+                opts = ["-@", str(thr)] + (["--chunkSize", str(ck)] if ck else [])
+                t1 = time.perf_counter()
+                subprocess.run([str(oracle), "extract", str(sp) + ".fa", str(sp) + ".bam"] + opts + extra + ["-o", "out"], check=True, capture_output=True, cwd=d)
+                timings[name] = time.perf_counter() - t1
+            same = all((work / "co_single" / f).read_bytes() == (work / "co_allcore" / f).read_bytes() for f in os.listdir(work / "co_single"))
             calls = 0
-            for line in open(work / "co" / "out_CpG.bedGraph"):
+            for line in open(work / "co_single" / "out_CpG.bedGraph"):
                 f = line.split("\t")
                 if len(f) == 6:
                     calls += int(f[4]) + int(f[5])
-            threads = str(min(64, os.cpu_count() or 1))
-            best = None
-            for _ in range(2):
-                t1 = time.perf_counter()
-                rg = mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=work / "cg")
-                dtc = time.perf_counter() - t1
-                best = dtc if best is None else min(best, dtc)
-            ident = rg.returncode == 0 and all((work / "cg" / f).read_bytes() == (work / "co" / f).read_bytes() for f in os.listdir(work / "co"))
-            result["cpu_baseline"] = {"value": calls / t_cpu, "unit": "CpG calls/s", "cores": 1, "kind": "port",
-                                      "sample": f"oracle/mdk_oracle extract (single-thread C restatement of the reference, end to end from the BAM file: inflate, pileup, text) on a "
-                                                f"{args.cpu_sample_length} bp / {args.coverage}x sample of the same synthetic workload: {t_cpu:.2f} s, {calls} CpG calls; "
-                                                f"the reference binary itself cannot be built here (no htslib)",
-                                      "seconds": t_cpu, "cpg_calls": calls}
-            result["e2e_cli"] = {"seconds": best, "value": calls / best, "unit": "CpG calls/s", "threads": int(threads), "speedup_vs_cpu_baseline": t_cpu / best,
-                                 "identical_to_oracle": bool(ident),
-                                 "note": "`MethylDackel extract` of this build on the same file, wall-clock of the whole process (start-up, HIP init ~0.4 s, inflate, pack, H2D, kernels, D2H, text)"}
+            threads = str(min(64, ncores))
+            e2e = {}
+            for name, env in (("default", {}), ("detached", {"MDK_DETACH": "1"})):
+                (work / f"cg_{name}").mkdir()
+                best = None
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    rg = mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=work / f"cg_{name}", env=env)
+                    dtc = time.perf_counter() - t1
+                    best = dtc if best is None else min(best, dtc)
+                ident = rg.returncode == 0 and all((work / f"cg_{name}" / f).read_bytes() == (work / "co_single" / f).read_bytes() for f in os.listdir(work / "co_single"))
+                e2e[name] = (best, bool(ident))
+            t_cpu = timings["allcore"]
+            result["cpu_baseline"] = {"value": calls / t_cpu, "unit": "CpG calls/s", "cores": ncores, "kind": "port",
+                                      "sample": f"oracle/mdk_oracle extract -@ {ncores} --chunkSize {chunk_all} (C restatement of the reference with its chunk-parallel worker threads, extract.c:325-350,1479-1486; "
+                                                f"end to end from the BAM file: inflate, pileup, text) on a {args.cpu_sample_length} bp / {args.coverage}x sample of the same synthetic workload: "
+                                                f"{t_cpu:.2f} s, {calls} CpG calls; the reference binary itself cannot be built here (no htslib)",
+                                      "seconds": t_cpu, "cpg_calls": calls, "identical_to_single_thread": bool(same),
+                                      "single_thread": {"value": calls / timings["single"], "seconds": timings["single"], "cores": 1}}
+            best, ident = e2e["default"]
+            result["e2e_cli"] = {"seconds": best, "value": calls / best, "unit": "CpG calls/s", "threads": int(threads),
+                                 "speedup_vs_cpu_baseline": t_cpu / best, "speedup_vs_single_thread": timings["single"] / best, "identical_to_oracle": ident,
+                                 "detached_seconds": e2e["detached"][0], "detached_identical": e2e["detached"][1],
+                                 "note": "`MethylDackel extract` of this build on the same file, wall-clock of the whole process, one process (start-up, HIP init, inflate, chunk preparation, H2D, kernels, "
+                                         "D2H, text, teardown); detached_seconds = the opt-in MDK_DETACH=1 mode, where the parent returns when the outputs are closed and a child finishes the GPU teardown"}
         print(json.dumps(result), flush=True)
+    if world > 1:
+        L.md_comm_close(comm)
     dev.close()
     plan.close()
     if world > 1:

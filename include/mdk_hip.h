@@ -187,6 +187,43 @@ int64_t md_sites_order(const md_site *site, const md_site_var *var, const md_til
  * every time) and time them with HIP events on the slot's stream. */
 int  md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench_result *out);
 
+/* The same for `n` uploaded slots holding DIFFERENT intervals, launched round robin on one stream (`iters` launches in
+ * all): with enough slots the working set exceeds the 256 MiB Infinity Cache and every launch streams its inputs from
+ * HBM.  algo_bytes / n_sites are per launch, averaged over the slots; ms_total == ms_pileup. */
+int  md_dev_bench_rotate(md_dev *h, const int *slots, int n, int warmup, int iters, md_bench_result *out);
+
+/* ---- multi-GPU: the exchange step of the interval-sharded path (SURVEY.md 8b last row, 8e) ----
+ * Chunk k of the reference's schedule belongs to GPU k mod N; per-interval site buffers travel to rank 0 (whose host writes
+ * the files) with ncclSend/ncclRecv groups over xGMI -- a gather, never a reduction.  RCCL is loaded on first use.
+ *   md_comm_open_rank   one process per GPU (torchrun-style launch): rank 0 makes an id, every rank gets it out of band
+ *   md_comm_open_local  one process driving n device handles = ranks 0..n-1 (`MethylDackel extract` with MDK_GPUS=n).
+ *                       Handles that share one physical device (tests on a single GPU) exchange with device copies.
+ * md_comm_gather: d_send/send_bytes are indexed by LOCAL rank, d_recv/recv_bytes by GLOBAL rank (read only where rank 0 is
+ * local; entry 0 may be NULL to leave rank 0's own buffer where it is).  Sizes must agree on both sides.  Asynchronous:
+ * the send buffers must be complete before the call, and md_comm_wait must return before either side is touched again. */
+#define MD_COMM_ID_BYTES 128
+typedef struct md_comm md_comm;
+int  md_comm_unique_id(uint8_t *id /* [MD_COMM_ID_BYTES] */);
+int  md_comm_open_rank(md_dev *h, int rank, int world, const uint8_t *id, md_comm **out);
+int  md_comm_open_local(md_dev *const *h, int n, md_comm **out);
+void md_comm_close(md_comm *c);
+int  md_comm_world(const md_comm *c);
+int  md_comm_gather(md_comm *c, const void *const *d_send, const uint64_t *send_bytes, void *const *d_recv, const uint64_t *recv_bytes);
+int  md_comm_wait(md_comm *c);
+
+/* The resident-input benchmark loop of bench.py: `n` >= 2 uploaded slots holding different intervals are launched round
+ * robin, two in flight (launch k is issued, then launch k-1 is collected, as extract_main does); the kernels write straight
+ * into a send buffer and, with a communicator, the results of `group` consecutive launches travel to rank 0 in one exchange
+ * while the next group is computed.  md_bench_verify compares what the last launch left in the send buffer with
+ * md_dev_download of the same interval (and, on rank 0, checks that every peer's data arrived). */
+typedef struct md_bench md_bench;
+typedef struct { uint64_t launches, slots_last, exchanges, bytes_per_exchange; } md_bench_run_result;
+int  md_bench_open(md_dev *h, md_comm *comm /* NULL: one GPU */, const int *slots, int n, int group, md_bench **out);
+int  md_bench_run(md_bench *b, int64_t launches, md_bench_run_result *out);
+int  md_bench_verify(md_bench *b);
+int64_t md_bench_region_bytes(const md_bench *b);
+void md_bench_close(md_bench *b);
+
 /* Test hook: effective (post-trim, post-overlap-resolution) base code and quality of every query base of
  * every read of an uploaded slot, written to host arrays laid out like the blob's qual/seq (one byte per
  * base, concatenated in read order; out_off[i] = start of read i). */

@@ -102,9 +102,16 @@ class mdk_chunk(C.Structure):
                 ("batch", md_read_batch), ("n_records_seen", C.c_uint64), ("pr", md_pr_batch), ("host", C.c_void_p)]
 
 
+class md_bench_run_result(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("slots_last", C.c_uint64), ("exchanges", C.c_uint64), ("bytes_per_exchange", C.c_uint64)]
+
+
+COMM_ID_BYTES = 128
+
 HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
-               "md_dev_bench", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned",
+               "md_dev_bench", "md_dev_bench_rotate", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_local", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait",
+               "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned",
                "md_dev_mbias_submit", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
                "md_dev_perread_submit", "md_dev_perread_download"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
@@ -148,6 +155,19 @@ def lib_hip():
         L.md_sites_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
         L.md_sites_order.restype = C.c_int64
         L.md_dev_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
+        L.md_dev_bench_rotate.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
+        L.md_comm_unique_id.argtypes = [C.c_char_p]
+        L.md_comm_open_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.md_comm_open_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+        L.md_comm_close.argtypes = [C.c_void_p]; L.md_comm_close.restype = None
+        L.md_comm_world.argtypes = [C.c_void_p]
+        L.md_comm_gather.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.md_comm_wait.argtypes = [C.c_void_p]
+        L.md_bench_open.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.md_bench_run.argtypes = [C.c_void_p, C.c_int64, C.POINTER(md_bench_run_result)]
+        L.md_bench_verify.argtypes = [C.c_void_p]
+        L.md_bench_region_bytes.argtypes = [C.c_void_p]; L.md_bench_region_bytes.restype = C.c_int64
+        L.md_bench_close.argtypes = [C.c_void_p]; L.md_bench_close.restype = None
         L.md_dev_debug_effective.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.md_dev_mbias_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_read_batch)]
         L.md_dev_mbias_read.argtypes = [C.c_void_p, C.POINTER(md_mbias)]
@@ -247,6 +267,13 @@ class Device:
 
     def bind_output(self, slot: int, d_site, d_var, d_seg, cap_sites: int, cap_tiles: int):
         self._chk(self.L.md_dev_bind_output(self.h, slot, d_site, d_var, d_seg, cap_sites, cap_tiles), "md_dev_bind_output")
+
+    def bench_rotate(self, slots, warmup: int, iters: int) -> md_bench_result:
+        """kernel time with HIP events while rotating over several resident intervals (working set beyond the Infinity Cache)"""
+        r = md_bench_result()
+        arr = (C.c_int * len(slots))(*slots)
+        self._chk(self.L.md_dev_bench_rotate(self.h, arr, len(slots), warmup, iters, C.byref(r)), "md_dev_bench_rotate")
+        return r
 
     def bench(self, slot: int, warmup: int, iters: int) -> md_bench_result:
         r = md_bench_result()

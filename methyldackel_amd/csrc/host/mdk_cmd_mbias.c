@@ -88,16 +88,16 @@ int mdk_plan_mbias_outputs(const mdk_plan *p, const char **opref, int *svg, int 
 }
 
 int mbias_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch; int rc, k = 0, ret = 0; devopen_t dop; pthread_t dth; md_mbias hist;
+    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch; int rc, k = 0, ret = 0; devopen_t dop; pthread_t dth; int dth_ok; md_mbias hist;
     if(argc > 2) hip_warm_up();
     rc = mdk_plan_open_mbias(argc, argv, &p);
     if(rc != 0 || !p) return rc;
     memset(&dop, 0, sizeof(dop));
     mdk_plan_dev_cfg(p, &dop.cfg);
     if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
-    pthread_create(&dth, NULL, devopen_main, &dop);
-    if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
-    pthread_join(dth, NULL);
+    dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
+    if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
+    if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `mbias`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     for(;; k++) {

@@ -85,16 +85,16 @@ int mdk_plan_emit_perread(mdk_plan *p, const mdk_chunk *c, const md_pr_count *co
 }
 
 int perRead_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth;
+    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; int dth_ok;
     if(argc > 2) hip_warm_up();
     rc = mdk_plan_open_perread(argc, argv, &p);
     if(rc != 0 || !p) return rc;
     memset(&dop, 0, sizeof(dop));
     mdk_plan_dev_cfg(p, &dop.cfg);
     if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
-    pthread_create(&dth, NULL, devopen_main, &dop);
-    if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
-    pthread_join(dth, NULL);
+    dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
+    if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
+    if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `perRead`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     while(more || have[0] || have[1]) {       /* two chunks in flight, as in extract_main */

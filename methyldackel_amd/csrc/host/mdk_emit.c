@@ -148,7 +148,9 @@ MDK_LOCAL int emitter_start(emitter *E, mdk_plan *p, int n_th) {
     E->job = xcalloc((size_t)E->n_job, sizeof(ejob)); E->th = xcalloc((size_t)E->n_th, sizeof(pthread_t));
     if(!E->job || !E->th) return -5;
     pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv_job, NULL); pthread_cond_init(&E->cv_free, NULL); pthread_cond_init(&E->cv_turn, NULL);
-    for(i = 0; i < E->n_th; i++) pthread_create(&E->th[i], NULL, emitter_main, E);
+    for(i = 0; i < E->n_th; i++) if(pthread_create(&E->th[i], NULL, emitter_main, E)) break;
+    if(i == 0) { fprintf(stderr, "[mdk] cannot create an emitter thread\n"); return -5; }
+    E->n_th = i;            /* fewer than asked for still drain the same queue */
     return 0;
 }
 /* hand a chunk and its sites over (both are copied: the caller's buffers are recycled) */

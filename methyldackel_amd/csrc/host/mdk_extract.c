@@ -35,18 +35,18 @@ MDK_LOCAL void leave_fast(int ret) {
 }
 /* the HIP runtime takes 0.1-0.4 s to come up: start that before anything else (options, BAM header, FASTA), on its own thread */
 static void *hipwarm_main(void *arg) { (void)arg; (void)md_dev_warm(getenv("MDK_DEVICE") ? atoi(getenv("MDK_DEVICE")) : 0); return NULL; }
-/* only in the command's child process, which always ends with _exit: a library caller whose bad command line makes us return
- * at once must not find a half-initialised runtime racing its exit handlers */
+/* only in the `MethylDackel` command, which always ends with _exit (leave_fast): a library caller whose bad command line makes
+ * us return at once must not find a half-initialised runtime racing its exit handlers */
 MDK_LOCAL void hip_warm_up(void) {
     pthread_t th;
-    if(!getenv("MDK_DONE_FD") || pthread_create(&th, NULL, hipwarm_main, NULL)) return;
+    if(!fast_exit_wanted() || pthread_create(&th, NULL, hipwarm_main, NULL)) return;
     if(getenv("MDK_INIT_FIRST")) pthread_join(th, NULL); else pthread_detach(th);      /* experiment: runtime first, inflate threads afterwards */
 }
 /* md_dev_last_error is per thread: keep the text of a failed open for the thread that reports it */
 MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); if(d->rc) snprintf(d->err, sizeof(d->err), "%s", md_dev_last_error()); return NULL; }
 
 int extract_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; emitter em;
+    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; int dth_ok; emitter em;
     double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta;
     if(argc > 2) hip_warm_up();
     rc = mdk_plan_open(argc, argv, &p);
@@ -56,9 +56,9 @@ int extract_main(int argc, char *argv[]) {
     memset(&dop, 0, sizeof(dop));
     mdk_plan_dev_cfg(p, &dop.cfg);
     if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
-    pthread_create(&dth, NULL, devopen_main, &dop);
-    if(!p->started && pipeline_start(p)) { pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
-    pthread_join(dth, NULL);
+    dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
+    if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
+    if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
     t_dev = now_s() - T0;
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }

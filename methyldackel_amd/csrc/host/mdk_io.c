@@ -144,7 +144,12 @@ static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status)
         if(nt > (nb + 7) / 8) nt = (nb + 7) / 8;
         if(nt < 1) nt = 1;
         if(nt == 1) inflate_worker(&job);
-        else { for(i = 0; i < nt; i++) pthread_create(&th[i], NULL, inflate_worker, &job); for(i = 0; i < nt; i++) pthread_join(th[i], NULL); }
+        else {      /* the workers pull members from one counter: whoever could be started shares the slab, this thread included */
+            int made = 0;
+            for(i = 0; i < nt - 1; i++) { if(pthread_create(&th[made], NULL, inflate_worker, &job)) break; made++; }
+            inflate_worker(&job);
+            for(i = 0; i < made; i++) pthread_join(th[i], NULL);
+        }
         pthread_mutex_destroy(&job.mu);
         if(!job.failed) {      /* the notes of all members, in stream order, into the slab's table */
             size_t tot = 0, o = 0;
@@ -201,7 +206,9 @@ static void *inflater_main(void *arg) {
 static void inflaters_start(mdk_bam *b) {
     int i;
     b->next_seq = b->push_seq = 0; b->io_status = 0;
-    for(i = 0; i < b->n_teams; i++) pthread_create(&b->inf_th[i], NULL, inflater_main, b);
+    for(i = 0; i < b->n_teams; i++) if(pthread_create(&b->inf_th[i], NULL, inflater_main, b)) break;
+    if(i == 0) { b->io_status = -1; snprintf(b->err, sizeof(b->err), "cannot create an inflate thread"); }
+    b->n_teams = i;
     b->inf_started = 1;
 }
 static void inflaters_stop(mdk_bam *b) {

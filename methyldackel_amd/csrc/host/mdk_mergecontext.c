@@ -88,6 +88,9 @@ int mergeContext_main(int argc, char *argv[]) {
         unmeth = (uint32_t)strtoul(f[5], &end, 10); if(end == f[5]) malformed("unmethylated count");
         fi = mdk_fasta_find(&fa, f[0]);
         if(fi < 0) { fprintf(stderr, "[mergeContext] Error, %s is an unknown chromosome name!\n", f[0]); break; }
+        /* a start outside the contig (bedGraph made against another FASTA, corrupt line): the reference fetches an empty window
+         * and reads past it; here the line is refused the way an unknown contig is */
+        if(start < 0 || (int64_t)start >= fa.len[fi]) { fprintf(stderr, "[mergeContext] Error, position %d is outside of %s (%" PRId64 " bases)!\n", start, f[0], fa.len[fi]); break; }
         chrom = xstrdup(f[0]);
         type = site_of(fa.seq[fi], fa.len[fi], start, &lo, &hi);
         if(type == 0) meet_or_wait(out, &cpg, chrom, lo, hi, meth, unmeth);

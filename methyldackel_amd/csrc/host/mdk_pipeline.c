@@ -102,25 +102,27 @@ done:
 /* ------------------------------------------------------------------------------------------------ */
 /* batch building                                                                                    */
 /* ------------------------------------------------------------------------------------------------ */
+/* realloc that keeps the old block (and its owner's pointer) when it fails */
+static int grow(void **p, size_t bytes) { void *q = realloc(*p, bytes ? bytes : 1); if(!q) return -1; *p = q; return 0; }
 static int bb_reserve(batchbuf *b, size_t more_reads, size_t more_blob, size_t more_qn, size_t more_cig) {
-    if(b->n + more_reads > b->cap_ri) { b->cap_ri = (b->n + more_reads) * 2 + 1024; b->ri = realloc(b->ri, b->cap_ri * sizeof(rinfo)); if(!b->ri) return -1; }
+    if(b->n + more_reads > b->cap_ri) { size_t nc = (b->n + more_reads) * 2 + 1024; if(grow((void **)&b->ri, nc * sizeof(rinfo))) return -1; b->cap_ri = nc; }
     if(b->blob_len + more_blob > b->cap_blob) {
         size_t nc = (b->blob_len + more_blob) * 2 + (1 << 20); uint8_t *d = md_host_alloc(nc);
         if(!d) return -1;
         if(b->blob_len) memcpy(d, b->blob, b->blob_len);
         md_host_free(b->blob); b->blob = d; b->cap_blob = nc;
     }
-    if(b->qn_len + more_qn > b->qn_cap) { b->qn_cap = (b->qn_len + more_qn) * 2 + 65536; b->qn = realloc(b->qn, b->qn_cap); if(!b->qn) return -1; }
-    if(b->cig_len + more_cig > b->cig_cap) { b->cig_cap = (b->cig_len + more_cig) * 2 + 4096; b->cig = realloc(b->cig, b->cig_cap * 4); if(!b->cig) return -1; }
+    if(b->qn_len + more_qn > b->qn_cap) { size_t nc = (b->qn_len + more_qn) * 2 + 65536; if(grow((void **)&b->qn, nc)) return -1; b->qn_cap = nc; }
+    if(b->cig_len + more_cig > b->cig_cap) { size_t nc = (b->cig_len + more_cig) * 2 + 4096; if(grow((void **)&b->cig, nc * 4)) return -1; b->cig_cap = nc; }
     return 0;
 }
 /* one-shot reservation at the start of a chunk (buffers are empty): no doubling, pinned memory is precious */
 static int bb_reserve_exact(batchbuf *b, size_t reads, size_t blob, size_t qn, size_t cig, size_t segs) {
-    if(reads > b->cap_ri) { b->cap_ri = reads + reads / 8; b->ri = realloc(b->ri, b->cap_ri * sizeof(rinfo)); if(!b->ri) return -1; }
-    if(blob > b->cap_blob) { md_host_free(b->blob); b->cap_blob = blob + blob / 8; b->blob = md_host_alloc(b->cap_blob); if(!b->blob) return -1; }
-    if(qn > b->qn_cap) { b->qn_cap = qn + qn / 8; b->qn = realloc(b->qn, b->qn_cap); if(!b->qn) return -1; }
-    if(cig > b->cig_cap) { b->cig_cap = cig + cig / 8; b->cig = realloc(b->cig, b->cig_cap * 4); if(!b->cig) return -1; }
-    if(segs > b->cap_seg) { md_host_free(b->seg); b->cap_seg = segs + segs / 8; b->seg = md_host_alloc(b->cap_seg * sizeof(md_seg)); if(!b->seg) return -1; }
+    if(reads > b->cap_ri) { size_t nc = reads + reads / 8; if(grow((void **)&b->ri, nc * sizeof(rinfo))) return -1; b->cap_ri = nc; }
+    if(blob > b->cap_blob) { md_host_free(b->blob); b->cap_blob = 0; b->blob = md_host_alloc(blob + blob / 8); if(!b->blob) return -1; b->cap_blob = blob + blob / 8; }
+    if(qn > b->qn_cap) { size_t nc = qn + qn / 8; if(grow((void **)&b->qn, nc)) return -1; b->qn_cap = nc; }
+    if(cig > b->cig_cap) { size_t nc = cig + cig / 8; if(grow((void **)&b->cig, nc * 4)) return -1; b->cig_cap = nc; }
+    if(segs > b->cap_seg) { md_host_free(b->seg); b->cap_seg = 0; b->seg = md_host_alloc((segs + segs / 8) * sizeof(md_seg)); if(!b->seg) return -1; b->cap_seg = segs + segs / 8; }
     return 0;
 }
 static int seg_reserve(batchbuf *b, size_t more) {
@@ -148,16 +150,17 @@ static qent *qt_get(const batchbuf *b, uint32_t qoff, uint32_t h) {
         if(e->h == h && !strcmp(b->qn + e->qoff, name)) return e;
     }
 }
-static void qt_prepare(size_t expect) {
+static int qt_prepare(size_t expect) {
     size_t want = 1024;
     while(want < expect + expect / 2 + 16) want <<= 1;
-    if(want > t_qt_cap) { free(t_qt); t_qt = calloc(want, sizeof(qent)); t_qt_cap = want; t_gen = 0; }
+    if(want > t_qt_cap) { free(t_qt); t_qt_cap = 0; t_gen = 0; t_qt = calloc(want, sizeof(qent)); if(!t_qt) return -1; t_qt_cap = want; }
     if(++t_gen == 0x7fffffff) { size_t i; for(i = 0; i < t_qt_cap; i++) t_qt[i].used = 0; t_gen = 1; }     /* a new generation empties the table */
     t_side_n = 0;
+    return 0;
 }
-static void pair_reads(batchbuf *b, int32_t tid) {
+static int pair_reads(batchbuf *b, int32_t tid) {
     size_t i, n = b->n; int32_t prev_pos = 0; int first = 1;
-    qt_prepare(n);
+    if(qt_prepare(n)) return -1;
     for(i = 0; i < n; i++) {
         rinfo *r = &b->ri[i]; int32_t pos = r->pos, end = r->rend; int inserted; qent *e; int k, w, evicted = 0;
         r->mate = -1; r->second = 0;
@@ -183,12 +186,13 @@ static void pair_reads(batchbuf *b, int32_t tid) {
             }
             if(e->nlive < 2) e->live[e->nlive++] = end;
             else {
-                if(t_side_n == t_side_cap) { t_side_cap = t_side_cap ? t_side_cap * 2 : 1024; t_side = realloc(t_side, sizeof(*t_side) * t_side_cap); if(!t_side) { fprintf(stderr, "[mdk] out of memory\n"); abort(); } }
+                if(t_side_n == t_side_cap) { size_t nc = t_side_cap ? t_side_cap * 2 : 1024; if(grow((void **)&t_side, sizeof(*t_side) * nc)) return -1; t_side_cap = nc; }
                 t_side[t_side_n].end = end; t_side[t_side_n].next = e->more; e->more = (int32_t)++t_side_n;
             }
         }
         prev_pos = pos; first = 0;
     }
+    return 0;
 }
 
 /* CIGAR -> gapless runs (reference start, query start, length); what calculate_positions (overlaps.c:27-52) and
@@ -200,7 +204,7 @@ static int cigar_runs(const uint32_t *cig, int ncig, int32_t pos, int32_t lq, ru
         int op = cig[k] & 15; int32_t len = (int32_t)(cig[k] >> 4);
         if(cigar_is_match(op)) {
             int32_t l = len; if(y + l > lq) l = lq - y;            /* malformed CIGAR guard */
-            if(l > 0) { if(n == *cap) { *cap = *cap ? *cap * 2 : 16; *out = realloc(*out, sizeof(run_t) * *cap); if(!*out) { fprintf(stderr, "[mdk] out of memory\n"); abort(); } } (*out)[n].x = x; (*out)[n].y = y; (*out)[n].l = l; n++; }
+            if(l > 0) { if(n == *cap) { int nc = *cap ? *cap * 2 : 16; if(grow((void **)out, sizeof(run_t) * (size_t)nc)) return -1; *cap = nc; } (*out)[n].x = x; (*out)[n].y = y; (*out)[n].l = l; n++; }
             x += len; y += len;
         } else if(op == 1 || op == 4) y += len;
         else if(op == 2 || op == 3) x += len;
@@ -215,7 +219,7 @@ static int cigar_runs(const uint32_t *cig, int ncig, int32_t pos, int32_t lq, ru
 typedef struct { md_seg *v; size_t n, cap; } segheap;
 static int heap_push(segheap *h, const md_seg *g) {
     size_t i;
-    if(h->n == h->cap) { h->cap = h->cap ? h->cap * 2 : 256; h->v = realloc(h->v, h->cap * sizeof(md_seg)); if(!h->v) return -1; }
+    if(h->n == h->cap) { size_t nc = h->cap ? h->cap * 2 : 256; if(grow((void **)&h->v, nc * sizeof(md_seg))) return -1; h->cap = nc; }
     for(i = h->n++; i > 0 && h->v[(i - 1) / 2].rpos > g->rpos; i = (i - 1) / 2) h->v[i] = h->v[(i - 1) / 2];
     h->v[i] = *g;
     return 0;
@@ -243,10 +247,12 @@ static int build_segments(mdk_plan *p, batchbuf *b, int64_t beg, int64_t end) {
         r = &b->ri[i];
         sf = (uint8_t)((r->strand & 7) | ((r->bamflag & 0x80) ? MDK_SF_READ2 : 0) | (r->second ? MDK_SF_SECOND : 0));
         no = cigar_runs(b->cig + r->cig_off, r->ncig, r->pos, (int32_t)r->lq, &ro, &co);
+        if(no < 0) return -1;
         /* only pairs whose strands agree in parity are resolved against each other (overlaps.c:63-65) */
         if(r->mate >= 0 && (((int)r->strand - (int)b->ri[r->mate].strand) & 1) == 0) {
             m = &b->ri[r->mate];
             nm = cigar_runs(b->cig + m->cig_off, m->ncig, m->pos, (int32_t)m->lq, &rm, &cm);
+            if(nm < 0) return -1;
             msf = (uint8_t)((m->strand & 7) | ((m->bamflag & 0x80) ? MDK_SF_READ2 : 0));
         }
         for(a = 0; a < no; a++) {
@@ -323,7 +329,7 @@ pack:
 
 static int carry_push(uint8_t **buf, size_t *len, size_t *cap, const mdk_rec *r) {
     size_t need = *len + 4 + r->raw_len;
-    if(need > *cap) { *cap = need * 2 + 65536; *buf = realloc(*buf, *cap); if(!*buf) return -1; }
+    if(need > *cap) { size_t nc = need * 2 + 65536; if(grow((void **)buf, nc)) return -1; *cap = nc; }
     memcpy(*buf + *len, &r->raw_len, 4); memcpy(*buf + *len + 4, r->raw, r->raw_len); *len = need;
     return 0;
 }
@@ -363,7 +369,7 @@ typedef struct pslot {
 
 static int raw_push(pslot *sl, const mdk_rec *r) {
     size_t need = sl->raw_len + 4 + r->raw_len;
-    if(need > sl->raw_cap) { sl->raw_cap = need * 2 + (1 << 20); sl->raw = realloc(sl->raw, sl->raw_cap); if(!sl->raw) return -1; }
+    if(need > sl->raw_cap) { size_t nc = need * 2 + (1 << 20); if(grow((void **)&sl->raw, nc)) return -1; sl->raw_cap = nc; }
     memcpy(sl->raw + sl->raw_len, &r->raw_len, 4); memcpy(sl->raw + sl->raw_len + 4, r->raw, r->raw_len); sl->raw_len = need;
     return 0;
 }
@@ -448,7 +454,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
                 size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
                 if(g && g->slab == cs && g->end == roff) g->end = roff + 4 + q.len;
                 else {
-                    if(sl->n_rg == sl->cap_rg) { sl->cap_rg = sl->cap_rg ? sl->cap_rg * 2 : 16; sl->rg = realloc(sl->rg, sizeof(rrange) * sl->cap_rg); if(!sl->rg) return -5; }
+                    if(sl->n_rg == sl->cap_rg) { int nc = sl->cap_rg ? sl->cap_rg * 2 : 16; if(grow((void **)&sl->rg, sizeof(rrange) * (size_t)nc)) return -5; sl->cap_rg = nc; }
                     g = &sl->rg[sl->n_rg++]; g->slab = cs; g->beg = roff; g->end = roff + 4 + q.len; mdk_slab_ref(bam, cs);
                 }
                 sl->n_stream++;
@@ -492,7 +498,7 @@ static int worker_process(mdk_plan *p, pslot *sl) {
     t1 = now_s();
     if(p->o.perread) {        /* no pairing, no segments: the device walks each read's CIGAR itself */
         size_t i;
-        if(b->cap_pr < b->n + 1) { b->cap_pr = (b->n + 1) * 2; free(b->pr); b->pr = malloc(sizeof(md_pr_read) * b->cap_pr); if(!b->pr) return -5; }
+        if(b->cap_pr < b->n + 1) { free(b->pr); b->cap_pr = 0; b->pr = malloc(sizeof(md_pr_read) * (b->n + 1) * 2); if(!b->pr) return -5; b->cap_pr = (b->n + 1) * 2; }
         for(i = 0; i < b->n; i++) {
             const rinfo *ri = &b->ri[i]; md_pr_read *q = &b->pr[i];
             q->pos = ri->pos; q->off4 = ri->off4; q->l_qseq = ri->lq; q->cig_off = ri->cig_off; q->n_cigar = ri->ncig; q->strand = ri->strand; q->reserved = 0;
@@ -502,7 +508,7 @@ static int worker_process(mdk_plan *p, pslot *sl) {
         pthread_mutex_lock(&p->mu); p->t_collect += t1 - t0; pthread_mutex_unlock(&p->mu);
         return 0;
     }
-    if(!p->o.mbias) pair_reads(b, c->tid);          /* mbias installs no overlap handler (MBias.c:158-161): every read counts on its own */
+    if(!p->o.mbias && pair_reads(b, c->tid)) return -5;          /* mbias installs no overlap handler (MBias.c:158-161): every read counts on its own */
     t2 = now_s();
     if(build_segments(p, b, c->beg, c->end)) return -5;
     c->batch.tid = c->tid; c->batch.beg = c->beg; c->batch.end = c->end; c->batch.n_segs = (int32_t)b->n_seg; c->batch.seg = b->seg;
@@ -567,10 +573,22 @@ MDK_LOCAL int pipeline_start(mdk_plan *p) {
     p->worker_th = calloc((size_t)p->n_workers, sizeof(pthread_t));
     if(!p->slot || !p->worker_th) return -5;
     pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_free, NULL); pthread_cond_init(&p->cv_raw, NULL); pthread_cond_init(&p->cv_done, NULL);
-    p->held[0] = p->held[1] = -1; p->next_out = 0; p->started = 1;
-    pthread_create(&p->reader_th, NULL, reader_main, p);
-    for(i = 0; i < p->n_workers; i++) pthread_create(&p->worker_th[i], NULL, worker_main, p);
+    p->held[0] = p->held[1] = -1; p->next_out = 0;
+    /* workers first: fewer than asked for is fine (they all take chunks from the same queue), none is not */
+    for(i = 0; i < p->n_workers; i++) if(pthread_create(&p->worker_th[i], NULL, worker_main, p)) break;
+    if(i < p->n_workers) { if(i == 0) { fprintf(stderr, "[mdk] cannot create a worker thread\n"); goto fail; } p->n_workers = i; }
+    if(pthread_create(&p->reader_th, NULL, reader_main, p)) {
+        fprintf(stderr, "[mdk] cannot create the reader thread\n");
+        pthread_mutex_lock(&p->mu); p->quit = 1; pthread_cond_broadcast(&p->cv_raw); pthread_mutex_unlock(&p->mu);
+        for(i = 0; i < p->n_workers; i++) pthread_join(p->worker_th[i], NULL);
+        goto fail;
+    }
+    p->started = 1;
     return 0;
+fail:
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_free); pthread_cond_destroy(&p->cv_raw); pthread_cond_destroy(&p->cv_done);
+    free(p->slot); free(p->worker_th); p->slot = NULL; p->worker_th = NULL;
+    return -5;
 }
 MDK_LOCAL void pipeline_stop(mdk_plan *p) {
     int i;

@@ -1,0 +1,289 @@
+// mdk_comm.hip -- the exchange step of the interval-sharded path, and the resident-input benchmark loop that uses it.
+//
+// `extract` shards by interval with no data dependence between intervals: chunk k of the reference's schedule
+// (extract.c:325-350) belongs to GPU k mod N, and the only exchange is the per-interval site buffers travelling to the GPU
+// whose host writes the files -- a gather with no reduction, done with ncclSend/ncclRecv groups over xGMI.  The reference has
+// no counterpart (its workers share one address space and write through outputMutex, extract.c:514-535).
+//
+// RCCL is loaded with dlopen the first time a communicator is asked for: a single-GPU run never pays for loading it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <chrono>
+#include "mdk_hip_internal.hpp"
+
+struct Rccl {
+    void *so = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr; decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr; decltype(&ncclSend) Send = nullptr; decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr; decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static Rccl *rccl() {
+    static Rccl R; static int state = 0;       // 0 untried, 1 loaded, -1 unavailable
+    if(state == 0) {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for(const char *n : names) { R.so = dlopen(n, RTLD_NOW | RTLD_LOCAL); if(R.so) break; }
+        state = -1;
+        if(R.so) {
+#define SYM(f) R.f = (decltype(R.f))dlsym(R.so, "nccl" #f)
+            SYM(GetUniqueId); SYM(CommInitRank); SYM(CommInitAll); SYM(CommDestroy); SYM(Send); SYM(Recv); SYM(GroupStart); SYM(GroupEnd); SYM(GetErrorString);
+#undef SYM
+            if(R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.Send && R.Recv && R.GroupStart && R.GroupEnd && R.GetErrorString) state = 1;
+        }
+    }
+    if(state != 1) { snprintf(g_err, sizeof(g_err), "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); return nullptr; }
+    return &R;
+}
+static int nfail(Rccl *R, const char *what, ncclResult_t r) { snprintf(g_err, sizeof(g_err), "%s: %s", what, R->GetErrorString(r)); return MDK_ERR_HIP; }
+#define NCHK(call) do { ncclResult_t r_ = (call); if(r_ != ncclSuccess) return nfail(R, #call, r_); } while(0)
+
+// A communicator over `world` ranks, root 0.  This process drives `n_local` of them: one (its own GPU) when there is one
+// process per GPU, all of them when one process feeds every GPU of the node.
+struct md_comm {
+    int world = 0, n_local = 0; bool copies = false;          // copies: the local ranks share one physical device (tests): plain D2D copies, no RCCL
+    std::vector<int> rank; std::vector<md_dev *> dev; std::vector<ncclComm_t> comm; std::vector<hipStream_t> stream; std::vector<hipEvent_t> ev;
+};
+
+extern "C" int md_comm_unique_id(uint8_t *id) {
+    Rccl *R = rccl(); if(!R) return MDK_ERR_NODEVICE;
+    static_assert(sizeof(ncclUniqueId) == MD_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u; NCHK(R->GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+static int comm_streams(md_comm *c) {
+    c->stream.resize(c->n_local); c->ev.resize(c->n_local);
+    for(int i = 0; i < c->n_local; i++) {
+        HIPCHK(hipSetDevice(c->dev[i]->device));
+        HIPCHK(hipStreamCreateWithFlags(&c->stream[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+extern "C" int md_comm_open_rank(md_dev *h, int rank, int world, const uint8_t *id, md_comm **out) {
+    if(!h || !out || !id || world < 1 || rank < 0 || rank >= world) return fail(MDK_ERR_ARG, "md_comm_open_rank", hipSuccess);
+    *out = nullptr;
+    Rccl *R = rccl(); if(!R) return MDK_ERR_NODEVICE;
+    md_comm *c = new md_comm(); c->world = world; c->n_local = 1; c->rank = {rank}; c->dev = {h}; c->comm.resize(1);
+    HIPCHK(hipSetDevice(h->device));
+    ncclUniqueId u; memcpy(&u, id, sizeof(u));
+    ncclResult_t r = R->CommInitRank(&c->comm[0], world, u, rank);
+    if(r != ncclSuccess) { delete c; return nfail(R, "ncclCommInitRank", r); }
+    int rc = comm_streams(c); if(rc) { delete c; return rc; }
+    *out = c;
+    return 0;
+}
+
+extern "C" int md_comm_open_local(md_dev *const *h, int n, md_comm **out) {
+    if(!h || !out || n < 1) return fail(MDK_ERR_ARG, "md_comm_open_local", hipSuccess);
+    *out = nullptr;
+    md_comm *c = new md_comm(); c->world = n; c->n_local = n;
+    bool shared = false;
+    for(int i = 0; i < n; i++) { if(!h[i]) { delete c; return fail(MDK_ERR_ARG, "md_comm_open_local: null device", hipSuccess); } c->rank.push_back(i); c->dev.push_back(h[i]); for(int j = 0; j < i; j++) if(h[j]->device == h[i]->device) shared = true; }
+    c->copies = shared || n == 1;
+    if(!c->copies) {
+        Rccl *R = rccl(); if(!R) { delete c; return MDK_ERR_NODEVICE; }
+        std::vector<int> devs; for(int i = 0; i < n; i++) devs.push_back(h[i]->device);
+        c->comm.resize(n);
+        ncclResult_t r = R->CommInitAll(c->comm.data(), n, devs.data());
+        if(r != ncclSuccess) { delete c; return nfail(R, "ncclCommInitAll", r); }
+    }
+    int rc = comm_streams(c); if(rc) { delete c; return rc; }
+    *out = c;
+    return 0;
+}
+
+extern "C" void md_comm_close(md_comm *c) {
+    if(!c) return;
+    for(int i = 0; i < c->n_local; i++) {
+        (void)hipSetDevice(c->dev[i]->device);
+        if(i < (int)c->stream.size() && c->stream[i]) { (void)hipStreamSynchronize(c->stream[i]); (void)hipStreamDestroy(c->stream[i]); }
+        if(i < (int)c->ev.size() && c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    }
+    if(!c->comm.empty()) { Rccl *R = rccl(); if(R) for(ncclComm_t k : c->comm) if(k) (void)R->CommDestroy(k); }
+    delete c;
+}
+
+extern "C" int md_comm_world(const md_comm *c) { return c ? c->world : MDK_ERR_ARG; }
+
+// One exchange.  d_send/send_bytes are indexed by LOCAL rank; d_recv/recv_bytes by GLOBAL rank and only read where rank 0 is
+// local.  Rank 0's own contribution is copied when d_recv[0] is given and differs from its send buffer.  Asynchronous on the
+// communicator's streams: the caller guarantees the send buffers are complete (their kernels have been waited for) and
+// calls md_comm_wait before touching either side again.
+extern "C" int md_comm_gather(md_comm *c, const void *const *d_send, const uint64_t *send_bytes, void *const *d_recv, const uint64_t *recv_bytes) {
+    if(!c || !d_send || !send_bytes) return fail(MDK_ERR_ARG, "md_comm_gather", hipSuccess);
+    int root_local = -1;
+    for(int i = 0; i < c->n_local; i++) if(c->rank[i] == 0) root_local = i;
+    if(root_local >= 0 && (!d_recv || !recv_bytes)) return fail(MDK_ERR_ARG, "md_comm_gather: the root needs receive buffers", hipSuccess);
+    if(c->copies) {        // every rank is local and on one device: the "links" are device-to-device copies
+        for(int i = 0; i < c->n_local; i++) {
+            const int r = c->rank[i];
+            if(!d_recv[r] || d_recv[r] == d_send[i] || !send_bytes[i]) continue;
+            if(recv_bytes[r] != send_bytes[i]) return fail(MDK_ERR_ARG, "md_comm_gather: size mismatch", hipSuccess);
+            HIPCHK(hipSetDevice(c->dev[i]->device));
+            HIPCHK(hipMemcpyAsync(d_recv[r], d_send[i], (size_t)send_bytes[i], hipMemcpyDeviceToDevice, c->stream[i]));
+        }
+    } else {
+        Rccl *R = rccl(); if(!R) return MDK_ERR_NODEVICE;
+        NCHK(R->GroupStart());
+        for(int i = 0; i < c->n_local; i++) {
+            if(c->rank[i] == 0 || !send_bytes[i]) continue;
+            ncclResult_t r = R->Send(d_send[i], (size_t)send_bytes[i], ncclUint8, 0, c->comm[i], c->stream[i]);
+            if(r != ncclSuccess) { (void)R->GroupEnd(); return nfail(R, "ncclSend", r); }
+        }
+        if(root_local >= 0) {
+            for(int r = 1; r < c->world; r++) {
+                if(!recv_bytes[r]) continue;
+                ncclResult_t q = R->Recv(d_recv[r], (size_t)recv_bytes[r], ncclUint8, r, c->comm[root_local], c->stream[root_local]);
+                if(q != ncclSuccess) { (void)R->GroupEnd(); return nfail(R, "ncclRecv", q); }
+            }
+        }
+        NCHK(R->GroupEnd());
+        if(root_local >= 0 && d_recv[0] && d_recv[0] != d_send[root_local] && send_bytes[root_local]) {
+            HIPCHK(hipSetDevice(c->dev[root_local]->device));
+            HIPCHK(hipMemcpyAsync(d_recv[0], d_send[root_local], (size_t)send_bytes[root_local], hipMemcpyDeviceToDevice, c->stream[root_local]));
+        }
+    }
+    for(int i = 0; i < c->n_local; i++) { HIPCHK(hipSetDevice(c->dev[i]->device)); HIPCHK(hipEventRecord(c->ev[i], c->stream[i])); }
+    return 0;
+}
+
+extern "C" int md_comm_wait(md_comm *c) {
+    if(!c) return fail(MDK_ERR_ARG, "md_comm_wait", hipSuccess);
+    for(int i = 0; i < c->n_local; i++) { HIPCHK(hipSetDevice(c->dev[i]->device)); HIPCHK(hipEventSynchronize(c->ev[i])); }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident-input benchmark loop (bench.py): `n` uploaded slots holding different intervals are launched round robin, two
+// in flight -- launch k is issued, then launch k-1 is collected (its site count read back), as extract_main does -- and
+// the results of `group` consecutive launches are written by the kernels straight into one send buffer that travels to
+// rank 0 in a single exchange while the next group is computed into the other buffer.
+// ------------------------------------------------------------------------------------------------
+struct md_bench {
+    md_dev *h = nullptr; md_comm *comm = nullptr; std::vector<int> slots; int group = 0, world = 1, rank = 0;
+    int64_t cap = 0, tcap = 0; size_t E = 0, off_var = 0, off_seg = 0;       // one launch's region: sites, [var], tile segments
+    uint8_t *send[2] = {nullptr, nullptr}; std::vector<uint8_t *> recv[2]; bool pending[2] = {false, false};
+    int64_t last_k = -1;
+};
+
+extern "C" void md_bench_close(md_bench *b) {
+    if(!b) return;
+    (void)hipSetDevice(b->h->device);
+    if(b->comm) (void)md_comm_wait(b->comm);
+    for(int i : b->slots) (void)md_dev_bind_output(b->h, i, nullptr, nullptr, nullptr, 0, 0);
+    for(int x = 0; x < 2; x++) { if(b->send[x]) (void)hipFree(b->send[x]); for(uint8_t *p : b->recv[x]) if(p) (void)hipFree(p); }
+    delete b;
+}
+
+extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, int group, md_bench **out) {
+    if(!h || !slots || n < 2 || group < 1 || !out) return fail(MDK_ERR_ARG, "md_bench_open: needs at least two uploaded slots", hipSuccess);
+    if(comm && comm->n_local != 1) return fail(MDK_ERR_ARG, "md_bench_open: one process per GPU", hipSuccess);
+    *out = nullptr;
+    HIPCHK(hipSetDevice(h->device));
+    md_bench *b = new md_bench(); b->h = h; b->comm = comm; b->group = group;
+    if(comm) { b->world = comm->world; b->rank = comm->rank[0]; }
+    for(int i = 0; i < n; i++) {
+        Slot *s = get_slot(h, slots[i]);
+        if(!s || !s->uploaded) { delete b; return fail(MDK_ERR_ARG, "md_bench_open: slot not uploaded", hipSuccess); }
+        int rc = md_dev_bind_output(h, slots[i], nullptr, nullptr, nullptr, 0, 0); if(rc) { delete b; return rc; }
+        rc = launch_kernels(h, s, false); if(rc) { delete b; return rc; } s->launched = true;
+        int64_t c = finish_count(h, s); if(c < 0) { delete b; return (int)c; }
+        if(c > b->cap) b->cap = c;
+        if(s->ntiles > b->tcap) b->tcap = s->ntiles;
+        b->slots.push_back(slots[i]);
+    }
+    b->cap += 64; b->tcap += 1;
+    b->off_var = (size_t)b->cap * sizeof(md_site);
+    b->off_seg = b->off_var + (h->variant ? (size_t)b->cap * sizeof(md_site_var) : 0);
+    b->E = (b->off_seg + (size_t)b->tcap * sizeof(md_tile_seg) + 255) & ~(size_t)255;
+    for(int x = 0; x < 2; x++) {
+        hipError_t e = hipMalloc((void **)&b->send[x], b->E * (size_t)group);
+        if(e == hipSuccess) e = hipMemset(b->send[x], 0, b->E * (size_t)group);
+        if(e != hipSuccess) { md_bench_close(b); return fail(MDK_ERR_NOMEM, "hipMalloc(bench send buffer)", e); }
+        if(comm && b->rank == 0) {
+            b->recv[x].assign((size_t)b->world, nullptr);
+            for(int r = 1; r < b->world; r++) {
+                e = hipMalloc((void **)&b->recv[x][r], b->E * (size_t)group);
+                if(e == hipSuccess) e = hipMemset(b->recv[x][r], 0, b->E * (size_t)group);
+                if(e != hipSuccess) { md_bench_close(b); return fail(MDK_ERR_NOMEM, "hipMalloc(bench receive buffer)", e); }
+            }
+        }
+    }
+    *out = b;
+    return 0;
+}
+
+extern "C" int64_t md_bench_region_bytes(const md_bench *b) { return b ? (int64_t)b->E : MDK_ERR_ARG; }
+
+static int bench_exchange(md_bench *b, int x) {
+    if(!b->comm) return 0;
+    const void *snd[1] = {b->send[x]}; uint64_t sb[1] = {(uint64_t)b->E * (uint64_t)b->group};
+    std::vector<void *> rcv((size_t)b->world, nullptr); std::vector<uint64_t> rb((size_t)b->world, 0);
+    if(b->rank == 0) for(int r = 1; r < b->world; r++) { rcv[r] = b->recv[x][r]; rb[r] = sb[0]; }
+    int rc = md_comm_gather(b->comm, snd, sb, rcv.data(), rb.data());
+    if(rc) return rc;
+    b->pending[x] = true;
+    return 0;
+}
+
+// `launches` passes of the hot path, each over the next resident interval; returns when every launch has been collected and
+// every exchange has completed.  The caller brackets this call with its barrier + device sync and takes the time.
+extern "C" int md_bench_run(md_bench *b, int64_t launches, md_bench_run_result *out) {
+    if(!b || launches < 0 || !out) return fail(MDK_ERR_ARG, "md_bench_run", hipSuccess);
+    md_dev *h = b->h; const int n = (int)b->slots.size(), G = b->group;
+    HIPCHK(hipSetDevice(h->device));
+    memset(out, 0, sizeof(*out));
+    int64_t sites = 0;
+    for(int64_t k = 0; k < launches; k++) {
+        const int x = (int)((k / G) & 1), e = (int)(k % G);
+        if(e == 0 && b->pending[x]) { int rc = md_comm_wait(b->comm); if(rc) return rc; b->pending[0] = b->pending[1] = false; }     // this buffer is about to be overwritten
+        uint8_t *base = b->send[x] + (size_t)e * b->E;
+        int rc = md_dev_bind_output(h, b->slots[k % n], base, h->variant ? base + b->off_var : nullptr, base + b->off_seg, b->cap, b->tcap); if(rc) return rc;
+        Slot *s = get_slot(h, b->slots[k % n]);
+        rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
+        if(k) {
+            int64_t c = finish_count(h, get_slot(h, b->slots[(k - 1) % n])); if(c < 0) return (int)c;
+            sites = c;
+            if(k % G == 0) { rc = bench_exchange(b, (int)(((k - 1) / G) & 1)); if(rc) return rc; out->exchanges++; }
+        }
+    }
+    if(launches) {
+        int64_t c = finish_count(h, get_slot(h, b->slots[(launches - 1) % n])); if(c < 0) return (int)c;
+        sites = c;
+        int rc = bench_exchange(b, (int)(((launches - 1) / G) & 1)); if(rc) return rc;
+        if(b->comm) out->exchanges++;
+        b->last_k = launches - 1;
+    }
+    if(b->comm) { int rc = md_comm_wait(b->comm); if(rc) return rc; b->pending[0] = b->pending[1] = false; }
+    out->launches = (uint64_t)launches; out->slots_last = (uint64_t)sites; out->bytes_per_exchange = b->comm ? (uint64_t)b->E * (uint64_t)G : 0;
+    return 0;
+}
+
+// After md_bench_run: the sites the last launch left in the send buffer (ordered by tile) must be the sites md_dev_download
+// gives for the same interval; on rank 0 every peer's last region must hold sites too.  0 = verified.
+extern "C" int md_bench_verify(md_bench *b) {
+    if(!b || b->last_k < 0) return fail(MDK_ERR_ARG, "md_bench_verify: nothing was run", hipSuccess);
+    md_dev *h = b->h; const int n = (int)b->slots.size(), G = b->group; const int64_t k = b->last_k;
+    HIPCHK(hipSetDevice(h->device));
+    const int x = (int)((k / G) & 1), e = (int)(k % G), slot = b->slots[k % n];
+    std::vector<uint8_t> reg(b->E);
+    HIPCHK(hipMemcpy(reg.data(), b->send[x] + (size_t)e * b->E, b->E, hipMemcpyDeviceToHost));
+    Slot *s = get_slot(h, slot);
+    std::vector<md_site> ord((size_t)b->cap);
+    int64_t got = md_sites_order((const md_site *)reg.data(), nullptr, (const md_tile_seg *)(reg.data() + b->off_seg), s->ntiles, b->cap, ord.data(), nullptr);
+    int rc = md_dev_bind_output(h, slot, nullptr, nullptr, nullptr, 0, 0); if(rc) return rc;
+    rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
+    md_sites ref; rc = md_dev_download(h, slot, &ref); if(rc) return rc;
+    if(got != ref.n_sites || (got && memcmp(ord.data(), ref.site, (size_t)got * sizeof(md_site)))) { snprintf(g_err, sizeof(g_err), "bench: bound-output sites differ from md_dev_download (%lld vs %lld)", (long long)got, (long long)ref.n_sites); return MDK_ERR_ARG; }
+    if(b->comm && b->rank == 0) {
+        for(int r = 1; r < b->world; r++) {
+            HIPCHK(hipMemcpy(reg.data(), b->recv[x][r] + (size_t)e * b->E, b->E, hipMemcpyDeviceToHost));
+            const md_tile_seg *ts = (const md_tile_seg *)(reg.data() + b->off_seg); uint64_t tot = 0;
+            for(int64_t t = 0; t < b->tcap; t++) tot += ts[t].cnt;
+            if(!tot) { snprintf(g_err, sizeof(g_err), "bench: nothing was received from rank %d", r); return MDK_ERR_ARG; }
+        }
+    }
+    return 0;
+}

@@ -27,36 +27,25 @@
 //               each tile's read payload in LDS with LDS-DMA -- 43-62 us, 70 KiB per workgroup kills occupancy.)
 //
 // Integer/byte work, HBM-bound: no MFMA anywhere (DESIGN.md has the roofline accounting).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
 #include <atomic>
 #include <mutex>
-#include <vector>
 #include <algorithm>
-#include "mdk_hip.h"
+#include "mdk_hip_internal.hpp"
 
-#define WG 512
-#define WAVES (WG / 64)
 #define DEFAULT_TILE 2048
 #define PERMAX 4                   // reference positions owned by one thread: tile = WG * per, per <= PERMAX
 #define MAX_TILE (WG * PERMAX)
-#define RING 64                    // site counters: launch i uses counter i%RING and clears the next one
 #define LDS_LIMIT 163840          // 160 KiB per CU / per workgroup on gfx950
 
-static thread_local char g_err[512] = "";
-static int fail(int code, const char *what, hipError_t e) {
+thread_local char g_err[512] = "";
+int fail(int code, const char *what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e));
     return code;
 }
-#define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return fail(MDK_ERR_HIP, #call, e_); } while(0)
 
 // ------------------------------------------------------------------------------------------------
 // kernel parameters
 // ------------------------------------------------------------------------------------------------
-struct TileEnt { int first, last; };     // segments [first,last) of the batch overlap the tile (one contiguous run: the batch is coordinate sorted)
 
 struct KParams {
     const md_seg *seg; const uint8_t *blob;
@@ -519,53 +508,6 @@ __global__ __launch_bounds__(WG) void k_debug_effective(const KParams P, int n_s
 // ------------------------------------------------------------------------------------------------
 // host side of the library
 // ------------------------------------------------------------------------------------------------
-template <typename T> struct DBuf {
-    T *p = nullptr; size_t cap = 0;
-    int need(size_t n) {
-        if(n <= cap) return 0;
-        if(p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        size_t want = n + n / 4 + 64;
-        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc", e);
-        cap = want; return 0;
-    }
-    void release() { if(p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-template <typename T> struct HBuf {
-    T *p = nullptr; size_t cap = 0;
-    int need(size_t n) {
-        if(n <= cap) return 0;
-        if(p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
-        size_t want = n + n / 4 + 64;
-        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
-        if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipHostMalloc", e);
-        cap = want; return 0;
-    }
-    void release() { if(p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct Slot {
-    hipStream_t stream = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
-    DBuf<md_seg> d_seg_in; DBuf<uint8_t> d_blob;
-    DBuf<TileEnt> d_tiles; HBuf<TileEnt> h_tiles;
-    DBuf<md_site> d_site; DBuf<md_site_var> d_var; DBuf<md_tile_seg> d_seg; DBuf<uint32_t> d_total; DBuf<int> d_err;
-    HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; HBuf<uint32_t> h_total; HBuf<int> h_err;
-    DBuf<md_pr_read> d_pr; DBuf<uint32_t> d_cig; DBuf<md_pr_count> d_prc; HBuf<md_pr_count> h_prc; int pr_n = -1;      // perRead
-    // caller-bound output (device memory owned by the caller)
-    md_site *b_site = nullptr; md_site_var *b_var = nullptr; md_tile_seg *b_seg = nullptr; int64_t b_cap_sites = 0, b_cap_tiles = 0;
-    int n_segs = 0, n_reads = 0, ntiles = 0, tid = -1, tile = 0, lds_bytes = 0; int64_t beg = 0, end = 0; uint64_t read_bytes = 0;
-    bool uploaded = false, launched = false; unsigned ring = 0;
-};
-
-struct md_dev {
-    int device; md_dev_cfg cfg; int tile, n_slots; bool variant;
-    std::vector<Slot> slots;
-    std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
-    uint32_t *d_hist = nullptr; int hist_cap = 0, hist_len = 0; std::vector<uint32_t> h_hist;      // mbias: rows [q][16], q < hist_cap
-};
-
 extern "C" const char *md_dev_last_error(void) { return g_err; }
 
 extern "C" int md_dev_count(void) {
@@ -688,7 +630,7 @@ extern "C" int md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs,
     return 0;
 }
 
-static Slot *get_slot(md_dev *h, int slot) { if(!h || slot < 0 || slot >= h->n_slots) { fail(MDK_ERR_ARG, "bad slot", hipSuccess); return nullptr; } return &h->slots[slot]; }
+Slot *get_slot(md_dev *h, int slot) { if(!h || slot < 0 || slot >= h->n_slots) { fail(MDK_ERR_ARG, "bad slot", hipSuccess); return nullptr; } return &h->slots[slot]; }
 
 // segment run of every tile
 static void build_tiles(const md_read_batch *b, int TILE, TileEnt *te, int ntiles) {
@@ -761,18 +703,20 @@ static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
     return 0;
 }
 
-static int launch_kernels(md_dev *h, Slot *s, bool time_pileup) {
+// `on` = stream to launch on (the slot's own unless a benchmark lines several slots up on one stream)
+int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on) {
+    hipStream_t st = on ? on : s->stream;
     s->ring++;                                          // a fresh (already zero) site counter for this launch
     if(s->ntiles > 0) {
         KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
         int grid = P.nper * 8;
-        if(time_pileup) HIPCHK(hipEventRecord(s->k0, s->stream));
-        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
-        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
-        if(time_pileup) HIPCHK(hipEventRecord(s->k1, s->stream));
+        if(time_pileup) HIPCHK(hipEventRecord(s->k0, st));
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, st, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, st, P);
+        if(time_pileup) HIPCHK(hipEventRecord(s->k1, st));
         HIPCHK(hipGetLastError());
     } else {
-        HIPCHK(hipMemsetAsync(s->d_total.p, 0, sizeof(uint32_t) * RING, s->stream));
+        HIPCHK(hipMemsetAsync(s->d_total.p, 0, sizeof(uint32_t) * RING, st));
     }
     return 0;
 }
@@ -899,7 +843,7 @@ extern "C" int md_dev_perread_download(md_dev *h, int slot, const md_pr_count **
 }
 
 // wait for the launch, read the total, check the error word
-static int64_t finish_count(md_dev *h, Slot *s) {
+int64_t finish_count(md_dev *h, Slot *s) {
     if(!s->launched) { fail(MDK_ERR_ARG, "slot not launched", hipSuccess); return MDK_ERR_ARG; }
     if(hipMemcpyAsync(s->h_total.p, s->d_total.p + (s->ring % RING), sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H total", hipGetLastError());
     if(hipMemcpyAsync(s->h_err.p, s->d_err.p, sizeof(int), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H err", hipGetLastError());
@@ -1034,6 +978,37 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
     // sum over reads [16 + 4 n_cigar + ceil(l/2) + l] + interval length + 8 per site (+8 with nOff/nVariant)
     out->algo_bytes = s->read_bytes + (uint64_t)(s->end - s->beg) + (uint64_t)n * (h->variant ? 16 : 8);
     out->tile = s->tile; out->n_tiles = s->ntiles; out->lds_bytes = s->lds_bytes;
+    return 0;
+}
+
+// Several uploaded slots (distinct intervals, all resident) launched round robin on ONE stream between two HIP events:
+// the per-launch time of the pileup kernel when its inputs stream from HBM (the slots together exceed the 256 MiB
+// Infinity Cache) instead of being re-read from cache as in md_dev_bench.
+extern "C" int md_dev_bench_rotate(md_dev *h, const int *slots, int n, int warmup, int iters, md_bench_result *out) {
+    if(!h || !slots || n < 1 || iters < 1 || !out) return fail(MDK_ERR_ARG, "md_dev_bench_rotate", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    memset(out, 0, sizeof(*out));
+    uint64_t bytes = 0, sites = 0;
+    for(int i = 0; i < n; i++) {
+        Slot *s = get_slot(h, slots[i]);
+        if(!s || !s->uploaded) return fail(MDK_ERR_ARG, "md_dev_bench_rotate: slot not uploaded", hipSuccess);
+        int rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
+        md_sites tmp; rc = md_dev_download(h, slots[i], &tmp); if(rc) return rc;
+        sites += (uint64_t)tmp.n_sites;
+        bytes += s->read_bytes + (uint64_t)(s->end - s->beg) + (uint64_t)tmp.n_sites * (h->variant ? 16 : 8);
+    }
+    Slot *s0 = get_slot(h, slots[0]);
+    for(int i = 0; i < warmup; i++) { int rc = launch_kernels(h, get_slot(h, slots[i % n]), false, s0->stream); if(rc) return rc; }
+    HIPCHK(hipStreamSynchronize(s0->stream));
+    float ms = 0;
+    HIPCHK(hipEventRecord(s0->k0, s0->stream));
+    for(int i = 0; i < iters; i++) { int rc = launch_kernels(h, get_slot(h, slots[i % n]), false, s0->stream); if(rc) return rc; }
+    HIPCHK(hipEventRecord(s0->k1, s0->stream));
+    HIPCHK(hipEventSynchronize(s0->k1));
+    HIPCHK(hipEventElapsedTime(&ms, s0->k0, s0->k1));
+    out->ms_pileup = ms / (float)iters; out->ms_total = out->ms_pileup;
+    out->algo_bytes = bytes / (uint64_t)n; out->n_sites = sites / (uint64_t)n;       // per launch, averaged over the rotation
+    out->tile = s0->tile; out->n_tiles = s0->ntiles; out->lds_bytes = s0->lds_bytes;
     return 0;
 }
 

@@ -77,6 +77,8 @@ def extract_sharded(args, count_fn_factory, device=None):
                 break
             meta.append(c)
             if not (c.skipped & mdk.CHUNK_FOREIGN) and not (c.skipped & mdk.CHUNK_EMPTY):
+                # the exchange below carries ONE buffer per rank and round, addressed by `index % world`
+                assert owned is None and c.index % world == rank, "a round must hold exactly one chunk per owner"
                 sites, var = count_fn(plan, c)
                 owned = np.concatenate([sites, var], axis=1) if variant else sites
                 mine += 1

@@ -109,10 +109,11 @@ SYN_CMDS = [
 
 
 @pytest.mark.parametrize("which,extra", SYN_CMDS, ids=[f"{w}:{' '.join(e)}" for w, e in SYN_CMDS])
-@pytest.mark.parametrize("env", [{"MDK_TILE": "512"}, {}, {"MDK_TILE": "4096"}], ids=["tile512", "tile2048", "tile4096"])
+@pytest.mark.parametrize("env", [{"MDK_TILE": "512"}, {"MDK_TILE": "1024"}, {}], ids=["tile512", "tile1024", "tile2048"])
 def test_cli_synthetic_byte_exact(tmp_path, small_synth, which, extra, env):
-    """every command line under three tile geometries (1, 4 and 8 reference positions per thread; at 512 positions a tile's
-    segment run overflows the 512 lanes of its workgroup, so the multi-round path runs too)"""
+    """every command line under three distinct tile geometries (1, 2 and 4 reference positions per thread -- the library clamps
+    larger requests to 2048, test_tile_geometry_is_what_was_asked_for; at 512 positions a tile's segment run overflows the 512
+    lanes of its workgroup, so the multi-round path runs too)"""
     args = [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")]
     if "BW" in extra:       # the oracle has no bigWig reader: it gets the same track as BBM
         compare_cli(tmp_path, args + [str(small_synth / "pe.bw") if e == "BW" else e for e in extra], env=env,
@@ -296,4 +297,15 @@ def test_high_depth_100x_byte_exact(tmp_path):
     """100x coverage (BASELINE configs[4] depth): several rounds of segments per tile"""
     synth(tmp_path / "deep", "-L", "150000", "-c", "100", "-s", "41", "--bbm")
     compare_cli(tmp_path, [str(tmp_path / "deep.fa"), str(tmp_path / "deep.bam"), "--mergeContext", "--CHG", "-B", str(tmp_path / "deep.bbm")])
-    compare_cli(tmp_path, [str(tmp_path / "deep.fa"), str(tmp_path / "deep.bam"), "--CHH", "--minOppositeDepth", "10", "--maxVariantFrac", "0.1"], env={"MDK_TILE": "4096"})
+    compare_cli(tmp_path, [str(tmp_path / "deep.fa"), str(tmp_path / "deep.bam"), "--CHH", "--minOppositeDepth", "10", "--maxVariantFrac", "0.1"], env={"MDK_TILE": "1024"})
+
+
+def test_tile_geometry_is_what_was_asked_for():
+    """the three geometries of the matrix above are really three: md_dev_open rounds a request up to a multiple of 512 and
+    clamps it to 2048 positions (4 per thread)"""
+    import ctypes as C
+    for ask, want in ((512, 512), (1024, 1024), (0, 2048), (2048, 2048), (700, 1024), (4096, 2048)):
+        cfg = mdk.md_dev_cfg(); cfg.keepCpG = 1; cfg.minPhred = 5; cfg.tile = ask
+        dev = mdk.Device(cfg, device=0)
+        assert mdk.lib_hip().md_dev_tile(dev.h) == want, ask
+        dev.close()

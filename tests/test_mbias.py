@@ -189,3 +189,29 @@ def test_option_errors_match_the_oracle(tmp_path, args, rc):
     assert f"returned {want}" in g.stdout
     first = lambda s: [l for l in s.splitlines() if l.strip()][:1]       # usage texts differ by design; the message does not
     assert first(g.stderr) == first(o.stderr)
+
+
+@pytest.mark.parametrize("extra", [[], ["--CHG", "--CHH"], ["--noCpG", "--CHH", "-q", "20", "-p", "12"]], ids=["cpg", "allctx", "chh_q20_p12"])
+def test_mbias_totals_equal_extract_totals_single_end(tmp_path, extra):
+    """Cross-check that does not rest on the mbias restatement alone: without mate-overlap handling (single-end reads, so
+    extract's overlap rule never fires and mbias has none, MBias.c:158-161) every methylation call `extract` counts at a
+    position is the same (read, base) event `mbias` files under the base's position in the read.  So the column sums of the
+    mbias table must equal the count sums of extract's bedGraphs, per context set, for the same filters (one chunk, so
+    mbias' window-relative contexts at chunk edges cannot differ)."""
+    from conftest import run_oracle, synth
+    synth(tmp_path / "se", "-L", "60000", "-c", "18", "-s", "31", "--single", "--extras")
+    args = [tmp_path / "se.fa", tmp_path / "se.bam"] + extra
+    o = oracle_mbias(args + ["--noSVG", "--txt", "o"], cwd=tmp_path)      # mbias --txt prints the table
+    assert o.returncode == 0, o.stderr
+    table = parse_txt(o.stdout)
+    (tmp_path / "e").mkdir()
+    e = run_oracle(args + ["-o", "x"], cwd=tmp_path / "e")
+    assert e.returncode == 0, e.stderr
+    meth = unmeth = 0
+    for f in (tmp_path / "e").iterdir():
+        for line in open(f):
+            t = line.split("\t")
+            if len(t) == 6:
+                meth += int(t[4]); unmeth += int(t[5])
+    assert (sum(v[0] for v in table.values()), sum(v[1] for v in table.values())) == (meth, unmeth)
+    assert meth + unmeth > 5000

@@ -1,34 +1,74 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 output of tools/gpu_round.sh (under gpurun_out/) into the small summaries kept in profiles/."""
-import collections, csv, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
-shutil.copy(f"{src}/{tag}_prof_kt/kt_kernel_stats.csv", f"{dst}/{tag}_rocprofv3_kernel_stats.csv")
+
+
+def find(d, name):
+    g = glob.glob(f"{src}/{tag}_{d}/**/{name}", recursive=True)
+    return g[0] if g else None
+
+
+kt = find("prof_kt", "kt_kernel_stats.csv")
+if kt:
+    shutil.copy(kt, f"{dst}/{tag}_rocprofv3_kernel_stats.csv")
 for f in ("bench.json", "bench_under_rocprof.json", "pytest_gpu.log", "smoke.log"):
     if os.path.exists(f"{src}/{tag}_{f}"):
         shutil.copy(f"{src}/{tag}_{f}", f"{dst}/{tag}_{f}")
+
+
+def counters(d, match):
+    f = find(d, "p_counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if f:
+        for r in csv.DictReader(open(f)):
+            for m in match:
+                if m in r["Kernel_Name"]:
+                    agg[m][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
 pmc = {}
 for d in ("sq", "fetch", "write_lds", "cache"):
-    f = f"{src}/{tag}_prof_pmc_{d}/p_counter_collection.csv"
-    if not os.path.exists(f):
-        continue
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "k_pileup" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
+    for k, v in counters("prof_pmc_" + d, ["k_pileup"])["k_pileup"].items():
         pmc[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
-out = {"kernel": "k_pileup<false>", "command": "python bench.py --steps 20 --warmup 5 --no-cpu-baseline (one rocprofv3 --pmc pass per counter group)", "counters": pmc}
+out = {"kernel": "k_pileup<false>", "command": "python bench.py --no-cpu-baseline --steps 2 --warmup 1 --passes 4 (16 resident 1 Mb intervals in rotation, ~0.8 GB working set; one rocprofv3 --pmc pass per counter group)", "counters": pmc}
+
+# calibration: bytes of the distinct 64-byte lines each calibration kernel touches / what the counter reported (KiB)
+calib = {}
+exp = None
+try:
+    exp = json.loads([l for l in open(f"{src}/{tag}_calib_expected.json") if l.startswith("{")][-1])["expected"]
+except Exception:
+    pass
+if exp:
+    names = list(exp.keys())
+    fe, wr = counters("calib_fetch", names), counters("calib_write", names)
+    for n in names:
+        e = {"expected_bytes_64B_lines": exp[n]["bytes64"], "expected_bytes_128B_pairs": exp[n]["bytes128"]}
+        if fe[n].get("FETCH_SIZE"):
+            v = fe[n]["FETCH_SIZE"]; m = sum(v) / len(v) * 1024
+            e["FETCH_SIZE_bytes"] = m; e["fetch_factor_64"] = exp[n]["bytes64"] / m if m else None; e["fetch_factor_128"] = exp[n]["bytes128"] / m if m else None
+        if wr[n].get("WRITE_SIZE"):
+            v = wr[n]["WRITE_SIZE"]; m = sum(v) / len(v) * 1024
+            e["WRITE_SIZE_bytes"] = m; e["write_factor_64"] = exp[n]["bytes64"] / m if m else None
+        calib[n] = e
+    out["calibration"] = calib
 if "FETCH_SIZE" in pmc:
     fs, ws = pmc["FETCH_SIZE"]["mean_per_dispatch"], pmc.get("WRITE_SIZE", {"mean_per_dispatch": 0})["mean_per_dispatch"]
+    ff = (calib.get("calib_gather_pair") or {}).get("fetch_factor_64")
+    wf = (calib.get("calib_write16") or {}).get("write_factor_64")
     out["hbm_traffic_bytes_per_launch"] = {
-        "fetch_raw": fs * 1024, "write_raw": ws * 1024,
-        "fetch_x2_gfx950_correction": fs * 2048,
-        "note": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide streaming reads by 2x (MI355X_MICROARCH.md, HBM section); "
-                "this kernel's reads are byte-granular so the factor is uncalibrated: the truth lies between fetch_raw and fetch_x2. After the first "
-                "iteration the whole 50 MB working set sits in the 256 MiB Infinity Cache, whose hits these counters include."}
+        "fetch_raw": fs * 1024, "write_raw": ws * 1024, "fetch_factor": ff, "write_factor": wf,
+        "fetch_calibrated": fs * 1024 * (ff if ff else 2.0), "write_calibrated": ws * 1024 * (wf if wf else 1.0),
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) per k_pileup dispatch while rotating over 16 resident 1 Mb intervals (working set ~0.8 GB, beyond the "
+                "256 MiB Infinity Cache), multiplied by the factors tools/mdk_calib measured on this box for this kernel's own access patterns: FETCH_SIZE x %s "
+                "(calib_gather_pair: a sequence byte and a quality byte ~80 B apart per 228-byte read payload, 1 GiB buffer, distinct 64-byte lines known exactly), "
+                "WRITE_SIZE x %s (calib_write16: coalesced 16-byte stores)" % (("%.3f" % ff) if ff else "2 (uncalibrated)", ("%.3f" % wf) if wf else "1 (uncalibrated)")}
 json.dump(out, open(f"{dst}/{tag}_rocprofv3_pmc_summary.json", "w"), indent=1)
-print(open(f"{dst}/{tag}_rocprofv3_kernel_stats.csv").read())
-print(json.dumps(out, indent=1)[:1500])
+if kt:
+    print(open(f"{dst}/{tag}_rocprofv3_kernel_stats.csv").read())
+print(json.dumps(out, indent=1)[:4000])
