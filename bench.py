@@ -224,7 +224,7 @@ def main():
     # tools/mdk_calib (byte gathers of a known line count), or left null
     traffic, traffic_note = None, None
     try:
-        prof = json.load(open(REPO / "profiles" / "r02_rocprofv3_pmc_summary.json"))
+        prof = json.load(open(sorted((REPO / "profiles").glob("r02*_rocprofv3_pmc_summary.json"))[-1]))      # the latest committed summary of this round
         hb = prof["hbm_traffic_bytes_per_launch"]
         if not extra and not args.synth_args and args.length == 1_000_000:
             traffic = hb["fetch_calibrated"] + hb["write_calibrated"]

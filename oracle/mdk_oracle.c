@@ -55,6 +55,7 @@
 #include <string.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <time.h>
 
 #define ORACLE_VERSION "0.6.1"
 /* Differential-search knob (tests/t8_differential.py): MDK_ORACLE_PERTURB=<n> makes ONE rule deviate
@@ -118,6 +119,9 @@ static int32_t rec_endpos(const brec *r) { return r->pos + (r->rlen > 0 ? r->rle
  * and record decoding scale with the workers.  This oracle keeps the whole file in memory instead, so the same work is
  * spread over the N threads up front: members are inflated block-parallel, records are decoded range-parallel. */
 static int g_load_threads = 1;
+static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#define PHASE(name) do { if(getenv("MDK_ORACLE_PROFILE")) { double t_ = wall_s(); fprintf(stderr, "[oracle] %-22s %.3f s\n", name, t_ - g_t0); g_t0 = t_; } } while(0)
+static double g_t0;
 typedef struct { const uint8_t *raw; const size_t *moff, *mout; const uint32_t *mlen, *misz, *mhdr; size_t nm; uint8_t *out; int k, n, bad; } inflate_job;
 static void *inflate_main(void *arg) {
     inflate_job *j = arg; size_t i; z_stream zs;
@@ -159,10 +163,12 @@ static int bam_load(const char *fn, bamfile *bf) {
     int nt = g_load_threads < 1 ? 1 : g_load_threads, k, bad = 0;
     memset(bf, 0, sizeof(*bf));
     if(!f) return -1;
+    g_t0 = wall_s();
     fseek(f, 0, SEEK_END); rawlen = ftell(f); fseek(f, 0, SEEK_SET);
     raw = xmalloc(rawlen);
     if(fread(raw, 1, rawlen, f) != rawlen) { fclose(f); free(raw); return -1; }
     fclose(f);
+    PHASE("read file");
     /* member table (BGZF: concatenated gzip members with a 'BC' extra subfield holding the member size) */
     moff = xmalloc(mcap * sizeof(size_t)); mout = xmalloc(mcap * sizeof(size_t)); mlen = xmalloc(mcap * 4); misz = xmalloc(mcap * 4); mhdr = xmalloc(mcap * 4);
     while(o + 18 <= rawlen) {
@@ -179,7 +185,9 @@ static int bam_load(const char *fn, bamfile *bf) {
         moff[nm] = o; mlen[nm] = (uint32_t)bsize + 1; mhdr[nm] = 12u + xlen; misz[nm] = rd32(raw + o + bsize + 1 - 4); mout[nm] = total; total += misz[nm]; nm++;
         o += (size_t)bsize + 1;
     }
-    bf->data = xmalloc(total + 1); bf->len = total;
+    PHASE("member table");
+    bf->data = xmalloc(total + 1);
+    bf->len = total;
     {
         pthread_t *th = xmalloc(sizeof(pthread_t) * nt); inflate_job *job = xmalloc(sizeof(inflate_job) * nt);
         for(k = 0; k < nt; k++) { inflate_job j = {raw, moff, mout, mlen, misz, mhdr, nm, bf->data, k, nt, 0}; job[k] = j; if(k) pthread_create(&th[k], NULL, inflate_main, &job[k]); }
@@ -189,6 +197,7 @@ static int bam_load(const char *fn, bamfile *bf) {
         free(th); free(job);
     }
     free(raw); free(moff); free(mout); free(mlen); free(misz); free(mhdr);
+    PHASE("inflate");
     if(bad) return -2;
     /* header */
     if(bf->len < 12 || memcmp(bf->data, "BAM\1", 4)) return -3;
@@ -211,6 +220,7 @@ static int bam_load(const char *fn, bamfile *bf) {
         roff[bf->n_rec++] = o;
         o += 4 + (size_t)bs;
     }
+    PHASE("record walk");
     bf->rec = xmalloc((bf->n_rec + 1) * sizeof(brec));
     {
         pthread_t *th = xmalloc(sizeof(pthread_t) * nt); decode_job *job = xmalloc(sizeof(decode_job) * nt);
@@ -221,9 +231,11 @@ static int bam_load(const char *fn, bamfile *bf) {
         free(th); free(job);
     }
     free(roff);
+    PHASE("record decode");
     if(bad) return -3;
     /* per-tid ranges; the pileup needs coordinate-sorted input (htslib errors out otherwise) */
     bf->tid_lo = xmalloc(sizeof(size_t) * (bf->n_targets + 1));
+    (void)0;
     bf->tid_hi = xmalloc(sizeof(size_t) * (bf->n_targets + 1));
     for(i = 0; i < (size_t)bf->n_targets; i++) bf->tid_lo[i] = bf->tid_hi[i] = 0;
     for(i = 0; i < bf->n_rec; i++) {
@@ -234,6 +246,7 @@ static int bam_load(const char *fn, bamfile *bf) {
         if(i > bf->tid_lo[b->tid] && bf->rec[i - 1].pos > b->pos) { fprintf(stderr, "oracle: BAM is not coordinate sorted\n"); return -4; }
         bf->tid_hi[b->tid] = i + 1;
     }
+    PHASE("contig ranges");
     return 0;
 }
 
@@ -1409,12 +1422,14 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
     if(getenv("MDK_ORACLE_DUMP")) dump_fp = fopen(getenv("MDK_ORACLE_DUMP"), "w");
 
     {   /* extract.c:1479-1486 */
+        PHASE("fasta, outputs");
         extractArgs ea = {&config, &bf, &fa}; int nt = config.nThreads < 1 ? 1 : config.nThreads; pthread_t *threads = calloc((size_t)nt, sizeof(pthread_t));
         if(dump_fp) nt = 1;      /* the per-column dump is written as columns are finished: one worker keeps it ordered */
         for(i = 1; i < nt; i++) pthread_create(threads + i, NULL, extractCalls, &ea);
         extractCalls(&ea);
         for(i = 1; i < nt; i++) pthread_join(threads[i], NULL);
         free(threads);
+        PHASE("chunks (all workers)");
     }
 
     if(dump_fp) { fclose(dump_fp); dump_fp = NULL; }

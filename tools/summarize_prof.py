@@ -59,15 +59,17 @@ if exp:
     out["calibration"] = calib
 if "FETCH_SIZE" in pmc:
     fs, ws = pmc["FETCH_SIZE"]["mean_per_dispatch"], pmc.get("WRITE_SIZE", {"mean_per_dispatch": 0})["mean_per_dispatch"]
-    ff = (calib.get("calib_gather_pair") or {}).get("fetch_factor_64")
+    ff = (calib.get("calib_gather_pair") or {}).get("fetch_factor_128")
     wf = (calib.get("calib_write16") or {}).get("write_factor_64")
     out["hbm_traffic_bytes_per_launch"] = {
         "fetch_raw": fs * 1024, "write_raw": ws * 1024, "fetch_factor": ff, "write_factor": wf,
         "fetch_calibrated": fs * 1024 * (ff if ff else 2.0), "write_calibrated": ws * 1024 * (wf if wf else 1.0),
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) per k_pileup dispatch while rotating over 16 resident 1 Mb intervals (working set ~0.8 GB, beyond the "
                 "256 MiB Infinity Cache), multiplied by the factors tools/mdk_calib measured on this box for this kernel's own access patterns: FETCH_SIZE x %s "
-                "(calib_gather_pair: a sequence byte and a quality byte ~80 B apart per 228-byte read payload, 1 GiB buffer, distinct 64-byte lines known exactly), "
-                "WRITE_SIZE x %s (calib_write16: coalesced 16-byte stores)" % (("%.3f" % ff) if ff else "2 (uncalibrated)", ("%.3f" % wf) if wf else "1 (uncalibrated)")}
+                "(calib_gather_pair: a sequence byte and a quality byte ~80 B apart per 228-byte read payload, 1 GiB buffer).  The calibration shows the memory side "
+                "moves 128-byte granules and the counter tallies each as 64 bytes: one byte from every 64-byte line and one byte from every second line both read as "
+                "half the buffer, so the factor is 2 against the distinct 128-byte granules touched (1.17 against distinct 64-byte lines); WRITE_SIZE x %s "
+                "(calib_write16: coalesced 16-byte stores)" % (("%.3f" % ff) if ff else "2 (uncalibrated)", ("%.3f" % wf) if wf else "1 (uncalibrated)")}
 json.dump(out, open(f"{dst}/{tag}_rocprofv3_pmc_summary.json", "w"), indent=1)
 if kt:
     print(open(f"{dst}/{tag}_rocprofv3_kernel_stats.csv").read())
