@@ -41,6 +41,9 @@ typedef struct {
     uint64_t n_records_seen;   /* BAM records examined for this chunk (before admission) */
     md_pr_batch pr;            /* perRead plans: the reads that start in the chunk (batch is unused then) */
     const void *host;          /* perRead plans: the plan's own record of those reads (names), for mdk_plan_emit_perread */
+    int32_t  prep;             /* 1: device preparation -- `raw` describes the chunk's records for md_dev_submit_raw and `batch` is empty
+                                  (until mdk_plan_host_prepare) */
+    md_raw_batch raw;
 } mdk_chunk;
 
 /* Parse an `extract` command line (argv[0] = "extract"), open inputs.  rc follows extract_main:
@@ -53,6 +56,14 @@ void mdk_plan_dev_cfg(const mdk_plan *p, md_dev_cfg *cfg);
 int  mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid);
 /* 1: chunk produced; 0: schedule finished; <0: error */
 int  mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c);
+/* Where a chunk's per-record work happens.  mode 0 (what mdk_plan_open gives): on the host -- chunks carry `batch`.
+ * mode 1 (what extract_main uses): on the device -- chunks carry `raw`, and md_dev_set_prep must be given
+ * mdk_plan_prep_cfg's configuration (plus md_dev_set_mappability per contig, done by mdk_plan_ensure_reference).
+ * Must be called before the first mdk_plan_next_chunk.  mdk_plan_host_prepare fills `batch` of a mode-1 chunk after all
+ * (for a chunk the device answered with MDK_ERR_PREP_HOST); valid until the second-next mdk_plan_next_chunk. */
+int  mdk_plan_set_prep(mdk_plan *p, int mode);
+void mdk_plan_prep_cfg(const mdk_plan *p, md_prep_cfg *cfg);
+int  mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c);
 /* host post-pass for one chunk (variant filter, --mergeContext, formats; extract.c:443-510), appended to
  * the plan's output files.  Chunks must be emitted in index order. */
 int  mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *sites);

@@ -37,6 +37,8 @@ extern "C" {
 #define MDK_ERR_STRAND0  (-5)   /* a read of undeterminable strand reached a methylation call
                                    (the reference aborts there: common.c:122-125) */
 #define MDK_ERR_NOMEM    (-6)
+#define MDK_ERR_PREP_HOST (-7)  /* device chunk preparation met a read name it does not handle (more records of one name than a
+                                   lane keeps): prepare this chunk on the host (md_dev_submit of a host-built batch) */
 
 typedef struct md_dev md_dev;
 
@@ -108,6 +110,44 @@ typedef struct {
     int32_t n_tiles;
     const md_site *d_site; const md_site_var *d_var; const md_tile_seg *d_seg;   /* DEVICE pointers */
 } md_sites_dev;
+
+/* ---- chunk preparation on the device ----
+ * Instead of a host-built md_read_batch the device can take the records of a chunk as they lie in the inflated BAM stream and
+ * do the reference's per-record work itself: filter_func's admission tests (common.c:416-444) with the NH / XG aux walk,
+ * getStrand (common.c:84-116), the mappability windows (common.c:277-335), the BED span test (common.c:432-439), the
+ * conversion-efficiency filter (common.c:338-404), the read-name pairing of the overlap constructor/destructor callbacks
+ * (overlaps.c:121-147, with htslib's buffer eviction) and the CIGAR -> segment expansion (overlaps.c:27-52).
+ * md_prep_cfg: the part of `Config` those steps read (MethylDackel.h:90-126). */
+typedef struct {
+    int32_t min_mapq, ignore_flags, require_flags, keep_dupes, ignore_nh, keep_singleton, keep_discordant;
+    int32_t min_phred;            /* -p, for the conversion-efficiency filter */
+    float   min_conv_eff;         /* --minConversionEfficiency, 0 = off */
+    int32_t map_on, min_mappable; /* -M/-B given; --minMappableBases */
+    int32_t no_pairing;           /* mbias: no overlap handler is installed (MBias.c:158-161) */
+} md_prep_cfg;
+/* host memory holding whole records back to back, each as in the file: uint32 block_size, then block_size bytes */
+typedef struct { const uint8_t *ptr; uint64_t bytes; } md_raw_range;
+/* The candidate records of ONE chunk: everything the region query [beg,end) of the chunk's contig returns (pos < end,
+ * bam_endpos > beg), in file order.  rec_off[i] = offset of record i's block_size word in the concatenation of the ranges
+ * (less than 4 GiB in total).  woff/wlen: the reference window the chunk fetches (extract.c:381), which the
+ * conversion-efficiency filter classifies inside.  Host-owned; valid until the slot is waited for. */
+typedef struct {
+    int32_t tid; int64_t beg, end;
+    int32_t n_ranges; const md_raw_range *range;
+    int32_t n_records; const uint32_t *rec_off;
+    int64_t woff, wlen;
+} md_raw_batch;
+int  md_dev_set_prep(md_dev *h, const md_prep_cfg *cfg);
+/* mappability of a contig, 1 bit per base (bit i%32 of word i/32; 1 = mappable), for the admission windows */
+int  md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bits, int64_t n_bases);
+/* md_dev_upload_raw = H2D of the ranges + the preparation kernels; the slot is then in the same state as after md_dev_upload
+ * (launch / download / wait / bench work on it).  md_dev_submit_raw = upload_raw + launch.  md_dev_download / md_dev_wait
+ * return MDK_ERR_PREP_HOST when the preparation gave up on the chunk (see above). */
+int  md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b);
+int  md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b);
+/* Test hook: the segments the device built for an uploaded slot (off4 / m_off4 are BYTE offsets into the uploaded records,
+ * qualities follow the sequence without padding), their number, and the number of admitted reads. */
+int  md_dev_debug_segments(md_dev *h, int slot, md_seg *out, int64_t cap, int64_t *n_segs, int64_t *n_reads);
 
 typedef struct {
     float ms_total;      /* one launch bracketed by HIP events on the slot's stream (includes lone-launch dispatch latency), mean over iters */

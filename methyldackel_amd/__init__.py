@@ -50,6 +50,21 @@ class md_read_batch(C.Structure):
                 ("n_reads", C.c_int32), ("algo_bytes", C.c_uint64)]
 
 
+class md_prep_cfg(C.Structure):
+    _fields_ = [("min_mapq", C.c_int32), ("ignore_flags", C.c_int32), ("require_flags", C.c_int32), ("keep_dupes", C.c_int32), ("ignore_nh", C.c_int32),
+                ("keep_singleton", C.c_int32), ("keep_discordant", C.c_int32), ("min_phred", C.c_int32), ("min_conv_eff", C.c_float),
+                ("map_on", C.c_int32), ("min_mappable", C.c_int32), ("no_pairing", C.c_int32)]
+
+
+class md_raw_range(C.Structure):
+    _fields_ = [("ptr", C.POINTER(C.c_uint8)), ("bytes", C.c_uint64)]
+
+
+class md_raw_batch(C.Structure):
+    _fields_ = [("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("n_ranges", C.c_int32), ("range", C.POINTER(md_raw_range)),
+                ("n_records", C.c_int32), ("rec_off", C.POINTER(C.c_uint32)), ("woff", C.c_int64), ("wlen", C.c_int64)]
+
+
 class md_region(C.Structure):
     _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("strand", C.c_int32)]
 
@@ -99,7 +114,8 @@ class md_bench_result(C.Structure):
 
 class mdk_chunk(C.Structure):
     _fields_ = [("index", C.c_uint32), ("tid", C.c_int32), ("beg", C.c_int64), ("end", C.c_int64), ("skipped", C.c_int32),
-                ("batch", md_read_batch), ("n_records_seen", C.c_uint64), ("pr", md_pr_batch), ("host", C.c_void_p)]
+                ("batch", md_read_batch), ("n_records_seen", C.c_uint64), ("pr", md_pr_batch), ("host", C.c_void_p),
+                ("prep", C.c_int32), ("raw", md_raw_batch)]
 
 
 class md_bench_run_result(C.Structure):
@@ -112,11 +128,12 @@ HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_bench_rotate", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_local", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait",
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned",
+               "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_submit_raw", "md_dev_debug_segments",
                "md_dev_mbias_submit", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
                "md_dev_perread_submit", "md_dev_perread_download"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
-                   "mdk_plan_target_len", "mdk_plan_regions",
+                   "mdk_plan_target_len", "mdk_plan_regions", "mdk_plan_set_prep", "mdk_plan_prep_cfg", "mdk_plan_host_prepare",
                    "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report",
                    "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread", "mergeContext_main"]
 
@@ -169,6 +186,11 @@ def lib_hip():
         L.md_bench_region_bytes.argtypes = [C.c_void_p]; L.md_bench_region_bytes.restype = C.c_int64
         L.md_bench_close.argtypes = [C.c_void_p]; L.md_bench_close.restype = None
         L.md_dev_debug_effective.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.md_dev_set_prep.argtypes = [C.c_void_p, C.POINTER(md_prep_cfg)]
+        L.md_dev_set_mappability.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.md_dev_upload_raw.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_raw_batch)]
+        L.md_dev_submit_raw.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_raw_batch)]
+        L.md_dev_debug_segments.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_seg), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.md_dev_mbias_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_read_batch)]
         L.md_dev_mbias_read.argtypes = [C.c_void_p, C.POINTER(md_mbias)]
         L.md_dev_mbias_reset.argtypes = [C.c_void_p]
@@ -212,6 +234,9 @@ def lib_extract():
         L.mdk_plan_open_perread.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         L.mdk_plan_emit_perread.argtypes = [C.c_void_p, C.POINTER(mdk_chunk), C.POINTER(md_pr_count), C.c_int64]
         L.mdk_plan_regions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(md_region)), C.POINTER(C.c_int64)]
+        L.mdk_plan_set_prep.argtypes = [C.c_void_p, C.c_int]
+        L.mdk_plan_prep_cfg.argtypes = [C.c_void_p, C.POINTER(md_prep_cfg)]; L.mdk_plan_prep_cfg.restype = None
+        L.mdk_plan_host_prepare.argtypes = [C.c_void_p, C.POINTER(mdk_chunk)]
         _ext = L
     return _ext
 
@@ -248,6 +273,24 @@ class Device:
 
     def submit(self, slot: int, batch: md_read_batch):
         self._chk(self.L.md_dev_submit(self.h, slot, C.byref(batch)), "md_dev_submit")
+
+    def set_prep(self, cfg: "md_prep_cfg"):
+        self._chk(self.L.md_dev_set_prep(self.h, C.byref(cfg)), "md_dev_set_prep")
+
+    def upload_raw(self, slot: int, raw: "md_raw_batch"):
+        """H2D of a chunk's BAM records + the device preparation (admission, pairing, segments)"""
+        self._chk(self.L.md_dev_upload_raw(self.h, slot, C.byref(raw)), "md_dev_upload_raw")
+
+    def submit_raw(self, slot: int, raw: "md_raw_batch"):
+        self._chk(self.L.md_dev_submit_raw(self.h, slot, C.byref(raw)), "md_dev_submit_raw")
+
+    def debug_segments(self, slot: int):
+        """-> (list of md_seg as the device preparation built them, number of admitted reads)"""
+        n, nr = C.c_int64(), C.c_int64()
+        self._chk(self.L.md_dev_debug_segments(self.h, slot, None, 0, C.byref(n), C.byref(nr)), "md_dev_debug_segments")
+        arr = (md_seg * max(1, n.value))()
+        self._chk(self.L.md_dev_debug_segments(self.h, slot, arr, n.value, C.byref(n), C.byref(nr)), "md_dev_debug_segments")
+        return arr, n.value, nr.value
 
     def upload(self, slot: int, batch: md_read_batch):
         self._chk(self.L.md_dev_upload(self.h, slot, C.byref(batch)), "md_dev_upload")
@@ -351,6 +394,21 @@ class Plan:
     def set_shard(self, rank: int, world: int):
         if self.L.mdk_plan_set_shard(self.p, rank, world):
             raise MdkError("mdk_plan_set_shard: bad rank/world")
+
+    def set_prep(self, mode: int):
+        """0: chunks are prepared on the host (`batch`); 1: they come as raw records for the device (`raw`)"""
+        if self.L.mdk_plan_set_prep(self.p, mode):
+            raise MdkError("mdk_plan_set_prep: not possible for this plan (already started, or a perRead/mbias plan)")
+
+    def prep_cfg(self) -> "md_prep_cfg":
+        c = md_prep_cfg()
+        self.L.mdk_plan_prep_cfg(self.p, C.byref(c))
+        return c
+
+    def host_prepare(self, chunk: "mdk_chunk"):
+        rc = self.L.mdk_plan_host_prepare(self.p, C.byref(chunk))
+        if rc:
+            raise MdkError(f"mdk_plan_host_prepare failed ({rc})")
 
     def next_chunk(self):
         c = mdk_chunk()

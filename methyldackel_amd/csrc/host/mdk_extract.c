@@ -47,7 +47,7 @@ MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_ope
 
 int extract_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; int dth_ok; emitter em;
-    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta;
+    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta; int n_host_prep = 0;
     if(argc > 2) hip_warm_up();
     rc = mdk_plan_open(argc, argv, &p);
     t_open = now_s() - T0;
@@ -56,12 +56,16 @@ int extract_main(int argc, char *argv[]) {
     memset(&dop, 0, sizeof(dop));
     mdk_plan_dev_cfg(p, &dop.cfg);
     if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
+    /* the per-record work of a chunk (admission, strand, name pairing, CIGAR expansion) runs on the device; MDK_HOST_PREP=1 keeps
+     * it on the host's chunk workers (the round-1 arrangement, and what a chunk the device gives up on falls back to) */
+    if(!getenv("MDK_HOST_PREP")) mdk_plan_set_prep(p, 1);
     dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
     if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
     t_dev = now_s() - T0;
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
     if(emitter_start(&em, p, p->o.n_threads >= 8 ? 8 : p->o.n_threads)) { md_dev_close(dev); mdk_plan_close(p); return -5; }
     /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then hand k-1 to the emitter */
     while(more || have[0] || have[1]) {
@@ -76,7 +80,7 @@ int extract_main(int argc, char *argv[]) {
                 if(!ch[cur].skipped) {
                     ta = now_s();
                     rc = mdk_plan_ensure_reference(p, dev, ch[cur].tid);
-                    if(!rc) rc = md_dev_submit(dev, cur, &ch[cur].batch);
+                    if(!rc) rc = ch[cur].prep ? md_dev_submit_raw(dev, cur, &ch[cur].raw) : md_dev_submit(dev, cur, &ch[cur].batch);
                     w_sub += now_s() - ta;
                     if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
                 }
@@ -88,6 +92,12 @@ int extract_main(int argc, char *argv[]) {
             if(!ch[prev].skipped) {
                 ta = now_s();
                 rc = md_dev_download(dev, prev, &sites);
+                if(rc == MDK_ERR_PREP_HOST) {          /* a read name the device preparation does not handle: this chunk the slow way */
+                    rc = mdk_plan_host_prepare(p, &ch[prev]);
+                    if(!rc) rc = md_dev_submit(dev, prev, &ch[prev].batch);
+                    if(!rc) rc = md_dev_download(dev, prev, &sites);
+                    n_host_prep++;
+                }
                 w_down += now_s() - ta;
                 if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
@@ -101,7 +111,7 @@ int extract_main(int argc, char *argv[]) {
         if(!more && !have[0] && !have[1]) break;
     }
     { double tw = now_s(); emitter_stop(&em); w_emit += now_s() - tw; }
-    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0);
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0, n_host_prep);
     if(ret == 0) mdk_plan_finish(p);
     if(fast_exit_wanted()) leave_fast(ret);
     md_dev_close(dev);

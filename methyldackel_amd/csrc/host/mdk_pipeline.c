@@ -365,10 +365,20 @@ typedef struct pslot {
     uint64_t n_stream;                                    /* records in the ranges (for up-front reservation) */
     const char *win; int64_t woff, wlen;
     batchbuf bb; int rc;
+    /* device preparation: the same records described for md_dev_upload_raw -- the copied records, then the ranges -- with
+     * every record's offset in that concatenation; the slabs stay referenced until the chunk is recycled (the H2D copies
+     * read them, and a chunk the device gives up on is prepared from them by mdk_plan_host_prepare) */
+    uint32_t *roff; size_t n_roff, cap_roff; uint64_t rg_base; md_raw_range *rr; int cap_rr; int hold_slabs, prepared;
 } pslot;
 
+static int roff_push(pslot *sl, uint64_t off) {
+    if(sl->n_roff == sl->cap_roff) { size_t nc = sl->cap_roff ? sl->cap_roff * 2 : 1u << 18; if(grow((void **)&sl->roff, nc * sizeof(uint32_t))) return -1; sl->cap_roff = nc; }
+    sl->roff[sl->n_roff++] = (uint32_t)off;
+    return 0;
+}
 static int raw_push(pslot *sl, const mdk_rec *r) {
     size_t need = sl->raw_len + 4 + r->raw_len;
+    if(sl->hold_slabs && roff_push(sl, sl->raw_len)) return -1;
     if(need > sl->raw_cap) { size_t nc = need * 2 + (1 << 20); if(grow((void **)&sl->raw, nc)) return -1; sl->raw_cap = nc; }
     memcpy(sl->raw + sl->raw_len, &r->raw_len, 4); memcpy(sl->raw + sl->raw_len + 4, r->raw, r->raw_len); sl->raw_len = need;
     return 0;
@@ -378,6 +388,7 @@ static int raw_push(pslot *sl, const mdk_rec *r) {
 static int reader_fill(mdk_plan *p, pslot *sl) {
     const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; int rc, fi, collect; mdk_rec r; size_t off; mdk_chunk *c = &sl->c;
     memset(c, 0, sizeof(*c)); sl->raw_len = 0; sl->n_rg = 0; sl->n_stream = 0; sl->win = NULL; sl->woff = sl->wlen = 0;
+    sl->n_roff = 0; sl->rg_base = 0; sl->prepared = 0; sl->hold_slabs = p->dev_prep;
     /* extract.c:325-350 */
     c->index = p->bin++;
     tid = p->g_tid; beg = p->g_pos; end = (uint32_t)(beg + o->chunk_size);
@@ -454,10 +465,12 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
                 size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
                 if(g && g->slab == cs && g->end == roff) g->end = roff + 4 + q.len;
                 else {
+                    if(g) sl->rg_base += g->end - g->beg;
                     if(sl->n_rg == sl->cap_rg) { int nc = sl->cap_rg ? sl->cap_rg * 2 : 16; if(grow((void **)&sl->rg, sizeof(rrange) * (size_t)nc)) return -5; sl->cap_rg = nc; }
                     g = &sl->rg[sl->n_rg++]; g->slab = cs; g->beg = roff; g->end = roff + 4 + q.len; mdk_slab_ref(bam, cs);
                 }
                 sl->n_stream++;
+                if(sl->hold_slabs && roff_push(sl, (uint64_t)sl->raw_len + sl->rg_base + (roff - g->beg))) return -5;
             }
             if((uint32_t)q.endp > end) { r.raw = raw; r.raw_len = q.len; if(carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5; }
         }
@@ -491,9 +504,9 @@ static int worker_process(mdk_plan *p, pslot *sl) {
             off += 4 + (size_t)len;
             if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen, c->beg, c->end) < 0) return -5;
         }
-        mdk_slab_unref(p->bam, sl->rg[g].slab);
+        if(!sl->hold_slabs) mdk_slab_unref(p->bam, sl->rg[g].slab);
     }
-    sl->n_rg = 0;
+    if(!sl->hold_slabs) sl->n_rg = 0;
     if(bb_reserve(b, 1, 16, 16, 1) || seg_reserve(b, 1)) return -5;          /* never hand out NULL arrays */
     t1 = now_s();
     if(p->o.perread) {        /* no pairing, no segments: the device walks each read's CIGAR itself */
@@ -517,6 +530,26 @@ static int worker_process(mdk_plan *p, pslot *sl) {
     return 0;
 }
 
+/* describe the chunk's records for md_dev_upload_raw (no per-record work on the host) */
+static int describe_raw(mdk_plan *p, pslot *sl) {
+    mdk_chunk *c = &sl->c; int g, n = 0; uint64_t total = sl->raw_len;
+    if(sl->n_rg + 1 > sl->cap_rr) { int nc = sl->n_rg + 8; if(grow((void **)&sl->rr, sizeof(md_raw_range) * (size_t)nc)) return -5; sl->cap_rr = nc; }
+    if(sl->raw_len) { sl->rr[n].ptr = sl->raw; sl->rr[n].bytes = sl->raw_len; n++; }
+    for(g = 0; g < sl->n_rg; g++) { sl->rr[n].ptr = sl->rg[g].slab->buf + sl->rg[g].beg; sl->rr[n].bytes = sl->rg[g].end - sl->rg[g].beg; total += sl->rr[n].bytes; n++; }
+    if(total >= 0xffffff00ull) { fprintf(stderr, "[mdk] a chunk holds more than 4 GiB of records; use a smaller --chunkSize\n"); return -2; }
+    c->raw.tid = c->tid; c->raw.beg = c->beg; c->raw.end = c->end; c->raw.n_ranges = n; c->raw.range = sl->rr;
+    c->raw.n_records = (int32_t)sl->n_roff; c->raw.rec_off = sl->roff; c->raw.woff = sl->woff; c->raw.wlen = sl->wlen;
+    c->prep = 1;
+    (void)p;
+    return 0;
+}
+static void slot_release_slabs(mdk_plan *p, pslot *sl) {
+    int g;
+    if(!sl->hold_slabs) return;
+    for(g = 0; g < sl->n_rg; g++) mdk_slab_unref(p->bam, sl->rg[g].slab);
+    sl->n_rg = 0;
+}
+
 static void *reader_main(void *arg) {
     mdk_plan *p = arg;
     for(;;) {
@@ -530,7 +563,9 @@ static void *reader_main(void *arg) {
         rc = reader_fill(p, sl);
         pthread_mutex_lock(&p->mu);
         p->t_rwait += t1 - t0; p->t_rfill += now_s() - t1;
-        if(rc == 1) { sl->state = S_RAW; pthread_cond_signal(&p->cv_raw); }
+        if(rc == 1 && p->dev_prep && !sl->c.skipped) { int r2 = describe_raw(p, sl); if(r2 < 0) rc = r2; }
+        if(rc == 1 && p->dev_prep) { sl->rc = 0; sl->state = S_DONE; pthread_cond_broadcast(&p->cv_done); }     /* nothing to do per record on the host */
+        else if(rc == 1) { sl->state = S_RAW; pthread_cond_signal(&p->cv_raw); }
         else { sl->state = S_FREE; if(rc < 0) p->pipe_rc = rc; p->reader_done = 1; pthread_cond_broadcast(&p->cv_raw); pthread_cond_broadcast(&p->cv_done); }
         pthread_mutex_unlock(&p->mu);
         if(rc != 1) break;
@@ -597,7 +632,7 @@ MDK_LOCAL void pipeline_stop(mdk_plan *p) {
     mdk_bam_abort(p->bam);          /* wake the reader if it is waiting for inflated data */
     pthread_join(p->reader_th, NULL);
     for(i = 0; i < p->n_workers; i++) pthread_join(p->worker_th[i], NULL);
-    for(i = 0; i < p->n_slot; i++) { int g; for(g = 0; g < p->slot[i].n_rg; g++) mdk_slab_unref(p->bam, p->slot[i].rg[g].slab); bb_free(&p->slot[i].bb); free(p->slot[i].raw); free(p->slot[i].rg); }
+    for(i = 0; i < p->n_slot; i++) { int g; for(g = 0; g < p->slot[i].n_rg; g++) mdk_slab_unref(p->bam, p->slot[i].rg[g].slab); bb_free(&p->slot[i].bb); free(p->slot[i].raw); free(p->slot[i].rg); free(p->slot[i].roff); free(p->slot[i].rr); }
     free(p->slot); free(p->worker_th); p->slot = NULL; p->started = 0;
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_free); pthread_cond_destroy(&p->cv_raw); pthread_cond_destroy(&p->cv_done);
 }
@@ -607,7 +642,7 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
     if(!p->started && pipeline_start(p)) return -5;
     pthread_mutex_lock(&p->mu);
     /* the chunk handed out two calls ago is no longer referenced by the caller: recycle its buffers */
-    if(p->held[1] >= 0) { p->slot[p->held[1]].state = S_FREE; pthread_cond_signal(&p->cv_free); }
+    if(p->held[1] >= 0) { slot_release_slabs(p, &p->slot[p->held[1]]); p->slot[p->held[1]].state = S_FREE; pthread_cond_signal(&p->cv_free); }
     p->held[1] = p->held[0]; p->held[0] = -1;
     for(;;) {
         int active = 0;
@@ -631,3 +666,15 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
     return rc;
 }
 
+
+/* A chunk handed out for device preparation, prepared on the host after all (the device reported MDK_ERR_PREP_HOST): the
+ * same admission, pairing and segments as a host-mode plan produces, from the records the slot still references. */
+int mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c) {
+    int i, rc; pslot *sl = NULL;
+    if(!p || !c || !p->started) return -1;
+    for(i = 0; i < 2; i++) if(p->held[i] >= 0 && p->slot[p->held[i]].c.index == c->index) sl = &p->slot[p->held[i]];
+    if(!sl || !sl->hold_slabs) return -1;
+    if(!sl->prepared) { rc = worker_process(p, sl); if(rc < 0) return rc; sl->prepared = 1; }
+    c->batch = sl->c.batch;
+    return 0;
+}

@@ -483,6 +483,20 @@ int mdk_plan_set_shard(mdk_plan *p, int rank, int world) {
     p->shard_rank = rank; p->shard_world = world;
     return 0;
 }
+int mdk_plan_set_prep(mdk_plan *p, int mode) {
+    if(!p || p->started || mode < 0 || mode > 1) return -1;
+    if(mode == 1 && (p->o.perread || p->o.mbias)) return -1;       /* those commands prepare on the host */
+    p->dev_prep = mode;
+    return 0;
+}
+void mdk_plan_prep_cfg(const mdk_plan *p, md_prep_cfg *cfg) {
+    const opts_t *o = &p->o;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->min_mapq = o->min_mapq; cfg->ignore_flags = o->ignore_flags; cfg->require_flags = o->require_flags; cfg->keep_dupes = o->keep_dupes;
+    cfg->ignore_nh = o->ignore_nh; cfg->keep_singleton = o->keep_singleton; cfg->keep_discordant = o->keep_discordant;
+    cfg->min_phred = o->min_phred; cfg->min_conv_eff = (float)o->min_conv_eff; cfg->map_on = p->map_on; cfg->min_mappable = o->min_mappable;
+    cfg->no_pairing = o->mbias;
+}
 int mdk_plan_n_targets(const mdk_plan *p) { return p->bam->n_targets; }
 const char *mdk_plan_target_name(const mdk_plan *p, int32_t tid) { return (tid >= 0 && tid < p->bam->n_targets) ? p->bam->target_name[tid] : NULL; }
 int64_t mdk_plan_target_len(const mdk_plan *p, int32_t tid) { return (tid >= 0 && tid < p->bam->n_targets) ? (int64_t)p->bam->target_len[tid] : -1; }
@@ -504,6 +518,12 @@ int mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid) {
     i = md_dev_set_reference(dev, tid, p->fa.seq[fi], p->fa.len[fi]);
     if(i) return i;
     if(p->bed_on && !p->o.perread && (i = md_dev_set_regions(dev, tid, p->bed_run[tid], p->bed_nrun[tid])) != 0) return i;     /* perRead uses -l only to pass over chunks (perRead.c:150-166) */
+    if(p->dev_prep && p->map_on) {       /* the admission windows are tested on the device: the contig's track goes with its bases */
+        int c = p->map_of_tid[tid];
+        if(c >= 0) i = md_dev_set_mappability(dev, tid, (const uint32_t *)p->map_bits[c], (int64_t)p->map_len[c]);
+        else i = md_dev_set_mappability(dev, tid, NULL, 0);
+        if(i) return i;
+    }
     if(p->n_ref == p->cap_ref) { p->cap_ref = p->cap_ref ? p->cap_ref * 2 : 32; p->ref_dev = xrealloc(p->ref_dev, sizeof(md_dev *) * p->cap_ref); p->ref_tid = xrealloc(p->ref_tid, sizeof(int32_t) * p->cap_ref); }
     p->ref_dev[p->n_ref] = dev; p->ref_tid[p->n_ref] = tid; p->n_ref++;
     return 0;

@@ -89,6 +89,7 @@ struct mdk_plan {
     mdk_bam *bam; mdk_bai *bai; int need_seek; mdk_fasta fa; int *fa_of_tid;
     /* schedule cursor (main.c:10-13 globals) */
     uint32_t g_tid, g_pos, g_end, bin;
+    int dev_prep;                      /* chunks are handed out as raw records for the device to prepare (extract; see mdk_plan_set_prep) */
     int shard_rank, shard_world;       /* interval sharding: this process packs chunk k iff k % world == rank */
     uint64_t n_variant_positions;
     /* stream state */

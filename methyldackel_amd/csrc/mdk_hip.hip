@@ -56,6 +56,8 @@ struct KParams {
     int keepmask, minPhred;
     int bounds[16], abounds[16];
     int *err;
+    int packed;                   // 0: payload = blob + 4*off4, qualities after the sequence padded to 4 bytes (host-built batches);
+                                  // 1: payload = blob + off4 (byte offset into the uploaded BAM records), qualities directly after the sequence
     int mbias; uint32_t *hist; int hist_lq;     // mbias: window-relative contexts at the chunk edges; histogram rows [q][16]; rows kept in LDS
     unsigned long long *dbg;      // optional phase timestamps: 8 words per workgroup (MDK_PHASES=1)
 };
@@ -78,7 +80,8 @@ struct RD {       // addressing of one read's payload + its trimming window
 };
 __device__ __forceinline__ RD make_rd(const KParams &P, uint32_t off4, uint32_t lq, int strand, int read2) {
     RD d; d.lq = (int)lq;
-    d.seq = P.blob + 4ull * off4; d.qual = d.seq + ((((d.lq + 1) >> 1) + 3) & ~3);
+    if(P.packed) { d.seq = P.blob + off4; d.qual = d.seq + ((d.lq + 1) >> 1); }
+    else { d.seq = P.blob + 4ull * off4; d.qual = d.seq + ((((d.lq + 1) >> 1) + 3) & ~3); }
     trim_window(P, strand, read2, d.lq, d.lo, d.hi);
     return d;
 }
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
     // everything this thread needs from HBM before it can start is requested up front, in one round:
     // the context codes of the PER consecutive positions it owns, and its first segment record
     const TileEnt te = P.tiles[t];
-    const int first = te.first, last = te.last;
+    const int first = te.last > te.first ? te.first : 0, last = te.last > te.first ? te.last : 0;      // a tile no segment touches: (INT_MAX, 0) from the device preparation
     int code[PERMAX];
     load_codes(P, T0, tlen, PER, tid, code);
     md_seg g0; g0.rpos = 0x7fffffff; g0.len = 0;
@@ -415,7 +418,8 @@ __global__ __launch_bounds__(WG, 8) void k_mbias(const KParams P) {
     const int64_t T1 = (T0 + TILE < P.end) ? T0 + TILE : P.end;
     const int tlen = (int)(T1 - T0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TileEnt te = P.tiles[t];
+    TileEnt te = P.tiles[t];
+    if(te.last <= te.first) { te.first = 0; te.last = 0; }
     int code[PERMAX];
     load_codes(P, T0, tlen, PER, tid, code);
     const int nh = 16 * P.hist_lq;
@@ -573,6 +577,8 @@ extern "C" void md_dev_close(md_dev *h) {
     (void)hipDeviceSynchronize();
     for(auto &s : h->slots) {
         s.d_seg_in.release(); s.d_blob.release(); s.d_tiles.release(); s.h_tiles.release();
+        s.d_raw.release(); s.d_recoff.release(); s.d_prec.release(); s.d_hash.release(); s.d_blk.release(); s.d_prd.release(); s.d_mate.release(); s.d_second.release();
+        s.d_segcnt.release(); s.d_hkey.release(); s.d_hhead.release(); s.d_hnext.release(); s.d_pcnt.release(); s.h_pcnt.release();
         s.d_pr.release(); s.d_cig.release(); s.d_prc.release(); s.h_prc.release();
         s.d_site.release(); s.d_var.release(); s.d_seg.release(); s.d_total.release(); s.d_err.release();
         s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release(); s.h_total.release(); s.h_err.release();
@@ -580,6 +586,8 @@ extern "C" void md_dev_close(md_dev *h) {
         if(s.stream) (void)hipStreamDestroy(s.stream);
     }
     if(h->d_hist) (void)hipFree(h->d_hist);
+    for(uint32_t *p : h->mapbits) if(p) (void)hipFree(p);
+    for(md_region *p : h->d_runs) if(p) (void)hipFree(p);
     for(char *p : h->ref) if(p) (void)hipFree(p);
     for(uint8_t *p : h->refcode) if(p) (void)hipFree(p);
     delete h;
@@ -617,16 +625,18 @@ extern "C" int md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs,
             return fail(MDK_ERR_ARG, "md_dev_set_regions: runs must be sorted, disjoint, non-empty, strand in 0..2", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
     const int64_t len = h->reflen[tid];
-    if(len <= 0) return 0;
     md_region *d = nullptr;
     hipError_t e = hipMalloc((void **)&d, sizeof(md_region) * (size_t)(n ? n : 1));
     if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(regions)", e);
     if(n) { e = hipMemcpy(d, runs, sizeof(md_region) * (size_t)n, hipMemcpyHostToDevice); if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_HIP, "hipMemcpy(regions)", e); } }
     int64_t blocks = (len + WG - 1) / WG; if(blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_mask_regions, dim3((unsigned)blocks), dim3(WG), 0, 0, h->refcode[tid], len, d, n);
+    if(len > 0) hipLaunchKernelGGL(k_mask_regions, dim3((unsigned)blocks), dim3(WG), 0, 0, h->refcode[tid], len, d, n);
     e = hipGetLastError(); if(e == hipSuccess) e = hipDeviceSynchronize();
-    (void)hipFree(d);
-    if(e != hipSuccess) return fail(MDK_ERR_HIP, "k_mask_regions", e);
+    if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_HIP, "k_mask_regions", e); }
+    // the runs stay resident: the device chunk preparation tests every read's span against them (common.c:432-439)
+    if((size_t)tid >= h->d_runs.size()) { h->d_runs.resize(tid + 1, nullptr); h->n_runs.resize(tid + 1, 0); h->has_runs.resize(tid + 1, 0); }
+    if(h->d_runs[tid]) (void)hipFree(h->d_runs[tid]);
+    h->d_runs[tid] = d; h->n_runs[tid] = n; h->has_runs[tid] = 1;
     return 0;
 }
 
@@ -653,7 +663,7 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));          // the slot's previous contents are being replaced
     const int64_t span = b->end - b->beg;
-    s->n_segs = b->n_segs; s->n_reads = b->n_reads; s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->uploaded = false; s->launched = false;
+    s->n_segs = b->n_segs; s->n_reads = b->n_reads; s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->uploaded = false; s->launched = false; s->raw_layout = false;
     const int TILE = h->tile;
     const int ntiles = (int)((span + TILE - 1) / TILE);
     if(s->h_tiles.need((size_t)(ntiles > 0 ? ntiles : 1))) return MDK_ERR_NOMEM;
@@ -687,7 +697,7 @@ extern "C" int md_dev_bind_output(md_dev *h, int slot, void *d_site, void *d_var
 
 static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
     memset(&P, 0, sizeof(P));
-    P.seg = s->d_seg_in.p; P.blob = s->d_blob.p;
+    P.seg = s->d_seg_in.p; P.blob = s->raw_layout ? s->d_raw.p : s->d_blob.p; P.packed = s->raw_layout ? 1 : 0;
     P.ctxcode = h->refcode[s->tid]; P.reflen = h->reflen[s->tid];
     P.beg = s->beg; P.end = s->end; P.tile = s->tile; P.ntiles = s->ntiles; P.nper = (s->ntiles + 7) / 8;
     P.tiles = s->d_tiles.p;
@@ -847,8 +857,17 @@ int64_t finish_count(md_dev *h, Slot *s) {
     if(!s->launched) { fail(MDK_ERR_ARG, "slot not launched", hipSuccess); return MDK_ERR_ARG; }
     if(hipMemcpyAsync(s->h_total.p, s->d_total.p + (s->ring % RING), sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H total", hipGetLastError());
     if(hipMemcpyAsync(s->h_err.p, s->d_err.p, sizeof(int), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H err", hipGetLastError());
+    if(s->raw_layout && hipMemcpyAsync(s->h_pcnt.p, s->d_pcnt.p, sizeof(PrepCounters), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H preparation counters", hipGetLastError());
     hipError_t e = hipStreamSynchronize(s->stream);
     if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
+    if(s->raw_layout) {
+        int rc = prep_outcome(h, s);
+        if(rc == MDK_ERR_PREP_REDO) {            // the segment array was too small: preparation is queued again, the pileup follows it
+            rc = launch_kernels(h, s, false); if(rc) return rc;
+            return finish_count(h, s);
+        }
+        if(rc) return rc;
+    }
     if(s->h_err.p[0]) { snprintf(g_err, sizeof(g_err), "Can't determine the strand of a read!"); (void)hipMemset(s->d_err.p, 0, sizeof(int)); return MDK_ERR_STRAND0; }
     int64_t n = (int64_t)s->h_total.p[0];
     int64_t cap = s->b_site ? s->b_cap_sites : (int64_t)s->d_site.cap;

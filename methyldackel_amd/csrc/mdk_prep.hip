@@ -98,17 +98,20 @@ __device__ __forceinline__ int strand_of(uint32_t flag, const uint8_t *xg) {    
 // check_mappability (common.c:277-335) on a 1-bit-per-base track: does [start, start+l) hold at least `need` mappable bases,
 // counted in a signed char as the reference does (a count that passes 127 wraps and never passes)
 __device__ bool map_window_passes(const PrepParams &P, int64_t start, int l) {
-    if(l <= 0 || start < 0 || start + l > P.maplen || !P.mapbits) return false;
+    const int need = P.cfg.min_mappable;
+    if(l <= 0) return false;
+    if(need <= 0) return true;
+    if(need > 127) return false;                       // the running count is a signed char: it never gets there
+    if(start < 0 || !P.mapbits) return false;          // a negative start is a huge uint32 in the reference: past the array
+    const int64_t nbits = ((P.maplen + 7) / 8) * 8;    // the track is stored in whole bytes; bits past it read as 0
+    int64_t end = start + l; if(end > nbits) end = nbits;
     int n = 0;
-    for(int64_t p = start; p < start + l;) {
-        const int64_t w = p >> 5; const int b = (int)(p & 31); int take = 32 - b; if(take > start + l - p) take = (int)(start + l - p);
+    for(int64_t p = start; p < end;) {
+        const int64_t w = p >> 5; const int b = (int)(p & 31); int take = 32 - b; if(take > end - p) take = (int)(end - p);
         uint32_t word = P.mapbits[w] >> b; if(take < 32) word &= (1u << take) - 1u;
         n += __popc(word); p += take;
     }
-    // the reference increments a `char` per mappable base and tests it after every increment: it passes the first time the
-    // count reaches `need` -- which it can only do while counting up through 1..127
-    const int need = P.cfg.min_mappable;
-    return need <= 127 && need >= 1 ? n >= need : (need < 1 ? n >= 1 : false);
+    return n >= need;
 }
 
 __device__ bool bed_touches(const PrepParams &P, int64_t beg, int64_t end) {     // any run overlapping [beg, end)

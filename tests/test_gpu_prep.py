@@ -1,0 +1,155 @@
+"""GPU: chunk preparation on the device (csrc/mdk_prep.hip) against the host's (csrc/host/mdk_pipeline.c), chunk by chunk.
+
+Both turn the same candidate records into md_seg arrays; the device emits them in read order, the host in order of
+reference start, and payload offsets differ by construction (bytes into the uploaded records vs 4-byte units into a packed
+blob), so the comparison is on everything else as a multiset.  Per-position results from the device-prepared slot must equal
+the host-prepared one exactly.  The command line tests of the other files run the device preparation too (it is the
+default of `extract`); here MDK_HOST_PREP=1 is exercised as well."""
+import ctypes as C
+import os
+from collections import Counter
+
+import pytest
+
+import methyldackel_amd as mdk
+from bamwriter import record, write_bam, write_fasta
+from conftest import GOLDEN, synth
+from test_gpu_parity import compare_cli
+
+pytestmark = pytest.mark.gpu
+
+
+def seg_key(g):
+    k = (g.rpos, g.len, g.q0, g.l_qseq, g.sf)
+    return k + ((g.msf, g.m_q0, g.m_l_qseq) if g.sf & 32 else ())
+
+
+def sites_list(s):
+    out = []
+    for i in range(s.n_sites):
+        r = s.site[i]
+        out.append((r.pos, r.nmeth, r.nunmeth, r.meta) + ((s.var[i].noff, s.var[i].nvar) if s.var else ()))
+    return out
+
+
+def both_ways(args):
+    """every chunk through host preparation and through device preparation on the same device handle"""
+    ph, pd = mdk.Plan(args), mdk.Plan(args)
+    pd.set_prep(1)
+    cfg = ph.dev_cfg()
+    dev = mdk.Device(cfg)
+    dev.set_prep(pd.prep_cfg())
+    n_chunks = n_reads = n_segs = 0
+    while True:
+        ch, cd = ph.next_chunk(), pd.next_chunk()
+        assert (ch is None) == (cd is None)
+        if ch is None:
+            break
+        assert (ch.index, ch.tid, ch.beg, ch.end, ch.skipped) == (cd.index, cd.tid, cd.beg, cd.end, cd.skipped)
+        if ch.skipped:
+            continue
+        ph.ensure_reference(dev, ch.tid); pd.ensure_reference(dev, cd.tid)
+        dev.submit(0, ch.batch)
+        want = sites_list(dev.download(0))
+        dev.submit_raw(1, cd.raw)
+        got = sites_list(dev.download(1))
+        segs, n, nr = dev.debug_segments(1)
+        assert nr == ch.batch.n_reads and n == ch.batch.n_segs, (ch.index, nr, ch.batch.n_reads, n, ch.batch.n_segs)
+        assert Counter(seg_key(segs[i]) for i in range(n)) == Counter(seg_key(ch.batch.seg[i]) for i in range(ch.batch.n_segs)), ch.index
+        assert got == want, ch.index
+        n_chunks += 1; n_reads += nr; n_segs += n
+    dev.close(); ph.close(); pd.close()
+    return n_chunks, n_reads, n_segs
+
+
+CMDS = [
+    ("pe", []),
+    ("pe", ["--CHG", "--CHH", "--chunkSize", "2500"]),
+    ("pe", ["-q", "0", "-F", "0", "--keepDupes", "--keepSingleton", "--keepDiscordant", "--ignoreNH", "--chunkSize", "9000"]),
+    ("pe", ["-R", "2", "--minOppositeDepth", "2", "--maxVariantFrac", "0.3", "--chunkSize", "5000"]),
+    ("pe", ["--minConversionEfficiency", "0.7", "--CHH", "--chunkSize", "6000"]),
+    ("pe", ["-B", "BBM", "--minMappableBases", "30", "--chunkSize", "7000"]),
+    ("pe", ["-M", "BW", "--mappabilityThreshold", "0.5", "--chunkSize", "8000"]),
+    ("pe", ["--OT", "3,140,5,130", "--nOB", "2,3,4,5", "--chunkSize", "10000"]),
+    ("bis", ["--CHG", "--chunkSize", "4000"]),
+    ("se", ["--CHH", "--chunkSize", "3000"]),
+]
+
+
+@pytest.mark.parametrize("which,extra", CMDS, ids=[f"{w}:{' '.join(e)}" for w, e in CMDS])
+def test_device_prep_equals_host_prep(tmp_path, small_synth, which, extra):
+    extra = [str(small_synth / "pe.bbm") if e == "BBM" else str(small_synth / "pe.bw") if e == "BW" else e for e in extra]
+    n_chunks, n_reads, n_segs = both_ways([str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")] + extra + ["-o", str(tmp_path / "x")])
+    assert n_chunks >= 1 and n_reads > 1000 and n_segs >= n_reads
+
+
+def test_device_prep_on_reference_fixtures(tmp_path):
+    for fa, bam, extra in (("cg100.fa", "cg_aln.bam", ["-q", "2"]), ("cg100.fa", "cg_aln.bam", ["--ignoreFlags", "0xD00", "-q", "2"]), ("cg100.fa", "cg_with_variants.bam", ["-p", "1", "-q", "0", "--minOppositeDepth", "3"]),
+                           ("chgchh.fa", "chgchh_aln.bam", ["-q", "5", "--minConversionEfficiency", "0.9"]), ("cg100.fa", "NH.bam", ["-q", "1"]), ("cg100.fa", "cg_aln.bam", ["-q", "2", "--chunkSize", "7"])):
+        both_ways([str(GOLDEN / fa), str(GOLDEN / bam)] + extra + ["-o", str(tmp_path / "x")])
+
+
+def test_device_prep_bed(tmp_path, small_synth):
+    from bedgen import random_bed
+    bed = tmp_path / "r.bed"
+    names = [l[1:].split()[0] for l in open(small_synth / "pe.fa") if l.startswith(">")]      # contig names come from the generator's FASTA
+    random_bed(bed, list(zip(names, [40000, 20000])), 60, seed=3)
+    both_ways([str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "-l", str(bed), "--keepStrand", "--chunkSize", "5000", "-o", str(tmp_path / "x")])
+
+
+def many_records_one_name(tmp_path, n):
+    ref = ("ACGTCGCGTTCGAACGCGTA" * 40)[:800]
+    recs = []
+    for k in range(n):
+        pos = 10 + 7 * k
+        fl = 99 if k % 2 == 0 else 147
+        recs.append(record(0, pos, fl, "60M", ref[pos:pos + 60].replace("C", "T") if k % 3 == 0 else ref[pos:pos + 60], 35, qname="same", mpos=pos + 7))
+    write_bam(tmp_path / "m.bam", [("c1", len(ref))], recs)
+    write_fasta(tmp_path / "m.fa", [("c1", ref)])
+    return str(tmp_path / "m.fa"), str(tmp_path / "m.bam")
+
+
+@pytest.mark.parametrize("n", [3, 16, 17, 40])
+def test_names_with_many_records(tmp_path, n):
+    """3 and 16 records of one name stay on the device; 17 and 40 make it hand the chunk back (MDK_ERR_PREP_HOST) and the
+    command prepares it on the host: byte-identical to the oracle either way"""
+    fa, bam = many_records_one_name(tmp_path, n)
+    compare_cli(tmp_path, [fa, bam, "-F", "0", "-q", "0", "--keepDupes"])
+    # and through the API: the device's answer for the big groups is the documented error code
+    plan = mdk.Plan([fa, bam, "-F", "0", "-q", "0", "--keepDupes", "-o", str(tmp_path / "x")]); plan.set_prep(1)
+    dev = mdk.Device(plan.dev_cfg()); dev.set_prep(plan.prep_cfg())
+    c = plan.next_chunk(); plan.ensure_reference(dev, c.tid)
+    dev.submit_raw(0, c.raw)
+    s = mdk.md_sites()
+    rc = dev.L.md_dev_download(dev.h, 0, C.byref(s))
+    assert rc == (0 if n <= 16 else -7)
+    if rc:
+        plan.host_prepare(c)
+        dev.submit(0, c.batch)
+        assert dev.download(0).n_sites > 0
+    dev.close(); plan.close()
+
+
+@pytest.mark.parametrize("which,extra", [("pe", ["--CHG", "--chunkSize", "2500", "--mergeContext"]), ("bis", ["--CHH"]), ("pe", ["--minConversionEfficiency", "0.7"])])
+def test_host_prep_mode_still_byte_exact(tmp_path, small_synth, which, extra):
+    compare_cli(tmp_path, [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")] + extra, env={"MDK_HOST_PREP": "1"})
+
+
+def test_segment_array_growth(tmp_path):
+    """reads full of deletions: far more segments than the 2-per-record the first launch reserves, so the preparation runs
+    twice (MDK_ERR_PREP_REDO inside the library)"""
+    import random
+    rng = random.Random(5)
+    ref = "".join(rng.choice("ACGT") for _ in range(3000))
+    recs = []
+    for k in range(300):
+        pos = rng.randrange(0, 2000)
+        cig = "".join(f"8M1D" for _ in range(9)) + "8M"
+        seq = "".join(ref[pos + 9 * j:pos + 9 * j + 8] for j in range(10))
+        recs.append((pos, record(0, pos, 0 if k % 2 else 16, cig, seq, 30, qname=f"d{k}")))
+    recs.sort(key=lambda x: x[0])
+    write_bam(tmp_path / "d.bam", [("c1", len(ref))], [r for _, r in recs])
+    write_fasta(tmp_path / "d.fa", [("c1", ref)])
+    compare_cli(tmp_path, [str(tmp_path / "d.fa"), str(tmp_path / "d.bam"), "--CHH", "--CHG"])
+    n_chunks, n_reads, n_segs = both_ways([str(tmp_path / "d.fa"), str(tmp_path / "d.bam"), "--CHH", "-o", str(tmp_path / "x")])
+    assert n_segs == 10 * n_reads
