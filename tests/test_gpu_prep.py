@@ -80,7 +80,7 @@ CMDS = [
 def test_device_prep_equals_host_prep(tmp_path, small_synth, which, extra):
     extra = [str(small_synth / "pe.bbm") if e == "BBM" else str(small_synth / "pe.bw") if e == "BW" else e for e in extra]
     n_chunks, n_reads, n_segs = both_ways([str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")] + extra + ["-o", str(tmp_path / "x")])
-    assert n_chunks >= 1 and n_reads > 1000 and n_segs >= n_reads
+    assert n_chunks >= 1 and n_reads > 500 and n_segs >= n_reads
 
 
 def test_device_prep_on_reference_fixtures(tmp_path):
