@@ -30,10 +30,10 @@ static Rccl *rccl() {
             if(R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.Send && R.Recv && R.GroupStart && R.GroupEnd && R.GetErrorString) state = 1;
         }
     }
-    if(state != 1) { snprintf(g_err, sizeof(g_err), "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); return nullptr; }
+    if(state != 1) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); return nullptr; }
     return &R;
 }
-static int nfail(Rccl *R, const char *what, ncclResult_t r) { snprintf(g_err, sizeof(g_err), "%s: %s", what, R->GetErrorString(r)); return MDK_ERR_HIP; }
+static int nfail(Rccl *R, const char *what, ncclResult_t r) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "%s: %s", what, R->GetErrorString(r)); return MDK_ERR_HIP; }
 #define NCHK(call) do { ncclResult_t r_ = (call); if(r_ != ncclSuccess) return nfail(R, #call, r_); } while(0)
 
 // A communicator over `world` ranks, root 0.  This process drives `n_local` of them: one (its own GPU) when there is one
@@ -276,13 +276,13 @@ extern "C" int md_bench_verify(md_bench *b) {
     int rc = md_dev_bind_output(h, slot, nullptr, nullptr, nullptr, 0, 0); if(rc) return rc;
     rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
     md_sites ref; rc = md_dev_download(h, slot, &ref); if(rc) return rc;
-    if(got != ref.n_sites || (got && memcmp(ord.data(), ref.site, (size_t)got * sizeof(md_site)))) { snprintf(g_err, sizeof(g_err), "bench: bound-output sites differ from md_dev_download (%lld vs %lld)", (long long)got, (long long)ref.n_sites); return MDK_ERR_ARG; }
+    if(got != ref.n_sites || (got && memcmp(ord.data(), ref.site, (size_t)got * sizeof(md_site)))) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "bench: bound-output sites differ from md_dev_download (%lld vs %lld)", (long long)got, (long long)ref.n_sites); return MDK_ERR_ARG; }
     if(b->comm && b->rank == 0) {
         for(int r = 1; r < b->world; r++) {
             HIPCHK(hipMemcpy(reg.data(), b->recv[x][r] + (size_t)e * b->E, b->E, hipMemcpyDeviceToHost));
             const md_tile_seg *ts = (const md_tile_seg *)(reg.data() + b->off_seg); uint64_t tot = 0;
             for(int64_t t = 0; t < b->tcap; t++) tot += ts[t].cnt;
-            if(!tot) { snprintf(g_err, sizeof(g_err), "bench: nothing was received from rank %d", r); return MDK_ERR_ARG; }
+            if(!tot) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "bench: nothing was received from rank %d", r); return MDK_ERR_ARG; }
         }
     }
     return 0;

@@ -37,7 +37,8 @@
 #define MAX_TILE (WG * PERMAX)
 #define LDS_LIMIT 163840          // 160 KiB per CU / per workgroup on gfx950
 
-thread_local char g_err[512] = "";
+static thread_local char g_err[MDK_ERR_BYTES] = "";
+char *mdk_err_buf() { return g_err; }
 int fail(int code, const char *what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e));
     return code;

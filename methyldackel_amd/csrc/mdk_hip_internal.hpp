@@ -14,7 +14,8 @@
 #define RING 64                    // site counters: launch i uses counter i%RING and clears the next one
 
 #define MDK_HIDDEN __attribute__((visibility("hidden")))
-extern MDK_HIDDEN thread_local char g_err[512];
+MDK_HIDDEN char *mdk_err_buf();            // the calling thread's message buffer (512 bytes), what md_dev_last_error returns
+#define MDK_ERR_BYTES 512
 MDK_HIDDEN int fail(int code, const char *what, hipError_t e);
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return fail(MDK_ERR_HIP, #call, e_); } while(0)
 

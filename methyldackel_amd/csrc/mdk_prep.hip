@@ -479,7 +479,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     if(!s || !b || b->n_records < 0 || b->n_ranges < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_upload_raw", hipSuccess);
     if(!h->prep_set) return fail(MDK_ERR_ARG, "md_dev_upload_raw: md_dev_set_prep was not called", hipSuccess);
     if(b->n_records && (!b->range || !b->rec_off)) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null array", hipSuccess);
-    if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(g_err, sizeof(g_err), "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
+    if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     uint64_t total = 0;
@@ -521,9 +521,9 @@ extern "C" int md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b) {
 // has been enlarged -- the caller (finish_count) runs preparation + pileup again on the resident records.
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s) {
     const PrepCounters &c = *s->h_pcnt.p;
-    if(c.malformed) { snprintf(g_err, sizeof(g_err), "malformed BAM record in the chunk"); return MDK_ERR_ARG; }
-    if(c.strand0) { snprintf(g_err, sizeof(g_err), "Can't determine the strand of a read!"); return MDK_ERR_STRAND0; }
-    if(c.fallback) { snprintf(g_err, sizeof(g_err), "a read name with more than %d records or %d live reads: this chunk needs the host preparation", MAXG, MAXLIVE); return MDK_ERR_PREP_HOST; }
+    if(c.malformed) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "malformed BAM record in the chunk"); return MDK_ERR_ARG; }
+    if(c.strand0) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "Can't determine the strand of a read!"); return MDK_ERR_STRAND0; }
+    if(c.fallback) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "a read name with more than %d records or %d live reads: this chunk needs the host preparation", MAXG, MAXLIVE); return MDK_ERR_PREP_HOST; }
     s->n_reads = (int)c.n_adm; s->n_segs = (int)c.n_segs; s->read_bytes = c.algo_bytes;
     if((size_t)c.n_segs > s->d_seg_in.cap) {
         HIPCHK(hipStreamSynchronize(s->stream));

@@ -97,11 +97,11 @@ def test_device_prep_bed(tmp_path, small_synth):
     both_ways([str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "-l", str(bed), "--keepStrand", "--chunkSize", "5000", "-o", str(tmp_path / "x")])
 
 
-def many_records_one_name(tmp_path, n):
+def many_records_one_name(tmp_path, n, step=10):
     ref = ("ACGTCGCGTTCGAACGCGTA" * 40)[:800]
     recs = []
     for k in range(n):
-        pos = 10 + 7 * k
+        pos = 10 + step * k
         fl = 99 if k % 2 == 0 else 147
         recs.append(record(0, pos, fl, "60M", ref[pos:pos + 60].replace("C", "T") if k % 3 == 0 else ref[pos:pos + 60], 35, qname="same", mpos=pos + 7))
     write_bam(tmp_path / "m.bam", [("c1", len(ref))], recs)
@@ -109,11 +109,12 @@ def many_records_one_name(tmp_path, n):
     return str(tmp_path / "m.fa"), str(tmp_path / "m.bam")
 
 
-@pytest.mark.parametrize("n", [3, 16, 17, 40])
-def test_names_with_many_records(tmp_path, n):
-    """3 and 16 records of one name stay on the device; 17 and 40 make it hand the chunk back (MDK_ERR_PREP_HOST) and the
-    command prepares it on the host: byte-identical to the oracle either way"""
-    fa, bam = many_records_one_name(tmp_path, n)
+@pytest.mark.parametrize("n,step,on_device", [(3, 10, True), (16, 10, True), (17, 10, False), (40, 10, False), (14, 5, False), (14, 8, True)])
+def test_names_with_many_records(tmp_path, n, step, on_device):
+    """up to 16 records of one name, at most 8 of them in the pileup buffer at once (60-base reads every `step` bases), stay on
+    the device; beyond either limit it hands the chunk back (MDK_ERR_PREP_HOST) and the command prepares it on the host:
+    byte-identical to the oracle either way"""
+    fa, bam = many_records_one_name(tmp_path, n, step)
     compare_cli(tmp_path, [fa, bam, "-F", "0", "-q", "0", "--keepDupes"])
     # and through the API: the device's answer for the big groups is the documented error code
     plan = mdk.Plan([fa, bam, "-F", "0", "-q", "0", "--keepDupes", "-o", str(tmp_path / "x")]); plan.set_prep(1)
@@ -122,7 +123,7 @@ def test_names_with_many_records(tmp_path, n):
     dev.submit_raw(0, c.raw)
     s = mdk.md_sites()
     rc = dev.L.md_dev_download(dev.h, 0, C.byref(s))
-    assert rc == (0 if n <= 16 else -7)
+    assert rc == (0 if on_device else -7)
     if rc:
         plan.host_prepare(c)
         dev.submit(0, c.batch)
