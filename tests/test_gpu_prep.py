@@ -109,7 +109,7 @@ def many_records_one_name(tmp_path, n, step=10):
     return str(tmp_path / "m.fa"), str(tmp_path / "m.bam")
 
 
-@pytest.mark.parametrize("n,step,on_device", [(3, 10, True), (16, 10, True), (17, 10, False), (40, 10, False), (14, 5, False), (14, 8, True)])
+@pytest.mark.parametrize("n,step,on_device", [(3, 10, True), (16, 10, True), (17, 10, False), (40, 10, False), (14, 5, False), (14, 9, True)])
 def test_names_with_many_records(tmp_path, n, step, on_device):
     """up to 16 records of one name, at most 8 of them in the pileup buffer at once (60-base reads every `step` bases), stay on
     the device; beyond either limit it hands the chunk back (MDK_ERR_PREP_HOST) and the command prepares it on the host:
