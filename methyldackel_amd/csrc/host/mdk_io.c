@@ -13,14 +13,15 @@ static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-typedef struct { const uint8_t *in; uint32_t in_len; uint8_t *out; uint32_t out_len; int th; size_t sum0; uint32_t n_sum; int ok; } blk_t;
+typedef struct { const uint8_t *in; uint32_t in_len; uint8_t *out; uint32_t out_len; int th; size_t sum0; uint32_t n_sum; int ok;
+                 int32_t tid0, pos0, tidN, posN, min_endp, max_endp; int sorted; } blk_t;
 typedef struct { mdk_rsum *v; size_t n, cap; } sumbuf;
 typedef struct { blk_t *blk; int n; int next; int failed; int n_th; int next_th; const uint8_t *base; sumbuf sb[64]; pthread_mutex_t mu; } inflate_job;
 
 /* walk one inflated member from its first byte (see mdk_io.h); the notes go to the calling thread's buffer */
 static void note_records(blk_t *b, sumbuf *sb, const uint8_t *base) {
     const uint8_t *d = b->out; uint32_t L = b->out_len, o = 0;
-    b->sum0 = sb->n; b->n_sum = 0; b->ok = 0;
+    b->sum0 = sb->n; b->n_sum = 0; b->ok = 0; b->sorted = 1; b->min_endp = 0x7fffffff; b->max_endp = (int32_t)0x80000000; b->tid0 = b->tidN = -1; b->pos0 = b->posN = -1;
     while(o + 4 <= L) {
         uint32_t bs = le32(d + o), lq, nc, k; const uint8_t *r = d + o + 4, *c; int32_t rl = 0; mdk_rsum *q;
         if(bs < 32 || (uint64_t)o + 4 + bs > L) return;
@@ -31,6 +32,12 @@ static void note_records(blk_t *b, sumbuf *sb, const uint8_t *base) {
         if(sb->n == sb->cap) { sb->cap = sb->cap ? sb->cap * 2 : 4096; sb->v = realloc(sb->v, sizeof(mdk_rsum) * sb->cap); if(!sb->v) { sb->cap = sb->n = 0; return; } }
         q = &sb->v[sb->n++];
         q->off = (uint32_t)(d + o - base); q->len = bs; q->tid = (int32_t)le32(r); q->pos = (int32_t)le32(r + 4); q->endp = q->pos + (rl > 0 ? rl : 1);
+        if(b->n_sum == 0) { b->tid0 = q->tid; b->pos0 = q->pos; }
+        else if(q->tid < 0 || q->tid < b->tidN || (q->tid == b->tidN && q->pos < b->posN)) b->sorted = 0;
+        if(q->tid < 0) b->sorted = 0;                       /* unplaced records: leave them to the record-by-record path */
+        b->tidN = q->tid; b->posN = q->pos;
+        if(q->endp < b->min_endp) b->min_endp = q->endp;
+        if(q->endp > b->max_endp) b->max_endp = q->endp;
         b->n_sum++;
         o += 4 + bs;
     }
@@ -161,6 +168,7 @@ static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status)
                 for(i = 0; i < nb; i++) {
                     mdk_member *m = &s->mem[i];
                     m->off = (uint32_t)(blk[i].out - s->buf); m->n_sum = blk[i].n_sum; m->sum0 = (uint32_t)o; m->ok = blk[i].ok && (blk[i].n_sum == 0 || job.sb[blk[i].th].v != NULL);
+                    m->tid0 = blk[i].tid0; m->pos0 = blk[i].pos0; m->tidN = blk[i].tidN; m->posN = blk[i].posN; m->min_endp = blk[i].min_endp; m->max_endp = blk[i].max_endp; m->sorted = blk[i].sorted;
                     if(m->ok && m->n_sum) memcpy(s->sum + o, job.sb[blk[i].th].v + blk[i].sum0, sizeof(mdk_rsum) * m->n_sum);
                     if(m->ok) o += m->n_sum; else m->n_sum = 0;
                 }
@@ -361,6 +369,18 @@ int mdk_bam_peek_sum(mdk_bam *b, mdk_rsum *o, const uint8_t **raw) {
     }
     *raw = r.raw;
     return 1;
+}
+int mdk_bam_member_run(mdk_bam *b, const mdk_rsum **v, size_t *n, const mdk_member **m) {
+    if(b->sum_i >= b->sum_end || !b->cur || b->mem_i < 1) return 0;
+    *v = b->cur->sum + b->sum_i; *n = b->sum_end - b->sum_i; *m = &b->cur->mem[b->mem_i - 1];
+    return 1;
+}
+void mdk_bam_advance_run(mdk_bam *b, size_t k) {
+    const mdk_rsum *last;
+    if(!k) return;
+    last = &b->cur->sum[b->sum_i + k - 1];
+    b->sum_i += k; b->n_fast += k; b->n_records += k;
+    b->off = (size_t)last->off + 4 + (size_t)last->len;
 }
 void mdk_bam_advance_sum(mdk_bam *b, const mdk_rsum *r) {
     if(b->sum_i < b->sum_end) { b->sum_i++; b->n_fast++; } else b->n_slow++;

@@ -33,7 +33,8 @@ static inline char *xstrdup(const char *s) { char *q = strdup(s); return q ? q :
  * that other cores have just written.  Any other file (records split across members) simply never matches and is
  * scanned the slow way. */
 typedef struct { uint32_t off, len; int32_t tid, pos, endp; } mdk_rsum;          /* off: of the block_size word in the slab; len: block_size */
-typedef struct { uint32_t off, n_sum; uint32_t sum0; int ok; } mdk_member;     /* off: first byte in the slab; records sum[sum0 .. sum0+n_sum) */
+typedef struct { uint32_t off, n_sum; uint32_t sum0; int ok;          /* off: first byte in the slab; records sum[sum0 .. sum0+n_sum) */
+                 int32_t tid0, pos0, tidN, posN, min_endp, max_endp; int sorted; } mdk_member;    /* digest of an ok member: first/last record, extent of the ends, coordinate order inside */
 typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs;
                           mdk_rsum *sum; size_t n_sum, cap_sum; mdk_member *mem; int n_mem, cap_mem; } mdk_slab;
 
@@ -83,6 +84,10 @@ void mdk_bam_advance(mdk_bam *b, const mdk_rec *r);
 /* the same walk for callers that only need a record's place and extent: *raw = first byte after block_size */
 int mdk_bam_peek_sum(mdk_bam *b, mdk_rsum *r, const uint8_t **raw);
 void mdk_bam_advance_sum(mdk_bam *b, const mdk_rsum *r);
+/* when the scanner stands inside an ok member (after a mdk_bam_peek_sum that returned 1): the summaries it has not handed out
+ * yet, v[0..n), and the member's digest; 0 otherwise.  mdk_bam_advance_run consumes the first k of them at once. */
+int mdk_bam_member_run(mdk_bam *b, const mdk_rsum **v, size_t *n, const mdk_member **m);
+void mdk_bam_advance_run(mdk_bam *b, size_t k);
 /* decode a raw record (bytes after block_size) */
 int mdk_rec_parse(const uint8_t *raw, uint32_t len, mdk_rec *r);
 

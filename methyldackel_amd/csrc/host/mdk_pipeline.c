@@ -453,6 +453,33 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
         mdk_rsum q; const uint8_t *raw;
         rc = mdk_bam_peek_sum(bam, &q, &raw);
         if(rc != 1) break;
+        {   /* a whole (rest of a) BGZF member at once, from the digest its inflating thread left: every record on this contig,
+             * in order, starting before the chunk's end, reaching into the chunk, none reaching beyond it */
+            const mdk_rsum *v; size_t n; const mdk_member *m;
+            if(mdk_bam_member_run(bam, &v, &n, &m) && n > 1 && m->sorted && m->tid0 == (int32_t)tid && m->tidN == (int32_t)tid && m->posN < (int32_t)end &&
+               m->min_endp > (int32_t)beg && m->max_endp <= (int32_t)end && !(v[0].tid < p->last_tid || (v[0].tid == p->last_tid && v[0].pos < p->last_pos))) {
+                c->n_records_seen += n;
+                if(collect) {
+                    size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL; size_t k, rend = (size_t)v[n - 1].off + 4 + v[n - 1].len;
+                    if(g && g->slab == cs && g->end == roff) g->end = rend;
+                    else {
+                        if(g) sl->rg_base += g->end - g->beg;
+                        if(sl->n_rg == sl->cap_rg) { int nc = sl->cap_rg ? sl->cap_rg * 2 : 16; if(grow((void **)&sl->rg, sizeof(rrange) * (size_t)nc)) return -5; sl->cap_rg = nc; }
+                        g = &sl->rg[sl->n_rg++]; g->slab = cs; g->beg = roff; g->end = rend; mdk_slab_ref(bam, cs);
+                    }
+                    sl->n_stream += n;
+                    if(sl->hold_slabs) {
+                        const uint64_t base = (uint64_t)sl->raw_len + sl->rg_base - g->beg;
+                        if(sl->n_roff + n > sl->cap_roff) { size_t nc = (sl->n_roff + n) * 2 + (1u << 18); if(grow((void **)&sl->roff, nc * sizeof(uint32_t))) return -5; sl->cap_roff = nc; }
+                        for(k = 0; k < n; k++) sl->roff[sl->n_roff + k] = (uint32_t)(base + v[k].off);
+                        sl->n_roff += n;
+                    }
+                }
+                p->last_tid = (int32_t)tid; p->last_pos = v[n - 1].pos;
+                mdk_bam_advance_run(bam, n);
+                continue;
+            }
+        }
         if(q.tid >= 0) {
             if(q.tid < p->last_tid || (q.tid == p->last_tid && q.pos < p->last_pos)) { fprintf(stderr, "[mdk] %s is not coordinate sorted; `extract` needs sorted alignments\n", o->bam_name); return -2; }
             if(q.tid > (int32_t)tid) break;
