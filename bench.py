@@ -103,20 +103,23 @@ def main():
     # host side: decode + admit + pack the R intervals once; they then stay resident in HBM, one per device slot
     t0 = time.time()
     plan = mdk.Plan(cmd)
+    plan.set_prep(1)                         # as `MethylDackel extract` runs: the chunk's BAM records go to the device, which prepares them itself
     cfg = plan.dev_cfg()
     cfg.n_slots = R + 2                      # R resident intervals + two slots for the streamed figure
     dev = mdk.Device(cfg, device=dev_index)
-    reads = segs = n_sites_sum = cpg_calls = all_calls = 0
+    dev.set_prep(plan.prep_cfg())
+    reads = segs = n_sites_sum = cpg_calls = all_calls = raw_bytes = raw_records = 0
     keep_batches = []                        # (host copies of two batches for the streamed figure)
     n_chunks = 0
     while n_chunks < R:
         chunk = plan.next_chunk()
         assert chunk is not None and not chunk.skipped, "the synthetic contig must give R full chunks"
         plan.ensure_reference(dev, chunk.tid)
-        dev.upload(n_chunks, chunk.batch)
+        dev.upload_raw(n_chunks, chunk.raw)   # H2D of the records + admission, strand, name pairing, CIGAR expansion on the device
         dev.launch(n_chunks)
         sites = dev.download(n_chunks)        # waits: the pipeline's host buffers may be recycled after this
-        reads += chunk.batch.n_reads; segs += chunk.batch.n_segs; n_sites_sum += sites.n_sites
+        _, n_seg_dev, n_read_dev = dev.debug_segments(n_chunks)
+        reads += n_read_dev; segs += n_seg_dev; n_sites_sum += sites.n_sites; raw_bytes += sum(chunk.raw.range[i].bytes for i in range(chunk.raw.n_ranges)); raw_records += chunk.raw.n_records
         for i in range(sites.n_sites):
             r = sites.site[i]
             c = r.nmeth + r.nunmeth
@@ -124,10 +127,10 @@ def main():
             if ((r.meta >> 1) & 3) == 0:
                 cpg_calls += c
         if n_chunks < 2:
-            b = chunk.batch
-            seg_copy = C.create_string_buffer(C.string_at(b.seg, b.n_segs * C.sizeof(mdk.md_seg)), b.n_segs * C.sizeof(mdk.md_seg))
-            blob_copy = C.create_string_buffer(C.string_at(b.blob, b.blob_bytes), b.blob_bytes)
-            keep_batches.append((b.tid, b.beg, b.end, b.n_segs, b.n_reads, b.blob_bytes, b.algo_bytes, seg_copy, blob_copy))
+            b = chunk.raw
+            cat = b"".join(C.string_at(b.range[i].ptr, b.range[i].bytes) for i in range(b.n_ranges))
+            offs = C.string_at(b.rec_off, 4 * b.n_records)
+            keep_batches.append((b.tid, b.beg, b.end, b.n_records, b.woff, b.wlen, cat, offs))
         n_chunks += 1
     t_host = time.time() - t0
     slots = list(range(R))
@@ -193,31 +196,37 @@ def main():
     # and launched while chunk k is downloaded
     streamed = None
     if world == 1 and len(keep_batches) == 2:
-        pinned, batches = [], []
+        pinned, batches, keep = [], [], []
         L.md_host_alloc.restype = C.c_void_p
-        for (tid, beg, end, n_segs, n_reads, blob_bytes, algo_bytes, seg_copy, blob_copy) in keep_batches:
-            ps = L.md_host_alloc(C.c_uint64(len(seg_copy))); pb = L.md_host_alloc(C.c_uint64(len(blob_copy)))
-            C.memmove(ps, seg_copy, len(seg_copy)); C.memmove(pb, blob_copy, len(blob_copy))
-            pinned += [ps, pb]
-            b = mdk.md_read_batch(); b.tid = tid; b.beg = beg; b.end = end; b.n_segs = n_segs; b.seg = C.cast(ps, C.POINTER(mdk.md_seg))
-            b.blob = C.cast(pb, C.POINTER(C.c_uint8)); b.blob_bytes = blob_bytes; b.n_reads = n_reads; b.algo_bytes = algo_bytes
-            batches.append(b)
+        for (tid, beg, end, n_rec, woff, wlen, cat, offs) in keep_batches:
+            pc = L.md_host_alloc(C.c_uint64(len(cat))); po = L.md_host_alloc(C.c_uint64(len(offs)))
+            C.memmove(pc, cat, len(cat)); C.memmove(po, offs, len(offs))
+            pinned += [pc, po]
+            rg = (mdk.md_raw_range * 1)(); rg[0].ptr = C.cast(pc, C.POINTER(C.c_uint8)); rg[0].bytes = len(cat)
+            b = mdk.md_raw_batch(); b.tid = tid; b.beg = beg; b.end = end; b.n_ranges = 1; b.range = rg; b.n_records = n_rec
+            b.rec_off = C.cast(po, C.POINTER(C.c_uint32)); b.woff = woff; b.wlen = wlen
+            batches.append(b); keep.append(rg)
         n_stream = 200
         for timed in (False, True):
+            nn = n_stream if timed else 10
             ts = time.perf_counter()
-            dev.submit(R, batches[0])
-            for k in range(1, n_stream if timed else 10):
-                dev.submit(R + (k & 1), batches[k & 1])
+            dev.submit_raw(R, batches[0])
+            for k in range(1, nn):
+                dev.submit_raw(R + (k & 1), batches[k & 1])
                 dev.download(R + ((k - 1) & 1))
-            dev.download(R + ((n_stream if timed else 10) - 1 & 1))
+            dev.download(R + ((nn - 1) & 1))
             t_stream = time.perf_counter() - ts
-        h2d = (len(keep_batches[0][7]) + len(keep_batches[0][8]) + len(keep_batches[1][7]) + len(keep_batches[1][8])) / 2
+        h2d = (len(keep_batches[0][6]) + len(keep_batches[0][7]) + len(keep_batches[1][6]) + len(keep_batches[1][7])) / 2
         per_chunk_calls = cpg_calls / R
         streamed = {"ms_per_chunk": t_stream / n_stream * 1e3, "value": per_chunk_calls * n_stream / t_stream, "unit": "CpG calls/s", "h2d_bytes_per_chunk": int(h2d),
                     "h2d_GBps": h2d * n_stream / t_stream / 1e9,
-                    "note": "per chunk: hipMemcpyAsync of segments + payload from pinned host memory, k_pileup, D2H of the site records; two slots (chunk k+1 is uploaded and launched while chunk k is downloaded)"}
+                    "note": "per chunk: hipMemcpyAsync of the chunk's BAM records + record table from pinned host memory, the preparation kernels, k_pileup, D2H of the site records; "
+                            "two slots (chunk k+1 is uploaded and launched while chunk k is downloaded)"}
         for p in pinned:
             L.md_host_free(C.c_void_p(p))
+    prep_ms = C.c_float(0)
+    rc = L.md_dev_bench_prep(dev.h, 0, 3, 30, C.byref(prep_ms))
+    assert rc == 0, L.md_dev_last_error()
 
     # HBM traffic of the kernel cannot be sampled from inside this process; it is taken from the committed rocprofv3 PMC summary
     # of this same command (profiles/, produced by tools/gpu_round.sh + tools/summarize_prof.py) with the calibration measured by
@@ -242,7 +251,8 @@ def main():
             "value": value, "unit": "CpG calls/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3 if args.steps else 0.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32", "data": "synthetic",
-            "config": {"workload": ("S1: synthetic 30x PE 2x150 WGBS, CpG-only extract in 1 Mb chunks (BASELINE.json configs[1])" if headline
+            "config": {"layout": "as `MethylDackel extract` leaves it: BAM records resident, segments built by the device preparation, sequence/quality bytes read in place",
+                       "workload": ("S1: synthetic 30x PE 2x150 WGBS, CpG-only extract in 1 Mb chunks (BASELINE.json configs[1])" if headline
                                     else f"synthetic {args.length} bp chunks, {args.coverage}x, extract {' '.join(extra)}") +
                                    f"; per GPU {R} different resident 1 Mb intervals (~{br.algo_bytes * R / 1e6:.0f} MB algorithmic, beyond the 256 MiB Infinity Cache)",
                        "step": f"one pass over a batch of {args.passes} x {R} = {launches_per_step} chunks per GPU (the {R} resident intervals in rotation)",
@@ -259,6 +269,11 @@ def main():
                          "cache_resident_comparison": {"kernel_ms": br1.ms_pileup, "achieved": br1.algo_bytes / (br1.ms_pileup / 1e3) / 1e9 if br1.ms_pileup > 0 else 0.0,
                                                        "note": "interval 0 relaunched back to back: its ~52 MB stay in the 256 MiB Infinity Cache (the round-1 measurement)"}},
             "host_prep_s": t_host,
+            "device_prep": {"ms_per_chunk": prep_ms.value, "records_per_chunk": raw_records // R, "record_bytes_per_chunk": raw_bytes // R,
+                            "achieved_GBps": (raw_bytes / R) / (prep_ms.value / 1e3) / 1e9 if prep_ms.value > 0 else 0.0,
+                            "note": "per chunk, before the pileup: k_rec_scan (fields, CIGAR length, NH/XG aux walk, admission, strand), k_compact + name table, k_pair (overlap pairing with "
+                                    "buffer eviction), k_seg_count/k_seg_write (CIGAR -> segments, tile runs), two block scans; HIP events around 30 repetitions on resident records. "
+                                    "Runs once per chunk in `extract`; the step of this benchmark is the pileup over the segments it leaves resident"},
         }
         if world > 1:
             result["exchange"] = {"exchanges": exchanges, "bytes_per_exchange_per_rank": bytes_per_exchange, "transport": "ncclSend/ncclRecv group (libmdk_hip md_comm_gather)"}

@@ -145,6 +145,9 @@ int  md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bits, int64_
  * return MDK_ERR_PREP_HOST when the preparation gave up on the chunk (see above). */
 int  md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b);
 int  md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b);
+/* The preparation kernels of a slot uploaded with md_dev_upload_raw, re-run `iters` times on the resident records and timed
+ * with HIP events (the slot's segments are the same afterwards). */
+int  md_dev_bench_prep(md_dev *h, int slot, int warmup, int iters, float *ms_per_chunk);
 /* Test hook: the segments the device built for an uploaded slot (off4 / m_off4 are BYTE offsets into the uploaded records,
  * qualities follow the sequence without padding), their number, and the number of admitted reads. */
 int  md_dev_debug_segments(md_dev *h, int slot, md_seg *out, int64_t cap, int64_t *n_segs, int64_t *n_reads);

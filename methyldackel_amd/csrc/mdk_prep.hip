@@ -336,8 +336,9 @@ struct RunIt {
     }
 };
 
+// lo/hi: reference extent of the pieces written (for the tile runs); untouched when nothing is emitted
 template <bool WRITE>
-__device__ __forceinline__ uint32_t read_segments(const PrepParams &P, uint32_t a, md_seg *out, uint32_t base) {
+__device__ __forceinline__ uint32_t read_segments(const PrepParams &P, uint32_t a, md_seg *out, uint32_t base, int64_t &lo, int64_t &hi) {
     const PrepRead r = P.rd[a];
     const int32_t mi = P.mate[a];
     PrepRead m; bool paired = false;
@@ -363,9 +364,8 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, uint32_t 
                     const uint32_t o = base + n;
                     if((int64_t)o < P.cap_seg) {
                         out[o] = g;
-                        int64_t lo = cur, hi = pe; if(lo < P.beg) lo = P.beg; if(hi > P.end) hi = P.end;
-                        const int t0 = (int)((lo - P.beg) / P.tile), t1 = (int)((hi - 1 - P.beg) / P.tile);
-                        for(int t = t0; t <= t1; t++) { atomicMin(&P.tiles[t].first, (int)o); atomicMax(&P.tiles[t].last, (int)o + 1); }
+                        if(cur < lo) lo = cur;
+                        if(pe > hi) hi = pe;
                     }
                 }
                 n++;
@@ -381,7 +381,8 @@ __global__ __launch_bounds__(PB) void k_seg_count(const PrepParams P) {
     const uint32_t a = blockIdx.x * PB + threadIdx.x, n_adm = P.cnt->n_adm;
     uint32_t n = 0; unsigned long long bytes = 0;
     if(a < n_adm) {
-        n = read_segments<false>(P, a, nullptr, 0);
+        int64_t lo = 0, hi = 0;
+        n = read_segments<false>(P, a, nullptr, 0, lo, hi);
         P.segcnt[a] = n;
         const PrepRead r = P.rd[a];
         bytes = 16ull + 4ull * r.ncig + ((unsigned long long)r.lq + 1) / 2 + r.lq;        // SURVEY.md 8d, per admitted read
@@ -409,7 +410,24 @@ __global__ __launch_bounds__(PB) void k_seg_write(const PrepParams P) {
     __syncthreads();
     uint32_t base = P.segblkoff[blockIdx.x] + incl - n;
     for(int w = 0; w < wave; w++) base += wsum[w];
-    if(n) (void)read_segments<true>(P, a, P.seg, base);
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    if(n) (void)read_segments<true>(P, a, P.seg, base, lo, hi);
+    // Tile runs: tile t's run [first, last) must cover every segment touching t.  A lane contributes [base, base + n) to every
+    // tile its pieces reach -- a superset, which is all k_pileup needs.  Reads are in coordinate order, so the lanes of a wave
+    // touching one tile are (nearly always) consecutive: only the first of them lowers `first`, only the last raises `last`,
+    // instead of two contended atomics per segment (275 us -> a few us per 1 Mb chunk).
+    int t0 = 0x7fffffff, t1 = -1;
+    if(n && hi > lo && (int64_t)base < P.cap_seg) {
+        if(lo < P.beg) lo = P.beg;
+        if(hi > P.end) hi = P.end;
+        t0 = (int)((lo - P.beg) / P.tile); t1 = (int)((hi - 1 - P.beg) / P.tile);
+    }
+    const int p0 = __shfl_up(t0, 1), p1 = __shfl_up(t1, 1), n0 = __shfl_down(t0, 1), n1 = __shfl_down(t1, 1);
+    uint32_t top = base + n; if((int64_t)top > P.cap_seg) top = (uint32_t)P.cap_seg;
+    for(int t = t0; t <= t1; t++) {
+        if(lane == 0 || t < p0 || t > p1) atomicMin(&P.tiles[t].first, (int)base);
+        if(lane == 63 || t < n0 || t > n1) atomicMax(&P.tiles[t].last, (int)top);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -531,6 +549,22 @@ MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s) {
         int rc = enqueue_prep(h, s); if(rc) return rc;
         return MDK_ERR_PREP_REDO;
     }
+    return 0;
+}
+
+// the preparation kernels of an uploaded raw slot re-run `iters` times on the resident records, timed with HIP events on the
+// slot's stream (bench.py: what the device spends per chunk before the pileup)
+extern "C" int md_dev_bench_prep(md_dev *h, int slot, int warmup, int iters, float *ms_per_chunk) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !s->uploaded || !s->raw_layout || iters < 1 || !ms_per_chunk) return fail(MDK_ERR_ARG, "md_dev_bench_prep: needs a slot uploaded with md_dev_upload_raw", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    for(int i = 0; i < warmup; i++) { int rc = enqueue_prep(h, s); if(rc) return rc; }
+    HIPCHK(hipEventRecord(s->k0, s->stream));
+    for(int i = 0; i < iters; i++) { int rc = enqueue_prep(h, s); if(rc) return rc; }
+    HIPCHK(hipEventRecord(s->k1, s->stream));
+    HIPCHK(hipEventSynchronize(s->k1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, s->k0, s->k1));
+    *ms_per_chunk = ms / (float)iters;
     return 0;
 }
 
