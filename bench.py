@@ -10,7 +10,8 @@ the hot path over a batch of P x R chunks (default P = 256: 4096 chunk launches)
 times in rotation.  Inside a step every launch is issued and collected (site count read back) with two launches in flight,
 exactly as extract_main drives the device; with N ranks the kernels write into send buffers and the results of 8
 consecutive launches travel to rank 0 with one ncclSend/ncclRecv exchange (libmdk_hip's md_comm, RCCL over xGMI) while the
-next group is computed.  The loop is libmdk_hip's md_bench_run (C); Python only brackets it.
+next launch is computed.  A kernel launch covers 8 resident chunks (md_dev_launch_group): one 1 Mb chunk is only 489
+workgroups, fewer than two per CU.  The loop is libmdk_hip's md_bench_run (C); Python only brackets it.
 
 Also on the JSON line:
   roofline     -- k_pileup: algorithmic bytes per launch (SURVEY.md 8d formula, averaged over the R intervals) / HIP-event
@@ -35,7 +36,7 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 S1_SEED = 0x5EED0001
-GROUP = 8                    # launches per exchange
+GROUP = 8                    # resident chunks per kernel launch (md_dev_launch_group) = chunks per exchange
 
 
 def log(*a):
@@ -85,7 +86,7 @@ def main():
         dist.barrier()
     L = mdk.lib_hip()
 
-    R = max(2, args.resident)
+    R = max(2 * GROUP, (args.resident + GROUP - 1) // GROUP * GROUP)
     work = Path(tempfile.mkdtemp(prefix=f"mdk_bench_r{rank}_"))
     data = Path(args.data_dir) if args.data_dir else work
     data.mkdir(parents=True, exist_ok=True)
@@ -151,11 +152,11 @@ def main():
     rc = L.md_bench_open(dev.h, comm if world > 1 else None, slot_arr, R, GROUP, C.byref(bench))
     assert rc == 0, L.md_dev_last_error()
 
-    launches_per_step = args.passes * R
+    launches_per_step = args.passes * R        # chunk passes per step; GROUP of them share one kernel launch
     res = mdk.md_bench_run_result()
 
     def run(k_steps):
-        rc = L.md_bench_run(bench, k_steps * launches_per_step, C.byref(res))
+        rc = L.md_bench_run(bench, k_steps * launches_per_step // GROUP, C.byref(res))
         assert rc == 0, L.md_dev_last_error()
 
     def fence():
@@ -187,7 +188,8 @@ def main():
         total_cpg_calls, total_calls, total_sites = cpg_calls, all_calls, int(n_sites_sum)
 
     # kernel-level timing with HIP events on the launch stream, inside the library, rotating over the R resident intervals
-    br = dev.bench_rotate(slots, 2 * R, max(200, 50 * R))
+    br = dev.bench_rotate(slots, 8, 200, per_launch=GROUP)
+    br_single = dev.bench_rotate(slots, 2 * R, max(200, 50 * R))
     pile_s = br.ms_pileup / 1e3
     achieved = br.algo_bytes / pile_s / 1e9 if pile_s > 0 else 0.0
     br1 = dev.bench(0, 5, 200)                 # one interval relaunched on cache-resident data, for comparison with round 1
@@ -255,17 +257,20 @@ def main():
                        "workload": ("S1: synthetic 30x PE 2x150 WGBS, CpG-only extract in 1 Mb chunks (BASELINE.json configs[1])" if headline
                                     else f"synthetic {args.length} bp chunks, {args.coverage}x, extract {' '.join(extra)}") +
                                    f"; per GPU {R} different resident 1 Mb intervals (~{br.algo_bytes * R / 1e6:.0f} MB algorithmic, beyond the 256 MiB Infinity Cache)",
-                       "step": f"one pass over a batch of {args.passes} x {R} = {launches_per_step} chunks per GPU (the {R} resident intervals in rotation)",
-                       "chunk_launches_per_step_per_gpu": launches_per_step, "ms_per_chunk_launch": dt / launches * 1e3 if launches else 0.0,
+                       "step": f"one pass over a batch of {args.passes} x {R} = {launches_per_step} chunks per GPU (the {R} resident intervals in rotation), {GROUP} chunks per kernel launch",
+                       "chunks_per_step_per_gpu": launches_per_step, "kernel_launches_per_step_per_gpu": launches_per_step // GROUP, "ms_per_chunk": dt / launches * 1e3 if launches else 0.0,
                        "interval_bp": args.length, "coverage": args.coverage, "resident_intervals_per_gpu": R,
                        "reads_admitted_per_interval": reads // R, "segments_per_interval": segs // R, "records_per_gpu": synth_info["records"],
                        "sites_per_interval": int(n_sites_sum) // R, "cpg_calls_per_interval": int(cpg_calls) // R,
-                       "tile": int(br.tile), "tiles": int(br.n_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes),
-                       "parallelism": f"interval-sharded x{n_gpus}" + (f" + RCCL gather of site buffers to rank 0 ({GROUP} launches per exchange, {bytes_per_exchange} B per exchange and rank)" if world > 1 else ""),
-                       "in_flight": "2 launches per GPU (launch k is issued, then launch k-1 is collected, as extract_main does); every launch is issued and collected inside the timed region"},
+                       "tile": int(br.tile), "tiles_per_launch": int(br.n_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes),
+                       "parallelism": f"interval-sharded x{n_gpus}" + (f" + RCCL gather of site buffers to rank 0 ({GROUP} chunks = one launch per exchange, {bytes_per_exchange} B per exchange and rank)" if world > 1 else ""),
+                       "in_flight": "2 kernel launches per GPU (launch g is issued, then the chunks of launch g-1 are collected, as extract_main does); every launch is issued and collected inside the timed region"},
             "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup,
-                         "measured": f"HIP events around {max(200, 50 * R)} launches rotating over the {R} resident intervals on one stream",
+                         "chunks_per_launch": GROUP, "kernel_ms_per_chunk": br.ms_pileup / GROUP,
+                         "measured": f"HIP events around 200 launches of k_pileup_multi ({GROUP} resident 1 Mb chunks per launch, {int(br.n_tiles)} workgroups) rotating over the {R} resident intervals on one stream",
+                         "one_chunk_per_launch": {"kernel_ms": br_single.ms_pileup, "achieved": br_single.algo_bytes / (br_single.ms_pileup / 1e3) / 1e9 if br_single.ms_pileup > 0 else 0.0,
+                                                  "note": "k_pileup over ONE 1 Mb chunk (489 workgroups, fewer than two per CU), rotating over the resident intervals: what round 1 launched"},
                          "cache_resident_comparison": {"kernel_ms": br1.ms_pileup, "achieved": br1.algo_bytes / (br1.ms_pileup / 1e3) / 1e9 if br1.ms_pileup > 0 else 0.0,
                                                        "note": "interval 0 relaunched back to back: its ~52 MB stay in the 256 MiB Infinity Cache (the round-1 measurement)"}},
             "host_prep_s": t_host,

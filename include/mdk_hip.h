@@ -210,6 +210,11 @@ int  md_dev_perread_download(md_dev *h, int slot, const md_pr_count **counts, in
 int  md_dev_upload(md_dev *h, int slot, const md_read_batch *b);
 int  md_dev_launch(md_dev *h, int slot);
 int  md_dev_submit(md_dev *h, int slot, const md_read_batch *b);
+/* One kernel launch over several uploaded slots (at most md_dev_group_max() = 8, all different): a 1 Mb chunk alone is
+ * fewer than two workgroups per CU, so resident chunks are launched together; each keeps its own reads, outputs and site
+ * counter, and download / wait are per slot as after md_dev_launch. */
+int  md_dev_launch_group(md_dev *h, const int *slots, int n);
+int  md_dev_group_max(void);
 int  md_dev_download(md_dev *h, int slot, md_sites *out);
 int  md_dev_sync(md_dev *h);
 
@@ -230,10 +235,11 @@ int64_t md_sites_order(const md_site *site, const md_site_var *var, const md_til
  * every time) and time them with HIP events on the slot's stream. */
 int  md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench_result *out);
 
-/* The same for `n` uploaded slots holding DIFFERENT intervals, launched round robin on one stream (`iters` launches in
- * all): with enough slots the working set exceeds the 256 MiB Infinity Cache and every launch streams its inputs from
- * HBM.  algo_bytes / n_sites are per launch, averaged over the slots; ms_total == ms_pileup. */
-int  md_dev_bench_rotate(md_dev *h, const int *slots, int n, int warmup, int iters, md_bench_result *out);
+/* The same for `n` uploaded slots holding DIFFERENT intervals, launched `per_launch` at a time (1 = md_dev_launch, more =
+ * md_dev_launch_group; n must be a multiple) round robin on one stream, `iters` launches in all: with enough slots the
+ * working set exceeds the 256 MiB Infinity Cache and every launch streams its inputs from HBM.  algo_bytes / n_sites /
+ * n_tiles are per LAUNCH, averaged over the rotation; ms_total == ms_pileup. */
+int  md_dev_bench_rotate(md_dev *h, const int *slots, int n, int per_launch, int warmup, int iters, md_bench_result *out);
 
 /* ---- multi-GPU: the exchange step of the interval-sharded path (SURVEY.md 8b last row, 8e) ----
  * Chunk k of the reference's schedule belongs to GPU k mod N; per-interval site buffers travel to rank 0 (whose host writes
@@ -254,11 +260,12 @@ int  md_comm_world(const md_comm *c);
 int  md_comm_gather(md_comm *c, const void *const *d_send, const uint64_t *send_bytes, void *const *d_recv, const uint64_t *recv_bytes);
 int  md_comm_wait(md_comm *c);
 
-/* The resident-input benchmark loop of bench.py: `n` >= 2 uploaded slots holding different intervals are launched round
- * robin, two in flight (launch k is issued, then launch k-1 is collected, as extract_main does); the kernels write straight
- * into a send buffer and, with a communicator, the results of `group` consecutive launches travel to rank 0 in one exchange
- * while the next group is computed.  md_bench_verify compares what the last launch left in the send buffer with
- * md_dev_download of the same interval (and, on rank 0, checks that every peer's data arrived). */
+/* The resident-input benchmark loop of bench.py: `n` uploaded slots holding different intervals are launched `group` at a
+ * time (md_dev_launch_group; n a multiple of group, at least two groups) round robin, two launches in flight (launch g is
+ * issued, then launch g-1 is collected, as extract_main does); the kernels write straight into a send buffer and, with a
+ * communicator, the results of a launch travel to rank 0 in one exchange while the next launch is computed.
+ * md_bench_run(launches): that many kernel launches.  md_bench_verify compares what the last launch left in the send buffer
+ * with md_dev_download of the same intervals (and, on rank 0, checks that every peer's data arrived). */
 typedef struct md_bench md_bench;
 typedef struct { uint64_t launches, slots_last, exchanges, bytes_per_exchange; } md_bench_run_result;
 int  md_bench_open(md_dev *h, md_comm *comm /* NULL: one GPU */, const int *slots, int n, int group, md_bench **out);

@@ -126,7 +126,7 @@ COMM_ID_BYTES = 128
 
 HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
-               "md_dev_bench", "md_dev_bench_rotate", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_local", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait",
+               "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_local", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait",
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned",
                "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep",
                "md_dev_mbias_submit", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
@@ -172,7 +172,8 @@ def lib_hip():
         L.md_sites_order.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]
         L.md_sites_order.restype = C.c_int64
         L.md_dev_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
-        L.md_dev_bench_rotate.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
+        L.md_dev_bench_rotate.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(md_bench_result)]
+        L.md_dev_launch_group.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int]
         L.md_comm_unique_id.argtypes = [C.c_char_p]
         L.md_comm_open_rank.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
         L.md_comm_open_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
@@ -312,12 +313,17 @@ class Device:
     def bind_output(self, slot: int, d_site, d_var, d_seg, cap_sites: int, cap_tiles: int):
         self._chk(self.L.md_dev_bind_output(self.h, slot, d_site, d_var, d_seg, cap_sites, cap_tiles), "md_dev_bind_output")
 
-    def bench_rotate(self, slots, warmup: int, iters: int) -> md_bench_result:
-        """kernel time with HIP events while rotating over several resident intervals (working set beyond the Infinity Cache)"""
+    def bench_rotate(self, slots, warmup: int, iters: int, per_launch: int = 1) -> md_bench_result:
+        """kernel time with HIP events while rotating over several resident intervals (working set beyond the Infinity Cache),
+        `per_launch` intervals per kernel launch"""
         r = md_bench_result()
         arr = (C.c_int * len(slots))(*slots)
-        self._chk(self.L.md_dev_bench_rotate(self.h, arr, len(slots), warmup, iters, C.byref(r)), "md_dev_bench_rotate")
+        self._chk(self.L.md_dev_bench_rotate(self.h, arr, len(slots), per_launch, warmup, iters, C.byref(r)), "md_dev_bench_rotate")
         return r
+
+    def launch_group(self, slots):
+        arr = (C.c_int * len(slots))(*slots)
+        self._chk(self.L.md_dev_launch_group(self.h, arr, len(slots)), "md_dev_launch_group")
 
     def bench(self, slot: int, warmup: int, iters: int) -> md_bench_result:
         r = md_bench_result()

@@ -156,16 +156,17 @@ extern "C" int md_comm_wait(md_comm *c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Resident-input benchmark loop (bench.py): `n` uploaded slots holding different intervals are launched round robin, two
-// in flight -- launch k is issued, then launch k-1 is collected (its site count read back), as extract_main does -- and
-// the results of `group` consecutive launches are written by the kernels straight into one send buffer that travels to
-// rank 0 in a single exchange while the next group is computed into the other buffer.
+// Resident-input benchmark loop (bench.py): `n` uploaded slots holding different intervals are launched `group` at a time
+// (md_dev_launch_group: one kernel over `group` chunks), the groups round robin, two launches in flight -- launch g is
+// issued, then launch g-1 is collected (the site count of each of its chunks read back), as extract_main does -- and the
+// kernels write straight into a send buffer that travels to rank 0 in one exchange per launch while the next launch is
+// computed into the other buffer.
 // ------------------------------------------------------------------------------------------------
 struct md_bench {
-    md_dev *h = nullptr; md_comm *comm = nullptr; std::vector<int> slots; int group = 0, world = 1, rank = 0;
-    int64_t cap = 0, tcap = 0; size_t E = 0, off_var = 0, off_seg = 0;       // one launch's region: sites, [var], tile segments
+    md_dev *h = nullptr; md_comm *comm = nullptr; std::vector<int> slots; int group = 0, ngroups = 0, world = 1, rank = 0;
+    int64_t cap = 0, tcap = 0; size_t E = 0, off_var = 0, off_seg = 0;       // one chunk's region: sites, [var], tile segments
     uint8_t *send[2] = {nullptr, nullptr}; std::vector<uint8_t *> recv[2]; bool pending[2] = {false, false};
-    int64_t last_k = -1;
+    int64_t last_g = -1;
 };
 
 extern "C" void md_bench_close(md_bench *b) {
@@ -178,11 +179,11 @@ extern "C" void md_bench_close(md_bench *b) {
 }
 
 extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, int group, md_bench **out) {
-    if(!h || !slots || n < 2 || group < 1 || !out) return fail(MDK_ERR_ARG, "md_bench_open: needs at least two uploaded slots", hipSuccess);
+    if(!h || !slots || group < 1 || group > md_dev_group_max() || n < 2 * group || n % group || !out) return fail(MDK_ERR_ARG, "md_bench_open: needs at least two groups of uploaded slots", hipSuccess);
     if(comm && comm->n_local != 1) return fail(MDK_ERR_ARG, "md_bench_open: one process per GPU", hipSuccess);
     *out = nullptr;
     HIPCHK(hipSetDevice(h->device));
-    md_bench *b = new md_bench(); b->h = h; b->comm = comm; b->group = group;
+    md_bench *b = new md_bench(); b->h = h; b->comm = comm; b->group = group; b->ngroups = n / group;
     if(comm) { b->world = comm->world; b->rank = comm->rank[0]; }
     for(int i = 0; i < n; i++) {
         Slot *s = get_slot(h, slots[i]);
@@ -227,62 +228,64 @@ static int bench_exchange(md_bench *b, int x) {
     b->pending[x] = true;
     return 0;
 }
+static int bench_collect(md_bench *b, int64_t g, int64_t *sites) {
+    const int *gs = b->slots.data() + (g % b->ngroups) * b->group;
+    for(int i = 0; i < b->group; i++) { int64_t c = finish_count(b->h, get_slot(b->h, gs[i])); if(c < 0) return (int)c; *sites = c; }
+    return bench_exchange(b, (int)(g & 1));
+}
 
-// `launches` passes of the hot path, each over the next resident interval; returns when every launch has been collected and
-// every exchange has completed.  The caller brackets this call with its barrier + device sync and takes the time.
+// `launches` kernel launches, each one pass of the hot path over the next `group` resident intervals; returns when every
+// launch has been collected and every exchange has completed.  The caller brackets this call with its barrier + device sync.
 extern "C" int md_bench_run(md_bench *b, int64_t launches, md_bench_run_result *out) {
     if(!b || launches < 0 || !out) return fail(MDK_ERR_ARG, "md_bench_run", hipSuccess);
-    md_dev *h = b->h; const int n = (int)b->slots.size(), G = b->group;
+    md_dev *h = b->h; const int K = b->group;
     HIPCHK(hipSetDevice(h->device));
     memset(out, 0, sizeof(*out));
     int64_t sites = 0;
-    for(int64_t k = 0; k < launches; k++) {
-        const int x = (int)((k / G) & 1), e = (int)(k % G);
-        if(e == 0 && b->pending[x]) { int rc = md_comm_wait(b->comm); if(rc) return rc; b->pending[0] = b->pending[1] = false; }     // this buffer is about to be overwritten
-        uint8_t *base = b->send[x] + (size_t)e * b->E;
-        int rc = md_dev_bind_output(h, b->slots[k % n], base, h->variant ? base + b->off_var : nullptr, base + b->off_seg, b->cap, b->tcap); if(rc) return rc;
-        Slot *s = get_slot(h, b->slots[k % n]);
-        rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
-        if(k) {
-            int64_t c = finish_count(h, get_slot(h, b->slots[(k - 1) % n])); if(c < 0) return (int)c;
-            sites = c;
-            if(k % G == 0) { rc = bench_exchange(b, (int)(((k - 1) / G) & 1)); if(rc) return rc; out->exchanges++; }
+    for(int64_t g = 0; g < launches; g++) {
+        const int x = (int)(g & 1);
+        if(b->pending[x]) { int rc = md_comm_wait(b->comm); if(rc) return rc; b->pending[0] = b->pending[1] = false; }     // this buffer is about to be overwritten
+        const int *gs = b->slots.data() + (g % b->ngroups) * K;
+        for(int i = 0; i < K; i++) {
+            uint8_t *base = b->send[x] + (size_t)i * b->E;
+            int rc = md_dev_bind_output(h, gs[i], base, h->variant ? base + b->off_var : nullptr, base + b->off_seg, b->cap, b->tcap); if(rc) return rc;
         }
+        int rc = K == 1 ? md_dev_launch(h, gs[0]) : md_dev_launch_group(h, gs, K); if(rc) return rc;
+        if(g) { rc = bench_collect(b, g - 1, &sites); if(rc) return rc; if(b->comm) out->exchanges++; }
     }
     if(launches) {
-        int64_t c = finish_count(h, get_slot(h, b->slots[(launches - 1) % n])); if(c < 0) return (int)c;
-        sites = c;
-        int rc = bench_exchange(b, (int)(((launches - 1) / G) & 1)); if(rc) return rc;
+        int rc = bench_collect(b, launches - 1, &sites); if(rc) return rc;
         if(b->comm) out->exchanges++;
-        b->last_k = launches - 1;
+        b->last_g = launches - 1;
     }
     if(b->comm) { int rc = md_comm_wait(b->comm); if(rc) return rc; b->pending[0] = b->pending[1] = false; }
-    out->launches = (uint64_t)launches; out->slots_last = (uint64_t)sites; out->bytes_per_exchange = b->comm ? (uint64_t)b->E * (uint64_t)G : 0;
+    out->launches = (uint64_t)launches; out->slots_last = (uint64_t)sites; out->bytes_per_exchange = b->comm ? (uint64_t)b->E * (uint64_t)K : 0;
     return 0;
 }
 
 // After md_bench_run: the sites the last launch left in the send buffer (ordered by tile) must be the sites md_dev_download
-// gives for the same interval; on rank 0 every peer's last region must hold sites too.  0 = verified.
+// gives for the same intervals; on rank 0 every peer's regions must hold sites too.  0 = verified.
 extern "C" int md_bench_verify(md_bench *b) {
-    if(!b || b->last_k < 0) return fail(MDK_ERR_ARG, "md_bench_verify: nothing was run", hipSuccess);
-    md_dev *h = b->h; const int n = (int)b->slots.size(), G = b->group; const int64_t k = b->last_k;
+    if(!b || b->last_g < 0) return fail(MDK_ERR_ARG, "md_bench_verify: nothing was run", hipSuccess);
+    md_dev *h = b->h; const int K = b->group; const int64_t g = b->last_g;
     HIPCHK(hipSetDevice(h->device));
-    const int x = (int)((k / G) & 1), e = (int)(k % G), slot = b->slots[k % n];
-    std::vector<uint8_t> reg(b->E);
-    HIPCHK(hipMemcpy(reg.data(), b->send[x] + (size_t)e * b->E, b->E, hipMemcpyDeviceToHost));
-    Slot *s = get_slot(h, slot);
-    std::vector<md_site> ord((size_t)b->cap);
-    int64_t got = md_sites_order((const md_site *)reg.data(), nullptr, (const md_tile_seg *)(reg.data() + b->off_seg), s->ntiles, b->cap, ord.data(), nullptr);
-    int rc = md_dev_bind_output(h, slot, nullptr, nullptr, nullptr, 0, 0); if(rc) return rc;
-    rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
-    md_sites ref; rc = md_dev_download(h, slot, &ref); if(rc) return rc;
-    if(got != ref.n_sites || (got && memcmp(ord.data(), ref.site, (size_t)got * sizeof(md_site)))) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "bench: bound-output sites differ from md_dev_download (%lld vs %lld)", (long long)got, (long long)ref.n_sites); return MDK_ERR_ARG; }
-    if(b->comm && b->rank == 0) {
-        for(int r = 1; r < b->world; r++) {
-            HIPCHK(hipMemcpy(reg.data(), b->recv[x][r] + (size_t)e * b->E, b->E, hipMemcpyDeviceToHost));
-            const md_tile_seg *ts = (const md_tile_seg *)(reg.data() + b->off_seg); uint64_t tot = 0;
-            for(int64_t t = 0; t < b->tcap; t++) tot += ts[t].cnt;
-            if(!tot) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "bench: nothing was received from rank %d", r); return MDK_ERR_ARG; }
+    const int x = (int)(g & 1); const int *gs = b->slots.data() + (g % b->ngroups) * K;
+    std::vector<uint8_t> reg(b->E); std::vector<md_site> ord((size_t)b->cap);
+    for(int i = 0; i < K; i++) {
+        HIPCHK(hipMemcpy(reg.data(), b->send[x] + (size_t)i * b->E, b->E, hipMemcpyDeviceToHost));
+        Slot *s = get_slot(h, gs[i]);
+        int64_t got = md_sites_order((const md_site *)reg.data(), nullptr, (const md_tile_seg *)(reg.data() + b->off_seg), s->ntiles, b->cap, ord.data(), nullptr);
+        int rc = md_dev_bind_output(h, gs[i], nullptr, nullptr, nullptr, 0, 0); if(rc) return rc;
+        rc = launch_kernels(h, s, false); if(rc) return rc; s->launched = true;
+        md_sites ref; rc = md_dev_download(h, gs[i], &ref); if(rc) return rc;
+        if(got != ref.n_sites || (got && memcmp(ord.data(), ref.site, (size_t)got * sizeof(md_site)))) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "bench: bound-output sites of chunk %d of the last launch differ from md_dev_download (%lld vs %lld)", i, (long long)got, (long long)ref.n_sites); return MDK_ERR_ARG; }
+        if(b->comm && b->rank == 0) {
+            for(int r = 1; r < b->world; r++) {
+                HIPCHK(hipMemcpy(reg.data(), b->recv[x][r] + (size_t)i * b->E, b->E, hipMemcpyDeviceToHost));
+                const md_tile_seg *ts = (const md_tile_seg *)(reg.data() + b->off_seg); uint64_t tot = 0;
+                for(int64_t t = 0; t < b->tcap; t++) tot += ts[t].cnt;
+                if(!tot) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "bench: nothing was received from rank %d", r); return MDK_ERR_ARG; }
+            }
         }
     }
     return 0;

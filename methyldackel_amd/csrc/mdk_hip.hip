@@ -268,8 +268,9 @@ __device__ __forceinline__ void build_lists(const KParams &P, int PER, int tid, 
     lds_barrier();
 }
 
+// one workgroup, one tile `t` of the interval P describes (b: the workgroup's index in the launch, for the phase profile only)
 template <bool VARIANT>
-__global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
+__device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const int b) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int TILE = P.tile, PER = TILE / WG;
     uint32_t *cm = lds, *cu = lds + TILE, *co = lds + 2 * TILE, *cv = lds + 3 * TILE;
@@ -277,14 +278,11 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
     __shared__ int wsum[WAVES];
     __shared__ uint32_t sbase;
 
-    const int b = blockIdx.x;
-    const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
-    if(t >= P.ntiles) return;
     const int64_t T0 = P.beg + (int64_t)t * TILE;
     const int64_t T1 = (T0 + TILE < P.end) ? T0 + TILE : P.end;
     const int tlen = (int)(T1 - T0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if(b == 0 && tid == 0) *P.total_next = 0;    // the counter the NEXT launch on this stream will use
+    if(t == 0 && tid == 0) *P.total_next = 0;    // the counter the NEXT launch of this slot will use
 
     unsigned long long tr0 = 0, tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
     if(P.dbg) { tr0 = wall_clock64(); tc0 = clock64(); }
@@ -365,6 +363,30 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
             d[0] = tr0; d[1] = wall_clock64(); d[2] = tc1 - tc0; d[3] = tc2 - tc1; d[4] = tc3 - tc2; d[5] = tc4 - tc3; d[6] = (unsigned long long)(last - first); d[7] = (unsigned long long)t;
         }
     }
+}
+
+template <bool VARIANT>
+__global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
+    const int b = blockIdx.x;
+    const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
+    if(t >= P.ntiles) return;
+    pileup_tile<VARIANT>(P, t, b);
+}
+
+// Several intervals (chunks of the reference's schedule, each with its own reads, outputs and site counter) in ONE launch:
+// a 1 Mb chunk is 489 tiles -- fewer than two workgroups per CU, one short generation whose dispatch ramp and barrier tail
+// are a third of its time -- so resident chunks are launched MAXM at a time.  The per-interval parameters travel in the
+// kernel arguments; a workgroup finds its interval from the tile prefix.
+#define MAXM 8
+struct KMulti { int n, nper; int tstart[MAXM + 1]; KParams P[MAXM]; };
+template <bool VARIANT>
+__global__ __launch_bounds__(WG, 8) void k_pileup_multi(const KMulti M) {
+    const int b = blockIdx.x;
+    const int tg = (b & 7) * M.nper + (b >> 3);
+    if(tg >= M.tstart[M.n]) return;
+    int j = 0;
+    while(j + 1 < M.n && tg >= M.tstart[j + 1]) j++;
+    pileup_tile<VARIANT>(M.P[j], tg - M.tstart[j], b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -557,8 +579,8 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     h->variant = cfg->minOppositeDepth > 0;
     while(fixed_lds(h->tile, h->variant) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
     if(fixed_lds(h->tile, h->variant) > 65536) {    // more than the default dynamic-LDS window: opt in
-        if(h->variant) HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true)));
-        else HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false)));
+        if(h->variant) { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true))); }
+        else { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); }
     }
     h->slots.resize(h->n_slots);
     for(auto &s : h->slots) {
@@ -741,6 +763,50 @@ extern "C" int md_dev_launch(md_dev *h, int slot) {
     s->launched = true;
     return 0;
 }
+
+// One kernel launch over up to MAXM uploaded slots (see k_pileup_multi).  The launch goes to the first slot's stream, ordered
+// after whatever the other slots' streams still have queued (their uploads / preparation); every slot's stream then waits
+// for it, so download / wait per slot work as after md_dev_launch.
+int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cross_sync) {
+    if(!h || !slots || n < 1 || n > MAXM) return fail(MDK_ERR_ARG, "md_dev_launch_group: 1..8 slots", hipSuccess);
+    static_assert(sizeof(KMulti) <= 4096, "kernel arguments are limited to 4 KiB");
+    KMulti M; memset(&M, 0, sizeof(M));
+    Slot *s0 = get_slot(h, slots[0]); if(!s0) return MDK_ERR_ARG;
+    hipStream_t st = on ? on : s0->stream;
+    int total = 0;
+    for(int i = 0; i < n; i++) {
+        Slot *s = get_slot(h, slots[i]);
+        if(!s || !s->uploaded) return fail(MDK_ERR_ARG, "md_dev_launch_group: slot not uploaded", hipSuccess);
+        for(int k = 0; k < i; k++) if(slots[k] == slots[i]) return fail(MDK_ERR_ARG, "md_dev_launch_group: a slot is listed twice", hipSuccess);
+        if(s->tile != s0->tile) return fail(MDK_ERR_ARG, "md_dev_launch_group: slots of different tile size", hipSuccess);
+        s->ring++;
+        int rc = fill_kparams(h, s, M.P[i]); if(rc) return rc;
+        M.tstart[i] = total; total += s->ntiles > 0 ? s->ntiles : 0;
+        if(s->ntiles <= 0) HIPCHK(hipMemsetAsync(s->d_total.p, 0, sizeof(uint32_t) * RING, s->stream));
+        if(cross_sync && s->stream != st) { HIPCHK(hipEventRecord(s->e0, s->stream)); HIPCHK(hipStreamWaitEvent(st, s->e0, 0)); }
+    }
+    M.n = n; M.tstart[n] = total; M.nper = (total + 7) / 8;
+    if(total > 0) {
+        if(h->variant) hipLaunchKernelGGL(k_pileup_multi<true>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
+        else hipLaunchKernelGGL(k_pileup_multi<false>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
+        HIPCHK(hipGetLastError());
+    }
+    if(cross_sync) {
+        HIPCHK(hipEventRecord(s0->e1, st));
+        for(int i = 0; i < n; i++) { Slot *s = get_slot(h, slots[i]); if(s->stream != st) HIPCHK(hipStreamWaitEvent(s->stream, s0->e1, 0)); }
+    }
+    for(int i = 0; i < n; i++) get_slot(h, slots[i])->launched = true;
+    return 0;
+}
+// One kernel launch over up to MAXM uploaded slots (see k_pileup_multi).  The launch goes to the first slot's stream, ordered
+// after whatever the other slots' streams still have queued (their uploads / preparation); every slot's stream then waits
+// for it, so download / wait per slot work as after md_dev_launch.
+extern "C" int md_dev_launch_group(md_dev *h, const int *slots, int n) {
+    if(!h) return fail(MDK_ERR_ARG, "md_dev_launch_group", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    return launch_group_on(h, slots, n, nullptr, true);
+}
+extern "C" int md_dev_group_max(void) { return MAXM; }
 
 extern "C" int md_dev_submit(md_dev *h, int slot, const md_read_batch *b) {
     int rc = md_dev_upload(h, slot, b);
@@ -1004,8 +1070,8 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
 // Several uploaded slots (distinct intervals, all resident) launched round robin on ONE stream between two HIP events:
 // the per-launch time of the pileup kernel when its inputs stream from HBM (the slots together exceed the 256 MiB
 // Infinity Cache) instead of being re-read from cache as in md_dev_bench.
-extern "C" int md_dev_bench_rotate(md_dev *h, const int *slots, int n, int warmup, int iters, md_bench_result *out) {
-    if(!h || !slots || n < 1 || iters < 1 || !out) return fail(MDK_ERR_ARG, "md_dev_bench_rotate", hipSuccess);
+extern "C" int md_dev_bench_rotate(md_dev *h, const int *slots, int n, int per_launch, int warmup, int iters, md_bench_result *out) {
+    if(!h || !slots || n < 1 || iters < 1 || !out || per_launch < 1 || per_launch > MAXM || n % per_launch) return fail(MDK_ERR_ARG, "md_dev_bench_rotate", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
     memset(out, 0, sizeof(*out));
     uint64_t bytes = 0, sites = 0;
@@ -1018,17 +1084,19 @@ extern "C" int md_dev_bench_rotate(md_dev *h, const int *slots, int n, int warmu
         bytes += s->read_bytes + (uint64_t)(s->end - s->beg) + (uint64_t)tmp.n_sites * (h->variant ? 16 : 8);
     }
     Slot *s0 = get_slot(h, slots[0]);
-    for(int i = 0; i < warmup; i++) { int rc = launch_kernels(h, get_slot(h, slots[i % n]), false, s0->stream); if(rc) return rc; }
+    const int groups = n / per_launch;
+    auto go = [&](int g) -> int { return per_launch == 1 ? launch_kernels(h, get_slot(h, slots[g % n]), false, s0->stream) : launch_group_on(h, slots + (g % groups) * per_launch, per_launch, s0->stream, false); };
+    for(int i = 0; i < warmup; i++) { int rc = go(i); if(rc) return rc; }
     HIPCHK(hipStreamSynchronize(s0->stream));
     float ms = 0;
     HIPCHK(hipEventRecord(s0->k0, s0->stream));
-    for(int i = 0; i < iters; i++) { int rc = launch_kernels(h, get_slot(h, slots[i % n]), false, s0->stream); if(rc) return rc; }
+    for(int i = 0; i < iters; i++) { int rc = go(i); if(rc) return rc; }
     HIPCHK(hipEventRecord(s0->k1, s0->stream));
     HIPCHK(hipEventSynchronize(s0->k1));
     HIPCHK(hipEventElapsedTime(&ms, s0->k0, s0->k1));
     out->ms_pileup = ms / (float)iters; out->ms_total = out->ms_pileup;
-    out->algo_bytes = bytes / (uint64_t)n; out->n_sites = sites / (uint64_t)n;       // per launch, averaged over the rotation
-    out->tile = s0->tile; out->n_tiles = s0->ntiles; out->lds_bytes = s0->lds_bytes;
+    out->algo_bytes = bytes / (uint64_t)groups; out->n_sites = sites / (uint64_t)groups;       // per launch, averaged over the rotation
+    out->tile = s0->tile; out->n_tiles = s0->ntiles * per_launch; out->lds_bytes = s0->lds_bytes;
     return 0;
 }
 

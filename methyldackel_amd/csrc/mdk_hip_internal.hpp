@@ -82,6 +82,7 @@ struct md_dev {
 
 MDK_HIDDEN Slot *get_slot(md_dev *h, int slot);
 MDK_HIDDEN int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on = nullptr);
+MDK_HIDDEN int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cross_sync);
 MDK_HIDDEN int64_t finish_count(md_dev *h, Slot *s);
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s);
 #endif

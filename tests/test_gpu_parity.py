@@ -309,3 +309,38 @@ def test_tile_geometry_is_what_was_asked_for():
         dev = mdk.Device(cfg, device=0)
         assert mdk.lib_hip().md_dev_tile(dev.h) == want, ask
         dev.close()
+
+
+def test_group_launch_equals_single_launches(tmp_path):
+    """md_dev_launch_group: one kernel over several uploaded chunks (k_pileup_multi) gives every chunk exactly the sites its own
+    launch gives; device-prepared and host-prepared slots mixed, empty chunk included"""
+    synth(tmp_path / "g", "-L", "30000,2000", "-c", "20", "-s", "77", "--extras")
+    args = [str(tmp_path / "g.fa"), str(tmp_path / "g.bam"), "--CHG", "--chunkSize", "4000", "--minOppositeDepth", "2", "-o", str(tmp_path / "x")]
+    ph, pd = mdk.Plan(args), mdk.Plan(args)
+    pd.set_prep(1)
+    cfg = ph.dev_cfg(); cfg.n_slots = 8
+    dev = mdk.Device(cfg); dev.set_prep(pd.prep_cfg())
+    assert dev.L.md_dev_group_max() == 8
+
+    def sl(s):
+        return [(s.site[i].pos, s.site[i].nmeth, s.site[i].nunmeth, s.site[i].meta, s.var[i].noff, s.var[i].nvar) for i in range(s.n_sites)]
+    want, k, total = [], 0, 0
+    while k < 8:
+        ch, cd = ph.next_chunk(), pd.next_chunk()
+        assert ch is not None
+        ph.ensure_reference(dev, ch.tid)
+        if k % 2:
+            dev.upload(k, ch.batch)
+        else:
+            dev.upload_raw(k, cd.raw)
+        dev.launch(k)
+        want.append(sl(dev.download(k)))
+        k += 1
+    for group in ([0, 1, 2, 3, 4, 5, 6, 7], [7, 3, 5], [2], [6, 0]):
+        dev.launch_group(group)
+        for j in group:
+            got = sl(dev.download(j))
+            assert got == want[j], (group, j)
+            total += len(got)
+    assert total > 2000
+    dev.close(); ph.close(); pd.close()

@@ -21,9 +21,12 @@ def child(a):
         c = plan.next_chunk(); plan.ensure_reference(dev, c.tid); dev.upload_raw(i, c.raw); dev.launch(i); dev.download(i)
     one = dev.bench(0, 10, 300)
     rot = dev.bench_rotate(list(range(R)), 2 * R, 50 * R)
+    K = int(os.environ.get("KB_GROUP", "8"))
+    grp = dev.bench_rotate(list(range(R)), 8, 100, per_launch=K) if R % K == 0 and R >= K else None
     pm = C.c_float(0); dev.L.md_dev_bench_prep(dev.h, 0, 3, 20, C.byref(pm))
     print(json.dumps({"cached_us": round(one.ms_pileup * 1e3, 2), "hbm_us": round(rot.ms_pileup * 1e3, 2), "algo_MB": round(rot.algo_bytes / 1e6, 2),
-                      "frac_hbm": round(rot.algo_bytes / (rot.ms_pileup / 1e3) / 8e12, 4), "tile": one.tile, "tiles": one.n_tiles, "sites": int(rot.n_sites), "prep_us": round(pm.value * 1e3, 1)}))
+                      "frac_hbm": round(rot.algo_bytes / (rot.ms_pileup / 1e3) / 8e12, 4), "tile": one.tile, "tiles": one.n_tiles, "sites": int(rot.n_sites), "prep_us": round(pm.value * 1e3, 1),
+                      "group": None if grp is None else {"chunks": K, "us_per_launch": round(grp.ms_pileup * 1e3, 1), "us_per_chunk": round(grp.ms_pileup * 1e3 / K, 2), "frac_hbm": round(grp.algo_bytes / (grp.ms_pileup / 1e3) / 8e12, 4)}}))
     dev.close(); plan.close()
 
 
