@@ -18,7 +18,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 REPO = ROOT.parent
-BUILD = ROOT / "_build"
+BUILD = Path(os.environ["MDK_BUILD_DIR"]) if os.environ.get("MDK_BUILD_DIR") else ROOT / "_build"      # MDK_BUILD_DIR: experiment builds (tools/kbench.py)
 LIB_HIP = BUILD / "libmdk_hip.so"
 LIB_EXTRACT = BUILD / "libmdk_extract.so"
 CLI = BUILD / "MethylDackel"

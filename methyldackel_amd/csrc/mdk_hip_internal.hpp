@@ -9,7 +9,9 @@
 #include <vector>
 #include "mdk_hip.h"
 
+#ifndef WG
 #define WG 512
+#endif
 #define WAVES (WG / 64)
 #define RING 64                    // site counters: launch i uses counter i%RING and clears the next one
 

@@ -31,11 +31,17 @@ def counters(d, match):
     return agg
 
 
-pmc = {}
+pmc, pmc_single = {}, {}
 for d in ("sq", "fetch", "write_lds", "cache"):
-    for k, v in counters("prof_pmc_" + d, ["k_pileup"])["k_pileup"].items():
+    c = counters("prof_pmc_" + d, ["k_pileup_multi", "k_pileup<"])
+    for k, v in c["k_pileup_multi"].items():
         pmc[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
-out = {"kernel": "k_pileup<false>", "command": "python bench.py --no-cpu-baseline --steps 2 --warmup 1 --passes 4 (16 resident 1 Mb intervals in rotation, ~0.8 GB working set; one rocprofv3 --pmc pass per counter group)", "counters": pmc}
+    for k, v in c["k_pileup<"].items():
+        pmc_single[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
+CHUNKS = 8
+out = {"kernel": "k_pileup_multi<false> (8 resident 1 Mb chunks per launch)", "chunks_per_launch": CHUNKS,
+       "command": "python bench.py --no-cpu-baseline --steps 2 --warmup 1 --passes 4 (16 resident 1 Mb intervals in rotation, ~1 GB working set; one rocprofv3 --pmc pass per counter group)",
+       "counters": pmc, "counters_one_chunk_per_launch_k_pileup": pmc_single}
 
 # calibration: bytes of the distinct 64-byte lines each calibration kernel touches / what the counter reported (KiB)
 calib = {}
@@ -64,7 +70,8 @@ if "FETCH_SIZE" in pmc:
     out["hbm_traffic_bytes_per_launch"] = {
         "fetch_raw": fs * 1024, "write_raw": ws * 1024, "fetch_factor": ff, "write_factor": wf,
         "fetch_calibrated": fs * 1024 * (ff if ff else 2.0), "write_calibrated": ws * 1024 * (wf if wf else 1.0),
-        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) per k_pileup dispatch while rotating over 16 resident 1 Mb intervals (working set ~0.8 GB, beyond the "
+        "per_chunk": {"fetch_calibrated": fs * 1024 * (ff if ff else 2.0) / CHUNKS, "write_calibrated": ws * 1024 * (wf if wf else 1.0) / CHUNKS},
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) per k_pileup_multi dispatch (8 chunks) while rotating over 16 resident 1 Mb intervals (working set ~0.8 GB, beyond the "
                 "256 MiB Infinity Cache), multiplied by the factors tools/mdk_calib measured on this box for this kernel's own access patterns: FETCH_SIZE x %s "
                 "(calib_gather_pair: a sequence byte and a quality byte ~80 B apart per 228-byte read payload, 1 GiB buffer).  The calibration shows the memory side "
                 "moves 128-byte granules and the counter tallies each as 64 bytes: one byte from every 64-byte line and one byte from every second line both read as "
