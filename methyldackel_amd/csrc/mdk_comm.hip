@@ -230,7 +230,9 @@ static int bench_exchange(md_bench *b, int x) {
 }
 static int bench_collect(md_bench *b, int64_t g, int64_t *sites) {
     const int *gs = b->slots.data() + (g % b->ngroups) * b->group;
-    for(int i = 0; i < b->group; i++) { int64_t c = finish_count(b->h, get_slot(b->h, gs[i])); if(c < 0) return (int)c; *sites = c; }
+    int64_t counts[16];
+    int rc = finish_group(b->h, gs, b->group, counts); if(rc) return rc;
+    *sites = counts[b->group - 1];
     return bench_exchange(b, (int)(g & 1));
 }
 

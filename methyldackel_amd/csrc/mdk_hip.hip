@@ -583,12 +583,14 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
         else { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); }
     }
     h->slots.resize(h->n_slots);
+    if(h->d_status.need((size_t)h->n_slots) || h->h_status.need((size_t)h->n_slots)) return MDK_ERR_NOMEM;
+    HIPCHK(hipMemset(h->d_status.p, 0, sizeof(SlotStatus) * (size_t)h->n_slots));
+    memset(h->h_status.p, 0, sizeof(SlotStatus) * (size_t)h->n_slots);
+    for(int i = 0; i < h->n_slots; i++) { Slot &s = h->slots[i]; s.index = i; s.d_total.p = h->d_status.p[i].total; s.d_err.p = &h->d_status.p[i].err; s.d_pcnt.p = &h->d_status.p[i].pc; s.h_st.p = &h->h_status.p[i]; }
     for(auto &s : h->slots) {
         HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         HIPCHK(hipEventCreate(&s.e0)); HIPCHK(hipEventCreate(&s.e1)); HIPCHK(hipEventCreate(&s.k0)); HIPCHK(hipEventCreate(&s.k1));
-        if(s.d_err.need(1) || s.h_err.need(1) || s.d_total.need(RING) || s.h_total.need(1)) return MDK_ERR_NOMEM;
-        HIPCHK(hipMemset(s.d_err.p, 0, sizeof(int)));
-        HIPCHK(hipMemset(s.d_total.p, 0, sizeof(uint32_t) * RING));
+        s.run = s.stream;
     }
     *out = h;
     return 0;
@@ -601,13 +603,14 @@ extern "C" void md_dev_close(md_dev *h) {
     for(auto &s : h->slots) {
         s.d_seg_in.release(); s.d_blob.release(); s.d_tiles.release(); s.h_tiles.release();
         s.d_raw.release(); s.d_recoff.release(); s.d_prec.release(); s.d_hash.release(); s.d_blk.release(); s.d_prd.release(); s.d_mate.release(); s.d_second.release();
-        s.d_segcnt.release(); s.d_hkey.release(); s.d_hhead.release(); s.d_hnext.release(); s.d_pcnt.release(); s.h_pcnt.release();
+        s.d_segcnt.release(); s.d_hkey.release(); s.d_hhead.release(); s.d_hnext.release();
         s.d_pr.release(); s.d_cig.release(); s.d_prc.release(); s.h_prc.release();
-        s.d_site.release(); s.d_var.release(); s.d_seg.release(); s.d_total.release(); s.d_err.release();
-        s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release(); s.h_total.release(); s.h_err.release();
+        s.d_site.release(); s.d_var.release(); s.d_seg.release();
+        s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release();
         if(s.e0) (void)hipEventDestroy(s.e0); if(s.e1) (void)hipEventDestroy(s.e1); if(s.k0) (void)hipEventDestroy(s.k0); if(s.k1) (void)hipEventDestroy(s.k1);
         if(s.stream) (void)hipStreamDestroy(s.stream);
     }
+    h->d_status.release(); h->h_status.release();
     if(h->d_hist) (void)hipFree(h->d_hist);
     for(uint32_t *p : h->mapbits) if(p) (void)hipFree(p);
     for(md_region *p : h->d_runs) if(p) (void)hipFree(p);
@@ -685,6 +688,8 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(g_err, sizeof(g_err), "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));          // the slot's previous contents are being replaced
+    if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
+    s->fresh = true;
     const int64_t span = b->end - b->beg;
     s->n_segs = b->n_segs; s->n_reads = b->n_reads; s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->uploaded = false; s->launched = false; s->raw_layout = false;
     const int TILE = h->tile;
@@ -739,6 +744,8 @@ static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
 // `on` = stream to launch on (the slot's own unless a benchmark lines several slots up on one stream)
 int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on) {
     hipStream_t st = on ? on : s->stream;
+    if(s->fresh && st != s->stream) { HIPCHK(hipEventRecord(s->e0, s->stream)); HIPCHK(hipStreamWaitEvent(st, s->e0, 0)); }      // the slot's upload / preparation comes first
+    s->fresh = false; s->run = st;
     s->ring++;                                          // a fresh (already zero) site counter for this launch
     if(s->ntiles > 0) {
         KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
@@ -782,8 +789,9 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
         s->ring++;
         int rc = fill_kparams(h, s, M.P[i]); if(rc) return rc;
         M.tstart[i] = total; total += s->ntiles > 0 ? s->ntiles : 0;
-        if(s->ntiles <= 0) HIPCHK(hipMemsetAsync(s->d_total.p, 0, sizeof(uint32_t) * RING, s->stream));
-        if(cross_sync && s->stream != st) { HIPCHK(hipEventRecord(s->e0, s->stream)); HIPCHK(hipStreamWaitEvent(st, s->e0, 0)); }
+        if(s->ntiles <= 0) HIPCHK(hipMemsetAsync(s->d_total.p, 0, sizeof(uint32_t) * RING, st));
+        if(cross_sync && s->fresh && s->stream != st) { HIPCHK(hipEventRecord(s->e0, s->stream)); HIPCHK(hipStreamWaitEvent(st, s->e0, 0)); }      // its upload / preparation comes first
+        s->fresh = false; s->run = st;
     }
     M.n = n; M.tstart[n] = total; M.nper = (total + 7) / 8;
     if(total > 0) {
@@ -791,11 +799,7 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
         else hipLaunchKernelGGL(k_pileup_multi<false>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
         HIPCHK(hipGetLastError());
     }
-    if(cross_sync) {
-        HIPCHK(hipEventRecord(s0->e1, st));
-        for(int i = 0; i < n; i++) { Slot *s = get_slot(h, slots[i]); if(s->stream != st) HIPCHK(hipStreamWaitEvent(s->stream, s0->e1, 0)); }
-    }
-    for(int i = 0; i < n; i++) get_slot(h, slots[i])->launched = true;
+    for(int i = 0; i < n; i++) get_slot(h, slots[i])->launched = true;      // collected through each slot's `run` stream (finish_count)
     return 0;
 }
 // One kernel launch over up to MAXM uploaded slots (see k_pileup_multi).  The launch goes to the first slot's stream, ordered
@@ -919,14 +923,9 @@ extern "C" int md_dev_perread_download(md_dev *h, int slot, const md_pr_count **
     return 0;
 }
 
-// wait for the launch, read the total, check the error word
-int64_t finish_count(md_dev *h, Slot *s) {
-    if(!s->launched) { fail(MDK_ERR_ARG, "slot not launched", hipSuccess); return MDK_ERR_ARG; }
-    if(hipMemcpyAsync(s->h_total.p, s->d_total.p + (s->ring % RING), sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H total", hipGetLastError());
-    if(hipMemcpyAsync(s->h_err.p, s->d_err.p, sizeof(int), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H err", hipGetLastError());
-    if(s->raw_layout && hipMemcpyAsync(s->h_pcnt.p, s->d_pcnt.p, sizeof(PrepCounters), hipMemcpyDeviceToHost, s->stream) != hipSuccess) return fail(MDK_ERR_HIP, "D2H preparation counters", hipGetLastError());
-    hipError_t e = hipStreamSynchronize(s->stream);
-    if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
+// what a launch left for the host: the status block is already in h_st
+static int64_t finish_eval(md_dev *h, Slot *s) {
+    const SlotStatus &st = *s->h_st.p;
     if(s->raw_layout) {
         int rc = prep_outcome(h, s);
         if(rc == MDK_ERR_PREP_REDO) {            // the segment array was too small: preparation is queued again, the pileup follows it
@@ -935,11 +934,35 @@ int64_t finish_count(md_dev *h, Slot *s) {
         }
         if(rc) return rc;
     }
-    if(s->h_err.p[0]) { snprintf(g_err, sizeof(g_err), "Can't determine the strand of a read!"); (void)hipMemset(s->d_err.p, 0, sizeof(int)); return MDK_ERR_STRAND0; }
-    int64_t n = (int64_t)s->h_total.p[0];
+    if(st.err) { snprintf(g_err, sizeof(g_err), "Can't determine the strand of a read!"); (void)hipMemset(s->d_err.p, 0, sizeof(int)); return MDK_ERR_STRAND0; }
+    int64_t n = (int64_t)st.total[s->ring % RING];
     int64_t cap = s->b_site ? s->b_cap_sites : (int64_t)s->d_site.cap;
     if(n > cap) { snprintf(g_err, sizeof(g_err), "site buffer too small: %lld sites, capacity %lld", (long long)n, (long long)cap); return MDK_ERR_ARG; }
     return n;
+}
+// wait for the launch, read the status block (site count, error word, preparation counters) with one copy
+int64_t finish_count(md_dev *h, Slot *s) {
+    if(!s->launched) { fail(MDK_ERR_ARG, "slot not launched", hipSuccess); return MDK_ERR_ARG; }
+    hipStream_t st = s->run ? s->run : s->stream;
+    if(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MDK_ERR_HIP, "D2H status", hipGetLastError());
+    hipError_t e = hipStreamSynchronize(st);
+    if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
+    return finish_eval(h, s);
+}
+// the same for the slots of one group launch: one copy covering all of them
+int finish_group(md_dev *h, const int *slots, int n, int64_t *counts) {
+    int lo = 0x7fffffff, hi = -1; hipStream_t st = nullptr;
+    for(int i = 0; i < n; i++) {
+        Slot *s = get_slot(h, slots[i]); if(!s || !s->launched) return fail(MDK_ERR_ARG, "slot not launched", hipSuccess);
+        if(i == 0) st = s->run; else if(s->run != st) st = nullptr;
+        lo = std::min(lo, s->index); hi = std::max(hi, s->index);
+    }
+    if(!st) { for(int i = 0; i < n; i++) { int64_t c = finish_count(h, get_slot(h, slots[i])); if(c < 0) return (int)c; counts[i] = c; } return 0; }
+    if(hipMemcpyAsync(h->h_status.p + lo, h->d_status.p + lo, sizeof(SlotStatus) * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MDK_ERR_HIP, "D2H status", hipGetLastError());
+    hipError_t e = hipStreamSynchronize(st);
+    if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
+    for(int i = 0; i < n; i++) { int64_t c = finish_eval(h, get_slot(h, slots[i])); if(c < 0) return (int)c; counts[i] = c; }
+    return 0;
 }
 
 extern "C" int md_dev_wait(md_dev *h, int slot, md_sites_dev *out) {

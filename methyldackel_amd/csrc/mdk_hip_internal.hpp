@@ -56,14 +56,20 @@ struct PrepRead { int32_t pos, rend; uint32_t seq_off, lq, cig_off, qn_off; uint
 struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, pad; uint64_t algo_bytes; };
 #define MDK_ERR_PREP_REDO (-100)   // internal: the segment array was enlarged and the preparation re-enqueued
 
+// everything the host reads back after a launch, one block per slot inside ONE device array (and its pinned mirror), so that
+// a launch over several slots is collected with a single copy
+struct SlotStatus { uint32_t total[RING]; int32_t err; uint32_t pad; PrepCounters pc; };
+template <typename T> struct Ref { T *p = nullptr; };        // a view into the status arrays (not owned)
+
 struct Slot {
     hipStream_t stream = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
     DBuf<md_seg> d_seg_in; DBuf<uint8_t> d_blob;
     DBuf<TileEnt> d_tiles; HBuf<TileEnt> h_tiles;
-    DBuf<md_site> d_site; DBuf<md_site_var> d_var; DBuf<md_tile_seg> d_seg; DBuf<uint32_t> d_total; DBuf<int> d_err;
-    HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; HBuf<uint32_t> h_total; HBuf<int> h_err;
+    DBuf<md_site> d_site; DBuf<md_site_var> d_var; DBuf<md_tile_seg> d_seg; Ref<uint32_t> d_total; Ref<int> d_err;
+    HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; Ref<SlotStatus> h_st; int index = 0;
+    hipStream_t run = nullptr; bool fresh = false;       // run: the stream the latest pileup launch went to; fresh: work queued on `stream` that no launch has been ordered after yet
     DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRec> d_prec; DBuf<uint64_t> d_hash; DBuf<uint32_t> d_blk; DBuf<PrepRead> d_prd; DBuf<int32_t> d_mate; DBuf<uint8_t> d_second;
-    DBuf<uint32_t> d_segcnt; DBuf<uint64_t> d_hkey; DBuf<int32_t> d_hhead, d_hnext; DBuf<PrepCounters> d_pcnt; HBuf<PrepCounters> h_pcnt;
+    DBuf<uint32_t> d_segcnt; DBuf<uint64_t> d_hkey; DBuf<int32_t> d_hhead, d_hnext; Ref<PrepCounters> d_pcnt;
     uint32_t hmask = 0; int pr_nrec = 0; uint64_t raw_bytes = 0; bool raw_layout = false; int64_t woff = 0, wlen = 0;
     DBuf<md_pr_read> d_pr; DBuf<uint32_t> d_cig; DBuf<md_pr_count> d_prc; HBuf<md_pr_count> h_prc; int pr_n = -1;      // perRead
     // caller-bound output (device memory owned by the caller)
@@ -76,6 +82,7 @@ struct md_dev {
     int device; md_dev_cfg cfg; int tile, n_slots; bool variant;
     std::vector<Slot> slots;
     std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
+    DBuf<SlotStatus> d_status; HBuf<SlotStatus> h_status;
     md_prep_cfg prep; bool prep_set = false; std::vector<uint32_t *> mapbits; std::vector<int64_t> maplen;
     std::vector<md_region *> d_runs; std::vector<int64_t> n_runs; std::vector<char> has_runs;       // -l runs kept for the read prefilter
     uint32_t *d_hist = nullptr; int hist_cap = 0, hist_len = 0; std::vector<uint32_t> h_hist;      // mbias: rows [q][16], q < hist_cap
@@ -86,5 +93,6 @@ MDK_HIDDEN Slot *get_slot(md_dev *h, int slot);
 MDK_HIDDEN int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on = nullptr);
 MDK_HIDDEN int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cross_sync);
 MDK_HIDDEN int64_t finish_count(md_dev *h, Slot *s);
+MDK_HIDDEN int finish_group(md_dev *h, const int *slots, int n, int64_t *counts);
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s);
 #endif

@@ -500,6 +500,8 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
+    s->fresh = true;
     uint64_t total = 0;
     for(int i = 0; i < b->n_ranges; i++) total += b->range[i].bytes;
     if(total >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_upload_raw: more than 4 GiB of records in one chunk", hipSuccess);
@@ -512,7 +514,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
     s->hmask = pow2_at_least(nn * 2) - 1;
     if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prec.need(nn) || s->d_hash.need(nn) || s->d_blk.need(4 * (size_t)(nb + 1)) ||
-       s->d_prd.need(nn) || s->d_mate.need(nn) || s->d_second.need(nn) || s->d_segcnt.need(nn) || s->d_hnext.need(nn) || s->d_pcnt.need(1) || s->h_pcnt.need(1) ||
+       s->d_prd.need(nn) || s->d_mate.need(nn) || s->d_second.need(nn) || s->d_segcnt.need(nn) || s->d_hnext.need(nn) ||
        s->d_hkey.need((size_t)s->hmask + 1) || s->d_hhead.need((size_t)s->hmask + 1) || s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
     if(!s->b_site) {
         if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
@@ -538,15 +540,17 @@ extern "C" int md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b) {
 // after the slot's stream has drained: what the preparation found.  MDK_ERR_PREP_REDO: the segment array was too small and
 // has been enlarged -- the caller (finish_count) runs preparation + pileup again on the resident records.
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s) {
-    const PrepCounters &c = *s->h_pcnt.p;
+    const PrepCounters &c = s->h_st.p->pc;
     if(c.malformed) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "malformed BAM record in the chunk"); return MDK_ERR_ARG; }
     if(c.strand0) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "Can't determine the strand of a read!"); return MDK_ERR_STRAND0; }
     if(c.fallback) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "a read name with more than %d records or %d live reads: this chunk needs the host preparation", MAXG, MAXLIVE); return MDK_ERR_PREP_HOST; }
     s->n_reads = (int)c.n_adm; s->n_segs = (int)c.n_segs; s->read_bytes = c.algo_bytes;
     if((size_t)c.n_segs > s->d_seg_in.cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
+        if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
         if(s->d_seg_in.need((size_t)c.n_segs + 64)) return MDK_ERR_NOMEM;
         int rc = enqueue_prep(h, s); if(rc) return rc;
+        s->fresh = true;
         return MDK_ERR_PREP_REDO;
     }
     return 0;
@@ -564,6 +568,7 @@ extern "C" int md_dev_bench_prep(md_dev *h, int slot, int warmup, int iters, flo
     HIPCHK(hipEventRecord(s->k1, s->stream));
     HIPCHK(hipEventSynchronize(s->k1));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, s->k0, s->k1));
+    s->fresh = true;
     *ms_per_chunk = ms / (float)iters;
     return 0;
 }
@@ -575,9 +580,9 @@ extern "C" int md_dev_debug_segments(md_dev *h, int slot, md_seg *out, int64_t c
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     if(s->raw_layout) {
-        HIPCHK(hipMemcpy(s->h_pcnt.p, s->d_pcnt.p, sizeof(PrepCounters), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&s->h_st.p->pc, s->d_pcnt.p, sizeof(PrepCounters), hipMemcpyDeviceToHost));
         int rc = prep_outcome(h, s);
-        if(rc == MDK_ERR_PREP_REDO) { HIPCHK(hipStreamSynchronize(s->stream)); HIPCHK(hipMemcpy(s->h_pcnt.p, s->d_pcnt.p, sizeof(PrepCounters), hipMemcpyDeviceToHost)); rc = prep_outcome(h, s); }
+        if(rc == MDK_ERR_PREP_REDO) { HIPCHK(hipStreamSynchronize(s->stream)); HIPCHK(hipMemcpy(&s->h_st.p->pc, s->d_pcnt.p, sizeof(PrepCounters), hipMemcpyDeviceToHost)); rc = prep_outcome(h, s); }
         if(rc) return rc;
     }
     *n_segs = s->n_segs; if(n_reads) *n_reads = s->n_reads;
