@@ -6,7 +6,7 @@ Metric (BASELINE.json): CpG calls/s, synthetic 30x paired-end WGBS, CpG-only ext
 Workload.  Every rank holds R (default 16) DIFFERENT S1-sized intervals resident in HBM: the R chunks the reference's
 schedule (1 Mb chunks, extract.c:325-350) cuts out of an R Mb synthetic contig, each about 52 MB of admitted reads, about
 0.8 GB together -- beyond the 256 MiB Infinity Cache, so every launch streams its inputs from HBM.  One STEP is one pass of
-the hot path over a batch of P x R chunks (default P = 256: 4096 chunk launches), i.e. the R resident intervals presented P
+the hot path over a batch of P x R chunks (default P = 384: 6144 chunks in 768 kernel launches), i.e. the R resident intervals presented P
 times in rotation.  Inside a step every launch is issued and collected (site count read back) with two launches in flight,
 exactly as extract_main drives the device; with N ranks the kernels write into send buffers and the results of 8
 consecutive launches travel to rank 0 with one ncclSend/ncclRecv exchange (libmdk_hip's md_comm, RCCL over xGMI) while the
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--resident", type=int, default=16, help="R: resident 1 Mb intervals per rank (R x ~52 MB must exceed the 256 MiB Infinity Cache)")
-    ap.add_argument("--passes", type=int, default=256, help="P: a step presents the R resident intervals P times (P x R chunk launches)")
+    ap.add_argument("--passes", type=int, default=384, help="P: a step presents the R resident intervals P times (P x R chunk launches)")
     ap.add_argument("--length", type=int, default=1_000_000, help="interval (chunk) length; S1 = 1 Mb")
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--extra", default="", help="extra extract options, e.g. '--CHG --CHH' (not the headline config)")

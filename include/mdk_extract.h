@@ -62,6 +62,9 @@ int  mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c);
  * Must be called before the first mdk_plan_next_chunk.  mdk_plan_host_prepare fills `batch` of a mode-1 chunk after all
  * (for a chunk the device answered with MDK_ERR_PREP_HOST); valid until the second-next mdk_plan_next_chunk. */
 int  mdk_plan_set_prep(mdk_plan *p, int mode);
+/* how many of the chunks handed out last stay valid (default 2: a chunk's arrays live until the second-next
+ * mdk_plan_next_chunk); a caller that keeps more chunks in flight (several GPUs) raises it first.  2..40. */
+int  mdk_plan_set_hold(mdk_plan *p, int n);
 void mdk_plan_prep_cfg(const mdk_plan *p, md_prep_cfg *cfg);
 int  mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c);
 /* host post-pass for one chunk (variant filter, --mergeContext, formats; extract.c:443-510), appended to

@@ -259,6 +259,10 @@ void md_comm_close(md_comm *c);
 int  md_comm_world(const md_comm *c);
 int  md_comm_gather(md_comm *c, const void *const *d_send, const uint64_t *send_bytes, void *const *d_recv, const uint64_t *recv_bytes);
 int  md_comm_wait(md_comm *c);
+/* md_dev_download for a chunk computed on rank `src` of a LOCAL communicator: its site buffer (records, variant evidence, tile
+ * segments) is gathered to rank 0 over the links and read by the host from rank 0's memory; errors as md_dev_download.  The
+ * returned arrays belong to the communicator and stay valid until the next md_comm_download of the same (src, slot). */
+int  md_comm_download(md_comm *c, int src, int slot, md_sites *out);
 
 /* The resident-input benchmark loop of bench.py: `n` uploaded slots holding different intervals are launched `group` at a
  * time (md_dev_launch_group; n a multiple of group, at least two groups) round robin, two launches in flight (launch g is

@@ -630,12 +630,15 @@ MDK_LOCAL int pipeline_start(mdk_plan *p) {
      * byte of its chunk (expensive to allocate), so the pipeline depth is bounded; -@ still sizes the inflate pool */
     p->n_workers = p->o.n_threads < 1 ? 1 : p->o.n_threads;
     { int cap = getenv("MDK_WORKERS") ? atoi(getenv("MDK_WORKERS")) : 12; if(cap < 1) cap = 1; if(p->n_workers > cap) p->n_workers = cap; }
-    p->n_slot = p->n_workers + 3;
+    if(p->n_hold < 2) p->n_hold = 2;
+    p->n_slot = p->n_workers + 1 + p->n_hold;
     p->slot = calloc((size_t)p->n_slot, sizeof(pslot));
     p->worker_th = calloc((size_t)p->n_workers, sizeof(pthread_t));
     if(!p->slot || !p->worker_th) return -5;
     pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->cv_free, NULL); pthread_cond_init(&p->cv_raw, NULL); pthread_cond_init(&p->cv_done, NULL);
-    p->held[0] = p->held[1] = -1; p->next_out = 0;
+    if(p->n_hold < 2) p->n_hold = 2;
+    for(i = 0; i < p->n_hold; i++) p->held[i] = -1;
+    p->next_out = 0;
     /* workers first: fewer than asked for is fine (they all take chunks from the same queue), none is not */
     for(i = 0; i < p->n_workers; i++) if(pthread_create(&p->worker_th[i], NULL, worker_main, p)) break;
     if(i < p->n_workers) { if(i == 0) { fprintf(stderr, "[mdk] cannot create a worker thread\n"); goto fail; } p->n_workers = i; }
@@ -668,9 +671,12 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
     int i, found = -1, rc = 0;
     if(!p->started && pipeline_start(p)) return -5;
     pthread_mutex_lock(&p->mu);
-    /* the chunk handed out two calls ago is no longer referenced by the caller: recycle its buffers */
-    if(p->held[1] >= 0) { slot_release_slabs(p, &p->slot[p->held[1]]); p->slot[p->held[1]].state = S_FREE; pthread_cond_signal(&p->cv_free); }
-    p->held[1] = p->held[0]; p->held[0] = -1;
+    {   /* the oldest chunk still held is no longer referenced by the caller: recycle its buffers */
+        const int last = p->n_hold - 1;
+        if(p->held[last] >= 0) { slot_release_slabs(p, &p->slot[p->held[last]]); p->slot[p->held[last]].state = S_FREE; pthread_cond_signal(&p->cv_free); }
+        for(i = last; i > 0; i--) p->held[i] = p->held[i - 1];
+        p->held[0] = -1;
+    }
     for(;;) {
         int active = 0;
         for(i = 0; i < p->n_slot; i++) {
@@ -699,7 +705,7 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
 int mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c) {
     int i, rc; pslot *sl = NULL;
     if(!p || !c || !p->started) return -1;
-    for(i = 0; i < 2; i++) if(p->held[i] >= 0 && p->slot[p->held[i]].c.index == c->index) sl = &p->slot[p->held[i]];
+    for(i = 0; i < p->n_hold; i++) if(p->held[i] >= 0 && p->slot[p->held[i]].c.index == c->index) sl = &p->slot[p->held[i]];
     if(!sl || !sl->hold_slabs) return -1;
     if(!sl->prepared) { rc = worker_process(p, sl); if(rc < 0) return rc; sl->prepared = 1; }
     c->batch = sl->c.batch;

@@ -489,6 +489,11 @@ int mdk_plan_set_prep(mdk_plan *p, int mode) {
     p->dev_prep = mode;
     return 0;
 }
+int mdk_plan_set_hold(mdk_plan *p, int n) {
+    if(!p || p->started || n < 2 || n > 40) return -1;
+    p->n_hold = n;
+    return 0;
+}
 void mdk_plan_prep_cfg(const mdk_plan *p, md_prep_cfg *cfg) {
     const opts_t *o = &p->o;
     memset(cfg, 0, sizeof(*cfg));

@@ -99,7 +99,7 @@ struct mdk_plan {
     /* chunk pipeline: reader thread -> worker threads -> ordered delivery (see the pipeline section) */
     struct pslot *slot; int n_slot, n_workers; pthread_t reader_th, *worker_th; int started, quit, pipe_rc, reader_done;
     pthread_mutex_t mu; pthread_cond_t cv_free, cv_raw, cv_done;
-    uint32_t next_out; int held[2];
+    uint32_t next_out; int held[40], n_hold;      /* the chunks handed out last (newest first); the oldest is recycled by the next hand-out */
     /* mappability */
     int map_on; uint32_t map_n; char **map_names; uint32_t *map_len; uint8_t **map_bits; int *map_of_tid;
     /* -l: per contig, the disjoint runs a position must fall in (and the strand a read must have there) */

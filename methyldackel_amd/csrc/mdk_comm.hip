@@ -38,9 +38,11 @@ static int nfail(Rccl *R, const char *what, ncclResult_t r) { snprintf(mdk_err_b
 
 // A communicator over `world` ranks, root 0.  This process drives `n_local` of them: one (its own GPU) when there is one
 // process per GPU, all of them when one process feeds every GPU of the node.
+struct CommStage { DBuf<uint8_t> d; HBuf<uint8_t> raw; HBuf<md_site> site; HBuf<md_site_var> var; };      // where rank 0 receives one (rank, slot)'s result
 struct md_comm {
     int world = 0, n_local = 0; bool copies = false;          // copies: the local ranks share one physical device (tests): plain D2D copies, no RCCL
     std::vector<int> rank; std::vector<md_dev *> dev; std::vector<ncclComm_t> comm; std::vector<hipStream_t> stream; std::vector<hipEvent_t> ev;
+    std::vector<CommStage> stage; int stage_slots = 0;
 };
 
 extern "C" int md_comm_unique_id(uint8_t *id) {
@@ -101,6 +103,7 @@ extern "C" void md_comm_close(md_comm *c) {
         if(i < (int)c->stream.size() && c->stream[i]) { (void)hipStreamSynchronize(c->stream[i]); (void)hipStreamDestroy(c->stream[i]); }
         if(i < (int)c->ev.size() && c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     }
+    if(!c->stage.empty()) { (void)hipSetDevice(c->dev[0]->device); for(auto &g : c->stage) { g.d.release(); g.raw.release(); g.site.release(); g.var.release(); } }
     if(!c->comm.empty()) { Rccl *R = rccl(); if(R) for(ncclComm_t k : c->comm) if(k) (void)R->CommDestroy(k); }
     delete c;
 }
@@ -152,6 +155,44 @@ extern "C" int md_comm_gather(md_comm *c, const void *const *d_send, const uint6
 extern "C" int md_comm_wait(md_comm *c) {
     if(!c) return fail(MDK_ERR_ARG, "md_comm_wait", hipSuccess);
     for(int i = 0; i < c->n_local; i++) { HIPCHK(hipSetDevice(c->dev[i]->device)); HIPCHK(hipEventSynchronize(c->ev[i])); }
+    return 0;
+}
+
+// md_dev_download for a chunk that another GPU of a local communicator computed: the per-interval site buffer travels from
+// rank `src` to rank 0 over the links (site records, variant evidence, tile segments -- one exchange each), and rank 0's host
+// reads it from rank 0's memory.  This is the "RCCL gather of per-interval bedGraph buffers" of the sharded command.
+extern "C" int md_comm_download(md_comm *c, int src, int slot, md_sites *out) {
+    if(!c || !out || src < 0 || src >= c->world || c->n_local != c->world) return fail(MDK_ERR_ARG, "md_comm_download: needs a local communicator", hipSuccess);
+    md_dev *root = c->dev[0], *from = c->dev[src];
+    if(src == 0) return md_dev_download(root, slot, out);
+    memset(out, 0, sizeof(*out));
+    md_sites_dev dv;
+    int rc = md_dev_wait(from, slot, &dv); if(rc) return rc;
+    if(slot >= c->stage_slots) { c->stage_slots = slot + 1; c->stage.resize((size_t)c->world * 64); }
+    if(slot >= 64) return fail(MDK_ERR_ARG, "md_comm_download: slot", hipSuccess);
+    CommStage &g = c->stage[(size_t)src * 64 + slot];
+    const bool variant = dv.d_var != nullptr;
+    const size_t nS = (size_t)dv.n_slots * sizeof(md_site), nV = variant ? (size_t)dv.n_slots * sizeof(md_site_var) : 0, nT = (size_t)dv.n_tiles * sizeof(md_tile_seg);
+    const size_t oV = (nS + 255) & ~(size_t)255, oT = (oV + nV + 255) & ~(size_t)255, tot = oT + nT + 256;
+    HIPCHK(hipSetDevice(root->device));
+    if(g.d.need(tot) || g.raw.need(tot) || g.site.need((size_t)dv.n_slots + 1) || (variant && g.var.need((size_t)dv.n_slots + 1))) return MDK_ERR_NOMEM;
+    const void *parts[3] = {dv.d_site, dv.d_var, dv.d_seg}; const size_t bytes[3] = {nS, nV, nT}, offs[3] = {0, oV, oT};
+    std::vector<const void *> snd((size_t)c->n_local, nullptr); std::vector<uint64_t> sb((size_t)c->n_local, 0);
+    std::vector<void *> rcv((size_t)c->world, nullptr); std::vector<uint64_t> rb((size_t)c->world, 0);
+    for(int k = 0; k < 3; k++) {
+        if(!bytes[k]) continue;
+        snd[src] = parts[k]; sb[src] = bytes[k]; rcv[src] = g.d.p + offs[k]; rb[src] = bytes[k];
+        rc = md_comm_gather(c, snd.data(), sb.data(), rcv.data(), rb.data()); if(rc) return rc;
+    }
+    rc = md_comm_wait(c); if(rc) return rc;
+    HIPCHK(hipSetDevice(root->device));
+    if(nS) HIPCHK(hipMemcpy(g.raw.p, g.d.p, oT + nT, hipMemcpyDeviceToHost));
+    int64_t n = 0;
+    if(dv.n_slots) {
+        n = md_sites_order((const md_site *)g.raw.p, variant ? (const md_site_var *)(g.raw.p + oV) : nullptr, (const md_tile_seg *)(g.raw.p + oT), dv.n_tiles, dv.n_slots, g.site.p, variant ? g.var.p : nullptr);
+        if(n < 0) return fail(MDK_ERR_ARG, "md_comm_download: inconsistent tile segments", hipSuccess);
+    }
+    out->n_sites = n; out->site = g.site.p; out->var = variant ? g.var.p : nullptr;
     return 0;
 }
 

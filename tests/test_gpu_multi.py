@@ -1,0 +1,69 @@
+"""GPU: the sharded command and the exchange layer (csrc/mdk_comm.hip).
+
+`MethylDackel extract` with MDK_GPUS=N feeds N device handles from one host pipeline -- chunk k on rank k mod N -- and brings
+every chunk of rank > 0 back through rank 0 (md_comm_download).  On this box all ranks are the same physical GPU
+(MDK_GPU_MAP=0,0,..), where the exchange is a device copy instead of ncclSend/ncclRecv; everything else -- the schedule, two
+slots per rank, 2N chunks in flight, ordered emission -- is the multi-GPU code path.  RCCL itself is exercised with the one
+communicator a single GPU allows (world size 1)."""
+import ctypes as C
+
+import pytest
+
+import methyldackel_amd as mdk
+from conftest import synth
+from test_gpu_parity import compare_cli
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+@pytest.mark.parametrize("extra", [["--chunkSize", "3000"], ["--CHG", "--CHH", "--mergeContext", "--chunkSize", "5000", "--minOppositeDepth", "2", "--maxVariantFrac", "0.4"]], ids=["cpg", "allctx_merge_variant"])
+def test_sharded_command_byte_exact(tmp_path, small_synth, n, extra):
+    compare_cli(tmp_path, [str(small_synth / "pe.fa"), str(small_synth / "pe.bam")] + extra, env={"MDK_GPUS": str(n), "MDK_GPU_MAP": ",".join(["0"] * n)})
+
+
+def test_sharded_command_with_host_fallback_and_empty_chunks(tmp_path):
+    """a name with 40 records (the device hands the chunk back) and contigs without reads, across 2 ranks"""
+    from bamwriter import record, write_bam, write_fasta
+    ref = ("ACGTCGCGTTCGAACGCGTA" * 60)[:1100]
+    recs = [record(1, 10 + 10 * k, 99 if k % 2 == 0 else 147, "60M", ref[10 + 10 * k:70 + 10 * k], 35, qname="same", mpos=20 + 10 * k) for k in range(40)]
+    recs += [record(1, 600 + 3 * k, 0, "50M", ref[600 + 3 * k:650 + 3 * k], 30, qname=f"u{k}") for k in range(60)]
+    write_bam(tmp_path / "m.bam", [("empty1", 500), ("c1", len(ref)), ("empty2", 300)], recs)
+    write_fasta(tmp_path / "m.fa", [("empty1", "ACGT" * 125), ("c1", ref), ("empty2", "CG" * 150)])
+    compare_cli(tmp_path, [str(tmp_path / "m.fa"), str(tmp_path / "m.bam"), "-F", "0", "-q", "0", "--keepDupes", "--chunkSize", "400"], env={"MDK_GPUS": "2", "MDK_GPU_MAP": "0,0"})
+
+
+def test_more_gpus_than_visible_is_refused(tmp_path, small_synth):
+    r = mdk.run_cli([str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "-o", "x"], cwd=tmp_path, env={"MDK_GPUS": "9"})
+    if mdk.lib_hip().md_dev_count() < 9:
+        assert r.returncode != 0 and "MDK_GPUS=9" in r.stderr
+
+
+def test_rccl_single_rank_communicator(tmp_path, small_synth):
+    """librccl is loaded on demand, an id is made, a world-1 communicator initialised on the device handle; the exchange of a
+    one-rank world has no peer to talk to and completes; a local one-rank communicator downloads like md_dev_download"""
+    L = mdk.lib_hip()
+    plan = mdk.Plan([str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--chunkSize", "20000", "-o", str(tmp_path / "x")])
+    dev = mdk.Device(plan.dev_cfg())
+    idb = C.create_string_buffer(mdk.COMM_ID_BYTES)
+    assert L.md_comm_unique_id(idb) == 0, L.md_dev_last_error()
+    assert any(idb.raw)
+    comm = C.c_void_p()
+    assert L.md_comm_open_rank(dev.h, 0, 1, idb.raw, C.byref(comm)) == 0, L.md_dev_last_error()
+    assert L.md_comm_world(comm) == 1
+    c = plan.next_chunk(); plan.ensure_reference(dev, c.tid)
+    dev.submit(0, c.batch)
+    dv = dev.wait(0)
+    snd = (C.c_void_p * 1)(dv.d_site); sb = (C.c_uint64 * 1)(dv.n_slots * 16)
+    rcv = (C.c_void_p * 1)(None); rb = (C.c_uint64 * 1)(0)
+    assert L.md_comm_gather(comm, snd, sb, rcv, rb) == 0, L.md_dev_last_error()
+    assert L.md_comm_wait(comm) == 0
+    L.md_comm_close(comm)
+    # local communicator over one handle
+    L.md_comm_download.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(mdk.md_sites)]
+    hs = (C.c_void_p * 1)(dev.h)
+    assert L.md_comm_open_local(hs, 1, C.byref(comm)) == 0
+    s = mdk.md_sites()
+    assert L.md_comm_download(comm, 0, 0, C.byref(s)) == 0 and s.n_sites == dev.download(0).n_sites > 0
+    L.md_comm_close(comm)
+    dev.close(); plan.close()
