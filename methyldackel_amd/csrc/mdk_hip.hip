@@ -209,80 +209,6 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
     }
 }
 
-// byte j (0..15) of four dwords held in registers
-__device__ __forceinline__ uint32_t byte_of(const uint4 &v, int j) {
-    const uint32_t w = j < 8 ? (j < 4 ? v.x : v.y) : (j < 12 ? v.z : v.w);
-    return (w >> ((j & 3) << 3)) & 0xffu;
-}
-__device__ __forceinline__ uint4 load16(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }      // one global_load_dwordx4, any alignment
-
-// The same work as lane_seg for DENSE contexts (--CHG / --CHH: every second base of a read is a site of its strand).  Fetching a
-// byte per site makes every lane of a load instruction touch its own cache line, and the vector L1 takes a line per clock:
-// ~37 sites x 4 bytes per read keep it busy for the whole kernel (64-77 us per 1 Mb chunk).  Here a lane takes its segment in
-// windows of 16 query bases: four 16-byte loads per window (sequence and qualities of the read and of its overlap partner --
-// the partner's window is the same 16 reference positions), then only the sites inside the window are visited, their bases
-// picked out of registers.
-template <bool VARIANT>
-__device__ __forceinline__ void lane_seg_win(const KParams &P, const md_seg &g, int T0, int T1,
-                                             const uint16_t *listC, int nC, const uint16_t *listG, int nG,
-                                             uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv) {
-    const int send = g.rpos + (int)g.len;
-    if(g.rpos >= T1 || send <= T0) return;
-    const int strand = g.sf & MDK_SF_STRAND;
-    const bool odd = strand & 1, second = (g.sf & MDK_SF_SECOND) != 0, partner = (g.sf & MDK_SF_PARTNER) != 0;
-    const RD o = make_rd(P, g.off4, g.l_qseq, strand, g.sf & MDK_SF_READ2);
-    RD m = o;
-    if(partner) m = make_rd(P, g.m_off4, g.m_l_qseq, g.msf & MDK_SF_STRAND, g.msf & MDK_SF_READ2);
-    const int lo_off = g.rpos > T0 ? g.rpos - T0 : 0, hi_off = (send < T1 ? send : T1) - T0;
-    const int badrs = strand == 0 ? 6 : (odd ? 4 : 2);
-    const int qshift = (int)g.q0 - (g.rpos - T0);                  // query index of tile offset l: l + qshift
-    const int mdelta = (int)g.m_q0 - (int)g.q0;                    // partner's query index: own + mdelta
-#pragma unroll
-    for(int pass = 0; pass < (VARIANT ? 2 : 1); pass++) {
-        const bool callpass = pass == 0;
-        const bool useC = (odd == callpass);
-        const uint16_t *list = useC ? listC : listG; const int n = useC ? nC : nG;
-        int a = 0, b = n;
-        while(a < b) { int mid = (a + b) >> 1; if((int)(list[mid] & 0x1fff) < lo_off) a = mid + 1; else b = mid; }
-        int i = a;
-        while(i < n) {
-            const int l0 = list[i] & 0x1fff;
-            if(l0 >= hi_off) break;
-            const int wq = l0 + qshift, mwq = wq + mdelta;            // window: query bases [wq, wq+16) of the read, [mwq, mwq+16) of the partner
-            const uint4 S = load16(o.seq + (wq >> 1)), Q = load16(o.qual + wq);
-            uint4 MS = S, MQ = Q;
-            if(partner) { MS = load16(m.seq + (mwq >> 1)); MQ = load16(m.qual + mwq); }
-            const int wend = l0 + 16 < hi_off ? l0 + 16 : hi_off;    // tile offsets of this window: [l0, wend)
-            while(i < n) {
-                const int e = list[i], l = e & 0x1fff;
-                if(l >= wend) break;
-                i++;
-                if((badrs >> (e >> 13)) & 1) continue;
-                const int k = l - l0, q = wq + k, mq = mwq + k;
-                int bq = 15, ql = 0;
-                if(q >= o.lo && q < o.hi) { const uint32_t sb = byte_of(S, (q >> 1) - (wq >> 1)); bq = (q & 1) ? (sb & 15) : (sb >> 4); ql = (int)byte_of(Q, k); }
-                if(partner) {
-                    int mb = 15, mqv = 0;
-                    if(mq >= m.lo && mq < m.hi) { const uint32_t sb = byte_of(MS, (mq >> 1) - (mwq >> 1)); mb = (mq & 1) ? (sb & 15) : (sb >> 4); mqv = (int)byte_of(MQ, k); }
-                    ql = resolve_overlap(second, bq, ql, mb, mqv);
-                }
-                if(callpass) {
-                    if(strand == 0) atomicExch(P.err, 1);
-                    if(ql >= P.minPhred) {
-                        if(odd) { if(bq == 2) atomicAdd(&cm[l], 1u); else if(bq == 8) atomicAdd(&cu[l], 1u); }
-                        else { if(bq == 4) atomicAdd(&cm[l], 1u); else if(bq == 1) atomicAdd(&cu[l], 1u); }
-                    }
-                } else if(VARIANT) {
-                    if(ql >= P.minPhred) {
-                        atomicAdd(&co[l], 1u);
-                        if(odd ? (bq != 4 && bq != 15) : (bq != 2 && bq != 15)) atomicAdd(&cv[l], 1u);
-                    }
-                }
-            }
-        }
-    }
-}
-
 // barrier that orders LDS traffic only (does not drain this wave's outstanding global loads)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -343,7 +269,7 @@ __device__ __forceinline__ void build_lists(const KParams &P, int PER, int tid, 
 }
 
 // one workgroup, one tile `t` of the interval P describes (b: the workgroup's index in the launch, for the phase profile only)
-template <bool VARIANT, bool DENSE>
+template <bool VARIANT>
 __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const int b) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int TILE = P.tile, PER = TILE / WG;
@@ -383,18 +309,10 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     if(P.dbg) tc1 = clock64();
 
     // phase 2: one segment per lane, WG segments per round
-    if(DENSE) {                // dense contexts (--CHG / --CHH): windows of 16 bases per lane instead of a byte per site
-        if(first + tid < last) lane_seg_win<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
-        for(int r = first + WG + tid; r < last; r += WG) {
-            const md_seg g = P.seg[r];
-            lane_seg_win<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
-        }
-    } else {
-        if(first + tid < last) lane_seg<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
-        for(int r = first + WG + tid; r < last; r += WG) {
-            const md_seg g = P.seg[r];
-            lane_seg<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
-        }
+    if(first + tid < last) lane_seg<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
+    for(int r = first + WG + tid; r < last; r += WG) {
+        const md_seg g = P.seg[r];
+        lane_seg<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
     }
     // reserve this tile's output segment: at most one site per kept context position (unused slots stay empty,
     // md_tile_seg.cnt says how many are filled).  Issued by the first thread once its own segments are done, so the
@@ -447,12 +365,12 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     }
 }
 
-template <bool VARIANT, bool DENSE>
+template <bool VARIANT>
 __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
     const int b = blockIdx.x;
     const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
     if(t >= P.ntiles) return;
-    pileup_tile<VARIANT, DENSE>(P, t, b);
+    pileup_tile<VARIANT>(P, t, b);
 }
 
 // Several intervals (chunks of the reference's schedule, each with its own reads, outputs and site counter) in ONE launch:
@@ -461,14 +379,14 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
 // kernel arguments; a workgroup finds its interval from the tile prefix.
 #define MAXM 8
 struct KMulti { int n, nper; int tstart[MAXM + 1]; KParams P[MAXM]; };
-template <bool VARIANT, bool DENSE>
+template <bool VARIANT>
 __global__ __launch_bounds__(WG, 8) void k_pileup_multi(const KMulti M) {
     const int b = blockIdx.x;
     const int tg = (b & 7) * M.nper + (b >> 3);
     if(tg >= M.tstart[M.n]) return;
     int j = 0;
     while(j + 1 < M.n && tg >= M.tstart[j + 1]) j++;
-    pileup_tile<VARIANT, DENSE>(M.P[j], tg - M.tstart[j], b);
+    pileup_tile<VARIANT>(M.P[j], tg - M.tstart[j], b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -633,15 +551,11 @@ extern "C" int md_dev_warm(int device) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
     hipFuncAttributes fa;
-    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_pileup<false, false>));
+    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_pileup<false>));
     HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_classify));
     return 0;
 }
 
-// the four instantiations of a pileup kernel, picked by what the options ask for
-#define PILEUP_LAUNCH(KERN, variant, dense, grid, lds, st, ARG) do { \
-    if(variant) { if(dense) hipLaunchKernelGGL((KERN<true, true>), dim3(grid), dim3(WG), (size_t)(lds), st, ARG); else hipLaunchKernelGGL((KERN<true, false>), dim3(grid), dim3(WG), (size_t)(lds), st, ARG); } \
-    else { if(dense) hipLaunchKernelGGL((KERN<false, true>), dim3(grid), dim3(WG), (size_t)(lds), st, ARG); else hipLaunchKernelGGL((KERN<false, false>), dim3(grid), dim3(WG), (size_t)(lds), st, ARG); } } while(0)
 static int fixed_lds(int tile, bool variant) { return tile * ((variant ? 16 : 8) + 4); }
 
 extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
@@ -664,13 +578,9 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2;
     h->variant = cfg->minOppositeDepth > 0;
     while(fixed_lds(h->tile, h->variant) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
-    h->dense = (cfg->keepCHG || cfg->keepCHH) && !getenv("MDK_NO_DENSE");
     if(fixed_lds(h->tile, h->variant) > 65536) {    // more than the default dynamic-LDS window: opt in
-        const int lds = fixed_lds(h->tile, h->variant);
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if(h->variant) { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true))); }
+        else { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); }
     }
     h->slots.resize(h->n_slots);
     if(h->d_status.need((size_t)h->n_slots) || h->h_status.need((size_t)h->n_slots)) return MDK_ERR_NOMEM;
@@ -841,7 +751,8 @@ int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on) {
         KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
         int grid = P.nper * 8;
         if(time_pileup) HIPCHK(hipEventRecord(s->k0, st));
-        PILEUP_LAUNCH(k_pileup, h->variant, h->dense, grid, s->lds_bytes, st, P);
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, st, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, st, P);
         if(time_pileup) HIPCHK(hipEventRecord(s->k1, st));
         HIPCHK(hipGetLastError());
     } else {
@@ -884,7 +795,8 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
     }
     M.n = n; M.tstart[n] = total; M.nper = (total + 7) / 8;
     if(total > 0) {
-        PILEUP_LAUNCH(k_pileup_multi, h->variant, h->dense, M.nper * 8, s0->lds_bytes, st, M);
+        if(h->variant) hipLaunchKernelGGL(k_pileup_multi<true>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
+        else hipLaunchKernelGGL(k_pileup_multi<false>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
         HIPCHK(hipGetLastError());
     }
     for(int i = 0; i < n; i++) get_slot(h, slots[i])->launched = true;      // collected through each slot's `run` stream (finish_count)
@@ -1150,7 +1062,8 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
         HIPCHK(hipMalloc((void **)&dd, nw * 8)); HIPCHK(hipMemset(dd, 0, nw * 8));
         s->ring++; rc = fill_kparams(h, s, P); if(rc) return rc;
         P.dbg = dd;
-        PILEUP_LAUNCH(k_pileup, h->variant, h->dense, grid, s->lds_bytes, s->stream, P);
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipMemcpy(hd.data(), dd, nw * 8, hipMemcpyDeviceToHost)); (void)hipFree(dd);
         unsigned long long r0 = ~0ull, r1 = 0; double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}; size_t cnt = 0; std::vector<double> starts, ends, life;
