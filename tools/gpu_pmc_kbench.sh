@@ -3,7 +3,8 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; TAG=$1; EX="$2"; mkdir -p $O /tmp/kbench
 cd /tmp; export TMPDIR=/tmp
 python $R/tools/kbench.py --resident 16 --cmds "x:$EX" > /dev/null 2>&1     # makes the data
-B="python $R/tools/kbench.py --child --resident 16 --data /tmp/kbench --extra=$EX"
+export KB_EXTRA="$EX"
+B="python $R/tools/kbench.py --child --resident 16 --data /tmp/kbench"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $O/${TAG}_sq -o p -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU -d $O/${TAG}_sq2 -o p -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE TCP_TCC_READ_REQ_sum -d $O/${TAG}_fetch -o p -- $B > /dev/null 2>&1

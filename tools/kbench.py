@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--child", action="store_true"); ap.add_argument("--extra", default="")
     a = ap.parse_args()
     if a.child:
+        if os.environ.get("KB_EXTRA") is not None:
+            a.extra = os.environ["KB_EXTRA"]
         return child(a)
     os.makedirs(a.data, exist_ok=True)
     prefix = Path(a.data) / f"k_{a.resident}"
