@@ -6,6 +6,7 @@
 #include <string.h>
 #include <zlib.h>
 #include <time.h>
+#include <dlfcn.h>
 static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 #define CCHUNK (8u << 20)      /* compressed bytes inflated into one slab */
@@ -44,8 +45,28 @@ static void note_records(blk_t *b, sumbuf *sb, const uint8_t *base) {
     b->ok = o == L;
 }
 
+/* libdeflate inflates a BGZF member two to three times faster than zlib (it is what htslib itself uses when it is built with
+ * it).  The image ships the runtime library without its header, so it is bound by name; without it zlib does the work. */
+typedef struct { void *(*alloc)(void); int (*run)(void *, const void *, size_t, void *, size_t, size_t *); void (*release)(void *); } ldeflate_t;
+static const ldeflate_t *ldeflate(void) {
+    static ldeflate_t L; static int state = 0; static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_mutex_lock(&mu);
+    if(state == 0) {
+        void *so = getenv("MDK_ZLIB_INFLATE") ? NULL : dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        state = -1;
+        if(so) {
+            L.alloc = (void *(*)(void))dlsym(so, "libdeflate_alloc_decompressor");
+            L.run = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(so, "libdeflate_deflate_decompress");
+            L.release = (void (*)(void *))dlsym(so, "libdeflate_free_decompressor");
+            if(L.alloc && L.run && L.release) state = 1;
+        }
+    }
+    pthread_mutex_unlock(&mu);
+    return state == 1 ? &L : NULL;
+}
+
 static void *inflate_worker(void *arg) {
-    inflate_job *job = arg; z_stream zs; int inited = 0, me;
+    inflate_job *job = arg; z_stream zs; int inited = 0, me; const ldeflate_t *LD = ldeflate(); void *ld = LD ? LD->alloc() : NULL;
     pthread_mutex_lock(&job->mu); me = job->next_th++; pthread_mutex_unlock(&job->mu);
     for(;;) {
         int i;
@@ -55,6 +76,12 @@ static void *inflate_worker(void *arg) {
             blk_t *b = &job->blk[k];
             b->th = me; b->sum0 = job->sb[me].n; b->n_sum = 0; b->ok = 1;      /* an empty member (the EOF marker) holds no record and ends where it starts */
             if(!b->out_len) continue;
+            if(ld) {
+                size_t got = 0;
+                if(LD->run(ld, b->in, b->in_len, b->out, b->out_len, &got) != 0 || got != b->out_len) { job->failed = 1; b->ok = 0; continue; }
+                note_records(b, &job->sb[me], job->base);
+                continue;
+            }
             if(!inited) { memset(&zs, 0, sizeof(zs)); if(inflateInit2(&zs, -15) != Z_OK) { job->failed = 1; return NULL; } inited = 1; }
             else inflateReset(&zs);
             zs.next_in = (Bytef *)b->in; zs.avail_in = b->in_len; zs.next_out = b->out; zs.avail_out = b->out_len;
@@ -63,6 +90,7 @@ static void *inflate_worker(void *arg) {
         }
     }
     if(inited) inflateEnd(&zs);
+    if(ld) LD->release(ld);
     return NULL;
 }
 

@@ -55,6 +55,7 @@
 #include <string.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <dlfcn.h>
 #include <time.h>
 
 #define ORACLE_VERSION "0.6.1"
@@ -123,10 +124,30 @@ static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
 #define PHASE(name) do { if(getenv("MDK_ORACLE_PROFILE")) { double t_ = wall_s(); fprintf(stderr, "[oracle] %-22s %.3f s\n", name, t_ - g_t0); g_t0 = t_; } } while(0)
 static double g_t0;
 typedef struct { const uint8_t *raw; const size_t *moff, *mout; const uint32_t *mlen, *misz, *mhdr; size_t nm; uint8_t *out; int k, n, bad; } inflate_job;
+/* htslib inflates BGZF members with libdeflate when it is built with it (two to three times faster than zlib); the image has
+ * the runtime library without its header, so it is bound by name here too -- the CPU baseline should not be slower than the
+ * reference would be.  MDK_ZLIB_INFLATE=1 or a missing library leave zlib. */
+typedef struct { void *(*alloc)(void); int (*run)(void *, const void *, size_t, void *, size_t, size_t *); void (*release)(void *); } ldeflate_t;
+static ldeflate_t g_ld; static int g_ld_state;
+static void ldeflate_init(void) {
+    void *so = getenv("MDK_ZLIB_INFLATE") ? NULL : dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    g_ld_state = -1;
+    if(so) {
+        g_ld.alloc = (void *(*)(void))dlsym(so, "libdeflate_alloc_decompressor");
+        g_ld.run = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(so, "libdeflate_deflate_decompress");
+        g_ld.release = (void (*)(void *))dlsym(so, "libdeflate_free_decompressor");
+        if(g_ld.alloc && g_ld.run && g_ld.release) g_ld_state = 1;
+    }
+}
 static void *inflate_main(void *arg) {
-    inflate_job *j = arg; size_t i; z_stream zs;
+    inflate_job *j = arg; size_t i; z_stream zs; void *ld = g_ld_state == 1 ? g_ld.alloc() : NULL;
     for(i = (size_t)j->k; i < j->nm; i += (size_t)j->n) {
         if(!j->misz[i]) continue;
+        if(ld) {
+            size_t got = 0;
+            if(g_ld.run(ld, j->raw + j->moff[i] + j->mhdr[i], j->mlen[i] - j->mhdr[i] - 8, j->out + j->mout[i], j->misz[i], &got) != 0 || got != j->misz[i]) { j->bad = 1; break; }
+            continue;
+        }
         memset(&zs, 0, sizeof(zs));
         zs.next_in = (uint8_t *)j->raw + j->moff[i] + j->mhdr[i]; zs.avail_in = j->mlen[i] - j->mhdr[i] - 8;
         zs.next_out = j->out + j->mout[i]; zs.avail_out = j->misz[i];
@@ -134,6 +155,7 @@ static void *inflate_main(void *arg) {
         if(inflate(&zs, Z_FINISH) != Z_STREAM_END) { inflateEnd(&zs); j->bad = 1; return NULL; }
         inflateEnd(&zs);
     }
+    if(ld) g_ld.release(ld);
     return NULL;
 }
 typedef struct { bamfile *bf; const size_t *roff; size_t lo, hi; int32_t max_rlen; int bad; } decode_job;
@@ -188,6 +210,7 @@ static int bam_load(const char *fn, bamfile *bf) {
     PHASE("member table");
     bf->data = xmalloc(total + 1);
     bf->len = total;
+    if(g_ld_state == 0) ldeflate_init();
     {
         pthread_t *th = xmalloc(sizeof(pthread_t) * nt); inflate_job *job = xmalloc(sizeof(inflate_job) * nt);
         for(k = 0; k < nt; k++) { inflate_job j = {raw, moff, mout, mlen, misz, mhdr, nm, bf->data, k, nt, 0}; job[k] = j; if(k) pthread_create(&th[k], NULL, inflate_main, &job[k]); }
