@@ -123,7 +123,23 @@ static int g_load_threads = 1;
 static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 #define PHASE(name) do { if(getenv("MDK_ORACLE_PROFILE")) { double t_ = wall_s(); fprintf(stderr, "[oracle] %-22s %.3f s\n", name, t_ - g_t0); g_t0 = t_; } } while(0)
 static double g_t0;
-typedef struct { const uint8_t *raw; const size_t *moff, *mout; const uint32_t *mlen, *misz, *mhdr; size_t nm; uint8_t *out; int k, n, bad; } inflate_job;
+typedef struct { const uint8_t *raw; const size_t *moff, *mout; const uint32_t *mlen, *misz, *mhdr; size_t nm; uint8_t *out; int k, n, bad;
+                 size_t *roff; size_t n_roff, cap_roff; uint32_t *mcount; } inflate_job;      /* roff/mcount: the records each member holds when it starts on a record boundary */
+/* htslib never lets a record straddle two BGZF members (bam_write1 flushes first), so a member normally starts on a record
+ * boundary: the thread that inflated it walks it at once.  mcount[i] = records found, or UINT32_MAX when the walk does not
+ * end exactly at the member's last byte (then the whole file is walked serially instead). */
+static void walk_member(inflate_job *j, size_t i) {
+    const uint8_t *d = j->out + j->mout[i]; size_t L = j->misz[i], o = 0; uint32_t n = 0;
+    while(o + 4 <= L) {
+        uint32_t bs = rd32(d + o);
+        if(bs < 32 || o + 4 + (size_t)bs > L) break;
+        if(j->n_roff == j->cap_roff) { j->cap_roff = j->cap_roff ? j->cap_roff * 2 : 65536; j->roff = xrealloc(j->roff, j->cap_roff * sizeof(size_t)); }
+        j->roff[j->n_roff++] = j->mout[i] + o; n++;
+        o += 4 + (size_t)bs;
+    }
+    if(o != L) { j->n_roff -= n; n = UINT32_MAX; }
+    j->mcount[i] = n;
+}
 /* htslib inflates BGZF members with libdeflate when it is built with it (two to three times faster than zlib); the image has
  * the runtime library without its header, so it is bound by name here too -- the CPU baseline should not be slower than the
  * reference would be.  MDK_ZLIB_INFLATE=1 or a missing library leave zlib. */
@@ -146,6 +162,7 @@ static void *inflate_main(void *arg) {
         if(ld) {
             size_t got = 0;
             if(g_ld.run(ld, j->raw + j->moff[i] + j->mhdr[i], j->mlen[i] - j->mhdr[i] - 8, j->out + j->mout[i], j->misz[i], &got) != 0 || got != j->misz[i]) { j->bad = 1; break; }
+            if(j->mcount) walk_member(j, i);
             continue;
         }
         memset(&zs, 0, sizeof(zs));
@@ -154,6 +171,7 @@ static void *inflate_main(void *arg) {
         if(inflateInit2(&zs, -15) != Z_OK) { j->bad = 1; return NULL; }
         if(inflate(&zs, Z_FINISH) != Z_STREAM_END) { inflateEnd(&zs); j->bad = 1; return NULL; }
         inflateEnd(&zs);
+        if(j->mcount) walk_member(j, i);
     }
     if(ld) g_ld.release(ld);
     return NULL;
@@ -181,7 +199,7 @@ static void *decode_main(void *arg) {
 }
 static int bam_load(const char *fn, bamfile *bf) {
     FILE *f = fopen(fn, "rb");
-    uint8_t *raw; size_t rawlen, o = 0, cap, i, nm = 0, mcap = 1024, total = 0, *moff, *mout, *roff; uint32_t *mlen, *misz, *mhdr;
+    uint8_t *raw; size_t rawlen, o = 0, cap, i, nm = 0, mcap = 1024, total = 0, *moff, *mout, *roff; uint32_t *mlen, *misz, *mhdr, *mcount = NULL; inflate_job *ijob = NULL;
     int nt = g_load_threads < 1 ? 1 : g_load_threads, k, bad = 0;
     memset(bf, 0, sizeof(*bf));
     if(!f) return -1;
@@ -213,13 +231,14 @@ static int bam_load(const char *fn, bamfile *bf) {
     if(g_ld_state == 0) ldeflate_init();
     {
         pthread_t *th = xmalloc(sizeof(pthread_t) * nt); inflate_job *job = xmalloc(sizeof(inflate_job) * nt);
-        for(k = 0; k < nt; k++) { inflate_job j = {raw, moff, mout, mlen, misz, mhdr, nm, bf->data, k, nt, 0}; job[k] = j; if(k) pthread_create(&th[k], NULL, inflate_main, &job[k]); }
+        mcount = xmalloc((nm + 1) * sizeof(uint32_t));
+        for(k = 0; k < nt; k++) { inflate_job j = {raw, moff, mout, mlen, misz, mhdr, nm, bf->data, k, nt, 0, NULL, 0, 0, mcount}; job[k] = j; if(k) pthread_create(&th[k], NULL, inflate_main, &job[k]); }
         inflate_main(&job[0]);
         for(k = 1; k < nt; k++) pthread_join(th[k], NULL);
         for(k = 0; k < nt; k++) bad |= job[k].bad;
-        free(th); free(job);
+        free(th); ijob = job;
     }
-    free(raw); free(moff); free(mout); free(mlen); free(misz); free(mhdr);
+    free(raw); free(moff); free(mlen); free(mhdr);
     PHASE("inflate");
     if(bad) return -2;
     /* header */
@@ -234,14 +253,39 @@ static int bam_load(const char *fn, bamfile *bf) {
         bf->target_len[i] = rd32(bf->data + o + 4 + ln);
         o += 8 + ln;
     }
-    /* records: where they start (a serial walk over the block_size words), then the fields (range-parallel) */
+    /* records: where they start, then the fields (range-parallel).  The inflating threads have walked every member that
+     * starts on a record boundary; the member the header ends in is walked from the first record here, and a file whose
+     * records do straddle members falls back to one serial walk over the block_size words. */
     cap = 1024; roff = xmalloc(cap * sizeof(size_t));
-    while(o + 4 <= bf->len) {
-        uint32_t bs = rd32(bf->data + o);
-        if(o + 4 + bs > bf->len || bs < 32) { free(roff); return -3; }
-        if(bf->n_rec == cap) { cap *= 2; roff = xrealloc(roff, cap * sizeof(size_t)); }
-        roff[bf->n_rec++] = o;
-        o += 4 + (size_t)bs;
+    {
+        size_t im = 0, ocur = o, end_im, tot = 0; int ok = 1; size_t *cur = calloc((size_t)nt, sizeof(size_t));
+        while(im + 1 < nm && mout[im + 1] <= o) im++;                    /* member holding the first record's first byte */
+        end_im = mout[im] + misz[im];
+        while(ocur + 4 <= end_im) {                                      /* rest of that member */
+            uint32_t bs = rd32(bf->data + ocur);
+            if(bs < 32 || ocur + 4 + (size_t)bs > end_im) break;
+            if(bf->n_rec == cap) { cap *= 2; roff = xrealloc(roff, cap * sizeof(size_t)); }
+            roff[bf->n_rec++] = ocur; ocur += 4 + (size_t)bs;
+        }
+        if(ocur != end_im && !(im + 1 == nm && ocur == bf->len)) ok = 0;
+        for(i = 0; i <= im && i < nm; i++) if(mcount[i] != UINT32_MAX) cur[i % (size_t)nt] += mcount[i];      /* what the threads noted for the header members is not used */
+        for(i = im + 1; i < nm && ok; i++) { if(mcount[i] == UINT32_MAX) ok = 0; else tot += mcount[i]; }
+        if(ok) {
+            if(bf->n_rec + tot + 1 > cap) { cap = bf->n_rec + tot + 1; roff = xrealloc(roff, cap * sizeof(size_t)); }
+            for(i = im + 1; i < nm; i++) { const size_t t = i % (size_t)nt; memcpy(roff + bf->n_rec, ijob[t].roff + cur[t], mcount[i] * sizeof(size_t)); cur[t] += mcount[i]; bf->n_rec += mcount[i]; }
+        } else {
+            bf->n_rec = 0;
+            while(o + 4 <= bf->len) {
+                uint32_t bs = rd32(bf->data + o);
+                if(o + 4 + bs > bf->len || bs < 32) { free(roff); return -3; }
+                if(bf->n_rec == cap) { cap *= 2; roff = xrealloc(roff, cap * sizeof(size_t)); }
+                roff[bf->n_rec++] = o;
+                o += 4 + (size_t)bs;
+            }
+        }
+        free(cur);
+        for(k = 0; k < nt; k++) free(ijob[k].roff);
+        free(ijob); free(mcount); free(mout); free(misz);
     }
     PHASE("record walk");
     bf->rec = xmalloc((bf->n_rec + 1) * sizeof(brec));

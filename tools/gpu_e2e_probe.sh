@@ -5,7 +5,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; L=${1:-64000000}; D=/tmp/e2e; mkdir -p $D; cd $D
 M=$R/methyldackel_amd/_build/MethylDackel
 for th in 16 32 48 64 96; do
   for rep in 1 2; do
-    /usr/bin/env time -f "threads $th wall %e s user %U sys %S maxrss %M KB" env MDK_HOST_PROFILE=1 $M extract s$L.fa s$L.bam -@ $th -o out 2>&1 | grep -E "mdk main|mdk host|wall" | sed 's/; records found.*reader:/; reader:/'
+    t0=$(date +%s.%N); MDK_HOST_PROFILE=1 $M extract s$L.fa s$L.bam -@ $th -o out 2>&1 | grep -E "mdk main|mdk host" | sed 's/; records found.*reader:/; reader:/'; t1=$(date +%s.%N)
+    python3 -c "print('threads $th wall %.3f s' % ($t1 - $t0))"
   done
 done
 echo "--- oracle all-core phases"
