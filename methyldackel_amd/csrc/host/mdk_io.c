@@ -1,12 +1,15 @@
 /* mdk_io.c -- BGZF/BAM streaming reader (parallel block inflate) and FASTA loader.  See mdk_io.h. */
 #define _GNU_SOURCE
 #include "mdk_io.h"
+#include "mdk_hip.h"       /* md_host_alloc / md_host_free: staging memory for the slabs */
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 #include <time.h>
 #include <dlfcn.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 #define CCHUNK (8u << 20)      /* compressed bytes inflated into one slab */
@@ -108,7 +111,9 @@ static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) {          /* inflater si
     }
     pthread_mutex_unlock(&b->mu);
     if(!s) return NULL;
-    if(s->cap < need_cap) { free(s->buf); s->cap = need_cap + (need_cap >> 3); s->buf = malloc(s->cap); if(!s->buf) { free(s); return NULL; } }
+    /* slabs are what the device preparation uploads from: staging memory (pinned for inputs large enough to repay the pinning,
+     * md_host_set_pinned in mdk_plan.c), so that the H2D copies of a chunk are asynchronous and run at the link's speed */
+    if(s->cap < need_cap) { md_host_free(s->buf); s->cap = need_cap + (need_cap >> 3); s->buf = md_host_alloc(s->cap); if(!s->buf) { free(s); return NULL; } }
     s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM; s->n_mem = 0; s->n_sum = 0;
     return s;
 }
@@ -130,6 +135,10 @@ typedef struct { uint8_t *cbuf; blk_t *blk; int nb; size_t total; uint64_t seq; 
 static int next_piece(mdk_bam *b, piece *pc) {
     size_t n, off = 0, total = 0; blk_t *blk = NULL; int nb = 0, mb = 0;
     memset(pc, 0, sizeof(*pc));
+    if(b->map) {        /* mapped file: the window is a view, nothing is read or copied here */
+        b->cbuf = (uint8_t *)b->map + b->map_pos; b->clen = b->map_len - b->map_pos;
+        if(b->clen > CCHUNK + (1u << 17)) b->clen = CCHUNK + (1u << 17); else b->file_eof = 1;
+    } else
     if(!b->file_eof) {
         if(b->ccap < b->clen + CCHUNK) { b->ccap = b->clen + CCHUNK; b->cbuf = realloc(b->cbuf, b->ccap); if(!b->cbuf) return -1; }
         n = fread(b->cbuf + b->clen, 1, CCHUNK, b->f);
@@ -151,10 +160,12 @@ static int next_piece(mdk_bam *b, piece *pc) {
     }
     if(nb == 0) {
         free(blk);
-        if(b->file_eof) { if(b->clen) { snprintf(b->err, sizeof(b->err), "truncated BGZF member at end of file"); return -2; } return 1; }
+        if(b->file_eof) { int trunc = b->clen != 0; if(b->map) { b->cbuf = NULL; b->clen = 0; } if(trunc) { snprintf(b->err, sizeof(b->err), "truncated BGZF member at end of file"); return -2; } return 1; }
+        if(b->map) { b->cbuf = NULL; b->clen = 0; }
         snprintf(b->err, sizeof(b->err), "BGZF member larger than the read window"); return -2;
     }
-    {   /* the piece keeps this window; the tail that belongs to the next member starts a new one */
+    if(b->map) { b->map_pos += off; b->cbuf = NULL; b->clen = 0; if(b->map_pos < b->map_len) b->file_eof = 0; }
+    else {   /* the piece keeps this window; the tail that belongs to the next member starts a new one */
         size_t left = b->clen - off; uint8_t *nw = malloc(left + CCHUNK + 64);
         if(!nw) { free(blk); return -1; }
         memcpy(nw, b->cbuf + off, left);
@@ -291,6 +302,13 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     if(!b) return NULL;
     b->f = fopen(fn, "rb");
     if(!b->f) { free(b); return NULL; }
+    if(!getenv("MDK_NO_MMAP")) {
+        struct stat st;
+        if(fstat(fileno(b->f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(b->f), 0);
+            if(m != MAP_FAILED) { b->map = m; b->map_len = (size_t)st.st_size; b->map_pos = 0; (void)madvise(m, b->map_len, MADV_SEQUENTIAL); (void)madvise(m, b->map_len, MADV_WILLNEED); }
+        }
+    }
     b->nthreads = nthreads < 1 ? 1 : nthreads;
     b->max_alloc = b->nthreads * 2 + 8;           /* how far the inflaters may run ahead of the consumers, in slabs (~48 MB each) */
     if(b->max_alloc > 48) b->max_alloc = 48;       /* the chunk slots hold ~2 slabs each, the queue 8, the teams 4: more only costs memory */
@@ -324,13 +342,13 @@ void mdk_bam_close(mdk_bam *b) {
     int i;
     if(!b) return;
     inflaters_stop(b);
-    if(b->cur) { free(b->cur->buf); free(b->cur->sum); free(b->cur->mem); free(b->cur); }
-    for(i = 0; i < b->q_n; i++) { free(b->queue[i]->buf); free(b->queue[i]->sum); free(b->queue[i]->mem); free(b->queue[i]); }
-    for(i = 0; i < b->n_pool; i++) { free(b->pool[i]->buf); free(b->pool[i]->sum); free(b->pool[i]->mem); free(b->pool[i]); }
+    if(b->cur) { md_host_free(b->cur->buf); free(b->cur->sum); free(b->cur->mem); free(b->cur); }
+    for(i = 0; i < b->q_n; i++) { md_host_free(b->queue[i]->buf); free(b->queue[i]->sum); free(b->queue[i]->mem); free(b->queue[i]); }
+    for(i = 0; i < b->n_pool; i++) { md_host_free(b->pool[i]->buf); free(b->pool[i]->sum); free(b->pool[i]->mem); free(b->pool[i]); }
     free(b->pool);
     if(b->f) fclose(b->f);
     if(b->target_name) for(i = 0; i < b->n_targets; i++) free(b->target_name[i]);
-    free(b->target_name); free(b->target_len); free(b->text); free(b->cbuf);
+    free(b->target_name); free(b->target_len); free(b->text); if(b->map) munmap((void *)b->map, b->map_len); else free(b->cbuf);
     pthread_mutex_destroy(&b->mu); pthread_mutex_destroy(&b->io_mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool); pthread_cond_destroy(&b->cv_turn);
     free(b);
 }
@@ -470,7 +488,8 @@ int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
     b->q_n = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
     pthread_mutex_unlock(&b->mu);
     if(b->cur) { mdk_slab_unref(b, b->cur); b->cur = NULL; }
-    if(fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET)) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; }
+    if(b->map) { if((size_t)(voffset >> 16) > b->map_len) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; } b->map_pos = (size_t)(voffset >> 16); }
+    else if(fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET)) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; }
     inflaters_start(b);
     if((voffset & 0xffff) || 1) {
         int rc = need(b, (size_t)(voffset & 0xffff) + 1);

@@ -50,6 +50,7 @@ typedef struct mdk_bam {
     mdk_slab *queue[8]; int q_n; int inf_done, quit;
     mdk_slab **pool; int n_pool, cap_pool, n_alloc, max_alloc;
     uint8_t *cbuf; size_t ccap, clen; int file_eof;
+    const uint8_t *map; size_t map_len, map_pos;   /* the file mapped read-only: the inflate threads read the compressed bytes where the page cache has them (no copy) */
     /* scanner position */
     mdk_slab *cur; size_t off;
     int mem_i; size_t sum_i, sum_end;        /* next member to look at; records of the current ok member still to hand out */
