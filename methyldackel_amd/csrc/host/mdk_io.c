@@ -306,7 +306,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
         struct stat st;
         if(fstat(fileno(b->f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
             void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(b->f), 0);
-            if(m != MAP_FAILED) { b->map = m; b->map_len = (size_t)st.st_size; b->map_pos = 0; (void)madvise(m, b->map_len, MADV_SEQUENTIAL); (void)madvise(m, b->map_len, MADV_WILLNEED); }
+            if(m != MAP_FAILED) { b->map = m; b->map_len = (size_t)st.st_size; b->map_pos = 0; (void)madvise(m, b->map_len, MADV_SEQUENTIAL); }
         }
     }
     b->nthreads = nthreads < 1 ? 1 : nthreads;
