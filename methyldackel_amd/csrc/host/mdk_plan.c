@@ -279,6 +279,11 @@ MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional
     opts_t *o = &p->o; int i; char *oname; FILE *bbm = NULL;
     o->fasta_name = argv[first_positional]; o->bam_name = argv[first_positional + 1];
     if(o->n_threads < 1) o->n_threads = 1;
+    {   /* the reader's slabs are staging memory too and the inflate threads start allocating them at once: decide by the file's
+         * size before it is opened (a -r region can only turn pinning off again, below) */
+        struct stat st0; long long min_bytes = getenv("MDK_PIN_MIN_BYTES") ? atoll(getenv("MDK_PIN_MIN_BYTES")) : 1500000000LL;
+        md_host_set_pinned(!(stat(o->bam_name, &st0) == 0 && (long long)st0.st_size < min_bytes));
+    }
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
     if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
     p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */

@@ -1155,8 +1155,8 @@ extern "C" void md_host_set_pinned(int on) { g_want_pinned.store(on != 0); }
 extern "C" void *md_host_alloc(uint64_t bytes) {
     void *p = nullptr; size_t n = (size_t)bytes + 64;
     static std::once_flag once; static int pinned_ok = 0;          // several chunk workers may be the first caller at the same time
+    if(!g_want_pinned.load()) { if(posix_memalign(&p, 4096, n) != 0) return nullptr; memcpy(p, "MDKMAL", 7); return (char *)p + 64; }      // (does not touch the HIP runtime)
     std::call_once(once, [] { int c = 0; pinned_ok = (!getenv("MDK_NO_PIN") && hipGetDeviceCount(&c) == hipSuccess && c > 0) ? 1 : 0; });
-    if(!g_want_pinned.load()) { if(posix_memalign(&p, 4096, n) != 0) return nullptr; memcpy(p, "MDKMAL", 7); return (char *)p + 64; }
     if(pinned_ok && hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess) { memcpy(p, "MDKPIN", 7); return (char *)p + 64; }
     if(posix_memalign(&p, 4096, n) != 0) return nullptr;
     memcpy(p, "MDKMAL", 7);
