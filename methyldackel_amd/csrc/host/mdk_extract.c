@@ -127,6 +127,7 @@ static int extract_multi(mdk_plan *p, int N, const int *map) {
 int extract_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; int dth_ok; emitter em;
     double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta; int n_host_prep = 0;
+    if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] entered at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
     if(argc > 2) hip_warm_up();
     rc = mdk_plan_open(argc, argv, &p);
     t_open = now_s() - T0;
@@ -193,6 +194,7 @@ int extract_main(int argc, char *argv[]) {
     { double tw = now_s(); emitter_stop(&em); w_emit += now_s() - tw; }
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0, n_host_prep);
     if(ret == 0) mdk_plan_finish(p);
+    if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
     if(fast_exit_wanted()) leave_fast(ret);
     md_dev_close(dev);
     mdk_plan_close(p);

@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; L=${1:-64000000}; D=/tmp/e2e; mkdir -p $D; cd $D
 M=$R/methyldackel_amd/_build/MethylDackel
 for th in ${THREADS:-16 32 64}; do
   for rep in 1 2 3; do
-    t0=$(date +%s.%N); MDK_HOST_PROFILE=1 $M extract s$L.fa s$L.bam -@ $th -o out 2>&1 | grep -E "mdk main|mdk host" | sed 's/; records found.*reader:/; reader:/'; t1=$(date +%s.%N)
-    python3 -c "print('threads $th wall %.3f s' % ($t1 - $t0))"
+    t0=$(date +%s.%N); MDK_HOST_PROFILE=1 $M extract s$L.fa s$L.bam -@ $th -o out 2>&1 | grep -E "mdk main|mdk host" | sed -e "s/^\[mdk main\] \(entered\|leaving\)/[t0 $t0] \1/" | sed 's/; records found.*reader:/; reader:/'; t1=$(date +%s.%N)
+    python3 -c "print('threads $th wall %.3f s (t1 epoch %.3f)' % ($t1 - $t0, $t1))"
   done
 done
 echo "--- pinned staging forced"
