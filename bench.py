@@ -315,6 +315,7 @@ def main():
                 (work / f"cg_{name}").mkdir()
                 best = None
                 for _ in range(3):
+                    time.sleep(0.6)          # let the previous process' GPU context finish tearing down: back-to-back commands otherwise wait for each other's teardown (up to 0.25 s at start-up and at exit)
                     t1 = time.perf_counter()
                     rg = mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=work / f"cg_{name}", env=env)
                     dtc = time.perf_counter() - t1

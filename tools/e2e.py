@@ -24,6 +24,7 @@ for mode in os.environ.get("E2E_MODES", "dev,host").split(","):
         g = f"{w}/g_{mode}_{th}"; os.makedirs(g)
         best = None
         for rep in range(3):
+            time.sleep(0.6)      # back-to-back commands wait for the previous process' GPU teardown
             t = time.time(); r = subprocess.run([f"{REPO}/methyldackel_amd/_build/MethylDackel", "extract", s + ".fa", s + ".bam", "-o", "out", "-@", th] + extra, cwd=g, capture_output=True, text=True, env=env)
             dt = time.time() - t
             if best is None or dt < best:
