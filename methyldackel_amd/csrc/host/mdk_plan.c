@@ -281,7 +281,7 @@ MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional
     if(o->n_threads < 1) o->n_threads = 1;
     {   /* the reader's slabs are staging memory too and the inflate threads start allocating them at once: decide by the file's
          * size before it is opened (a -r region can only turn pinning off again, below) */
-        struct stat st0; long long min_bytes = getenv("MDK_PIN_MIN_BYTES") ? atoll(getenv("MDK_PIN_MIN_BYTES")) : 1500000000LL;
+        struct stat st0; long long min_bytes = getenv("MDK_PIN_MIN_BYTES") ? atoll(getenv("MDK_PIN_MIN_BYTES")) : 16000000000LL;
         md_host_set_pinned(!(stat(o->bam_name, &st0) == 0 && (long long)st0.st_size < min_bytes));
     }
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
@@ -343,9 +343,9 @@ region:
     }
     /* -l (extract.c:1469-1477, MBias.c:524-532) */
     if(o->bed_name && load_bed(p) != 0) { fprintf(stderr, "There was an error while reading in your BED file!\n"); plan_free(p); return 1; }
-    {   /* staging buffers: pinning ~1 GB of them costs ~0.3 s before the first chunk can be packed; only worth it when there
-         * are enough chunks to upload (a pageable upload of one chunk costs ~5 ms more than a pinned one) */
-        struct stat st; long long min_bytes = getenv("MDK_PIN_MIN_BYTES") ? atoll(getenv("MDK_PIN_MIN_BYTES")) : 1500000000LL; int pin = 1;
+    {   /* staging memory (the reader's slabs): pinning ~2.5 GB of it costs ~0.7 s and delays the device start-up; only worth it when there
+         * are thousands of chunks to upload (a pageable upload costs the submitting thread ~2 ms per chunk): BAM files of 16 GB and more */
+        struct stat st; long long min_bytes = getenv("MDK_PIN_MIN_BYTES") ? atoll(getenv("MDK_PIN_MIN_BYTES")) : 16000000000LL; int pin = 1;
         if(stat(o->bam_name, &st) == 0 && (long long)st.st_size < min_bytes) pin = 0;
         if(o->region && p->g_tid < (uint32_t)p->bam->n_targets) {      /* a region of a large file: count its chunks instead */
             uint64_t span = (p->g_end ? p->g_end : p->bam->target_len[p->g_tid]) - (uint64_t)p->g_pos;

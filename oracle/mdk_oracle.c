@@ -158,7 +158,7 @@ static void ldeflate_init(void) {
 static void *inflate_main(void *arg) {
     inflate_job *j = arg; size_t i; z_stream zs; void *ld = g_ld_state == 1 ? g_ld.alloc() : NULL;
     for(i = (size_t)j->k; i < j->nm; i += (size_t)j->n) {
-        if(!j->misz[i]) continue;
+        if(!j->misz[i]) { if(j->mcount) j->mcount[i] = 0; continue; }        /* an empty member (the EOF marker) holds no record */
         if(ld) {
             size_t got = 0;
             if(g_ld.run(ld, j->raw + j->moff[i] + j->mhdr[i], j->mlen[i] - j->mhdr[i] - 8, j->out + j->mout[i], j->misz[i], &got) != 0 || got != j->misz[i]) { j->bad = 1; break; }
