@@ -7,8 +7,8 @@ Workload.  Every rank holds R (default 16) DIFFERENT S1-sized intervals resident
 schedule (1 Mb chunks, extract.c:325-350) cuts out of an R Mb synthetic contig, each about 52 MB of admitted reads, about
 0.8 GB together -- beyond the 256 MiB Infinity Cache, so every launch streams its inputs from HBM.  One STEP is one pass of
 the hot path over a batch of P x R chunks (default P = 384: 6144 chunks in 768 kernel launches), i.e. the R resident intervals presented P
-times in rotation.  Inside a step every launch is issued and collected (site count read back) with two launches in flight,
-exactly as extract_main drives the device; with N ranks the kernels write into send buffers and the results of 8
+times in rotation.  Inside a step every launch is issued and collected (site counts read back) with two launches queued
+on one in-order stream (launch g is issued, then launch g-1 is collected); with N ranks the kernels write into send buffers and the results of 8
 consecutive launches travel to rank 0 with one ncclSend/ncclRecv exchange (libmdk_hip's md_comm, RCCL over xGMI) while the
 next launch is computed.  A kernel launch covers 8 resident chunks (md_dev_launch_group): one 1 Mb chunk is only 489
 workgroups, fewer than two per CU.  The loop is libmdk_hip's md_bench_run (C); Python only brackets it.
@@ -264,7 +264,7 @@ def main():
                        "sites_per_interval": int(n_sites_sum) // R, "cpg_calls_per_interval": int(cpg_calls) // R,
                        "tile": int(br.tile), "tiles_per_launch": int(br.n_tiles), "lds_bytes_per_workgroup": int(br.lds_bytes),
                        "parallelism": f"interval-sharded x{n_gpus}" + (f" + RCCL gather of site buffers to rank 0 ({GROUP} chunks = one launch per exchange, {bytes_per_exchange} B per exchange and rank)" if world > 1 else ""),
-                       "in_flight": "2 kernel launches per GPU (launch g is issued, then the chunks of launch g-1 are collected, as extract_main does); every launch is issued and collected inside the timed region"},
+                       "in_flight": "2 kernel launches queued per GPU, in order on one stream (launch g is issued, then the chunks of launch g-1 are collected: their site counts read back with one copy); every launch is issued and collected inside the timed region"},
             "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_note, "algo_bytes_per_launch": int(br.algo_bytes), "kernel_ms": br.ms_pileup,
                          "chunks_per_launch": GROUP, "kernel_ms_per_chunk": br.ms_pileup / GROUP,

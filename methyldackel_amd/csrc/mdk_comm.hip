@@ -207,6 +207,7 @@ struct md_bench {
     md_dev *h = nullptr; md_comm *comm = nullptr; std::vector<int> slots; int group = 0, ngroups = 0, world = 1, rank = 0;
     int64_t cap = 0, tcap = 0; size_t E = 0, off_var = 0, off_seg = 0;       // one chunk's region: sites, [var], tile segments
     uint8_t *send[2] = {nullptr, nullptr}; std::vector<uint8_t *> recv[2]; bool pending[2] = {false, false};
+    hipStream_t stream = nullptr; hipEvent_t done[2] = {nullptr, nullptr};      // every launch goes to this one stream, followed by the copy of its status blocks and an event
     int64_t last_g = -1;
 };
 
@@ -215,7 +216,8 @@ extern "C" void md_bench_close(md_bench *b) {
     (void)hipSetDevice(b->h->device);
     if(b->comm) (void)md_comm_wait(b->comm);
     for(int i : b->slots) (void)md_dev_bind_output(b->h, i, nullptr, nullptr, nullptr, 0, 0);
-    for(int x = 0; x < 2; x++) { if(b->send[x]) (void)hipFree(b->send[x]); for(uint8_t *p : b->recv[x]) if(p) (void)hipFree(p); }
+    for(int x = 0; x < 2; x++) { if(b->send[x]) (void)hipFree(b->send[x]); for(uint8_t *p : b->recv[x]) if(p) (void)hipFree(p); if(b->done[x]) (void)hipEventDestroy(b->done[x]); }
+    if(b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     delete b;
 }
 
@@ -236,6 +238,8 @@ extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, 
         if(s->ntiles > b->tcap) b->tcap = s->ntiles;
         b->slots.push_back(slots[i]);
     }
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    for(int x = 0; x < 2; x++) HIPCHK(hipEventCreateWithFlags(&b->done[x], hipEventDisableTiming));
     b->cap += 64; b->tcap += 1;
     b->off_var = (size_t)b->cap * sizeof(md_site);
     b->off_seg = b->off_var + (h->variant ? (size_t)b->cap * sizeof(md_site_var) : 0);
@@ -269,16 +273,19 @@ static int bench_exchange(md_bench *b, int x) {
     b->pending[x] = true;
     return 0;
 }
+// launch g is finished when its event has fired: its status blocks are on the host by then
 static int bench_collect(md_bench *b, int64_t g, int64_t *sites) {
     const int *gs = b->slots.data() + (g % b->ngroups) * b->group;
-    int64_t counts[16];
-    int rc = finish_group(b->h, gs, b->group, counts); if(rc) return rc;
-    *sites = counts[b->group - 1];
+    HIPCHK(hipEventSynchronize(b->done[g & 1]));
+    for(int i = 0; i < b->group; i++) { int64_t c = finish_eval(b->h, get_slot(b->h, gs[i])); if(c < 0) return (int)c; *sites = c; }
     return bench_exchange(b, (int)(g & 1));
 }
 
 // `launches` kernel launches, each one pass of the hot path over the next `group` resident intervals; returns when every
 // launch has been collected and every exchange has completed.  The caller brackets this call with its barrier + device sync.
+// All launches go to one stream, in order, each followed by the copy of its chunks' status blocks and an event; the host
+// keeps two launches queued (launch g is issued, then launch g-1 is collected), so the GPU never waits for the host and a
+// kernel never shares the GPU with its neighbour -- the durations rocprofv3 reports for it are those of the kernel alone.
 extern "C" int md_bench_run(md_bench *b, int64_t launches, md_bench_run_result *out) {
     if(!b || launches < 0 || !out) return fail(MDK_ERR_ARG, "md_bench_run", hipSuccess);
     md_dev *h = b->h; const int K = b->group;
@@ -289,11 +296,15 @@ extern "C" int md_bench_run(md_bench *b, int64_t launches, md_bench_run_result *
         const int x = (int)(g & 1);
         if(b->pending[x]) { int rc = md_comm_wait(b->comm); if(rc) return rc; b->pending[0] = b->pending[1] = false; }     // this buffer is about to be overwritten
         const int *gs = b->slots.data() + (g % b->ngroups) * K;
+        int lo = 0x7fffffff, hi = -1;
         for(int i = 0; i < K; i++) {
             uint8_t *base = b->send[x] + (size_t)i * b->E;
             int rc = md_dev_bind_output(h, gs[i], base, h->variant ? base + b->off_var : nullptr, base + b->off_seg, b->cap, b->tcap); if(rc) return rc;
+            const int idx = get_slot(h, gs[i])->index; if(idx < lo) lo = idx; if(idx > hi) hi = idx;
         }
-        int rc = K == 1 ? md_dev_launch(h, gs[0]) : md_dev_launch_group(h, gs, K); if(rc) return rc;
+        int rc = launch_group_on(h, gs, K, b->stream, true); if(rc) return rc;
+        HIPCHK(hipMemcpyAsync(h->h_status.p + lo, h->d_status.p + lo, sizeof(SlotStatus) * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipEventRecord(b->done[x], b->stream));
         if(g) { rc = bench_collect(b, g - 1, &sites); if(rc) return rc; if(b->comm) out->exchanges++; }
     }
     if(launches) {

@@ -924,7 +924,7 @@ extern "C" int md_dev_perread_download(md_dev *h, int slot, const md_pr_count **
 }
 
 // what a launch left for the host: the status block is already in h_st
-static int64_t finish_eval(md_dev *h, Slot *s) {
+int64_t finish_eval(md_dev *h, Slot *s) {
     const SlotStatus &st = *s->h_st.p;
     if(s->raw_layout) {
         int rc = prep_outcome(h, s);

@@ -93,6 +93,7 @@ MDK_HIDDEN Slot *get_slot(md_dev *h, int slot);
 MDK_HIDDEN int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on = nullptr);
 MDK_HIDDEN int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cross_sync);
 MDK_HIDDEN int64_t finish_count(md_dev *h, Slot *s);
+MDK_HIDDEN int64_t finish_eval(md_dev *h, Slot *s);      // the status block is already on the host
 MDK_HIDDEN int finish_group(md_dev *h, const int *slots, int n, int64_t *counts);
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s);
 #endif
