@@ -74,6 +74,15 @@ def test_config3_contig_ladder_two_ranks(ladder, tmp_path):
     same_outputs(ladder / "oracle", gd)
 
 
+def test_config3_contig_ladder_sharded_command(ladder, tmp_path):
+    """the same run through the sharded command itself (MDK_GPUS=4, all ranks on this box's GPU): one host pipeline, chunk k on
+    rank k mod 4, 8 chunks in flight, results of ranks 1-3 gathered to rank 0 (md_comm_download)"""
+    gd = tmp_path / "gpu"; gd.mkdir()
+    r = mdk.run_cli([str(ladder / "g.fa"), str(ladder / "g.bam"), "-@", "32", "-o", "out"], cwd=gd, env={"MDK_GPUS": "4", "MDK_GPU_MAP": "0,0,0,0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    same_outputs(ladder / "oracle", gd)
+
+
 def test_config4_100x_merge_bigwig(tmp_path):
     """8 Mb at 100x with --mergeContext and the bigWig mappability filter (-M, own bbi reader); the oracle has no bigWig
     reader and is given the same track as BBM (-B), which the product also accepts and must agree with"""
