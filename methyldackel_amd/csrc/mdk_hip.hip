@@ -140,9 +140,7 @@ __global__ __launch_bounds__(WG) void k_mask_regions(uint8_t *code, int64_t n, c
     }
 }
 
-#ifndef KB_DENSE
-#define KB_DENSE 8
-#endif
+#define KB 2      // positions per batch: their base/qual bytes (own + partner) are all in flight together
 
 // One segment, one lane.
 // STAGED: bytes [slo, shi) of the payload buffer are in LDS at stg; a read wholly inside is served from there
@@ -151,7 +149,6 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
                                          const uint16_t *listC, int nC, const uint16_t *listG, int nG,
                                          uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv,
                                          const uint8_t *stg, uint32_t slo, uint32_t shi) {
-    constexpr int KB = STAGED ? KB_DENSE : 2;      // positions per batch: their base/qual bytes (own + partner) are all in flight together
     const int send = g.rpos + (int)g.len;
     if(g.rpos >= T1 || send <= T0) return;                        // inside the tile's run but not on the tile
     const int strand = g.sf & MDK_SF_STRAND;
