@@ -57,7 +57,6 @@ struct KParams {
     int keepmask, minPhred;
     int bounds[16], abounds[16];
     int *err;
-    int stage_bytes;              // dense contexts: LDS bytes for staging a tile's read payload (0: none)
     int packed;                   // 0: payload = blob + 4*off4, qualities after the sequence padded to 4 bytes (host-built batches);
                                   // 1: payload = blob + off4 (byte offset into the uploaded BAM records), qualities directly after the sequence
     int mbias; uint32_t *hist; int hist_lq;     // mbias: window-relative contexts at the chunk edges; histogram rows [q][16]; rows kept in LDS
@@ -143,12 +142,10 @@ __global__ __launch_bounds__(WG) void k_mask_regions(uint8_t *code, int64_t n, c
 #define KB 2      // positions per batch: their base/qual bytes (own + partner) are all in flight together
 
 // One segment, one lane.
-// STAGED: bytes [slo, shi) of the payload buffer are in LDS at stg; a read wholly inside is served from there
-template <bool VARIANT, bool STAGED>
+template <bool VARIANT>
 __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int T0, int T1,
                                          const uint16_t *listC, int nC, const uint16_t *listG, int nG,
-                                         uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv,
-                                         const uint8_t *stg, uint32_t slo, uint32_t shi) {
+                                         uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv) {
     const int send = g.rpos + (int)g.len;
     if(g.rpos >= T1 || send <= T0) return;                        // inside the tile's run but not on the tile
     const int strand = g.sf & MDK_SF_STRAND;
@@ -157,10 +154,6 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
     RD m = o;
     if(partner) m = make_rd(P, g.m_off4, g.m_l_qseq, g.msf & MDK_SF_STRAND, g.msf & MDK_SF_READ2);
     const int lo_off = g.rpos > T0 ? g.rpos - T0 : 0, hi_off = (send < T1 ? send : T1) - T0;   // tile offsets covered
-    // where this read's (and its partner's) bytes are: LDS offsets of sequence and qualities when staged
-    const uint32_t ob = (uint32_t)(o.seq - P.blob), oq = (uint32_t)(o.qual - o.seq), mb_ = (uint32_t)(m.seq - P.blob), mq_ = (uint32_t)(m.qual - m.seq);
-    const bool oin = STAGED && ob >= slo && ob + oq + (uint32_t)o.lq <= shi, min_ = STAGED && mb_ >= slo && mb_ + mq_ + (uint32_t)m.lq <= shi;
-    const uint8_t *os = stg + (ob - slo), *ms = stg + (mb_ - slo);
     // --keepStrand: region strand codes (bits 13-14 of a list entry) this read is invisible at (bed.c:56-64):
     // '+' regions (1) want OT/CTOT, '-' regions (2) want OB/CTOB, a read of unknown strand matches neither
     const int badrs = strand == 0 ? 6 : (odd ? 4 : 2);
@@ -188,8 +181,8 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
                 sb[k] = 0xff; qb[k] = 0; msb[k] = 0xff; mqb[k] = 0;
                 if(li[k] >= 0) {
                     const int d = T0 + li[k] - g.rpos, q = (int)g.q0 + d, mq = (int)g.m_q0 + d;
-                    if(q >= o.lo && q < o.hi) { if(oin) { sb[k] = os[q >> 1]; qb[k] = os[oq + q]; } else { sb[k] = o.seq[q >> 1]; qb[k] = o.qual[q]; } }
-                    if(partner && mq >= m.lo && mq < m.hi) { if(min_) { msb[k] = ms[mq >> 1]; mqb[k] = ms[mq_ + mq]; } else { msb[k] = m.seq[mq >> 1]; mqb[k] = m.qual[mq]; } }
+                    if(q >= o.lo && q < o.hi) { sb[k] = o.seq[q >> 1]; qb[k] = o.qual[q]; }
+                    if(partner && mq >= m.lo && mq < m.hi) { msb[k] = m.seq[mq >> 1]; mqb[k] = m.qual[mq]; }
                 }
             }
             // 3. use them
@@ -276,13 +269,12 @@ __device__ __forceinline__ void build_lists(const KParams &P, int PER, int tid, 
 }
 
 // one workgroup, one tile `t` of the interval P describes (b: the workgroup's index in the launch, for the phase profile only)
-template <bool VARIANT, bool DENSE>
+template <bool VARIANT>
 __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const int b) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int TILE = P.tile, PER = TILE / WG;
     uint32_t *cm = lds, *cu = lds + TILE, *co = lds + 2 * TILE, *cv = lds + 3 * TILE;
     uint16_t *listC = (uint16_t *)(lds + (VARIANT ? 4 : 2) * TILE), *listG = listC + TILE;
-    uint8_t *stg = (uint8_t *)(lds + (VARIANT ? 4 : 2) * TILE + TILE);       // DENSE: P.stage_bytes of read payload, 16-byte aligned (TILE is a multiple of 512)
     __shared__ int wsum[WAVES];
     __shared__ uint32_t sbase;
 
@@ -302,20 +294,6 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     load_codes(P, T0, tlen, PER, tid, code);
     md_seg g0; g0.rpos = 0x7fffffff; g0.len = 0;
     if(first + tid < last) g0 = P.seg[first + tid];
-    // DENSE (--CHG / --CHH: every second base of a read is a site of its strand): a lane visits its read ~10 times, and between
-    // visits the other lanes of the XCD evict its lines from L1 and L2 -- every 128-byte granule came from HBM 3.6 times.  The
-    // reads of a tile lie next to each other in the payload buffer (file order), so the workgroup copies that byte range into
-    // LDS once, coalesced, and the visits are served from there.  What does not fit (or lies elsewhere: reads carried over from
-    // the previous chunk, reads reaching in over a long reference skip) is read from memory as before.
-    uint32_t slo = 0, shi = 0;
-    if(DENSE && last > first) {
-        const uint32_t cap = (uint32_t)P.stage_bytes;
-        shi = te.bhi; slo = te.blo & ~15u;
-        if(shi - slo > cap) slo = (shi - cap + 15u) & ~15u;           // keep the upper end: outliers lie below (earlier in the file)
-        const uint32_t nb = shi - slo;
-        const uint8_t *src = P.blob + slo;
-        for(uint32_t i = (uint32_t)tid * 16u; i < nb; i += WG * 16u) *(uint4 *)(stg + i) = *(const uint4 *)(src + i);      // the last vector may run up to 15 bytes past shi: inside the buffer's slack
-    }
 
     // phase 1: sorted C / G position lists (wave scan + one cross-wave exchange), counters zeroed
 #pragma unroll
@@ -331,10 +309,10 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     if(P.dbg) tc1 = clock64();
 
     // phase 2: one segment per lane, WG segments per round
-    if(first + tid < last) lane_seg<VARIANT, DENSE>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv, stg, slo, shi);
+    if(first + tid < last) lane_seg<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
     for(int r = first + WG + tid; r < last; r += WG) {
         const md_seg g = P.seg[r];
-        lane_seg<VARIANT, DENSE>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv, stg, slo, shi);
+        lane_seg<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
     }
     // reserve this tile's output segment: at most one site per kept context position (unused slots stay empty,
     // md_tile_seg.cnt says how many are filled).  Issued by the first thread once its own segments are done, so the
@@ -387,12 +365,12 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     }
 }
 
-template <bool VARIANT, bool DENSE>
-__global__ __launch_bounds__(WG, DENSE ? 4 : 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU (dense: LDS allows two, 128 VGPRs)
+template <bool VARIANT>
+__global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
     const int b = blockIdx.x;
     const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
     if(t >= P.ntiles) return;
-    pileup_tile<VARIANT, DENSE>(P, t, b);
+    pileup_tile<VARIANT>(P, t, b);
 }
 
 // Several intervals (chunks of the reference's schedule, each with its own reads, outputs and site counter) in ONE launch:
@@ -401,14 +379,14 @@ __global__ __launch_bounds__(WG, DENSE ? 4 : 8) void k_pileup(const KParams P) {
 // kernel arguments; a workgroup finds its interval from the tile prefix.
 #define MAXM 8
 struct KMulti { int n, nper; int tstart[MAXM + 1]; KParams P[MAXM]; };
-template <bool VARIANT, bool DENSE>
-__global__ __launch_bounds__(WG, DENSE ? 4 : 8) void k_pileup_multi(const KMulti M) {
+template <bool VARIANT>
+__global__ __launch_bounds__(WG, 8) void k_pileup_multi(const KMulti M) {
     const int b = blockIdx.x;
     const int tg = (b & 7) * M.nper + (b >> 3);
     if(tg >= M.tstart[M.n]) return;
     int j = 0;
     while(j + 1 < M.n && tg >= M.tstart[j + 1]) j++;
-    pileup_tile<VARIANT, DENSE>(M.P[j], tg - M.tstart[j], b);
+    pileup_tile<VARIANT>(M.P[j], tg - M.tstart[j], b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -573,15 +551,11 @@ extern "C" int md_dev_warm(int device) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
     hipFuncAttributes fa;
-    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_pileup<false, false>));
+    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_pileup<false>));
     HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_classify));
     return 0;
 }
 
-// the four instantiations of a pileup kernel, picked by what the options ask for
-#define PILEUP_LAUNCH(KERN, variant, dense, grid, lds, st, ARG) do { \
-    if(variant) { if(dense) hipLaunchKernelGGL((KERN<true, true>), dim3(grid), dim3(WG), (size_t)(lds), st, ARG); else hipLaunchKernelGGL((KERN<true, false>), dim3(grid), dim3(WG), (size_t)(lds), st, ARG); } \
-    else { if(dense) hipLaunchKernelGGL((KERN<false, true>), dim3(grid), dim3(WG), (size_t)(lds), st, ARG); else hipLaunchKernelGGL((KERN<false, false>), dim3(grid), dim3(WG), (size_t)(lds), st, ARG); } } while(0)
 static int fixed_lds(int tile, bool variant) { return tile * ((variant ? 16 : 8) + 4); }
 
 extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
@@ -598,24 +572,15 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     HIPCHK(hipSetDevice(device));
     md_dev *h = new md_dev();
     h->device = device; h->cfg = *cfg;
-    // dense contexts (--CHG / --CHH): the tile's read payload is staged in LDS -- 1024-position tiles and a 64 KiB stage let two
-    // workgroups share a CU; MDK_NO_STAGE=1 keeps the byte gathers from memory
-    h->dense = (cfg->keepCHG || cfg->keepCHH) && !getenv("MDK_NO_STAGE");
-    h->stage_bytes = h->dense ? (getenv("MDK_STAGE_KB") ? atoi(getenv("MDK_STAGE_KB")) * 1024 : 65536) : 0;
-    if(h->stage_bytes < 4096) { h->stage_bytes = 0; h->dense = false; }
-    h->stage_bytes &= ~15;
-    h->tile = cfg->tile > 0 ? cfg->tile : (h->dense ? 1024 : DEFAULT_TILE);
+    h->tile = cfg->tile > 0 ? cfg->tile : DEFAULT_TILE;
     h->tile = (h->tile + WG - 1) / WG * WG;
     if(h->tile > MAX_TILE) h->tile = MAX_TILE;
     h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2;
     h->variant = cfg->minOppositeDepth > 0;
-    while(fixed_lds(h->tile, h->variant) + h->stage_bytes > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
-    if(fixed_lds(h->tile, h->variant) + h->stage_bytes > 65536) {    // more than the default dynamic-LDS window: opt in
-        const int lds = fixed_lds(h->tile, h->variant) + h->stage_bytes;
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    while(fixed_lds(h->tile, h->variant) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
+    if(fixed_lds(h->tile, h->variant) > 65536) {    // more than the default dynamic-LDS window: opt in
+        if(h->variant) { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true))); }
+        else { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); }
     }
     h->slots.resize(h->n_slots);
     if(h->d_status.need((size_t)h->n_slots) || h->h_status.need((size_t)h->n_slots)) return MDK_ERR_NOMEM;
@@ -705,16 +670,15 @@ Slot *get_slot(md_dev *h, int slot) { if(!h || slot < 0 || slot >= h->n_slots) {
 
 // segment run of every tile
 static void build_tiles(const md_read_batch *b, int TILE, TileEnt *te, int ntiles) {
-    for(int t = 0; t < ntiles; t++) { te[t].first = 0x7fffffff; te[t].last = 0; te[t].blo = 0xffffffffu; te[t].bhi = 0; }
+    for(int t = 0; t < ntiles; t++) { te[t].first = 0x7fffffff; te[t].last = 0; }
     for(int i = 0; i < b->n_segs; i++) {
         int64_t lo = b->seg[i].rpos, hi = lo + b->seg[i].len;
         if(hi <= lo || hi <= b->beg || lo >= b->end) continue;
         if(lo < b->beg) lo = b->beg; if(hi > b->end) hi = b->end;
         int t0 = (int)((lo - b->beg) / TILE), t1 = (int)((hi - 1 - b->beg) / TILE);
-        const uint32_t lq = b->seg[i].l_qseq, bl = 4u * b->seg[i].off4, bh = bl + ((((lq + 1) >> 1) + 3) & ~3u) + lq;      // the read's bytes in the padded blob
-        for(int t = t0; t <= t1; t++) { if(te[t].first > i) te[t].first = i; te[t].last = i + 1; if(bl < te[t].blo) te[t].blo = bl; if(bh > te[t].bhi) te[t].bhi = bh; }
+        for(int t = t0; t <= t1; t++) { if(te[t].first > i) te[t].first = i; te[t].last = i + 1; }
     }
-    for(int t = 0; t < ntiles; t++) if(te[t].last == 0) { te[t].first = 0; te[t].blo = te[t].bhi = 0; }
+    for(int t = 0; t < ntiles; t++) if(te[t].last == 0) te[t].first = 0;
 }
 
 extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
@@ -732,7 +696,7 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     const int ntiles = (int)((span + TILE - 1) / TILE);
     if(s->h_tiles.need((size_t)(ntiles > 0 ? ntiles : 1))) return MDK_ERR_NOMEM;
     build_tiles(b, TILE, s->h_tiles.p, ntiles);
-    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = fixed_lds(TILE, h->variant) + h->stage_bytes;
+    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = fixed_lds(TILE, h->variant);
     s->read_bytes = b->algo_bytes;
     size_t ns = (size_t)b->n_segs, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     if(s->d_seg_in.need(ns + 1) || s->d_blob.need((size_t)b->blob_bytes + 64)) return MDK_ERR_NOMEM;
@@ -770,7 +734,6 @@ static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
         P.site = s->b_site; P.var = s->b_var; P.tseg = s->b_seg; P.cap_sites = s->b_cap_sites;
     } else { P.site = s->d_site.p; P.var = s->d_var.p; P.tseg = s->d_seg.p; P.cap_sites = (int64_t)s->d_site.cap; }
     P.total = s->d_total.p + (s->ring % RING); P.total_next = s->d_total.p + ((s->ring + 1) % RING);
-    P.stage_bytes = h->stage_bytes;
     P.keepmask = (h->cfg.keepCpG ? 1 : 0) | (h->cfg.keepCHG ? 2 : 0) | (h->cfg.keepCHH ? 4 : 0);
     P.minPhred = h->cfg.minPhred;
     for(int i = 0; i < 16; i++) { P.bounds[i] = h->cfg.bounds[i]; P.abounds[i] = h->cfg.absoluteBounds[i]; }
@@ -788,7 +751,8 @@ int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on) {
         KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
         int grid = P.nper * 8;
         if(time_pileup) HIPCHK(hipEventRecord(s->k0, st));
-        PILEUP_LAUNCH(k_pileup, h->variant, h->dense, grid, s->lds_bytes, st, P);
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, st, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, st, P);
         if(time_pileup) HIPCHK(hipEventRecord(s->k1, st));
         HIPCHK(hipGetLastError());
     } else {
@@ -831,7 +795,8 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
     }
     M.n = n; M.tstart[n] = total; M.nper = (total + 7) / 8;
     if(total > 0) {
-        PILEUP_LAUNCH(k_pileup_multi, h->variant, h->dense, M.nper * 8, s0->lds_bytes, st, M);
+        if(h->variant) hipLaunchKernelGGL(k_pileup_multi<true>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
+        else hipLaunchKernelGGL(k_pileup_multi<false>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
         HIPCHK(hipGetLastError());
     }
     for(int i = 0; i < n; i++) get_slot(h, slots[i])->launched = true;      // collected through each slot's `run` stream (finish_count)
@@ -1097,7 +1062,8 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
         HIPCHK(hipMalloc((void **)&dd, nw * 8)); HIPCHK(hipMemset(dd, 0, nw * 8));
         s->ring++; rc = fill_kparams(h, s, P); if(rc) return rc;
         P.dbg = dd;
-        PILEUP_LAUNCH(k_pileup, h->variant, h->dense, grid, s->lds_bytes, s->stream, P);
+        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
+        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipMemcpy(hd.data(), dd, nw * 8, hipMemcpyDeviceToHost)); (void)hipFree(dd);
         unsigned long long r0 = ~0ull, r1 = 0; double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}; size_t cnt = 0; std::vector<double> starts, ends, life;

@@ -21,8 +21,7 @@ MDK_HIDDEN char *mdk_err_buf();            // the calling thread's message buffe
 MDK_HIDDEN int fail(int code, const char *what, hipError_t e);
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return fail(MDK_ERR_HIP, #call, e_); } while(0)
 
-struct TileEnt { int first, last; uint32_t blo, bhi; };     // segments [first,last) of the batch overlap the tile (one contiguous run: the batch is coordinate sorted);
-                                                            // [blo,bhi): bytes of the payload buffer their reads' sequence+qualities occupy (dense contexts stage them in LDS)
+struct TileEnt { int first, last; };     // segments [first,last) of the batch overlap the tile (one contiguous run: the batch is coordinate sorted)
 
 template <typename T> struct DBuf {
     T *p = nullptr; size_t cap = 0;
@@ -80,7 +79,7 @@ struct Slot {
 };
 
 struct md_dev {
-    int device; md_dev_cfg cfg; int tile, n_slots; bool variant, dense = false; int stage_bytes = 0;      // dense: --CHG/--CHH kept: the tile's read payload is staged in LDS
+    int device; md_dev_cfg cfg; int tile, n_slots; bool variant;
     std::vector<Slot> slots;
     std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
     DBuf<SlotStatus> d_status; HBuf<SlotStatus> h_status;

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *cnt, uint3
     __shared__ uint32_t wsum[16]; __shared__ uint32_t carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if(tid == 0) carry = 0;
-    if(tiles) for(int t = tid; t < ntiles; t += 1024) { tiles[t].first = 0x7fffffff; tiles[t].last = 0; tiles[t].blo = 0xffffffffu; tiles[t].bhi = 0; }
+    if(tiles) for(int t = tid; t < ntiles; t += 1024) { tiles[t].first = 0x7fffffff; tiles[t].last = 0; }
     __syncthreads();
     for(int base = 0; base < n; base += 1024) {
         const int i = base + tid; const uint32_t v = i < n ? cnt[i] : 0;
@@ -412,35 +412,21 @@ __global__ __launch_bounds__(PB) void k_seg_write(const PrepParams P) {
     for(int w = 0; w < wave; w++) base += wsum[w];
     int64_t lo = INT64_MAX, hi = INT64_MIN;
     if(n) (void)read_segments<true>(P, a, P.seg, base, lo, hi);
-    // Tile runs: tile t's run [first, last) must cover every segment touching t, and [blo, bhi) the payload bytes of their
-    // reads (dense contexts stage that range in LDS).  A lane contributes [base, base + n) and its read's bytes to every tile
-    // its pieces reach -- a superset, which is all k_pileup needs.  Reads are in coordinate order, so a wave reaches very few
-    // distinct tiles: per tile the wave reduces its lanes' contributions and one lane issues the four atomics, instead of
-    // contended atomics per segment (275 us -> 18 us per 1 Mb chunk).
+    // Tile runs: tile t's run [first, last) must cover every segment touching t.  A lane contributes [base, base + n) to every
+    // tile its pieces reach -- a superset, which is all k_pileup needs.  Reads are in coordinate order, so the lanes of a wave
+    // touching one tile are (nearly always) consecutive: only the first of them lowers `first`, only the last raises `last`,
+    // instead of two contended atomics per segment (275 us -> a few us per 1 Mb chunk).
     int t0 = 0x7fffffff, t1 = -1;
     if(n && hi > lo && (int64_t)base < P.cap_seg) {
         if(lo < P.beg) lo = P.beg;
         if(hi > P.end) hi = P.end;
         t0 = (int)((lo - P.beg) / P.tile); t1 = (int)((hi - 1 - P.beg) / P.tile);
     }
+    const int p0 = __shfl_up(t0, 1), p1 = __shfl_up(t1, 1), n0 = __shfl_down(t0, 1), n1 = __shfl_down(t1, 1);
     uint32_t top = base + n; if((int64_t)top > P.cap_seg) top = (uint32_t)P.cap_seg;
-    uint32_t bl = 0xffffffffu, bh = 0;
-    if(t1 >= t0) { const PrepRead r = P.rd[a]; bl = r.seq_off; bh = r.seq_off + ((r.lq + 1) >> 1) + r.lq; }
-    int next = t0;                                             // lowest tile of this lane not yet handled
-    for(;;) {
-        int t = next <= t1 ? next : 0x7fffffff;
-#pragma unroll
-        for(int d = 32; d; d >>= 1) { const int o = __shfl_xor(t, d); if(o < t) t = o; }       // the wave's lowest unhandled tile
-        if(t == 0x7fffffff) break;
-        const bool mine = next <= t1 && next == t;
-        uint32_t f = mine ? base : 0xffffffffu, l = mine ? top : 0u, x = mine ? bl : 0xffffffffu, y = mine ? bh : 0u;
-#pragma unroll
-        for(int d = 32; d; d >>= 1) {
-            const uint32_t f2 = __shfl_xor(f, d), l2 = __shfl_xor(l, d), x2 = __shfl_xor(x, d), y2 = __shfl_xor(y, d);
-            if(f2 < f) f = f2; if(l2 > l) l = l2; if(x2 < x) x = x2; if(y2 > y) y = y2;
-        }
-        if(lane == 0) { atomicMin(&P.tiles[t].first, (int)f); atomicMax(&P.tiles[t].last, (int)l); atomicMin(&P.tiles[t].blo, x); atomicMax(&P.tiles[t].bhi, y); }
-        if(mine) next++;
+    for(int t = t0; t <= t1; t++) {
+        if(lane == 0 || t < p0 || t > p1) atomicMin(&P.tiles[t].first, (int)base);
+        if(lane == 63 || t < n0 || t > n1) atomicMax(&P.tiles[t].last, (int)top);
     }
 }
 
@@ -522,7 +508,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     const int64_t span = b->end - b->beg; const int TILE = h->tile;
     const int ntiles = (int)((span + TILE - 1) / TILE), n = b->n_records, nb = (n + PB - 1) / PB;
     s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->woff = b->woff; s->wlen = b->wlen; s->uploaded = false; s->launched = false;
-    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = TILE * ((h->variant ? 16 : 8) + 4) + h->stage_bytes;
+    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = TILE * ((h->variant ? 16 : 8) + 4);
     s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->n_segs = -1; s->n_reads = -1; s->read_bytes = 0;
     const size_t nn = (size_t)n + 1, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
