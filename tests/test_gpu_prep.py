@@ -154,3 +154,106 @@ def test_segment_array_growth(tmp_path):
     compare_cli(tmp_path, [str(tmp_path / "d.fa"), str(tmp_path / "d.bam"), "--CHH", "--CHG"])
     n_chunks, n_reads, n_segs = both_ways([str(tmp_path / "d.fa"), str(tmp_path / "d.bam"), "--CHH", "-o", str(tmp_path / "x")])
     assert n_segs == 10 * n_reads
+
+
+def random_bam(tmp_path, seed, n_reads=700, strand0=True):
+    """records the synthetic generator never writes: every aux type (incl. B arrays, H strings, double, malformed tails), NH and
+    XG tags of every integer/char type before and after other tags, names of 1..60 characters, names shared by 1-5 records,
+    CIGARs with I/D/N/S/H/P/=/X and more query bases than the record stores, every flag combination, mates on other contigs"""
+    import random
+    import struct as st
+    from bamwriter import aux_Z, aux_i
+    rng = random.Random(seed)
+    L = 6000
+    ref = "".join(rng.choice("ACGTCGCGN" if i % 97 else "acgt") for i in range(L))
+    names = [("n%d" % k) * rng.randint(1, 6) for k in range(n_reads // 2)] + ["x", "a-very-long-read-name/with:punctuation.and_more_characters_0123456789"]
+    recs = []
+    for _ in range(n_reads):
+        pos = rng.randrange(0, L - 400)
+        ops = []
+        q = 0
+        for _k in range(rng.randint(1, 6)):
+            op = rng.choice("MMMMM=XIDNSHP")
+            ln = rng.randint(1, 60)
+            ops.append((ln, op))
+            if op in "M=XIS":
+                q += ln
+        if not any(op in "M=X" for _, op in ops):
+            ops.append((rng.randint(1, 80), "M")); q += ops[-1][0]
+        cig = "".join(f"{ln}{op}" for ln, op in ops)
+        lq = q if rng.random() < 0.9 else max(0, q - rng.randint(1, 10))           # sometimes fewer bases than the CIGAR consumes
+        seq = "".join(rng.choice("ACGTN") for _ in range(lq))
+        qual = [rng.choice([0, 3, 5, 20, 37, 41, 93, 214, 255]) for _ in range(lq)]
+        flag = rng.choice([0, 16, 99, 147, 83, 163, 65, 129, 113, 177, 73, 89, 1024, 512, 256, 2048, 4, 69, 0x63 | 0x400] + ([1, 3] if strand0 else []))       # 1, 3: paired without read number = strand 0
+        aux = b""
+        tags = []
+        if rng.random() < 0.5:
+            t = rng.choice("cCsSiI")
+            tags.append(aux_i("NH", rng.choice([0, 1, 2, 5, -1] if t in "csi" else [0, 1, 2, 5, 200]), t) if rng.random() < 0.9 else aux_Z("NH", "2"))
+        if rng.random() < 0.5:
+            tags.append(aux_Z("XG", rng.choice(["CT", "GA", "C", "G", "", "TT"])) if rng.random() < 0.85 else aux_i("XG", 7, "C"))
+        for _k in range(rng.randint(0, 4)):
+            t = rng.choice(["AS", "XM", "MD", "ZB", "ZH", "ZD", "ZA"])
+            if t == "AS": tags.append(aux_i("AS", rng.randint(-100, 100), "i"))
+            elif t == "XM": tags.append(aux_Z("XM", "".join(rng.choice("zZ.hHxX") for _ in range(rng.randint(0, 150)))))
+            elif t == "MD": tags.append(aux_Z("MD", str(rng.randint(1, 150))))
+            elif t == "ZB": sub = rng.choice("cCsSiIf"); n = rng.randint(0, 9); w = {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]; tags.append(b"ZBB" + sub.encode() + st.pack("<i", n) + bytes(rng.randrange(256) for _ in range(n * w)))
+            elif t == "ZH": tags.append(b"ZHH" + b"1AE301" + b"\0")
+            elif t == "ZD": tags.append(b"ZDd" + st.pack("<d", rng.random()))
+            else: tags.append(b"ZAA" + bytes([rng.randrange(33, 127)]))
+        rng.shuffle(tags)
+        aux = b"".join(tags)
+        if rng.random() < 0.04:
+            aux += rng.choice([b"XGZCT", b"NH", b"NHq\x01", b"XGB?\x01\0\0\0", b"ZZZunterminated"])        # malformed tail: the walk stops there
+        recs.append((pos, len(recs), record(0, pos, flag, cig, seq, qual, qname=rng.choice(names), mapq=rng.choice([0, 3, 10, 40, 255]),
+                                            mtid=rng.choice([0, 0, 0, 1, -1]), mpos=rng.randrange(0, L), aux=aux)))
+    recs.sort(key=lambda x: (x[0], x[1]))
+    tag = f"r{seed}{'s' if strand0 else 'n'}"
+    write_bam(tmp_path / f"{tag}.bam", [("c1", L), ("c2", 100)], [r for _, _, r in recs])
+    write_fasta(tmp_path / f"{tag}.fa", [("c1", ref), ("c2", "ACGT" * 25)])
+    return str(tmp_path / f"{tag}.fa"), str(tmp_path / f"{tag}.bam")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_device_prep_on_random_records(tmp_path, seed):
+    """host preparation == device preparation (admission, strand, pairing, segments) chunk by chunk on adversarial records, under
+    several option sets; chunks the device hands back (names with many records) are counted, not compared"""
+    with_s0, without_s0 = random_bam(tmp_path, seed), random_bam(tmp_path, seed, strand0=False)
+    for extra in (["-q", "0", "-F", "0", "--keepDupes", "--keepSingleton", "--keepDiscordant", "--CHH", "--chunkSize", "700"],
+                  ["-q", "5", "--ignoreNH", "--chunkSize", "1500", "--CHG"], ["-R", "1", "-F", "1024", "--chunkSize", "6000"],
+                  ["-q", "0", "--minConversionEfficiency", "0.3", "--CHH", "--keepDiscordant", "--keepSingleton", "--chunkSize", "900"]):
+        # (the conversion-efficiency filter aborts the process on a strand-0 read, host and reference alike: those records stay out)
+        fa, bam = without_s0 if "--minConversionEfficiency" in extra else with_s0
+        args = [fa, bam] + extra + ["-o", str(tmp_path / "x")]
+        ph, pd = mdk.Plan(args), mdk.Plan(args)
+        pd.set_prep(1)
+        dev = mdk.Device(ph.dev_cfg()); dev.set_prep(pd.prep_cfg())
+        compared = handed_back = 0
+        while True:
+            ch, cd = ph.next_chunk(), pd.next_chunk()
+            assert (ch is None) == (cd is None)
+            if ch is None:
+                break
+            if ch.skipped:
+                continue
+            ph.ensure_reference(dev, ch.tid); pd.ensure_reference(dev, cd.tid)
+            dev.submit_raw(1, cd.raw)
+            s = mdk.md_sites()
+            rc = dev.L.md_dev_download(dev.h, 1, C.byref(s))
+            if rc == -7:
+                handed_back += 1
+                continue
+            if rc == -5:                       # a strand-0 read reached a call: the host-prepared chunk must say the same
+                dev.submit(0, ch.batch)
+                assert dev.L.md_dev_download(dev.h, 0, C.byref(mdk.md_sites())) == -5
+                continue
+            assert rc == 0, dev.L.md_dev_last_error()
+            got = sites_list(s)
+            segs, n, nr = dev.debug_segments(1)
+            dev.submit(0, ch.batch)
+            assert nr == ch.batch.n_reads and n == ch.batch.n_segs, (seed, extra, ch.index)
+            assert Counter(seg_key(segs[i]) for i in range(n)) == Counter(seg_key(ch.batch.seg[i]) for i in range(ch.batch.n_segs)), (seed, extra, ch.index)
+            assert got == sites_list(dev.download(0)), (seed, extra, ch.index)
+            compared += 1
+        assert compared >= 1
+        dev.close(); ph.close(); pd.close()
