@@ -2,9 +2,11 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o exp_gpu_inflate tools/exp_gpu_inflate.hip -lz ; run: exp_gpu_inflate file.bam 64
 // Round 2 result on MI355X (32 Mb synthetic BAM: 27,774 members, 519 MB compressed, 1.7 GB inflated; output compared byte for
 // byte with zlib: identical): global decode tables + byte refills 108 ms (5.0 GB/s compressed); fast tables in LDS, 32-bit
-// refills, 8-byte match copies 69 ms (7.9 GB/s); refill prefetch + literal batching: no change.  The whole file is only 434
+// refills, 8-byte match copies 69 ms (7.9 GB/s); refill prefetch + literal batching: no change; a uniform micro-step loop (every
+// iteration a lane either copies one chunk of a pending match or decodes one symbol; not kept in this file): 114 ms -- slower.  The whole file is only 434
 // waves (1.7 per CU) and a wave's 64 members diverge: every step costs the longest path among its lanes, and the match copies
-// are loops of dependent global loads (a 258-byte match stalls the other 63 members for ~30 load latencies).  About the speed of
+// are loops of dependent global loads whose s_waitcnt also waits for the lane's preceding byte stores (a match source has to come
+// back through L2 after the stores that produced it; the 32 KiB window per member does not fit on chip for 64 members a wave).  About the speed of
 // 64-128 host threads with libdeflate -- not enough to move the inflate to the device as it is.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
