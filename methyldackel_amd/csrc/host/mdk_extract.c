@@ -70,7 +70,7 @@ static void *gpuopen_main(void *arg) { gpuopen_t *d = arg; d->rc = md_dev_open(d
 
 static int extract_multi(mdk_plan *p, int N, const int *map) {
     md_dev *dev[MDK_MAX_GPUS]; gpuopen_t go[MDK_MAX_GPUS]; pthread_t th[MDK_MAX_GPUS]; int made[MDK_MAX_GPUS]; md_comm *comm = NULL; emitter em;
-    mdk_chunk *ring = NULL; int F = 2 * N, head = 0, count = 0, more = 1, ret = 0, rc, i; uint32_t k = 0; md_prep_cfg pc;
+    mdk_chunk *ring = NULL; int where[2 * MDK_MAX_GPUS][2]; int F = 2 * N, head = 0, count = 0, more = 1, ret = 0, rc, i; uint32_t k = 0; md_prep_cfg pc;      /* where[i]: device and slot of ring[i] */
     memset(dev, 0, sizeof(dev));
     for(i = 0; i < N; i++) { memset(&go[i], 0, sizeof(go[i])); mdk_plan_dev_cfg(p, &go[i].cfg); go[i].device = map[i]; made[i] = pthread_create(&th[i], NULL, gpuopen_main, &go[i]) == 0; }
     if(!p->started && pipeline_start(p)) ret = -5;
@@ -83,7 +83,7 @@ static int extract_multi(mdk_plan *p, int N, const int *map) {
     if(ret) { free(ring); if(comm) md_comm_close(comm); for(i = 0; i < N; i++) if(dev[i]) md_dev_close(dev[i]); mdk_plan_close(p); return ret; }
     while(more || count) {
         if(more && count < F) {                                 /* submit chunk k on device k mod N, slot (k / N) mod 2 */
-            mdk_chunk *c = &ring[(head + count) % F];
+            const int at = (head + count) % F; mdk_chunk *c = &ring[at];
             rc = mdk_plan_next_chunk(p, c);
             if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
             if(rc == 0) { more = 0; continue; }
@@ -92,7 +92,7 @@ static int extract_multi(mdk_plan *p, int N, const int *map) {
                 rc = mdk_plan_ensure_reference(p, dev[d], c->tid);
                 if(!rc) rc = c->prep ? md_dev_submit_raw(dev[d], sl, &c->raw) : md_dev_submit(dev[d], sl, &c->batch);
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
-                c->n_records_seen = ((uint64_t)d << 8) | (uint64_t)sl | (1ull << 63);      /* remember where it went (the field is informational) */
+                where[at][0] = d; where[at][1] = sl;
                 k++;
             }
             count++;
@@ -101,7 +101,7 @@ static int extract_multi(mdk_plan *p, int N, const int *map) {
         {   /* collect the oldest chunk */
             mdk_chunk *c = &ring[head]; md_sites sites; memset(&sites, 0, sizeof(sites));
             if(!c->skipped) {
-                const int d = (int)((c->n_records_seen >> 8) & 0xff), sl = (int)(c->n_records_seen & 0xff);
+                const int d = where[head][0], sl = where[head][1];
                 rc = md_comm_download(comm, d, sl, &sites);
                 if(rc == MDK_ERR_PREP_HOST) {
                     rc = mdk_plan_host_prepare(p, c);
