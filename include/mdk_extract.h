@@ -57,7 +57,7 @@ int  mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid);
 /* 1: chunk produced; 0: schedule finished; <0: error */
 int  mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c);
 /* Where a chunk's per-record work happens.  mode 0 (what mdk_plan_open gives): on the host -- chunks carry `batch`.
- * mode 1 (what extract_main uses): on the device -- chunks carry `raw`, and md_dev_set_prep must be given
+ * mode 1 (what extract_main and mbias_main use; not available to perRead plans): on the device -- chunks carry `raw`, and md_dev_set_prep must be given
  * mdk_plan_prep_cfg's configuration (plus md_dev_set_mappability per contig, done by mdk_plan_ensure_reference).
  * Must be called before the first mdk_plan_next_chunk.  mdk_plan_host_prepare fills `batch` of a mode-1 chunk after all
  * (for a chunk the device answered with MDK_ERR_PREP_HOST); valid until the second-next mdk_plan_next_chunk. */

@@ -129,7 +129,7 @@ HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md
                "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_local", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_download",
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned",
                "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep",
-               "md_dev_mbias_submit", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
+               "md_dev_mbias_submit", "md_dev_mbias_submit_raw", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
                "md_dev_perread_submit", "md_dev_perread_download"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
@@ -195,6 +195,7 @@ def lib_hip():
         L.md_dev_bench_prep.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.md_dev_debug_segments.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_seg), C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.md_dev_mbias_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_read_batch)]
+        L.md_dev_mbias_submit_raw.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_raw_batch)]
         L.md_dev_mbias_read.argtypes = [C.c_void_p, C.POINTER(md_mbias)]
         L.md_dev_mbias_reset.argtypes = [C.c_void_p]
         L.md_dev_slot_sync.argtypes = [C.c_void_p, C.c_int]
@@ -334,6 +335,9 @@ class Device:
     def mbias_submit(self, slot: int, batch: md_read_batch):
         """accumulate the batch's calls into the device histogram; the batch must stay alive until slot_sync(slot)"""
         self._chk(self.L.md_dev_mbias_submit(self.h, slot, C.byref(batch)), "md_dev_mbias_submit")
+
+    def mbias_submit_raw(self, slot: int, raw: "md_raw_batch"):
+        self._chk(self.L.md_dev_mbias_submit_raw(self.h, slot, C.byref(raw)), "md_dev_mbias_submit_raw")
 
     def slot_sync(self, slot: int):
         self._chk(self.L.md_dev_slot_sync(self.h, slot), "md_dev_slot_sync")

@@ -95,11 +95,13 @@ int mbias_main(int argc, char *argv[]) {
     memset(&dop, 0, sizeof(dop));
     mdk_plan_dev_cfg(p, &dop.cfg);
     if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
+    if(!getenv("MDK_HOST_PREP")) mdk_plan_set_prep(p, 1);       /* admission, strand and CIGAR expansion on the device, as in extract (no pairing: MBias.c:158-161) */
     dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
     if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `mbias`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
     for(;; k++) {
         /* chunk k goes to slot k&1; the batch handed out two calls ago is recycled by the next call, so its upload must be over */
         if((rc = md_dev_slot_sync(dev, k & 1)) != 0) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
@@ -109,7 +111,8 @@ int mbias_main(int argc, char *argv[]) {
         if(ch.skipped & MDK_CHUNK_NOREF) { ret = -4; break; }        /* the reference's worker gives up here and its caller then crashes (MBias.c:150-155,543) */
         if(ch.skipped) continue;
         rc = mdk_plan_ensure_reference(p, dev, ch.tid);
-        if(!rc) rc = md_dev_mbias_submit(dev, k & 1, &ch.batch);
+        if(!rc) rc = ch.prep ? md_dev_mbias_submit_raw(dev, k & 1, &ch.raw) : md_dev_mbias_submit(dev, k & 1, &ch.batch);
+        if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
         if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
     }
     if(ret == 0) {

@@ -490,7 +490,7 @@ int mdk_plan_set_shard(mdk_plan *p, int rank, int world) {
 }
 int mdk_plan_set_prep(mdk_plan *p, int mode) {
     if(!p || p->started || mode < 0 || mode > 1) return -1;
-    if(mode == 1 && (p->o.perread || p->o.mbias)) return -1;       /* those commands prepare on the host */
+    if(mode == 1 && p->o.perread) return -1;       /* perRead prepares on the host (its output needs every kept read's name) */
     p->dev_prep = mode;
     return 0;
 }

@@ -853,6 +853,35 @@ extern "C" int md_dev_mbias_submit(md_dev *h, int slot, const md_read_batch *b) 
     return 0;
 }
 
+// the same from the chunk's raw records: the device prepares them (no pairing: md_prep_cfg.no_pairing) and tells how long the
+// longest admitted read is, which sizes the histogram rows kept in LDS -- one wait for the preparation per chunk
+extern "C" int md_dev_mbias_submit_raw(md_dev *h, int slot, const md_raw_batch *b) {
+    if(!h || !h->prep_set || !h->prep.no_pairing) return fail(MDK_ERR_ARG, "md_dev_mbias_submit_raw: md_dev_set_prep with no_pairing first", hipSuccess);
+    int rc = md_dev_upload_raw(h, slot, b);
+    if(rc) return rc;
+    Slot *s = get_slot(h, slot);
+    HIPCHK(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    rc = prep_outcome(h, s);
+    if(rc == MDK_ERR_PREP_REDO) {
+        HIPCHK(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        rc = prep_outcome(h, s);
+    }
+    if(rc) return rc;
+    const int maxlq = (int)s->h_st.p->pc.max_lq;
+    if((rc = hist_reserve(h, maxlq > 1 ? maxlq : 1)) != 0) return rc;
+    if(maxlq > h->hist_len) h->hist_len = maxlq;
+    if(s->ntiles <= 0 || s->n_segs <= 0) return 0;
+    KParams P; if((rc = fill_kparams(h, s, P)) != 0) return rc;
+    P.mbias = 1; P.hist = h->d_hist;
+    P.hist_lq = maxlq < MB_LQ ? (maxlq + 7) & ~7 : MB_LQ; if(P.hist_lq > h->hist_cap) P.hist_lq = h->hist_cap;
+    const size_t lds = (size_t)s->tile * 4 + (size_t)P.hist_lq * 16 * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_mbias, dim3(P.nper * 8), dim3(WG), lds, s->stream, P);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int md_dev_slot_sync(md_dev *h, int slot) {
     Slot *s = get_slot(h, slot);
     if(!s) return MDK_ERR_ARG;

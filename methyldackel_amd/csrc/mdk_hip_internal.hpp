@@ -53,7 +53,7 @@ template <typename T> struct HBuf {
 // device chunk preparation (mdk_prep.hip)
 struct PrepRec  { int32_t pos, rend; uint32_t seq_off, lq, cig_off, qn_off; uint16_t ncig, flag; uint8_t strand, lqname, adm, pad; };    // one candidate record
 struct PrepRead { int32_t pos, rend; uint32_t seq_off, lq, cig_off, qn_off; uint16_t ncig, flag; uint8_t strand, lqname; uint16_t pad; };  // one admitted read, file order
-struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, pad; uint64_t algo_bytes; };
+struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, max_lq; uint64_t algo_bytes; };      // max_lq: longest admitted read (mbias sizes its histogram by it)
 #define MDK_ERR_PREP_REDO (-100)   // internal: the segment array was enlarged and the preparation re-enqueued
 
 // everything the host reads back after a launch, one block per slot inside ONE device array (and its pinned mirror), so that

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(PB) void k_rec_scan(const PrepParams P) {
                 R.strand = (uint8_t)strand;
                 if(keep) {
                     adm = 1;
+                    if(c.no_pairing) atomicMax(&P.cnt->max_lq, (uint32_t)lq);          // mbias: rows of the histogram
                     uint64_t h = 0xcbf29ce484222325ULL;
                     for(uint32_t k = 0; k + 1 < lqn && qn[k]; k++) h = (h ^ qn[k]) * 0x100000001b3ULL;
                     P.hash[i] = h ? h : 1;

@@ -83,3 +83,41 @@ def test_s1_mbias(tmp_path):
     synth(tmp_path / "S1", "-L", "1000000", "-c", "30", "-s", "0x5EED0001")
     compare_mbias(tmp_path, [str(tmp_path / "S1.fa"), str(tmp_path / "S1.bam"), "-@", "8"])
     compare_mbias(tmp_path, [str(tmp_path / "S1.fa"), str(tmp_path / "S1.bam"), "-@", "8", "--CHG", "--CHH", "--nOT", "6,6,6,6", "--nOB", "6,6,6,6"])
+
+
+@pytest.mark.parametrize("extra", [["--CHG", "--CHH", "--chunkSize", "4000", "--nOT", "2,3,4,5"], ["-q", "0", "-F", "0", "--keepDupes", "--keepSingleton", "--keepDiscordant", "--chunkSize", "9000"],
+                                   ["--noCpG", "--CHH", "-p", "20", "--OT", "5,140,5,140"]], ids=["allctx", "everything_admitted", "chh_trim"])
+def test_abi_histogram_device_prep_equals_host_prep(tmp_path, small_synth, extra):
+    """md_dev_mbias_submit_raw (records prepared on the device, no pairing) accumulates the same histogram as md_dev_mbias_submit
+    of the host-built batches; the command (which uses the raw path) is compared with the oracle by the tests above, and with
+    MDK_HOST_PREP=1 below"""
+    args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam")] + extra + ["--noSVG"]
+    hists = []
+    for mode in (0, 1):
+        plan = mdk.Plan(args, command="mbias")
+        plan.set_prep(mode)
+        dev = mdk.Device(plan.dev_cfg())
+        if mode:
+            dev.set_prep(plan.prep_cfg())
+        k = 0
+        while True:
+            dev.slot_sync(k & 1)
+            c = plan.next_chunk()
+            if c is None:
+                break
+            if c.skipped:
+                continue
+            plan.ensure_reference(dev, c.tid)
+            if mode:
+                assert c.prep == 1
+                dev.mbias_submit_raw(k & 1, c.raw)
+            else:
+                dev.mbias_submit(k & 1, c.batch)
+            k += 1
+        hists.append(dev.mbias_read())
+        dev.close(); plan.close()
+    assert hists[0].shape == hists[1].shape and (hists[0] == hists[1]).all() and hists[0].sum() > 1000
+
+
+def test_cli_host_prep_mode(tmp_path, small_synth):
+    compare_mbias(tmp_path, [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--CHG", "--chunkSize", "7000"], env={"MDK_HOST_PREP": "1"}, svg=False)
