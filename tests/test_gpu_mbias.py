@@ -86,7 +86,7 @@ def test_s1_mbias(tmp_path):
 
 
 @pytest.mark.parametrize("extra", [["--CHG", "--CHH", "--chunkSize", "4000", "--nOT", "2,3,4,5"], ["-q", "0", "-F", "0", "--keepDupes", "--keepSingleton", "--keepDiscordant", "--chunkSize", "9000"],
-                                   ["--noCpG", "--CHH", "-p", "20", "--OT", "5,140,5,140"]], ids=["allctx", "everything_admitted", "chh_trim"])
+                                   ["--noCpG", "--CHH", "-p", "20", "--nOB", "1,2,3,4"], ["--CHH", "--minConversionEfficiency", "0.6", "--chunkSize", "5000"]], ids=["allctx", "everything_admitted", "chh_trim", "conversion_efficiency"])
 def test_abi_histogram_device_prep_equals_host_prep(tmp_path, small_synth, extra):
     """md_dev_mbias_submit_raw (records prepared on the device, no pairing) accumulates the same histogram as md_dev_mbias_submit
     of the host-built batches; the command (which uses the raw path) is compared with the oracle by the tests above, and with
