@@ -57,7 +57,7 @@ int  mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid);
 /* 1: chunk produced; 0: schedule finished; <0: error */
 int  mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c);
 /* Where a chunk's per-record work happens.  mode 0 (what mdk_plan_open gives): on the host -- chunks carry `batch`.
- * mode 1 (what extract_main and mbias_main use; not available to perRead plans): on the device -- chunks carry `raw`, and md_dev_set_prep must be given
+ * mode 1 (what the commands use): on the device -- chunks carry `raw`, and md_dev_set_prep must be given
  * mdk_plan_prep_cfg's configuration (plus md_dev_set_mappability per contig, done by mdk_plan_ensure_reference).
  * Must be called before the first mdk_plan_next_chunk.  mdk_plan_host_prepare fills `batch` of a mode-1 chunk after all
  * (for a chunk the device answered with MDK_ERR_PREP_HOST); valid until the second-next mdk_plan_next_chunk. */
@@ -105,6 +105,9 @@ int  mdk_mbias_report(const md_mbias *hist, const char *opref, int svg, int txt,
 int  perRead_main(int argc, char *argv[]);
 int  mdk_plan_open_perread(int argc, char *argv[], mdk_plan **out);
 int  mdk_plan_emit_perread(mdk_plan *p, const mdk_chunk *c, const md_pr_count *counts, int64_t n);
+/* the same for a chunk handed out as raw records (mdk_plan_set_prep(p, 1)): kept[i] = index into c->raw.rec_off of the i-th kept
+ * read, counts[i] its calls (md_dev_perread_download_raw); names and positions are read from the records themselves */
+int  mdk_plan_emit_perread_raw(mdk_plan *p, const mdk_chunk *c, const uint32_t *kept, const md_pr_count *counts, int64_t n);
 
 /* ---- `mergeContext` (mergeContext.c; main.c:19,53-54): text-to-text host tool, no device work ---- */
 int  mergeContext_main(int argc, char *argv[]);

@@ -124,6 +124,7 @@ typedef struct {
     float   min_conv_eff;         /* --minConversionEfficiency, 0 = off */
     int32_t map_on, min_mappable; /* -M/-B given; --minMappableBases */
     int32_t no_pairing;           /* mbias: no overlap handler is installed (MBias.c:158-161) */
+    int32_t perread;              /* perRead: a record is kept iff it STARTS inside the chunk and passes -R / -F / -q (perRead.c:178-183) */
 } md_prep_cfg;
 /* host memory holding whole records back to back, each as in the file: uint32 block_size, then block_size bytes */
 typedef struct { const uint8_t *ptr; uint64_t bytes; } md_raw_range;
@@ -208,6 +209,10 @@ typedef struct { int32_t tid; int64_t beg, end; int32_t n_reads; const md_pr_rea
 typedef struct { uint32_t nmeth, nunmeth; } md_pr_count;
 int  md_dev_perread_submit(md_dev *h, int slot, const md_pr_batch *b);                 /* H2D + kernel + D2H enqueued on the slot's stream */
 int  md_dev_perread_download(md_dev *h, int slot, const md_pr_count **counts, int64_t *n);   /* waits; memory owned by the slot */
+/* the same from the chunk's raw records (md_dev_set_prep with perread = 1): the device selects the reads (kept[i] = index into
+ * the batch's rec_off of the i-th kept read, ascending) and walks them; n kept reads, counts[i] belongs to kept[i] */
+int  md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch *b);
+int  md_dev_perread_download_raw(md_dev *h, int slot, const uint32_t **kept, const md_pr_count **counts, int64_t *n);
 
 /* slot in [0, n_slots): upload is H2D on the slot's stream; launch enqueues the kernels; download waits for
  * the slot and returns the sites.  md_dev_submit = upload + launch. */

@@ -53,7 +53,7 @@ class md_read_batch(C.Structure):
 class md_prep_cfg(C.Structure):
     _fields_ = [("min_mapq", C.c_int32), ("ignore_flags", C.c_int32), ("require_flags", C.c_int32), ("keep_dupes", C.c_int32), ("ignore_nh", C.c_int32),
                 ("keep_singleton", C.c_int32), ("keep_discordant", C.c_int32), ("min_phred", C.c_int32), ("min_conv_eff", C.c_float),
-                ("map_on", C.c_int32), ("min_mappable", C.c_int32), ("no_pairing", C.c_int32)]
+                ("map_on", C.c_int32), ("min_mappable", C.c_int32), ("no_pairing", C.c_int32), ("perread", C.c_int32)]
 
 
 class md_raw_range(C.Structure):
@@ -130,12 +130,12 @@ HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned",
                "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep",
                "md_dev_mbias_submit", "md_dev_mbias_submit_raw", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
-               "md_dev_perread_submit", "md_dev_perread_download"]
+               "md_dev_perread_submit", "md_dev_perread_download", "md_dev_perread_submit_raw", "md_dev_perread_download_raw"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len", "mdk_plan_regions", "mdk_plan_set_prep", "mdk_plan_set_hold", "mdk_plan_prep_cfg", "mdk_plan_host_prepare",
                    "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report",
-                   "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread", "mergeContext_main"]
+                   "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread", "mdk_plan_emit_perread_raw", "mergeContext_main"]
 
 _hip = None
 _ext = None
@@ -201,6 +201,8 @@ def lib_hip():
         L.md_dev_slot_sync.argtypes = [C.c_void_p, C.c_int]
         L.md_dev_perread_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_pr_batch)]
         L.md_dev_perread_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(md_pr_count)), C.POINTER(C.c_int64)]
+        L.md_dev_perread_submit_raw.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_raw_batch)]
+        L.md_dev_perread_download_raw.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(md_pr_count)), C.POINTER(C.c_int64)]
         L.md_host_alloc.restype = C.c_void_p
         L.md_host_alloc.argtypes = [C.c_uint64]
         L.md_host_free.argtypes = [C.c_void_p]
@@ -237,6 +239,7 @@ def lib_extract():
         L.mergeContext_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
         L.mdk_plan_open_perread.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p)]
         L.mdk_plan_emit_perread.argtypes = [C.c_void_p, C.POINTER(mdk_chunk), C.POINTER(md_pr_count), C.c_int64]
+        L.mdk_plan_emit_perread_raw.argtypes = [C.c_void_p, C.POINTER(mdk_chunk), C.POINTER(C.c_uint32), C.POINTER(md_pr_count), C.c_int64]
         L.mdk_plan_regions.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(md_region)), C.POINTER(C.c_int64)]
         L.mdk_plan_set_prep.argtypes = [C.c_void_p, C.c_int]
         L.mdk_plan_prep_cfg.argtypes = [C.c_void_p, C.POINTER(md_prep_cfg)]; L.mdk_plan_prep_cfg.restype = None
@@ -357,6 +360,13 @@ class Device:
         out, n = C.POINTER(md_pr_count)(), C.c_int64()
         self._chk(self.L.md_dev_perread_download(self.h, slot, C.byref(out), C.byref(n)), "md_dev_perread_download")
         return [(out[i].nmeth, out[i].nunmeth) for i in range(n.value)]
+
+    def perread_raw(self, slot: int, raw: "md_raw_batch"):
+        """perRead from a chunk's raw records: -> (kept record indices, [(nmeth, nunmeth)]) as the device selected and walked them"""
+        self._chk(self.L.md_dev_perread_submit_raw(self.h, slot, C.byref(raw)), "md_dev_perread_submit_raw")
+        kept, out, n = C.POINTER(C.c_uint32)(), C.POINTER(md_pr_count)(), C.c_int64()
+        self._chk(self.L.md_dev_perread_download_raw(self.h, slot, C.byref(kept), C.byref(out), C.byref(n)), "md_dev_perread_download_raw")
+        return [kept[i] for i in range(n.value)], [(out[i].nmeth, out[i].nunmeth) for i in range(n.value)]
 
     def mbias_reset(self):
         self._chk(self.L.md_dev_mbias_reset(self.h), "md_dev_mbias_reset")

@@ -84,6 +84,32 @@ int mdk_plan_emit_perread(mdk_plan *p, const mdk_chunk *c, const md_pr_count *co
     return 0;
 }
 
+int mdk_plan_emit_perread_raw(mdk_plan *p, const mdk_chunk *c, const uint32_t *kept, const md_pr_count *counts, int64_t n) {
+    const char *chrom; int64_t i; char line[10000]; sbuf *ob; int r = 0; uint64_t base = 0;
+    if(!p || !c || !p->o.perread || !c->prep || (n && (!kept || !counts))) return -1;
+    if(c->index != p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
+    p->next_emit++;
+    if(c->skipped) return 0;
+    chrom = p->bam->target_name[c->tid];
+    ob = &p->ob[0]; ob->l = 0;
+    for(i = 0; i < n; i++) {                          /* addRead, perRead.c:16-36; the kept reads come in file order, so the range cursor only moves forward */
+        uint32_t m = counts[i].nmeth, u = counts[i].nunmeth, off; const uint8_t *rec; int32_t pos; int l;
+        if((int64_t)kept[i] >= c->raw.n_records) return -2;
+        off = c->raw.rec_off[kept[i]];
+        while(r < c->raw.n_ranges && (uint64_t)off >= base + c->raw.range[r].bytes) { base += c->raw.range[r].bytes; r++; }
+        if(r >= c->raw.n_ranges) return -2;
+        rec = c->raw.range[r].ptr + (off - base) + 4;
+        memcpy(&pos, rec + 4, 4);
+        if(m + u > 0) l = snprintf(line, sizeof(line), "%s\t%s\t%" PRId64 "\t%f\t%" PRIu32 "\n", (const char *)(rec + 32), chrom, (int64_t)pos, 100. * ((double)m) / (m + u), m + u);
+        else l = snprintf(line, sizeof(line), "%s\t%s\t%" PRId64 "\t0.0\t%" PRIu32 "\n", (const char *)(rec + 32), chrom, (int64_t)pos, m + u);
+        if(l >= (int)sizeof(line)) l = (int)sizeof(line) - 1;
+        sb_put(ob, line, (size_t)l);
+    }
+    if(ob->l) fputs(ob->s, p->pr_out);
+    ob->l = 0;
+    return 0;
+}
+
 int perRead_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; int dth_ok;
     if(argc > 2) hip_warm_up();
@@ -92,11 +118,13 @@ int perRead_main(int argc, char *argv[]) {
     memset(&dop, 0, sizeof(dop));
     mdk_plan_dev_cfg(p, &dop.cfg);
     if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
+    if(!getenv("MDK_HOST_PREP")) mdk_plan_set_prep(p, 1);       /* the device selects the reads (perRead.c:178-183) and walks them where they lie in the records */
     dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
     if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `perRead`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
     while(more || have[0] || have[1]) {       /* two chunks in flight, as in extract_main */
         int cur = k & 1, prev = cur ^ 1;
         if(more) {
@@ -104,7 +132,11 @@ int perRead_main(int argc, char *argv[]) {
             if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
             if(rc == 0) more = 0;
             else {
-                if(!ch[cur].skipped && ch[cur].pr.n_reads) {
+                if(ch[cur].prep && !ch[cur].skipped) {
+                    rc = mdk_plan_ensure_reference(p, dev, ch[cur].tid);
+                    if(!rc) rc = md_dev_perread_submit_raw(dev, cur, &ch[cur].raw);
+                    if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+                } else if(!ch[cur].skipped && ch[cur].pr.n_reads) {
                     rc = mdk_plan_ensure_reference(p, dev, ch[cur].tid);
                     if(!rc) rc = md_dev_perread_submit(dev, cur, &ch[cur].pr);
                     if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
@@ -114,6 +146,15 @@ int perRead_main(int argc, char *argv[]) {
         }
         if(have[prev]) {
             const md_pr_count *cnt = NULL; int64_t n = 0;
+            if(ch[prev].prep && !ch[prev].skipped) {
+                const uint32_t *kept = NULL;
+                rc = md_dev_perread_download_raw(dev, prev, &kept, &cnt, &n);
+                if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+                if(mdk_plan_emit_perread_raw(p, &ch[prev], kept, cnt, n)) { ret = MDK_RC_DEVICE; break; }
+                have[prev] = 0; k++;
+                if(!more && !have[0] && !have[1]) break;
+                continue;
+            }
             if(!ch[prev].skipped && ch[prev].pr.n_reads) {
                 rc = md_dev_perread_download(dev, prev, &cnt, &n);
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }

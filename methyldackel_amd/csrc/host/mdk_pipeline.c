@@ -590,10 +590,13 @@ static void *reader_main(void *arg) {
         rc = reader_fill(p, sl);
         pthread_mutex_lock(&p->mu);
         p->t_rwait += t1 - t0; p->t_rfill += now_s() - t1;
-        if(rc == 1 && p->dev_prep && !sl->c.skipped) { int r2 = describe_raw(p, sl); if(r2 < 0) rc = r2; }
-        if(rc == 1 && p->dev_prep) { sl->rc = 0; sl->state = S_DONE; pthread_cond_broadcast(&p->cv_done); }     /* nothing to do per record on the host */
-        else if(rc == 1) { sl->state = S_RAW; pthread_cond_signal(&p->cv_raw); }
-        else { sl->state = S_FREE; if(rc < 0) p->pipe_rc = rc; p->reader_done = 1; pthread_cond_broadcast(&p->cv_raw); pthread_cond_broadcast(&p->cv_done); }
+        {   /* perRead lists the reads of a contig the FASTA lacks with zero calls (perRead.c:176): no device work, the host selects them */
+            const int host_listing = p->o.perread && sl->c.skipped == MDK_CHUNK_NOREF;
+            if(rc == 1 && p->dev_prep && !sl->c.skipped) { int r2 = describe_raw(p, sl); if(r2 < 0) rc = r2; }
+            if(rc == 1 && p->dev_prep && !host_listing) { sl->rc = 0; sl->state = S_DONE; pthread_cond_broadcast(&p->cv_done); }     /* nothing to do per record on the host */
+            else if(rc == 1) { sl->state = S_RAW; pthread_cond_signal(&p->cv_raw); }
+            else { sl->state = S_FREE; if(rc < 0) p->pipe_rc = rc; p->reader_done = 1; pthread_cond_broadcast(&p->cv_raw); pthread_cond_broadcast(&p->cv_done); }
+        }
         pthread_mutex_unlock(&p->mu);
         if(rc != 1) break;
     }

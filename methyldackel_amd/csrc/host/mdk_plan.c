@@ -490,7 +490,6 @@ int mdk_plan_set_shard(mdk_plan *p, int rank, int world) {
 }
 int mdk_plan_set_prep(mdk_plan *p, int mode) {
     if(!p || p->started || mode < 0 || mode > 1) return -1;
-    if(mode == 1 && p->o.perread) return -1;       /* perRead prepares on the host (its output needs every kept read's name) */
     p->dev_prep = mode;
     return 0;
 }
@@ -505,7 +504,7 @@ void mdk_plan_prep_cfg(const mdk_plan *p, md_prep_cfg *cfg) {
     cfg->min_mapq = o->min_mapq; cfg->ignore_flags = o->ignore_flags; cfg->require_flags = o->require_flags; cfg->keep_dupes = o->keep_dupes;
     cfg->ignore_nh = o->ignore_nh; cfg->keep_singleton = o->keep_singleton; cfg->keep_discordant = o->keep_discordant;
     cfg->min_phred = o->min_phred; cfg->min_conv_eff = (float)o->min_conv_eff; cfg->map_on = p->map_on; cfg->min_mappable = o->min_mappable;
-    cfg->no_pairing = o->mbias;
+    cfg->no_pairing = o->mbias; cfg->perread = o->perread;
 }
 int mdk_plan_n_targets(const mdk_plan *p) { return p->bam->n_targets; }
 const char *mdk_plan_target_name(const mdk_plan *p, int32_t tid) { return (tid >= 0 && tid < p->bam->n_targets) ? p->bam->target_name[tid] : NULL; }

@@ -469,44 +469,13 @@ struct PRParams {
     const md_pr_read *read; const uint32_t *cigar; const uint8_t *blob; const uint8_t *ctxcode;
     int64_t reflen, wend; int n, minPhred; md_pr_count *out;
 };
-__device__ __forceinline__ int pr_cigar_type(uint32_t op) { return (0x3C1A7u >> ((op & 15) << 1)) & 3; }    // M I D N S H P = X (B: 0): bit 0 query, bit 1 reference
-
 __global__ __launch_bounds__(256) void k_perread(const PRParams P) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if(i >= P.n) return;
     const md_pr_read r = P.read[i];
     const uint8_t *seq = P.blob + 4ull * r.off4, *qual = seq + ((((r.l_qseq + 1) >> 1) + 3) & ~3u);
     const uint32_t *cig = P.cigar + r.cig_off;
-    const bool odd = r.strand & 1;
-    uint32_t rp = 0, mp = (uint32_t)r.pos, nm = 0, nu = 0; int k = 0, off = 0;
-    while(rp < r.l_qseq && k < (int)r.n_cigar) {
-        if(off >= (int)(cig[k] >> 4)) { off = 0; k++; }
-        if(k >= (int)r.n_cigar) break;
-        const uint32_t c = cig[k]; const int type = pr_cigar_type(c);
-        if(type & 2) {
-            if(type & 1) {
-                if((int)qual[rp] < P.minPhred) { mp++; rp++; off++; }
-                int dir = 0;
-                if((int64_t)mp <= P.wend && (int64_t)mp < P.reflen) {
-                    const int code = P.ctxcode[mp] & 15;
-                    if(code == 1) dir = ((int64_t)mp == P.wend) ? 0 : 1;       // C of a CpG
-                    else if(code == 2) dir = -1;                                // G of a CpG
-                }
-                if(dir) {
-                    int b;
-                    if(rp < r.l_qseq) b = (seq[rp >> 1] >> ((~rp & 1) << 2)) & 15;
-                    else if(r.l_qseq & 1) b = seq[rp >> 1] & 15;
-                    else b = (qual[0] >> 4) & 15;
-                    if(dir == 1 && odd) { if(b == 2) nm++; else if(b == 8) nu++; }
-                    else if(dir == -1 && !odd) { if(b == 4) nm++; else if(b == 1) nu++; }
-                }
-                mp++; rp++; off++;
-            } else { mp += c >> 4; k++; off = 0; }
-        } else if(type & 1) { rp += c >> 4; k++; off = 0; }
-        else { off = 0; k++; }
-    }
-    md_pr_count o; o.nmeth = nm; o.nunmeth = nu;
-    P.out[i] = o;
+    P.out[i] = perread_walk(seq, qual, r.l_qseq, (int)r.n_cigar, r.pos, r.strand & 1, P.ctxcode, P.reflen, P.wend, P.minPhred, [cig](int k) { return cig[k]; });
 }
 
 // test hook: effective (post-trim, post-overlap-resolution) base and quality of every base of every segment,
@@ -603,7 +572,7 @@ extern "C" void md_dev_close(md_dev *h) {
     for(auto &s : h->slots) {
         s.d_seg_in.release(); s.d_blob.release(); s.d_tiles.release(); s.h_tiles.release();
         s.d_raw.release(); s.d_recoff.release(); s.d_prec.release(); s.d_hash.release(); s.d_blk.release(); s.d_prd.release(); s.d_mate.release(); s.d_second.release();
-        s.d_segcnt.release(); s.d_hkey.release(); s.d_hhead.release(); s.d_hnext.release();
+        s.d_segcnt.release(); s.d_aidx.release(); s.h_aidx.release(); s.d_hkey.release(); s.d_hhead.release(); s.d_hnext.release();
         s.d_pr.release(); s.d_cig.release(); s.d_prc.release(); s.h_prc.release();
         s.d_site.release(); s.d_var.release(); s.d_seg.release();
         s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release();

@@ -69,7 +69,7 @@ struct Slot {
     HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; Ref<SlotStatus> h_st; int index = 0;
     hipStream_t run = nullptr; bool fresh = false;       // run: the stream the latest pileup launch went to; fresh: work queued on `stream` that no launch has been ordered after yet
     DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRec> d_prec; DBuf<uint64_t> d_hash; DBuf<uint32_t> d_blk; DBuf<PrepRead> d_prd; DBuf<int32_t> d_mate; DBuf<uint8_t> d_second;
-    DBuf<uint32_t> d_segcnt; DBuf<uint64_t> d_hkey; DBuf<int32_t> d_hhead, d_hnext; Ref<PrepCounters> d_pcnt;
+    DBuf<uint32_t> d_segcnt, d_aidx; HBuf<uint32_t> h_aidx; DBuf<uint64_t> d_hkey; DBuf<int32_t> d_hhead, d_hnext; Ref<PrepCounters> d_pcnt;
     uint32_t hmask = 0; int pr_nrec = 0; uint64_t raw_bytes = 0; bool raw_layout = false; int64_t woff = 0, wlen = 0;
     DBuf<md_pr_read> d_pr; DBuf<uint32_t> d_cig; DBuf<md_pr_count> d_prc; HBuf<md_pr_count> h_prc; int pr_n = -1;      // perRead
     // caller-bound output (device memory owned by the caller)
@@ -88,6 +88,47 @@ struct md_dev {
     uint32_t *d_hist = nullptr; int hist_cap = 0, hist_len = 0; std::vector<uint32_t> h_hist;      // mbias: rows [q][16], q < hist_cap
 };
 
+
+// perRead (perRead.c:38-94): the walk of one read over its CIGAR, shared by the kernel over host-built batches (k_perread) and the
+// one over device-prepared records (k_perread_raw).  `cig(k)` returns CIGAR word k.  What it does after a base below -p -- it steps
+// one base on and evaluates that base without looking at its quality or at the CIGAR again, which can run one element past the
+// sequence -- is the reference's; that element is what the BAM record holds there (padding nibble of the last sequence byte, or
+// the high nibble of the first quality byte).  CpG context comes from the resident context codes, clipped to the window the command
+// fetches for the chunk ([max(beg-2,0), end+10000], perRead.c:176): past `wend` nothing is a CpG, and a C at `wend` is not one.
+__device__ __forceinline__ int pr_cigar_type(uint32_t op) { return (0x3C1A7u >> ((op & 15) << 1)) & 3; }    // M I D N S H P = X (B: 0): bit 0 query, bit 1 reference
+template <typename CigarAt>
+__device__ __forceinline__ md_pr_count perread_walk(const uint8_t *seq, const uint8_t *qual, uint32_t l_qseq, int n_cigar, int32_t pos, bool odd,
+                                                    const uint8_t *ctxcode, int64_t reflen, int64_t wend, int minPhred, CigarAt cig) {
+    uint32_t rp = 0, mp = (uint32_t)pos, nm = 0, nu = 0; int k = 0, off = 0;
+    while(rp < l_qseq && k < n_cigar) {
+        if(off >= (int)(cig(k) >> 4)) { off = 0; k++; }
+        if(k >= n_cigar) break;
+        const uint32_t c = cig(k); const int type = pr_cigar_type(c);
+        if(type & 2) {
+            if(type & 1) {
+                if((int)qual[rp] < minPhred) { mp++; rp++; off++; }
+                int dir = 0;
+                if((int64_t)mp <= wend && (int64_t)mp < reflen) {
+                    const int code = ctxcode[mp] & 15;
+                    if(code == 1) dir = ((int64_t)mp == wend) ? 0 : 1;       // C of a CpG
+                    else if(code == 2) dir = -1;                              // G of a CpG
+                }
+                if(dir) {
+                    int b;
+                    if(rp < l_qseq) b = (seq[rp >> 1] >> ((~rp & 1) << 2)) & 15;
+                    else if(l_qseq & 1) b = seq[rp >> 1] & 15;
+                    else b = (qual[0] >> 4) & 15;
+                    if(dir == 1 && odd) { if(b == 2) nm++; else if(b == 8) nu++; }
+                    else if(dir == -1 && !odd) { if(b == 4) nm++; else if(b == 1) nu++; }
+                }
+                mp++; rp++; off++;
+            } else { mp += c >> 4; k++; off = 0; }
+        } else if(type & 1) { rp += c >> 4; k++; off = 0; }
+        else { off = 0; k++; }
+    }
+    md_pr_count o; o.nmeth = nm; o.nunmeth = nu;
+    return o;
+}
 
 MDK_HIDDEN Slot *get_slot(md_dev *h, int slot);
 MDK_HIDDEN int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on = nullptr);

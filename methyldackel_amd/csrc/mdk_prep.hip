@@ -35,7 +35,7 @@ struct PrepParams {
     const md_region *runs; int64_t nruns; int bed_on;
     PrepRec *rec; uint64_t *hash;                    // per candidate record
     uint32_t *blockcnt, *blockoff; int nblocks;
-    PrepRead *rd; int32_t *mate; uint8_t *second;    // per admitted read
+    PrepRead *rd; int32_t *mate; uint8_t *second; uint32_t *aidx;    // per admitted read (aidx: its index among the candidate records)
     uint64_t *hkey; int32_t *hhead, *hnext; uint32_t hmask;
     uint32_t *segcnt; uint32_t *segblk, *segblkoff;  // per admitted read / per block
     md_seg *seg; int64_t cap_seg;
@@ -177,6 +177,15 @@ __global__ __launch_bounds__(PB) void k_rec_scan(const PrepParams P) {
                 R.pos = pos; R.rend = pos + rlen; R.lq = (uint32_t)lq; R.ncig = (uint16_t)ncig; R.flag = (uint16_t)flag; R.lqname = (uint8_t)lqn;
                 R.seq_off = (uint32_t)(seq - P.raw); R.cig_off = (uint32_t)(cig - P.raw); R.qn_off = (uint32_t)(qn - P.raw);
                 const md_prep_cfg &c = P.cfg;
+                if(c.perread) {          // perRead.c:178-183: alignments that start inside the chunk; flag masks and MAPQ only
+                    const uint8_t *nh, *xg;
+                    bool keepr = (int64_t)pos >= P.beg && (int64_t)pos < P.end;
+                    keepr = keepr && !(c.require_flags && ((uint32_t)c.require_flags & flag) != (uint32_t)c.require_flags);
+                    keepr = keepr && !(c.ignore_flags && ((uint32_t)c.ignore_flags & flag) != 0) && (int)mapq >= c.min_mapq;
+                    if(keepr) { scan_aux(aux, end, nh, xg); R.strand = (uint8_t)strand_of(flag, xg); adm = 1; }
+                    R.adm = (uint8_t)adm; P.rec[i] = R;
+                    goto counted;
+                }
                 // filter_func, common.c:416-444 (the region query behind it: pos < end, bam_endpos > beg)
                 bool keep = tid == P.tid && !(flag & 0x4) && (int64_t)pos < P.end && (int64_t)pos + (rlen > 0 ? rlen : 1) > P.beg;
                 keep = keep && (int)mapq >= c.min_mapq && !(flag & (uint32_t)c.ignore_flags);
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(PB) void k_rec_scan(const PrepParams P) {
         R.adm = (uint8_t)adm;
         P.rec[i] = R;
     }
+counted:
     const unsigned long long m = __ballot(adm);
     if((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
     __syncthreads();
@@ -258,7 +268,8 @@ __global__ __launch_bounds__(PB) void k_compact(const PrepParams P) {
     for(int w = 0; w < wave; w++) a += wcnt[w];
     PrepRead D; D.pos = R.pos; D.rend = R.rend; D.seq_off = R.seq_off; D.lq = R.lq; D.cig_off = R.cig_off; D.qn_off = R.qn_off; D.ncig = R.ncig; D.flag = R.flag; D.strand = R.strand; D.lqname = R.lqname; D.pad = 0;
     P.rd[a] = D; P.mate[a] = -1; P.second[a] = 0;
-    if(P.cfg.no_pairing) return;
+    if(P.aidx) P.aidx[a] = (uint32_t)i;
+    if(P.cfg.no_pairing || P.cfg.perread) return;
     // name table: open addressing on the 64-bit hash, members chained through hnext (order is restored by k_pair)
     const uint64_t h = P.hash[i]; uint32_t s = (uint32_t)(h ^ (h >> 32)) & P.hmask;
     for(;;) {
@@ -431,6 +442,15 @@ __global__ __launch_bounds__(PB) void k_seg_write(const PrepParams P) {
     }
 }
 
+// perRead over device-selected reads: the walk of k_perread on the records where they lie
+__global__ __launch_bounds__(PB) void k_perread_raw(const PrepParams P, const uint8_t *ctxcode, int64_t wend, md_pr_count *out) {
+    const uint32_t a = blockIdx.x * PB + threadIdx.x;
+    if(a >= P.cnt->n_adm) return;
+    const PrepRead r = P.rd[a];
+    const uint8_t *seq = P.raw + r.seq_off, *qual = seq + ((r.lq + 1) >> 1), *cg = P.raw + r.cig_off;
+    out[a] = perread_walk(seq, qual, r.lq, (int)r.ncig, r.pos, r.strand & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg](int k) { return ld32(cg + 4 * k); });
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -536,6 +556,56 @@ extern "C" int md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b) {
     int rc = md_dev_upload_raw(h, slot, b);
     if(rc) return rc;
     return md_dev_launch(h, slot);
+}
+
+extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch *b) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !b || b->n_records < 0 || b->n_ranges < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw", hipSuccess);
+    if(!h->prep_set || !h->prep.perread) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: md_dev_set_prep with perread first", hipSuccess);
+    if(b->n_records && (!b->range || !b->rec_off)) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: null array", hipSuccess);
+    if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->pr_n = -1; s->uploaded = false; s->launched = false;
+    uint64_t total = 0;
+    for(int i = 0; i < b->n_ranges; i++) total += b->range[i].bytes;
+    if(total >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: more than 4 GiB of records in one chunk", hipSuccess);
+    const int n = b->n_records, nb = (n + PB - 1) / PB; const size_t nn = (size_t)n + 1;
+    s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true;
+    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prec.need(nn) || s->d_hash.need(nn) || s->d_blk.need(4 * (size_t)(nb + 1)) || s->d_prd.need(nn) ||
+       s->d_mate.need(nn) || s->d_second.need(nn) || s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
+    uint64_t o = 0;
+    for(int i = 0; i < b->n_ranges; i++) { if(b->range[i].bytes) HIPCHK(hipMemcpyAsync(s->d_raw.p + o, b->range[i].ptr, (size_t)b->range[i].bytes, hipMemcpyHostToDevice, s->stream)); o += b->range[i].bytes; }
+    if(n) HIPCHK(hipMemcpyAsync(s->d_recoff.p, b->rec_off, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    PrepParams P; memset(&P, 0, sizeof(P));
+    P.raw = s->d_raw.p; P.raw_bytes = total; P.rec_off = s->d_recoff.p; P.n_rec = n; P.cfg = h->prep; P.tid = b->tid; P.beg = b->beg; P.end = b->end;
+    P.ref = h->ref[b->tid]; P.reflen = h->reflen[b->tid];
+    P.rec = s->d_prec.p; P.hash = s->d_hash.p; P.blockcnt = s->d_blk.p; P.blockoff = s->d_blk.p + nb; P.nblocks = nb;
+    P.rd = s->d_prd.p; P.mate = s->d_mate.p; P.second = s->d_second.p; P.aidx = s->d_aidx.p; P.cnt = s->d_pcnt.p;
+    HIPCHK(hipMemsetAsync(s->d_pcnt.p, 0, sizeof(PrepCounters), s->stream));
+    if(n > 0) hipLaunchKernelGGL(k_rec_scan, dim3(nb), dim3(PB), 0, s->stream, P);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s->stream, (const uint32_t *)P.blockcnt, P.blockoff, nb, &s->d_pcnt.p->n_adm, (TileEnt *)nullptr, 0);
+    if(n > 0) {
+        hipLaunchKernelGGL(k_compact, dim3(nb), dim3(PB), 0, s->stream, P);
+        int64_t wend = b->end + 10000; if(wend > P.reflen - 1) wend = P.reflen - 1;
+        hipLaunchKernelGGL(k_perread_raw, dim3(nb), dim3(PB), 0, s->stream, P, (const uint8_t *)h->refcode[b->tid], wend, s->d_prc.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(s->h_aidx.p, s->d_aidx.p, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(s->h_prc.p, s->d_prc.p, sizeof(md_pr_count) * (size_t)n, hipMemcpyDeviceToHost, s->stream));
+    }
+    HIPCHK(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, s->stream));
+    s->pr_n = n;
+    return 0;
+}
+
+extern "C" int md_dev_perread_download_raw(md_dev *h, int slot, const uint32_t **kept, const md_pr_count **counts, int64_t *n) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !kept || !counts || !n || s->pr_n < 0) return fail(MDK_ERR_ARG, "md_dev_perread_download_raw: nothing submitted on this slot", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if(s->h_st.p->pc.malformed) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "malformed BAM record in the chunk"); return MDK_ERR_ARG; }
+    *kept = s->h_aidx.p; *counts = s->h_prc.p; *n = (int64_t)s->h_st.p->pc.n_adm;
+    return 0;
 }
 
 // after the slot's stream has drained: what the preparation found.  MDK_ERR_PREP_REDO: the segment array was too small and

@@ -1,5 +1,7 @@
 """GPU parity for `perRead`: `MethylDackel perRead` (k_perread, one lane per read) against the oracle's restatement of
 perRead.c -- output text byte-identical; and the kernel at the C-ABI against the slow Python walk."""
+import ctypes as C
+
 import pytest
 
 import methyldackel_amd as mdk
@@ -69,3 +71,45 @@ def test_s1_perread(tmp_path):
     synth(tmp_path / "S1", "-L", "1000000", "-c", "30", "-s", "0x5EED0001")
     compare(tmp_path, [str(tmp_path / "S1.fa"), str(tmp_path / "S1.bam"), "-@", "8"])
     compare(tmp_path, [str(tmp_path / "S1.fa"), str(tmp_path / "S1.bam"), "-@", "8", "-p", "20", "-q", "0"])
+
+
+@pytest.mark.parametrize("extra", [["-p", "25", "--chunkSize", "9000"], ["-q", "0", "-F", "16", "-R", "1", "--chunkSize", "3000"], ["-p", "1", "-q", "40"]], ids=["p25", "flags", "p1_q40"])
+def test_abi_device_selected_reads_equal_host_selected(tmp_path, small_synth, extra):
+    """md_dev_perread_submit_raw (the device selects the reads that start in the chunk and pass -R/-F/-q, and walks them where they
+    lie in the BAM records) against md_dev_perread_submit of the host-selected reads: same reads in the same order (checked by
+    position), same counts"""
+    import struct
+    args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam")] + extra + ["-o", str(tmp_path / "x")]
+    ph, pd = mdk.Plan(args, command="perRead"), mdk.Plan(args, command="perRead")
+    pd.set_prep(1)
+    dev = mdk.Device(ph.dev_cfg()); dev.set_prep(pd.prep_cfg())
+    assert pd.prep_cfg().perread == 1
+    n = 0
+    while True:
+        ch, cd = ph.next_chunk(), pd.next_chunk()
+        assert (ch is None) == (cd is None)
+        if ch is None:
+            break
+        if ch.skipped:
+            continue
+        ph.ensure_reference(dev, ch.tid)
+        want = dev.perread(0, ch.pr) if ch.pr.n_reads else []
+        kept, got = dev.perread_raw(1, cd.raw)
+        assert got == want, ch.index
+        cat = b"".join(C.string_at(cd.raw.range[i].ptr, cd.raw.range[i].bytes) for i in range(cd.raw.n_ranges))
+        pos = [struct.unpack_from("<i", cat, cd.raw.rec_off[k] + 8)[0] for k in kept]
+        assert pos == [ch.pr.read[i].pos for i in range(ch.pr.n_reads)], ch.index
+        n += len(got)
+    assert n > 500
+    dev.close(); ph.close(); pd.close()
+
+
+def test_cli_host_prep_mode(tmp_path, small_synth):
+    import os
+    od, gd = tmp_path / "oracle", tmp_path / "gpu"
+    od.mkdir(), gd.mkdir()
+    args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--chunkSize", "6000", "-o", "out.txt"]
+    ro = oracle_perread(args, cwd=od)
+    rg = mdk.run_cli(args, cwd=gd, command="perRead", env={"MDK_HOST_PREP": "1"})
+    assert rg.returncode == ro.returncode == 0
+    assert (gd / "out.txt").read_bytes() == (od / "out.txt").read_bytes()
