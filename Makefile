@@ -3,6 +3,7 @@
 HIPCC  ?= hipcc
 CC     ?= gcc
 ARCH   ?= gfx950
+HIPFLAGS ?=
 B      := methyldackel_amd/_build
 CFLAGS ?= -O2 -g -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -fPIC -pthread
 HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bigwig.c methyldackel_amd/csrc/host/mdk_mbias.c methyldackel_amd/csrc/host/mdk_mergecontext.c methyldackel_amd/csrc/host/mdk_plan.c methyldackel_amd/csrc/host/mdk_pipeline.c methyldackel_amd/csrc/host/mdk_emit.c methyldackel_amd/csrc/host/mdk_extract.c methyldackel_amd/csrc/host/mdk_cmd_mbias.c methyldackel_amd/csrc/host/mdk_cmd_perread.c
@@ -12,7 +13,7 @@ all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 HIPSRC := methyldackel_amd/csrc/mdk_hip.hip methyldackel_amd/csrc/mdk_comm.hip methyldackel_amd/csrc/mdk_prep.hip
 $(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp include/mdk_hip.h
 	@mkdir -p $(B)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -Iinclude -Imethyldackel_amd/csrc -o $@ $(HIPSRC) -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS) -Iinclude -Imethyldackel_amd/csrc -o $@ $(HIPSRC) -ldl
 
 $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldackel_amd/csrc/host/mdk_plan.h include/mdk_extract.h include/mdk_hip.h $(B)/libmdk_hip.so
 	$(CC) $(CFLAGS) -shared -Iinclude -o $@ $(HOSTSRC) -L$(B) -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm

@@ -541,7 +541,9 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     HIPCHK(hipSetDevice(device));
     md_dev *h = new md_dev();
     h->device = device; h->cfg = *cfg;
-    h->tile = cfg->tile > 0 ? cfg->tile : DEFAULT_TILE;
+    // default tile: 4 positions per thread for CpG-only runs (~1.5 sites per segment), 2 when CHG/CHH are counted (~21 sites
+    // per segment: one round of segments per tile and half the imbalance at the barrier; 56 vs 64 us per 1 Mb chunk, profiles/r02_kbench_experiments.txt)
+    h->tile = cfg->tile > 0 ? cfg->tile : ((cfg->keepCHG || cfg->keepCHH) ? DEFAULT_TILE / 2 : DEFAULT_TILE);
     h->tile = (h->tile + WG - 1) / WG * WG;
     if(h->tile > MAX_TILE) h->tile = MAX_TILE;
     h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2;

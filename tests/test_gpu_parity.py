@@ -109,7 +109,7 @@ SYN_CMDS = [
 
 
 @pytest.mark.parametrize("which,extra", SYN_CMDS, ids=[f"{w}:{' '.join(e)}" for w, e in SYN_CMDS])
-@pytest.mark.parametrize("env", [{"MDK_TILE": "512"}, {"MDK_TILE": "1024"}, {}], ids=["tile512", "tile1024", "tile2048"])
+@pytest.mark.parametrize("env", [{"MDK_TILE": "512"}, {"MDK_TILE": "1024"}, {"MDK_TILE": "2048"}], ids=["tile512", "tile1024", "tile2048"])
 def test_cli_synthetic_byte_exact(tmp_path, small_synth, which, extra, env):
     """every command line under three distinct tile geometries (1, 2 and 4 reference positions per thread -- the library clamps
     larger requests to 2048, test_tile_geometry_is_what_was_asked_for; at 512 positions a tile's segment run overflows the 512
@@ -309,6 +309,11 @@ def test_tile_geometry_is_what_was_asked_for():
         dev = mdk.Device(cfg, device=0)
         assert mdk.lib_hip().md_dev_tile(dev.h) == want, ask
         dev.close()
+    # the library default: 2048 for CpG-only runs, 1024 as soon as CHG or CHH are counted
+    cfg = mdk.md_dev_cfg(); cfg.keepCpG = 1; cfg.keepCHH = 1; cfg.minPhred = 5
+    dev = mdk.Device(cfg, device=0)
+    assert mdk.lib_hip().md_dev_tile(dev.h) == 1024
+    dev.close()
 
 
 def test_group_launch_equals_single_launches(tmp_path):
