@@ -21,6 +21,7 @@ extern "C" {
 
 #define MDK_RC_NODEVICE (-20)   /* GPU path unavailable */
 #define MDK_RC_DEVICE   (-21)   /* a device operation failed mid-run */
+#define MDK_RC_OUTPUT   (-22)   /* writing an output file failed (message on stderr) */
 
 int extract_main(int argc, char *argv[]);
 

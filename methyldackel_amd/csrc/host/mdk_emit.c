@@ -4,9 +4,32 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* text post-pass (extract.c:443-510 driving writeCall/processLast, extract.c:39-99,207-222)          */
 /* ------------------------------------------------------------------------------------------------ */
+/* decimal digits of v at q, as printf's %u / %i would write them; returns the end */
+static inline char *put_u32(char *q, uint32_t v) { char t[10]; int n = 0; do { t[n++] = (char)('0' + v % 10); v /= 10; } while(v); while(n) *q++ = t[--n]; return q; }
+static inline char *put_i32(char *q, int32_t v) { if(v < 0) { *q++ = '-'; return put_u32(q, (uint32_t)(-(int64_t)v)); } return put_u32(q, (uint32_t)v); }
+
 static void put_site(mdk_plan *p, sbuf *dst, const char *chrom, int32_t pos, int width, uint32_t m, uint32_t u, int ref_is_c, const char *cctx, const char *tri) {
     const opts_t *o = &p->o; char line[10000]; int n; uint32_t cov = m + u;      /* the size of writeCall's buffer (extract.c:40): lines longer than that are cut the same way */
     if(cov < (uint32_t)o->min_depth && !o->cytosine_report) return;
+    /* the all-integer formats are written digit by digit straight into the chunk's text (a dense-context run prints some
+     * 10^7 lines per 32 Mb); anything with a %f, or a line that could reach writeCall's 10000 bytes, goes through snprintf */
+    if(!o->fraction && !o->logit && !o->methylkit) {
+        const size_t cl = strlen(chrom);
+        if(cl < 9000) {
+            char *q0 = sb_room(dst, cl + 128), *q = q0;
+            memcpy(q, chrom, cl); q += cl; *q++ = '\t';
+            if(o->counts) { q = put_i32(q, pos); *q++ = '\t'; q = put_i32(q, pos + width); *q++ = '\t'; q = put_i32(q, (int32_t)cov); }
+            else if(o->cytosine_report) {
+                q = put_i32(q, pos + 1); *q++ = '\t'; *q++ = ref_is_c ? '+' : '-'; *q++ = '\t'; q = put_u32(q, m); *q++ = '\t'; q = put_u32(q, u); *q++ = '\t'; *q++ = 'C';
+                { size_t k = strlen(cctx); memcpy(q, cctx, k); q += k; } *q++ = '\t'; { size_t k = strlen(tri); memcpy(q, tri, k); q += k; }
+            } else {
+                q = put_i32(q, pos); *q++ = '\t'; q = put_i32(q, pos + width); *q++ = '\t'; q = put_i32(q, (int)(100.0 * ((double)m) / cov)); *q++ = '\t';
+                q = put_u32(q, m); *q++ = '\t'; q = put_u32(q, u);
+            }
+            *q++ = '\n'; *q = 0; dst->l += (size_t)(q - q0);
+            return;
+        }
+    }
     if(o->fraction) n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%f\n", chrom, pos, pos + width, ((double)m) / cov);
     else if(o->counts) n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%i\n", chrom, pos, pos + width, cov);
     else if(o->logit) { double f = ((double)m) / cov; n = snprintf(line, sizeof(line), "%s\t%i\t%i\t%f\n", chrom, pos, pos + width, log(f) - log(1 - f)); }
@@ -116,6 +139,10 @@ int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
 /* ------------------------------------------------------------------------------------------------ */
 /* extract_main's emitter: chunks are formatted by a few threads and written in chunk order          */
 /* ------------------------------------------------------------------------------------------------ */
+static int pwrite_all(int fd, const char *s, size_t n, int64_t off) {
+    while(n) { ssize_t w = pwrite(fd, s, n, (off_t)off); if(w < 0) { if(errno == EINTR) continue; return -1; } s += w; n -= (size_t)w; off += w; }
+    return 0;
+}
 static void *emitter_main(void *arg) {
     emitter *E = arg;
     for(;;) {
@@ -134,6 +161,19 @@ static void *emitter_main(void *arg) {
         pthread_mutex_lock(&E->mu);
         E->t_format += now_s() - t0;
         while(E->next_write != j->c.index) pthread_cond_wait(&E->cv_turn, &E->mu);
+        if(E->pw) {                              /* in turn: only the byte ranges; the copying into the files runs in parallel */
+            int64_t at[3] = {0, 0, 0}; int k, bad = 0; const int nk = E->p->o.cytosine_report ? 1 : 3;
+            for(k = 0; k < nk; k++) if(E->p->o.cytosine_report || E->p->o.ctx_on[k]) { at[k] = E->woff[k]; E->woff[k] += (int64_t)j->e.ob[k].l; }
+            E->p->n_variant_positions += j->e.n_variant;
+            E->next_write++; pthread_cond_broadcast(&E->cv_turn);
+            pthread_mutex_unlock(&E->mu);
+            for(k = 0; k < nk; k++) if((E->p->o.cytosine_report || E->p->o.ctx_on[k]) && j->e.ob[k].l && pwrite_all(E->fd[k], j->e.ob[k].s, j->e.ob[k].l, at[k])) bad = 1;
+            pthread_mutex_lock(&E->mu);
+            if(bad && !E->failed) { E->failed = 1; fprintf(stderr, "[mdk] writing the output failed: %s\n", strerror(errno)); }
+            j->state = EJ_FREE; pthread_cond_signal(&E->cv_free);
+            pthread_mutex_unlock(&E->mu);
+            continue;
+        }
         emit_write(E->p, &j->e);                 /* in turn, so under the lock: nobody else may write now anyway */
         E->next_write++; j->state = EJ_FREE;
         pthread_cond_broadcast(&E->cv_turn); pthread_cond_signal(&E->cv_free);
@@ -148,6 +188,17 @@ MDK_LOCAL int emitter_start(emitter *E, mdk_plan *p, int n_th) {
     E->job = xcalloc((size_t)E->n_job, sizeof(ejob)); E->th = xcalloc((size_t)E->n_th, sizeof(pthread_t));
     if(!E->job || !E->th) return -5;
     pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv_job, NULL); pthread_cond_init(&E->cv_free, NULL); pthread_cond_init(&E->cv_turn, NULL);
+    {   /* regular output files (what -o makes): what has been written so far (the header lines) is flushed, from here on the
+         * emitter threads write at explicit offsets.  Anything else (a FIFO, /dev/null) keeps the ordered stream writes. */
+        const int nk = p->o.cytosine_report ? 1 : 3; int k;
+        E->pw = getenv("MDK_NO_PWRITE") ? 0 : 1;
+        for(k = 0; k < nk && E->pw; k++) {
+            struct stat st; off_t at;
+            if(!(p->o.cytosine_report || p->o.ctx_on[k])) continue;
+            if(!p->out[k] || fflush(p->out[k]) || (E->fd[k] = fileno(p->out[k])) < 0 || fstat(E->fd[k], &st) || !S_ISREG(st.st_mode) || (at = lseek(E->fd[k], 0, SEEK_CUR)) < 0) { E->pw = 0; break; }
+            E->woff[k] = (int64_t)at;
+        }
+    }
     for(i = 0; i < E->n_th; i++) if(pthread_create(&E->th[i], NULL, emitter_main, E)) break;
     if(i == 0) { fprintf(stderr, "[mdk] cannot create an emitter thread\n"); return -5; }
     E->n_th = i;            /* fewer than asked for still drain the same queue */
@@ -181,6 +232,7 @@ MDK_LOCAL void emitter_stop(emitter *E) {
     E->quit = 1; pthread_cond_broadcast(&E->cv_job);
     pthread_mutex_unlock(&E->mu);
     for(i = 0; i < E->n_th; i++) pthread_join(E->th[i], NULL);
+    if(E->pw) { int k; const int nk = E->p->o.cytosine_report ? 1 : 3; for(k = 0; k < nk; k++) if((E->p->o.cytosine_report || E->p->o.ctx_on[k]) && E->p->out[k]) (void)fseeko(E->p->out[k], (off_t)E->woff[k], SEEK_SET); }
     for(i = 0; i < E->n_job; i++) { int k; free(E->job[i].site); free(E->job[i].var); for(k = 0; k < 3; k++) free(E->job[i].e.ob[k].s); }
     E->p->t_emit += E->t_format;
     free(E->job); free(E->th); E->th = NULL;

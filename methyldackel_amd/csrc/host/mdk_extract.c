@@ -17,6 +17,13 @@
 /* ------------------------------------------------------------------------------------------------ */
 /* The `MethylDackel` command asks (MDK_FAST_EXIT) to leave with _exit once the outputs are closed, skipping the unpinning
  * of buffers and the HIP shutdown.  Not under a profiler or another injected tool: those finalise at normal exit. */
+static double rss_mb(int shared) {      /* resident set (or its file-backed/shared part) in MB: host profile only */
+    long vm = 0, rss = 0, shr = 0; FILE *sf = fopen("/proc/self/statm", "r");
+    if(sf) { if(fscanf(sf, "%ld %ld %ld", &vm, &rss, &shr) != 3) rss = shr = 0; fclose(sf); }
+    return (shared ? shr : rss) * 4096e-6;
+}
+/* formatting threads: 8 are ahead of a CpG-only run; the dense contexts print ~20x the lines */
+static int emit_threads(const mdk_plan *p) { const int cap = (p->o.ctx_on[1] || p->o.ctx_on[2]) ? 24 : 8; return p->o.n_threads >= cap ? cap : p->o.n_threads; }
 MDK_LOCAL int fast_exit_wanted(void) {
     const char *pre = getenv("LD_PRELOAD");
     if(!getenv("MDK_FAST_EXIT")) return 0;
@@ -79,7 +86,7 @@ static int extract_multi(mdk_plan *p, int N, const int *map) {
     if(!ret && md_comm_open_local(dev, N, &comm)) { fprintf(stderr, "[mdk] cannot set up the exchange between the GPUs: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; }
     if(!ret && p->dev_prep) { mdk_plan_prep_cfg(p, &pc); for(i = 0; i < N; i++) md_dev_set_prep(dev[i], &pc); }
     if(!ret) { ring = calloc((size_t)F, sizeof(mdk_chunk)); if(!ring) ret = -5; }
-    if(!ret && emitter_start(&em, p, p->o.n_threads >= 8 ? 8 : p->o.n_threads)) ret = -5;
+    if(!ret && emitter_start(&em, p, emit_threads(p))) ret = -5;
     if(ret) { free(ring); if(comm) md_comm_close(comm); for(i = 0; i < N; i++) if(dev[i]) md_dev_close(dev[i]); mdk_plan_close(p); return ret; }
     while(more || count) {
         if(more && count < F) {                                 /* submit chunk k on device k mod N, slot (k / N) mod 2 */
@@ -116,6 +123,7 @@ static int extract_multi(mdk_plan *p, int N, const int *map) {
         }
     }
     emitter_stop(&em);
+    if(em.failed && !ret) ret = MDK_RC_OUTPUT;
     if(ret == 0) mdk_plan_finish(p);
     if(fast_exit_wanted()) leave_fast(ret);
     free(ring); md_comm_close(comm);
@@ -131,6 +139,7 @@ int extract_main(int argc, char *argv[]) {
     if(argc > 2) hip_warm_up();
     rc = mdk_plan_open(argc, argv, &p);
     t_open = now_s() - T0;
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] resident after plan open %.0f MB\n", rss_mb(0));
     if(rc != 0 || !p) return rc;
     /* HIP initialisation takes a few hundred ms: do it while the host pipeline already inflates and packs */
     memset(&dop, 0, sizeof(dop));
@@ -144,10 +153,11 @@ int extract_main(int argc, char *argv[]) {
     if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
     t_dev = now_s() - T0;
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] resident at device ready %.0f MB\n", rss_mb(0));
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
-    if(emitter_start(&em, p, p->o.n_threads >= 8 ? 8 : p->o.n_threads)) { md_dev_close(dev); mdk_plan_close(p); return -5; }
+    if(emitter_start(&em, p, emit_threads(p))) { md_dev_close(dev); mdk_plan_close(p); return -5; }
     /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then hand k-1 to the emitter */
     while(more || have[0] || have[1]) {
         int cur = k & 1, prev = cur ^ 1;
@@ -192,12 +202,15 @@ int extract_main(int argc, char *argv[]) {
         if(!more && !have[0] && !have[1]) break;
     }
     { double tw = now_s(); emitter_stop(&em); w_emit += now_s() - tw; }
+    if(em.failed && !ret) ret = MDK_RC_OUTPUT;
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0, n_host_prep);
     if(ret == 0) mdk_plan_finish(p);
-    if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
+    if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f (resident %.0f MB, of which file-backed/shared %.0f MB)\n", ts.tv_sec + 1e-9 * ts.tv_nsec, rss_mb(0), rss_mb(1)); }
     if(fast_exit_wanted()) leave_fast(ret);
-    md_dev_close(dev);
-    mdk_plan_close(p);
+    { double tc = now_s(), td;
+      md_dev_close(dev); td = now_s();
+      mdk_plan_close(p);
+      if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] device closed in %.3fs, plan (slabs, reference, mapped file) in %.3fs\n", td - tc, now_s() - td); }
     return ret;
 }
 

@@ -56,8 +56,13 @@ typedef struct {
 /* text buffer */
 typedef struct { char *s; size_t l, m; } sbuf;
 static inline void sb_put(sbuf *b, const char *s, size_t n) {
-    if(b->l + n + 1 > b->m) { b->m = (b->l + n + 1) * 2; b->s = realloc(b->s, b->m); }
+    if(b->l + n + 1 > b->m) { b->m = (b->l + n + 1) * 2; b->s = realloc(b->s, b->m); if(!b->s) { fprintf(stderr, "[mdk] out of memory while formatting output\n"); abort(); } }
     memcpy(b->s + b->l, s, n); b->l += n; b->s[b->l] = 0;
+}
+/* room for n more bytes (+ the terminating 0): the caller writes at b->s + b->l and advances b->l itself */
+static inline char *sb_room(sbuf *b, size_t n) {
+    if(b->l + n + 1 > b->m) { b->m = (b->l + n + 1) * 2; b->s = realloc(b->s, b->m); if(!b->s) { fprintf(stderr, "[mdk] out of memory while formatting output\n"); abort(); } }
+    return b->s + b->l;
 }
 
 /* one admitted read, host-side only (the device gets segments) */
@@ -120,6 +125,7 @@ typedef struct { int state; mdk_chunk c; md_sites s; md_site *site; md_site_var 
 typedef struct {
     mdk_plan *p; ejob *job; int n_job, n_th; pthread_t *th; pthread_mutex_t mu; pthread_cond_t cv_job, cv_free, cv_turn;
     uint32_t next_write; int quit; double t_format;
+    int pw, fd[3], failed; int64_t woff[3];      /* pw: the outputs are regular files -> a chunk reserves its byte range in turn and is written with pwrite outside the lock */
 } emitter;
 
 /* opening the device on its own thread while the host pipeline is already running (mdk_extract.c) */
