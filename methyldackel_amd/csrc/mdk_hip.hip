@@ -210,6 +210,130 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
     }
 }
 
+// ---- dense contexts (CHG/CHH counted, ~20 sites per segment): a quarter of a wavefront per segment --------------------------
+// With a lane per segment every lane walks its own read, so a wavefront's byte loads touch 64 different reads (one L1 access
+// per loaded byte) and the lanes run as long as the segment with the most sites.  Here the 64 lanes first prepare their 64
+// segments (trimming windows, payload offsets, the [a,b) range of the tile's site list the segment covers), then the
+// wavefront goes through them four at a time: 16 neighbouring lanes take 16 neighbouring sites of ONE read (parameters by
+// ds_bpermute from the lane that prepared it), so their loads fall into the same one or two cache lines.
+#ifndef PILEUP_WAVES
+#define PILEUP_WAVES 8
+#endif
+#ifndef QL
+#define QL 8          // lanes per segment
+#endif
+#ifndef QU
+#define QU 2          // sites per lane whose bytes are in flight together
+#endif
+struct SegQ {
+    uint32_t oseq, oqual, mseq, mqual;        // payload byte offsets in the blob (uploads are < 4 GiB): sequence, qualities; own and partner
+    int cq, lo, mcq, mlo; uint32_t wlen, mwlen;   // query index = tile offset + cq; kept window [lo, lo + wlen)
+    uint32_t w[2];                            // per pass: strand | second << 3 | partner << 4 | first list entry << 5 | number of sites << 18
+};
+
+// first list entry whose tile offset (low 13 bits) is >= x; `top` = highest power of two <= n (0 for an empty list)
+__device__ __forceinline__ int list_lower_bound(const uint16_t *list, int n, int top, int x) {
+    int a = 0;
+    for(int step = top; step; step >>= 1) { const int ia = a + step; if(ia <= n && (int)(list[ia - 1] & 0x1fff) < x) a = ia; }
+    return a;
+}
+
+template <bool VARIANT>
+__device__ __forceinline__ SegQ seg_setup(const KParams &P, const md_seg &g, int T0, int T1, const uint16_t *listC, int nC, int nG, int topC, int topG) {
+    SegQ s; s.oseq = s.oqual = s.mseq = s.mqual = 0; s.cq = s.lo = s.mcq = s.mlo = 0; s.wlen = s.mwlen = 0; s.w[0] = s.w[1] = 0;
+    const int send = g.rpos + (int)g.len;
+    if(g.rpos >= T1 || send <= T0) return s;                      // no segment for this lane, or inside the tile's run but not on the tile
+    const int strand = g.sf & MDK_SF_STRAND;
+    const bool odd = strand & 1, second = (g.sf & MDK_SF_SECOND) != 0, partner = (g.sf & MDK_SF_PARTNER) != 0;
+    int lo, hi;
+    trim_window(P, strand, g.sf & MDK_SF_READ2, (int)g.l_qseq, lo, hi);
+    s.oseq = P.packed ? g.off4 : g.off4 << 2;
+    s.oqual = s.oseq + (P.packed ? (g.l_qseq + 1) >> 1 : (((g.l_qseq + 1) >> 1) + 3) & ~3u);
+    s.lo = lo; s.wlen = hi > lo ? (unsigned)(hi - lo) : 0u;
+    s.cq = T0 - g.rpos + (int)g.q0;
+    if(partner) {
+        int mlo, mhi;
+        trim_window(P, g.msf & MDK_SF_STRAND, g.msf & MDK_SF_READ2, (int)g.m_l_qseq, mlo, mhi);
+        s.mseq = P.packed ? g.m_off4 : g.m_off4 << 2;
+        s.mqual = s.mseq + (P.packed ? (g.m_l_qseq + 1) >> 1 : (((g.m_l_qseq + 1) >> 1) + 3) & ~3u);
+        s.mlo = mlo; s.mwlen = mhi > mlo ? (unsigned)(mhi - mlo) : 0u;
+        s.mcq = T0 - g.rpos + (int)g.m_q0;
+    }
+    const int lo_off = g.rpos > T0 ? g.rpos - T0 : 0, hi_off = (send < T1 ? send : T1) - T0;   // tile offsets covered
+#pragma unroll
+    for(int pass = 0; pass < (VARIANT ? 2 : 1); pass++) {
+        const bool useC = (odd == (pass == 0));   // calls: OT/CTOT on C, OB/CTOB on G; opposite-strand evidence: the other list
+        const uint16_t *list = useC ? listC : listC + P.tile; const int n = useC ? nC : nG, top = useC ? topC : topG;
+        const int a = list_lower_bound(list, n, top, lo_off), b = list_lower_bound(list, n, top, hi_off);
+        s.w[pass] = (uint32_t)strand | (second ? 8u : 0u) | (partner ? 16u : 0u) | (uint32_t)((useC ? 0 : P.tile) + a) << 5 | (uint32_t)(b - a) << 18;
+    }
+    return s;
+}
+
+template <bool VARIANT>
+__device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, int lane, const uint16_t *listC,
+                                              uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv) {
+    const int sub = lane & (QL - 1), qbase = lane & (64 - QL);
+    const uint8_t *const blob = P.blob; const int minPhred = P.minPhred;
+#pragma unroll
+    for(int pass = 0; pass < (VARIANT ? 2 : 1); pass++) {
+        const bool callpass = pass == 0;
+        if(__ballot((s.w[pass] >> 18) != 0) == 0) continue;       // no lane of this wavefront has a site in this pass
+        for(int it = 0; it < QL; it++) {
+            const int owner = qbase | it;                          // the lane that prepared the segment this quarter works on now
+            const uint32_t w = (uint32_t)__shfl((int)s.w[pass], owner);
+            const int n = (int)(w >> 18);
+            if(__ballot(n != 0) == 0) continue;
+            const uint32_t oseq = (uint32_t)__shfl((int)s.oseq, owner), oqual = (uint32_t)__shfl((int)s.oqual, owner), wlen = (uint32_t)__shfl((int)s.wlen, owner);
+            const int cq = __shfl(s.cq, owner), lo = __shfl(s.lo, owner);
+            const bool partner = (w >> 4) & 1;
+            uint32_t mseq = 0, mqual = 0, mwlen = 0; int mcq = 0, mlo = 0;
+            if(__ballot(partner && n != 0) != 0) {
+                mseq = (uint32_t)__shfl((int)s.mseq, owner); mqual = (uint32_t)__shfl((int)s.mqual, owner); mwlen = (uint32_t)__shfl((int)s.mwlen, owner);
+                mcq = __shfl(s.mcq, owner); mlo = __shfl(s.mlo, owner);
+            }
+            const int strand = w & 7; const bool odd = strand & 1, second = (w >> 3) & 1;
+            // --keepStrand: region strand codes (bits 13-14 of a list entry) this read is invisible at (bed.c:56-64):
+            // '+' regions (1) want OT/CTOT, '-' regions (2) want OB/CTOB, a read of unknown strand matches neither
+            const int badrs = strand == 0 ? 6 : (odd ? 4 : 2);
+            const uint16_t *list = listC + ((w >> 5) & 0x1fff);
+            for(int j = sub; j < n; j += QU * QL) {
+                // 1. which sites (no base has been touched yet); 2. every byte they need is requested; 3. they are used
+                int l[QU]; bool ok[QU]; int q[QU], mq[QU]; uint32_t sb[QU], qb[QU], msb[QU], mqb[QU];
+#pragma unroll
+                for(int k = 0; k < QU; k++) {
+                    const int jj = j + k * QL; ok[k] = jj < n;
+                    const int e = ok[k] ? (int)list[jj] : 0;
+                    l[k] = e & 0x1fff;
+                    if((badrs >> (e >> 13)) & 1) ok[k] = false;
+                    q[k] = l[k] + cq; mq[k] = l[k] + mcq;
+                    sb[k] = 0xff; qb[k] = 0; msb[k] = 0xff; mqb[k] = 0;   // a trimmed base needs no load: it reads as N with quality 0
+                    if(ok[k] && (unsigned)(q[k] - lo) < wlen) { sb[k] = blob[oseq + (uint32_t)(q[k] >> 1)]; qb[k] = blob[oqual + (uint32_t)q[k]]; }
+                    if(ok[k] && partner && (unsigned)(mq[k] - mlo) < mwlen) { msb[k] = blob[mseq + (uint32_t)(mq[k] >> 1)]; mqb[k] = blob[mqual + (uint32_t)mq[k]]; }
+                }
+#pragma unroll
+                for(int k = 0; k < QU; k++) {
+                    if(!ok[k]) continue;
+                    const int bq = (q[k] & 1) ? (sb[k] & 15) : (sb[k] >> 4); int ql = (int)qb[k];
+                    if(partner) { const int mb = (mq[k] & 1) ? (msb[k] & 15) : (msb[k] >> 4); ql = resolve_overlap(second, bq, ql, mb, (int)mqb[k]); }
+                    if(callpass) {
+                        if(strand == 0) atomicExch(P.err, 1);                 // reference: assert(strand != 0) (common.c:122-125)
+                        if(ql >= minPhred) {
+                            if(odd) { if(bq == 2) atomicAdd(&cm[l[k]], 1u); else if(bq == 8) atomicAdd(&cu[l[k]], 1u); }
+                            else { if(bq == 4) atomicAdd(&cm[l[k]], 1u); else if(bq == 1) atomicAdd(&cu[l[k]], 1u); }
+                        }
+                    } else if(VARIANT) {
+                        if(ql >= minPhred) {
+                            atomicAdd(&co[l[k]], 1u);
+                            if(odd ? (bq != 4 && bq != 15) : (bq != 2 && bq != 15)) atomicAdd(&cv[l[k]], 1u);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // barrier that orders LDS traffic only (does not drain this wave's outstanding global loads)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -270,7 +394,7 @@ __device__ __forceinline__ void build_lists(const KParams &P, int PER, int tid, 
 }
 
 // one workgroup, one tile `t` of the interval P describes (b: the workgroup's index in the launch, for the phase profile only)
-template <bool VARIANT>
+template <bool VARIANT, bool QW>
 __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const int b) {
     extern __shared__ __align__(16) uint32_t lds[];
     const int TILE = P.tile, PER = TILE / WG;
@@ -309,11 +433,21 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     build_lists(P, PER, tid, lane, wave, code, listC, listG, wsum, nC, nG);
     if(P.dbg) tc1 = clock64();
 
-    // phase 2: one segment per lane, WG segments per round
-    if(first + tid < last) lane_seg<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
-    for(int r = first + WG + tid; r < last; r += WG) {
-        const md_seg g = P.seg[r];
-        lane_seg<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
+    // phase 2: WG segments per round.  One segment per lane, or (QW) prepared by one lane each and worked on by 16
+    if constexpr(QW) {
+        const int topC = nC ? 1 << (31 - __clz(nC)) : 0, topG = nG ? 1 << (31 - __clz(nG)) : 0;
+        for(int r0 = first; r0 < last; r0 += WG) {                 // uniform: every lane takes part in the exchange of every round
+            md_seg g = g0;
+            if(r0 != first) { g.rpos = 0x7fffffff; g.len = 0; if(r0 + tid < last) g = P.seg[r0 + tid]; }
+            const SegQ sq = seg_setup<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, nG, topC, topG);
+            quarter_sites<VARIANT>(P, sq, lane, listC, cm, cu, co, cv);
+        }
+    } else {
+        if(first + tid < last) lane_seg<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
+        for(int r = first + WG + tid; r < last; r += WG) {
+            const md_seg g = P.seg[r];
+            lane_seg<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
+        }
     }
     // reserve this tile's output segment: at most one site per kept context position (unused slots stay empty,
     // md_tile_seg.cnt says how many are filled).  Issued by the first thread once its own segments are done, so the
@@ -366,12 +500,12 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     }
 }
 
-template <bool VARIANT>
-__global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
+template <bool VARIANT, bool QW>
+__global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
     const int b = blockIdx.x;
     const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
     if(t >= P.ntiles) return;
-    pileup_tile<VARIANT>(P, t, b);
+    pileup_tile<VARIANT, QW>(P, t, b);
 }
 
 // Several intervals (chunks of the reference's schedule, each with its own reads, outputs and site counter) in ONE launch:
@@ -380,14 +514,14 @@ __global__ __launch_bounds__(WG, 8) void k_pileup(const KParams P) {     // 64 V
 // kernel arguments; a workgroup finds its interval from the tile prefix.
 #define MAXM 8
 struct KMulti { int n, nper; int tstart[MAXM + 1]; KParams P[MAXM]; };
-template <bool VARIANT>
-__global__ __launch_bounds__(WG, 8) void k_pileup_multi(const KMulti M) {
+template <bool VARIANT, bool QW>
+__global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup_multi(const KMulti M) {
     const int b = blockIdx.x;
     const int tg = (b & 7) * M.nper + (b >> 3);
     if(tg >= M.tstart[M.n]) return;
     int j = 0;
     while(j + 1 < M.n && tg >= M.tstart[j + 1]) j++;
-    pileup_tile<VARIANT>(M.P[j], tg - M.tstart[j], b);
+    pileup_tile<VARIANT, QW>(M.P[j], tg - M.tstart[j], b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,6 +647,22 @@ extern "C" int md_dev_count(void) {
     return n;
 }
 
+// the four instantiations of the pileup: with / without the opposite-strand counters, lane or quarter-wavefront per segment
+static const void *pileup_fn(bool variant, bool qw) {
+    return variant ? (qw ? (const void *)k_pileup<true, true> : (const void *)k_pileup<true, false>) : (qw ? (const void *)k_pileup<false, true> : (const void *)k_pileup<false, false>);
+}
+static const void *pileup_multi_fn(bool variant, bool qw) {
+    return variant ? (qw ? (const void *)k_pileup_multi<true, true> : (const void *)k_pileup_multi<true, false>) : (qw ? (const void *)k_pileup_multi<false, true> : (const void *)k_pileup_multi<false, false>);
+}
+static void launch_pileup(const md_dev *h, int grid, size_t lds, hipStream_t st, const KParams &P) {
+    if(h->variant) { if(h->qw) hipLaunchKernelGGL((k_pileup<true, true>), dim3(grid), dim3(WG), lds, st, P); else hipLaunchKernelGGL((k_pileup<true, false>), dim3(grid), dim3(WG), lds, st, P); }
+    else { if(h->qw) hipLaunchKernelGGL((k_pileup<false, true>), dim3(grid), dim3(WG), lds, st, P); else hipLaunchKernelGGL((k_pileup<false, false>), dim3(grid), dim3(WG), lds, st, P); }
+}
+static void launch_pileup_multi(const md_dev *h, int grid, size_t lds, hipStream_t st, const KMulti &M) {
+    if(h->variant) { if(h->qw) hipLaunchKernelGGL((k_pileup_multi<true, true>), dim3(grid), dim3(WG), lds, st, M); else hipLaunchKernelGGL((k_pileup_multi<true, false>), dim3(grid), dim3(WG), lds, st, M); }
+    else { if(h->qw) hipLaunchKernelGGL((k_pileup_multi<false, true>), dim3(grid), dim3(WG), lds, st, M); else hipLaunchKernelGGL((k_pileup_multi<false, false>), dim3(grid), dim3(WG), lds, st, M); }
+}
+
 // Bring the runtime all the way up for a device -- context, code object -- without needing a configuration yet, so that a
 // caller can overlap it with its own start-up; md_dev_open afterwards finds it done.
 extern "C" int md_dev_warm(int device) {
@@ -521,7 +671,7 @@ extern "C" int md_dev_warm(int device) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
     hipFuncAttributes fa;
-    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_pileup<false>));
+    HIPCHK(hipFuncGetAttributes(&fa, pileup_fn(false, false)));
     HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_classify));
     return 0;
 }
@@ -542,17 +692,19 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     HIPCHK(hipSetDevice(device));
     md_dev *h = new md_dev();
     h->device = device; h->cfg = *cfg;
-    // default tile: 4 positions per thread for CpG-only runs (~1.5 sites per segment), 2 when CHG/CHH are counted (~21 sites
-    // per segment: one round of segments per tile and half the imbalance at the barrier; 56 vs 64 us per 1 Mb chunk, profiles/r02_kbench_experiments.txt)
-    h->tile = cfg->tile > 0 ? cfg->tile : ((cfg->keepCHG || cfg->keepCHH) ? DEFAULT_TILE / 2 : DEFAULT_TILE);
+    // default tile: 4 positions per thread (2048) for CpG-only runs, 3 (1536) when CHG/CHH are counted: with ~20 sites per
+    // segment the quarter-wavefront kernel wants a tile's segments in one round of the workgroup (8-chunk launches: 33.8 us
+    // per 1 Mb chunk at 1536, 36.0 at 2048, 40.6 at 1024; one chunk per launch: 57.7 / 66.0 / 48.3; profiles/r02_kbench_experiments.txt)
+    h->tile = cfg->tile > 0 ? cfg->tile : ((cfg->keepCHG || cfg->keepCHH) ? 1536 : DEFAULT_TILE);
     h->tile = (h->tile + WG - 1) / WG * WG;
     if(h->tile > MAX_TILE) h->tile = MAX_TILE;
     h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2;
     h->variant = cfg->minOppositeDepth > 0;
+    h->qw = (cfg->keepCHG || cfg->keepCHH) && !getenv("MDK_NO_QW");       // dense contexts: a quarter of a wavefront per segment (MDK_NO_QW: the lane-per-segment kernel, for comparison)
     while(fixed_lds(h->tile, h->variant) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
     if(fixed_lds(h->tile, h->variant) > 65536) {    // more than the default dynamic-LDS window: opt in
-        if(h->variant) { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, true))); }
-        else { HIPCHK(hipFuncSetAttribute((const void *)k_pileup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); HIPCHK(hipFuncSetAttribute((const void *)k_pileup_multi<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, false))); }
+        HIPCHK(hipFuncSetAttribute(pileup_fn(h->variant, h->qw), hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, h->variant)));
+        HIPCHK(hipFuncSetAttribute(pileup_multi_fn(h->variant, h->qw), hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, h->variant)));
     }
     h->slots.resize(h->n_slots);
     if(h->d_status.need((size_t)h->n_slots) || h->h_status.need((size_t)h->n_slots)) return MDK_ERR_NOMEM;
@@ -662,6 +814,7 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     HIPCHK(hipStreamSynchronize(s->stream));          // the slot's previous contents are being replaced
     if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
     s->fresh = true;
+    if((uint64_t)b->blob_bytes >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_upload: more than 4 GiB of read payload in one chunk", hipSuccess);   // the dense-context kernel addresses payload bytes with 32 bits
     const int64_t span = b->end - b->beg;
     s->n_segs = b->n_segs; s->n_reads = b->n_reads; s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->uploaded = false; s->launched = false; s->raw_layout = false;
     const int TILE = h->tile;
@@ -723,8 +876,7 @@ int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on) {
         KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
         int grid = P.nper * 8;
         if(time_pileup) HIPCHK(hipEventRecord(s->k0, st));
-        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, st, P);
-        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, st, P);
+        launch_pileup(h, grid, (size_t)s->lds_bytes, st, P);
         if(time_pileup) HIPCHK(hipEventRecord(s->k1, st));
         HIPCHK(hipGetLastError());
     } else {
@@ -767,8 +919,7 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
     }
     M.n = n; M.tstart[n] = total; M.nper = (total + 7) / 8;
     if(total > 0) {
-        if(h->variant) hipLaunchKernelGGL(k_pileup_multi<true>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
-        else hipLaunchKernelGGL(k_pileup_multi<false>, dim3(M.nper * 8), dim3(WG), (size_t)s0->lds_bytes, st, M);
+        launch_pileup_multi(h, M.nper * 8, (size_t)s0->lds_bytes, st, M);
         HIPCHK(hipGetLastError());
     }
     for(int i = 0; i < n; i++) get_slot(h, slots[i])->launched = true;      // collected through each slot's `run` stream (finish_count)
@@ -1063,8 +1214,7 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
         HIPCHK(hipMalloc((void **)&dd, nw * 8)); HIPCHK(hipMemset(dd, 0, nw * 8));
         s->ring++; rc = fill_kparams(h, s, P); if(rc) return rc;
         P.dbg = dd;
-        if(h->variant) hipLaunchKernelGGL(k_pileup<true>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
-        else hipLaunchKernelGGL(k_pileup<false>, dim3(grid), dim3(WG), (size_t)s->lds_bytes, s->stream, P);
+        launch_pileup(h, grid, (size_t)s->lds_bytes, s->stream, P);
         HIPCHK(hipStreamSynchronize(s->stream));
         HIPCHK(hipMemcpy(hd.data(), dd, nw * 8, hipMemcpyDeviceToHost)); (void)hipFree(dd);
         unsigned long long r0 = ~0ull, r1 = 0; double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}; size_t cnt = 0; std::vector<double> starts, ends, life;

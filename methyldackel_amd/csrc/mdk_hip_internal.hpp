@@ -79,7 +79,7 @@ struct Slot {
 };
 
 struct md_dev {
-    int device; md_dev_cfg cfg; int tile, n_slots; bool variant;
+    int device; md_dev_cfg cfg; int tile, n_slots; bool variant; bool qw = false;    /* qw: dense contexts, a quarter of a wavefront per segment */
     std::vector<Slot> slots;
     std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
     DBuf<SlotStatus> d_status; HBuf<SlotStatus> h_status;

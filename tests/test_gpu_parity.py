@@ -109,11 +109,13 @@ SYN_CMDS = [
 
 
 @pytest.mark.parametrize("which,extra", SYN_CMDS, ids=[f"{w}:{' '.join(e)}" for w, e in SYN_CMDS])
-@pytest.mark.parametrize("env", [{"MDK_TILE": "512"}, {"MDK_TILE": "1024"}, {"MDK_TILE": "2048"}], ids=["tile512", "tile1024", "tile2048"])
+@pytest.mark.parametrize("env", [{"MDK_TILE": "512"}, {"MDK_TILE": "1024"}, {"MDK_TILE": "1536"}, {"MDK_TILE": "2048"}, {"MDK_NO_QW": "1"}],
+                         ids=["tile512", "tile1024", "tile1536", "tile2048", "lane-per-segment"])
 def test_cli_synthetic_byte_exact(tmp_path, small_synth, which, extra, env):
-    """every command line under three distinct tile geometries (1, 2 and 4 reference positions per thread -- the library clamps
+    """every command line under four distinct tile geometries (1 to 4 reference positions per thread -- the library clamps
     larger requests to 2048, test_tile_geometry_is_what_was_asked_for; at 512 positions a tile's segment run overflows the 512
-    lanes of its workgroup, so the multi-round path runs too)"""
+    lanes of its workgroup, so the multi-round path runs too).  Command lines that count CHG or CHH run the quarter-wavefront
+    kernel; the last column sends them through the lane-per-segment kernel as well (MDK_NO_QW)"""
     args = [str(small_synth / f"{which}.fa"), str(small_synth / f"{which}.bam")]
     if "BW" in extra:       # the oracle has no bigWig reader: it gets the same track as BBM
         compare_cli(tmp_path, args + [str(small_synth / "pe.bw") if e == "BW" else e for e in extra], env=env,
@@ -309,10 +311,10 @@ def test_tile_geometry_is_what_was_asked_for():
         dev = mdk.Device(cfg, device=0)
         assert mdk.lib_hip().md_dev_tile(dev.h) == want, ask
         dev.close()
-    # the library default: 2048 for CpG-only runs, 1024 as soon as CHG or CHH are counted
+    # the library default: 2048 for CpG-only runs, 1536 as soon as CHG or CHH are counted
     cfg = mdk.md_dev_cfg(); cfg.keepCpG = 1; cfg.keepCHH = 1; cfg.minPhred = 5
     dev = mdk.Device(cfg, device=0)
-    assert mdk.lib_hip().md_dev_tile(dev.h) == 1024
+    assert mdk.lib_hip().md_dev_tile(dev.h) == 1536
     dev.close()
 
 
