@@ -230,6 +230,28 @@ def main():
     rc = L.md_dev_bench_prep(dev.h, 0, 3, 30, C.byref(prep_ms))
     assert rc == 0, L.md_dev_last_error()
 
+    # the dense-context configuration (BASELINE.json configs[2]: --CHG --CHH on the same reads) through its own kernel
+    # (8 lanes of a wavefront per segment), same resident intervals, same rotation, same 8-chunk launches
+    dense = None
+    if world == 1 and not extra and not args.synth_args and args.length == 1_000_000:
+        plan2 = mdk.Plan([str(prefix) + ".fa", str(prefix) + ".bam", "--chunkSize", str(args.length), "-@", str(min(32, os.cpu_count() or 1)), "--CHG", "--CHH", "-o", str(work / "dense")])
+        plan2.set_prep(1)
+        cfg2 = plan2.dev_cfg(); cfg2.n_slots = R
+        dev2 = mdk.Device(cfg2, device=dev_index); dev2.set_prep(plan2.prep_cfg())
+        calls2 = 0
+        for i in range(R):
+            c2 = plan2.next_chunk(); plan2.ensure_reference(dev2, c2.tid); dev2.upload_raw(i, c2.raw); dev2.launch(i)
+            st2 = dev2.download(i)
+            calls2 += sum(st2.site[k].nmeth + st2.site[k].nunmeth for k in range(st2.n_sites))
+        brd = dev2.bench_rotate(slots, 8, 100, per_launch=GROUP)
+        dense = {"workload": "the same R resident intervals with --CHG --CHH (BASELINE.json configs[2])", "kernel": "k_pileup_multi<.., QW> (8 lanes per segment)",
+                 "tile": int(brd.tile), "kernel_ms": brd.ms_pileup, "kernel_ms_per_chunk": brd.ms_pileup / GROUP, "algo_bytes_per_launch": int(brd.algo_bytes),
+                 "achieved": brd.algo_bytes / (brd.ms_pileup / 1e3) / 1e9 if brd.ms_pileup > 0 else 0.0, "unit": "GB/s",
+                 "frac": brd.algo_bytes / (brd.ms_pileup / 1e3) / 1e9 / HBM_PEAK_GBS if brd.ms_pileup > 0 else 0.0,
+                 "sites_per_interval": int(brd.n_sites) // GROUP, "calls_per_interval": calls2 // R,
+                 "value": (calls2 / R) * GROUP / (brd.ms_pileup / 1e3) if brd.ms_pileup > 0 else 0.0, "value_unit": "cytosine calls/s (all contexts), kernel only"}
+        dev2.close(); plan2.close()
+
     # HBM traffic of the kernel cannot be sampled from inside this process; it is taken from the committed rocprofv3 PMC summary
     # of this same command (profiles/, produced by tools/gpu_round.sh + tools/summarize_prof.py) with the calibration measured by
     # tools/mdk_calib (byte gathers of a known line count), or left null
@@ -284,6 +306,8 @@ def main():
             result["exchange"] = {"exchanges": exchanges, "bytes_per_exchange_per_rank": bytes_per_exchange, "transport": "ncclSend/ncclRecv group (libmdk_hip md_comm_gather)"}
         if streamed:
             result["streamed"] = streamed
+        if dense:
+            result["dense_contexts"] = dense
         if not args.no_cpu_baseline and world == 1:
             # CPU baseline on a bounded sample of the same workload: the same generator and parameters at 32 Mb, end to end from
             # the BAM file; the product's CLI is timed on the same file.

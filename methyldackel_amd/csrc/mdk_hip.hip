@@ -88,22 +88,7 @@ __device__ __forceinline__ RD make_rd(const KParams &P, uint32_t off4, uint32_t 
     return d;
 }
 
-// (uint8_t)(q + 0.2*q) as evaluated by the reference on x86-64 (overlaps.c:103,106): floor(6q/5) mod 256.
-// md_dev_open checks this identity against the C expression for all 256 values.
-__device__ __forceinline__ int boost(int q) { return ((q * 6) / 5) & 255; }
-
-// cust_tweak_overlap_quality for one matched pair of bases (overlaps.c:90-109); a = earlier in file
-__device__ __forceinline__ int resolve_overlap(bool ownIsSecond, int b, int ql, int mb, int mq) {
-    int ba = ownIsSecond ? mb : b, qa = ownIsSecond ? mq : ql, bb = ownIsSecond ? b : mb, qb = ownIsSecond ? ql : mq;
-    if(ba != bb) {
-        if(qa > qb && ba != 15) { qa -= qb; qb = 0; }
-        else if(qb > qa && bb != 15) { qb -= qa; qa = 0; }
-        else { qa = 0; qb = 0; }
-    } else {
-        if(qa > qb) { qa = boost(qa); qb = 0; } else { qb = boost(qb); qa = 0; }
-    }
-    return ownIsSecond ? qb : qa;
-}
+#include "mdk_overlap_rule.h"      // boost, resolve_overlap (the literal rule), resolve_own (the same as selects)
 
 // context code of a reference position: 0 = not C/G, else 1 + 2*type + isG (type 0 CpG, 1 CHG, 2 CHH).
 // (x & 0x5f) folds 'c'->'C', 'g'->'G' and maps no other FASTA letter onto C or G.
@@ -274,7 +259,7 @@ template <bool VARIANT>
 __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, int lane, const uint16_t *listC,
                                               uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv) {
     const int sub = lane & (QL - 1), qbase = lane & (64 - QL);
-    const uint8_t *const blob = P.blob; const int minPhred = P.minPhred;
+    const uint8_t *const blob = P.blob; const int minPhred = P.minPhred, tile = P.tile;
 #pragma unroll
     for(int pass = 0; pass < (VARIANT ? 2 : 1); pass++) {
         const bool callpass = pass == 0;
@@ -297,6 +282,7 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
             // '+' regions (1) want OT/CTOT, '-' regions (2) want OB/CTOB, a read of unknown strand matches neither
             const int badrs = strand == 0 ? 6 : (odd ? 4 : 2);
             const uint16_t *list = listC + ((w >> 5) & 0x1fff);
+            const int mcode = odd ? 2 : 4, ucode = odd ? 8 : 1;      // the strand's C read as C (methylated) / as T (unmethylated): BAM codes C=2 T=8, G=4 A=1
             for(int j = sub; j < n; j += QU * QL) {
                 // 1. which sites (no base has been touched yet); 2. every byte they need is requested; 3. they are used
                 int l[QU]; bool ok[QU]; int q[QU], mq[QU]; uint32_t sb[QU], qb[QU], msb[QU], mqb[QU];
@@ -315,13 +301,10 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
                 for(int k = 0; k < QU; k++) {
                     if(!ok[k]) continue;
                     const int bq = (q[k] & 1) ? (sb[k] & 15) : (sb[k] >> 4); int ql = (int)qb[k];
-                    if(partner) { const int mb = (mq[k] & 1) ? (msb[k] & 15) : (msb[k] >> 4); ql = resolve_overlap(second, bq, ql, mb, (int)mqb[k]); }
+                    if(partner) { const int mb = (mq[k] & 1) ? (msb[k] & 15) : (msb[k] >> 4); ql = resolve_own(second, bq, ql, mb, (int)mqb[k]); }
                     if(callpass) {
                         if(strand == 0) atomicExch(P.err, 1);                 // reference: assert(strand != 0) (common.c:122-125)
-                        if(ql >= minPhred) {
-                            if(odd) { if(bq == 2) atomicAdd(&cm[l[k]], 1u); else if(bq == 8) atomicAdd(&cu[l[k]], 1u); }
-                            else { if(bq == 4) atomicAdd(&cm[l[k]], 1u); else if(bq == 1) atomicAdd(&cu[l[k]], 1u); }
-                        }
+                        if(ql >= minPhred && (bq == mcode || bq == ucode)) atomicAdd(&cm[(bq == ucode ? tile : 0) + l[k]], 1u);     // cu = cm + tile
                     } else if(VARIANT) {
                         if(ql >= minPhred) {
                             atomicAdd(&co[l[k]], 1u);
