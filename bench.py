@@ -23,6 +23,7 @@ Also on the JSON line:
 """
 import argparse
 import ctypes as C
+import numpy as np
 import json
 import os
 import subprocess
@@ -242,7 +243,9 @@ def main():
         for i in range(R):
             c2 = plan2.next_chunk(); plan2.ensure_reference(dev2, c2.tid); dev2.upload_raw(i, c2.raw); dev2.launch(i)
             st2 = dev2.download(i)
-            calls2 += sum(st2.site[k].nmeth + st2.site[k].nunmeth for k in range(st2.n_sites))
+            if st2.n_sites:
+                a2 = np.ctypeslib.as_array(C.cast(st2.site, C.POINTER(C.c_uint32)), shape=(int(st2.n_sites), 4))      # md_site = {pos, nmeth, nunmeth, meta}
+                calls2 += int(a2[:, 1].sum(dtype=np.int64) + a2[:, 2].sum(dtype=np.int64))
         brd = dev2.bench_rotate(slots, 8, 100, per_launch=GROUP)
         dense = {"workload": "the same R resident intervals with --CHG --CHH (BASELINE.json configs[2])", "kernel": "k_pileup_multi<.., QW> (8 lanes per segment)",
                  "tile": int(brd.tile), "kernel_ms": brd.ms_pileup, "kernel_ms_per_chunk": brd.ms_pileup / GROUP, "algo_bytes_per_launch": int(brd.algo_bytes),
