@@ -16,6 +16,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr; decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr; decltype(&ncclSend) Send = nullptr; decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr; decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
 };
 static Rccl *rccl() {
     static Rccl R; static int state = 0;       // 0 untried, 1 loaded, -1 unavailable
@@ -25,9 +26,9 @@ static Rccl *rccl() {
         state = -1;
         if(R.so) {
 #define SYM(f) R.f = (decltype(R.f))dlsym(R.so, "nccl" #f)
-            SYM(GetUniqueId); SYM(CommInitRank); SYM(CommInitAll); SYM(CommDestroy); SYM(Send); SYM(Recv); SYM(GroupStart); SYM(GroupEnd); SYM(GetErrorString);
+            SYM(GetUniqueId); SYM(CommInitRank); SYM(CommInitAll); SYM(CommDestroy); SYM(Send); SYM(Recv); SYM(GroupStart); SYM(GroupEnd); SYM(GetErrorString); SYM(AllReduce);
 #undef SYM
-            if(R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.Send && R.Recv && R.GroupStart && R.GroupEnd && R.GetErrorString) state = 1;
+            if(R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.Send && R.Recv && R.GroupStart && R.GroupEnd && R.GetErrorString && R.AllReduce) state = 1;
         }
     }
     if(state != 1) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); return nullptr; }
@@ -215,7 +216,12 @@ extern "C" void md_bench_close(md_bench *b) {
     if(!b) return;
     (void)hipSetDevice(b->h->device);
     if(b->comm) (void)md_comm_wait(b->comm);
-    for(int i : b->slots) (void)md_dev_bind_output(b->h, i, nullptr, nullptr, nullptr, 0, 0);
+    if(b->stream) (void)hipStreamSynchronize(b->stream);
+    for(int i : b->slots) {
+        (void)md_dev_bind_output(b->h, i, nullptr, nullptr, nullptr, 0, 0);
+        Slot *s = get_slot(b->h, i);
+        if(s && s->run == b->stream) s->run = nullptr;          // the launch stream goes away with the loop: the slot is collected on its own stream again
+    }
     for(int x = 0; x < 2; x++) { if(b->send[x]) (void)hipFree(b->send[x]); for(uint8_t *p : b->recv[x]) if(p) (void)hipFree(p); if(b->done[x]) (void)hipEventDestroy(b->done[x]); }
     if(b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     delete b;
@@ -237,6 +243,21 @@ extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, 
         if(c > b->cap) b->cap = c;
         if(s->ntiles > b->tcap) b->tcap = s->ntiles;
         b->slots.push_back(slots[i]);
+    }
+    if(comm && !comm->copies && !comm->comm.empty()) {
+        // every rank sends one region per chunk and rank 0 posts a receive of the same size for it: the region must be sized by
+        // the largest site count / tile count of ANY rank (the ranks hold different intervals), so the ranks agree on it here
+        Rccl *R = rccl(); if(!R) { delete b; return MDK_ERR_NODEVICE; }
+        long long hv[2] = {(long long)b->cap, (long long)b->tcap}, *dv = nullptr;
+        hipError_t e = hipMalloc((void **)&dv, sizeof(hv));
+        if(e == hipSuccess) e = hipMemcpy(dv, hv, sizeof(hv), hipMemcpyHostToDevice);
+        if(e != hipSuccess) { if(dv) (void)hipFree(dv); delete b; return fail(MDK_ERR_NOMEM, "md_bench_open: capacity exchange", e); }
+        ncclResult_t r = R->AllReduce(dv, dv, 2, ncclInt64, ncclMax, comm->comm[0], comm->stream[0]);
+        if(r == ncclSuccess) { e = hipStreamSynchronize(comm->stream[0]); if(e == hipSuccess) e = hipMemcpy(hv, dv, sizeof(hv), hipMemcpyDeviceToHost); }
+        (void)hipFree(dv);
+        if(r != ncclSuccess) { delete b; return nfail(R, "ncclAllReduce(max of the ranks' site and tile counts)", r); }
+        if(e != hipSuccess) { delete b; return fail(MDK_ERR_HIP, "md_bench_open: capacity exchange", e); }
+        b->cap = (int64_t)hv[0]; b->tcap = (int64_t)hv[1];
     }
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     for(int x = 0; x < 2; x++) HIPCHK(hipEventCreateWithFlags(&b->done[x], hipEventDisableTiming));

@@ -58,6 +58,17 @@ def test_rccl_single_rank_communicator(tmp_path, small_synth):
     rcv = (C.c_void_p * 1)(None); rb = (C.c_uint64 * 1)(0)
     assert L.md_comm_gather(comm, snd, sb, rcv, rb) == 0, L.md_dev_last_error()
     assert L.md_comm_wait(comm) == 0
+    # the benchmark loop over this communicator: the ranks agree on the size of an exchanged region with an ncclAllReduce
+    # (max of their site / tile counts) before any send or receive is posted; with one rank the agreement is its own size
+    c2 = plan.next_chunk(); dev.submit(1, c2.batch); dev.wait(1)
+    slots = (C.c_int * 2)(0, 1); bench = C.c_void_p()
+    assert L.md_bench_open(dev.h, comm, slots, 2, 1, C.byref(bench)) == 0, L.md_dev_last_error()
+    region = L.md_bench_region_bytes(bench)
+    assert region >= 16 * max(dv.n_slots, 1) and region % 256 == 0
+    res = mdk.md_bench_run_result()
+    assert L.md_bench_run(bench, 6, C.byref(res)) == 0, L.md_dev_last_error()
+    assert res.launches == 6 and L.md_bench_verify(bench) == 0, L.md_dev_last_error()
+    L.md_bench_close(bench)
     L.md_comm_close(comm)
     # local communicator over one handle
     L.md_comm_download.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(mdk.md_sites)]

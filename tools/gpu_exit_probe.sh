@@ -12,7 +12,7 @@ import subprocess, sys, time, os, re
 R, L, out = sys.argv[1:4]; extra = sys.argv[4:]
 env = dict(os.environ, MDK_HOST_PROFILE="1")
 t0 = time.time()
-r = subprocess.run([f"{R}/methyldackel_amd/_build/MethylDackel", "extract", f"s{L}.fa", f"s{L}.bam", "-o", out, "-@", "64"] + extra, capture_output=True, text=True, env=env)
+r = subprocess.run([f"{R}/methyldackel_amd/_build/MethylDackel", "extract", f"s{L}.fa", f"s{L}.bam", "-o", out, "-@", os.environ.get("PROBE_THREADS", "64")] + extra, capture_output=True, text=True, env=env)
 t1 = time.time()
 ent = float(re.search(r"entered at epoch ([0-9.]+)", r.stderr).group(1)); lea = float(re.search(r"leaving at epoch ([0-9.]+)", r.stderr).group(1))
 sz = sum(os.path.getsize(f) for f in [out + s for s in ("_CpG.bedGraph", "_CHG.bedGraph", "_CHH.bedGraph", ".cytosine_report.txt")] if os.path.exists(f))
