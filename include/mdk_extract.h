@@ -110,6 +110,12 @@ int  mdk_plan_emit_perread(mdk_plan *p, const mdk_chunk *c, const md_pr_count *c
  * read, counts[i] its calls (md_dev_perread_download_raw); names and positions are read from the records themselves */
 int  mdk_plan_emit_perread_raw(mdk_plan *p, const mdk_chunk *c, const uint32_t *kept, const md_pr_count *counts, int64_t n);
 
+/* Bind the calling thread, and every thread it creates from now on, to the CPUs next to the index-th AMD GPU (sysfs
+ * local_cpulist, GPUs in PCI order), if that leaves at least half of the CPUs the process may use.  Returns the number of CPUs
+ * bound to, 0 if nothing was changed (no such GPU, one NUMA node, MDK_NO_BIND set).  The `MethylDackel` command calls it for
+ * its single-GPU commands; a library caller decides for itself.  No counterpart in the reference. */
+int  mdk_bind_to_device_node(int index);
+
 /* ---- `mergeContext` (mergeContext.c; main.c:19,53-54): text-to-text host tool, no device work ---- */
 int  mergeContext_main(int argc, char *argv[]);
 

@@ -55,6 +55,11 @@ int main(int argc, char *argv[]) {
     if(argc == 1) { usage_main(); return 0; }
     if(!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage_main(); return 0; }
     if(!strcmp(argv[1], "-v") || !strcmp(argv[1], "--version")) { printf("0.6.1 (using HTSlib version none; methyldackel_amd MI355X build)\n"); return 0; }
+    if(!strcmp(argv[1], "extract") || !strcmp(argv[1], "mbias") || !strcmp(argv[1], "perRead")) {
+        /* one GPU: stay on the CPUs next to it (the inflate threads first-touch what the GPU uploads from); several GPUs: float */
+        const char *g = getenv("MDK_GPUS"), *dv = getenv("MDK_DEVICE");
+        if(!g || !*g || !strcmp(g, "1")) (void)mdk_bind_to_device_node(dv ? atoi(dv) : 0);
+    }
     if(!strcmp(argv[1], "extract")) {
         setenv("MDK_FAST_EXIT", "1", 0);      /* a process about to end need not unpin buffers and shut the runtime down politely */
         return run_detached(extract_main, argc - 1, argv + 1);
