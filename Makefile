@@ -10,8 +10,8 @@ HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bi
 
 all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 
-HIPSRC := methyldackel_amd/csrc/mdk_hip.hip methyldackel_amd/csrc/mdk_comm.hip methyldackel_amd/csrc/mdk_prep.hip
-$(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp methyldackel_amd/csrc/mdk_overlap_rule.h include/mdk_hip.h
+HIPSRC := methyldackel_amd/csrc/mdk_hip.hip methyldackel_amd/csrc/mdk_comm.hip methyldackel_amd/csrc/mdk_prep.hip methyldackel_amd/csrc/mdk_inflate.hip
+$(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp methyldackel_amd/csrc/mdk_overlap_rule.h methyldackel_amd/csrc/mdk_inflate_core.h include/mdk_hip.h
 	@mkdir -p $(B)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS) -Iinclude -Imethyldackel_amd/csrc -o $@ $(HIPSRC) -ldl
 
@@ -21,7 +21,16 @@ $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldac
 $(B)/MethylDackel: methyldackel_amd/csrc/host/main.c $(B)/libmdk_extract.so
 	$(CC) $(CFLAGS) -Iinclude -o $@ methyldackel_amd/csrc/host/main.c -L$(B) -lmdk_extract -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
 
-tools: tools/_build/mdk_synth tools/_build/mdk_calib
+tools: tools/_build/mdk_synth tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/piece_bench tools/_build/pin_probe
+tools/_build/pin_probe: tools/pin_probe.hip
+	@mkdir -p tools/_build
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ tools/pin_probe.hip
+tools/_build/inflate_emu: tools/inflate_emu.cpp methyldackel_amd/csrc/mdk_inflate_core.h
+	@mkdir -p tools/_build
+	g++ -O2 -Wall -o $@ tools/inflate_emu.cpp -Imethyldackel_amd/csrc -lz
+tools/_build/piece_bench: tools/piece_bench.c include/mdk_hip.h $(B)/libmdk_hip.so
+	@mkdir -p tools/_build
+	$(CC) -O2 -g -Wall -Iinclude -o $@ tools/piece_bench.c -L$(B) -lmdk_hip -Wl,-rpath,'$$ORIGIN/../../$(B)' -lz
 tools/_build/mdk_calib: tools/mdk_calib.hip
 	@mkdir -p tools/_build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ tools/mdk_calib.hip

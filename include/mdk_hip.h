@@ -153,6 +153,40 @@ int  md_dev_bench_prep(md_dev *h, int slot, int warmup, int iters, float *ms_per
  * qualities follow the sequence without padding), their number, and the number of admitted reads. */
 int  md_dev_debug_segments(md_dev *h, int slot, md_seg *out, int64_t cap, int64_t *n_segs, int64_t *n_reads);
 
+/* ---- BGZF inflate and BAM record framing on the device ----
+ * What the reference gets from htslib inside sam_itr_next (common.c:413): bgzf_read_block's inflate of each <= 64 KiB member and
+ * bam_read1's framing of the records in it.  The host hands over a PIECE of the file -- a run of whole BGZF members, compressed,
+ * as they lie in the file -- with a table of its members (found by walking the 18-byte BGZF headers: BSIZE, and ISIZE from each
+ * member's trailer); the device inflates every member (one wavefront each), walks the records of every member from its first
+ * byte, and leaves: the inflated bytes, a table with the offset of every record, and per member a DIGEST (first/last record,
+ * extent of the read ends, coordinate order inside) from which the host applies the reference's chunk schedule
+ * (extract.c:325-350) without ever seeing a record.  Inflated bytes and record table stay in device memory; a chunk's records
+ * are then handed to md_dev_upload_raw as device-resident ranges (md_raw_range.d_rec_off != NULL). */
+typedef struct { uint64_t in_off; uint32_t in_len, out_len; uint64_t out_off; } md_inf_member;   /* deflate stream at comp + in_off, in_len bytes; ISIZE; where its bytes go (running sum of ISIZE) */
+typedef struct {
+    uint32_t n_rec, first_rec;           /* records in the member; index of its first record in the piece's record table */
+    int32_t tid0, pos0, tidN, posN;      /* first and last record */
+    int32_t min_endp, max_endp;          /* extent of bam_endpos over the member's records */
+    int32_t ok, sorted;                  /* ok: the member starts and ends on record boundaries; sorted: placed records in coordinate order, none unplaced */
+} md_inf_digest;
+typedef struct md_piece md_piece;
+typedef struct {
+    int32_t n_mem; const md_inf_digest *digest;      /* host memory owned by the piece, valid until its next submit */
+    uint32_t n_records; uint64_t out_bytes;
+    const uint8_t *d_out; const uint32_t *d_rec_off;  /* DEVICE pointers: inflated bytes; offset (in d_out) of every record's block_size word */
+} md_piece_info;
+int  md_piece_create(md_dev *h, md_piece **out);     /* its own stream, buffers grown on demand */
+void md_piece_destroy(md_piece *p);
+/* asynchronous: H2D of `comp` (pinned memory makes it a DMA) and the member table, the kernels, D2H of the digests.  The member
+ * table must be contiguous (out_off = running sum of out_len), out_len <= 65536.  comp/mem must stay valid until md_piece_wait. */
+int  md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_bytes, const md_inf_member *mem, int32_t n_mem);
+int  md_piece_wait(md_piece *p, md_piece_info *info);
+/* inflated bytes / record offsets copied back to the host (tests; files whose records straddle members) */
+int  md_piece_read(md_piece *p, uint64_t off, uint64_t bytes, uint8_t *dst);
+int  md_piece_read_records(md_piece *p, uint32_t first, uint32_t n, uint32_t *dst);
+/* the kernels alone, re-run on the resident piece and timed with HIP events on its stream */
+int  md_piece_bench(md_piece *p, int iters, float *ms_inflate, float *ms_walk);
+
 typedef struct {
     float ms_total;      /* one launch bracketed by HIP events on the slot's stream (includes lone-launch dispatch latency), mean over iters */
     float ms_pileup;     /* the pileup kernel: `iters` launches back to back between two HIP events, divided by iters */

@@ -1,0 +1,317 @@
+// mdk_inflate.hip -- BGZF inflate and BAM record framing on the device (the step the reference pays for
+// inside htslib's sam_itr_next, common.c:413).
+//
+//   k_inflate     one WAVEFRONT per BGZF member.  Lane 0 decodes Huffman symbols (mdk_inflate_core.h: that part of DEFLATE is
+//                 sequential) in batches of <= 64 symbols: literals go straight into a 4 KiB output window in LDS, matches become
+//                 tokens.  Between batches all 64 lanes work: (1) top up the LDS ring of compressed words with one coalesced
+//                 load, (2) FAR matches -- source older than the LDS window -- one lane per token, bytes from global memory
+//                 (written by an earlier batch of this wavefront), (3) NEAR matches in stream order, each by all lanes from the
+//                 window (a self-overlapping match doubles the copied span per round), (4) the batch's bytes leave the window
+//                 for global memory, coalesced.  A 64 KiB member is ~16 k symbols; the file's ~10^4..10^5 members are what
+//                 fills the machine (one lane per member, round 2's experiment, left 434 wavefronts of diverging lanes).
+//   k_walk        one lane per member: chases the block_size words from the member's first byte (htslib never lets a record
+//                 straddle two members), counts the records, notes whether the walk ends exactly at the member's end.
+//   k_rec_table   after an exclusive scan of the counts: one lane per member walks again and writes each record's offset, and
+//                 the member's digest (first/last record, extent of the read ends, coordinate order inside) -- what the host's
+//                 inflate threads leave per member (csrc/host/mdk_io.c note_records).
+#include "mdk_hip_internal.hpp"
+#include "mdk_inflate_core.h"
+
+// coherent byte / word loads of what this wavefront stored earlier (plain loads could hit a stale line in the CU's L1)
+__device__ __forceinline__ uint32_t ld_u8_l2(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct InfParams {
+    const uint8_t *comp;              // the piece's compressed bytes (device), 4-byte aligned base
+    const md_inf_member *mem; int n_mem;
+    uint8_t *out;                     // inflated bytes
+    uint32_t *status;                 // [0] = first error: code | member << 8 (0 = none)
+};
+
+// hands the decoder state of lane 0 to every lane (uniform mode: after lane 0 alone has parsed a block header)
+struct InfBcast {
+    __device__ __forceinline__ uint32_t word(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+    __device__ __forceinline__ void operator()(InfDec &d) const {
+        d.lo = word(d.lo); d.hi = word(d.hi); d.nx = word(d.nx); d.sh = word(d.sh); d.widx = word(d.widx); d.pos = word(d.pos); d.out_len = word(d.out_len);
+        d.in_block = word(d.in_block); d.last = word(d.last); d.stored_left = word(d.stored_left);
+    }
+};
+// VARIANT bit 0: the decoder's values are uniform (readfirstlane behind every LDS load: scalar registers, scalar arithmetic and
+// branches) instead of living in lane 0's vector registers under an execution mask; bit 1: between the phases of one wavefront only the compiler is fenced (LDS operations of a wavefront are
+// executed in order) instead of s_waitcnt + s_barrier.
+template <int VARIANT>
+__global__ __launch_bounds__(64) void k_inflate(const InfParams P) {
+    constexpr bool LIGHT = (VARIANT & 2) != 0, MIX = (VARIANT & 4) != 0;
+    // MIX (bit 2): odd members decode on the scalar unit, even ones on the vector unit -- the two issue ports of a SIMD then
+    // both carry decoders (wave-uniform choice)
+    const bool UNI = MIX ? (blockIdx.x & 1) != 0 : (VARIANT & 1) != 0;
+    __shared__ InfShared S;
+    auto sync = [&]() { if(LIGHT) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); };
+    const int m = blockIdx.x, lane = threadIdx.x;
+    if(m >= P.n_mem) return;
+    const md_inf_member M = P.mem[m];
+    if(M.out_len == 0) return;
+    const uint64_t a0 = M.in_off & ~3ull;                               // aligned start of the stream's words
+    const uint32_t skip = (uint32_t)(M.in_off & 3ull);
+    const uint32_t n_words = (uint32_t)((M.in_off + M.in_len + 3 - a0) >> 2);
+    const uint32_t *words = (const uint32_t *)(P.comp + a0);
+    uint8_t *out = P.out + M.out_off;
+    uint32_t filled = 0;                                               // stream words put into the ring so far (wave-uniform)
+    InfDec d;
+    // first fill: the whole ring
+    for(; filled < INF_IN_WORDS; filled += 64) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = w < n_words ? words[w] : 0u; }
+    __syncthreads();
+    inf_dec_init(d, S.in, skip, M.out_len);
+    if(UNI) InfBcast()(d);
+    uint32_t taken = 3;
+    for(;;) {
+        // (1) top up the ring: word w may replace word w-256 once the decoder has taken that one
+        while(filled + 64 <= taken + INF_IN_WORDS) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = w < n_words ? words[w] : 0u; filled += 64; }
+        sync();
+        // the decoder runs with one lane enabled; in uniform mode what it loads goes through readfirstlane, so its state stays in
+        // scalar registers inside the region and is made uniform again behind it
+        if(lane == 0) { if(UNI) inf_decode_batch<true>(d, S, true, InfNoBcast()); else inf_decode_batch<false>(d, S, true, InfNoBcast()); }
+        if(UNI) InfBcast()(d);
+        sync();
+        const uint32_t n_tok = S.n_tok, beg = S.batch_beg, end = S.batch_end, err = S.err, fin = S.finished;
+        taken = S.words_used;
+        if(err || taken > n_words + 3) { if(lane == 0) atomicCAS(P.status, 0u, (err ? err : (uint32_t)INF_E_INPUT) | ((uint32_t)m << 8)); return; }
+        // (2) far matches: one lane per token; every byte comes from global memory
+        bool far = false;
+        InfToken t; t.dst = 0; t.len_dist = 0;
+        if((uint32_t)lane < n_tok) { t = S.tok[lane]; far = inf_tok_far(t, beg); }
+        if(__ballot(far)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the earlier batches' stores have reached L2
+            if(far) {
+                const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16);
+                uint32_t i = 0;
+                for(; i + 4 <= len; i += 4) {
+                    const uint32_t b0 = ld_u8_l2(out + src + i), b1 = ld_u8_l2(out + src + i + 1), b2 = ld_u8_l2(out + src + i + 2), b3 = ld_u8_l2(out + src + i + 3);
+                    S.win[(t.dst + i) & (INF_WIN - 1)] = (uint8_t)b0; S.win[(t.dst + i + 1) & (INF_WIN - 1)] = (uint8_t)b1;
+                    S.win[(t.dst + i + 2) & (INF_WIN - 1)] = (uint8_t)b2; S.win[(t.dst + i + 3) & (INF_WIN - 1)] = (uint8_t)b3;
+                }
+                for(; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = (uint8_t)ld_u8_l2(out + src + i);
+            }
+            sync();
+        }
+        // (3) near matches, in stream order, each by the whole wavefront
+        unsigned long long near = __ballot((uint32_t)lane < n_tok && !far);
+        while(near) {
+            const int k = __ffsll((long long)near) - 1; near &= near - 1;
+            const InfToken q = S.tok[k];                                        // same address for every lane: a broadcast read
+            const uint32_t len = q.len_dist & 0xffffu, dist = q.len_dist >> 16;
+            uint32_t done = 0, span = dist;
+            while(done < len) {
+                const uint32_t n = span < len - done ? span : len - done;
+                inf_near_round(S.win, q.dst, dist, done, n, (uint32_t)lane);
+                sync();
+                done += n; span <<= 1;
+            }
+        }
+        // (4) the batch leaves the window
+        for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
+        if(fin) return;
+    }
+}
+
+// ---- record framing ----
+struct WalkParams {
+    const uint8_t *out; const md_inf_member *mem; int n_mem;
+    uint32_t *count;                  // [n_mem] records per member; 0xffffffff = the walk did not end at the member's end
+    uint32_t *rec_off;                // record table of the piece: offset of each record's block_size word in `out`
+    const uint32_t *first;            // [n_mem] exclusive scan of the counts
+    md_inf_digest *dig;               // [n_mem]
+};
+__device__ __forceinline__ uint32_t ldu32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_walk(const WalkParams P) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if(m >= P.n_mem) return;
+    const md_inf_member M = P.mem[m];
+    const uint8_t *d = P.out + M.out_off; const uint32_t L = M.out_len;
+    uint32_t o = 0, n = 0; bool ok = true;
+    md_inf_digest g; g.n_rec = 0; g.ok = 0; g.sorted = 1; g.tid0 = g.tidN = -1; g.pos0 = g.posN = -1; g.min_endp = 0x7fffffff; g.max_endp = (int32_t)0x80000000; g.first_rec = 0;
+    const uint32_t base = WRITE ? P.first[m] : 0u;
+    if(WRITE && P.count[m] == 0xffffffffu) { g.first_rec = base; P.dig[m] = g; return; }
+    while(o + 4 <= L) {
+        const uint8_t *r = d + o + 4;
+        const uint32_t bs = ldu32(d + o);
+        if(bs < 32 || (uint64_t)o + 4 + bs > L) { ok = false; break; }
+        const uint32_t lq = r[8], nc = (uint32_t)r[12] | ((uint32_t)r[13] << 8);
+        if(32u + lq + 4u * nc > bs) { ok = false; break; }
+        if(WRITE) {
+            const int32_t tid = (int32_t)ldu32(r), pos = (int32_t)ldu32(r + 4);
+            const uint8_t *c = r + 32 + lq; int32_t rl = 0;
+            for(uint32_t k = 0; k < nc; k++) { const uint32_t v = ldu32(c + 4 * k), op = v & 15u; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int32_t)(v >> 4); }
+            const int32_t endp = pos + (rl > 0 ? rl : 1);
+            P.rec_off[base + n] = (uint32_t)(M.out_off + o);
+            if(n == 0) { g.tid0 = tid; g.pos0 = pos; }
+            else if(tid < 0 || tid < g.tidN || (tid == g.tidN && pos < g.posN)) g.sorted = 0;
+            if(tid < 0) g.sorted = 0;
+            g.tidN = tid; g.posN = pos;
+            if(endp < g.min_endp) g.min_endp = endp;
+            if(endp > g.max_endp) g.max_endp = endp;
+        }
+        n++; o += 4 + bs;
+    }
+    ok = ok && o == L;
+    if(!WRITE) { P.count[m] = ok ? n : 0xffffffffu; return; }
+    g.n_rec = n; g.ok = ok ? 1 : 0; g.first_rec = base;
+    P.dig[m] = g;
+}
+
+// exclusive scan of the per-member record counts (one workgroup; a piece has a few thousand members); a member whose walk failed
+// counts as 0.  total -> status[1]
+__global__ __launch_bounds__(1024) void k_walk_scan(const uint32_t *cnt, uint32_t *first, int n, uint32_t *status) {
+    __shared__ uint32_t wsum[16]; __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if(tid == 0) carry = 0;
+    __syncthreads();
+    for(int b = 0; b < n; b += 1024) {
+        const int i = b + tid; uint32_t v = i < n ? cnt[i] : 0u; if(v == 0xffffffffu) v = 0;
+        uint32_t incl = v;
+#pragma unroll
+        for(int dd = 1; dd < 64; dd <<= 1) { const uint32_t t = __shfl_up(incl, dd); if(lane >= dd) incl += t; }
+        if(lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t pre = carry; for(int w = 0; w < wave; w++) pre += wsum[w];
+        if(i < n) first[i] = pre + incl - v;
+        __syncthreads();
+        if(tid == 1023) carry = pre + incl;
+        __syncthreads();
+    }
+    if(tid == 0) status[1] = carry;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: pieces
+// ------------------------------------------------------------------------------------------------
+static void launch_inflate(int variant, int n_mem, hipStream_t st, const InfParams &IP) {
+    switch(variant & 7) {
+    case 0: hipLaunchKernelGGL(k_inflate<0>, dim3(n_mem), dim3(64), 0, st, IP); break;
+    case 1: hipLaunchKernelGGL(k_inflate<1>, dim3(n_mem), dim3(64), 0, st, IP); break;
+    case 2: hipLaunchKernelGGL(k_inflate<2>, dim3(n_mem), dim3(64), 0, st, IP); break;
+    case 3: hipLaunchKernelGGL(k_inflate<3>, dim3(n_mem), dim3(64), 0, st, IP); break;
+    case 4: case 5: hipLaunchKernelGGL(k_inflate<4>, dim3(n_mem), dim3(64), 0, st, IP); break;
+    default: hipLaunchKernelGGL(k_inflate<6>, dim3(n_mem), dim3(64), 0, st, IP); break;
+    }
+}
+#ifndef INF_DEFAULT_VARIANT
+#define INF_DEFAULT_VARIANT 1
+#endif
+struct md_piece {
+    int variant = getenv("MDK_INFLATE_VARIANT") ? atoi(getenv("MDK_INFLATE_VARIANT")) : INF_DEFAULT_VARIANT;
+    md_dev *h = nullptr; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+    DBuf<uint8_t> d_comp, d_out; DBuf<md_inf_member> d_mem; DBuf<uint32_t> d_cnt, d_first, d_recoff, d_status; DBuf<md_inf_digest> d_dig;
+    HBuf<md_inf_digest> h_dig; HBuf<uint32_t> h_status;
+    int n_mem = 0; uint64_t out_bytes = 0, comp_bytes = 0; uint32_t n_rec_cap = 0; bool busy = false;
+};
+
+extern "C" int md_piece_create(md_dev *h, md_piece **out) {
+    if(!h || !out) return fail(MDK_ERR_ARG, "md_piece_create", hipSuccess);
+    *out = nullptr;
+    HIPCHK(hipSetDevice(h->device));
+    md_piece *p = new md_piece(); p->h = h;
+    if(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
+    if(p->d_status.need(4) || p->h_status.need(4)) { delete p; return MDK_ERR_NOMEM; }
+    *out = p;
+    return 0;
+}
+extern "C" void md_piece_destroy(md_piece *p) {
+    if(!p) return;
+    (void)hipSetDevice(p->h->device);
+    if(p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    if(p->done) (void)hipEventDestroy(p->done);
+    p->d_comp.release(); p->d_out.release(); p->d_mem.release(); p->d_cnt.release(); p->d_first.release(); p->d_recoff.release(); p->d_status.release(); p->d_dig.release();
+    p->h_dig.release(); p->h_status.release();
+    delete p;
+}
+
+// H2D of the compressed bytes and the member table, inflate, record framing, D2H of the digests: all queued on the piece's
+// stream; md_piece_wait returns when it is all done.  comp should be pinned memory (md_host_alloc) for the copy to be a DMA.
+extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_bytes, const md_inf_member *mem, int n_mem) {
+    if(!p || !comp || !mem || n_mem < 1) return fail(MDK_ERR_ARG, "md_piece_submit", hipSuccess);
+    md_dev *h = p->h;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    uint64_t out_bytes = 0;
+    for(int i = 0; i < n_mem; i++) {
+        if(mem[i].out_off != out_bytes || mem[i].out_len > 65536u || mem[i].in_off + mem[i].in_len > comp_bytes) return fail(MDK_ERR_ARG, "md_piece_submit: member table", hipSuccess);
+        out_bytes += mem[i].out_len;
+    }
+    if(out_bytes >= (1ull << 32) - 65536) return fail(MDK_ERR_ARG, "md_piece_submit: more than 4 GiB inflated in one piece", hipSuccess);
+    const uint32_t rec_cap = (uint32_t)(out_bytes / 36 + 16);          // a BAM record is at least 36 bytes with its block_size word
+    if(p->d_comp.need((size_t)comp_bytes + 1024) || p->d_out.need((size_t)out_bytes + 1024) || p->d_mem.need((size_t)n_mem) || p->d_cnt.need((size_t)n_mem) || p->d_first.need((size_t)n_mem) ||
+       p->d_dig.need((size_t)n_mem) || p->h_dig.need((size_t)n_mem) || p->d_recoff.need((size_t)rec_cap)) return MDK_ERR_NOMEM;
+    p->n_mem = n_mem; p->out_bytes = out_bytes; p->comp_bytes = comp_bytes; p->n_rec_cap = rec_cap;
+    hipStream_t st = p->stream;
+    HIPCHK(hipMemcpyAsync(p->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->d_mem.p, mem, sizeof(md_inf_member) * (size_t)n_mem, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(p->d_status.p, 0, 16, st));
+    InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p;
+    launch_inflate(p->variant, n_mem, st, IP);
+    WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
+    hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
+    hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)p->d_cnt.p, p->d_first.p, n_mem, p->d_status.p);
+    hipLaunchKernelGGL(k_walk<true>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(p->h_dig.p, p->d_dig.p, sizeof(md_inf_digest) * (size_t)n_mem, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(p->h_status.p, p->d_status.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(p->done, st));
+    p->busy = true;
+    return 0;
+}
+
+extern "C" int md_piece_wait(md_piece *p, md_piece_info *info) {
+    if(!p || !info || !p->busy) return fail(MDK_ERR_ARG, "md_piece_wait: nothing submitted", hipSuccess);
+    HIPCHK(hipSetDevice(p->h->device));
+    HIPCHK(hipEventSynchronize(p->done));
+    p->busy = false;
+    const uint32_t st = p->h_status.p[0];
+    if(st) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "BGZF inflate failed on the device (corrupt file?): error %u in member %u of the piece", st & 255u, st >> 8); return MDK_ERR_ARG; }
+    info->n_mem = p->n_mem; info->digest = p->h_dig.p; info->n_records = p->h_status.p[1]; info->out_bytes = p->out_bytes;
+    info->d_out = p->d_out.p; info->d_rec_off = p->d_recoff.p;
+    return 0;
+}
+
+// the inflated bytes (or a part of them) back on the host: tests, and files whose records straddle members
+extern "C" int md_piece_read(md_piece *p, uint64_t off, uint64_t bytes, uint8_t *dst) {
+    if(!p || !dst || off + bytes > p->out_bytes) return fail(MDK_ERR_ARG, "md_piece_read", hipSuccess);
+    HIPCHK(hipSetDevice(p->h->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if(bytes) HIPCHK(hipMemcpy(dst, p->d_out.p + off, (size_t)bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int md_piece_read_records(md_piece *p, uint32_t first, uint32_t n, uint32_t *dst) {
+    if(!p || !dst || (uint64_t)first + n > p->n_rec_cap) return fail(MDK_ERR_ARG, "md_piece_read_records", hipSuccess);
+    HIPCHK(hipSetDevice(p->h->device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if(n) HIPCHK(hipMemcpy(dst, p->d_recoff.p + first, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// the kernels alone on resident input, timed with HIP events on the piece's stream (bench.py / tools)
+extern "C" int md_piece_bench(md_piece *p, int iters, float *ms_inflate, float *ms_walk) {
+    if(!p || iters < 1 || !p->n_mem) return fail(MDK_ERR_ARG, "md_piece_bench", hipSuccess);
+    HIPCHK(hipSetDevice(p->h->device));
+    hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+    hipStream_t st = p->stream; const int n_mem = p->n_mem;
+    InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p;
+    WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipEventRecord(e0, st));
+    for(int i = 0; i < iters; i++) launch_inflate(p->variant, n_mem, st, IP);
+    HIPCHK(hipEventRecord(e1, st));
+    for(int i = 0; i < iters; i++) {
+        hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
+        hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)p->d_cnt.p, p->d_first.p, n_mem, p->d_status.p);
+        hipLaunchKernelGGL(k_walk<true>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
+    }
+    HIPCHK(hipEventRecord(e2, st));
+    HIPCHK(hipEventSynchronize(e2));
+    float a = 0, b = 0; HIPCHK(hipEventElapsedTime(&a, e0, e1)); HIPCHK(hipEventElapsedTime(&b, e1, e2));
+    if(ms_inflate) *ms_inflate = a / (float)iters;
+    if(ms_walk) *ms_walk = b / (float)iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    return 0;
+}

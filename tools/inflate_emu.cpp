@@ -1,0 +1,132 @@
+// inflate_emu.cpp -- TEST INFRASTRUCTURE: the device inflate (csrc/mdk_inflate_core.h + the wavefront phases of k_inflate in
+// csrc/mdk_inflate.hip) executed on the host, lane by lane, over every member of a BGZF file and compared with zlib byte for
+// byte.  The decoding lane's code is the very code the kernel runs (the header compiles for both); the 64-lane phases are
+// re-stated here with the same per-lane bodies and the kernel's barriers turned into loop boundaries.
+//   build: g++ -O2 -o tools/_build/inflate_emu tools/inflate_emu.cpp -Imethyldackel_amd/csrc -lz
+//   run:   inflate_emu file.bam [max_members]      (exit 0 = every member identical to zlib)
+// Also: inflate_emu --selftest  runs deflate streams made with zlib at every level/strategy (stored, fixed, dynamic blocks,
+// long matches, distance-1 runs, maximum-distance matches, empty input).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <zlib.h>
+#include "mdk_inflate_core.h"
+
+// one member, as k_inflate does it; returns 0 or the error code
+static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uint8_t *out, uint32_t out_len, uint64_t *n_far, uint64_t *n_near, uint64_t *n_batches) {
+    static InfShared S; InfDec d;
+    if(out_len == 0) return 0;
+    const uint64_t a0 = in_off & ~3ull; const uint32_t skip = (uint32_t)(in_off & 3ull);
+    const uint32_t n_words = (uint32_t)((in_off + in_len + 3 - a0) >> 2);
+    auto word = [&](uint32_t w) -> uint32_t { uint32_t v = 0; if(w < n_words) memcpy(&v, comp + a0 + 4ull * w, 4); return v; };   // (the caller pads the buffer)
+    uint32_t filled = 0;
+    for(; filled < INF_IN_WORDS; filled += 64) for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); }
+    inf_dec_init(d, S.in, skip, out_len);
+    uint32_t taken = 3;
+    for(;;) {
+        while(filled + 64 <= taken + INF_IN_WORDS) { for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); } filled += 64; }
+        inf_decode_batch<false>(d, S, true, InfNoBcast());
+        (*n_batches)++;
+        const uint32_t n_tok = S.n_tok, beg = S.batch_beg, end = S.batch_end, err = S.err, fin = S.finished;
+        taken = S.words_used;
+        if(err) return (int)err;
+        if(taken > n_words + 3) return INF_E_INPUT;
+        if(end - beg > INF_BATCH_BYTES || n_tok > INF_MAX_TOK) return 100;
+        bool far[64];
+        for(uint32_t lane = 0; lane < 64; lane++) {
+            far[lane] = false;
+            if(lane < n_tok) {
+                const InfToken t = S.tok[lane]; far[lane] = inf_tok_far(t, beg);
+                if(far[lane]) {
+                    const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16);
+                    if(src + len > beg) return 101;                       // a far source must lie wholly in what earlier batches wrote
+                    for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = out[src + i];
+                    (*n_far)++;
+                }
+            }
+        }
+        for(uint32_t k = 0; k < n_tok; k++) {
+            if(far[k]) continue;
+            const InfToken q = S.tok[k]; const uint32_t len = q.len_dist & 0xffffu, dist = q.len_dist >> 16;
+            if(q.dst - dist + INF_WIN < end) return 102;                  // a near source must still be in the window at the end of the batch
+            uint32_t done = 0, span = dist;
+            while(done < len) {
+                const uint32_t n = span < len - done ? span : len - done;
+                uint8_t snap[INF_WIN]; memcpy(snap, S.win, INF_WIN);      // all lanes read before any lane's write is seen: the round must not depend on lane order
+                for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[(q.dst + done + i) & (INF_WIN - 1)] = snap[(q.dst - dist + i) & (INF_WIN - 1)];
+                done += n; span <<= 1;
+            }
+            (*n_near)++;
+        }
+        for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
+        if(fin) return 0;
+    }
+}
+
+static int check_stream(const std::vector<uint8_t> &raw, int level, int strategy, const char *what) {
+    std::vector<uint8_t> comp(compressBound(raw.size()) + 64 + 8); z_stream zs; memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, level, Z_DEFLATED, -15, 8, strategy);
+    const int lead = 1 + (int)(raw.size() % 3);                                // an unaligned start, as in a file
+    zs.next_in = (Bytef *)raw.data(); zs.avail_in = (uInt)raw.size(); zs.next_out = comp.data() + lead; zs.avail_out = (uInt)(comp.size() - lead - 8);
+    deflate(&zs, Z_FINISH); const uint32_t clen = (uint32_t)zs.total_out; deflateEnd(&zs);
+    std::vector<uint8_t> got(raw.size() + 8, 0xEE); uint64_t a = 0, b = 0, c = 0;
+    const int rc = emu_member(comp.data(), (uint64_t)lead, clen, got.data(), (uint32_t)raw.size(), &a, &b, &c);
+    if(rc || memcmp(got.data(), raw.data(), raw.size())) { fprintf(stderr, "selftest FAILED: %s level %d strategy %d size %zu: rc %d\n", what, level, strategy, raw.size(), rc); return 1; }
+    return 0;
+}
+static int selftest(void) {
+    int bad = 0; uint64_t s = 88172645463325252ull; auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for(int kind = 0; kind < 8; kind++) for(size_t size : {(size_t)0, (size_t)1, (size_t)7, (size_t)300, (size_t)5000, (size_t)65280, (size_t)65536}) {
+        std::vector<uint8_t> raw(size);
+        for(size_t i = 0; i < size; i++) {
+            switch(kind) {
+            case 0: raw[i] = (uint8_t)rnd(); break;                                         // incompressible: stored blocks
+            case 1: raw[i] = 'A'; break;                                                    // distance-1 runs, length 258
+            case 2: raw[i] = "ACGT"[rnd() & 3]; break;                                      // 4 symbols: short codes
+            case 3: raw[i] = (uint8_t)(i < 40000 ? rnd() : raw[i - 32768 > 0 && i >= 32768 ? i - 32768 : 0]); break;     // maximum-distance matches
+            case 4: raw[i] = (uint8_t)((i % 600) < 300 ? (rnd() % 200) : raw[i >= 300 ? i - 300 : 0]); break;            // many symbols: long codes + mid-range matches
+            case 5: raw[i] = (uint8_t)((i / 3) % 251); break;
+            case 6: raw[i] = (uint8_t)(rnd() % 3 ? 'x' : (rnd() & 255)); break;
+            default: raw[i] = (uint8_t)((i % 7 == 0) ? rnd() : (i & 255)); break;
+            }
+        }
+        for(int level : {0, 1, 4, 6, 9}) for(int strat : {Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY, Z_RLE, Z_FILTERED}) bad += check_stream(raw, level, strat, "synthetic");
+    }
+    // a skewed alphabet of 286 used symbols with lengths up to 15: sub-tables of every depth
+    { std::vector<uint8_t> raw; double p = 0.5; for(int sym = 0; sym < 256; sym++) { size_t n = (size_t)(60000 * p) + 1; for(size_t k = 0; k < n; k++) raw.push_back((uint8_t)sym); if(sym < 14) p /= 2; }
+      for(size_t i = raw.size() - 1; i > 0; i--) { size_t j = rnd() % (i + 1); uint8_t t = raw[i]; raw[i] = raw[j]; raw[j] = t; }
+      if(raw.size() > 65536) raw.resize(65536);
+      for(int level : {1, 6, 9}) bad += check_stream(raw, level, Z_HUFFMAN_ONLY, "skewed") + check_stream(raw, level, Z_DEFAULT_STRATEGY, "skewed"); }
+    printf("selftest: %s\n", bad ? "FAILED" : "ok");
+    return bad ? 1 : 0;
+}
+
+int main(int argc, char **argv) {
+    if(argc > 1 && !strcmp(argv[1], "--selftest")) return selftest();
+    if(argc < 2) { fprintf(stderr, "usage: inflate_emu file.bam [max_members] | --selftest\n"); return 2; }
+    FILE *f = fopen(argv[1], "rb"); if(!f) { perror(argv[1]); return 2; }
+    fseek(f, 0, SEEK_END); size_t n = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> raw(n + 64, 0); if(fread(raw.data(), 1, n, f) != n) return 2; fclose(f);
+    const long maxm = argc > 2 ? atol(argv[2]) : -1;
+    size_t o = 0; long m = 0, bad = 0; uint64_t tot = 0, n_far = 0, n_near = 0, n_batches = 0;
+    std::vector<uint8_t> ref(65536 + 64), got(65536 + 64);
+    while(o + 18 <= n && (maxm < 0 || m < maxm)) {
+        const uint16_t xlen = (uint16_t)(raw[o + 10] | raw[o + 11] << 8); const uint32_t bs = (uint32_t)(raw[o + 16] | raw[o + 17] << 8) + 1; uint32_t isz; memcpy(&isz, &raw[o + bs - 4], 4);
+        const uint64_t in_off = o + 12 + xlen; const uint32_t in_len = bs - 12 - xlen - 8;
+        if(isz) {
+            z_stream zs; memset(&zs, 0, sizeof zs); zs.next_in = raw.data() + in_off; zs.avail_in = in_len; zs.next_out = ref.data(); zs.avail_out = isz;
+            inflateInit2(&zs, -15); const int zr = inflate(&zs, Z_FINISH); inflateEnd(&zs);
+            if(zr != Z_STREAM_END) { fprintf(stderr, "zlib failed on member %ld\n", m); return 2; }
+            memset(got.data(), 0xEE, isz);
+            const int rc = emu_member(raw.data(), in_off, in_len, got.data(), isz, &n_far, &n_near, &n_batches);
+            if(rc || memcmp(got.data(), ref.data(), isz)) { if(bad < 5) { size_t k = 0; while(k < isz && got[k] == ref[k]) k++; fprintf(stderr, "member %ld (file offset %zu): rc %d, first difference at byte %zu of %u\n", m, o, rc, k, isz); } bad++; }
+            tot += isz;
+        }
+        o += bs; m++;
+    }
+    printf("{\"members\": %ld, \"inflated_bytes\": %llu, \"mismatching_members\": %ld, \"batches\": %llu, \"far_matches\": %llu, \"near_matches\": %llu}\n", m, (unsigned long long)tot, bad,
+           (unsigned long long)n_batches, (unsigned long long)n_far, (unsigned long long)n_near);
+    return bad ? 1 : 0;
+}
