@@ -126,8 +126,12 @@ typedef struct {
     int32_t no_pairing;           /* mbias: no overlap handler is installed (MBias.c:158-161) */
     int32_t perread;              /* perRead: a record is kept iff it STARTS inside the chunk and passes -R / -F / -q (perRead.c:178-183) */
 } md_prep_cfg;
-/* host memory holding whole records back to back, each as in the file: uint32 block_size, then block_size bytes */
-typedef struct { const uint8_t *ptr; uint64_t bytes; } md_raw_range;
+/* whole records back to back, each as in the file: uint32 block_size, then block_size bytes.  A range lies either in host memory
+ * (d_rec_off == NULL; its records' offsets are the next n_records entries of the batch's rec_off array) or -- a run of members of
+ * a piece inflated on the device (md_piece_*) -- in DEVICE memory: ptr and d_rec_off are device pointers, d_rec_off[i] - rec_delta is
+ * the offset of the range's record i from ptr.  n_records must be filled in for every range as soon as one range is on the
+ * device; a batch of host ranges only may leave it 0. */
+typedef struct { const uint8_t *ptr; uint64_t bytes; const uint32_t *d_rec_off; uint32_t n_records, rec_delta; } md_raw_range;
 /* The candidate records of ONE chunk: everything the region query [beg,end) of the chunk's contig returns (pos < end,
  * bam_endpos > beg), in file order.  rec_off[i] = offset of record i's block_size word in the concatenation of the ranges
  * (less than 4 GiB in total).  woff/wlen: the reference window the chunk fetches (extract.c:381), which the
@@ -146,6 +150,10 @@ int  md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bits, int64_
  * return MDK_ERR_PREP_HOST when the preparation gave up on the chunk (see above). */
 int  md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b);
 int  md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b);
+/* the records of an uploaded slot back on the host, as the device holds them: the concatenation of the batch's ranges (bytes)
+ * and every record's offset in it (rec_off[n_records]); for a chunk the device preparation gives up on (MDK_ERR_PREP_HOST)
+ * whose records were inflated on the device and so never existed in host memory.  bytes/n_records: capacities in, sizes out. */
+int  md_dev_read_raw(md_dev *h, int slot, uint8_t *bytes, uint64_t *n_bytes, uint32_t *rec_off, uint32_t *n_records);
 /* The preparation kernels of a slot uploaded with md_dev_upload_raw, re-run `iters` times on the resident records and timed
  * with HIP events (the slot's segments are the same afterwards). */
 int  md_dev_bench_prep(md_dev *h, int slot, int warmup, int iters, float *ms_per_chunk);

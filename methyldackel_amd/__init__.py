@@ -57,7 +57,7 @@ class md_prep_cfg(C.Structure):
 
 
 class md_raw_range(C.Structure):
-    _fields_ = [("ptr", C.POINTER(C.c_uint8)), ("bytes", C.c_uint64)]
+    _fields_ = [("ptr", C.POINTER(C.c_uint8)), ("bytes", C.c_uint64), ("d_rec_off", C.POINTER(C.c_uint32)), ("n_records", C.c_uint32), ("rec_delta", C.c_uint32)]
 
 
 class md_raw_batch(C.Structure):

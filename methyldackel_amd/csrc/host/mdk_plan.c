@@ -279,11 +279,10 @@ MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional
     opts_t *o = &p->o; int i; char *oname; FILE *bbm = NULL;
     o->fasta_name = argv[first_positional]; o->bam_name = argv[first_positional + 1];
     if(o->n_threads < 1) o->n_threads = 1;
-    {   /* the reader's slabs are staging memory too and the inflate threads start allocating them at once: decide by the file's
-         * size before it is opened (a -r region can only turn pinning off again, below) */
-        struct stat st0; long long min_bytes = getenv("MDK_PIN_MIN_BYTES") ? atoll(getenv("MDK_PIN_MIN_BYTES")) : 16000000000LL;
-        md_host_set_pinned(!(stat(o->bam_name, &st0) == 0 && (long long)st0.st_size < min_bytes));
-    }
+    /* staging memory (the reader's slabs, the batch buffers) is huge-page memory that libmdk_hip registers with the runtime the
+     * first time an upload reads from it (md_host_alloc): allocating it never waits for the device to come up, and every upload
+     * is a DMA off the submitting thread -- the pinned double-buffered feed of the north star, for inputs of any size */
+    md_host_set_pinned(0);
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
     if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
     p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */
@@ -343,16 +342,6 @@ region:
     }
     /* -l (extract.c:1469-1477, MBias.c:524-532) */
     if(o->bed_name && load_bed(p) != 0) { fprintf(stderr, "There was an error while reading in your BED file!\n"); plan_free(p); return 1; }
-    {   /* staging memory (the reader's slabs): pinning ~2.5 GB of it costs ~0.7 s and delays the device start-up; only worth it when there
-         * are thousands of chunks to upload (a pageable upload costs the submitting thread ~2 ms per chunk): BAM files of 16 GB and more */
-        struct stat st; long long min_bytes = getenv("MDK_PIN_MIN_BYTES") ? atoll(getenv("MDK_PIN_MIN_BYTES")) : 16000000000LL; int pin = 1;
-        if(stat(o->bam_name, &st) == 0 && (long long)st.st_size < min_bytes) pin = 0;
-        if(o->region && p->g_tid < (uint32_t)p->bam->n_targets) {      /* a region of a large file: count its chunks instead */
-            uint64_t span = (p->g_end ? p->g_end : p->bam->target_len[p->g_tid]) - (uint64_t)p->g_pos;
-            if(span / o->chunk_size < 90) pin = 0;
-        }
-        md_host_set_pinned(pin);
-    }
     return 0;
 }
 

@@ -814,6 +814,7 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
         if(h->variant && s->d_var.need((size_t)span + 16)) return MDK_ERR_NOMEM;
     }
     if(ns) {
+        host_block_ensure_registered(b->seg); host_block_ensure_registered(b->blob);
         HIPCHK(hipMemcpyAsync(s->d_seg_in.p, b->seg, ns * sizeof(md_seg), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->d_blob.p, b->blob, (size_t)b->blob_bytes, hipMemcpyHostToDevice, s->stream));
     }
@@ -1034,6 +1035,7 @@ extern "C" int md_dev_perread_submit(md_dev *h, int slot, const md_pr_batch *b) 
     const size_t n = (size_t)b->n_reads;
     if(s->d_pr.need(n + 1) || s->d_cig.need((size_t)b->n_cigar + 1) || s->d_blob.need((size_t)b->blob_bytes + 64) || s->d_prc.need(n + 1) || s->h_prc.need(n + 1)) return MDK_ERR_NOMEM;
     if(n) {
+        host_block_ensure_registered(b->blob);
         HIPCHK(hipMemcpyAsync(s->d_pr.p, b->read, n * sizeof(md_pr_read), hipMemcpyHostToDevice, s->stream));
         if(b->n_cigar) HIPCHK(hipMemcpyAsync(s->d_cig.p, b->cigar, (size_t)b->n_cigar * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
         HIPCHK(hipMemcpyAsync(s->d_blob.p, b->blob, (size_t)b->blob_bytes, hipMemcpyHostToDevice, s->stream));
@@ -1281,22 +1283,41 @@ extern "C" int md_dev_debug_effective(md_dev *h, int slot, uint8_t *out_base, ui
     return 0;
 }
 
-// Staging memory for the host: pinned when a device is present (so hipMemcpyAsync really is asynchronous),
-// ordinary page-aligned memory otherwise (lets the host-side packing logic be exercised on a machine without a
-// GPU; nothing is computed there).  A 64-byte header in front of the block remembers which kind it is.
-// Pageable staging blocks of several MB are 2 MiB-aligned and offered to the kernel as transparent huge pages: a 45 MB slab
-// is then 23 page faults instead of 11,500 for the inflate threads, and a process that leaves with gigabytes of them
-// resident is torn down in a millisecond instead of a quarter of a second (profiles/r02h_exit_probe*.txt).
+// Staging memory for the host.  Blocks of several MB are 2 MiB-aligned and offered to the kernel as transparent huge pages (a 45 MB
+// slab is 23 page faults for the inflate threads instead of 11,500); the library REGISTERS such a block with the runtime the
+// first time an upload reads from it (hipHostRegister of huge-page memory: 4.7 ms per 512 MB on the MI355X box,
+// profiles/r03a_pin_probe.json), after which hipMemcpyAsync from it is a DMA at the link's 56 GB/s that costs the submitting
+// thread a microsecond -- pageable, the same copy is a 13 GB/s CPU copy on the submitting thread.  Allocation itself never
+// touches the HIP runtime, so the inflate threads can fill slabs while the device is still coming up.  A 64-byte header in front
+// of the block remembers which kind it is.  md_host_set_pinned(1) (default off in the commands) allocates with hipHostMalloc.
+struct HostBlock { char *base; size_t len; bool registered; };
+static std::mutex g_blocks_mu; static std::vector<HostBlock> g_blocks;       // sorted by base
 static void *plain_alloc(size_t n) {
     void *p = nullptr;
     static const int thp = getenv("MDK_NO_THP") ? 0 : 1;
+    size_t len = n;
     if(thp && n >= (4u << 20)) {
-        const size_t len = (n + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        len = (n + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
         if(posix_memalign(&p, 2u << 20, len) != 0) return nullptr;
         (void)madvise(p, len, MADV_HUGEPAGE);
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        HostBlock b{(char *)p, len, false};
+        g_blocks.insert(std::upper_bound(g_blocks.begin(), g_blocks.end(), b, [](const HostBlock &x, const HostBlock &y) { return x.base < y.base; }), b);
     } else if(posix_memalign(&p, 4096, n) != 0) return nullptr;
     memcpy(p, "MDKMAL", 7);
     return (char *)p + 64;
+}
+// before an upload from [ptr, ptr+bytes): if that lies in a huge-page staging block not yet known to the runtime, register the block
+MDK_HIDDEN void host_block_ensure_registered(const void *ptr) {
+    static const int off = getenv("MDK_NO_PIN") ? 1 : 0;
+    if(off) return;
+    std::lock_guard<std::mutex> lk(g_blocks_mu);
+    HostBlock key{(char *)ptr, 0, false};
+    auto it = std::upper_bound(g_blocks.begin(), g_blocks.end(), key, [](const HostBlock &x, const HostBlock &y) { return x.base < y.base; });
+    if(it == g_blocks.begin()) return;
+    --it;
+    if((char *)ptr >= it->base + it->len || it->registered) return;
+    if(hipHostRegister(it->base, it->len, hipHostRegisterDefault) == hipSuccess) it->registered = true; else (void)hipGetLastError();      // a block that cannot be registered is uploaded pageable
 }
 static std::atomic<int> g_want_pinned{1};
 extern "C" void md_host_set_pinned(int on) { g_want_pinned.store(on != 0); }
@@ -1311,5 +1332,12 @@ extern "C" void *md_host_alloc(uint64_t bytes) {
 extern "C" void md_host_free(void *q) {
     if(!q) return;
     char *p = (char *)q - 64;
-    if(!memcmp(p, "MDKPIN", 7)) (void)hipHostFree(p); else free(p);
+    if(!memcmp(p, "MDKPIN", 7)) { (void)hipHostFree(p); return; }
+    {
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        HostBlock key{p, 0, false};
+        auto it = std::lower_bound(g_blocks.begin(), g_blocks.end(), key, [](const HostBlock &x, const HostBlock &y) { return x.base < y.base; });
+        if(it != g_blocks.end() && it->base == p) { if(it->registered) (void)hipHostUnregister(p); g_blocks.erase(it); }
+    }
+    free(p);
 }

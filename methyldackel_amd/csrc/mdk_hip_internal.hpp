@@ -131,6 +131,7 @@ __device__ __forceinline__ md_pr_count perread_walk(const uint8_t *seq, const ui
 }
 
 MDK_HIDDEN Slot *get_slot(md_dev *h, int slot);
+MDK_HIDDEN void host_block_ensure_registered(const void *ptr);      // a huge-page staging block is registered with the runtime at its first upload
 MDK_HIDDEN int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on = nullptr);
 MDK_HIDDEN int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cross_sync);
 MDK_HIDDEN int64_t finish_count(md_dev *h, Slot *s);

@@ -18,7 +18,7 @@
 #include "mdk_inflate_core.h"
 
 // coherent byte / word loads of what this wavefront stored earlier (plain loads could hit a stale line in the CU's L1)
-__device__ __forceinline__ uint32_t ld_u8_l2(const uint8_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_u32_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct InfParams {
     const uint8_t *comp;              // the piece's compressed bytes (device), 4-byte aligned base
@@ -31,23 +31,16 @@ struct InfParams {
 struct InfBcast {
     __device__ __forceinline__ uint32_t word(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     __device__ __forceinline__ void operator()(InfDec &d) const {
-        d.lo = word(d.lo); d.hi = word(d.hi); d.nx = word(d.nx); d.sh = word(d.sh); d.widx = word(d.widx); d.pos = word(d.pos); d.out_len = word(d.out_len);
+        d.bb = (uint64_t)word((uint32_t)d.bb) | ((uint64_t)word((uint32_t)(d.bb >> 32)) << 32); d.cnt = word(d.cnt); d.nx = word(d.nx); d.widx = word(d.widx); d.pos = word(d.pos); d.out_len = word(d.out_len);
         d.in_block = word(d.in_block); d.last = word(d.last); d.stored_left = word(d.stored_left);
     }
 };
-// VARIANT bit 0: the decoder's values are uniform (readfirstlane behind every LDS load: scalar registers, scalar arithmetic and
-// branches) instead of living in lane 0's vector registers under an execution mask; bit 1: between the phases of one wavefront only the compiler is fenced (LDS operations of a wavefront are
-// executed in order) instead of s_waitcnt + s_barrier.
-template <int VARIANT>
-__global__ __launch_bounds__(64) void k_inflate(const InfParams P) {
-    constexpr bool LIGHT = (VARIANT & 2) != 0, MIX = (VARIANT & 4) != 0;
-    // MIX (bit 2): odd members decode on the scalar unit, even ones on the vector unit -- the two issue ports of a SIMD then
-    // both carry decoders (wave-uniform choice)
-    const bool UNI = MIX ? (blockIdx.x & 1) != 0 : (VARIANT & 1) != 0;
-    __shared__ InfShared S;
+// One member by one wavefront.  UNI: the decoder's values are uniform (readfirstlane behind every LDS load: scalar registers, scalar
+// arithmetic and branches) instead of living in lane 0's vector registers under an execution mask.  LIGHT: between the phases of
+// one wavefront only the compiler is fenced (the LDS operations of a wavefront are executed in order) instead of s_waitcnt + s_barrier.
+template <bool UNI, bool LIGHT>
+__device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S, const int m, const int lane) {
     auto sync = [&]() { if(LIGHT) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); };
-    const int m = blockIdx.x, lane = threadIdx.x;
-    if(m >= P.n_mem) return;
     const md_inf_member M = P.mem[m];
     if(M.out_len == 0) return;
     const uint64_t a0 = M.in_off & ~3ull;                               // aligned start of the stream's words
@@ -69,7 +62,7 @@ __global__ __launch_bounds__(64) void k_inflate(const InfParams P) {
         sync();
         // the decoder runs with one lane enabled; in uniform mode what it loads goes through readfirstlane, so its state stays in
         // scalar registers inside the region and is made uniform again behind it
-        if(lane == 0) { if(UNI) inf_decode_batch<true>(d, S, true, InfNoBcast()); else inf_decode_batch<false>(d, S, true, InfNoBcast()); }
+        if(lane == 0) inf_decode_batch<UNI>(d, S);
         if(UNI) InfBcast()(d);
         sync();
         const uint32_t n_tok = S.n_tok, beg = S.batch_beg, end = S.batch_end, err = S.err, fin = S.finished;
@@ -82,35 +75,59 @@ __global__ __launch_bounds__(64) void k_inflate(const InfParams P) {
         if(__ballot(far)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the earlier batches' stores have reached L2
             if(far) {
-                const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16);
-                uint32_t i = 0;
-                for(; i + 4 <= len; i += 4) {
-                    const uint32_t b0 = ld_u8_l2(out + src + i), b1 = ld_u8_l2(out + src + i + 1), b2 = ld_u8_l2(out + src + i + 2), b3 = ld_u8_l2(out + src + i + 3);
-                    S.win[(t.dst + i) & (INF_WIN - 1)] = (uint8_t)b0; S.win[(t.dst + i + 1) & (INF_WIN - 1)] = (uint8_t)b1;
-                    S.win[(t.dst + i + 2) & (INF_WIN - 1)] = (uint8_t)b2; S.win[(t.dst + i + 3) & (INF_WIN - 1)] = (uint8_t)b3;
+                // 16 bytes per round trip: the five aligned words that hold them are requested together, then cut to the source's
+                // byte offset (v_alignbyte) and stored into the window byte by byte (its position there is unaligned too)
+                const uint32_t len = t.len_dist & 0xffffu; const uint8_t *sp = out + (t.dst - (t.len_dist >> 16));
+                for(uint32_t i = 0; i < len; i += 16) {
+                    const uintptr_t a = (uintptr_t)(sp + i); const uint32_t *wp = (const uint32_t *)(a & ~(uintptr_t)3); const uint32_t k = (uint32_t)(a & 3u);
+                    const uint32_t n = len - i < 16u ? len - i : 16u;
+                    const uint32_t w0 = ld_u32_l2(wp), w1 = ld_u32_l2(wp + 1), w2 = ld_u32_l2(wp + 2), w3 = ld_u32_l2(wp + 3), w4 = ld_u32_l2(wp + 4);
+                    uint32_t b[4] = {__builtin_amdgcn_alignbyte(w1, w0, k), __builtin_amdgcn_alignbyte(w2, w1, k), __builtin_amdgcn_alignbyte(w3, w2, k), __builtin_amdgcn_alignbyte(w4, w3, k)};
+#pragma unroll
+                    for(uint32_t q = 0; q < 16; q++) if(q < n) S.win[(t.dst + i + q) & (INF_WIN - 1)] = (uint8_t)(b[q >> 2] >> (8 * (q & 3)));
                 }
-                for(; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = (uint8_t)ld_u8_l2(out + src + i);
             }
             sync();
         }
-        // (3) near matches, in stream order, each by the whole wavefront
+        // (3) near matches, in stream order, each by the whole wavefront; the token travels from the lane that holds it by readlane
         unsigned long long near = __ballot((uint32_t)lane < n_tok && !far);
         while(near) {
             const int k = __ffsll((long long)near) - 1; near &= near - 1;
-            const InfToken q = S.tok[k];                                        // same address for every lane: a broadcast read
-            const uint32_t len = q.len_dist & 0xffffu, dist = q.len_dist >> 16;
+            const uint32_t qdst = (uint32_t)__builtin_amdgcn_readlane((int)t.dst, k), qld = (uint32_t)__builtin_amdgcn_readlane((int)t.len_dist, k);
+            const uint32_t len = qld & 0xffffu, dist = qld >> 16;
             uint32_t done = 0, span = dist;
             while(done < len) {
                 const uint32_t n = span < len - done ? span : len - done;
-                inf_near_round(S.win, q.dst, dist, done, n, (uint32_t)lane);
+                inf_near_round(S.win, qdst, dist, done, n, (uint32_t)lane);
                 sync();
                 done += n; span <<= 1;
             }
         }
         // (4) the batch leaves the window
-        for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
+        {   // whole aligned words of the window as dwords (the global address is whatever the member's offset makes it), the edges as bytes
+            const uint32_t p0 = (beg + 3u) & ~3u, p1 = end & ~3u;
+            if(p0 <= p1) {
+                for(uint32_t p = p0 + 4u * lane; p < p1; p += 256) { const uint32_t v = *(const uint32_t *)&S.win[p & (INF_WIN - 1)]; __builtin_memcpy(out + p, &v, 4); }
+                if(beg + lane < p0) out[beg + lane] = S.win[(beg + lane) & (INF_WIN - 1)];
+                if(p1 + lane < end) out[p1 + lane] = S.win[(p1 + lane) & (INF_WIN - 1)];
+            } else for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
+        }
         if(fin) return;
     }
+}
+// VARIANT bit 0: UNI, bit 1: LIGHT (see inflate_member), bit 2: MIX -- odd members decode on the scalar unit, even ones on the vector
+// unit, so that both issue ports of a SIMD carry decoders (the choice is uniform per wavefront).
+#ifndef INF_WAVES
+#define INF_WAVES 7
+#endif
+template <int VARIANT>
+__global__ __launch_bounds__(64, INF_WAVES) void k_inflate(const InfParams P) {
+    constexpr bool LIGHT = (VARIANT & 2) != 0, MIX = (VARIANT & 4) != 0;
+    __shared__ InfShared S;
+    const int m = blockIdx.x, lane = threadIdx.x;
+    if(m >= P.n_mem) return;
+    if(MIX) { if(m & 1) inflate_member<true, LIGHT>(P, S, m, lane); else inflate_member<false, LIGHT>(P, S, m, lane); }
+    else inflate_member<(VARIANT & 1) != 0, LIGHT>(P, S, m, lane);
 }
 
 // ---- record framing ----
@@ -197,7 +214,7 @@ static void launch_inflate(int variant, int n_mem, hipStream_t st, const InfPara
     }
 }
 #ifndef INF_DEFAULT_VARIANT
-#define INF_DEFAULT_VARIANT 1
+#define INF_DEFAULT_VARIANT 0
 #endif
 struct md_piece {
     int variant = getenv("MDK_INFLATE_VARIANT") ? atoi(getenv("MDK_INFLATE_VARIANT")) : INF_DEFAULT_VARIANT;

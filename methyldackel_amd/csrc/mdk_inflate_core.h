@@ -2,7 +2,7 @@
 //
 // Where this sits: the reference pays for BGZF inflate inside htslib's sam_itr_next (common.c:413); SURVEY.md 8(f) rank 1 moves it
 // to the device.  A member (<= 64 KiB of BAM, bgzf.c of htslib: BGZF_BLOCK_SIZE 0xff00) is one raw deflate stream.  Symbol
-// boundaries depend on every symbol before them, so one lane of the wavefront decodes symbols -- this file -- while everything
+// boundaries depend on every symbol before them, so ONE decoder per wavefront walks the symbols -- this file -- while everything
 // that is not sequential is done by all 64 lanes in mdk_inflate.hip: staging the compressed words into an LDS ring, copying the
 // LZ77 matches (sources further back than the LDS window come from global memory, nearer ones from the window) and writing the
 // finished bytes out coalesced.
@@ -20,32 +20,44 @@
 #define MDK_HDN __device__ __noinline__
 #define MDK_HDM __device__ __forceinline__
 #else
-#define MDK_HDM inline
 #define MDK_HD static inline
 #define MDK_HDN static
+#define MDK_HDM inline
 #endif
 
 // ---- geometry of one wavefront's LDS state ----
 #define INF_LIT_TB    9                    // root bits of the literal/length table
 #define INF_DIST_TB   8                    // root bits of the distance table
-#define INF_LIT_CAP   1024                 // entries: 512 root + sub-tables (RFC-valid codes with root 9 need at most 852)
-#define INF_DIST_CAP  512                  // entries: 256 root + sub-tables (at most 402 with root 8)
+#define INF_LIT_CAP   864                  // entries: 512 root + sub-tables (a complete code of 286 symbols with root 9 needs at most 852)
+#define INF_DIST_CAP  416                  // entries: 256 root + sub-tables (at most 402 with root 8)
 #define INF_IN_WORDS  256                  // compressed-input ring, 32-bit words (power of two)
-#define INF_WIN       4096                 // output window ring, bytes (power of two)
-#define INF_BATCH_BYTES 2048               // a batch never produces more than this (<= INF_WIN / 2)
-#define INF_BATCH_SYMS  64                 // ... nor more symbols than this (bounds the input a batch consumes)
-#define INF_MAX_TOK   64                   // match tokens per batch (<= INF_BATCH_SYMS)
+#ifndef INF_WIN
+#define INF_WIN       2048                 // output window ring, bytes (power of two)
+#endif
+#define INF_BATCH_BYTES (INF_WIN / 2)      // a batch never produces more than this
+#define INF_BATCH_WORDS 150                // ... nor takes more than this many words from the input ring (the ring is topped up to >= 193 ahead)
+#define INF_MAX_TOK   64                   // ... nor holds more match tokens than this (one per lane)
 
-// table entry (32 bits): bits 0-3 bits to consume, bit 4 literal, bit 5 special (with bits 6-7: which), bits 8-12 extra bits /
-// sub-table bits, bits 16-31 value.  The decoder's common cases are one bit test each.
-#define INF_F_LIT   0x10u                  // literal: value = byte
-#define INF_F_SPEC  0x20u                  // not a literal, not a length: sub-table pointer, end of block, or unassigned code space
-#define INF_K_LEN   0u                     // length symbol: value = base length, extra = extra bits          (also distance: base distance)
-#define INF_K_LIT   INF_F_LIT
-#define INF_K_SUB   (INF_F_SPEC | 0x00u)   // pointer: value = first entry of the sub-table, extra = its index bits
-#define INF_K_EOB   (INF_F_SPEC | 0x40u)   // end of block
-#define INF_K_BAD   (INF_F_SPEC | 0x80u)   // unassigned code space
-#define INF_KIND(e) ((e) & 0xf0u)
+// Literal/length table entry, 16 bits (the tables of a wavefront are 3.3 KiB of LDS):
+//   length symbol   1 eee bbbbbbbb nnnn   e = extra bits (0..5), b = base length - 3 (0..255), n = code bits to consume
+//   everything else 0 kk vvvvvvvvv nnnn   k = 0 literal (v = byte), 1 sub-table pointer (v = first entry - 512, n = its index bits),
+//                                         2 end of block, 3 unassigned code space
+// so that the decoder's commonest case -- a length -- is one bit test and three field extractions.
+typedef uint16_t inf_lit_t;
+#define INF_L_LEN   0x8000u
+#define INF_L_KIND(e) ((e) & 0x6000u)
+#define INF_L_LIT   0x0000u
+#define INF_L_SUB   0x2000u
+#define INF_L_EOB   0x4000u
+#define INF_L_BAD   0x6000u
+// Distance table entry, 32 bits: bits 0-3 code bits to consume (pointer: index bits of the sub-table), bits 4-5 kind (0 distance
+// symbol, 1 sub-table pointer, 3 unassigned), bits 8-11 extra bits, bits 16-31 base distance (pointer: first entry of the sub-table).
+// The code-length alphabet of a dynamic block header is decoded through the same memory: kind 0, "base" = symbol.
+typedef uint32_t inf_dist_t;
+#define INF_D_KIND(e) ((e) & 0x30u)
+#define INF_D_SYM   0x00u
+#define INF_D_SUB   0x10u
+#define INF_D_BAD   0x30u
 
 // error codes (0 = fine)
 enum { INF_OK = 0, INF_E_BTYPE = 1, INF_E_STORED = 2, INF_E_HEADER = 3, INF_E_CODELEN = 4, INF_E_LITTABLE = 5, INF_E_DISTTABLE = 6, INF_E_SYMBOL = 7,
@@ -55,19 +67,20 @@ struct InfToken { uint32_t dst; uint32_t len_dist; };       // dst: position in 
 
 // Everything one wavefront keeps in LDS for the member it inflates.
 struct InfShared {
-    uint32_t lit[INF_LIT_CAP];
-    uint32_t dist[INF_DIST_CAP];
+    inf_dist_t dist[INF_DIST_CAP];
+    inf_lit_t lit[INF_LIT_CAP];
     uint32_t in[INF_IN_WORDS];             // ring of compressed words: word w of the stream lives in in[w & (INF_IN_WORDS-1)]
     uint8_t  win[INF_WIN];                 // ring of output bytes: byte p of the member lives in win[p & (INF_WIN-1)]
     InfToken tok[INF_MAX_TOK];
-    // written by the decoding lane at the end of a batch, read by all lanes after the barrier
+    // written by the decoder at the end of a batch, read by all lanes after the barrier
     uint32_t n_tok, batch_beg, batch_end, words_used, finished, err;
 };
 
-// The decoding lane's registers between batches.
+// The decoder's registers between batches.  `bb` holds the next `cnt` bits of the stream, least significant first; 32 <= cnt <= 63
+// between any two steps, so a step can look at 32 bits without asking.
 struct InfDec {
-    uint32_t lo, hi, nx;                   // bit buffer: 64 bits of the stream from word `widx-3`.. ; nx = word prefetched one refill ahead
-    uint32_t sh;                           // bits of `lo` already consumed (0..31)
+    uint64_t bb; uint32_t cnt;
+    uint32_t nx;                           // the stream word after the ones in bb, fetched one refill ahead of its use
     uint32_t widx;                         // next stream word to fetch from the ring
     uint32_t pos;                          // bytes produced so far
     uint32_t out_len;                      // the member's ISIZE
@@ -76,21 +89,19 @@ struct InfDec {
     uint32_t stored_left;                  // bytes of the stored block still to copy
 };
 
-// UNI = the decoder runs on EVERY lane of the wavefront with identical values (instead of on lane 0 alone): what it reads from
-// LDS goes through readfirstlane, so the compiler keeps the whole decoder state in scalar registers, its arithmetic on the scalar
-// unit and its branches scalar -- the vector unit, which the wavefronts of a SIMD share, is left with the LDS accesses.
+// UNI = the decoder's values are wave-uniform: what it reads from LDS goes through readfirstlane, so the compiler keeps the whole
+// decoder state in scalar registers, does its arithmetic on the scalar unit and branches with scalar branches.
 #if defined(__HIPCC__)
 #define INF_RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #else
-#define INF_RFL(x) (x)
+#define INF_RFL(x) ((uint32_t)(x))
 #endif
 #define INF_LD(x) (UNI ? INF_RFL(x) : (uint32_t)(x))
-MDK_HD uint32_t inf_funnel(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }      // low 32 bits of (hi:lo) >> sh, sh in 0..31
-MDK_HD uint32_t inf_peek(const InfDec &d) { return inf_funnel(d.hi, d.lo, d.sh); }
+MDK_HD uint32_t inf_peek(const InfDec &d) { return (uint32_t)d.bb; }
 template <bool UNI>
 MDK_HD void inf_consume(InfDec &d, const uint32_t *in, uint32_t n) {     // n <= 32
-    d.sh += n;
-    if(d.sh >= 32) { d.sh -= 32; d.lo = d.hi; d.hi = d.nx; d.nx = INF_LD(in[d.widx & (INF_IN_WORDS - 1)]); d.widx++; }
+    d.bb >>= n; d.cnt -= n;
+    if(d.cnt < 32) { d.bb |= (uint64_t)d.nx << d.cnt; d.cnt += 32; d.nx = INF_LD(in[d.widx & (INF_IN_WORDS - 1)]); d.widx++; }
 }
 template <bool UNI>
 MDK_HD uint32_t inf_get(InfDec &d, const uint32_t *in, uint32_t n) {     // n <= 16
@@ -100,11 +111,10 @@ MDK_HD uint32_t inf_get(InfDec &d, const uint32_t *in, uint32_t n) {     // n <=
 }
 // first use: the ring already holds the first words of the stream; `skip_bytes` = bytes of word 0 in front of the member's first byte
 MDK_HD void inf_dec_init(InfDec &d, const uint32_t *in, uint32_t skip_bytes, uint32_t out_len) {
-    d.lo = in[0]; d.hi = in[1]; d.nx = in[2]; d.widx = 3; d.sh = 8 * skip_bytes;
+    d.bb = (uint64_t)in[0] | ((uint64_t)in[1] << 32); d.cnt = 64; d.nx = in[2]; d.widx = 3;
     d.pos = 0; d.out_len = out_len; d.in_block = 0; d.last = 0; d.stored_left = 0;
+    inf_consume<false>(d, in, 8 * skip_bytes);
 }
-// stream words the decoder has taken from the ring so far (it holds up to three of them in registers)
-MDK_HD uint32_t inf_words_taken(const InfDec &d) { return d.widx; }
 
 MDK_HD uint32_t inf_rev(uint32_t code, int len) {          // the low `len` bits of code, reversed
     uint32_t r = 0;
@@ -112,27 +122,31 @@ MDK_HD uint32_t inf_rev(uint32_t code, int len) {          // the low `len` bits
     return r;
 }
 
+// entries of the three alphabets (without the code-bit count, which the builder adds)
 MDK_HD uint32_t inf_lit_entry(int sym) {
     const uint16_t LBASE[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
     const uint8_t LEXT[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
-    if(sym < 256) return ((uint32_t)sym << 16) | INF_K_LIT;
-    if(sym == 256) return INF_K_EOB;
-    if(sym < 286) return ((uint32_t)LBASE[sym - 257] << 16) | ((uint32_t)LEXT[sym - 257] << 8) | INF_K_LEN;
-    return INF_K_BAD;
+    if(sym < 256) return INF_L_LIT | ((uint32_t)sym << 4);
+    if(sym == 256) return INF_L_EOB;
+    if(sym < 286) return INF_L_LEN | ((uint32_t)LEXT[sym - 257] << 12) | ((uint32_t)(LBASE[sym - 257] - 3) << 4);
+    return INF_L_BAD;
 }
 MDK_HD uint32_t inf_dist_entry(int sym) {
     const uint16_t DBASE[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
     const uint8_t DEXT[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
-    if(sym < 30) return ((uint32_t)DBASE[sym] << 16) | ((uint32_t)DEXT[sym] << 8) | INF_K_LEN;
-    return INF_K_BAD;
+    if(sym < 30) return ((uint32_t)DBASE[sym] << 16) | ((uint32_t)DEXT[sym] << 8) | INF_D_SYM;
+    return INF_D_BAD;
 }
 
 // Canonical Huffman code of `n` symbols with lengths lens[] (0 = unused, <= 15) -> two-level decode table.
-// kind 0: literal/length alphabet, 1: distance alphabet, 2: code-length alphabet (entries: value = symbol, kind LIT).
-// An over-subscribed set of lengths is an error; an incomplete one leaves BAD entries (legal for a distance code with a single
-// symbol, RFC 1951 3.2.7; zlib-made streams are otherwise complete, and a BAD entry is reported when the stream reaches it).
-MDK_HDN int inf_build(const uint8_t *lens, int n, int tb, uint32_t *tab, int cap, int kind, uint16_t *sorted /* [n] scratch */) {
+// kind 0: literal/length alphabet (T = inf_lit_t), 1: distance alphabet, 2: code-length alphabet (both T = inf_dist_t).
+// An over-subscribed set of lengths is an error; an incomplete one leaves unassigned entries (legal for a distance code with a
+// single symbol, RFC 1951 3.2.7; zlib-made streams are otherwise complete, and an unassigned entry is reported when the stream
+// reaches it).
+template <typename T>
+MDK_HD int inf_build_t(const uint8_t *lens, int n, int tb, T *tab, int cap, int kind, uint16_t *sorted /* [n] scratch */) {
     uint16_t count[16], offs[16];
+    const uint32_t bad = kind == 0 ? INF_L_BAD : INF_D_BAD;
     for(int l = 0; l < 16; l++) count[l] = 0;
     for(int i = 0; i < n; i++) count[lens[i]]++;
     count[0] = 0;
@@ -143,26 +157,25 @@ MDK_HDN int inf_build(const uint8_t *lens, int n, int tb, uint32_t *tab, int cap
     int total = 0;
     for(int i = 0; i < n; i++) if(lens[i]) { sorted[offs[lens[i]]++] = (uint16_t)i; total++; }
     const int root = 1 << tb;
-    for(int i = 0; i < root; i++) tab[i] = INF_K_BAD;
+    for(int i = 0; i < root; i++) tab[i] = (T)bad;
     int next_free = root;
     uint32_t code = 0; int idx = 0;
     int sub_prefix = -1, sub_start = 0, sub_bits = 0;
     for(int l = 1; l <= 15; l++) {
         for(int k = 0; k < count[l]; k++, idx++, code++) {
             const int sym = sorted[idx];
-            uint32_t e = kind == 0 ? inf_lit_entry(sym) : kind == 1 ? inf_dist_entry(sym) : (((uint32_t)sym << 16) | INF_K_LIT);
+            uint32_t e = kind == 0 ? inf_lit_entry(sym) : kind == 1 ? inf_dist_entry(sym) : (((uint32_t)sym << 16) | INF_D_SYM);
             const uint32_t rev = inf_rev(code, l);
             if(l <= tb) {
                 e |= (uint32_t)l;
-                for(uint32_t j = rev; j < (uint32_t)root; j += 1u << l) tab[j] = e;
+                for(uint32_t j = rev; j < (uint32_t)root; j += 1u << l) tab[j] = (T)e;
             } else {
                 const int prefix = (int)(rev & (uint32_t)(root - 1));
                 if(prefix != sub_prefix) {
                     // the codes sharing these first tb bits are the next ones in canonical order, lengths ascending: the last of them sizes the sub-table
                     int maxl = l; uint32_t c2 = code; int l2 = l, k2 = k, i2 = idx;
                     for(;;) {
-                        // advance (c2, l2) to the next code in canonical order
-                        i2++; k2++; c2++;
+                        i2++; k2++; c2++;                                     // (c2, l2) -> the next code in canonical order
                         while(l2 <= 15 && k2 >= count[l2]) { l2++; k2 = 0; c2 <<= 1; }
                         if(l2 > 15 || i2 >= total) break;
                         if((int)(inf_rev(c2, l2) & (uint32_t)(root - 1)) != prefix) break;
@@ -171,17 +184,20 @@ MDK_HDN int inf_build(const uint8_t *lens, int n, int tb, uint32_t *tab, int cap
                     sub_prefix = prefix; sub_bits = maxl - tb; sub_start = next_free;
                     if(sub_start + (1 << sub_bits) > cap) return -2;
                     next_free += 1 << sub_bits;
-                    for(int j = 0; j < (1 << sub_bits); j++) tab[sub_start + j] = INF_K_BAD;
-                    tab[prefix] = ((uint32_t)sub_start << 16) | INF_K_SUB | ((uint32_t)sub_bits << 8) | (uint32_t)tb;
+                    for(int j = 0; j < (1 << sub_bits); j++) tab[sub_start + j] = (T)bad;
+                    tab[prefix] = kind == 0 ? (T)(INF_L_SUB | ((uint32_t)(sub_start - root) << 4) | (uint32_t)sub_bits)
+                                            : (T)(((uint32_t)sub_start << 16) | INF_D_SUB | (uint32_t)sub_bits);
                 }
                 e |= (uint32_t)(l - tb);
-                for(uint32_t j = rev >> tb; j < (1u << sub_bits); j += 1u << (l - tb)) tab[sub_start + j] = e;
+                for(uint32_t j = rev >> tb; j < (1u << sub_bits); j += 1u << (l - tb)) tab[sub_start + j] = (T)e;
             }
         }
         code <<= 1;
     }
     return 0;
 }
+MDK_HDN int inf_build_lit(const uint8_t *lens, int n, inf_lit_t *tab, uint16_t *sorted) { return inf_build_t<inf_lit_t>(lens, n, INF_LIT_TB, tab, INF_LIT_CAP, 0, sorted); }
+MDK_HDN int inf_build_dist(const uint8_t *lens, int n, int tb, inf_dist_t *tab, int kind, uint16_t *sorted) { return inf_build_t<inf_dist_t>(lens, n, tb, tab, INF_DIST_CAP, kind, sorted); }
 
 // Block header (RFC 1951 3.2.3-3.2.7); for a dynamic block also the code lengths and both tables.  The ring must hold the
 // whole header (a dynamic header is at most 14 + 19*3 + 316*14 bits < 160 words).
@@ -192,7 +208,7 @@ MDK_HD int inf_block_header_body(InfDec &d, InfShared &S) {
     const uint32_t type = inf_get<false>(d, S.in, 2);
     if(type == 3) return INF_E_BTYPE;
     if(type == 0) {
-        inf_consume<false>(d, S.in, (8 - (d.sh & 7)) & 7);            // to the next byte boundary of the stream (sh counts bits of a 4-byte-aligned word)
+        inf_consume<false>(d, S.in, d.cnt & 7);                  // to the next byte boundary: every word put into bb was whole bytes, so the bits still in bb tell
         const uint32_t len = inf_get<false>(d, S.in, 16), nlen = inf_get<false>(d, S.in, 16);
         if((len ^ 0xffffu) != nlen) return INF_E_STORED;
         d.stored_left = len; d.in_block = 2;
@@ -203,9 +219,9 @@ MDK_HD int inf_block_header_body(InfDec &d, InfShared &S) {
         for(int k = 144; k < 256; k++) lens[k] = 9;
         for(int k = 256; k < 280; k++) lens[k] = 7;
         for(int k = 280; k < 288; k++) lens[k] = 8;
-        if(inf_build(lens, 288, INF_LIT_TB, S.lit, INF_LIT_CAP, 0, sorted)) return INF_E_LITTABLE;
+        if(inf_build_lit(lens, 288, S.lit, sorted)) return INF_E_LITTABLE;
         for(int k = 0; k < 30; k++) lens[k] = 5;
-        if(inf_build(lens, 30, INF_DIST_TB, S.dist, INF_DIST_CAP, 1, sorted)) return INF_E_DISTTABLE;
+        if(inf_build_dist(lens, 30, INF_DIST_TB, S.dist, 1, sorted)) return INF_E_DISTTABLE;
         d.in_block = 1;
         return INF_OK;
     }
@@ -214,11 +230,11 @@ MDK_HD int inf_block_header_body(InfDec &d, InfShared &S) {
     for(int k = 0; k < 19; k++) lens[k] = 0;
     for(int k = 0; k < ncode; k++) lens[CLORD[k]] = (uint8_t)inf_get<false>(d, S.in, 3);
     // the code-length code (<= 7 bits) is decoded through the distance table's memory, which is rebuilt afterwards
-    if(inf_build(lens, 19, 7, S.dist, INF_DIST_CAP, 2, sorted)) return INF_E_CODELEN;
+    if(inf_build_dist(lens, 19, 7, S.dist, 2, sorted)) return INF_E_CODELEN;
     int idx = 0; const int want = nlit + ndist;
     while(idx < want) {
         const uint32_t e = S.dist[inf_peek(d) & 127u];
-        if(INF_KIND(e) != INF_K_LIT) return INF_E_CODELEN;
+        if(INF_D_KIND(e) != INF_D_SYM) return INF_E_CODELEN;
         inf_consume<false>(d, S.in, e & 15u);
         const int sym = (int)(e >> 16);
         if(sym < 16) lens[idx++] = (uint8_t)sym;
@@ -232,12 +248,11 @@ MDK_HD int inf_block_header_body(InfDec &d, InfShared &S) {
         }
     }
     if(lens[256] == 0) return INF_E_LITTABLE;                  // a block without an end-of-block code never ends
-    if(inf_build(lens + nlit, ndist, INF_DIST_TB, S.dist, INF_DIST_CAP, 1, sorted)) return INF_E_DISTTABLE;
-    if(inf_build(lens, nlit, INF_LIT_TB, S.lit, INF_LIT_CAP, 0, sorted)) return INF_E_LITTABLE;
+    if(inf_build_dist(lens + nlit, ndist, INF_DIST_TB, S.dist, 1, sorted)) return INF_E_DISTTABLE;
+    if(inf_build_lit(lens, nlit, S.lit, sorted)) return INF_E_LITTABLE;
     d.in_block = 1;
     return INF_OK;
 }
-
 // ... out of line, the state in and out BY VALUE: a decoder state whose address an out-of-line call had taken would live in
 // private memory, and the compiler treats whatever is loaded from there as divergent (no scalar registers, no scalar branches).
 struct InfHdr { InfDec d; int err; };
@@ -246,74 +261,65 @@ MDK_HDN InfHdr inf_block_header(const InfDec d_in, InfShared &S) {
     return H;
 }
 
-// One batch: symbols are decoded until INF_BATCH_SYMS of them, INF_BATCH_BYTES of output, the end of the stream or an error.
-// Literals go straight into the window ring; matches become tokens (their bytes are produced by the whole wavefront
-// afterwards).  Leaves the batch description in S (n_tok, batch_beg, batch_end, words_used, finished, err).
-// UNI = false: called by the decoding lane alone.  UNI = true: called by every lane with identical state (see INF_RFL);
-// `lead` is true on the one lane that performs the stores, and a block header -- rare, branchy, with private arrays -- is
-// still parsed by that lane alone and the state handed round afterwards (`bcast`).
-template <bool UNI, typename Bcast>
-MDK_HD void inf_decode_batch(InfDec &d, InfShared &S, bool lead, Bcast bcast) {
-    const uint32_t beg = d.pos, lim = beg + (INF_BATCH_BYTES - 258); uint32_t pos = beg, nsym = 0, ntok = 0, err = INF_OK, finished = 0;
+// One batch: a block header, or symbols until INF_BATCH_BYTES of output, INF_MAX_TOK matches, INF_BATCH_WORDS of input, the end
+// of the block or an error.  Literals go straight into the window ring; matches become tokens (their bytes are produced by the
+// whole wavefront afterwards).  Leaves the batch description in S (n_tok, batch_beg, batch_end, words_used, finished, err).
+// Bounds against the member's size are checked once per batch: a batch only writes the LDS window and only reads global memory
+// behind `pos`.
+template <bool UNI>
+MDK_HD void inf_decode_batch(InfDec &d, InfShared &S) {
+    const uint32_t beg = d.pos; uint32_t pos = beg, ntok = 0, err = INF_OK, finished = 0;
     if(d.in_block == 0) {                                     // a block header is a batch of its own: the ring is full enough for all of it then
-        if(lead) { const InfHdr H = inf_block_header(d, S); d = H.d; err = (uint32_t)H.err; }
-        if(UNI) { bcast(d); err = bcast.word(err); }
-    } else if(d.in_block == 2) {                              // stored block: bytes through the bit reader, one symbol each
-        while(nsym < INF_BATCH_SYMS && d.stored_left) {
-            const uint32_t v = inf_get<UNI>(d, S.in, 8);
-            if(lead) S.win[pos & (INF_WIN - 1)] = (uint8_t)v;
-            pos++; d.stored_left--; nsym++;
-        }
+        const InfHdr H = inf_block_header(d, S); d = H.d; err = (uint32_t)H.err;
+    } else if(d.in_block == 2) {                              // stored block: bytes through the bit reader
+        uint32_t k = 0;
+        while(k < 64 && d.stored_left) { S.win[pos & (INF_WIN - 1)] = (uint8_t)inf_get<UNI>(d, S.in, 8); pos++; d.stored_left--; k++; }
         if(d.stored_left == 0) { d.in_block = 0; finished = d.last; }
     } else {
-        // the fast loop: Huffman symbols until the batch is full, the block ends or something is wrong.  Bounds against the
-        // member's size are checked once per batch (a batch only writes the LDS window, and reads global memory behind `pos`).
-        uint32_t lo = d.lo, hi = d.hi, nx = d.nx, sh = d.sh, widx = d.widx;
-#define INF_TAKE(n) do { sh += (n); if(sh >= 32) { sh -= 32; lo = hi; hi = nx; nx = INF_LD(S.in[widx & (INF_IN_WORDS - 1)]); widx++; } } while(0)
+        // the fast loop; one exit, through `stop`
+        uint64_t bb = d.bb; uint32_t cnt = d.cnt, nx = d.nx, widx = d.widx, stop = 0;
+        const uint32_t lim = beg + (INF_BATCH_BYTES - 258), wlim = widx + INF_BATCH_WORDS;
+#define INF_TAKE(n) do { bb >>= (n); cnt -= (n); if(cnt < 32) { bb |= (uint64_t)nx << cnt; cnt += 32; nx = INF_LD(S.in[widx & (INF_IN_WORDS - 1)]); widx++; if(widx > wlim) stop |= 1u; } } while(0)
         do {
-            uint32_t x = inf_funnel(hi, lo, sh), used = 0;
+            uint32_t x = (uint32_t)bb, used = 0;
             uint32_t e = INF_LD(S.lit[x & ((1u << INF_LIT_TB) - 1u)]);
-            if(e & INF_F_SPEC) {
-                if(INF_KIND(e) == INF_K_SUB) { x >>= INF_LIT_TB; used = INF_LIT_TB; e = INF_LD(S.lit[(e >> 16) + (x & ((1u << ((e >> 8) & 31u)) - 1u))]); }
-                if(e & INF_F_SPEC) {
-                    if(INF_KIND(e) == INF_K_EOB) { INF_TAKE(used + (e & 15u)); d.in_block = 0; finished = d.last; }
-                    else err = INF_E_SYMBOL;
-                    break;
+            if((e & (INF_L_LEN | 0x6000u)) == INF_L_SUB) {    // a code longer than the root table
+                x >>= INF_LIT_TB; used = INF_LIT_TB;
+                e = INF_LD(S.lit[(1u << INF_LIT_TB) + ((e >> 4) & 511u) + (x & ((1u << (e & 15u)) - 1u))]);
+            }
+            const uint32_t nb = e & 15u;
+            if(e & INF_L_LEN) {
+                const uint32_t eb = (e >> 12) & 7u, len = ((e >> 4) & 255u) + 3u + ((x >> nb) & ((1u << eb) - 1u));
+                INF_TAKE(used + nb + eb);
+                uint32_t y = (uint32_t)bb, used2 = 0;
+                uint32_t f = INF_LD(S.dist[y & ((1u << INF_DIST_TB) - 1u)]);
+                if(INF_D_KIND(f) == INF_D_SUB) { y >>= INF_DIST_TB; used2 = INF_DIST_TB; f = INF_LD(S.dist[(f >> 16) + (y & ((1u << (f & 15u)) - 1u))]); }
+                const uint32_t nb2 = f & 15u, eb2 = (f >> 8) & 15u, dist = (f >> 16) + ((y >> nb2) & ((1u << eb2) - 1u));
+                INF_TAKE(used2 + nb2 + eb2);
+                if(INF_D_KIND(f) != INF_D_SYM || dist > pos) { err = INF_E_DIST; stop |= 2u; }
+                else {
+                    InfToken t; t.dst = pos; t.len_dist = len | (dist << 16); S.tok[ntok] = t;
+                    ntok++; pos += len;
+                    if(ntok == INF_MAX_TOK) stop |= 1u;
                 }
-            }
-            nsym++;
-            if(e & INF_F_LIT) {
-                INF_TAKE(used + (e & 15u));
-                if(lead) S.win[pos & (INF_WIN - 1)] = (uint8_t)(e >> 16);
+            } else if(INF_L_KIND(e) == INF_L_LIT) {
+                INF_TAKE(used + nb);
+                S.win[pos & (INF_WIN - 1)] = (uint8_t)(e >> 4);
                 pos++;
-                continue;
+            } else {
+                if(INF_L_KIND(e) == INF_L_EOB) { INF_TAKE(used + nb); d.in_block = 0; finished = d.last; } else err = INF_E_SYMBOL;
+                stop |= 2u;
             }
-            const uint32_t nb = e & 15u, eb = (e >> 8) & 31u;
-            const uint32_t len = (e >> 16) + ((x >> nb) & ((1u << eb) - 1u));
-            INF_TAKE(used + nb + eb);
-            uint32_t y = inf_funnel(hi, lo, sh), used2 = 0;
-            uint32_t f = INF_LD(S.dist[y & ((1u << INF_DIST_TB) - 1u)]);
-            if(f & INF_F_SPEC) {
-                if(INF_KIND(f) == INF_K_SUB) { y >>= INF_DIST_TB; used2 = INF_DIST_TB; f = INF_LD(S.dist[(f >> 16) + (y & ((1u << ((f >> 8) & 31u)) - 1u))]); }
-                if(f & INF_F_SPEC) { err = INF_E_DIST; break; }
-            }
-            const uint32_t nb2 = f & 15u, eb2 = (f >> 8) & 31u;
-            const uint32_t dist = (f >> 16) + ((y >> nb2) & ((1u << eb2) - 1u));
-            INF_TAKE(used2 + nb2 + eb2);
-            if(dist > pos) { err = INF_E_DIST; break; }
-            if(lead) { InfToken t; t.dst = pos; t.len_dist = len | (dist << 16); S.tok[ntok] = t; }
-            ntok++;
-            pos += len;
-        } while(nsym < INF_BATCH_SYMS && pos <= lim);
+            if(pos > lim) stop |= 1u;
+        } while(!stop);
 #undef INF_TAKE
-        d.lo = lo; d.hi = hi; d.nx = nx; d.sh = sh; d.widx = widx;
+        d.bb = bb; d.cnt = cnt; d.nx = nx; d.widx = widx;
     }
     d.pos = pos;
     if(!err && pos > d.out_len) err = INF_E_OVERRUN;
     if(!err && finished && pos != d.out_len) err = INF_E_SHORT;
-    if(lead) { S.n_tok = ntok; S.batch_beg = beg; S.batch_end = pos; S.words_used = inf_words_taken(d); S.finished = finished; S.err = err; }
+    S.n_tok = ntok; S.batch_beg = beg; S.batch_end = pos; S.words_used = d.widx; S.finished = finished; S.err = err;
 }
-struct InfNoBcast { MDK_HDM void operator()(InfDec &) const {} MDK_HDM uint32_t word(uint32_t v) const { return v; } };
 
 // ---- the parts every lane runs (bodies only; the barriers between them are the caller's) ----
 // A token is NEAR when its whole source lies in the window ring as it will be at the end of this batch, FAR when the source

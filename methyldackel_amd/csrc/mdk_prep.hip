@@ -451,9 +451,49 @@ __global__ __launch_bounds__(PB) void k_perread_raw(const PrepParams P, const ui
     out[a] = perread_walk(seq, qual, r.lq, (int)r.ncig, r.pos, r.strand & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg](int k) { return ld32(cg + 4 * k); });
 }
 
+// record offsets of a device-resident range (offsets in the piece it was inflated in) -> offsets in the chunk's concatenation
+__global__ __launch_bounds__(256) void k_rebase(uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t add) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if(i < n) dst[i] = src[i] + add;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// the H2D (host ranges) or D2D (ranges of a piece inflated on the device) copies of a chunk's records and of its record table
+static int copy_ranges(md_dev *h, Slot *s, const md_raw_batch *b) {
+    bool any_dev = false; uint64_t nrec_sum = 0;
+    for(int i = 0; i < b->n_ranges; i++) { if(b->range[i].d_rec_off) any_dev = true; nrec_sum += b->range[i].n_records; }
+    if(any_dev && nrec_sum != (uint64_t)b->n_records) return fail(MDK_ERR_ARG, "md_dev_upload_raw: with a device-resident range every range must carry its record count", hipSuccess);
+    uint64_t o = 0; uint32_t idx = 0, hidx = 0;
+    for(int i = 0; i < b->n_ranges; i++) {
+        const md_raw_range &r = b->range[i];
+        if(r.d_rec_off) {
+            if(r.bytes) HIPCHK(hipMemcpyAsync(s->d_raw.p + o, r.ptr, (size_t)r.bytes, hipMemcpyDeviceToDevice, s->stream));
+            if(r.n_records) hipLaunchKernelGGL(k_rebase, dim3((r.n_records + 255) / 256), dim3(256), 0, s->stream, s->d_recoff.p + idx, r.d_rec_off, r.n_records, (uint32_t)o - r.rec_delta);
+        } else {
+            if(r.bytes) { host_block_ensure_registered(r.ptr); HIPCHK(hipMemcpyAsync(s->d_raw.p + o, r.ptr, (size_t)r.bytes, hipMemcpyHostToDevice, s->stream)); }
+            if(any_dev && r.n_records) HIPCHK(hipMemcpyAsync(s->d_recoff.p + idx, b->rec_off + hidx, sizeof(uint32_t) * (size_t)r.n_records, hipMemcpyHostToDevice, s->stream));
+            hidx += r.n_records;
+        }
+        idx += r.n_records; o += r.bytes;
+    }
+    if(!any_dev && b->n_records) { host_block_ensure_registered(b->rec_off); HIPCHK(hipMemcpyAsync(s->d_recoff.p, b->rec_off, sizeof(uint32_t) * (size_t)b->n_records, hipMemcpyHostToDevice, s->stream)); }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+extern "C" int md_dev_read_raw(md_dev *h, int slot, uint8_t *bytes, uint64_t *n_bytes, uint32_t *rec_off, uint32_t *n_records) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !s->raw_layout || !bytes || !n_bytes || !rec_off || !n_records) return fail(MDK_ERR_ARG, "md_dev_read_raw: needs a slot uploaded with md_dev_upload_raw", hipSuccess);
+    if(*n_bytes < s->raw_bytes || *n_records < (uint32_t)s->pr_nrec) { *n_bytes = s->raw_bytes; *n_records = (uint32_t)s->pr_nrec; return fail(MDK_ERR_ARG, "md_dev_read_raw: buffers too small", hipSuccess); }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if(s->raw_bytes) HIPCHK(hipMemcpy(bytes, s->d_raw.p, (size_t)s->raw_bytes, hipMemcpyDeviceToHost));
+    if(s->pr_nrec) HIPCHK(hipMemcpy(rec_off, s->d_recoff.p, sizeof(uint32_t) * (size_t)s->pr_nrec, hipMemcpyDeviceToHost));
+    *n_bytes = s->raw_bytes; *n_records = (uint32_t)s->pr_nrec;
+    return 0;
+}
+
 extern "C" int md_dev_set_prep(md_dev *h, const md_prep_cfg *cfg) {
     if(!h || !cfg) return fail(MDK_ERR_ARG, "md_dev_set_prep", hipSuccess);
     h->prep = *cfg; h->prep_set = true;
@@ -541,12 +581,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
         if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
         if(h->variant && s->d_var.need((size_t)span + 16)) return MDK_ERR_NOMEM;
     }
-    uint64_t o = 0;
-    for(int i = 0; i < b->n_ranges; i++) {
-        if(b->range[i].bytes) HIPCHK(hipMemcpyAsync(s->d_raw.p + o, b->range[i].ptr, (size_t)b->range[i].bytes, hipMemcpyHostToDevice, s->stream));
-        o += b->range[i].bytes;
-    }
-    if(n) HIPCHK(hipMemcpyAsync(s->d_recoff.p, b->rec_off, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
     int rc = enqueue_prep(h, s); if(rc) return rc;
     s->uploaded = true;
     return 0;
@@ -574,9 +609,7 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true;
     if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prec.need(nn) || s->d_hash.need(nn) || s->d_blk.need(4 * (size_t)(nb + 1)) || s->d_prd.need(nn) ||
        s->d_mate.need(nn) || s->d_second.need(nn) || s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
-    uint64_t o = 0;
-    for(int i = 0; i < b->n_ranges; i++) { if(b->range[i].bytes) HIPCHK(hipMemcpyAsync(s->d_raw.p + o, b->range[i].ptr, (size_t)b->range[i].bytes, hipMemcpyHostToDevice, s->stream)); o += b->range[i].bytes; }
-    if(n) HIPCHK(hipMemcpyAsync(s->d_recoff.p, b->rec_off, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s->stream));
+    { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
     PrepParams P; memset(&P, 0, sizeof(P));
     P.raw = s->d_raw.p; P.raw_bytes = total; P.rec_off = s->d_recoff.p; P.n_rec = n; P.cfg = h->prep; P.tid = b->tid; P.beg = b->beg; P.end = b->end;
     P.ref = h->ref[b->tid]; P.reflen = h->reflen[b->tid];

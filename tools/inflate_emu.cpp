@@ -27,7 +27,7 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
     uint32_t taken = 3;
     for(;;) {
         while(filled + 64 <= taken + INF_IN_WORDS) { for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); } filled += 64; }
-        inf_decode_batch<false>(d, S, true, InfNoBcast());
+        inf_decode_batch<false>(d, S);
         (*n_batches)++;
         const uint32_t n_tok = S.n_tok, beg = S.batch_beg, end = S.batch_end, err = S.err, fin = S.finished;
         taken = S.words_used;
