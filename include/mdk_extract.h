@@ -68,6 +68,13 @@ int  mdk_plan_set_prep(mdk_plan *p, int mode);
 int  mdk_plan_set_hold(mdk_plan *p, int n);
 void mdk_plan_prep_cfg(const mdk_plan *p, md_prep_cfg *cfg);
 int  mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c);
+/* the same when the chunk was uploaded to `slot` of `dev` and some of its records were inflated on the device (they are read back) */
+int  mdk_plan_host_prepare_from(mdk_plan *p, mdk_chunk *c, md_dev *dev, int slot);
+/* BGZF inflate of the plan's BAM on this device as well (include/mdk_hip.h md_piece_*): from now on pieces of the
+ * file are inflated by whoever is free, a host inflate team or the device, and chunks may name device-resident ranges.  Only for
+ * plans in device-preparation mode of the `extract` command; mdk_plan_detach_device must precede md_dev_close. */
+int  mdk_plan_attach_device(mdk_plan *p, md_dev *dev);
+void mdk_plan_detach_device(mdk_plan *p);
 /* host post-pass for one chunk (variant filter, --mergeContext, formats; extract.c:443-510), appended to
  * the plan's output files.  Chunks must be emitted in index order. */
 int  mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *sites);

@@ -65,6 +65,20 @@ class md_raw_batch(C.Structure):
                 ("n_records", C.c_int32), ("rec_off", C.POINTER(C.c_uint32)), ("woff", C.c_int64), ("wlen", C.c_int64)]
 
 
+class md_inf_member(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("out_len", C.c_uint32), ("out_off", C.c_uint64)]
+
+
+class md_inf_digest(C.Structure):
+    _fields_ = [("n_rec", C.c_uint32), ("first_rec", C.c_uint32), ("tid0", C.c_int32), ("pos0", C.c_int32), ("tidN", C.c_int32), ("posN", C.c_int32),
+                ("min_endp", C.c_int32), ("max_endp", C.c_int32), ("ok", C.c_int32), ("sorted", C.c_int32)]
+
+
+class md_piece_info(C.Structure):
+    _fields_ = [("n_mem", C.c_int32), ("digest", C.POINTER(md_inf_digest)), ("n_records", C.c_uint32), ("out_bytes", C.c_uint64),
+                ("d_out", C.c_void_p), ("d_rec_off", C.c_void_p)]
+
+
 class md_region(C.Structure):
     _fields_ = [("start", C.c_int32), ("end", C.c_int32), ("strand", C.c_int32)]
 
@@ -130,10 +144,12 @@ HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned",
                "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep",
                "md_dev_mbias_submit", "md_dev_mbias_submit_raw", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
-               "md_dev_perread_submit", "md_dev_perread_download", "md_dev_perread_submit_raw", "md_dev_perread_download_raw"]
+               "md_dev_perread_submit", "md_dev_perread_download", "md_dev_perread_submit_raw", "md_dev_perread_download_raw", "md_dev_read_raw",
+               "md_piece_create", "md_piece_destroy", "md_piece_submit", "md_piece_wait", "md_piece_read", "md_piece_read_records", "md_piece_bench"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len", "mdk_plan_regions", "mdk_plan_set_prep", "mdk_plan_set_hold", "mdk_plan_prep_cfg", "mdk_plan_host_prepare",
+                   "mdk_plan_host_prepare_from", "mdk_plan_attach_device", "mdk_plan_detach_device",
                    "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report",
                    "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread", "mdk_plan_emit_perread_raw", "mergeContext_main", "mdk_bind_to_device_node"]
 
@@ -202,6 +218,14 @@ def lib_hip():
         L.md_dev_perread_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_pr_batch)]
         L.md_dev_perread_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(md_pr_count)), C.POINTER(C.c_int64)]
         L.md_dev_perread_submit_raw.argtypes = [C.c_void_p, C.c_int, C.POINTER(md_raw_batch)]
+        L.md_dev_read_raw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint32)]
+        L.md_piece_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.md_piece_destroy.argtypes = [C.c_void_p]; L.md_piece_destroy.restype = None
+        L.md_piece_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(md_inf_member), C.c_int32]
+        L.md_piece_wait.argtypes = [C.c_void_p, C.POINTER(md_piece_info)]
+        L.md_piece_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        L.md_piece_read_records.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.md_piece_bench.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.md_dev_perread_download_raw.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(md_pr_count)), C.POINTER(C.c_int64)]
         L.md_host_alloc.restype = C.c_void_p
         L.md_host_alloc.argtypes = [C.c_uint64]
@@ -244,6 +268,9 @@ def lib_extract():
         L.mdk_plan_set_prep.argtypes = [C.c_void_p, C.c_int]
         L.mdk_plan_prep_cfg.argtypes = [C.c_void_p, C.POINTER(md_prep_cfg)]; L.mdk_plan_prep_cfg.restype = None
         L.mdk_plan_host_prepare.argtypes = [C.c_void_p, C.POINTER(mdk_chunk)]
+        L.mdk_plan_host_prepare_from.argtypes = [C.c_void_p, C.POINTER(mdk_chunk), C.c_void_p, C.c_int]
+        L.mdk_plan_attach_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.mdk_plan_detach_device.argtypes = [C.c_void_p]; L.mdk_plan_detach_device.restype = None
         _ext = L
     return _ext
 
@@ -427,6 +454,23 @@ class Plan:
         self.L.mdk_plan_prep_cfg(self.p, C.byref(c))
         return c
 
+    def attach_device(self, dev: "Device"):
+        """BGZF inflate on the device too (include/mdk_extract.h mdk_plan_attach_device); detach_device before the device is closed"""
+        rc = self.L.mdk_plan_attach_device(self.p, dev.h)
+        if rc != 0:
+            raise MdkError(f"mdk_plan_attach_device rc={rc}")
+        self._attached = True
+
+    def detach_device(self):
+        if getattr(self, "_attached", False) and self.p:
+            self.L.mdk_plan_detach_device(self.p)
+            self._attached = False
+
+    def host_prepare_from(self, chunk: "mdk_chunk", dev: "Device", slot: int):
+        rc = self.L.mdk_plan_host_prepare_from(self.p, C.byref(chunk), dev.h, slot)
+        if rc != 0:
+            raise MdkError(f"mdk_plan_host_prepare_from rc={rc}")
+
     def host_prepare(self, chunk: "mdk_chunk"):
         rc = self.L.mdk_plan_host_prepare(self.p, C.byref(chunk))
         if rc:
@@ -474,6 +518,7 @@ class Plan:
 
     def close(self):
         if self.p:
+            self.detach_device()
             self.L.mdk_plan_close(self.p)
             self.p = C.c_void_p()
 

@@ -241,7 +241,7 @@ MDK_LOCAL void emitter_stop(emitter *E) {
 
 int mdk_plan_finish(mdk_plan *p) {
     int i;
-    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] inflate+frame+admit+pack %.3fs (inflate alone %.3fs)  pairing %.3fs  segments %.3fs  emit %.3fs; records found in the inflate threads' tables %" PRIu64 ", by walking %" PRIu64 "; reader: scanning %.3fs, waiting for a free slot %.3fs; workers busy %.3fs idle %.3fs (sum over %d)\n", p->t_collect, p->bam->t_inflate, p->t_pair, p->t_segs, p->t_emit, p->bam->n_fast, p->bam->n_slow, p->t_rfill, p->t_rwait, p->t_wbusy, p->t_widle, p->n_workers);
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] inflate+frame+admit+pack %.3fs (inflate alone %.3fs)  pairing %.3fs  segments %.3fs  emit %.3fs; records found in the inflate threads' tables %" PRIu64 ", by walking %" PRIu64 "; reader: scanning %.3fs, waiting for a free slot %.3fs; workers busy %.3fs idle %.3fs (sum over %d); pieces inflated by the host teams %" PRIu64 ", on the device %" PRIu64 " (of which read back: %" PRIu64 ")\n", p->t_collect, p->bam->t_inflate, p->t_pair, p->t_segs, p->t_emit, p->bam->n_fast, p->bam->n_slow, p->t_rfill, p->t_rwait, p->t_wbusy, p->t_widle, p->n_workers, p->bam->n_host_pieces, p->bam->n_dev_pieces, p->bam->n_materialized);
     if(p->n_variant_positions) printf("%" PRIu64 " positions were excluded due to likely being variants.\n", p->n_variant_positions);
     if(p->o.cytosine_report) { if(p->out[0]) fclose(p->out[0]); p->out[0] = p->out[1] = p->out[2] = NULL; }
     else for(i = 0; i < 3; i++) if(p->out[i]) { fclose(p->out[i]); p->out[i] = NULL; }

@@ -156,8 +156,8 @@ int extract_main(int argc, char *argv[]) {
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] resident at device ready %.0f MB\n", rss_mb(0));
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
-    if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
-    if(emitter_start(&em, p, emit_threads(p))) { md_dev_close(dev); mdk_plan_close(p); return -5; }
+    if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); mdk_plan_attach_device(p, dev); }      /* from here on the device inflates pieces of the file too */
+    if(emitter_start(&em, p, emit_threads(p))) { mdk_plan_detach_device(p); md_dev_close(dev); mdk_plan_close(p); return -5; }
     /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then hand k-1 to the emitter */
     while(more || have[0] || have[1]) {
         int cur = k & 1, prev = cur ^ 1;
@@ -184,7 +184,7 @@ int extract_main(int argc, char *argv[]) {
                 ta = now_s();
                 rc = md_dev_download(dev, prev, &sites);
                 if(rc == MDK_ERR_PREP_HOST) {          /* a read name the device preparation does not handle: this chunk the slow way */
-                    rc = mdk_plan_host_prepare(p, &ch[prev]);
+                    rc = mdk_plan_host_prepare_from(p, &ch[prev], dev, prev);
                     if(!rc) rc = md_dev_submit(dev, prev, &ch[prev].batch);
                     if(!rc) rc = md_dev_download(dev, prev, &sites);
                     n_host_prep++;
@@ -208,6 +208,7 @@ int extract_main(int argc, char *argv[]) {
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f (resident %.0f MB, of which file-backed/shared %.0f MB)\n", ts.tv_sec + 1e-9 * ts.tv_nsec, rss_mb(0), rss_mb(1)); }
     if(fast_exit_wanted()) leave_fast(ret);
     { double tc = now_s(), td;
+      mdk_plan_detach_device(p);
       md_dev_close(dev); td = now_s();
       mdk_plan_close(p);
       if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] device closed in %.3fs, plan (slabs, reference, mapped file) in %.3fs\n", td - tc, now_s() - td); }

@@ -12,7 +12,8 @@
 #include <sys/stat.h>
 static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
-#define CCHUNK (8u << 20)      /* compressed bytes inflated into one slab */
+#define CCHUNK (8u << 20)      /* compressed bytes a host team inflates into one slab */
+#define GCHUNK (64u << 20)     /* compressed bytes of a piece inflated on the device: ~3,400 members, one wavefront each */
 
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -98,7 +99,7 @@ static void *inflate_worker(void *arg) {
 }
 
 /* ---- slabs ---- */
-static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) {          /* inflater side: a free slab with room for need_cap bytes */
+static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, int force) {          /* a free slab with room for need_cap bytes; force: never wait for one to come back */
     mdk_slab *s = NULL;
     pthread_mutex_lock(&b->mu);
     while(!b->quit) {
@@ -106,7 +107,7 @@ static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) {          /* inflater si
         /* max_alloc only bounds how far the inflater runs AHEAD: when the scanner has nothing queued it may be collecting a
          * chunk that spans more slabs than the cap (huge --chunkSize, deep coverage) and every slab it holds stays pinned
          * until the chunk is complete, so waiting for one to come back would never end */
-        if(b->n_alloc < b->max_alloc || b->q_n == 0) { b->n_alloc++; s = calloc(1, sizeof(*s)); break; }
+        if(force || b->n_alloc < b->max_alloc || b->n_ready == 0) { b->n_alloc++; s = calloc(1, sizeof(*s)); break; }
         pthread_cond_wait(&b->cv_pool, &b->mu);
     }
     pthread_mutex_unlock(&b->mu);
@@ -117,12 +118,19 @@ static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) {          /* inflater si
     s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM; s->n_mem = 0; s->n_sum = 0;
     return s;
 }
+static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) { return slab_get_ex(b, need_cap, 0); }
 void mdk_slab_ref(mdk_bam *b, mdk_slab *s) { pthread_mutex_lock(&b->mu); s->refs++; pthread_mutex_unlock(&b->mu); }
 void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
     pthread_mutex_lock(&b->mu);
     if(--s->refs == 0) {
-        if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = xrealloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); }
-        b->pool[b->n_pool++] = s; pthread_cond_signal(&b->cv_pool);
+        if(s->piece) {
+            if(b->n_dpool == b->cap_dpool) { b->cap_dpool = b->cap_dpool ? b->cap_dpool * 2 : 8; b->dpool = xrealloc(b->dpool, sizeof(mdk_slab *) * b->cap_dpool); }
+            b->dpool[b->n_dpool++] = s;
+        } else {
+            if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = xrealloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); }
+            b->pool[b->n_pool++] = s;
+        }
+        pthread_cond_broadcast(&b->cv_pool);
     }
     pthread_mutex_unlock(&b->mu);
 }
@@ -132,18 +140,18 @@ typedef struct { uint8_t *cbuf; blk_t *blk; int nb; size_t total; uint64_t seq; 
 
 /* under io_mu: read CCHUNK more compressed bytes, list every complete member; the unfinished tail moves to a fresh window.
  * status: 0 a piece was produced, 1 end of file, <0 error */
-static int next_piece(mdk_bam *b, piece *pc) {
+static int next_piece(mdk_bam *b, piece *pc, size_t want) {
     size_t n, off = 0, total = 0; blk_t *blk = NULL; int nb = 0, mb = 0;
     memset(pc, 0, sizeof(*pc));
     if(b->map) {        /* mapped file: the window is a view, nothing is read or copied here */
         b->cbuf = (uint8_t *)b->map + b->map_pos; b->clen = b->map_len - b->map_pos;
-        if(b->clen > CCHUNK + (1u << 17)) b->clen = CCHUNK + (1u << 17); else b->file_eof = 1;
+        if(b->clen > want + (1u << 17)) b->clen = want + (1u << 17); else b->file_eof = 1;
     } else
     if(!b->file_eof) {
-        if(b->ccap < b->clen + CCHUNK) { b->ccap = b->clen + CCHUNK; b->cbuf = realloc(b->cbuf, b->ccap); if(!b->cbuf) return -1; }
-        n = fread(b->cbuf + b->clen, 1, CCHUNK, b->f);
+        if(b->ccap < b->clen + want) { b->ccap = b->clen + want; b->cbuf = realloc(b->cbuf, b->ccap); if(!b->cbuf) return -1; }
+        n = fread(b->cbuf + b->clen, 1, want, b->f);
         b->clen += n;
-        if(n < CCHUNK) b->file_eof = 1;
+        if(n < want) b->file_eof = 1;
     }
     while(off + 18 <= b->clen) {
         const uint8_t *p = b->cbuf + off; uint16_t xlen; uint32_t bsize = 0, isize; size_t x; int have = 0;
@@ -166,10 +174,10 @@ static int next_piece(mdk_bam *b, piece *pc) {
     }
     if(b->map) { b->map_pos += off; b->cbuf = NULL; b->clen = 0; if(b->map_pos < b->map_len) b->file_eof = 0; }
     else {   /* the piece keeps this window; the tail that belongs to the next member starts a new one */
-        size_t left = b->clen - off; uint8_t *nw = malloc(left + CCHUNK + 64);
+        size_t left = b->clen - off; uint8_t *nw = malloc(left + GCHUNK + 64);
         if(!nw) { free(blk); return -1; }
         memcpy(nw, b->cbuf + off, left);
-        pc->cbuf = b->cbuf; b->cbuf = nw; b->ccap = left + CCHUNK + 64; b->clen = left;
+        pc->cbuf = b->cbuf; b->cbuf = nw; b->ccap = left + GCHUNK + 64; b->clen = left;
     }
     pc->blk = blk; pc->nb = nb; pc->total = total;
     return 0;
@@ -206,7 +214,7 @@ static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status)
             if(s->sum && s->mem) {
                 for(i = 0; i < nb; i++) {
                     mdk_member *m = &s->mem[i];
-                    m->off = (uint32_t)(blk[i].out - s->buf); m->n_sum = blk[i].n_sum; m->sum0 = (uint32_t)o; m->ok = blk[i].ok && (blk[i].n_sum == 0 || job.sb[blk[i].th].v != NULL);
+                    m->off = (uint32_t)(blk[i].out - s->buf); m->len = blk[i].out_len; m->n_sum = blk[i].n_sum; m->sum0 = (uint32_t)o; m->ok = blk[i].ok && (blk[i].n_sum == 0 || job.sb[blk[i].th].v != NULL);
                     m->tid0 = blk[i].tid0; m->pos0 = blk[i].pos0; m->tidN = blk[i].tidN; m->posN = blk[i].posN; m->min_endp = blk[i].min_endp; m->max_endp = blk[i].max_endp; m->sorted = blk[i].sorted;
                     if(m->ok && m->n_sum) memcpy(s->sum + o, job.sb[blk[i].th].v + blk[i].sum0, sizeof(mdk_rsum) * m->n_sum);
                     if(m->ok) o += m->n_sum; else m->n_sum = 0;
@@ -220,82 +228,209 @@ static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status)
     return s;
 }
 
+/* ---- slabs inflated on the device ---- */
+static mdk_slab *dslab_get(mdk_bam *b) {          /* a free device slab (its piece keeps its device buffers from use to use) */
+    mdk_slab *s = NULL;
+    pthread_mutex_lock(&b->mu);
+    while(!b->quit) {
+        if(b->n_dpool) { s = b->dpool[--b->n_dpool]; break; }
+        if(b->n_dalloc < b->max_dalloc || b->n_ready == 0) { b->n_dalloc++; s = calloc(1, sizeof(*s)); break; }
+        pthread_cond_wait(&b->cv_pool, &b->mu);
+    }
+    pthread_mutex_unlock(&b->mu);
+    if(!s) return NULL;
+    if(!s->piece && md_piece_create(b->dev, &s->piece)) { free(s); return NULL; }
+    s->refs = 1; s->beg = s->end = 0; s->n_mem = 0; s->n_sum = 0;
+    return s;
+}
+/* one piece through the device: the compressed bytes are staged in registered memory, md_piece_submit/wait inflates them and frames
+ * the records; what comes back to the host is one digest per member */
+static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *status) {
+    blk_t *blk = pc->blk; const int nb = pc->nb; mdk_slab *s; md_inf_member *mt; md_piece_info info; int i; uint64_t o = 0;
+    const uint8_t *c0 = blk[0].in; const size_t span = (size_t)((blk[nb - 1].in + blk[nb - 1].in_len) - c0);
+    *status = 0;
+    s = dslab_get(b);
+    if(!s) { *status = b->quit ? 1 : -1; return NULL; }
+    if(b->gpu_stage_cap[team] < span + 64) { md_host_free(b->gpu_stage[team]); b->gpu_stage_cap[team] = span + (span >> 3) + (1u << 20); b->gpu_stage[team] = md_host_alloc(b->gpu_stage_cap[team]); if(!b->gpu_stage[team]) { b->gpu_stage_cap[team] = 0; mdk_slab_unref(b, s); *status = -1; return NULL; } }
+    memcpy(b->gpu_stage[team], c0, span);
+    mt = malloc(sizeof(*mt) * (size_t)nb);
+    if(!mt) { mdk_slab_unref(b, s); *status = -1; return NULL; }
+    for(i = 0; i < nb; i++) { mt[i].in_off = (uint64_t)(blk[i].in - c0); mt[i].in_len = blk[i].in_len; mt[i].out_len = blk[i].out_len; mt[i].out_off = o; o += blk[i].out_len; }
+    if(md_piece_submit(s->piece, b->gpu_stage[team], span, mt, nb) || md_piece_wait(s->piece, &info)) {
+        pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu);
+        free(mt); mdk_slab_unref(b, s); *status = -2; return NULL;
+    }
+    if(s->cap_mem < nb) { free(s->mem); s->cap_mem = nb + 64; s->mem = malloc(sizeof(mdk_member) * (size_t)s->cap_mem); }
+    if(!s->mem) { s->cap_mem = 0; free(mt); mdk_slab_unref(b, s); *status = -1; return NULL; }
+    for(i = 0; i < nb; i++) {
+        mdk_member *m = &s->mem[i]; const md_inf_digest *g = &info.digest[i];
+        m->off = (uint32_t)mt[i].out_off; m->len = mt[i].out_len; m->n_sum = g->n_rec; m->sum0 = g->first_rec; m->ok = g->ok;
+        m->tid0 = g->tid0; m->pos0 = g->pos0; m->tidN = g->tidN; m->posN = g->posN; m->min_endp = g->min_endp; m->max_endp = g->max_endp; m->sorted = g->sorted;
+    }
+    s->n_mem = nb; s->d_buf = info.d_out; s->d_rec_off = info.d_rec_off; s->d_bytes = info.out_bytes; s->d_records = info.n_records; s->beg = 0; s->end = (size_t)info.out_bytes;
+    free(mt);
+    return s;
+}
+/* a device slab the scanner cannot take member by member (a record straddles two members, or the slab before it ended inside a
+ * record): its bytes come back to the host and it is walked like a slab a host team inflated */
+static mdk_slab *slab_materialize(mdk_bam *b, mdk_slab *d) {
+    mdk_slab *s = slab_get_ex(b, MDK_SLAB_HEADROOM + (size_t)d->d_bytes + 64, 1); int i;      /* the scanner itself is asking: it must not wait for slabs only it can release */
+    if(!s) return NULL;
+    s->end = s->beg + (size_t)d->d_bytes;
+    if(md_piece_read(d->piece, 0, d->d_bytes, s->buf + s->beg)) { pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, s); return NULL; }
+    if(s->cap_mem < d->n_mem) { free(s->mem); s->cap_mem = d->n_mem + 64; s->mem = malloc(sizeof(mdk_member) * (size_t)s->cap_mem); if(!s->mem) { s->cap_mem = 0; mdk_slab_unref(b, s); return NULL; } }
+    for(i = 0; i < d->n_mem; i++) { s->mem[i] = d->mem[i]; s->mem[i].off += (uint32_t)s->beg; s->mem[i].ok = 0; s->mem[i].n_sum = 0; }      /* no summaries: record by record */
+    s->n_mem = d->n_mem; s->n_sum = 0;
+    b->n_materialized++;
+    return s;
+}
+
+/* a finished slab (or the news that there will be no more) goes to the scanner; slabs are taken in piece order */
+static int deliver(mdk_bam *b, mdk_slab *s, uint64_t seq) {
+    pthread_mutex_lock(&b->mu);
+    while(seq >= b->pop_seq + MDK_READY && !b->quit) pthread_cond_wait(&b->cv_pool, &b->mu);
+    if(b->quit) { pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, s); return -1; }
+    b->ready[seq % MDK_READY] = s; b->n_ready++;
+    if(s->piece) b->n_dev_pieces++; else b->n_host_pieces++;
+    pthread_cond_broadcast(&b->cv_q);
+    pthread_mutex_unlock(&b->mu);
+    return 0;
+}
+typedef struct { mdk_bam *b; int gpu_team; } team_arg;        /* gpu_team < 0: a host team */
 static void *inflater_main(void *arg) {
-    mdk_bam *b = arg;
+    team_arg *ta = arg; mdk_bam *b = ta->b; const int gt = ta->gpu_team;
     for(;;) {
         piece pc; int st; mdk_slab *s = NULL;
         pthread_mutex_lock(&b->io_mu);
         if(b->io_status) { pthread_mutex_unlock(&b->io_mu); break; }              /* another team has seen the end (or an error) */
-        st = next_piece(b, &pc);
+        st = next_piece(b, &pc, gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK);
         if(st == 0) pc.seq = b->next_seq++; else b->io_status = st;
         pthread_mutex_unlock(&b->io_mu);
-        if(st == 0) { s = inflate_piece(b, &pc, b->team_threads, &st); free(pc.cbuf); free(pc.blk); }
-        pthread_mutex_lock(&b->mu);
+        if(st == 0) { s = gt >= 0 ? inflate_piece_device(b, &pc, gt, &st) : inflate_piece(b, &pc, b->team_threads, &st); free(pc.cbuf); free(pc.blk); }
         if(s) {
-            while(b->push_seq != pc.seq && !b->quit) pthread_cond_wait(&b->cv_turn, &b->mu);
-            while(b->q_n == (int)(sizeof(b->queue) / sizeof(b->queue[0])) && !b->quit) pthread_cond_wait(&b->cv_pool, &b->mu);
-            if(b->quit) { pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, s); break; }
-            b->queue[b->q_n++] = s; b->push_seq++;
-            pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_turn);
-            pthread_mutex_unlock(&b->mu);
+            if(deliver(b, s, pc.seq)) break;
+            /* test hook (MDK_DEVICE_INFLATE_ONLY=1, `extract` only): the host teams leave after the piece that holds the BAM header, so that
+             * every other piece is inflated on the device however small the file is */
+            if(gt < 0 && b->host_leaves && b->header_done) break;
             continue;
         }
-        /* end of file or an error: report it once everything handed out before has been queued */
-        if(st < 0) { if(!b->inf_done || b->inf_done == 1) b->inf_done = st; pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_turn); pthread_mutex_unlock(&b->mu); break; }
-        while(b->push_seq != b->next_seq && !b->quit && b->inf_done >= 0) pthread_cond_wait(&b->cv_turn, &b->mu);
-        if(!b->inf_done) b->inf_done = 1;
+        /* the end of the file, or an error */
+        pthread_mutex_lock(&b->mu);
+        if(st < 0) { if(b->inf_done >= 0) b->inf_done = st; }
+        else if(!b->io_end) b->io_end = 1;
         pthread_cond_broadcast(&b->cv_q);
         pthread_mutex_unlock(&b->mu);
         break;
     }
+    free(ta);
     return NULL;
 }
 static void inflaters_start(mdk_bam *b) {
     int i;
-    b->next_seq = b->push_seq = 0; b->io_status = 0;
-    for(i = 0; i < b->n_teams; i++) if(pthread_create(&b->inf_th[i], NULL, inflater_main, b)) break;
-    if(i == 0) { b->io_status = -1; snprintf(b->err, sizeof(b->err), "cannot create an inflate thread"); }
+    b->next_seq = b->pop_seq = 0; b->io_status = 0; b->io_end = 0;
+    for(i = 0; i < b->n_teams; i++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = -1; if(pthread_create(&b->inf_th[i], NULL, inflater_main, ta)) { free(ta); break; } }
+    if(i == 0) { b->io_status = -1; b->inf_done = -1; snprintf(b->err, sizeof(b->err), "cannot create an inflate thread"); }
     b->n_teams = i;
     b->inf_started = 1;
+    if(b->dev && b->n_gpu_teams) { int k; for(k = 0; k < b->n_gpu_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } } b->n_gpu_teams = k; b->gpu_started = 1; }
 }
 static void inflaters_stop(mdk_bam *b) {
     int i;
     if(!b->inf_started) return;
-    pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_turn); pthread_mutex_unlock(&b->mu);
+    pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
     for(i = 0; i < b->n_teams; i++) pthread_join(b->inf_th[i], NULL);
+    if(b->gpu_started) { for(i = 0; i < b->n_gpu_teams; i++) pthread_join(b->gpu_th[i], NULL); b->gpu_started = 0; }
     b->inf_started = 0;
+}
+int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
+    int k;
+    if(!b || !dev || b->dev) return -1;
+    if(n_teams < 1) n_teams = 1;
+    if(n_teams > 4) n_teams = 4;
+    b->dev = dev; b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + 4;
+    if(!b->inf_started) return 0;                                 /* (a seek restarts every team) */
+    for(k = 0; k < n_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } }
+    b->n_gpu_teams = k; b->gpu_started = 1;
+    return 0;
+}
+static void slab_destroy(mdk_slab *s) { if(!s) return; if(s->piece) md_piece_destroy(s->piece); md_host_free(s->buf); free(s->sum); free(s->mem); free(s); }
+void mdk_bam_detach_device(mdk_bam *b) {
+    int i;
+    if(!b || !b->dev) return;
+    /* the device teams end; slabs they made that are still queued or held are destroyed with the reader (mdk_bam_close) or here */
+    pthread_mutex_lock(&b->mu); b->quit = 1; if(!b->inf_done) b->inf_done = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
+    if(b->gpu_started) { for(i = 0; i < b->n_gpu_teams; i++) pthread_join(b->gpu_th[i], NULL); b->gpu_started = 0; }
+    for(i = 0; i < b->n_teams && b->inf_started; i++) pthread_join(b->inf_th[i], NULL);
+    b->inf_started = 0;
+    pthread_mutex_lock(&b->mu);
+    for(i = 0; i < MDK_READY; i++) if(b->ready[i] && b->ready[i]->piece) { slab_destroy(b->ready[i]); b->ready[i] = NULL; b->n_ready--; }
+    for(i = 0; i < b->n_dpool; i++) slab_destroy(b->dpool[i]);
+    b->n_dpool = 0;
+    if(b->cur && b->cur->piece) { slab_destroy(b->cur); b->cur = NULL; }
+    pthread_mutex_unlock(&b->mu);
+    for(i = 0; i < 4; i++) { md_host_free(b->gpu_stage[i]); b->gpu_stage[i] = NULL; b->gpu_stage_cap[i] = 0; }
+    b->dev = NULL; b->n_gpu_teams = 0;
 }
 
 /* scanner side: next inflated slab (blocking); NULL at end of data or on error (b->inf_done < 0) */
 static mdk_slab *slab_next(mdk_bam *b) {
     mdk_slab *s = NULL; double t0 = io_now();
     pthread_mutex_lock(&b->mu);
-    if(!b->q_n) pthread_cond_broadcast(&b->cv_pool);        /* starving: the inflater may take a slab beyond the cap */
-    while(!b->q_n && !b->inf_done) pthread_cond_wait(&b->cv_q, &b->mu);
-    if(b->q_n) { s = b->queue[0]; memmove(b->queue, b->queue + 1, sizeof(mdk_slab *) * (size_t)(--b->q_n)); }
-    pthread_cond_broadcast(&b->cv_pool);          /* a queue slot is free / the scanner is about to starve: let the inflater go on */
+    if(!b->n_ready) pthread_cond_broadcast(&b->cv_pool);        /* starving: the inflaters may take a slab beyond the cap */
+    for(;;) {
+        mdk_slab **slot = &b->ready[b->pop_seq % MDK_READY];
+        if(*slot) { s = *slot; *slot = NULL; b->n_ready--; b->pop_seq++; break; }
+        if(b->inf_done < 0 || b->quit) break;
+        if(b->io_end) {                /* the file has ended: done once every piece handed out has been taken */
+            uint64_t handed; pthread_mutex_unlock(&b->mu); pthread_mutex_lock(&b->io_mu); handed = b->next_seq; pthread_mutex_unlock(&b->io_mu); pthread_mutex_lock(&b->mu);
+            if(b->ready[b->pop_seq % MDK_READY]) continue;
+            if(b->pop_seq >= handed) { if(!b->inf_done) b->inf_done = 1; break; }
+        }
+        pthread_cond_wait(&b->cv_q, &b->mu);
+    }
+    pthread_cond_broadcast(&b->cv_pool);          /* a place is free / the scanner is about to starve: let the inflaters go on */
     pthread_mutex_unlock(&b->mu);
     b->t_inflate += io_now() - t0;
     return s;
 }
 
 /* make at least n bytes available at the scan position, moving to the next slab when the current one runs out
- * (the unfinished tail is completed in the next slab's headroom); 1 ok, 0 clean end of data, <0 error */
+ * (the unfinished tail is completed in the next slab's headroom); 1 ok, 0 clean end of data, <0 error.
+ * A slab inflated on the device becomes current with off == end: the caller sees that through mdk_bam_at_device. */
+static int slab_all_ok(const mdk_slab *s) { int i; for(i = 0; i < s->n_mem; i++) if(!s->mem[i].ok) return 0; return 1; }
 static int need(mdk_bam *b, size_t n) {
-    while(!b->cur || b->cur->end - b->off < n) {
-        mdk_slab *s = slab_next(b); size_t left = b->cur ? b->cur->end - b->off : 0;
+    for(;;) {
+        mdk_slab *s; size_t left;
+        if(b->cur && b->cur->piece) { if(b->mem_i < b->cur->n_mem) return 2; }          /* standing in a device slab: nothing to read through */
+        else if(b->cur && b->cur->end - b->off >= n) return 1;
+        s = slab_next(b); left = (b->cur && !b->cur->piece) ? b->cur->end - b->off : 0;
         if(!s) {
             if(b->inf_done < 0) return b->inf_done;
             if(left == 0) return 0;
             snprintf(b->err, sizeof(b->err), "truncated BAM record at end of file"); return -2;
+        }
+        if(s->piece && (left || !slab_all_ok(s))) { mdk_slab *h = slab_materialize(b, s); mdk_slab_unref(b, s); if(!h) return -2; s = h; }
+        if(s->piece) {
+            if(b->cur) mdk_slab_unref(b, b->cur);
+            b->cur = s; b->off = 0; b->mem_i = 0; b->sum_i = b->sum_end = 0;
+            continue;
         }
         if(left > s->beg) { snprintf(b->err, sizeof(b->err), "BAM record larger than %u bytes", MDK_SLAB_HEADROOM); mdk_slab_unref(b, s); return -2; }
         if(left) { memcpy(s->buf + s->beg - left, b->cur->buf + b->off, left); s->beg -= left; }
         if(b->cur) mdk_slab_unref(b, b->cur);
         b->cur = s; b->off = s->beg; b->mem_i = 0; b->sum_i = b->sum_end = 0;
     }
+}
+int mdk_bam_at_device(mdk_bam *b, mdk_slab **s, int *mi) {
+    int rc;
+    if(b->sum_i < b->sum_end) return 0;                        /* inside a host member's summaries */
+    rc = need(b, 1);
+    if(rc < 0) return rc;
+    if(rc != 2) return 0;
+    *s = b->cur; *mi = b->mem_i;
     return 1;
 }
+void mdk_bam_dev_advance(mdk_bam *b) { if(b->cur && b->cur->piece && b->mem_i < b->cur->n_mem) { b->n_records += b->cur->mem[b->mem_i].n_sum; b->n_fast += b->cur->mem[b->mem_i].n_sum; b->mem_i++; } }
 
 mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     mdk_bam *b = xcalloc(1, sizeof(*b)); int rc; uint32_t i; size_t o;
@@ -313,8 +448,11 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     b->max_alloc = b->nthreads * 2 + 8;           /* how far the inflaters may run ahead of the consumers, in slabs (~48 MB each) */
     if(b->max_alloc > 48) b->max_alloc = 48;       /* the chunk slots hold ~2 slabs each, the queue 8, the teams 4: more only costs memory */
     if(getenv("MDK_SLAB_CAP")) b->max_alloc = atoi(getenv("MDK_SLAB_CAP")) > 1 ? atoi(getenv("MDK_SLAB_CAP")) : 2;
-    pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL); pthread_cond_init(&b->cv_turn, NULL);
+    pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL);
     b->n_teams = b->nthreads >= 32 ? 4 : b->nthreads >= 8 ? 2 : 1;
+    if(getenv("MDK_DEVICE_INFLATE_ONLY")) { b->host_leaves = 1; b->n_teams = 1; }
+    b->gpu_piece_bytes = GCHUNK;
+    if(getenv("MDK_GPU_PIECE_MB") && atof(getenv("MDK_GPU_PIECE_MB")) >= 0.25 && atof(getenv("MDK_GPU_PIECE_MB")) <= 64) b->gpu_piece_bytes = (size_t)(atof(getenv("MDK_GPU_PIECE_MB")) * 1048576.0);      /* test hook: many small device pieces */
     if(getenv("MDK_INFLATE_TEAMS")) { b->n_teams = atoi(getenv("MDK_INFLATE_TEAMS")); if(b->n_teams < 1) b->n_teams = 1; if(b->n_teams > 8) b->n_teams = 8; }
     b->team_threads = (b->nthreads + b->n_teams - 1) / b->n_teams;
     inflaters_start(b);
@@ -335,6 +473,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
         b->target_len[i] = le32(b->cur->buf + o + 4 + ln);
         b->off += 8 + (size_t)ln;
     }
+    pthread_mutex_lock(&b->mu); b->header_done = 1; pthread_mutex_unlock(&b->mu);
     return b;
 }
 
@@ -342,20 +481,22 @@ void mdk_bam_close(mdk_bam *b) {
     int i;
     if(!b) return;
     inflaters_stop(b);
-    if(b->cur) { md_host_free(b->cur->buf); free(b->cur->sum); free(b->cur->mem); free(b->cur); }
-    for(i = 0; i < b->q_n; i++) { md_host_free(b->queue[i]->buf); free(b->queue[i]->sum); free(b->queue[i]->mem); free(b->queue[i]); }
-    for(i = 0; i < b->n_pool; i++) { md_host_free(b->pool[i]->buf); free(b->pool[i]->sum); free(b->pool[i]->mem); free(b->pool[i]); }
-    free(b->pool);
+    if(b->cur) slab_destroy(b->cur);
+    for(i = 0; i < MDK_READY; i++) if(b->ready[i]) slab_destroy(b->ready[i]);
+    for(i = 0; i < b->n_pool; i++) slab_destroy(b->pool[i]);
+    for(i = 0; i < b->n_dpool; i++) slab_destroy(b->dpool[i]);
+    for(i = 0; i < 4; i++) md_host_free(b->gpu_stage[i]);
+    free(b->pool); free(b->dpool);
     if(b->f) fclose(b->f);
     if(b->target_name) for(i = 0; i < b->n_targets; i++) free(b->target_name[i]);
     free(b->target_name); free(b->target_len); free(b->text); if(b->map) munmap((void *)b->map, b->map_len); else free(b->cbuf);
-    pthread_mutex_destroy(&b->mu); pthread_mutex_destroy(&b->io_mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool); pthread_cond_destroy(&b->cv_turn);
+    pthread_mutex_destroy(&b->mu); pthread_mutex_destroy(&b->io_mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool);
     free(b);
 }
 
 void mdk_bam_abort(mdk_bam *b) {
     if(!b) return;
-    pthread_mutex_lock(&b->mu); b->quit = 1; if(!b->inf_done) b->inf_done = 1; pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_turn); pthread_mutex_unlock(&b->mu);
+    pthread_mutex_lock(&b->mu); b->quit = 1; if(!b->inf_done) b->inf_done = 1; pthread_cond_broadcast(&b->cv_q); pthread_cond_broadcast(&b->cv_pool); pthread_mutex_unlock(&b->mu);
 }
 
 mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off) { *off = b->off; return b->cur; }
@@ -377,7 +518,7 @@ int mdk_rec_parse(const uint8_t *r, uint32_t len, mdk_rec *o) {
 
 int mdk_bam_peek(mdk_bam *b, mdk_rec *r) {
     int rc = need(b, 4); uint32_t bs;
-    if(rc <= 0) return rc;
+    if(rc <= 0 || rc == 2) return rc;            /* 2: the scanner stands in a slab inflated on the device (mdk_bam_at_device) */
     bs = le32(b->cur->buf + b->off);
     rc = need(b, 4 + (size_t)bs);
     if(rc <= 0) { if(rc == 0) { snprintf(b->err, sizeof(b->err), "truncated BAM record at end of file"); return -2; } return rc; }
@@ -394,7 +535,7 @@ int mdk_bam_peek_sum(mdk_bam *b, mdk_rsum *o, const uint8_t **raw) {
             return 1;
         }
         rc = need(b, 4);
-        if(rc <= 0) return rc;
+        if(rc <= 0 || rc == 2) return rc;
         {   /* does an ok member begin exactly here? */
             mdk_slab *s = b->cur;
             while(b->mem_i < s->n_mem && s->mem[b->mem_i].off < b->off) b->mem_i++;
@@ -484,17 +625,19 @@ int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
     int i;
     inflaters_stop(b);
     pthread_mutex_lock(&b->mu);
-    for(i = 0; i < b->q_n; i++) { if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = xrealloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); } b->pool[b->n_pool++] = b->queue[i]; }
-    b->q_n = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
+    for(i = 0; i < MDK_READY; i++) if(b->ready[i]) { mdk_slab *q = b->ready[i]; b->ready[i] = NULL; q->refs = 1; pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, q); pthread_mutex_lock(&b->mu); }
+    b->n_ready = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
     pthread_mutex_unlock(&b->mu);
     if(b->cur) { mdk_slab_unref(b, b->cur); b->cur = NULL; }
     if(b->map) { if((size_t)(voffset >> 16) > b->map_len) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; } b->map_pos = (size_t)(voffset >> 16); }
     else if(fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET)) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; }
     inflaters_start(b);
-    if((voffset & 0xffff) || 1) {
+    {
         int rc = need(b, (size_t)(voffset & 0xffff) + 1);
         if(rc < 0) return rc;
         if(rc == 0) return 0;                          /* nothing there */
+        if(rc == 2) return 1;                          /* a slab inflated on the device is taken from the first record of its first member: the
+                                                          records in front of the offset end before the window the caller asked for, and it passes over them */
         b->off += (size_t)(voffset & 0xffff);
     }
     return 1;

@@ -33,10 +33,15 @@ static inline char *xstrdup(const char *s) { char *q = strdup(s); return q ? q :
  * that other cores have just written.  Any other file (records split across members) simply never matches and is
  * scanned the slow way. */
 typedef struct { uint32_t off, len; int32_t tid, pos, endp; } mdk_rsum;          /* off: of the block_size word in the slab; len: block_size */
-typedef struct { uint32_t off, n_sum; uint32_t sum0; int ok;          /* off: first byte in the slab; records sum[sum0 .. sum0+n_sum) */
+typedef struct { uint32_t off, len, n_sum; uint32_t sum0; int ok;     /* off, len: its bytes in the slab; records sum[sum0 .. sum0+n_sum) */
                  int32_t tid0, pos0, tidN, posN, min_endp, max_endp; int sorted; } mdk_member;    /* digest of an ok member: first/last record, extent of the ends, coordinate order inside */
+/* A slab inflated ON THE DEVICE (piece != NULL) has no host bytes and no record summaries: buf and sum are NULL,
+ * d_buf / d_rec_off are device pointers (inflated bytes; offset of every record in d_buf), mem[] holds the members' digests with
+ * off/len in d_buf and sum0/n_sum indexing d_rec_off.  The reader applies the chunk schedule to such a slab member by member. */
+struct md_piece;
 typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs;
-                          mdk_rsum *sum; size_t n_sum, cap_sum; mdk_member *mem; int n_mem, cap_mem; } mdk_slab;
+                          mdk_rsum *sum; size_t n_sum, cap_sum; mdk_member *mem; int n_mem, cap_mem;
+                          struct md_piece *piece; const uint8_t *d_buf; const uint32_t *d_rec_off; uint64_t d_bytes; uint32_t d_records; } mdk_slab;
 
 typedef struct mdk_bam {
     FILE *f;
@@ -45,9 +50,17 @@ typedef struct mdk_bam {
      * and cheap), inflates it with its share of the threads while another team is already reading the following piece,
      * and queues the slab when its turn comes (seq order) */
     pthread_t inf_th[8]; int n_teams, team_threads, inf_started;
-    pthread_mutex_t mu, io_mu; pthread_cond_t cv_q, cv_pool, cv_turn;
-    uint64_t next_seq, push_seq; int io_status;     /* pieces handed out / slabs queued; 0 reading, 1 end of file, <0 error */
-    mdk_slab *queue[8]; int q_n; int inf_done, quit;
+    pthread_mutex_t mu, io_mu; pthread_cond_t cv_q, cv_pool;
+    uint64_t next_seq; int io_status;               /* (io_mu) pieces handed out; 0 reading, 1 end of file, <0 error */
+    /* (mu) finished slabs wait in ready[seq % MDK_READY] until the scanner has taken every earlier one: a team that finishes early
+     * goes on with its next piece instead of waiting for its turn (device pieces are several times larger than host pieces) */
+#define MDK_READY 64
+    mdk_slab *ready[MDK_READY]; int n_ready; uint64_t pop_seq; int io_end;      /* io_end: copy of io_status once non-zero */
+    int inf_done, quit, host_leaves, header_done; size_t gpu_piece_bytes;
+    /* teams that inflate on the device (mdk_bam_attach_device): each stages a piece of the file in registered memory and hands it
+     * to the device library (md_piece_*); they share the piece counter with the host teams */
+    struct md_dev *dev; pthread_t gpu_th[4]; int n_gpu_teams, gpu_started; uint8_t *gpu_stage[4]; size_t gpu_stage_cap[4];
+    mdk_slab **dpool; int n_dpool, cap_dpool, n_dalloc, max_dalloc; uint64_t n_dev_pieces, n_host_pieces, n_materialized;
     mdk_slab **pool; int n_pool, cap_pool, n_alloc, max_alloc;
     uint8_t *cbuf; size_t ccap, clen; int file_eof;
     const uint8_t *map; size_t map_len, map_pos;   /* the file mapped read-only: the inflate threads read the compressed bytes where the page cache has them (no copy) */
@@ -77,6 +90,14 @@ mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off);
 void mdk_slab_ref(mdk_bam *b, mdk_slab *s);
 void mdk_slab_unref(mdk_bam *b, mdk_slab *s);
 void mdk_bam_close(mdk_bam *b);
+/* from now on, pieces of the file are also inflated on this device (n_teams threads, each with its own device piece); safe while
+ * the host teams are running.  mdk_bam_detach_device stops those threads and frees the device pieces: before md_dev_close. */
+int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams);
+void mdk_bam_detach_device(mdk_bam *b);
+/* stream position for slabs inflated on the device: 1 = the scanner stands at member *mi of device slab *s; 0 = it stands in a host
+ * slab (use mdk_bam_peek_sum), or at the end of the data; <0 error.  mdk_bam_dev_advance consumes that member. */
+int mdk_bam_at_device(mdk_bam *b, mdk_slab **s, int *mi);
+void mdk_bam_dev_advance(mdk_bam *b);
 /* make every blocked or future read return end-of-data (used to stop a reader thread) */
 void mdk_bam_abort(mdk_bam *b);
 /* 1 = record available, 0 = end of file, <0 = error (b->err) */

@@ -357,18 +357,22 @@ static uint32_t adjust_end(const mdk_plan *p, uint32_t tid, uint32_t end) {
 /*   consumer: mdk_plan_next_chunk hands the chunks out in schedule order                                            */
 /* ------------------------------------------------------------------------------------------------ */
 enum { S_FREE = 0, S_FILL, S_RAW, S_WORK, S_DONE, S_HELD };
-typedef struct { mdk_slab *slab; size_t beg, end; } rrange;      /* records parsed in place from an inflate slab */
+/* The records of a chunk are a list of RANGES in file order: records parsed in place in a slab a host team inflated (RG_HOST),
+ * records copied into the slot's own buffer -- straddlers carried over from the previous chunk (RG_COPY) --, or whole members of a
+ * slab inflated on the device (RG_DEV; the device filters the members' records against the chunk itself). */
+enum { RG_HOST = 0, RG_COPY = 1, RG_DEV = 2 };
+typedef struct { int kind; mdk_slab *slab; size_t beg, end; uint64_t cat0; uint32_t n_rec; int m0, m1; } rrange;      /* cat0: offset of its first byte in the concatenation of the chunk's ranges */
 typedef struct pslot {
     int state; mdk_chunk c;
-    uint8_t *raw; size_t raw_len, raw_cap;                /* copied records (straddlers from earlier chunks): [u32 len][record bytes]... */
-    rrange *rg; int n_rg, cap_rg;                         /* then these ranges of the stream, in order */
+    uint8_t *raw; size_t raw_len, raw_cap;                /* copied records: [u32 len][record bytes]... */
+    rrange *rg; int n_rg, cap_rg; uint64_t cat_len;       /* the ranges, in order; bytes in all of them */
     uint64_t n_stream;                                    /* records in the ranges (for up-front reservation) */
     const char *win; int64_t woff, wlen;
     batchbuf bb; int rc;
-    /* device preparation: the same records described for md_dev_upload_raw -- the copied records, then the ranges -- with
-     * every record's offset in that concatenation; the slabs stay referenced until the chunk is recycled (the H2D copies
-     * read them, and a chunk the device gives up on is prepared from them by mdk_plan_host_prepare) */
-    uint32_t *roff; size_t n_roff, cap_roff; uint64_t rg_base; md_raw_range *rr; int cap_rr; int hold_slabs, prepared;
+    /* device preparation: the same records described for md_dev_upload_raw with every host-resident record's offset in the
+     * concatenation of the ranges; the slabs stay referenced until the chunk is recycled (the copies read them, and a chunk the
+     * device gives up on is prepared from them by mdk_plan_host_prepare) */
+    uint32_t *roff; size_t n_roff, cap_roff; md_raw_range *rr; int cap_rr; int hold_slabs, prepared, n_dev_rg;
 } pslot;
 
 static int roff_push(pslot *sl, uint64_t off) {
@@ -376,11 +380,47 @@ static int roff_push(pslot *sl, uint64_t off) {
     sl->roff[sl->n_roff++] = (uint32_t)off;
     return 0;
 }
-static int raw_push(pslot *sl, const mdk_rec *r) {
-    size_t need = sl->raw_len + 4 + r->raw_len;
-    if(sl->hold_slabs && roff_push(sl, sl->raw_len)) return -1;
+static rrange *rg_new(mdk_plan *p, pslot *sl, int kind, mdk_slab *slab, size_t beg) {
+    rrange *g;
+    if(sl->n_rg == sl->cap_rg) { int nc = sl->cap_rg ? sl->cap_rg * 2 : 16; if(grow((void **)&sl->rg, sizeof(rrange) * (size_t)nc)) return NULL; sl->cap_rg = nc; }
+    g = &sl->rg[sl->n_rg++]; memset(g, 0, sizeof(*g));
+    g->kind = kind; g->slab = slab; g->beg = g->end = beg; g->cat0 = sl->cat_len;
+    if(slab) mdk_slab_ref(p->bam, slab);
+    return g;
+}
+static int raw_push(mdk_plan *p, pslot *sl, const mdk_rec *r) {
+    size_t need = sl->raw_len + 4 + r->raw_len; rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
     if(need > sl->raw_cap) { size_t nc = need * 2 + (1 << 20); if(grow((void **)&sl->raw, nc)) return -1; sl->raw_cap = nc; }
+    if(!(g && g->kind == RG_COPY && g->end == sl->raw_len)) { g = rg_new(p, sl, RG_COPY, NULL, sl->raw_len); if(!g) return -1; }
+    if(sl->hold_slabs && roff_push(sl, sl->cat_len)) return -1;
     memcpy(sl->raw + sl->raw_len, &r->raw_len, 4); memcpy(sl->raw + sl->raw_len + 4, r->raw, r->raw_len); sl->raw_len = need;
+    g->end = need; g->n_rec++; sl->cat_len += 4 + (uint64_t)r->raw_len;
+    return 0;
+}
+/* one more member of a device slab */
+static int dev_push(mdk_plan *p, pslot *sl, mdk_slab *ds, int mi) {
+    const mdk_member *m = &ds->mem[mi]; rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
+    if(!(g && g->kind == RG_DEV && g->slab == ds && g->m1 == mi)) { g = rg_new(p, sl, RG_DEV, ds, m->off); if(!g) return -1; g->m0 = mi; sl->n_dev_rg++; }
+    g->m1 = mi + 1; g->end = (size_t)m->off + m->len; g->n_rec += m->n_sum; sl->cat_len += m->len; sl->n_stream += m->n_sum;
+    return 0;
+}
+/* members of device slabs that the next chunk has to look at again: a list in file order, each with the number of bytes of the
+ * host-side carry that precede it there */
+static void dm_clear(mdk_plan *p) { int i; for(i = 0; i < p->n_dm; i++) mdk_slab_unref(p->bam, p->dm[i].slab); p->n_dm = 0; }
+static int dm2_push(mdk_plan *p, mdk_slab *ds, int mi) {
+    if(p->n_dm2 == p->cap_dm2) { int nc = p->cap_dm2 ? p->cap_dm2 * 2 : 64; if(grow((void **)&p->dm2, sizeof(*p->dm2) * (size_t)nc)) return -1; p->cap_dm2 = nc; }
+    p->dm2[p->n_dm2].slab = ds; p->dm2[p->n_dm2].mi = mi; p->dm2[p->n_dm2].mark = p->carry2_len; p->n_dm2++;
+    mdk_slab_ref(p->bam, ds);
+    return 0;
+}
+/* a member of a device slab against the chunk [beg,end) of contig tid: into the chunk's ranges when one of its records may overlap
+ * the chunk (the device tests every record), onto the next chunk's list when one of its records may reach or start beyond `end` */
+static int dev_member(mdk_plan *p, pslot *sl, mdk_slab *ds, int mi, int32_t tid, uint32_t beg, uint32_t end, int collect) {
+    const mdk_member *m = &ds->mem[mi]; const int32_t tN = m->tidN < 0 ? 0x7fffffff : m->tidN;      /* unplaced records sort behind every contig */
+    const int multi = m->tid0 != m->tidN;
+    if(m->n_sum == 0 || m->tid0 < 0) return 0;
+    if(tN >= tid && (m->tid0 < tid || m->pos0 < (int32_t)end) && (multi || m->max_endp > (int32_t)beg)) { if(collect && dev_push(p, sl, ds, mi)) return -5; }
+    if(tN > tid || (tN == tid && (m->max_endp > (int32_t)end || m->posN >= (int32_t)end))) { if(dm2_push(p, ds, mi)) return -5; }
     return 0;
 }
 
@@ -388,7 +428,7 @@ static int raw_push(pslot *sl, const mdk_rec *r) {
 static int reader_fill(mdk_plan *p, pslot *sl) {
     const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; int rc, fi, collect; mdk_rec r; size_t off; mdk_chunk *c = &sl->c;
     memset(c, 0, sizeof(*c)); sl->raw_len = 0; sl->n_rg = 0; sl->n_stream = 0; sl->win = NULL; sl->woff = sl->wlen = 0;
-    sl->n_roff = 0; sl->rg_base = 0; sl->prepared = 0; sl->hold_slabs = p->dev_prep;
+    sl->n_roff = 0; sl->cat_len = 0; sl->prepared = 0; sl->hold_slabs = p->dev_prep; sl->n_dev_rg = 0;
     /* extract.c:325-350 */
     c->index = p->bin++;
     tid = p->g_tid; beg = p->g_pos; end = (uint32_t)(beg + o->chunk_size);
@@ -404,7 +444,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
     if(p->shard_world > 1 && (int)(c->index % (uint32_t)p->shard_world) != p->shard_rank) c->skipped |= MDK_CHUNK_FOREIGN;
     if(p->bed_on && !bed_touches(p, (int32_t)tid, beg, end)) {      /* extract.c:352-369: the chunk is passed over before anything else happens */
         c->skipped |= MDK_CHUNK_BED;
-        if(p->bai) { p->need_seek = 1; p->carry_len = 0; p->carry_tid = -1; return 1; }      /* do not even read its records */
+        if(p->bai) { p->need_seek = 1; p->carry_len = 0; p->carry_tid = -1; dm_clear(p); return 1; }      /* do not even read its records */
     }
     fi = p->fa_of_tid[tid];
     if(c->skipped & MDK_CHUNK_BED) ;
@@ -424,7 +464,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
     /* With a .bai the stream is repositioned instead of read through: once at the start of a -r region, and before every
      * own chunk of a sharded run (foreign chunks are then not read at all, like the reference's per-chunk region query). */
     if(p->bai && (p->need_seek || p->shard_world > 1)) {
-        p->carry_len = 0; p->carry_tid = -1;
+        p->carry_len = 0; p->carry_tid = -1; dm_clear(p);
         if(c->skipped & MDK_CHUNK_FOREIGN) return 1;
         {
             uint64_t vo = mdk_bai_start(p->bai, (int32_t)tid, beg);
@@ -436,22 +476,45 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
     }
     /* reads of this chunk, file order: straddlers carried over from the previous chunk, then the stream */
     collect = !c->skipped || (o->perread && c->skipped == MDK_CHUNK_NOREF);      /* perRead still lists the reads of a contig the FASTA lacks (all zero) */
-    p->carry2_len = 0;
-    if(p->carry_tid == (int32_t)tid) {
-        for(off = 0; off < p->carry_len;) {
-            uint32_t len; int32_t rlen, endp;
-            memcpy(&len, p->carry + off, 4);
-            if(mdk_rec_parse(p->carry + off + 4, len, &r) != 0) return -2;
-            off += 4 + (size_t)len;
-            rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
-            c->n_records_seen++;
-            if(endp > (int32_t)beg && r.pos < (int32_t)end && collect) { if(raw_push(sl, &r)) return -5; }
-            if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
+    p->carry2_len = 0; p->n_dm2 = 0;
+    {   /* what the previous chunk left: copied records and members of device slabs, merged back into file order */
+        int di = 0; const int same = p->carry_tid == (int32_t)tid; const size_t clen = same ? p->carry_len : 0;
+        for(off = 0;;) {
+            while(di < p->n_dm && (p->dm[di].mark <= off || off >= clen)) { int r2 = dev_member(p, sl, p->dm[di].slab, p->dm[di].mi, (int32_t)tid, beg, end, collect); if(r2) return r2; di++; }
+            if(off >= clen) break;
+            {
+                uint32_t len; int32_t rlen, endp;
+                memcpy(&len, p->carry + off, 4);
+                if(mdk_rec_parse(p->carry + off + 4, len, &r) != 0) return -2;
+                off += 4 + (size_t)len;
+                rlen = cigar_ref_len(&r); endp = r.pos + (rlen > 0 ? rlen : 1);
+                c->n_records_seen++;
+                if(endp > (int32_t)beg && r.pos < (int32_t)end && collect) { if(raw_push(p, sl, &r)) return -5; }
+                if((uint32_t)endp > end && carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5;
+            }
         }
+        dm_clear(p);
     }
     for(;;) {
         mdk_rsum q; const uint8_t *raw;
+        {   /* a slab inflated on the device is taken member by member, from the digests */
+            mdk_slab *ds; int mi; int k = mdk_bam_at_device(bam, &ds, &mi);
+            if(k < 0) { rc = k; break; }
+            if(k == 1) {
+                const mdk_member *m = &ds->mem[mi]; rc = 1;
+                if(m->n_sum && m->tid0 >= 0) {
+                    if(m->tid0 < p->last_tid || (m->tid0 == p->last_tid && m->pos0 < p->last_pos) || (!m->sorted && m->tidN >= 0)) { fprintf(stderr, "[mdk] %s is not coordinate sorted; `extract` needs sorted alignments\n", o->bam_name); return -2; }
+                    if(m->tid0 > (int32_t)tid || (m->tid0 == (int32_t)tid && m->pos0 >= (int32_t)end)) break;
+                    c->n_records_seen += m->n_sum;
+                    { int r2 = dev_member(p, sl, ds, mi, (int32_t)tid, beg, end, collect); if(r2) return r2; }
+                    if(m->tidN >= 0) { p->last_tid = m->tidN; p->last_pos = m->posN; }
+                }
+                mdk_bam_dev_advance(bam);
+                continue;
+            }
+        }
         rc = mdk_bam_peek_sum(bam, &q, &raw);
+        if(rc == 2) continue;
         if(rc != 1) break;
         {   /* a whole (rest of a) BGZF member at once, from the digest its inflating thread left: every record on this contig,
              * in order, starting before the chunk's end, reaching into the chunk, none reaching beyond it */
@@ -461,15 +524,11 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
                 c->n_records_seen += n;
                 if(collect) {
                     size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL; size_t k, rend = (size_t)v[n - 1].off + 4 + v[n - 1].len;
-                    if(g && g->slab == cs && g->end == roff) g->end = rend;
-                    else {
-                        if(g) sl->rg_base += g->end - g->beg;
-                        if(sl->n_rg == sl->cap_rg) { int nc = sl->cap_rg ? sl->cap_rg * 2 : 16; if(grow((void **)&sl->rg, sizeof(rrange) * (size_t)nc)) return -5; sl->cap_rg = nc; }
-                        g = &sl->rg[sl->n_rg++]; g->slab = cs; g->beg = roff; g->end = rend; mdk_slab_ref(bam, cs);
-                    }
+                    if(!(g && g->kind == RG_HOST && g->slab == cs && g->end == roff)) { g = rg_new(p, sl, RG_HOST, cs, roff); if(!g) return -5; }
+                    g->end = rend; g->n_rec += (uint32_t)n; sl->cat_len = g->cat0 + (g->end - g->beg);
                     sl->n_stream += n;
                     if(sl->hold_slabs) {
-                        const uint64_t base = (uint64_t)sl->raw_len + sl->rg_base - g->beg;
+                        const uint64_t base = g->cat0 - g->beg;
                         if(sl->n_roff + n > sl->cap_roff) { size_t nc = (sl->n_roff + n) * 2 + (1u << 18); if(grow((void **)&sl->roff, nc * sizeof(uint32_t))) return -5; sl->cap_roff = nc; }
                         for(k = 0; k < n; k++) sl->roff[sl->n_roff + k] = (uint32_t)(base + v[k].off);
                         sl->n_roff += n;
@@ -490,14 +549,10 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
             c->n_records_seen++;
             if(q.endp > (int32_t)beg && collect) {          /* in place: extend the open range or start a new one */
                 size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
-                if(g && g->slab == cs && g->end == roff) g->end = roff + 4 + q.len;
-                else {
-                    if(g) sl->rg_base += g->end - g->beg;
-                    if(sl->n_rg == sl->cap_rg) { int nc = sl->cap_rg ? sl->cap_rg * 2 : 16; if(grow((void **)&sl->rg, sizeof(rrange) * (size_t)nc)) return -5; sl->cap_rg = nc; }
-                    g = &sl->rg[sl->n_rg++]; g->slab = cs; g->beg = roff; g->end = roff + 4 + q.len; mdk_slab_ref(bam, cs);
-                }
+                if(!(g && g->kind == RG_HOST && g->slab == cs && g->end == roff)) { g = rg_new(p, sl, RG_HOST, cs, roff); if(!g) return -5; }
+                if(sl->hold_slabs && roff_push(sl, g->cat0 + (roff - g->beg))) return -5;
+                g->end = roff + 4 + q.len; g->n_rec++; sl->cat_len = g->cat0 + (g->end - g->beg);
                 sl->n_stream++;
-                if(sl->hold_slabs && roff_push(sl, (uint64_t)sl->raw_len + sl->rg_base + (roff - g->beg))) return -5;
             }
             if((uint32_t)q.endp > end) { r.raw = raw; r.raw_len = q.len; if(carry_push(&p->carry2, &p->carry2_len, &p->carry2_cap, &r)) return -5; }
         }
@@ -505,33 +560,28 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
     }
     if(rc < 0) { fprintf(stderr, "[mdk] error while reading %s: %s\n", o->bam_name, bam->err); return -2; }
     { uint8_t *t = p->carry; size_t tc = p->carry_cap; p->carry = p->carry2; p->carry_len = p->carry2_len; p->carry_cap = p->carry2_cap; p->carry2 = t; p->carry2_cap = tc; p->carry2_len = 0; p->carry_tid = (int32_t)tid; }
+    { void *t = p->dm; int tc = p->cap_dm; p->dm = p->dm2; p->n_dm = p->n_dm2; p->cap_dm = p->cap_dm2; p->dm2 = t; p->cap_dm2 = tc; p->n_dm2 = 0; }
     return 1;
 }
 
 /* admission + packing + pairing + segments of one chunk */
 static int worker_process(mdk_plan *p, pslot *sl) {
     batchbuf *b = &sl->bb; mdk_chunk *c = &sl->c; size_t off; mdk_rec r; double t0 = now_s(), t1, t2;
-    int g; size_t bytes = sl->raw_len;
+    int g; size_t bytes = 0;
     b->n = 0; b->blob_len = 0; b->qn_len = 0; b->cig_len = 0; b->n_seg = 0; b->algo_bytes = 0;
-    /* one reservation per chunk instead of growing (the blob is pinned memory, which is expensive to allocate): the
+    /* one reservation per chunk instead of growing (the blob is staging memory, which is expensive to allocate): the
      * payload, names and CIGARs of the admitted reads are all smaller than the raw records they come from */
-    for(g = 0; g < sl->n_rg; g++) bytes += sl->rg[g].end - sl->rg[g].beg;
+    for(g = 0; g < sl->n_rg; g++) { if(sl->rg[g].kind == RG_DEV) { fprintf(stderr, "[mdk] internal: a chunk inflated on the device reached the host preparation without its bytes\n"); return -2; } bytes += sl->rg[g].end - sl->rg[g].beg; }
     if(bb_reserve_exact(b, (size_t)sl->n_stream + c->n_records_seen + 16, bytes - bytes / 8 + 65536, bytes / 4 + 4096, bytes / 16 + 4096, 2 * (size_t)sl->n_stream + 4096)) return -5;
-    for(off = 0; off < sl->raw_len;) {
-        uint32_t len; memcpy(&len, sl->raw + off, 4);
-        if(mdk_rec_parse(sl->raw + off + 4, len, &r) != 0) return -2;
-        off += 4 + (size_t)len;
-        if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen, c->beg, c->end) < 0) return -5;
-    }
     for(g = 0; g < sl->n_rg; g++) {
-        const uint8_t *base = sl->rg[g].slab->buf;
+        const uint8_t *base = sl->rg[g].kind == RG_COPY ? sl->raw : sl->rg[g].slab->buf;
         for(off = sl->rg[g].beg; off < sl->rg[g].end;) {
             uint32_t len; memcpy(&len, base + off, 4);
             if(mdk_rec_parse(base + off + 4, len, &r) != 0) return -2;
             off += 4 + (size_t)len;
             if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen, c->beg, c->end) < 0) return -5;
         }
-        if(!sl->hold_slabs) mdk_slab_unref(p->bam, sl->rg[g].slab);
+        if(!sl->hold_slabs && sl->rg[g].slab) mdk_slab_unref(p->bam, sl->rg[g].slab);
     }
     if(!sl->hold_slabs) sl->n_rg = 0;
     if(bb_reserve(b, 1, 16, 16, 1) || seg_reserve(b, 1)) return -5;          /* never hand out NULL arrays */
@@ -559,13 +609,19 @@ static int worker_process(mdk_plan *p, pslot *sl) {
 
 /* describe the chunk's records for md_dev_upload_raw (no per-record work on the host) */
 static int describe_raw(mdk_plan *p, pslot *sl) {
-    mdk_chunk *c = &sl->c; int g, n = 0; uint64_t total = sl->raw_len;
+    mdk_chunk *c = &sl->c; int g; uint64_t nrec = 0;
     if(sl->n_rg + 1 > sl->cap_rr) { int nc = sl->n_rg + 8; if(grow((void **)&sl->rr, sizeof(md_raw_range) * (size_t)nc)) return -5; sl->cap_rr = nc; }
-    if(sl->raw_len) { sl->rr[n].ptr = sl->raw; sl->rr[n].bytes = sl->raw_len; n++; }
-    for(g = 0; g < sl->n_rg; g++) { sl->rr[n].ptr = sl->rg[g].slab->buf + sl->rg[g].beg; sl->rr[n].bytes = sl->rg[g].end - sl->rg[g].beg; total += sl->rr[n].bytes; n++; }
-    if(total >= 0xffffff00ull) { fprintf(stderr, "[mdk] a chunk holds more than 4 GiB of records; use a smaller --chunkSize\n"); return -2; }
-    c->raw.tid = c->tid; c->raw.beg = c->beg; c->raw.end = c->end; c->raw.n_ranges = n; c->raw.range = sl->rr;
-    c->raw.n_records = (int32_t)sl->n_roff; c->raw.rec_off = sl->roff; c->raw.woff = sl->woff; c->raw.wlen = sl->wlen;
+    for(g = 0; g < sl->n_rg; g++) {
+        const rrange *q = &sl->rg[g]; md_raw_range *o = &sl->rr[g];
+        o->bytes = q->end - q->beg; o->n_records = q->n_rec; o->d_rec_off = NULL; o->rec_delta = 0;
+        if(q->kind == RG_COPY) o->ptr = sl->raw + q->beg;
+        else if(q->kind == RG_HOST) o->ptr = q->slab->buf + q->beg;
+        else { o->ptr = q->slab->d_buf + q->beg; o->d_rec_off = q->slab->d_rec_off + q->slab->mem[q->m0].sum0; o->rec_delta = (uint32_t)q->beg; }
+        nrec += q->n_rec;
+    }
+    if(sl->cat_len >= 0xffffff00ull) { fprintf(stderr, "[mdk] a chunk holds more than 4 GiB of records; use a smaller --chunkSize\n"); return -2; }
+    c->raw.tid = c->tid; c->raw.beg = c->beg; c->raw.end = c->end; c->raw.n_ranges = sl->n_rg; c->raw.range = sl->rr;
+    c->raw.n_records = (int32_t)nrec; c->raw.rec_off = sl->roff; c->raw.woff = sl->woff; c->raw.wlen = sl->wlen;
     c->prep = 1;
     (void)p;
     return 0;
@@ -573,7 +629,7 @@ static int describe_raw(mdk_plan *p, pslot *sl) {
 static void slot_release_slabs(mdk_plan *p, pslot *sl) {
     int g;
     if(!sl->hold_slabs) return;
-    for(g = 0; g < sl->n_rg; g++) mdk_slab_unref(p->bam, sl->rg[g].slab);
+    for(g = 0; g < sl->n_rg; g++) if(sl->rg[g].slab) mdk_slab_unref(p->bam, sl->rg[g].slab);
     sl->n_rg = 0;
 }
 
@@ -665,7 +721,8 @@ MDK_LOCAL void pipeline_stop(mdk_plan *p) {
     mdk_bam_abort(p->bam);          /* wake the reader if it is waiting for inflated data */
     pthread_join(p->reader_th, NULL);
     for(i = 0; i < p->n_workers; i++) pthread_join(p->worker_th[i], NULL);
-    for(i = 0; i < p->n_slot; i++) { int g; for(g = 0; g < p->slot[i].n_rg; g++) mdk_slab_unref(p->bam, p->slot[i].rg[g].slab); bb_free(&p->slot[i].bb); free(p->slot[i].raw); free(p->slot[i].rg); free(p->slot[i].roff); free(p->slot[i].rr); }
+    dm_clear(p); { int k; for(k = 0; k < p->n_dm2; k++) mdk_slab_unref(p->bam, p->dm2[k].slab); p->n_dm2 = 0; }
+    for(i = 0; i < p->n_slot; i++) { int g; for(g = 0; g < p->slot[i].n_rg; g++) if(p->slot[i].rg[g].slab) mdk_slab_unref(p->bam, p->slot[i].rg[g].slab); bb_free(&p->slot[i].bb); free(p->slot[i].raw); free(p->slot[i].rg); free(p->slot[i].roff); free(p->slot[i].rr); }
     free(p->slot); free(p->worker_th); p->slot = NULL; p->started = 0;
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_free); pthread_cond_destroy(&p->cv_raw); pthread_cond_destroy(&p->cv_done);
 }
@@ -705,12 +762,36 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
 
 /* A chunk handed out for device preparation, prepared on the host after all (the device reported MDK_ERR_PREP_HOST): the
  * same admission, pairing and segments as a host-mode plan produces, from the records the slot still references. */
+static pslot *held_slot(mdk_plan *p, const mdk_chunk *c) {
+    int i;
+    for(i = 0; i < p->n_hold; i++) if(p->held[i] >= 0 && p->slot[p->held[i]].c.index == c->index) return &p->slot[p->held[i]];
+    return NULL;
+}
 int mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c) {
-    int i, rc; pslot *sl = NULL;
+    int rc; pslot *sl = NULL;
     if(!p || !c || !p->started) return -1;
-    for(i = 0; i < p->n_hold; i++) if(p->held[i] >= 0 && p->slot[p->held[i]].c.index == c->index) sl = &p->slot[p->held[i]];
+    sl = held_slot(p, c);
     if(!sl || !sl->hold_slabs) return -1;
     if(!sl->prepared) { rc = worker_process(p, sl); if(rc < 0) return rc; sl->prepared = 1; }
     c->batch = sl->c.batch;
     return 0;
+}
+/* the same for a chunk some of whose records were inflated on the device and so never were in host memory: the records as the
+ * device slot holds them (the concatenation of the chunk's ranges) come back first and stand in for the ranges */
+int mdk_plan_host_prepare_from(mdk_plan *p, mdk_chunk *c, md_dev *dev, int slot) {
+    pslot *sl;
+    if(!p || !c || !p->started) return -1;
+    sl = held_slot(p, c);
+    if(!sl || !sl->hold_slabs) return -1;
+    if(!sl->prepared && sl->n_dev_rg) {
+        uint64_t nb = sl->cat_len + 64; uint32_t nr = (uint32_t)c->raw.n_records + 1; rrange *g;
+        if(nb > sl->raw_cap) { if(grow((void **)&sl->raw, nb)) return -5; sl->raw_cap = nb; }
+        if(nr > sl->cap_roff) { if(grow((void **)&sl->roff, sizeof(uint32_t) * (size_t)nr)) return -5; sl->cap_roff = nr; }
+        if(md_dev_read_raw(dev, slot, sl->raw, &nb, sl->roff, &nr)) return -2;
+        slot_release_slabs(p, sl);
+        sl->raw_len = (size_t)nb; sl->n_roff = nr; sl->cat_len = 0; sl->n_dev_rg = 0;
+        g = rg_new(p, sl, RG_COPY, NULL, 0); if(!g) return -5;
+        g->end = (size_t)nb; g->n_rec = nr; sl->cat_len = nb;
+    }
+    return mdk_plan_host_prepare(p, c);
 }

@@ -283,6 +283,8 @@ MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional
      * first time an upload reads from it (md_host_alloc): allocating it never waits for the device to come up, and every upload
      * is a DMA off the submitting thread -- the pinned double-buffered feed of the north star, for inputs of any size */
     md_host_set_pinned(0);
+    /* the test hook that leaves every piece after the header's to the device only makes sense where a device will be attached */
+    if(o->mbias || o->perread || getenv("MDK_HOST_INFLATE") || getenv("MDK_HOST_PREP") || (getenv("MDK_GPUS") && atoi(getenv("MDK_GPUS")) > 1)) unsetenv("MDK_DEVICE_INFLATE_ONLY");
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
     if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
     p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */
@@ -343,6 +345,19 @@ region:
     /* -l (extract.c:1469-1477, MBias.c:524-532) */
     if(o->bed_name && load_bed(p) != 0) { fprintf(stderr, "There was an error while reading in your BED file!\n"); plan_free(p); return 1; }
     return 0;
+}
+
+/* BGZF inflate on the device as well (mdk_io.c): the `extract` command in device-preparation mode only -- `mbias` and `perRead` format
+ * from the records on the host.  MDK_HOST_INFLATE=1 keeps every piece on the host's inflate threads. */
+int mdk_plan_attach_device(mdk_plan *p, md_dev *dev) {
+    if(!p || !dev || !p->bam) return -1;
+    if(!p->dev_prep || p->o.mbias || p->o.perread || getenv("MDK_HOST_INFLATE")) return 0;
+    return mdk_bam_attach_device(p->bam, dev, getenv("MDK_GPU_INFLATE_TEAMS") ? atoi(getenv("MDK_GPU_INFLATE_TEAMS")) : 3);
+}
+void mdk_plan_detach_device(mdk_plan *p) {
+    if(!p || !p->bam || !p->bam->dev) return;
+    if(p->started) pipeline_stop(p);            /* the reader holds slabs of device pieces */
+    mdk_bam_detach_device(p->bam);
 }
 
 int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {

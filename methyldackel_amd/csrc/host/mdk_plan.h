@@ -101,6 +101,7 @@ struct mdk_plan {
     int32_t last_tid, last_pos; int at_eof;
     uint8_t *carry; size_t carry_len, carry_cap; int32_t carry_tid;
     uint8_t *carry2; size_t carry2_len, carry2_cap;
+    struct { mdk_slab *slab; int mi; size_t mark; } *dm, *dm2; int n_dm, cap_dm, n_dm2, cap_dm2;      /* members of device-inflated slabs the next chunk looks at again (mdk_pipeline.c) */
     /* chunk pipeline: reader thread -> worker threads -> ordered delivery (see the pipeline section) */
     struct pslot *slot; int n_slot, n_workers; pthread_t reader_th, *worker_th; int started, quit, pipe_rc, reader_done;
     pthread_mutex_t mu; pthread_cond_t cv_free, cv_raw, cv_done;

@@ -115,19 +115,17 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
         if(fin) return;
     }
 }
-// VARIANT bit 0: UNI, bit 1: LIGHT (see inflate_member), bit 2: MIX -- odd members decode on the scalar unit, even ones on the vector
-// unit, so that both issue ports of a SIMD carry decoders (the choice is uniform per wavefront).
+// VARIANT bit 0: UNI, bit 1: LIGHT (see inflate_member).  (Measured and dropped, profiles/r03_inflate_experiments.json: odd members on
+// the scalar unit and even ones on the vector unit in one launch -- no faster than the slower of the two.)
 #ifndef INF_WAVES
-#define INF_WAVES 7
+#define INF_WAVES 6
 #endif
 template <int VARIANT>
 __global__ __launch_bounds__(64, INF_WAVES) void k_inflate(const InfParams P) {
-    constexpr bool LIGHT = (VARIANT & 2) != 0, MIX = (VARIANT & 4) != 0;
     __shared__ InfShared S;
     const int m = blockIdx.x, lane = threadIdx.x;
     if(m >= P.n_mem) return;
-    if(MIX) { if(m & 1) inflate_member<true, LIGHT>(P, S, m, lane); else inflate_member<false, LIGHT>(P, S, m, lane); }
-    else inflate_member<(VARIANT & 1) != 0, LIGHT>(P, S, m, lane);
+    inflate_member<(VARIANT & 1) != 0, (VARIANT & 2) != 0>(P, S, m, lane);
 }
 
 // ---- record framing ----
@@ -204,13 +202,11 @@ __global__ __launch_bounds__(1024) void k_walk_scan(const uint32_t *cnt, uint32_
 // host side: pieces
 // ------------------------------------------------------------------------------------------------
 static void launch_inflate(int variant, int n_mem, hipStream_t st, const InfParams &IP) {
-    switch(variant & 7) {
+    switch(variant & 3) {
     case 0: hipLaunchKernelGGL(k_inflate<0>, dim3(n_mem), dim3(64), 0, st, IP); break;
     case 1: hipLaunchKernelGGL(k_inflate<1>, dim3(n_mem), dim3(64), 0, st, IP); break;
     case 2: hipLaunchKernelGGL(k_inflate<2>, dim3(n_mem), dim3(64), 0, st, IP); break;
-    case 3: hipLaunchKernelGGL(k_inflate<3>, dim3(n_mem), dim3(64), 0, st, IP); break;
-    case 4: case 5: hipLaunchKernelGGL(k_inflate<4>, dim3(n_mem), dim3(64), 0, st, IP); break;
-    default: hipLaunchKernelGGL(k_inflate<6>, dim3(n_mem), dim3(64), 0, st, IP); break;
+    default: hipLaunchKernelGGL(k_inflate<3>, dim3(n_mem), dim3(64), 0, st, IP); break;
     }
 }
 #ifndef INF_DEFAULT_VARIANT
@@ -262,6 +258,7 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
        p->d_dig.need((size_t)n_mem) || p->h_dig.need((size_t)n_mem) || p->d_recoff.need((size_t)rec_cap)) return MDK_ERR_NOMEM;
     p->n_mem = n_mem; p->out_bytes = out_bytes; p->comp_bytes = comp_bytes; p->n_rec_cap = rec_cap;
     hipStream_t st = p->stream;
+    host_block_ensure_registered(comp);
     HIPCHK(hipMemcpyAsync(p->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->d_mem.p, mem, sizeof(md_inf_member) * (size_t)n_mem, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(p->d_status.p, 0, 16, st));
