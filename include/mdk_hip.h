@@ -340,6 +340,8 @@ void *md_host_alloc(uint64_t bytes);
  * on = 0 makes later md_host_alloc calls return pageable memory (the host does this for inputs of a few dozen chunks). */
 void  md_host_set_pinned(int on);
 void  md_host_free(void *p);
+/* what registering staging blocks has cost so far (seconds on the uploading threads, calls, bytes) */
+void  md_host_profile(double *seconds, uint64_t *calls, uint64_t *bytes);
 
 #ifdef __cplusplus
 }

@@ -203,6 +203,7 @@ int extract_main(int argc, char *argv[]) {
     }
     { double tw = now_s(); emitter_stop(&em); w_emit += now_s() - tw; }
     if(em.failed && !ret) ret = MDK_RC_OUTPUT;
+    if(getenv("MDK_HOST_PROFILE")) { double rs = 0; uint64_t rc2 = 0, rb = 0; md_host_profile(&rs, &rc2, &rb); fprintf(stderr, "[mdk main] staging blocks registered: %" PRIu64 " (%.0f MB) in %.3fs\n", rc2, rb / 1048576.0, rs); }
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0, n_host_prep);
     if(ret == 0) mdk_plan_finish(p);
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f (resident %.0f MB, of which file-backed/shared %.0f MB)\n", ts.tv_sec + 1e-9 * ts.tv_nsec, rss_mb(0), rss_mb(1)); }

@@ -31,6 +31,7 @@
 #include <atomic>
 #include <mutex>
 #include <algorithm>
+#include <chrono>
 #include "mdk_hip_internal.hpp"
 
 #define DEFAULT_TILE 2048
@@ -1292,6 +1293,7 @@ extern "C" int md_dev_debug_effective(md_dev *h, int slot, uint8_t *out_base, ui
 // of the block remembers which kind it is.  md_host_set_pinned(1) (default off in the commands) allocates with hipHostMalloc.
 struct HostBlock { char *base; size_t len; bool registered; };
 static std::mutex g_blocks_mu; static std::vector<HostBlock> g_blocks;       // sorted by base
+static double g_reg_seconds = 0; static uint64_t g_reg_calls = 0, g_reg_bytes = 0;
 static void *plain_alloc(size_t n) {
     void *p = nullptr;
     static const int thp = getenv("MDK_NO_THP") ? 0 : 1;
@@ -1317,8 +1319,12 @@ MDK_HIDDEN void host_block_ensure_registered(const void *ptr) {
     if(it == g_blocks.begin()) return;
     --it;
     if((char *)ptr >= it->base + it->len || it->registered) return;
+    const auto t0 = std::chrono::steady_clock::now();
     if(hipHostRegister(it->base, it->len, hipHostRegisterDefault) == hipSuccess) it->registered = true; else (void)hipGetLastError();      // a block that cannot be registered is uploaded pageable
+    g_reg_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); g_reg_calls++; g_reg_bytes += it->len;
 }
+// MDK_HOST_PROFILE: what registering the staging blocks cost
+extern "C" void md_host_profile(double *seconds, uint64_t *calls, uint64_t *bytes) { std::lock_guard<std::mutex> lk(g_blocks_mu); if(seconds) *seconds = g_reg_seconds; if(calls) *calls = g_reg_calls; if(bytes) *bytes = g_reg_bytes; }
 static std::atomic<int> g_want_pinned{1};
 extern "C" void md_host_set_pinned(int on) { g_want_pinned.store(on != 0); }
 extern "C" void *md_host_alloc(uint64_t bytes) {

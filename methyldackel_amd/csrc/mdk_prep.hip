@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void k_rebase(uint32_t *dst, const uint32_t *s
 static int copy_ranges(md_dev *h, Slot *s, const md_raw_batch *b) {
     bool any_dev = false; uint64_t nrec_sum = 0;
     for(int i = 0; i < b->n_ranges; i++) { if(b->range[i].d_rec_off) any_dev = true; nrec_sum += b->range[i].n_records; }
+    { uint64_t host_rec = 0; for(int i = 0; i < b->n_ranges; i++) if(!b->range[i].d_rec_off) host_rec += any_dev ? b->range[i].n_records : 0; if((any_dev ? host_rec : (uint64_t)b->n_records) && !b->rec_off) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null record table", hipSuccess); }
     if(any_dev && nrec_sum != (uint64_t)b->n_records) return fail(MDK_ERR_ARG, "md_dev_upload_raw: with a device-resident range every range must carry its record count", hipSuccess);
     uint64_t o = 0; uint32_t idx = 0, hidx = 0;
     for(int i = 0; i < b->n_ranges; i++) {
@@ -557,7 +558,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     Slot *s = get_slot(h, slot);
     if(!s || !b || b->n_records < 0 || b->n_ranges < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_upload_raw", hipSuccess);
     if(!h->prep_set) return fail(MDK_ERR_ARG, "md_dev_upload_raw: md_dev_set_prep was not called", hipSuccess);
-    if(b->n_records && (!b->range || !b->rec_off)) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null array", hipSuccess);
+    if(b->n_records && !b->range) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null array", hipSuccess);
     if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -597,7 +598,7 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     Slot *s = get_slot(h, slot);
     if(!s || !b || b->n_records < 0 || b->n_ranges < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw", hipSuccess);
     if(!h->prep_set || !h->prep.perread) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: md_dev_set_prep with perread first", hipSuccess);
-    if(b->n_records && (!b->range || !b->rec_off)) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: null array", hipSuccess);
+    if(b->n_records && !b->range) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: null array", hipSuccess);
     if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));

@@ -87,7 +87,11 @@ def test_piece_inflate_equals_zlib_and_record_walk(tmp_path):
             ref = zlib.decompress(raw[io:io + il], wbits=-15) if isz else b""
             assert len(ref) == isz and got.raw[tab[i].out_off:tab[i].out_off + isz] == ref, f"member {i}"
             w = walk(ref); g = info.digest[i]
-            assert w is not None and g.ok == 1 and g.first_rec == first
+            assert g.first_rec == first
+            if w is None:               # the member holding the BAM header (and the records behind it in the same member)
+                assert g.ok == 0 and g.n_rec == 0
+                continue
+            assert g.ok == 1
             offs, dg = w
             assert (g.n_rec, ) + ((g.tid0, g.pos0, g.tidN, g.posN, g.min_endp, g.max_endp, g.sorted) if offs else ()) == (dg[0], ) + (dg[1:] if offs else ())
             assert [recs[first + k] for k in range(len(offs))] == [tab[i].out_off + x for x in offs]
