@@ -57,6 +57,8 @@ void mdk_plan_dev_cfg(const mdk_plan *p, md_dev_cfg *cfg);
 int  mdk_plan_ensure_reference(mdk_plan *p, md_dev *dev, int32_t tid);
 /* 1: chunk produced; 0: schedule finished; <0: error */
 int  mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c);
+/* the same without waiting: 2 (nothing handed out) when the next chunk of the schedule is not ready yet */
+int  mdk_plan_try_next_chunk(mdk_plan *p, mdk_chunk *c);
 /* Where a chunk's per-record work happens.  mode 0 (what mdk_plan_open gives): on the host -- chunks carry `batch`.
  * mode 1 (what the commands use): on the device -- chunks carry `raw`, and md_dev_set_prep must be given
  * mdk_plan_prep_cfg's configuration (plus md_dev_set_mappability per contig, done by mdk_plan_ensure_reference).

@@ -157,6 +157,9 @@ int  md_dev_read_raw(md_dev *h, int slot, uint8_t *bytes, uint64_t *n_bytes, uin
 /* The preparation kernels of a slot uploaded with md_dev_upload_raw, re-run `iters` times on the resident records and timed
  * with HIP events (the slot's segments are the same afterwards). */
 int  md_dev_bench_prep(md_dev *h, int slot, int warmup, int iters, float *ms_per_chunk);
+/* the same over `n` uploaded raw slots holding different intervals, `per_launch` chunks per launch of each preparation kernel (as
+ * md_dev_launch_group prepares them), round robin on one stream: ms per LAUNCH when the records stream from HBM */
+int  md_dev_bench_prep_rotate(md_dev *h, const int *slots, int n, int per_launch, int warmup, int iters, float *ms_per_launch);
 /* Test hook: the segments the device built for an uploaded slot (off4 / m_off4 are BYTE offsets into the uploaded records,
  * qualities follow the sequence without padding), their number, and the number of admitted reads. */
 int  md_dev_debug_segments(md_dev *h, int slot, md_seg *out, int64_t cap, int64_t *n_segs, int64_t *n_reads);
@@ -261,9 +264,10 @@ int  md_dev_perread_download_raw(md_dev *h, int slot, const uint32_t **kept, con
 int  md_dev_upload(md_dev *h, int slot, const md_read_batch *b);
 int  md_dev_launch(md_dev *h, int slot);
 int  md_dev_submit(md_dev *h, int slot, const md_read_batch *b);
-/* One kernel launch over several uploaded slots (at most md_dev_group_max() = 8, all different): a 1 Mb chunk alone is
- * fewer than two workgroups per CU, so resident chunks are launched together; each keeps its own reads, outputs and site
- * counter, and download / wait are per slot as after md_dev_launch. */
+/* One launch of each kernel over several uploaded slots (at most md_dev_group_max() = 8, all different): a 1 Mb chunk alone is
+ * fewer than two workgroups per CU, so chunks are launched together -- the preparation kernels of the slots uploaded with
+ * md_dev_upload_raw (queued here, not at upload) and the pileup; each chunk keeps its own reads, outputs and site counter, and
+ * download / wait are per slot as after md_dev_launch. */
 int  md_dev_launch_group(md_dev *h, const int *slots, int n);
 int  md_dev_group_max(void);
 int  md_dev_download(md_dev *h, int slot, md_sites *out);
@@ -325,6 +329,9 @@ typedef struct md_bench md_bench;
 typedef struct { uint64_t launches, slots_last, exchanges, bytes_per_exchange; } md_bench_run_result;
 int  md_bench_open(md_dev *h, md_comm *comm /* NULL: one GPU */, const int *slots, int n, int group, md_bench **out);
 int  md_bench_run(md_bench *b, int64_t launches, md_bench_run_result *out);
+/* on = 1 (default when the slots hold raw records): every launch of md_bench_run prepares its chunks again from their resident
+ * records before the pileup -- the whole device work `extract` does per chunk; on = 0: the pileup alone over the resident segments */
+int  md_bench_set_prep(md_bench *b, int on);
 int  md_bench_verify(md_bench *b);
 int64_t md_bench_region_bytes(const md_bench *b);
 void md_bench_close(md_bench *b);

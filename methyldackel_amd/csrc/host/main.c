@@ -60,12 +60,19 @@ int main(int argc, char *argv[]) {
         const char *g = getenv("MDK_GPUS"), *dv = getenv("MDK_DEVICE");
         if(!g || !*g || !strcmp(g, "1")) (void)mdk_bind_to_device_node(dv ? atoi(dv) : 0);
     }
-    if(!strcmp(argv[1], "extract")) {
-        setenv("MDK_FAST_EXIT", "1", 0);      /* a process about to end need not unpin buffers and shut the runtime down politely */
-        return run_detached(extract_main, argc - 1, argv + 1);
+    {   /* a process about to end need not unpin buffers and shut the runtime down politely (MDK_FAST_EXIT: the command leaves with
+         * _exit once its outputs are closed).  A command that comes BACK here returned early -- a bad option, a missing input -- possibly
+         * while the thread that warms the HIP runtime up is still inside hipInit: leave with _exit as well, so that no exit handler or
+         * static destructor runs under that thread's feet and the command's own return code is what the caller sees. */
+        int (*cmd)(int, char **) = !strcmp(argv[1], "extract") ? extract_main : !strcmp(argv[1], "mbias") ? mbias_main : !strcmp(argv[1], "perRead") ? perRead_main : NULL;
+        if(cmd) {
+            int rc;
+            setenv("MDK_FAST_EXIT", "1", 0);
+            rc = run_detached(cmd, argc - 1, argv + 1);
+            fflush(stdout); fflush(stderr);
+            _exit(rc & 0xff);
+        }
     }
-    if(!strcmp(argv[1], "mbias")) { setenv("MDK_FAST_EXIT", "1", 0); return run_detached(mbias_main, argc - 1, argv + 1); }
-    if(!strcmp(argv[1], "perRead")) { setenv("MDK_FAST_EXIT", "1", 0); return run_detached(perRead_main, argc - 1, argv + 1); }
     if(!strcmp(argv[1], "mergeContext")) return mergeContext_main(argc - 1, argv + 1);
     fprintf(stderr, "Unknown command!\n"); usage_main(); return -1;
 }

@@ -43,6 +43,10 @@ int mdk_bind_to_device_node(int index) {
     const char *root = getenv("MDK_SYSFS_DRM") ? getenv("MDK_SYSFS_DRM") : "/sys/class/drm";
     DIR *d; struct dirent *e; gpu_ent *g = NULL; int ng = 0, cap = 0, bound = 0; char path[PATH_MAX + 64], line[4096];
     cpu_set_t local, cur, both; int n_cur, n_both;
+    /* a *_VISIBLE_DEVICES variable renumbers (and may hide) devices: the HIP index then says nothing about the sysfs order, and a
+     * wrong guess pins every thread of the command to the far socket -- float instead */
+    { static const char *const vis[] = {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"}; int k;
+      for(k = 0; k < 4; k++) { const char *v = getenv(vis[k]); if(v && *v) return 0; } }
     if(getenv("MDK_NO_BIND") || index < 0 || !(d = opendir(root))) return 0;
     while((e = readdir(d)) != NULL) {          /* card<N> (not card<N>-<connector>) of vendor 0x1002, in PCI address order = HIP's default order */
         const char *p = e->d_name; gpu_ent x;

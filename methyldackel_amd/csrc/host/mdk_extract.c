@@ -132,9 +132,17 @@ static int extract_multi(mdk_plan *p, int N, const int *map) {
     return ret;
 }
 
+/* Chunks travel to the device in GROUPS of up to MDK_GROUP: a 1 Mb chunk alone is fewer than two workgroups per CU and pays every
+ * launch boundary itself, so whatever the reader has ready when a group is opened (at least one chunk, at most eight) is uploaded
+ * into the group's slots and prepared and piled up with one launch per kernel (md_dev_launch_group); while that runs, the next
+ * group is assembled, then the finished one is collected chunk by chunk in schedule order and handed to the emitter.  The
+ * reference's unit of work is the chunk (extract.c:325-350); here it is the unit of scheduling and of output only. */
+#define MDK_GROUP 8
+typedef struct { mdk_chunk ch[MDK_GROUP]; int slot[MDK_GROUP]; int n, launched[MDK_GROUP]; } cgroup;
+
 int extract_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; mdk_chunk ch[2]; int have[2] = {0, 0}; int rc, k = 0, ret = 0, more = 1; devopen_t dop; pthread_t dth; int dth_ok; emitter em;
-    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta; int n_host_prep = 0;
+    mdk_plan *p = NULL; md_dev *dev = NULL; cgroup *G = NULL; int rc, ret = 0, more = 1, cur = 0, i; devopen_t dop; pthread_t dth; int dth_ok; emitter em;
+    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta; int n_host_prep = 0; uint64_t n_groups = 0, n_chunks = 0;
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] entered at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
     if(argc > 2) hip_warm_up();
     rc = mdk_plan_open(argc, argv, &p);
@@ -144,11 +152,13 @@ int extract_main(int argc, char *argv[]) {
     /* HIP initialisation takes a few hundred ms: do it while the host pipeline already inflates and packs */
     memset(&dop, 0, sizeof(dop));
     mdk_plan_dev_cfg(p, &dop.cfg);
+    dop.cfg.n_slots = 2 * MDK_GROUP;
     if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
     /* the per-record work of a chunk (admission, strand, name pairing, CIGAR expansion) runs on the device; MDK_HOST_PREP=1 keeps
      * it on the host's chunk workers (the round-1 arrangement, and what a chunk the device gives up on falls back to) */
     if(!getenv("MDK_HOST_PREP")) mdk_plan_set_prep(p, 1);
     { int map[MDK_MAX_GPUS], n = parse_gpus(map); if(n < 0) { mdk_plan_close(p); return MDK_RC_NODEVICE; } if(n > 1) { mdk_plan_set_hold(p, 2 * n + 1); return extract_multi(p, n, map); } }
+    mdk_plan_set_hold(p, 2 * MDK_GROUP + 1);
     dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
     if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
@@ -157,36 +167,48 @@ int extract_main(int argc, char *argv[]) {
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); mdk_plan_attach_device(p, dev); }      /* from here on the device inflates pieces of the file too */
-    if(emitter_start(&em, p, emit_threads(p))) { mdk_plan_detach_device(p); md_dev_close(dev); mdk_plan_close(p); return -5; }
-    /* two chunks in flight: build+submit chunk k while chunk k-1 finishes on the device, then hand k-1 to the emitter */
-    while(more || have[0] || have[1]) {
-        int cur = k & 1, prev = cur ^ 1;
-        if(more) {
+    G = calloc(2, sizeof(cgroup));
+    if(!G || emitter_start(&em, p, emit_threads(p))) { free(G); mdk_plan_detach_device(p); md_dev_close(dev); mdk_plan_close(p); return -5; }
+    for(i = 0; i < MDK_GROUP; i++) { G[0].slot[i] = i; G[1].slot[i] = MDK_GROUP + i; }
+    while(more || G[0].n || G[1].n) {
+        cgroup *g = &G[cur], *o = &G[cur ^ 1];
+        /* open a group: the first chunk is waited for, the others are taken only if they are ready now */
+        g->n = 0;
+        while(more && g->n < MDK_GROUP) {
+            mdk_chunk *c = &g->ch[g->n];
             ta = now_s();
-            rc = mdk_plan_next_chunk(p, &ch[cur]);
+            rc = g->n == 0 ? mdk_plan_next_chunk(p, c) : mdk_plan_try_next_chunk(p, c);
             w_next += now_s() - ta;
+            if(rc == 2) break;
             if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
-            if(rc == 0) more = 0;
-            else {
-                if(!ch[cur].skipped) {
-                    ta = now_s();
-                    rc = mdk_plan_ensure_reference(p, dev, ch[cur].tid);
-                    if(!rc) rc = ch[cur].prep ? md_dev_submit_raw(dev, cur, &ch[cur].raw) : md_dev_submit(dev, cur, &ch[cur].batch);
-                    w_sub += now_s() - ta;
-                    if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
-                }
-                have[cur] = 1;
-            }
-        }
-        if(have[prev]) {
-            md_sites sites; memset(&sites, 0, sizeof(sites));
-            if(!ch[prev].skipped) {
+            if(rc == 0) { more = 0; break; }
+            g->launched[g->n] = 0;
+            if(!c->skipped) {
                 ta = now_s();
-                rc = md_dev_download(dev, prev, &sites);
+                rc = mdk_plan_ensure_reference(p, dev, c->tid);
+                if(!rc) rc = c->prep ? md_dev_upload_raw(dev, g->slot[g->n], &c->raw) : md_dev_upload(dev, g->slot[g->n], &c->batch);
+                w_sub += now_s() - ta;
+                if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+                g->launched[g->n] = 1;
+            }
+            g->n++; n_chunks++;
+        }
+        if(ret) break;
+        {   /* one launch per kernel for the group's chunks */
+            int ls[MDK_GROUP], nl = 0;
+            for(i = 0; i < g->n; i++) if(g->launched[i]) ls[nl++] = g->slot[i];
+            if(nl) { ta = now_s(); rc = md_dev_launch_group(dev, ls, nl); w_sub += now_s() - ta; n_groups++; if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; } }
+        }
+        /* collect the group before it, in schedule order */
+        for(i = 0; i < o->n && !ret; i++) {
+            md_sites sites; memset(&sites, 0, sizeof(sites));
+            if(o->launched[i]) {
+                ta = now_s();
+                rc = md_dev_download(dev, o->slot[i], &sites);
                 if(rc == MDK_ERR_PREP_HOST) {          /* a read name the device preparation does not handle: this chunk the slow way */
-                    rc = mdk_plan_host_prepare_from(p, &ch[prev], dev, prev);
-                    if(!rc) rc = md_dev_submit(dev, prev, &ch[prev].batch);
-                    if(!rc) rc = md_dev_download(dev, prev, &sites);
+                    rc = mdk_plan_host_prepare_from(p, &o->ch[i], dev, o->slot[i]);
+                    if(!rc) rc = md_dev_submit(dev, o->slot[i], &o->ch[i].batch);
+                    if(!rc) rc = md_dev_download(dev, o->slot[i], &sites);
                     n_host_prep++;
                 }
                 w_down += now_s() - ta;
@@ -194,25 +216,25 @@ int extract_main(int argc, char *argv[]) {
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
             }
             ta = now_s();
-            if(emitter_push(&em, &ch[prev], &sites)) { ret = MDK_RC_DEVICE; break; }
+            if(emitter_push(&em, &o->ch[i], &sites)) { ret = MDK_RC_DEVICE; break; }
             w_emit += now_s() - ta;
-            have[prev] = 0;
         }
-        k++;
-        if(!more && !have[0] && !have[1]) break;
+        o->n = 0;
+        if(ret) break;
+        cur ^= 1;
     }
     { double tw = now_s(); emitter_stop(&em); w_emit += now_s() - tw; }
     if(em.failed && !ret) ret = MDK_RC_OUTPUT;
-    if(getenv("MDK_HOST_PROFILE")) { double rs = 0; uint64_t rc2 = 0, rb = 0; md_host_profile(&rs, &rc2, &rb); fprintf(stderr, "[mdk main] staging blocks registered: %" PRIu64 " (%.0f MB) in %.3fs\n", rc2, rb / 1048576.0, rs); }
+    if(getenv("MDK_HOST_PROFILE")) { double rs = 0; uint64_t rc2 = 0, rb = 0; md_host_profile(&rs, &rc2, &rb); fprintf(stderr, "[mdk main] staging blocks registered: %" PRIu64 " (%.0f MB) in %.3fs; %" PRIu64 " chunks in %" PRIu64 " group launches\n", rc2, rb / 1048576.0, rs, n_chunks, n_groups); }
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0, n_host_prep);
     if(ret == 0) mdk_plan_finish(p);
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f (resident %.0f MB, of which file-backed/shared %.0f MB)\n", ts.tv_sec + 1e-9 * ts.tv_nsec, rss_mb(0), rss_mb(1)); }
     if(fast_exit_wanted()) leave_fast(ret);
     { double tc = now_s(), td;
+      free(G);
       mdk_plan_detach_device(p);
       md_dev_close(dev); td = now_s();
       mdk_plan_close(p);
       if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] device closed in %.3fs, plan (slabs, reference, mapped file) in %.3fs\n", td - tc, now_s() - td); }
     return ret;
 }
-

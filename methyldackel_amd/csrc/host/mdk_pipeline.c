@@ -727,16 +727,14 @@ MDK_LOCAL void pipeline_stop(mdk_plan *p) {
     pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_free); pthread_cond_destroy(&p->cv_raw); pthread_cond_destroy(&p->cv_done);
 }
 
-int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
+static int next_chunk_ex(mdk_plan *p, mdk_chunk *c, int nonblock);
+int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) { return next_chunk_ex(p, c, 0); }
+/* the same, but 2 (and nothing handed out) when the next chunk of the schedule is not ready yet */
+int mdk_plan_try_next_chunk(mdk_plan *p, mdk_chunk *c) { return next_chunk_ex(p, c, 1); }
+static int next_chunk_ex(mdk_plan *p, mdk_chunk *c, int nonblock) {
     int i, found = -1, rc = 0;
     if(!p->started && pipeline_start(p)) return -5;
     pthread_mutex_lock(&p->mu);
-    {   /* the oldest chunk still held is no longer referenced by the caller: recycle its buffers */
-        const int last = p->n_hold - 1;
-        if(p->held[last] >= 0) { slot_release_slabs(p, &p->slot[p->held[last]]); p->slot[p->held[last]].state = S_FREE; pthread_cond_signal(&p->cv_free); }
-        for(i = last; i > 0; i--) p->held[i] = p->held[i - 1];
-        p->held[0] = -1;
-    }
     for(;;) {
         int active = 0;
         for(i = 0; i < p->n_slot; i++) {
@@ -747,10 +745,17 @@ int mdk_plan_next_chunk(mdk_plan *p, mdk_chunk *c) {
         if(found >= 0) break;
         if(p->pipe_rc < 0) { rc = p->pipe_rc; break; }
         if(p->reader_done && !active) { rc = 0; break; }
+        if(nonblock) { pthread_mutex_unlock(&p->mu); return 2; }
         pthread_cond_wait(&p->cv_done, &p->mu);
     }
     if(found >= 0) {
         pslot *sl = &p->slot[found];
+        {   /* the oldest chunk still held is no longer referenced by the caller: recycle its buffers */
+            const int last = p->n_hold - 1;
+            if(p->held[last] >= 0) { slot_release_slabs(p, &p->slot[p->held[last]]); p->slot[p->held[last]].state = S_FREE; pthread_cond_signal(&p->cv_free); }
+            for(i = last; i > 0; i--) p->held[i] = p->held[i - 1];
+            p->held[0] = -1;
+        }
         if(sl->rc < 0) rc = sl->rc; else { *c = sl->c; rc = 1; }
         sl->state = S_HELD; p->held[0] = found; p->next_out++;
     }

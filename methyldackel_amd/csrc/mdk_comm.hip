@@ -209,7 +209,7 @@ struct md_bench {
     int64_t cap = 0, tcap = 0; size_t E = 0, off_var = 0, off_seg = 0;       // one chunk's region: sites, [var], tile segments
     uint8_t *send[2] = {nullptr, nullptr}; std::vector<uint8_t *> recv[2]; bool pending[2] = {false, false};
     hipStream_t stream = nullptr; hipEvent_t done[2] = {nullptr, nullptr};      // every launch goes to this one stream, followed by the copy of its status blocks and an event
-    int64_t last_g = -1;
+    int64_t last_g = -1; bool prep = false;      // prep: every launch prepares its chunks again from their resident raw records
 };
 
 extern "C" void md_bench_close(md_bench *b) {
@@ -261,6 +261,7 @@ extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, 
     }
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     for(int x = 0; x < 2; x++) HIPCHK(hipEventCreateWithFlags(&b->done[x], hipEventDisableTiming));
+    b->prep = true; for(int i : b->slots) if(!get_slot(h, i)->raw_layout) b->prep = false;
     b->cap += 64; b->tcap += 1;
     b->off_var = (size_t)b->cap * sizeof(md_site);
     b->off_seg = b->off_var + (h->variant ? (size_t)b->cap * sizeof(md_site_var) : 0);
@@ -283,6 +284,12 @@ extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, 
 }
 
 extern "C" int64_t md_bench_region_bytes(const md_bench *b) { return b ? (int64_t)b->E : MDK_ERR_ARG; }
+extern "C" int md_bench_set_prep(md_bench *b, int on) {
+    if(!b) return MDK_ERR_ARG;
+    if(on) for(int i : b->slots) if(!get_slot(b->h, i)->raw_layout) return fail(MDK_ERR_ARG, "md_bench_set_prep: the slots hold host-built batches", hipSuccess);
+    b->prep = on != 0;
+    return 0;
+}
 
 static int bench_exchange(md_bench *b, int x) {
     if(!b->comm) return 0;
@@ -321,7 +328,8 @@ extern "C" int md_bench_run(md_bench *b, int64_t launches, md_bench_run_result *
         for(int i = 0; i < K; i++) {
             uint8_t *base = b->send[x] + (size_t)i * b->E;
             int rc = md_dev_bind_output(h, gs[i], base, h->variant ? base + b->off_var : nullptr, base + b->off_seg, b->cap, b->tcap); if(rc) return rc;
-            const int idx = get_slot(h, gs[i])->index; if(idx < lo) lo = idx; if(idx > hi) hi = idx;
+            Slot *sl = get_slot(h, gs[i]); const int idx = sl->index; if(idx < lo) lo = idx; if(idx > hi) hi = idx;
+            if(b->prep) sl->prep_pending = true;             // the launch below then runs the preparation kernels of its chunks first
         }
         int rc = launch_group_on(h, gs, K, b->stream, true); if(rc) return rc;
         HIPCHK(hipMemcpyAsync(h->h_status.p + lo, h->d_status.p + lo, sizeof(SlotStatus) * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, b->stream));

@@ -496,7 +496,6 @@ __global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup(const KParams P) { 
 // a 1 Mb chunk is 489 tiles -- fewer than two workgroups per CU, one short generation whose dispatch ramp and barrier tail
 // are a third of its time -- so resident chunks are launched MAXM at a time.  The per-interval parameters travel in the
 // kernel arguments; a workgroup finds its interval from the tile prefix.
-#define MAXM 8
 struct KMulti { int n, nper; int tstart[MAXM + 1]; KParams P[MAXM]; };
 template <bool VARIANT, bool QW>
 __global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup_multi(const KMulti M) {
@@ -710,8 +709,8 @@ extern "C" void md_dev_close(md_dev *h) {
     (void)hipDeviceSynchronize();
     for(auto &s : h->slots) {
         s.d_seg_in.release(); s.d_blob.release(); s.d_tiles.release(); s.h_tiles.release();
-        s.d_raw.release(); s.d_recoff.release(); s.d_prec.release(); s.d_hash.release(); s.d_blk.release(); s.d_prd.release(); s.d_mate.release(); s.d_second.release();
-        s.d_segcnt.release(); s.d_aidx.release(); s.h_aidx.release(); s.d_hkey.release(); s.d_hhead.release(); s.d_hnext.release();
+        s.d_raw.release(); s.d_recoff.release(); s.d_prd.release(); s.d_nslot.release(); s.d_zero.release();
+        s.d_aidx.release(); s.h_aidx.release(); s.d_hnext.release();
         s.d_pr.release(); s.d_cig.release(); s.d_prc.release(); s.h_prc.release();
         s.d_site.release(); s.d_var.release(); s.d_seg.release();
         s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release();
@@ -854,7 +853,8 @@ static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
 // `on` = stream to launch on (the slot's own unless a benchmark lines several slots up on one stream)
 int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on) {
     hipStream_t st = on ? on : s->stream;
-    if(s->fresh && st != s->stream) { HIPCHK(hipEventRecord(s->e0, s->stream)); HIPCHK(hipStreamWaitEvent(st, s->e0, 0)); }      // the slot's upload / preparation comes first
+    if(s->fresh && st != s->stream) { HIPCHK(hipEventRecord(s->e0, s->stream)); HIPCHK(hipStreamWaitEvent(st, s->e0, 0)); }      // the slot's upload comes first
+    if(s->raw_layout && s->prep_pending) { Slot *one[1] = {s}; int rc = enqueue_prep_group(h, one, 1, st); if(rc) return rc; }       // its preparation, then the pileup
     s->fresh = false; s->run = st;
     s->ring++;                                          // a fresh (already zero) site counter for this launch
     if(s->ntiles > 0) {
@@ -903,6 +903,11 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
         s->fresh = false; s->run = st;
     }
     M.n = n; M.tstart[n] = total; M.nper = (total + 7) / 8;
+    {   // chunks whose records were uploaded but not prepared yet: their preparation kernels, all chunks per launch
+        Slot *pend[MAXM]; int np = 0;
+        for(int i = 0; i < n; i++) { Slot *s = get_slot(h, slots[i]); if(s->raw_layout && s->prep_pending) pend[np++] = s; }
+        if(np) { int rc = enqueue_prep_group(h, pend, np, st); if(rc) return rc; }
+    }
     if(total > 0) {
         launch_pileup_multi(h, M.nper * 8, (size_t)s0->lds_bytes, st, M);
         HIPCHK(hipGetLastError());
@@ -968,6 +973,7 @@ extern "C" int md_dev_mbias_submit_raw(md_dev *h, int slot, const md_raw_batch *
     int rc = md_dev_upload_raw(h, slot, b);
     if(rc) return rc;
     Slot *s = get_slot(h, slot);
+    { Slot *one[1] = {s}; rc = enqueue_prep_group(h, one, 1, s->stream); if(rc) return rc; }
     HIPCHK(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
     rc = prep_outcome(h, s);

@@ -14,6 +14,7 @@
 #endif
 #define WAVES (WG / 64)
 #define RING 64                    // site counters: launch i uses counter i%RING and clears the next one
+#define MAXM 8                     // chunks one launch (preparation or pileup) covers at most
 
 #define MDK_HIDDEN __attribute__((visibility("hidden")))
 MDK_HIDDEN char *mdk_err_buf();            // the calling thread's message buffer (512 bytes), what md_dev_last_error returns
@@ -51,7 +52,6 @@ template <typename T> struct HBuf {
 };
 
 // device chunk preparation (mdk_prep.hip)
-struct PrepRec  { int32_t pos, rend; uint32_t seq_off, lq, cig_off, qn_off; uint16_t ncig, flag; uint8_t strand, lqname, adm, pad; };    // one candidate record
 struct PrepRead { int32_t pos, rend; uint32_t seq_off, lq, cig_off, qn_off; uint16_t ncig, flag; uint8_t strand, lqname; uint16_t pad; };  // one admitted read, file order
 struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, max_lq; uint64_t algo_bytes; };      // max_lq: longest admitted read (mbias sizes its histogram by it)
 #define MDK_ERR_PREP_REDO (-100)   // internal: the segment array was enlarged and the preparation re-enqueued
@@ -68,9 +68,10 @@ struct Slot {
     DBuf<md_site> d_site; DBuf<md_site_var> d_var; DBuf<md_tile_seg> d_seg; Ref<uint32_t> d_total; Ref<int> d_err;
     HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; Ref<SlotStatus> h_st; int index = 0;
     hipStream_t run = nullptr; bool fresh = false;       // run: the stream the latest pileup launch went to; fresh: work queued on `stream` that no launch has been ordered after yet
-    DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRec> d_prec; DBuf<uint64_t> d_hash; DBuf<uint32_t> d_blk; DBuf<PrepRead> d_prd; DBuf<int32_t> d_mate; DBuf<uint8_t> d_second;
-    DBuf<uint32_t> d_segcnt, d_aidx; HBuf<uint32_t> h_aidx; DBuf<uint64_t> d_hkey; DBuf<int32_t> d_hhead, d_hnext; Ref<PrepCounters> d_pcnt;
+    DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRead> d_prd; DBuf<uint32_t> d_nslot, d_aidx; HBuf<uint32_t> h_aidx; DBuf<int32_t> d_hnext; Ref<PrepCounters> d_pcnt;
+    DBuf<uint8_t> d_zero;              // what a preparation launch starts from zeroed: name table (keys, heads), per-workgroup counts, tickets
     uint32_t hmask = 0; int pr_nrec = 0; uint64_t raw_bytes = 0; bool raw_layout = false; int64_t woff = 0, wlen = 0;
+    bool prep_pending = false;         // records uploaded, preparation kernels not yet queued (they go with the launch, several chunks at a time)
     DBuf<md_pr_read> d_pr; DBuf<uint32_t> d_cig; DBuf<md_pr_count> d_prc; HBuf<md_pr_count> h_prc; int pr_n = -1;      // perRead
     // caller-bound output (device memory owned by the caller)
     md_site *b_site = nullptr; md_site_var *b_var = nullptr; md_tile_seg *b_seg = nullptr; int64_t b_cap_sites = 0, b_cap_tiles = 0;
@@ -138,4 +139,5 @@ MDK_HIDDEN int64_t finish_count(md_dev *h, Slot *s);
 MDK_HIDDEN int64_t finish_eval(md_dev *h, Slot *s);      // the status block is already on the host
 MDK_HIDDEN int finish_group(md_dev *h, const int *slots, int n, int64_t *counts);
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s);
+MDK_HIDDEN int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st);      // preparation kernels of up to MAXM uploaded raw slots, one launch each kernel
 #endif

@@ -1,18 +1,23 @@
 // mdk_prep.hip -- chunk preparation on the device: from the inflated BAM records of a chunk, as they lie in the file, to
-// the segment array k_pileup consumes.  What the reference does for this inside htslib's iterator and pileup buffer:
+// the segment array k_pileup consumes.  What the reference does for this inside htslib's iterator and pileup buffer, in TWO kernels
+// per launch, each over up to 8 chunks at once (a 1 Mb chunk is ~780 workgroups: alone it leaves the machine half empty and every
+// launch boundary is paid per chunk):
 //
-//   k_rec_scan   one lane per BAM record: the record's fields, its CIGAR (reference length, bam_cigar2rlen), the aux walk
-//                for NH and XG (bam_aux_get), getStrand (common.c:84-116) and filter_func's admission tests in its order
-//                (common.c:416-444: unmapped, MAPQ, -F, -R, duplicates, NH, mappability windows, singleton, discordant,
-//                BED span, conversion efficiency); a 64-bit hash of the read name for the pairing.
-//   k_compact    stream compaction of the admitted records, file order kept (it is the order bam_plp_push sees them in),
-//                and insertion into a name-keyed hash table (what khash does in custom_overlap_constructor).
-//   k_pair       one lane per name: the records of a name in file order go through the constructor/destructor state
+//   k_prep_scan  one lane per BAM record: the record's fields (dword loads at the record's own alignment), its CIGAR (reference
+//                length, bam_cigar2rlen), the aux walk for NH and XG (bam_aux_get), getStrand (common.c:84-116) and filter_func's
+//                admission tests in its order (common.c:416-444: unmapped, MAPQ, -F, -R, duplicates, NH, mappability windows,
+//                singleton, discordant, BED span, conversion efficiency).  The admitted records are compacted IN FILE ORDER (the
+//                order bam_plp_push sees them in) inside the same kernel: a workgroup draws a ticket, publishes its count, and adds
+//                up the counts of the tickets before it -- they all belong to workgroups that are already running, so nobody waits
+//                for a workgroup that has not started.  Each admitted read goes into a name-keyed hash table (what khash does in
+//                custom_overlap_constructor).
+//   k_prep_segs  one lane per admitted read: the records of its name, in file order, go through the constructor/destructor state
 //                machine of overlaps.c:121-147 *including* htslib's buffer eviction (a read leaves the pileup buffer once a
-//                later read starts beyond its end, and its destructor erases the name): who is resolved against whom.
-//   k_segments   one lane per admitted read: CIGAR -> gapless runs (calculate_positions, overlaps.c:27-52; htslib
-//                resolve_cigar2), cut where the partner's runs begin and end, clipped to the chunk; counted, scanned,
-//                written; every segment also widens the [first,last) run of the tiles it touches.
+//                later read starts beyond its end, and its destructor erases the name) -- every read of a name runs the few
+//                steps of its own group, which is cheaper than a launch of its own; then CIGAR -> gapless runs
+//                (calculate_positions, overlaps.c:27-52; htslib resolve_cigar2), cut where the partner's runs begin and end,
+//                clipped to the chunk: counted, placed by the same ticket scheme, written; every segment also widens the
+//                [first,last) run of the tiles it touches.
 //
 // Nothing is copied: segments address sequence and qualities inside the uploaded record bytes (MDK layout 1, see
 // KParams::unit/packed in mdk_hip.hip).  A name with more records than a lane keeps in registers, or more live reads than
@@ -23,9 +28,10 @@
 #define PB 256                       // threads per block of the per-record kernels
 #define MAXG 16                      // records of one name a lane sorts in registers
 #define MAXLIVE 8                    // reads of one name alive in the pileup buffer at once
+#define CNT_READY 0x80000000u        // a workgroup's published count: this bit | count
 
-__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
-__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }       // the hardware reads at any alignment
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
 struct PrepParams {
     const uint8_t *raw; uint64_t raw_bytes; const uint32_t *rec_off; int n_rec;
@@ -33,15 +39,15 @@ struct PrepParams {
     const char *ref; int64_t reflen;                 // contig letters (conversion efficiency)
     const uint32_t *mapbits; int64_t maplen;         // 1 bit per base, or NULL
     const md_region *runs; int64_t nruns; int bed_on;
-    PrepRec *rec; uint64_t *hash;                    // per candidate record
-    uint32_t *blockcnt, *blockoff; int nblocks;
-    PrepRead *rd; int32_t *mate; uint8_t *second; uint32_t *aidx;    // per admitted read (aidx: its index among the candidate records)
-    uint64_t *hkey; int32_t *hhead, *hnext; uint32_t hmask;
-    uint32_t *segcnt; uint32_t *segblk, *segblkoff;  // per admitted read / per block
+    PrepRead *rd; uint32_t *slot; uint32_t *aidx;    // per admitted read: the read, its slot in the name table, (perRead) its index among the candidate records
+    uint64_t *hkey; int32_t *hhead, *hnext; uint32_t hmask;      // hhead: index + 1 of the name's latest read, 0 = empty
+    uint32_t *cntA, *cntS, *ticket; int nblocks;     // per workgroup: published counts of admitted reads / segments; two ticket counters
     md_seg *seg; int64_t cap_seg;
     TileEnt *tiles; int ntiles, tile;
     PrepCounters *cnt;
+    uint8_t *zero; uint64_t zero_bytes;              // what a launch starts from zeroed: name table, counts, tickets
 };
+struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 
 // ---- aux area: first NH and first XG, as bam_aux_get finds them; a malformed area ends the walk ----
 __device__ void scan_aux(const uint8_t *s, const uint8_t *e, const uint8_t *&nh, const uint8_t *&xg) {
@@ -153,12 +159,50 @@ done:
     return nu / ((float)(nm + nu));
 }
 
-__global__ __launch_bounds__(PB) void k_rec_scan(const PrepParams P) {
-    __shared__ uint32_t wcnt[PB / 64];
-    const int i = blockIdx.x * PB + threadIdx.x;
-    int adm = 0;
+// sum over the lanes of a workgroup (PB threads); every thread gets the result
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *red) {
+#pragma unroll
+    for(int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    if((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+#pragma unroll
+    for(int w = 0; w < PB / 64; w++) t += red[w];
+    __syncthreads();
+    return t;
+}
+// what the workgroups holding earlier tickets counted, added up (they are running: a ticket is drawn by a workgroup that has started)
+__device__ __forceinline__ uint32_t tickets_before(const uint32_t *cnt, uint32_t tk, uint32_t *red) {
+    uint32_t part = 0;
+    for(uint32_t q = threadIdx.x; q < tk; q += PB) {
+        uint32_t v;
+        while(!((v = __hip_atomic_load(&cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & CNT_READY)) __builtin_amdgcn_s_sleep(1);
+        part += v & ~CNT_READY;
+    }
+    return block_sum(part, red);
+}
+
+// everything a launch starts from zeroed, for all its chunks (one launch instead of two memsets per chunk)
+__global__ __launch_bounds__(PB) void k_prep_zero(const PrepMulti M) {
+    for(int j = 0; j < M.n; j++) {
+        const PrepParams &P = M.P[j];
+        uint4 *z = (uint4 *)P.zero; const uint64_t n16 = P.zero_bytes >> 4;
+        for(uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * PB) z[i] = make_uint4(0, 0, 0, 0);
+        for(int t = blockIdx.x * PB + threadIdx.x; t < P.ntiles; t += gridDim.x * PB) { P.tiles[t].first = 0x7fffffff; P.tiles[t].last = 0; }      // the tile runs start empty
+        if(blockIdx.x == 0 && threadIdx.x < sizeof(PrepCounters) / 4) ((uint32_t *)P.cnt)[threadIdx.x] = 0;
+    }
+}
+
+__global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
+    __shared__ uint32_t s_tk, wcnt[PB / 64], red[PB / 64];
+    int j = 0;
+    while(j + 1 < M.n && (int)blockIdx.x >= M.bstart[j + 1]) j++;
+    const PrepParams &P = M.P[j];
+    if(threadIdx.x == 0) s_tk = atomicAdd(&P.ticket[0], 1u);
+    __syncthreads();
+    const uint32_t tk = s_tk; const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int adm = 0; PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
     if(i < P.n_rec) {
-        PrepRec R; memset(&R, 0, sizeof(R));
         const uint64_t o = P.rec_off[i];
         bool ok = o + 4 + 32 <= P.raw_bytes;
         uint32_t bs = 0;
@@ -166,7 +210,8 @@ __global__ __launch_bounds__(PB) void k_rec_scan(const PrepParams P) {
         if(ok) { bs = ld32(P.raw + o); ok = bs >= 32 && o + 4 + (uint64_t)bs <= P.raw_bytes; }
         if(ok) {
             const int32_t tid = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
-            const uint32_t lqn = r[8], mapq = r[9], ncig = ld16(r + 12), flag = ld16(r + 14);
+            const uint32_t w8 = ld32(r + 8), w12 = ld32(r + 12);
+            const uint32_t lqn = w8 & 255u, mapq = (w8 >> 8) & 255u, ncig = w12 & 0xffffu, flag = w12 >> 16;
             const int32_t lq = (int32_t)ld32(r + 16), mpos = (int32_t)ld32(r + 24);
             const uint64_t need = 32ull + lqn + 4ull * ncig + (uint64_t)((lq > 0 ? lq : 0) + 1) / 2 + (uint64_t)(lq > 0 ? lq : 0);
             ok = lq >= 0 && need <= bs && lqn >= 1;
@@ -174,110 +219,75 @@ __global__ __launch_bounds__(PB) void k_rec_scan(const PrepParams P) {
                 const uint8_t *qn = r + 32, *cig = qn + lqn, *seq = cig + 4 * ncig, *qual = seq + (lq + 1) / 2, *aux = qual + lq, *end = r + bs;
                 int32_t rlen = 0;
                 for(uint32_t k = 0; k < ncig; k++) { const uint32_t c = ld32(cig + 4 * k); const int op = c & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t)(c >> 4); }
-                R.pos = pos; R.rend = pos + rlen; R.lq = (uint32_t)lq; R.ncig = (uint16_t)ncig; R.flag = (uint16_t)flag; R.lqname = (uint8_t)lqn;
-                R.seq_off = (uint32_t)(seq - P.raw); R.cig_off = (uint32_t)(cig - P.raw); R.qn_off = (uint32_t)(qn - P.raw);
+                D.pos = pos; D.rend = pos + rlen; D.lq = (uint32_t)lq; D.ncig = (uint16_t)ncig; D.flag = (uint16_t)flag; D.lqname = (uint8_t)lqn;
+                D.seq_off = (uint32_t)(seq - P.raw); D.cig_off = (uint32_t)(cig - P.raw); D.qn_off = (uint32_t)(qn - P.raw);
                 const md_prep_cfg &c = P.cfg;
                 if(c.perread) {          // perRead.c:178-183: alignments that start inside the chunk; flag masks and MAPQ only
                     const uint8_t *nh, *xg;
                     bool keepr = (int64_t)pos >= P.beg && (int64_t)pos < P.end;
                     keepr = keepr && !(c.require_flags && ((uint32_t)c.require_flags & flag) != (uint32_t)c.require_flags);
                     keepr = keepr && !(c.ignore_flags && ((uint32_t)c.ignore_flags & flag) != 0) && (int)mapq >= c.min_mapq;
-                    if(keepr) { scan_aux(aux, end, nh, xg); R.strand = (uint8_t)strand_of(flag, xg); adm = 1; }
-                    R.adm = (uint8_t)adm; P.rec[i] = R;
-                    goto counted;
-                }
-                // filter_func, common.c:416-444 (the region query behind it: pos < end, bam_endpos > beg)
-                bool keep = tid == P.tid && !(flag & 0x4) && (int64_t)pos < P.end && (int64_t)pos + (rlen > 0 ? rlen : 1) > P.beg;
-                keep = keep && (int)mapq >= c.min_mapq && !(flag & (uint32_t)c.ignore_flags);
-                keep = keep && !(c.require_flags && (flag & (uint32_t)c.require_flags) != (uint32_t)c.require_flags);
-                keep = keep && !(!c.keep_dupes && (flag & 0x400));
-                int strand = 0;
-                if(keep) {
-                    const uint8_t *nh, *xg;
-                    scan_aux(aux, end, nh, xg);
-                    if(!c.ignore_nh && nh && (int)aux_int(nh) > 1) keep = false;
-                    strand = strand_of(flag, xg);
-                }
-                if(keep && c.map_on) {
-                    int64_t s1, s2;
-                    if((flag & 0x40) || ((flag & 0x10) && (flag & 0x80))) { s1 = pos; s2 = mpos; } else { s2 = pos; s1 = mpos; }
-                    if(!map_window_passes(P, s1, lq) && !map_window_passes(P, s2, lq)) keep = false;
-                }
-                if(keep && !c.keep_singleton && (flag & 0x9) == 0x9) keep = false;
-                if(keep && !c.keep_discordant && (flag & 0x3) == 0x1) keep = false;
-                if(keep && P.bed_on && !bed_touches(P, pos, (int64_t)pos + (rlen > 0 ? rlen : 1))) keep = false;
-                if(keep && c.min_conv_eff > 0.0f) {
-                    int e = 0;
-                    if(conv_efficiency(P, cig, (int)ncig, pos, seq, qual, lq, strand, &e) < c.min_conv_eff) keep = false;
-                    if(e) atomicExch(&P.cnt->strand0, 1u);
-                }
-                R.strand = (uint8_t)strand;
-                if(keep) {
-                    adm = 1;
-                    if(c.no_pairing) atomicMax(&P.cnt->max_lq, (uint32_t)lq);          // mbias: rows of the histogram
-                    uint64_t h = 0xcbf29ce484222325ULL;
-                    for(uint32_t k = 0; k + 1 < lqn && qn[k]; k++) h = (h ^ qn[k]) * 0x100000001b3ULL;
-                    P.hash[i] = h ? h : 1;
+                    if(keepr) { scan_aux(aux, end, nh, xg); D.strand = (uint8_t)strand_of(flag, xg); adm = 1; }
+                } else {
+                    // filter_func, common.c:416-444 (the region query behind it: pos < end, bam_endpos > beg)
+                    bool keep = tid == P.tid && !(flag & 0x4) && (int64_t)pos < P.end && (int64_t)pos + (rlen > 0 ? rlen : 1) > P.beg;
+                    keep = keep && (int)mapq >= c.min_mapq && !(flag & (uint32_t)c.ignore_flags);
+                    keep = keep && !(c.require_flags && (flag & (uint32_t)c.require_flags) != (uint32_t)c.require_flags);
+                    keep = keep && !(!c.keep_dupes && (flag & 0x400));
+                    int strand = 0;
+                    if(keep) {
+                        const uint8_t *nh, *xg;
+                        scan_aux(aux, end, nh, xg);
+                        if(!c.ignore_nh && nh && (int)aux_int(nh) > 1) keep = false;
+                        strand = strand_of(flag, xg);
+                    }
+                    if(keep && c.map_on) {
+                        int64_t s1, s2;
+                        if((flag & 0x40) || ((flag & 0x10) && (flag & 0x80))) { s1 = pos; s2 = mpos; } else { s2 = pos; s1 = mpos; }
+                        if(!map_window_passes(P, s1, lq) && !map_window_passes(P, s2, lq)) keep = false;
+                    }
+                    if(keep && !c.keep_singleton && (flag & 0x9) == 0x9) keep = false;
+                    if(keep && !c.keep_discordant && (flag & 0x3) == 0x1) keep = false;
+                    if(keep && P.bed_on && !bed_touches(P, pos, (int64_t)pos + (rlen > 0 ? rlen : 1))) keep = false;
+                    if(keep && c.min_conv_eff > 0.0f) {
+                        int e = 0;
+                        if(conv_efficiency(P, cig, (int)ncig, pos, seq, qual, lq, strand, &e) < c.min_conv_eff) keep = false;
+                        if(e) atomicExch(&P.cnt->strand0, 1u);
+                    }
+                    D.strand = (uint8_t)strand;
+                    if(keep) {
+                        adm = 1;
+                        if(c.no_pairing) atomicMax(&P.cnt->max_lq, (uint32_t)lq);          // mbias: rows of the histogram
+                        else { h = 0xcbf29ce484222325ULL; for(uint32_t k = 0; k + 1 < lqn && qn[k]; k++) h = (h ^ qn[k]) * 0x100000001b3ULL; if(!h) h = 1; }
+                    }
                 }
             }
         }
         if(!ok) atomicExch(&P.cnt->malformed, 1u);
-        R.adm = (uint8_t)adm;
-        P.rec[i] = R;
     }
-counted:
+    // file-order compaction: rank inside the workgroup, plus what the earlier tickets admitted
     const unsigned long long m = __ballot(adm);
-    if((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if(threadIdx.x == 0) { uint32_t s = 0; for(int w = 0; w < PB / 64; w++) s += wcnt[w]; P.blockcnt[blockIdx.x] = s; }
-}
-
-// exclusive scan of per-block counts (one workgroup; n is a few thousand at most); total -> *total.  Also resets the tiles.
-__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *cnt, uint32_t *off, int n, uint32_t *total, TileEnt *tiles, int ntiles) {
-    __shared__ uint32_t wsum[16]; __shared__ uint32_t carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if(tid == 0) carry = 0;
-    if(tiles) for(int t = tid; t < ntiles; t += 1024) { tiles[t].first = 0x7fffffff; tiles[t].last = 0; }
-    __syncthreads();
-    for(int base = 0; base < n; base += 1024) {
-        const int i = base + tid; const uint32_t v = i < n ? cnt[i] : 0;
-        uint32_t incl = v;
-#pragma unroll
-        for(int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if(lane >= d) incl += t; }
-        if(lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t pre = carry; for(int w = 0; w < wave; w++) pre += wsum[w];
-        if(i < n) off[i] = pre + incl - v;
-        __syncthreads();
-        if(tid == 1023) carry = pre + incl;
-        __syncthreads();
-    }
-    if(tid == 0) *total = carry;
-}
-
-__global__ __launch_bounds__(PB) void k_compact(const PrepParams P) {
-    __shared__ uint32_t wcnt[PB / 64];
-    const int i = blockIdx.x * PB + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    PrepRec R; R.adm = 0;
-    if(i < P.n_rec) R = P.rec[i];
-    const unsigned long long m = __ballot(R.adm);
     if(lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    if(!R.adm) return;
-    uint32_t a = P.blockoff[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for(int w = 0; w < wave; w++) a += wcnt[w];
-    PrepRead D; D.pos = R.pos; D.rend = R.rend; D.seq_off = R.seq_off; D.lq = R.lq; D.cig_off = R.cig_off; D.qn_off = R.qn_off; D.ncig = R.ncig; D.flag = R.flag; D.strand = R.strand; D.lqname = R.lqname; D.pad = 0;
-    P.rd[a] = D; P.mate[a] = -1; P.second[a] = 0;
+    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0;
+    for(int w = 0; w < PB / 64; w++) { if(w < wave) rank += wcnt[w]; total += wcnt[w]; }
+    if(threadIdx.x == 0) __hip_atomic_store(&P.cntA[tk], total | CNT_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t base = tickets_before(P.cntA, tk, red);
+    if((int)tk == P.nblocks - 1 && threadIdx.x == 0) P.cnt->n_adm = base + total;
+    if(!adm) return;
+    const uint32_t a = base + rank;
+    P.rd[a] = D;
     if(P.aidx) P.aidx[a] = (uint32_t)i;
     if(P.cfg.no_pairing || P.cfg.perread) return;
-    // name table: open addressing on the 64-bit hash, members chained through hnext (order is restored by k_pair)
-    const uint64_t h = P.hash[i]; uint32_t s = (uint32_t)(h ^ (h >> 32)) & P.hmask;
+    // name table: open addressing on the 64-bit hash, members chained through hnext (file order is restored by whoever walks a chain)
+    uint32_t sl = (uint32_t)(h ^ (h >> 32)) & P.hmask;
     for(;;) {
-        const unsigned long long old = atomicCAS((unsigned long long *)&P.hkey[s], 0ull, (unsigned long long)h);
+        const unsigned long long old = atomicCAS((unsigned long long *)&P.hkey[sl], 0ull, (unsigned long long)h);
         if(old == 0ull || old == (unsigned long long)h) break;
-        s = (s + 1) & P.hmask;
+        sl = (sl + 1) & P.hmask;
     }
-    P.hnext[a] = atomicExch(&P.hhead[s], (int32_t)a);
+    P.slot[a] = sl;
+    P.hnext[a] = atomicExch(&P.hhead[sl], (int32_t)a + 1) - 1;
 }
 
 __device__ __forceinline__ bool same_name(const PrepParams &P, const PrepRead &x, const PrepRead &y) {
@@ -287,44 +297,42 @@ __device__ __forceinline__ bool same_name(const PrepParams &P, const PrepRead &x
     return true;
 }
 
-// overlaps.c:121-147 + the pileup buffer's eviction, per read name (see pair_reads in csrc/host/mdk_pipeline.c for the host
-// statement of the same rule): a read enters the buffer iff its end lies beyond the column about to be emitted (the start of
-// the previously admitted read); entering, it first drops the name's reads that have been swept out (end < that column) --
-// any such drop erases the name's pending entry --, then either becomes pending or is paired with the pending read.
-__global__ __launch_bounds__(PB) void k_pair(const PrepParams P, const uint32_t *n_adm_p) {
-    const uint32_t s = blockIdx.x * PB + threadIdx.x;
-    if(s > P.hmask || P.hkey[s] == 0) return;
+// overlaps.c:121-147 + the pileup buffer's eviction, for the name of read `a` (see pair_reads in csrc/host/mdk_pipeline.c for the
+// host statement of the same rule): a read enters the buffer iff its end lies beyond the column about to be emitted (the start of
+// the previously admitted read); entering, it first drops the name's reads that have been swept out (end < that column) -- any
+// such drop erases the name's pending entry --, then either becomes pending or is paired with the pending read.  Returns the read
+// `a` is resolved against (-1: none) and whether `a` is the later of the two.
+__device__ int32_t pair_of(const PrepParams &P, const uint32_t a, const PrepRead &ra, bool &second) {
+    second = false;
+    if(!(ra.flag & 0x1) || (ra.flag & 12)) return -1;               // such a read never becomes pending nor pairs (it still occupies the buffer for others)
     int32_t idx[MAXG]; int k = 0;
-    for(int32_t a = P.hhead[s]; a >= 0; a = P.hnext[a]) { if(k == MAXG) { atomicExch(&P.cnt->fallback, 1u); return; } idx[k++] = a; }
-    for(int i = 1; i < k; i++) { const int32_t v = idx[i]; int j = i - 1; while(j >= 0 && idx[j] > v) { idx[j + 1] = idx[j]; j--; } idx[j + 1] = v; }
-    uint32_t done = 0;                                    // records of other names that share the hash are handled as their own group
-    for(int g = 0; g < k; g++) {
-        if(done & (1u << g)) continue;
-        const PrepRead lead = P.rd[idx[g]];
-        int32_t pending = -1; int32_t live[MAXLIVE]; int nlive = 0;
-        for(int i = g; i < k; i++) {
-            if(done & (1u << i)) continue;
-            const int32_t a = idx[i];
-            const PrepRead x = P.rd[a];
-            if(i != g && !same_name(P, lead, x)) continue;
-            done |= 1u << i;
-            const bool first = a == 0;
-            const int32_t prev_pos = first ? 0 : P.rd[a - 1].pos;
-            const bool inserted = first ? (P.tid > 0 || x.rend > 0) : (x.rend > prev_pos);
-            if(!inserted) continue;
-            bool evicted = false; int w = 0;
-            for(int q = 0; q < nlive; q++) { if(!first && live[q] < prev_pos) evicted = true; else live[w++] = live[q]; }
-            nlive = w;
-            if(evicted) pending = -1;
-            if((x.flag & 0x1) && !(x.flag & 12)) {
-                if(pending < 0) pending = a;
-                else { P.mate[pending] = a; P.mate[a] = pending; P.second[a] = 1; pending = -1; }
+    for(int32_t x = P.hhead[P.slot[a]] - 1; x >= 0; x = P.hnext[x]) { if(k == MAXG) { atomicExch(&P.cnt->fallback, 1u); return -1; } idx[k++] = x; }
+    for(int i = 1; i < k; i++) { const int32_t v = idx[i]; int q = i - 1; while(q >= 0 && idx[q] > v) { idx[q + 1] = idx[q]; q--; } idx[q + 1] = v; }
+    int32_t pending = -1, mate = -1; int32_t live[MAXLIVE]; int nlive = 0;
+    for(int i = 0; i < k; i++) {
+        const int32_t x = idx[i];
+        const PrepRead X = (uint32_t)x == a ? ra : P.rd[x];
+        if((uint32_t)x != a && !same_name(P, ra, X)) continue;      // another name in the same slot
+        const bool first = x == 0;
+        const int32_t prev_pos = first ? 0 : P.rd[x - 1].pos;
+        const bool inserted = first ? (P.tid > 0 || X.rend > 0) : (X.rend > prev_pos);
+        if(!inserted) continue;
+        bool evicted = false; int w = 0;
+        for(int q = 0; q < nlive; q++) { if(!first && live[q] < prev_pos) evicted = true; else live[w++] = live[q]; }
+        nlive = w;
+        if(evicted) pending = -1;
+        if((X.flag & 0x1) && !(X.flag & 12)) {
+            if(pending < 0) pending = x;
+            else {
+                if((uint32_t)pending == a) { mate = x; second = false; }
+                else if((uint32_t)x == a) { mate = pending; second = true; }
+                pending = -1;
             }
-            if(nlive == MAXLIVE) { atomicExch(&P.cnt->fallback, 1u); return; }
-            live[nlive++] = x.rend;
         }
+        if(nlive == MAXLIVE) { atomicExch(&P.cnt->fallback, 1u); return -1; }
+        live[nlive++] = X.rend;
     }
-    (void)n_adm_p;
+    return mate;
 }
 
 // gapless runs of a CIGAR, one at a time (calculate_positions, overlaps.c:27-52)
@@ -350,15 +358,12 @@ struct RunIt {
 
 // lo/hi: reference extent of the pieces written (for the tile runs); untouched when nothing is emitted
 template <bool WRITE>
-__device__ __forceinline__ uint32_t read_segments(const PrepParams &P, uint32_t a, md_seg *out, uint32_t base, int64_t &lo, int64_t &hi) {
-    const PrepRead r = P.rd[a];
-    const int32_t mi = P.mate[a];
-    PrepRead m; bool paired = false;
-    if(mi >= 0) { m = P.rd[mi]; paired = (((int)r.strand - (int)m.strand) & 1) == 0; }       // overlaps.c:63-65
+__device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const PrepRead &r, const bool has_mate, const PrepRead &m, const bool is_second, md_seg *out, uint32_t base, int64_t &lo, int64_t &hi) {
+    const bool paired = has_mate && (((int)r.strand - (int)m.strand) & 1) == 0;       // overlaps.c:63-65
     RunIt own, oth;
     own.init(P.raw + r.cig_off, r.ncig, r.pos, (int32_t)r.lq);
     if(paired) oth.init(P.raw + m.cig_off, m.ncig, m.pos, (int32_t)m.lq); else oth.valid = false;
-    const uint8_t sf = (uint8_t)((r.strand & 7) | ((r.flag & 0x80) ? MDK_SF_READ2 : 0) | (P.second[a] ? MDK_SF_SECOND : 0));
+    const uint8_t sf = (uint8_t)((r.strand & 7) | ((r.flag & 0x80) ? MDK_SF_READ2 : 0) | (is_second ? MDK_SF_SECOND : 0));
     const uint8_t msf = paired ? (uint8_t)((m.strand & 7) | ((m.flag & 0x80) ? MDK_SF_READ2 : 0)) : 0;
     uint32_t n = 0;
     for(; own.valid; own.next()) {
@@ -388,42 +393,44 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, uint32_t 
     return n;
 }
 
-__global__ __launch_bounds__(PB) void k_seg_count(const PrepParams P) {
-    __shared__ uint32_t wsum[PB / 64]; __shared__ unsigned long long wbytes[PB / 64];
-    const uint32_t a = blockIdx.x * PB + threadIdx.x, n_adm = P.cnt->n_adm;
+__global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
+    __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64];
+    int j = 0;
+    while(j + 1 < M.n && (int)blockIdx.x >= M.bstart[j + 1]) j++;
+    const PrepParams &P = M.P[j];
+    if(threadIdx.x == 0) s_tk = atomicAdd(&P.ticket[1], 1u);
+    __syncthreads();
+    const uint32_t tk = s_tk, n_adm = P.cnt->n_adm;
+    if(tk * PB >= n_adm) return;                          // (a workgroup that leaves here is never waited for: every ticket before an active one is active)
+    const uint32_t a = tk * PB + threadIdx.x; const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool active = a < n_adm;
+    PrepRead r; memset(&r, 0, sizeof(r)); PrepRead m = r; bool has_mate = false, is_second = false;
     uint32_t n = 0; unsigned long long bytes = 0;
-    if(a < n_adm) {
+    if(active) {
+        r = P.rd[a];
+        if(!P.cfg.no_pairing) { const int32_t mi = pair_of(P, a, r, is_second); if(mi >= 0) { has_mate = true; m = P.rd[mi]; } }
         int64_t lo = 0, hi = 0;
-        n = read_segments<false>(P, a, nullptr, 0, lo, hi);
-        P.segcnt[a] = n;
-        const PrepRead r = P.rd[a];
+        n = read_segments<false>(P, r, has_mate, m, is_second, nullptr, 0, lo, hi);
         bytes = 16ull + 4ull * r.ncig + ((unsigned long long)r.lq + 1) / 2 + r.lq;        // SURVEY.md 8d, per admitted read
     }
-    uint32_t s = n; unsigned long long b = bytes;
-#pragma unroll
-    for(int d = 32; d; d >>= 1) { s += __shfl_xor(s, d); b += __shfl_xor(b, d); }
-    if((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = s; wbytes[threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if(threadIdx.x == 0) {
-        uint32_t t = 0; unsigned long long tb = 0; for(int w = 0; w < PB / 64; w++) { t += wsum[w]; tb += wbytes[w]; }
-        P.segblk[blockIdx.x] = t;
-        if(tb) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, tb);
-    }
-}
-
-__global__ __launch_bounds__(PB) void k_seg_write(const PrepParams P) {
-    __shared__ uint32_t wsum[PB / 64];
-    const uint32_t a = blockIdx.x * PB + threadIdx.x, n_adm = P.cnt->n_adm; const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t n = a < n_adm ? P.segcnt[a] : 0;
+    // where this read's segments go: scan inside the workgroup, plus what the earlier tickets counted
     uint32_t incl = n;
 #pragma unroll
     for(int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if(lane >= d) incl += t; }
     if(lane == 63) wsum[wave] = incl;
     __syncthreads();
-    uint32_t base = P.segblkoff[blockIdx.x] + incl - n;
-    for(int w = 0; w < wave; w++) base += wsum[w];
+    uint32_t base = incl - n, total = 0;
+    for(int w = 0; w < PB / 64; w++) { if(w < wave) base += wsum[w]; total += wsum[w]; }
+    if(threadIdx.x == 0) __hip_atomic_store(&P.cntS[tk], total | CNT_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    { unsigned long long b = bytes;
+#pragma unroll
+      for(int d = 32; d; d >>= 1) b += __shfl_xor(b, d);
+      if(lane == 0 && b) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, b); }
+    const uint32_t before = tickets_before(P.cntS, tk, red);
+    base += before;
+    if((tk + 1) * PB >= n_adm && threadIdx.x == 0) P.cnt->n_segs = before + total;
     int64_t lo = INT64_MAX, hi = INT64_MIN;
-    if(n) (void)read_segments<true>(P, a, P.seg, base, lo, hi);
+    if(n) (void)read_segments<true>(P, r, has_mate, m, is_second, P.seg, base, lo, hi);
     // Tile runs: tile t's run [first, last) must cover every segment touching t.  A lane contributes [base, base + n) to every
     // tile its pieces reach -- a superset, which is all k_pileup needs.  Reads are in coordinate order, so the lanes of a wave
     // touching one tile are (nearly always) consecutive: only the first of them lowers `first`, only the last raises `last`,
@@ -518,39 +525,43 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
 
 static uint32_t pow2_at_least(size_t n) { uint32_t p = 1024; while(p < n) p <<= 1; return p; }
 
-static int enqueue_prep(md_dev *h, Slot *s) {
-    PrepParams P; memset(&P, 0, sizeof(P));
-    const int n = s->pr_nrec, nb = (n + PB - 1) / PB;
+// layout of a slot's zeroed region: hkey[H] (8 bytes each), hhead[H], cntA[nb], cntS[nb], ticket[2]; sizes rounded to 16 bytes
+static size_t zero_bytes_for(uint32_t hmask, int nb) { return (((size_t)hmask + 1) * 12 + (size_t)(nb > 0 ? nb : 1) * 8 + 8 + 15) & ~(size_t)15; }
+static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
+    memset(&P, 0, sizeof(P));
+    const int n = s->pr_nrec, nb = (n + PB - 1) / PB; const size_t H = (size_t)s->hmask + 1;
     P.raw = s->d_raw.p; P.raw_bytes = s->raw_bytes; P.rec_off = s->d_recoff.p; P.n_rec = n;
     P.cfg = h->prep; P.tid = s->tid; P.beg = s->beg; P.end = s->end; P.woff = s->woff; P.wlen = s->wlen;
     P.ref = h->ref[s->tid]; P.reflen = h->reflen[s->tid];
     if(h->prep.map_on && (size_t)s->tid < h->mapbits.size()) { P.mapbits = h->mapbits[s->tid]; P.maplen = h->maplen[s->tid]; }
     P.bed_on = (size_t)s->tid < h->d_runs.size() && h->has_runs[s->tid]; if(P.bed_on) { P.runs = h->d_runs[s->tid]; P.nruns = h->n_runs[s->tid]; }
-    P.rec = s->d_prec.p; P.hash = s->d_hash.p; P.blockcnt = s->d_blk.p; P.blockoff = s->d_blk.p + nb; P.nblocks = nb;
-    P.rd = s->d_prd.p; P.mate = s->d_mate.p; P.second = s->d_second.p;
-    P.hkey = s->d_hkey.p; P.hhead = s->d_hhead.p; P.hnext = s->d_hnext.p; P.hmask = s->hmask;
-    P.segcnt = s->d_segcnt.p; P.segblk = s->d_blk.p + 2 * nb; P.segblkoff = s->d_blk.p + 3 * nb;
+    P.rd = s->d_prd.p; P.slot = s->d_nslot.p; P.aidx = h->prep.perread ? s->d_aidx.p : nullptr; P.hnext = s->d_hnext.p; P.hmask = s->hmask;
+    uint8_t *z = s->d_zero.p;
+    P.hkey = (uint64_t *)z; P.hhead = (int32_t *)(z + H * 8); P.cntA = (uint32_t *)(z + H * 12); P.cntS = P.cntA + (nb > 0 ? nb : 1); P.ticket = P.cntS + (nb > 0 ? nb : 1);
+    P.nblocks = nb; P.zero = z; P.zero_bytes = zero_bytes_for(s->hmask, nb);
     P.seg = s->d_seg_in.p; P.cap_seg = (int64_t)s->d_seg_in.cap;
     P.tiles = s->d_tiles.p; P.ntiles = s->ntiles; P.tile = s->tile;
     P.cnt = s->d_pcnt.p;
-    hipStream_t st = s->stream;
-    HIPCHK(hipMemsetAsync(s->d_pcnt.p, 0, sizeof(PrepCounters), st));
-    if(!h->prep.no_pairing) {
-        HIPCHK(hipMemsetAsync(s->d_hkey.p, 0, sizeof(uint64_t) * ((size_t)s->hmask + 1), st));
-        HIPCHK(hipMemsetAsync(s->d_hhead.p, 0xff, sizeof(int32_t) * ((size_t)s->hmask + 1), st));
+}
+// the preparation of up to MAXM uploaded raw slots on stream `st`: zero, scan (+ compaction, name table), segments -- each kernel
+// once for all of them.  The caller has ordered `st` behind the slots' uploads.
+int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
+    if(n < 1 || n > MAXM) return fail(MDK_ERR_ARG, "enqueue_prep_group", hipSuccess);
+    static_assert(sizeof(PrepMulti) <= 4096, "kernel arguments are limited to 4 KiB");
+    PrepMulti M; memset(&M, 0, sizeof(M));
+    int total = 0; size_t zmax = 0;
+    for(int i = 0; i < n; i++) { fill_prep(h, ss[i], M.P[i]); M.bstart[i] = total; total += M.P[i].nblocks; zmax = std::max<size_t>(zmax, (size_t)M.P[i].zero_bytes); ss[i]->prep_pending = false; }
+    M.n = n; M.bstart[n] = total;
+    int zgrid = (int)std::min<size_t>(2048, (zmax / 16 + PB - 1) / PB); if(zgrid < 1) zgrid = 1;
+    hipLaunchKernelGGL(k_prep_zero, dim3(zgrid), dim3(PB), 0, st, M);
+    if(total > 0) {
+        hipLaunchKernelGGL(k_prep_scan, dim3(total), dim3(PB), 0, st, M);
+        if(!h->prep.perread) hipLaunchKernelGGL(k_prep_segs, dim3(total), dim3(PB), 0, st, M);
     }
-    if(n > 0) hipLaunchKernelGGL(k_rec_scan, dim3(nb), dim3(PB), 0, st, P);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, (const uint32_t *)P.blockcnt, P.blockoff, nb, &s->d_pcnt.p->n_adm, s->d_tiles.p, s->ntiles);
-    if(n > 0) {
-        hipLaunchKernelGGL(k_compact, dim3(nb), dim3(PB), 0, st, P);
-        if(!h->prep.no_pairing) hipLaunchKernelGGL(k_pair, dim3((s->hmask + PB) / PB), dim3(PB), 0, st, P, (const uint32_t *)&s->d_pcnt.p->n_adm);
-        hipLaunchKernelGGL(k_seg_count, dim3(nb), dim3(PB), 0, st, P);
-    } else HIPCHK(hipMemsetAsync(s->d_blk.p, 0, sizeof(uint32_t) * 4 * (size_t)(nb > 0 ? nb : 1), st));
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, (const uint32_t *)P.segblk, P.segblkoff, nb, &s->d_pcnt.p->n_segs, (TileEnt *)nullptr, 0);
-    if(n > 0) hipLaunchKernelGGL(k_seg_write, dim3(nb), dim3(PB), 0, st, P);
     HIPCHK(hipGetLastError());
     return 0;
 }
+static int enqueue_prep(md_dev *h, Slot *s, hipStream_t st = nullptr) { Slot *one[1] = {s}; return enqueue_prep_group(h, one, 1, st ? st : s->stream); }
 
 // H2D of the chunk's record bytes and record table, then the preparation kernels: the slot ends up "uploaded", with its
 // segments and tile runs in device memory, exactly as after md_dev_upload of a host-built batch.
@@ -574,16 +585,15 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->n_segs = -1; s->n_reads = -1; s->read_bytes = 0;
     const size_t nn = (size_t)n + 1, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
-    s->hmask = pow2_at_least(nn * 2) - 1;
-    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prec.need(nn) || s->d_hash.need(nn) || s->d_blk.need(4 * (size_t)(nb + 1)) ||
-       s->d_prd.need(nn) || s->d_mate.need(nn) || s->d_second.need(nn) || s->d_segcnt.need(nn) || s->d_hnext.need(nn) ||
-       s->d_hkey.need((size_t)s->hmask + 1) || s->d_hhead.need((size_t)s->hmask + 1) || s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
+    s->hmask = pow2_at_least(nn + nn / 2) - 1;
+    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_nslot.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+       s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
     if(!s->b_site) {
         if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
         if(h->variant && s->d_var.need((size_t)span + 16)) return MDK_ERR_NOMEM;
     }
     { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
-    int rc = enqueue_prep(h, s); if(rc) return rc;
+    s->prep_pending = true;            // the preparation kernels are queued with the launch: alone (md_dev_launch) or with up to seven other chunks (md_dev_launch_group)
     s->uploaded = true;
     return 0;
 }
@@ -607,20 +617,13 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     for(int i = 0; i < b->n_ranges; i++) total += b->range[i].bytes;
     if(total >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: more than 4 GiB of records in one chunk", hipSuccess);
     const int n = b->n_records, nb = (n + PB - 1) / PB; const size_t nn = (size_t)n + 1;
-    s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true;
-    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prec.need(nn) || s->d_hash.need(nn) || s->d_blk.need(4 * (size_t)(nb + 1)) || s->d_prd.need(nn) ||
-       s->d_mate.need(nn) || s->d_second.need(nn) || s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
+    s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->hmask = 1023; s->ntiles = 0; s->tile = h->tile;
+    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_nslot.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+       s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
     { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
-    PrepParams P; memset(&P, 0, sizeof(P));
-    P.raw = s->d_raw.p; P.raw_bytes = total; P.rec_off = s->d_recoff.p; P.n_rec = n; P.cfg = h->prep; P.tid = b->tid; P.beg = b->beg; P.end = b->end;
-    P.ref = h->ref[b->tid]; P.reflen = h->reflen[b->tid];
-    P.rec = s->d_prec.p; P.hash = s->d_hash.p; P.blockcnt = s->d_blk.p; P.blockoff = s->d_blk.p + nb; P.nblocks = nb;
-    P.rd = s->d_prd.p; P.mate = s->d_mate.p; P.second = s->d_second.p; P.aidx = s->d_aidx.p; P.cnt = s->d_pcnt.p;
-    HIPCHK(hipMemsetAsync(s->d_pcnt.p, 0, sizeof(PrepCounters), s->stream));
-    if(n > 0) hipLaunchKernelGGL(k_rec_scan, dim3(nb), dim3(PB), 0, s->stream, P);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s->stream, (const uint32_t *)P.blockcnt, P.blockoff, nb, &s->d_pcnt.p->n_adm, (TileEnt *)nullptr, 0);
+    { int rc = enqueue_prep(h, s); if(rc) return rc; }                 // perread mode: selection + file-order compaction only (k_prep_scan)
     if(n > 0) {
-        hipLaunchKernelGGL(k_compact, dim3(nb), dim3(PB), 0, s->stream, P);
+        PrepParams P; fill_prep(h, s, P);
         int64_t wend = b->end + 10000; if(wend > P.reflen - 1) wend = P.reflen - 1;
         hipLaunchKernelGGL(k_perread_raw, dim3(nb), dim3(PB), 0, s->stream, P, (const uint8_t *)h->refcode[b->tid], wend, s->d_prc.p);
         HIPCHK(hipGetLastError());
@@ -678,12 +681,33 @@ extern "C" int md_dev_bench_prep(md_dev *h, int slot, int warmup, int iters, flo
     return 0;
 }
 
+// the same for `n` uploaded raw slots holding different intervals, `per_launch` of them per launch of each preparation kernel,
+// round robin on one stream, `iters` launches in all: what the preparation costs per launch when its inputs stream from HBM
+extern "C" int md_dev_bench_prep_rotate(md_dev *h, const int *slots, int n, int per_launch, int warmup, int iters, float *ms_per_launch) {
+    if(!h || !slots || n < 1 || iters < 1 || !ms_per_launch || per_launch < 1 || per_launch > MAXM || n % per_launch) return fail(MDK_ERR_ARG, "md_dev_bench_prep_rotate", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<Slot *> ss((size_t)n);
+    for(int i = 0; i < n; i++) { ss[i] = get_slot(h, slots[i]); if(!ss[i] || !ss[i]->uploaded || !ss[i]->raw_layout) return fail(MDK_ERR_ARG, "md_dev_bench_prep_rotate: needs slots uploaded with md_dev_upload_raw", hipSuccess); HIPCHK(hipStreamSynchronize(ss[i]->stream)); if(ss[i]->run) HIPCHK(hipStreamSynchronize(ss[i]->run)); }
+    Slot *s0 = ss[0]; const int groups = n / per_launch;
+    for(int i = 0; i < warmup; i++) { int rc = enqueue_prep_group(h, ss.data() + (i % groups) * per_launch, per_launch, s0->stream); if(rc) return rc; }
+    HIPCHK(hipEventRecord(s0->k0, s0->stream));
+    for(int i = 0; i < iters; i++) { int rc = enqueue_prep_group(h, ss.data() + (i % groups) * per_launch, per_launch, s0->stream); if(rc) return rc; }
+    HIPCHK(hipEventRecord(s0->k1, s0->stream));
+    HIPCHK(hipEventSynchronize(s0->k1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, s0->k0, s0->k1));
+    for(int i = 0; i < n; i++) ss[i]->fresh = true;
+    *ms_per_launch = ms / (float)iters;
+    return 0;
+}
+
 // test hook: the segments the preparation built (device order), and the admitted reads behind them
 extern "C" int md_dev_debug_segments(md_dev *h, int slot, md_seg *out, int64_t cap, int64_t *n_segs, int64_t *n_reads) {
     Slot *s = get_slot(h, slot);
     if(!s || !s->uploaded || !n_segs) return fail(MDK_ERR_ARG, "md_dev_debug_segments", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
+    if(s->raw_layout && s->prep_pending) { int rc = enqueue_prep(h, s); if(rc) return rc; }
     HIPCHK(hipStreamSynchronize(s->stream));
+    if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
     if(s->raw_layout) {
         HIPCHK(hipMemcpy(&s->h_st.p->pc, s->d_pcnt.p, sizeof(PrepCounters), hipMemcpyDeviceToHost));
         int rc = prep_outcome(h, s);

@@ -49,6 +49,8 @@ def test_binds_to_the_gpus_local_cpus(tmp_path):
     assert run(tmp_path, 1) == (len(hi), hi)                     # the VGA card of another vendor is not counted
     assert run(tmp_path, 2) == (0, allowed)                      # no such GPU: nothing changes
     assert run(tmp_path, 0, MDK_NO_BIND="1") == (0, allowed)
+    assert run(tmp_path, 0, ROCR_VISIBLE_DEVICES="1") == (0, allowed)      # a renumbered device list: the index says nothing about sysfs order
+    assert run(tmp_path, 0, HIP_VISIBLE_DEVICES="") == (len(lo), lo)       # (an empty variable is no restriction)
 
 
 @pytest.mark.parametrize("cpulist", ["", "0-3,x", "3-1", "-2", "0", "99999"])
