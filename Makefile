@@ -36,7 +36,7 @@ tools/_build/mdk_calib: tools/mdk_calib.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ tools/mdk_calib.hip
 tools/_build/mdk_synth: tools/mdk_synth.c
 	@mkdir -p tools/_build
-	$(CC) -O2 -g -o $@ tools/mdk_synth.c -lz -lm
+	$(CC) -O2 -g -o $@ tools/mdk_synth.c -lz -lm -lpthread
 
 oracle:
 	$(MAKE) -C oracle

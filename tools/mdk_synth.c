@@ -21,6 +21,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
+#include <pthread.h>
+#include <time.h>
+#include <unistd.h>
 
 typedef struct { uint64_t s; } rng_t;
 static uint64_t rnd(rng_t *r) { uint64_t x = r->s; x ^= x >> 12; x ^= x << 25; x ^= x >> 27; r->s = x; return x * 2685821657736338717ULL; }
@@ -35,28 +38,66 @@ static void b32(buf_t *b, uint32_t v) { uint8_t x[4] = {v, v >> 8, v >> 16, v >>
 static void b16(buf_t *b, uint16_t v) { uint8_t x[2] = {(uint8_t)v, (uint8_t)(v >> 8)}; bput(b, x, 2); }
 static void b8(buf_t *b, uint8_t v) { bput(b, &v, 1); }
 
-/* ---- BGZF writer ---- */
-typedef struct { FILE *f; uint8_t blk[65280]; int n; int level; uint64_t fpos; } bgzf_t;
+/* ---- BGZF writer ----
+ * Members are cut exactly as a sequential writer would cut them (bgzf_write / bgzf_flush below), but only noted; bgzf_close compresses
+ * them with a pool of threads and writes them in order.  The file is byte for byte what one thread would have written: a member's
+ * compressed bytes depend on nothing but its own content.  Virtual offsets (for the BAI) are therefore known only afterwards:
+ * callers note (member index, offset in member) and ask bgzf_voffset once the file is closed. */
+typedef struct { uint8_t *raw; uint32_t n; uint8_t *comp; uint32_t clen; uint64_t fpos; } member_t;
+/* blocks that live until the process ends come from 64 MB slabs (tens of thousands of 64 KB mallocs and frees across threads made
+ * the allocator spend more time in the kernel than zlib spent compressing) */
+typedef struct { uint8_t *p; size_t left; } bump_t;
+static uint8_t *bump(bump_t *b, size_t n) { uint8_t *q; n = (n + 63) & ~(size_t)63; if(b->left < n) { b->left = n > (64u << 20) ? n : (64u << 20); b->p = malloc(b->left); } q = b->p; b->p += n; b->left -= n; return q; }
+typedef struct { FILE *f; uint8_t blk[65280]; int n; int level; member_t *m; size_t nm, mm; size_t next; pthread_mutex_t mu; bump_t raws; } bgzf_t;
 static void bgzf_flush(bgzf_t *z) {
-    uint8_t out[70000]; z_stream zs; uint32_t crc; int clen; uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
     if(!z->n) return;
-    memset(&zs, 0, sizeof(zs));
-    deflateInit2(&zs, z->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
-    zs.next_in = z->blk; zs.avail_in = z->n; zs.next_out = out; zs.avail_out = sizeof(out);
-    deflate(&zs, Z_FINISH); clen = (int)zs.total_out; deflateEnd(&zs);
-    crc = crc32(crc32(0, NULL, 0), z->blk, z->n);
-    { int bsize = clen + 25; hdr[16] = bsize & 0xff; hdr[17] = bsize >> 8; }
-    fwrite(hdr, 1, 18, z->f); fwrite(out, 1, clen, z->f); z->fpos += 18 + (uint64_t)clen + 8;
-    { uint8_t t[8] = {crc, crc >> 8, crc >> 16, crc >> 24, (uint8_t)z->n, (uint8_t)(z->n >> 8), (uint8_t)(z->n >> 16), (uint8_t)(z->n >> 24)}; fwrite(t, 1, 8, z->f); }
+    if(z->nm == z->mm) { z->mm = z->mm ? z->mm * 2 : 4096; z->m = realloc(z->m, z->mm * sizeof(member_t)); }
+    z->m[z->nm].raw = bump(&z->raws, (size_t)z->n); memcpy(z->m[z->nm].raw, z->blk, (size_t)z->n); z->m[z->nm].n = (uint32_t)z->n; z->m[z->nm].comp = NULL; z->nm++;
     z->n = 0;
 }
 static void bgzf_write(bgzf_t *z, const void *d, size_t n) {
     const uint8_t *p = d;
     while(n) { size_t k = sizeof(z->blk) - z->n; if(k > n) k = n; memcpy(z->blk + z->n, p, k); z->n += k; p += k; n -= k; if(z->n == (int)sizeof(z->blk)) bgzf_flush(z); }
 }
-static void bgzf_close(bgzf_t *z) {
+static void *bgzf_worker(void *arg) {
+    bgzf_t *z = arg; bump_t mine = {NULL, 0}; static __thread uint8_t out[70000 + 64];
+    for(;;) {
+        size_t i; member_t *m; z_stream zs; uint32_t crc; int clen; uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
+        pthread_mutex_lock(&z->mu); i = z->next++; pthread_mutex_unlock(&z->mu);
+        if(i >= z->nm) break;
+        m = &z->m[i];
+        memset(&zs, 0, sizeof(zs));
+        deflateInit2(&zs, z->level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = m->raw; zs.avail_in = m->n; zs.next_out = out + 18; zs.avail_out = 70000;
+        deflate(&zs, Z_FINISH); clen = (int)zs.total_out; deflateEnd(&zs);
+        crc = crc32(crc32(0, NULL, 0), m->raw, m->n);
+        { int bsize = clen + 25; hdr[16] = bsize & 0xff; hdr[17] = bsize >> 8; }
+        memcpy(out, hdr, 18);
+        { uint8_t t[8] = {crc, crc >> 8, crc >> 16, crc >> 24, (uint8_t)m->n, (uint8_t)(m->n >> 8), (uint8_t)(m->n >> 16), (uint8_t)(m->n >> 24)}; memcpy(out + 18 + clen, t, 8); }
+        m->clen = (uint32_t)(18 + clen + 8); m->comp = bump(&mine, m->clen); memcpy(m->comp, out, m->clen); m->raw = NULL;
+    }
+    return NULL;
+}
+/* compress everything, fix the members' file positions, write; the member table stays for bgzf_voffset */
+static uint64_t bgzf_finish(bgzf_t *z) {
     static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    bgzf_flush(z); fwrite(eof, 1, 28, z->f); fclose(z->f);
+    pthread_t th[64]; int nt = (int)sysconf(_SC_NPROCESSORS_ONLN), k, made = 0; uint64_t fpos = 0; size_t i;
+    bgzf_flush(z);
+    if(getenv("MDK_SYNTH_THREADS")) nt = atoi(getenv("MDK_SYNTH_THREADS"));
+    if(nt > 64) nt = 64;
+    if(nt < 1) nt = 1;
+    z->next = 0; pthread_mutex_init(&z->mu, NULL);
+    for(k = 0; k < nt - 1; k++) { if(pthread_create(&th[made], NULL, bgzf_worker, z)) break; made++; }
+    bgzf_worker(z);
+    for(k = 0; k < made; k++) pthread_join(th[k], NULL);
+    for(i = 0; i < z->nm; i++) { z->m[i].fpos = fpos; fwrite(z->m[i].comp, 1, z->m[i].clen, z->f); fpos += z->m[i].clen; z->m[i].comp = NULL; }
+    fwrite(eof, 1, 28, z->f); fclose(z->f);
+    return fpos;
+}
+/* (member index, offset inside it) -> virtual offset; a position at the very end of the last noted member = start of the next */
+static uint64_t bgzf_voffset(const bgzf_t *z, uint64_t end_fpos, size_t member, uint32_t within) {
+    if(member >= z->nm) return (end_fpos << 16) | within;
+    return (z->m[member].fpos << 16) | within;
 }
 
 /* ---- reference ---- */
@@ -250,12 +291,14 @@ int main(int argc, char **argv) {
             }
         }
     }
+    if(getenv("MDK_SYNTH_PROFILE")) fprintf(stderr, "[synth] reads generated at %.2f s\n", clock() / (double)CLOCKS_PER_SEC);
     for(i = 0; i < nrec; i++) recs[i].d = pool.p + offs[i];
     qsort(recs, nrec, sizeof(rec_t), rec_cmp);
+    if(getenv("MDK_SYNTH_PROFILE")) fprintf(stderr, "[synth] sorted at %.2f s (cpu)\n", clock() / (double)CLOCKS_PER_SEC);
 
     snprintf(fn, sizeof(fn), "%s.bam", prefix);
     { bgzf_t z; buf_t h = {0, 0, 0}; char txt[65536]; int n = 0;
-      z.f = fopen(fn, "wb"); z.n = 0; z.level = level; z.fpos = 0; if(!z.f) { perror(fn); return 1; }
+      memset(&z, 0, sizeof(z)); z.f = fopen(fn, "wb"); z.level = level; if(!z.f) { perror(fn); return 1; }
       n += snprintf(txt + n, sizeof(txt) - n, "@HD\tVN:1.6\tSO:coordinate\n");
       for(t = 0; t < nct; t++) n += snprintf(txt + n, sizeof(txt) - n, "@SQ\tSN:%s\tLN:%" PRId64 "\n", ct[t].name, ct[t].len);
       n += snprintf(txt + n, sizeof(txt) - n, "@PG\tID:mdk_synth\tPN:mdk_synth\tCL:seed=%" PRIu64 "\n", seed);
@@ -264,23 +307,29 @@ int main(int argc, char **argv) {
       bgzf_write(&z, h.p, h.l); bgzf_flush(&z);
       {   /* records + a BAI (linear index per contig, one catch-all bin 0 per contig holding the contig's byte range) */
           uint64_t **lin = calloc(nct, sizeof(uint64_t *)), *first = calloc(nct, 8), *last = calloc(nct, 8); size_t *nlin = calloc(nct, sizeof(size_t));
+          /* where every record starts / ends: (member, offset in member); the virtual offsets follow once the members are compressed */
+          size_t *rm = malloc((nrec + 1) * sizeof(size_t)), *em = malloc((nrec + 1) * sizeof(size_t)); uint32_t *rw = malloc((nrec + 1) * 4), *ew = malloc((nrec + 1) * 4); uint64_t end_fpos;
           for(t = 0; t < nct; t++) { nlin[t] = (size_t)((ct[t].len >> 14) + 1); lin[t] = calloc(nlin[t], 8); }
           for(i = 0; i < nrec; i++) {
-              uint64_t vo; int32_t tid = recs[i].tid, pos = recs[i].pos; int64_t w, w1; uint32_t ncig, k, rl = 0; const uint8_t *r = recs[i].d + 4;
               if(z.n + 4 > (int)sizeof(z.blk)) bgzf_flush(&z);          /* keep the block_size word inside one member */
               /* as htslib does (bam_write1 -> bgzf_flush_try): a record that fits a member never straddles two */
               if(!split_records && z.n && recs[i].n <= sizeof(z.blk) && z.n + recs[i].n > sizeof(z.blk)) bgzf_flush(&z);
-              vo = (z.fpos << 16) | (uint64_t)z.n;
+              rm[i] = z.nm; rw[i] = (uint32_t)z.n;
+              bgzf_write(&z, recs[i].d, recs[i].n);
+              em[i] = z.nm; ew[i] = (uint32_t)z.n;
+          }
+          end_fpos = bgzf_finish(&z);
+          for(i = 0; i < nrec; i++) {
+              uint64_t vo = bgzf_voffset(&z, end_fpos, rm[i], rw[i]); int32_t tid = recs[i].tid, pos = recs[i].pos; int64_t w, w1; uint32_t ncig, k, rl = 0; const uint8_t *r = recs[i].d + 4;
               ncig = r[12] | (r[13] << 8);
               for(k = 0; k < ncig; k++) { const uint8_t *c = r + 32 + r[8] + 4 * k; uint32_t cv = c[0] | (c[1] << 8) | (c[2] << 16) | ((uint32_t)c[3] << 24), op = cv & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cv >> 4; }
               w1 = ((int64_t)pos + (rl ? rl : 1) - 1) >> 14;
               for(w = pos >> 14; w <= w1 && w < (int64_t)nlin[tid]; w++) if(!lin[tid][w]) lin[tid][w] = vo;
               if(!first[tid]) first[tid] = vo;
-              bgzf_write(&z, recs[i].d, recs[i].n);
-              last[tid] = (z.fpos << 16) | (uint64_t)z.n;
+              last[tid] = bgzf_voffset(&z, end_fpos, em[i], ew[i]);
           }
-          bgzf_flush(&z);
-          for(t = 0; t < nct; t++) if(first[t]) last[t] = z.fpos << 16;      /* generous end for the catch-all chunk */
+          for(t = 0; t < nct; t++) if(first[t]) last[t] = end_fpos << 16;      /* generous end for the catch-all chunk */
+          free(rm); free(em); free(rw); free(ew);
           if(!no_bai) {
               buf_t x = {0, 0, 0}; FILE *bf;
               bput(&x, "BAI\1", 4); b32(&x, (uint32_t)nct);
@@ -294,7 +343,7 @@ int main(int argc, char **argv) {
               fwrite(x.p, 1, x.l, bf); fclose(bf); free(x.p);
           }
       }
-      bgzf_close(&z); free(h.p); }
+      free(z.m); free(h.p); }
 
     if(want_bbm || want_bw) {     /* synthetic mappability track: values {0, 0.5, 1.0}; written as BBM and/or bigWig (same values) */
         typedef struct { int64_t beg, end; uint8_t val; } mrun; mrun **runs = calloc(nct, sizeof(mrun *)); size_t *nr = calloc(nct, sizeof(size_t));
