@@ -310,6 +310,13 @@ typedef struct md_comm md_comm;
 int  md_comm_unique_id(uint8_t *id /* [MD_COMM_ID_BYTES] */);
 int  md_comm_open_rank(md_dev *h, int rank, int world, const uint8_t *id, md_comm **out);
 int  md_comm_open_local(md_dev *const *h, int n, md_comm **out);
+/* one process per rank where ranks SHARE a physical device (tests of the multi-process path on a single GPU: RCCL refuses two ranks
+ * on one device): no RCCL; rank 0's receive buffers are mapped into the peers with HIP IPC and a "send" is a device copy into the
+ * mapping.  `oob` is the caller's out-of-band all-gather (every rank contributes `bytes` bytes, receives world*bytes in rank order;
+ * bench.py gives torch.distributed over gloo), used to agree on sizes and to pass the IPC handles round.  Only md_bench_* uses such
+ * a communicator. */
+typedef int (*md_comm_oob_fn)(void *ctx, const void *send, void *recv, uint64_t bytes);
+int  md_comm_open_rank_shared(md_dev *h, int rank, int world, md_comm_oob_fn oob, void *ctx, md_comm **out);
 void md_comm_close(md_comm *c);
 int  md_comm_world(const md_comm *c);
 int  md_comm_gather(md_comm *c, const void *const *d_send, const uint64_t *send_bytes, void *const *d_recv, const uint64_t *recv_bytes);

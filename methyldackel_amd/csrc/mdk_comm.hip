@@ -44,6 +44,7 @@ struct md_comm {
     int world = 0, n_local = 0; bool copies = false;          // copies: the local ranks share one physical device (tests): plain D2D copies, no RCCL
     std::vector<int> rank; std::vector<md_dev *> dev; std::vector<ncclComm_t> comm; std::vector<hipStream_t> stream; std::vector<hipEvent_t> ev;
     std::vector<CommStage> stage; int stage_slots = 0;
+    bool ipc = false; md_comm_oob_fn oob = nullptr; void *oob_ctx = nullptr;      // ranks of different processes on one device: IPC mappings instead of RCCL
 };
 
 extern "C" int md_comm_unique_id(uint8_t *id) {
@@ -73,6 +74,15 @@ extern "C" int md_comm_open_rank(md_dev *h, int rank, int world, const uint8_t *
     ncclUniqueId u; memcpy(&u, id, sizeof(u));
     ncclResult_t r = R->CommInitRank(&c->comm[0], world, u, rank);
     if(r != ncclSuccess) { delete c; return nfail(R, "ncclCommInitRank", r); }
+    int rc = comm_streams(c); if(rc) { delete c; return rc; }
+    *out = c;
+    return 0;
+}
+
+extern "C" int md_comm_open_rank_shared(md_dev *h, int rank, int world, md_comm_oob_fn oob, void *ctx, md_comm **out) {
+    if(!h || !out || !oob || world < 1 || rank < 0 || rank >= world) return fail(MDK_ERR_ARG, "md_comm_open_rank_shared", hipSuccess);
+    *out = nullptr;
+    md_comm *c = new md_comm(); c->world = world; c->n_local = 1; c->rank = {rank}; c->dev = {h}; c->ipc = true; c->oob = oob; c->oob_ctx = ctx;
     int rc = comm_streams(c); if(rc) { delete c; return rc; }
     *out = c;
     return 0;
@@ -209,6 +219,7 @@ struct md_bench {
     int64_t cap = 0, tcap = 0; size_t E = 0, off_var = 0, off_seg = 0;       // one chunk's region: sites, [var], tile segments
     uint8_t *send[2] = {nullptr, nullptr}; std::vector<uint8_t *> recv[2]; bool pending[2] = {false, false};
     hipStream_t stream = nullptr; hipEvent_t done[2] = {nullptr, nullptr};      // every launch goes to this one stream, followed by the copy of its status blocks and an event
+    uint8_t *ipc_dst[2] = {nullptr, nullptr};    // (ipc communicator, rank > 0) rank 0's receive buffers for this rank, mapped here
     int64_t last_g = -1; bool prep = false;      // prep: every launch prepares its chunks again from their resident raw records
 };
 
@@ -222,7 +233,7 @@ extern "C" void md_bench_close(md_bench *b) {
         Slot *s = get_slot(b->h, i);
         if(s && s->run == b->stream) s->run = nullptr;          // the launch stream goes away with the loop: the slot is collected on its own stream again
     }
-    for(int x = 0; x < 2; x++) { if(b->send[x]) (void)hipFree(b->send[x]); for(uint8_t *p : b->recv[x]) if(p) (void)hipFree(p); if(b->done[x]) (void)hipEventDestroy(b->done[x]); }
+    for(int x = 0; x < 2; x++) { if(b->ipc_dst[x]) (void)hipIpcCloseMemHandle(b->ipc_dst[x]); if(b->send[x]) (void)hipFree(b->send[x]); for(uint8_t *p : b->recv[x]) if(p) (void)hipFree(p); if(b->done[x]) (void)hipEventDestroy(b->done[x]); }
     if(b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     delete b;
 }
@@ -244,7 +255,12 @@ extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, 
         if(s->ntiles > b->tcap) b->tcap = s->ntiles;
         b->slots.push_back(slots[i]);
     }
-    if(comm && !comm->copies && !comm->comm.empty()) {
+    if(comm && comm->ipc) {      // the same agreement through the caller's out-of-band all-gather
+        std::vector<long long> all((size_t)2 * comm->world); long long mine[2] = {(long long)b->cap, (long long)b->tcap};
+        if(comm->oob(comm->oob_ctx, mine, all.data(), sizeof(mine))) { delete b; return fail(MDK_ERR_ARG, "md_bench_open: out-of-band all-gather failed", hipSuccess); }
+        for(int r = 0; r < comm->world; r++) { b->cap = std::max<int64_t>(b->cap, all[2 * r]); b->tcap = std::max<int64_t>(b->tcap, all[2 * r + 1]); }
+    }
+    if(comm && !comm->ipc && !comm->copies && !comm->comm.empty()) {
         // every rank sends one region per chunk and rank 0 posts a receive of the same size for it: the region must be sized by
         // the largest site count / tile count of ANY rank (the ranks hold different intervals), so the ranks agree on it here
         Rccl *R = rccl(); if(!R) { delete b; return MDK_ERR_NODEVICE; }
@@ -279,6 +295,13 @@ extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, 
             }
         }
     }
+    if(comm && comm->ipc) {      // rank 0 exports its receive buffers, every other rank maps the two that are meant for it
+        const int W = comm->world; std::vector<hipIpcMemHandle_t> mine((size_t)2 * W), all((size_t)2 * W * W);
+        memset(mine.data(), 0, sizeof(hipIpcMemHandle_t) * mine.size());
+        if(b->rank == 0) for(int x = 0; x < 2; x++) for(int r = 1; r < W; r++) { hipError_t e = hipIpcGetMemHandle(&mine[(size_t)x * W + r], b->recv[x][r]); if(e != hipSuccess) { md_bench_close(b); return fail(MDK_ERR_HIP, "hipIpcGetMemHandle", e); } }
+        if(comm->oob(comm->oob_ctx, mine.data(), all.data(), sizeof(hipIpcMemHandle_t) * mine.size())) { md_bench_close(b); return fail(MDK_ERR_ARG, "md_bench_open: out-of-band all-gather failed", hipSuccess); }
+        if(b->rank > 0) for(int x = 0; x < 2; x++) { hipError_t e = hipIpcOpenMemHandle((void **)&b->ipc_dst[x], all[(size_t)x * W + b->rank], hipIpcMemLazyEnablePeerAccess); if(e != hipSuccess) { md_bench_close(b); return fail(MDK_ERR_HIP, "hipIpcOpenMemHandle", e); } }
+    }
     *out = b;
     return 0;
 }
@@ -293,6 +316,13 @@ extern "C" int md_bench_set_prep(md_bench *b, int on) {
 
 static int bench_exchange(md_bench *b, int x) {
     if(!b->comm) return 0;
+    if(b->comm->ipc) {           // a device copy into rank 0's buffer, through the mapping; rank 0 has nothing to post
+        md_comm *c = b->comm;
+        if(b->rank > 0) HIPCHK(hipMemcpyAsync(b->ipc_dst[x], b->send[x], (size_t)b->E * (size_t)b->group, hipMemcpyDeviceToDevice, c->stream[0]));
+        HIPCHK(hipEventRecord(c->ev[0], c->stream[0]));
+        b->pending[x] = true;
+        return 0;
+    }
     const void *snd[1] = {b->send[x]}; uint64_t sb[1] = {(uint64_t)b->E * (uint64_t)b->group};
     std::vector<void *> rcv((size_t)b->world, nullptr); std::vector<uint64_t> rb((size_t)b->world, 0);
     if(b->rank == 0) for(int r = 1; r < b->world; r++) { rcv[r] = b->recv[x][r]; rb[r] = sb[0]; }

@@ -1,0 +1,36 @@
+"""GPU tests of bench.py's multi-rank path: `--gpus N` starts its ranks itself, n_gpus is the number of ranks that joined the exchange,
+and every launch's results travel to rank 0.  On a one-GPU box both ranks sit on device 0 and exchange through an IPC mapping of rank
+0's buffers (RCCL refuses two ranks on one device); with two or more devices the same command goes over RCCL (ncclSend/ncclRecv)."""
+import json
+import subprocess
+import sys
+
+import pytest
+
+import methyldackel_amd as mdk
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--passes", "2", "--no-cpu-baseline"] + list(extra),
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_two_ranks_on_one_device_exchange_every_launch():
+    j = run_bench("--devices", "0,0")
+    assert j["n_gpus"] == 2
+    assert j["exchange"]["exchanges"] == j["config"]["launches_per_step_per_gpu"] > 0
+    assert "IPC" in j["exchange"]["transport"]
+    assert j["value"] > 0 and j["scaling"] == "weak"
+
+
+def test_two_devices_exchange_over_rccl():
+    if mdk.lib_hip().md_dev_count() < 2:
+        pytest.skip("needs two GPUs: ncclSend/ncclRecv between devices")
+    j = run_bench()
+    assert j["n_gpus"] == 2 and j["exchange"]["exchanges"] > 0
+    assert "ncclSend" in j["exchange"]["transport"]

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Turn the rocprofv3 output of tools/gpu_round.sh (under gpurun_out/) into the small summaries kept in profiles/."""
-import collections, csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+"""Turn the rocprofv3 output of tools/gpu_round.sh (under gpurun_out/) into the small summaries kept in profiles/.
+One entry per kernel, keyed by its FULL name (template arguments included: round 2's summary matched "k_pileup_multi" by prefix and so
+averaged the CpG-only and the dense-context instantiation), and one per kernel family of bench.py's step."""
+import collections, csv, glob, json, os, re, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
+chunks = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
 
@@ -12,6 +15,12 @@ def find(d, name):
     return g[0] if g else None
 
 
+def canon(kernel_name):
+    n = re.sub(r"^void\s+", "", kernel_name.strip())
+    n = re.sub(r"\(.*\)\s*$", "", n)               # the argument list
+    return n.replace(", ", ",").replace(" ", "")
+
+
 kt = find("prof_kt", "kt_kernel_stats.csv")
 if kt:
     shutil.copy(kt, f"{dst}/{tag}_rocprofv3_kernel_stats.csv")
@@ -19,65 +28,35 @@ for f in ("bench.json", "bench_under_rocprof.json", "pytest_gpu.log", "smoke.log
     if os.path.exists(f"{src}/{tag}_{f}"):
         shutil.copy(f"{src}/{tag}_{f}", f"{dst}/{tag}_{f}")
 
-
-def counters(d, match):
-    f = find(d, "p_counter_collection.csv")
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))          # kernel -> counter -> values per dispatch
+for d in ("sq", "fetch", "write_lds", "cache"):
+    f = find("prof_pmc_" + d, "p_counter_collection.csv")
     if f:
         for r in csv.DictReader(open(f)):
-            for m in match:
-                if m in r["Kernel_Name"]:
-                    agg[m][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return agg
+            agg[canon(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
-
-pmc, pmc_single = {}, {}
-for d in ("sq", "fetch", "write_lds", "cache"):
-    c = counters("prof_pmc_" + d, ["k_pileup_multi", "k_pileup<"])
-    for k, v in c["k_pileup_multi"].items():
-        pmc[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
-    for k, v in c["k_pileup<"].items():
-        pmc_single[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
-CHUNKS = 8
-out = {"kernel": "k_pileup_multi<false> (8 resident 1 Mb chunks per launch)", "chunks_per_launch": CHUNKS,
-       "command": "python bench.py --no-cpu-baseline --steps 2 --warmup 1 --passes 4 (16 resident 1 Mb intervals in rotation, ~1 GB working set; one rocprofv3 --pmc pass per counter group)",
-       "counters": pmc, "counters_one_chunk_per_launch_k_pileup": pmc_single}
-
-# calibration: bytes of the distinct 64-byte lines each calibration kernel touches / what the counter reported (KiB)
-calib = {}
-exp = None
-try:
-    exp = json.loads([l for l in open(f"{src}/{tag}_calib_expected.json") if l.startswith("{")][-1])["expected"]
-except Exception:
-    pass
-if exp:
-    names = list(exp.keys())
-    fe, wr = counters("calib_fetch", names), counters("calib_write", names)
-    for n in names:
-        e = {"expected_bytes_64B_lines": exp[n]["bytes64"], "expected_bytes_128B_pairs": exp[n]["bytes128"]}
-        if fe[n].get("FETCH_SIZE"):
-            v = fe[n]["FETCH_SIZE"]; m = sum(v) / len(v) * 1024
-            e["FETCH_SIZE_bytes"] = m; e["fetch_factor_64"] = exp[n]["bytes64"] / m if m else None; e["fetch_factor_128"] = exp[n]["bytes128"] / m if m else None
-        if wr[n].get("WRITE_SIZE"):
-            v = wr[n]["WRITE_SIZE"]; m = sum(v) / len(v) * 1024
-            e["WRITE_SIZE_bytes"] = m; e["write_factor_64"] = exp[n]["bytes64"] / m if m else None
-        calib[n] = e
-    out["calibration"] = calib
-if "FETCH_SIZE" in pmc:
-    fs, ws = pmc["FETCH_SIZE"]["mean_per_dispatch"], pmc.get("WRITE_SIZE", {"mean_per_dispatch": 0})["mean_per_dispatch"]
-    ff = (calib.get("calib_gather_pair") or {}).get("fetch_factor_128")
-    wf = (calib.get("calib_write16") or {}).get("write_factor_64")
-    out["hbm_traffic_bytes_per_launch"] = {
-        "fetch_raw": fs * 1024, "write_raw": ws * 1024, "fetch_factor": ff, "write_factor": wf,
-        "fetch_calibrated": fs * 1024 * (ff if ff else 2.0), "write_calibrated": ws * 1024 * (wf if wf else 1.0),
-        "per_chunk": {"fetch_calibrated": fs * 1024 * (ff if ff else 2.0) / CHUNKS, "write_calibrated": ws * 1024 * (wf if wf else 1.0) / CHUNKS},
-        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) per k_pileup_multi dispatch (8 chunks) while rotating over 16 resident 1 Mb intervals (working set ~0.8 GB, beyond the "
-                "256 MiB Infinity Cache), multiplied by the factors tools/mdk_calib measured on this box for this kernel's own access patterns: FETCH_SIZE x %s "
-                "(calib_gather_pair: a sequence byte and a quality byte ~80 B apart per 228-byte read payload, 1 GiB buffer).  The calibration shows the memory side "
-                "moves 128-byte granules and the counter tallies each as 64 bytes: one byte from every 64-byte line and one byte from every second line both read as "
-                "half the buffer, so the factor is 2 against the distinct 128-byte granules touched (1.17 against distinct 64-byte lines); WRITE_SIZE x %s "
-                "(calib_write16: coalesced 16-byte stores)" % (("%.3f" % ff) if ff else "2 (uncalibrated)", ("%.3f" % wf) if wf else "1 (uncalibrated)")}
+kernels = {}
+for name, cs in agg.items():
+    if not name.startswith("k_"):
+        continue
+    e = {"name": name, "chunks_per_launch": chunks, "counters": {k: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)} for k, v in cs.items()}}
+    e["dispatches"] = max(len(v) for v in cs.values())
+    if "FETCH_SIZE" in cs:
+        fr = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024
+        wr = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024 if "WRITE_SIZE" in cs else 0.0
+        e["hbm_bytes_per_launch"] = {"fetch_raw": fr, "write_raw": wr, "fetch_x2_plus_write": 2 * fr + wr}
+    kernels[name] = e
+fam = {"pileup": ["k_pileup_multi<false,false>"], "preparation": ["k_prep_zero", "k_prep_scan", "k_prep_segs"], "pileup_dense": ["k_pileup_multi<false,true>"]}
+families = {}
+for fn, ks in fam.items():
+    have = [kernels[k] for k in ks if k in kernels and "hbm_bytes_per_launch" in kernels[k]]
+    if len(have) == len(ks):
+        families[fn] = {"kernels": ks, "dispatches": [k["dispatches"] for k in have], "chunks_per_launch": chunks,
+                        "hbm_bytes_per_launch": {x: sum(k["hbm_bytes_per_launch"][x] for k in have) for x in ("fetch_raw", "write_raw", "fetch_x2_plus_write")}}
+out = {"command": "python bench.py --no-cpu-baseline --steps 2 --warmup 1 --passes 4 (16 resident 1 Mb intervals in rotation, ~0.9 GB of records; one rocprofv3 --pmc pass per counter group)",
+       "unit_note": "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; fetch_x2_plus_write applies MI355X_MICROARCH.md's gfx950 correction (128-byte requests tallied as 64) to the fetch side only",
+       "kernels": kernels, "families": families}
 json.dump(out, open(f"{dst}/{tag}_rocprofv3_pmc_summary.json", "w"), indent=1)
 if kt:
     print(open(f"{dst}/{tag}_rocprofv3_kernel_stats.csv").read())
-print(json.dumps(out, indent=1)[:4000])
+print(json.dumps({k: v for k, v in families.items()}, indent=1)[:3000])
