@@ -6,7 +6,7 @@ ARCH   ?= gfx950
 HIPFLAGS ?=
 B      := methyldackel_amd/_build
 CFLAGS ?= -O2 -g -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -fPIC -pthread
-HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bigwig.c methyldackel_amd/csrc/host/mdk_mbias.c methyldackel_amd/csrc/host/mdk_mergecontext.c methyldackel_amd/csrc/host/mdk_plan.c methyldackel_amd/csrc/host/mdk_pipeline.c methyldackel_amd/csrc/host/mdk_emit.c methyldackel_amd/csrc/host/mdk_extract.c methyldackel_amd/csrc/host/mdk_cmd_mbias.c methyldackel_amd/csrc/host/mdk_cmd_perread.c methyldackel_amd/csrc/host/mdk_affinity.c
+HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bigwig.c methyldackel_amd/csrc/host/mdk_mbias.c methyldackel_amd/csrc/host/mdk_mergecontext.c methyldackel_amd/csrc/host/mdk_plan.c methyldackel_amd/csrc/host/mdk_pipeline.c methyldackel_amd/csrc/host/mdk_emit.c methyldackel_amd/csrc/host/mdk_extract.c methyldackel_amd/csrc/host/mdk_cmd_mbias.c methyldackel_amd/csrc/host/mdk_cmd_perread.c methyldackel_amd/csrc/host/mdk_affinity.c methyldackel_amd/csrc/host/mdk_ranks.c
 
 all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 

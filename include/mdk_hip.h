@@ -325,6 +325,18 @@ int  md_comm_wait(md_comm *c);
  * segments) is gathered to rank 0 over the links and read by the host from rank 0's memory; errors as md_dev_download.  The
  * returned arrays belong to the communicator and stay valid until the next md_comm_download of the same (src, slot). */
 int  md_comm_download(md_comm *c, int src, int slot, md_sites *out);
+/* One process per GPU (md_comm_open_rank): a finished chunk's result travels from the rank that computed it to rank 0, which writes the
+ * files.  The sizes go first, out of band (the command's TCP connection between the ranks): md_comm_result_header waits for the slot's
+ * kernels and describes what will be sent (rc = what md_dev_download would have returned: 0, MDK_ERR_PREP_HOST, MDK_ERR_STRAND0 ...);
+ * md_comm_result_send then posts the ncclSend of the three arrays (site records, variant evidence, tile segments) and
+ * md_comm_result_recv, on rank 0 with the header it was given, the matching ncclRecv, waits, copies to the host and orders the sites.
+ * The returned arrays belong to the communicator and stay valid until the next md_comm_result_recv from the same rank. */
+typedef struct { int64_t n_slots; int32_t n_tiles, variant, rc, reserved; } md_result_hdr;
+int  md_comm_result_header(md_dev *h, int slot, md_result_hdr *hdr);
+int  md_comm_result_send(md_comm *c, int slot, const md_result_hdr *hdr);
+int  md_comm_result_recv(md_comm *c, int src, const md_result_hdr *hdr, md_sites *out);
+/* PCI bus id of the handle's device ("0000:c1:00.0"): two ranks on the same physical device cannot be RCCL peers */
+int  md_dev_pci_bus_id(const md_dev *h, char *buf, int cap);
 
 /* The resident-input benchmark loop of bench.py: `n` uploaded slots holding different intervals are launched `group` at a
  * time (md_dev_launch_group; n a multiple of group, at least two groups) round robin, two launches in flight (launch g is

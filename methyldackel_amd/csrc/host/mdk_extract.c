@@ -144,6 +144,7 @@ int extract_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; cgroup *G = NULL; int rc, ret = 0, more = 1, cur = 0, i; devopen_t dop; pthread_t dth; int dth_ok; emitter em;
     double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta; int n_host_prep = 0; uint64_t n_groups = 0, n_chunks = 0;
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] entered at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
+    { int rk = 0, wd = 1, m = ranks_from_env(&rk, &wd); if(m < 0) return -1; if(m > 0) return extract_ranks(argc, argv, rk, wd); }       /* one process per GPU (mdk_ranks.c) */
     if(argc > 2) hip_warm_up();
     rc = mdk_plan_open(argc, argv, &p);
     t_open = now_s() - T0;

@@ -89,8 +89,10 @@ static int load_bbm(mdk_plan *p, FILE *f) {
     p->map_on = 1;
     return 0;
 }
-/* the 0..100 value the reference stores for one bigWig value (extract.c:1137-1144): (char)(raw*100 + 0.5), NaN -> 0 */
-static unsigned char map_value(float raw) { if(isnan(raw)) return 0; return (unsigned char)(char)((raw * 100) + 0.5); }
+/* the 0..100 value the reference stores for one bigWig value (extract.c:1137-1144): the float goes into a DOUBLE first (`double val_raw =
+ * vals->value[j]`), then (char)(val_raw*100 + 0.5), NaN -> 0.  The arithmetic is in double: 0.005f is 0.00499999988..., so it becomes 0, while
+ * a product formed in float would round to 0.5 and give 1 (tests/test_bigwig_edges.py holds the hand-computed values). */
+static unsigned char map_value(float raw) { const double val_raw = raw; if(isnan(raw)) return 0; return (unsigned char)(char)((val_raw * 100) + 0.5); }
 
 /* -M: mappability from a bigWig (extract.c:1071-1233), optionally re-encoded as BBM (-O / -N).  The run-length writer
  * follows the reference's state machine (runs of 2..155 as [len+99][v], longer as [255][u16 len][v], at most 65535 per run,

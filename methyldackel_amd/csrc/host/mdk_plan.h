@@ -148,4 +148,6 @@ MDK_LOCAL int fast_exit_wanted(void);
 MDK_LOCAL void leave_fast(int ret);
 MDK_LOCAL void hip_warm_up(void);
 MDK_LOCAL void *devopen_main(void *arg);
+MDK_LOCAL int ranks_from_env(int *rank, int *world);
+MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world);
 #endif

@@ -207,6 +207,67 @@ extern "C" int md_comm_download(md_comm *c, int src, int slot, md_sites *out) {
     return 0;
 }
 
+// ---- one process per GPU: a chunk's result from the rank that computed it to rank 0 (sizes travel out of band first) ----
+extern "C" int md_dev_pci_bus_id(const md_dev *h, char *buf, int cap) {
+    if(!h || !buf || cap < 16) return fail(MDK_ERR_ARG, "md_dev_pci_bus_id", hipSuccess);
+    HIPCHK(hipDeviceGetPCIBusId(buf, cap, h->device));
+    return 0;
+}
+extern "C" int md_comm_result_header(md_dev *h, int slot, md_result_hdr *hdr) {
+    if(!h || !hdr) return fail(MDK_ERR_ARG, "md_comm_result_header", hipSuccess);
+    memset(hdr, 0, sizeof(*hdr));
+    md_sites_dev dv; const int rc = md_dev_wait(h, slot, &dv);
+    hdr->rc = rc; hdr->variant = h->variant ? 1 : 0;
+    if(!rc) { hdr->n_slots = dv.n_slots; hdr->n_tiles = dv.n_tiles; }
+    return 0;
+}
+static void result_layout(const md_result_hdr *h, size_t &nS, size_t &nV, size_t &nT, size_t &oV, size_t &oT, size_t &tot) {
+    nS = (size_t)h->n_slots * sizeof(md_site); nV = h->variant ? (size_t)h->n_slots * sizeof(md_site_var) : 0; nT = (size_t)h->n_tiles * sizeof(md_tile_seg);
+    oV = (nS + 255) & ~(size_t)255; oT = (oV + nV + 255) & ~(size_t)255; tot = oT + nT + 256;
+}
+extern "C" int md_comm_result_send(md_comm *c, int slot, const md_result_hdr *hdr) {
+    if(!c || !hdr || c->n_local != 1 || c->comm.empty() || c->rank[0] == 0) return fail(MDK_ERR_ARG, "md_comm_result_send: needs a rank communicator (md_comm_open_rank) and a rank other than 0", hipSuccess);
+    if(hdr->rc || !hdr->n_slots) return 0;                     // nothing follows such a header
+    Rccl *R = rccl(); if(!R) return MDK_ERR_NODEVICE;
+    md_dev *h = c->dev[0]; Slot *s = get_slot(h, slot); if(!s) return MDK_ERR_ARG;
+    const md_site *d_site = s->b_site ? s->b_site : s->d_site.p; const md_site_var *d_var = s->b_site ? s->b_var : s->d_var.p; const md_tile_seg *d_seg = s->b_site ? s->b_seg : s->d_seg.p;
+    size_t nS, nV, nT, oV, oT, tot; result_layout(hdr, nS, nV, nT, oV, oT, tot);
+    HIPCHK(hipSetDevice(h->device));
+    NCHK(R->GroupStart());
+    ncclResult_t r = R->Send(d_site, nS, ncclUint8, 0, c->comm[0], c->stream[0]);
+    if(r == ncclSuccess && nV) r = R->Send(d_var, nV, ncclUint8, 0, c->comm[0], c->stream[0]);
+    if(r == ncclSuccess && nT) r = R->Send(d_seg, nT, ncclUint8, 0, c->comm[0], c->stream[0]);
+    if(r != ncclSuccess) { (void)R->GroupEnd(); return nfail(R, "ncclSend", r); }
+    NCHK(R->GroupEnd());
+    HIPCHK(hipEventRecord(c->ev[0], c->stream[0]));
+    return 0;
+}
+extern "C" int md_comm_result_recv(md_comm *c, int src, const md_result_hdr *hdr, md_sites *out) {
+    if(!c || !hdr || !out || c->n_local != 1 || c->comm.empty() || c->rank[0] != 0 || src < 1 || src >= c->world) return fail(MDK_ERR_ARG, "md_comm_result_recv: rank 0 of a rank communicator only", hipSuccess);
+    memset(out, 0, sizeof(*out));
+    if(hdr->rc) return hdr->rc;
+    if(!hdr->n_slots) return 0;
+    Rccl *R = rccl(); if(!R) return MDK_ERR_NODEVICE;
+    md_dev *h = c->dev[0];
+    if(c->stage.size() < (size_t)c->world) c->stage.resize((size_t)c->world);
+    CommStage &g = c->stage[(size_t)src];
+    size_t nS, nV, nT, oV, oT, tot; result_layout(hdr, nS, nV, nT, oV, oT, tot);
+    HIPCHK(hipSetDevice(h->device));
+    if(g.d.need(tot) || g.raw.need(tot) || g.site.need((size_t)hdr->n_slots + 1) || (hdr->variant && g.var.need((size_t)hdr->n_slots + 1))) return MDK_ERR_NOMEM;
+    NCHK(R->GroupStart());
+    ncclResult_t r = R->Recv(g.d.p, nS, ncclUint8, src, c->comm[0], c->stream[0]);
+    if(r == ncclSuccess && nV) r = R->Recv(g.d.p + oV, nV, ncclUint8, src, c->comm[0], c->stream[0]);
+    if(r == ncclSuccess && nT) r = R->Recv(g.d.p + oT, nT, ncclUint8, src, c->comm[0], c->stream[0]);
+    if(r != ncclSuccess) { (void)R->GroupEnd(); return nfail(R, "ncclRecv", r); }
+    NCHK(R->GroupEnd());
+    HIPCHK(hipMemcpyAsync(g.raw.p, g.d.p, oT + nT, hipMemcpyDeviceToHost, c->stream[0]));
+    HIPCHK(hipStreamSynchronize(c->stream[0]));
+    const int64_t n = md_sites_order((const md_site *)g.raw.p, hdr->variant ? (const md_site_var *)(g.raw.p + oV) : nullptr, (const md_tile_seg *)(g.raw.p + oT), hdr->n_tiles, hdr->n_slots, g.site.p, hdr->variant ? g.var.p : nullptr);
+    if(n < 0) return fail(MDK_ERR_ARG, "md_comm_result_recv: inconsistent tile segments", hipSuccess);
+    out->n_sites = n; out->site = g.site.p; out->var = hdr->variant ? g.var.p : nullptr;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Resident-input benchmark loop (bench.py): `n` uploaded slots holding different intervals are launched `group` at a time
 // (md_dev_launch_group: one kernel over `group` chunks), the groups round robin, two launches in flight -- launch g is
