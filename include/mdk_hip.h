@@ -299,17 +299,15 @@ int  md_dev_bench_rotate(md_dev *h, const int *slots, int n, int per_launch, int
 /* ---- multi-GPU: the exchange step of the interval-sharded path (SURVEY.md 8b last row, 8e) ----
  * Chunk k of the reference's schedule belongs to GPU k mod N; per-interval site buffers travel to rank 0 (whose host writes
  * the files) with ncclSend/ncclRecv groups over xGMI -- a gather, never a reduction.  RCCL is loaded on first use.
- *   md_comm_open_rank   one process per GPU (torchrun-style launch): rank 0 makes an id, every rank gets it out of band
- *   md_comm_open_local  one process driving n device handles = ranks 0..n-1 (`MethylDackel extract` with MDK_GPUS=n).
- *                       Handles that share one physical device (tests on a single GPU) exchange with device copies.
- * md_comm_gather: d_send/send_bytes are indexed by LOCAL rank, d_recv/recv_bytes by GLOBAL rank (read only where rank 0 is
- * local; entry 0 may be NULL to leave rank 0's own buffer where it is).  Sizes must agree on both sides.  Asynchronous:
+ *   md_comm_open_rank   one process per GPU (torchrun-style launch, or the command's own ranks mode, csrc/host/mdk_ranks.c):
+ *                       rank 0 makes an id, every rank gets it out of band
+ * md_comm_gather: d_send/send_bytes have one entry (this rank's buffer), d_recv/recv_bytes are indexed by rank and only read
+ * on rank 0 (entry 0 may be NULL to leave rank 0's own buffer where it is).  Sizes must agree on both sides.  Asynchronous:
  * the send buffers must be complete before the call, and md_comm_wait must return before either side is touched again. */
 #define MD_COMM_ID_BYTES 128
 typedef struct md_comm md_comm;
 int  md_comm_unique_id(uint8_t *id /* [MD_COMM_ID_BYTES] */);
 int  md_comm_open_rank(md_dev *h, int rank, int world, const uint8_t *id, md_comm **out);
-int  md_comm_open_local(md_dev *const *h, int n, md_comm **out);
 /* one process per rank where ranks SHARE a physical device (tests of the multi-process path on a single GPU: RCCL refuses two ranks
  * on one device): no RCCL; rank 0's receive buffers are mapped into the peers with HIP IPC and a "send" is a device copy into the
  * mapping.  `oob` is the caller's out-of-band all-gather (every rank contributes `bytes` bytes, receives world*bytes in rank order;
@@ -321,10 +319,6 @@ void md_comm_close(md_comm *c);
 int  md_comm_world(const md_comm *c);
 int  md_comm_gather(md_comm *c, const void *const *d_send, const uint64_t *send_bytes, void *const *d_recv, const uint64_t *recv_bytes);
 int  md_comm_wait(md_comm *c);
-/* md_dev_download for a chunk computed on rank `src` of a LOCAL communicator: its site buffer (records, variant evidence, tile
- * segments) is gathered to rank 0 over the links and read by the host from rank 0's memory; errors as md_dev_download.  The
- * returned arrays belong to the communicator and stay valid until the next md_comm_download of the same (src, slot). */
-int  md_comm_download(md_comm *c, int src, int slot, md_sites *out);
 /* One process per GPU (md_comm_open_rank): a finished chunk's result travels from the rank that computed it to rank 0, which writes the
  * files.  The sizes go first, out of band (the command's TCP connection between the ranks): md_comm_result_header waits for the slot's
  * kernels and describes what will be sent (rc = what md_dev_download would have returned: 0, MDK_ERR_PREP_HOST, MDK_ERR_STRAND0 ...);

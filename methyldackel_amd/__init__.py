@@ -141,7 +141,7 @@ md_comm_oob_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ui
 
 HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
-               "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_rank_shared", "md_comm_open_local", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_download", "md_comm_result_header", "md_comm_result_send", "md_comm_result_recv", "md_dev_pci_bus_id",
+               "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_rank_shared", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_result_header", "md_comm_result_send", "md_comm_result_recv", "md_dev_pci_bus_id",
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned", "md_host_profile",
                "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep", "md_dev_bench_prep_rotate", "md_bench_set_prep",
                "md_dev_mbias_submit", "md_dev_mbias_submit_raw", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
@@ -196,12 +196,10 @@ def lib_hip():
         L.md_comm_open_rank_shared.argtypes = [C.c_void_p, C.c_int, C.c_int, md_comm_oob_fn, C.c_void_p, C.POINTER(C.c_void_p)]
         L.md_bench_set_prep.argtypes = [C.c_void_p, C.c_int]
         L.md_dev_bench_prep_rotate.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
-        L.md_comm_open_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
         L.md_comm_close.argtypes = [C.c_void_p]; L.md_comm_close.restype = None
         L.md_comm_world.argtypes = [C.c_void_p]
         L.md_comm_gather.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
         L.md_comm_wait.argtypes = [C.c_void_p]
-        L.md_comm_download.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(md_sites)]
         L.md_bench_open.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.md_bench_run.argtypes = [C.c_void_p, C.c_int64, C.POINTER(md_bench_run_result)]
         L.md_bench_verify.argtypes = [C.c_void_p]
@@ -551,11 +549,53 @@ def sites_to_rows(s: md_sites):
     return rows
 
 
-def run_cli(args, cwd=None, env=None, command="extract"):
-    """Run the `MethylDackel extract` (or `mbias`) command of this build; returns CompletedProcess."""
+def run_cli(args, cwd=None, env=None, command="extract", ranks=None):
+    """Run the `MethylDackel extract` (or `mbias`) command of this build; returns CompletedProcess.  `ranks=N` runs the command
+    as N processes, one per GPU (csrc/host/mdk_ranks.c), and returns rank 0's."""
     if not CLI.exists():
         raise MdkError(f"{CLI} is missing (run `make`)")
     e = dict(os.environ)
     if env:
         e.update(env)
+    if ranks:
+        return run_ranks(args, ranks, cwd=cwd, env=e, command=command)
+    if "MDK_WORLD" not in e:
+        e["MDK_NO_RANKS"] = "1"        # a caller that is itself a torchrun rank (bench.py) runs the command alone, not as its rank
     return subprocess.run([str(CLI), command] + [str(a) for a in args], cwd=cwd, env=e, capture_output=True, text=True)
+
+
+def run_ranks(args, n, cwd=None, env=None, command="extract", devices=None, timeout=900):
+    """`MethylDackel extract` as N processes: rank k takes chunks k, k+N, ... of the one schedule every rank derives from the
+    same inputs, and rank 0 collects and writes (csrc/host/mdk_ranks.c; the launcher a site would use is `torchrun
+    --no-python` or tools/extract_ranks.sh).  `devices`: GPU ordinal per rank (default: rank k on GPU k modulo the visible
+    GPUs).  Returns rank 0's CompletedProcess with `.rank_returncodes` and `.rank_stderr` of all ranks."""
+    import socket
+    if not CLI.exists():
+        raise MdkError(f"{CLI} is missing (run `make`)")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update({"MDK_RANK": str(r), "MDK_WORLD": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        if devices is not None:
+            e["MDK_DEVICE"] = str(devices[r])
+        procs.append(subprocess.Popen([str(CLI), command] + [str(a) for a in args], cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        import threading
+        res = [None] * n
+
+        def drain(i):
+            res[i] = procs[i].communicate(timeout=timeout)
+        ths = [threading.Thread(target=drain, args=(i,)) for i in range(n)]
+        [t.start() for t in ths]; [t.join() for t in ths]
+        outs = res
+    finally:
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.kill()
+    out0 = outs[0] or ("", "")
+    cp = subprocess.CompletedProcess(procs[0].args, procs[0].returncode, out0[0], out0[1])
+    cp.rank_returncodes = [p_.returncode for p_ in procs]
+    cp.rank_stderr = [(o or ("", ""))[1] for o in outs]
+    return cp

@@ -56,9 +56,10 @@ int main(int argc, char *argv[]) {
     if(!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage_main(); return 0; }
     if(!strcmp(argv[1], "-v") || !strcmp(argv[1], "--version")) { printf("0.6.1 (using HTSlib version none; methyldackel_amd MI355X build)\n"); return 0; }
     if(!strcmp(argv[1], "extract") || !strcmp(argv[1], "mbias") || !strcmp(argv[1], "perRead")) {
-        /* one GPU: stay on the CPUs next to it (the inflate threads first-touch what the GPU uploads from); several GPUs: float */
-        const char *g = getenv("MDK_GPUS"), *dv = getenv("MDK_DEVICE");
-        if(!g || !*g || !strcmp(g, "1")) (void)mdk_bind_to_device_node(dv ? atoi(dv) : 0);
+        /* stay on the CPUs next to the GPU (the inflate threads first-touch what the GPU uploads from); a rank of a several-GPU run
+         * (csrc/host/mdk_ranks.c) takes the device its rank names */
+        const char *dv = getenv("MDK_DEVICE"), *lr = getenv("LOCAL_RANK"), *mr = getenv("MDK_RANK");
+        (void)mdk_bind_to_device_node(dv ? atoi(dv) : lr ? atoi(lr) : mr ? atoi(mr) : 0);
     }
     {   /* a process about to end need not unpin buffers and shut the runtime down politely (MDK_FAST_EXIT: the command leaves with
          * _exit once its outputs are closed).  A command that comes BACK here returned early -- a bad option, a missing input -- possibly

@@ -52,86 +52,6 @@ MDK_LOCAL void hip_warm_up(void) {
 /* md_dev_last_error is per thread: keep the text of a failed open for the thread that reports it */
 MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); if(d->rc) snprintf(d->err, sizeof(d->err), "%s", md_dev_last_error()); return NULL; }
 
-/* ------------------------------------------------------------------------------------------------ */
-/* several GPUs of one node (MDK_GPUS=N): interval sharding                                          */
-/* ------------------------------------------------------------------------------------------------ */
-/* One host pipeline feeds N devices: chunk k of the reference's schedule (extract.c:325-350) goes to device k mod N, two
- * slots per device, so up to 2N chunks are in flight.  Results come back in chunk order: a chunk of device 0 is downloaded
- * directly, any other chunk's site buffer is first gathered to device 0 over xGMI (md_comm_download: ncclSend/ncclRecv) and
- * read from there, while the chunks submitted after it keep the other devices busy.  MDK_GPU_MAP=a,b,... names the
- * physical device of each rank (ranks that share a device exchange with device copies: tests on a single GPU). */
-#define MDK_MAX_GPUS 16
-static int parse_gpus(int *map) {
-    const char *g = getenv("MDK_GPUS"), *m = getenv("MDK_GPU_MAP"); int n = 1, i, avail = md_dev_count();
-    if(!g || !*g) return 1;
-    n = !strcmp(g, "all") ? avail : atoi(g);
-    if(n < 1) n = 1;
-    if(n > MDK_MAX_GPUS) n = MDK_MAX_GPUS;
-    for(i = 0; i < n; i++) map[i] = i;
-    if(m) { for(i = 0; i < n && *m; i++) { map[i] = atoi(m); while(*m && *m != ',') m++; if(*m == ',') m++; } }
-    else if(n > avail && avail > 0) { fprintf(stderr, "[mdk] MDK_GPUS=%d but only %d device(s) are visible\n", n, avail); return -1; }
-    return n;
-}
-typedef struct { md_dev_cfg cfg; int device; md_dev *dev; int rc; char err[512]; } gpuopen_t;
-static void *gpuopen_main(void *arg) { gpuopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); if(d->rc) snprintf(d->err, sizeof(d->err), "%s", md_dev_last_error()); return NULL; }
-
-static int extract_multi(mdk_plan *p, int N, const int *map) {
-    md_dev *dev[MDK_MAX_GPUS]; gpuopen_t go[MDK_MAX_GPUS]; pthread_t th[MDK_MAX_GPUS]; int made[MDK_MAX_GPUS]; md_comm *comm = NULL; emitter em;
-    mdk_chunk *ring = NULL; int where[2 * MDK_MAX_GPUS][2]; int F = 2 * N, head = 0, count = 0, more = 1, ret = 0, rc, i; uint32_t k = 0; md_prep_cfg pc;      /* where[i]: device and slot of ring[i] */
-    memset(dev, 0, sizeof(dev));
-    for(i = 0; i < N; i++) { memset(&go[i], 0, sizeof(go[i])); mdk_plan_dev_cfg(p, &go[i].cfg); go[i].device = map[i]; made[i] = pthread_create(&th[i], NULL, gpuopen_main, &go[i]) == 0; }
-    if(!p->started && pipeline_start(p)) ret = -5;
-    for(i = 0; i < N; i++) { if(made[i]) pthread_join(th[i], NULL); else gpuopen_main(&go[i]); dev[i] = go[i].dev; }
-    for(i = 0; i < N && !ret; i++) if(go[i].rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", go[i].device, go[i].err); ret = MDK_RC_NODEVICE; }
-    if(!ret && md_comm_open_local(dev, N, &comm)) { fprintf(stderr, "[mdk] cannot set up the exchange between the GPUs: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; }
-    if(!ret && p->dev_prep) { mdk_plan_prep_cfg(p, &pc); for(i = 0; i < N; i++) md_dev_set_prep(dev[i], &pc); }
-    if(!ret) { ring = calloc((size_t)F, sizeof(mdk_chunk)); if(!ring) ret = -5; }
-    if(!ret && emitter_start(&em, p, emit_threads(p))) ret = -5;
-    if(ret) { free(ring); if(comm) md_comm_close(comm); for(i = 0; i < N; i++) if(dev[i]) md_dev_close(dev[i]); mdk_plan_close(p); return ret; }
-    while(more || count) {
-        if(more && count < F) {                                 /* submit chunk k on device k mod N, slot (k / N) mod 2 */
-            const int at = (head + count) % F; mdk_chunk *c = &ring[at];
-            rc = mdk_plan_next_chunk(p, c);
-            if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
-            if(rc == 0) { more = 0; continue; }
-            if(!c->skipped) {
-                const int d = (int)(k % (uint32_t)N), sl = (int)((k / (uint32_t)N) & 1);
-                rc = mdk_plan_ensure_reference(p, dev[d], c->tid);
-                if(!rc) rc = c->prep ? md_dev_submit_raw(dev[d], sl, &c->raw) : md_dev_submit(dev[d], sl, &c->batch);
-                if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
-                where[at][0] = d; where[at][1] = sl;
-                k++;
-            }
-            count++;
-            continue;
-        }
-        {   /* collect the oldest chunk */
-            mdk_chunk *c = &ring[head]; md_sites sites; memset(&sites, 0, sizeof(sites));
-            if(!c->skipped) {
-                const int d = where[head][0], sl = where[head][1];
-                rc = md_comm_download(comm, d, sl, &sites);
-                if(rc == MDK_ERR_PREP_HOST) {
-                    rc = mdk_plan_host_prepare(p, c);
-                    if(!rc) rc = md_dev_submit(dev[d], sl, &c->batch);
-                    if(!rc) rc = md_comm_download(comm, d, sl, &sites);
-                }
-                if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
-                if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
-            }
-            if(emitter_push(&em, c, &sites)) { ret = MDK_RC_DEVICE; break; }
-            head = (head + 1) % F; count--;
-        }
-    }
-    emitter_stop(&em);
-    if(em.failed && !ret) ret = MDK_RC_OUTPUT;
-    if(ret == 0) mdk_plan_finish(p);
-    if(fast_exit_wanted()) leave_fast(ret);
-    free(ring); md_comm_close(comm);
-    for(i = 0; i < N; i++) md_dev_close(dev[i]);
-    mdk_plan_close(p);
-    return ret;
-}
-
 /* Chunks travel to the device in GROUPS of up to MDK_GROUP: a 1 Mb chunk alone is fewer than two workgroups per CU and pays every
  * launch boundary itself, so whatever the reader has ready when a group is opened (at least one chunk, at most eight) is uploaded
  * into the group's slots and prepared and piled up with one launch per kernel (md_dev_launch_group); while that runs, the next
@@ -158,7 +78,6 @@ int extract_main(int argc, char *argv[]) {
     /* the per-record work of a chunk (admission, strand, name pairing, CIGAR expansion) runs on the device; MDK_HOST_PREP=1 keeps
      * it on the host's chunk workers (the round-1 arrangement, and what a chunk the device gives up on falls back to) */
     if(!getenv("MDK_HOST_PREP")) mdk_plan_set_prep(p, 1);
-    { int map[MDK_MAX_GPUS], n = parse_gpus(map); if(n < 0) { mdk_plan_close(p); return MDK_RC_NODEVICE; } if(n > 1) { mdk_plan_set_hold(p, 2 * n + 1); return extract_multi(p, n, map); } }
     mdk_plan_set_hold(p, 2 * MDK_GROUP + 1);
     dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
     if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }

@@ -286,7 +286,7 @@ MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional
      * is a DMA off the submitting thread -- the pinned double-buffered feed of the north star, for inputs of any size */
     md_host_set_pinned(0);
     /* the test hook that leaves every piece after the header's to the device only makes sense where a device will be attached */
-    if(o->mbias || o->perread || getenv("MDK_HOST_INFLATE") || getenv("MDK_HOST_PREP") || (getenv("MDK_GPUS") && atoi(getenv("MDK_GPUS")) > 1)) unsetenv("MDK_DEVICE_INFLATE_ONLY");
+    if(o->mbias || o->perread || getenv("MDK_HOST_INFLATE") || getenv("MDK_HOST_PREP")) unsetenv("MDK_DEVICE_INFLATE_ONLY");
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
     if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
     p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */

@@ -20,6 +20,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 
 typedef struct { int rank, world, *fd; } ranks_t;       /* rank 0: fd[r] = connection to rank r; the others: fd[0] = connection to rank 0 */
 
@@ -36,6 +37,7 @@ static int ranks_open(ranks_t *R) {
         struct sockaddr_in a; int ls = socket(AF_INET, SOCK_STREAM, 0);
         if(ls < 0) return -1;
         setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        { struct timeval tv; tv.tv_sec = 120; tv.tv_usec = 0; setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv)); }      /* accept() gives up on a peer that never shows */
         memset(&a, 0, sizeof(a)); a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_ANY); a.sin_port = htons((uint16_t)port);
         if(bind(ls, (struct sockaddr *)&a, sizeof(a)) || listen(ls, R->world)) { fprintf(stderr, "[mdk] rank 0 cannot listen on port %d: %s\n", port, strerror(errno)); close(ls); return -1; }
         for(i = 1; i < R->world; i++) {
@@ -141,17 +143,18 @@ MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world) {
     mdk_plan_set_hold(p, F + 3);
     memset(&dop, 0, sizeof(dop)); mdk_plan_dev_cfg(p, &dop.cfg); dop.cfg.n_slots = 2;
     { int nd = md_dev_count(); const char *lr = getenv("LOCAL_RANK"); dop.device = getenv("MDK_DEVICE") ? atoi(getenv("MDK_DEVICE")) : nd > 0 ? (lr ? atoi(lr) : rank) % nd : 0; }
+    /* the control connections first: a rank that cannot get its device says so by hanging up, and nobody waits for it */
+    if(ranks_open(&R)) { ranks_close(&R); mdk_plan_close(p); return MDK_RC_DEVICE; }
     devopen_main(&dop); dev = dop.dev;
-    if(dop.rc) { fprintf(stderr, "[mdk] rank %d cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", rank, dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(dop.rc) { fprintf(stderr, "[mdk] rank %d cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", rank, dop.device, dop.err); ranks_close(&R); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); mdk_plan_attach_device(p, dev); }
     /* bootstrap: everybody tells rank 0 which device it sits on; rank 0 decides the data channel and hands the RCCL id round */
-    if(ranks_open(&R)) { ret = MDK_RC_DEVICE; goto out; }
     (void)md_dev_pci_bus_id(dev, pci, (int)sizeof(pci));
     if(rank == 0) {
         char (*all)[64] = calloc((size_t)world, 64); int j;
         if(!all) { ret = -5; goto out; }
         snprintf(all[0], 64, "%s", pci);
-        for(i = 1; i < world; i++) if(rd_all(R.fd[i], all[i], 64)) { free(all); ret = MDK_RC_DEVICE; goto out; }
+        for(i = 1; i < world; i++) if(rd_all(R.fd[i], all[i], 64)) { fprintf(stderr, "[mdk] rank %d left before the run began\n", i); free(all); ret = MDK_RC_DEVICE; goto out; }
         for(i = 0; i < world; i++) for(j = 0; j < i; j++) if(!strncmp(all[i], all[j], 64)) use_rccl = 0;     /* two ranks on one physical device (all on this node: torchrun --nnodes=1) */
         if(getenv("MDK_RANKS_TCP")) use_rccl = 0;
         free(all);

@@ -37,11 +37,11 @@ static Rccl *rccl() {
 static int nfail(Rccl *R, const char *what, ncclResult_t r) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "%s: %s", what, R->GetErrorString(r)); return MDK_ERR_HIP; }
 #define NCHK(call) do { ncclResult_t r_ = (call); if(r_ != ncclSuccess) return nfail(R, #call, r_); } while(0)
 
-// A communicator over `world` ranks, root 0.  This process drives `n_local` of them: one (its own GPU) when there is one
-// process per GPU, all of them when one process feeds every GPU of the node.
+// A communicator over `world` ranks, root 0: one process per GPU, so this process drives exactly one of them (n_local == 1;
+// the vectors are what is left of a one-process-many-devices mode that the process-per-GPU command replaced).
 struct CommStage { DBuf<uint8_t> d; HBuf<uint8_t> raw; HBuf<md_site> site; HBuf<md_site_var> var; };      // where rank 0 receives one (rank, slot)'s result
 struct md_comm {
-    int world = 0, n_local = 0; bool copies = false;          // copies: the local ranks share one physical device (tests): plain D2D copies, no RCCL
+    int world = 0, n_local = 0;
     std::vector<int> rank; std::vector<md_dev *> dev; std::vector<ncclComm_t> comm; std::vector<hipStream_t> stream; std::vector<hipEvent_t> ev;
     std::vector<CommStage> stage; int stage_slots = 0;
     bool ipc = false; md_comm_oob_fn oob = nullptr; void *oob_ctx = nullptr;      // ranks of different processes on one device: IPC mappings instead of RCCL
@@ -88,25 +88,6 @@ extern "C" int md_comm_open_rank_shared(md_dev *h, int rank, int world, md_comm_
     return 0;
 }
 
-extern "C" int md_comm_open_local(md_dev *const *h, int n, md_comm **out) {
-    if(!h || !out || n < 1) return fail(MDK_ERR_ARG, "md_comm_open_local", hipSuccess);
-    *out = nullptr;
-    md_comm *c = new md_comm(); c->world = n; c->n_local = n;
-    bool shared = false;
-    for(int i = 0; i < n; i++) { if(!h[i]) { delete c; return fail(MDK_ERR_ARG, "md_comm_open_local: null device", hipSuccess); } c->rank.push_back(i); c->dev.push_back(h[i]); for(int j = 0; j < i; j++) if(h[j]->device == h[i]->device) shared = true; }
-    c->copies = shared || n == 1;
-    if(!c->copies) {
-        Rccl *R = rccl(); if(!R) { delete c; return MDK_ERR_NODEVICE; }
-        std::vector<int> devs; for(int i = 0; i < n; i++) devs.push_back(h[i]->device);
-        c->comm.resize(n);
-        ncclResult_t r = R->CommInitAll(c->comm.data(), n, devs.data());
-        if(r != ncclSuccess) { delete c; return nfail(R, "ncclCommInitAll", r); }
-    }
-    int rc = comm_streams(c); if(rc) { delete c; return rc; }
-    *out = c;
-    return 0;
-}
-
 extern "C" void md_comm_close(md_comm *c) {
     if(!c) return;
     for(int i = 0; i < c->n_local; i++) {
@@ -130,15 +111,7 @@ extern "C" int md_comm_gather(md_comm *c, const void *const *d_send, const uint6
     int root_local = -1;
     for(int i = 0; i < c->n_local; i++) if(c->rank[i] == 0) root_local = i;
     if(root_local >= 0 && (!d_recv || !recv_bytes)) return fail(MDK_ERR_ARG, "md_comm_gather: the root needs receive buffers", hipSuccess);
-    if(c->copies) {        // every rank is local and on one device: the "links" are device-to-device copies
-        for(int i = 0; i < c->n_local; i++) {
-            const int r = c->rank[i];
-            if(!d_recv[r] || d_recv[r] == d_send[i] || !send_bytes[i]) continue;
-            if(recv_bytes[r] != send_bytes[i]) return fail(MDK_ERR_ARG, "md_comm_gather: size mismatch", hipSuccess);
-            HIPCHK(hipSetDevice(c->dev[i]->device));
-            HIPCHK(hipMemcpyAsync(d_recv[r], d_send[i], (size_t)send_bytes[i], hipMemcpyDeviceToDevice, c->stream[i]));
-        }
-    } else {
+    {
         Rccl *R = rccl(); if(!R) return MDK_ERR_NODEVICE;
         NCHK(R->GroupStart());
         for(int i = 0; i < c->n_local; i++) {
@@ -166,44 +139,6 @@ extern "C" int md_comm_gather(md_comm *c, const void *const *d_send, const uint6
 extern "C" int md_comm_wait(md_comm *c) {
     if(!c) return fail(MDK_ERR_ARG, "md_comm_wait", hipSuccess);
     for(int i = 0; i < c->n_local; i++) { HIPCHK(hipSetDevice(c->dev[i]->device)); HIPCHK(hipEventSynchronize(c->ev[i])); }
-    return 0;
-}
-
-// md_dev_download for a chunk that another GPU of a local communicator computed: the per-interval site buffer travels from
-// rank `src` to rank 0 over the links (site records, variant evidence, tile segments -- one exchange each), and rank 0's host
-// reads it from rank 0's memory.  This is the "RCCL gather of per-interval bedGraph buffers" of the sharded command.
-extern "C" int md_comm_download(md_comm *c, int src, int slot, md_sites *out) {
-    if(!c || !out || src < 0 || src >= c->world || c->n_local != c->world) return fail(MDK_ERR_ARG, "md_comm_download: needs a local communicator", hipSuccess);
-    md_dev *root = c->dev[0], *from = c->dev[src];
-    if(src == 0) return md_dev_download(root, slot, out);
-    memset(out, 0, sizeof(*out));
-    md_sites_dev dv;
-    int rc = md_dev_wait(from, slot, &dv); if(rc) return rc;
-    if(slot >= c->stage_slots) { c->stage_slots = slot + 1; c->stage.resize((size_t)c->world * 64); }
-    if(slot >= 64) return fail(MDK_ERR_ARG, "md_comm_download: slot", hipSuccess);
-    CommStage &g = c->stage[(size_t)src * 64 + slot];
-    const bool variant = dv.d_var != nullptr;
-    const size_t nS = (size_t)dv.n_slots * sizeof(md_site), nV = variant ? (size_t)dv.n_slots * sizeof(md_site_var) : 0, nT = (size_t)dv.n_tiles * sizeof(md_tile_seg);
-    const size_t oV = (nS + 255) & ~(size_t)255, oT = (oV + nV + 255) & ~(size_t)255, tot = oT + nT + 256;
-    HIPCHK(hipSetDevice(root->device));
-    if(g.d.need(tot) || g.raw.need(tot) || g.site.need((size_t)dv.n_slots + 1) || (variant && g.var.need((size_t)dv.n_slots + 1))) return MDK_ERR_NOMEM;
-    const void *parts[3] = {dv.d_site, dv.d_var, dv.d_seg}; const size_t bytes[3] = {nS, nV, nT}, offs[3] = {0, oV, oT};
-    std::vector<const void *> snd((size_t)c->n_local, nullptr); std::vector<uint64_t> sb((size_t)c->n_local, 0);
-    std::vector<void *> rcv((size_t)c->world, nullptr); std::vector<uint64_t> rb((size_t)c->world, 0);
-    for(int k = 0; k < 3; k++) {
-        if(!bytes[k]) continue;
-        snd[src] = parts[k]; sb[src] = bytes[k]; rcv[src] = g.d.p + offs[k]; rb[src] = bytes[k];
-        rc = md_comm_gather(c, snd.data(), sb.data(), rcv.data(), rb.data()); if(rc) return rc;
-    }
-    rc = md_comm_wait(c); if(rc) return rc;
-    HIPCHK(hipSetDevice(root->device));
-    if(nS) HIPCHK(hipMemcpy(g.raw.p, g.d.p, oT + nT, hipMemcpyDeviceToHost));
-    int64_t n = 0;
-    if(dv.n_slots) {
-        n = md_sites_order((const md_site *)g.raw.p, variant ? (const md_site_var *)(g.raw.p + oV) : nullptr, (const md_tile_seg *)(g.raw.p + oT), dv.n_tiles, dv.n_slots, g.site.p, variant ? g.var.p : nullptr);
-        if(n < 0) return fail(MDK_ERR_ARG, "md_comm_download: inconsistent tile segments", hipSuccess);
-    }
-    out->n_sites = n; out->site = g.site.p; out->var = variant ? g.var.p : nullptr;
     return 0;
 }
 
@@ -321,7 +256,7 @@ extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, 
         if(comm->oob(comm->oob_ctx, mine, all.data(), sizeof(mine))) { delete b; return fail(MDK_ERR_ARG, "md_bench_open: out-of-band all-gather failed", hipSuccess); }
         for(int r = 0; r < comm->world; r++) { b->cap = std::max<int64_t>(b->cap, all[2 * r]); b->tcap = std::max<int64_t>(b->tcap, all[2 * r + 1]); }
     }
-    if(comm && !comm->ipc && !comm->copies && !comm->comm.empty()) {
+    if(comm && !comm->ipc && !comm->comm.empty()) {
         // every rank sends one region per chunk and rank 0 posts a receive of the same size for it: the region must be sized by
         // the largest site count / tile count of ANY rank (the ranks hold different intervals), so the ranks agree on it here
         Rccl *R = rccl(); if(!R) { delete b; return MDK_ERR_NODEVICE; }

@@ -1,14 +1,12 @@
-"""Interval-sharded `extract` over several GPUs of one node: one process per GPU (torchrun), RCCL for the exchange.
+"""CPU harness for the host side of the sharded `extract`: shard ownership, schedule agreement and ordered emission under a
+torch.distributed process group (gloo), with the counting step injected by the test (tests/test_sharding_gloo.py).
 
-The path shards naturally: per-position counts depend only on the reads overlapping the position, and
-the reference already processes the genome as independent chunks (extract.c:325-350).  Chunk k of the reference's
-schedule is owned by rank k % world.  Every rank walks the same schedule (mdk_plan_set_shard) but admits, packs and
-counts only its own chunks; after each round of `world` chunks the per-chunk site buffers are gathered to rank 0 --
-the one real exchange step -- and rank 0 replays the chunks in index order through the host emitters, so the output
-files are byte-identical to a single-GPU run.
-
-The counting step is injectable (`count_fn`) so that the sharding / gather / ordered-emit logic can be exercised on a
-CPU-only box with the gloo backend (tests/test_sharding_gloo.py); the product always uses the GPU (`device_count_fn`).
+The multi-GPU product is NOT this module: it is the command itself run as one process per GPU (csrc/host/mdk_ranks.c, started
+by `torchrun --no-python`, tools/extract_ranks.sh or methyldackel_amd.run_ranks), whose ranks exchange site buffers with
+ncclSend/ncclRecv.  Both walk the same schedule through mdk_plan_set_shard: chunk k of the reference's schedule
+(extract.c:325-350) belongs to rank k % world; every rank admits, packs and counts only its own chunks; rank 0 replays the
+chunks in index order through the host emitters, so the output files are byte-identical to a single-process run.  There is no
+GPU code path in here.
 """
 from __future__ import annotations
 
@@ -20,21 +18,6 @@ import torch
 import torch.distributed as dist
 
 import methyldackel_amd as mdk
-
-
-def device_count_fn(dev: "mdk.Device"):
-    """chunk -> (sites ndarray [n,4] uint32, var ndarray [n,2] uint32 or None), computed on this rank's GPU"""
-    def fn(plan, chunk):
-        plan.ensure_reference(dev, chunk.tid)
-        dev.submit(0, chunk.batch)
-        s = dev.download(0)
-        n = s.n_sites
-        sites = np.ctypeslib.as_array(C.cast(s.site, C.POINTER(C.c_uint32)), shape=(n, 4)).copy() if n else np.zeros((0, 4), np.uint32)
-        var = None
-        if s.var:
-            var = np.ctypeslib.as_array(C.cast(s.var, C.POINTER(C.c_uint32)), shape=(n, 2)).copy() if n else np.zeros((0, 2), np.uint32)
-        return sites, var
-    return fn
 
 
 def _as_md_sites(sites: np.ndarray, var):
@@ -106,31 +89,3 @@ def extract_sharded(args, count_fn_factory, device=None):
         plan.finish()
     plan.close()
     return mine
-
-
-def main(argv=None):
-    """torchrun entry point: python -m torch.distributed.run --nproc-per-node N -m methyldackel_amd.multi [extract options] ref.fa aln.bam"""
-    import sys
-    argv = list(sys.argv[1:] if argv is None else argv)
-    if argv and argv[0] == "extract":
-        argv = argv[1:]
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("methyldackel_amd.multi needs GPUs (there is no CPU path)")
-    torch.cuda.set_device(local)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    devs = {}
-
-    def factory(plan):
-        devs["d"] = mdk.Device(plan.dev_cfg(), device=local)
-        return device_count_fn(devs["d"])
-
-    extract_sharded(argv, factory, device=torch.device("cuda", local))
-    devs["d"].close()
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-if __name__ == "__main__":
-    main()

@@ -1,10 +1,11 @@
-"""GPU: the sharded command and the exchange layer (csrc/mdk_comm.hip).
+"""GPU: the command as one process per GPU (csrc/host/mdk_ranks.c) and the exchange layer (csrc/mdk_comm.hip).
 
-`MethylDackel extract` with MDK_GPUS=N feeds N device handles from one host pipeline -- chunk k on rank k mod N -- and brings
-every chunk of rank > 0 back through rank 0 (md_comm_download).  On this box all ranks are the same physical GPU
-(MDK_GPU_MAP=0,0,..), where the exchange is a device copy instead of ncclSend/ncclRecv; everything else -- the schedule, two
-slots per rank, 2N chunks in flight, ordered emission -- is the multi-GPU code path.  RCCL itself is exercised with the one
-communicator a single GPU allows (world size 1)."""
+`MethylDackel extract` started N times with MDK_RANK/MDK_WORLD (or by torchrun) shards the chunk schedule -- chunk k on rank
+k mod N -- and rank 0 collects every chunk and writes.  On this box all ranks sit on the same physical GPU, which RCCL
+refuses; rank 0 sees the equal PCI bus ids during the bootstrap and the site buffers travel over the ranks' TCP connections
+instead of ncclSend/ncclRecv.  Everything else -- the schedule, two slots per rank, the ring on rank 0, ordered emission -- is
+the multi-GPU code path.  RCCL itself is exercised with the one communicator a single GPU allows (world size 1) and, when the
+box has two GPUs, by tests/test_gpu_bench.py."""
 import ctypes as C
 
 import pytest
@@ -19,7 +20,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("n", [2, 3, 8])
 @pytest.mark.parametrize("extra", [["--chunkSize", "3000"], ["--CHG", "--CHH", "--mergeContext", "--chunkSize", "5000", "--minOppositeDepth", "2", "--maxVariantFrac", "0.4"]], ids=["cpg", "allctx_merge_variant"])
 def test_sharded_command_byte_exact(tmp_path, small_synth, n, extra):
-    compare_cli(tmp_path, [str(small_synth / "pe.fa"), str(small_synth / "pe.bam")] + extra, env={"MDK_GPUS": str(n), "MDK_GPU_MAP": ",".join(["0"] * n)})
+    compare_cli(tmp_path, [str(small_synth / "pe.fa"), str(small_synth / "pe.bam")] + extra, ranks=n, env={"MDK_DEVICE": "0"})
 
 
 def test_sharded_command_with_host_fallback_and_empty_chunks(tmp_path):
@@ -30,18 +31,27 @@ def test_sharded_command_with_host_fallback_and_empty_chunks(tmp_path):
     recs += [record(1, 600 + 3 * k, 0, "50M", ref[600 + 3 * k:650 + 3 * k], 30, qname=f"u{k}") for k in range(60)]
     write_bam(tmp_path / "m.bam", [("empty1", 500), ("c1", len(ref)), ("empty2", 300)], recs)
     write_fasta(tmp_path / "m.fa", [("empty1", "ACGT" * 125), ("c1", ref), ("empty2", "CG" * 150)])
-    compare_cli(tmp_path, [str(tmp_path / "m.fa"), str(tmp_path / "m.bam"), "-F", "0", "-q", "0", "--keepDupes", "--chunkSize", "400"], env={"MDK_GPUS": "2", "MDK_GPU_MAP": "0,0"})
+    compare_cli(tmp_path, [str(tmp_path / "m.fa"), str(tmp_path / "m.bam"), "-F", "0", "-q", "0", "--keepDupes", "--chunkSize", "400"], ranks=2, env={"MDK_DEVICE": "0"})
 
 
-def test_more_gpus_than_visible_is_refused(tmp_path, small_synth):
-    r = mdk.run_cli([str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "-o", "x"], cwd=tmp_path, env={"MDK_GPUS": "9"})
-    if mdk.lib_hip().md_dev_count() < 9:
-        assert r.returncode != 0 and "MDK_GPUS=9" in r.stderr
+def test_unindexed_bam_and_region(tmp_path, small_synth):
+    """without a .bai every rank reads the stream through and keeps its own chunks; with -r the schedule starts inside a contig"""
+    import shutil
+    shutil.copy(small_synth / "pe.fa", tmp_path / "u.fa"); shutil.copy(small_synth / "pe.bam", tmp_path / "u.bam")
+    compare_cli(tmp_path, [str(tmp_path / "u.fa"), str(tmp_path / "u.bam"), "--chunkSize", "2500"], ranks=3, env={"MDK_DEVICE": "0"})
+    compare_cli(tmp_path, [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--chunkSize", "2500", "-r", "chrS1:5000-30000"], ranks=2, env={"MDK_DEVICE": "0"})
+
+
+def test_a_rank_that_cannot_start_ends_the_others(tmp_path, small_synth):
+    """rank 1 is given a device that does not exist: it leaves with the no-device code and rank 0, waiting for it, gives up too"""
+    r = mdk.run_ranks([str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "-o", "x"], 2, cwd=tmp_path, devices=[0, 99], timeout=120)
+    assert r.rank_returncodes[1] != 0 and r.rank_returncodes[0] != 0, r.rank_stderr
+    assert "cannot open MI355X device 99" in r.rank_stderr[1]
 
 
 def test_rccl_single_rank_communicator(tmp_path, small_synth):
     """librccl is loaded on demand, an id is made, a world-1 communicator initialised on the device handle; the exchange of a
-    one-rank world has no peer to talk to and completes; a local one-rank communicator downloads like md_dev_download"""
+    one-rank world has no peer to talk to and completes"""
     L = mdk.lib_hip()
     plan = mdk.Plan([str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--chunkSize", "20000", "-o", str(tmp_path / "x")])
     dev = mdk.Device(plan.dev_cfg())
@@ -69,12 +79,5 @@ def test_rccl_single_rank_communicator(tmp_path, small_synth):
     assert L.md_bench_run(bench, 6, C.byref(res)) == 0, L.md_dev_last_error()
     assert res.launches == 6 and L.md_bench_verify(bench) == 0, L.md_dev_last_error()
     L.md_bench_close(bench)
-    L.md_comm_close(comm)
-    # local communicator over one handle
-    L.md_comm_download.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(mdk.md_sites)]
-    hs = (C.c_void_p * 1)(dev.h)
-    assert L.md_comm_open_local(hs, 1, C.byref(comm)) == 0
-    s = mdk.md_sites()
-    assert L.md_comm_download(comm, 0, 0, C.byref(s)) == 0 and s.n_sites == dev.download(0).n_sites > 0
     L.md_comm_close(comm)
     dev.close(); plan.close()

@@ -20,12 +20,14 @@ SUFFIXES = ["_CpG.bedGraph", "_CHG.bedGraph", "_CHH.bedGraph", "_CpG.meth.bedGra
             "_CHH.logit.bedGraph", "_CpG.methylKit", "_CHG.methylKit", "_CHH.methylKit", ".cytosine_report.txt"]
 
 
-def compare_cli(tmp_path, args, env=None, oracle_args=None):
+def compare_cli(tmp_path, args, env=None, oracle_args=None, ranks=None):
     """same command line through the oracle and the product; same prefix (in different dirs) so headers agree"""
     od, gd = tmp_path / "oracle", tmp_path / "gpu"
     od.mkdir(exist_ok=True), gd.mkdir(exist_ok=True)
     ro = run_oracle(list(oracle_args if oracle_args is not None else args) + ["-o", "out"], cwd=od)
-    rg = mdk.run_cli(list(args) + ["-o", "out"], cwd=gd, env=env)
+    rg = mdk.run_cli(list(args) + ["-o", "out"], cwd=gd, env=env, ranks=ranks)
+    if ranks:
+        assert all(rc == rg.returncode for rc in rg.rank_returncodes), (rg.rank_returncodes, rg.rank_stderr)
     assert rg.returncode == ro.returncode, (rg.returncode, ro.returncode, rg.stderr[-2000:])
     assert rg.stdout == ro.stdout
     assert [l for l in rg.stderr.splitlines() if l.startswith("loading mappability")] == [l.replace(".bbm", ".bw") for l in ro.stderr.splitlines() if l.startswith("loading mappability")] or oracle_args is None
@@ -213,45 +215,12 @@ def test_no_cpu_fallback_symbols():
     assert "extract_main" in out and "oracle" not in out.lower()
 
 
-def _shard_worker(rank, world, port, args, ret):
-    import sys
-    sys.path.insert(0, str(mdk.REPO))
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # two ranks share cuda:0 here, so the exchange goes over gloo
-    from methyldackel_amd import multi
-    devs = {}
-
-    def factory(plan):
-        devs["d"] = mdk.Device(plan.dev_cfg(), device=0)
-        return multi.device_count_fn(devs["d"])
-
-    ret[rank] = multi.extract_sharded(args, factory)
-    devs["d"].close()
-    dist.barrier()
-    dist.destroy_process_group()
-
-
 def test_sharded_two_ranks_byte_exact(tmp_path, small_synth):
-    """interval sharding with real kernels: 2 ranks (both on this box's single GPU), rank 0 writes; output == oracle"""
-    import socket
-    import torch.multiprocessing as mp
+    """the command as two processes (both on this box's single GPU, so the site buffers travel over the ranks' TCP
+    connection instead of ncclSend/ncclRecv): rank 0 writes; output == oracle"""
     args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "--CHG", "--mergeContext", "--chunkSize", "3000", "--minOppositeDepth", "2", "--maxVariantFrac", "0.4"]
-    od, gd = tmp_path / "oracle", tmp_path / "gpu"
-    od.mkdir(), gd.mkdir()
-    ro = run_oracle(args + ["-o", "out"], cwd=od)
-    assert ro.returncode == 0
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cwd = os.getcwd(); os.chdir(gd)
-    try:
-        mgr = mp.Manager(); ret = mgr.dict()
-        mp.spawn(_shard_worker, args=(2, port, args + ["-o", "out"], ret), nprocs=2, join=True)
-    finally:
-        os.chdir(cwd)
-    assert ret[0] > 0 and ret[1] > 0
-    for f in os.listdir(od):
-        if f.startswith("out"):
-            assert filecmp.cmp(od / f, gd / f, shallow=False), f
+    od, gd = compare_cli(tmp_path, args, ranks=2, env={"MDK_DEVICE": "0"})
+    assert sorted(os.listdir(od)) == sorted(os.listdir(gd))
 
 
 def test_effective_bases_hook_matches_evaluator(tmp_path, small_synth):

@@ -9,6 +9,7 @@ extrapolation separately"), byte-exact against the oracle:
 """
 import filecmp
 import os
+import re
 import socket
 import subprocess
 
@@ -57,29 +58,15 @@ def test_config3_contig_ladder_one_gpu(ladder, tmp_path):
     assert n > 900_000        # ~1 CpG per 50 bp and strand, almost all covered at 30x
 
 
-def test_config3_contig_ladder_two_ranks(ladder, tmp_path):
-    """the same run interval-sharded over two ranks (both on this box's GPU): chunk k belongs to rank k % 2, rank 0 gathers
-    and writes; 24 contigs exercise the contig hand-over of the schedule on both ranks"""
-    import torch.multiprocessing as mp
-    from test_gpu_parity import _shard_worker
+@pytest.mark.parametrize("n", [2, 4])
+def test_config3_contig_ladder_ranks(ladder, tmp_path, n):
+    """the same run as N processes (all on this box's GPU): chunk k belongs to rank k % N, rank 0 collects and writes; 24
+    contigs exercise the contig hand-over of the schedule on every rank"""
     gd = tmp_path / "gpu"; gd.mkdir()
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cwd = os.getcwd(); os.chdir(gd)
-    try:
-        mgr = mp.Manager(); ret = mgr.dict()
-        mp.spawn(_shard_worker, args=(2, port, [str(ladder / "g.fa"), str(ladder / "g.bam"), "-@", "16", "-o", "out"], ret), nprocs=2, join=True)
-    finally:
-        os.chdir(cwd)
-    assert ret[0] > 10 and ret[1] > 10
-    same_outputs(ladder / "oracle", gd)
-
-
-def test_config3_contig_ladder_sharded_command(ladder, tmp_path):
-    """the same run through the sharded command itself (MDK_GPUS=4, all ranks on this box's GPU): one host pipeline, chunk k on
-    rank k mod 4, 8 chunks in flight, results of ranks 1-3 gathered to rank 0 (md_comm_download)"""
-    gd = tmp_path / "gpu"; gd.mkdir()
-    r = mdk.run_cli([str(ladder / "g.fa"), str(ladder / "g.bam"), "-@", "32", "-o", "out"], cwd=gd, env={"MDK_GPUS": "4", "MDK_GPU_MAP": "0,0,0,0"})
-    assert r.returncode == 0, r.stderr[-2000:]
+    r = mdk.run_cli([str(ladder / "g.fa"), str(ladder / "g.bam"), "-@", "16", "-o", "out"], cwd=gd, ranks=n, env={"MDK_DEVICE": "0", "MDK_HOST_PROFILE": "1"})
+    assert r.rank_returncodes == [0] * n, r.rank_stderr
+    own = [int(re.search(r"rank %d: (\d+) own chunks" % k, r.rank_stderr[k]).group(1)) for k in range(n)]
+    assert min(own) > 10 and max(own) - min(own) <= 1
     same_outputs(ladder / "oracle", gd)
 
 
