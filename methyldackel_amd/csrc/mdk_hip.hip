@@ -709,7 +709,7 @@ extern "C" void md_dev_close(md_dev *h) {
     (void)hipDeviceSynchronize();
     for(auto &s : h->slots) {
         s.d_seg_in.release(); s.d_blob.release(); s.d_tiles.release(); s.h_tiles.release();
-        s.d_raw.release(); s.d_recoff.release(); s.d_prd.release(); s.d_nslot.release(); s.d_zero.release();
+        s.d_raw.release(); s.d_recoff.release(); s.d_prd.release(); s.d_zero.release();
         s.d_aidx.release(); s.h_aidx.release(); s.d_hnext.release();
         s.d_pr.release(); s.d_cig.release(); s.d_prc.release(); s.h_prc.release();
         s.d_site.release(); s.d_var.release(); s.d_seg.release();

@@ -52,7 +52,16 @@ template <typename T> struct HBuf {
 };
 
 // device chunk preparation (mdk_prep.hip)
-struct PrepRead { int32_t pos, rend; uint32_t seq_off, lq, cig_off, qn_off; uint16_t ncig, flag; uint8_t strand, lqname; uint16_t pad; };  // one admitted read, file order
+// one admitted read, file order.  64 bytes, so that k_prep_segs meets everything it needs about a read and its mate in four 16-byte
+// loads instead of going back to the record: the name's first 16 bytes (zero-filled past its end; nlen = its strlen), the first
+// three CIGAR operations, and the read's slot in the name table.
+struct alignas(16) PrepRead {
+    int32_t pos, rend; uint16_t ncig, flag; uint8_t strand, nlen; uint16_t pad;       // quad 0 + quad 1: what pairing looks at in the OTHER reads of a name
+    uint32_t name[4];
+    uint32_t seq_off, lq, cig_off, qn_off;                                              // quad 2 + quad 3: what the segments of a read (and of its mate) need
+    uint32_t cig[3]; uint32_t slot;
+};
+static_assert(sizeof(PrepRead) == 64, "PrepRead layout");
 struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, max_lq; uint64_t algo_bytes; };      // max_lq: longest admitted read (mbias sizes its histogram by it)
 #define MDK_ERR_PREP_REDO (-100)   // internal: the segment array was enlarged and the preparation re-enqueued
 
@@ -68,7 +77,7 @@ struct Slot {
     DBuf<md_site> d_site; DBuf<md_site_var> d_var; DBuf<md_tile_seg> d_seg; Ref<uint32_t> d_total; Ref<int> d_err;
     HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; Ref<SlotStatus> h_st; int index = 0;
     hipStream_t run = nullptr; bool fresh = false;       // run: the stream the latest pileup launch went to; fresh: work queued on `stream` that no launch has been ordered after yet
-    DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRead> d_prd; DBuf<uint32_t> d_nslot, d_aidx; HBuf<uint32_t> h_aidx; DBuf<int32_t> d_hnext; Ref<PrepCounters> d_pcnt;
+    DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRead> d_prd; DBuf<uint32_t> d_aidx; HBuf<uint32_t> h_aidx; DBuf<int32_t> d_hnext; Ref<PrepCounters> d_pcnt;
     DBuf<uint8_t> d_zero;              // what a preparation launch starts from zeroed: name table (keys, heads), per-workgroup counts, tickets
     uint32_t hmask = 0; int pr_nrec = 0; uint64_t raw_bytes = 0; bool raw_layout = false; int64_t woff = 0, wlen = 0;
     bool prep_pending = false;         // records uploaded, preparation kernels not yet queued (they go with the launch, several chunks at a time)

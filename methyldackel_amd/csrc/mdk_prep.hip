@@ -32,6 +32,11 @@
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }       // the hardware reads at any alignment
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint4 ld128(const uint8_t *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+// A lane walks ITS record, so every load of a wave touches 64 different cache lines and costs what 64 lines cost, whatever its width:
+// the kernels below fetch 16 (header, name, CIGAR) or 8 (aux fields) bytes at a time and take them apart in registers.  The record
+// buffer is allocated 64 bytes longer than the records (md_dev_upload_raw), so a wide load that starts inside never leaves it.
 
 struct PrepParams {
     const uint8_t *raw; uint64_t raw_bytes; const uint32_t *rec_off; int n_rec;
@@ -39,7 +44,7 @@ struct PrepParams {
     const char *ref; int64_t reflen;                 // contig letters (conversion efficiency)
     const uint32_t *mapbits; int64_t maplen;         // 1 bit per base, or NULL
     const md_region *runs; int64_t nruns; int bed_on;
-    PrepRead *rd; uint32_t *slot; uint32_t *aidx;    // per admitted read: the read, its slot in the name table, (perRead) its index among the candidate records
+    PrepRead *rd; uint32_t *aidx;    // per admitted read: the read, (perRead) its index among the candidate records
     uint64_t *hkey; int32_t *hhead, *hnext; uint32_t hmask;      // hhead: index + 1 of the name's latest read, 0 = empty
     uint32_t *cntA, *cntS, *ticket; int nblocks;     // per workgroup: published counts of admitted reads / segments; two ticket counters
     md_seg *seg; int64_t cap_seg;
@@ -50,39 +55,59 @@ struct PrepParams {
 struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 
 // ---- aux area: first NH and first XG, as bam_aux_get finds them; a malformed area ends the walk ----
-__device__ void scan_aux(const uint8_t *s, const uint8_t *e, const uint8_t *&nh, const uint8_t *&xg) {
-    nh = nullptr; xg = nullptr;
+// One 8-byte load per field: tag (2), type (1) and the first five value bytes -- all of a fixed-size value that NH or XG can have, and
+// the first letter of a string, which is all getStrand looks at.  Only a string longer than four letters costs further loads.
+struct AuxHit { bool nh, xg; int64_t nh_val; uint8_t xg1; };
+__device__ __forceinline__ int first_zero_byte(uint64_t x, int n) {        // index of the first zero among the low n (<= 8) bytes, or n
+    if(n < 8) x |= ~0ull << (8 * n);
+    const uint64_t t = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+    return t ? (int)(__ffsll((unsigned long long)t) - 1) >> 3 : n;
+}
+__device__ AuxHit scan_aux(const uint8_t *s, const uint8_t *e) {
+    AuxHit A; A.nh = false; A.xg = false; A.nh_val = 0; A.xg1 = 0;
     while(e - s >= 3) {
-        const uint8_t *ty = s + 2, *v = s + 3; size_t sz;
-        const uint8_t t = *ty;
+        const uint64_t w = ld64(s);
+        const uint8_t t = (uint8_t)(w >> 16); const uint8_t *v = s + 3; size_t sz;
+        const int64_t avail = e - v;
         if(t == 'A' || t == 'c' || t == 'C') sz = 1;
         else if(t == 's' || t == 'S') sz = 2;
         else if(t == 'i' || t == 'I' || t == 'f') sz = 4;
         else if(t == 'd') sz = 8;
-        else if(t == 'Z' || t == 'H') { const uint8_t *z = v; while(z < e && *z) z++; if(z >= e) return; sz = (size_t)(z - v) + 1; }
-        else if(t == 'B') {
-            size_t es; if(e - v < 5) return;
-            const uint8_t st = v[0];
-            if(st == 'c' || st == 'C') es = 1; else if(st == 's' || st == 'S') es = 2; else if(st == 'i' || st == 'I' || st == 'f') es = 4; else return;
-            sz = 5 + es * (size_t)ld32(v + 1);
-        } else return;
-        if((size_t)(e - v) < sz) return;
-        if(s[0] == 'N' && s[1] == 'H' && !nh) nh = ty;
-        else if(s[0] == 'X' && s[1] == 'G' && !xg) xg = ty;
+        else if(t == 'Z' || t == 'H') {
+            int n = avail < 5 ? (int)avail : 5, k = first_zero_byte(w >> 24, n);
+            if(k < n) sz = (size_t)k + 1;
+            else {
+                const uint8_t *z = v + 5; bool found = false;
+                if(avail <= 5) return A;
+                while(z < e) { n = e - z < 8 ? (int)(e - z) : 8; k = first_zero_byte(ld64(z), n); if(k < n) { z += k; found = true; break; } z += 8; }
+                if(!found) return A;
+                sz = (size_t)(z - v) + 1;
+            }
+        } else if(t == 'B') {
+            size_t es; if(avail < 5) return A;
+            const uint8_t st = (uint8_t)(w >> 24);
+            if(st == 'c' || st == 'C') es = 1; else if(st == 's' || st == 'S') es = 2; else if(st == 'i' || st == 'I' || st == 'f') es = 4; else return A;
+            sz = 5 + es * (size_t)(uint32_t)(w >> 32);
+        } else return A;
+        if((size_t)avail < sz) return A;
+        const uint32_t tag = (uint32_t)w & 0xffffu;
+        if(tag == ('N' | 'H' << 8) && !A.nh) {
+            A.nh = true;
+            const uint32_t val = (uint32_t)(w >> 24);
+            switch(t) {                                      // bam_aux2i; other types read as 0
+            case 'c': A.nh_val = (int8_t)val; break; case 'C': A.nh_val = (uint8_t)val; break;
+            case 's': A.nh_val = (int16_t)val; break; case 'S': A.nh_val = (uint16_t)val; break;
+            case 'i': A.nh_val = (int32_t)val; break; case 'I': A.nh_val = val; break;
+            default: A.nh_val = 0;
+            }
+        } else if(tag == ('X' | 'G' << 8) && !A.xg) { A.xg = true; A.xg1 = (uint8_t)(w >> 24); }
         s = v + sz;
     }
+    return A;
 }
-__device__ __forceinline__ int64_t aux_int(const uint8_t *ty) {
-    switch(*ty) {
-    case 'c': return (int8_t)ty[1]; case 'C': return ty[1];
-    case 's': return (int16_t)ld16(ty + 1); case 'S': return ld16(ty + 1);
-    case 'i': return (int32_t)ld32(ty + 1); case 'I': return ld32(ty + 1);
-    }
-    return 0;
-}
-__device__ __forceinline__ int strand_of(uint32_t flag, const uint8_t *xg) {        // common.c:84-116
+__device__ __forceinline__ int strand_of(uint32_t flag, const AuxHit &A) {        // common.c:84-116
     int conv = 0;
-    if(xg && (xg[1] == 'C' || xg[1] == 'G')) conv = xg[1];
+    if(A.xg && (A.xg1 == 'C' || A.xg1 == 'G')) conv = A.xg1;
     if(!conv) {
         if(!(flag & 0x1)) return (flag & 0x10) ? 2 : 1;
         if((flag & 0x50) == 0x50) return 2;
@@ -205,29 +230,29 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     if(i < P.n_rec) {
         const uint64_t o = P.rec_off[i];
         bool ok = o + 4 + 32 <= P.raw_bytes;
-        uint32_t bs = 0;
-        const uint8_t *r = P.raw + o + 4;
-        if(ok) { bs = ld32(P.raw + o); ok = bs >= 32 && o + 4 + (uint64_t)bs <= P.raw_bytes; }
         if(ok) {
-            const int32_t tid = (int32_t)ld32(r), pos = (int32_t)ld32(r + 4);
-            const uint32_t w8 = ld32(r + 8), w12 = ld32(r + 12);
-            const uint32_t lqn = w8 & 255u, mapq = (w8 >> 8) & 255u, ncig = w12 & 0xffffu, flag = w12 >> 16;
-            const int32_t lq = (int32_t)ld32(r + 16), mpos = (int32_t)ld32(r + 24);
+            const uint8_t *r = P.raw + o + 4;
+            const uint4 h0 = ld128(P.raw + o), h1 = ld128(P.raw + o + 16);          // block_size refID pos (l_read_name mapq bin) | (n_cigar flag) l_seq next_refID next_pos
+            const uint32_t bs = h0.x;
+            const int32_t tid = (int32_t)h0.y, pos = (int32_t)h0.z;
+            const uint32_t lqn = h0.w & 255u, mapq = (h0.w >> 8) & 255u, ncig = h1.x & 0xffffu, flag = h1.x >> 16;
+            const int32_t lq = (int32_t)h1.y, mpos = (int32_t)h1.w;
             const uint64_t need = 32ull + lqn + 4ull * ncig + (uint64_t)((lq > 0 ? lq : 0) + 1) / 2 + (uint64_t)(lq > 0 ? lq : 0);
-            ok = lq >= 0 && need <= bs && lqn >= 1;
+            ok = bs >= 32 && o + 4 + (uint64_t)bs <= P.raw_bytes && lq >= 0 && need <= bs && lqn >= 1;
             if(ok) {
                 const uint8_t *qn = r + 32, *cig = qn + lqn, *seq = cig + 4 * ncig, *qual = seq + (lq + 1) / 2, *aux = qual + lq, *end = r + bs;
+                const uint4 cb = ld128(cig);                      // the first four CIGAR operations
                 int32_t rlen = 0;
-                for(uint32_t k = 0; k < ncig; k++) { const uint32_t c = ld32(cig + 4 * k); const int op = c & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t)(c >> 4); }
-                D.pos = pos; D.rend = pos + rlen; D.lq = (uint32_t)lq; D.ncig = (uint16_t)ncig; D.flag = (uint16_t)flag; D.lqname = (uint8_t)lqn;
+                for(uint32_t k = 0; k < ncig; k++) { const uint32_t c = k == 0 ? cb.x : k == 1 ? cb.y : k == 2 ? cb.z : k == 3 ? cb.w : ld32(cig + 4 * k); const int op = c & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t)(c >> 4); }
+                D.pos = pos; D.rend = pos + rlen; D.lq = (uint32_t)lq; D.ncig = (uint16_t)ncig; D.flag = (uint16_t)flag;
                 D.seq_off = (uint32_t)(seq - P.raw); D.cig_off = (uint32_t)(cig - P.raw); D.qn_off = (uint32_t)(qn - P.raw);
+                D.cig[0] = cb.x; D.cig[1] = cb.y; D.cig[2] = cb.z;
                 const md_prep_cfg &c = P.cfg;
                 if(c.perread) {          // perRead.c:178-183: alignments that start inside the chunk; flag masks and MAPQ only
-                    const uint8_t *nh, *xg;
                     bool keepr = (int64_t)pos >= P.beg && (int64_t)pos < P.end;
                     keepr = keepr && !(c.require_flags && ((uint32_t)c.require_flags & flag) != (uint32_t)c.require_flags);
                     keepr = keepr && !(c.ignore_flags && ((uint32_t)c.ignore_flags & flag) != 0) && (int)mapq >= c.min_mapq;
-                    if(keepr) { scan_aux(aux, end, nh, xg); D.strand = (uint8_t)strand_of(flag, xg); adm = 1; }
+                    if(keepr) { const AuxHit A = scan_aux(aux, end); D.strand = (uint8_t)strand_of(flag, A); adm = 1; }
                 } else {
                     // filter_func, common.c:416-444 (the region query behind it: pos < end, bam_endpos > beg)
                     bool keep = tid == P.tid && !(flag & 0x4) && (int64_t)pos < P.end && (int64_t)pos + (rlen > 0 ? rlen : 1) > P.beg;
@@ -236,10 +261,9 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
                     keep = keep && !(!c.keep_dupes && (flag & 0x400));
                     int strand = 0;
                     if(keep) {
-                        const uint8_t *nh, *xg;
-                        scan_aux(aux, end, nh, xg);
-                        if(!c.ignore_nh && nh && (int)aux_int(nh) > 1) keep = false;
-                        strand = strand_of(flag, xg);
+                        const AuxHit A = scan_aux(aux, end);
+                        if(!c.ignore_nh && A.nh && (int)A.nh_val > 1) keep = false;
+                        strand = strand_of(flag, A);
                     }
                     if(keep && c.map_on) {
                         int64_t s1, s2;
@@ -258,7 +282,29 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
                     if(keep) {
                         adm = 1;
                         if(c.no_pairing) atomicMax(&P.cnt->max_lq, (uint32_t)lq);          // mbias: rows of the histogram
-                        else { h = 0xcbf29ce484222325ULL; for(uint32_t k = 0; k + 1 < lqn && qn[k]; k++) h = (h ^ qn[k]) * 0x100000001b3ULL; if(!h) h = 1; }
+                        else {
+                            // the name as strcmp sees it (its letters up to the first NUL, at most l_read_name - 1 of them), 16 bytes at a time:
+                            // hashed, and its first block kept in the read
+                            uint32_t nlen = 0; h = 0x9e3779b97f4a7c15ULL;
+                            for(int32_t left = (int32_t)lqn - 1, blk = 0; left > 0; left -= 16, blk++) {
+                                const uint4 nb = ld128(qn + 16 * blk);
+                                const int lim = left < 16 ? left : 16;
+                                int z = first_zero_byte((uint64_t)nb.x | (uint64_t)nb.y << 32, 8);
+                                if(z == 8) z += first_zero_byte((uint64_t)nb.z | (uint64_t)nb.w << 32, 8);
+                                const int take = z < lim ? z : lim;
+                                uint32_t w[4] = {nb.x, nb.y, nb.z, nb.w};
+#pragma unroll
+                                for(int d = 0; d < 4; d++) { const int kept = take - 4 * d; if(kept <= 0) w[d] = 0; else if(kept < 4) w[d] &= (1u << (8 * kept)) - 1u; }
+#pragma unroll
+                                for(int d = 0; d < 4; d++) { h = (h ^ w[d]) * 0xff51afd7ed558ccdULL; h ^= h >> 29; }
+                                if(blk == 0) { D.name[0] = w[0]; D.name[1] = w[1]; D.name[2] = w[2]; D.name[3] = w[3]; }
+                                nlen += (uint32_t)take;
+                                if(take < 16) break;
+                            }
+                            D.nlen = (uint8_t)nlen;
+                            h = (h ^ nlen) * 0xc4ceb9fe1a85ec53ULL; h ^= h >> 32;
+                            if(!h) h = 1;
+                        }
                     }
                 }
             }
@@ -276,9 +322,8 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     if((int)tk == P.nblocks - 1 && threadIdx.x == 0) P.cnt->n_adm = base + total;
     if(!adm) return;
     const uint32_t a = base + rank;
-    P.rd[a] = D;
     if(P.aidx) P.aidx[a] = (uint32_t)i;
-    if(P.cfg.no_pairing || P.cfg.perread) return;
+    if(P.cfg.no_pairing || P.cfg.perread) { P.rd[a] = D; return; }
     // name table: open addressing on the 64-bit hash, members chained through hnext (file order is restored by whoever walks a chain)
     uint32_t sl = (uint32_t)(h ^ (h >> 32)) & P.hmask;
     for(;;) {
@@ -286,14 +331,16 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
         if(old == 0ull || old == (unsigned long long)h) break;
         sl = (sl + 1) & P.hmask;
     }
-    P.slot[a] = sl;
+    D.slot = sl;
+    P.rd[a] = D;
     P.hnext[a] = atomicExch(&P.hhead[sl], (int32_t)a + 1) - 1;
 }
 
-__device__ __forceinline__ bool same_name(const PrepParams &P, const PrepRead &x, const PrepRead &y) {
-    if(x.lqname != y.lqname) return false;
+__device__ __forceinline__ bool same_name(const PrepParams &P, const PrepRead &x, const PrepRead &y) {       // strcmp(x, y) == 0
+    if(x.nlen != y.nlen || x.name[0] != y.name[0] || x.name[1] != y.name[1] || x.name[2] != y.name[2] || x.name[3] != y.name[3]) return false;
+    if(x.nlen <= 16) return true;
     const uint8_t *p = P.raw + x.qn_off, *q = P.raw + y.qn_off;
-    for(int k = 0; k < x.lqname; k++) { if(p[k] != q[k]) return false; if(!p[k]) break; }
+    for(int k = 16; k < x.nlen; k++) if(p[k] != q[k]) return false;
     return true;
 }
 
@@ -306,12 +353,14 @@ __device__ int32_t pair_of(const PrepParams &P, const uint32_t a, const PrepRead
     second = false;
     if(!(ra.flag & 0x1) || (ra.flag & 12)) return -1;               // such a read never becomes pending nor pairs (it still occupies the buffer for others)
     int32_t idx[MAXG]; int k = 0;
-    for(int32_t x = P.hhead[P.slot[a]] - 1; x >= 0; x = P.hnext[x]) { if(k == MAXG) { atomicExch(&P.cnt->fallback, 1u); return -1; } idx[k++] = x; }
+    for(int32_t x = P.hhead[ra.slot] - 1; x >= 0; x = P.hnext[x]) { if(k == MAXG) { atomicExch(&P.cnt->fallback, 1u); return -1; } idx[k++] = x; }
     for(int i = 1; i < k; i++) { const int32_t v = idx[i]; int q = i - 1; while(q >= 0 && idx[q] > v) { idx[q + 1] = idx[q]; q--; } idx[q + 1] = v; }
     int32_t pending = -1, mate = -1; int32_t live[MAXLIVE]; int nlive = 0;
     for(int i = 0; i < k; i++) {
         const int32_t x = idx[i];
-        const PrepRead X = (uint32_t)x == a ? ra : P.rd[x];
+        PrepRead X;                                                 // of another read only the first two quads (pos rend ncig flag strand nlen | name) are fetched
+        if((uint32_t)x == a) X = ra;
+        else { const uint4 *q = (const uint4 *)&P.rd[x]; uint4 *d = (uint4 *)&X; d[0] = q[0]; d[1] = q[1]; X.qn_off = 0; if(X.nlen > 16) X.qn_off = P.rd[x].qn_off; }
         if((uint32_t)x != a && !same_name(P, ra, X)) continue;      // another name in the same slot
         const bool first = x == 0;
         const int32_t prev_pos = first ? 0 : P.rd[x - 1].pos;
@@ -337,13 +386,13 @@ __device__ int32_t pair_of(const PrepParams &P, const uint32_t a, const PrepRead
 
 // gapless runs of a CIGAR, one at a time (calculate_positions, overlaps.c:27-52)
 struct RunIt {
-    const uint8_t *cig; int n, k; int32_t x, y, lq;
+    const uint8_t *cig; uint32_t c0, c1, c2; int n, k; int32_t x, y, lq;         // the first three operations travel with the read (PrepRead::cig)
     int32_t rx, ry, rl; bool valid;
-    __device__ void init(const uint8_t *c, int ncig, int32_t pos, int32_t lq_) { cig = c; n = ncig; k = 0; x = pos; y = 0; lq = lq_; valid = false; next(); }
+    __device__ void init(const uint8_t *raw, const PrepRead &r) { cig = raw + r.cig_off; c0 = r.cig[0]; c1 = r.cig[1]; c2 = r.cig[2]; n = r.ncig; k = 0; x = r.pos; y = 0; lq = (int32_t)r.lq; valid = false; next(); }
     __device__ void next() {
         valid = false;
         while(k < n) {
-            const uint32_t c = ld32(cig + 4 * k); k++;
+            const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : ld32(cig + 4 * k); k++;
             const int op = c & 15; const int32_t len = (int32_t)(c >> 4);
             if(op == 0 || op == 7 || op == 8) {
                 int32_t l = len; if(y + l > lq) l = lq - y;          // a CIGAR that consumes more bases than the record stores
@@ -361,8 +410,8 @@ template <bool WRITE>
 __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const PrepRead &r, const bool has_mate, const PrepRead &m, const bool is_second, md_seg *out, uint32_t base, int64_t &lo, int64_t &hi) {
     const bool paired = has_mate && (((int)r.strand - (int)m.strand) & 1) == 0;       // overlaps.c:63-65
     RunIt own, oth;
-    own.init(P.raw + r.cig_off, r.ncig, r.pos, (int32_t)r.lq);
-    if(paired) oth.init(P.raw + m.cig_off, m.ncig, m.pos, (int32_t)m.lq); else oth.valid = false;
+    own.init(P.raw, r);
+    if(paired) oth.init(P.raw, m); else oth.valid = false;
     const uint8_t sf = (uint8_t)((r.strand & 7) | ((r.flag & 0x80) ? MDK_SF_READ2 : 0) | (is_second ? MDK_SF_SECOND : 0));
     const uint8_t msf = paired ? (uint8_t)((m.strand & 7) | ((m.flag & 0x80) ? MDK_SF_READ2 : 0)) : 0;
     uint32_t n = 0;
@@ -455,7 +504,7 @@ __global__ __launch_bounds__(PB) void k_perread_raw(const PrepParams P, const ui
     if(a >= P.cnt->n_adm) return;
     const PrepRead r = P.rd[a];
     const uint8_t *seq = P.raw + r.seq_off, *qual = seq + ((r.lq + 1) >> 1), *cg = P.raw + r.cig_off;
-    out[a] = perread_walk(seq, qual, r.lq, (int)r.ncig, r.pos, r.strand & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg](int k) { return ld32(cg + 4 * k); });
+    out[a] = perread_walk(seq, qual, r.lq, (int)r.ncig, r.pos, r.strand & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg, &r](int k) { return k < 3 ? r.cig[k] : ld32(cg + 4 * k); });
 }
 
 // record offsets of a device-resident range (offsets in the piece it was inflated in) -> offsets in the chunk's concatenation
@@ -535,7 +584,7 @@ static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
     P.ref = h->ref[s->tid]; P.reflen = h->reflen[s->tid];
     if(h->prep.map_on && (size_t)s->tid < h->mapbits.size()) { P.mapbits = h->mapbits[s->tid]; P.maplen = h->maplen[s->tid]; }
     P.bed_on = (size_t)s->tid < h->d_runs.size() && h->has_runs[s->tid]; if(P.bed_on) { P.runs = h->d_runs[s->tid]; P.nruns = h->n_runs[s->tid]; }
-    P.rd = s->d_prd.p; P.slot = s->d_nslot.p; P.aidx = h->prep.perread ? s->d_aidx.p : nullptr; P.hnext = s->d_hnext.p; P.hmask = s->hmask;
+    P.rd = s->d_prd.p; P.aidx = h->prep.perread ? s->d_aidx.p : nullptr; P.hnext = s->d_hnext.p; P.hmask = s->hmask;
     uint8_t *z = s->d_zero.p;
     P.hkey = (uint64_t *)z; P.hhead = (int32_t *)(z + H * 8); P.cntA = (uint32_t *)(z + H * 12); P.cntS = P.cntA + (nb > 0 ? nb : 1); P.ticket = P.cntS + (nb > 0 ? nb : 1);
     P.nblocks = nb; P.zero = z; P.zero_bytes = zero_bytes_for(s->hmask, nb);
@@ -586,7 +635,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     const size_t nn = (size_t)n + 1, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
     s->hmask = pow2_at_least(nn + nn / 2) - 1;
-    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_nslot.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
        s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
     if(!s->b_site) {
         if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
@@ -618,7 +667,7 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     if(total >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: more than 4 GiB of records in one chunk", hipSuccess);
     const int n = b->n_records, nb = (n + PB - 1) / PB; const size_t nn = (size_t)n + 1;
     s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->hmask = 1023; s->ntiles = 0; s->tile = h->tile;
-    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_nslot.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
        s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
     { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
     { int rc = enqueue_prep(h, s); if(rc) return rc; }                 // perread mode: selection + file-order compaction only (k_prep_scan)

@@ -1,0 +1,34 @@
+"""CPU: the device inflate's decoder (csrc/mdk_inflate_core.h, compiled for the host) and the host re-statement of the kernel's
+64-lane phases (tools/inflate_emu.cpp) against zlib -- deflate streams of every level and strategy (stored, fixed, dynamic blocks,
+distance-1 runs, maximum-distance matches, empty input) and every BGZF member of the reference's fixture BAMs.  The kernel itself is
+compared with zlib on the GPU (tests/test_gpu_inflate.py); this test keeps the shared decoder honest where there is no GPU."""
+import subprocess
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+EMU = REPO / "tools" / "_build" / "inflate_emu"
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not EMU.exists():
+        subprocess.run(["make", "-C", str(REPO), "tools/_build/inflate_emu"], check=True, capture_output=True)
+    return EMU
+
+
+def test_selftest_streams(emu):
+    r = subprocess.run([str(emu), "--selftest"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("bam", sorted(p.name for p in (REPO / "tests" / "golden").glob("*.bam")))
+def test_fixture_members_equal_zlib(emu, bam):
+    r = subprocess.run([str(emu), str(REPO / "tests" / "golden" / bam)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_synthetic_bam_members_equal_zlib(emu, small_synth):
+    r = subprocess.run([str(emu), str(small_synth / "pe.bam")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
