@@ -73,6 +73,7 @@ def median_run(fn, runs=3):
 
 
 def main():
+    t_start = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -166,6 +167,7 @@ def main():
             keep_batches.append((b.tid, b.beg, b.end, b.n_records, b.woff, b.wlen, cat, offs))
         n_chunks += 1
     t_host = time.time() - t0
+    log(f"[bench] rank {rank}: {R} intervals resident after {t_host:.1f} s")
     slots = list(range(R))
     slot_arr = (C.c_int * R)(*slots)
 
@@ -226,6 +228,7 @@ def main():
         rc = L.md_bench_verify(bench)
         assert rc == 0, L.md_dev_last_error()
     exchanges, bytes_per_exchange = int(res.exchanges), int(res.bytes_per_exchange)
+    log(f"[bench] rank {rank}: timed loop {dt:.2f} s")
     L.md_bench_close(bench)
 
     if world > 1:
@@ -378,7 +381,9 @@ def main():
             result["streamed"] = streamed
         if dense:
             result["dense_contexts"] = dense
+        log(f"[bench] device legs done in {time.time() - t_start:.0f} s")
         if not args.no_cpu_baseline and world == 1:
+          try:
             oracle = REPO / "oracle/_build/mdk_oracle"
             ncores = os.cpu_count() or 1
             threads = str(min(64, ncores))
@@ -393,14 +398,17 @@ def main():
             def run_oracle(sp, name, thr, ck, runs):
                 d = work / f"co_{name}"; d.mkdir()
                 opts = ["-@", str(thr)] + (["--chunkSize", str(ck)] if ck else [])
-                return median_run(lambda: subprocess.run([str(oracle), "extract", str(sp) + ".fa", str(sp) + ".bam"] + opts + extra + ["-o", "out"], check=True, capture_output=True, cwd=d), runs), d
+                r = median_run(lambda: subprocess.run([str(oracle), "extract", str(sp) + ".fa", str(sp) + ".bam"] + opts + extra + ["-o", "out"], check=True, capture_output=True, cwd=d, timeout=600), runs), d
+                log(f"[bench] oracle {name}: {r[0][1]}")
+                return r
 
             def run_ours(sp, name, env, runs=3):
                 d = work / f"cg_{name}"; d.mkdir(); rcs = []; ts = []
                 for _ in range(runs):
                     time.sleep(0.3)            # (outside the clock) a back-to-back command otherwise waits for the previous process' GPU context to be torn down
                     t1 = time.perf_counter()
-                    rcs.append(mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=d, env=env).returncode); ts.append(time.perf_counter() - t1)
+                    rcs.append(mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=d, env=env, timeout=180).returncode); ts.append(time.perf_counter() - t1)
+                log(f"[bench] {name}: {ts}")
                 return statistics.median(ts), ts, d, all(r == 0 for r in rcs)
 
             def calls_of(d):
@@ -443,6 +451,9 @@ def main():
                                        "cpu_all_cores_seconds": t_la, "cpu_runs": ts_la, "seconds": t_lg, "runs": ts_lg, "value": calls_l / t_lg, "unit": "CpG calls/s",
                                        "speedup_vs_cpu_all_cores": t_la / t_lg, "identical_to_oracle": bool(ident_l), "host_inflate_only_seconds": t_lh, "host_inflate_only_runs": ts_lh,
                                        "protocol": "3 runs each, median, whole-process wall clock"}
+          except Exception as ex:            # a leg that fails or hangs (timeout) must not take the measured line with it
+            result["legs_error"] = repr(ex)[:500]
+            log(f"[bench] a CPU/end-to-end leg failed: {ex!r}")
         print(json.dumps(result), flush=True)
     if world > 1:
         L.md_comm_close(comm)

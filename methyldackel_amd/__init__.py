@@ -549,7 +549,7 @@ def sites_to_rows(s: md_sites):
     return rows
 
 
-def run_cli(args, cwd=None, env=None, command="extract", ranks=None):
+def run_cli(args, cwd=None, env=None, command="extract", ranks=None, timeout=None):
     """Run the `MethylDackel extract` (or `mbias`) command of this build; returns CompletedProcess.  `ranks=N` runs the command
     as N processes, one per GPU (csrc/host/mdk_ranks.c), and returns rank 0's."""
     if not CLI.exists():
@@ -558,10 +558,10 @@ def run_cli(args, cwd=None, env=None, command="extract", ranks=None):
     if env:
         e.update(env)
     if ranks:
-        return run_ranks(args, ranks, cwd=cwd, env=e, command=command)
+        return run_ranks(args, ranks, cwd=cwd, env=e, command=command, timeout=timeout or 900)
     if "MDK_WORLD" not in e:
         e["MDK_NO_RANKS"] = "1"        # a caller that is itself a torchrun rank (bench.py) runs the command alone, not as its rank
-    return subprocess.run([str(CLI), command] + [str(a) for a in args], cwd=cwd, env=e, capture_output=True, text=True)
+    return subprocess.run([str(CLI), command] + [str(a) for a in args], cwd=cwd, env=e, capture_output=True, text=True, timeout=timeout)
 
 
 def run_ranks(args, n, cwd=None, env=None, command="extract", devices=None, timeout=900):

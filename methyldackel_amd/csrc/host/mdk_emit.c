@@ -139,8 +139,8 @@ int mdk_plan_emit(mdk_plan *p, const mdk_chunk *c, const md_sites *s) {
 /* ------------------------------------------------------------------------------------------------ */
 /* extract_main's emitter: chunks are formatted by a few threads and written in chunk order          */
 /* ------------------------------------------------------------------------------------------------ */
-static int pwrite_all(int fd, const char *s, size_t n, int64_t off) {
-    while(n) { ssize_t w = pwrite(fd, s, n, (off_t)off); if(w < 0) { if(errno == EINTR) continue; return -1; } s += w; n -= (size_t)w; off += w; }
+static int pwrite_all(int fd, const char *s, size_t n, int64_t off) {       /* 0, or the errno of the write that failed */
+    while(n) { ssize_t w = pwrite(fd, s, n, (off_t)off); if(w < 0) { if(errno == EINTR) continue; return errno ? errno : EIO; } if(w == 0) return ENOSPC; s += w; n -= (size_t)w; off += w; }
     return 0;
 }
 static void *emitter_main(void *arg) {
@@ -167,9 +167,9 @@ static void *emitter_main(void *arg) {
             E->p->n_variant_positions += j->e.n_variant;
             E->next_write++; pthread_cond_broadcast(&E->cv_turn);
             pthread_mutex_unlock(&E->mu);
-            for(k = 0; k < nk; k++) if((E->p->o.cytosine_report || E->p->o.ctx_on[k]) && j->e.ob[k].l && pwrite_all(E->fd[k], j->e.ob[k].s, j->e.ob[k].l, at[k])) bad = 1;
+            for(k = 0; k < nk; k++) if((E->p->o.cytosine_report || E->p->o.ctx_on[k]) && j->e.ob[k].l && !bad) bad = pwrite_all(E->fd[k], j->e.ob[k].s, j->e.ob[k].l, at[k]);
             pthread_mutex_lock(&E->mu);
-            if(bad && !E->failed) { E->failed = 1; fprintf(stderr, "[mdk] writing the output failed: %s\n", strerror(errno)); }
+            if(bad && !E->failed) { E->failed = 1; fprintf(stderr, "[mdk] writing the output failed: %s\n", strerror(bad)); }
             j->state = EJ_FREE; pthread_cond_signal(&E->cv_free);
             pthread_mutex_unlock(&E->mu);
             continue;
@@ -208,6 +208,7 @@ MDK_LOCAL int emitter_start(emitter *E, mdk_plan *p, int n_th) {
 MDK_LOCAL int emitter_push(emitter *E, const mdk_chunk *c, const md_sites *s) {
     ejob *j = NULL; int i;
     if(c->index != E->p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
+    if(E->failed) return -3;                     /* a write has failed (the reason was printed): the caller stops feeding the GPU for a file that cannot be completed */
     E->p->next_emit++;
     pthread_mutex_lock(&E->mu);
     for(;;) { for(i = 0; i < E->n_job; i++) if(E->job[i].state == EJ_FREE) { j = &E->job[i]; break; } if(j) break; pthread_cond_wait(&E->cv_free, &E->mu); }

@@ -136,7 +136,7 @@ int extract_main(int argc, char *argv[]) {
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
             }
             ta = now_s();
-            if(emitter_push(&em, &o->ch[i], &sites)) { ret = MDK_RC_DEVICE; break; }
+            if(emitter_push(&em, &o->ch[i], &sites)) { ret = em.failed ? MDK_RC_OUTPUT : MDK_RC_DEVICE; break; }
             w_emit += now_s() - ta;
         }
         o->n = 0;

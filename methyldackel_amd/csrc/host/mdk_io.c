@@ -99,15 +99,17 @@ static void *inflate_worker(void *arg) {
 }
 
 /* ---- slabs ---- */
-static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, int force) {          /* a free slab with room for need_cap bytes; force: never wait for one to come back */
+#define SEQ_FORCE UINT64_MAX
+static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, uint64_t seq) {          /* a free slab with room for need_cap bytes, for piece `seq`; SEQ_FORCE: never wait for one to come back */
     mdk_slab *s = NULL;
     pthread_mutex_lock(&b->mu);
     while(!b->quit) {
         if(b->n_pool) { s = b->pool[--b->n_pool]; break; }
-        /* max_alloc only bounds how far the inflater runs AHEAD: when the scanner has nothing queued it may be collecting a
-         * chunk that spans more slabs than the cap (huge --chunkSize, deep coverage) and every slab it holds stays pinned
-         * until the chunk is complete, so waiting for one to come back would never end */
-        if(force || b->n_alloc < b->max_alloc || b->n_ready == 0) { b->n_alloc++; s = calloc(1, sizeof(*s)); break; }
+        /* max_alloc only bounds how far the inflaters run AHEAD.  The piece the scanner takes next (seq == pop_seq) never waits: the
+         * scanner may be collecting a chunk that spans more slabs than the cap (huge --chunkSize, deep coverage), and the chunks the
+         * consumer still holds keep their slabs until it has been given further chunks -- slabs that only come back if the scanner
+         * goes on.  (Slabs delivered out of order by other teams say nothing about that: n_ready > 0 is not "the scanner has work".) */
+        if(seq == SEQ_FORCE || b->n_alloc < b->max_alloc || seq == b->pop_seq) { b->n_alloc++; s = calloc(1, sizeof(*s)); break; }
         pthread_cond_wait(&b->cv_pool, &b->mu);
     }
     pthread_mutex_unlock(&b->mu);
@@ -118,7 +120,6 @@ static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, int force) {          
     s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM; s->n_mem = 0; s->n_sum = 0;
     return s;
 }
-static mdk_slab *slab_get(mdk_bam *b, size_t need_cap) { return slab_get_ex(b, need_cap, 0); }
 void mdk_slab_ref(mdk_bam *b, mdk_slab *s) { pthread_mutex_lock(&b->mu); s->refs++; pthread_mutex_unlock(&b->mu); }
 void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
     pthread_mutex_lock(&b->mu);
@@ -187,7 +188,7 @@ static int next_piece(mdk_bam *b, piece *pc, size_t want) {
 static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status) {
     blk_t *blk = pc->blk; int nb = pc->nb; mdk_slab *s;
     *status = 0;
-    s = slab_get(b, MDK_SLAB_HEADROOM + pc->total + 64);
+    s = slab_get_ex(b, MDK_SLAB_HEADROOM + pc->total + 64, pc->seq);
     if(!s) { *status = b->quit ? 1 : -1; return NULL; }
     { size_t o = s->beg; for(int i = 0; i < nb; i++) { blk[i].out = s->buf + o; o += blk[i].out_len; } s->end = o; }
     {
@@ -229,12 +230,12 @@ static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status)
 }
 
 /* ---- slabs inflated on the device ---- */
-static mdk_slab *dslab_get(mdk_bam *b) {          /* a free device slab (its piece keeps its device buffers from use to use) */
+static mdk_slab *dslab_get(mdk_bam *b, uint64_t seq) {          /* a free device slab (its piece keeps its device buffers from use to use) */
     mdk_slab *s = NULL;
     pthread_mutex_lock(&b->mu);
     while(!b->quit) {
         if(b->n_dpool) { s = b->dpool[--b->n_dpool]; break; }
-        if(b->n_dalloc < b->max_dalloc || b->n_ready == 0) { b->n_dalloc++; s = calloc(1, sizeof(*s)); break; }
+        if(b->n_dalloc < b->max_dalloc || seq == b->pop_seq) { b->n_dalloc++;      /* (as slab_get_ex) */ s = calloc(1, sizeof(*s)); break; }
         pthread_cond_wait(&b->cv_pool, &b->mu);
     }
     pthread_mutex_unlock(&b->mu);
@@ -249,7 +250,7 @@ static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *stat
     blk_t *blk = pc->blk; const int nb = pc->nb; mdk_slab *s; md_inf_member *mt; md_piece_info info; int i; uint64_t o = 0;
     const uint8_t *c0 = blk[0].in; const size_t span = (size_t)((blk[nb - 1].in + blk[nb - 1].in_len) - c0);
     *status = 0;
-    s = dslab_get(b);
+    s = dslab_get(b, pc->seq);
     if(!s) { *status = b->quit ? 1 : -1; return NULL; }
     if(b->gpu_stage_cap[team] < span + 64) { md_host_free(b->gpu_stage[team]); b->gpu_stage_cap[team] = span + (span >> 3) + (1u << 20); b->gpu_stage[team] = md_host_alloc(b->gpu_stage_cap[team]); if(!b->gpu_stage[team]) { b->gpu_stage_cap[team] = 0; mdk_slab_unref(b, s); *status = -1; return NULL; } }
     memcpy(b->gpu_stage[team], c0, span);
@@ -274,7 +275,7 @@ static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *stat
 /* a device slab the scanner cannot take member by member (a record straddles two members, or the slab before it ended inside a
  * record): its bytes come back to the host and it is walked like a slab a host team inflated */
 static mdk_slab *slab_materialize(mdk_bam *b, mdk_slab *d) {
-    mdk_slab *s = slab_get_ex(b, MDK_SLAB_HEADROOM + (size_t)d->d_bytes + 64, 1); int i;      /* the scanner itself is asking: it must not wait for slabs only it can release */
+    mdk_slab *s = slab_get_ex(b, MDK_SLAB_HEADROOM + (size_t)d->d_bytes + 64, SEQ_FORCE); int i;      /* the scanner itself is asking: it must not wait for slabs only it can release */
     if(!s) return NULL;
     s->end = s->beg + (size_t)d->d_bytes;
     if(md_piece_read(d->piece, 0, d->d_bytes, s->buf + s->beg)) { pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, s); return NULL; }
@@ -376,7 +377,7 @@ void mdk_bam_detach_device(mdk_bam *b) {
 static mdk_slab *slab_next(mdk_bam *b) {
     mdk_slab *s = NULL; double t0 = io_now();
     pthread_mutex_lock(&b->mu);
-    if(!b->n_ready) pthread_cond_broadcast(&b->cv_pool);        /* starving: the inflaters may take a slab beyond the cap */
+    pthread_cond_broadcast(&b->cv_pool);        /* the team that holds piece pop_seq may take a slab beyond the cap */
     for(;;) {
         mdk_slab **slot = &b->ready[b->pop_seq % MDK_READY];
         if(*slot) { s = *slot; *slot = NULL; b->n_ready--; b->pop_seq++; break; }

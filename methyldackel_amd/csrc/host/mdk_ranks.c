@@ -219,7 +219,7 @@ MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world) {
             else rc = 0;                              /* passed over by everybody (-l, a contig the FASTA lacks) */
             if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
             if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
-            if(emitter_push(&em, c, &sites)) { ret = MDK_RC_DEVICE; break; }
+            if(emitter_push(&em, c, &sites)) { ret = em.failed ? MDK_RC_OUTPUT : MDK_RC_DEVICE; break; }
             head = (head + 1) % F; count--;
         }
     }

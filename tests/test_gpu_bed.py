@@ -8,7 +8,7 @@ import pytest
 import methyldackel_amd as mdk
 from bedgen import random_bed
 from conftest import read_dump, run_oracle, synth
-from test_gpu_parity import _shard_worker, abi_sites, compare_cli
+from test_gpu_parity import abi_sites, compare_cli
 
 pytestmark = pytest.mark.gpu
 
@@ -61,23 +61,10 @@ def test_set_regions_rejects_bad_runs(tmp_path, small_synth):
 
 
 def test_sharded_two_ranks_with_bed_byte_exact(tmp_path, small_synth):
-    import socket
-    import torch.multiprocessing as mp
+    """-l with the command as two processes: chunks no region touches are passed over by every rank"""
     bed = random_bed(tmp_path / "r.bed", PE, n=25, seed=31)
     args = [str(small_synth / "pe.fa"), str(small_synth / "pe.bam"), "-l", str(bed), "--keepStrand", "--CHG", "--chunkSize", "3000"]
-    od, gd = tmp_path / "oracle", tmp_path / "gpu"
-    od.mkdir(), gd.mkdir()
-    assert run_oracle(args + ["-o", "out"], cwd=od).returncode == 0
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cwd = os.getcwd(); os.chdir(gd)
-    try:
-        mgr = mp.Manager(); ret = mgr.dict()
-        mp.spawn(_shard_worker, args=(2, port, args + ["-o", "out"], ret), nprocs=2, join=True)
-    finally:
-        os.chdir(cwd)
-    for f in os.listdir(od):
-        if f.startswith("out"):
-            assert filecmp.cmp(od / f, gd / f, shallow=False), f
+    compare_cli(tmp_path, args, ranks=2, env={"MDK_DEVICE": "0"})
 
 
 def test_bed_1mb_panel_byte_exact(tmp_path):
