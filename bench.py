@@ -249,9 +249,10 @@ def main():
     assert L.md_dev_bench_prep_rotate(dev.h, slot_arr, R, 1, R, 10 * R, C.byref(prep1_ms)) == 0, L.md_dev_last_error()
     pile_s, prep_s = br.ms_pileup / 1e3, prep_ms.value / 1e3
     # algorithmic bytes per LAUNCH (GROUP chunks).  Pileup: SURVEY.md 8d (reads' payload + reference + sites).  Preparation: every byte of the
-    # chunk's records once (they are walked where they lie) + 36 B written and read per admitted read + 32 B per segment written.
+    # chunk's records once (the fields it needs sit at both ends of a record: every 128-byte line is touched) + the 32-byte segments it
+    # writes; its intermediates (64 B per admitted read, the name table) are overhead, not algorithmic bytes.
     pile_bytes = int(br.algo_bytes)
-    prep_bytes = int((raw_bytes / R + 72.0 * reads / R + 32.0 * segs / R) * GROUP)
+    prep_bytes = int((raw_bytes / R + 32.0 * segs / R) * GROUP)
     fam = {
         "pileup": {"kernel": "k_pileup_multi<false,false>", "bound": "hbm", "kernel_ms": br.ms_pileup, "kernel_ms_per_chunk": br.ms_pileup / GROUP, "algo_bytes_per_launch": pile_bytes,
                    "achieved": pile_bytes / pile_s / 1e9 if pile_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s"},

@@ -1,47 +1,10 @@
 /* main.c -- `MethylDackel` command of the MI355X build: `extract`, `mbias`, `perRead` on the GPU and the `mergeContext`
  * text tool (the reference's dispatcher is main.c:39-62). */
-#include <errno.h>
-#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/types.h>
-#include <sys/wait.h>
 #include <unistd.h>
 #include "mdk_extract.h"
-
-/* MDK_DETACH=1 (opt-in, for interactive use) runs a GPU command in a child process.  When the work is done and the outputs
- * are closed the child reports its return code through a pipe and closes its standard streams; this process then ends at
- * once, while the child is left to the part nobody needs to wait for: the kernel unpinning the staging buffers and tearing
- * down the GPU context (~0.3 s).  A child that dies without reporting (abort, crash) is waited for and its fate is passed on.
- * The default is one process that ends when everything has been released: a scheduler or container that kills the process
- * group when the command returns, or a back-to-back invocation, must not meet a child still holding VRAM and pinned memory. */
-static int run_detached(int (*cmd)(int, char **), int argc, char *argv[]) {
-    int fd[2]; pid_t pid; char num[16];
-    { const char *d = getenv("MDK_DETACH"); if(!d || !*d || *d == '0' || getenv("MDK_NO_DETACH") || pipe(fd)) return cmd(argc, argv); }
-    fflush(stdout); fflush(stderr);
-    pid = fork();
-    if(pid < 0) { close(fd[0]); close(fd[1]); return cmd(argc, argv); }
-    if(pid == 0) {
-        int rc;
-        close(fd[0]);
-        snprintf(num, sizeof(num), "%d", fd[1]); setenv("MDK_DONE_FD", num, 1);
-        rc = cmd(argc, argv);                                  /* a successful run does not come back (leave_fast) */
-        fflush(stdout); fflush(stderr);
-        if(write(fd[1], &rc, sizeof(rc)) != (ssize_t)sizeof(rc)) _exit(rc & 0xff);
-        _exit(rc & 0xff);
-    } else {
-        int rc = 0, st = 0; ssize_t n;
-        close(fd[1]);
-        do n = read(fd[0], &rc, sizeof(rc)); while(n < 0 && errno == EINTR);       /* any other failure: fall back to waitpid below */
-        if(n == (ssize_t)sizeof(rc)) _exit(rc & 0xff);
-        if(waitpid(pid, &st, 0) == pid) {
-            if(WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); }
-            if(WIFEXITED(st)) _exit(WEXITSTATUS(st));
-        }
-        _exit(255);
-    }
-}
 
 static void usage_main(void) {
     fprintf(stderr, "MethylDackel (methyldackel_amd, MI355X build of the `extract` path)\n"
@@ -69,7 +32,7 @@ int main(int argc, char *argv[]) {
         if(cmd) {
             int rc;
             setenv("MDK_FAST_EXIT", "1", 0);
-            rc = run_detached(cmd, argc - 1, argv + 1);
+            rc = cmd(argc - 1, argv + 1);
             fflush(stdout); fflush(stderr);
             _exit(rc & 0xff);
         }

@@ -31,13 +31,10 @@ MDK_LOCAL int fast_exit_wanted(void) {
     if(pre && (strstr(pre, "rocprof") || strstr(pre, "roctx") || strstr(pre, "rocm"))) return 0;
     return 1;
 }
-/* leave now: outputs are flushed and closed.  When the `MethylDackel` command runs the work in a child process (main.c),
- * MDK_DONE_FD names the pipe on which the parent waits for the result: it is told first, and the standard streams are
- * closed, so that nobody waits for the kernel to unpin ~1 GB of staging buffers and tear the GPU context down. */
+/* leave now: outputs are flushed and closed; nobody needs to wait for staging buffers to be unpinned one by one and for the
+ * runtime's exit handlers (the `MethylDackel` command only: main.c sets MDK_FAST_EXIT) */
 MDK_LOCAL void leave_fast(int ret) {
-    const char *fd = getenv("MDK_DONE_FD");
     fflush(stdout); fflush(stderr);
-    if(fd) { int f = atoi(fd), rc = ret; if(f > 2 && write(f, &rc, sizeof(rc)) == (ssize_t)sizeof(rc)) { close(f); close(0); close(1); close(2); } }
     _exit(ret & 0xff);
 }
 /* the HIP runtime takes 0.1-0.4 s to come up: start that before anything else (options, BAM header, FASTA), on its own thread */
@@ -47,7 +44,7 @@ static void *hipwarm_main(void *arg) { (void)arg; (void)md_dev_warm(getenv("MDK_
 MDK_LOCAL void hip_warm_up(void) {
     pthread_t th;
     if(!fast_exit_wanted() || pthread_create(&th, NULL, hipwarm_main, NULL)) return;
-    if(getenv("MDK_INIT_FIRST")) pthread_join(th, NULL); else pthread_detach(th);      /* experiment: runtime first, inflate threads afterwards */
+    pthread_detach(th);
 }
 /* md_dev_last_error is per thread: keep the text of a failed open for the thread that reports it */
 MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); if(d->rc) snprintf(d->err, sizeof(d->err), "%s", md_dev_last_error()); return NULL; }

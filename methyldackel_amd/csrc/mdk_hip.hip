@@ -62,7 +62,6 @@ struct KParams {
     int packed;                   // 0: payload = blob + 4*off4, qualities after the sequence padded to 4 bytes (host-built batches);
                                   // 1: payload = blob + off4 (byte offset into the uploaded BAM records), qualities directly after the sequence
     int mbias; uint32_t *hist; int hist_lq;     // mbias: window-relative contexts at the chunk edges; histogram rows [q][16]; rows kept in LDS
-    unsigned long long *dbg;      // optional phase timestamps: 8 words per workgroup (MDK_PHASES=1)
 };
 
 // kept query-index window [lo,hi) of a read after --OT-style and --nOT-style trimming (common.c:137-208)
@@ -393,8 +392,6 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if(t == 0 && tid == 0) *P.total_next = 0;    // the counter the NEXT launch of this slot will use
 
-    unsigned long long tr0 = 0, tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0, tc4 = 0;
-    if(P.dbg) { tr0 = wall_clock64(); tc0 = clock64(); }
     // everything this thread needs from HBM before it can start is requested up front, in one round:
     // the context codes of the PER consecutive positions it owns, and its first segment record
     const TileEnt te = P.tiles[t];
@@ -415,7 +412,6 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     }
     int nC, nG;
     build_lists(P, PER, tid, lane, wave, code, listC, listG, wsum, nC, nG);
-    if(P.dbg) tc1 = clock64();
 
     // phase 2: WG segments per round.  One segment per lane, or (QW) prepared by one lane each and worked on by 16
     if constexpr(QW) {
@@ -438,9 +434,7 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     // atomic's round trip overlaps the wait for the slower wavefronts, and the tiles' atomics are spread in time.
     uint32_t reserved = 0;
     if(tid == 0) reserved = (nC + nG) ? atomicAdd(P.total, (uint32_t)(nC + nG)) : 0u;
-    if(P.dbg) tc2 = clock64();
     __syncthreads();
-    if(P.dbg) tc3 = clock64();
 
     // phase 3: compaction.  Every thread packs the positions it owns; one atomic reserves the tile's segment;
     // 16-byte site records are written in ascending position order.
@@ -473,13 +467,6 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
                 }
                 o++;
             }
-        }
-    }
-    if(P.dbg) {
-        tc4 = clock64();
-        if(lane == 0) {
-            unsigned long long *d = P.dbg + ((size_t)b * WAVES + wave) * 8;
-            d[0] = tr0; d[1] = wall_clock64(); d[2] = tc1 - tc0; d[3] = tc2 - tc1; d[4] = tc3 - tc2; d[5] = tc4 - tc3; d[6] = (unsigned long long)(last - first); d[7] = (unsigned long long)t;
         }
     }
 }
@@ -1199,33 +1186,6 @@ extern "C" int md_dev_bench(md_dev *h, int slot, int warmup, int iters, md_bench
         pk = (double)b;
     }
     out->ms_total = (float)(tot / iters); out->ms_pileup = (float)(pk / iters);
-    if(getenv("MDK_PHASES") && s->ntiles > 0) {        // one instrumented launch: where does a workgroup spend its time?
-        KParams P; rc = fill_kparams(h, s, P); if(rc) return rc;
-        int grid = P.nper * 8; size_t nw = (size_t)grid * WAVES * 8;
-        unsigned long long *dd = nullptr; std::vector<unsigned long long> hd(nw);
-        HIPCHK(hipMalloc((void **)&dd, nw * 8)); HIPCHK(hipMemset(dd, 0, nw * 8));
-        s->ring++; rc = fill_kparams(h, s, P); if(rc) return rc;
-        P.dbg = dd;
-        launch_pileup(h, grid, (size_t)s->lds_bytes, s->stream, P);
-        HIPCHK(hipStreamSynchronize(s->stream));
-        HIPCHK(hipMemcpy(hd.data(), dd, nw * 8, hipMemcpyDeviceToHost)); (void)hipFree(dd);
-        unsigned long long r0 = ~0ull, r1 = 0; double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0}; size_t cnt = 0; std::vector<double> starts, ends, life;
-        for(size_t i = 0; i < nw; i += 8) { if(!hd[i]) continue; r0 = std::min(r0, hd[i]); r1 = std::max(r1, hd[i + 1]); }
-        for(size_t i = 0; i < nw; i += 8) {
-            if(!hd[i]) continue;
-            cnt++; starts.push_back((double)(hd[i] - r0) / 100.0); ends.push_back((double)(hd[i + 1] - r0) / 100.0); life.push_back((double)(hd[i + 1] - hd[i]) / 100.0);
-            for(int k = 0; k < 4; k++) { sum[k] += (double)hd[i + 2 + k]; mx[k] = std::max(mx[k], (double)hd[i + 2 + k]); }
-        }
-        std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end()); std::sort(life.begin(), life.end());
-        if(cnt) {
-            fprintf(stderr, "[phases] waves %zu, launch span %.2f us (realtime clock)\n", cnt, (double)(r1 - r0) / 100.0);
-            fprintf(stderr, "[phases] wave start  us: p0 %.2f p50 %.2f p90 %.2f p100 %.2f\n", starts[0], starts[cnt / 2], starts[cnt * 9 / 10], starts[cnt - 1]);
-            fprintf(stderr, "[phases] wave end    us: p0 %.2f p50 %.2f p90 %.2f p100 %.2f\n", ends[0], ends[cnt / 2], ends[cnt * 9 / 10], ends[cnt - 1]);
-            fprintf(stderr, "[phases] wave life   us: p0 %.2f p50 %.2f p90 %.2f p100 %.2f\n", life[0], life[cnt / 2], life[cnt * 9 / 10], life[cnt - 1]);
-            const char *nm[4] = {"lists(+hdr issue)", "reads", "wait at barrier", "compaction"};
-            for(int k = 0; k < 4; k++) fprintf(stderr, "[phases] %-18s mean %8.0f max %8.0f shader clocks\n", nm[k], sum[k] / cnt, mx[k]);
-        }
-    }
     out->n_sites = (uint64_t)n;
     // sum over reads [16 + 4 n_cigar + ceil(l/2) + l] + interval length + 8 per site (+8 with nOff/nVariant)
     out->algo_bytes = s->read_bytes + (uint64_t)(s->end - s->beg) + (uint64_t)n * (h->variant ? 16 : 8);

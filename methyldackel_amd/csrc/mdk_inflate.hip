@@ -201,19 +201,13 @@ __global__ __launch_bounds__(1024) void k_walk_scan(const uint32_t *cnt, uint32_
 // ------------------------------------------------------------------------------------------------
 // host side: pieces
 // ------------------------------------------------------------------------------------------------
-static void launch_inflate(int variant, int n_mem, hipStream_t st, const InfParams &IP) {
-    switch(variant & 3) {
-    case 0: hipLaunchKernelGGL(k_inflate<0>, dim3(n_mem), dim3(64), 0, st, IP); break;
-    case 1: hipLaunchKernelGGL(k_inflate<1>, dim3(n_mem), dim3(64), 0, st, IP); break;
-    case 2: hipLaunchKernelGGL(k_inflate<2>, dim3(n_mem), dim3(64), 0, st, IP); break;
-    default: hipLaunchKernelGGL(k_inflate<3>, dim3(n_mem), dim3(64), 0, st, IP); break;
-    }
-}
-#ifndef INF_DEFAULT_VARIANT
-#define INF_DEFAULT_VARIANT 0
+// the decoder variant is a build-time choice (experiments: make B=dir HIPFLAGS=-DINF_VARIANT=1..3); 0 -- decoder in lane 0's vector
+// registers, full barriers between the phases -- is the fastest measured (profiles/r03_inflate_experiments.json)
+#ifndef INF_VARIANT
+#define INF_VARIANT 0
 #endif
+static void launch_inflate(int n_mem, hipStream_t st, const InfParams &IP) { hipLaunchKernelGGL(k_inflate<INF_VARIANT>, dim3(n_mem), dim3(64), 0, st, IP); }
 struct md_piece {
-    int variant = getenv("MDK_INFLATE_VARIANT") ? atoi(getenv("MDK_INFLATE_VARIANT")) : INF_DEFAULT_VARIANT;
     md_dev *h = nullptr; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
     DBuf<uint8_t> d_comp, d_out; DBuf<md_inf_member> d_mem; DBuf<uint32_t> d_cnt, d_first, d_recoff, d_status; DBuf<md_inf_digest> d_dig;
     HBuf<md_inf_digest> h_dig; HBuf<uint32_t> h_status;
@@ -263,7 +257,7 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
     HIPCHK(hipMemcpyAsync(p->d_mem.p, mem, sizeof(md_inf_member) * (size_t)n_mem, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(p->d_status.p, 0, 16, st));
     InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p;
-    launch_inflate(p->variant, n_mem, st, IP);
+    launch_inflate(n_mem, st, IP);
     WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
     hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
     hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)p->d_cnt.p, p->d_first.p, n_mem, p->d_status.p);
@@ -314,7 +308,7 @@ extern "C" int md_piece_bench(md_piece *p, int iters, float *ms_inflate, float *
     WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventRecord(e0, st));
-    for(int i = 0; i < iters; i++) launch_inflate(p->variant, n_mem, st, IP);
+    for(int i = 0; i < iters; i++) launch_inflate(n_mem, st, IP);
     HIPCHK(hipEventRecord(e1, st));
     for(int i = 0; i < iters; i++) {
         hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);

@@ -3,14 +3,17 @@
 // per launch, each over up to 8 chunks at once (a 1 Mb chunk is ~780 workgroups: alone it leaves the machine half empty and every
 // launch boundary is paid per chunk):
 //
-//   k_prep_scan  one lane per BAM record: the record's fields (dword loads at the record's own alignment), its CIGAR (reference
-//                length, bam_cigar2rlen), the aux walk for NH and XG (bam_aux_get), getStrand (common.c:84-116) and filter_func's
-//                admission tests in its order (common.c:416-444: unmapped, MAPQ, -F, -R, duplicates, NH, mappability windows,
-//                singleton, discordant, BED span, conversion efficiency).  The admitted records are compacted IN FILE ORDER (the
-//                order bam_plp_push sees them in) inside the same kernel: a workgroup draws a ticket, publishes its count, and adds
-//                up the counts of the tickets before it -- they all belong to workgroups that are already running, so nobody waits
-//                for a workgroup that has not started.  Each admitted read goes into a name-keyed hash table (what khash does in
-//                custom_overlap_constructor).
+//   k_prep_scan  one lane per BAM record.  A lane walks ITS record, so every load of a wavefront touches 64 different cache lines and
+//                costs that whatever its width: the record is fetched 16 bytes at a time (two loads for the fixed fields, one for the
+//                name's first block, one for the first four CIGAR operations, 8 bytes per aux field) and taken apart in registers:
+//                reference length (bam_cigar2rlen), the aux walk for NH and XG (bam_aux_get), getStrand (common.c:84-116) and
+//                filter_func's admission tests in its order (common.c:416-444: unmapped, MAPQ, -F, -R, duplicates, NH, mappability
+//                windows, singleton, discordant, BED span, conversion efficiency).  The admitted records are compacted IN FILE ORDER
+//                (the order bam_plp_push sees them in) inside the same kernel: a workgroup draws a ticket, publishes its count, and
+//                adds up the counts of the tickets before it -- they all belong to workgroups that are already running, so nobody
+//                waits for a workgroup that has not started.  What later steps need of a read travels in a 64-byte PrepRead (name
+//                head, first CIGAR operations, table slot), and each admitted read goes into a name-keyed hash table (what khash
+//                does in custom_overlap_constructor).
 //   k_prep_segs  one lane per admitted read: the records of its name, in file order, go through the constructor/destructor state
 //                machine of overlaps.c:121-147 *including* htslib's buffer eviction (a read leaves the pileup buffer once a
 //                later read starts beyond its end, and its destructor erases the name) -- every read of a name runs the few
@@ -25,7 +28,9 @@
 #include <algorithm>
 #include "mdk_hip_internal.hpp"
 
+#ifndef PB
 #define PB 256                       // threads per block of the per-record kernels
+#endif
 #define MAXG 16                      // records of one name a lane sorts in registers
 #define MAXLIVE 8                    // reads of one name alive in the pileup buffer at once
 #define CNT_READY 0x80000000u        // a workgroup's published count: this bit | count

@@ -2,7 +2,7 @@
  *   piece_bench file.bam [piece_MB=64] [in_flight=3] [verify=1]
  * Splits the file into pieces of whole BGZF members, stages each piece in pinned memory, runs it through md_piece_submit / wait
  * with `in_flight` pieces queued, and reports: wall-clock of the whole file (staging copy + H2D + kernels + D2H of the digests),
- * the kernels alone on a resident piece for every kernel variant (HIP events), and -- verify=1 -- whether every inflated byte
+ * the kernels alone on a resident piece (HIP events), and -- verify=1 -- whether every inflated byte
  * equals zlib's, every record offset equals the host's walk and every digest equals what csrc/host/mdk_io.c note_records leaves.
  * build: make tools   (gcc, links libmdk_hip.so) */
 #define _GNU_SOURCE
@@ -116,17 +116,13 @@ int main(int argc, char **argv) {
         const double dt = now() - t0;
         printf(", \"pass2\": {\"seconds\": %.4f, \"GBps_compressed\": %.2f, \"GBps_inflated\": %.2f}", dt, n / dt / 1e9, tot_out / dt / 1e9);
     }
-    /* kernels alone on the largest resident piece, per variant */
+    /* kernels alone on the largest resident piece */
     { int big = 0; for(int i = 1; i < np; i++) if(pc[i].m1 - pc[i].m0 > pc[big].m1 - pc[big].m0) big = i;
       const piece_t *q = &pc[big]; const size_t cb = q->file_end - q->file_off;
       printf(", \"kernel_only\": {\"piece_members\": %d, \"piece_comp_MB\": %.1f, \"piece_out_MB\": %.1f", q->m1 - q->m0, cb / 1048576.0, q->out_bytes / 1048576.0);
       memcpy(stage[0], raw + q->file_off, cb);
-      const char *vars = getenv("PIECE_BENCH_VARIANTS") ? getenv("PIECE_BENCH_VARIANTS") : "0 1 2 3 4 6";
-      for(const char *v = vars; *v;) {
-          while(*v == ' ') v++;
-          if(!*v) break;
-          const int var = atoi(v); while(*v && *v != ' ') v++;
-          char buf[16]; snprintf(buf, sizeof buf, "%d", var); setenv("MDK_INFLATE_VARIANT", buf, 1);
+      {   /* (the decoder variant is chosen when the library is built: make B=dir HIPFLAGS=-DINF_VARIANT=n) */
+          const int var = 0;
           md_piece *X; md_piece_info info; float a = 0, b = 0;
           if(md_piece_create(dev, &X) || md_piece_submit(X, stage[0], cb, mem + q->m0, q->m1 - q->m0) || md_piece_wait(X, &info)) { fprintf(stderr, "variant %d: %s\n", var, md_dev_last_error()); return 1; }
           if(md_piece_bench(X, 5, &a, &b)) { fprintf(stderr, "md_piece_bench: %s\n", md_dev_last_error()); return 1; }
