@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 3, GPU call: what the preparation kernels spend their time on -- builds with parts switched off (PREP_EXP, timing only)
+# round 3, GPU call: what the preparation kernels spend their time on -- builds with parts switched off (-DPREP_EXP=n, timing only).
+# Kept as the record of how profiles/r03l_prep_experiments.txt was made: the PREP_EXP switches were removed from csrc/mdk_prep.hip afterwards.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp PREP_BENCH_FAST=1
 for v in "" e1 e2 e4 e7 e8 e32 e40; do
   if [ -n "$v" ]; then export MDK_BUILD_DIR=$R/methyldackel_amd/_exp_$v; else unset MDK_BUILD_DIR; fi
