@@ -283,36 +283,38 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
             const int badrs = strand == 0 ? 6 : (odd ? 4 : 2);
             const uint16_t *list = listC + ((w >> 5) & 0x1fff);
             const int mcode = odd ? 2 : 4, ucode = odd ? 8 : 1;      // the strand's C read as C (methylated) / as T (unmethylated): BAM codes C=2 T=8, G=4 A=1
-            for(int j = sub; j < n; j += QU * QL) {
+            // a lane takes two ADJACENT entries of the list per step (one LDS load), the 8 lanes of a segment 16 consecutive sites
+            bool anyok = false;
+            for(int j = 2 * sub; j < n; j += 2 * QL) {
                 // 1. which sites (no base has been touched yet); 2. every byte they need is requested; 3. they are used
-                int l[QU]; bool ok[QU]; int q[QU], mq[QU]; uint32_t sb[QU], qb[QU], msb[QU], mqb[QU];
-#pragma unroll
-                for(int k = 0; k < QU; k++) {
-                    const int jj = j + k * QL; ok[k] = jj < n;
-                    const int e = ok[k] ? (int)list[jj] : 0;
-                    l[k] = e & 0x1fff;
-                    if((badrs >> (e >> 13)) & 1) ok[k] = false;
-                    q[k] = l[k] + cq; mq[k] = l[k] + mcq;
-                    sb[k] = 0xff; qb[k] = 0; msb[k] = 0xff; mqb[k] = 0;   // a trimmed base needs no load: it reads as N with quality 0
-                    if(ok[k] && (unsigned)(q[k] - lo) < wlen) { sb[k] = blob[oseq + (uint32_t)(q[k] >> 1)]; qb[k] = blob[oqual + (uint32_t)q[k]]; }
-                    if(ok[k] && partner && (unsigned)(mq[k] - mlo) < mwlen) { msb[k] = blob[mseq + (uint32_t)(mq[k] >> 1)]; mqb[k] = blob[mqual + (uint32_t)mq[k]]; }
-                }
-#pragma unroll
-                for(int k = 0; k < QU; k++) {
-                    if(!ok[k]) continue;
-                    const int bq = (q[k] & 1) ? (sb[k] & 15) : (sb[k] >> 4); int ql = (int)qb[k];
-                    if(partner) { const int mb = (mq[k] & 1) ? (msb[k] & 15) : (msb[k] >> 4); ql = resolve_own(second, bq, ql, mb, (int)mqb[k]); }
+                uint32_t e01; __builtin_memcpy(&e01, list + j, 4);             // (the second entry is whatever follows the list when j + 1 == n)
+                const uint32_t e0 = e01 & 0xffffu, e1 = e01 >> 16;
+                const int l0 = (int)(e0 & 0x1fffu), l1 = (int)(e1 & 0x1fffu);
+                const bool ok0 = !((badrs >> (e0 >> 13)) & 1), ok1 = j + 1 < n && !((badrs >> (e1 >> 13)) & 1);
+                const int q0 = l0 + cq, q1 = l1 + cq, mq0 = l0 + mcq, mq1 = l1 + mcq;
+                uint32_t sb0 = 0xff, qb0 = 0, msb0 = 0xff, mqb0 = 0, sb1 = 0xff, qb1 = 0, msb1 = 0xff, mqb1 = 0;   // a trimmed base needs no load: it reads as N with quality 0
+                if(ok0 && (unsigned)(q0 - lo) < wlen) { sb0 = blob[oseq + (uint32_t)(q0 >> 1)]; qb0 = blob[oqual + (uint32_t)q0]; }
+                if(ok0 && partner && (unsigned)(mq0 - mlo) < mwlen) { msb0 = blob[mseq + (uint32_t)(mq0 >> 1)]; mqb0 = blob[mqual + (uint32_t)mq0]; }
+                if(ok1 && (unsigned)(q1 - lo) < wlen) { sb1 = blob[oseq + (uint32_t)(q1 >> 1)]; qb1 = blob[oqual + (uint32_t)q1]; }
+                if(ok1 && partner && (unsigned)(mq1 - mlo) < mwlen) { msb1 = blob[mseq + (uint32_t)(mq1 >> 1)]; mqb1 = blob[mqual + (uint32_t)mq1]; }
+                auto use = [&](const bool ok, const int l, const int q, const int mq, const uint32_t sb, const uint32_t qb, const uint32_t msb, const uint32_t mqb) {
+                    if(!ok) return;
+                    const int bq = (int)((sb >> ((~q & 1) << 2)) & 15u); int ql = (int)qb;
+                    if(partner) { const int mb = (int)((msb >> ((~mq & 1) << 2)) & 15u); ql = resolve_own(second, bq, ql, mb, (int)mqb); }
                     if(callpass) {
-                        if(strand == 0) atomicExch(P.err, 1);                 // reference: assert(strand != 0) (common.c:122-125)
-                        if(ql >= minPhred && (bq == mcode || bq == ucode)) atomicAdd(&cm[(bq == ucode ? tile : 0) + l[k]], 1u);     // cu = cm + tile
+                        if(ql >= minPhred && (bq == mcode || bq == ucode)) atomicAdd(&cm[(bq == ucode ? tile : 0) + l], 1u);     // cu = cm + tile
                     } else if(VARIANT) {
                         if(ql >= minPhred) {
-                            atomicAdd(&co[l[k]], 1u);
-                            if(odd ? (bq != 4 && bq != 15) : (bq != 2 && bq != 15)) atomicAdd(&cv[l[k]], 1u);
+                            atomicAdd(&co[l], 1u);
+                            if(odd ? (bq != 4 && bq != 15) : (bq != 2 && bq != 15)) atomicAdd(&cv[l], 1u);
                         }
                     }
-                }
+                };
+                use(ok0, l0, q0, mq0, sb0, qb0, msb0, mqb0);
+                use(ok1, l1, q1, mq1, sb1, qb1, msb1, mqb1);
+                anyok = anyok || ok0 || ok1;
             }
+            if(callpass && strand == 0 && anyok) atomicExch(P.err, 1);        // a read of unknown strand reached a call; reference: assert(strand != 0) (common.c:122-125)
         }
     }
 }
@@ -320,10 +322,13 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
 // barrier that orders LDS traffic only (does not drain this wave's outstanding global loads)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// inclusive scan over the 64 lanes of a wavefront
+// inclusive scan over the 64 lanes of a wavefront.  The lane number goes through an empty asm first: the tile routine scans twice, long
+// before and long after its main loop, and the six shuffle addresses of the first scan would otherwise be kept for the second -- in
+// scratch, under the 64-VGPR cap: 24 bytes written and read back per thread, 100 MB per launch of 8 chunks.
 __device__ __forceinline__ int wave_scan_incl(int v, int lane) {
+    asm volatile("" : "+v"(lane));
 #pragma unroll
-    for(int d = 1; d < 64; d <<= 1) { int n = __shfl_up(v, d); if(lane >= d) v += n; }
+    for(int d = 1; d < 64; d <<= 1) { const int n = __builtin_amdgcn_ds_bpermute((lane >= d ? lane - d : lane) << 2, v); if(lane >= d) v += n; }
     return v;
 }
 
@@ -413,6 +418,12 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
     int nC, nG;
     build_lists(P, PER, tid, lane, wave, code, listC, listG, wsum, nC, nG);
 
+    // the context codes are needed again in phase 3: they cross phase 2 as ONE register (a byte each), not four
+    uint32_t codes = 0;
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++) codes |= (uint32_t)(code[j] & 0xff) << (8 * j);
+    asm volatile("" : "+v"(codes));
+
     // phase 2: WG segments per round.  One segment per lane, or (QW) prepared by one lane each and worked on by 16
     if constexpr(QW) {
         const int topC = nC ? 1 << (31 - __clz(nC)) : 0, topG = nG ? 1 << (31 - __clz(nG)) : 0;
@@ -438,6 +449,8 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
 
     // phase 3: compaction.  Every thread packs the positions it owns; one atomic reserves the tile's segment;
     // 16-byte site records are written in ascending position order.
+#pragma unroll
+    for(int j = 0; j < PERMAX; j++) code[j] = (int)((codes >> (8 * j)) & 0xffu);
     uint32_t vm[PERMAX], vu[PERMAX], vo[PERMAX], vv[PERMAX]; int cnt = 0;
 #pragma unroll
     for(int j = 0; j < PERMAX; j++) {

@@ -11,7 +11,9 @@
 
 /* (uint8_t)(q + 0.2*q) as evaluated by the reference on x86-64 (overlaps.c:103,106): floor(6q/5) mod 256.
  * md_dev_open checks this identity against the C expression for all 256 values. */
-MDK_HD int boost(int q) { return ((q * 6) / 5) & 255; }
+/* (for 0 <= q <= 255: x/5 == (x * 52429) >> 18 for every x < 2^16, and both products fit 24-bit multiplies, which the GPU issues at
+ * full rate where a 32-bit multiply and a multiply-high take four cycles each) */
+MDK_HD int boost(int q) { return (int)(((((unsigned)q & 255u) * 6u) * 52429u) >> 18) & 255; }
 
 /* cust_tweak_overlap_quality, literally: a = the read earlier in the file, b = the later one; returns what the OWN base's
  * quality becomes (b, ql: own base and quality; mb, mq: the partner's) */
