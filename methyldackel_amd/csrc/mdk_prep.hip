@@ -341,41 +341,70 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     P.hnext[a] = atomicExch(&P.hhead[sl], (int32_t)a + 1) - 1;
 }
 
-__device__ __forceinline__ bool same_name(const PrepParams &P, const PrepRead &x, const PrepRead &y) {       // strcmp(x, y) == 0
-    if(x.nlen != y.nlen || x.name[0] != y.name[0] || x.name[1] != y.name[1] || x.name[2] != y.name[2] || x.name[3] != y.name[3]) return false;
-    if(x.nlen <= 16) return true;
-    const uint8_t *p = P.raw + x.qn_off, *q = P.raw + y.qn_off;
-    for(int k = 16; k < x.nlen; k++) if(p[k] != q[k]) return false;
-    return true;
-}
-
 // overlaps.c:121-147 + the pileup buffer's eviction, for the name of read `a` (see pair_reads in csrc/host/mdk_pipeline.c for the
 // host statement of the same rule): a read enters the buffer iff its end lies beyond the column about to be emitted (the start of
 // the previously admitted read); entering, it first drops the name's reads that have been swept out (end < that column) -- any
 // such drop erases the name's pending entry --, then either becomes pending or is paired with the pending read.  Returns the read
 // `a` is resolved against (-1: none) and whether `a` is the later of the two.
+// what pairing looks at in another read of the name: quad 0 (pos rend ncig|flag strand|nlen) and quad 1 (the name's first 16 bytes) of its
+// PrepRead, taken apart in registers (a PrepRead filled through a pointer would live in scratch)
+struct OtherRead { int32_t rend; uint32_t flag, nlen; uint4 name; };
+__device__ __forceinline__ OtherRead other_read(const PrepParams &P, const int32_t x) {
+    const uint4 *q = (const uint4 *)&P.rd[x]; const uint4 q0 = q[0], q1 = q[1];
+    OtherRead O; O.rend = (int32_t)q0.y; O.flag = q0.z >> 16; O.nlen = (q0.w >> 8) & 255u; O.name = q1;
+    return O;
+}
+__device__ __forceinline__ bool same_name_as(const PrepParams &P, const PrepRead &x, const OtherRead &y, const int32_t yi) {       // strcmp == 0
+    if(x.nlen != y.nlen || x.name[0] != y.name.x || x.name[1] != y.name.y || x.name[2] != y.name.z || x.name[3] != y.name.w) return false;
+    if(x.nlen <= 16) return true;
+    const uint8_t *p = P.raw + x.qn_off, *q = P.raw + P.rd[yi].qn_off;
+    for(int k = 16; k < x.nlen; k++) if(p[k] != q[k]) return false;
+    return true;
+}
+__device__ __forceinline__ bool pairs(const uint32_t flag) { return (flag & 0x1) && !(flag & 12); }
+
+// Returns the read `a` is resolved against (-1: none) and whether `a` is the later of the two.
 __device__ int32_t pair_of(const PrepParams &P, const uint32_t a, const PrepRead &ra, bool &second) {
     second = false;
-    if(!(ra.flag & 0x1) || (ra.flag & 12)) return -1;               // such a read never becomes pending nor pairs (it still occupies the buffer for others)
+    if(!pairs(ra.flag)) return -1;                                  // such a read never becomes pending nor pairs (it still occupies the buffer for others)
+    // the name's chain: newest first; nearly always the read and one other
+    const int32_t x1 = P.hhead[ra.slot] - 1;
+    const int32_t x2 = x1 >= 0 ? P.hnext[x1] : -1;
+    if(x2 < 0) return -1;                                           // alone under its name: pending for ever
+    const int32_t x3 = P.hnext[x2];
+    if(x3 < 0) {
+        // two reads: the rule in closed form.  f, s = the earlier and the later in the file; one of them is `a`.  f enters the buffer (unless
+        // it ends before the column being emitted) and becomes pending; s enters, sweeps f out if f ends before the start of the read
+        // admitted before s -- which erases the pending entry --, and otherwise is paired with it.
+        const int32_t f = x1 < x2 ? x1 : x2, sx = x1 < x2 ? x2 : x1, o = (uint32_t)f == a ? sx : f;
+        const OtherRead O = other_read(P, o);
+        const int32_t prev_f = f ? P.rd[f - 1].pos : 0, prev_s = P.rd[sx - 1].pos;
+        if(!same_name_as(P, ra, O, o)) return -1;                   // two names with one hash
+        const bool a_first = (uint32_t)f == a;
+        const int32_t rend_f = a_first ? ra.rend : O.rend, rend_s = a_first ? O.rend : ra.rend;
+        const bool in_f = f == 0 ? (P.tid > 0 || rend_f > 0) : rend_f > prev_f;
+        const bool in_s = rend_s > prev_s;
+        if(!in_f || !in_s || !pairs(O.flag) || rend_f < prev_s) return -1;
+        second = !a_first;
+        return o;
+    }
     int32_t idx[MAXG]; int k = 0;
-    for(int32_t x = P.hhead[ra.slot] - 1; x >= 0; x = P.hnext[x]) { if(k == MAXG) { atomicExch(&P.cnt->fallback, 1u); return -1; } idx[k++] = x; }
+    for(int32_t x = x1; x >= 0; x = P.hnext[x]) { if(k == MAXG) { atomicExch(&P.cnt->fallback, 1u); return -1; } idx[k++] = x; }
     for(int i = 1; i < k; i++) { const int32_t v = idx[i]; int q = i - 1; while(q >= 0 && idx[q] > v) { idx[q + 1] = idx[q]; q--; } idx[q + 1] = v; }
     int32_t pending = -1, mate = -1; int32_t live[MAXLIVE]; int nlive = 0;
     for(int i = 0; i < k; i++) {
         const int32_t x = idx[i];
-        PrepRead X;                                                 // of another read only the first two quads (pos rend ncig flag strand nlen | name) are fetched
-        if((uint32_t)x == a) X = ra;
-        else { const uint4 *q = (const uint4 *)&P.rd[x]; uint4 *d = (uint4 *)&X; d[0] = q[0]; d[1] = q[1]; X.qn_off = 0; if(X.nlen > 16) X.qn_off = P.rd[x].qn_off; }
-        if((uint32_t)x != a && !same_name(P, ra, X)) continue;      // another name in the same slot
+        int32_t rend = ra.rend; uint32_t flag = ra.flag;
+        if((uint32_t)x != a) { const OtherRead O = other_read(P, x); if(!same_name_as(P, ra, O, x)) continue; rend = O.rend; flag = O.flag; }      // (continue: another name with the same hash)
         const bool first = x == 0;
         const int32_t prev_pos = first ? 0 : P.rd[x - 1].pos;
-        const bool inserted = first ? (P.tid > 0 || X.rend > 0) : (X.rend > prev_pos);
+        const bool inserted = first ? (P.tid > 0 || rend > 0) : (rend > prev_pos);
         if(!inserted) continue;
         bool evicted = false; int w = 0;
         for(int q = 0; q < nlive; q++) { if(!first && live[q] < prev_pos) evicted = true; else live[w++] = live[q]; }
         nlive = w;
         if(evicted) pending = -1;
-        if((X.flag & 0x1) && !(X.flag & 12)) {
+        if(pairs(flag)) {
             if(pending < 0) pending = x;
             else {
                 if((uint32_t)pending == a) { mate = x; second = false; }
@@ -384,7 +413,7 @@ __device__ int32_t pair_of(const PrepParams &P, const uint32_t a, const PrepRead
             }
         }
         if(nlive == MAXLIVE) { atomicExch(&P.cnt->fallback, 1u); return -1; }
-        live[nlive++] = X.rend;
+        live[nlive++] = rend;
     }
     return mate;
 }
