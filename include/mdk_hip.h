@@ -362,6 +362,10 @@ void  md_host_set_pinned(int on);
 void  md_host_free(void *p);
 /* what registering staging blocks has cost so far (seconds on the uploading threads, calls, bytes) */
 void  md_host_profile(double *seconds, uint64_t *calls, uint64_t *bytes);
+/* a staging block is registered with the runtime (hipHostRegister) the first time an upload reads from it; a thread that has just FILLED
+ * one may do that itself once a device is open (h: that device), so that the thread submitting uploads does not have to.  ptr: anywhere
+ * inside the block */
+void  md_host_register(md_dev *h, const void *ptr);
 
 #ifdef __cplusplus
 }

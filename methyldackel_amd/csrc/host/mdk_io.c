@@ -308,6 +308,7 @@ static void *inflater_main(void *arg) {
         if(st == 0) pc.seq = b->next_seq++; else b->io_status = st;
         pthread_mutex_unlock(&b->io_mu);
         if(st == 0) { s = gt >= 0 ? inflate_piece_device(b, &pc, gt, &st) : inflate_piece(b, &pc, b->team_threads, &st); free(pc.cbuf); free(pc.blk); }
+        if(s && gt < 0 && b->dev) md_host_register(b->dev, s->buf);          /* the device is up: the slab this team has just filled is made known to the runtime here, not by the thread that uploads from it */
         if(s) {
             if(deliver(b, s, pc.seq)) break;
             /* test hook (MDK_DEVICE_INFLATE_ONLY=1, `extract` only): the host teams leave after the piece that holds the BAM header, so that

@@ -31,6 +31,7 @@
 #include <atomic>
 #include <mutex>
 #include <algorithm>
+#include <condition_variable>
 #include <chrono>
 #include "mdk_hip_internal.hpp"
 
@@ -1270,9 +1271,11 @@ extern "C" int md_dev_debug_effective(md_dev *h, int slot, uint8_t *out_base, ui
 // thread a microsecond -- pageable, the same copy is a 13 GB/s CPU copy on the submitting thread.  Allocation itself never
 // touches the HIP runtime, so the inflate threads can fill slabs while the device is still coming up.  A 64-byte header in front
 // of the block remembers which kind it is.  md_host_set_pinned(1) (default off in the commands) allocates with hipHostMalloc.
-struct HostBlock { char *base; size_t len; bool registered; };
+struct HostBlock { char *base; size_t len; int state; };          // state: 0 not registered, 1 being registered (by whoever set it), 2 registered, 3 cannot be
 static std::mutex g_blocks_mu; static std::vector<HostBlock> g_blocks;       // sorted by base
+static std::condition_variable g_blocks_cv;                          // a block left state 1
 static double g_reg_seconds = 0; static uint64_t g_reg_calls = 0, g_reg_bytes = 0;
+static bool block_less(const HostBlock &x, const HostBlock &y) { return x.base < y.base; }
 static void *plain_alloc(size_t n) {
     void *p = nullptr;
     static const int thp = getenv("MDK_NO_THP") ? 0 : 1;
@@ -1282,26 +1285,42 @@ static void *plain_alloc(size_t n) {
         if(posix_memalign(&p, 2u << 20, len) != 0) return nullptr;
         (void)madvise(p, len, MADV_HUGEPAGE);
         std::lock_guard<std::mutex> lk(g_blocks_mu);
-        HostBlock b{(char *)p, len, false};
-        g_blocks.insert(std::upper_bound(g_blocks.begin(), g_blocks.end(), b, [](const HostBlock &x, const HostBlock &y) { return x.base < y.base; }), b);
+        HostBlock b{(char *)p, len, 0};
+        g_blocks.insert(std::upper_bound(g_blocks.begin(), g_blocks.end(), b, block_less), b);
     } else if(posix_memalign(&p, 4096, n) != 0) return nullptr;
     memcpy(p, "MDKMAL", 7);
     return (char *)p + 64;
 }
-// before an upload from [ptr, ptr+bytes): if that lies in a huge-page staging block not yet known to the runtime, register the block
+// If `ptr` lies in a huge-page staging block not yet known to the runtime, register the block.  Called before an upload reads from it
+// (md_dev_upload_raw, md_piece_submit) and, once the device is open, by the inflate team that has just filled it (md_host_register): the
+// lock is given up for the duration of hipHostRegister, and whoever meets a block in the middle of that waits for it.
 MDK_HIDDEN void host_block_ensure_registered(const void *ptr) {
     static const int off = getenv("MDK_NO_PIN") ? 1 : 0;
     if(off) return;
-    std::lock_guard<std::mutex> lk(g_blocks_mu);
-    HostBlock key{(char *)ptr, 0, false};
-    auto it = std::upper_bound(g_blocks.begin(), g_blocks.end(), key, [](const HostBlock &x, const HostBlock &y) { return x.base < y.base; });
-    if(it == g_blocks.begin()) return;
-    --it;
-    if((char *)ptr >= it->base + it->len || it->registered) return;
-    const auto t0 = std::chrono::steady_clock::now();
-    if(hipHostRegister(it->base, it->len, hipHostRegisterDefault) == hipSuccess) it->registered = true; else (void)hipGetLastError();      // a block that cannot be registered is uploaded pageable
-    g_reg_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); g_reg_calls++; g_reg_bytes += it->len;
+    std::unique_lock<std::mutex> lk(g_blocks_mu);
+    for(;;) {
+        HostBlock key{(char *)ptr, 0, 0};
+        auto it = std::upper_bound(g_blocks.begin(), g_blocks.end(), key, block_less);
+        if(it == g_blocks.begin()) return;
+        --it;
+        if((char *)ptr >= it->base + it->len || it->state >= 2) return;
+        if(it->state == 1) { g_blocks_cv.wait(lk); continue; }
+        char *const base = it->base; const size_t len = it->len; it->state = 1;
+        lk.unlock();
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool ok = hipHostRegister(base, len, hipHostRegisterDefault) == hipSuccess;
+        if(!ok) (void)hipGetLastError();                             // a block that cannot be registered is uploaded pageable
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        lk.lock();
+        HostBlock k2{base, 0, 0};
+        it = std::lower_bound(g_blocks.begin(), g_blocks.end(), k2, block_less);     // (the vector may have moved; the block cannot have gone: md_host_free waits for state 1 to pass)
+        if(it != g_blocks.end() && it->base == base) it->state = ok ? 2 : 3;
+        g_reg_seconds += dt; g_reg_calls++; g_reg_bytes += len;
+        g_blocks_cv.notify_all();
+        return;
+    }
 }
+extern "C" void md_host_register(md_dev *h, const void *ptr) { if(h) (void)hipSetDevice(h->device); host_block_ensure_registered(ptr); }
 // MDK_HOST_PROFILE: what registering the staging blocks cost
 extern "C" void md_host_profile(double *seconds, uint64_t *calls, uint64_t *bytes) { std::lock_guard<std::mutex> lk(g_blocks_mu); if(seconds) *seconds = g_reg_seconds; if(calls) *calls = g_reg_calls; if(bytes) *bytes = g_reg_bytes; }
 static std::atomic<int> g_want_pinned{1};
@@ -1319,10 +1338,16 @@ extern "C" void md_host_free(void *q) {
     char *p = (char *)q - 64;
     if(!memcmp(p, "MDKPIN", 7)) { (void)hipHostFree(p); return; }
     {
-        std::lock_guard<std::mutex> lk(g_blocks_mu);
-        HostBlock key{p, 0, false};
-        auto it = std::lower_bound(g_blocks.begin(), g_blocks.end(), key, [](const HostBlock &x, const HostBlock &y) { return x.base < y.base; });
-        if(it != g_blocks.end() && it->base == p) { if(it->registered) (void)hipHostUnregister(p); g_blocks.erase(it); }
+        std::unique_lock<std::mutex> lk(g_blocks_mu);
+        HostBlock key{p, 0, 0};
+        for(;;) {
+            auto it = std::lower_bound(g_blocks.begin(), g_blocks.end(), key, block_less);
+            if(it == g_blocks.end() || it->base != p) break;
+            if(it->state == 1) { g_blocks_cv.wait(lk); continue; }          // somebody is registering it right now
+            if(it->state == 2) (void)hipHostUnregister(p);
+            g_blocks.erase(it);
+            break;
+        }
     }
     free(p);
 }
