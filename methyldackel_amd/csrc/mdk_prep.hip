@@ -50,7 +50,7 @@ struct PrepParams {
     const uint32_t *mapbits; int64_t maplen;         // 1 bit per base, or NULL
     const md_region *runs; int64_t nruns; int bed_on;
     PrepRead *rd; uint32_t *aidx;    // per admitted read: the read, (perRead) its index among the candidate records
-    uint64_t *hkey; int32_t *hhead, *hnext; uint32_t hmask;      // hhead: index + 1 of the name's latest read, 0 = empty
+    unsigned long long *hent; int32_t *hnext; uint32_t hmask;      // name table: (high half of the name's hash) << 32 | (index + 1 of the name's latest read); 0 = empty
     uint32_t *cntA, *cntS, *ticket; int nblocks;     // per workgroup: published counts of admitted reads / segments; two ticket counters
     md_seg *seg; int64_t cap_seg;
     TileEnt *tiles; int ntiles, tile;
@@ -58,6 +58,24 @@ struct PrepParams {
     uint8_t *zero; uint64_t zero_bytes;              // what a launch starts from zeroed: name table, counts, tickets
 };
 struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
+
+// Which chunk of the launch a workgroup works for.  Workgroups are dealt to the 8 XCDs round robin and every XCD has its own 4 MB L2:
+// workgroup b serves chunk (b mod 8) mod n, so that with eight chunks per launch an XCD sees one chunk only and that chunk's name table
+// (2 MB) and ticket counters stay in its L2 instead of every L2 thrashing over all eight.  WHICH records of the chunk a workgroup
+// takes is decided by the ticket it draws, not by its index; the launch holds at least as many workgroups per chunk as the chunk has
+// tickets (enqueue_prep_group), and a workgroup that draws a ticket beyond them leaves.
+#ifndef PREP_XCD
+#define PREP_XCD 1
+#endif
+__device__ __forceinline__ int chunk_of_block(const PrepMulti &M) {
+#if PREP_XCD
+    return (int)((blockIdx.x & 7u) % (unsigned)M.n);
+#else
+    int j = 0;
+    while(j + 1 < M.n && (int)blockIdx.x >= M.bstart[j + 1]) j++;
+    return j;
+#endif
+}
 
 // ---- aux area: first NH and first XG, as bam_aux_get finds them; a malformed area ends the walk ----
 // One 8-byte load per field: tag (2), type (1) and the first five value bytes -- all of a fixed-size value that NH or XG can have, and
@@ -225,12 +243,11 @@ __global__ __launch_bounds__(PB) void k_prep_zero(const PrepMulti M) {
 
 __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     __shared__ uint32_t s_tk, wcnt[PB / 64], red[PB / 64];
-    int j = 0;
-    while(j + 1 < M.n && (int)blockIdx.x >= M.bstart[j + 1]) j++;
-    const PrepParams &P = M.P[j];
+    const PrepParams &P = M.P[chunk_of_block(M)];
     if(threadIdx.x == 0) s_tk = atomicAdd(&P.ticket[0], 1u);
     __syncthreads();
     const uint32_t tk = s_tk; const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than tickets for this chunk
     int adm = 0; PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
     if(i < P.n_rec) {
         const uint64_t o = P.rec_off[i];
@@ -329,23 +346,26 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     const uint32_t a = base + rank;
     if(P.aidx) P.aidx[a] = (uint32_t)i;
     if(P.cfg.no_pairing || P.cfg.perread) { P.rd[a] = D; return; }
-    // name table: open addressing on the 64-bit hash, members chained through hnext (file order is restored by whoever walks a chain)
-    uint32_t sl = (uint32_t)(h ^ (h >> 32)) & P.hmask;
+    // name table: open addressing; an entry is (high half of the name's hash, the name's latest read), the name's earlier reads hang off
+    // hnext.  One 8-byte word per name, so an insertion touches one line of a 2 MB table: the first read of a name takes an empty entry
+    // with one compare-and-swap, a later one replaces the head with a second (file order is restored by whoever walks the chain).
+    const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)(a + 1u);
+    uint32_t sl = (uint32_t)h & P.hmask; int32_t before = -1;
     for(;;) {
-        const unsigned long long old = atomicCAS((unsigned long long *)&P.hkey[sl], 0ull, (unsigned long long)h);
-        if(old == 0ull || old == (unsigned long long)h) break;
+        unsigned long long old = atomicCAS(&P.hent[sl], 0ull, mine);
+        if(old == 0ull) break;
+        if((old >> 32) == (key >> 32)) {
+            for(;;) { const unsigned long long seen = atomicCAS(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
+            before = (int32_t)(uint32_t)old - 1;
+            break;
+        }
         sl = (sl + 1) & P.hmask;
     }
     D.slot = sl;
     P.rd[a] = D;
-    P.hnext[a] = atomicExch(&P.hhead[sl], (int32_t)a + 1) - 1;
+    P.hnext[a] = before;
 }
 
-// overlaps.c:121-147 + the pileup buffer's eviction, for the name of read `a` (see pair_reads in csrc/host/mdk_pipeline.c for the
-// host statement of the same rule): a read enters the buffer iff its end lies beyond the column about to be emitted (the start of
-// the previously admitted read); entering, it first drops the name's reads that have been swept out (end < that column) -- any
-// such drop erases the name's pending entry --, then either becomes pending or is paired with the pending read.  Returns the read
-// `a` is resolved against (-1: none) and whether `a` is the later of the two.
 // what pairing looks at in another read of the name: quad 0 (pos rend ncig|flag strand|nlen) and quad 1 (the name's first 16 bytes) of its
 // PrepRead, taken apart in registers (a PrepRead filled through a pointer would live in scratch)
 struct OtherRead { int32_t rend; uint32_t flag, nlen; uint4 name; };
@@ -368,7 +388,7 @@ __device__ int32_t pair_of(const PrepParams &P, const uint32_t a, const PrepRead
     second = false;
     if(!pairs(ra.flag)) return -1;                                  // such a read never becomes pending nor pairs (it still occupies the buffer for others)
     // the name's chain: newest first; nearly always the read and one other
-    const int32_t x1 = P.hhead[ra.slot] - 1;
+    const int32_t x1 = (int32_t)(uint32_t)P.hent[ra.slot] - 1;
     const int32_t x2 = x1 >= 0 ? P.hnext[x1] : -1;
     if(x2 < 0) return -1;                                           // alone under its name: pending for ever
     const int32_t x3 = P.hnext[x2];
@@ -478,9 +498,7 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const Pre
 
 __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64];
-    int j = 0;
-    while(j + 1 < M.n && (int)blockIdx.x >= M.bstart[j + 1]) j++;
-    const PrepParams &P = M.P[j];
+    const PrepParams &P = M.P[chunk_of_block(M)];
     if(threadIdx.x == 0) s_tk = atomicAdd(&P.ticket[1], 1u);
     __syncthreads();
     const uint32_t tk = s_tk, n_adm = P.cnt->n_adm;
@@ -608,8 +626,8 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
 
 static uint32_t pow2_at_least(size_t n) { uint32_t p = 1024; while(p < n) p <<= 1; return p; }
 
-// layout of a slot's zeroed region: hkey[H] (8 bytes each), hhead[H], cntA[nb], cntS[nb], ticket[2]; sizes rounded to 16 bytes
-static size_t zero_bytes_for(uint32_t hmask, int nb) { return (((size_t)hmask + 1) * 12 + (size_t)(nb > 0 ? nb : 1) * 8 + 8 + 15) & ~(size_t)15; }
+// layout of a slot's zeroed region: hent[H] (8 bytes each), cntA[nb], cntS[nb], ticket[2]; sizes rounded to 16 bytes
+static size_t zero_bytes_for(uint32_t hmask, int nb) { return (((size_t)hmask + 1) * 8 + (size_t)(nb > 0 ? nb : 1) * 8 + 8 + 15) & ~(size_t)15; }
 static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
     memset(&P, 0, sizeof(P));
     const int n = s->pr_nrec, nb = (n + PB - 1) / PB; const size_t H = (size_t)s->hmask + 1;
@@ -620,7 +638,7 @@ static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
     P.bed_on = (size_t)s->tid < h->d_runs.size() && h->has_runs[s->tid]; if(P.bed_on) { P.runs = h->d_runs[s->tid]; P.nruns = h->n_runs[s->tid]; }
     P.rd = s->d_prd.p; P.aidx = h->prep.perread ? s->d_aidx.p : nullptr; P.hnext = s->d_hnext.p; P.hmask = s->hmask;
     uint8_t *z = s->d_zero.p;
-    P.hkey = (uint64_t *)z; P.hhead = (int32_t *)(z + H * 8); P.cntA = (uint32_t *)(z + H * 12); P.cntS = P.cntA + (nb > 0 ? nb : 1); P.ticket = P.cntS + (nb > 0 ? nb : 1);
+    P.hent = (unsigned long long *)z; P.cntA = (uint32_t *)(z + H * 8); P.cntS = P.cntA + (nb > 0 ? nb : 1); P.ticket = P.cntS + (nb > 0 ? nb : 1);
     P.nblocks = nb; P.zero = z; P.zero_bytes = zero_bytes_for(s->hmask, nb);
     P.seg = s->d_seg_in.p; P.cap_seg = (int64_t)s->d_seg_in.cap;
     P.tiles = s->d_tiles.p; P.ntiles = s->ntiles; P.tile = s->tile;
@@ -638,8 +656,17 @@ int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
     int zgrid = (int)std::min<size_t>(2048, (zmax / 16 + PB - 1) / PB); if(zgrid < 1) zgrid = 1;
     hipLaunchKernelGGL(k_prep_zero, dim3(zgrid), dim3(PB), 0, st, M);
     if(total > 0) {
-        hipLaunchKernelGGL(k_prep_scan, dim3(total), dim3(PB), 0, st, M);
-        if(!h->prep.perread) hipLaunchKernelGGL(k_prep_segs, dim3(total), dim3(PB), 0, st, M);
+        int grid = total;
+#if PREP_XCD
+        {   // chunk j is served by the workgroups b with (b mod 8) mod n == j (chunk_of_block): enough of them for its nblocks tickets
+            int per8 = 1;
+            for(int j = 0; j < n; j++) { int xcds = 0; for(int x = 0; x < 8; x++) if(x % n == j) xcds++; if(xcds) per8 = std::max(per8, (M.P[j].nblocks + xcds - 1) / xcds); else per8 = std::max(per8, M.P[j].nblocks); }
+            grid = 8 * per8;
+        }
+        static_assert(MAXM <= 8, "chunk_of_block deals the chunks of a launch to 8 XCDs");
+#endif
+        hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), 0, st, M);
+        if(!h->prep.perread) hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -668,7 +695,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->n_segs = -1; s->n_reads = -1; s->read_bytes = 0;
     const size_t nn = (size_t)n + 1, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
-    s->hmask = pow2_at_least(nn + nn / 2) - 1;
+    s->hmask = pow2_at_least(nn + nn / 4) - 1;          // names are at most the records: load factor <= 0.8, ~0.4 for pairs; 2 MB for a 1 Mb chunk at 30x
     if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
        s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
     if(!s->b_site) {
