@@ -291,6 +291,7 @@ extern "C" int md_bench_open(md_dev *h, md_comm *comm, const int *slots, int n, 
             }
         }
     }
+    HIPCHK(hipDeviceSynchronize());      // the memsets above have run before the bench stream (non-blocking) or a peer touches the buffers
     if(comm && comm->ipc) {      // rank 0 exports its receive buffers, every other rank maps the two that are meant for it
         const int W = comm->world; std::vector<hipIpcMemHandle_t> mine((size_t)2 * W), all((size_t)2 * W * W);
         memset(mine.data(), 0, sizeof(hipIpcMemHandle_t) * mine.size());

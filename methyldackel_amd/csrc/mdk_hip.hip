@@ -693,6 +693,7 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     h->slots.resize(h->n_slots);
     if(h->d_status.need((size_t)h->n_slots) || h->h_status.need((size_t)h->n_slots)) return MDK_ERR_NOMEM;
     HIPCHK(hipMemset(h->d_status.p, 0, sizeof(SlotStatus) * (size_t)h->n_slots));
+    HIPCHK(hipDeviceSynchronize());                    // (the memset has run before any of the slots' non-blocking streams is used)
     memset(h->h_status.p, 0, sizeof(SlotStatus) * (size_t)h->n_slots);
     for(int i = 0; i < h->n_slots; i++) { Slot &s = h->slots[i]; s.index = i; s.d_total.p = h->d_status.p[i].total; s.d_err.p = &h->d_status.p[i].err; s.d_pcnt.p = &h->d_status.p[i].pc; s.h_st.p = &h->h_status.p[i]; }
     for(auto &s : h->slots) {
@@ -945,6 +946,7 @@ static int hist_reserve(md_dev *h, int rows) {
     if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(mbias histogram)", e);
     HIPCHK(hipMemset(d, 0, (size_t)cap * 16 * sizeof(uint32_t)));
     if(h->d_hist) { HIPCHK(hipMemcpy(d, h->d_hist, (size_t)h->hist_cap * 16 * sizeof(uint32_t), hipMemcpyDeviceToDevice)); (void)hipFree(h->d_hist); }
+    HIPCHK(hipDeviceSynchronize());                    // hipMemset of device memory returns before it has run, and the slots' streams do not wait for the null stream: a k_mbias launched now could add its counts first and have them wiped
     h->d_hist = d; h->hist_cap = cap;
     return 0;
 }
@@ -1024,7 +1026,7 @@ extern "C" int md_dev_mbias_reset(md_dev *h) {
     if(!h) return MDK_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipDeviceSynchronize());
-    if(h->d_hist) HIPCHK(hipMemset(h->d_hist, 0, (size_t)h->hist_cap * 16 * sizeof(uint32_t)));
+    if(h->d_hist) { HIPCHK(hipMemset(h->d_hist, 0, (size_t)h->hist_cap * 16 * sizeof(uint32_t))); HIPCHK(hipDeviceSynchronize()); }
     h->hist_len = 0;
     return 0;
 }

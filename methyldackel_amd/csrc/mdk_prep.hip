@@ -86,7 +86,7 @@ __device__ __forceinline__ int first_zero_byte(uint64_t x, int n) {        // in
     const uint64_t t = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
     return t ? (int)(__ffsll((unsigned long long)t) - 1) >> 3 : n;
 }
-__device__ AuxHit scan_aux(const uint8_t *s, const uint8_t *e) {
+__device__ __forceinline__ AuxHit scan_aux(const uint8_t *s, const uint8_t *e) {
     AuxHit A; A.nh = false; A.xg = false; A.nh_val = 0; A.xg1 = 0;
     while(e - s >= 3) {
         const uint64_t w = ld64(s);
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(PB) void k_prep_zero(const PrepMulti M) {
 
 __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     __shared__ uint32_t s_tk, wcnt[PB / 64], red[PB / 64];
+    __shared__ uint4 stage[4 * PB];                       // the workgroup's PrepReads on their way out (64 bytes each)
     const PrepParams &P = M.P[chunk_of_block(M)];
     if(threadIdx.x == 0) s_tk = atomicAdd(&P.ticket[0], 1u);
     __syncthreads();
@@ -342,28 +343,42 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     if(threadIdx.x == 0) __hip_atomic_store(&P.cntA[tk], total | CNT_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t base = tickets_before(P.cntA, tk, red);
     if((int)tk == P.nblocks - 1 && threadIdx.x == 0) P.cnt->n_adm = base + total;
-    if(!adm) return;
     const uint32_t a = base + rank;
-    if(P.aidx) P.aidx[a] = (uint32_t)i;
-    if(P.cfg.no_pairing || P.cfg.perread) { P.rd[a] = D; return; }
-    // name table: open addressing; an entry is (high half of the name's hash, the name's latest read), the name's earlier reads hang off
-    // hnext.  One 8-byte word per name, so an insertion touches one line of a 2 MB table: the first read of a name takes an empty entry
-    // with one compare-and-swap, a later one replaces the head with a second (file order is restored by whoever walks the chain).
-    const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)(a + 1u);
-    uint32_t sl = (uint32_t)h & P.hmask; int32_t before = -1;
-    for(;;) {
-        unsigned long long old = atomicCAS(&P.hent[sl], 0ull, mine);
-        if(old == 0ull) break;
-        if((old >> 32) == (key >> 32)) {
-            for(;;) { const unsigned long long seen = atomicCAS(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
-            before = (int32_t)(uint32_t)old - 1;
-            break;
+    if(adm) {
+        if(P.aidx) P.aidx[a] = (uint32_t)i;
+        if(!(P.cfg.no_pairing || P.cfg.perread)) {
+            // name table: open addressing; an entry is (high half of the name's hash, the name's latest read), the name's earlier reads hang
+            // off hnext.  One 8-byte word per name, so an insertion touches one line of a 2 MB table: the first read of a name takes an
+            // empty entry with one compare-and-swap, a later one replaces the head with a second (file order is restored by whoever
+            // walks the chain).
+            const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)(a + 1u);
+            uint32_t sl = (uint32_t)h & P.hmask; int32_t before = -1;
+            for(;;) {
+                unsigned long long old = atomicCAS(&P.hent[sl], 0ull, mine);
+                if(old == 0ull) break;
+                if((old >> 32) == (key >> 32)) {
+                    for(;;) { const unsigned long long seen = atomicCAS(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
+                    before = (int32_t)(uint32_t)old - 1;
+                    break;
+                }
+                sl = (sl + 1) & P.hmask;
+            }
+            D.slot = sl;
+            P.hnext[a] = before;
         }
-        sl = (sl + 1) & P.hmask;
+        // the PrepRead goes to the workgroup's stage in LDS first: written straight from the lanes, its four quads would leave in four store
+        // instructions of 16 bytes per 64 -- partial lines, which the memory side does not merge (WRITE_SIZE was 2.7x the bytes stored)
+        uint4 *st = stage + 4 * rank;
+        st[0] = make_uint4((uint32_t)D.pos, (uint32_t)D.rend, (uint32_t)D.ncig | (uint32_t)D.flag << 16, (uint32_t)D.strand | (uint32_t)D.nlen << 8);
+        st[1] = make_uint4(D.name[0], D.name[1], D.name[2], D.name[3]);
+        st[2] = make_uint4(D.seq_off, D.lq, D.cig_off, D.qn_off);
+        st[3] = make_uint4(D.cig[0], D.cig[1], D.cig[2], D.slot);
     }
-    D.slot = sl;
-    P.rd[a] = D;
-    P.hnext[a] = before;
+    __syncthreads();
+    {   // ... and from there to rd[base .. base + total) as whole lines
+        uint4 *out = (uint4 *)(P.rd + base);
+        for(uint32_t q = threadIdx.x; q < 4 * total; q += PB) out[q] = stage[q];
+    }
 }
 
 // what pairing looks at in another read of the name: quad 0 (pos rend ncig|flag strand|nlen) and quad 1 (the name's first 16 bytes) of its
