@@ -133,7 +133,8 @@ typedef struct {
  * device; a batch of host ranges only may leave it 0. */
 typedef struct { const uint8_t *ptr; uint64_t bytes; const uint32_t *d_rec_off; uint32_t n_records, rec_delta; } md_raw_range;
 /* The candidate records of ONE chunk: everything the region query [beg,end) of the chunk's contig returns (pos < end,
- * bam_endpos > beg), in file order.  rec_off[i] = offset of record i's block_size word in the concatenation of the ranges
+ * bam_endpos > beg), in file order.  Host ranges hold exactly those; a range in device memory is a run of whole BGZF members and may hold
+ * records of the neighbouring chunk or contig at its ends, which the preparation drops (it redoes the query per record).  rec_off[i] = offset of record i's block_size word in the concatenation of the ranges
  * (less than 4 GiB in total).  woff/wlen: the reference window the chunk fetches (extract.c:381), which the
  * conversion-efficiency filter classifies inside.  Host-owned; valid until the slot is waited for. */
 typedef struct {
