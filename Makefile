@@ -11,7 +11,7 @@ HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bi
 all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 
 HIPSRC := methyldackel_amd/csrc/mdk_hip.hip methyldackel_amd/csrc/mdk_comm.hip methyldackel_amd/csrc/mdk_prep.hip methyldackel_amd/csrc/mdk_inflate.hip
-$(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp methyldackel_amd/csrc/mdk_overlap_rule.h methyldackel_amd/csrc/mdk_inflate_core.h include/mdk_hip.h
+$(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp methyldackel_amd/csrc/mdk_overlap_rule.h methyldackel_amd/csrc/mdk_pair_rule.h methyldackel_amd/csrc/mdk_inflate_core.h include/mdk_hip.h
 	@mkdir -p $(B)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS) -Iinclude -Imethyldackel_amd/csrc -o $@ $(HIPSRC) -ldl
 

@@ -27,12 +27,12 @@
 // its window holds, sets a flag and the host prepares that chunk the slow way (mdk_pipeline.c) -- same segments either way.
 #include <algorithm>
 #include "mdk_hip_internal.hpp"
+#include "mdk_pair_rule.h"          // the pending/pairing machine of the overlap callbacks, shared with its host test
 
 #ifndef PB
 #define PB 256                       // threads per block of the per-record kernels
 #endif
 #define MAXG 16                      // records of one name a lane sorts in registers
-#define MAXLIVE 8                    // reads of one name alive in the pileup buffer at once
 #define CNT_READY 0x80000000u        // a workgroup's published count: this bit | count
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }       // the hardware reads at any alignment
@@ -396,61 +396,38 @@ __device__ __forceinline__ bool same_name_as(const PrepParams &P, const PrepRead
     for(int k = 16; k < x.nlen; k++) if(p[k] != q[k]) return false;
     return true;
 }
-__device__ __forceinline__ bool pairs(const uint32_t flag) { return (flag & 0x1) && !(flag & 12); }
-
-// Returns the read `a` is resolved against (-1: none) and whether `a` is the later of the two.
+// Returns the read `a` is resolved against (-1: none) and whether `a` is the later of the two (the rule: mdk_pair_rule.h).
 __device__ int32_t pair_of(const PrepParams &P, const uint32_t a, const PrepRead &ra, bool &second) {
     second = false;
-    if(!pairs(ra.flag)) return -1;                                  // such a read never becomes pending nor pairs (it still occupies the buffer for others)
+    if(!mdk_pairs(ra.flag)) return -1;                              // such a read never becomes pending nor pairs (it still occupies the buffer for others)
     // the name's chain: newest first; nearly always the read and one other
     const int32_t x1 = (int32_t)(uint32_t)P.hent[ra.slot] - 1;
     const int32_t x2 = x1 >= 0 ? P.hnext[x1] : -1;
     if(x2 < 0) return -1;                                           // alone under its name: pending for ever
     const int32_t x3 = P.hnext[x2];
     if(x3 < 0) {
-        // two reads: the rule in closed form.  f, s = the earlier and the later in the file; one of them is `a`.  f enters the buffer (unless
-        // it ends before the column being emitted) and becomes pending; s enters, sweeps f out if f ends before the start of the read
-        // admitted before s -- which erases the pending entry --, and otherwise is paired with it.
+        // two reads f < s, one of them `a`: the rule in closed form (mdk_pair_two)
         const int32_t f = x1 < x2 ? x1 : x2, sx = x1 < x2 ? x2 : x1, o = (uint32_t)f == a ? sx : f;
         const OtherRead O = other_read(P, o);
         const int32_t prev_f = f ? P.rd[f - 1].pos : 0, prev_s = P.rd[sx - 1].pos;
         if(!same_name_as(P, ra, O, o)) return -1;                   // two names with one hash
         const bool a_first = (uint32_t)f == a;
-        const int32_t rend_f = a_first ? ra.rend : O.rend, rend_s = a_first ? O.rend : ra.rend;
-        const bool in_f = f == 0 ? (P.tid > 0 || rend_f > 0) : rend_f > prev_f;
-        const bool in_s = rend_s > prev_s;
-        if(!in_f || !in_s || !pairs(O.flag) || rend_f < prev_s) return -1;
-        second = !a_first;
-        return o;
+        return mdk_pair_two(P.tid, a, f, sx, a_first ? ra.flag : O.flag, a_first ? ra.rend : O.rend, prev_f,
+                            a_first ? O.flag : ra.flag, a_first ? O.rend : ra.rend, prev_s, second);
     }
     int32_t idx[MAXG]; int k = 0;
     for(int32_t x = x1; x >= 0; x = P.hnext[x]) { if(k == MAXG) { atomicExch(&P.cnt->fallback, 1u); return -1; } idx[k++] = x; }
     for(int i = 1; i < k; i++) { const int32_t v = idx[i]; int q = i - 1; while(q >= 0 && idx[q] > v) { idx[q + 1] = idx[q]; q--; } idx[q + 1] = v; }
-    int32_t pending = -1, mate = -1; int32_t live[MAXLIVE]; int nlive = 0;
+    MdkPairState S; mdk_pair_init(S);
     for(int i = 0; i < k; i++) {
         const int32_t x = idx[i];
         int32_t rend = ra.rend; uint32_t flag = ra.flag;
         if((uint32_t)x != a) { const OtherRead O = other_read(P, x); if(!same_name_as(P, ra, O, x)) continue; rend = O.rend; flag = O.flag; }      // (continue: another name with the same hash)
-        const bool first = x == 0;
-        const int32_t prev_pos = first ? 0 : P.rd[x - 1].pos;
-        const bool inserted = first ? (P.tid > 0 || rend > 0) : (rend > prev_pos);
-        if(!inserted) continue;
-        bool evicted = false; int w = 0;
-        for(int q = 0; q < nlive; q++) { if(!first && live[q] < prev_pos) evicted = true; else live[w++] = live[q]; }
-        nlive = w;
-        if(evicted) pending = -1;
-        if(pairs(flag)) {
-            if(pending < 0) pending = x;
-            else {
-                if((uint32_t)pending == a) { mate = x; second = false; }
-                else if((uint32_t)x == a) { mate = pending; second = true; }
-                pending = -1;
-            }
-        }
-        if(nlive == MAXLIVE) { atomicExch(&P.cnt->fallback, 1u); return -1; }
-        live[nlive++] = rend;
+        mdk_pair_step(S, P.tid, a, x, flag, rend, x == 0 ? 0 : P.rd[x - 1].pos);
+        if(S.overflow) { atomicExch(&P.cnt->fallback, 1u); return -1; }
     }
-    return mate;
+    second = S.second;
+    return S.mate;
 }
 
 // gapless runs of a CIGAR, one at a time (calculate_positions, overlaps.c:27-52)
@@ -776,7 +753,7 @@ MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s) {
     const PrepCounters &c = s->h_st.p->pc;
     if(c.malformed) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "malformed BAM record in the chunk"); return MDK_ERR_ARG; }
     if(c.strand0) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "Can't determine the strand of a read!"); return MDK_ERR_STRAND0; }
-    if(c.fallback) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "a read name with more than %d records or %d live reads: this chunk needs the host preparation", MAXG, MAXLIVE); return MDK_ERR_PREP_HOST; }
+    if(c.fallback) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "a read name with more than %d records or %d live reads: this chunk needs the host preparation", MAXG, MDK_MAXLIVE); return MDK_ERR_PREP_HOST; }
     s->n_reads = (int)c.n_adm; s->n_segs = (int)c.n_segs; s->read_bytes = c.algo_bytes;
     if((size_t)c.n_segs > s->d_seg_in.cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
