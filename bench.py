@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--large-sample-length", type=int, default=128_000_000, help="bp of the second, larger end-to-end sample (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="the step is the pileup alone over resident segments (round 2's loop; for profiling that kernel)")
+    ap.add_argument("--no-exchange", action="store_true", help="N ranks without the gather of site buffers to rank 0 (what the run falls back to when no communicator can be made)")
     ap.add_argument("--devices", default="", help="comma list: physical device of each local rank (tests: two ranks on one GPU)")
     ap.add_argument("--data-dir", default="", help="keep the synthetic inputs here and reuse them on the next run (profiling passes)")
     args = ap.parse_args()
@@ -172,20 +173,24 @@ def main():
     slots = list(range(R))
     slot_arr = (C.c_int * R)(*slots)
 
-    comm = C.c_void_p()
+    comm = C.c_void_p(); exchange_off = None
     if world > 1:
         idbuf = torch.zeros(mdk.COMM_ID_BYTES, dtype=torch.uint8)
+        have_id = torch.tensor([1], dtype=torch.int64)
         if rank == 0:
             raw = C.create_string_buffer(mdk.COMM_ID_BYTES)
-            rc = L.md_comm_unique_id(raw)
-            assert rc == 0, L.md_dev_last_error()
-            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-        dist.broadcast(idbuf, src=0)
+            if L.md_comm_unique_id(raw) == 0:
+                idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+            else:                                                     # librccl could not be loaded: the ranks run without the exchange (below)
+                have_id[0] = 0; log(f"[bench] no RCCL id: {(L.md_dev_last_error() or b'?').decode(errors='replace')}")
+        dist.broadcast(idbuf, src=0); dist.broadcast(have_id, src=0)
         # ranks that share a physical device cannot be RCCL peers: they exchange through an IPC mapping of rank 0's receive buffers
         phys = torch.tensor([dev_index], dtype=torch.int64); allphys = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(allphys, phys)
         shared = len({int(x.item()) for x in allphys}) < world
-        if shared:
+        if args.no_exchange:
+            cb = None; rc = -2
+        elif shared:
             def oob_allgather(_ctx, send, recv, nbytes):
                 t = torch.frombuffer(bytearray(C.string_at(send, nbytes)), dtype=torch.uint8).clone(); outs = [torch.zeros(nbytes, dtype=torch.uint8) for _ in range(world)]
                 dist.all_gather(outs, t)
@@ -193,16 +198,37 @@ def main():
                 return 0
             cb = mdk.md_comm_oob_fn(oob_allgather)
             rc = L.md_comm_open_rank_shared(dev.h, rank, world, cb, None, C.byref(comm))
+        elif int(have_id.item()) == 0:
+            cb = None; rc = -2
         else:
             cb = None
             rc = L.md_comm_open_rank(dev.h, rank, world, bytes(idbuf.numpy().tobytes()), C.byref(comm))
-        assert rc == 0, L.md_dev_last_error()
+        # every rank must hold a communicator before anyone enters a collective on it: if one could not be made (no usable RCCL, a device
+        # the library refuses), all ranks go on WITHOUT the exchange -- the interval-sharded work itself needs none -- and the line says so
+        comm_err = "" if rc == 0 else "--no-exchange" if args.no_exchange else (L.md_dev_last_error() or b"?").decode(errors="replace")
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            log(f"[bench] rank {rank}: no exchange between the ranks ({comm_err or 'another rank could not create its communicator'})")
+            if rc == 0:
+                L.md_comm_close(comm)
+            comm = C.c_void_p()
+            exchange_off = comm_err or "a rank could not create its communicator"
         joined = torch.tensor([1], dtype=torch.int64); dist.all_reduce(joined, op=dist.ReduceOp.SUM)
-        n_gpus = int(joined.item())                                   # ranks that hold a communicator
+        n_gpus = int(joined.item())                                   # ranks taking part
     else:
         n_gpus, shared = 1, False
     bench = C.c_void_p()
-    rc = L.md_bench_open(dev.h, comm if world > 1 else None, slot_arr, R, GROUP, C.byref(bench))
+    use_comm = world > 1 and bool(comm.value)
+    rc = L.md_bench_open(dev.h, comm if use_comm else None, slot_arr, R, GROUP, C.byref(bench))
+    if world > 1:
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64); dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and use_comm:                          # (the size agreement over the communicator failed somewhere: once more without it)
+            exchange_off = (L.md_dev_last_error() or b"?").decode(errors="replace") if rc else "md_bench_open failed on another rank"
+            log(f"[bench] rank {rank}: no exchange between the ranks ({exchange_off})")
+            if rc == 0:
+                L.md_bench_close(bench)
+            bench = C.c_void_p(); use_comm = False
+            rc = L.md_bench_open(dev.h, None, slot_arr, R, GROUP, C.byref(bench))
     assert rc == 0, L.md_dev_last_error()
     assert L.md_bench_set_prep(bench, 0 if args.kernel_only else 1) == 0, L.md_dev_last_error()
 
@@ -378,7 +404,8 @@ def main():
         }
         if world > 1:
             result["exchange"] = {"exchanges": exchanges, "bytes_per_exchange_per_rank": bytes_per_exchange,
-                                  "transport": "device copies into an IPC mapping of rank 0's buffers (ranks sharing one physical GPU)" if shared else "ncclSend/ncclRecv group (libmdk_hip md_comm_gather)"}
+                                  "transport": f"NONE -- the ranks ran without the gather of site buffers to rank 0: {exchange_off}" if exchange_off else
+                                               "device copies into an IPC mapping of rank 0's buffers (ranks sharing one physical GPU)" if shared else "ncclSend/ncclRecv group (libmdk_hip md_comm_gather)"}
         if streamed:
             result["streamed"] = streamed
         if dense:

@@ -34,3 +34,10 @@ def test_two_devices_exchange_over_rccl():
     j = run_bench()
     assert j["n_gpus"] == 2 and j["exchange"]["exchanges"] > 0
     assert "ncclSend" in j["exchange"]["transport"]
+
+
+def test_two_ranks_without_the_exchange():
+    """what the run falls back to when a communicator cannot be made: the ranks still do their interval-sharded work, and the line says so"""
+    j = run_bench("--devices", "0,0", "--no-exchange")
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    assert j["exchange"]["exchanges"] == 0 and j["exchange"]["transport"].startswith("NONE")
