@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 3, GPU call: what the name-table compare-and-swaps cost k_prep_scan (a build that stores instead: timing only, wrong results)
+# round 3, GPU call: what the name-table compare-and-swaps cost k_prep_scan (a build that stores instead, -DPREP_EXP_NOATOMIC: timing only, wrong
+# results).  Kept as the record of how profiles/r03aa_prep_noatomic.txt was made: the switch was removed from csrc/mdk_prep.hip afterwards.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp PREP_BENCH_FAST=1
 for v in "" noatomic; do
   if [ -n "$v" ]; then export MDK_BUILD_DIR=$R/methyldackel_amd/_exp_$v; else unset MDK_BUILD_DIR; fi
