@@ -357,7 +357,8 @@ def main():
     # used only when that summary's dispatches are this run's kernels; raw counter bytes and the calibrated estimate are kept apart
     traffic, traffic_info = None, None
     try:
-        cand = sorted((REPO / "profiles").glob("r03*_rocprofv3_pmc_summary.json"))
+        # the round's final summary (rNNfin_*) if there is one, else the last one of the latest round by name
+        cand = sorted((REPO / "profiles").glob("r[0-9][0-9]*_rocprofv3_pmc_summary.json"), key=lambda q: (q.name[:3], "fin" in q.name.split("_")[0], q.name))
         prof = json.load(open(cand[-1]))
         k = prof["families"].get(dominant)
         if k and not extra and not args.synth_args and args.length == 1_000_000 and k.get("chunks_per_launch") == GROUP:
