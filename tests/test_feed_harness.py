@@ -45,6 +45,9 @@ CONFIGS = [
     (1, 12, 8, {"MDK_DEVICE_INFLATE_ONLY": "1", "MDK_GPU_PIECE_MB": "0.25", "MDK_SLAB_CAP": "2"}),        # ... every piece after the header on the "device"
     (1, 40, 8, {"MDK_DEVICE_INFLATE_ONLY": "1", "MDK_GPU_PIECE_MB": "0.25"}),
     (0, 12, 8, {"MDK_SLAB_CAP": "2", "MDK_INFLATE_TEAMS": "4"}),                                            # host teams only, delivering out of order
+    (1, 3, 1, {"MDK_GPU_PIECE_MB": "0.5"}),                                                                # -@ 1: one host thread next to the device teams
+    (1, 20, 2, {"MDK_DEVICE_INFLATE_ONLY": "1", "MDK_GPU_PIECE_MB": "1", "MDK_SLAB_CAP": "2"}),
+    (0, 0, 1, {}),
 ]
 
 
