@@ -67,7 +67,7 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
         sync();
         const uint32_t n_tok = S.n_tok, beg = S.batch_beg, end = S.batch_end, err = S.err, fin = S.finished;
         taken = S.words_used;
-        if(err || taken > n_words + 3) { if(lane == 0) atomicCAS(P.status, 0u, (err ? err : (uint32_t)INF_E_INPUT) | ((uint32_t)m << 8)); return; }
+        if(err || taken > n_words + 3 || (fin && inf_overran_input(taken, S.bits_left, skip, M.in_len))) { if(lane == 0) atomicCAS(P.status, 0u, (err ? err : (uint32_t)INF_E_INPUT) | ((uint32_t)m << 8)); return; }
         // (2) far matches: one lane per token; every byte comes from global memory
         bool far = false;
         InfToken t; t.dst = 0; t.len_dist = 0;

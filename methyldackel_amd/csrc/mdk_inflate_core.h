@@ -73,7 +73,7 @@ struct InfShared {
     uint8_t  win[INF_WIN];                 // ring of output bytes: byte p of the member lives in win[p & (INF_WIN-1)]
     InfToken tok[INF_MAX_TOK];
     // written by the decoder at the end of a batch, read by all lanes after the barrier
-    uint32_t n_tok, batch_beg, batch_end, words_used, finished, err;
+    uint32_t n_tok, batch_beg, batch_end, words_used, bits_left, finished, err;      // bits_left: fetched (words_used words) but not consumed, less the prefetched word
 };
 
 // The decoder's registers between batches.  `bb` holds the next `cnt` bits of the stream, least significant first; 32 <= cnt <= 63
@@ -140,18 +140,20 @@ MDK_HD uint32_t inf_dist_entry(int sym) {
 
 // Canonical Huffman code of `n` symbols with lengths lens[] (0 = unused, <= 15) -> two-level decode table.
 // kind 0: literal/length alphabet (T = inf_lit_t), 1: distance alphabet, 2: code-length alphabet (both T = inf_dist_t).
-// An over-subscribed set of lengths is an error; an incomplete one leaves unassigned entries (legal for a distance code with a
-// single symbol, RFC 1951 3.2.7; zlib-made streams are otherwise complete, and an unassigned entry is reported when the stream
-// reaches it).
+// An over-subscribed set of lengths is an error.  An incomplete one is an error too, as in zlib (inftrees.c: "incomplete set"), unless
+// it has no code at all or a single code of length 1 (RFC 1951 3.2.7: one distance code) -- a stream zlib rejects is rejected here
+// (tools/inflate_emu.cpp --fuzz); `strict` = 0 is for the fixed block's distance code, whose 30 five-bit codes leave two unassigned.
 template <typename T>
-MDK_HD int inf_build_t(const uint8_t *lens, int n, int tb, T *tab, int cap, int kind, uint16_t *sorted /* [n] scratch */) {
+MDK_HD int inf_build_t(const uint8_t *lens, int n, int tb, T *tab, int cap, int kind, uint16_t *sorted /* [n] scratch */, int strict) {
     uint16_t count[16], offs[16];
     const uint32_t bad = kind == 0 ? INF_L_BAD : INF_D_BAD;
     for(int l = 0; l < 16; l++) count[l] = 0;
     for(int i = 0; i < n; i++) count[lens[i]]++;
     count[0] = 0;
     int left = 1;
-    for(int l = 1; l < 16; l++) { left <<= 1; left -= count[l]; if(left < 0) return -1; }
+    int maxl_used = 0;
+    for(int l = 1; l < 16; l++) { left <<= 1; left -= count[l]; if(left < 0) return -1; if(count[l]) maxl_used = l; }
+    if(strict && left > 0 && maxl_used != 0 && (kind == 2 || maxl_used != 1)) return -3;
     offs[1] = 0;
     for(int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
     int total = 0;
@@ -196,8 +198,8 @@ MDK_HD int inf_build_t(const uint8_t *lens, int n, int tb, T *tab, int cap, int 
     }
     return 0;
 }
-MDK_HDN int inf_build_lit(const uint8_t *lens, int n, inf_lit_t *tab, uint16_t *sorted) { return inf_build_t<inf_lit_t>(lens, n, INF_LIT_TB, tab, INF_LIT_CAP, 0, sorted); }
-MDK_HDN int inf_build_dist(const uint8_t *lens, int n, int tb, inf_dist_t *tab, int kind, uint16_t *sorted) { return inf_build_t<inf_dist_t>(lens, n, tb, tab, INF_DIST_CAP, kind, sorted); }
+MDK_HDN int inf_build_lit(const uint8_t *lens, int n, inf_lit_t *tab, uint16_t *sorted) { return inf_build_t<inf_lit_t>(lens, n, INF_LIT_TB, tab, INF_LIT_CAP, 0, sorted, 1); }
+MDK_HDN int inf_build_dist(const uint8_t *lens, int n, int tb, inf_dist_t *tab, int kind, uint16_t *sorted, int strict = 1) { return inf_build_t<inf_dist_t>(lens, n, tb, tab, INF_DIST_CAP, kind, sorted, strict); }
 
 // Block header (RFC 1951 3.2.3-3.2.7); for a dynamic block also the code lengths and both tables.  The ring must hold the
 // whole header (a dynamic header is at most 14 + 19*3 + 316*14 bits < 160 words).
@@ -221,7 +223,7 @@ MDK_HD int inf_block_header_body(InfDec &d, InfShared &S) {
         for(int k = 280; k < 288; k++) lens[k] = 8;
         if(inf_build_lit(lens, 288, S.lit, sorted)) return INF_E_LITTABLE;
         for(int k = 0; k < 30; k++) lens[k] = 5;
-        if(inf_build_dist(lens, 30, INF_DIST_TB, S.dist, 1, sorted)) return INF_E_DISTTABLE;
+        if(inf_build_dist(lens, 30, INF_DIST_TB, S.dist, 1, sorted, 0)) return INF_E_DISTTABLE;
         d.in_block = 1;
         return INF_OK;
     }
@@ -318,7 +320,13 @@ MDK_HD void inf_decode_batch(InfDec &d, InfShared &S) {
     d.pos = pos;
     if(!err && pos > d.out_len) err = INF_E_OVERRUN;
     if(!err && finished && pos != d.out_len) err = INF_E_SHORT;
-    S.n_tok = ntok; S.batch_beg = beg; S.batch_end = pos; S.words_used = d.widx; S.finished = finished; S.err = err;
+    S.n_tok = ntok; S.batch_beg = beg; S.batch_end = pos; S.words_used = d.widx; S.bits_left = d.cnt; S.finished = finished; S.err = err;
+}
+
+// Has a finished member consumed more bits than its stream holds?  (Words past the stream read as zero, and zeros can decode: seven of
+// them are the end-of-block code of a fixed block.  zlib calls that stream truncated; so do we.)
+MDK_HD bool inf_overran_input(uint32_t words_used, uint32_t bits_left, uint32_t skip_bytes, uint32_t in_len) {
+    return 32ull * words_used - bits_left - 32ull > 8ull * ((uint64_t)skip_bytes + in_len);
 }
 
 // ---- the parts every lane runs (bodies only; the barriers between them are the caller's) ----

@@ -18,6 +18,13 @@ def emu():
     return EMU
 
 
+def test_damaged_streams_are_rejected_or_equal_zlib(emu):
+    """bits flipped, bytes overwritten, streams cut short, wrong announced sizes: the decoder comes back, writes nothing beyond the announced
+    size, and accepts only what zlib accepts, with the same bytes"""
+    r = subprocess.run([str(emu), "--fuzz", "150000"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 FAILURES" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_selftest_streams(emu):
     r = subprocess.run([str(emu), "--selftest"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

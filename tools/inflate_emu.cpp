@@ -4,7 +4,7 @@
 // re-stated here with the same per-lane bodies and the kernel's barriers turned into loop boundaries.
 //   build: g++ -O2 -o tools/_build/inflate_emu tools/inflate_emu.cpp -Imethyldackel_amd/csrc -lz
 //   run:   inflate_emu file.bam [max_members]      (exit 0 = every member identical to zlib)
-// Also: inflate_emu --selftest  runs deflate streams made with zlib at every level/strategy (stored, fixed, dynamic blocks,
+// Also: inflate_emu --fuzz N runs N damaged streams (see fuzz()); inflate_emu --selftest  runs deflate streams made with zlib at every level/strategy (stored, fixed, dynamic blocks,
 // long matches, distance-1 runs, maximum-distance matches, empty input).
 #include <stdint.h>
 #include <stdio.h>
@@ -25,14 +25,15 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
     for(; filled < INF_IN_WORDS; filled += 64) for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); }
     inf_dec_init(d, S.in, skip, out_len);
     uint32_t taken = 3;
-    for(;;) {
+    for(uint64_t turns = 0;; turns++) {
+        if(turns > 200000) return 103;                                   // a batch must consume input or produce output: 64 KiB cannot take this long
         while(filled + 64 <= taken + INF_IN_WORDS) { for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); } filled += 64; }
         inf_decode_batch<false>(d, S);
         (*n_batches)++;
         const uint32_t n_tok = S.n_tok, beg = S.batch_beg, end = S.batch_end, err = S.err, fin = S.finished;
         taken = S.words_used;
         if(err) return (int)err;
-        if(taken > n_words + 3) return INF_E_INPUT;
+        if(taken > n_words + 3 || (fin && inf_overran_input(taken, S.bits_left, skip, in_len))) return INF_E_INPUT;
         if(end - beg > INF_BATCH_BYTES || n_tok > INF_MAX_TOK) return 100;
         bool far[64];
         for(uint32_t lane = 0; lane < 64; lane++) {
@@ -73,7 +74,7 @@ static int check_stream(const std::vector<uint8_t> &raw, int level, int strategy
     deflate(&zs, Z_FINISH); const uint32_t clen = (uint32_t)zs.total_out; deflateEnd(&zs);
     std::vector<uint8_t> got(raw.size() + 8, 0xEE); uint64_t a = 0, b = 0, c = 0;
     const int rc = emu_member(comp.data(), (uint64_t)lead, clen, got.data(), (uint32_t)raw.size(), &a, &b, &c);
-    if(rc || memcmp(got.data(), raw.data(), raw.size())) { fprintf(stderr, "selftest FAILED: %s level %d strategy %d size %zu: rc %d\n", what, level, strategy, raw.size(), rc); return 1; }
+    if(rc || (raw.size() && memcmp(got.data(), raw.data(), raw.size()))) { fprintf(stderr, "selftest FAILED: %s level %d strategy %d size %zu: rc %d\n", what, level, strategy, raw.size(), rc); return 1; }
     return 0;
 }
 static int selftest(void) {
@@ -103,8 +104,49 @@ static int selftest(void) {
     return bad ? 1 : 0;
 }
 
+// Damaged input: valid deflate streams with bits flipped, bytes overwritten, the stream cut short or the announced output size wrong.  The
+// decoder must come back (it is bounded by its input and by the announced size), must not write a byte beyond that size, and, when it
+// reports success, must have produced what zlib produces from the same damaged stream (a flip in a literal's bits is still a valid
+// stream).  On the GPU the same code runs with nobody to catch a wild pointer, so this is where it is tried.
+static int fuzz(long iters) {
+    uint64_t s = 0x9e3779b97f4a7c15ull; auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    long ok = 0, rejected = 0, bad = 0;
+    for(long it = 0; it < iters; it++) {
+        const size_t size = 1 + rnd() % (it % 7 == 0 ? 65536 : 6000); std::vector<uint8_t> raw(size);
+        const int kind = (int)(rnd() % 4);
+        for(size_t i = 0; i < size; i++) raw[i] = kind == 0 ? (uint8_t)rnd() : kind == 1 ? "ACGT"[rnd() & 3] : kind == 2 ? (uint8_t)((i % 97) < 60 ? 'q' : rnd() % 11) : (uint8_t)(i >= 700 && (rnd() & 3) ? raw[i - 700] : rnd());
+        std::vector<uint8_t> comp(compressBound(size) + 64 + 16, 0); z_stream zs; memset(&zs, 0, sizeof zs);
+        const int levels[4] = {0, 1, 6, 9}, strats[3] = {Z_DEFAULT_STRATEGY, Z_FIXED, Z_HUFFMAN_ONLY};
+        deflateInit2(&zs, levels[rnd() % 4], Z_DEFLATED, -15, 8, strats[rnd() % 3]);
+        const int lead = (int)(rnd() % 4);
+        zs.next_in = raw.data(); zs.avail_in = (uInt)size; zs.next_out = comp.data() + lead; zs.avail_out = (uInt)(comp.size() - lead - 16);
+        deflate(&zs, Z_FINISH); uint32_t clen = (uint32_t)zs.total_out; deflateEnd(&zs);
+        uint32_t out_len = (uint32_t)size;
+        switch(rnd() % 5) {                                                      // the damage
+        case 0: for(int k = 1 + (int)(rnd() % 4); k > 0; k--) comp[lead + rnd() % clen] ^= (uint8_t)(1u << (rnd() & 7)); break;
+        case 1: for(int k = 1 + (int)(rnd() % 6); k > 0; k--) comp[lead + rnd() % clen] = (uint8_t)rnd(); break;
+        case 2: clen = (uint32_t)(rnd() % clen); break;                          // cut short
+        case 3: out_len = (uint32_t)(rnd() & 1 ? rnd() % (size + 1) : size + 1 + rnd() % 300); if(out_len > 65536) out_len = 65536; break;      // wrong ISIZE
+        default: comp[lead + rnd() % (clen < 12 ? clen : 12)] ^= (uint8_t)rnd(); break;      // the block header
+        }
+        std::vector<uint8_t> got((size_t)out_len + 64, 0xEE); uint64_t a = 0, b = 0, c = 0;
+        const int rc = emu_member(comp.data(), (uint64_t)lead, clen, got.data(), out_len, &a, &b, &c);
+        for(size_t i = out_len; i < got.size(); i++) if(got[i] != 0xEE) { fprintf(stderr, "fuzz %ld: a byte was written beyond the announced size (rc %d)\n", it, rc); bad++; break; }
+        if(rc == 0 && out_len) {                                                 // accepted: then zlib accepts it too, with the same bytes
+            std::vector<uint8_t> ref((size_t)out_len + 8); z_stream zi; memset(&zi, 0, sizeof zi); inflateInit2(&zi, -15);
+            zi.next_in = comp.data() + lead; zi.avail_in = clen; zi.next_out = ref.data(); zi.avail_out = out_len;
+            const int zr = inflate(&zi, Z_FINISH); const size_t zout = zi.total_out; inflateEnd(&zi);
+            if(zr != Z_STREAM_END || zout != out_len || memcmp(ref.data(), got.data(), out_len)) { fprintf(stderr, "fuzz %ld: accepted a stream zlib does not inflate to the same %u bytes (zlib rc %d, %zu bytes)\n", it, out_len, zr, zout); bad++; }
+            ok++;
+        } else rejected++;
+    }
+    printf("fuzz: %ld damaged streams, %ld rejected, %ld accepted and equal to zlib, %ld FAILURES\n", iters, rejected, ok, bad);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
     if(argc > 1 && !strcmp(argv[1], "--selftest")) return selftest();
+    if(argc > 2 && !strcmp(argv[1], "--fuzz")) return fuzz(atol(argv[2]));
     if(argc < 2) { fprintf(stderr, "usage: inflate_emu file.bam [max_members] | --selftest\n"); return 2; }
     FILE *f = fopen(argv[1], "rb"); if(!f) { perror(argv[1]); return 2; }
     fseek(f, 0, SEEK_END); size_t n = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
