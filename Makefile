@@ -11,7 +11,7 @@ HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bi
 all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 
 HIPSRC := methyldackel_amd/csrc/mdk_hip.hip methyldackel_amd/csrc/mdk_comm.hip methyldackel_amd/csrc/mdk_prep.hip methyldackel_amd/csrc/mdk_inflate.hip
-$(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp methyldackel_amd/csrc/mdk_overlap_rule.h methyldackel_amd/csrc/mdk_pair_rule.h methyldackel_amd/csrc/mdk_inflate_core.h include/mdk_hip.h
+$(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp methyldackel_amd/csrc/mdk_overlap_rule.h methyldackel_amd/csrc/mdk_pair_rule.h methyldackel_amd/csrc/mdk_inflate_core.h methyldackel_amd/csrc/mdk_crc32_core.h include/mdk_hip.h
 	@mkdir -p $(B)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS) -Iinclude -Imethyldackel_amd/csrc -o $@ $(HIPSRC) -ldl
 
@@ -31,7 +31,7 @@ tools/_build/feed_harness: tools/feed_harness.c methyldackel_amd/csrc/host/mdk_i
 tools/_build/pin_probe: tools/pin_probe.hip
 	@mkdir -p tools/_build
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ tools/pin_probe.hip
-tools/_build/inflate_emu: tools/inflate_emu.cpp methyldackel_amd/csrc/mdk_inflate_core.h
+tools/_build/inflate_emu: tools/inflate_emu.cpp methyldackel_amd/csrc/mdk_inflate_core.h methyldackel_amd/csrc/mdk_crc32_core.h
 	@mkdir -p tools/_build
 	g++ -O2 -Wall -o $@ tools/inflate_emu.cpp -Imethyldackel_amd/csrc -lz
 tools/_build/piece_bench: tools/piece_bench.c include/mdk_hip.h $(B)/libmdk_hip.so

@@ -50,6 +50,8 @@ typedef struct {
     int32_t absoluteBounds[16];          /* --nOT/--nOB/--nCTOT/--nCTOB, same indexing */
     int32_t tile;                        /* reference positions per LDS tile; 0 = library default */
     int32_t n_slots;                     /* batches that may be in flight at once; 0 = 2 (double buffering) */
+    int32_t n_streams;                   /* 0 = a stream per slot; k > 0 = k streams, slots 8j .. 8j+7 work on stream j % k: the slots of one
+                                            md_dev_launch_group can share a stream -- creating one costs the runtime ~5 ms */
 } md_dev_cfg;
 
 /* The device sees every admitted alignment as one or more gapless SEGMENTS: the CIGAR is expanded on the host
@@ -169,12 +171,12 @@ int  md_dev_debug_segments(md_dev *h, int slot, md_seg *out, int64_t cap, int64_
  * What the reference gets from htslib inside sam_itr_next (common.c:413): bgzf_read_block's inflate of each <= 64 KiB member and
  * bam_read1's framing of the records in it.  The host hands over a PIECE of the file -- a run of whole BGZF members, compressed,
  * as they lie in the file -- with a table of its members (found by walking the 18-byte BGZF headers: BSIZE, and ISIZE from each
- * member's trailer); the device inflates every member (one wavefront each), walks the records of every member from its first
+ * member's trailer); the device inflates every member (one wavefront each), checks its CRC32, walks the records of every member from its first
  * byte, and leaves: the inflated bytes, a table with the offset of every record, and per member a DIGEST (first/last record,
  * extent of the read ends, coordinate order inside) from which the host applies the reference's chunk schedule
  * (extract.c:325-350) without ever seeing a record.  Inflated bytes and record table stay in device memory; a chunk's records
  * are then handed to md_dev_upload_raw as device-resident ranges (md_raw_range.d_rec_off != NULL). */
-typedef struct { uint64_t in_off; uint32_t in_len, out_len; uint64_t out_off; } md_inf_member;   /* deflate stream at comp + in_off, in_len bytes; ISIZE; where its bytes go (running sum of ISIZE) */
+typedef struct { uint64_t in_off; uint32_t in_len, out_len; uint64_t out_off; uint32_t crc32, reserved; } md_inf_member;   /* deflate stream at comp + in_off, in_len bytes; ISIZE; where its bytes go (running sum of ISIZE); the CRC32 of the member's trailer, checked on the device as htslib's bgzf_read_block checks it */
 typedef struct {
     uint32_t n_rec, first_rec;           /* records in the member; index of its first record in the piece's record table */
     int32_t tid0, pos0, tidN, posN;      /* first and last record */
@@ -198,6 +200,7 @@ int  md_piece_read(md_piece *p, uint64_t off, uint64_t bytes, uint8_t *dst);
 int  md_piece_read_records(md_piece *p, uint32_t first, uint32_t n, uint32_t *dst);
 /* the kernels alone, re-run on the resident piece and timed with HIP events on its stream */
 int  md_piece_bench(md_piece *p, int iters, float *ms_inflate, float *ms_walk);
+int  md_piece_bench_crc(md_piece *p, int iters, float *ms_crc);      /* k_crc32 alone on the resident piece (and its verdict) */
 
 typedef struct {
     float ms_total;      /* one launch bracketed by HIP events on the slot's stream (includes lone-launch dispatch latency), mean over iters */
@@ -212,6 +215,9 @@ int  md_dev_count(void);                                       /* number of HIP 
  * input headers are still being read) */
 int  md_dev_warm(int device);
 int  md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out);
+/* room for the references of contigs 0..n-1, so that a thread may upload the next contig (md_dev_set_reference and what goes with it) while
+ * others work on slots of contigs already uploaded; without it md_dev_set_reference must not run next to other calls on the handle */
+int  md_dev_reserve_contigs(md_dev *h, int32_t n);
 void md_dev_close(md_dev *h);
 const char *md_dev_last_error(void);
 int  md_dev_tile(const md_dev *h);
@@ -272,6 +278,10 @@ int  md_dev_submit(md_dev *h, int slot, const md_read_batch *b);
 int  md_dev_launch_group(md_dev *h, const int *slots, int n);
 int  md_dev_group_max(void);
 int  md_dev_download(md_dev *h, int slot, md_sites *out);
+/* md_dev_download for the slots of ONE md_dev_launch_group, with one wait and one round of copies for all of them instead of one per slot:
+ * rc[i] is what md_dev_download(slots[i]) would have returned (0, MDK_ERR_PREP_HOST, MDK_ERR_STRAND0, ...) and out[i] its sites.  Returns 0 when
+ * the collection itself worked, whatever the rc[i]. */
+int  md_dev_download_group(md_dev *h, const int *slots, int n, md_sites *out, int *rc);
 int  md_dev_sync(md_dev *h);
 
 /* Make the kernels of `slot` write their result into caller-provided DEVICE buffers (e.g. torch tensors that are
@@ -363,10 +373,19 @@ void  md_host_set_pinned(int on);
 void  md_host_free(void *p);
 /* what registering staging blocks has cost so far (seconds on the uploading threads, calls, bytes) */
 void  md_host_profile(double *seconds, uint64_t *calls, uint64_t *bytes);
+/* MDK_HOST_PROFILE=1: seconds and calls the host threads have spent inside the library per site (waiting for a slot, allocating, queueing
+ * copies, launching, waiting for results, copying them back, ...), as one line of text */
+int   md_dev_profile_text(char *buf, int cap);
 /* a staging block is registered with the runtime (hipHostRegister) the first time an upload reads from it; a thread that has just FILLED
  * one may do that itself once a device is open (h: that device), so that the thread submitting uploads does not have to.  ptr: anywhere
  * inside the block */
 void  md_host_register(md_dev *h, const void *ptr);
+/* register every staging block that is not registered yet, with `threads` threads; returns how many there were.  For the moment the device
+ * comes up: the blocks filled until then would otherwise be registered one by one by the thread that uploads from them */
+int   md_host_register_all(md_dev *h, int threads);
+/* for a process about to END: give the pages of every staging block back to the system, from `threads` threads at once (contents are lost,
+ * the blocks stay allocated and must not be uploaded from again) -- the kernel otherwise tears them down on one core at exit */
+void  md_host_trim(int threads);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ class MdkError(RuntimeError):
 class md_dev_cfg(C.Structure):
     _fields_ = [("keepCpG", C.c_int32), ("keepCHG", C.c_int32), ("keepCHH", C.c_int32), ("minPhred", C.c_int32),
                 ("minOppositeDepth", C.c_int32), ("bounds", C.c_int32 * 16), ("absoluteBounds", C.c_int32 * 16),
-                ("tile", C.c_int32), ("n_slots", C.c_int32)]
+                ("tile", C.c_int32), ("n_slots", C.c_int32), ("n_streams", C.c_int32)]
 
 
 class md_seg(C.Structure):
@@ -66,7 +66,7 @@ class md_raw_batch(C.Structure):
 
 
 class md_inf_member(C.Structure):
-    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("out_len", C.c_uint32), ("out_off", C.c_uint64)]
+    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("out_len", C.c_uint32), ("out_off", C.c_uint64), ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class md_inf_digest(C.Structure):
@@ -141,12 +141,12 @@ md_comm_oob_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ui
 
 HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
-               "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_rank_shared", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_result_header", "md_comm_result_send", "md_comm_result_recv", "md_dev_pci_bus_id",
-               "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned", "md_host_profile", "md_host_register",
+               "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_dev_download_group", "md_dev_reserve_contigs", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_rank_shared", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_result_header", "md_comm_result_send", "md_comm_result_recv", "md_dev_pci_bus_id",
+               "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned", "md_host_profile", "md_dev_profile_text", "md_host_register", "md_host_register_all", "md_host_trim",
                "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep", "md_dev_bench_prep_rotate", "md_bench_set_prep",
                "md_dev_mbias_submit", "md_dev_mbias_submit_raw", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
                "md_dev_perread_submit", "md_dev_perread_download", "md_dev_perread_submit_raw", "md_dev_perread_download_raw", "md_dev_read_raw",
-               "md_piece_create", "md_piece_destroy", "md_piece_submit", "md_piece_wait", "md_piece_read", "md_piece_read_records", "md_piece_bench"]
+               "md_piece_create", "md_piece_destroy", "md_piece_submit", "md_piece_wait", "md_piece_read", "md_piece_read_records", "md_piece_bench", "md_piece_bench_crc"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_try_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len", "mdk_plan_regions", "mdk_plan_set_prep", "mdk_plan_set_hold", "mdk_plan_prep_cfg", "mdk_plan_host_prepare",

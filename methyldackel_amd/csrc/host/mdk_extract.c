@@ -1,13 +1,16 @@
 /*
- * mdk_extract.c -- host side of the MI355X `MethylDackel extract` path.
+ * mdk_extract.c -- extract_main, the drop-in entry point of the MI355X `MethylDackel extract` path (extract.c:706 in the reference).
  *
  * Division of labour:
- *   host  : BGZF inflate + BAM record framing (mdk_io.c), read admission (the flag/tag/MAPQ tests of
- *           filter_func, common.c:416-444), strand determination (getStrand, common.c:84-116), the
- *           qname pairing that htslib's constructor/destructor callbacks perform (overlaps.c:121-147),
- *           packing into the SoA batch of include/mdk_hip.h, the reference's chunk schedule
- *           (extract.c:325-350, common.c:466-493) and the text post-pass (extract.c:443-510, 39-99).
- *   device: everything per base -- trimming, overlap resolution, context classification, counting.
+ *   host  : options and inputs (mdk_plan.c), reading the file and part of the BGZF inflate (mdk_io.c), the reference's chunk
+ *           schedule (extract.c:325-350, common.c:466-493) applied to member digests and record tables (mdk_pipeline.c), and the
+ *           text post-pass (extract.c:443-510, 39-99; mdk_emit.c).  Per record or per base the host does nothing, except for a
+ *           chunk the device hands back (MDK_ERR_PREP_HOST) and under MDK_HOST_PREP=1.
+ *   device: the rest of the BGZF inflate and the record framing (k_inflate, k_walk), read admission (filter_func, common.c:416-444),
+ *           strand (getStrand, common.c:84-116), read-name pairing (overlaps.c:121-147), CIGAR expansion, trimming, overlap
+ *           resolution, context classification, counting.
+ * Three threads move the chunks here: this one uploads and launches them in groups, a second collects the results and hands them
+ * to the emitter, a third uploads the contigs' references ahead of the chunks that need them.
  * There is no CPU implementation of the per-base work in this library.
  */
 #include "mdk_plan.h"
@@ -51,15 +54,104 @@ MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_ope
 
 /* Chunks travel to the device in GROUPS of up to MDK_GROUP: a 1 Mb chunk alone is fewer than two workgroups per CU and pays every
  * launch boundary itself, so whatever the reader has ready when a group is opened (at least one chunk, at most eight) is uploaded
- * into the group's slots and prepared and piled up with one launch per kernel (md_dev_launch_group); while that runs, the next
- * group is assembled, then the finished one is collected chunk by chunk in schedule order and handed to the emitter.  The
- * reference's unit of work is the chunk (extract.c:325-350); here it is the unit of scheduling and of output only. */
+ * into the group's slots and prepared and piled up with one launch per kernel (md_dev_launch_group).  MDK_NGROUPS groups are in
+ * flight, each on its own stream: while one computes, the next is uploaded by this thread and the one before is collected by the
+ * collector thread (one wait and one round of copies per group, md_dev_download_group) and handed to the emitter in schedule
+ * order.  The reference's unit of work is the chunk (extract.c:325-350); here it is the unit of scheduling and of output only. */
 #define MDK_GROUP 8
-typedef struct { mdk_chunk ch[MDK_GROUP]; int slot[MDK_GROUP]; int n, launched[MDK_GROUP]; } cgroup;
+#define MDK_NGROUPS 3
+enum { G_FREE = 0, G_FILL, G_LAUNCHED };
+typedef struct { mdk_chunk ch[MDK_GROUP]; int slot[MDK_GROUP]; int n, launched[MDK_GROUP], state; } cgroup;
+typedef struct {
+    mdk_plan *p; md_dev *dev; emitter *em; cgroup G[MDK_NGROUPS];
+    pthread_mutex_t mu; pthread_cond_t cv;
+    int ret, up_done;                    /* (mu) first error; the uploader has launched its last group */
+    uint64_t n_up, n_col;                /* (mu) groups launched / collected: group k lives in G[k % MDK_NGROUPS] */
+    int *ref_state; int ref_quit, ref_done; int32_t ref_t0, ref_t1;        /* (mu) per contig: 0 not uploaded yet, 1 resident, < 0 the error its upload met; ref_done: the thread has left */
+    double w_down, w_emit; int n_host_prep;
+} xpipe;
+static void xp_fail(xpipe *X, int ret) { pthread_mutex_lock(&X->mu); if(!X->ret) X->ret = ret; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu); }
+
+/* the contigs' bases (and BED runs, mappability tracks) go to the device ahead of the chunks, in schedule order */
+static void *refs_main(void *arg) {
+    xpipe *X = arg; mdk_plan *p = X->p; int32_t t;
+    for(t = X->ref_t0; t < X->ref_t1 && t < p->bam->n_targets; t++) {
+        int rc = 1, q;
+        pthread_mutex_lock(&X->mu); q = X->ref_quit || X->ret; pthread_mutex_unlock(&X->mu);
+        if(q) break;
+        if(p->fa_of_tid[t] >= 0) { rc = mdk_plan_ensure_reference(p, X->dev, t); rc = rc ? (rc < 0 ? rc : -1) : 1; }
+        pthread_mutex_lock(&X->mu); X->ref_state[t] = rc; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
+    }
+    pthread_mutex_lock(&X->mu); X->ref_done = 1; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
+    return NULL;
+}
+static int ref_wait(xpipe *X, int32_t tid) {
+    int rc;
+    pthread_mutex_lock(&X->mu);
+    while(!X->ref_state[tid] && !X->ret && !X->ref_done) pthread_cond_wait(&X->cv, &X->mu);
+    rc = X->ref_state[tid];
+    pthread_mutex_unlock(&X->mu);
+    if(!rc && !X->ret) { rc = mdk_plan_ensure_reference(X->p, X->dev, tid); return rc; }       /* a contig the thread did not have on its list (it has left: nobody else uploads) */
+    return rc == 1 ? 0 : rc ? rc : -1;
+}
+
+/* collects the launched groups in order: results to the emitter, the group back to the uploader */
+static void *collector_main(void *arg) {
+    xpipe *X = arg; mdk_plan *p = X->p; md_dev *dev = X->dev; int i;
+    for(;;) {
+        cgroup *g; int ls[MDK_GROUP], li[MDK_GROUP], nl = 0, rcs[MDK_GROUP], rc = 0, bad = 0; md_sites st[MDK_GROUP], sites[MDK_GROUP]; double ta;
+        pthread_mutex_lock(&X->mu);
+        while(X->n_col == X->n_up && !X->up_done && !X->ret) pthread_cond_wait(&X->cv, &X->mu);
+        if(X->ret || X->n_col == X->n_up) { pthread_mutex_unlock(&X->mu); break; }
+        g = &X->G[X->n_col % MDK_NGROUPS];
+        pthread_mutex_unlock(&X->mu);
+        memset(sites, 0, sizeof(sites));
+        for(i = 0; i < g->n; i++) if(g->launched[i]) { ls[nl] = g->slot[i]; li[nl] = i; nl++; }
+        ta = now_s();
+        if(nl) rc = md_dev_download_group(dev, ls, nl, st, rcs);
+        if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); xp_fail(X, MDK_RC_DEVICE); break; }
+        for(i = 0; i < nl && !bad; i++) {
+            const int k = li[i];
+            rc = rcs[i];
+            if(rc == MDK_ERR_PREP_HOST) {          /* a read name the device preparation does not handle: this chunk the slow way */
+                static int told = 0;
+                if(!told) { told = 1; fprintf(stderr, "[mdk] note: a chunk holds a read name with more records than the device preparation handles (secondary/supplementary-rich or amplicon-like data); such chunks are prepared on the host, which is slower\n"); }
+                rc = mdk_plan_host_prepare_from(p, &g->ch[k], dev, g->slot[k]);
+                if(!rc) rc = md_dev_submit(dev, g->slot[k], &g->ch[k].batch);
+                if(!rc) rc = md_dev_download(dev, g->slot[k], &st[i]);
+                X->n_host_prep++;
+            }
+            if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
+            if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); xp_fail(X, MDK_RC_DEVICE); bad = 1; break; }
+            sites[k] = st[i];
+        }
+        X->w_down += now_s() - ta;
+        if(bad) break;
+        ta = now_s();
+        for(i = 0; i < g->n; i++) if(emitter_push(X->em, &g->ch[i], &sites[i])) { xp_fail(X, X->em->failed ? MDK_RC_OUTPUT : MDK_RC_DEVICE); bad = 1; break; }
+        X->w_emit += now_s() - ta;
+        if(bad) break;
+        pthread_mutex_lock(&X->mu); g->n = 0; g->state = G_FREE; X->n_col++; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
+    }
+    return NULL;
+}
+
+/* the slabs the host teams filled while the runtime was still starting: registered with it now, next to the uploader instead of by it */
+static void *prereg_main(void *arg) { md_dev *dev = arg; (void)md_host_register_all(dev, 4); return NULL; }
+
+/* opening the device on its own thread while the host pipeline already inflates: the handle, the room for the contigs, the
+ * preparation's options */
+typedef struct { devopen_t d; mdk_plan *p; } xopen;
+static void *xopen_main(void *arg) {
+    xopen *o = arg; devopen_main(&o->d);
+    if(!o->d.rc) (void)md_dev_reserve_contigs(o->d.dev, o->p->bam->n_targets);
+    if(!o->d.rc && o->p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(o->p, &pc); md_dev_set_prep(o->d.dev, &pc); }
+    return NULL;
+}
 
 int extract_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; cgroup *G = NULL; int rc, ret = 0, more = 1, cur = 0, i; devopen_t dop; pthread_t dth; int dth_ok; emitter em;
-    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_down = 0, w_emit = 0, ta; int n_host_prep = 0; uint64_t n_groups = 0, n_chunks = 0;
+    mdk_plan *p = NULL; md_dev *dev = NULL; xpipe *X = NULL; int rc, ret = 0, more = 1, i, g_i; xopen dop; pthread_t dth, cth, rth, preg; int dth_ok, cth_ok = 0, rth_ok = 0, preg_ok = 0; emitter em;
+    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_group = 0, w_ref = 0, ta; uint64_t n_chunks = 0; int32_t ref_t0, ref_t1;
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] entered at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
     { int rk = 0, wd = 1, m = ranks_from_env(&rk, &wd); if(m < 0) return -1; if(m > 0) return extract_ranks(argc, argv, rk, wd); }       /* one process per GPU (mdk_ranks.c) */
     if(argc > 2) hip_warm_up();
@@ -67,29 +159,45 @@ int extract_main(int argc, char *argv[]) {
     t_open = now_s() - T0;
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] resident after plan open %.0f MB\n", rss_mb(0));
     if(rc != 0 || !p) return rc;
-    /* HIP initialisation takes a few hundred ms: do it while the host pipeline already inflates and packs */
-    memset(&dop, 0, sizeof(dop));
-    mdk_plan_dev_cfg(p, &dop.cfg);
-    dop.cfg.n_slots = 2 * MDK_GROUP;
-    if(getenv("MDK_DEVICE")) dop.device = atoi(getenv("MDK_DEVICE"));
+    ref_t0 = p->o.region ? (int32_t)p->g_tid : 0; ref_t1 = (p->o.region && p->g_end) ? ref_t0 + 1 : p->bam->n_targets;       /* (before the reader moves the schedule) */
+    /* HIP initialisation takes 0.1-0.2 s: it runs while the host pipeline already inflates */
+    memset(&dop, 0, sizeof(dop)); dop.p = p;
+    mdk_plan_dev_cfg(p, &dop.d.cfg);
+    dop.d.cfg.n_slots = MDK_NGROUPS * MDK_GROUP; dop.d.cfg.n_streams = MDK_NGROUPS;
+    if(getenv("MDK_DEVICE")) dop.d.device = atoi(getenv("MDK_DEVICE"));
     /* the per-record work of a chunk (admission, strand, name pairing, CIGAR expansion) runs on the device; MDK_HOST_PREP=1 keeps
      * it on the host's chunk workers (the round-1 arrangement, and what a chunk the device gives up on falls back to) */
     if(!getenv("MDK_HOST_PREP")) mdk_plan_set_prep(p, 1);
-    mdk_plan_set_hold(p, 2 * MDK_GROUP + 1);
-    dth_ok = pthread_create(&dth, NULL, devopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
-    if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
-    if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
+    mdk_plan_set_hold(p, MDK_NGROUPS * MDK_GROUP + 2);
+    dth_ok = pthread_create(&dth, NULL, xopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
+    if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.d.dev) md_dev_close(dop.d.dev); mdk_plan_close(p); return -5; }
+    if(dth_ok) pthread_join(dth, NULL); else xopen_main(&dop);
     t_dev = now_s() - T0;
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] resident at device ready %.0f MB\n", rss_mb(0));
-    dev = dop.dev;
-    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
-    if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); mdk_plan_attach_device(p, dev); }      /* from here on the device inflates pieces of the file too */
-    G = calloc(2, sizeof(cgroup));
-    if(!G || emitter_start(&em, p, emit_threads(p))) { free(G); mdk_plan_detach_device(p); md_dev_close(dev); mdk_plan_close(p); return -5; }
-    for(i = 0; i < MDK_GROUP; i++) { G[0].slot[i] = i; G[1].slot[i] = MDK_GROUP + i; }
-    while(more || G[0].n || G[1].n) {
-        cgroup *g = &G[cur], *o = &G[cur ^ 1];
-        /* open a group: the first chunk is waited for, the others are taken only if they are ready now */
+    dev = dop.d.dev;
+    if(dop.d.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.d.device, dop.d.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(p->dev_prep) mdk_plan_attach_device(p, dev);      /* from here on the device inflates pieces of the file too */
+    X = calloc(1, sizeof(*X));
+    if(X) X->ref_state = calloc((size_t)p->bam->n_targets + 1, sizeof(int));
+    if(!X || !X->ref_state || emitter_start(&em, p, emit_threads(p))) { if(X) free(X->ref_state); free(X); mdk_plan_detach_device(p); md_dev_close(dev); mdk_plan_close(p); return -5; }
+    X->p = p; X->dev = dev; X->em = &em; X->ref_t0 = ref_t0; X->ref_t1 = ref_t1; pthread_mutex_init(&X->mu, NULL); pthread_cond_init(&X->cv, NULL);
+    for(g_i = 0; g_i < MDK_NGROUPS; g_i++) for(i = 0; i < MDK_GROUP; i++) X->G[g_i].slot[i] = g_i * MDK_GROUP + i;
+    preg_ok = !getenv("MDK_NO_PREREG") && pthread_create(&preg, NULL, prereg_main, dev) == 0;
+    rth_ok = pthread_create(&rth, NULL, refs_main, X) == 0;
+    cth_ok = pthread_create(&cth, NULL, collector_main, X) == 0;
+    if(!rth_ok || !cth_ok) { fprintf(stderr, "[mdk] cannot create a thread\n"); ret = -5; more = 0; }
+    while(more && !ret) {
+        cgroup *g;
+        /* the next group, once the collector has given it back */
+        ta = now_s();
+        pthread_mutex_lock(&X->mu);
+        g = &X->G[X->n_up % MDK_NGROUPS];
+        while(g->state != G_FREE && !X->ret) pthread_cond_wait(&X->cv, &X->mu);
+        ret = X->ret; g->state = G_FILL;
+        pthread_mutex_unlock(&X->mu);
+        w_group += now_s() - ta;
+        if(ret) break;
+        /* the first chunk is waited for, the others are taken only if they are ready now */
         g->n = 0;
         while(more && g->n < MDK_GROUP) {
             mdk_chunk *c = &g->ch[g->n];
@@ -101,8 +209,8 @@ int extract_main(int argc, char *argv[]) {
             if(rc == 0) { more = 0; break; }
             g->launched[g->n] = 0;
             if(!c->skipped) {
+                ta = now_s(); rc = ref_wait(X, c->tid); w_ref += now_s() - ta;
                 ta = now_s();
-                rc = mdk_plan_ensure_reference(p, dev, c->tid);
                 if(!rc) rc = c->prep ? md_dev_upload_raw(dev, g->slot[g->n], &c->raw) : md_dev_upload(dev, g->slot[g->n], &c->batch);
                 w_sub += now_s() - ta;
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
@@ -114,41 +222,37 @@ int extract_main(int argc, char *argv[]) {
         {   /* one launch per kernel for the group's chunks */
             int ls[MDK_GROUP], nl = 0;
             for(i = 0; i < g->n; i++) if(g->launched[i]) ls[nl++] = g->slot[i];
-            if(nl) { ta = now_s(); rc = md_dev_launch_group(dev, ls, nl); w_sub += now_s() - ta; n_groups++; if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; } }
+            if(nl) { ta = now_s(); rc = md_dev_launch_group(dev, ls, nl); w_sub += now_s() - ta; if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; } }
         }
-        /* collect the group before it, in schedule order */
-        for(i = 0; i < o->n && !ret; i++) {
-            md_sites sites; memset(&sites, 0, sizeof(sites));
-            if(o->launched[i]) {
-                ta = now_s();
-                rc = md_dev_download(dev, o->slot[i], &sites);
-                if(rc == MDK_ERR_PREP_HOST) {          /* a read name the device preparation does not handle: this chunk the slow way */
-                    rc = mdk_plan_host_prepare_from(p, &o->ch[i], dev, o->slot[i]);
-                    if(!rc) rc = md_dev_submit(dev, o->slot[i], &o->ch[i].batch);
-                    if(!rc) rc = md_dev_download(dev, o->slot[i], &sites);
-                    n_host_prep++;
-                }
-                w_down += now_s() - ta;
-                if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
-                if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
-            }
-            ta = now_s();
-            if(emitter_push(&em, &o->ch[i], &sites)) { ret = em.failed ? MDK_RC_OUTPUT : MDK_RC_DEVICE; break; }
-            w_emit += now_s() - ta;
-        }
-        o->n = 0;
-        if(ret) break;
-        cur ^= 1;
+        pthread_mutex_lock(&X->mu);
+        if(g->n) { g->state = G_LAUNCHED; X->n_up++; } else g->state = G_FREE;
+        pthread_cond_broadcast(&X->cv);
+        pthread_mutex_unlock(&X->mu);
     }
-    { double tw = now_s(); emitter_stop(&em); w_emit += now_s() - tw; }
+    if(ret) xp_fail(X, ret);
+    pthread_mutex_lock(&X->mu); X->up_done = 1; X->ref_quit = 1; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
+    if(cth_ok) pthread_join(cth, NULL);
+    if(rth_ok) pthread_join(rth, NULL);
+    if(preg_ok) pthread_join(preg, NULL);
+    if(!ret) ret = X->ret;
+    { double tw = now_s(); emitter_stop(&em); X->w_emit += now_s() - tw; }
     if(em.failed && !ret) ret = MDK_RC_OUTPUT;
-    if(getenv("MDK_HOST_PROFILE")) { double rs = 0; uint64_t rc2 = 0, rb = 0; md_host_profile(&rs, &rc2, &rb); fprintf(stderr, "[mdk main] staging blocks registered: %" PRIu64 " (%.0f MB) in %.3fs; %" PRIu64 " chunks in %" PRIu64 " group launches\n", rc2, rb / 1048576.0, rs, n_chunks, n_groups); }
-    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, loop: wait-for-chunk %.3fs submit %.3fs download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_sub, w_down, w_emit, now_s() - T0, n_host_prep);
+    if(getenv("MDK_HOST_PROFILE")) { double rs = 0; uint64_t rc2 = 0, rb = 0; md_host_profile(&rs, &rc2, &rb); fprintf(stderr, "[mdk main] staging blocks registered: %" PRIu64 " (%.0f MB) in %.3fs; %" PRIu64 " chunks in %" PRIu64 " group launches\n", rc2, rb / 1048576.0, rs, n_chunks, X->n_up); }
+    if(getenv("MDK_HOST_PROFILE")) { char pt[1024]; if(md_dev_profile_text(pt, sizeof(pt)) == 0) fprintf(stderr, "[mdk hip] host threads inside the device library: %s\n", pt); }
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, uploader: wait-for-chunk %.3fs wait-for-reference %.3fs wait-for-group %.3fs submit %.3fs; collector: download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_ref, w_group, w_sub, X->w_down, X->w_emit, now_s() - T0, X->n_host_prep);
     if(ret == 0) mdk_plan_finish(p);
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f (resident %.0f MB, of which file-backed/shared %.0f MB)\n", ts.tv_sec + 1e-9 * ts.tv_nsec, rss_mb(0), rss_mb(1)); }
-    if(fast_exit_wanted()) leave_fast(ret);
+    if(fast_exit_wanted()) {      /* the process ends here (the `MethylDackel` command): its GBs of staging memory go back from many threads, not from one core at exit */
+        double tt = now_s();
+        if(!getenv("MDK_NO_TRIM")) {
+            pipeline_stop(p); mdk_bam_stop(p->bam); (void)md_dev_sync(dev);       /* nobody fills or uploads from a staging block any more (after a whole file they have all left already) */
+            md_host_trim(16);
+        }
+        if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] staging memory given back in %.3fs (resident now %.0f MB)\n", now_s() - tt, rss_mb(0));
+        leave_fast(ret);
+    }
     { double tc = now_s(), td;
-      free(G);
+      pthread_mutex_destroy(&X->mu); pthread_cond_destroy(&X->cv); free(X->ref_state); free(X);
       mdk_plan_detach_device(p);
       md_dev_close(dev); td = now_s();
       mdk_plan_close(p);

@@ -18,7 +18,7 @@ static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, 
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-typedef struct { const uint8_t *in; uint32_t in_len; uint8_t *out; uint32_t out_len; int th; size_t sum0; uint32_t n_sum; int ok;
+typedef struct { const uint8_t *in; uint32_t in_len; uint8_t *out; uint32_t out_len, crc; int th; size_t sum0; uint32_t n_sum; int ok;      /* crc: the CRC32 of the member's trailer */
                  int32_t tid0, pos0, tidN, posN, min_endp, max_endp; int sorted; } blk_t;
 typedef struct { mdk_rsum *v; size_t n, cap; } sumbuf;
 typedef struct { blk_t *blk; int n; int next; int failed; int n_th; int next_th; const uint8_t *base; sumbuf sb[64]; pthread_mutex_t mu; } inflate_job;
@@ -51,7 +51,7 @@ static void note_records(blk_t *b, sumbuf *sb, const uint8_t *base) {
 
 /* libdeflate inflates a BGZF member two to three times faster than zlib (it is what htslib itself uses when it is built with
  * it).  The image ships the runtime library without its header, so it is bound by name; without it zlib does the work. */
-typedef struct { void *(*alloc)(void); int (*run)(void *, const void *, size_t, void *, size_t, size_t *); void (*release)(void *); } ldeflate_t;
+typedef struct { void *(*alloc)(void); int (*run)(void *, const void *, size_t, void *, size_t, size_t *); void (*release)(void *); uint32_t (*crc)(uint32_t, const void *, size_t); } ldeflate_t;
 static const ldeflate_t *ldeflate(void) {
     static ldeflate_t L; static int state = 0; static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
     pthread_mutex_lock(&mu);
@@ -62,13 +62,17 @@ static const ldeflate_t *ldeflate(void) {
             L.alloc = (void *(*)(void))dlsym(so, "libdeflate_alloc_decompressor");
             L.run = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(so, "libdeflate_deflate_decompress");
             L.release = (void (*)(void *))dlsym(so, "libdeflate_free_decompressor");
-            if(L.alloc && L.run && L.release) state = 1;
+            L.crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(so, "libdeflate_crc32");
+            if(L.alloc && L.run && L.release && L.crc) state = 1;
         }
     }
     pthread_mutex_unlock(&mu);
     return state == 1 ? &L : NULL;
 }
 
+/* what htslib's bgzf_read_block checks behind sam_itr_next (common.c:413): the CRC32 of the inflated bytes against the member's trailer
+ * (ISIZE is checked by the inflate itself: it must produce exactly that many bytes).  MDK_NO_CRC=1 skips it (timing comparisons). */
+static int crc_wanted(void) { static int w = -1; if(w < 0) w = getenv("MDK_NO_CRC") ? 0 : 1; return w; }
 static void *inflate_worker(void *arg) {
     inflate_job *job = arg; z_stream zs; int inited = 0, me; const ldeflate_t *LD = ldeflate(); void *ld = LD ? LD->alloc() : NULL;
     pthread_mutex_lock(&job->mu); me = job->next_th++; pthread_mutex_unlock(&job->mu);
@@ -83,6 +87,7 @@ static void *inflate_worker(void *arg) {
             if(ld) {
                 size_t got = 0;
                 if(LD->run(ld, b->in, b->in_len, b->out, b->out_len, &got) != 0 || got != b->out_len) { job->failed = 1; b->ok = 0; continue; }
+                if(crc_wanted() && LD->crc(0, b->out, b->out_len) != b->crc) { job->failed = 2; b->ok = 0; continue; }
                 note_records(b, &job->sb[me], job->base);
                 continue;
             }
@@ -90,6 +95,7 @@ static void *inflate_worker(void *arg) {
             else inflateReset(&zs);
             zs.next_in = (Bytef *)b->in; zs.avail_in = b->in_len; zs.next_out = b->out; zs.avail_out = b->out_len;
             if(inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) { job->failed = 1; b->ok = 0; continue; }
+            if(crc_wanted() && (uint32_t)crc32(0L, b->out, b->out_len) != b->crc) { job->failed = 2; b->ok = 0; continue; }
             note_records(b, &job->sb[me], job->base);
         }
     }
@@ -137,7 +143,7 @@ void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
 }
 
 /* a piece of the file: the complete BGZF members found in the read window, with the compressed bytes they live in */
-typedef struct { uint8_t *cbuf; blk_t *blk; int nb; size_t total; uint64_t seq; } piece;
+typedef struct { uint8_t *cbuf; blk_t *blk; int nb; size_t total; uint64_t seq; size_t map_beg, map_end; } piece;      /* map_beg/end: its bytes in the mapped file */
 
 /* under io_mu: read CCHUNK more compressed bytes, list every complete member; the unfinished tail moves to a fresh window.
  * status: 0 a piece was produced, 1 end of file, <0 error */
@@ -164,7 +170,7 @@ static int next_piece(mdk_bam *b, piece *pc, size_t want) {
         if(off + bsize > b->clen) break;
         isize = le32(p + bsize - 4);
         if(nb == mb) { mb = mb ? mb * 2 : 1024; blk = realloc(blk, sizeof(blk_t) * mb); if(!blk) return -1; }
-        blk[nb].in = p + 12 + xlen; blk[nb].in_len = bsize - 12 - xlen - 8; blk[nb].out = NULL; blk[nb].out_len = isize; nb++;
+        blk[nb].in = p + 12 + xlen; blk[nb].in_len = bsize - 12 - xlen - 8; blk[nb].out = NULL; blk[nb].out_len = isize; blk[nb].crc = le32(p + bsize - 8); nb++;
         total += isize; off += bsize;
     }
     if(nb == 0) {
@@ -173,7 +179,7 @@ static int next_piece(mdk_bam *b, piece *pc, size_t want) {
         if(b->map) { b->cbuf = NULL; b->clen = 0; }
         snprintf(b->err, sizeof(b->err), "BGZF member larger than the read window"); return -2;
     }
-    if(b->map) { b->map_pos += off; b->cbuf = NULL; b->clen = 0; if(b->map_pos < b->map_len) b->file_eof = 0; }
+    if(b->map) { pc->map_beg = b->map_pos; pc->map_end = b->map_pos + off; b->map_pos += off; b->cbuf = NULL; b->clen = 0; if(b->map_pos < b->map_len) b->file_eof = 0; }
     else {   /* the piece keeps this window; the tail that belongs to the next member starts a new one */
         size_t left = b->clen - off; uint8_t *nw = malloc(left + GCHUNK + 64);
         if(!nw) { free(blk); return -1; }
@@ -224,7 +230,7 @@ static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status)
             }
         }
         for(i = 0; i < 64; i++) free(job.sb[i].v);
-        if(job.failed) { pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "BGZF inflate failed (corrupt file?)"); pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, s); *status = -2; return NULL; }
+        if(job.failed) { pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), job.failed == 2 ? "a BGZF member fails its CRC32 check (corrupt file)" : "BGZF inflate failed (corrupt file?)"); pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, s); *status = -2; return NULL; }
     }
     return s;
 }
@@ -256,7 +262,7 @@ static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *stat
     memcpy(b->gpu_stage[team], c0, span);
     mt = malloc(sizeof(*mt) * (size_t)nb);
     if(!mt) { mdk_slab_unref(b, s); *status = -1; return NULL; }
-    for(i = 0; i < nb; i++) { mt[i].in_off = (uint64_t)(blk[i].in - c0); mt[i].in_len = blk[i].in_len; mt[i].out_len = blk[i].out_len; mt[i].out_off = o; o += blk[i].out_len; }
+    for(i = 0; i < nb; i++) { mt[i].in_off = (uint64_t)(blk[i].in - c0); mt[i].in_len = blk[i].in_len; mt[i].out_len = blk[i].out_len; mt[i].out_off = o; mt[i].crc32 = blk[i].crc; mt[i].reserved = 0; o += blk[i].out_len; }
     if(md_piece_submit(s->piece, b->gpu_stage[team], span, mt, nb) || md_piece_wait(s->piece, &info)) {
         pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu);
         free(mt); mdk_slab_unref(b, s); *status = -2; return NULL;
@@ -307,7 +313,12 @@ static void *inflater_main(void *arg) {
         st = next_piece(b, &pc, gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK);
         if(st == 0) pc.seq = b->next_seq++; else b->io_status = st;
         pthread_mutex_unlock(&b->io_mu);
-        if(st == 0) { s = gt >= 0 ? inflate_piece_device(b, &pc, gt, &st) : inflate_piece(b, &pc, b->team_threads, &st); free(pc.cbuf); free(pc.blk); }
+        if(st == 0) {
+            s = gt >= 0 ? inflate_piece_device(b, &pc, gt, &st) : inflate_piece(b, &pc, b->team_threads, &st); free(pc.cbuf); free(pc.blk);
+            /* the piece's pages of the file mapping are done with (inflated, or copied to the device's staging block): unmapped here, piece by piece
+             * and on many threads, they are not left for the kernel to walk on one core when the process ends (they stay in the page cache) */
+            if(b->map && pc.map_end > pc.map_beg) { const size_t a = (pc.map_beg + 4095) & ~(size_t)4095, e = pc.map_end & ~(size_t)4095; if(e > a) (void)madvise((void *)(b->map + a), e - a, MADV_DONTNEED); }
+        }
         if(s && gt < 0 && b->dev) md_host_register(b->dev, s->buf);          /* the device is up: the slab this team has just filled is made known to the runtime here, not by the thread that uploads from it */
         if(s) {
             if(deliver(b, s, pc.seq)) break;
@@ -344,6 +355,7 @@ static void inflaters_stop(mdk_bam *b) {
     if(b->gpu_started) { for(i = 0; i < b->n_gpu_teams; i++) pthread_join(b->gpu_th[i], NULL); b->gpu_started = 0; }
     b->inf_started = 0;
 }
+void mdk_bam_stop(mdk_bam *b) { if(b) inflaters_stop(b); }
 int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     int k;
     if(!b || !dev || b->dev) return -1;

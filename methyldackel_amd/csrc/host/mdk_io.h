@@ -98,6 +98,8 @@ void mdk_bam_detach_device(mdk_bam *b);
  * slab (use mdk_bam_peek_sum), or at the end of the data; <0 error.  mdk_bam_dev_advance consumes that member. */
 int mdk_bam_at_device(mdk_bam *b, mdk_slab **s, int *mi);
 void mdk_bam_dev_advance(mdk_bam *b);
+/* end the inflate teams (host and device) and wait for them; nothing is freed.  A seek starts them again. */
+void mdk_bam_stop(mdk_bam *b);
 /* make every blocked or future read return end-of-data (used to stop a reader thread) */
 void mdk_bam_abort(mdk_bam *b);
 /* 1 = record available, 0 = end of file, <0 = error (b->err) */

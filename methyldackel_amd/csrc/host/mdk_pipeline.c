@@ -567,7 +567,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
 /* admission + packing + pairing + segments of one chunk */
 static int worker_process(mdk_plan *p, pslot *sl) {
     batchbuf *b = &sl->bb; mdk_chunk *c = &sl->c; size_t off; mdk_rec r; double t0 = now_s(), t1, t2;
-    int g; size_t bytes = 0;
+    int g; size_t bytes = 0; int32_t rl;
     b->n = 0; b->blob_len = 0; b->qn_len = 0; b->cig_len = 0; b->n_seg = 0; b->algo_bytes = 0;
     /* one reservation per chunk instead of growing (the blob is staging memory, which is expensive to allocate): the
      * payload, names and CIGARs of the admitted reads are all smaller than the raw records they come from */
@@ -579,7 +579,12 @@ static int worker_process(mdk_plan *p, pslot *sl) {
             uint32_t len; memcpy(&len, base + off, 4);
             if(mdk_rec_parse(base + off + 4, len, &r) != 0) return -2;
             off += 4 + (size_t)len;
-            if(admit_and_pack(p, b, &r, cigar_ref_len(&r), sl->win, sl->woff, sl->wlen, c->beg, c->end) < 0) return -5;
+            rl = cigar_ref_len(&r);
+            /* the region query of the chunk (sam_itr_queryi behind extract.c:379: this contig, pos < end, bam_endpos > beg).  Host ranges hold
+             * exactly its records already; the records of a chunk handed back by the device (mdk_plan_host_prepare_from) are whole BGZF
+             * members, which carry the neighbouring chunk's -- and at a contig's first or last member the neighbouring contig's -- records */
+            if(!p->o.perread && (r.tid != c->tid || (int64_t)r.pos >= c->end || (int64_t)r.pos + (rl > 0 ? rl : 1) <= c->beg)) continue;
+            if(admit_and_pack(p, b, &r, rl, sl->win, sl->woff, sl->wlen, c->beg, c->end) < 0) return -5;
         }
         if(!sl->hold_slabs && sl->rg[g].slab) mdk_slab_unref(p->bam, sl->rg[g].slab);
     }
@@ -767,10 +772,12 @@ static int next_chunk_ex(mdk_plan *p, mdk_chunk *c, int nonblock) {
 
 /* A chunk handed out for device preparation, prepared on the host after all (the device reported MDK_ERR_PREP_HOST): the
  * same admission, pairing and segments as a host-mode plan produces, from the records the slot still references. */
-static pslot *held_slot(mdk_plan *p, const mdk_chunk *c) {
-    int i;
-    for(i = 0; i < p->n_hold; i++) if(p->held[i] >= 0 && p->slot[p->held[i]].c.index == c->index) return &p->slot[p->held[i]];
-    return NULL;
+static pslot *held_slot(mdk_plan *p, const mdk_chunk *c) {      /* (another thread may be taking the next chunk meanwhile) */
+    int i; pslot *sl = NULL;
+    pthread_mutex_lock(&p->mu);
+    for(i = 0; i < p->n_hold; i++) if(p->held[i] >= 0 && p->slot[p->held[i]].c.index == c->index) { sl = &p->slot[p->held[i]]; break; }
+    pthread_mutex_unlock(&p->mu);
+    return sl;
 }
 int mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c) {
     int rc; pslot *sl = NULL;

@@ -32,6 +32,7 @@
 #include <mutex>
 #include <algorithm>
 #include <condition_variable>
+#include <thread>
 #include <chrono>
 #include "mdk_hip_internal.hpp"
 
@@ -45,6 +46,20 @@ char *mdk_err_buf() { return g_err; }
 int fail(int code, const char *what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e));
     return code;
+}
+
+// ---- MDK_HOST_PROFILE: seconds the calling threads spend inside the library, per site ----
+static std::atomic<uint64_t> g_prof_ns[PF_N], g_prof_calls[PF_N];
+bool mdk_prof_on() { static const bool on = getenv("MDK_HOST_PROFILE") != nullptr; return on; }
+double mdk_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void mdk_prof_add(int site, double seconds) { g_prof_ns[site].fetch_add((uint64_t)(seconds * 1e9), std::memory_order_relaxed); g_prof_calls[site].fetch_add(1, std::memory_order_relaxed); }
+extern "C" int md_dev_profile_text(char *buf, int cap) {
+    static const char *const name[PF_N] = {"upload:wait-for-slot", "upload:alloc", "upload:copies", "launch", "collect:wait", "download:copy", "download:order", "set_reference", "piece:submit", "piece:wait"};
+    int o = 0;
+    if(!buf || cap < 1) return MDK_ERR_ARG;
+    buf[0] = 0;
+    for(int i = 0; i < PF_N && o < cap - 1; i++) o += snprintf(buf + o, (size_t)(cap - o), "%s%s %.3fs/%llu", i ? ", " : "", name[i], g_prof_ns[i].load() * 1e-9, (unsigned long long)g_prof_calls[i].load());
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,14 +664,38 @@ static void launch_pileup_multi(const md_dev *h, int grid, size_t lds, hipStream
 
 // Bring the runtime all the way up for a device -- context, code object -- without needing a configuration yet, so that a
 // caller can overlap it with its own start-up; md_dev_open afterwards finds it done.
+// streams made ahead of md_dev_open by md_dev_warm (creating one costs the runtime ~5 ms, and needs nothing the options decide)
+static std::mutex g_stash_mu; static std::vector<hipStream_t> g_stash; static int g_stash_dev = -1;
+#define WARM_STREAMS 4
+static hipStream_t stream_take(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_stash_mu);
+        if(g_stash_dev == device && !g_stash.empty()) { hipStream_t s = g_stash.back(); g_stash.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+}
 extern "C" int md_dev_warm(int device) {
+    const double t0 = mdk_now();
     int n = md_dev_count();
+    const double t1 = mdk_now();
     if(n <= 0 || device < 0 || device >= n) return MDK_ERR_NODEVICE;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
+    const double t2 = mdk_now();
     hipFuncAttributes fa;
     HIPCHK(hipFuncGetAttributes(&fa, pileup_fn(false, false)));
     HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_classify));
+    const double t3 = mdk_now();
+    for(int i = 0; i < WARM_STREAMS; i++) {
+        hipStream_t s = nullptr;
+        if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        std::lock_guard<std::mutex> lk(g_stash_mu);
+        if(g_stash_dev != device) { g_stash.clear(); g_stash_dev = device; }
+        g_stash.push_back(s);
+    }
+    if(mdk_prof_on()) fprintf(stderr, "[mdk hip] warm-up: runtime init + device count %.3fs, context (hipSetDevice + hipFree(0)) %.3fs, code object of the pileup kernels %.3fs, %d streams %.3fs\n", t1 - t0, t2 - t1, t3 - t2, WARM_STREAMS, mdk_now() - t3);
     return 0;
 }
 
@@ -665,6 +704,7 @@ static int fixed_lds(int tile, bool variant) { return tile * ((variant ? 16 : 8)
 extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     if(!cfg || !out) return fail(MDK_ERR_ARG, "md_dev_open", hipSuccess);
     *out = nullptr;
+    const double t_open0 = mdk_now();
     // the boost identity the kernels rely on, checked against the reference's C expression
     for(int q = 0; q < 256; q++) {
         uint8_t v = (uint8_t)q; v = (uint8_t)(int)(v + 0.2 * v);
@@ -696,11 +736,16 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     HIPCHK(hipDeviceSynchronize());                    // (the memset has run before any of the slots' non-blocking streams is used)
     memset(h->h_status.p, 0, sizeof(SlotStatus) * (size_t)h->n_slots);
     for(int i = 0; i < h->n_slots; i++) { Slot &s = h->slots[i]; s.index = i; s.d_total.p = h->d_status.p[i].total; s.d_err.p = &h->d_status.p[i].err; s.d_pcnt.p = &h->d_status.p[i].pc; s.h_st.p = &h->h_status.p[i]; }
+    const double t_open1 = mdk_now();
+    const bool shared = cfg->n_streams > 0;
+    const int n_streams = shared ? std::min(cfg->n_streams, (h->n_slots + MAXM - 1) / MAXM) : h->n_slots;
+    for(int i = 0; i < n_streams; i++) { hipStream_t st = stream_take(device); if(!st) return fail(MDK_ERR_HIP, "hipStreamCreateWithFlags", hipGetLastError()); h->streams.push_back(st); }
     for(auto &s : h->slots) {
-        HIPCHK(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        s.stream = h->streams[(size_t)(shared ? s.index / MAXM : s.index) % (size_t)n_streams];
         HIPCHK(hipEventCreate(&s.e0)); HIPCHK(hipEventCreate(&s.e1)); HIPCHK(hipEventCreate(&s.k0)); HIPCHK(hipEventCreate(&s.k1));
         s.run = s.stream;
     }
+    if(mdk_prof_on()) fprintf(stderr, "[mdk hip] md_dev_open: %.3fs (of which streams and events of %d slots %.3fs)\n", mdk_now() - t_open0, h->n_slots, mdk_now() - t_open1);
     *out = h;
     return 0;
 }
@@ -717,9 +762,10 @@ extern "C" void md_dev_close(md_dev *h) {
         s.d_site.release(); s.d_var.release(); s.d_seg.release();
         s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release();
         if(s.e0) (void)hipEventDestroy(s.e0); if(s.e1) (void)hipEventDestroy(s.e1); if(s.k0) (void)hipEventDestroy(s.k0); if(s.k1) (void)hipEventDestroy(s.k1);
-        if(s.stream) (void)hipStreamDestroy(s.stream);
     }
+    for(hipStream_t st : h->streams) if(st) (void)hipStreamDestroy(st);
     h->d_status.release(); h->h_status.release();
+    if(h->d_crc) (void)hipFree(h->d_crc);
     if(h->d_hist) (void)hipFree(h->d_hist);
     for(uint32_t *p : h->mapbits) if(p) (void)hipFree(p);
     for(md_region *p : h->d_runs) if(p) (void)hipFree(p);
@@ -730,8 +776,20 @@ extern "C" void md_dev_close(md_dev *h) {
 
 extern "C" int md_dev_tile(const md_dev *h) { return h ? h->tile : MDK_ERR_ARG; }
 
+// the per-contig tables at their final size: md_dev_set_reference / _regions / _mappability of one contig then never move the entries
+// of another, which a thread working on a slot of that contig may be reading
+extern "C" int md_dev_reserve_contigs(md_dev *h, int32_t n) {
+    if(!h || n < 0) return fail(MDK_ERR_ARG, "md_dev_reserve_contigs", hipSuccess);
+    const size_t k = (size_t)n;
+    if(h->ref.size() < k) { h->ref.resize(k, nullptr); h->refcode.resize(k, nullptr); h->reflen.resize(k, 0); }
+    if(h->d_runs.size() < k) { h->d_runs.resize(k, nullptr); h->n_runs.resize(k, 0); h->has_runs.resize(k, 0); }
+    if(h->mapbits.size() < k) { h->mapbits.resize(k, nullptr); h->maplen.resize(k, 0); }
+    return 0;
+}
+
 extern "C" int md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int64_t len) {
     if(!h || tid < 0 || !seq || len < 0) return fail(MDK_ERR_ARG, "md_dev_set_reference", hipSuccess);
+    ProfScope pf(PF_SETREF);
     HIPCHK(hipSetDevice(h->device));
     if((size_t)tid >= h->ref.size()) { h->ref.resize(tid + 1, nullptr); h->refcode.resize(tid + 1, nullptr); h->reflen.resize(tid + 1, 0); }
     if(h->ref[tid]) { (void)hipFree(h->ref[tid]); h->ref[tid] = nullptr; }
@@ -922,6 +980,7 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
 // for it, so download / wait per slot work as after md_dev_launch.
 extern "C" int md_dev_launch_group(md_dev *h, const int *slots, int n) {
     if(!h) return fail(MDK_ERR_ARG, "md_dev_launch_group", hipSuccess);
+    ProfScope pf(PF_LAUNCH);
     HIPCHK(hipSetDevice(h->device));
     return launch_group_on(h, slots, n, nullptr, true);
 }
@@ -1091,9 +1150,12 @@ int64_t finish_eval(md_dev *h, Slot *s) {
 int64_t finish_count(md_dev *h, Slot *s) {
     if(!s->launched) { fail(MDK_ERR_ARG, "slot not launched", hipSuccess); return MDK_ERR_ARG; }
     hipStream_t st = s->run ? s->run : s->stream;
-    if(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MDK_ERR_HIP, "D2H status", hipGetLastError());
-    hipError_t e = hipStreamSynchronize(st);
-    if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
+    {
+        ProfScope pf(PF_FIN_WAIT);
+        if(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MDK_ERR_HIP, "D2H status", hipGetLastError());
+        hipError_t e = hipStreamSynchronize(st);
+        if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
+    }
     return finish_eval(h, s);
 }
 // the same for the slots of one group launch: one copy covering all of them
@@ -1151,10 +1213,14 @@ extern "C" int md_dev_download(md_dev *h, int slot, md_sites *out) {
     if(s->h_site.need(nn + 1) || s->h_sorted.need(nn + 1) || s->h_seg.need(nt)) return MDK_ERR_NOMEM;
     if(h->variant && (s->h_var.need(nn + 1) || s->h_vsorted.need(nn + 1))) return MDK_ERR_NOMEM;
     if(nn) {
-        HIPCHK(hipMemcpyAsync(s->h_site.p, dv.d_site, nn * sizeof(md_site), hipMemcpyDeviceToHost, s->stream));
-        if(h->variant) HIPCHK(hipMemcpyAsync(s->h_var.p, dv.d_var, nn * sizeof(md_site_var), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipMemcpyAsync(s->h_seg.p, dv.d_seg, (size_t)s->ntiles * sizeof(md_tile_seg), hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(hipStreamSynchronize(s->stream));
+        {
+            ProfScope pf(PF_DL_COPY);
+            HIPCHK(hipMemcpyAsync(s->h_site.p, dv.d_site, nn * sizeof(md_site), hipMemcpyDeviceToHost, s->stream));
+            if(h->variant) HIPCHK(hipMemcpyAsync(s->h_var.p, dv.d_var, nn * sizeof(md_site_var), hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipMemcpyAsync(s->h_seg.p, dv.d_seg, (size_t)s->ntiles * sizeof(md_tile_seg), hipMemcpyDeviceToHost, s->stream));
+            HIPCHK(hipStreamSynchronize(s->stream));
+        }
+        ProfScope pf2(PF_DL_ORDER);
         nsites = md_sites_order(s->h_site.p, h->variant ? s->h_var.p : nullptr, s->h_seg.p, s->ntiles, dv.n_slots, s->h_sorted.p, h->variant ? s->h_vsorted.p : nullptr);
         if(nsites < 0) return fail(MDK_ERR_ARG, "md_dev_download: inconsistent tile segments", hipSuccess);
     }
@@ -1162,10 +1228,59 @@ extern "C" int md_dev_download(md_dev *h, int slot, md_sites *out) {
     return 0;
 }
 
+// the results of one group launch: one wait (the status blocks of all its slots with one copy), then the site arrays of every slot
+// queued before a single synchronisation -- a download per slot costs a wait and a round trip each, ~1 ms per chunk
+extern "C" int md_dev_download_group(md_dev *h, const int *slots, int n, md_sites *out, int *rcs) {
+    if(!h || !slots || !out || !rcs || n < 1 || n > MAXM) return fail(MDK_ERR_ARG, "md_dev_download_group", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    int lo = 0x7fffffff, hi = -1; hipStream_t st = nullptr; Slot *ss[MAXM]; int64_t cnt[MAXM];
+    for(int i = 0; i < n; i++) {
+        Slot *s = get_slot(h, slots[i]); if(!s || !s->launched) return fail(MDK_ERR_ARG, "md_dev_download_group: slot not launched", hipSuccess);
+        ss[i] = s; memset(&out[i], 0, sizeof(out[i])); rcs[i] = 0;
+        if(i == 0) st = s->run; else if(s->run != st) st = nullptr;
+        lo = std::min(lo, s->index); hi = std::max(hi, s->index);
+    }
+    if(!st) {      // not one launch: slot by slot
+        for(int i = 0; i < n; i++) rcs[i] = md_dev_download(h, slots[i], &out[i]);
+        return 0;
+    }
+    {
+        ProfScope pf(PF_FIN_WAIT);
+        if(hipMemcpyAsync(h->h_status.p + lo, h->d_status.p + lo, sizeof(SlotStatus) * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MDK_ERR_HIP, "D2H status", hipGetLastError());
+        hipError_t e = hipStreamSynchronize(st);
+        if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
+    }
+    for(int i = 0; i < n; i++) { cnt[i] = finish_eval(h, ss[i]); if(cnt[i] < 0) rcs[i] = (int)cnt[i]; }      // (a chunk whose segment array had to grow is prepared and piled up again in there)
+    {
+        ProfScope pf(PF_DL_COPY);
+        for(int i = 0; i < n; i++) {
+            Slot *s = ss[i]; if(rcs[i] || cnt[i] == 0) continue;
+            const size_t nn = (size_t)cnt[i], nt = (size_t)(s->ntiles > 0 ? s->ntiles : 1);
+            if(s->h_site.need(nn + 1) || s->h_sorted.need(nn + 1) || s->h_seg.need(nt) || (h->variant && (s->h_var.need(nn + 1) || s->h_vsorted.need(nn + 1)))) { rcs[i] = MDK_ERR_NOMEM; continue; }
+            const md_site *d_site = s->b_site ? s->b_site : s->d_site.p; const md_site_var *d_var = s->b_site ? s->b_var : s->d_var.p; const md_tile_seg *d_seg = s->b_site ? s->b_seg : s->d_seg.p;
+            HIPCHK(hipMemcpyAsync(s->h_site.p, d_site, nn * sizeof(md_site), hipMemcpyDeviceToHost, st));
+            if(h->variant) HIPCHK(hipMemcpyAsync(s->h_var.p, d_var, nn * sizeof(md_site_var), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(s->h_seg.p, d_seg, (size_t)s->ntiles * sizeof(md_tile_seg), hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    ProfScope pf2(PF_DL_ORDER);
+    for(int i = 0; i < n; i++) {
+        Slot *s = ss[i]; if(rcs[i]) continue;
+        int64_t nsites = 0;
+        if(cnt[i]) {
+            nsites = md_sites_order(s->h_site.p, h->variant ? s->h_var.p : nullptr, s->h_seg.p, s->ntiles, cnt[i], s->h_sorted.p, h->variant ? s->h_vsorted.p : nullptr);
+            if(nsites < 0) { rcs[i] = fail(MDK_ERR_ARG, "md_dev_download_group: inconsistent tile segments", hipSuccess); continue; }
+        }
+        out[i].n_sites = nsites; out[i].site = s->h_sorted.p; out[i].var = h->variant ? s->h_vsorted.p : nullptr;
+    }
+    return 0;
+}
+
 extern "C" int md_dev_sync(md_dev *h) {
     if(!h) return fail(MDK_ERR_ARG, "md_dev_sync", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
-    for(auto &s : h->slots) HIPCHK(hipStreamSynchronize(s.stream));
+    for(hipStream_t st : h->streams) HIPCHK(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -1325,6 +1440,37 @@ MDK_HIDDEN void host_block_ensure_registered(const void *ptr) {
 extern "C" void md_host_register(md_dev *h, const void *ptr) { if(h) (void)hipSetDevice(h->device); host_block_ensure_registered(ptr); }
 // MDK_HOST_PROFILE: what registering the staging blocks cost
 extern "C" void md_host_profile(double *seconds, uint64_t *calls, uint64_t *bytes) { std::lock_guard<std::mutex> lk(g_blocks_mu); if(seconds) *seconds = g_reg_seconds; if(calls) *calls = g_reg_calls; if(bytes) *bytes = g_reg_bytes; }
+// every staging block not yet known to the runtime is registered now, by `threads` threads (the caller: a helper thread of the command, once
+// the device is up -- the slabs filled while the runtime was still starting would otherwise be registered one by one by the thread that uploads)
+extern "C" int md_host_register_all(md_dev *h, int threads) {
+    if(h) (void)hipSetDevice(h->device);
+    std::vector<char *> todo;
+    { std::lock_guard<std::mutex> lk(g_blocks_mu); for(const HostBlock &b : g_blocks) if(b.state == 0) todo.push_back(b.base); }
+    if(threads < 1) threads = 1;
+    if(threads > 16) threads = 16;
+    std::atomic<size_t> next{0};
+    auto work = [&]() { if(h) (void)hipSetDevice(h->device); for(;;) { const size_t i = next.fetch_add(1); if(i >= todo.size()) break; host_block_ensure_registered(todo[i]); } };
+    std::vector<std::thread> th;
+    for(int i = 1; i < threads && (size_t)i < todo.size(); i++) th.emplace_back(work);
+    work();
+    for(auto &t : th) t.join();
+    return (int)todo.size();
+}
+// For a process about to END: the pages of every staging block go back to the system now, from `threads` threads at once (contents are lost,
+// the blocks stay allocated).  The kernel otherwise tears the address space down on one core when the process exits -- 37 ms per GB on the
+// MI355X box even with huge pages (profiles/r04a_e2e.txt), a third of a second for the slabs of a 2 GB BAM.
+extern "C" void md_host_trim(int threads) {
+    std::vector<HostBlock> all;
+    { std::unique_lock<std::mutex> lk(g_blocks_mu); while(std::any_of(g_blocks.begin(), g_blocks.end(), [](const HostBlock &b) { return b.state == 1; })) g_blocks_cv.wait(lk); all = g_blocks; for(HostBlock &b : g_blocks) if(b.state == 2) b.state = 0; }
+    if(threads < 1) threads = 1;
+    if(threads > 32) threads = 32;
+    std::atomic<size_t> next{0};
+    auto work = [&]() { for(;;) { const size_t i = next.fetch_add(1); if(i >= all.size()) break; if(all[i].state == 2) (void)hipHostUnregister(all[i].base); (void)madvise(all[i].base, all[i].len, MADV_DONTNEED); } };
+    std::vector<std::thread> th;
+    for(int i = 1; i < threads && (size_t)i < all.size(); i++) th.emplace_back(work);
+    work();
+    for(auto &t : th) t.join();
+}
 static std::atomic<int> g_want_pinned{1};
 extern "C" void md_host_set_pinned(int on) { g_want_pinned.store(on != 0); }
 extern "C" void *md_host_alloc(uint64_t bytes) {

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <mutex>
 #include "mdk_hip.h"
 
 #ifndef WG
@@ -89,7 +90,9 @@ struct Slot {
 };
 
 struct md_dev {
-    int device; md_dev_cfg cfg; int tile, n_slots; bool variant; bool qw = false;    /* qw: dense contexts, a quarter of a wavefront per segment */
+    int device; md_dev_cfg cfg; int tile, n_slots; bool variant; bool qw = false;
+    std::vector<hipStream_t> streams;        // the streams the slots work on (cfg.n_streams of them, or one per slot)
+    std::mutex crc_mu; void *d_crc = nullptr;   // constants of k_crc32 (mdk_inflate.hip), made by the first piece    /* qw: dense contexts, a quarter of a wavefront per segment */
     std::vector<Slot> slots;
     std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
     DBuf<SlotStatus> d_status; HBuf<SlotStatus> h_status;
@@ -140,6 +143,12 @@ __device__ __forceinline__ md_pr_count perread_walk(const uint8_t *seq, const ui
     return o;
 }
 
+// MDK_HOST_PROFILE=1: where the host threads' time inside the library goes (seconds and calls per site), printed by md_dev_profile_dump
+enum { PF_UP_SYNC = 0, PF_UP_ALLOC, PF_UP_COPY, PF_LAUNCH, PF_FIN_WAIT, PF_DL_COPY, PF_DL_ORDER, PF_SETREF, PF_PIECE_SUBMIT, PF_PIECE_WAIT, PF_N };
+MDK_HIDDEN bool mdk_prof_on();
+MDK_HIDDEN void mdk_prof_add(int site, double seconds);
+MDK_HIDDEN double mdk_now();
+struct ProfScope { int site; double t0; ProfScope(int s) : site(s), t0(mdk_prof_on() ? mdk_now() : 0.0) {} ~ProfScope() { if(mdk_prof_on()) mdk_prof_add(site, mdk_now() - t0); } };
 MDK_HIDDEN Slot *get_slot(md_dev *h, int slot);
 MDK_HIDDEN void host_block_ensure_registered(const void *ptr);      // a huge-page staging block is registered with the runtime at its first upload
 MDK_HIDDEN int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on = nullptr);

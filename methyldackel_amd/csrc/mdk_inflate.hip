@@ -2,20 +2,25 @@
 // inside htslib's sam_itr_next, common.c:413).
 //
 //   k_inflate     one WAVEFRONT per BGZF member.  Lane 0 decodes Huffman symbols (mdk_inflate_core.h: that part of DEFLATE is
-//                 sequential) in batches of <= 64 symbols: literals go straight into a 4 KiB output window in LDS, matches become
-//                 tokens.  Between batches all 64 lanes work: (1) top up the LDS ring of compressed words with one coalesced
+//                 sequential) in batches of <= 64 match tokens / 1 KiB of output: literals go straight into a 2 KiB output window (INF_WIN) in
+//                 LDS, matches become tokens.  Between batches all 64 lanes work: (1) top up the LDS ring of compressed words with one coalesced
 //                 load, (2) FAR matches -- source older than the LDS window -- one lane per token, bytes from global memory
 //                 (written by an earlier batch of this wavefront), (3) NEAR matches in stream order, each by all lanes from the
 //                 window (a self-overlapping match doubles the copied span per round), (4) the batch's bytes leave the window
 //                 for global memory, coalesced.  A 64 KiB member is ~16 k symbols; the file's ~10^4..10^5 members are what
 //                 fills the machine (one lane per member, round 2's experiment, left 434 wavefronts of diverging lanes).
-//   k_walk        one lane per member: chases the block_size words from the member's first byte (htslib never lets a record
+//   k_crc32       one wavefront per member: the CRC32 of the inflated bytes against the member's trailer -- what htslib's bgzf_read_block
+//                 checks for every block the reference reads.  Coalesced 16-byte loads; every lane keeps the CRC of its own column of the
+//                 member (slice-by-4 tables and a "1008 zero bytes" operator in LDS), the 64 columns are merged with GF(2) multiplications.
+//   k_walk<false> one lane per member: chases the block_size words from the member's first byte (htslib never lets a record
 //                 straddle two members), counts the records, notes whether the walk ends exactly at the member's end.
-//   k_rec_table   after an exclusive scan of the counts: one lane per member walks again and writes each record's offset, and
-//                 the member's digest (first/last record, extent of the read ends, coordinate order inside) -- what the host's
-//                 inflate threads leave per member (csrc/host/mdk_io.c note_records).
+//   k_walk_scan   exclusive scan of the counts.
+//   k_walk<true>  one lane per member walks again and writes each record's offset, and the member's digest (first/last record, extent
+//                 of the read ends, coordinate order inside) -- what the host's inflate threads leave per member (csrc/host/mdk_io.c
+//                 note_records).
 #include "mdk_hip_internal.hpp"
 #include "mdk_inflate_core.h"
+#include "mdk_crc32_core.h"
 
 // coherent byte / word loads of what this wavefront stored earlier (plain loads could hit a stale line in the CU's L1)
 __device__ __forceinline__ uint32_t ld_u32_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -128,6 +133,31 @@ __global__ __launch_bounds__(64, INF_WAVES) void k_inflate(const InfParams P) {
     inflate_member<(VARIANT & 1) != 0, (VARIANT & 2) != 0>(P, S, m, lane);
 }
 
+
+// ---- CRC-32 of the inflated members (mdk_crc32_core.h) ----
+struct CrcParams { const uint8_t *out; const md_inf_member *mem; int n_mem; const CrcConst *K; uint32_t *status; };
+#define CRC_WAVES 4
+__global__ __launch_bounds__(64 * CRC_WAVES) void k_crc32(const CrcParams P) {
+    __shared__ uint32_t T[4][256], Z[4][256]; __shared__ uint32_t lvl[6], p8[17];
+    for(int i = threadIdx.x; i < 1024; i += 64 * CRC_WAVES) { (&T[0][0])[i] = (&P.K->T[0][0])[i]; (&Z[0][0])[i] = (&P.K->Z[0][0])[i]; }
+    if(threadIdx.x < 6) lvl[threadIdx.x] = P.K->lvl[threadIdx.x];
+    if(threadIdx.x < 17) p8[threadIdx.x] = P.K->p8[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for(int m = blockIdx.x * CRC_WAVES + wave; m < P.n_mem; m += gridDim.x * CRC_WAVES) {
+        const md_inf_member M = P.mem[m];
+        const uint32_t L = M.out_len;
+        if(L == 0) { if(lane == 0 && M.crc32 != 0u) atomicCAS(P.status, 0u, (uint32_t)INF_E_CRC | ((uint32_t)m << 8)); continue; }
+        uint32_t c = crc_lane(T, Z, P.out + M.out_off, L, lane);
+#pragma unroll
+        for(int l = 0; l < 6; l++) { const uint32_t left = (uint32_t)__shfl((int)c, lane - (1 << l)); c ^= crc_mul(left, lvl[l]); }      // only the last lane of each group of 2^(l+1) matters
+        if(lane == 63) {
+            const uint32_t crc = crc_finish(c, L, p8);
+            if(crc != M.crc32) atomicCAS(P.status, 0u, (uint32_t)INF_E_CRC | ((uint32_t)m << 8));
+        }
+    }
+}
+
 // ---- record framing ----
 struct WalkParams {
     const uint8_t *out; const md_inf_member *mem; int n_mem;
@@ -212,8 +242,25 @@ struct md_piece {
     DBuf<uint8_t> d_comp, d_out; DBuf<md_inf_member> d_mem; DBuf<uint32_t> d_cnt, d_first, d_recoff, d_status; DBuf<md_inf_digest> d_dig;
     HBuf<md_inf_digest> h_dig; HBuf<uint32_t> h_status;
     int n_mem = 0; uint64_t out_bytes = 0, comp_bytes = 0; uint32_t n_rec_cap = 0; bool busy = false;
+    bool check_crc = true;              // MDK_NO_CRC=1 leaves the check out (timing comparisons)
 };
+// the constants of k_crc32, once per device handle
+static const CrcConst *crc_const_of(md_dev *h) {
+    std::lock_guard<std::mutex> lk(h->crc_mu);
+    if(!h->d_crc) {
+        CrcConst *K = new CrcConst(); crc_make_const(*K);
+        void *d = nullptr;
+        if(hipMalloc(&d, sizeof(CrcConst)) == hipSuccess && hipMemcpy(d, K, sizeof(CrcConst), hipMemcpyHostToDevice) == hipSuccess) h->d_crc = d; else { if(d) (void)hipFree(d); (void)hipGetLastError(); }
+        delete K;
+    }
+    return (const CrcConst *)h->d_crc;
+}
 
+static void launch_crc(md_dev *h, md_piece *p, hipStream_t st) {
+    CrcParams C; C.out = p->d_out.p; C.mem = p->d_mem.p; C.n_mem = p->n_mem; C.K = (const CrcConst *)h->d_crc; C.status = p->d_status.p;
+    int grid = (p->n_mem + CRC_WAVES - 1) / CRC_WAVES; if(grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_crc32, dim3(grid), dim3(64 * CRC_WAVES), 0, st, C);
+}
 extern "C" int md_piece_create(md_dev *h, md_piece **out) {
     if(!h || !out) return fail(MDK_ERR_ARG, "md_piece_create", hipSuccess);
     *out = nullptr;
@@ -221,6 +268,8 @@ extern "C" int md_piece_create(md_dev *h, md_piece **out) {
     md_piece *p = new md_piece(); p->h = h;
     if(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
     if(p->d_status.need(4) || p->h_status.need(4)) { delete p; return MDK_ERR_NOMEM; }
+    p->check_crc = !getenv("MDK_NO_CRC");
+    if(p->check_crc && !crc_const_of(h)) { delete p; return fail(MDK_ERR_NOMEM, "md_piece_create: CRC tables", hipSuccess); }
     *out = p;
     return 0;
 }
@@ -238,6 +287,7 @@ extern "C" void md_piece_destroy(md_piece *p) {
 // stream; md_piece_wait returns when it is all done.  comp should be pinned memory (md_host_alloc) for the copy to be a DMA.
 extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_bytes, const md_inf_member *mem, int n_mem) {
     if(!p || !comp || !mem || n_mem < 1) return fail(MDK_ERR_ARG, "md_piece_submit", hipSuccess);
+    ProfScope pf(PF_PIECE_SUBMIT);
     md_dev *h = p->h;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -258,6 +308,7 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
     HIPCHK(hipMemsetAsync(p->d_status.p, 0, 16, st));
     InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p;
     launch_inflate(n_mem, st, IP);
+    if(p->check_crc) launch_crc(h, p, st);
     WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
     hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
     hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(1024), 0, st, (const uint32_t *)p->d_cnt.p, p->d_first.p, n_mem, p->d_status.p);
@@ -272,10 +323,12 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
 
 extern "C" int md_piece_wait(md_piece *p, md_piece_info *info) {
     if(!p || !info || !p->busy) return fail(MDK_ERR_ARG, "md_piece_wait: nothing submitted", hipSuccess);
+    ProfScope pf(PF_PIECE_WAIT);
     HIPCHK(hipSetDevice(p->h->device));
     HIPCHK(hipEventSynchronize(p->done));
     p->busy = false;
     const uint32_t st = p->h_status.p[0];
+    if((st & 255u) == (uint32_t)INF_E_CRC) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "a BGZF member fails its CRC32 check (corrupt file): member %u of the piece", st >> 8); return MDK_ERR_ARG; }
     if(st) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "BGZF inflate failed on the device (corrupt file?): error %u in member %u of the piece", st & 255u, st >> 8); return MDK_ERR_ARG; }
     info->n_mem = p->n_mem; info->digest = p->h_dig.p; info->n_records = p->h_status.p[1]; info->out_bytes = p->out_bytes;
     info->d_out = p->d_out.p; info->d_rec_off = p->d_recoff.p;
@@ -299,6 +352,23 @@ extern "C" int md_piece_read_records(md_piece *p, uint32_t first, uint32_t n, ui
 }
 
 // the kernels alone on resident input, timed with HIP events on the piece's stream (bench.py / tools)
+extern "C" int md_piece_bench_crc(md_piece *p, int iters, float *ms_crc) {
+    if(!p || iters < 1 || !p->n_mem || !ms_crc) return fail(MDK_ERR_ARG, "md_piece_bench_crc", hipSuccess);
+    HIPCHK(hipSetDevice(p->h->device));
+    if(!crc_const_of(p->h)) return fail(MDK_ERR_NOMEM, "md_piece_bench_crc: CRC tables", hipSuccess);
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipEventRecord(e0, p->stream));
+    for(int i = 0; i < iters; i++) launch_crc(p->h, p, p->stream);
+    HIPCHK(hipEventRecord(e1, p->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float a = 0; HIPCHK(hipEventElapsedTime(&a, e0, e1));
+    *ms_crc = a / (float)iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    uint32_t st = 0; HIPCHK(hipMemcpy(&st, p->d_status.p, 4, hipMemcpyDeviceToHost));
+    if(st) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "CRC32 / inflate status %u in member %u", st & 255u, st >> 8); return MDK_ERR_ARG; }
+    return 0;
+}
 extern "C" int md_piece_bench(md_piece *p, int iters, float *ms_inflate, float *ms_walk) {
     if(!p || iters < 1 || !p->n_mem) return fail(MDK_ERR_ARG, "md_piece_bench", hipSuccess);
     HIPCHK(hipSetDevice(p->h->device));

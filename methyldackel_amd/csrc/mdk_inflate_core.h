@@ -61,7 +61,7 @@ typedef uint32_t inf_dist_t;
 
 // error codes (0 = fine)
 enum { INF_OK = 0, INF_E_BTYPE = 1, INF_E_STORED = 2, INF_E_HEADER = 3, INF_E_CODELEN = 4, INF_E_LITTABLE = 5, INF_E_DISTTABLE = 6, INF_E_SYMBOL = 7,
-       INF_E_DIST = 8, INF_E_OVERRUN = 9, INF_E_INPUT = 10, INF_E_SHORT = 11 };
+       INF_E_DIST = 8, INF_E_OVERRUN = 9, INF_E_INPUT = 10, INF_E_SHORT = 11, INF_E_CRC = 12 };
 
 struct InfToken { uint32_t dst; uint32_t len_dist; };       // dst: position in the member's output; len | dist << 16
 

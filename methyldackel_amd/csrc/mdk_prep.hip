@@ -674,8 +674,11 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     if(b->n_records && !b->range) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null array", hipSuccess);
     if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(s->stream));
-    if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
+    {
+        ProfScope pf(PF_UP_SYNC);
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
+    }
     s->fresh = true;
     uint64_t total = 0;
     for(int i = 0; i < b->n_ranges; i++) total += b->range[i].bytes;
@@ -688,13 +691,16 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     const size_t nn = (size_t)n + 1, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
     s->hmask = pow2_at_least(nn + nn / 4) - 1;          // names are at most the records: load factor <= 0.8, ~0.4 for pairs; 2 MB for a 1 Mb chunk at 30x
-    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
-       s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
-    if(!s->b_site) {
-        if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
-        if(h->variant && s->d_var.need((size_t)span + 16)) return MDK_ERR_NOMEM;
+    {
+        ProfScope pf(PF_UP_ALLOC);
+        if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+           s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
+        if(!s->b_site) {
+            if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
+            if(h->variant && s->d_var.need((size_t)span + 16)) return MDK_ERR_NOMEM;
+        }
     }
-    { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
+    { ProfScope pf(PF_UP_COPY); int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
     s->prep_pending = true;            // the preparation kernels are queued with the launch: alone (md_dev_launch) or with up to seven other chunks (md_dev_launch_group)
     s->uploaded = true;
     return 0;

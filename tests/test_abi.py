@@ -41,7 +41,7 @@ def test_extract_library_exports_header():
 def test_struct_layouts_match_the_c_abi():
     assert C.sizeof(mdk.md_seg) == 32
     assert C.sizeof(mdk.md_site) == 16 and C.sizeof(mdk.md_site_var) == 8 and C.sizeof(mdk.md_tile_seg) == 8
-    assert C.sizeof(mdk.md_dev_cfg) == 4 * (5 + 32 + 2)
+    assert C.sizeof(mdk.md_dev_cfg) == 4 * (5 + 32 + 3)
 
 
 def test_no_device_is_a_loud_error_not_a_fallback(tmp_path):

@@ -18,6 +18,9 @@ from test_gpu_parity import compare_cli
 pytestmark = pytest.mark.gpu
 
 
+CRCS = {}            # deflate stream offset -> CRC32 of the member's trailer (filled by bgzf_members)
+
+
 def bgzf_members(raw):
     out, o = [], 0
     while o + 18 <= len(raw):
@@ -25,6 +28,7 @@ def bgzf_members(raw):
         bs = struct.unpack_from("<H", raw, o + 16)[0] + 1
         isz = struct.unpack_from("<I", raw, o + bs - 4)[0]
         out.append((o + 12 + xlen, bs - 12 - xlen - 8, isz))
+        CRCS[o + 12 + xlen] = struct.unpack_from("<I", raw, o + bs - 8)[0]
         o += bs
     return out
 
@@ -71,7 +75,7 @@ def test_piece_inflate_equals_zlib_and_record_walk(tmp_path):
     stage = L.md_host_alloc(C.c_uint64(len(raw) + 64)); C.memmove(stage, raw, len(raw))
     tab = (mdk.md_inf_member * len(mem))(); o = 0
     for i, (io, il, isz) in enumerate(mem):
-        tab[i].in_off, tab[i].in_len, tab[i].out_len, tab[i].out_off = io, il, isz, o; o += isz
+        tab[i].in_off, tab[i].in_len, tab[i].out_len, tab[i].out_off, tab[i].crc32 = io, il, isz, o, CRCS[io]; o += isz
     piece = C.c_void_p(); info = mdk.md_piece_info()
     assert L.md_piece_create(dev.h, C.byref(piece)) == 0, L.md_dev_last_error()
     for variant_pass in range(2):       # twice: the second submit reuses the piece's buffers
@@ -173,3 +177,50 @@ def test_chunk_handed_back_to_the_host_with_device_resident_records(tmp_path):
     out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
     (tmp_path / "r.bam").write_bytes(bytes(out))
     od, gd = compare_cli(tmp_path, [str(tmp_path / "r.fa"), str(tmp_path / "r.bam"), "-q", "0"], env=dict(DEV, MDK_HOST_PROFILE="1"))
+    assert fell_back(tmp_path) >= 1, "the chunk was expected to fall back to the host preparation"
+
+
+def fell_back(tmp_path):
+    """chunks the command prepared on the host after all (MDK_HOST_PROFILE line of extract_main)"""
+    import re
+    m = re.search(r"chunks prepared on the host after all: (\d+)", (tmp_path / "gpu_stderr.txt").read_text())
+    return int(m.group(1)) if m else -1
+
+
+def test_handed_back_chunks_drop_the_neighbours_records(tmp_path):
+    """The same with two contigs and chunks smaller than a BGZF member's span: the members read back for a handed-back chunk also hold
+    the records of the neighbouring chunks and -- the member that straddles the contig boundary -- of the other contig; the host
+    preparation must redo the chunk's region query on them (chrB is short: its single chunk starts at 0, where chrA's reads would
+    otherwise be counted at chrB's coordinates)."""
+    import random
+    from bamwriter import record, write_fasta
+    rnd = random.Random(5)
+    refs = [("chrA", "".join(rnd.choice("ACGT") for _ in range(30000))), ("chrB", "".join(rnd.choice("ACGT") for _ in range(2500)))]
+    write_fasta(tmp_path / "r.fa", refs)
+    recs = []
+    for tid, (_, ref) in enumerate(refs):
+        n = 6000 if tid == 0 else 900
+        for i in range(n):
+            pos = rnd.randrange(0, len(ref) - 120)
+            recs.append((tid, pos, record(tid, pos, 0, "100M", ref[pos:pos + 100], 30, qname=f"dup{tid}" if i % 10 == 0 else f"r{tid}_{i}")))
+    recs.sort(key=lambda r: (r[0], r[1]))
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrA\tLN:30000\n@SQ\tSN:chrB\tLN:2500\n"
+    hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 2) + struct.pack("<i", 5) + b"chrA\0" + struct.pack("<i", 30000) + struct.pack("<i", 5) + b"chrB\0" + struct.pack("<i", 2500)
+    out, blk = bytearray(), bytearray()
+
+    def flush():
+        nonlocal blk
+        if blk:
+            c = zlib.compressobj(6, zlib.DEFLATED, -15); comp = c.compress(bytes(blk)) + c.flush()
+            out.extend(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(bytes(blk)), len(blk)))
+            blk = bytearray()
+    blk += hdr; flush()
+    for _, _, r in recs:                  # members end on record boundaries, wherever the contig changes
+        if len(blk) + len(r) > 50000:
+            flush()
+        blk += r
+    flush()
+    out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    (tmp_path / "r.bam").write_bytes(bytes(out))
+    od, gd = compare_cli(tmp_path, [str(tmp_path / "r.fa"), str(tmp_path / "r.bam"), "-q", "0", "--chunkSize", "2000"], env=dict(DEV, MDK_HOST_PROFILE="1"))
+    assert fell_back(tmp_path) >= 2

@@ -26,6 +26,7 @@ def compare_cli(tmp_path, args, env=None, oracle_args=None, ranks=None):
     od.mkdir(exist_ok=True), gd.mkdir(exist_ok=True)
     ro = run_oracle(list(oracle_args if oracle_args is not None else args) + ["-o", "out"], cwd=od)
     rg = mdk.run_cli(list(args) + ["-o", "out"], cwd=gd, env=env, ranks=ranks)
+    (tmp_path / "gpu_stderr.txt").write_text(rg.stderr)
     if ranks:
         assert all(rc == rg.returncode for rc in rg.rank_returncodes), (rg.rank_returncodes, rg.rank_stderr)
     assert rg.returncode == ro.returncode, (rg.returncode, ro.returncode, rg.stderr[-2000:])

@@ -25,6 +25,13 @@ def test_damaged_streams_are_rejected_or_equal_zlib(emu):
     assert r.returncode == 0 and " 0 FAILURES" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_wavefront_crc32_equals_zlib(emu):
+    """k_crc32's arithmetic (csrc/mdk_crc32_core.h: a register per lane over its column of the member, merged with GF(2) multiplications) on the
+    host: every length up to 2100, random and maximal lengths, any alignment, all-zero / all-one / random bytes"""
+    r = subprocess.run([str(emu), "--crc", "6000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '"mismatches": 0' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_selftest_streams(emu):
     r = subprocess.run([str(emu), "--selftest"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -13,6 +13,7 @@
 #include <vector>
 #include <zlib.h>
 #include "mdk_inflate_core.h"
+#include "mdk_crc32_core.h"
 
 // one member, as k_inflate does it; returns 0 or the error code
 static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uint8_t *out, uint32_t out_len, uint64_t *n_far, uint64_t *n_near, uint64_t *n_batches) {
@@ -144,8 +145,34 @@ static int fuzz(long iters) {
     return bad ? 1 : 0;
 }
 
+// k_crc32 on the host: the per-lane bodies are the kernel's (mdk_crc32_core.h), the six shuffle levels run over an array
+static uint32_t emu_crc32(const CrcConst &K, const uint8_t *d, uint32_t L) {
+    if(L == 0) return 0;
+    uint32_t c[64];
+    for(int lane = 0; lane < 64; lane++) c[lane] = crc_lane(K.T, K.Z, d, L, lane);
+    for(int l = 0; l < 6; l++) { uint32_t nx[64]; for(int lane = 0; lane < 64; lane++) { const int src = lane - (1 << l); nx[lane] = c[lane] ^ crc_mul(src >= 0 ? c[src] : 0xdeadbeefu, K.lvl[l]); } memcpy(c, nx, sizeof c); }
+    return crc_finish(c[63], L, K.p8);
+}
+static int crctest(long n) {
+    static CrcConst K; crc_make_const(K);
+    std::vector<uint8_t> buf(65536 + 64 + 16); uint64_t rs = 0x9E3779B97F4A7C15ull; long bad = 0;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+    for(long it = 0; it < n; it++) {
+        // every length up to 2100 (first blocks, block edges), then random lengths up to 65536; the member starts at any alignment
+        const uint32_t L = it <= 2100 ? (uint32_t)it : (it & 1) ? (uint32_t)(rnd() % 65537) : 65536u - (uint32_t)(rnd() % 40);
+        const size_t off = 16 + (size_t)(rnd() % 16);
+        const int kind = (int)(rnd() % 4);
+        for(size_t i = 0; i < buf.size(); i++) buf[i] = kind == 0 ? 0 : kind == 1 ? 0xff : (uint8_t)rnd();
+        const uint32_t want = (uint32_t)crc32(0L, buf.data() + off, L), got = emu_crc32(K, buf.data() + off, L);
+        if(want != got) { if(bad < 5) fprintf(stderr, "crc32 of %u bytes (kind %d): zlib %08x, lanes %08x\n", L, kind, want, got); bad++; }
+    }
+    printf("{\"crc_cases\": %ld, \"mismatches\": %ld}\n", n, bad);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv) {
     if(argc > 1 && !strcmp(argv[1], "--selftest")) return selftest();
+    if(argc > 2 && !strcmp(argv[1], "--crc")) return crctest(atol(argv[2]));
     if(argc > 2 && !strcmp(argv[1], "--fuzz")) return fuzz(atol(argv[2]));
     if(argc < 2) { fprintf(stderr, "usage: inflate_emu file.bam [max_members] | --selftest\n"); return 2; }
     FILE *f = fopen(argv[1], "rb"); if(!f) { perror(argv[1]); return 2; }

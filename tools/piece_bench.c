@@ -33,7 +33,7 @@ int main(int argc, char **argv) {
     for(size_t o = 0; o + 18 <= n;) {
         const uint32_t xlen = raw[o + 10] | (raw[o + 11] << 8), bs = (raw[o + 16] | (raw[o + 17] << 8)) + 1u;
         if(nm == cap) { cap *= 2; mem = realloc(mem, sizeof(*mem) * cap); mfile = realloc(mfile, sizeof(size_t) * cap); }
-        mem[nm].in_off = o + 12 + xlen; mem[nm].in_len = bs - 12 - xlen - 8; mem[nm].out_len = le32(raw + o + bs - 4); mem[nm].out_off = 0; mfile[nm] = o; nm++;
+        mem[nm].in_off = o + 12 + xlen; mem[nm].in_len = bs - 12 - xlen - 8; mem[nm].out_len = le32(raw + o + bs - 4); mem[nm].crc32 = le32(raw + o + bs - 8); mem[nm].reserved = 0; mem[nm].out_off = 0; mfile[nm] = o; nm++;
         o += bs;
     }
     piece_t *pc = malloc(sizeof(piece_t) * (nm + 1)); int np = 0; uint64_t tot_out = 0;

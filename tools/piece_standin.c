@@ -38,6 +38,7 @@ int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_bytes, const
         zs.next_in = (Bytef *)(comp + mem[i].in_off); zs.avail_in = mem[i].in_len; zs.next_out = d; zs.avail_out = L;
         if(inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); return -1; }
         inflateEnd(&zs);
+        if((uint32_t)crc32(0L, d, L) != mem[i].crc32) return -1;       /* as the device's k_crc32 */
         while(o + 4 <= L) {                                         /* the member's records, from its first byte */
             const uint32_t bs = u32(d + o); const uint8_t *r = d + o + 4; uint32_t lq, nc, k; int32_t rl = 0, tid, pos, endp;
             if(bs < 32 || (uint64_t)o + 4 + bs > L) break;
