@@ -21,7 +21,7 @@ $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldac
 $(B)/MethylDackel: methyldackel_amd/csrc/host/main.c $(B)/libmdk_extract.so
 	$(CC) $(CFLAGS) -Iinclude -o $@ methyldackel_amd/csrc/host/main.c -L$(B) -lmdk_extract -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
 
-tools: tools/_build/mdk_synth tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/piece_bench tools/_build/pin_probe tools/_build/feed_harness tools/_build/libmdk_piece_standin.so
+tools: tools/_build/mdk_synth tools/_build/mdk_replicate tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/piece_bench tools/_build/pin_probe tools/_build/feed_harness tools/_build/libmdk_piece_standin.so
 tools/_build/libmdk_piece_standin.so: tools/piece_standin.c include/mdk_hip.h
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -Wall -shared -fPIC -Iinclude -o $@ tools/piece_standin.c -lz
@@ -40,6 +40,9 @@ tools/_build/piece_bench: tools/piece_bench.c include/mdk_hip.h $(B)/libmdk_hip.
 tools/_build/mdk_calib: tools/mdk_calib.hip
 	@mkdir -p tools/_build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ tools/mdk_calib.hip
+tools/_build/mdk_replicate: tools/mdk_replicate.c
+	@mkdir -p tools/_build
+	$(CC) -O2 -g -Wall -o $@ tools/mdk_replicate.c -lz -lpthread
 tools/_build/mdk_synth: tools/mdk_synth.c
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -o $@ tools/mdk_synth.c -lz -lm -lpthread

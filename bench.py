@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--synth-args", default="", help="extra mdk_synth options, e.g. '--clean' (not the headline config)")
     ap.add_argument("--cpu-sample-length", type=int, default=32_000_000, help="bp of the same synthetic workload the CPU oracle is timed on")
     ap.add_argument("--large-sample-length", type=int, default=128_000_000, help="bp of the second, larger end-to-end sample (0 = skip)")
+    ap.add_argument("--xl-copies", type=int, default=4, help="the XL end-to-end sample = this many copies of the large sample as that many contigs (<= 1: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="the step is the pileup alone over resident segments (round 2's loop; for profiling that kernel)")
     ap.add_argument("--no-exchange", action="store_true", help="N ranks without the gather of site buffers to rank 0 (what the run falls back to when no communicator can be made)")
@@ -165,7 +166,7 @@ def main():
         if n_chunks < 2:
             b = chunk.raw
             cat = b"".join(C.string_at(b.range[i].ptr, b.range[i].bytes) for i in range(b.n_ranges))
-            offs = C.string_at(b.rec_off, 4 * b.n_records)
+            offs = np.asarray(mdk.raw_record_offsets(b), dtype=np.uint32).tobytes()
             keep_batches.append((b.tid, b.beg, b.end, b.n_records, b.woff, b.wlen, cat, offs))
         n_chunks += 1
     t_host = time.time() - t0
@@ -428,7 +429,7 @@ def main():
             def run_oracle(sp, name, thr, ck, runs):
                 d = work / f"co_{name}"; d.mkdir()
                 opts = ["-@", str(thr)] + (["--chunkSize", str(ck)] if ck else [])
-                r = median_run(lambda: subprocess.run([str(oracle), "extract", str(sp) + ".fa", str(sp) + ".bam"] + opts + extra + ["-o", "out"], check=True, capture_output=True, cwd=d, timeout=600), runs), d
+                r = median_run(lambda: subprocess.run([str(oracle), "extract", str(sp) + ".fa", str(sp) + ".bam"] + opts + extra + ["-o", "out"], check=True, capture_output=True, cwd=d, timeout=900), runs), d
                 log(f"[bench] oracle {name}: {r[0][1]}")
                 return r
 
@@ -437,7 +438,7 @@ def main():
                 for _ in range(runs):
                     time.sleep(0.3)            # (outside the clock) a back-to-back command otherwise waits for the previous process' GPU context to be torn down
                     t1 = time.perf_counter()
-                    r = mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=d, env=dict(env, MDK_HOST_PROFILE="1"), timeout=180)
+                    r = mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=d, env=dict(env, MDK_HOST_PROFILE="1"), timeout=300)
                     ts.append(time.perf_counter() - t1); rcs.append(r.returncode)
                     m = re.search(r"total ([0-9.]+)s; chunks prepared", r.stderr)          # the command's own clock, entry of extract_main to outputs closed
                     inner.append(float(m.group(1)) if m else None)
@@ -453,40 +454,84 @@ def main():
                 return n
 
             sp = sample(args.cpu_sample_length, "small")
-            chunk_all = max(50_000, args.cpu_sample_length // (4 * ncores))      # the reference's chunk-parallel workers need enough chunks to go round (outputs do not depend on --chunkSize)
+            # the CPU baseline is the BEST the CPU path does over a small sweep of worker threads x chunk size (one run each), then 3 runs at that
+            # setting; the reference's chunk-parallel workers need enough chunks to go round, and outputs do not depend on --chunkSize
             (t_single, ts_single), d_single = run_oracle(sp, "single", 1, None, 3)
-            (t_all, ts_all), d_all = run_oracle(sp, "allcore", ncores, chunk_all, 3)
+            sweep = []
+            for thr, ck in ((32, 250_000), (64, 50_000), (64, 250_000), (128, 1_000_000), (ncores, max(50_000, args.cpu_sample_length // (4 * ncores)))):
+                if thr > ncores:
+                    continue
+                (t1, _), _ = run_oracle(sp, f"sweep_{thr}_{ck}", thr, ck, 1)
+                sweep.append({"threads": thr, "chunk_size": ck, "seconds": t1})
+            best = min(sweep, key=lambda q: q["seconds"])
+            (t_all, ts_all), d_all = run_oracle(sp, "allcore", best["threads"], best["chunk_size"], 3)
             same = all((d_single / f).read_bytes() == (d_all / f).read_bytes() for f in os.listdir(d_single))
             calls = calls_of(d_single)
             t_g, ts_g, d_g, ok_g, in_g = run_ours(sp, "default", {})
             ident = ok_g and all((d_g / f).read_bytes() == (d_single / f).read_bytes() for f in os.listdir(d_single))
-            t_h, ts_h, d_h, ok_h, in_h = run_ours(sp, "hostinflate", {"MDK_HOST_INFLATE": "1"})
-            result["cpu_baseline"] = {"value": calls / t_all, "unit": "CpG calls/s", "cores": ncores, "kind": "port",
-                                      "sample": f"oracle/mdk_oracle extract -@ {ncores} --chunkSize {chunk_all} (C restatement of the reference with its chunk-parallel worker threads, extract.c:325-350,1479-1486; "
-                                                f"end to end from the BAM file: inflate, pileup, text) on a {args.cpu_sample_length} bp / {args.coverage}x sample of the same synthetic workload; 3 runs, median "
+            result["cpu_baseline"] = {"value": calls / t_all, "unit": "CpG calls/s", "cores": best["threads"], "kind": "port",
+                                      "sample": f"oracle/mdk_oracle extract -@ {best['threads']} --chunkSize {best['chunk_size']} -- the fastest of a sweep over worker threads x chunk size on this box's {ncores} hardware threads "
+                                                f"(C restatement of the reference with its chunk-parallel worker threads, extract.c:325-350,1479-1486; end to end from the BAM file: inflate with CRC32 check, pileup, text) "
+                                                f"on a {args.cpu_sample_length} bp / {args.coverage}x sample of the same synthetic workload; 3 runs, median "
                                                 f"{t_all:.2f} s, {calls} CpG calls; the reference binary itself cannot be built here (no htslib)",
-                                      "seconds": t_all, "runs": ts_all, "cpg_calls": calls, "identical_to_single_thread": bool(same),
+                                      "seconds": t_all, "runs": ts_all, "cpg_calls": calls, "identical_to_single_thread": bool(same), "host_threads": ncores, "sweep": sweep,
                                       "single_thread": {"value": calls / t_single, "seconds": t_single, "runs": ts_single, "cores": 1}}
             result["e2e_cli"] = {"seconds": t_g, "runs": ts_g, "value": calls / t_g, "unit": "CpG calls/s", "threads": int(threads), "protocol": "3 runs, median, whole-process wall clock (the CPU baseline's protocol)",
                                  "speedup_vs_cpu_baseline": t_all / t_g, "speedup_vs_single_thread": t_single / t_g, "identical_to_oracle": bool(ident),
-                                 "host_inflate_only_seconds": t_h, "host_inflate_only_runs": ts_h,
-                                 "inside_process_runs": in_g, "host_inflate_only_inside_process_runs": in_h,
+                                 "inside_process_runs": in_g, "bam_bytes": os.path.getsize(str(sp) + ".bam"),
                                  "note": "`MethylDackel extract` of this build on the same file, one process (start-up, HIP init, inflate on the host's threads and -- once the device is up -- on the device, "
-                                         "chunk preparation, H2D, kernels, D2H, text, teardown); host_inflate_only = MDK_HOST_INFLATE=1.  `seconds` is the parent's wall clock and includes the process exit, "
-                                         "which the driver ends either at once or after ~0.35 s (DESIGN.md 4); inside_process_runs = the command's own clock from entry to outputs closed"}
+                                         "chunk preparation, H2D, kernels, D2H, text, teardown).  `seconds` is the parent's wall clock and includes the process exit; "
+                                         "inside_process_runs = the command's own clock from entry to outputs closed"}
+            # the device inflate on the record: the 32 Mb sample's BGZF members through md_piece_* (tools/piece_bench: whole file in 64 MB pieces, three in
+            # flight, and the kernels alone on the largest resident piece, HIP events)
+            try:
+                pb = subprocess.run([str(REPO / "tools/_build/piece_bench"), str(sp) + ".bam", "64", "3", "0"], capture_output=True, text=True, timeout=300)
+                pj = json.loads(pb.stdout)
+                kv = pj["kernel_only"]["v0"]
+                inf_bytes = kv["comp_bytes"] + kv["out_bytes"]
+                result["inflate"] = {"workload": f"the {args.cpu_sample_length} bp sample's BAM: {pj['members']} BGZF members, {pj['file_MB']:.0f} MB -> {pj['inflated_MB']:.0f} MB",
+                                     "pipelined": {"GBps_compressed": pj["pass1"]["GBps_compressed"], "GBps_inflated": pj["pass1"]["GBps_inflated"], "seconds": pj["pass1"]["seconds"],
+                                                   "note": "whole file through md_piece_submit / md_piece_wait: staging copy, H2D of the compressed bytes, k_inflate, k_crc32, k_walk, digests back; 64 MB pieces, 3 in flight"},
+                                     "GBps_compressed": kv["GBps_compressed"], "GBps_inflated": kv["GBps_inflated"],
+                                     "roofline": {"kernel": "k_inflate", "bound": "hbm", "kernel_ms": kv["inflate_ms"], "algo_bytes_per_launch": inf_bytes, "achieved": inf_bytes / (kv["inflate_ms"] * 1e6), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": inf_bytes / (kv["inflate_ms"] * 1e6) / HBM_PEAK_GBS, "members_per_launch": pj["kernel_only"]["piece_members"],
+                                                  "note": "algorithmic bytes = compressed bytes read + inflated bytes written, one 64 MB piece per launch; the kernel is bound by one lane's dependent symbol decode per member, not by HBM (DESIGN.md 4)"},
+                                     "crc32_ms": kv["crc32_ms"], "walk_ms": kv["walk_ms"], "crc32_GBps": kv["out_bytes"] / (kv["crc32_ms"] * 1e6) if kv["crc32_ms"] > 0 else None}
+            except Exception as ex:
+                result["inflate"] = {"error": repr(ex)[:300]}
             if args.large_sample_length and headline:
                 spl = sample(args.large_sample_length, "large")
-                ck = max(50_000, args.large_sample_length // (4 * ncores))
-                (t_la, ts_la), d_la = run_oracle(spl, "large_allcore", ncores, ck, 3)
-                t_lg, ts_lg, d_lg, ok_lg, in_lg = run_ours(spl, "large_default", {})
-                t_lh, ts_lh, d_lh, ok_lh, in_lh = run_ours(spl, "large_hostinflate", {"MDK_HOST_INFLATE": "1"})
+                alt = (32, 250_000) if best["threads"] != 32 else (64, 250_000)
+                (t_alt, _), _ = run_oracle(spl, "large_alt", alt[0], alt[1], 1)
+                (t_la, ts_la), d_la = run_oracle(spl, "large_allcore", best["threads"], best["chunk_size"], 2)
+                cfg_l = {"threads": best["threads"], "chunk_size": best["chunk_size"]}
+                if t_alt < t_la:
+                    (t_la, ts_la), d_la = run_oracle(spl, "large_alt3", alt[0], alt[1], 2); ts_la = ts_la + [t_alt]; t_la = statistics.median(ts_la); cfg_l = {"threads": alt[0], "chunk_size": alt[1]}
+                t_lg, ts_lg, d_lg, ok_lg, in_lg = run_ours(spl, "large_default", {}, runs=5)
                 ident_l = ok_lg and all((d_lg / f).read_bytes() == (d_la / f).read_bytes() for f in os.listdir(d_la))
                 calls_l = calls_of(d_la)
-                result["e2e_large"] = {"sample_bp": args.large_sample_length, "bam_bytes": os.path.getsize(str(spl) + ".bam"), "cpg_calls": calls_l,
-                                       "cpu_all_cores_seconds": t_la, "cpu_runs": ts_la, "seconds": t_lg, "runs": ts_lg, "value": calls_l / t_lg, "unit": "CpG calls/s",
-                                       "speedup_vs_cpu_all_cores": t_la / t_lg, "identical_to_oracle": bool(ident_l), "host_inflate_only_seconds": t_lh, "host_inflate_only_runs": ts_lh,
-                                       "inside_process_runs": in_lg, "host_inflate_only_inside_process_runs": in_lh,
-                                       "protocol": "3 runs each, median, whole-process wall clock"}
+                bam_l = os.path.getsize(str(spl) + ".bam")
+                result["e2e_large"] = {"sample_bp": args.large_sample_length, "bam_bytes": bam_l, "cpg_calls": calls_l,
+                                       "cpu_all_cores_seconds": t_la, "cpu_runs": ts_la, "cpu_setting": cfg_l, "seconds": t_lg, "runs": ts_lg, "value": calls_l / t_lg, "unit": "CpG calls/s",
+                                       "speedup_vs_cpu_all_cores": t_la / t_lg, "identical_to_oracle": bool(ident_l),
+                                       "inside_process_runs": in_lg, "bam_GBps": bam_l / t_lg / 1e9,
+                                       "protocol": "CPU: the sweep's best setting and one alternative, the faster of them, median; this build: 5 runs, median; whole-process wall clock"}
+                if args.xl_copies > 1:
+                    # a sample large enough that start-up and exit are a small part of the run: K copies of the large sample as K contigs (tools/mdk_replicate)
+                    spx = data / f"xl_{args.large_sample_length}x{args.xl_copies}_{args.coverage}"
+                    if not Path(str(spx) + ".bam").exists():
+                        t1 = time.time()
+                        subprocess.run([str(REPO / "tools/_build/mdk_replicate"), str(spl), str(spx), str(args.xl_copies)], check=True, capture_output=True, timeout=600)
+                        log(f"[bench] xl sample written in {time.time() - t1:.1f} s")
+                    (t_xa, ts_xa), d_xa = run_oracle(spx, "xl_allcore", cfg_l["threads"], cfg_l["chunk_size"], 1)
+                    t_xg, ts_xg, d_xg, ok_xg, in_xg = run_ours(spx, "xl_default", {}, runs=3)
+                    ident_x = ok_xg and all((d_xg / f).read_bytes() == (d_xa / f).read_bytes() for f in os.listdir(d_xa))
+                    calls_x = calls_of(d_xa); bam_x = os.path.getsize(str(spx) + ".bam")
+                    result["e2e_xl"] = {"sample_bp": args.large_sample_length * args.xl_copies, "contigs": args.xl_copies, "bam_bytes": bam_x, "cpg_calls": calls_x,
+                                        "cpu_all_cores_seconds": t_xa, "cpu_runs": ts_xa, "cpu_setting": cfg_l, "seconds": t_xg, "runs": ts_xg, "value": calls_x / t_xg, "unit": "CpG calls/s",
+                                        "speedup_vs_cpu_all_cores": t_xa / t_xg, "identical_to_oracle": bool(ident_x), "inside_process_runs": in_xg,
+                                        "bam_GBps": bam_x / t_xg / 1e9, "bam_GBps_inside_process": [bam_x / q / 1e9 if q else None for q in in_xg],
+                                        "protocol": "CPU: one run at the large sample's setting; this build: 3 runs, median; whole-process wall clock"}
           except Exception as ex:            # a leg that fails or hangs (timeout) must not take the measured line with it
             result["legs_error"] = repr(ex)[:500]
             log(f"[bench] a CPU/end-to-end leg failed: {ex!r}")

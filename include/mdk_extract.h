@@ -72,6 +72,10 @@ void mdk_plan_prep_cfg(const mdk_plan *p, md_prep_cfg *cfg);
 int  mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c);
 /* the same when the chunk was uploaded to `slot` of `dev` and some of its records were inflated on the device (they are read back) */
 int  mdk_plan_host_prepare_from(mdk_plan *p, mdk_chunk *c, md_dev *dev, int slot);
+/* the host memory behind a mode-1 chunk's record ranges is no longer needed (its upload has completed: md_dev_upload_wait): the inflate
+ * teams may reuse it now instead of when the chunk is recycled.  The chunk stays valid otherwise; mdk_plan_host_prepare_from then reads
+ * all of its records back from the device. */
+int  mdk_plan_release_records(mdk_plan *p, const mdk_chunk *c);
 /* BGZF inflate of the plan's BAM on this device as well (include/mdk_hip.h md_piece_*): from now on pieces of the
  * file are inflated by whoever is free, a host inflate team or the device, and chunks may name device-resident ranges.  Only for
  * plans in device-preparation mode of the `extract` command; mdk_plan_detach_device must precede md_dev_close. */

@@ -128,16 +128,19 @@ typedef struct {
     int32_t no_pairing;           /* mbias: no overlap handler is installed (MBias.c:158-161) */
     int32_t perread;              /* perRead: a record is kept iff it STARTS inside the chunk and passes -R / -F / -q (perRead.c:178-183) */
 } md_prep_cfg;
-/* whole records back to back, each as in the file: uint32 block_size, then block_size bytes.  A range lies either in host memory
- * (d_rec_off == NULL; its records' offsets are the next n_records entries of the batch's rec_off array) or -- a run of members of
- * a piece inflated on the device (md_piece_*) -- in DEVICE memory: ptr and d_rec_off are device pointers, d_rec_off[i] - rec_delta is
- * the offset of the range's record i from ptr.  n_records must be filled in for every range as soon as one range is on the
- * device; a batch of host ranges only may leave it 0. */
-typedef struct { const uint8_t *ptr; uint64_t bytes; const uint32_t *d_rec_off; uint32_t n_records, rec_delta; } md_raw_range;
+/* whole records back to back, each as in the file: uint32 block_size, then block_size bytes.  Where the records of a range start is told in one
+ * of three ways:
+ *   d_rec_off != NULL   the range lies in DEVICE memory -- a run of members of a piece inflated on the device (md_piece_*): ptr and d_rec_off are
+ *                       device pointers, d_rec_off[i] - rec_delta is the offset of the range's record i from ptr;
+ *   h_rec_off != NULL   host memory with a table of its own (what the thread that inflated the bytes noted): h_rec_off[i] - rec_delta is the
+ *                       offset of record i from ptr (host memory, read before md_dev_upload_raw returns or asynchronously when it is staging memory);
+ *   neither             host memory; its records' offsets are the next n_records entries of the batch's rec_off array.
+ * n_records must be filled in for every range as soon as one range has a table of either kind; a batch without any may leave it 0. */
+typedef struct { const uint8_t *ptr; uint64_t bytes; const uint32_t *d_rec_off; uint32_t n_records, rec_delta; const uint32_t *h_rec_off; } md_raw_range;
 /* The candidate records of ONE chunk: everything the region query [beg,end) of the chunk's contig returns (pos < end,
  * bam_endpos > beg), in file order.  Host ranges hold exactly those; a range in device memory is a run of whole BGZF members and may hold
- * records of the neighbouring chunk or contig at its ends, which the preparation drops (it redoes the query per record).  rec_off[i] = offset of record i's block_size word in the concatenation of the ranges
- * (less than 4 GiB in total).  woff/wlen: the reference window the chunk fetches (extract.c:381), which the
+ * records of the neighbouring chunk or contig at its ends, which the preparation drops (it redoes the query per record).  rec_off = for the records
+ * of the ranges WITHOUT a table of their own, in order: offset of the record's block_size word in the concatenation of all ranges (less than 4 GiB in total).  woff/wlen: the reference window the chunk fetches (extract.c:381), which the
  * conversion-efficiency filter classifies inside.  Host-owned; valid until the slot is waited for. */
 typedef struct {
     int32_t tid; int64_t beg, end;
@@ -152,6 +155,8 @@ int  md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bits, int64_
  * (launch / download / wait / bench work on it).  md_dev_submit_raw = upload_raw + launch.  md_dev_download / md_dev_wait
  * return MDK_ERR_PREP_HOST when the preparation gave up on the chunk (see above). */
 int  md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b);
+/* waits until the copies md_dev_upload_raw (or md_dev_upload) queued for the slot have read their host memory, which may then be reused */
+int  md_dev_upload_wait(md_dev *h, int slot);
 int  md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b);
 /* the records of an uploaded slot back on the host, as the device holds them: the concatenation of the batch's ranges (bytes)
  * and every record's offset in it (rec_off[n_records]); for a chunk the device preparation gives up on (MDK_ERR_PREP_HOST)
@@ -383,9 +388,6 @@ void  md_host_register(md_dev *h, const void *ptr);
 /* register every staging block that is not registered yet, with `threads` threads; returns how many there were.  For the moment the device
  * comes up: the blocks filled until then would otherwise be registered one by one by the thread that uploads from them */
 int   md_host_register_all(md_dev *h, int threads);
-/* for a process about to END: give the pages of every staging block back to the system, from `threads` threads at once (contents are lost,
- * the blocks stay allocated and must not be uploaded from again) -- the kernel otherwise tears them down on one core at exit */
-void  md_host_trim(int threads);
 
 #ifdef __cplusplus
 }

@@ -57,7 +57,7 @@ class md_prep_cfg(C.Structure):
 
 
 class md_raw_range(C.Structure):
-    _fields_ = [("ptr", C.POINTER(C.c_uint8)), ("bytes", C.c_uint64), ("d_rec_off", C.POINTER(C.c_uint32)), ("n_records", C.c_uint32), ("rec_delta", C.c_uint32)]
+    _fields_ = [("ptr", C.POINTER(C.c_uint8)), ("bytes", C.c_uint64), ("d_rec_off", C.POINTER(C.c_uint32)), ("n_records", C.c_uint32), ("rec_delta", C.c_uint32), ("h_rec_off", C.POINTER(C.c_uint32))]
 
 
 class md_raw_batch(C.Structure):
@@ -139,18 +139,37 @@ class md_bench_run_result(C.Structure):
 COMM_ID_BYTES = 128
 md_comm_oob_fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)      # out-of-band all-gather for md_comm_open_rank_shared
 
+def raw_record_offsets(raw):
+    """offset, in the concatenation of the batch's ranges, of every record of an md_raw_batch whose ranges all lie in HOST memory: from each
+    range's own table (h_rec_off) or, for ranges without one, from the batch's rec_off array (include/mdk_hip.h md_raw_range)"""
+    out, o, hidx = [], 0, 0
+    tables = any(bool(raw.range[i].h_rec_off) or bool(raw.range[i].d_rec_off) for i in range(raw.n_ranges))
+    if not tables:
+        return [raw.rec_off[i] for i in range(raw.n_records)]
+    for i in range(raw.n_ranges):
+        r = raw.range[i]
+        if r.d_rec_off:
+            raise MdkError("raw_record_offsets: a range lies in device memory")
+        if r.h_rec_off:
+            out += [r.h_rec_off[k] - r.rec_delta + o for k in range(r.n_records)]
+        else:
+            out += [raw.rec_off[hidx + k] for k in range(r.n_records)]; hidx += r.n_records
+        o += r.bytes
+    return out
+
+
 HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_dev_download_group", "md_dev_reserve_contigs", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_rank_shared", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_result_header", "md_comm_result_send", "md_comm_result_recv", "md_dev_pci_bus_id",
-               "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned", "md_host_profile", "md_dev_profile_text", "md_host_register", "md_host_register_all", "md_host_trim",
-               "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep", "md_dev_bench_prep_rotate", "md_bench_set_prep",
+               "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned", "md_host_profile", "md_dev_profile_text", "md_host_register", "md_host_register_all",
+               "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_upload_wait", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep", "md_dev_bench_prep_rotate", "md_bench_set_prep",
                "md_dev_mbias_submit", "md_dev_mbias_submit_raw", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
                "md_dev_perread_submit", "md_dev_perread_download", "md_dev_perread_submit_raw", "md_dev_perread_download_raw", "md_dev_read_raw",
                "md_piece_create", "md_piece_destroy", "md_piece_submit", "md_piece_wait", "md_piece_read", "md_piece_read_records", "md_piece_bench", "md_piece_bench_crc"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_try_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len", "mdk_plan_regions", "mdk_plan_set_prep", "mdk_plan_set_hold", "mdk_plan_prep_cfg", "mdk_plan_host_prepare",
-                   "mdk_plan_host_prepare_from", "mdk_plan_attach_device", "mdk_plan_detach_device",
+                   "mdk_plan_host_prepare_from", "mdk_plan_release_records", "mdk_plan_attach_device", "mdk_plan_detach_device",
                    "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report",
                    "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread", "mdk_plan_emit_perread_raw", "mergeContext_main", "mdk_bind_to_device_node"]
 

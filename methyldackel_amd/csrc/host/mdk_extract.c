@@ -137,7 +137,7 @@ static void *collector_main(void *arg) {
 }
 
 /* the slabs the host teams filled while the runtime was still starting: registered with it now, next to the uploader instead of by it */
-static void *prereg_main(void *arg) { md_dev *dev = arg; (void)md_host_register_all(dev, 4); return NULL; }
+static void *prereg_main(void *arg) { md_dev *dev = arg; (void)md_host_register_all(dev, 1); return NULL; }
 
 /* opening the device on its own thread while the host pipeline already inflates: the handle, the room for the contigs, the
  * preparation's options */
@@ -151,7 +151,7 @@ static void *xopen_main(void *arg) {
 
 int extract_main(int argc, char *argv[]) {
     mdk_plan *p = NULL; md_dev *dev = NULL; xpipe *X = NULL; int rc, ret = 0, more = 1, i, g_i; xopen dop; pthread_t dth, cth, rth, preg; int dth_ok, cth_ok = 0, rth_ok = 0, preg_ok = 0; emitter em;
-    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_group = 0, w_ref = 0, ta; uint64_t n_chunks = 0; int32_t ref_t0, ref_t1;
+    double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_group = 0, w_ref = 0, w_rel = 0, ta; uint64_t n_chunks = 0; int32_t ref_t0, ref_t1;
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] entered at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
     { int rk = 0, wd = 1, m = ranks_from_env(&rk, &wd); if(m < 0) return -1; if(m > 0) return extract_ranks(argc, argv, rk, wd); }       /* one process per GPU (mdk_ranks.c) */
     if(argc > 2) hip_warm_up();
@@ -228,6 +228,15 @@ int extract_main(int argc, char *argv[]) {
         if(g->n) { g->state = G_LAUNCHED; X->n_up++; } else g->state = G_FREE;
         pthread_cond_broadcast(&X->cv);
         pthread_mutex_unlock(&X->mu);
+        /* once the group's records have crossed the link (a few ms: they were queued before the kernels), the staging memory they came from
+         * goes back to the inflate teams -- not when the results are in */
+        if(g->n && !getenv("MDK_NO_EARLY_RELEASE")) {
+            int last = -1;
+            for(i = 0; i < g->n; i++) if(g->launched[i] && g->ch[i].prep) last = i;
+            ta = now_s();
+            if(last >= 0 && md_dev_upload_wait(dev, g->slot[last]) == 0) for(i = 0; i < g->n; i++) if(g->launched[i] && g->ch[i].prep) (void)mdk_plan_release_records(p, &g->ch[i]);
+            w_rel += now_s() - ta;
+        }
     }
     if(ret) xp_fail(X, ret);
     pthread_mutex_lock(&X->mu); X->up_done = 1; X->ref_quit = 1; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
@@ -239,18 +248,10 @@ int extract_main(int argc, char *argv[]) {
     if(em.failed && !ret) ret = MDK_RC_OUTPUT;
     if(getenv("MDK_HOST_PROFILE")) { double rs = 0; uint64_t rc2 = 0, rb = 0; md_host_profile(&rs, &rc2, &rb); fprintf(stderr, "[mdk main] staging blocks registered: %" PRIu64 " (%.0f MB) in %.3fs; %" PRIu64 " chunks in %" PRIu64 " group launches\n", rc2, rb / 1048576.0, rs, n_chunks, X->n_up); }
     if(getenv("MDK_HOST_PROFILE")) { char pt[1024]; if(md_dev_profile_text(pt, sizeof(pt)) == 0) fprintf(stderr, "[mdk hip] host threads inside the device library: %s\n", pt); }
-    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, uploader: wait-for-chunk %.3fs wait-for-reference %.3fs wait-for-group %.3fs submit %.3fs; collector: download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_ref, w_group, w_sub, X->w_down, X->w_emit, now_s() - T0, X->n_host_prep);
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, uploader: wait-for-chunk %.3fs wait-for-reference %.3fs wait-for-group %.3fs submit %.3fs wait-for-uploads %.3fs; collector: download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_ref, w_group, w_sub, w_rel, X->w_down, X->w_emit, now_s() - T0, X->n_host_prep);
     if(ret == 0) mdk_plan_finish(p);
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f (resident %.0f MB, of which file-backed/shared %.0f MB)\n", ts.tv_sec + 1e-9 * ts.tv_nsec, rss_mb(0), rss_mb(1)); }
-    if(fast_exit_wanted()) {      /* the process ends here (the `MethylDackel` command): its GBs of staging memory go back from many threads, not from one core at exit */
-        double tt = now_s();
-        if(!getenv("MDK_NO_TRIM")) {
-            pipeline_stop(p); mdk_bam_stop(p->bam); (void)md_dev_sync(dev);       /* nobody fills or uploads from a staging block any more (after a whole file they have all left already) */
-            md_host_trim(16);
-        }
-        if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] staging memory given back in %.3fs (resident now %.0f MB)\n", now_s() - tt, rss_mb(0));
-        leave_fast(ret);
-    }
+    if(fast_exit_wanted()) leave_fast(ret);
     { double tc = now_s(), td;
       pthread_mutex_destroy(&X->mu); pthread_cond_destroy(&X->cv); free(X->ref_state); free(X);
       mdk_plan_detach_device(p);

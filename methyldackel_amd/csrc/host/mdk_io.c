@@ -217,13 +217,14 @@ static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status)
             for(i = 0; i < nb; i++) tot += blk[i].n_sum;
             if(s->cap_sum < tot + 1) { free(s->sum); s->cap_sum = tot + tot / 8 + 1024; s->sum = malloc(sizeof(mdk_rsum) * s->cap_sum); }
             if(s->cap_mem < nb) { free(s->mem); s->cap_mem = nb + 64; s->mem = malloc(sizeof(mdk_member) * (size_t)s->cap_mem); }
+            if(s->cap_off32 < tot + 1) { free(s->off32); s->cap_off32 = tot + tot / 8 + 1024; s->off32 = malloc(sizeof(uint32_t) * s->cap_off32); }
             s->n_mem = 0; s->n_sum = 0;
-            if(s->sum && s->mem) {
+            if(s->sum && s->mem && s->off32) {
                 for(i = 0; i < nb; i++) {
                     mdk_member *m = &s->mem[i];
                     m->off = (uint32_t)(blk[i].out - s->buf); m->len = blk[i].out_len; m->n_sum = blk[i].n_sum; m->sum0 = (uint32_t)o; m->ok = blk[i].ok && (blk[i].n_sum == 0 || job.sb[blk[i].th].v != NULL);
                     m->tid0 = blk[i].tid0; m->pos0 = blk[i].pos0; m->tidN = blk[i].tidN; m->posN = blk[i].posN; m->min_endp = blk[i].min_endp; m->max_endp = blk[i].max_endp; m->sorted = blk[i].sorted;
-                    if(m->ok && m->n_sum) memcpy(s->sum + o, job.sb[blk[i].th].v + blk[i].sum0, sizeof(mdk_rsum) * m->n_sum);
+                    if(m->ok && m->n_sum) { uint32_t k; memcpy(s->sum + o, job.sb[blk[i].th].v + blk[i].sum0, sizeof(mdk_rsum) * m->n_sum); for(k = 0; k < m->n_sum; k++) s->off32[o + k] = s->sum[o + k].off; }
                     if(m->ok) o += m->n_sum; else m->n_sum = 0;
                 }
                 s->n_mem = nb; s->n_sum = o;
@@ -355,7 +356,6 @@ static void inflaters_stop(mdk_bam *b) {
     if(b->gpu_started) { for(i = 0; i < b->n_gpu_teams; i++) pthread_join(b->gpu_th[i], NULL); b->gpu_started = 0; }
     b->inf_started = 0;
 }
-void mdk_bam_stop(mdk_bam *b) { if(b) inflaters_stop(b); }
 int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     int k;
     if(!b || !dev || b->dev) return -1;
@@ -367,7 +367,7 @@ int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     b->n_gpu_teams = k; b->gpu_started = 1;
     return 0;
 }
-static void slab_destroy(mdk_slab *s) { if(!s) return; if(s->piece) md_piece_destroy(s->piece); md_host_free(s->buf); free(s->sum); free(s->mem); free(s); }
+static void slab_destroy(mdk_slab *s) { if(!s) return; if(s->piece) md_piece_destroy(s->piece); md_host_free(s->buf); free(s->sum); free(s->off32); free(s->mem); free(s); }
 void mdk_bam_detach_device(mdk_bam *b) {
     int i;
     if(!b || !b->dev) return;
@@ -446,6 +446,8 @@ int mdk_bam_at_device(mdk_bam *b, mdk_slab **s, int *mi) {
 }
 void mdk_bam_dev_advance(mdk_bam *b) { if(b->cur && b->cur->piece && b->mem_i < b->cur->n_mem) { b->n_records += b->cur->mem[b->mem_i].n_sum; b->n_fast += b->cur->mem[b->mem_i].n_sum; b->mem_i++; } }
 
+/* the file could be opened but not read as a BAM: say why (a damaged BGZF member, a failed CRC32 check) before the caller's "Couldn't open" */
+static mdk_bam *open_fail(mdk_bam *b, const char *fn) { if(b->err[0]) fprintf(stderr, "[mdk] %s: %s\n", fn, b->err); mdk_bam_close(b); return NULL; }
 mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     mdk_bam *b = xcalloc(1, sizeof(*b)); int rc; uint32_t i; size_t o;
     if(!b) return NULL;
@@ -459,8 +461,11 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
         }
     }
     b->nthreads = nthreads < 1 ? 1 : nthreads;
-    b->max_alloc = b->nthreads * 2 + 8;           /* how far the inflaters may run ahead of the consumers, in slabs (~48 MB each) */
-    if(b->max_alloc > 48) b->max_alloc = 48;       /* the chunk slots hold ~2 slabs each, the queue 8, the teams 4: more only costs memory */
+    /* how far the host teams may run ahead of the consumers, in slabs (~27 MB inflated each: one piece of CCHUNK compressed bytes).  A dozen:
+     * every slab is registered with the runtime the first time it is uploaded from (1 ms), and what a process has registered costs the
+     * kernel ~0.13 s per GB when the process ends (profiles/r04d_*: 60 slabs made `extract` of a 2 GB BAM 0.45 s slower than 30 did).  The
+     * teams that find no slab wait; the device inflates what they do not get to. */
+    b->max_alloc = b->nthreads >= 8 ? 12 : b->nthreads + 4;
     if(getenv("MDK_SLAB_CAP")) b->max_alloc = atoi(getenv("MDK_SLAB_CAP")) > 1 ? atoi(getenv("MDK_SLAB_CAP")) : 2;
     pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL);
     b->n_teams = b->nthreads >= 32 ? 4 : b->nthreads >= 8 ? 2 : 1;
@@ -470,18 +475,18 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     if(getenv("MDK_INFLATE_TEAMS")) { b->n_teams = atoi(getenv("MDK_INFLATE_TEAMS")); if(b->n_teams < 1) b->n_teams = 1; if(b->n_teams > 8) b->n_teams = 8; }
     b->team_threads = (b->nthreads + b->n_teams - 1) / b->n_teams;
     inflaters_start(b);
-    if((rc = need(b, 12)) <= 0 || memcmp(b->cur->buf + b->off, "BAM\1", 4)) { mdk_bam_close(b); return NULL; }
+    if((rc = need(b, 12)) <= 0 || memcmp(b->cur->buf + b->off, "BAM\1", 4)) return open_fail(b, fn);
     b->l_text = le32(b->cur->buf + b->off + 4);
-    if(need(b, 12 + (size_t)b->l_text) <= 0) { mdk_bam_close(b); return NULL; }
+    if(need(b, 12 + (size_t)b->l_text) <= 0) return open_fail(b, fn);
     b->text = xmalloc((size_t)b->l_text + 1); memcpy(b->text, b->cur->buf + b->off + 8, b->l_text); b->text[b->l_text] = 0;
     b->n_targets = (int32_t)le32(b->cur->buf + b->off + 8 + b->l_text);
     b->off += 12 + (size_t)b->l_text;
     b->target_name = xcalloc((size_t)b->n_targets + 1, sizeof(char *)); b->target_len = xcalloc((size_t)b->n_targets + 1, sizeof(uint32_t));
     for(i = 0; i < (uint32_t)b->n_targets; i++) {
         uint32_t ln;
-        if(need(b, 4) <= 0) { mdk_bam_close(b); return NULL; }
+        if(need(b, 4) <= 0) return open_fail(b, fn);
         ln = le32(b->cur->buf + b->off);
-        if(need(b, 8 + (size_t)ln) <= 0) { mdk_bam_close(b); return NULL; }
+        if(need(b, 8 + (size_t)ln) <= 0) return open_fail(b, fn);
         o = b->off;
         b->target_name[i] = xmalloc((size_t)ln + 1); memcpy(b->target_name[i], b->cur->buf + o + 4, ln); b->target_name[i][ln] = 0;
         b->target_len[i] = le32(b->cur->buf + o + 4 + ln);

@@ -41,6 +41,7 @@ typedef struct { uint32_t off, len, n_sum; uint32_t sum0; int ok;     /* off, le
 struct md_piece;
 typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs;
                           mdk_rsum *sum; size_t n_sum, cap_sum; mdk_member *mem; int n_mem, cap_mem;
+                          uint32_t *off32; size_t cap_off32;        /* off32[i] = sum[i].off: the records' places as one array, which the device takes as it is (md_raw_range.h_rec_off) */
                           struct md_piece *piece; const uint8_t *d_buf; const uint32_t *d_rec_off; uint64_t d_bytes; uint32_t d_records; } mdk_slab;
 
 typedef struct mdk_bam {
@@ -98,8 +99,6 @@ void mdk_bam_detach_device(mdk_bam *b);
  * slab (use mdk_bam_peek_sum), or at the end of the data; <0 error.  mdk_bam_dev_advance consumes that member. */
 int mdk_bam_at_device(mdk_bam *b, mdk_slab **s, int *mi);
 void mdk_bam_dev_advance(mdk_bam *b);
-/* end the inflate teams (host and device) and wait for them; nothing is freed.  A seek starts them again. */
-void mdk_bam_stop(mdk_bam *b);
 /* make every blocked or future read return end-of-data (used to stop a reader thread) */
 void mdk_bam_abort(mdk_bam *b);
 /* 1 = record available, 0 = end of file, <0 = error (b->err) */

@@ -361,7 +361,7 @@ enum { S_FREE = 0, S_FILL, S_RAW, S_WORK, S_DONE, S_HELD };
  * records copied into the slot's own buffer -- straddlers carried over from the previous chunk (RG_COPY) --, or whole members of a
  * slab inflated on the device (RG_DEV; the device filters the members' records against the chunk itself). */
 enum { RG_HOST = 0, RG_COPY = 1, RG_DEV = 2 };
-typedef struct { int kind; mdk_slab *slab; size_t beg, end; uint64_t cat0; uint32_t n_rec; int m0, m1; } rrange;      /* cat0: offset of its first byte in the concatenation of the chunk's ranges */
+typedef struct { int kind; mdk_slab *slab; size_t beg, end; uint64_t cat0; uint32_t n_rec; int m0, m1; int tab; size_t tab0; } rrange;      /* cat0: offset of its first byte in the concatenation of the chunk's ranges; tab: a host range of whole members, its records are slab->off32[tab0 .. tab0 + n_rec) */
 typedef struct pslot {
     int state; mdk_chunk c;
     uint8_t *raw; size_t raw_len, raw_cap;                /* copied records: [u32 len][record bytes]... */
@@ -373,6 +373,8 @@ typedef struct pslot {
      * concatenation of the ranges; the slabs stay referenced until the chunk is recycled (the copies read them, and a chunk the
      * device gives up on is prepared from them by mdk_plan_host_prepare) */
     uint32_t *roff; size_t n_roff, cap_roff; md_raw_range *rr; int cap_rr; int hold_slabs, prepared, n_dev_rg;
+    int released;                                         /* the slabs behind the ranges were given back early (mdk_plan_release_records) */
+    int use_tab;                                          /* whole members of host slabs travel with the slab's own record table instead of an entry per record in roff (not perRead: its emitter looks the kept records up in roff) */
 } pslot;
 
 static int roff_push(pslot *sl, uint64_t off) {
@@ -428,7 +430,7 @@ static int dev_member(mdk_plan *p, pslot *sl, mdk_slab *ds, int mi, int32_t tid,
 static int reader_fill(mdk_plan *p, pslot *sl) {
     const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; int rc, fi, collect; mdk_rec r; size_t off; mdk_chunk *c = &sl->c;
     memset(c, 0, sizeof(*c)); sl->raw_len = 0; sl->n_rg = 0; sl->n_stream = 0; sl->win = NULL; sl->woff = sl->wlen = 0;
-    sl->n_roff = 0; sl->cat_len = 0; sl->prepared = 0; sl->hold_slabs = p->dev_prep; sl->n_dev_rg = 0;
+    sl->n_roff = 0; sl->cat_len = 0; sl->prepared = 0; sl->released = 0; sl->hold_slabs = p->dev_prep; sl->n_dev_rg = 0; sl->use_tab = p->dev_prep && !o->perread && !getenv("MDK_NO_RECTAB");
     /* extract.c:325-350 */
     c->index = p->bin++;
     tid = p->g_tid; beg = p->g_pos; end = (uint32_t)(beg + o->chunk_size);
@@ -524,10 +526,11 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
                 c->n_records_seen += n;
                 if(collect) {
                     size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL; size_t k, rend = (size_t)v[n - 1].off + 4 + v[n - 1].len;
-                    if(!(g && g->kind == RG_HOST && g->slab == cs && g->end == roff)) { g = rg_new(p, sl, RG_HOST, cs, roff); if(!g) return -5; }
+                    const size_t t0 = (size_t)(v - cs->sum); const int tab = sl->use_tab && cs->off32 != NULL;
+                    if(!(g && g->kind == RG_HOST && g->slab == cs && g->end == roff && g->tab == tab && (!tab || g->tab0 + g->n_rec == t0))) { g = rg_new(p, sl, RG_HOST, cs, roff); if(!g) return -5; g->tab = tab; g->tab0 = t0; }
                     g->end = rend; g->n_rec += (uint32_t)n; sl->cat_len = g->cat0 + (g->end - g->beg);
                     sl->n_stream += n;
-                    if(sl->hold_slabs) {
+                    if(sl->hold_slabs && !tab) {
                         const uint64_t base = g->cat0 - g->beg;
                         if(sl->n_roff + n > sl->cap_roff) { size_t nc = (sl->n_roff + n) * 2 + (1u << 18); if(grow((void **)&sl->roff, nc * sizeof(uint32_t))) return -5; sl->cap_roff = nc; }
                         for(k = 0; k < n; k++) sl->roff[sl->n_roff + k] = (uint32_t)(base + v[k].off);
@@ -549,7 +552,7 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
             c->n_records_seen++;
             if(q.endp > (int32_t)beg && collect) {          /* in place: extend the open range or start a new one */
                 size_t roff; mdk_slab *cs = mdk_bam_cur_slab(bam, &roff); rrange *g = sl->n_rg ? &sl->rg[sl->n_rg - 1] : NULL;
-                if(!(g && g->kind == RG_HOST && g->slab == cs && g->end == roff)) { g = rg_new(p, sl, RG_HOST, cs, roff); if(!g) return -5; }
+                if(!(g && g->kind == RG_HOST && g->slab == cs && g->end == roff && !g->tab)) { g = rg_new(p, sl, RG_HOST, cs, roff); if(!g) return -5; }
                 if(sl->hold_slabs && roff_push(sl, g->cat0 + (roff - g->beg))) return -5;
                 g->end = roff + 4 + q.len; g->n_rec++; sl->cat_len = g->cat0 + (g->end - g->beg);
                 sl->n_stream++;
@@ -618,9 +621,9 @@ static int describe_raw(mdk_plan *p, pslot *sl) {
     if(sl->n_rg + 1 > sl->cap_rr) { int nc = sl->n_rg + 8; if(grow((void **)&sl->rr, sizeof(md_raw_range) * (size_t)nc)) return -5; sl->cap_rr = nc; }
     for(g = 0; g < sl->n_rg; g++) {
         const rrange *q = &sl->rg[g]; md_raw_range *o = &sl->rr[g];
-        o->bytes = q->end - q->beg; o->n_records = q->n_rec; o->d_rec_off = NULL; o->rec_delta = 0;
+        o->bytes = q->end - q->beg; o->n_records = q->n_rec; o->d_rec_off = NULL; o->h_rec_off = NULL; o->rec_delta = 0;
         if(q->kind == RG_COPY) o->ptr = sl->raw + q->beg;
-        else if(q->kind == RG_HOST) o->ptr = q->slab->buf + q->beg;
+        else if(q->kind == RG_HOST) { o->ptr = q->slab->buf + q->beg; if(q->tab) { o->h_rec_off = q->slab->off32 + q->tab0; o->rec_delta = (uint32_t)q->beg; } }
         else { o->ptr = q->slab->d_buf + q->beg; o->d_rec_off = q->slab->d_rec_off + q->slab->mem[q->m0].sum0; o->rec_delta = (uint32_t)q->beg; }
         nrec += q->n_rec;
     }
@@ -795,15 +798,24 @@ int mdk_plan_host_prepare_from(mdk_plan *p, mdk_chunk *c, md_dev *dev, int slot)
     if(!p || !c || !p->started) return -1;
     sl = held_slot(p, c);
     if(!sl || !sl->hold_slabs) return -1;
-    if(!sl->prepared && sl->n_dev_rg) {
+    if(!sl->prepared && (sl->n_dev_rg || sl->released)) {
         uint64_t nb = sl->cat_len + 64; uint32_t nr = (uint32_t)c->raw.n_records + 1; rrange *g;
         if(nb > sl->raw_cap) { if(grow((void **)&sl->raw, nb)) return -5; sl->raw_cap = nb; }
         if(nr > sl->cap_roff) { if(grow((void **)&sl->roff, sizeof(uint32_t) * (size_t)nr)) return -5; sl->cap_roff = nr; }
         if(md_dev_read_raw(dev, slot, sl->raw, &nb, sl->roff, &nr)) return -2;
         slot_release_slabs(p, sl);
-        sl->raw_len = (size_t)nb; sl->n_roff = nr; sl->cat_len = 0; sl->n_dev_rg = 0;
+        sl->raw_len = (size_t)nb; sl->n_roff = nr; sl->cat_len = 0; sl->n_dev_rg = 0; sl->released = 0;
         g = rg_new(p, sl, RG_COPY, NULL, 0); if(!g) return -5;
         g->end = (size_t)nb; g->n_rec = nr; sl->cat_len = nb;
     }
     return mdk_plan_host_prepare(p, c);
+}
+
+int mdk_plan_release_records(mdk_plan *p, const mdk_chunk *c) {
+    pslot *sl;
+    if(!p || !c || !p->started) return -1;
+    sl = held_slot(p, c);
+    if(!sl || !sl->hold_slabs || sl->prepared) return -1;
+    if(sl->n_rg) { slot_release_slabs(p, sl); sl->released = 1; }
+    return 0;
 }

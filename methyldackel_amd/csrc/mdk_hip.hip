@@ -62,6 +62,63 @@ extern "C" int md_dev_profile_text(char *buf, int cap) {
     return 0;
 }
 
+// ---- carved device memory (DBuf, mdk_hip_internal.hpp) ----
+struct Arena { std::mutex mu; std::vector<char *> blocks; size_t cur = 0, used = 0; long live = 0; };       // cur: block being carved; used: bytes of it taken
+static Arena g_arena[16];
+static const bool g_arena_on = getenv("MDK_NO_ARENA") == nullptr;
+void *arena_take(size_t bytes) {
+    int dev = 0;
+    if(!g_arena_on || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Arena &A = g_arena[dev];
+    bytes = (bytes + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> lk(A.mu);
+    for(;;) {
+        if(A.cur < A.blocks.size() && A.used + bytes <= ARENA_BLOCK) { char *p = A.blocks[A.cur] + A.used; A.used += bytes; A.live++; return p; }
+        if(A.cur + 1 < A.blocks.size()) { A.cur++; A.used = 0; continue; }
+        char *b = nullptr;
+        if(hipMalloc((void **)&b, ARENA_BLOCK) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        A.blocks.push_back(b); A.cur = A.blocks.size() - 1; A.used = 0;
+    }
+}
+void arena_give(void *p) {
+    for(Arena &A : g_arena) {
+        std::lock_guard<std::mutex> lk(A.mu);
+        for(char *b : A.blocks) if((char *)p >= b && (char *)p < b + ARENA_BLOCK) {
+            if(--A.live == 0) { A.cur = 0; A.used = 0; while(A.blocks.size() > 2) { (void)hipFree(A.blocks.back()); A.blocks.pop_back(); } }      // nothing carved is in use: start over (a process that opens many handles in turn)
+            return;
+        }
+    }
+}
+// ... and the same for pinned host memory (HBuf); pinned memory belongs to no device
+struct HArena { std::mutex mu; std::vector<char *> blocks; size_t cur = 0, used = 0; long live = 0; };
+static HArena g_harena;
+void *harena_take(size_t bytes) {
+    if(!g_arena_on) return nullptr;
+    HArena &A = g_harena;
+    bytes = (bytes + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> lk(A.mu);
+    for(;;) {
+        if(A.cur < A.blocks.size() && A.used + bytes <= HARENA_BLOCK) { char *p = A.blocks[A.cur] + A.used; A.used += bytes; A.live++; return p; }
+        if(A.cur + 1 < A.blocks.size()) { A.cur++; A.used = 0; continue; }
+        char *b = nullptr;
+        if(hipHostMalloc((void **)&b, HARENA_BLOCK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        A.blocks.push_back(b); A.cur = A.blocks.size() - 1; A.used = 0;
+    }
+}
+void harena_give(void *p) {
+    HArena &A = g_harena;
+    std::lock_guard<std::mutex> lk(A.mu);
+    for(char *b : A.blocks) if((char *)p >= b && (char *)p < b + HARENA_BLOCK) {
+        if(--A.live == 0) { A.cur = 0; A.used = 0; while(A.blocks.size() > 2) { (void)hipHostFree(A.blocks.back()); A.blocks.pop_back(); } }
+        return;
+    }
+}
+static void arena_prime(int device) {          // the first block, while the caller is still starting up (md_dev_warm)
+    (void)device;
+    void *p = arena_take(256); if(p) arena_give(p);
+    p = harena_take(256); if(p) harena_give(p);
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernel parameters
 // ------------------------------------------------------------------------------------------------
@@ -695,7 +752,9 @@ extern "C" int md_dev_warm(int device) {
         if(g_stash_dev != device) { g_stash.clear(); g_stash_dev = device; }
         g_stash.push_back(s);
     }
-    if(mdk_prof_on()) fprintf(stderr, "[mdk hip] warm-up: runtime init + device count %.3fs, context (hipSetDevice + hipFree(0)) %.3fs, code object of the pileup kernels %.3fs, %d streams %.3fs\n", t1 - t0, t2 - t1, t3 - t2, WARM_STREAMS, mdk_now() - t3);
+    const double t4 = mdk_now();
+    arena_prime(device);
+    if(mdk_prof_on()) fprintf(stderr, "[mdk hip] warm-up: runtime init + device count %.3fs, context (hipSetDevice + hipFree(0)) %.3fs, code object of the pileup kernels %.3fs, %d streams %.3fs, first blocks of carved device / pinned memory %.3fs\n", t1 - t0, t2 - t1, t3 - t2, WARM_STREAMS, t4 - t3, mdk_now() - t4);
     return 0;
 }
 
@@ -764,6 +823,7 @@ extern "C" void md_dev_close(md_dev *h) {
         if(s.e0) (void)hipEventDestroy(s.e0); if(s.e1) (void)hipEventDestroy(s.e1); if(s.k0) (void)hipEventDestroy(s.k0); if(s.k1) (void)hipEventDestroy(s.k1);
     }
     for(hipStream_t st : h->streams) if(st) (void)hipStreamDestroy(st);
+    if(h->ref_stream) (void)hipStreamDestroy(h->ref_stream);
     h->d_status.release(); h->h_status.release();
     if(h->d_crc) (void)hipFree(h->d_crc);
     if(h->d_hist) (void)hipFree(h->d_hist);
@@ -799,13 +859,15 @@ extern "C" int md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int
     if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(reference)", e);
     e = hipMalloc((void **)&c, (size_t)len + 16);
     if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_NOMEM, "hipMalloc(reference codes)", e); }
-    HIPCHK(hipMemcpy(d, seq, (size_t)len, hipMemcpyHostToDevice));
+    // on a stream of its own: a contig can be uploaded (by another thread) while chunks of the contigs before it are worked on, and neither waits for the other
+    if(!h->ref_stream) HIPCHK(hipStreamCreateWithFlags(&h->ref_stream, hipStreamNonBlocking));
+    HIPCHK(hipMemcpyAsync(d, seq, (size_t)len, hipMemcpyHostToDevice, h->ref_stream));
     if(len > 0) {
         int64_t blocks = (len + WG - 1) / WG; if(blocks > 65536) blocks = 65536;
-        hipLaunchKernelGGL(k_classify, dim3((unsigned)blocks), dim3(WG), 0, 0, d, c, len);
+        hipLaunchKernelGGL(k_classify, dim3((unsigned)blocks), dim3(WG), 0, h->ref_stream, d, c, len);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipDeviceSynchronize());
     }
+    HIPCHK(hipStreamSynchronize(h->ref_stream));
     h->ref[tid] = d; h->refcode[tid] = c; h->reflen[tid] = len;
     return 0;
 }
@@ -823,8 +885,9 @@ extern "C" int md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs,
     if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(regions)", e);
     if(n) { e = hipMemcpy(d, runs, sizeof(md_region) * (size_t)n, hipMemcpyHostToDevice); if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_HIP, "hipMemcpy(regions)", e); } }
     int64_t blocks = (len + WG - 1) / WG; if(blocks > 65536) blocks = 65536;
-    if(len > 0) hipLaunchKernelGGL(k_mask_regions, dim3((unsigned)blocks), dim3(WG), 0, 0, h->refcode[tid], len, d, n);
-    e = hipGetLastError(); if(e == hipSuccess) e = hipDeviceSynchronize();
+    if(!h->ref_stream) HIPCHK(hipStreamCreateWithFlags(&h->ref_stream, hipStreamNonBlocking));
+    if(len > 0) hipLaunchKernelGGL(k_mask_regions, dim3((unsigned)blocks), dim3(WG), 0, h->ref_stream, h->refcode[tid], len, d, n);
+    e = hipGetLastError(); if(e == hipSuccess) e = hipStreamSynchronize(h->ref_stream);
     if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_HIP, "k_mask_regions", e); }
     // the runs stay resident: the device chunk preparation tests every read's span against them (common.c:432-439)
     if((size_t)tid >= h->d_runs.size()) { h->d_runs.resize(tid + 1, nullptr); h->n_runs.resize(tid + 1, 0); h->has_runs.resize(tid + 1, 0); }
@@ -854,8 +917,11 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     if(b->n_segs && (!b->seg || !b->blob)) return fail(MDK_ERR_ARG, "md_dev_upload: null array", hipSuccess);
     if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(g_err, sizeof(g_err), "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(s->stream));          // the slot's previous contents are being replaced
-    if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
+    if(s->busy) {                                     // the slot's previous contents are being replaced
+        HIPCHK(hipStreamSynchronize(s->stream));
+        if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
+    }
+    s->busy = true;
     s->fresh = true;
     if((uint64_t)b->blob_bytes >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_upload: more than 4 GiB of read payload in one chunk", hipSuccess);   // the dense-context kernel addresses payload bytes with 32 bits
     const int64_t span = b->end - b->beg;
@@ -1224,6 +1290,7 @@ extern "C" int md_dev_download(md_dev *h, int slot, md_sites *out) {
         nsites = md_sites_order(s->h_site.p, h->variant ? s->h_var.p : nullptr, s->h_seg.p, s->ntiles, dv.n_slots, s->h_sorted.p, h->variant ? s->h_vsorted.p : nullptr);
         if(nsites < 0) return fail(MDK_ERR_ARG, "md_dev_download: inconsistent tile segments", hipSuccess);
     }
+    s->busy = false;                                   // its stream has been waited for and nothing was queued since
     out->n_sites = nsites; out->site = s->h_sorted.p; out->var = h->variant ? s->h_vsorted.p : nullptr;
     return 0;
 }
@@ -1264,6 +1331,7 @@ extern "C" int md_dev_download_group(md_dev *h, const int *slots, int n, md_site
         }
         HIPCHK(hipStreamSynchronize(st));
     }
+    for(int i = 0; i < n; i++) ss[i]->busy = false;   // the stream has been waited for and nothing was queued since (a slot that reported an error included)
     ProfScope pf2(PF_DL_ORDER);
     for(int i = 0; i < n; i++) {
         Slot *s = ss[i]; if(rcs[i]) continue;
@@ -1455,21 +1523,6 @@ extern "C" int md_host_register_all(md_dev *h, int threads) {
     work();
     for(auto &t : th) t.join();
     return (int)todo.size();
-}
-// For a process about to END: the pages of every staging block go back to the system now, from `threads` threads at once (contents are lost,
-// the blocks stay allocated).  The kernel otherwise tears the address space down on one core when the process exits -- 37 ms per GB on the
-// MI355X box even with huge pages (profiles/r04a_e2e.txt), a third of a second for the slabs of a 2 GB BAM.
-extern "C" void md_host_trim(int threads) {
-    std::vector<HostBlock> all;
-    { std::unique_lock<std::mutex> lk(g_blocks_mu); while(std::any_of(g_blocks.begin(), g_blocks.end(), [](const HostBlock &b) { return b.state == 1; })) g_blocks_cv.wait(lk); all = g_blocks; for(HostBlock &b : g_blocks) if(b.state == 2) b.state = 0; }
-    if(threads < 1) threads = 1;
-    if(threads > 32) threads = 32;
-    std::atomic<size_t> next{0};
-    auto work = [&]() { for(;;) { const size_t i = next.fetch_add(1); if(i >= all.size()) break; if(all[i].state == 2) (void)hipHostUnregister(all[i].base); (void)madvise(all[i].base, all[i].len, MADV_DONTNEED); } };
-    std::vector<std::thread> th;
-    for(int i = 1; i < threads && (size_t)i < all.size(); i++) th.emplace_back(work);
-    work();
-    for(auto &t : th) t.join();
 }
 static std::atomic<int> g_want_pinned{1};
 extern "C" void md_host_set_pinned(int on) { g_want_pinned.store(on != 0); }

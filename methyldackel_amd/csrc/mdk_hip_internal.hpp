@@ -25,31 +25,45 @@ MDK_HIDDEN int fail(int code, const char *what, hipError_t e);
 
 struct TileEnt { int first, last; };     // segments [first,last) of the batch overlap the tile (one contiguous run: the batch is coordinate sorted)
 
+// Device buffers.  A hipMalloc costs the calling thread ~0.2 ms whatever its size, and a slot needs ten buffers the first time it is used
+// (two dozen slots: 50 ms of the thread that uploads): buffers below ARENA_MAX are carved out of 1 GiB blocks instead (one hipMalloc per
+// block, per device).  Carved memory is handed back only when the last carved buffer of the device is released -- then the blocks are
+// reused from their start --, and a buffer that grows takes a new piece: 288 GB of HBM make that a fair price.
+#define ARENA_BLOCK (1ull << 30)
+#define ARENA_MAX (256ull << 20)
+MDK_HIDDEN void *arena_take(size_t bytes);          // NULL: no room could be made (the caller falls back to hipMalloc)
+MDK_HIDDEN void arena_give(void *p);
 template <typename T> struct DBuf {
-    T *p = nullptr; size_t cap = 0;
+    T *p = nullptr; size_t cap = 0; bool carved = false;
     int need(size_t n) {
         if(n <= cap) return 0;
-        if(p) (void)hipFree(p);
-        p = nullptr; cap = 0;
+        release();
         size_t want = n + n / 4 + 64;
+        if(want * sizeof(T) < ARENA_MAX) { p = (T *)arena_take(want * sizeof(T)); if(p) { carved = true; cap = want; return 0; } }
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
-        if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc", e);
+        if(e != hipSuccess) { p = nullptr; return fail(MDK_ERR_NOMEM, "hipMalloc", e); }
         cap = want; return 0;
     }
-    void release() { if(p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if(p) { if(carved) arena_give(p); else (void)hipFree(p); } p = nullptr; cap = 0; carved = false; }
 };
+// pinned host buffers (results on their way back): a hipHostMalloc costs the calling thread ~1 ms, and every slot needs three the first time
+// its results are collected -- small ones are carved out of 32 MiB pinned blocks the same way
+#define HARENA_BLOCK (32ull << 20)
+#define HARENA_MAX (8ull << 20)
+MDK_HIDDEN void *harena_take(size_t bytes);
+MDK_HIDDEN void harena_give(void *p);
 template <typename T> struct HBuf {
-    T *p = nullptr; size_t cap = 0;
+    T *p = nullptr; size_t cap = 0; bool carved = false;
     int need(size_t n) {
         if(n <= cap) return 0;
-        if(p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
+        release();
         size_t want = n + n / 4 + 64;
+        if(want * sizeof(T) < HARENA_MAX) { p = (T *)harena_take(want * sizeof(T)); if(p) { carved = true; cap = want; return 0; } }
         hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
-        if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipHostMalloc", e);
+        if(e != hipSuccess) { p = nullptr; return fail(MDK_ERR_NOMEM, "hipHostMalloc", e); }
         cap = want; return 0;
     }
-    void release() { if(p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if(p) { if(carved) harena_give(p); else (void)hipHostFree(p); } p = nullptr; cap = 0; carved = false; }
 };
 
 // device chunk preparation (mdk_prep.hip)
@@ -87,12 +101,14 @@ struct Slot {
     md_site *b_site = nullptr; md_site_var *b_var = nullptr; md_tile_seg *b_seg = nullptr; int64_t b_cap_sites = 0, b_cap_tiles = 0;
     int n_segs = 0, n_reads = 0, ntiles = 0, tid = -1, tile = 0, lds_bytes = 0; int64_t beg = 0, end = 0; uint64_t read_bytes = 0;
     bool uploaded = false, launched = false; unsigned ring = 0;
+    bool busy = false;                 // work of this slot may still be running on its stream (uploaded or launched, results not collected yet): the next upload waits for the stream first
 };
 
 struct md_dev {
     int device; md_dev_cfg cfg; int tile, n_slots; bool variant; bool qw = false;
     std::vector<hipStream_t> streams;        // the streams the slots work on (cfg.n_streams of them, or one per slot)
-    std::mutex crc_mu; void *d_crc = nullptr;   // constants of k_crc32 (mdk_inflate.hip), made by the first piece    /* qw: dense contexts, a quarter of a wavefront per segment */
+    std::mutex crc_mu; void *d_crc = nullptr;   // constants of k_crc32 (mdk_inflate.hip), made by the first piece
+    hipStream_t ref_stream = nullptr;           // md_dev_set_reference works here, so that it neither waits for nor holds up the slots' streams    /* qw: dense contexts, a quarter of a wavefront per segment */
     std::vector<Slot> slots;
     std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
     DBuf<SlotStatus> d_status; HBuf<SlotStatus> h_status;

@@ -562,10 +562,10 @@ __global__ __launch_bounds__(256) void k_rebase(uint32_t *dst, const uint32_t *s
 // ------------------------------------------------------------------------------------------------
 // the H2D (host ranges) or D2D (ranges of a piece inflated on the device) copies of a chunk's records and of its record table
 static int copy_ranges(md_dev *h, Slot *s, const md_raw_batch *b) {
-    bool any_dev = false; uint64_t nrec_sum = 0;
-    for(int i = 0; i < b->n_ranges; i++) { if(b->range[i].d_rec_off) any_dev = true; nrec_sum += b->range[i].n_records; }
-    { uint64_t host_rec = 0; for(int i = 0; i < b->n_ranges; i++) if(!b->range[i].d_rec_off) host_rec += any_dev ? b->range[i].n_records : 0; if((any_dev ? host_rec : (uint64_t)b->n_records) && !b->rec_off) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null record table", hipSuccess); }
-    if(any_dev && nrec_sum != (uint64_t)b->n_records) return fail(MDK_ERR_ARG, "md_dev_upload_raw: with a device-resident range every range must carry its record count", hipSuccess);
+    bool any_tab = false; uint64_t nrec_sum = 0, loose = 0;
+    for(int i = 0; i < b->n_ranges; i++) { const md_raw_range &r = b->range[i]; if(r.d_rec_off || r.h_rec_off) any_tab = true; else loose += r.n_records; nrec_sum += r.n_records; }
+    if((any_tab ? loose : (uint64_t)b->n_records) && !b->rec_off) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null record table", hipSuccess);
+    if(any_tab && nrec_sum != (uint64_t)b->n_records) return fail(MDK_ERR_ARG, "md_dev_upload_raw: with a range that has its own record table every range must carry its record count", hipSuccess);
     uint64_t o = 0; uint32_t idx = 0, hidx = 0;
     for(int i = 0; i < b->n_ranges; i++) {
         const md_raw_range &r = b->range[i];
@@ -574,12 +574,19 @@ static int copy_ranges(md_dev *h, Slot *s, const md_raw_batch *b) {
             if(r.n_records) hipLaunchKernelGGL(k_rebase, dim3((r.n_records + 255) / 256), dim3(256), 0, s->stream, s->d_recoff.p + idx, r.d_rec_off, r.n_records, (uint32_t)o - r.rec_delta);
         } else {
             if(r.bytes) { host_block_ensure_registered(r.ptr); HIPCHK(hipMemcpyAsync(s->d_raw.p + o, r.ptr, (size_t)r.bytes, hipMemcpyHostToDevice, s->stream)); }
-            if(any_dev && r.n_records) HIPCHK(hipMemcpyAsync(s->d_recoff.p + idx, b->rec_off + hidx, sizeof(uint32_t) * (size_t)r.n_records, hipMemcpyHostToDevice, s->stream));
-            hidx += r.n_records;
+            if(r.h_rec_off) {          // the range's own table: as it is, then re-based where it lands
+                if(r.n_records) {
+                    HIPCHK(hipMemcpyAsync(s->d_recoff.p + idx, r.h_rec_off, sizeof(uint32_t) * (size_t)r.n_records, hipMemcpyHostToDevice, s->stream));
+                    hipLaunchKernelGGL(k_rebase, dim3((r.n_records + 255) / 256), dim3(256), 0, s->stream, s->d_recoff.p + idx, (const uint32_t *)(s->d_recoff.p + idx), r.n_records, (uint32_t)o - r.rec_delta);
+                }
+            } else {
+                if(any_tab && r.n_records) HIPCHK(hipMemcpyAsync(s->d_recoff.p + idx, b->rec_off + hidx, sizeof(uint32_t) * (size_t)r.n_records, hipMemcpyHostToDevice, s->stream));
+                hidx += r.n_records;
+            }
         }
         idx += r.n_records; o += r.bytes;
     }
-    if(!any_dev && b->n_records) { host_block_ensure_registered(b->rec_off); HIPCHK(hipMemcpyAsync(s->d_recoff.p, b->rec_off, sizeof(uint32_t) * (size_t)b->n_records, hipMemcpyHostToDevice, s->stream)); }
+    if(!any_tab && b->n_records) { host_block_ensure_registered(b->rec_off); HIPCHK(hipMemcpyAsync(s->d_recoff.p, b->rec_off, sizeof(uint32_t) * (size_t)b->n_records, hipMemcpyHostToDevice, s->stream)); }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -674,11 +681,12 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     if(b->n_records && !b->range) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null array", hipSuccess);
     if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
-    {
+    if(s->busy) {                                    // work of the slot's previous chunk may still be running (its results were not collected)
         ProfScope pf(PF_UP_SYNC);
         HIPCHK(hipStreamSynchronize(s->stream));
         if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
     }
+    s->busy = true;
     s->fresh = true;
     uint64_t total = 0;
     for(int i = 0; i < b->n_ranges; i++) total += b->range[i].bytes;
@@ -700,9 +708,17 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
             if(h->variant && s->d_var.need((size_t)span + 16)) return MDK_ERR_NOMEM;
         }
     }
-    { ProfScope pf(PF_UP_COPY); int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
+    { ProfScope pf(PF_UP_COPY); int rcc = copy_ranges(h, s, b); if(rcc) return rcc; HIPCHK(hipEventRecord(s->e1, s->stream)); }
     s->prep_pending = true;            // the preparation kernels are queued with the launch: alone (md_dev_launch) or with up to seven other chunks (md_dev_launch_group)
     s->uploaded = true;
+    return 0;
+}
+
+extern "C" int md_dev_upload_wait(md_dev *h, int slot) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !s->uploaded) return fail(MDK_ERR_ARG, "md_dev_upload_wait: slot not uploaded", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    if(s->raw_layout) HIPCHK(hipEventSynchronize(s->e1)); else HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
 
@@ -720,6 +736,7 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));
+    s->busy = true;
     s->pr_n = -1; s->uploaded = false; s->launched = false;
     uint64_t total = 0;
     for(int i = 0; i < b->n_ranges; i++) total += b->range[i].bytes;

@@ -143,7 +143,7 @@ static void walk_member(inflate_job *j, size_t i) {
 /* htslib inflates BGZF members with libdeflate when it is built with it (two to three times faster than zlib); the image has
  * the runtime library without its header, so it is bound by name here too -- the CPU baseline should not be slower than the
  * reference would be.  MDK_ZLIB_INFLATE=1 or a missing library leave zlib. */
-typedef struct { void *(*alloc)(void); int (*run)(void *, const void *, size_t, void *, size_t, size_t *); void (*release)(void *); } ldeflate_t;
+typedef struct { void *(*alloc)(void); int (*run)(void *, const void *, size_t, void *, size_t, size_t *); void (*release)(void *);  uint32_t (*crc)(uint32_t, const void *, size_t); } ldeflate_t;
 static ldeflate_t g_ld; static int g_ld_state;
 static void ldeflate_init(void) {
     void *so = getenv("MDK_ZLIB_INFLATE") ? NULL : dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
@@ -152,6 +152,7 @@ static void ldeflate_init(void) {
         g_ld.alloc = (void *(*)(void))dlsym(so, "libdeflate_alloc_decompressor");
         g_ld.run = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(so, "libdeflate_deflate_decompress");
         g_ld.release = (void (*)(void *))dlsym(so, "libdeflate_free_decompressor");
+        g_ld.crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(so, "libdeflate_crc32");
         if(g_ld.alloc && g_ld.run && g_ld.release) g_ld_state = 1;
     }
 }
@@ -162,6 +163,8 @@ static void *inflate_main(void *arg) {
         if(ld) {
             size_t got = 0;
             if(g_ld.run(ld, j->raw + j->moff[i] + j->mhdr[i], j->mlen[i] - j->mhdr[i] - 8, j->out + j->mout[i], j->misz[i], &got) != 0 || got != j->misz[i]) { j->bad = 1; break; }
+            /* htslib's bgzf_read_block checks every block's CRC32 against its trailer (with libdeflate's crc32 when it is built with it) */
+            if((g_ld.crc ? g_ld.crc(0, j->out + j->mout[i], j->misz[i]) : (uint32_t)crc32(0L, j->out + j->mout[i], j->misz[i])) != rd32(j->raw + j->moff[i] + j->mlen[i] - 8)) { j->bad = 1; break; }
             if(j->mcount) walk_member(j, i);
             continue;
         }
@@ -171,6 +174,7 @@ static void *inflate_main(void *arg) {
         if(inflateInit2(&zs, -15) != Z_OK) { j->bad = 1; return NULL; }
         if(inflate(&zs, Z_FINISH) != Z_STREAM_END) { inflateEnd(&zs); j->bad = 1; return NULL; }
         inflateEnd(&zs);
+        if((uint32_t)crc32(0L, j->out + j->mout[i], j->misz[i]) != rd32(j->raw + j->moff[i] + j->mlen[i] - 8)) { j->bad = 1; return NULL; }
         if(j->mcount) walk_member(j, i);
     }
     if(ld) g_ld.release(ld);

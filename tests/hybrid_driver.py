@@ -39,8 +39,9 @@ while (c := plan.next_chunk()) is not None:
     h = hashlib.sha1(); n = 0; o = 0; hidx = 0; host_bytes = []
     if not any_dev:
         cat = b"".join(C.string_at(raw.range[i].ptr, raw.range[i].bytes) for i in range(raw.n_ranges))
-        for i in range(raw.n_records):
-            off = raw.rec_off[i]; bs, = struct.unpack_from("<I", cat, off)
+        offs = mdk.raw_record_offsets(raw); assert len(offs) == raw.n_records
+        for off in offs:
+            bs, = struct.unpack_from("<I", cat, off)
             assert in_region(cat[off:off + 4 + bs], c), "host ranges hold the region query's records only"
             h.update(cat[off:off + 4 + bs]); n += 1
         assert sum(raw.range[i].bytes for i in range(raw.n_ranges)) == len(cat)
@@ -50,7 +51,7 @@ while (c := plan.next_chunk()) is not None:
             data = C.string_at(r.ptr, r.bytes) if r.bytes else b""
             covered = 0
             for k in range(r.n_records):
-                off = (r.d_rec_off[k] - r.rec_delta) if r.d_rec_off else (raw.rec_off[hidx + k] - o)
+                off = (r.d_rec_off[k] - r.rec_delta) if r.d_rec_off else (r.h_rec_off[k] - r.rec_delta) if r.h_rec_off else (raw.rec_off[hidx + k] - o)
                 bs, = struct.unpack_from("<I", data, off)
                 covered += 4 + bs
                 if in_region(data[off:off + 4 + bs], c):
@@ -60,7 +61,7 @@ while (c := plan.next_chunk()) is not None:
             assert covered == r.bytes, "a range holds exactly its records"
             if r.d_rec_off:
                 n_dev_ranges += 1
-            else:
+            elif not r.h_rec_off:
                 hidx += r.n_records
             o += r.bytes
     print(json.dumps({"index": c.index, "tid": c.tid, "beg": c.beg, "end": c.end, "n": n, "sha1": h.hexdigest()}))

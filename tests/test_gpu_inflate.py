@@ -156,7 +156,8 @@ def test_chunk_handed_back_to_the_host_with_device_resident_records(tmp_path):
     recs = []
     for i in range(6000):
         pos = rnd.randrange(0, 29800)
-        recs.append((pos, record(0, pos, 0, "100M", ref[pos:pos + 100], 30, qname="dup" if i % 300 == 0 else f"r{i}")))
+        dup = i % 300 == 0          # 20 records of one name, paired flags: the name's chain is walked (a lane keeps 16) -> the chunk goes back to the host
+        recs.append((pos, record(0, pos, 0x43 if dup else 0, "100M", ref[pos:pos + 100], 30, qname="dup" if dup else f"r{i}")))
     recs.sort(key=lambda r: r[0])
     text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrA\tLN:30000\n"
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chrA\0" + struct.pack("<i", 30000)
@@ -202,7 +203,8 @@ def test_handed_back_chunks_drop_the_neighbours_records(tmp_path):
         n = 6000 if tid == 0 else 900
         for i in range(n):
             pos = rnd.randrange(0, len(ref) - 120)
-            recs.append((tid, pos, record(tid, pos, 0, "100M", ref[pos:pos + 100], 30, qname=f"dup{tid}" if i % 10 == 0 else f"r{tid}_{i}")))
+            dup = i % 10 == 0
+            recs.append((tid, pos, record(tid, pos, 0x43 if dup else 0, "100M", ref[pos:pos + 100], 30, qname=f"dup{tid}" if dup else f"r{tid}_{i}")))
     recs.sort(key=lambda r: (r[0], r[1]))
     text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chrA\tLN:30000\n@SQ\tSN:chrB\tLN:2500\n"
     hdr = b"BAM\1" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", 2) + struct.pack("<i", 5) + b"chrA\0" + struct.pack("<i", 30000) + struct.pack("<i", 5) + b"chrB\0" + struct.pack("<i", 2500)
@@ -224,3 +226,36 @@ def test_handed_back_chunks_drop_the_neighbours_records(tmp_path):
     (tmp_path / "r.bam").write_bytes(bytes(out))
     od, gd = compare_cli(tmp_path, [str(tmp_path / "r.fa"), str(tmp_path / "r.bam"), "-q", "0", "--chunkSize", "2000"], env=dict(DEV, MDK_HOST_PROFILE="1"))
     assert fell_back(tmp_path) >= 2
+
+
+def stored_members_bam(raw, flip_member=None):
+    """the same BAM with every member re-written as STORED deflate blocks (level 0); optionally one payload byte of one member flipped, the
+    member's CRC32 and ISIZE left as they were: it still inflates to ISIZE bytes, but not to the bytes the trailer vouches for"""
+    out = bytearray()
+    for k, (io, il, isz) in enumerate(bgzf_members(raw)):
+        data = zlib.decompress(raw[io:io + il], wbits=-15) if isz else b""
+        c = zlib.compressobj(0, zlib.DEFLATED, -15); comp = bytearray(c.compress(data) + c.flush())
+        if flip_member is not None and k == flip_member:
+            assert len(comp) > 40 and isz
+            comp[20] ^= 0x5a                  # (5 bytes of stored-block header, then the bytes themselves)
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + bytes(comp) + struct.pack("<II", zlib.crc32(data), len(data))
+    return bytes(out)
+
+
+def test_a_byte_flipped_inside_a_stored_block_fails_the_crc32_check(tmp_path):
+    """What htslib verifies behind sam_itr_next (bgzf_read_block: CRC32 and ISIZE of every block): a damaged byte that raw inflate cannot
+    notice must stop the run on the host's inflate path and on the device's (k_crc32), and stops the oracle; the undamaged file passes"""
+    synth(tmp_path / "s", "-L", "120000", "-c", "20", "-s", "9")
+    raw = (tmp_path / "s.bam").read_bytes()
+    (tmp_path / "ok.bam").write_bytes(stored_members_bam(raw))
+    (tmp_path / "bad.bam").write_bytes(stored_members_bam(raw, flip_member=7))
+    compare_cli(tmp_path, [str(tmp_path / "s.fa"), str(tmp_path / "ok.bam")], env=DEV)
+    from conftest import run_oracle
+    (tmp_path / "o2").mkdir()
+    assert run_oracle([str(tmp_path / "s.fa"), str(tmp_path / "bad.bam"), "-o", "out"], cwd=tmp_path / "o2").returncode != 0
+    for name, env in (("device", DEV), ("host", {"MDK_HOST_INFLATE": "1"})):
+        d = tmp_path / name; d.mkdir()
+        r = mdk.run_cli([str(tmp_path / "s.fa"), str(tmp_path / "bad.bam"), "-o", "out"], cwd=d, env=env)
+        assert r.returncode != 0 and "CRC32" in r.stderr, (name, r.returncode, r.stderr[-800:])
+        r = mdk.run_cli([str(tmp_path / "s.fa"), str(tmp_path / "bad.bam"), "-o", "out"], cwd=d, env=dict(env, MDK_NO_CRC="1"))
+        assert r.returncode == 0, (name, "without the check the damage goes unnoticed", r.stderr[-800:])

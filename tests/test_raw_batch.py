@@ -41,8 +41,9 @@ def raw_chunks(args):
         assert c.prep == 1 and c.batch.n_segs == 0
         cat = b"".join(C.string_at(c.raw.range[i].ptr, c.raw.range[i].bytes) for i in range(c.raw.n_ranges))
         recs = []
-        for i in range(c.raw.n_records):
-            o = c.raw.rec_off[i]
+        offs = mdk.raw_record_offsets(c.raw)
+        assert len(offs) == c.raw.n_records
+        for o in offs:
             bs, = struct.unpack_from("<I", cat, o)
             recs.append(cat[o:o + 4 + bs])
         assert sum(len(r) for r in recs) == len(cat), "the ranges hold exactly the listed records"

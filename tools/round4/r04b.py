@@ -36,11 +36,20 @@ def ours(L, env, tag, reps=3, threads="64"):
             if l.startswith("[mdk"): say("   ", l[:700])
         if r.returncode: say(r.stderr[-1500:])
     say(f"== {L} [{tag}] walls {['%.3f' % w for w in walls]} median {sorted(walls)[len(walls) // 2]:.3f}")
+VAR = os.environ.get("R04_VARIANTS", "default,notrim,hostinflate").split(",")
 for L in sizes:
-    ours(L, {}, f"default{L}", 5)
-    ours(L, {"MDK_NO_TRIM": "1"}, f"notrim{L}", 3)
-    ours(L, {"MDK_NO_PREREG": "1"}, f"noprereg{L}", 2)
-    ours(L, {"MDK_HOST_INFLATE": "1"}, f"hostinflate{L}", 2)
-    ours(L, {"MDK_GPU_INFLATE_TEAMS": "4"}, f"gteams4_{L}", 2)
-    ours(L, {}, f"t32_{L}", 2, threads="32")
-    ours(L, {}, f"t128_{L}", 2, threads="128")
+    if "default" in VAR: ours(L, {}, f"default{L}", 5)
+    if "notrim" in VAR: ours(L, {"MDK_NO_TRIM": "1"}, f"notrim{L}", 3)
+    if "cap12" in VAR: ours(L, {"MDK_SLAB_CAP": "12"}, f"cap12_{L}", 3)
+    if "cap20" in VAR: ours(L, {"MDK_SLAB_CAP": "20"}, f"cap20_{L}", 3)
+    if "norelease" in VAR: ours(L, {"MDK_NO_EARLY_RELEASE": "1"}, f"norelease{L}", 3)
+    if "norectab" in VAR: ours(L, {"MDK_NO_RECTAB": "1"}, f"norectab{L}", 3)
+    if "cap24" in VAR: ours(L, {"MDK_SLAB_CAP": "24"}, f"cap24_{L}", 3)
+    if "cap8" in VAR: ours(L, {"MDK_SLAB_CAP": "8"}, f"cap8_{L}", 3)
+    if "noprereg" in VAR: ours(L, {"MDK_NO_PREREG": "1"}, f"noprereg{L}", 2)
+    if "hostinflate" in VAR: ours(L, {"MDK_HOST_INFLATE": "1"}, f"hostinflate{L}", 2)
+    if "gteams4" in VAR: ours(L, {"MDK_GPU_INFLATE_TEAMS": "4"}, f"gteams4_{L}", 2)
+    if "noarena" in VAR: ours(L, {"MDK_NO_ARENA": "1"}, f"noarena{L}", 2)
+    if "nocrc" in VAR: ours(L, {"MDK_NO_CRC": "1"}, f"nocrc{L}", 3)
+    if "t32" in VAR: ours(L, {}, f"t32_{L}", 2, threads="32")
+    if "t128" in VAR: ours(L, {}, f"t128_{L}", 2, threads="128")
