@@ -21,10 +21,13 @@ $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldac
 $(B)/MethylDackel: methyldackel_amd/csrc/host/main.c $(B)/libmdk_extract.so
 	$(CC) $(CFLAGS) -Iinclude -o $@ methyldackel_amd/csrc/host/main.c -L$(B) -lmdk_extract -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
 
-tools: tools/_build/mdk_synth tools/_build/mdk_replicate tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/piece_bench tools/_build/pin_probe tools/_build/feed_harness tools/_build/libmdk_piece_standin.so
+tools: tools/_build/mdk_synth tools/_build/mdk_replicate tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/piece_bench tools/_build/pin_probe tools/_build/feed_harness tools/_build/libmdk_piece_standin.so tools/_build/libmdk_dev_standin.so
 tools/_build/libmdk_piece_standin.so: tools/piece_standin.c include/mdk_hip.h
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -Wall -shared -fPIC -Iinclude -o $@ tools/piece_standin.c -lz
+tools/_build/libmdk_dev_standin.so: tools/dev_standin.c tools/piece_standin.c include/mdk_hip.h
+	@mkdir -p tools/_build
+	$(CC) -O2 -g -Wall -shared -fPIC -Iinclude -Itools -o $@ tools/dev_standin.c -lz -lpthread
 tools/_build/feed_harness: tools/feed_harness.c methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_io.h include/mdk_hip.h
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -Wall -Iinclude -Imethyldackel_amd/csrc/host -o $@ tools/feed_harness.c -lz -lpthread -ldl

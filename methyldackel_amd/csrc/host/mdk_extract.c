@@ -139,43 +139,40 @@ static void *collector_main(void *arg) {
 /* the slabs the host teams filled while the runtime was still starting: registered with it now, next to the uploader instead of by it */
 static void *prereg_main(void *arg) { md_dev *dev = arg; (void)md_host_register_all(dev, 1); return NULL; }
 
-/* opening the device on its own thread while the host pipeline already inflates: the handle, the room for the contigs, the
- * preparation's options */
-typedef struct { devopen_t d; mdk_plan *p; } xopen;
-static void *xopen_main(void *arg) {
-    xopen *o = arg; devopen_main(&o->d);
-    if(!o->d.rc) (void)md_dev_reserve_contigs(o->d.dev, o->p->bam->n_targets);
-    if(!o->d.rc && o->p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(o->p, &pc); md_dev_set_prep(o->d.dev, &pc); }
-    return NULL;
+/* opening the device on its own thread, from the moment the options are known: the inputs (BAM header, index, FASTA) are opened meanwhile */
+typedef struct { devopen_t d; pthread_t th; int started; } xopen;
+static void xopen_start(mdk_plan *p, void *arg) {
+    xopen *o = arg;
+    mdk_plan_dev_cfg(p, &o->d.cfg);
+    o->d.cfg.n_slots = MDK_NGROUPS * MDK_GROUP; o->d.cfg.n_streams = MDK_NGROUPS;
+    if(getenv("MDK_DEVICE")) o->d.device = atoi(getenv("MDK_DEVICE"));
+    o->started = pthread_create(&o->th, NULL, devopen_main, &o->d) == 0;
 }
 
 int extract_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; xpipe *X = NULL; int rc, ret = 0, more = 1, i, g_i; xopen dop; pthread_t dth, cth, rth, preg; int dth_ok, cth_ok = 0, rth_ok = 0, preg_ok = 0; emitter em;
+    mdk_plan *p = NULL; md_dev *dev = NULL; xpipe *X = NULL; int rc, ret = 0, more = 1, i, g_i; xopen dop; pthread_t cth, rth, preg; int cth_ok = 0, rth_ok = 0, preg_ok = 0; emitter em;
     double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_group = 0, w_ref = 0, w_rel = 0, ta; uint64_t n_chunks = 0; int32_t ref_t0, ref_t1;
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] entered at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
     { int rk = 0, wd = 1, m = ranks_from_env(&rk, &wd); if(m < 0) return -1; if(m > 0) return extract_ranks(argc, argv, rk, wd); }       /* one process per GPU (mdk_ranks.c) */
     if(argc > 2) hip_warm_up();
-    rc = mdk_plan_open(argc, argv, &p);
+    memset(&dop, 0, sizeof(dop));
+    rc = plan_open_ex(argc, argv, &p, xopen_start, &dop);
     t_open = now_s() - T0;
+    if(rc != 0 || !p) { if(dop.started) { pthread_join(dop.th, NULL); if(dop.d.dev) md_dev_close(dop.d.dev); } return rc; }
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] resident after plan open %.0f MB\n", rss_mb(0));
-    if(rc != 0 || !p) return rc;
     ref_t0 = p->o.region ? (int32_t)p->g_tid : 0; ref_t1 = (p->o.region && p->g_end) ? ref_t0 + 1 : p->bam->n_targets;       /* (before the reader moves the schedule) */
-    /* HIP initialisation takes 0.1-0.2 s: it runs while the host pipeline already inflates */
-    memset(&dop, 0, sizeof(dop)); dop.p = p;
-    mdk_plan_dev_cfg(p, &dop.d.cfg);
-    dop.d.cfg.n_slots = MDK_NGROUPS * MDK_GROUP; dop.d.cfg.n_streams = MDK_NGROUPS;
-    if(getenv("MDK_DEVICE")) dop.d.device = atoi(getenv("MDK_DEVICE"));
     /* the per-record work of a chunk (admission, strand, name pairing, CIGAR expansion) runs on the device; MDK_HOST_PREP=1 keeps
      * it on the host's chunk workers (the round-1 arrangement, and what a chunk the device gives up on falls back to) */
     if(!getenv("MDK_HOST_PREP")) mdk_plan_set_prep(p, 1);
     mdk_plan_set_hold(p, MDK_NGROUPS * MDK_GROUP + 2);
-    dth_ok = pthread_create(&dth, NULL, xopen_main, &dop) == 0;       /* no thread: open the device here, after the pipeline has started */
-    if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.d.dev) md_dev_close(dop.d.dev); mdk_plan_close(p); return -5; }
-    if(dth_ok) pthread_join(dth, NULL); else xopen_main(&dop);
+    if(!p->started && pipeline_start(p)) { if(dop.started) pthread_join(dop.th, NULL); if(dop.d.dev) md_dev_close(dop.d.dev); mdk_plan_close(p); return -5; }
+    if(dop.started) pthread_join(dop.th, NULL); else { xopen_start(p, &dop); if(dop.started) pthread_join(dop.th, NULL); else devopen_main(&dop.d); }
     t_dev = now_s() - T0;
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] resident at device ready %.0f MB\n", rss_mb(0));
     dev = dop.d.dev;
     if(dop.d.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.d.device, dop.d.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    (void)md_dev_reserve_contigs(dev, p->bam->n_targets);
+    if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
     if(p->dev_prep) mdk_plan_attach_device(p, dev);      /* from here on the device inflates pieces of the file too */
     X = calloc(1, sizeof(*X));
     if(X) X->ref_state = calloc((size_t)p->bam->n_targets + 1, sizeof(int));
@@ -209,7 +206,7 @@ int extract_main(int argc, char *argv[]) {
             if(rc == 0) { more = 0; break; }
             g->launched[g->n] = 0;
             if(!c->skipped) {
-                ta = now_s(); rc = ref_wait(X, c->tid); w_ref += now_s() - ta;
+                ta = now_s(); rc = c->prep ? 0 : ref_wait(X, c->tid); w_ref += now_s() - ta;       /* (raw records can cross the link before the contig's bases have) */
                 ta = now_s();
                 if(!rc) rc = c->prep ? md_dev_upload_raw(dev, g->slot[g->n], &c->raw) : md_dev_upload(dev, g->slot[g->n], &c->batch);
                 w_sub += now_s() - ta;
@@ -222,6 +219,10 @@ int extract_main(int argc, char *argv[]) {
         {   /* one launch per kernel for the group's chunks */
             int ls[MDK_GROUP], nl = 0;
             for(i = 0; i < g->n; i++) if(g->launched[i]) ls[nl++] = g->slot[i];
+            ta = now_s();
+            for(i = 0, rc = 0; i < g->n && !rc; i++) if(g->launched[i] && g->ch[i].prep) rc = ref_wait(X, g->ch[i].tid);
+            w_ref += now_s() - ta;
+            if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
             if(nl) { ta = now_s(); rc = md_dev_launch_group(dev, ls, nl); w_sub += now_s() - ta; if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; } }
         }
         pthread_mutex_lock(&X->mu);

@@ -247,7 +247,7 @@ static mdk_slab *dslab_get(mdk_bam *b, uint64_t seq) {          /* a free device
     }
     pthread_mutex_unlock(&b->mu);
     if(!s) return NULL;
-    if(!s->piece && md_piece_create(b->dev, &s->piece)) { free(s); return NULL; }
+    if(!s->piece && md_piece_create(b->dev, &s->piece)) { pthread_mutex_lock(&b->mu); b->n_dalloc--; snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu); free(s); return NULL; }
     s->refs = 1; s->beg = s->end = 0; s->n_mem = 0; s->n_sum = 0;
     return s;
 }
@@ -264,10 +264,12 @@ static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *stat
     mt = malloc(sizeof(*mt) * (size_t)nb);
     if(!mt) { mdk_slab_unref(b, s); *status = -1; return NULL; }
     for(i = 0; i < nb; i++) { mt[i].in_off = (uint64_t)(blk[i].in - c0); mt[i].in_len = blk[i].in_len; mt[i].out_len = blk[i].out_len; mt[i].out_off = o; mt[i].crc32 = blk[i].crc; mt[i].reserved = 0; o += blk[i].out_len; }
-    if(md_piece_submit(s->piece, b->gpu_stage[team], span, mt, nb) || md_piece_wait(s->piece, &info)) {
+    { int rs = md_piece_submit(s->piece, b->gpu_stage[team], span, mt, nb);
+      if(rs == MDK_ERR_NOMEM) { free(mt); mdk_slab_unref(b, s); *status = -1; return NULL; }      /* no device memory for this piece: the host's inflate takes it */
+      if(rs || md_piece_wait(s->piece, &info)) {
         pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu);
         free(mt); mdk_slab_unref(b, s); *status = -2; return NULL;
-    }
+      } }
     if(s->cap_mem < nb) { free(s->mem); s->cap_mem = nb + 64; s->mem = malloc(sizeof(mdk_member) * (size_t)s->cap_mem); }
     if(!s->mem) { s->cap_mem = 0; free(mt); mdk_slab_unref(b, s); *status = -1; return NULL; }
     for(i = 0; i < nb; i++) {
@@ -315,7 +317,11 @@ static void *inflater_main(void *arg) {
         if(st == 0) pc.seq = b->next_seq++; else b->io_status = st;
         pthread_mutex_unlock(&b->io_mu);
         if(st == 0) {
-            s = gt >= 0 ? inflate_piece_device(b, &pc, gt, &st) : inflate_piece(b, &pc, b->team_threads, &st); free(pc.cbuf); free(pc.blk);
+            /* a device team's piece goes to the host's inflate after all when it would inflate to more than the device addresses in one piece
+             * (4 GiB: a ratio above 64, low-complexity data) or when the device cannot take it for want of a resource (status -1) */
+            if(gt >= 0 && pc.total < 0xfff00000ull) { s = inflate_piece_device(b, &pc, gt, &st); if(!s && st == -1) { pthread_mutex_lock(&b->mu); const int q = b->quit; pthread_mutex_unlock(&b->mu); if(!q) { st = 0; s = inflate_piece(b, &pc, b->team_threads, &st); } } }
+            else s = inflate_piece(b, &pc, b->team_threads, &st);
+            free(pc.cbuf); free(pc.blk);
             /* the piece's pages of the file mapping are done with (inflated, or copied to the device's staging block): unmapped here, piece by piece
              * and on many threads, they are not left for the kernel to walk on one core when the process ends (they stay in the page cache) */
             if(b->map && pc.map_end > pc.map_beg) { const size_t a = (pc.map_beg + 4095) & ~(size_t)4095, e = pc.map_end & ~(size_t)4095; if(e > a) (void)madvise((void *)(b->map + a), e - a, MADV_DONTNEED); }
@@ -360,17 +366,21 @@ int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     int k;
     if(!b || !dev || b->dev) return -1;
     if(n_teams < 1) n_teams = 1;
-    if(n_teams > 4) n_teams = 4;
+    if(n_teams > 6) n_teams = 6;
+    pthread_mutex_lock(&b->life_mu);                              /* (the reader thread may be inside a seek, which stops and restarts every team) */
     b->dev = dev; b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + 4;
-    if(!b->inf_started) return 0;                                 /* (a seek restarts every team) */
-    for(k = 0; k < n_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } }
-    b->n_gpu_teams = k; b->gpu_started = 1;
+    if(b->inf_started) {
+        for(k = 0; k < n_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } }
+        b->n_gpu_teams = k; b->gpu_started = 1;
+    }
+    pthread_mutex_unlock(&b->life_mu);
     return 0;
 }
 static void slab_destroy(mdk_slab *s) { if(!s) return; if(s->piece) md_piece_destroy(s->piece); md_host_free(s->buf); free(s->sum); free(s->off32); free(s->mem); free(s); }
 void mdk_bam_detach_device(mdk_bam *b) {
     int i;
     if(!b || !b->dev) return;
+    pthread_mutex_lock(&b->life_mu);
     /* the device teams end; slabs they made that are still queued or held are destroyed with the reader (mdk_bam_close) or here */
     pthread_mutex_lock(&b->mu); b->quit = 1; if(!b->inf_done) b->inf_done = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
     if(b->gpu_started) { for(i = 0; i < b->n_gpu_teams; i++) pthread_join(b->gpu_th[i], NULL); b->gpu_started = 0; }
@@ -382,8 +392,9 @@ void mdk_bam_detach_device(mdk_bam *b) {
     b->n_dpool = 0;
     if(b->cur && b->cur->piece) { slab_destroy(b->cur); b->cur = NULL; }
     pthread_mutex_unlock(&b->mu);
-    for(i = 0; i < 4; i++) { md_host_free(b->gpu_stage[i]); b->gpu_stage[i] = NULL; b->gpu_stage_cap[i] = 0; }
+    for(i = 0; i < 6; i++) { md_host_free(b->gpu_stage[i]); b->gpu_stage[i] = NULL; b->gpu_stage_cap[i] = 0; }
     b->dev = NULL; b->n_gpu_teams = 0;
+    pthread_mutex_unlock(&b->life_mu);
 }
 
 /* scanner side: next inflated slab (blocking); NULL at end of data or on error (b->inf_done < 0) */
@@ -467,7 +478,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
      * teams that find no slab wait; the device inflates what they do not get to. */
     b->max_alloc = b->nthreads >= 8 ? 12 : b->nthreads + 4;
     if(getenv("MDK_SLAB_CAP")) b->max_alloc = atoi(getenv("MDK_SLAB_CAP")) > 1 ? atoi(getenv("MDK_SLAB_CAP")) : 2;
-    pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL);
+    pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_mutex_init(&b->life_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL);
     b->n_teams = b->nthreads >= 32 ? 4 : b->nthreads >= 8 ? 2 : 1;
     if(getenv("MDK_DEVICE_INFLATE_ONLY")) { b->host_leaves = 1; b->n_teams = 1; }
     b->gpu_piece_bytes = GCHUNK;
@@ -504,12 +515,12 @@ void mdk_bam_close(mdk_bam *b) {
     for(i = 0; i < MDK_READY; i++) if(b->ready[i]) slab_destroy(b->ready[i]);
     for(i = 0; i < b->n_pool; i++) slab_destroy(b->pool[i]);
     for(i = 0; i < b->n_dpool; i++) slab_destroy(b->dpool[i]);
-    for(i = 0; i < 4; i++) md_host_free(b->gpu_stage[i]);
+    for(i = 0; i < 6; i++) md_host_free(b->gpu_stage[i]);
     free(b->pool); free(b->dpool);
     if(b->f) fclose(b->f);
     if(b->target_name) for(i = 0; i < b->n_targets; i++) free(b->target_name[i]);
     free(b->target_name); free(b->target_len); free(b->text); if(b->map) munmap((void *)b->map, b->map_len); else free(b->cbuf);
-    pthread_mutex_destroy(&b->mu); pthread_mutex_destroy(&b->io_mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool);
+    pthread_mutex_destroy(&b->mu); pthread_mutex_destroy(&b->io_mu); pthread_mutex_destroy(&b->life_mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool);
     free(b);
 }
 
@@ -642,15 +653,17 @@ uint64_t mdk_bai_start(const mdk_bai *x, int32_t tid, int64_t beg) {
 
 int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
     int i;
+    pthread_mutex_lock(&b->life_mu);
     inflaters_stop(b);
     pthread_mutex_lock(&b->mu);
     for(i = 0; i < MDK_READY; i++) if(b->ready[i]) { mdk_slab *q = b->ready[i]; b->ready[i] = NULL; q->refs = 1; pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, q); pthread_mutex_lock(&b->mu); }
     b->n_ready = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
     pthread_mutex_unlock(&b->mu);
     if(b->cur) { mdk_slab_unref(b, b->cur); b->cur = NULL; }
-    if(b->map) { if((size_t)(voffset >> 16) > b->map_len) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; } b->map_pos = (size_t)(voffset >> 16); }
-    else if(fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET)) { snprintf(b->err, sizeof(b->err), "seek failed"); return -2; }
+    if(b->map) { if((size_t)(voffset >> 16) > b->map_len) { snprintf(b->err, sizeof(b->err), "seek failed"); pthread_mutex_unlock(&b->life_mu); return -2; } b->map_pos = (size_t)(voffset >> 16); }
+    else if(fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET)) { snprintf(b->err, sizeof(b->err), "seek failed"); pthread_mutex_unlock(&b->life_mu); return -2; }
     inflaters_start(b);
+    pthread_mutex_unlock(&b->life_mu);
     {
         int rc = need(b, (size_t)(voffset & 0xffff) + 1);
         if(rc < 0) return rc;

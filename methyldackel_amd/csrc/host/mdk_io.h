@@ -51,7 +51,7 @@ typedef struct mdk_bam {
      * and cheap), inflates it with its share of the threads while another team is already reading the following piece,
      * and queues the slab when its turn comes (seq order) */
     pthread_t inf_th[8]; int n_teams, team_threads, inf_started;
-    pthread_mutex_t mu, io_mu; pthread_cond_t cv_q, cv_pool;
+    pthread_mutex_t mu, io_mu, life_mu; pthread_cond_t cv_q, cv_pool;      /* life_mu: starting / stopping the teams (a seek by the reader thread vs. mdk_bam_attach_device by the caller's) */
     uint64_t next_seq; int io_status;               /* (io_mu) pieces handed out; 0 reading, 1 end of file, <0 error */
     /* (mu) finished slabs wait in ready[seq % MDK_READY] until the scanner has taken every earlier one: a team that finishes early
      * goes on with its next piece instead of waiting for its turn (device pieces are several times larger than host pieces) */
@@ -60,7 +60,7 @@ typedef struct mdk_bam {
     int inf_done, quit, host_leaves, header_done; size_t gpu_piece_bytes;
     /* teams that inflate on the device (mdk_bam_attach_device): each stages a piece of the file in registered memory and hands it
      * to the device library (md_piece_*); they share the piece counter with the host teams */
-    struct md_dev *dev; pthread_t gpu_th[4]; int n_gpu_teams, gpu_started; uint8_t *gpu_stage[4]; size_t gpu_stage_cap[4];
+    struct md_dev *dev; pthread_t gpu_th[6]; int n_gpu_teams, gpu_started; uint8_t *gpu_stage[6]; size_t gpu_stage_cap[6];
     mdk_slab **dpool; int n_dpool, cap_dpool, n_dalloc, max_dalloc; uint64_t n_dev_pieces, n_host_pieces, n_materialized;
     mdk_slab **pool; int n_pool, cap_pool, n_alloc, max_alloc;
     uint8_t *cbuf; size_t ccap, clen; int file_eof;

@@ -354,6 +354,7 @@ region:
 int mdk_plan_attach_device(mdk_plan *p, md_dev *dev) {
     if(!p || !dev || !p->bam) return -1;
     if(!p->dev_prep || p->o.mbias || p->o.perread || getenv("MDK_HOST_INFLATE")) return 0;
+    if(p->bai && p->shard_world > 1) return 0;      /* a rank of a sharded run seeks before every chunk of its own: a 64 MB device piece per seek would be thrown away with the next */
     return mdk_bam_attach_device(p->bam, dev, getenv("MDK_GPU_INFLATE_TEAMS") ? atoi(getenv("MDK_GPU_INFLATE_TEAMS")) : 3);
 }
 void mdk_plan_detach_device(mdk_plan *p) {
@@ -362,7 +363,10 @@ void mdk_plan_detach_device(mdk_plan *p) {
     mdk_bam_detach_device(p->bam);
 }
 
-int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
+int mdk_plan_open(int argc, char *argv[], mdk_plan **out) { return plan_open_ex(argc, argv, out, NULL, NULL); }
+/* after_options: called once the command line has been parsed and checked, before the inputs are opened (extract_main starts opening the
+ * device there: what the device needs to know are options, and the inputs take another 0.1 s) */
+MDK_LOCAL int plan_open_ex(int argc, char *argv[], mdk_plan **out, void (*after_options)(mdk_plan *, void *), void *ctx) {
     static const struct option longopts[] = {
         {"opref", required_argument, 0, 'o'}, {"fraction", no_argument, 0, 'f'}, {"counts", no_argument, 0, 'c'}, {"logit", no_argument, 0, 'm'},
         {"minDepth", required_argument, 0, 'd'}, {"noCpG", no_argument, 0, O_NOCPG}, {"CHG", no_argument, 0, O_CHG}, {"CHH", no_argument, 0, O_CHH},
@@ -463,6 +467,7 @@ int mdk_plan_open(int argc, char *argv[], mdk_plan **out) {
         return rc;
     }
 
+    if(after_options) after_options(p, ctx);
     { int rc = plan_attach_inputs(p, argv, optind); if(rc) return rc; }
     *out = p;
     return 0;

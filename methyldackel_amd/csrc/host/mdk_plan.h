@@ -133,6 +133,7 @@ typedef struct {
 typedef struct { int device; md_dev_cfg cfg; md_dev *dev; int rc; char err[512]; } devopen_t;
 
 MDK_LOCAL void plan_free(mdk_plan *p);
+MDK_LOCAL int plan_open_ex(int argc, char *argv[], mdk_plan **out, void (*after_options)(mdk_plan *, void *), void *ctx);
 MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional);
 MDK_LOCAL void parse_bounds(const char *arg, int *dst);
 MDK_LOCAL void bb_free(batchbuf *b);

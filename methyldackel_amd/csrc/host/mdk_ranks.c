@@ -5,7 +5,7 @@
  * uploads shard with the GPUs: csrc/host/mdk_pipeline.c reader_fill), computes them on its GPU, and the per-interval site buffers
  * travel to rank 0, which alone writes the files, in schedule order (the reference's ordered flush, extract.c:514-535).
  *
- * Launch: N processes with MDK_RANK / MDK_WORLD (or torchrun's RANK / WORLD_SIZE), MASTER_ADDR (default 127.0.0.1) and MASTER_PORT;
+ * Launch: N processes with MDK_RANK / MDK_WORLD (or, with MDK_TORCHRUN=1, torchrun's RANK / WORLD_SIZE), MASTER_ADDR (default 127.0.0.1) and MASTER_PORT;
  * LOCAL_RANK (or MDK_DEVICE) picks the GPU.  tools/extract_ranks.sh starts them on one node.
  *   control channel  one TCP connection from every rank to rank 0: the bootstrap (who sits on which device, the RCCL id) and, per
  *                    chunk, a 24-byte header with the sizes and the chunk's status;
@@ -29,7 +29,7 @@ static int rd_all(int fd, void *b, size_t n) { char *p = b; while(n) { ssize_t k
 
 static void ranks_close(ranks_t *R) { int i; if(!R->fd) return; for(i = 0; i < R->world; i++) if(R->fd[i] >= 0) close(R->fd[i]); free(R->fd); R->fd = NULL; }
 static int ranks_open(ranks_t *R) {
-    const char *addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1"; const int port = getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) : 29517;
+    const char *addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1"; const int port = getenv("MDK_PORT") ? atoi(getenv("MDK_PORT")) : getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + (getenv("MDK_WORLD") ? 0 : 1) : 29517;      /* under torchrun MASTER_PORT is the launcher's own store: the ranks meet one port above it */
     int i, one = 1;
     R->fd = malloc(sizeof(int) * (size_t)R->world); if(!R->fd) return -1;
     for(i = 0; i < R->world; i++) R->fd[i] = -1;
@@ -65,10 +65,11 @@ static int ranks_open(ranks_t *R) {
     return 0;
 }
 
-/* which ranks mode the environment asks for: MDK_WORLD/MDK_RANK, or torchrun's WORLD_SIZE/RANK together with MASTER_PORT */
+/* which ranks mode the environment asks for: MDK_WORLD/MDK_RANK, or -- only when MDK_TORCHRUN=1 says that this command IS the torchrun worker --
+ * torchrun's WORLD_SIZE/RANK.  (A command that merely inherits a torchrun worker's environment, e.g. started by one, runs alone.) */
 MDK_LOCAL int ranks_from_env(int *rank, int *world) {
     const char *w = getenv("MDK_WORLD"), *r = getenv("MDK_RANK");
-    if(!w && getenv("WORLD_SIZE") && getenv("RANK") && getenv("MASTER_PORT") && !getenv("MDK_NO_RANKS")) { w = getenv("WORLD_SIZE"); r = getenv("RANK"); }
+    if(!w && getenv("MDK_TORCHRUN") && getenv("WORLD_SIZE") && getenv("RANK") && getenv("MASTER_PORT") && !getenv("MDK_NO_RANKS")) { w = getenv("WORLD_SIZE"); r = getenv("RANK"); }
     if(!w || atoi(w) < 2) return 0;
     *world = atoi(w); *rank = r ? atoi(r) : 0;
     if(*rank < 0 || *rank >= *world || *world > 1024) { fprintf(stderr, "[mdk] bad rank %d of %d\n", *rank, *world); return -1; }

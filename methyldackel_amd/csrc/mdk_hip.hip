@@ -860,7 +860,7 @@ extern "C" int md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int
     e = hipMalloc((void **)&c, (size_t)len + 16);
     if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_NOMEM, "hipMalloc(reference codes)", e); }
     // on a stream of its own: a contig can be uploaded (by another thread) while chunks of the contigs before it are worked on, and neither waits for the other
-    if(!h->ref_stream) HIPCHK(hipStreamCreateWithFlags(&h->ref_stream, hipStreamNonBlocking));
+    if(!h->ref_stream && !(h->ref_stream = stream_take(h->device))) return fail(MDK_ERR_HIP, "hipStreamCreateWithFlags", hipGetLastError());
     HIPCHK(hipMemcpyAsync(d, seq, (size_t)len, hipMemcpyHostToDevice, h->ref_stream));
     if(len > 0) {
         int64_t blocks = (len + WG - 1) / WG; if(blocks > 65536) blocks = 65536;
@@ -885,7 +885,7 @@ extern "C" int md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs,
     if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(regions)", e);
     if(n) { e = hipMemcpy(d, runs, sizeof(md_region) * (size_t)n, hipMemcpyHostToDevice); if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_HIP, "hipMemcpy(regions)", e); } }
     int64_t blocks = (len + WG - 1) / WG; if(blocks > 65536) blocks = 65536;
-    if(!h->ref_stream) HIPCHK(hipStreamCreateWithFlags(&h->ref_stream, hipStreamNonBlocking));
+    if(!h->ref_stream && !(h->ref_stream = stream_take(h->device))) return fail(MDK_ERR_HIP, "hipStreamCreateWithFlags", hipGetLastError());
     if(len > 0) hipLaunchKernelGGL(k_mask_regions, dim3((unsigned)blocks), dim3(WG), 0, h->ref_stream, h->refcode[tid], len, d, n);
     e = hipGetLastError(); if(e == hipSuccess) e = hipStreamSynchronize(h->ref_stream);
     if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_HIP, "k_mask_regions", e); }

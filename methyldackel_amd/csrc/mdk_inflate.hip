@@ -1,9 +1,10 @@
 // mdk_inflate.hip -- BGZF inflate and BAM record framing on the device (the step the reference pays for
 // inside htslib's sam_itr_next, common.c:413).
 //
-//   k_inflate     one WAVEFRONT per BGZF member.  Lane 0 decodes Huffman symbols (mdk_inflate_core.h: that part of DEFLATE is
-//                 sequential) in batches of <= 64 match tokens / 1 KiB of output: literals go straight into a 2 KiB output window (INF_WIN) in
-//                 LDS, matches become tokens.  Between batches all 64 lanes work: (1) top up the LDS ring of compressed words with one coalesced
+//   k_inflate     one WAVEFRONT per BGZF member.  Inside a Huffman block every lane decodes the symbol that would start at its bit of the
+//                 stream's next 64 (mdk_inflate_core.h inf_decode_at) and a walk over the results picks the real ones -- ~7 symbols per round
+//                 of table lookups.  Batches of <= 64 match tokens / 1 KiB of output: literals go straight into a 2 KiB output window
+//                 (INF_WIN) in LDS, matches become tokens.  Between batches all 64 lanes work: (1) top up the LDS ring of compressed words with one coalesced
 //                 load, (2) FAR matches -- source older than the LDS window -- one lane per token, bytes from global memory
 //                 (written by an earlier batch of this wavefront), (3) NEAR matches in stream order, each by all lanes from the
 //                 window (a self-overlapping match doubles the copied span per round), (4) the batch's bytes leave the window
@@ -32,20 +33,8 @@ struct InfParams {
     uint32_t *status;                 // [0] = first error: code | member << 8 (0 = none)
 };
 
-// hands the decoder state of lane 0 to every lane (uniform mode: after lane 0 alone has parsed a block header)
-struct InfBcast {
-    __device__ __forceinline__ uint32_t word(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-    __device__ __forceinline__ void operator()(InfDec &d) const {
-        d.bb = (uint64_t)word((uint32_t)d.bb) | ((uint64_t)word((uint32_t)(d.bb >> 32)) << 32); d.cnt = word(d.cnt); d.nx = word(d.nx); d.widx = word(d.widx); d.pos = word(d.pos); d.out_len = word(d.out_len);
-        d.in_block = word(d.in_block); d.last = word(d.last); d.stored_left = word(d.stored_left);
-    }
-};
-// One member by one wavefront.  UNI: the decoder's values are uniform (readfirstlane behind every LDS load: scalar registers, scalar
-// arithmetic and branches) instead of living in lane 0's vector registers under an execution mask.  LIGHT: between the phases of
-// one wavefront only the compiler is fenced (the LDS operations of a wavefront are executed in order) instead of s_waitcnt + s_barrier.
-template <bool UNI, bool LIGHT>
+// One member by one wavefront.
 __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S, const int m, const int lane) {
-    auto sync = [&]() { if(LIGHT) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); };
     const md_inf_member M = P.mem[m];
     if(M.out_len == 0) return;
     const uint64_t a0 = M.in_off & ~3ull;                               // aligned start of the stream's words
@@ -53,26 +42,64 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
     const uint32_t n_words = (uint32_t)((M.in_off + M.in_len + 3 - a0) >> 2);
     const uint32_t *words = (const uint32_t *)(P.comp + a0);
     uint8_t *out = P.out + M.out_off;
-    uint32_t filled = 0;                                               // stream words put into the ring so far (wave-uniform)
-    InfDec d;
-    // first fill: the whole ring
-    for(; filled < INF_IN_WORDS; filled += 64) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = w < n_words ? words[w] : 0u; }
-    __syncthreads();
-    inf_dec_init(d, S.in, skip, M.out_len);
-    if(UNI) InfBcast()(d);
-    uint32_t taken = 3;
+    uint32_t filled = 0;                                               // stream words put into the ring so far
+    // everything below is wave-uniform: position in the stream (bits), bytes produced, the block the decoder stands in
+    uint32_t bitpos = 8u * skip, pos = 0, in_block = 0, last = 0, stored_left = 0;
+    auto fail = [&](uint32_t code) { if(lane == 0) atomicCAS(P.status, 0u, code | ((uint32_t)m << 8)); };
+    const unsigned long long lt = (1ull << lane) - 1ull;
     for(;;) {
-        // (1) top up the ring: word w may replace word w-256 once the decoder has taken that one
-        while(filled + 64 <= taken + INF_IN_WORDS) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = w < n_words ? words[w] : 0u; filled += 64; }
-        sync();
-        // the decoder runs with one lane enabled; in uniform mode what it loads goes through readfirstlane, so its state stays in
-        // scalar registers inside the region and is made uniform again behind it
-        if(lane == 0) inf_decode_batch<UNI>(d, S);
-        if(UNI) InfBcast()(d);
-        sync();
-        const uint32_t n_tok = S.n_tok, beg = S.batch_beg, end = S.batch_end, err = S.err, fin = S.finished;
-        taken = S.words_used;
-        if(err || taken > n_words + 3 || (fin && inf_overran_input(taken, S.bits_left, skip, M.in_len))) { if(lane == 0) atomicCAS(P.status, 0u, (err ? err : (uint32_t)INF_E_INPUT) | ((uint32_t)m << 8)); return; }
+        // (1) top up the ring: word w may replace word w-256 once the decoder stands behind that one
+        while(filled + 64 <= (bitpos >> 5) + INF_IN_WORDS) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = w < n_words ? words[w] : 0u; filled += 64; }
+        __syncthreads();
+        const uint32_t beg = pos; uint32_t n_tok = 0, err = 0, fin = 0;
+        if(in_block == 0) {                                            // a block header: one lane, through the bit reader; a batch of its own
+            if(lane == 0) inf_header_batch(S, bitpos);
+            __syncthreads();
+            bitpos = S.bitpos; in_block = S.in_block; last = S.last; stored_left = S.stored_left; err = S.err;
+        } else if(in_block == 2) {                                     // a stored block: bytes out of the ring, all lanes
+            const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH;
+            for(uint32_t i = lane; i < n; i += 64) S.win[(pos + i) & (INF_WIN - 1)] = inf_ring_byte(S, bitpos, i);
+            pos += n; bitpos += 8u * n; stored_left -= n;
+            if(stored_left == 0) { in_block = 0; fin = last; }
+        } else {
+            // a Huffman block, in rounds: every lane decodes the symbol that would start at its bit of the next 64; the walk keeps the real ones
+            const uint32_t lim = beg + (INF_BATCH_BYTES - 258), blim = bitpos + 32u * INF_BATCH_WORDS;
+            for(;;) {
+                const InfSym sy = inf_decode_at(S, bitpos + (uint32_t)lane);
+                // the walk: lane 0's symbol is real, the next real one starts where it ends, ... -- a scalar loop over readlane; adv = the symbol's
+                // bits, with bit 8 set where the walk ends behind this symbol (end of block) and bit 9 where it ends AT it (not a code)
+                const uint32_t adv = sy.kind >= 3 ? 0x200u : sy.kind == 2 ? (sy.nbits | 0x100u) : sy.nbits;
+                uint32_t off = 0, a = 0, lastl = 0; unsigned long long V = 0;
+                do { lastl = off; V |= 1ull << off; a = (uint32_t)__builtin_amdgcn_readlane((int)adv, (int)off); off += a & 0xffu; } while(off < 64 && a < 0x100u);
+                uint32_t stop = a >= 0x200u ? (uint32_t)__builtin_amdgcn_readlane((int)sy.kind, (int)lastl) : a >= 0x100u ? 2u : 0u;
+                if(stop >= 3) V &= ~(1ull << lastl);
+                bool valid = (V >> lane) & 1ull;
+                const uint32_t olen = !valid ? 0u : sy.kind == 0 ? 1u : sy.kind == 1 ? (sy.val & 0xffffu) : 0u;
+                uint32_t incl = olen;
+#pragma unroll
+                for(int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if(lane >= d) incl += t; }
+                const uint32_t dst = pos + incl - olen;
+                bool ism = valid && sy.kind == 1;
+                unsigned long long mball = __ballot(ism);
+                // the batch's limits: 64 match tokens, INF_BATCH_BYTES of output -- the first symbol that does not fit ends the round in front of it
+                const unsigned long long cm = __ballot(valid && ((ism && n_tok + (uint32_t)__popcll(mball & lt) >= INF_MAX_TOK) || dst + olen > beg + INF_BATCH_BYTES));
+                if(cm) { const int c = __ffsll((long long)cm) - 1; V &= (1ull << c) - 1ull; off = (uint32_t)c; stop = 1; valid = (V >> lane) & 1ull; ism = ism && valid; mball = __ballot(ism); }
+                if(__ballot(ism && (sy.val >> 16) > dst)) { err = INF_E_DIST; break; }
+                if(valid && sy.kind == 0) S.win[dst & (INF_WIN - 1)] = (uint8_t)sy.val;
+                if(ism) { InfToken t; t.dst = dst; t.len_dist = sy.val; S.tok[n_tok + (uint32_t)__popcll(mball & lt)] = t; }
+                n_tok += (uint32_t)__popcll(mball);
+                { const int hi = V ? 63 - __clzll((long long)V) : 0; pos = V ? (uint32_t)__builtin_amdgcn_readlane((int)(dst + olen), hi) : pos; }
+                bitpos += off;
+                if(stop >= 3) { err = stop == 3 ? INF_E_SYMBOL : INF_E_DIST; break; }
+                if(stop == 2) { in_block = 0; fin = last; break; }
+                if(stop == 1 || n_tok >= INF_MAX_TOK || pos > lim || bitpos > blim) break;
+            }
+            __syncthreads();                                          // the window and the tokens are in LDS for every lane
+        }
+        if(!err && pos > M.out_len) err = INF_E_OVERRUN;
+        if(!err && fin && pos != M.out_len) err = INF_E_SHORT;
+        if(err || (bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, M.in_len))) { fail(err ? err : (uint32_t)INF_E_INPUT); return; }
+        const uint32_t end = pos;
         // (2) far matches: one lane per token; every byte comes from global memory
         bool far = false;
         InfToken t; t.dst = 0; t.len_dist = 0;
@@ -92,20 +119,34 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
                     for(uint32_t q = 0; q < 16; q++) if(q < n) S.win[(t.dst + i + q) & (INF_WIN - 1)] = (uint8_t)(b[q >> 2] >> (8 * (q & 3)));
                 }
             }
-            sync();
+            __syncthreads();
         }
-        // (3) near matches, in stream order, each by the whole wavefront; the token travels from the lane that holds it by readlane
-        unsigned long long near = __ballot((uint32_t)lane < n_tok && !far);
-        while(near) {
-            const int k = __ffsll((long long)near) - 1; near &= near - 1;
-            const uint32_t qdst = (uint32_t)__builtin_amdgcn_readlane((int)t.dst, k), qld = (uint32_t)__builtin_amdgcn_readlane((int)t.len_dist, k);
-            const uint32_t len = qld & 0xffffu, dist = qld >> 16;
-            uint32_t done = 0, span = dist;
-            while(done < len) {
-                const uint32_t n = span < len - done ? span : len - done;
-                inf_near_round(S.win, qdst, dist, done, n, (uint32_t)lane);
-                sync();
-                done += n; span <<= 1;
+        // (3) near matches.  Everything below the first token not yet copied is final (literals were written while decoding), so every token whose
+        // source ends below that mark can be copied at once -- short ones (most: a BAM field repeated from the record before) each by its own
+        // lane, byte by byte, which also gets a match that overlaps its own output right; a long one, when it is the first, by the whole
+        // wavefront (span-doubling rounds).  A handful of rounds per batch instead of one per token.
+        {
+            const uint32_t len = t.len_dist & 0xffffu, dist = t.len_dist >> 16, src = t.dst - dist;
+            unsigned long long pending = __ballot((uint32_t)lane < n_tok && !far);
+            while(pending) {
+                const int f = __ffsll((long long)pending) - 1;
+                const uint32_t W = (uint32_t)__builtin_amdgcn_readlane((int)t.dst, f), flen = (uint32_t)__builtin_amdgcn_readlane((int)len, f);
+                if(flen > INF_NEAR_LANE_MAX) {
+                    const uint32_t fdist = (uint32_t)__builtin_amdgcn_readlane((int)dist, f);
+                    uint32_t done = 0, span = fdist;
+                    while(done < flen) {
+                        const uint32_t n = span < flen - done ? span : flen - done;
+                        inf_near_round(S.win, W, fdist, done, n, (uint32_t)lane);
+                        __syncthreads();
+                        done += n; span <<= 1;
+                    }
+                    pending &= ~(1ull << f);
+                    continue;
+                }
+                const bool ready = ((pending >> lane) & 1ull) && len <= INF_NEAR_LANE_MAX && (lane == f || src + len <= W);
+                if(ready) for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = S.win[(src + i) & (INF_WIN - 1)];
+                pending &= ~__ballot(ready);
+                __syncthreads();
             }
         }
         // (4) the batch leaves the window
@@ -120,19 +161,15 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
         if(fin) return;
     }
 }
-// VARIANT bit 0: UNI, bit 1: LIGHT (see inflate_member).  (Measured and dropped, profiles/r03_inflate_experiments.json: odd members on
-// the scalar unit and even ones on the vector unit in one launch -- no faster than the slower of the two.)
 #ifndef INF_WAVES
 #define INF_WAVES 6
 #endif
-template <int VARIANT>
 __global__ __launch_bounds__(64, INF_WAVES) void k_inflate(const InfParams P) {
     __shared__ InfShared S;
     const int m = blockIdx.x, lane = threadIdx.x;
     if(m >= P.n_mem) return;
-    inflate_member<(VARIANT & 1) != 0, (VARIANT & 2) != 0>(P, S, m, lane);
+    inflate_member(P, S, m, lane);
 }
-
 
 // ---- CRC-32 of the inflated members (mdk_crc32_core.h) ----
 struct CrcParams { const uint8_t *out; const md_inf_member *mem; int n_mem; const CrcConst *K; uint32_t *status; };
@@ -231,12 +268,7 @@ __global__ __launch_bounds__(1024) void k_walk_scan(const uint32_t *cnt, uint32_
 // ------------------------------------------------------------------------------------------------
 // host side: pieces
 // ------------------------------------------------------------------------------------------------
-// the decoder variant is a build-time choice (experiments: make B=dir HIPFLAGS=-DINF_VARIANT=1..3); 0 -- decoder in lane 0's vector
-// registers, full barriers between the phases -- is the fastest measured (profiles/r03_inflate_experiments.json)
-#ifndef INF_VARIANT
-#define INF_VARIANT 0
-#endif
-static void launch_inflate(int n_mem, hipStream_t st, const InfParams &IP) { hipLaunchKernelGGL(k_inflate<INF_VARIANT>, dim3(n_mem), dim3(64), 0, st, IP); }
+static void launch_inflate(int n_mem, hipStream_t st, const InfParams &IP) { hipLaunchKernelGGL(k_inflate, dim3(n_mem), dim3(64), 0, st, IP); }
 struct md_piece {
     md_dev *h = nullptr; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
     DBuf<uint8_t> d_comp, d_out; DBuf<md_inf_member> d_mem; DBuf<uint32_t> d_cnt, d_first, d_recoff, d_status; DBuf<md_inf_digest> d_dig;

@@ -1,11 +1,14 @@
 // mdk_inflate_core.h -- DEFLATE (RFC 1951) decoding of one BGZF member by ONE WAVEFRONT: the part that is sequential.
 //
 // Where this sits: the reference pays for BGZF inflate inside htslib's sam_itr_next (common.c:413); SURVEY.md 8(f) rank 1 moves it
-// to the device.  A member (<= 64 KiB of BAM, bgzf.c of htslib: BGZF_BLOCK_SIZE 0xff00) is one raw deflate stream.  Symbol
-// boundaries depend on every symbol before them, so ONE decoder per wavefront walks the symbols -- this file -- while everything
-// that is not sequential is done by all 64 lanes in mdk_inflate.hip: staging the compressed words into an LDS ring, copying the
-// LZ77 matches (sources further back than the LDS window come from global memory, nearer ones from the window) and writing the
-// finished bytes out coalesced.
+// to the device.  A member (<= 64 KiB of BAM, bgzf.c of htslib: BGZF_BLOCK_SIZE 0xff00) is one raw deflate stream.  Where a symbol
+// starts depends on every symbol before it -- but WHAT a symbol is depends only on the bits at its start and on the block's tables.  So
+// inside a Huffman block the 64 lanes of the wavefront each decode the symbol that WOULD start at "their" bit (the next 64 bit
+// positions of the stream: inf_decode_at, this file), and a short walk over the 64 results (lane 0's symbol is real; the next real one
+// starts where it ends; ...) picks the 5-8 of them that are: one round of table lookups per ~7 symbols instead of per symbol.  Block
+// headers go through the sequential bit reader below, by one lane.  Everything else is done by all 64 lanes in mdk_inflate.hip:
+// staging the compressed words into an LDS ring, copying the LZ77 matches (sources further back than the LDS window come from global
+// memory, nearer ones from the window) and writing the finished bytes out coalesced.
 //
 // The code here is plain C++ with no wave intrinsics: it compiles for the device (hipcc) and for the host (tests/emulation:
 // tools/inflate_emu.cpp runs the same functions over real BGZF files and compares with zlib), which is how it is tested
@@ -37,6 +40,7 @@
 #define INF_BATCH_BYTES (INF_WIN / 2)      // a batch never produces more than this
 #define INF_BATCH_WORDS 150                // ... nor takes more than this many words from the input ring (the ring is topped up to >= 193 ahead)
 #define INF_MAX_TOK   64                   // ... nor holds more match tokens than this (one per lane)
+#define INF_NEAR_LANE_MAX 32u              // a match up to this long whose source is final is copied by its own lane; longer ones by the whole wavefront
 
 // Literal/length table entry, 16 bits (the tables of a wavefront are 3.3 KiB of LDS):
 //   length symbol   1 eee bbbbbbbb nnnn   e = extra bits (0..5), b = base length - 3 (0..255), n = code bits to consume
@@ -72,8 +76,8 @@ struct InfShared {
     uint32_t in[INF_IN_WORDS];             // ring of compressed words: word w of the stream lives in in[w & (INF_IN_WORDS-1)]
     uint8_t  win[INF_WIN];                 // ring of output bytes: byte p of the member lives in win[p & (INF_WIN-1)]
     InfToken tok[INF_MAX_TOK];
-    // written by the decoder at the end of a batch, read by all lanes after the barrier
-    uint32_t n_tok, batch_beg, batch_end, words_used, bits_left, finished, err;      // bits_left: fetched (words_used words) but not consumed, less the prefetched word
+    // written by the lane that parsed a block header, read by all lanes after the barrier
+    uint32_t bitpos, in_block, last, stored_left, err;
 };
 
 // The decoder's registers between batches.  `bb` holds the next `cnt` bits of the stream, least significant first; 32 <= cnt <= 63
@@ -89,14 +93,7 @@ struct InfDec {
     uint32_t stored_left;                  // bytes of the stored block still to copy
 };
 
-// UNI = the decoder's values are wave-uniform: what it reads from LDS goes through readfirstlane, so the compiler keeps the whole
-// decoder state in scalar registers, does its arithmetic on the scalar unit and branches with scalar branches.
-#if defined(__HIPCC__)
-#define INF_RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-#else
-#define INF_RFL(x) ((uint32_t)(x))
-#endif
-#define INF_LD(x) (UNI ? INF_RFL(x) : (uint32_t)(x))
+#define INF_LD(x) ((uint32_t)(x))
 MDK_HD uint32_t inf_peek(const InfDec &d) { return (uint32_t)d.bb; }
 template <bool UNI>
 MDK_HD void inf_consume(InfDec &d, const uint32_t *in, uint32_t n) {     // n <= 32
@@ -109,12 +106,14 @@ MDK_HD uint32_t inf_get(InfDec &d, const uint32_t *in, uint32_t n) {     // n <=
     inf_consume<UNI>(d, in, n);
     return v;
 }
-// first use: the ring already holds the first words of the stream; `skip_bytes` = bytes of word 0 in front of the member's first byte
-MDK_HD void inf_dec_init(InfDec &d, const uint32_t *in, uint32_t skip_bytes, uint32_t out_len) {
-    d.bb = (uint64_t)in[0] | ((uint64_t)in[1] << 32); d.cnt = 64; d.nx = in[2]; d.widx = 3;
-    d.pos = 0; d.out_len = out_len; d.in_block = 0; d.last = 0; d.stored_left = 0;
-    inf_consume<false>(d, in, 8 * skip_bytes);
+// The stream's bits are numbered from bit 0 of ring word 0 (the member's first byte sits 8 * skip_bytes bits in).  The bit reader at a
+// position, and the position of a bit reader:
+MDK_HD void inf_dec_seek(InfDec &d, const uint32_t *in, uint32_t bitpos) {
+    const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    d.bb = ((uint64_t)in[w & (INF_IN_WORDS - 1)] | ((uint64_t)in[(w + 1) & (INF_IN_WORDS - 1)] << 32)) >> sh; d.cnt = 64 - sh;
+    d.nx = in[(w + 2) & (INF_IN_WORDS - 1)]; d.widx = w + 3;
 }
+MDK_HD uint32_t inf_dec_tell(const InfDec &d) { return 32u * (d.widx - 1u) - d.cnt; }
 
 MDK_HD uint32_t inf_rev(uint32_t code, int len) {          // the low `len` bits of code, reversed
     uint32_t r = 0;
@@ -263,70 +262,56 @@ MDK_HDN InfHdr inf_block_header(const InfDec d_in, InfShared &S) {
     return H;
 }
 
-// One batch: a block header, or symbols until INF_BATCH_BYTES of output, INF_MAX_TOK matches, INF_BATCH_WORDS of input, the end
-// of the block or an error.  Literals go straight into the window ring; matches become tokens (their bytes are produced by the
-// whole wavefront afterwards).  Leaves the batch description in S (n_tok, batch_beg, batch_end, words_used, finished, err).
-// Bounds against the member's size are checked once per batch: a batch only writes the LDS window and only reads global memory
-// behind `pos`.
-template <bool UNI>
-MDK_HD void inf_decode_batch(InfDec &d, InfShared &S) {
-    const uint32_t beg = d.pos; uint32_t pos = beg, ntok = 0, err = INF_OK, finished = 0;
-    if(d.in_block == 0) {                                     // a block header is a batch of its own: the ring is full enough for all of it then
-        const InfHdr H = inf_block_header(d, S); d = H.d; err = (uint32_t)H.err;
-    } else if(d.in_block == 2) {                              // stored block: bytes through the bit reader
-        uint32_t k = 0;
-        while(k < 64 && d.stored_left) { S.win[pos & (INF_WIN - 1)] = (uint8_t)inf_get<UNI>(d, S.in, 8); pos++; d.stored_left--; k++; }
-        if(d.stored_left == 0) { d.in_block = 0; finished = d.last; }
-    } else {
-        // the fast loop; one exit, through `stop`
-        uint64_t bb = d.bb; uint32_t cnt = d.cnt, nx = d.nx, widx = d.widx, stop = 0;
-        const uint32_t lim = beg + (INF_BATCH_BYTES - 258), wlim = widx + INF_BATCH_WORDS;
-#define INF_TAKE(n) do { bb >>= (n); cnt -= (n); if(cnt < 32) { bb |= (uint64_t)nx << cnt; cnt += 32; nx = INF_LD(S.in[widx & (INF_IN_WORDS - 1)]); widx++; if(widx > wlim) stop |= 1u; } } while(0)
-        do {
-            uint32_t x = (uint32_t)bb, used = 0;
-            uint32_t e = INF_LD(S.lit[x & ((1u << INF_LIT_TB) - 1u)]);
-            if((e & (INF_L_LEN | 0x6000u)) == INF_L_SUB) {    // a code longer than the root table
-                x >>= INF_LIT_TB; used = INF_LIT_TB;
-                e = INF_LD(S.lit[(1u << INF_LIT_TB) + ((e >> 4) & 511u) + (x & ((1u << (e & 15u)) - 1u))]);
-            }
-            const uint32_t nb = e & 15u;
-            if(e & INF_L_LEN) {
-                const uint32_t eb = (e >> 12) & 7u, len = ((e >> 4) & 255u) + 3u + ((x >> nb) & ((1u << eb) - 1u));
-                INF_TAKE(used + nb + eb);
-                uint32_t y = (uint32_t)bb, used2 = 0;
-                uint32_t f = INF_LD(S.dist[y & ((1u << INF_DIST_TB) - 1u)]);
-                if(INF_D_KIND(f) == INF_D_SUB) { y >>= INF_DIST_TB; used2 = INF_DIST_TB; f = INF_LD(S.dist[(f >> 16) + (y & ((1u << (f & 15u)) - 1u))]); }
-                const uint32_t nb2 = f & 15u, eb2 = (f >> 8) & 15u, dist = (f >> 16) + ((y >> nb2) & ((1u << eb2) - 1u));
-                INF_TAKE(used2 + nb2 + eb2);
-                if(INF_D_KIND(f) != INF_D_SYM || dist > pos) { err = INF_E_DIST; stop |= 2u; }
-                else {
-                    InfToken t; t.dst = pos; t.len_dist = len | (dist << 16); S.tok[ntok] = t;
-                    ntok++; pos += len;
-                    if(ntok == INF_MAX_TOK) stop |= 1u;
-                }
-            } else if(INF_L_KIND(e) == INF_L_LIT) {
-                INF_TAKE(used + nb);
-                S.win[pos & (INF_WIN - 1)] = (uint8_t)(e >> 4);
-                pos++;
-            } else {
-                if(INF_L_KIND(e) == INF_L_EOB) { INF_TAKE(used + nb); d.in_block = 0; finished = d.last; } else err = INF_E_SYMBOL;
-                stop |= 2u;
-            }
-            if(pos > lim) stop |= 1u;
-        } while(!stop);
-#undef INF_TAKE
-        d.bb = bb; d.cnt = cnt; d.nx = nx; d.widx = widx;
-    }
-    d.pos = pos;
-    if(!err && pos > d.out_len) err = INF_E_OVERRUN;
-    if(!err && finished && pos != d.out_len) err = INF_E_SHORT;
-    S.n_tok = ntok; S.batch_beg = beg; S.batch_end = pos; S.words_used = d.widx; S.bits_left = d.cnt; S.finished = finished; S.err = err;
+// A block header by ONE lane, through the bit reader; what it leaves (position behind the header, kind of block, tables) goes to S for all lanes.
+MDK_HD void inf_header_batch(InfShared &S, uint32_t bitpos) {
+    InfDec d; inf_dec_seek(d, S.in, bitpos);
+    d.pos = 0; d.out_len = 0; d.in_block = 0; d.last = 0; d.stored_left = 0;
+    const InfHdr H = inf_block_header(d, S);
+    S.bitpos = inf_dec_tell(H.d); S.in_block = H.d.in_block; S.last = H.d.last; S.stored_left = H.d.stored_left; S.err = (uint32_t)H.err;
 }
+
+// The symbol that starts at bit `bitpos` of the stream, whatever stands in front of it: kind 0 a literal (val = the byte), 1 a match (val =
+// length | distance << 16), 2 end of block, 3 / 4 not a code of the literal/length / of the distance alphabet.  nbits = its bits, extra
+// bits and distance code included (at most 15 + 5 + 15 + 13 = 48, of the 64 fetched).
+struct InfSym { uint32_t nbits, kind, val; };
+MDK_HD InfSym inf_decode_at(const InfShared &S, const uint32_t bitpos) {
+    const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    const uint32_t w0 = S.in[w & (INF_IN_WORDS - 1)], w1 = S.in[(w + 1) & (INF_IN_WORDS - 1)], w2 = S.in[(w + 2) & (INF_IN_WORDS - 1)];
+    uint64_t b = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
+    if(sh) b |= (uint64_t)w2 << (64 - sh);
+    uint32_t x = (uint32_t)b, used = 0;
+    uint32_t e = S.lit[x & ((1u << INF_LIT_TB) - 1u)];
+    if((e & (INF_L_LEN | 0x6000u)) == INF_L_SUB) {        // a code longer than the root table
+        x >>= INF_LIT_TB; used = INF_LIT_TB;
+        e = S.lit[(1u << INF_LIT_TB) + ((e >> 4) & 511u) + (x & ((1u << (e & 15u)) - 1u))];
+    }
+    const uint32_t nb = e & 15u;
+    InfSym s;
+    if(e & INF_L_LEN) {
+        const uint32_t eb = (e >> 12) & 7u, len = ((e >> 4) & 255u) + 3u + ((x >> nb) & ((1u << eb) - 1u));
+        const uint32_t t1 = used + nb + eb;
+        uint32_t y = (uint32_t)(b >> t1), used2 = 0;
+        uint32_t f = S.dist[y & ((1u << INF_DIST_TB) - 1u)];
+        if(INF_D_KIND(f) == INF_D_SUB) { y >>= INF_DIST_TB; used2 = INF_DIST_TB; f = S.dist[(f >> 16) + (y & ((1u << (f & 15u)) - 1u))]; }
+        const uint32_t nb2 = f & 15u, eb2 = (f >> 8) & 15u, dist = (f >> 16) + ((y >> nb2) & ((1u << eb2) - 1u));
+        s.nbits = t1 + used2 + nb2 + eb2; s.kind = INF_D_KIND(f) == INF_D_SYM ? 1u : 4u; s.val = len | (dist << 16);
+    } else {
+        const uint32_t k = INF_L_KIND(e);
+        s.nbits = used + nb; s.kind = k == INF_L_LIT ? 0u : k == INF_L_EOB ? 2u : 3u; s.val = (e >> 4) & 255u;
+    }
+    return s;
+}
+// byte `i` of the stream behind the byte-aligned position `bitpos` (a stored block's bytes), out of the ring
+MDK_HD uint8_t inf_ring_byte(const InfShared &S, uint32_t bitpos, uint32_t i) {
+    const uint32_t a = (bitpos >> 3) + i;
+    return (uint8_t)(S.in[(a >> 2) & (INF_IN_WORDS - 1)] >> (8u * (a & 3u)));
+}
+#define INF_STORED_BATCH 512u                 // bytes of a stored block copied per batch (the ring is kept >= 193 words ahead)
 
 // Has a finished member consumed more bits than its stream holds?  (Words past the stream read as zero, and zeros can decode: seven of
 // them are the end-of-block code of a fixed block.  zlib calls that stream truncated; so do we.)
-MDK_HD bool inf_overran_input(uint32_t words_used, uint32_t bits_left, uint32_t skip_bytes, uint32_t in_len) {
-    return 32ull * words_used - bits_left - 32ull > 8ull * ((uint64_t)skip_bytes + in_len);
+MDK_HD bool inf_overran_input(uint32_t bitpos, uint32_t skip_bytes, uint32_t in_len) {
+    return (uint64_t)bitpos > 8ull * ((uint64_t)skip_bytes + in_len);
 }
 
 // ---- the parts every lane runs (bodies only; the barriers between them are the caller's) ----

@@ -67,6 +67,9 @@ struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 #ifndef PREP_XCD
 #define PREP_XCD 1
 #endif
+#ifndef PREP_STAGE
+#define PREP_STAGE 1                  // k_prep_scan stages the record stream in LDS (0: every lane reads its record from HBM, round 3's arrangement)
+#endif
 __device__ __forceinline__ int chunk_of_block(const PrepMulti &M) {
 #if PREP_XCD
     return (int)((blockIdx.x & 7u) % (unsigned)M.n);
@@ -77,21 +80,39 @@ __device__ __forceinline__ int chunk_of_block(const PrepMulti &M) {
 #endif
 }
 
-// ---- aux area: first NH and first XG, as bam_aux_get finds them; a malformed area ends the walk ----
-// One 8-byte load per field: tag (2), type (1) and the first five value bytes -- all of a fixed-size value that NH or XG can have, and
-// the first letter of a string, which is all getStrand looks at.  Only a string longer than four letters costs further loads.
+// ---- a record through a view of its bytes; the aux area ----
 struct AuxHit { bool nh, xg; int64_t nh_val; uint8_t xg1; };
 __device__ __forceinline__ int first_zero_byte(uint64_t x, int n) {        // index of the first zero among the low n (<= 8) bytes, or n
     if(n < 8) x |= ~0ull << (8 * n);
     const uint64_t t = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
     return t ? (int)(__ffsll((unsigned long long)t) - 1) >> 3 : n;
 }
-__device__ __forceinline__ AuxHit scan_aux(const uint8_t *s, const uint8_t *e) {
+// Where a lane reads ITS record from.  GlobalView: the record bytes in HBM, loads of any alignment (every load of a wavefront then touches 64
+// different lines).  LdsView: the wavefront has staged the stretch of the record stream that holds its 64 records in LDS with coalesced
+// 16-byte loads (k_prep_scan), and the fields are picked out of it: aligned dword reads + v_alignbyte, the record starts at any byte.
+struct GlobalView {
+    const uint8_t *r;                              // the record's block_size word
+    __device__ __forceinline__ uint32_t u32(uint32_t x) const { return ld32(r + x); }
+    __device__ __forceinline__ uint64_t u64(uint32_t x) const { return ld64(r + x); }
+    __device__ __forceinline__ uint4 u128(uint32_t x) const { return ld128(r + x); }
+};
+struct LdsView {
+    const uint32_t *w; uint32_t b;                 // window words; byte offset of the record's block_size word in the window
+    __device__ __forceinline__ uint32_t u32(uint32_t x) const { const uint32_t a = b + x, i = a >> 2; return __builtin_amdgcn_alignbyte(w[i + 1], w[i], a & 3u); }
+    __device__ __forceinline__ uint64_t u64(uint32_t x) const { const uint32_t a = b + x, i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2]; return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, k) | (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, k) << 32; }
+    __device__ __forceinline__ uint4 u128(uint32_t x) const { const uint32_t a = b + x, i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2], w3 = w[i + 3], w4 = w[i + 4];
+        return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, k), __builtin_amdgcn_alignbyte(w2, w1, k), __builtin_amdgcn_alignbyte(w3, w2, k), __builtin_amdgcn_alignbyte(w4, w3, k)); }
+};
+// aux area [s, e) (offsets from the record's block_size word): first NH and first XG, as bam_aux_get finds them; a malformed area ends the walk.
+// One 8-byte read per field: tag (2), type (1) and the first five value bytes -- all of a fixed-size value that NH or XG can have, and the first
+// letter of a string, which is all getStrand looks at.  Only a string longer than four letters costs further reads.
+template <typename V>
+__device__ __forceinline__ AuxHit scan_aux(const V &v, uint32_t s, const uint32_t e) {
     AuxHit A; A.nh = false; A.xg = false; A.nh_val = 0; A.xg1 = 0;
-    while(e - s >= 3) {
-        const uint64_t w = ld64(s);
-        const uint8_t t = (uint8_t)(w >> 16); const uint8_t *v = s + 3; size_t sz;
-        const int64_t avail = e - v;
+    while(e >= s + 3) {
+        const uint64_t w = v.u64(s);
+        const uint8_t t = (uint8_t)(w >> 16); const uint32_t vo = s + 3; size_t sz;
+        const int64_t avail = (int64_t)e - vo;
         if(t == 'A' || t == 'c' || t == 'C') sz = 1;
         else if(t == 's' || t == 'S') sz = 2;
         else if(t == 'i' || t == 'I' || t == 'f') sz = 4;
@@ -100,11 +121,11 @@ __device__ __forceinline__ AuxHit scan_aux(const uint8_t *s, const uint8_t *e) {
             int n = avail < 5 ? (int)avail : 5, k = first_zero_byte(w >> 24, n);
             if(k < n) sz = (size_t)k + 1;
             else {
-                const uint8_t *z = v + 5; bool found = false;
+                uint32_t z = vo + 5; bool found = false;
                 if(avail <= 5) return A;
-                while(z < e) { n = e - z < 8 ? (int)(e - z) : 8; k = first_zero_byte(ld64(z), n); if(k < n) { z += k; found = true; break; } z += 8; }
+                while(z < e) { n = e - z < 8 ? (int)(e - z) : 8; k = first_zero_byte(v.u64(z), n); if(k < n) { z += k; found = true; break; } z += 8; }
                 if(!found) return A;
-                sz = (size_t)(z - v) + 1;
+                sz = (size_t)(z - vo) + 1;
             }
         } else if(t == 'B') {
             size_t es; if(avail < 5) return A;
@@ -124,7 +145,7 @@ __device__ __forceinline__ AuxHit scan_aux(const uint8_t *s, const uint8_t *e) {
             default: A.nh_val = 0;
             }
         } else if(tag == ('X' | 'G' << 8) && !A.xg) { A.xg = true; A.xg1 = (uint8_t)(w >> 24); }
-        s = v + sz;
+        s = vo + (uint32_t)sz;
     }
     return A;
 }
@@ -241,96 +262,128 @@ __global__ __launch_bounds__(PB) void k_prep_zero(const PrepMulti M) {
     }
 }
 
+// One record: fields, reference length, aux walk, strand, filter_func's tests in its order, name hash.  `v` reads the record's bytes (from HBM
+// or from the wavefront's staged window), o = the record's place in the chunk's record bytes.  Returns whether the record is admitted; D and h
+// are what the rest of the kernel needs of it.  ok = false: malformed.
+template <typename V>
+__device__ __forceinline__ int scan_record(const PrepParams &P, const V &v, const uint64_t o, PrepRead &D, uint64_t &h, bool &ok) {
+    int adm = 0;
+    const uint4 h0 = v.u128(0), h1 = v.u128(16);          // block_size refID pos (l_read_name mapq bin) | (n_cigar flag) l_seq next_refID next_pos
+    const uint32_t bs = h0.x;
+    const int32_t tid = (int32_t)h0.y, pos = (int32_t)h0.z;
+    const uint32_t lqn = h0.w & 255u, mapq = (h0.w >> 8) & 255u, ncig = h1.x & 0xffffu, flag = h1.x >> 16;
+    const int32_t lq = (int32_t)h1.y, mpos = (int32_t)h1.w;
+    const uint64_t need = 32ull + lqn + 4ull * ncig + (uint64_t)((lq > 0 ? lq : 0) + 1) / 2 + (uint64_t)(lq > 0 ? lq : 0);
+    ok = bs >= 32 && o + 4 + (uint64_t)bs <= P.raw_bytes && lq >= 0 && need <= bs && lqn >= 1;
+    if(!ok) return 0;
+    // offsets from the record's block_size word
+    const uint32_t qn = 4 + 32, cig = qn + lqn, seq = cig + 4 * ncig, qual = seq + (uint32_t)(lq + 1) / 2, aux = qual + (uint32_t)lq, end = 4 + bs;
+    const uint4 cb = v.u128(cig);                         // the first four CIGAR operations
+    int32_t rlen = 0;
+    for(uint32_t k = 0; k < ncig; k++) { const uint32_t c = k == 0 ? cb.x : k == 1 ? cb.y : k == 2 ? cb.z : k == 3 ? cb.w : v.u32(cig + 4 * k); const int op = c & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t)(c >> 4); }
+    D.pos = pos; D.rend = pos + rlen; D.lq = (uint32_t)lq; D.ncig = (uint16_t)ncig; D.flag = (uint16_t)flag;
+    D.seq_off = (uint32_t)(o + seq); D.cig_off = (uint32_t)(o + cig); D.qn_off = (uint32_t)(o + qn);
+    D.cig[0] = cb.x; D.cig[1] = cb.y; D.cig[2] = cb.z;
+    const md_prep_cfg &c = P.cfg;
+    if(c.perread) {          // perRead.c:178-183: alignments that start inside the chunk; flag masks and MAPQ only
+        bool keepr = (int64_t)pos >= P.beg && (int64_t)pos < P.end;
+        keepr = keepr && !(c.require_flags && ((uint32_t)c.require_flags & flag) != (uint32_t)c.require_flags);
+        keepr = keepr && !(c.ignore_flags && ((uint32_t)c.ignore_flags & flag) != 0) && (int)mapq >= c.min_mapq;
+        if(keepr) { const AuxHit A = scan_aux(v, aux, end); D.strand = (uint8_t)strand_of(flag, A); adm = 1; }
+        return adm;
+    }
+    // filter_func, common.c:416-444 (the region query behind it: pos < end, bam_endpos > beg)
+    bool keep = tid == P.tid && !(flag & 0x4) && (int64_t)pos < P.end && (int64_t)pos + (rlen > 0 ? rlen : 1) > P.beg;
+    keep = keep && (int)mapq >= c.min_mapq && !(flag & (uint32_t)c.ignore_flags);
+    keep = keep && !(c.require_flags && (flag & (uint32_t)c.require_flags) != (uint32_t)c.require_flags);
+    keep = keep && !(!c.keep_dupes && (flag & 0x400));
+    int strand = 0;
+    if(keep) {
+        const AuxHit A = scan_aux(v, aux, end);
+        if(!c.ignore_nh && A.nh && (int)A.nh_val > 1) keep = false;
+        strand = strand_of(flag, A);
+    }
+    if(keep && c.map_on) {
+        int64_t s1, s2;
+        if((flag & 0x40) || ((flag & 0x10) && (flag & 0x80))) { s1 = pos; s2 = mpos; } else { s2 = pos; s1 = mpos; }
+        if(!map_window_passes(P, s1, lq) && !map_window_passes(P, s2, lq)) keep = false;
+    }
+    if(keep && !c.keep_singleton && (flag & 0x9) == 0x9) keep = false;
+    if(keep && !c.keep_discordant && (flag & 0x3) == 0x1) keep = false;
+    if(keep && P.bed_on && !bed_touches(P, pos, (int64_t)pos + (rlen > 0 ? rlen : 1))) keep = false;
+    if(keep && c.min_conv_eff > 0.0f) {                   // (a rare option: straight from the record bytes in HBM)
+        int e = 0; const uint8_t *r = P.raw + o;
+        if(conv_efficiency(P, r + cig, (int)ncig, pos, r + seq, r + qual, lq, strand, &e) < c.min_conv_eff) keep = false;
+        if(e) atomicExch(&P.cnt->strand0, 1u);
+    }
+    D.strand = (uint8_t)strand;
+    if(!keep) return 0;
+    if(c.no_pairing) { atomicMax(&P.cnt->max_lq, (uint32_t)lq); return 1; }          // mbias: rows of the histogram
+    // the name as strcmp sees it (its letters up to the first NUL, at most l_read_name - 1 of them), 16 bytes at a time: hashed, and its
+    // first block kept in the read
+    uint32_t nlen = 0; h = 0x9e3779b97f4a7c15ULL;
+    for(int32_t left = (int32_t)lqn - 1, blk = 0; left > 0; left -= 16, blk++) {
+        const uint4 nb = v.u128(qn + 16 * blk);
+        const int lim = left < 16 ? left : 16;
+        int z = first_zero_byte((uint64_t)nb.x | (uint64_t)nb.y << 32, 8);
+        if(z == 8) z += first_zero_byte((uint64_t)nb.z | (uint64_t)nb.w << 32, 8);
+        const int take = z < lim ? z : lim;
+        uint32_t w[4] = {nb.x, nb.y, nb.z, nb.w};
+#pragma unroll
+        for(int d = 0; d < 4; d++) { const int kept = take - 4 * d; if(kept <= 0) w[d] = 0; else if(kept < 4) w[d] &= (1u << (8 * kept)) - 1u; }
+#pragma unroll
+        for(int d = 0; d < 4; d++) { h = (h ^ w[d]) * 0xff51afd7ed558ccdULL; h ^= h >> 29; }
+        if(blk == 0) { D.name[0] = w[0]; D.name[1] = w[1]; D.name[2] = w[2]; D.name[3] = w[3]; }
+        nlen += (uint32_t)take;
+        if(take < 16) break;
+    }
+    D.nlen = (uint8_t)nlen;
+    h = (h ^ nlen) * 0xc4ceb9fe1a85ec53ULL; h ^= h >> 32;
+    if(!h) h = 1;
+    return 1;
+}
+
+// bytes of the record stream a wavefront stages in LDS for its 64 records (a 2x150 library: 64 x 283 B = 18.1 KB); a record that does not lie
+// inside the window whole is read from HBM by its lane
+#ifndef RAWWIN
+#define RAWWIN 18944
+#endif
+#define RAWWIN_LDS (RAWWIN + 32)                      // (+ slack for the word reads of a field that ends at the window's end)
 __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     __shared__ uint32_t s_tk, wcnt[PB / 64], red[PB / 64];
-    __shared__ uint4 stage[4 * PB];                       // the workgroup's PrepReads on their way out (64 bytes each)
+    extern __shared__ __align__(16) uint4 dyn[];          // PB/64 windows of RAWWIN_LDS bytes; afterwards the workgroup's PrepReads on their way out (64 bytes each)
+    uint4 *const stage = dyn;
     const PrepParams &P = M.P[chunk_of_block(M)];
     if(threadIdx.x == 0) s_tk = atomicAdd(&P.ticket[0], 1u);
     __syncthreads();
     const uint32_t tk = s_tk; const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than tickets for this chunk
     int adm = 0; PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
+    // the wavefront's stretch of the record stream -> LDS, 1 KiB per instruction, straight from HBM (global_load_lds: no registers in between)
+    const int i0 = (int)(tk * PB) + 64 * wave;            // its first record
+    uint32_t wbase = 0, wlen = 0;
+    uint8_t *const win = (uint8_t *)dyn + (size_t)wave * RAWWIN_LDS;
+#if PREP_STAGE
+    if(i0 < P.n_rec) {
+        const uint64_t b0 = P.rec_off[i0], b1 = i0 + 64 < P.n_rec ? (uint64_t)P.rec_off[i0 + 64] : P.raw_bytes;
+        wbase = (uint32_t)(b0 & ~15ull);
+        uint64_t l = ((b1 - wbase) + 15) & ~15ull; if(l > RAWWIN) l = RAWWIN;
+        if((uint64_t)wbase + l > ((P.raw_bytes + 15) & ~15ull)) l = ((P.raw_bytes + 15) & ~15ull) - wbase;       // (the buffer is 64 bytes longer than the records)
+        wlen = (uint32_t)l;
+        const uint8_t *src = P.raw + wbase + 16 * lane;
+        for(uint32_t k = 0; k < wlen; k += 1024) if(k + 16 * lane < wlen) __builtin_amdgcn_global_load_lds((const void *)(src + k), (__attribute__((address_space(3))) void *)(win + k), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_wave_barrier();
+#endif
     if(i < P.n_rec) {
         const uint64_t o = P.rec_off[i];
         bool ok = o + 4 + 32 <= P.raw_bytes;
         if(ok) {
-            const uint8_t *r = P.raw + o + 4;
-            const uint4 h0 = ld128(P.raw + o), h1 = ld128(P.raw + o + 16);          // block_size refID pos (l_read_name mapq bin) | (n_cigar flag) l_seq next_refID next_pos
-            const uint32_t bs = h0.x;
-            const int32_t tid = (int32_t)h0.y, pos = (int32_t)h0.z;
-            const uint32_t lqn = h0.w & 255u, mapq = (h0.w >> 8) & 255u, ncig = h1.x & 0xffffu, flag = h1.x >> 16;
-            const int32_t lq = (int32_t)h1.y, mpos = (int32_t)h1.w;
-            const uint64_t need = 32ull + lqn + 4ull * ncig + (uint64_t)((lq > 0 ? lq : 0) + 1) / 2 + (uint64_t)(lq > 0 ? lq : 0);
-            ok = bs >= 32 && o + 4 + (uint64_t)bs <= P.raw_bytes && lq >= 0 && need <= bs && lqn >= 1;
-            if(ok) {
-                const uint8_t *qn = r + 32, *cig = qn + lqn, *seq = cig + 4 * ncig, *qual = seq + (lq + 1) / 2, *aux = qual + lq, *end = r + bs;
-                const uint4 cb = ld128(cig);                      // the first four CIGAR operations
-                int32_t rlen = 0;
-                for(uint32_t k = 0; k < ncig; k++) { const uint32_t c = k == 0 ? cb.x : k == 1 ? cb.y : k == 2 ? cb.z : k == 3 ? cb.w : ld32(cig + 4 * k); const int op = c & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t)(c >> 4); }
-                D.pos = pos; D.rend = pos + rlen; D.lq = (uint32_t)lq; D.ncig = (uint16_t)ncig; D.flag = (uint16_t)flag;
-                D.seq_off = (uint32_t)(seq - P.raw); D.cig_off = (uint32_t)(cig - P.raw); D.qn_off = (uint32_t)(qn - P.raw);
-                D.cig[0] = cb.x; D.cig[1] = cb.y; D.cig[2] = cb.z;
-                const md_prep_cfg &c = P.cfg;
-                if(c.perread) {          // perRead.c:178-183: alignments that start inside the chunk; flag masks and MAPQ only
-                    bool keepr = (int64_t)pos >= P.beg && (int64_t)pos < P.end;
-                    keepr = keepr && !(c.require_flags && ((uint32_t)c.require_flags & flag) != (uint32_t)c.require_flags);
-                    keepr = keepr && !(c.ignore_flags && ((uint32_t)c.ignore_flags & flag) != 0) && (int)mapq >= c.min_mapq;
-                    if(keepr) { const AuxHit A = scan_aux(aux, end); D.strand = (uint8_t)strand_of(flag, A); adm = 1; }
-                } else {
-                    // filter_func, common.c:416-444 (the region query behind it: pos < end, bam_endpos > beg)
-                    bool keep = tid == P.tid && !(flag & 0x4) && (int64_t)pos < P.end && (int64_t)pos + (rlen > 0 ? rlen : 1) > P.beg;
-                    keep = keep && (int)mapq >= c.min_mapq && !(flag & (uint32_t)c.ignore_flags);
-                    keep = keep && !(c.require_flags && (flag & (uint32_t)c.require_flags) != (uint32_t)c.require_flags);
-                    keep = keep && !(!c.keep_dupes && (flag & 0x400));
-                    int strand = 0;
-                    if(keep) {
-                        const AuxHit A = scan_aux(aux, end);
-                        if(!c.ignore_nh && A.nh && (int)A.nh_val > 1) keep = false;
-                        strand = strand_of(flag, A);
-                    }
-                    if(keep && c.map_on) {
-                        int64_t s1, s2;
-                        if((flag & 0x40) || ((flag & 0x10) && (flag & 0x80))) { s1 = pos; s2 = mpos; } else { s2 = pos; s1 = mpos; }
-                        if(!map_window_passes(P, s1, lq) && !map_window_passes(P, s2, lq)) keep = false;
-                    }
-                    if(keep && !c.keep_singleton && (flag & 0x9) == 0x9) keep = false;
-                    if(keep && !c.keep_discordant && (flag & 0x3) == 0x1) keep = false;
-                    if(keep && P.bed_on && !bed_touches(P, pos, (int64_t)pos + (rlen > 0 ? rlen : 1))) keep = false;
-                    if(keep && c.min_conv_eff > 0.0f) {
-                        int e = 0;
-                        if(conv_efficiency(P, cig, (int)ncig, pos, seq, qual, lq, strand, &e) < c.min_conv_eff) keep = false;
-                        if(e) atomicExch(&P.cnt->strand0, 1u);
-                    }
-                    D.strand = (uint8_t)strand;
-                    if(keep) {
-                        adm = 1;
-                        if(c.no_pairing) atomicMax(&P.cnt->max_lq, (uint32_t)lq);          // mbias: rows of the histogram
-                        else {
-                            // the name as strcmp sees it (its letters up to the first NUL, at most l_read_name - 1 of them), 16 bytes at a time:
-                            // hashed, and its first block kept in the read
-                            uint32_t nlen = 0; h = 0x9e3779b97f4a7c15ULL;
-                            for(int32_t left = (int32_t)lqn - 1, blk = 0; left > 0; left -= 16, blk++) {
-                                const uint4 nb = ld128(qn + 16 * blk);
-                                const int lim = left < 16 ? left : 16;
-                                int z = first_zero_byte((uint64_t)nb.x | (uint64_t)nb.y << 32, 8);
-                                if(z == 8) z += first_zero_byte((uint64_t)nb.z | (uint64_t)nb.w << 32, 8);
-                                const int take = z < lim ? z : lim;
-                                uint32_t w[4] = {nb.x, nb.y, nb.z, nb.w};
-#pragma unroll
-                                for(int d = 0; d < 4; d++) { const int kept = take - 4 * d; if(kept <= 0) w[d] = 0; else if(kept < 4) w[d] &= (1u << (8 * kept)) - 1u; }
-#pragma unroll
-                                for(int d = 0; d < 4; d++) { h = (h ^ w[d]) * 0xff51afd7ed558ccdULL; h ^= h >> 29; }
-                                if(blk == 0) { D.name[0] = w[0]; D.name[1] = w[1]; D.name[2] = w[2]; D.name[3] = w[3]; }
-                                nlen += (uint32_t)take;
-                                if(take < 16) break;
-                            }
-                            D.nlen = (uint8_t)nlen;
-                            h = (h ^ nlen) * 0xc4ceb9fe1a85ec53ULL; h ^= h >> 32;
-                            if(!h) h = 1;
-                        }
-                    }
-                }
-            }
+            uint32_t bs = 0;
+            const bool inwin = o >= wbase && o + 8 <= (uint64_t)wbase + wlen && (bs = LdsView{(const uint32_t *)win, (uint32_t)(o - wbase)}.u32(0), o + 4 + (uint64_t)bs <= (uint64_t)wbase + wlen);
+            if(inwin) adm = scan_record(P, LdsView{(const uint32_t *)win, (uint32_t)(o - wbase)}, o, D, h, ok);
+            else adm = scan_record(P, GlobalView{P.raw + o}, o, D, h, ok);
         }
         if(!ok) atomicExch(&P.cnt->malformed, 1u);
     }
@@ -623,6 +676,13 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
     return 0;
 }
 
+#define PREP_SCAN_LDS ((size_t)(PB / 64) * RAWWIN_LDS)
+static_assert(PREP_SCAN_LDS >= 4 * PB * sizeof(uint4), "the PrepRead stage lives in the windows' memory");
+MDK_HIDDEN int prep_kernels_init() {        // more dynamic LDS than the default window: once per process
+    static int rc = -1;
+    if(rc < 0) rc = hipFuncSetAttribute((const void *)k_prep_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess ? 0 : 1;
+    return rc;
+}
 static uint32_t pow2_at_least(size_t n) { uint32_t p = 1024; while(p < n) p <<= 1; return p; }
 
 // layout of a slot's zeroed region: hent[H] (8 bytes each), cntA[nb], cntS[nb], ticket[2]; sizes rounded to 16 bytes
@@ -647,6 +707,8 @@ static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
 // once for all of them.  The caller has ordered `st` behind the slots' uploads.
 int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
     if(n < 1 || n > MAXM) return fail(MDK_ERR_ARG, "enqueue_prep_group", hipSuccess);
+    for(int i = 0; i < n; i++) if((size_t)ss[i]->tid >= h->ref.size() || !h->ref[ss[i]->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", ss[i]->tid); return MDK_ERR_NOREF; }
+    if(prep_kernels_init()) return fail(MDK_ERR_HIP, "hipFuncSetAttribute(k_prep_scan)", hipGetLastError());
     static_assert(sizeof(PrepMulti) <= 4096, "kernel arguments are limited to 4 KiB");
     PrepMulti M; memset(&M, 0, sizeof(M));
     int total = 0; size_t zmax = 0;
@@ -664,7 +726,7 @@ int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
         }
         static_assert(MAXM <= 8, "chunk_of_block deals the chunks of a launch to 8 XCDs");
 #endif
-        hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), 0, st, M);
+        hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
         if(!h->prep.perread) hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M);
     }
     HIPCHK(hipGetLastError());
@@ -679,7 +741,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     if(!s || !b || b->n_records < 0 || b->n_ranges < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_upload_raw", hipSuccess);
     if(!h->prep_set) return fail(MDK_ERR_ARG, "md_dev_upload_raw: md_dev_set_prep was not called", hipSuccess);
     if(b->n_records && !b->range) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null array", hipSuccess);
-    if(b->tid < 0 || (size_t)b->tid >= h->ref.size() || !h->ref[b->tid]) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "reference for tid %d not uploaded", b->tid); return MDK_ERR_NOREF; }
+    if(b->tid < 0) return fail(MDK_ERR_ARG, "md_dev_upload_raw: contig", hipSuccess);      /* (the contig's reference is needed when the slot is launched, not yet here) */
     HIPCHK(hipSetDevice(h->device));
     if(s->busy) {                                    // work of the slot's previous chunk may still be running (its results were not collected)
         ProfScope pf(PF_UP_SYNC);

@@ -17,24 +17,68 @@
 
 // one member, as k_inflate does it; returns 0 or the error code
 static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uint8_t *out, uint32_t out_len, uint64_t *n_far, uint64_t *n_near, uint64_t *n_batches) {
-    static InfShared S; InfDec d;
+    static InfShared S;
     if(out_len == 0) return 0;
     const uint64_t a0 = in_off & ~3ull; const uint32_t skip = (uint32_t)(in_off & 3ull);
     const uint32_t n_words = (uint32_t)((in_off + in_len + 3 - a0) >> 2);
     auto word = [&](uint32_t w) -> uint32_t { uint32_t v = 0; if(w < n_words) memcpy(&v, comp + a0 + 4ull * w, 4); return v; };   // (the caller pads the buffer)
     uint32_t filled = 0;
-    for(; filled < INF_IN_WORDS; filled += 64) for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); }
-    inf_dec_init(d, S.in, skip, out_len);
-    uint32_t taken = 3;
+    uint32_t bitpos = 8u * skip, pos = 0, in_block = 0, last = 0, stored_left = 0;
     for(uint64_t turns = 0;; turns++) {
         if(turns > 200000) return 103;                                   // a batch must consume input or produce output: 64 KiB cannot take this long
-        while(filled + 64 <= taken + INF_IN_WORDS) { for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); } filled += 64; }
-        inf_decode_batch<false>(d, S);
+        while(filled + 64 <= (bitpos >> 5) + INF_IN_WORDS) { for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); } filled += 64; }
         (*n_batches)++;
-        const uint32_t n_tok = S.n_tok, beg = S.batch_beg, end = S.batch_end, err = S.err, fin = S.finished;
-        taken = S.words_used;
+        const uint32_t beg = pos; uint32_t n_tok = 0, err = 0, fin = 0;
+        if(in_block == 0) {
+            inf_header_batch(S, bitpos);
+            bitpos = S.bitpos; in_block = S.in_block; last = S.last; stored_left = S.stored_left; err = S.err;
+        } else if(in_block == 2) {
+            const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH;
+            for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[(pos + i) & (INF_WIN - 1)] = inf_ring_byte(S, bitpos, i);
+            pos += n; bitpos += 8u * n; stored_left -= n;
+            if(stored_left == 0) { in_block = 0; fin = last; }
+        } else {
+            // the rounds of k_inflate: the per-lane decode is the kernel's code, the cross-lane steps (walk by readlane, scan, ballots) run over arrays
+            const uint32_t lim = beg + (INF_BATCH_BYTES - 258), blim = bitpos + 32u * INF_BATCH_WORDS;
+            for(;;) {
+                InfSym sy[64];
+                for(uint32_t lane = 0; lane < 64; lane++) sy[lane] = inf_decode_at(S, bitpos + lane);
+                uint32_t adv[64]; for(uint32_t lane = 0; lane < 64; lane++) adv[lane] = sy[lane].kind >= 3 ? 0x200u : sy[lane].kind == 2 ? (sy[lane].nbits | 0x100u) : sy[lane].nbits;
+                uint32_t off = 0, a = 0, lastl = 0; uint64_t V = 0;
+                do { lastl = off; V |= 1ull << off; a = adv[off]; off += a & 0xffu; } while(off < 64 && a < 0x100u);
+                uint32_t stop = a >= 0x200u ? sy[lastl].kind : a >= 0x100u ? 2u : 0u;
+                if(stop >= 3) V &= ~(1ull << lastl);
+                uint32_t olen[64], dst[64], mpre[64]; uint32_t run = 0, nm = 0; uint64_t mball = 0, cm = 0;
+                for(uint32_t lane = 0; lane < 64; lane++) {
+                    const bool valid = (V >> lane) & 1ull;
+                    olen[lane] = !valid ? 0u : sy[lane].kind == 0 ? 1u : sy[lane].kind == 1 ? (sy[lane].val & 0xffffu) : 0u;
+                    dst[lane] = pos + run; run += olen[lane];
+                    mpre[lane] = nm; if(valid && sy[lane].kind == 1) { mball |= 1ull << lane; nm++; }
+                }
+                for(uint32_t lane = 0; lane < 64; lane++) { const bool valid = (V >> lane) & 1ull, ism = (mball >> lane) & 1ull; if(valid && ((ism && n_tok + mpre[lane] >= INF_MAX_TOK) || dst[lane] + olen[lane] > beg + INF_BATCH_BYTES)) cm |= 1ull << lane; }
+                if(cm) { const int c = __builtin_ctzll(cm); V &= (1ull << c) - 1ull; off = (uint32_t)c; stop = 1; mball &= V; }
+                bool baddist = false;
+                for(uint32_t lane = 0; lane < 64; lane++) if(((mball >> lane) & 1ull) && (sy[lane].val >> 16) > dst[lane]) baddist = true;
+                if(baddist) { err = INF_E_DIST; break; }
+                for(uint32_t lane = 0; lane < 64; lane++) {
+                    const bool valid = (V >> lane) & 1ull;
+                    if(valid && sy[lane].kind == 0) S.win[dst[lane] & (INF_WIN - 1)] = (uint8_t)sy[lane].val;
+                    if((mball >> lane) & 1ull) { InfToken t; t.dst = dst[lane]; t.len_dist = sy[lane].val; if(n_tok + mpre[lane] >= INF_MAX_TOK) return 104; S.tok[n_tok + mpre[lane]] = t; }
+                }
+                n_tok += (uint32_t)__builtin_popcountll(mball);
+                if(V) { const int hi = 63 - __builtin_clzll(V); pos = dst[hi] + olen[hi]; }
+                bitpos += off;
+                if(stop >= 3) { err = stop == 3 ? INF_E_SYMBOL : INF_E_DIST; break; }
+                if(stop == 2) { in_block = 0; fin = last; break; }
+                if(stop == 1 || n_tok >= INF_MAX_TOK || pos > lim || bitpos > blim) break;
+                if(!V) return 105;                                        // a round without progress (cannot happen: the first symbol of a round always fits)
+            }
+        }
+        if(!err && pos > out_len) err = INF_E_OVERRUN;
+        if(!err && fin && pos != out_len) err = INF_E_SHORT;
         if(err) return (int)err;
-        if(taken > n_words + 3 || (fin && inf_overran_input(taken, S.bits_left, skip, in_len))) return INF_E_INPUT;
+        if((bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, in_len))) return INF_E_INPUT;
+        const uint32_t end = pos;
         if(end - beg > INF_BATCH_BYTES || n_tok > INF_MAX_TOK) return 100;
         bool far[64];
         for(uint32_t lane = 0; lane < 64; lane++) {
@@ -49,18 +93,31 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
                 }
             }
         }
-        for(uint32_t k = 0; k < n_tok; k++) {
-            if(far[k]) continue;
-            const InfToken q = S.tok[k]; const uint32_t len = q.len_dist & 0xffffu, dist = q.len_dist >> 16;
-            if(q.dst - dist + INF_WIN < end) return 102;                  // a near source must still be in the window at the end of the batch
-            uint32_t done = 0, span = dist;
-            while(done < len) {
-                const uint32_t n = span < len - done ? span : len - done;
-                uint8_t snap[INF_WIN]; memcpy(snap, S.win, INF_WIN);      // all lanes read before any lane's write is seen: the round must not depend on lane order
-                for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[(q.dst + done + i) & (INF_WIN - 1)] = snap[(q.dst - dist + i) & (INF_WIN - 1)];
-                done += n; span <<= 1;
+        {   // the near phase of k_inflate: rounds over the tokens not yet copied
+            uint64_t pending = 0; for(uint32_t k = 0; k < n_tok; k++) if(!far[k]) pending |= 1ull << k;
+            int guard = 0;
+            while(pending) {
+                if(++guard > 200) return 106;
+                const int f = __builtin_ctzll(pending); const InfToken q = S.tok[f];
+                const uint32_t W = q.dst, flen = q.len_dist & 0xffffu;
+                if(q.dst - (q.len_dist >> 16) + INF_WIN < end) return 102;          // a near source must still be in the window at the end of the batch
+                if(flen > INF_NEAR_LANE_MAX) {
+                    const uint32_t fdist = q.len_dist >> 16; uint32_t done = 0, span = fdist;
+                    while(done < flen) {
+                        const uint32_t n = span < flen - done ? span : flen - done;
+                        uint8_t snap[INF_WIN]; memcpy(snap, S.win, INF_WIN);      // all lanes read before any lane's write is seen: the round must not depend on lane order
+                        for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[(W + done + i) & (INF_WIN - 1)] = snap[(W - fdist + i) & (INF_WIN - 1)];
+                        done += n; span <<= 1;
+                    }
+                    pending &= ~(1ull << f); (*n_near)++;
+                    continue;
+                }
+                uint64_t ready = 0;
+                for(uint32_t lane = 0; lane < n_tok; lane++) { const InfToken t = S.tok[lane]; const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16); if(((pending >> lane) & 1ull) && len <= INF_NEAR_LANE_MAX && ((int)lane == f || src + len <= W)) ready |= 1ull << lane; }
+                // the ready lanes copy at the same time, byte i of every token in step i: run from the LAST lane to the first to show that the order between lanes does not matter
+                for(int lane = 63; lane >= 0; lane--) if((ready >> lane) & 1ull) { const InfToken t = S.tok[lane]; const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16); for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = S.win[(src + i) & (INF_WIN - 1)]; (*n_near)++; }
+                pending &= ~ready;
             }
-            (*n_near)++;
         }
         for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
         if(fin) return 0;

@@ -28,10 +28,11 @@ def ours(L, env, tag, reps=3, threads="64"):
         d = work / f"o_{tag}_{rep}"; d.mkdir(exist_ok=True)
         t0 = time.perf_counter()
         r = mdk.run_cli([str(work / f"s{L}.fa"), str(work / f"s{L}.bam"), "-@", threads, "-o", "out"], cwd=d, env=dict(env, MDK_HOST_PROFILE="1"), timeout=120)
-        wall = time.perf_counter() - t0; walls.append(wall)
+        wall = time.perf_counter() - t0; walls.append(wall); t_end = time.time()
         m = re.search(r"total ([0-9.]+)s; chunks prepared", r.stderr)
         same = (d / "out_CpG.bedGraph").exists() and (d / "out_CpG.bedGraph").read_bytes() == (work / f"oracle{L}" / "out_CpG.bedGraph").read_bytes()
-        say(f"## {L} [{tag}] rep {rep} rc {r.returncode} wall {wall:.3f} inside {m.group(1) if m else '?'} identical {same}")
+        ml = re.search(r"leaving at epoch ([0-9.]+)", r.stderr)
+        say(f"## {L} [{tag}] rep {rep} rc {r.returncode} wall {wall:.3f} inside {m.group(1) if m else '?'} exit {t_end - float(ml.group(1)) if ml else -1:.3f} identical {same}")
         for l in r.stderr.splitlines():
             if l.startswith("[mdk"): say("   ", l[:700])
         if r.returncode: say(r.stderr[-1500:])
@@ -46,6 +47,7 @@ for L in sizes:
     if "norectab" in VAR: ours(L, {"MDK_NO_RECTAB": "1"}, f"norectab{L}", 3)
     if "cap24" in VAR: ours(L, {"MDK_SLAB_CAP": "24"}, f"cap24_{L}", 3)
     if "cap8" in VAR: ours(L, {"MDK_SLAB_CAP": "8"}, f"cap8_{L}", 3)
+    if "slowexit" in VAR: ours(L, {"HSA_TOOLS_LIB": ""}, f"slowexit{L}", 3)
     if "noprereg" in VAR: ours(L, {"MDK_NO_PREREG": "1"}, f"noprereg{L}", 2)
     if "hostinflate" in VAR: ours(L, {"MDK_HOST_INFLATE": "1"}, f"hostinflate{L}", 2)
     if "gteams4" in VAR: ours(L, {"MDK_GPU_INFLATE_TEAMS": "4"}, f"gteams4_{L}", 2)
