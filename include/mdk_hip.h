@@ -157,6 +157,8 @@ int  md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bits, int64_
 int  md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b);
 /* waits until the copies md_dev_upload_raw (or md_dev_upload) queued for the slot have read their host memory, which may then be reused */
 int  md_dev_upload_wait(md_dev *h, int slot);
+/* the same without waiting: 1 = they have, 0 = not yet, < 0 error */
+int  md_dev_upload_done(md_dev *h, int slot);
 int  md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b);
 /* the records of an uploaded slot back on the host, as the device holds them: the concatenation of the batch's ranges (bytes)
  * and every record's offset in it (rec_off[n_records]); for a chunk the device preparation gives up on (MDK_ERR_PREP_HOST)

@@ -61,7 +61,7 @@ MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_ope
 #define MDK_GROUP 8
 #define MDK_NGROUPS 3
 enum { G_FREE = 0, G_FILL, G_LAUNCHED };
-typedef struct { mdk_chunk ch[MDK_GROUP]; int slot[MDK_GROUP]; int n, launched[MDK_GROUP], state; } cgroup;
+typedef struct { mdk_chunk ch[MDK_GROUP]; int slot[MDK_GROUP]; int n, launched[MDK_GROUP], state, held, n_held, rel_slot[MDK_GROUP]; mdk_chunk rel_ch[MDK_GROUP]; } cgroup;      /* held: the host memory behind its records has not been given back yet */
 typedef struct {
     mdk_plan *p; md_dev *dev; emitter *em; cgroup G[MDK_NGROUPS];
     pthread_mutex_t mu; pthread_cond_t cv;
@@ -70,6 +70,21 @@ typedef struct {
     int *ref_state; int ref_quit, ref_done; int32_t ref_t0, ref_t1;        /* (mu) per contig: 0 not uploaded yet, 1 resident, < 0 the error its upload met; ref_done: the thread has left */
     double w_down, w_emit; int n_host_prep;
 } xpipe;
+/* Once a group's records have crossed the link (a few ms: they were queued before its kernels), the staging memory they came from goes back to
+ * the inflate teams -- not when the results are in.  block = 0: only if the copies are done already; 1: wait for them (the reader is out of
+ * chunks, perhaps for want of that very memory).  Called by the uploader thread only. */
+static void release_uploaded(xpipe *X, int block) {
+    int k, i;
+    if(getenv("MDK_NO_EARLY_RELEASE")) return;
+    for(k = 0; k < MDK_NGROUPS; k++) {
+        cgroup *g = &X->G[(X->n_up + (uint64_t)k) % MDK_NGROUPS]; int last = -1;      /* oldest first: the group about to be refilled, ..., the one launched last */
+        if(!g->held) continue;
+        for(i = 0; i < g->n_held; i++) if(g->rel_slot[i] >= 0) last = g->rel_slot[i];
+        if(last >= 0) { const int done = block ? (md_dev_upload_wait(X->dev, last) == 0) : md_dev_upload_done(X->dev, last) == 1; if(!done) return; }      /* (in order: a later group's copies are queued behind) */
+        for(i = 0; i < g->n_held; i++) if(g->rel_slot[i] >= 0) (void)mdk_plan_release_records(X->p, &g->rel_ch[i]);
+        g->held = 0; block = 0;
+    }
+}
 static void xp_fail(xpipe *X, int ret) { pthread_mutex_lock(&X->mu); if(!X->ret) X->ret = ret; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu); }
 
 /* the contigs' bases (and BED runs, mappability tracks) go to the device ahead of the chunks, in schedule order */
@@ -194,12 +209,17 @@ int extract_main(int argc, char *argv[]) {
         pthread_mutex_unlock(&X->mu);
         w_group += now_s() - ta;
         if(ret) break;
+        ta = now_s(); while(g->held) release_uploaded(X, 1); release_uploaded(X, 0); w_rel += now_s() - ta;
         /* the first chunk is waited for, the others are taken only if they are ready now */
         g->n = 0;
         while(more && g->n < MDK_GROUP) {
             mdk_chunk *c = &g->ch[g->n];
             ta = now_s();
-            rc = g->n == 0 ? mdk_plan_next_chunk(p, c) : mdk_plan_try_next_chunk(p, c);
+            rc = mdk_plan_try_next_chunk(p, c);
+            if(rc == 2 && g->n == 0) {      /* nothing ready: before waiting, give back what can be given back -- the reader may be short of that very memory */
+                const double tb = now_s(); release_uploaded(X, 1); w_rel += now_s() - tb; ta += now_s() - tb;
+                rc = mdk_plan_next_chunk(p, c);
+            }
             w_next += now_s() - ta;
             if(rc == 2) break;
             if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
@@ -225,19 +245,13 @@ int extract_main(int argc, char *argv[]) {
             if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
             if(nl) { ta = now_s(); rc = md_dev_launch_group(dev, ls, nl); w_sub += now_s() - ta; if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; } }
         }
+        g->n_held = g->n; g->held = 0;
+        for(i = 0; i < g->n; i++) { g->rel_slot[i] = (g->launched[i] && g->ch[i].prep) ? g->slot[i] : -1; g->rel_ch[i] = g->ch[i]; if(g->rel_slot[i] >= 0 && !getenv("MDK_NO_EARLY_RELEASE")) g->held = 1; }
         pthread_mutex_lock(&X->mu);
         if(g->n) { g->state = G_LAUNCHED; X->n_up++; } else g->state = G_FREE;
         pthread_cond_broadcast(&X->cv);
         pthread_mutex_unlock(&X->mu);
-        /* once the group's records have crossed the link (a few ms: they were queued before the kernels), the staging memory they came from
-         * goes back to the inflate teams -- not when the results are in */
-        if(g->n && !getenv("MDK_NO_EARLY_RELEASE")) {
-            int last = -1;
-            for(i = 0; i < g->n; i++) if(g->launched[i] && g->ch[i].prep) last = i;
-            ta = now_s();
-            if(last >= 0 && md_dev_upload_wait(dev, g->slot[last]) == 0) for(i = 0; i < g->n; i++) if(g->launched[i] && g->ch[i].prep) (void)mdk_plan_release_records(p, &g->ch[i]);
-            w_rel += now_s() - ta;
-        }
+        ta = now_s(); release_uploaded(X, 0); w_rel += now_s() - ta;
     }
     if(ret) xp_fail(X, ret);
     pthread_mutex_lock(&X->mu); X->up_done = 1; X->ref_quit = 1; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);

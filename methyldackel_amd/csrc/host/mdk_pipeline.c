@@ -443,7 +443,8 @@ static int reader_fill(mdk_plan *p, pslot *sl) {
     if(p->g_tid != (uint32_t)-1 && p->g_pos >= bam->target_len[tid]) { end = bam->target_len[tid]; p->g_tid++; p->g_pos = 0; }
     if(p->g_end && beg >= p->g_end) return 0;
     c->tid = (int32_t)tid; c->beg = beg; c->end = end;
-    if(p->shard_world > 1 && (int)(c->index % (uint32_t)p->shard_world) != p->shard_rank) c->skipped |= MDK_CHUNK_FOREIGN;
+    if(p->claim) { if(!p->claim(p->claim_ctx, c->index)) c->skipped |= MDK_CHUNK_FOREIGN; }
+    else if(p->shard_world > 1 && (int)(c->index % (uint32_t)p->shard_world) != p->shard_rank) c->skipped |= MDK_CHUNK_FOREIGN;
     if(p->bed_on && !bed_touches(p, (int32_t)tid, beg, end)) {      /* extract.c:352-369: the chunk is passed over before anything else happens */
         c->skipped |= MDK_CHUNK_BED;
         if(p->bai) { p->need_seek = 1; p->carry_len = 0; p->carry_tid = -1; dm_clear(p); return 1; }      /* do not even read its records */
@@ -696,7 +697,8 @@ MDK_LOCAL int pipeline_start(mdk_plan *p) {
     /* beyond a dozen workers the serial reader is the limit, and every slot pins ~1.2 bytes of host memory per raw BAM
      * byte of its chunk (expensive to allocate), so the pipeline depth is bounded; -@ still sizes the inflate pool */
     p->n_workers = p->o.n_threads < 1 ? 1 : p->o.n_threads;
-    { int cap = getenv("MDK_WORKERS") ? atoi(getenv("MDK_WORKERS")) : 12; if(cap < 1) cap = 1; if(p->n_workers > cap) p->n_workers = cap; }
+    { int cap = getenv("MDK_WORKERS") ? atoi(getenv("MDK_WORKERS")) : 12; if(cap < 1) cap = 1; if(p->claim && cap > 2) cap = 2;      /* a rank that claims its chunks must not claim far ahead of what it computes */
+      if(p->n_workers > cap) p->n_workers = cap; }
     if(p->n_hold < 2) p->n_hold = 2;
     p->n_slot = p->n_workers + 1 + p->n_hold;
     p->slot = calloc((size_t)p->n_slot, sizeof(pslot));
@@ -756,6 +758,15 @@ static int next_chunk_ex(mdk_plan *p, mdk_chunk *c, int nonblock) {
         if(nonblock) { pthread_mutex_unlock(&p->mu); return 2; }
         pthread_cond_wait(&p->cv_done, &p->mu);
     }
+    if(found >= 0 && p->slot[found].rc >= 0 && p->slot[found].c.skipped && !(p->o.perread && p->slot[found].c.skipped == MDK_CHUNK_NOREF)) {
+        /* a chunk that was passed over (another rank's, no BED region, no reference) carries nothing the caller could refer to later: its slot
+         * is free again at once and it does not push an older chunk out of the caller's hands -- a rank may see any number of other ranks'
+         * chunks between two of its own */
+        pslot *sl = &p->slot[found];
+        *c = sl->c; rc = 1;
+        slot_release_slabs(p, sl); sl->state = S_FREE; p->next_out++;
+        pthread_cond_signal(&p->cv_free);
+    } else
     if(found >= 0) {
         pslot *sl = &p->slot[found];
         {   /* the oldest chunk still held is no longer referenced by the caller: recycle its buffers */

@@ -96,6 +96,7 @@ struct mdk_plan {
     uint32_t g_tid, g_pos, g_end, bin;
     int dev_prep;                      /* chunks are handed out as raw records for the device to prepare (extract; see mdk_plan_set_prep) */
     int shard_rank, shard_world;       /* interval sharding: this process packs chunk k iff k % world == rank */
+    int (*claim)(void *ctx, uint32_t index); void *claim_ctx;      /* ... or, when set (mdk_ranks.c, MDK_CLAIM=1), iff claim(ctx, k): the ranks claim chunks as they get to them, as the reference's workers do (extract.c:325-350) */
     uint64_t n_variant_positions;
     /* stream state */
     int32_t last_tid, last_pos; int at_eof;

@@ -13,7 +13,11 @@
  *                    libmdk_hip md_comm_result_*) when every rank has a GPU of its own; when two ranks share a physical device --
  *                    a single-GPU box, where RCCL refuses duplicate devices: the tests -- the sender downloads the chunk and the
  *                    ordered site records follow the header over the TCP connection.
- * A rank never needs anything from another rank to compute: there is no collective anywhere on the data path. */
+ * A rank never needs anything from another rank to compute: there is no collective anywhere on the data path.
+ *
+ * MDK_CLAIM=1 (every rank): instead of k mod N the ranks CLAIM chunks as they get to them, as the reference's worker threads do under
+ * positionMutex (extract.c:325-350): rank 0 keeps the counter and hands out the next chunk index over a second connection per rank, so a
+ * rank whose chunks are deep gets fewer of them.  Rank 0 learns who computed a chunk from the counter's log. */
 #include "mdk_plan.h"
 #include <arpa/inet.h>
 #include <netdb.h>
@@ -22,17 +26,18 @@
 #include <sys/socket.h>
 #include <sys/time.h>
 
-typedef struct { int rank, world, *fd; } ranks_t;       /* rank 0: fd[r] = connection to rank r; the others: fd[0] = connection to rank 0 */
+#include <poll.h>
+typedef struct { int rank, world, *fd, *cfd, claim; } ranks_t;       /* rank 0: fd[r] = connection to rank r; the others: fd[0] = connection to rank 0; cfd: the same for the claims (MDK_CLAIM=1) */
 
 static int wr_all(int fd, const void *b, size_t n) { const char *p = b; while(n) { ssize_t k = send(fd, p, n, MSG_NOSIGNAL); if(k <= 0) { if(k < 0 && errno == EINTR) continue; return -1; } p += k; n -= (size_t)k; } return 0; }
 static int rd_all(int fd, void *b, size_t n) { char *p = b; while(n) { ssize_t k = recv(fd, p, n, 0); if(k <= 0) { if(k < 0 && errno == EINTR) continue; return -1; } p += k; n -= (size_t)k; } return 0; }
 
-static void ranks_close(ranks_t *R) { int i; if(!R->fd) return; for(i = 0; i < R->world; i++) if(R->fd[i] >= 0) close(R->fd[i]); free(R->fd); R->fd = NULL; }
+static void ranks_close(ranks_t *R) { int i; if(!R->fd) return; for(i = 0; i < R->world; i++) { if(R->fd[i] >= 0) close(R->fd[i]); if(R->cfd && R->cfd[i] >= 0) close(R->cfd[i]); } free(R->fd); free(R->cfd); R->fd = R->cfd = NULL; }
 static int ranks_open(ranks_t *R) {
     const char *addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1"; const int port = getenv("MDK_PORT") ? atoi(getenv("MDK_PORT")) : getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) + (getenv("MDK_WORLD") ? 0 : 1) : 29517;      /* under torchrun MASTER_PORT is the launcher's own store: the ranks meet one port above it */
     int i, one = 1;
-    R->fd = malloc(sizeof(int) * (size_t)R->world); if(!R->fd) return -1;
-    for(i = 0; i < R->world; i++) R->fd[i] = -1;
+    R->fd = malloc(sizeof(int) * (size_t)R->world); R->cfd = malloc(sizeof(int) * (size_t)R->world); if(!R->fd || !R->cfd) return -1;
+    for(i = 0; i < R->world; i++) R->fd[i] = R->cfd[i] = -1;
     if(R->rank == 0) {
         struct sockaddr_in a; int ls = socket(AF_INET, SOCK_STREAM, 0);
         if(ls < 0) return -1;
@@ -40,27 +45,30 @@ static int ranks_open(ranks_t *R) {
         { struct timeval tv; tv.tv_sec = 120; tv.tv_usec = 0; setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv)); }      /* accept() gives up on a peer that never shows */
         memset(&a, 0, sizeof(a)); a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_ANY); a.sin_port = htons((uint16_t)port);
         if(bind(ls, (struct sockaddr *)&a, sizeof(a)) || listen(ls, R->world)) { fprintf(stderr, "[mdk] rank 0 cannot listen on port %d: %s\n", port, strerror(errno)); close(ls); return -1; }
-        for(i = 1; i < R->world; i++) {
-            int c = accept(ls, NULL, NULL), r = -1;
-            if(c < 0 || rd_all(c, &r, sizeof(r)) || r < 1 || r >= R->world || R->fd[r] >= 0) { fprintf(stderr, "[mdk] rank 0: a peer failed to introduce itself\n"); if(c >= 0) close(c); close(ls); return -1; }
+        for(i = 1; i < (R->claim ? 2 : 1) * (R->world - 1) + 1; i++) {
+            int c = accept(ls, NULL, NULL), r = -1, *slot;
+            if(c < 0 || rd_all(c, &r, sizeof(r)) || (r & 0xffff) < 1 || (r & 0xffff) >= R->world || *(slot = (r & 0x10000) ? &R->cfd[r & 0xffff] : &R->fd[r & 0xffff]) >= 0 || ((r & 0x10000) && !R->claim)) { fprintf(stderr, "[mdk] rank 0: a peer failed to introduce itself\n"); if(c >= 0) close(c); close(ls); return -1; }
             setsockopt(c, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-            R->fd[r] = c;
+            *slot = c;
         }
         close(ls);
     } else {
         struct addrinfo hints, *res = NULL; char ps[16]; int tries, c = -1;
         memset(&hints, 0, sizeof(hints)); hints.ai_family = AF_INET; hints.ai_socktype = SOCK_STREAM; snprintf(ps, sizeof(ps), "%d", port);
         if(getaddrinfo(addr, ps, &hints, &res) || !res) { fprintf(stderr, "[mdk] rank %d cannot resolve %s\n", R->rank, addr); return -1; }
-        for(tries = 0; tries < 600; tries++) {          /* rank 0 may still be starting: up to a minute */
-            c = socket(AF_INET, SOCK_STREAM, 0);
-            if(c >= 0 && connect(c, res->ai_addr, res->ai_addrlen) == 0) break;
-            if(c >= 0) close(c);
-            c = -1; usleep(100000);
+        for(int pass = 0; pass < (R->claim ? 2 : 1); pass++) {
+            const int tag = R->rank | (pass ? 0x10000 : 0);
+            for(tries = 0, c = -1; tries < 600; tries++) {          /* rank 0 may still be starting: up to a minute */
+                c = socket(AF_INET, SOCK_STREAM, 0);
+                if(c >= 0 && connect(c, res->ai_addr, res->ai_addrlen) == 0) break;
+                if(c >= 0) close(c);
+                c = -1; usleep(100000);
+            }
+            if(c < 0 || wr_all(c, &tag, sizeof(int))) { fprintf(stderr, "[mdk] rank %d cannot reach rank 0 at %s:%d\n", R->rank, addr, port); if(c >= 0) close(c); freeaddrinfo(res); return -1; }
+            setsockopt(c, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            if(pass) R->cfd[0] = c; else R->fd[0] = c;
         }
         freeaddrinfo(res);
-        if(c < 0 || wr_all(c, &R->rank, sizeof(int))) { fprintf(stderr, "[mdk] rank %d cannot reach rank 0 at %s:%d\n", R->rank, addr, port); if(c >= 0) close(c); return -1; }
-        setsockopt(c, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-        R->fd[0] = c;
     }
     return 0;
 }
@@ -74,6 +82,60 @@ MDK_LOCAL int ranks_from_env(int *rank, int *world) {
     *world = atoi(w); *rank = r ? atoi(r) : 0;
     if(*rank < 0 || *rank >= *world || *world > 1024) { fprintf(stderr, "[mdk] bad rank %d of %d\n", *rank, *world); return -1; }
     return 1;
+}
+
+/* ---- MDK_CLAIM=1: chunks are claimed, not dealt ---- */
+typedef struct {
+    ranks_t *R; int have; uint32_t granted;                       /* every rank: the chunk index this rank holds a claim on */
+    pthread_mutex_t mu; pthread_cond_t cv; uint32_t next; int32_t *owner; uint32_t cap_owner; pthread_t th; int th_ok, quit;       /* rank 0: the counter and its log */
+} claimer;
+static uint32_t grant(claimer *Q, int rank) {
+    uint32_t g;
+    pthread_mutex_lock(&Q->mu);
+    g = Q->next++;
+    if(g >= Q->cap_owner) { const uint32_t nc = Q->cap_owner ? Q->cap_owner * 2 : 4096; Q->owner = xrealloc(Q->owner, sizeof(int32_t) * nc); Q->cap_owner = nc; }
+    Q->owner[g] = rank;
+    pthread_cond_broadcast(&Q->cv);
+    pthread_mutex_unlock(&Q->mu);
+    return g;
+}
+/* called by the plan's reader thread for every chunk of the schedule, in order: is it this rank's?  A rank holds one claim at a time; the
+ * chunks in front of it have been claimed by others (the counter only grows). */
+static int claim_chunk(void *ctx, uint32_t index) {
+    claimer *Q = ctx; ranks_t *R = Q->R;
+    if(!Q->have) {
+        if(R->rank == 0) Q->granted = grant(Q, 0);
+        else { uint32_t ask = index; if(wr_all(R->cfd[0], &ask, 4) || rd_all(R->cfd[0], &Q->granted, 4)) Q->granted = 0xffffffffu; }      /* rank 0 is gone: nothing is ours any more (the run fails at the next result) */
+        Q->have = 1;
+    }
+    if(index < Q->granted) return 0;
+    Q->have = 0;
+    return 1;
+}
+static void *dispenser_main(void *arg) {          /* rank 0: answers the other ranks' claims */
+    claimer *Q = arg; ranks_t *R = Q->R; struct pollfd *pf = xcalloc((size_t)R->world, sizeof(*pf)); int i, open = R->world - 1;
+    for(i = 1; i < R->world; i++) { pf[i].fd = R->cfd[i]; pf[i].events = POLLIN; }
+    while(open > 0) {
+        int q; pthread_mutex_lock(&Q->mu); q = Q->quit; pthread_mutex_unlock(&Q->mu);
+        if(q) break;
+        if(poll(pf + 1, (nfds_t)(R->world - 1), 200) <= 0) continue;
+        for(i = 1; i < R->world; i++) if(pf[i].fd >= 0 && (pf[i].revents & (POLLIN | POLLHUP | POLLERR))) {
+            uint32_t ask, g;
+            if(rd_all(pf[i].fd, &ask, 4)) { pf[i].fd = -1; open--; continue; }      /* the rank has walked the whole schedule (or died: its missing result says so) */
+            g = grant(Q, i);
+            if(wr_all(pf[i].fd, &g, 4)) { pf[i].fd = -1; open--; }
+        }
+    }
+    free(pf);
+    return NULL;
+}
+static int owner_wait(claimer *Q, uint32_t index) {       /* rank 0: who claimed chunk `index` (waits until somebody has) */
+    int r;
+    pthread_mutex_lock(&Q->mu);
+    while(index >= Q->next && !Q->quit) pthread_cond_wait(&Q->cv, &Q->mu);
+    r = index < Q->next ? Q->owner[index] : -1;
+    pthread_mutex_unlock(&Q->mu);
+    return r;
 }
 
 typedef struct { md_site *site; md_site_var *var; int64_t cap; } hostbuf;
@@ -132,20 +194,29 @@ static int recv_result(ranks_t *R, md_comm *comm, int src, hostbuf *hb, md_sites
 
 MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world) {
     mdk_plan *p = NULL; md_dev *dev = NULL; md_comm *comm = NULL; ranks_t R; devopen_t dop; emitter em; int have_em = 0, rc, ret = 0, i, n_host_prep = 0;
-    mdk_chunk *ring = NULL; int *rslot = NULL; hostbuf *hb = NULL; const int F = world + 2; int head = 0, count = 0, more = 1; uint32_t n_own = 0;
-    char pci[64] = ""; int use_rccl = 1; uint8_t id[MD_COMM_ID_BYTES];
-    R.rank = rank; R.world = world; R.fd = NULL;
+    /* rank 0 keeps F chunks in flight (its own computing, the others' arriving) and hands them on in schedule order.  Dealt k mod N, a round and a
+     * bit; claimed, several rounds: rank 0 collects in order, and while it waits for the oldest chunk -- somebody else's -- it may only claim and
+     * compute as far ahead as its ring is long, whereas the others never wait for anybody */
+    mdk_chunk *ring = NULL; int *rslot = NULL; hostbuf *hb = NULL; const int F = getenv("MDK_CLAIM") ? 3 * world + 6 : world + 2; int head = 0, count = 0, more = 1; uint32_t n_own = 0;
+    char pci[64] = ""; int use_rccl = 1; uint8_t id[MD_COMM_ID_BYTES]; claimer Q; uint64_t n_rec_own = 0;
+    R.rank = rank; R.world = world; R.fd = R.cfd = NULL; R.claim = getenv("MDK_CLAIM") != NULL;
+    memset(&Q, 0, sizeof(Q)); Q.R = &R; pthread_mutex_init(&Q.mu, NULL); pthread_cond_init(&Q.cv, NULL);
     if(rank != 0) setenv("MDK_NO_OUTPUT", "1", 1);              /* only rank 0 writes the files */
     rc = mdk_plan_open(argc, argv, &p);
     if(rc != 0 || !p) return rc;
     mdk_plan_set_prep(p, 1);
     mdk_plan_set_shard(p, rank, world);
-    if(world > 36) { fprintf(stderr, "[mdk] at most 36 ranks\n"); mdk_plan_close(p); return -1; }
-    mdk_plan_set_hold(p, F + 3);
-    memset(&dop, 0, sizeof(dop)); mdk_plan_dev_cfg(p, &dop.cfg); dop.cfg.n_slots = 2;
+    if(world > (getenv("MDK_CLAIM") ? 10 : 36)) { fprintf(stderr, "[mdk] at most %d ranks\n", getenv("MDK_CLAIM") ? 10 : 36); mdk_plan_close(p); return -1; }
+    mdk_plan_set_hold(p, rank == 0 || !getenv("MDK_CLAIM") ? F + 3 : 4);
+    memset(&dop, 0, sizeof(dop)); mdk_plan_dev_cfg(p, &dop.cfg); dop.cfg.n_slots = getenv("MDK_CLAIM") ? F : 2;      /* dealt k mod N, rank 0 never holds more than two chunks of its own among the F of its ring; claimed, all of them may be its own */
     { int nd = md_dev_count(); const char *lr = getenv("LOCAL_RANK"); dop.device = getenv("MDK_DEVICE") ? atoi(getenv("MDK_DEVICE")) : nd > 0 ? (lr ? atoi(lr) : rank) % nd : 0; }
     /* the control connections first: a rank that cannot get its device says so by hanging up, and nobody waits for it */
     if(ranks_open(&R)) { ranks_close(&R); mdk_plan_close(p); return MDK_RC_DEVICE; }
+    if(R.claim) {          /* (before the first mdk_plan_next_chunk starts the reader) */
+        p->claim = claim_chunk; p->claim_ctx = &Q;
+        if(rank == 0) Q.th_ok = pthread_create(&Q.th, NULL, dispenser_main, &Q) == 0;
+        if(rank == 0 && !Q.th_ok) { fprintf(stderr, "[mdk] cannot create a thread\n"); ranks_close(&R); mdk_plan_close(p); return -5; }
+    }
     devopen_main(&dop); dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] rank %d cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", rank, dop.device, dop.err); ranks_close(&R); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); mdk_plan_attach_device(p, dev); }
@@ -186,7 +257,7 @@ MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world) {
                 rc = mdk_plan_ensure_reference(p, dev, c.tid);
                 if(!rc) rc = md_dev_submit_raw(dev, sl, &c.raw);
                 if(rc) { fprintf(stderr, "[mdk] rank %d: device error: %s\n", rank, md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
-                n_own++;
+                n_own++; n_rec_own += c.n_records_seen;
                 if(have_prev) { rc = send_result(&R, dev, comm, p, &prev, prev_slot, &n_host_prep); have_prev = 0; if(rc) { if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); } fprintf(stderr, "[mdk] rank %d: %s\n", rank, md_dev_last_error()); ret = MDK_RC_DEVICE; break; } }
                 prev = c; prev_slot = sl; have_prev = 1;
             }
@@ -202,11 +273,11 @@ MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world) {
             if(rc == 0) { more = 0; continue; }
             rslot[at] = -1;
             if(!c->skipped) {                         /* an own chunk with records */
-                const int sl = (int)(n_own & 1);
+                const int sl = R.claim ? at : (int)(n_own & 1);
                 rc = mdk_plan_ensure_reference(p, dev, c->tid);
                 if(!rc) rc = md_dev_submit_raw(dev, sl, &c->raw);
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
-                rslot[at] = sl; n_own++;
+                rslot[at] = sl; n_own++; n_rec_own += c->n_records_seen;
             }
             count++;
             continue;
@@ -216,7 +287,11 @@ MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world) {
             if(rslot[head] >= 0) {                    /* rank 0's own */
                 rc = md_dev_download(dev, rslot[head], &sites);
                 if(rc == MDK_ERR_PREP_HOST) { rc = mdk_plan_host_prepare_from(p, c, dev, rslot[head]); if(!rc) rc = md_dev_submit(dev, rslot[head], &c->batch); if(!rc) rc = md_dev_download(dev, rslot[head], &sites); n_host_prep++; }
-            } else if(c->skipped == MDK_CHUNK_FOREIGN) rc = recv_result(&R, comm, (int)(c->index % (uint32_t)world), &hb[c->index % (uint32_t)world], &sites);      /* somebody else's, with records */
+            } else if(c->skipped == MDK_CHUNK_FOREIGN) {      /* somebody else's, with records */
+                const int src = R.claim ? owner_wait(&Q, c->index) : (int)(c->index % (uint32_t)world);
+                if(src < 1 || src >= world) { fprintf(stderr, "[mdk] nobody claimed chunk %" PRIu32 "\n", c->index); ret = MDK_RC_DEVICE; break; }
+                rc = recv_result(&R, comm, src, &hb[src], &sites);
+            }
             else rc = 0;                              /* passed over by everybody (-l, a contig the FASTA lacks) */
             if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
             if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
@@ -225,9 +300,10 @@ MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world) {
         }
     }
     if(have_em) { emitter_stop(&em); if(em.failed && !ret) ret = MDK_RC_OUTPUT; }
-    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk ranks] rank %d: %u own chunks, %d prepared on the host after all, rc %d\n", rank, n_own, n_host_prep, ret);
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk ranks] rank %d: %u own chunks (%s) holding %" PRIu64 " records, %d prepared on the host after all, rc %d\n", rank, n_own, R.claim ? "claimed" : "k mod N", n_rec_own, n_host_prep, ret);
     if(rank == 0 && ret == 0) mdk_plan_finish(p);
 out:
+    if(Q.th_ok) { pthread_mutex_lock(&Q.mu); Q.quit = 1; pthread_cond_broadcast(&Q.cv); pthread_mutex_unlock(&Q.mu); pthread_join(Q.th, NULL); }
     ranks_close(&R);
     if(fast_exit_wanted() && ret == 0) leave_fast(ret);
     if(hb) { for(i = 0; i < world; i++) { free(hb[i].site); free(hb[i].var); } free(hb); }

@@ -784,6 +784,16 @@ extern "C" int md_dev_upload_wait(md_dev *h, int slot) {
     return 0;
 }
 
+extern "C" int md_dev_upload_done(md_dev *h, int slot) {
+    Slot *s = get_slot(h, slot);
+    if(!s || !s->uploaded) return fail(MDK_ERR_ARG, "md_dev_upload_done: slot not uploaded", hipSuccess);
+    HIPCHK(hipSetDevice(h->device));
+    const hipError_t e = s->raw_layout ? hipEventQuery(s->e1) : hipStreamQuery(s->stream);
+    if(e == hipSuccess) return 1;
+    if(e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return fail(MDK_ERR_HIP, "hipEventQuery", e);
+}
+
 extern "C" int md_dev_submit_raw(md_dev *h, int slot, const md_raw_batch *b) {
     int rc = md_dev_upload_raw(h, slot, b);
     if(rc) return rc;

@@ -5,11 +5,14 @@
  * "Device memory" is host memory; BGZF pieces are tools/piece_standin.c (zlib); and what a slot "computes" is looked up, by the slot's
  * contig and interval, in the per-column counters the oracle dumped for the same command line (MDK_ORACLE_DUMP -> MDK_STANDIN_DUMP): the
  * counting itself is what the GPU tests check, everything AROUND it is what runs here.  MDK_STANDIN_HANDBACK=k makes every k-th uploaded chunk
- * come back with MDK_ERR_PREP_HOST once, as a chunk with an over-long read-name chain does on the device.
+ * come back with MDK_ERR_PREP_HOST once, as a chunk with an over-long read-name chain does on the device; MDK_STANDIN_US_PER_KREC=t makes a
+ * chunk take t microseconds per 1000 records on the "device" ("compute time" in the background, for the work balance between ranks).
  *   build: gcc -O2 -shared -fPIC -Iinclude -o tools/_build/libmdk_dev_standin.so tools/dev_standin.c -lz -lpthread */
 #define _GNU_SOURCE
 #include <pthread.h>
 #include <stdio.h>
+#include <time.h>
+#include <unistd.h>
 #include "piece_standin.c"
 
 typedef struct { int32_t tid; uint32_t pos, nm, nu, meta, noff, nvar; } row_t;
@@ -24,8 +27,9 @@ static void load_dump(void) {
     }
     fclose(f);
 }
-typedef struct { int used, launched, handed_back; int32_t tid; int64_t beg, end; uint8_t *raw; uint64_t raw_bytes, raw_cap; uint32_t *off; uint32_t n_rec, off_cap; md_site *site; md_site_var *var; int64_t cap; } sslot;
-struct md_dev { md_dev_cfg cfg; int n_slots; sslot *slot; long n_up; int handback; pthread_mutex_t mu; };
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+typedef struct { double ready_at; int used, launched, handed_back; int32_t tid; int64_t beg, end; uint8_t *raw; uint64_t raw_bytes, raw_cap; uint32_t *off; uint32_t n_rec, off_cap; md_site *site; md_site_var *var; int64_t cap; } sslot;
+struct md_dev { md_dev_cfg cfg; int n_slots; sslot *slot; long n_up; int handback; pthread_mutex_t mu; double busy_until; int us_per_krec; };
 const char *md_dev_last_error(void) { return t_err; }
 int md_dev_count(void) { return 1; }
 int md_dev_warm(int device) { (void)device; return 0; }
@@ -36,6 +40,7 @@ int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     if(!g_row && getenv("MDK_STANDIN_DUMP") == NULL) { snprintf(t_err, sizeof t_err, "dev_standin: MDK_STANDIN_DUMP is not set"); free(h); return MDK_ERR_NODEVICE; }
     h->cfg = *cfg; h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2; h->slot = calloc((size_t)h->n_slots, sizeof(sslot)); pthread_mutex_init(&h->mu, NULL);
     h->handback = getenv("MDK_STANDIN_HANDBACK") ? atoi(getenv("MDK_STANDIN_HANDBACK")) : 0;
+    h->us_per_krec = getenv("MDK_STANDIN_US_PER_KREC") ? atoi(getenv("MDK_STANDIN_US_PER_KREC")) : 0;
     *out = h; return h->slot ? 0 : MDK_ERR_NOMEM;
 }
 void md_dev_close(md_dev *h) { int i; if(!h) return; for(i = 0; i < h->n_slots; i++) { free(h->slot[i].raw); free(h->slot[i].off); free(h->slot[i].site); free(h->slot[i].var); } free(h->slot); free(h); }
@@ -82,8 +87,15 @@ int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     return 0;
 }
 int md_dev_upload_wait(md_dev *h, int slot) { return slot_of(h, slot) ? 0 : MDK_ERR_ARG; }
+int md_dev_upload_done(md_dev *h, int slot) { static __thread unsigned n; return slot_of(h, slot) ? (int)(++n % 3 != 0) : MDK_ERR_ARG; }      /* "not yet" now and then: the caller's waiting path runs too */
 int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) { sslot *s = slot_of(h, slot); if(!s || !b) return MDK_ERR_ARG; s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->used = 1; s->launched = 0; s->handed_back = 0; return 0; }
-int md_dev_launch(md_dev *h, int slot) { sslot *s = slot_of(h, slot); if(!s || !s->used) return MDK_ERR_ARG; s->launched = 1; return 0; }
+/* "compute time": MDK_STANDIN_US_PER_KREC microseconds per 1000 records of the chunk, one chunk after the other, in the background -- a download
+ * waits for what is left of it (tests of the work balance between ranks) */
+int md_dev_launch(md_dev *h, int slot) {
+    sslot *s = slot_of(h, slot); if(!s || !s->used) return MDK_ERR_ARG;
+    if(h->us_per_krec > 0) { const double t = now_s(); pthread_mutex_lock(&h->mu); s->ready_at = (h->busy_until > t ? h->busy_until : t) + 1e-9 * h->us_per_krec * s->n_rec; h->busy_until = s->ready_at; pthread_mutex_unlock(&h->mu); }
+    s->launched = 1; return 0;
+}
 int md_dev_launch_group(md_dev *h, const int *slots, int n) { int i; for(i = 0; i < n; i++) if(md_dev_launch(h, slots[i])) return MDK_ERR_ARG; return 0; }
 int md_dev_group_max(void) { return 8; }
 int md_dev_submit(md_dev *h, int slot, const md_read_batch *b) { int rc = md_dev_upload(h, slot, b); return rc ? rc : md_dev_launch(h, slot); }
@@ -98,6 +110,7 @@ int md_dev_download(md_dev *h, int slot, md_sites *out) {
     sslot *s = slot_of(h, slot); size_t a = 0, b = g_nrow, i; int64_t n = 0; const int variant = h && h->cfg.minOppositeDepth > 0;
     if(!s || !out || !s->launched) { snprintf(t_err, sizeof t_err, "dev_standin: slot not launched"); return MDK_ERR_ARG; }
     memset(out, 0, sizeof(*out));
+    { const double t = now_s(); if(s->ready_at > t) usleep((useconds_t)((s->ready_at - t) * 1e6)); }      /* the "device" is still computing this chunk */
     if(s->handed_back) { s->handed_back = 0; snprintf(t_err, sizeof t_err, "dev_standin: this chunk goes back to the host preparation"); return MDK_ERR_PREP_HOST; }
     while(a < b) { const size_t m = (a + b) / 2; if(g_row[m].tid < s->tid || (g_row[m].tid == s->tid && (int64_t)g_row[m].pos < s->beg)) a = m + 1; else b = m; }
     for(i = a; i < g_nrow && g_row[i].tid == s->tid && (int64_t)g_row[i].pos < s->end; i++) n++;
