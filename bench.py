@@ -434,7 +434,7 @@ def main():
                 return r
 
             def run_ours(sp, name, env, runs=3):
-                d = work / f"cg_{name}"; d.mkdir(); rcs = []; ts = []; inner = []
+                d = work / f"cg_{name}"; d.mkdir(); rcs = []; ts = []; inner = []; profs = []
                 for _ in range(runs):
                     time.sleep(0.3)            # (outside the clock) a back-to-back command otherwise waits for the previous process' GPU context to be torn down
                     t1 = time.perf_counter()
@@ -442,8 +442,16 @@ def main():
                     ts.append(time.perf_counter() - t1); rcs.append(r.returncode)
                     m = re.search(r"total ([0-9.]+)s; chunks prepared", r.stderr)          # the command's own clock, entry of extract_main to outputs closed
                     inner.append(float(m.group(1)) if m else None)
+                    profs.append([l[:400] for l in r.stderr.splitlines() if l.startswith("[mdk")])
                 log(f"[bench] {name}: wall {ts} inside the process {inner}")
-                return statistics.median(ts), ts, d, all(r == 0 for r in rcs), inner
+                # a run far off the others is kept with its own account of where the time went (MDK_HOST_PROFILE lines), not just as a number
+                med = statistics.median(ts)
+                for k, t in enumerate(ts):
+                    if t > 1.6 * med and t - med > 0.3:
+                        slow_runs.append({"leg": name, "run": k, "seconds": t, "median": med, "profile": profs[k]})
+                return med, ts, d, all(r == 0 for r in rcs), inner
+
+            slow_runs = []
 
             def calls_of(d):
                 n = 0
@@ -532,6 +540,8 @@ def main():
                                         "speedup_vs_cpu_all_cores": t_xa / t_xg, "identical_to_oracle": bool(ident_x), "inside_process_runs": in_xg,
                                         "bam_GBps": bam_x / t_xg / 1e9, "bam_GBps_inside_process": [bam_x / q / 1e9 if q else None for q in in_xg],
                                         "protocol": "CPU: one run at the large sample's setting; this build: 3 runs, median; whole-process wall clock"}
+            if slow_runs:
+                result["slow_runs"] = slow_runs
           except Exception as ex:            # a leg that fails or hangs (timeout) must not take the measured line with it
             result["legs_error"] = repr(ex)[:500]
             log(f"[bench] a CPU/end-to-end leg failed: {ex!r}")

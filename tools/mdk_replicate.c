@@ -32,10 +32,12 @@ static void *inflate_main(void *a) {
 }
 /* output members: block j of copy k (k = -1: the header block) */
 typedef struct { size_t beg, end; } blk_t;
-static blk_t *g_blk; static size_t g_nblk; static int g_K; static uint8_t **g_out; static uint32_t *g_outlen; static volatile size_t g_task;
+static blk_t *g_blk; static size_t g_nblk; static int g_K; static uint8_t **g_out; static uint32_t *g_outlen; static volatile size_t g_task; static size_t g_w0, g_w1;
+#define WINDOW 16384         /* members compressed per round into buffers that are used again: fresh memory for all 8.7 GB of output costs more than the compression */
 static const uint8_t *g_hdr; static size_t g_hdrlen;
-static uint8_t *bgzf_member(const uint8_t *d, size_t n, uint32_t *len) {
-    uint8_t *o = xm(n + n / 8 + 128); z_stream zs; uint32_t cl;
+static uint8_t *bgzf_member(const uint8_t *d, size_t n, uint32_t *len, uint8_t *o) {
+    z_stream zs; uint32_t cl;
+    if(!o) o = xm(n + n / 8 + 128);
     static const uint8_t H[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
     memcpy(o, H, 16);
     memset(&zs, 0, sizeof zs); zs.next_in = (Bytef *)d; zs.avail_in = (uInt)n; zs.next_out = o + 18; zs.avail_out = (uInt)(n + n / 8 + 64);
@@ -51,12 +53,12 @@ static void *deflate_main(void *a) {
     uint8_t *tmp = xm(65536 + 64);
     (void)a;
     for(;;) {
-        size_t t = __sync_fetch_and_add(&g_task, 1), k, j, o, n;
-        if(t >= (size_t)g_K * g_nblk) break;
+        size_t t = g_w0 + __sync_fetch_and_add(&g_task, 1), k, j, o, n;
+        if(t >= g_w1) break;
         k = t / g_nblk; j = t % g_nblk; n = g_blk[j].end - g_blk[j].beg;
         memcpy(tmp, g_data + g_blk[j].beg, n);
         for(o = 0; o + 4 <= n;) { uint32_t bs = le32(tmp + o); put32(tmp + o + 4, (uint32_t)k); if((int32_t)le32(tmp + o + 4 + 20) >= 0) put32(tmp + o + 4 + 20, (uint32_t)k); o += 4 + bs; }
-        g_out[t] = bgzf_member(tmp, n, &g_outlen[t]);
+        (void)bgzf_member(tmp, n, &g_outlen[t - g_w0], g_out[t - g_w0]);
     }
     free(tmp);
     return NULL;
@@ -96,14 +98,19 @@ int main(int argc, char **argv) {
       hb = xm((size_t)tl + 64 + (size_t)K * (l_name + 32)); memcpy(hb, "BAM\1", 4); put32(hb + 4, (uint32_t)tl); memcpy(hb + 8, txt, (size_t)tl); put32(hb + 8 + tl, (uint32_t)K); hl = 12 + (size_t)tl;
       for(k = 0; k < K; k++) { char nm[300]; int nl = snprintf(nm, sizeof nm, "%s_%d", ref_name, k + 1) + 1; put32(hb + hl, (uint32_t)nl); memcpy(hb + hl + 4, nm, (size_t)nl); put32(hb + hl + 4 + nl, ref_len); hl += 8 + (size_t)nl; }
       if(hl > 65280) { fprintf(stderr, "mdk_replicate: header too large\n"); return 1; }
-      g_hdr = hb; g_hdrlen = hl; hdr_member = bgzf_member(g_hdr, g_hdrlen, &hdr_len); }
-    g_K = K; g_out = xm(sizeof(uint8_t *) * (size_t)K * g_nblk); g_outlen = xm(sizeof(uint32_t) * (size_t)K * g_nblk);
-    for(t = 0; t < nt; t++) pthread_create(&th[t], NULL, deflate_main, NULL);
-    for(t = 0; t < nt; t++) pthread_join(th[t], NULL);
+      g_hdr = hb; g_hdrlen = hl; hdr_member = bgzf_member(g_hdr, g_hdrlen, &hdr_len, NULL); }
+    g_K = K; g_out = xm(sizeof(uint8_t *) * WINDOW); g_outlen = xm(sizeof(uint32_t) * WINDOW);
+    for(i = 0; i < WINDOW; i++) g_out[i] = xm(65536 + 8192 + 128);
     snprintf(fn, sizeof fn, "%s.bam", argv[2]); f = fopen(fn, "wb"); if(!f) { perror(fn); return 1; }
     { static const uint8_t EOFM[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t bytes = hdr_len;
+      setvbuf(f, NULL, _IOFBF, 8u << 20);
       fwrite(hdr_member, 1, hdr_len, f);
-      for(i = 0; i < (size_t)K * g_nblk; i++) { fwrite(g_out[i], 1, g_outlen[i], f); bytes += g_outlen[i]; free(g_out[i]); }
+      for(g_w0 = 0; g_w0 < (size_t)K * g_nblk; g_w0 = g_w1) {
+          g_w1 = g_w0 + WINDOW < (size_t)K * g_nblk ? g_w0 + WINDOW : (size_t)K * g_nblk; g_task = 0;
+          for(t = 0; t < nt; t++) pthread_create(&th[t], NULL, deflate_main, NULL);
+          for(t = 0; t < nt; t++) pthread_join(th[t], NULL);
+          for(i = 0; i < g_w1 - g_w0; i++) { fwrite(g_out[i], 1, g_outlen[i], f); bytes += g_outlen[i]; }
+      }
       fwrite(EOFM, 1, 28, f); if(fclose(f)) { perror(fn); return 1; }
       printf("{\"contigs\": %d, \"contig_bp\": %" PRIu32 ", \"members\": %zu, \"bam_bytes\": %" PRIu64 ", \"inflated_bytes\": %zu}\n", K, ref_len, (size_t)K * g_nblk + 2, bytes + 28, g_hdrlen + (size_t)K * (total - rec0)); }
     /* FASTA: the same bases under K names */
