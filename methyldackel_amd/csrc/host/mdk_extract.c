@@ -110,6 +110,19 @@ static int ref_wait(xpipe *X, int32_t tid) {
     return rc == 1 ? 0 : rc ? rc : -1;
 }
 
+/* MDK_WATCHDOG=1 (diagnostics): once a second, where every stage of the pipeline stands -- for a run that stalls */
+static volatile int g_up_phase, g_col_phase;
+static void *watchdog_main(void *arg) {
+    xpipe *X = arg; mdk_plan *p = X->p; mdk_bam *b = p->bam; int k; const double t0 = now_s();
+    for(;;) {
+        int q, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for(k = 0; k < 10; k++) { usleep(100000); pthread_mutex_lock(&X->mu); q = X->up_done && X->n_col == X->n_up; pthread_mutex_unlock(&X->mu); if(q) return NULL; }
+        for(k = 0; k < p->n_slot; k++) st[p->slot_state ? p->slot_state(p, k) & 7 : 0]++;
+        fprintf(stderr, "[mdk watchdog] %.1fs: uploader phase %d groups launched %" PRIu64 " collected %" PRIu64 " collector phase %d | chunks handed out %u, slots free/fill/raw/work/done/held %d/%d/%d/%d/%d/%d | pieces handed %" PRIu64 " popped %" PRIu64 " ready %d, slabs host %d(+%d free) device %d(+%d free), io %d inf_done %d\n",
+                now_s() - t0, g_up_phase, X->n_up, X->n_col, g_col_phase, p->next_out, st[0], st[1], st[2], st[3], st[4], st[5], b->next_seq, b->pop_seq, b->n_ready, b->n_alloc, b->n_pool, b->n_dalloc, b->n_dpool, b->io_status, b->inf_done);
+    }
+}
+
 /* collects the launched groups in order: results to the emitter, the group back to the uploader */
 static void *collector_main(void *arg) {
     xpipe *X = arg; mdk_plan *p = X->p; md_dev *dev = X->dev; int i;
@@ -122,8 +135,9 @@ static void *collector_main(void *arg) {
         pthread_mutex_unlock(&X->mu);
         memset(sites, 0, sizeof(sites));
         for(i = 0; i < g->n; i++) if(g->launched[i]) { ls[nl] = g->slot[i]; li[nl] = i; nl++; }
-        ta = now_s();
+        ta = now_s(); g_col_phase = 1;
         if(nl) rc = md_dev_download_group(dev, ls, nl, st, rcs);
+        g_col_phase = 2;
         if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); xp_fail(X, MDK_RC_DEVICE); break; }
         for(i = 0; i < nl && !bad; i++) {
             const int k = li[i];
@@ -143,9 +157,11 @@ static void *collector_main(void *arg) {
         X->w_down += now_s() - ta;
         if(bad) break;
         ta = now_s();
+        g_col_phase = 3;
         for(i = 0; i < g->n; i++) if(emitter_push(X->em, &g->ch[i], &sites[i])) { xp_fail(X, X->em->failed ? MDK_RC_OUTPUT : MDK_RC_DEVICE); bad = 1; break; }
         X->w_emit += now_s() - ta;
         if(bad) break;
+        g_col_phase = 0;
         pthread_mutex_lock(&X->mu); g->n = 0; g->state = G_FREE; X->n_col++; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
     }
     return NULL;
@@ -197,11 +213,12 @@ int extract_main(int argc, char *argv[]) {
     preg_ok = !getenv("MDK_NO_PREREG") && pthread_create(&preg, NULL, prereg_main, dev) == 0;
     rth_ok = pthread_create(&rth, NULL, refs_main, X) == 0;
     cth_ok = pthread_create(&cth, NULL, collector_main, X) == 0;
+    if(getenv("MDK_WATCHDOG")) { pthread_t wd; if(pthread_create(&wd, NULL, watchdog_main, X) == 0) pthread_detach(wd); }
     if(!rth_ok || !cth_ok) { fprintf(stderr, "[mdk] cannot create a thread\n"); ret = -5; more = 0; }
     while(more && !ret) {
         cgroup *g;
         /* the next group, once the collector has given it back */
-        ta = now_s();
+        ta = now_s(); g_up_phase = 1;
         pthread_mutex_lock(&X->mu);
         g = &X->G[X->n_up % MDK_NGROUPS];
         while(g->state != G_FREE && !X->ret) pthread_cond_wait(&X->cv, &X->mu);
@@ -209,7 +226,7 @@ int extract_main(int argc, char *argv[]) {
         pthread_mutex_unlock(&X->mu);
         w_group += now_s() - ta;
         if(ret) break;
-        ta = now_s(); while(g->held) release_uploaded(X, 1); release_uploaded(X, 0); w_rel += now_s() - ta;
+        g_up_phase = 2; ta = now_s(); while(g->held) release_uploaded(X, 1); release_uploaded(X, 0); w_rel += now_s() - ta; g_up_phase = 3;
         /* the first chunk is waited for, the others are taken only if they are ready now */
         g->n = 0;
         while(more && g->n < MDK_GROUP) {
@@ -217,8 +234,8 @@ int extract_main(int argc, char *argv[]) {
             ta = now_s();
             rc = mdk_plan_try_next_chunk(p, c);
             if(rc == 2 && g->n == 0) {      /* nothing ready: before waiting, give back what can be given back -- the reader may be short of that very memory */
-                const double tb = now_s(); release_uploaded(X, 1); w_rel += now_s() - tb; ta += now_s() - tb;
-                rc = mdk_plan_next_chunk(p, c);
+                const double tb = now_s(); g_up_phase = 4; release_uploaded(X, 1); w_rel += now_s() - tb; ta += now_s() - tb;
+                g_up_phase = 5; rc = mdk_plan_next_chunk(p, c); g_up_phase = 3;
             }
             w_next += now_s() - ta;
             if(rc == 2) break;
@@ -227,9 +244,9 @@ int extract_main(int argc, char *argv[]) {
             g->launched[g->n] = 0;
             if(!c->skipped) {
                 ta = now_s(); rc = c->prep ? 0 : ref_wait(X, c->tid); w_ref += now_s() - ta;       /* (raw records can cross the link before the contig's bases have) */
-                ta = now_s();
+                ta = now_s(); g_up_phase = 6;
                 if(!rc) rc = c->prep ? md_dev_upload_raw(dev, g->slot[g->n], &c->raw) : md_dev_upload(dev, g->slot[g->n], &c->batch);
-                w_sub += now_s() - ta;
+                w_sub += now_s() - ta; g_up_phase = 3;
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
                 g->launched[g->n] = 1;
             }
@@ -239,10 +256,11 @@ int extract_main(int argc, char *argv[]) {
         {   /* one launch per kernel for the group's chunks */
             int ls[MDK_GROUP], nl = 0;
             for(i = 0; i < g->n; i++) if(g->launched[i]) ls[nl++] = g->slot[i];
-            ta = now_s();
+            ta = now_s(); g_up_phase = 7;
             for(i = 0, rc = 0; i < g->n && !rc; i++) if(g->launched[i] && g->ch[i].prep) rc = ref_wait(X, g->ch[i].tid);
             w_ref += now_s() - ta;
             if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+            g_up_phase = 8;
             if(nl) { ta = now_s(); rc = md_dev_launch_group(dev, ls, nl); w_sub += now_s() - ta; if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; } }
         }
         g->n_held = g->n; g->held = 0;

@@ -692,8 +692,10 @@ static void *worker_main(void *arg) {
     free(t_qt); t_qt = NULL; t_qt_cap = 0; free(t_side); t_side = NULL; t_side_cap = t_side_n = 0;
     return NULL;
 }
+static int slot_state_of(const mdk_plan *p, int k) { return p->slot[k].state; }
 MDK_LOCAL int pipeline_start(mdk_plan *p) {
     int i;
+    p->slot_state = slot_state_of;
     /* beyond a dozen workers the serial reader is the limit, and every slot pins ~1.2 bytes of host memory per raw BAM
      * byte of its chunk (expensive to allocate), so the pipeline depth is bounded; -@ still sizes the inflate pool */
     p->n_workers = p->o.n_threads < 1 ? 1 : p->o.n_threads;

@@ -277,10 +277,16 @@ int mdk_plan_regions(const mdk_plan *p, int32_t tid, const md_region **runs, int
 
 /* everything after option parsing that `extract` and `mbias` share: inputs, (extract only) mappability and output
  * files, -r, -l.  Frees the plan and returns the reference's code on failure. */
+/* the FASTA is read (and compacted) on a thread of its own while the BAM is opened: 128 MB take as long as everything else here together */
+typedef struct { const char *fn; mdk_fasta *fa; int rc; } faload_t;
+static void *faload_main(void *arg) { faload_t *f = arg; f->rc = mdk_fasta_load(f->fn, f->fa); return NULL; }
 MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional) {
-    opts_t *o = &p->o; int i; char *oname; FILE *bbm = NULL;
+    opts_t *o = &p->o; int i; char *oname; FILE *bbm = NULL; faload_t fl; pthread_t fth; int fth_ok;
     o->fasta_name = argv[first_positional]; o->bam_name = argv[first_positional + 1];
     if(o->n_threads < 1) o->n_threads = 1;
+    fl.fn = o->fasta_name; fl.fa = &p->fa; fl.rc = 0;
+    fth_ok = pthread_create(&fth, NULL, faload_main, &fl) == 0;
+#define FA_JOIN() do { if(fth_ok) { pthread_join(fth, NULL); fth_ok = 0; } } while(0)
     /* staging memory (the reader's slabs, the batch buffers) is huge-page memory that libmdk_hip registers with the runtime the
      * first time an upload reads from it (md_host_alloc): allocating it never waits for the device to come up, and every upload
      * is a DMA off the submitting thread -- the pinned double-buffered feed of the north star, for inputs of any size */
@@ -288,15 +294,16 @@ MDK_LOCAL int plan_attach_inputs(mdk_plan *p, char *argv[], int first_positional
     /* the test hook that leaves every piece after the header's to the device only makes sense where a device will be attached */
     if(o->mbias || o->perread || getenv("MDK_HOST_INFLATE") || getenv("MDK_HOST_PREP")) unsetenv("MDK_DEVICE_INFLATE_ONLY");
     p->bam = mdk_bam_open(o->bam_name, o->n_threads);
-    if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); plan_free(p); return -4; }
+    if(!p->bam) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bam_name); FA_JOIN(); plan_free(p); return -4; }
     p->bai = getenv("MDK_NO_INDEX") ? NULL : mdk_bai_load(o->bam_name);        /* optional: lets -r and sharded runs skip most of the file */
-    if(!o->mbias && !o->perread && o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); plan_free(p); return -8; }
-    if(!o->mbias && !o->perread && o->bw_name) { int rc = load_bigwig(p); if(rc) { if(bbm) fclose(bbm); plan_free(p); return rc; } }
+    if(!o->mbias && !o->perread && o->bbm_name && (bbm = fopen(o->bbm_name, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", o->bbm_name); FA_JOIN(); plan_free(p); return -8; }
+    if(!o->mbias && !o->perread && o->bw_name) { int rc = load_bigwig(p); if(rc) { if(bbm) fclose(bbm); FA_JOIN(); plan_free(p); return rc; } }
     if(bbm) {                  /* as in the reference, a BBM given together with a bigWig replaces the bigWig's bitmaps */
         if(p->map_on) { uint32_t k; for(k = 0; k < p->map_n; k++) { free(p->map_names[k]); free(p->map_bits[k]); } free(p->map_names); free(p->map_len); free(p->map_bits); p->map_names = NULL; p->map_len = NULL; p->map_bits = NULL; p->map_n = 0; }
-        { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { plan_free(p); return rc; } }
+        { int rc = load_bbm(p, bbm); fclose(bbm); if(rc) { FA_JOIN(); plan_free(p); return rc; } }
     }
-    if(mdk_fasta_load(o->fasta_name, &p->fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", o->fasta_name); plan_free(p); return -4; }
+    if(fth_ok) FA_JOIN(); else fl.rc = mdk_fasta_load(o->fasta_name, &p->fa);
+    if(fl.rc != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", o->fasta_name); plan_free(p); return -4; }
     p->fa_of_tid = xmalloc(sizeof(int) * (size_t)(p->bam->n_targets + 1));
     for(i = 0; i < p->bam->n_targets; i++) p->fa_of_tid[i] = mdk_fasta_find(&p->fa, p->bam->target_name[i]);
     if(p->map_on) {

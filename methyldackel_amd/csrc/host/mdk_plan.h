@@ -104,6 +104,7 @@ struct mdk_plan {
     uint8_t *carry2; size_t carry2_len, carry2_cap;
     struct { mdk_slab *slab; int mi; size_t mark; } *dm, *dm2; int n_dm, cap_dm, n_dm2, cap_dm2;      /* members of device-inflated slabs the next chunk looks at again (mdk_pipeline.c) */
     /* chunk pipeline: reader thread -> worker threads -> ordered delivery (see the pipeline section) */
+    int (*slot_state)(const struct mdk_plan *, int);      /* (diagnostics) state of pipeline slot k */
     struct pslot *slot; int n_slot, n_workers; pthread_t reader_th, *worker_th; int started, quit, pipe_rc, reader_done;
     pthread_mutex_t mu; pthread_cond_t cv_free, cv_raw, cv_done;
     uint32_t next_out; int held[40], n_hold;      /* the chunks handed out last (newest first); the oldest is recycled by the next hand-out */

@@ -70,19 +70,7 @@ struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 #ifndef PREP_STAGE
 #define PREP_STAGE 1                  // k_prep_scan stages the record stream in LDS (0: every lane reads its record from HBM, round 3's arrangement)
 #endif
-// With exactly eight chunks in a launch (PREP_LOCAL kernels) a chunk belongs to ONE XCD, the one the hardware says the workgroup runs on, and
-// everything the workgroups of a chunk tell each other -- tickets, published counts, the name table's compare-and-swaps -- is done with
-// atomics that the XCD's own L2 resolves (workgroup scope: no trip to the memory side, which is what an agent-scope atomic on coarse-grained
-// memory costs on a part with eight L2s: ~2 us and a 64-byte write request each).  Polling is a read-modify-write too (an atomic add of 0):
-// those always execute in L2, a load of that scope might be served from the CU's own cache.  What other XCDs read -- the next kernel --
-// is written back at the kernel's end as always.  Because the assignment of workgroups to XCDs is the hardware's business, a workgroup here
-// keeps drawing tickets of its XCD's chunk until there are none left, however many workgroups that XCD was given.
-#ifndef PREP_LOCAL_ON
-#define PREP_LOCAL_ON 1
-#endif
-__device__ __forceinline__ uint32_t xcc_id() { return (uint32_t)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u; }       // hwreg(HW_REG_XCC_ID, 0, 4)
-template <bool L> __device__ __forceinline__ int chunk_of_block(const PrepMulti &M) {
-    if(L) return (int)xcc_id();
+__device__ __forceinline__ int chunk_of_block(const PrepMulti &M) {
 #if PREP_XCD
     return (int)((blockIdx.x & 7u) % (unsigned)M.n);
 #else
@@ -91,13 +79,14 @@ template <bool L> __device__ __forceinline__ int chunk_of_block(const PrepMulti 
     return j;
 #endif
 }
-template <bool L> __device__ __forceinline__ uint32_t sync_add(uint32_t *p, uint32_t v) { return L ? __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : atomicAdd(p, v); }
-template <bool L> __device__ __forceinline__ uint32_t sync_peek(uint32_t *p) { return L ? __hip_atomic_fetch_add(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool L> __device__ __forceinline__ void sync_set(uint32_t *p, uint32_t v) { if(L) (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <bool L> __device__ __forceinline__ unsigned long long sync_cas(unsigned long long *p, unsigned long long expected, unsigned long long desired) {
-    if(L) { (void)__hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return expected; }
-    return atomicCAS(p, expected, desired);
-}
+// What the workgroups of a chunk tell each other -- tickets, published counts, the name table's compare-and-swaps -- goes through agent-scope
+// atomics.  (Round 4 tried workgroup-scope atomics with a chunk pinned to the XCD s_getreg(XCC_ID) names and workgroups that keep drawing
+// tickets: the ISA is the same but for one cache bit, the gain was 4 %, and with three groups in flight on three streams the launches
+// dead-locked on the 16-contig 8.7 GB input -- gpurun_out r04l; removed.)
+__device__ __forceinline__ uint32_t sync_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ uint32_t sync_peek(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sync_set(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long sync_cas(unsigned long long *p, unsigned long long expected, unsigned long long desired) { return atomicCAS(p, expected, desired); }
 
 // ---- a record through a view of its bytes; the aux area ----
 struct AuxHit { bool nh, xg; int64_t nh_val; uint8_t xg1; };
@@ -260,12 +249,11 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *red) {
     return t;
 }
 // what the workgroups holding earlier tickets counted, added up (they are running: a ticket is drawn by a workgroup that has started)
-template <bool L>
 __device__ __forceinline__ uint32_t tickets_before(uint32_t *cnt, uint32_t tk, uint32_t *red) {
     uint32_t part = 0;
     for(uint32_t q = threadIdx.x; q < tk; q += PB) {
         uint32_t v;
-        while(!((v = sync_peek<L>(&cnt[q])) & CNT_READY)) __builtin_amdgcn_s_sleep(1);
+        while(!((v = sync_peek(&cnt[q])) & CNT_READY)) __builtin_amdgcn_s_sleep(1);
         part += v & ~CNT_READY;
     }
     return block_sum(part, red);
@@ -369,14 +357,12 @@ __device__ __forceinline__ int scan_record(const PrepParams &P, const V &v, cons
 #define RAWWIN 18944
 #endif
 #define RAWWIN_LDS (RAWWIN + 32)                      // (+ slack for the word reads of a field that ends at the window's end)
-template <bool L>
 __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     __shared__ uint32_t s_tk, wcnt[PB / 64], red[PB / 64];
     extern __shared__ __align__(16) uint4 dyn[];          // PB/64 windows of RAWWIN_LDS bytes; afterwards the workgroup's PrepReads on their way out (64 bytes each)
     uint4 *const stage = dyn;
-    const PrepParams &P = M.P[chunk_of_block<L>(M)];
-  for(;;) {                                               // (L: until the chunk's tickets are gone; otherwise once)
-    if(threadIdx.x == 0) s_tk = sync_add<L>(&P.ticket[0], 1u);
+    const PrepParams &P = M.P[chunk_of_block(M)];
+    if(threadIdx.x == 0) s_tk = sync_add(&P.ticket[0], 1u);
     __syncthreads();
     const uint32_t tk = s_tk; const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than tickets for this chunk
@@ -415,8 +401,8 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     __syncthreads();
     uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0;
     for(int w = 0; w < PB / 64; w++) { if(w < wave) rank += wcnt[w]; total += wcnt[w]; }
-    if(threadIdx.x == 0) sync_set<L>(&P.cntA[tk], total | CNT_READY);
-    const uint32_t base = tickets_before<L>(P.cntA, tk, red);
+    if(threadIdx.x == 0) sync_set(&P.cntA[tk], total | CNT_READY);
+    const uint32_t base = tickets_before(P.cntA, tk, red);
     if((int)tk == P.nblocks - 1 && threadIdx.x == 0) P.cnt->n_adm = base + total;
     const uint32_t a = base + rank;
     if(adm) {
@@ -429,10 +415,10 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
             const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)(a + 1u);
             uint32_t sl = (uint32_t)h & P.hmask; int32_t before = -1;
             for(;;) {
-                unsigned long long old = sync_cas<L>(&P.hent[sl], 0ull, mine);
+                unsigned long long old = sync_cas(&P.hent[sl], 0ull, mine);
                 if(old == 0ull) break;
                 if((old >> 32) == (key >> 32)) {
-                    for(;;) { const unsigned long long seen = sync_cas<L>(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
+                    for(;;) { const unsigned long long seen = sync_cas(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
                     before = (int32_t)(uint32_t)old - 1;
                     break;
                 }
@@ -454,9 +440,6 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
         uint4 *out = (uint4 *)(P.rd + base);
         for(uint32_t q = threadIdx.x; q < 4 * total; q += PB) out[q] = stage[q];
     }
-    if(!L) return;
-    __syncthreads();                                      // the stage and the windows are free for the next ticket
-  }
 }
 
 // what pairing looks at in another read of the name: quad 0 (pos rend ncig|flag strand|nlen) and quad 1 (the name's first 16 bytes) of its
@@ -566,12 +549,10 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const Pre
     return n;
 }
 
-template <bool L>
 __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64];
-    const PrepParams &P = M.P[chunk_of_block<L>(M)];
-  for(;;) {
-    if(threadIdx.x == 0) s_tk = sync_add<L>(&P.ticket[1], 1u);
+    const PrepParams &P = M.P[chunk_of_block(M)];
+    if(threadIdx.x == 0) s_tk = sync_add(&P.ticket[1], 1u);
     __syncthreads();
     const uint32_t tk = s_tk, n_adm = P.cnt->n_adm;
     if(tk * PB >= n_adm) return;                          // (a workgroup that leaves here is never waited for: every ticket before an active one is active)
@@ -594,12 +575,12 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     __syncthreads();
     uint32_t base = incl - n, total = 0;
     for(int w = 0; w < PB / 64; w++) { if(w < wave) base += wsum[w]; total += wsum[w]; }
-    if(threadIdx.x == 0) sync_set<L>(&P.cntS[tk], total | CNT_READY);
+    if(threadIdx.x == 0) sync_set(&P.cntS[tk], total | CNT_READY);
     { unsigned long long b = bytes;
 #pragma unroll
       for(int d = 32; d; d >>= 1) b += __shfl_xor(b, d);
       if(lane == 0 && b) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, b); }
-    const uint32_t before = tickets_before<L>(P.cntS, tk, red);
+    const uint32_t before = tickets_before(P.cntS, tk, red);
     base += before;
     if((tk + 1) * PB >= n_adm && threadIdx.x == 0) P.cnt->n_segs = before + total;
     int64_t lo = INT64_MAX, hi = INT64_MIN;
@@ -617,12 +598,9 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     const int p0 = __shfl_up(t0, 1), p1 = __shfl_up(t1, 1), n0 = __shfl_down(t0, 1), n1 = __shfl_down(t1, 1);
     uint32_t top = base + n; if((int64_t)top > P.cap_seg) top = (uint32_t)P.cap_seg;
     for(int t = t0; t <= t1; t++) {
-        if(lane == 0 || t < p0 || t > p1) { if(L) (void)__hip_atomic_fetch_min(&P.tiles[t].first, (int)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else atomicMin(&P.tiles[t].first, (int)base); }
-        if(lane == 63 || t < n0 || t > n1) { if(L) (void)__hip_atomic_fetch_max(&P.tiles[t].last, (int)top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); else atomicMax(&P.tiles[t].last, (int)top); }
+        if(lane == 0 || t < p0 || t > p1) atomicMin(&P.tiles[t].first, (int)base);
+        if(lane == 63 || t < n0 || t > n1) atomicMax(&P.tiles[t].last, (int)top);
     }
-    if(!L) return;
-    __syncthreads();
-  }
 }
 
 // perRead over device-selected reads: the walk of k_perread on the records where they lie
@@ -710,8 +688,7 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
 static_assert(PREP_SCAN_LDS >= 4 * PB * sizeof(uint4), "the PrepRead stage lives in the windows' memory");
 MDK_HIDDEN int prep_kernels_init() {        // more dynamic LDS than the default window: once per process
     static int rc = -1;
-    if(rc < 0) rc = (hipFuncSetAttribute((const void *)k_prep_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess &&
-                     hipFuncSetAttribute((const void *)k_prep_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess) ? 0 : 1;
+    if(rc < 0) rc = hipFuncSetAttribute((const void *)k_prep_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess ? 0 : 1;
     return rc;
 }
 static uint32_t pow2_at_least(size_t n) { uint32_t p = 1024; while(p < n) p <<= 1; return p; }
@@ -757,14 +734,8 @@ int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
         }
         static_assert(MAXM <= 8, "chunk_of_block deals the chunks of a launch to 8 XCDs");
 #endif
-        static const bool local_ok = PREP_LOCAL_ON && !getenv("MDK_PREP_AGENT_SCOPE");
-        if(n == MAXM && local_ok) {       // eight chunks, eight XCDs: a chunk's workgroups talk through their XCD's L2
-            hipLaunchKernelGGL(k_prep_scan<true>, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
-            if(!h->prep.perread) hipLaunchKernelGGL(k_prep_segs<true>, dim3(grid), dim3(PB), 0, st, M);
-        } else {
-            hipLaunchKernelGGL(k_prep_scan<false>, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
-            if(!h->prep.perread) hipLaunchKernelGGL(k_prep_segs<false>, dim3(grid), dim3(PB), 0, st, M);
-        }
+        hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
+        if(!h->prep.perread) hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -96,7 +96,8 @@ def test_ranks_driver_on_the_standin_equals_oracle(data, tmp_path, world, extra,
     assert rcs == [0] * world, errs
     same_outputs(od, gd)
     own = [int(re.search(r"rank \d+: (\d+) own chunks", e).group(1)) for e in errs]
-    assert min(own) >= 1 and all(("claimed" if "MDK_CLAIM" in env else "k mod N") in e for e in errs)
+    # (claimed: a rank that starts late on a loaded host may find every chunk of this small input taken -- its share is the balance test's business)
+    assert (sum(own) >= 1 if "MDK_CLAIM" in env else min(own) >= 1) and all(("claimed" if "MDK_CLAIM" in env else "k mod N") in e for e in errs)
 
 
 def skewed_bam(src, dst, window, keep_every):
