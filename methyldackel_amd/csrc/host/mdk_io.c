@@ -366,7 +366,7 @@ int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     int k;
     if(!b || !dev || b->dev) return -1;
     if(n_teams < 1) n_teams = 1;
-    if(n_teams > 6) n_teams = 6;
+    if(n_teams > MDK_GPU_TEAMS_MAX) n_teams = MDK_GPU_TEAMS_MAX;
     pthread_mutex_lock(&b->life_mu);                              /* (the reader thread may be inside a seek, which stops and restarts every team) */
     b->dev = dev; b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + 4;
     if(b->inf_started) {
@@ -392,7 +392,7 @@ void mdk_bam_detach_device(mdk_bam *b) {
     b->n_dpool = 0;
     if(b->cur && b->cur->piece) { slab_destroy(b->cur); b->cur = NULL; }
     pthread_mutex_unlock(&b->mu);
-    for(i = 0; i < 6; i++) { md_host_free(b->gpu_stage[i]); b->gpu_stage[i] = NULL; b->gpu_stage_cap[i] = 0; }
+    for(i = 0; i < MDK_GPU_TEAMS_MAX; i++) { md_host_free(b->gpu_stage[i]); b->gpu_stage[i] = NULL; b->gpu_stage_cap[i] = 0; }
     b->dev = NULL; b->n_gpu_teams = 0;
     pthread_mutex_unlock(&b->life_mu);
 }
@@ -515,7 +515,7 @@ void mdk_bam_close(mdk_bam *b) {
     for(i = 0; i < MDK_READY; i++) if(b->ready[i]) slab_destroy(b->ready[i]);
     for(i = 0; i < b->n_pool; i++) slab_destroy(b->pool[i]);
     for(i = 0; i < b->n_dpool; i++) slab_destroy(b->dpool[i]);
-    for(i = 0; i < 6; i++) md_host_free(b->gpu_stage[i]);
+    for(i = 0; i < MDK_GPU_TEAMS_MAX; i++) md_host_free(b->gpu_stage[i]);
     free(b->pool); free(b->dpool);
     if(b->f) fclose(b->f);
     if(b->target_name) for(i = 0; i < b->n_targets; i++) free(b->target_name[i]);

@@ -44,6 +44,7 @@ typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs;
                           uint32_t *off32; size_t cap_off32;        /* off32[i] = sum[i].off: the records' places as one array, which the device takes as it is (md_raw_range.h_rec_off) */
                           struct md_piece *piece; const uint8_t *d_buf; const uint32_t *d_rec_off; uint64_t d_bytes; uint32_t d_records; } mdk_slab;
 
+#define MDK_GPU_TEAMS_MAX 8        /* device inflate teams: a host thread, a pinned staging block and pieces in flight each */
 typedef struct mdk_bam {
     FILE *f;
     int nthreads;
@@ -60,7 +61,7 @@ typedef struct mdk_bam {
     int inf_done, quit, host_leaves, header_done; size_t gpu_piece_bytes;
     /* teams that inflate on the device (mdk_bam_attach_device): each stages a piece of the file in registered memory and hands it
      * to the device library (md_piece_*); they share the piece counter with the host teams */
-    struct md_dev *dev; pthread_t gpu_th[6]; int n_gpu_teams, gpu_started; uint8_t *gpu_stage[6]; size_t gpu_stage_cap[6];
+    struct md_dev *dev; pthread_t gpu_th[MDK_GPU_TEAMS_MAX]; int n_gpu_teams, gpu_started; uint8_t *gpu_stage[MDK_GPU_TEAMS_MAX]; size_t gpu_stage_cap[MDK_GPU_TEAMS_MAX];
     mdk_slab **dpool; int n_dpool, cap_dpool, n_dalloc, max_dalloc; uint64_t n_dev_pieces, n_host_pieces, n_materialized;
     mdk_slab **pool; int n_pool, cap_pool, n_alloc, max_alloc;
     uint8_t *cbuf; size_t ccap, clen; int file_eof;

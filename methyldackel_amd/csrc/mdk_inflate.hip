@@ -33,6 +33,19 @@ struct InfParams {
     uint32_t *status;                 // [0] = first error: code | member << 8 (0 = none)
 };
 
+// Inclusive prefix sum over the wavefront's 64 lanes in the VALU's own data paths (DPP: shifts inside the rows of 16, then lane 15 / lane 31
+// broadcast to the rows behind) -- six adds and no trip through LDS; __shfl_up compiles to ds_bpermute_b32, six dependent LDS round trips
+// in the middle of every decode round.
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1 (a lane without a source adds 0)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);      // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);      // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // One member by one wavefront.
 __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S, const int m, const int lane) {
     const md_inf_member M = P.mem[m];
@@ -69,26 +82,30 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
                 // the walk: lane 0's symbol is real, the next real one starts where it ends, ... -- a scalar loop over readlane; adv = the symbol's
                 // bits, with bit 8 set where the walk ends behind this symbol (end of block) and bit 9 where it ends AT it (not a code)
                 const uint32_t adv = sy.kind >= 3 ? 0x200u : sy.kind == 2 ? (sy.nbits | 0x100u) : sy.nbits;
+                // (either stop bit carries the walk past lane 63, so the loop tests one thing; where it really stands is put right behind it)
                 uint32_t off = 0, a = 0, lastl = 0; unsigned long long V = 0;
-                do { lastl = off; V |= 1ull << off; a = (uint32_t)__builtin_amdgcn_readlane((int)adv, (int)off); off += a & 0xffu; } while(off < 64 && a < 0x100u);
+                do { lastl = off; V |= 1ull << off; a = (uint32_t)__builtin_amdgcn_readlane((int)adv, (int)off); off += a; } while(off < 64);
+                off = lastl + (a & 0xffu);
                 uint32_t stop = a >= 0x200u ? (uint32_t)__builtin_amdgcn_readlane((int)sy.kind, (int)lastl) : a >= 0x100u ? 2u : 0u;
                 if(stop >= 3) V &= ~(1ull << lastl);
                 bool valid = (V >> lane) & 1ull;
                 const uint32_t olen = !valid ? 0u : sy.kind == 0 ? 1u : sy.kind == 1 ? (sy.val & 0xffffu) : 0u;
-                uint32_t incl = olen;
-#pragma unroll
-                for(int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if(lane >= d) incl += t; }
+                const uint32_t incl = wave_incl_sum(olen);
                 const uint32_t dst = pos + incl - olen;
                 bool ism = valid && sy.kind == 1;
                 unsigned long long mball = __ballot(ism);
                 // the batch's limits: 64 match tokens, INF_BATCH_BYTES of output -- the first symbol that does not fit ends the round in front of it
-                const unsigned long long cm = __ballot(valid && ((ism && n_tok + (uint32_t)__popcll(mball & lt) >= INF_MAX_TOK) || dst + olen > beg + INF_BATCH_BYTES));
+                // (rarely the case: asked of the round as a whole first -- its last real symbol's end, all its matches)
+                const uint32_t vend = V ? (uint32_t)__builtin_amdgcn_readlane((int)(dst + olen), 63 - __clzll((long long)V)) : pos;
+                unsigned long long cm = 0;
+                if(vend > beg + INF_BATCH_BYTES || n_tok + (uint32_t)__popcll(mball) > INF_MAX_TOK)
+                    cm = __ballot(valid && ((ism && n_tok + (uint32_t)__popcll(mball & lt) >= INF_MAX_TOK) || dst + olen > beg + INF_BATCH_BYTES));
                 if(cm) { const int c = __ffsll((long long)cm) - 1; V &= (1ull << c) - 1ull; off = (uint32_t)c; stop = 1; valid = (V >> lane) & 1ull; ism = ism && valid; mball = __ballot(ism); }
                 if(__ballot(ism && (sy.val >> 16) > dst)) { err = INF_E_DIST; break; }
                 if(valid && sy.kind == 0) S.win[dst & (INF_WIN - 1)] = (uint8_t)sy.val;
                 if(ism) { InfToken t; t.dst = dst; t.len_dist = sy.val; S.tok[n_tok + (uint32_t)__popcll(mball & lt)] = t; }
                 n_tok += (uint32_t)__popcll(mball);
-                { const int hi = V ? 63 - __clzll((long long)V) : 0; pos = V ? (uint32_t)__builtin_amdgcn_readlane((int)(dst + olen), hi) : pos; }
+                pos = cm ? (V ? (uint32_t)__builtin_amdgcn_readlane((int)(dst + olen), 63 - __clzll((long long)V)) : pos) : vend;
                 bitpos += off;
                 if(stop >= 3) { err = stop == 3 ? INF_E_SYMBOL : INF_E_DIST; break; }
                 if(stop == 2) { in_block = 0; fin = last; break; }
@@ -298,7 +315,7 @@ extern "C" int md_piece_create(md_dev *h, md_piece **out) {
     *out = nullptr;
     HIPCHK(hipSetDevice(h->device));
     md_piece *p = new md_piece(); p->h = h;
-    if(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
+    if(mdk_stream_create(&p->stream, false) != hipSuccess || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
     if(p->d_status.need(4) || p->h_status.need(4)) { delete p; return MDK_ERR_NOMEM; }
     p->check_crc = !getenv("MDK_NO_CRC");
     if(p->check_crc && !crc_const_of(h)) { delete p; return fail(MDK_ERR_NOMEM, "md_piece_create: CRC tables", hipSuccess); }

@@ -277,8 +277,8 @@ struct InfSym { uint32_t nbits, kind, val; };
 MDK_HD InfSym inf_decode_at(const InfShared &S, const uint32_t bitpos) {
     const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
     const uint32_t w0 = S.in[w & (INF_IN_WORDS - 1)], w1 = S.in[(w + 1) & (INF_IN_WORDS - 1)], w2 = S.in[(w + 2) & (INF_IN_WORDS - 1)];
-    uint64_t b = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh;
-    if(sh) b |= (uint64_t)w2 << (64 - sh);
+    // (the three words are asked for together; w2's share without a branch: shifted out whole when sh = 0)
+    const uint64_t b = (((uint64_t)w0 | ((uint64_t)w1 << 32)) >> sh) | ((((uint64_t)w2) << 1) << (63u - sh));
     uint32_t x = (uint32_t)b, used = 0;
     uint32_t e = S.lit[x & ((1u << INF_LIT_TB) - 1u)];
     if((e & (INF_L_LEN | 0x6000u)) == INF_L_SUB) {        // a code longer than the root table

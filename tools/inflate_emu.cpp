@@ -45,7 +45,8 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
                 for(uint32_t lane = 0; lane < 64; lane++) sy[lane] = inf_decode_at(S, bitpos + lane);
                 uint32_t adv[64]; for(uint32_t lane = 0; lane < 64; lane++) adv[lane] = sy[lane].kind >= 3 ? 0x200u : sy[lane].kind == 2 ? (sy[lane].nbits | 0x100u) : sy[lane].nbits;
                 uint32_t off = 0, a = 0, lastl = 0; uint64_t V = 0;
-                do { lastl = off; V |= 1ull << off; a = adv[off]; off += a & 0xffu; } while(off < 64 && a < 0x100u);
+                do { lastl = off; V |= 1ull << off; a = adv[off]; off += a; } while(off < 64);
+                off = lastl + (a & 0xffu);
                 uint32_t stop = a >= 0x200u ? sy[lastl].kind : a >= 0x100u ? 2u : 0u;
                 if(stop >= 3) V &= ~(1ull << lastl);
                 uint32_t olen[64], dst[64], mpre[64]; uint32_t run = 0, nm = 0; uint64_t mball = 0, cm = 0;
