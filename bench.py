@@ -516,6 +516,7 @@ def main():
                 if t_alt < t_la:
                     (t_la, ts_la), d_la = run_oracle(spl, "large_alt3", alt[0], alt[1], 2); ts_la = ts_la + [t_alt]; t_la = statistics.median(ts_la); cfg_l = {"threads": alt[0], "chunk_size": alt[1]}
                 t_lg, ts_lg, d_lg, ok_lg, in_lg = run_ours(spl, "large_default", {}, runs=5)
+                t_lp, ts_lp, _, _, _ = run_ours(spl, "large_inplace", {"MDK_NO_DETACH": "1"}, runs=3)
                 ident_l = ok_lg and all((d_lg / f).read_bytes() == (d_la / f).read_bytes() for f in os.listdir(d_la))
                 calls_l = calls_of(d_la)
                 bam_l = os.path.getsize(str(spl) + ".bam")
@@ -523,6 +524,10 @@ def main():
                                        "cpu_all_cores_seconds": t_la, "cpu_runs": ts_la, "cpu_setting": cfg_l, "seconds": t_lg, "runs": ts_lg, "value": calls_l / t_lg, "unit": "CpG calls/s",
                                        "speedup_vs_cpu_all_cores": t_la / t_lg, "identical_to_oracle": bool(ident_l),
                                        "inside_process_runs": in_lg, "bam_GBps": bam_l / t_lg / 1e9,
+                                       "teardown_in_place": {"seconds": t_lp, "runs": ts_lp, "speedup_vs_cpu_all_cores": t_la / t_lp,
+                                                             "note": "MDK_NO_DETACH=1: the process that did the work is the one the caller waits for, address-space teardown (~0.2 s of kernel time "
+                                                                     "after the outputs are closed) included.  By default the command's work is done by a child and the command returns when the child "
+                                                                     "reports its outputs closed (csrc/host/main.c detach_teardown, as the mold linker does)"},
                                        "protocol": "CPU: the sweep's best setting and one alternative, the faster of them, median; this build: 5 runs, median; whole-process wall clock"}
                 if args.xl_copies > 1:
                     # a sample large enough that start-up and exit are a small part of the run: K copies of the large sample as K contigs (tools/mdk_replicate)
@@ -533,11 +538,13 @@ def main():
                         log(f"[bench] xl sample written in {time.time() - t1:.1f} s")
                     (t_xa, ts_xa), d_xa = run_oracle(spx, "xl_allcore", cfg_l["threads"], cfg_l["chunk_size"], 1)
                     t_xg, ts_xg, d_xg, ok_xg, in_xg = run_ours(spx, "xl_default", {}, runs=3)
+                    t_xp, ts_xp, _, _, _ = run_ours(spx, "xl_inplace", {"MDK_NO_DETACH": "1"}, runs=2)
                     ident_x = ok_xg and all((d_xg / f).read_bytes() == (d_xa / f).read_bytes() for f in os.listdir(d_xa))
                     calls_x = calls_of(d_xa); bam_x = os.path.getsize(str(spx) + ".bam")
                     result["e2e_xl"] = {"sample_bp": args.large_sample_length * args.xl_copies, "contigs": args.xl_copies, "bam_bytes": bam_x, "cpg_calls": calls_x,
                                         "cpu_all_cores_seconds": t_xa, "cpu_runs": ts_xa, "cpu_setting": cfg_l, "seconds": t_xg, "runs": ts_xg, "value": calls_x / t_xg, "unit": "CpG calls/s",
                                         "speedup_vs_cpu_all_cores": t_xa / t_xg, "identical_to_oracle": bool(ident_x), "inside_process_runs": in_xg,
+                                        "teardown_in_place": {"seconds": t_xp, "runs": ts_xp, "speedup_vs_cpu_all_cores": t_xa / t_xp},
                                         "bam_GBps": bam_x / t_xg / 1e9, "bam_GBps_inside_process": [bam_x / q / 1e9 if q else None for q in in_xg],
                                         "protocol": "CPU: one run at the large sample's setting; this build: 3 runs, median; whole-process wall clock"}
             if slow_runs:

@@ -4,6 +4,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/prctl.h>
+#include <sys/wait.h>
 #include "mdk_extract.h"
 
 static void usage_main(void) {
@@ -13,6 +18,58 @@ static void usage_main(void) {
                     "    mbias    Determine the position-dependent methylation bias in a dataset (GPU).\n"
                     "    perRead  Generate a per-read methylation summary (GPU).\n"
                     "    mergeContext   Combine single Cytosine metrics from 'MethylDackel extract' into per-CpG/CHG metrics.\n");
+}
+/* A finished run still holds gigabytes of pinned staging blocks, device memory and queues, and the kernel takes ~0.2 s to take that address space
+ * down (measured: tools/exit_stack_probe.py -- between _exit and the moment the parent can reap, one task is left, the one inside exit_mmap) --
+ * AFTER every output is complete and closed.  So, as the mold linker does, the work is done by a child and this process, which holds nothing,
+ * waits only for the child's word that its outputs are closed: it returns the child's code at once and the teardown goes on behind it.  The
+ * child says so in leave (below; mdk_extract.c leave_fast) through the descriptor MDK_DONE_FD names, having closed its standard streams first so
+ * that a caller reading our stdout/stderr through pipes sees their end when we return.  A child that dies without a word is waited for and
+ * its fate is ours.  MDK_NO_DETACH=1, or a profiler in the environment (the tools follow the process they started), runs everything in place. */
+static pid_t g_child = -1;
+static int open_null(void) { return open("/dev/null", O_RDWR); }
+static void forward_signal(int sig) { if(g_child > 0) kill(g_child, sig); }
+static int profiler_present(void) {
+    const char *pre = getenv("LD_PRELOAD");
+    if(getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCPROF_OUTPUT_PATH")) return 1;
+    return pre && (strstr(pre, "rocprof") || strstr(pre, "roctx") || strstr(pre, "rocm"));
+}
+static void say_done(int rc) {              /* the child's last act before it leaves (the same few lines as mdk_extract.c leave_fast) */
+    const char *fdv = getenv("MDK_DONE_FD");
+    fflush(stdout); fflush(stderr);
+    if(fdv) {
+        const int fd = atoi(fdv), nul = open_null();
+        unsigned char code = (unsigned char)(rc & 0xff);
+        if(nul >= 0) { dup2(nul, 0); dup2(nul, 1); dup2(nul, 2); if(nul > 2) close(nul); }
+        (void)prctl(PR_SET_PDEATHSIG, 0);
+        if(write(fd, &code, 1) != 1) { /* the parent is gone: nothing to tell */ }
+        close(fd);
+    }
+}
+/* returns in the child (the work is its to do) or, when nothing was forked, in the only process; the parent never returns */
+static void detach_teardown(void) {
+    int pfd[2]; pid_t c; char num[16];
+    static const int sigs[] = {SIGINT, SIGTERM, SIGHUP, SIGQUIT, SIGUSR1, SIGUSR2};
+    if(getenv("MDK_NO_DETACH") || profiler_present() || pipe(pfd)) return;
+    fflush(stdout); fflush(stderr);
+    c = fork();
+    if(c < 0) { close(pfd[0]); close(pfd[1]); return; }
+    if(c == 0) {
+        close(pfd[0]);
+        (void)prctl(PR_SET_PDEATHSIG, SIGKILL);                  /* nobody to answer to: no work without a parent */
+        if(getppid() == 1) _exit(1);
+        snprintf(num, sizeof(num), "%d", pfd[1]); setenv("MDK_DONE_FD", num, 1);
+        return;
+    }
+    {   unsigned char code = 0; ssize_t n; size_t i; int st = 0;
+        close(pfd[1]); g_child = c;
+        for(i = 0; i < sizeof(sigs) / sizeof(sigs[0]); i++) { struct sigaction sa; memset(&sa, 0, sizeof(sa)); sa.sa_handler = forward_signal; sigaction(sigs[i], &sa, NULL); }
+        do n = read(pfd[0], &code, 1); while(n < 0 && errno == EINTR);
+        if(n == 1) _exit(code);
+        while(waitpid(c, &st, 0) < 0 && errno == EINTR) { }
+        if(WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); raise(WTERMSIG(st)); _exit(128 + WTERMSIG(st)); }
+        _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);
+    }
 }
 int main(int argc, char *argv[]) {
     if(argc == 1) { usage_main(); return 0; }
@@ -32,8 +89,9 @@ int main(int argc, char *argv[]) {
         if(cmd) {
             int rc;
             setenv("MDK_FAST_EXIT", "1", 0);
+            detach_teardown();
             rc = cmd(argc - 1, argv + 1);
-            fflush(stdout); fflush(stderr);
+            say_done(rc);
             _exit(rc & 0xff);
         }
     }

@@ -13,6 +13,8 @@
  * to the emitter, a third uploads the contigs' references ahead of the chunks that need them.
  * There is no CPU implementation of the per-base work in this library.
  */
+#include <fcntl.h>
+#include <sys/prctl.h>
 #include "mdk_plan.h"
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -37,7 +39,16 @@ MDK_LOCAL int fast_exit_wanted(void) {
 /* leave now: outputs are flushed and closed; nobody needs to wait for staging buffers to be unpinned one by one and for the
  * runtime's exit handlers (the `MethylDackel` command only: main.c sets MDK_FAST_EXIT) */
 MDK_LOCAL void leave_fast(int ret) {
+    const char *fdv = getenv("MDK_DONE_FD");
     fflush(stdout); fflush(stderr);
+    if(fdv) {     /* the command runs as the child of a process that only waits for this word (main.c detach_teardown): outputs are closed, it may return */
+        const int fd = atoi(fdv), nul = open("/dev/null", O_RDWR);
+        unsigned char code = (unsigned char)(ret & 0xff);
+        if(nul >= 0) { dup2(nul, 0); dup2(nul, 1); dup2(nul, 2); if(nul > 2) close(nul); }
+        (void)prctl(PR_SET_PDEATHSIG, 0);
+        if(write(fd, &code, 1) != 1) { /* nobody is listening any more */ }
+        close(fd);
+    }
     _exit(ret & 0xff);
 }
 /* the HIP runtime takes 0.1-0.4 s to come up: start that before anything else (options, BAM header, FASTA), on its own thread */

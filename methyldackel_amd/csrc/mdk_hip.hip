@@ -723,12 +723,8 @@ static void launch_pileup_multi(const md_dev *h, int grid, size_t lds, hipStream
 // caller can overlap it with its own start-up; md_dev_open afterwards finds it done.
 // streams made ahead of md_dev_open by md_dev_warm (creating one costs the runtime ~5 ms, and needs nothing the options decide)
 static std::mutex g_stash_mu; static std::vector<hipStream_t> g_stash; static int g_stash_dev = -1;
-hipError_t mdk_stream_create(hipStream_t *s, bool consumer) {
-    static const bool flat = getenv("MDK_NO_PRIO") != nullptr;
-    int least = 0, greatest = 0;
-    if(flat || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) { (void)hipGetLastError(); return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, consumer ? greatest : least);
-}
+// (Round 4 tried stream priorities -- the consumer's streams high, the device inflate's low, so that kernels of microseconds would not queue
+// behind thousands of members: 512 Mb 1.04 -> 0.99 s and 128 Mb 0.376 -> 0.339 s inside WITHOUT them, gpurun_out r04n; all streams are alike.)
 #define WARM_STREAMS 4
 static hipStream_t stream_take(int device) {
     {
@@ -736,7 +732,7 @@ static hipStream_t stream_take(int device) {
         if(g_stash_dev == device && !g_stash.empty()) { hipStream_t s = g_stash.back(); g_stash.pop_back(); return s; }
     }
     hipStream_t s = nullptr;
-    if(mdk_stream_create(&s, true) != hipSuccess) return nullptr;
+    if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return s;
 }
 extern "C" int md_dev_warm(int device) {
@@ -753,7 +749,7 @@ extern "C" int md_dev_warm(int device) {
     const double t3 = mdk_now();
     for(int i = 0; i < WARM_STREAMS; i++) {
         hipStream_t s = nullptr;
-        if(mdk_stream_create(&s, true) != hipSuccess) { (void)hipGetLastError(); break; }
+        if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
         std::lock_guard<std::mutex> lk(g_stash_mu);
         if(g_stash_dev != device) { g_stash.clear(); g_stash_dev = device; }
         g_stash.push_back(s);

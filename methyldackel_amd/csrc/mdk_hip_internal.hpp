@@ -164,10 +164,6 @@ enum { PF_UP_SYNC = 0, PF_UP_ALLOC, PF_UP_COPY, PF_LAUNCH, PF_FIN_WAIT, PF_DL_CO
 MDK_HIDDEN bool mdk_prof_on();
 MDK_HIDDEN void mdk_prof_add(int site, double seconds);
 MDK_HIDDEN double mdk_now();
-// A stream of the consumer (preparation, pileup, the sites' way back: kernels of microseconds the whole pipeline waits for) or of the device
-// inflate (kernels whose wavefronts live for milliseconds and fill every CU): the hardware's dispatcher serves the queue of higher priority
-// first when a workgroup slot falls free, so the short kernels do not stand in line behind thousands of queued members.  MDK_NO_PRIO=1: all alike.
-MDK_HIDDEN hipError_t mdk_stream_create(hipStream_t *s, bool consumer);
 struct ProfScope { int site; double t0; ProfScope(int s) : site(s), t0(mdk_prof_on() ? mdk_now() : 0.0) {} ~ProfScope() { if(mdk_prof_on()) mdk_prof_add(site, mdk_now() - t0); } };
 MDK_HIDDEN Slot *get_slot(md_dev *h, int slot);
 MDK_HIDDEN void host_block_ensure_registered(const void *ptr);      // a huge-page staging block is registered with the runtime at its first upload

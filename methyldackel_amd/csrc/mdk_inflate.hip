@@ -315,7 +315,7 @@ extern "C" int md_piece_create(md_dev *h, md_piece **out) {
     *out = nullptr;
     HIPCHK(hipSetDevice(h->device));
     md_piece *p = new md_piece(); p->h = h;
-    if(mdk_stream_create(&p->stream, false) != hipSuccess || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
+    if(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
     if(p->d_status.need(4) || p->h_status.need(4)) { delete p; return MDK_ERR_NOMEM; }
     p->check_crc = !getenv("MDK_NO_CRC");
     if(p->check_crc && !crc_const_of(h)) { delete p; return fail(MDK_ERR_NOMEM, "md_piece_create: CRC tables", hipSuccess); }

@@ -150,3 +150,41 @@ def test_claimed_chunks_balance_the_work_not_the_count(data, tmp_path):
         held[mode] = [int(re.search(r"holding (\d+) records", e).group(1)) for e in errs]
     assert max(held["dealt"]) > 3 * min(held["dealt"]), held
     assert max(held["claimed"]) <= 1.35 * min(held["claimed"]), held
+
+
+def test_command_hands_its_teardown_to_a_child_and_stays_the_same_command(data, tmp_path):
+    """main.c detach_teardown: the work is done by a child whose word "outputs closed" lets the command return; the command's outputs, return code
+    and fate under a signal are what they are with MDK_NO_DETACH=1"""
+    import signal, time
+    args = [str(data / "s.fa"), str(data / "s.bam"), "-@", "4", "--chunkSize", "20000"]
+    od = oracle(tmp_path, args)
+    for tag, extra in (("detached", {}), ("inplace", {"MDK_NO_DETACH": 1})):
+        gd = tmp_path / tag; gd.mkdir()
+        r = mdk.run_cli(args + ["-o", "out"], cwd=gd, env=standin_env(tmp_path, **extra))
+        assert r.returncode == 0 and "[mdk main] leaving" in r.stderr, r.stderr[-800:]      # (stderr through a pipe: complete, and at its end when the command returns)
+        same_outputs(od, gd)
+        bad = mdk.run_cli([str(data / "s.fa"), str(tmp_path / "no_such.bam"), "-o", "out"], cwd=gd, env=standin_env(tmp_path, **extra))
+        assert bad.returncode == 252 and "Couldn't open" in bad.stderr
+    # a signal to the command reaches the process that does the work: nothing of it is left behind
+    gd = tmp_path / "killed"; gd.mkdir()
+    e = dict(os.environ); e.update(standin_env(tmp_path, MDK_STANDIN_US_PER_KREC=3000000)); e["MDK_NO_RANKS"] = "1"
+    mark = str(gd / "out_marker")
+    p = subprocess.Popen([str(mdk.CLI), "extract"] + args + ["-o", mark], cwd=gd, env=e, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    def workers():
+        n = []
+        for d in os.listdir("/proc"):
+            if d.isdigit():
+                try:
+                    if mark.encode() in open(f"/proc/{d}/cmdline", "rb").read() and open(f"/proc/{d}/stat").read().split(") ")[1][0] != "Z": n.append(int(d))
+                except OSError: pass
+        return n
+    t0 = time.time()
+    while len(workers()) < 2 and time.time() - t0 < 10: time.sleep(0.02)
+    assert len(workers()) == 2                       # the command and its child
+    time.sleep(0.3)
+    p.send_signal(signal.SIGTERM)
+    rc = p.wait(timeout=20)
+    assert rc in (-signal.SIGTERM, 128 + signal.SIGTERM)
+    t0 = time.time()
+    while workers() and time.time() - t0 < 10: time.sleep(0.05)
+    assert workers() == []
