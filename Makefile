@@ -6,7 +6,7 @@ ARCH   ?= gfx950
 HIPFLAGS ?=
 B      := methyldackel_amd/_build
 CFLAGS ?= -O2 -g -Wall -Wextra -Wno-unused-parameter -Wno-sign-compare -fPIC -pthread
-HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_bigwig.c methyldackel_amd/csrc/host/mdk_mbias.c methyldackel_amd/csrc/host/mdk_mergecontext.c methyldackel_amd/csrc/host/mdk_plan.c methyldackel_amd/csrc/host/mdk_pipeline.c methyldackel_amd/csrc/host/mdk_emit.c methyldackel_amd/csrc/host/mdk_extract.c methyldackel_amd/csrc/host/mdk_cmd_mbias.c methyldackel_amd/csrc/host/mdk_cmd_perread.c methyldackel_amd/csrc/host/mdk_affinity.c methyldackel_amd/csrc/host/mdk_ranks.c
+HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_fasta.c methyldackel_amd/csrc/host/mdk_bigwig.c methyldackel_amd/csrc/host/mdk_mbias.c methyldackel_amd/csrc/host/mdk_mergecontext.c methyldackel_amd/csrc/host/mdk_plan.c methyldackel_amd/csrc/host/mdk_pipeline.c methyldackel_amd/csrc/host/mdk_emit.c methyldackel_amd/csrc/host/mdk_extract.c methyldackel_amd/csrc/host/mdk_cmd_mbias.c methyldackel_amd/csrc/host/mdk_cmd_perread.c methyldackel_amd/csrc/host/mdk_affinity.c methyldackel_amd/csrc/host/mdk_ranks.c
 
 all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 
@@ -21,7 +21,7 @@ $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldac
 $(B)/MethylDackel: methyldackel_amd/csrc/host/main.c $(B)/libmdk_extract.so
 	$(CC) $(CFLAGS) -Iinclude -o $@ methyldackel_amd/csrc/host/main.c -L$(B) -lmdk_extract -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
 
-tools: tools/_build/mdk_synth tools/_build/mdk_replicate tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/piece_bench tools/_build/pin_probe tools/_build/feed_harness tools/_build/libmdk_piece_standin.so tools/_build/libmdk_dev_standin.so
+tools: tools/_build/mdk_synth tools/_build/mdk_replicate tools/_build/fasta_probe tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/piece_bench tools/_build/pin_probe tools/_build/feed_harness tools/_build/libmdk_piece_standin.so tools/_build/libmdk_dev_standin.so
 tools/_build/libmdk_piece_standin.so: tools/piece_standin.c include/mdk_hip.h
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -Wall -shared -fPIC -Iinclude -o $@ tools/piece_standin.c -lz
@@ -43,6 +43,9 @@ tools/_build/piece_bench: tools/piece_bench.c include/mdk_hip.h $(B)/libmdk_hip.
 tools/_build/mdk_calib: tools/mdk_calib.hip
 	@mkdir -p tools/_build
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -o $@ tools/mdk_calib.hip
+tools/_build/fasta_probe: tools/fasta_probe.c methyldackel_amd/csrc/host/mdk_fasta.c methyldackel_amd/csrc/host/mdk_io.h
+	@mkdir -p tools/_build
+	$(CC) -O2 -g -Wall -Iinclude -o $@ tools/fasta_probe.c methyldackel_amd/csrc/host/mdk_fasta.c -lpthread
 tools/_build/mdk_replicate: tools/mdk_replicate.c
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -Wall -o $@ tools/mdk_replicate.c -lz -lpthread

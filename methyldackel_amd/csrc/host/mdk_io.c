@@ -675,34 +675,4 @@ int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
     return 1;
 }
 
-/* ---- FASTA ---- */
-int mdk_fasta_load(const char *fn, mdk_fasta *fa) {
-    FILE *f = fopen(fn, "rb"); size_t sz, i, w; char *d; int cur = -1, cap = 0;
-    memset(fa, 0, sizeof(*fa));
-    if(!f) return -1;
-    fseek(f, 0, SEEK_END); sz = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
-    d = malloc(sz + 2);
-    if(!d || fread(d, 1, sz, f) != sz) { fclose(f); free(d); return -1; }
-    fclose(f); d[sz] = '\n'; d[sz + 1] = 0;
-    fa->pool = d;
-    /* in-place compaction: header lines become NUL-terminated names, sequence lines lose their whitespace */
-    for(i = 0, w = 0; i < sz;) {
-        char *nl = memchr(d + i, '\n', sz + 1 - i); size_t e = (size_t)(nl - d);
-        if(d[i] == '>') {
-            size_t s = i + 1, t = s;
-            while(t < e && d[t] != ' ' && d[t] != '\t' && d[t] != '\r') t++;
-            if(cur >= 0) fa->len[cur] = (int64_t)(d + w - fa->seq[cur]);
-            if(fa->n == cap) { cap = cap ? cap * 2 : 64; fa->name = xrealloc(fa->name, sizeof(char *) * cap); fa->seq = xrealloc(fa->seq, sizeof(char *) * cap); fa->len = xrealloc(fa->len, sizeof(int64_t) * cap); }
-            memmove(d + w, d + s, t - s); fa->name[fa->n] = d + w; w += t - s; d[w++] = 0;
-            cur = fa->n++; fa->seq[cur] = d + w; fa->len[cur] = 0;
-        } else if(cur >= 0) {
-            size_t k;
-            for(k = i; k < e; k++) { unsigned char c = (unsigned char)d[k]; if(c > ' ' && c <= '~') d[w++] = (char)c; }
-        }
-        i = e + 1;
-    }
-    if(cur >= 0) fa->len[cur] = (int64_t)(d + w - fa->seq[cur]);
-    return 0;
-}
-void mdk_fasta_free(mdk_fasta *fa) { free(fa->pool); free(fa->name); free(fa->seq); free(fa->len); memset(fa, 0, sizeof(*fa)); }
-int mdk_fasta_find(const mdk_fasta *fa, const char *name) { int i; for(i = 0; i < fa->n; i++) if(!strcmp(fa->name[i], name)) return i; return -1; }
+/* (the FASTA loader: mdk_fasta.c) */

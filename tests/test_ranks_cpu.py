@@ -56,7 +56,7 @@ def same_outputs(od, gd):
     assert seen
 
 
-@pytest.mark.parametrize("extra,env", [([], {}), (["--chunkSize", "7000", "--mergeContext", "--CHG"], {}), (["--chunkSize", "20000"], {"MDK_STANDIN_HANDBACK": 3}),
+@pytest.mark.parametrize("extra,env", [([], {}), (["--chunkSize", "7000", "--mergeContext", "--CHG"], {"MDK_FASTA_THREADS": 5}), (["--chunkSize", "20000"], {"MDK_STANDIN_HANDBACK": 3}),
                                        (["--chunkSize", "333333", "--minOppositeDepth", "2", "--maxVariantFrac", "0.3", "--CHH"], {}), (["--chunkSize", "5000"], {"MDK_DEVICE_INFLATE_ONLY": 1, "MDK_GPU_PIECE_MB": "0.25", "MDK_STANDIN_HANDBACK": 5})])
 def test_extract_main_on_the_standin_equals_oracle(data, tmp_path, extra, env):
     """one process: extract_main's threads, groups of chunks in flight, slabs given back early, chunks handed back to the host preparation, pieces
