@@ -121,14 +121,20 @@ static int ref_wait(xpipe *X, int32_t tid) {
     return rc == 1 ? 0 : rc ? rc : -1;
 }
 
-/* MDK_WATCHDOG=1 (diagnostics): once a second, where every stage of the pipeline stands -- for a run that stalls */
+/* MDK_WATCHDOG=1 (diagnostics): once a second, where every stage of the pipeline stands -- for a run that stalls.  MDK_WATCHDOG=<ms> with
+ * ms >= 2: the same every <ms> milliseconds in short form, a time series of the queues between the stages (which one runs empty, which one full) */
 static volatile int g_up_phase, g_col_phase;
 static void *watchdog_main(void *arg) {
     xpipe *X = arg; mdk_plan *p = X->p; mdk_bam *b = p->bam; int k; const double t0 = now_s();
+    const int ms = atoi(getenv("MDK_WATCHDOG")) >= 2 ? atoi(getenv("MDK_WATCHDOG")) : 1000;
     for(;;) {
         int q, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for(k = 0; k < 10; k++) { usleep(100000); pthread_mutex_lock(&X->mu); q = X->up_done && X->n_col == X->n_up; pthread_mutex_unlock(&X->mu); if(q) return NULL; }
+        if(ms >= 1000) { for(k = 0; k < 10; k++) { usleep(100000); pthread_mutex_lock(&X->mu); q = X->up_done && X->n_col == X->n_up; pthread_mutex_unlock(&X->mu); if(q) return NULL; } }
+        else { usleep((useconds_t)ms * 1000); pthread_mutex_lock(&X->mu); q = X->up_done && X->n_col == X->n_up; pthread_mutex_unlock(&X->mu); if(q) return NULL; }
         for(k = 0; k < p->n_slot; k++) st[p->slot_state ? p->slot_state(p, k) & 7 : 0]++;
+        if(ms < 1000) fprintf(stderr, "[wd] t=%.3f up=%d L=%" PRIu64 " C=%" PRIu64 " col=%d out=%u slots=%d/%d/%d/%d/%d/%d pieces=%" PRIu64 "/%" PRIu64 "/%d slabs=%d+%d/%d+%d\n",
+                now_s() - t0, g_up_phase, X->n_up, X->n_col, g_col_phase, p->next_out, st[0], st[1], st[2], st[3], st[4], st[5], b->next_seq, b->pop_seq, b->n_ready, b->n_alloc, b->n_pool, b->n_dalloc, b->n_dpool);
+        else
         fprintf(stderr, "[mdk watchdog] %.1fs: uploader phase %d groups launched %" PRIu64 " collected %" PRIu64 " collector phase %d | chunks handed out %u, slots free/fill/raw/work/done/held %d/%d/%d/%d/%d/%d | pieces handed %" PRIu64 " popped %" PRIu64 " ready %d, slabs host %d(+%d free) device %d(+%d free), io %d inf_done %d\n",
                 now_s() - t0, g_up_phase, X->n_up, X->n_col, g_col_phase, p->next_out, st[0], st[1], st[2], st[3], st[4], st[5], b->next_seq, b->pop_seq, b->n_ready, b->n_alloc, b->n_pool, b->n_dalloc, b->n_dpool, b->io_status, b->inf_done);
     }
