@@ -113,6 +113,17 @@ void harena_give(void *p) {
         return;
     }
 }
+static void arena_reserve(size_t n_blocks) {      // blocks made ahead of their use (md_dev_warm's side thread): a hipMalloc inside arena_take holds every other taker up
+    int dev = 0;
+    if(!g_arena_on || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+    Arena &A = g_arena[dev];
+    for(;;) {
+        { std::lock_guard<std::mutex> lk(A.mu); if(A.blocks.size() >= n_blocks) return; }
+        char *b = nullptr;
+        if(hipMalloc((void **)&b, ARENA_BLOCK) != hipSuccess) { (void)hipGetLastError(); return; }
+        std::lock_guard<std::mutex> lk(A.mu); A.blocks.push_back(b);
+    }
+}
 static void arena_prime(int device) {          // the first block, while the caller is still starting up (md_dev_warm)
     (void)device;
     void *p = arena_take(256); if(p) arena_give(p);
@@ -756,6 +767,24 @@ extern "C" int md_dev_warm(int device) {
     }
     const double t4 = mdk_now();
     arena_prime(device);
+    // What the first chunk and the first piece would otherwise pay for on the pipeline's critical path (gpurun_out r04p, 3 ms time series: the first
+    // upload took 75 ms and the first group 60 ms, a later group 8): the code objects of the preparation and inflate kernels (every .hip file
+    // is a code object of its own, loaded at the first use of one of its kernels, ~30 ms each) and the copy engines' queues in both directions
+    // (made at the first copy).  On threads of their own, not waited for: whoever needs one of them first waits inside the runtime for that one.
+    if(!getenv("MDK_NO_WARM_SIDE")) {
+        std::thread([device]() { if(hipSetDevice(device) == hipSuccess) (void)prep_kernels_init(); }).detach();
+        std::thread([device]() { if(hipSetDevice(device) == hipSuccess) inflate_kernels_warm(); }).detach();
+        std::thread([device]() {
+            if(hipSetDevice(device) != hipSuccess) return;
+            hipStream_t s = stream_take(device); if(!s) return;
+            void *hp = harena_take(1u << 20), *dp = arena_take(1u << 20);
+            if(hp && dp) { memset(hp, 0, 1u << 20); (void)hipMemcpyAsync(dp, hp, 1u << 20, hipMemcpyHostToDevice, s); (void)hipMemcpyAsync(hp, dp, 1u << 20, hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); }
+            if(hp) harena_give(hp); if(dp) arena_give(dp);
+            arena_reserve(4);             // (24 slots of a 30x 1 Mb chunk each carve ~2.5 GiB)
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lk(g_stash_mu); g_stash.push_back(s);
+        }).detach();
+    }
     if(mdk_prof_on()) fprintf(stderr, "[mdk hip] warm-up: runtime init + device count %.3fs, context (hipSetDevice + hipFree(0)) %.3fs, code object of the pileup kernels %.3fs, %d streams %.3fs, first blocks of carved device / pinned memory %.3fs\n", t1 - t0, t2 - t1, t3 - t2, WARM_STREAMS, t4 - t3, mdk_now() - t4);
     return 0;
 }
@@ -1313,12 +1342,14 @@ extern "C" int md_dev_download_group(md_dev *h, const int *slots, int n, md_site
         for(int i = 0; i < n; i++) rcs[i] = md_dev_download(h, slots[i], &out[i]);
         return 0;
     }
+    static std::atomic<int> first_call{1}; const bool first = mdk_prof_on() && first_call.exchange(0); const double tf0 = first ? mdk_now() : 0;
     {
         ProfScope pf(PF_FIN_WAIT);
         if(hipMemcpyAsync(h->h_status.p + lo, h->d_status.p + lo, sizeof(SlotStatus) * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MDK_ERR_HIP, "D2H status", hipGetLastError());
         hipError_t e = hipStreamSynchronize(st);
         if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
     }
+    if(first) fprintf(stderr, "[mdk hip] the first group's results waited for %.3fs\n", mdk_now() - tf0);
     for(int i = 0; i < n; i++) { cnt[i] = finish_eval(h, ss[i]); if(cnt[i] < 0) rcs[i] = (int)cnt[i]; }      // (a chunk whose segment array had to grow is prepared and piled up again in there)
     {
         ProfScope pf(PF_DL_COPY);

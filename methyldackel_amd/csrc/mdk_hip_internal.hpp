@@ -173,5 +173,7 @@ MDK_HIDDEN int64_t finish_count(md_dev *h, Slot *s);
 MDK_HIDDEN int64_t finish_eval(md_dev *h, Slot *s);      // the status block is already on the host
 MDK_HIDDEN int finish_group(md_dev *h, const int *slots, int n, int64_t *counts);
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s);
+MDK_HIDDEN int prep_kernels_init();           // mdk_prep.hip: its code object loaded, the scan kernel's LDS limit set (once per process)
+MDK_HIDDEN void inflate_kernels_warm();      // mdk_inflate.hip: its code object loaded
 MDK_HIDDEN int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st);      // preparation kernels of up to MAXM uploaded raw slots, one launch each kernel
 #endif

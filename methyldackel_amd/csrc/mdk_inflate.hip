@@ -310,6 +310,12 @@ static void launch_crc(md_dev *h, md_piece *p, hipStream_t st) {
     int grid = (p->n_mem + CRC_WAVES - 1) / CRC_WAVES; if(grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_crc32, dim3(grid), dim3(64 * CRC_WAVES), 0, st, C);
 }
+void inflate_kernels_warm() {
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void *)k_inflate); (void)hipFuncGetAttributes(&fa, (const void *)k_crc32);
+    (void)hipFuncGetAttributes(&fa, (const void *)k_walk<false>); (void)hipFuncGetAttributes(&fa, (const void *)k_walk<true>); (void)hipFuncGetAttributes(&fa, (const void *)k_walk_scan);
+    (void)hipGetLastError();
+}
 extern "C" int md_piece_create(md_dev *h, md_piece **out) {
     if(!h || !out) return fail(MDK_ERR_ARG, "md_piece_create", hipSuccess);
     *out = nullptr;

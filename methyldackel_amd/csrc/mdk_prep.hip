@@ -26,6 +26,7 @@
 // KParams::unit/packed in mdk_hip.hip).  A name with more records than a lane keeps in registers, or more live reads than
 // its window holds, sets a flag and the host prepares that chunk the slow way (mdk_pipeline.c) -- same segments either way.
 #include <algorithm>
+#include <atomic>
 #include "mdk_hip_internal.hpp"
 #include "mdk_pair_rule.h"          // the pending/pairing machine of the overlap callbacks, shared with its host test
 
@@ -769,6 +770,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     const size_t nn = (size_t)n + 1, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
     s->hmask = pow2_at_least(nn + nn / 4) - 1;          // names are at most the records: load factor <= 0.8, ~0.4 for pairs; 2 MB for a 1 Mb chunk at 30x
+    static std::atomic<int> first_call{1}; const bool first = mdk_prof_on() && first_call.exchange(0); const double tf0 = first ? mdk_now() : 0; double tf1 = 0;
     {
         ProfScope pf(PF_UP_ALLOC);
         if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
@@ -778,7 +780,9 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
             if(h->variant && s->d_var.need((size_t)span + 16)) return MDK_ERR_NOMEM;
         }
     }
+    if(first) tf1 = mdk_now();
     { ProfScope pf(PF_UP_COPY); int rcc = copy_ranges(h, s, b); if(rcc) return rcc; HIPCHK(hipEventRecord(s->e1, s->stream)); }
+    if(first) fprintf(stderr, "[mdk hip] the first chunk's upload: device buffers %.3fs, registration + copies queued %.3fs\n", tf1 - tf0, mdk_now() - tf1);
     s->prep_pending = true;            // the preparation kernels are queued with the launch: alone (md_dev_launch) or with up to seven other chunks (md_dev_launch_group)
     s->uploaded = true;
     return 0;
