@@ -734,19 +734,26 @@ static void launch_pileup_multi(const md_dev *h, int grid, size_t lds, hipStream
 // caller can overlap it with its own start-up; md_dev_open afterwards finds it done.
 // streams made ahead of md_dev_open by md_dev_warm (creating one costs the runtime ~5 ms, and needs nothing the options decide)
 static std::mutex g_stash_mu; static std::vector<hipStream_t> g_stash; static int g_stash_dev = -1;
+static std::atomic<bool> g_warm_reg_stop{false};       // the caller's own registration thread has taken over (md_host_register_all with a handle)
 // (Round 4 tried stream priorities -- the consumer's streams high, the device inflate's low, so that kernels of microseconds would not queue
 // behind thousands of members: 512 Mb 1.04 -> 0.99 s and 128 Mb 0.376 -> 0.339 s inside WITHOUT them, gpurun_out r04n; all streams are alike.)
 #define WARM_STREAMS 4
+static std::condition_variable g_stash_cv; static int g_warm_state = 0;       // 1: md_dev_warm is on its way to making the streams, 2: it has
 static hipStream_t stream_take(int device) {
-    {
-        std::lock_guard<std::mutex> lk(g_stash_mu);
+    {   // (a caller that overtakes the warm-up -- md_dev_open on its own thread -- waits for the streams being made rather than making its own
+        // next to them: stream creation is serial inside the runtime, 5-9 ms each)
+        std::unique_lock<std::mutex> lk(g_stash_mu);
+        while(g_stash.empty() && g_warm_state == 1) g_stash_cv.wait(lk);
         if(g_stash_dev == device && !g_stash.empty()) { hipStream_t s = g_stash.back(); g_stash.pop_back(); return s; }
     }
     hipStream_t s = nullptr;
     if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return s;
 }
+hipStream_t mdk_stream_take(int device) { return stream_take(device); }
+struct WarmScope { WarmScope() { std::lock_guard<std::mutex> lk(g_stash_mu); g_warm_state = 1; } ~WarmScope() { { std::lock_guard<std::mutex> lk(g_stash_mu); g_warm_state = 2; } g_stash_cv.notify_all(); } };
 extern "C" int md_dev_warm(int device) {
+    WarmScope warm_scope;
     const double t0 = mdk_now();
     int n = md_dev_count();
     const double t1 = mdk_now();
@@ -754,25 +761,25 @@ extern "C" int md_dev_warm(int device) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
     const double t2 = mdk_now();
-    hipFuncAttributes fa;
-    HIPCHK(hipFuncGetAttributes(&fa, pileup_fn(false, false)));
-    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_classify));
-    const double t3 = mdk_now();
-    for(int i = 0; i < WARM_STREAMS; i++) {
-        hipStream_t s = nullptr;
-        if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
-        std::lock_guard<std::mutex> lk(g_stash_mu);
-        if(g_stash_dev != device) { g_stash.clear(); g_stash_dev = device; }
-        g_stash.push_back(s);
-    }
-    const double t4 = mdk_now();
-    arena_prime(device);
+    { std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev != device) { g_stash.clear(); g_stash_dev = device; } }
     // What the first chunk and the first piece would otherwise pay for on the pipeline's critical path (gpurun_out r04p, 3 ms time series: the first
     // upload took 75 ms and the first group 60 ms, a later group 8): the code objects of the preparation and inflate kernels (every .hip file
     // is a code object of its own, loaded at the first use of one of its kernels, ~30 ms each) and the copy engines' queues in both directions
     // (made at the first copy).  On threads of their own, not waited for: whoever needs one of them first waits inside the runtime for that one.
     if(!getenv("MDK_NO_WARM_SIDE")) {
+        // ... and the staging blocks the host's inflate fills while the runtime comes up are made known to it from the moment it IS up, not from the
+        // moment the device handle is open 60-90 ms later (the first chunk's upload waited 50-85 ms for the registration of ~30 blocks, r04q)
+        if(!getenv("MDK_NO_PIN") && !getenv("MDK_NO_PREREG"))
+            std::thread([device]() {
+                if(hipSetDevice(device) != hipSuccess) return;
+                const double t0 = mdk_now();
+                while(!g_warm_reg_stop.load() && mdk_now() - t0 < 1.0) { if(md_host_register_all(nullptr, 1) == 0) std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+            }).detach();
         std::thread([device]() { if(hipSetDevice(device) == hipSuccess) (void)prep_kernels_init(); }).detach();
+        std::thread([device]() {          // the device inflate's streams (mdk_inflate.hip piece_stream_of takes them from the stash)
+            if(hipSetDevice(device) != hipSuccess) return;
+            for(int i = 0; i < 4; i++) { hipStream_t s = nullptr; if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; } std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev == device) g_stash.insert(g_stash.begin(), s); else { (void)hipStreamDestroy(s); return; } }
+        }).detach();
         std::thread([device]() { if(hipSetDevice(device) == hipSuccess) inflate_kernels_warm(); }).detach();
         std::thread([device]() {
             if(hipSetDevice(device) != hipSuccess) return;
@@ -785,6 +792,20 @@ extern "C" int md_dev_warm(int device) {
             std::lock_guard<std::mutex> lk(g_stash_mu); g_stash.push_back(s);
         }).detach();
     }
+    hipFuncAttributes fa;
+    HIPCHK(hipFuncGetAttributes(&fa, pileup_fn(false, false)));
+    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_classify));
+    const double t3 = mdk_now();
+    for(int i = 0; i < WARM_STREAMS; i++) {
+        hipStream_t s = nullptr;
+        if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        { std::lock_guard<std::mutex> lk(g_stash_mu);
+          if(g_stash_dev != device) { g_stash.clear(); g_stash_dev = device; }
+          g_stash.push_back(s); }
+        g_stash_cv.notify_all();
+    }
+    const double t4 = mdk_now();
+    arena_prime(device);
     if(mdk_prof_on()) fprintf(stderr, "[mdk hip] warm-up: runtime init + device count %.3fs, context (hipSetDevice + hipFree(0)) %.3fs, code object of the pileup kernels %.3fs, %d streams %.3fs, first blocks of carved device / pinned memory %.3fs\n", t1 - t0, t2 - t1, t3 - t2, WARM_STREAMS, t4 - t3, mdk_now() - t4);
     return 0;
 }
@@ -854,6 +875,7 @@ extern "C" void md_dev_close(md_dev *h) {
         if(s.e0) (void)hipEventDestroy(s.e0); if(s.e1) (void)hipEventDestroy(s.e1); if(s.k0) (void)hipEventDestroy(s.k0); if(s.k1) (void)hipEventDestroy(s.k1);
     }
     for(hipStream_t st : h->streams) if(st) (void)hipStreamDestroy(st);
+    for(hipStream_t st : h->piece_streams) if(st) (void)hipStreamDestroy(st);
     if(h->ref_stream) (void)hipStreamDestroy(h->ref_stream);
     h->d_status.release(); h->h_status.release();
     if(h->d_crc) (void)hipFree(h->d_crc);
@@ -1544,7 +1566,7 @@ extern "C" void md_host_profile(double *seconds, uint64_t *calls, uint64_t *byte
 // every staging block not yet known to the runtime is registered now, by `threads` threads (the caller: a helper thread of the command, once
 // the device is up -- the slabs filled while the runtime was still starting would otherwise be registered one by one by the thread that uploads)
 extern "C" int md_host_register_all(md_dev *h, int threads) {
-    if(h) (void)hipSetDevice(h->device);
+    if(h) { (void)hipSetDevice(h->device); g_warm_reg_stop.store(true); }
     std::vector<char *> todo;
     { std::lock_guard<std::mutex> lk(g_blocks_mu); for(const HostBlock &b : g_blocks) if(b.state == 0) todo.push_back(b.base); }
     if(threads < 1) threads = 1;

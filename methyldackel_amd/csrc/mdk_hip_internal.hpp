@@ -108,6 +108,7 @@ struct md_dev {
     int device; md_dev_cfg cfg; int tile, n_slots; bool variant; bool qw = false;
     std::vector<hipStream_t> streams;        // the streams the slots work on (cfg.n_streams of them, or one per slot)
     std::mutex crc_mu; void *d_crc = nullptr;   // constants of k_crc32 (mdk_inflate.hip), made by the first piece
+    std::mutex piece_mu; std::vector<hipStream_t> piece_streams; int piece_rr = 0;      // the pieces' streams: a few, shared (mdk_inflate.hip piece_stream_of)
     hipStream_t ref_stream = nullptr;           // md_dev_set_reference works here, so that it neither waits for nor holds up the slots' streams    /* qw: dense contexts, a quarter of a wavefront per segment */
     std::vector<Slot> slots;
     std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
@@ -174,6 +175,7 @@ MDK_HIDDEN int64_t finish_eval(md_dev *h, Slot *s);      // the status block is 
 MDK_HIDDEN int finish_group(md_dev *h, const int *slots, int n, int64_t *counts);
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s);
 MDK_HIDDEN int prep_kernels_init();           // mdk_prep.hip: its code object loaded, the scan kernel's LDS limit set (once per process)
-MDK_HIDDEN void inflate_kernels_warm();      // mdk_inflate.hip: its code object loaded
+MDK_HIDDEN void inflate_kernels_warm();
+MDK_HIDDEN hipStream_t mdk_stream_take(int device);       // a stream made ahead by md_dev_warm, or a new one      // mdk_inflate.hip: its code object loaded
 MDK_HIDDEN int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st);      // preparation kernels of up to MAXM uploaded raw slots, one launch each kernel
 #endif

@@ -291,6 +291,7 @@ struct md_piece {
     DBuf<uint8_t> d_comp, d_out; DBuf<md_inf_member> d_mem; DBuf<uint32_t> d_cnt, d_first, d_recoff, d_status; DBuf<md_inf_digest> d_dig;
     HBuf<md_inf_digest> h_dig; HBuf<uint32_t> h_status;
     int n_mem = 0; uint64_t out_bytes = 0, comp_bytes = 0; uint32_t n_rec_cap = 0; bool busy = false;
+    bool own_stream = false, recorded = false;      // recorded: `done` has been recorded at least once (what waiting for the piece's own work means)
     bool check_crc = true;              // MDK_NO_CRC=1 leaves the check out (timing comparisons)
 };
 // the constants of k_crc32, once per device handle
@@ -316,12 +317,25 @@ void inflate_kernels_warm() {
     (void)hipFuncGetAttributes(&fa, (const void *)k_walk<false>); (void)hipFuncGetAttributes(&fa, (const void *)k_walk<true>); (void)hipFuncGetAttributes(&fa, (const void *)k_walk_scan);
     (void)hipGetLastError();
 }
+// A piece's work is queued on one of a FEW streams the pieces of a handle share (creating a stream costs the runtime 5-9 ms, one after the other:
+// eight teams that each made their own at the same moment kept the first device piece -- which the reader needs in file order -- 40 ms late,
+// gpurun_out r04q).  Four: each piece is ~3,400 wavefronts and the device holds ~6,000, so pieces on four streams fill it, and copies of one
+// overlap kernels of another.  MDK_PIECE_STREAMS=0: a stream per piece.
+static hipStream_t piece_stream_of(md_dev *h, bool *own) {
+    static const int want = getenv("MDK_PIECE_STREAMS") ? atoi(getenv("MDK_PIECE_STREAMS")) : 4;
+    *own = false;
+    if(want < 1) { hipStream_t s = nullptr; if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr; *own = true; return s; }
+    std::lock_guard<std::mutex> lk(h->piece_mu);
+    if((int)h->piece_streams.size() < want) { hipStream_t s = mdk_stream_take(h->device); if(!s) return nullptr; h->piece_streams.push_back(s); return s; }
+    return h->piece_streams[(size_t)(h->piece_rr++ % want)];
+}
+static hipError_t piece_sync(md_piece *p) { return p->recorded ? hipEventSynchronize(p->done) : hipSuccess; }      // the piece's own work, not its stream's
 extern "C" int md_piece_create(md_dev *h, md_piece **out) {
     if(!h || !out) return fail(MDK_ERR_ARG, "md_piece_create", hipSuccess);
     *out = nullptr;
     HIPCHK(hipSetDevice(h->device));
     md_piece *p = new md_piece(); p->h = h;
-    if(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
+    if(!(p->stream = piece_stream_of(h, &p->own_stream)) || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { if(p->own_stream && p->stream) (void)hipStreamDestroy(p->stream); delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
     if(p->d_status.need(4) || p->h_status.need(4)) { delete p; return MDK_ERR_NOMEM; }
     p->check_crc = !getenv("MDK_NO_CRC");
     if(p->check_crc && !crc_const_of(h)) { delete p; return fail(MDK_ERR_NOMEM, "md_piece_create: CRC tables", hipSuccess); }
@@ -331,7 +345,8 @@ extern "C" int md_piece_create(md_dev *h, md_piece **out) {
 extern "C" void md_piece_destroy(md_piece *p) {
     if(!p) return;
     (void)hipSetDevice(p->h->device);
-    if(p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    (void)piece_sync(p);
+    if(p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     if(p->done) (void)hipEventDestroy(p->done);
     p->d_comp.release(); p->d_out.release(); p->d_mem.release(); p->d_cnt.release(); p->d_first.release(); p->d_recoff.release(); p->d_status.release(); p->d_dig.release();
     p->h_dig.release(); p->h_status.release();
@@ -345,7 +360,7 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
     ProfScope pf(PF_PIECE_SUBMIT);
     md_dev *h = p->h;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(piece_sync(p));
     uint64_t out_bytes = 0;
     for(int i = 0; i < n_mem; i++) {
         if(mem[i].out_off != out_bytes || mem[i].out_len > 65536u || mem[i].in_off + mem[i].in_len > comp_bytes) return fail(MDK_ERR_ARG, "md_piece_submit: member table", hipSuccess);
@@ -372,7 +387,7 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
     HIPCHK(hipMemcpyAsync(p->h_dig.p, p->d_dig.p, sizeof(md_inf_digest) * (size_t)n_mem, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(p->h_status.p, p->d_status.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(p->done, st));
-    p->busy = true;
+    p->busy = true; p->recorded = true;
     return 0;
 }
 
@@ -394,14 +409,14 @@ extern "C" int md_piece_wait(md_piece *p, md_piece_info *info) {
 extern "C" int md_piece_read(md_piece *p, uint64_t off, uint64_t bytes, uint8_t *dst) {
     if(!p || !dst || off + bytes > p->out_bytes) return fail(MDK_ERR_ARG, "md_piece_read", hipSuccess);
     HIPCHK(hipSetDevice(p->h->device));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(piece_sync(p));
     if(bytes) HIPCHK(hipMemcpy(dst, p->d_out.p + off, (size_t)bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 extern "C" int md_piece_read_records(md_piece *p, uint32_t first, uint32_t n, uint32_t *dst) {
     if(!p || !dst || (uint64_t)first + n > p->n_rec_cap) return fail(MDK_ERR_ARG, "md_piece_read_records", hipSuccess);
     HIPCHK(hipSetDevice(p->h->device));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(piece_sync(p));
     if(n) HIPCHK(hipMemcpy(dst, p->d_recoff.p + first, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
     return 0;
 }
