@@ -10,10 +10,12 @@ HOSTSRC := methyldackel_amd/csrc/host/mdk_io.c methyldackel_amd/csrc/host/mdk_fa
 
 all: $(B)/libmdk_hip.so $(B)/libmdk_extract.so $(B)/MethylDackel tools oracle
 
+# -fgpu-rdc: the four sources become ONE code object; the runtime loads a code object at the first use of one of its kernels and each load
+# costs the command ~30 ms of start-up (three of them did: pileup, preparation, inflate)
 HIPSRC := methyldackel_amd/csrc/mdk_hip.hip methyldackel_amd/csrc/mdk_comm.hip methyldackel_amd/csrc/mdk_prep.hip methyldackel_amd/csrc/mdk_inflate.hip
 $(B)/libmdk_hip.so: $(HIPSRC) methyldackel_amd/csrc/mdk_hip_internal.hpp methyldackel_amd/csrc/mdk_overlap_rule.h methyldackel_amd/csrc/mdk_pair_rule.h methyldackel_amd/csrc/mdk_inflate_core.h methyldackel_amd/csrc/mdk_crc32_core.h include/mdk_hip.h
 	@mkdir -p $(B)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared $(HIPFLAGS) -Iinclude -Imethyldackel_amd/csrc -o $@ $(HIPSRC) -ldl
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fgpu-rdc $(HIPFLAGS) -Iinclude -Imethyldackel_amd/csrc -o $@ $(HIPSRC) -ldl
 
 $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldackel_amd/csrc/host/mdk_plan.h include/mdk_extract.h include/mdk_hip.h $(B)/libmdk_hip.so
 	$(CC) $(CFLAGS) -shared -Iinclude -o $@ $(HOSTSRC) -L$(B) -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm

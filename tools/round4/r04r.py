@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""round 4, GPU call q: code objects of the preparation / inflate kernels, copy-engine queues and carved device blocks made ahead on side threads of
+"""round 4, GPU call r (as q, plus: staging blocks registered from runtime-up, shared piece streams, open waits for warm streams): code objects of the preparation / inflate kernels, copy-engine queues and carved device blocks made ahead on side threads of
 the warm-up -- the first upload and the first group (75 ms and 60 ms in call p's time series) and the 128 Mb / 512 Mb walls"""
 import os, re, statistics, subprocess, sys, time, shutil
 from pathlib import Path
@@ -7,7 +7,7 @@ REPO = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(REPO))
 import methyldackel_amd as mdk
 O = REPO / "gpurun_out"; O.mkdir(exist_ok=True)
-out = open(O / "r04q_e2e.txt", "w")
+out = open(O / "r04r_e2e.txt", "w")
 def say(*a):
     print(*a, file=out, flush=True); print(*a, flush=True)
 work = Path("/tmp/mdk_r04"); work.mkdir(exist_ok=True)
@@ -37,9 +37,9 @@ def ours(name, env, tag, reps, keep=None, limit=60):
         if rc != 0 or rep == 1:
             say(f"## {name} [{tag}] rep {rep} rc {rc} wall {wall:.3f} inside {ins[-1]}")
             for l in [l for l in err.splitlines() if l.startswith("[mdk")][:16]: say("     ", l[:1300])
-        if keep and rep < 2: shutil.copy(d / "err.txt", O / f"r04q_{keep}_{rep}.txt")
+        if keep and rep < 2: shutil.copy(d / "err.txt", O / f"r04r_{keep}_{rep}.txt")
     say(f"== {name} [{tag}] walls {' '.join('%.3f' % w for w in walls)} | median {statistics.median(walls):.3f} | inside {' '.join('%.3f' % w for w in ins)} | median {statistics.median(ins):.3f}")
 ours("s128", {}, "one128", 7)
-ours("s128", {"MDK_NO_WARM_SIDE": "1"}, "one128_nowarmside", 5)
+ours("s128", {"MDK_PIECE_STREAMS": "0"}, "one128_ownstreams", 4)
 ours("y4", {}, "xl512", 3)
 ours("s128", {"MDK_WATCHDOG": "3"}, "one128_series", 2, keep="series128")
