@@ -440,9 +440,8 @@ def main():
                     for pid in os.listdir("/proc"):
                         if not pid.isdigit() or int(pid) == os.getpid():
                             continue
-                        try:
-                            cl = open(f"/proc/{pid}/cmdline", "rb").read()
-                            if b"MethylDackel" in cl and marker.encode() in cl and open(f"/proc/{pid}/stat").read().rsplit(") ", 1)[1][0] != "Z":
+                        try:      # (by name, not by command line: a process that is taking its address space down has none any more)
+                            if open(f"/proc/{pid}/comm").read().strip() == "MethylDackel" and open(f"/proc/{pid}/stat").read().rsplit(") ", 1)[1][0] != "Z":
                                 alive = True; break
                         except OSError:
                             pass

@@ -30,8 +30,7 @@ def gone(marker):
         for pid in os.listdir("/proc"):
             if pid.isdigit() and int(pid) != os.getpid():
                 try:
-                    cl = open(f"/proc/{pid}/cmdline", "rb").read()
-                    if b"MethylDackel" in cl and marker.encode() in cl and open(f"/proc/{pid}/stat").read().rsplit(") ", 1)[1][0] != "Z": alive = True; break
+                    if open(f"/proc/{pid}/comm").read().strip() == "MethylDackel" and open(f"/proc/{pid}/stat").read().rsplit(") ", 1)[1][0] != "Z": alive = True; break
                 except OSError: pass
         if not alive: return
         time.sleep(0.02)
