@@ -3,13 +3,14 @@
 //
 //   k_inflate     one WAVEFRONT per BGZF member.  Inside a Huffman block every lane decodes the symbol that would start at its bit of the
 //                 stream's next 64 (mdk_inflate_core.h inf_decode_at) and a walk over the results picks the real ones -- ~7 symbols per round
-//                 of table lookups.  Batches of <= 64 match tokens / 1 KiB of output: literals go straight into a 2 KiB output window
-//                 (INF_WIN) in LDS, matches become tokens.  Between batches all 64 lanes work: (1) top up the LDS ring of compressed words with one coalesced
-//                 load, (2) FAR matches -- source older than the LDS window -- one lane per token, bytes from global memory
-//                 (written by an earlier batch of this wavefront), (3) NEAR matches in stream order, each by all lanes from the
-//                 window (a self-overlapping match doubles the copied span per round), (4) the batch's bytes leave the window
-//                 for global memory, coalesced.  A 64 KiB member is ~16 k symbols; the file's ~10^4..10^5 members are what
-//                 fills the machine (one lane per member, round 2's experiment, left 434 wavefronts of diverging lanes).
+//                 of table lookups; their output positions are a prefix sum in DPP.  Batches of <= 64 match tokens / 1 KiB of output: literals
+//                 go straight into a 2 KiB output window (INF_WIN) in LDS, matches become tokens.  Between batches all 64 lanes work: (1) top
+//                 up the LDS ring of compressed words with one coalesced load, (2) FAR matches -- source older than the LDS window -- one lane
+//                 per token, bytes from global memory (written by an earlier batch of this wavefront), (3) NEAR matches: every token whose
+//                 source is final is copied at once, a short one by its own lane, a long one by the whole wavefront (a self-overlapping
+//                 match doubles the copied span per round), (4) the batch's bytes leave the window for global memory, coalesced.  A 64 KiB
+//                 member is ~22 k symbols; the file's ~10^4..10^5 members are what fills the machine (one lane per member, round 2's
+//                 experiment, left 434 wavefronts of diverging lanes).
 //   k_crc32       one wavefront per member: the CRC32 of the inflated bytes against the member's trailer -- what htslib's bgzf_read_block
 //                 checks for every block the reference reads.  Coalesced 16-byte loads; every lane keeps the CRC of its own column of the
 //                 member (slice-by-4 tables and a "1008 zero bytes" operator in LDS), the 64 columns are merged with GF(2) multiplications.
