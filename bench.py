@@ -454,9 +454,10 @@ def main():
                 for _ in range(runs):
                     # (outside the clock) the previous command's process -- by default a child the command does not wait for -- is still taking its address
                     # space down for 0.2-0.4 s after the command has returned; a command started into that shares the driver's locks with it and is
-                    # slower itself (5 runs 0.3 s apart: 0.40, 0.49, 0.65, 0.75, 0.80 s).  Runs are measured in isolation: the next one starts when
-                    # nothing of the previous one is left
-                    time.sleep(0.3); wait_gone(str(sp) + ".bam")
+                    # slower itself, mostly in the time until its device is usable (0.16 -> 0.25-0.45 s; 5 runs 0.3 s apart: 0.40, 0.49, 0.65, 0.75,
+                    # 0.80 s; gpurun_out r04t/r04u).  Runs are measured in isolation: the next one starts a second after the previous one's last
+                    # process has gone
+                    wait_gone(str(sp) + ".bam"); time.sleep(1.0)        # (the driver goes on releasing a process's GPU resources for a while after the process is gone)
                     t1 = time.perf_counter()
                     r = mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=d, env=dict(env, MDK_HOST_PROFILE="1"), timeout=300)
                     ts.append(time.perf_counter() - t1); rcs.append(r.returncode)
@@ -555,7 +556,7 @@ def main():
                                                              "note": "MDK_NO_DETACH=1: the process that did the work is the one the caller waits for, address-space teardown (~0.2 s of kernel time "
                                                                      "after the outputs are closed) included.  By default the command's work is done by a child and the command returns when the child "
                                                                      "reports its outputs closed (csrc/host/main.c detach_teardown, as the mold linker does)"},
-                                       "protocol": "CPU: the sweep's best setting and one alternative, the faster of them, median; this build: 5 runs, median; the caller's wall clock around the command, each run started when nothing of the previous one is left"}
+                                       "protocol": "CPU: the sweep's best setting and one alternative, the faster of them, median; this build: 5 runs, median; the caller's wall clock around the command, each run started one second after the previous command's last process has gone"}
                 if args.xl_copies > 1:
                     # a sample large enough that start-up and exit are a small part of the run: K copies of the large sample as K contigs (tools/mdk_replicate)
                     spx = data / f"xl_{args.large_sample_length}x{args.xl_copies}_{args.coverage}"
