@@ -77,8 +77,7 @@ typedef struct {
     mdk_plan *p; md_dev *dev; emitter *em; cgroup G[MDK_NGROUPS];
     pthread_mutex_t mu; pthread_cond_t cv;
     int ret, up_done;                    /* (mu) first error; the uploader has launched its last group */
-    uint64_t n_up, n_col, n_claim;       /* (mu) groups launched / collected and handed on, in order / taken by a collector: group k lives in G[k % MDK_NGROUPS] */
-    pthread_mutex_t fb_mu;               /* one collector at a time prepares a handed-back chunk on the host */
+    uint64_t n_up, n_col;                /* (mu) groups launched / collected: group k lives in G[k % MDK_NGROUPS] */
     int *ref_state; int ref_quit, ref_done; int32_t ref_t0, ref_t1;        /* (mu) per contig: 0 not uploaded yet, 1 resident, < 0 the error its upload met; ref_done: the thread has left */
     double w_down, w_emit; int n_host_prep;
 } xpipe;
@@ -141,19 +140,15 @@ static void *watchdog_main(void *arg) {
     }
 }
 
-/* Collects the launched groups: results to the emitter, the group back to the uploader.  TWO of these threads (MDK_COLLECTORS): each takes the
- * next launched group, waits for it and brings its results over -- side by side, the waits and copies of one group are latency, not work --
- * and then hands them to the emitter when every earlier group has been handed on (the emitter is fed in schedule order).  At 512 Mb the
- * uploader stood waiting for the one collector for half of the run (wait-for-group 0.44 s of 0.8 s, profiles/r04m_e2e.txt). */
+/* collects the launched groups in order: results to the emitter, the group back to the uploader */
 static void *collector_main(void *arg) {
     xpipe *X = arg; mdk_plan *p = X->p; md_dev *dev = X->dev; int i;
     for(;;) {
-        cgroup *g; int ls[MDK_GROUP], li[MDK_GROUP], nl = 0, rcs[MDK_GROUP], rc = 0, bad = 0; md_sites st[MDK_GROUP], sites[MDK_GROUP]; double ta, t_down, t_emit; uint64_t k;
+        cgroup *g; int ls[MDK_GROUP], li[MDK_GROUP], nl = 0, rcs[MDK_GROUP], rc = 0, bad = 0; md_sites st[MDK_GROUP], sites[MDK_GROUP]; double ta;
         pthread_mutex_lock(&X->mu);
-        while(X->n_claim == X->n_up && !X->up_done && !X->ret) pthread_cond_wait(&X->cv, &X->mu);
-        if(X->ret || X->n_claim == X->n_up) { pthread_mutex_unlock(&X->mu); break; }
-        k = X->n_claim++;
-        g = &X->G[k % MDK_NGROUPS];
+        while(X->n_col == X->n_up && !X->up_done && !X->ret) pthread_cond_wait(&X->cv, &X->mu);
+        if(X->ret || X->n_col == X->n_up) { pthread_mutex_unlock(&X->mu); break; }
+        g = &X->G[X->n_col % MDK_NGROUPS];
         pthread_mutex_unlock(&X->mu);
         memset(sites, 0, sizeof(sites));
         for(i = 0; i < g->n; i++) if(g->launched[i]) { ls[nl] = g->slot[i]; li[nl] = i; nl++; }
@@ -162,37 +157,29 @@ static void *collector_main(void *arg) {
         g_col_phase = 2;
         if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); xp_fail(X, MDK_RC_DEVICE); break; }
         for(i = 0; i < nl && !bad; i++) {
-            const int c = li[i];
+            const int k = li[i];
             rc = rcs[i];
             if(rc == MDK_ERR_PREP_HOST) {          /* a read name the device preparation does not handle: this chunk the slow way */
                 static int told = 0;
-                pthread_mutex_lock(&X->fb_mu);
                 if(!told) { told = 1; fprintf(stderr, "[mdk] note: a chunk holds a read name with more records than the device preparation handles (secondary/supplementary-rich or amplicon-like data); such chunks are prepared on the host, which is slower\n"); }
-                rc = mdk_plan_host_prepare_from(p, &g->ch[c], dev, g->slot[c]);
-                if(!rc) rc = md_dev_submit(dev, g->slot[c], &g->ch[c].batch);
-                if(!rc) rc = md_dev_download(dev, g->slot[c], &st[i]);
+                rc = mdk_plan_host_prepare_from(p, &g->ch[k], dev, g->slot[k]);
+                if(!rc) rc = md_dev_submit(dev, g->slot[k], &g->ch[k].batch);
+                if(!rc) rc = md_dev_download(dev, g->slot[k], &st[i]);
                 X->n_host_prep++;
-                pthread_mutex_unlock(&X->fb_mu);
             }
             if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
             if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); xp_fail(X, MDK_RC_DEVICE); bad = 1; break; }
-            sites[c] = st[i];
+            sites[k] = st[i];
         }
-        t_down = now_s() - ta;
-        if(bad) break;
-        /* its turn: every group before it has been handed to the emitter */
-        pthread_mutex_lock(&X->mu);
-        while(X->n_col != k && !X->ret) pthread_cond_wait(&X->cv, &X->mu);
-        bad = X->ret != 0;
-        pthread_mutex_unlock(&X->mu);
+        X->w_down += now_s() - ta;
         if(bad) break;
         ta = now_s();
         g_col_phase = 3;
         for(i = 0; i < g->n; i++) if(emitter_push(X->em, &g->ch[i], &sites[i])) { xp_fail(X, X->em->failed ? MDK_RC_OUTPUT : MDK_RC_DEVICE); bad = 1; break; }
-        t_emit = now_s() - ta;
+        X->w_emit += now_s() - ta;
         if(bad) break;
         g_col_phase = 0;
-        pthread_mutex_lock(&X->mu); g->n = 0; g->state = G_FREE; X->n_col++; X->w_down += t_down; X->w_emit += t_emit; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
+        pthread_mutex_lock(&X->mu); g->n = 0; g->state = G_FREE; X->n_col++; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
     }
     return NULL;
 }
@@ -211,7 +198,7 @@ static void xopen_start(mdk_plan *p, void *arg) {
 }
 
 int extract_main(int argc, char *argv[]) {
-    mdk_plan *p = NULL; md_dev *dev = NULL; xpipe *X = NULL; int rc, ret = 0, more = 1, i, g_i; xopen dop; pthread_t cth[MDK_NGROUPS], rth, preg; int cth_ok = 0, n_cth = 0, rth_ok = 0, preg_ok = 0; emitter em;
+    mdk_plan *p = NULL; md_dev *dev = NULL; xpipe *X = NULL; int rc, ret = 0, more = 1, i, g_i; xopen dop; pthread_t cth, rth, preg; int cth_ok = 0, rth_ok = 0, preg_ok = 0; emitter em;
     double T0 = now_s(), t_open, t_dev, w_next = 0, w_sub = 0, w_group = 0, w_ref = 0, w_rel = 0, ta; uint64_t n_chunks = 0; int32_t ref_t0, ref_t1;
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] entered at epoch %.3f\n", ts.tv_sec + 1e-9 * ts.tv_nsec); }
     { int rk = 0, wd = 1, m = ranks_from_env(&rk, &wd); if(m < 0) return -1; if(m > 0) return extract_ranks(argc, argv, rk, wd); }       /* one process per GPU (mdk_ranks.c) */
@@ -238,17 +225,11 @@ int extract_main(int argc, char *argv[]) {
     X = calloc(1, sizeof(*X));
     if(X) X->ref_state = calloc((size_t)p->bam->n_targets + 1, sizeof(int));
     if(!X || !X->ref_state || emitter_start(&em, p, emit_threads(p))) { if(X) free(X->ref_state); free(X); mdk_plan_detach_device(p); md_dev_close(dev); mdk_plan_close(p); return -5; }
-    X->p = p; X->dev = dev; X->em = &em; X->ref_t0 = ref_t0; X->ref_t1 = ref_t1; pthread_mutex_init(&X->mu, NULL); pthread_mutex_init(&X->fb_mu, NULL); pthread_cond_init(&X->cv, NULL);
+    X->p = p; X->dev = dev; X->em = &em; X->ref_t0 = ref_t0; X->ref_t1 = ref_t1; pthread_mutex_init(&X->mu, NULL); pthread_cond_init(&X->cv, NULL);
     for(g_i = 0; g_i < MDK_NGROUPS; g_i++) for(i = 0; i < MDK_GROUP; i++) X->G[g_i].slot[i] = g_i * MDK_GROUP + i;
     preg_ok = !getenv("MDK_NO_PREREG") && pthread_create(&preg, NULL, prereg_main, dev) == 0;
     rth_ok = pthread_create(&rth, NULL, refs_main, X) == 0;
-    {   /* (at most one fewer than there are groups: one group is always the uploader's) */
-        int want = getenv("MDK_COLLECTORS") ? atoi(getenv("MDK_COLLECTORS")) : 2;
-        if(want < 1) want = 1;
-        if(want > MDK_NGROUPS - 1) want = MDK_NGROUPS - 1;
-        while(n_cth < want && pthread_create(&cth[n_cth], NULL, collector_main, X) == 0) n_cth++;
-        cth_ok = n_cth > 0;
-    }
+    cth_ok = pthread_create(&cth, NULL, collector_main, X) == 0;
     if(getenv("MDK_WATCHDOG")) { pthread_t wd; if(pthread_create(&wd, NULL, watchdog_main, X) == 0) pthread_detach(wd); }
     if(!rth_ok || !cth_ok) { fprintf(stderr, "[mdk] cannot create a thread\n"); ret = -5; more = 0; }
     while(more && !ret) {
@@ -309,7 +290,7 @@ int extract_main(int argc, char *argv[]) {
     }
     if(ret) xp_fail(X, ret);
     pthread_mutex_lock(&X->mu); X->up_done = 1; X->ref_quit = 1; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
-    for(i = 0; i < n_cth; i++) pthread_join(cth[i], NULL);
+    if(cth_ok) pthread_join(cth, NULL);
     if(rth_ok) pthread_join(rth, NULL);
     if(preg_ok) pthread_join(preg, NULL);
     if(!ret) ret = X->ret;

@@ -57,12 +57,10 @@ def same_outputs(od, gd):
 
 
 @pytest.mark.parametrize("extra,env", [([], {}), (["--chunkSize", "7000", "--mergeContext", "--CHG"], {"MDK_FASTA_THREADS": 5}), (["--chunkSize", "20000"], {"MDK_STANDIN_HANDBACK": 3}),
-                                       (["--chunkSize", "333333", "--minOppositeDepth", "2", "--maxVariantFrac", "0.3", "--CHH"], {}), (["--chunkSize", "5000"], {"MDK_DEVICE_INFLATE_ONLY": 1, "MDK_GPU_PIECE_MB": "0.25", "MDK_STANDIN_HANDBACK": 5}),
-                                       (["--chunkSize", "3000", "--CHG"], {"MDK_STANDIN_US_PER_KREC": 20000, "MDK_STANDIN_HANDBACK": 7}), (["--chunkSize", "3000"], {"MDK_COLLECTORS": 1, "MDK_STANDIN_US_PER_KREC": 20000})])
+                                       (["--chunkSize", "333333", "--minOppositeDepth", "2", "--maxVariantFrac", "0.3", "--CHH"], {}), (["--chunkSize", "5000"], {"MDK_DEVICE_INFLATE_ONLY": 1, "MDK_GPU_PIECE_MB": "0.25", "MDK_STANDIN_HANDBACK": 5})])
 def test_extract_main_on_the_standin_equals_oracle(data, tmp_path, extra, env):
     """one process: extract_main's threads, groups of chunks in flight, slabs given back early, chunks handed back to the host preparation, pieces
-    "inflated on the device" (fifth case: every piece after the header's); the last two: chunks whose "device" time follows their records, so
-    that the groups of the two collector threads finish out of order (and the same with one collector)"""
+    "inflated on the device" (last case: every piece after the header's)"""
     args = [str(data / "s.fa"), str(data / "s.bam"), "-@", "4"] + extra
     od = oracle(tmp_path, args)
     gd = tmp_path / "gpu"; gd.mkdir()
