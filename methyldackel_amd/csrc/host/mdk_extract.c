@@ -70,11 +70,13 @@ MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_ope
  * collector thread (one wait and one round of copies per group, md_dev_download_group) and handed to the emitter in schedule
  * order.  The reference's unit of work is the chunk (extract.c:325-350); here it is the unit of scheduling and of output only. */
 #define MDK_GROUP 8
-#define MDK_NGROUPS 3
+#define MDK_NGROUPS_MAX 6
+static int g_ngroups = 3;            /* groups in flight (MDK_GROUPS_IN_FLIGHT=n, 2..6) */
+#define MDK_NGROUPS g_ngroups
 enum { G_FREE = 0, G_FILL, G_LAUNCHED };
 typedef struct { mdk_chunk ch[MDK_GROUP]; int slot[MDK_GROUP]; int n, launched[MDK_GROUP], state, held, n_held, rel_slot[MDK_GROUP]; mdk_chunk rel_ch[MDK_GROUP]; } cgroup;      /* held: the host memory behind its records has not been given back yet */
 typedef struct {
-    mdk_plan *p; md_dev *dev; emitter *em; cgroup G[MDK_NGROUPS];
+    mdk_plan *p; md_dev *dev; emitter *em; cgroup G[MDK_NGROUPS_MAX];
     pthread_mutex_t mu; pthread_cond_t cv;
     int ret, up_done;                    /* (mu) first error; the uploader has launched its last group */
     uint64_t n_up, n_col;                /* (mu) groups launched / collected: group k lives in G[k % MDK_NGROUPS] */
@@ -191,6 +193,7 @@ static void *prereg_main(void *arg) { md_dev *dev = arg; (void)md_host_register_
 typedef struct { devopen_t d; pthread_t th; int started; } xopen;
 static void xopen_start(mdk_plan *p, void *arg) {
     xopen *o = arg;
+    if(getenv("MDK_GROUPS_IN_FLIGHT")) { g_ngroups = atoi(getenv("MDK_GROUPS_IN_FLIGHT")); if(g_ngroups < 2) g_ngroups = 2; if(g_ngroups > MDK_NGROUPS_MAX) g_ngroups = MDK_NGROUPS_MAX; }
     mdk_plan_dev_cfg(p, &o->d.cfg);
     o->d.cfg.n_slots = MDK_NGROUPS * MDK_GROUP; o->d.cfg.n_streams = MDK_NGROUPS;
     if(getenv("MDK_DEVICE")) o->d.device = atoi(getenv("MDK_DEVICE"));

@@ -514,7 +514,7 @@ int mdk_plan_set_prep(mdk_plan *p, int mode) {
     return 0;
 }
 int mdk_plan_set_hold(mdk_plan *p, int n) {
-    if(!p || p->started || n < 2 || n > 40) return -1;
+    if(!p || p->started || n < 2 || n > MDK_HOLD_MAX) return -1;
     p->n_hold = n;
     return 0;
 }

@@ -89,6 +89,7 @@ typedef struct {
     uint64_t n_variant;
 } emit_ctx;
 
+#define MDK_HOLD_MAX 56        /* chunks a consumer may hold at once (mdk_plan_set_hold): 6 groups of 8 in flight + 2, with room */
 struct mdk_plan {
     opts_t o;
     mdk_bam *bam; mdk_bai *bai; int need_seek; mdk_fasta fa; int *fa_of_tid;
@@ -107,7 +108,7 @@ struct mdk_plan {
     int (*slot_state)(const struct mdk_plan *, int);      /* (diagnostics) state of pipeline slot k */
     struct pslot *slot; int n_slot, n_workers; pthread_t reader_th, *worker_th; int started, quit, pipe_rc, reader_done;
     pthread_mutex_t mu; pthread_cond_t cv_free, cv_raw, cv_done;
-    uint32_t next_out; int held[40], n_hold;      /* the chunks handed out last (newest first); the oldest is recycled by the next hand-out */
+    uint32_t next_out; int held[MDK_HOLD_MAX], n_hold;      /* the chunks handed out last (newest first); the oldest is recycled by the next hand-out */
     /* mappability */
     int map_on; uint32_t map_n; char **map_names; uint32_t *map_len; uint8_t **map_bits; int *map_of_tid;
     /* -l: per contig, the disjoint runs a position must fall in (and the strand a read must have there) */
