@@ -71,6 +71,17 @@ static void detach_teardown(void) {
         _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);
     }
 }
+/* The HIP runtime brings up every GPU it can see (hipInit on a node with eight of them does eight times the work) and this process uses one:
+ * before the runtime is loaded into the process that does the work, it is told to see that one only (ROCR_VISIBLE_DEVICES; the device is then
+ * number 0).  Not when the caller has restricted the devices already, and not for a rank of a several-GPU run (its peers' devices stay visible to
+ * the exchange layer).  MDK_NO_RESTRICT=1 leaves the environment alone. */
+static void see_own_device_only(void) {
+    const char *dv = getenv("MDK_DEVICE"), *w = getenv("MDK_WORLD"); const int d = dv ? atoi(dv) : 0; char num[16];
+    if(getenv("MDK_NO_RESTRICT") || getenv("ROCR_VISIBLE_DEVICES") || getenv("HIP_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES") || getenv("GPU_DEVICE_ORDINAL")) return;
+    if((w && atoi(w) > 1) || getenv("MDK_TORCHRUN") || d < 0) return;
+    snprintf(num, sizeof(num), "%d", d);
+    setenv("ROCR_VISIBLE_DEVICES", num, 1); setenv("MDK_DEVICE", "0", 1);
+}
 int main(int argc, char *argv[]) {
     if(argc == 1) { usage_main(); return 0; }
     if(!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help")) { usage_main(); return 0; }
@@ -89,6 +100,7 @@ int main(int argc, char *argv[]) {
         if(cmd) {
             int rc;
             setenv("MDK_FAST_EXIT", "1", 0);
+            see_own_device_only();
             detach_teardown();
             rc = cmd(argc - 1, argv + 1);
             say_done(rc);
