@@ -2,8 +2,8 @@
 // inside htslib's sam_itr_next, common.c:413).
 //
 //   k_inflate     one WAVEFRONT per BGZF member.  Inside a Huffman block every lane decodes the symbol that would start at its bit of the
-//                 stream's next 64 (mdk_inflate_core.h inf_decode_at) and a walk over the results picks the real ones -- ~7 symbols per round
-//                 of table lookups; their output positions are a prefix sum in DPP.  Batches of <= 64 match tokens / 1 KiB of output: literals
+//                 stream's next 64 (mdk_inflate_core.h inf_decode_at) and a walk over the results picks the real ones -- ~5 symbols per round
+//                 of table lookups on the bench's BAM (tools/inflate_emu prints the statistics); their output positions are a prefix sum in DPP.  Batches of <= 64 match tokens / 1 KiB of output: literals
 //                 go straight into a 2 KiB output window (INF_WIN) in LDS, matches become tokens.  Between batches all 64 lanes work: (1) top
 //                 up the LDS ring of compressed words with one coalesced load, (2) FAR matches -- source older than the LDS window -- one lane
 //                 per token, bytes from global memory (written by an earlier batch of this wavefront), (3) NEAR matches: every token whose

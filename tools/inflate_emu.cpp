@@ -15,6 +15,9 @@
 #include "mdk_inflate_core.h"
 #include "mdk_crc32_core.h"
 
+// statistics of the decode rounds (the file mode prints them): rounds, real symbols, literals / matches, near-match rounds, and -- what a round
+// over a 128-bit window would have resolved (the walk carried on over the next 64 bits where nothing but the window's end stopped it)
+static uint64_t g_rounds, g_syms, g_lits, g_matches, g_syms128, g_near_rounds, g_hdr_batches, g_round_cut;
 // one member, as k_inflate does it; returns 0 or the error code
 static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uint8_t *out, uint32_t out_len, uint64_t *n_far, uint64_t *n_near, uint64_t *n_batches) {
     static InfShared S;
@@ -30,7 +33,7 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
         (*n_batches)++;
         const uint32_t beg = pos; uint32_t n_tok = 0, err = 0, fin = 0;
         if(in_block == 0) {
-            inf_header_batch(S, bitpos);
+            inf_header_batch(S, bitpos); g_hdr_batches++;
             bitpos = S.bitpos; in_block = S.in_block; last = S.last; stored_left = S.stored_left; err = S.err;
         } else if(in_block == 2) {
             const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH;
@@ -67,6 +70,10 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
                     if((mball >> lane) & 1ull) { InfToken t; t.dst = dst[lane]; t.len_dist = sy[lane].val; if(n_tok + mpre[lane] >= INF_MAX_TOK) return 104; S.tok[n_tok + mpre[lane]] = t; }
                 }
                 n_tok += (uint32_t)__builtin_popcountll(mball);
+                {   // statistics
+                    const int nv = __builtin_popcountll(V); g_rounds++; g_syms += (uint64_t)nv; g_matches += (uint64_t)__builtin_popcountll(mball); g_lits += (uint64_t)(nv - __builtin_popcountll(mball)); g_syms128 += (uint64_t)nv;
+                    if(stop == 0) { uint32_t o2 = off; while(o2 < 128) { const InfSym y = inf_decode_at(S, bitpos + o2); if(y.kind >= 2) break; g_syms128++; o2 += y.nbits; } } else if(stop == 1) g_round_cut++;
+                }
                 if(V) { const int hi = 63 - __builtin_clzll(V); pos = dst[hi] + olen[hi]; }
                 bitpos += off;
                 if(stop >= 3) { err = stop == 3 ? INF_E_SYMBOL : INF_E_DIST; break; }
@@ -98,6 +105,7 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
             uint64_t pending = 0; for(uint32_t k = 0; k < n_tok; k++) if(!far[k]) pending |= 1ull << k;
             int guard = 0;
             while(pending) {
+                g_near_rounds++;
                 if(++guard > 200) return 106;
                 const int f = __builtin_ctzll(pending); const InfToken q = S.tok[f];
                 const uint32_t W = q.dst, flen = q.len_dist & 0xffffu;
@@ -253,7 +261,11 @@ int main(int argc, char **argv) {
         }
         o += bs; m++;
     }
-    printf("{\"members\": %ld, \"inflated_bytes\": %llu, \"mismatching_members\": %ld, \"batches\": %llu, \"far_matches\": %llu, \"near_matches\": %llu}\n", m, (unsigned long long)tot, bad,
-           (unsigned long long)n_batches, (unsigned long long)n_far, (unsigned long long)n_near);
+    printf("{\"members\": %ld, \"inflated_bytes\": %llu, \"mismatching_members\": %ld, \"batches\": %llu, \"far_matches\": %llu, \"near_matches\": %llu, "
+           "\"header_batches\": %llu, \"decode_rounds\": %llu, \"symbols\": %llu, \"literals\": %llu, \"matches\": %llu, \"symbols_per_round\": %.2f, \"rounds_cut_by_batch_limits\": %llu, "
+           "\"symbols_per_round_if_window_were_128_bits\": %.2f, \"near_rounds\": %llu, \"bytes_per_symbol\": %.2f}\n", m, (unsigned long long)tot, bad,
+           (unsigned long long)n_batches, (unsigned long long)n_far, (unsigned long long)n_near, (unsigned long long)g_hdr_batches, (unsigned long long)g_rounds, (unsigned long long)g_syms, (unsigned long long)g_lits,
+           (unsigned long long)g_matches, g_rounds ? (double)g_syms / (double)g_rounds : 0.0, (unsigned long long)g_round_cut, g_rounds ? (double)g_syms128 / (double)g_rounds : 0.0, (unsigned long long)g_near_rounds,
+           g_syms ? (double)tot / (double)g_syms : 0.0);
     return bad ? 1 : 0;
 }
