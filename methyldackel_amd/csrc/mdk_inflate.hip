@@ -3,7 +3,7 @@
 //
 //   k_inflate     one WAVEFRONT per BGZF member.  Inside a Huffman block every lane decodes the symbol that would start at its bit of the
 //                 stream's next 64 (mdk_inflate_core.h inf_decode_at) and a walk over the results picks the real ones -- ~5 symbols per round
-//                 of table lookups on the bench's BAM (tools/inflate_emu prints the statistics); their output positions are a prefix sum in DPP.  Batches of <= 64 match tokens / 1 KiB of output: literals
+//                 of table lookups on the bench's BAM (tools/inflate_emu prints the statistics); their output positions are a prefix sum in DPP.  Batches of <= 128 match tokens / 1 KiB of output: literals
 //                 go straight into a 2 KiB output window (INF_WIN) in LDS, matches become tokens.  Between batches all 64 lanes work: (1) top
 //                 up the LDS ring of compressed words with one coalesced load, (2) FAR matches -- source older than the LDS window -- one lane
 //                 per token, bytes from global memory (written by an earlier batch of this wavefront), (3) NEAR matches: every token whose
@@ -118,34 +118,42 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
         if(!err && fin && pos != M.out_len) err = INF_E_SHORT;
         if(err || (bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, M.in_len))) { fail(err ? err : (uint32_t)INF_E_INPUT); return; }
         const uint32_t end = pos;
-        // (2) far matches: one lane per token; every byte comes from global memory
-        bool far = false;
-        InfToken t; t.dst = 0; t.len_dist = 0;
-        if((uint32_t)lane < n_tok) { t = S.tok[lane]; far = inf_tok_far(t, beg); }
-        if(__ballot(far)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the earlier batches' stores have reached L2
-            if(far) {
-                // 16 bytes per round trip: the five aligned words that hold them are requested together, then cut to the source's
-                // byte offset (v_alignbyte) and stored into the window byte by byte (its position there is unaligned too)
-                const uint32_t len = t.len_dist & 0xffffu; const uint8_t *sp = out + (t.dst - (t.len_dist >> 16));
-                for(uint32_t i = 0; i < len; i += 16) {
-                    const uintptr_t a = (uintptr_t)(sp + i); const uint32_t *wp = (const uint32_t *)(a & ~(uintptr_t)3); const uint32_t k = (uint32_t)(a & 3u);
-                    const uint32_t n = len - i < 16u ? len - i : 16u;
-                    const uint32_t w0 = ld_u32_l2(wp), w1 = ld_u32_l2(wp + 1), w2 = ld_u32_l2(wp + 2), w3 = ld_u32_l2(wp + 3), w4 = ld_u32_l2(wp + 4);
-                    uint32_t b[4] = {__builtin_amdgcn_alignbyte(w1, w0, k), __builtin_amdgcn_alignbyte(w2, w1, k), __builtin_amdgcn_alignbyte(w3, w2, k), __builtin_amdgcn_alignbyte(w4, w3, k)};
+        // (2) far matches: one lane per token (of each 64 of them); every byte comes from global memory
+        {
+            bool waited = false;
+            for(uint32_t tb = 0; tb < n_tok; tb += 64) {
+                bool far = false;
+                InfToken t; t.dst = 0; t.len_dist = 0;
+                if(tb + (uint32_t)lane < n_tok) { t = S.tok[tb + (uint32_t)lane]; far = inf_tok_far(t, beg); }
+                if(__ballot(far)) {
+                    if(!waited) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); waited = true; }      // the earlier batches' stores have reached L2
+                    if(far) {
+                        // 16 bytes per round trip: the five aligned words that hold them are requested together, then cut to the source's
+                        // byte offset (v_alignbyte) and stored into the window byte by byte (its position there is unaligned too)
+                        const uint32_t len = t.len_dist & 0xffffu; const uint8_t *sp = out + (t.dst - (t.len_dist >> 16));
+                        for(uint32_t i = 0; i < len; i += 16) {
+                            const uintptr_t a = (uintptr_t)(sp + i); const uint32_t *wp = (const uint32_t *)(a & ~(uintptr_t)3); const uint32_t k = (uint32_t)(a & 3u);
+                            const uint32_t n = len - i < 16u ? len - i : 16u;
+                            const uint32_t w0 = ld_u32_l2(wp), w1 = ld_u32_l2(wp + 1), w2 = ld_u32_l2(wp + 2), w3 = ld_u32_l2(wp + 3), w4 = ld_u32_l2(wp + 4);
+                            uint32_t b[4] = {__builtin_amdgcn_alignbyte(w1, w0, k), __builtin_amdgcn_alignbyte(w2, w1, k), __builtin_amdgcn_alignbyte(w3, w2, k), __builtin_amdgcn_alignbyte(w4, w3, k)};
 #pragma unroll
-                    for(uint32_t q = 0; q < 16; q++) if(q < n) S.win[(t.dst + i + q) & (INF_WIN - 1)] = (uint8_t)(b[q >> 2] >> (8 * (q & 3)));
+                            for(uint32_t q = 0; q < 16; q++) if(q < n) S.win[(t.dst + i + q) & (INF_WIN - 1)] = (uint8_t)(b[q >> 2] >> (8 * (q & 3)));
+                        }
+                    }
                 }
             }
-            __syncthreads();
+            if(waited) __syncthreads();
         }
-        // (3) near matches.  Everything below the first token not yet copied is final (literals were written while decoding), so every token whose
-        // source ends below that mark can be copied at once -- short ones (most: a BAM field repeated from the record before) each by its own
-        // lane, byte by byte, which also gets a match that overlaps its own output right; a long one, when it is the first, by the whole
-        // wavefront (span-doubling rounds).  A handful of rounds per batch instead of one per token.
-        {
+        // (3) near matches, the tokens in stream order, 64 at a time.  Everything below the first token not yet copied is final (literals were
+        // written while decoding, far matches above, the 64 tokens before these), so every token whose source ends below that mark can be
+        // copied at once -- short ones (most: a BAM field repeated from the record before) each by its own lane, byte by byte, which also gets a
+        // match that overlaps its own output right; a long one, when it is the first, by the whole wavefront (span-doubling rounds).  A handful
+        // of rounds per 64 tokens instead of one per token.
+        for(uint32_t tb = 0; tb < n_tok; tb += 64) {
+            InfToken t; t.dst = 0; t.len_dist = 0; bool mine = false;
+            if(tb + (uint32_t)lane < n_tok) { t = S.tok[tb + (uint32_t)lane]; mine = !inf_tok_far(t, beg); }
             const uint32_t len = t.len_dist & 0xffffu, dist = t.len_dist >> 16, src = t.dst - dist;
-            unsigned long long pending = __ballot((uint32_t)lane < n_tok && !far);
+            unsigned long long pending = __ballot(mine);
             while(pending) {
                 const int f = __ffsll((long long)pending) - 1;
                 const uint32_t W = (uint32_t)__builtin_amdgcn_readlane((int)t.dst, f), flen = (uint32_t)__builtin_amdgcn_readlane((int)len, f);

@@ -88,12 +88,12 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
         if((bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, in_len))) return INF_E_INPUT;
         const uint32_t end = pos;
         if(end - beg > INF_BATCH_BYTES || n_tok > INF_MAX_TOK) return 100;
-        bool far[64];
-        for(uint32_t lane = 0; lane < 64; lane++) {
-            far[lane] = false;
-            if(lane < n_tok) {
-                const InfToken t = S.tok[lane]; far[lane] = inf_tok_far(t, beg);
-                if(far[lane]) {
+        bool far[INF_MAX_TOK];
+        for(uint32_t k = 0; k < INF_MAX_TOK; k++) {                      // the far phase: every token, 64 at a time on the device
+            far[k] = false;
+            if(k < n_tok) {
+                const InfToken t = S.tok[k]; far[k] = inf_tok_far(t, beg);
+                if(far[k]) {
                     const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16);
                     if(src + len > beg) return 101;                       // a far source must lie wholly in what earlier batches wrote
                     for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = out[src + i];
@@ -101,13 +101,13 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
                 }
             }
         }
-        {   // the near phase of k_inflate: rounds over the tokens not yet copied
-            uint64_t pending = 0; for(uint32_t k = 0; k < n_tok; k++) if(!far[k]) pending |= 1ull << k;
+        for(uint32_t tb = 0; tb < n_tok; tb += 64) {   // the near phase of k_inflate: the tokens in stream order, 64 at a time; rounds over those not yet copied
+            uint64_t pending = 0; for(uint32_t k = 0; k < 64 && tb + k < n_tok; k++) if(!far[tb + k]) pending |= 1ull << k;
             int guard = 0;
             while(pending) {
                 g_near_rounds++;
                 if(++guard > 200) return 106;
-                const int f = __builtin_ctzll(pending); const InfToken q = S.tok[f];
+                const int f = __builtin_ctzll(pending); const InfToken q = S.tok[tb + f];
                 const uint32_t W = q.dst, flen = q.len_dist & 0xffffu;
                 if(q.dst - (q.len_dist >> 16) + INF_WIN < end) return 102;          // a near source must still be in the window at the end of the batch
                 if(flen > INF_NEAR_LANE_MAX) {
@@ -122,9 +122,9 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
                     continue;
                 }
                 uint64_t ready = 0;
-                for(uint32_t lane = 0; lane < n_tok; lane++) { const InfToken t = S.tok[lane]; const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16); if(((pending >> lane) & 1ull) && len <= INF_NEAR_LANE_MAX && ((int)lane == f || src + len <= W)) ready |= 1ull << lane; }
+                for(uint32_t lane = 0; lane < 64 && tb + lane < n_tok; lane++) { const InfToken t = S.tok[tb + lane]; const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16); if(((pending >> lane) & 1ull) && len <= INF_NEAR_LANE_MAX && ((int)lane == f || src + len <= W)) ready |= 1ull << lane; }
                 // the ready lanes copy at the same time, byte i of every token in step i: run from the LAST lane to the first to show that the order between lanes does not matter
-                for(int lane = 63; lane >= 0; lane--) if((ready >> lane) & 1ull) { const InfToken t = S.tok[lane]; const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16); for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = S.win[(src + i) & (INF_WIN - 1)]; (*n_near)++; }
+                for(int lane = 63; lane >= 0; lane--) if((ready >> lane) & 1ull) { const InfToken t = S.tok[tb + lane]; const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16); for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = S.win[(src + i) & (INF_WIN - 1)]; (*n_near)++; }
                 pending &= ~ready;
             }
         }
