@@ -23,7 +23,7 @@ $(B)/libmdk_extract.so: $(HOSTSRC) methyldackel_amd/csrc/host/mdk_io.h methyldac
 $(B)/MethylDackel: methyldackel_amd/csrc/host/main.c $(B)/libmdk_extract.so
 	$(CC) $(CFLAGS) -Iinclude -o $@ methyldackel_amd/csrc/host/main.c -L$(B) -lmdk_extract -lmdk_hip -Wl,-rpath,'$$ORIGIN' -lz -lm
 
-tools: tools/_build/mdk_synth tools/_build/mdk_replicate tools/_build/fasta_probe tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/inflate_emu_wide tools/_build/piece_bench tools/_build/pin_probe tools/_build/feed_harness tools/_build/libmdk_piece_standin.so tools/_build/libmdk_dev_standin.so
+tools: tools/_build/mdk_synth tools/_build/mdk_replicate tools/_build/fasta_probe tools/_build/mdk_calib tools/_build/inflate_emu tools/_build/piece_bench tools/_build/pin_probe tools/_build/feed_harness tools/_build/libmdk_piece_standin.so tools/_build/libmdk_dev_standin.so
 tools/_build/libmdk_piece_standin.so: tools/piece_standin.c include/mdk_hip.h
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -Wall -shared -fPIC -Iinclude -o $@ tools/piece_standin.c -lz
@@ -39,10 +39,6 @@ tools/_build/pin_probe: tools/pin_probe.hip
 tools/_build/inflate_emu: tools/inflate_emu.cpp methyldackel_amd/csrc/mdk_inflate_core.h methyldackel_amd/csrc/mdk_crc32_core.h
 	@mkdir -p tools/_build
 	g++ -O2 -Wall -o $@ tools/inflate_emu.cpp -Imethyldackel_amd/csrc -lz
-# the experimental 128-bit decode round (csrc/mdk_inflate.hip under -DINF_WIDE=1; not the default build) on the host
-tools/_build/inflate_emu_wide: tools/inflate_emu.cpp methyldackel_amd/csrc/mdk_inflate_core.h methyldackel_amd/csrc/mdk_crc32_core.h
-	@mkdir -p tools/_build
-	g++ -O2 -Wall -DINF_WIDE=1 -o $@ tools/inflate_emu.cpp -Imethyldackel_amd/csrc -lz
 tools/_build/piece_bench: tools/piece_bench.c include/mdk_hip.h $(B)/libmdk_hip.so
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -Wall -Iinclude -o $@ tools/piece_bench.c -L$(B) -lmdk_hip -Wl,-rpath,'$$ORIGIN/../../$(B)' -lz

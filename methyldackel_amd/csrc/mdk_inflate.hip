@@ -78,58 +78,6 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
         } else {
             // a Huffman block, in rounds: every lane decodes the symbol that would start at its bit of the next 64; the walk keeps the real ones
             const uint32_t lim = beg + (INF_BATCH_BYTES - 258), blim = bitpos + 32u * INF_BATCH_WORDS;
-#if INF_WIDE
-            // EXPERIMENTAL (not the default build, not yet run on a device; tools/inflate_emu.cpp compiled with -DINF_WIDE=1 restates it and equals zlib):
-            // the round over the stream's next 128 bits -- lane l decodes the symbols that would start at bits l (A) and 64 + l (B); one walk over
-            // both halves, two prefix sums (B's on top of A's total), token ranks A before B.  ~9.5 real symbols per round instead of ~5 for the
-            // same number of dependent table look-ups and one walk set-up, one set of ballots and exit tests.
-            for(;;) {
-                const InfSym sa = inf_decode_at(S, bitpos + (uint32_t)lane), sb = inf_decode_at(S, bitpos + 64u + (uint32_t)lane);
-                const uint32_t advA = sa.kind >= 3 ? 0x200u : sa.kind == 2 ? (sa.nbits | 0x100u) : sa.nbits, advB = sb.kind >= 3 ? 0x200u : sb.kind == 2 ? (sb.nbits | 0x100u) : sb.nbits;
-                uint32_t off = 0, a = 0, lastl = 0; unsigned long long VA = 0, VB = 0;
-                do {
-                    lastl = off;
-                    if(off < 64) { VA |= 1ull << off; a = (uint32_t)__builtin_amdgcn_readlane((int)advA, (int)off); }
-                    else { VB |= 1ull << (off - 64u); a = (uint32_t)__builtin_amdgcn_readlane((int)advB, (int)(off - 64u)); }
-                    off += a;
-                } while(off < 128);
-                off = lastl + (a & 0xffu);
-                uint32_t stop = a >= 0x200u ? (lastl < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)sa.kind, (int)lastl) : (uint32_t)__builtin_amdgcn_readlane((int)sb.kind, (int)(lastl - 64u))) : a >= 0x100u ? 2u : 0u;
-                if(stop >= 3) { if(lastl < 64) VA &= ~(1ull << lastl); else VB &= ~(1ull << (lastl - 64u)); }
-                bool validA = (VA >> lane) & 1ull, validB = (VB >> lane) & 1ull;
-                const uint32_t olenA = !validA ? 0u : sa.kind == 0 ? 1u : sa.kind == 1 ? (sa.val & 0xffffu) : 0u, olenB = !validB ? 0u : sb.kind == 0 ? 1u : sb.kind == 1 ? (sb.val & 0xffffu) : 0u;
-                const uint32_t inclA = wave_incl_sum(olenA), totA = (uint32_t)__builtin_amdgcn_readlane((int)inclA, 63), inclB = wave_incl_sum(olenB) + totA;
-                const uint32_t dstA = pos + inclA - olenA, dstB = pos + inclB - olenB;
-                bool ismA = validA && sa.kind == 1, ismB = validB && sb.kind == 1;
-                unsigned long long mbA = __ballot(ismA), mbB = __ballot(ismB);
-                const uint32_t rankA = n_tok + (uint32_t)__popcll(mbA & lt), rankB = n_tok + (uint32_t)__popcll(mbA) + (uint32_t)__popcll(mbB & lt);
-                auto end_of = [&](unsigned long long va, unsigned long long vb) -> uint32_t {      // where the last real symbol's output ends
-                    if(vb) return (uint32_t)__builtin_amdgcn_readlane((int)(dstB + olenB), 63 - __clzll((long long)vb));
-                    if(va) return (uint32_t)__builtin_amdgcn_readlane((int)(dstA + olenA), 63 - __clzll((long long)va));
-                    return pos;
-                };
-                const uint32_t vend = end_of(VA, VB);
-                unsigned long long cmA = 0, cmB = 0;
-                if(vend > beg + INF_BATCH_BYTES || n_tok + (uint32_t)__popcll(mbA) + (uint32_t)__popcll(mbB) > INF_MAX_TOK) {
-                    cmA = __ballot(validA && ((ismA && rankA >= INF_MAX_TOK) || dstA + olenA > beg + INF_BATCH_BYTES));
-                    cmB = __ballot(validB && ((ismB && rankB >= INF_MAX_TOK) || dstB + olenB > beg + INF_BATCH_BYTES));
-                }
-                if(cmA) { const int c = __ffsll((long long)cmA) - 1; VA &= (1ull << c) - 1ull; VB = 0; off = (uint32_t)c; stop = 1; }
-                else if(cmB) { const int c = __ffsll((long long)cmB) - 1; VB &= (1ull << c) - 1ull; off = 64u + (uint32_t)c; stop = 1; }
-                if(cmA | cmB) { validA = (VA >> lane) & 1ull; validB = (VB >> lane) & 1ull; ismA = ismA && validA; ismB = ismB && validB; mbA = __ballot(ismA); mbB = __ballot(ismB); }
-                if(__ballot((ismA && (sa.val >> 16) > dstA) || (ismB && (sb.val >> 16) > dstB))) { err = INF_E_DIST; break; }
-                if(validA && sa.kind == 0) S.win[dstA & (INF_WIN - 1)] = (uint8_t)sa.val;
-                if(validB && sb.kind == 0) S.win[dstB & (INF_WIN - 1)] = (uint8_t)sb.val;
-                if(ismA) { InfToken t; t.dst = dstA; t.len_dist = sa.val; S.tok[rankA] = t; }
-                if(ismB) { InfToken t; t.dst = dstB; t.len_dist = sb.val; S.tok[rankB] = t; }
-                n_tok += (uint32_t)__popcll(mbA) + (uint32_t)__popcll(mbB);
-                pos = (cmA | cmB) ? end_of(VA, VB) : vend;
-                bitpos += off;
-                if(stop >= 3) { err = stop == 3 ? INF_E_SYMBOL : INF_E_DIST; break; }
-                if(stop == 2) { in_block = 0; fin = last; break; }
-                if(stop == 1 || n_tok >= INF_MAX_TOK || pos > lim || bitpos > blim) break;
-            }
-#else
             for(;;) {
                 const InfSym sy = inf_decode_at(S, bitpos + (uint32_t)lane);
                 // the walk: lane 0's symbol is real, the next real one starts where it ends, ... -- a scalar loop over readlane; adv = the symbol's
@@ -164,7 +112,6 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
                 if(stop == 2) { in_block = 0; fin = last; break; }
                 if(stop == 1 || n_tok >= INF_MAX_TOK || pos > lim || bitpos > blim) break;
             }
-#endif
             __syncthreads();                                          // the window and the tokens are in LDS for every lane
         }
         if(!err && pos > M.out_len) err = INF_E_OVERRUN;

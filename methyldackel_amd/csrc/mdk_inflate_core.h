@@ -40,9 +40,6 @@
 #define INF_BATCH_BYTES (INF_WIN / 2)      // a batch never produces more than this
 #define INF_BATCH_WORDS 150                // ... nor takes more than this many words from the input ring (the ring is topped up to >= 193 ahead)
 #define INF_MAX_TOK   128                  // ... nor holds more match tokens than this (two places per lane: with one, three quarters of the batches of a BAM member ended at ~470 bytes because the places were full -- 81 % of its symbols are matches)
-#ifndef INF_WIDE
-#define INF_WIDE 0                         // 1: a decode round looks at the stream's next 128 bits, two bit positions per lane (mdk_inflate.hip; EXPERIMENTAL: the host emulation of it
-#endif                                     //    equals zlib on every test stream, the kernel variant has not run on a device yet -- round 5's first measurement)
 #define INF_NEAR_LANE_MAX 32u              // a match up to this long whose source is final is copied by its own lane; longer ones by the whole wavefront
 
 // Literal/length table entry, 16 bits (the tables of a wavefront are 3.3 KiB of LDS):

@@ -43,47 +43,43 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
         } else {
             // the rounds of k_inflate: the per-lane decode is the kernel's code, the cross-lane steps (walk by readlane, scan, ballots) run over arrays
             const uint32_t lim = beg + (INF_BATCH_BYTES - 258), blim = bitpos + 32u * INF_BATCH_WORDS;
-            // (NPOS = 64: one bit position per lane; 128 with -DINF_WIDE=1: two, lane l's symbols A at bit l and B at bit 64 + l -- positions 0..63 are
-            // the A's, 64..127 the B's, and everything in position order is "A before B": walk, output offsets, token ranks)
-            const uint32_t NPOS = INF_WIDE ? 128u : 64u;
             for(;;) {
-                InfSym sy[128];
-                for(uint32_t q = 0; q < NPOS; q++) sy[q] = inf_decode_at(S, bitpos + q);
-                uint32_t adv[128]; for(uint32_t q = 0; q < NPOS; q++) adv[q] = sy[q].kind >= 3 ? 0x200u : sy[q].kind == 2 ? (sy[q].nbits | 0x100u) : sy[q].nbits;
-                uint32_t off = 0, a = 0, lastl = 0; bool V[128]; for(uint32_t q = 0; q < 128; q++) V[q] = false;
-                do { lastl = off; V[off] = true; a = adv[off]; off += a; } while(off < NPOS);
+                InfSym sy[64];
+                for(uint32_t lane = 0; lane < 64; lane++) sy[lane] = inf_decode_at(S, bitpos + lane);
+                uint32_t adv[64]; for(uint32_t lane = 0; lane < 64; lane++) adv[lane] = sy[lane].kind >= 3 ? 0x200u : sy[lane].kind == 2 ? (sy[lane].nbits | 0x100u) : sy[lane].nbits;
+                uint32_t off = 0, a = 0, lastl = 0; uint64_t V = 0;
+                do { lastl = off; V |= 1ull << off; a = adv[off]; off += a; } while(off < 64);
                 off = lastl + (a & 0xffu);
                 uint32_t stop = a >= 0x200u ? sy[lastl].kind : a >= 0x100u ? 2u : 0u;
-                if(stop >= 3) V[lastl] = false;
-                uint32_t olen[128], dst[128], mpre[128]; uint32_t run = 0, nm = 0; bool M[128]; int cut = -1;
-                for(uint32_t q = 0; q < NPOS; q++) {
-                    olen[q] = !V[q] ? 0u : sy[q].kind == 0 ? 1u : sy[q].kind == 1 ? (sy[q].val & 0xffffu) : 0u;
-                    dst[q] = pos + run; run += olen[q];
-                    mpre[q] = nm; M[q] = V[q] && sy[q].kind == 1; if(M[q]) nm++;
+                if(stop >= 3) V &= ~(1ull << lastl);
+                uint32_t olen[64], dst[64], mpre[64]; uint32_t run = 0, nm = 0; uint64_t mball = 0, cm = 0;
+                for(uint32_t lane = 0; lane < 64; lane++) {
+                    const bool valid = (V >> lane) & 1ull;
+                    olen[lane] = !valid ? 0u : sy[lane].kind == 0 ? 1u : sy[lane].kind == 1 ? (sy[lane].val & 0xffffu) : 0u;
+                    dst[lane] = pos + run; run += olen[lane];
+                    mpre[lane] = nm; if(valid && sy[lane].kind == 1) { mball |= 1ull << lane; nm++; }
                 }
-                for(uint32_t q = 0; q < NPOS && cut < 0; q++) if(V[q] && ((M[q] && n_tok + mpre[q] >= INF_MAX_TOK) || dst[q] + olen[q] > beg + INF_BATCH_BYTES)) cut = (int)q;
-                if(cut >= 0) { for(uint32_t q = (uint32_t)cut; q < NPOS; q++) { V[q] = false; M[q] = false; } off = (uint32_t)cut; stop = 1; }
+                for(uint32_t lane = 0; lane < 64; lane++) { const bool valid = (V >> lane) & 1ull, ism = (mball >> lane) & 1ull; if(valid && ((ism && n_tok + mpre[lane] >= INF_MAX_TOK) || dst[lane] + olen[lane] > beg + INF_BATCH_BYTES)) cm |= 1ull << lane; }
+                if(cm) { const int c = __builtin_ctzll(cm); V &= (1ull << c) - 1ull; off = (uint32_t)c; stop = 1; mball &= V; }
                 bool baddist = false;
-                for(uint32_t q = 0; q < NPOS; q++) if(M[q] && (sy[q].val >> 16) > dst[q]) baddist = true;
+                for(uint32_t lane = 0; lane < 64; lane++) if(((mball >> lane) & 1ull) && (sy[lane].val >> 16) > dst[lane]) baddist = true;
                 if(baddist) { err = INF_E_DIST; break; }
-                uint32_t nmk = 0; int hi = -1;
-                for(uint32_t q = 0; q < NPOS; q++) {
-                    if(V[q] && sy[q].kind == 0) S.win[dst[q] & (INF_WIN - 1)] = (uint8_t)sy[q].val;
-                    if(M[q]) { InfToken t; t.dst = dst[q]; t.len_dist = sy[q].val; if(n_tok + mpre[q] >= INF_MAX_TOK) return 104; S.tok[n_tok + mpre[q]] = t; nmk++; }
-                    if(V[q]) hi = (int)q;
+                for(uint32_t lane = 0; lane < 64; lane++) {
+                    const bool valid = (V >> lane) & 1ull;
+                    if(valid && sy[lane].kind == 0) S.win[dst[lane] & (INF_WIN - 1)] = (uint8_t)sy[lane].val;
+                    if((mball >> lane) & 1ull) { InfToken t; t.dst = dst[lane]; t.len_dist = sy[lane].val; if(n_tok + mpre[lane] >= INF_MAX_TOK) return 104; S.tok[n_tok + mpre[lane]] = t; }
                 }
-                n_tok += nmk;
+                n_tok += (uint32_t)__builtin_popcountll(mball);
                 {   // statistics
-                    uint32_t nv = 0; for(uint32_t q = 0; q < NPOS; q++) nv += V[q] ? 1u : 0u;
-                    g_rounds++; g_syms += nv; g_matches += nmk; g_lits += nv - nmk; g_syms128 += nv;
-                    if(stop == 0 && NPOS == 64) { uint32_t o2 = off; while(o2 < 128) { const InfSym y = inf_decode_at(S, bitpos + o2); if(y.kind >= 2) break; g_syms128++; o2 += y.nbits; } } else if(stop == 1) g_round_cut++;
+                    const int nv = __builtin_popcountll(V); g_rounds++; g_syms += (uint64_t)nv; g_matches += (uint64_t)__builtin_popcountll(mball); g_lits += (uint64_t)(nv - __builtin_popcountll(mball)); g_syms128 += (uint64_t)nv;
+                    if(stop == 0) { uint32_t o2 = off; while(o2 < 128) { const InfSym y = inf_decode_at(S, bitpos + o2); if(y.kind >= 2) break; g_syms128++; o2 += y.nbits; } } else if(stop == 1) g_round_cut++;
                 }
-                if(hi >= 0) pos = dst[hi] + olen[hi];
+                if(V) { const int hi = 63 - __builtin_clzll(V); pos = dst[hi] + olen[hi]; }
                 bitpos += off;
                 if(stop >= 3) { err = stop == 3 ? INF_E_SYMBOL : INF_E_DIST; break; }
                 if(stop == 2) { in_block = 0; fin = last; break; }
                 if(stop == 1 || n_tok >= INF_MAX_TOK || pos > lim || bitpos > blim) break;
-                if(hi < 0) return 105;                                    // a round without progress (cannot happen: the first symbol of a round always fits)
+                if(!V) return 105;                                        // a round without progress (cannot happen: the first symbol of a round always fits)
             }
         }
         if(!err && pos > out_len) err = INF_E_OVERRUN;
