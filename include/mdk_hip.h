@@ -196,7 +196,7 @@ typedef struct {
     uint32_t n_records; uint64_t out_bytes;
     const uint8_t *d_out; const uint32_t *d_rec_off;  /* DEVICE pointers: inflated bytes; offset (in d_out) of every record's block_size word */
 } md_piece_info;
-int  md_piece_create(md_dev *h, md_piece **out);     /* its own stream, buffers grown on demand */
+int  md_piece_create(md_dev *h, md_piece **out);     /* buffers grown on demand; its work is queued on one of a few streams the pieces of a handle share (four; MDK_PIECE_STREAMS=0: a stream of its own) */
 void md_piece_destroy(md_piece *p);
 /* asynchronous: H2D of `comp` (pinned memory makes it a DMA) and the member table, the kernels, D2H of the digests.  The member
  * table must be contiguous (out_off = running sum of out_len), out_len <= 65536.  comp/mem must stay valid until md_piece_wait. */
