@@ -106,6 +106,9 @@ int64_t mdk_plan_target_len(const mdk_plan *p, int32_t tid);
  * --noSVG; which = keepCpG + 2 keepCHG + 4 keepCHH as passed to makeSVGs, MBias.c:556).
  * mdk_mbias_report: makeSVGs + makeTXT (svg.c:300-454) over the histogram the device returns. */
 int  mbias_main(int argc, char *argv[]);
+/* for a caller that leaves with _exit after one of the entry points has returned (the `MethylDackel` command): joins the thread that brings the
+ * HIP runtime up and the device library's helper threads, so that none of them is inside the runtime when the process goes */
+void mdk_cli_quiesce(void);
 int  mdk_plan_open_mbias(int argc, char *argv[], mdk_plan **out);
 int  mdk_plan_mbias_outputs(const mdk_plan *p, const char **opref, int *svg, int *txt, int *which);
 int  mdk_mbias_report(const md_mbias *hist, const char *opref, int svg, int txt, int which);

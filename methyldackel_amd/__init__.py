@@ -158,7 +158,7 @@ def raw_record_offsets(raw):
     return out
 
 
-HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
+HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_quiesce", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_dev_download_group", "md_dev_reserve_contigs", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_rank_shared", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_result_header", "md_comm_result_send", "md_comm_result_recv", "md_dev_pci_bus_id",
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned", "md_host_profile", "md_dev_profile_text", "md_host_register", "md_host_register_all",
@@ -170,7 +170,7 @@ EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_
                    "mdk_plan_next_chunk", "mdk_plan_try_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len", "mdk_plan_regions", "mdk_plan_set_prep", "mdk_plan_set_hold", "mdk_plan_prep_cfg", "mdk_plan_host_prepare",
                    "mdk_plan_host_prepare_from", "mdk_plan_release_records", "mdk_plan_attach_device", "mdk_plan_detach_device",
-                   "mbias_main", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report",
+                   "mbias_main", "mdk_cli_quiesce", "mdk_plan_open_mbias", "mdk_plan_mbias_outputs", "mdk_mbias_report",
                    "perRead_main", "mdk_plan_open_perread", "mdk_plan_emit_perread", "mdk_plan_emit_perread_raw", "mergeContext_main", "mdk_bind_to_device_node"]
 
 _hip = None
@@ -574,6 +574,9 @@ def run_cli(args, cwd=None, env=None, command="extract", ranks=None, timeout=Non
     if not CLI.exists():
         raise MdkError(f"{CLI} is missing (run `make`)")
     e = dict(os.environ)
+    # a GPU exception in the command: the runtime prints what it was (address, reason) and aborts, instead of piping a GPU core dump to the
+    # host's core_pattern helper, which no container holds (that attempt is all round 4's one faulting run left on stderr)
+    e.setdefault("HSA_DISABLE_COREDUMP_ON_EXCEPTION", "1")
     if env:
         e.update(env)
     if ranks:

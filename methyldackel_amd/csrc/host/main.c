@@ -48,7 +48,7 @@ static void say_done(int rc) {              /* the child's last act before it le
 }
 /* returns in the child (the work is its to do) or, when nothing was forked, in the only process; the parent never returns */
 static void detach_teardown(void) {
-    int pfd[2]; pid_t c; char num[16];
+    int pfd[2]; pid_t c; char num[16]; const pid_t me = getpid();
     static const int sigs[] = {SIGINT, SIGTERM, SIGHUP, SIGQUIT, SIGUSR1, SIGUSR2};
     if(getenv("MDK_NO_DETACH") || profiler_present() || pipe(pfd)) return;
     fflush(stdout); fflush(stderr);
@@ -57,7 +57,7 @@ static void detach_teardown(void) {
     if(c == 0) {
         close(pfd[0]);
         (void)prctl(PR_SET_PDEATHSIG, SIGKILL);                  /* nobody to answer to: no work without a parent */
-        if(getppid() == 1) _exit(1);
+        if(getppid() != me) _exit(1);                            /* (the parent went between fork and prctl; PID 1 is a parent like any other) */
         snprintf(num, sizeof(num), "%d", pfd[1]); setenv("MDK_DONE_FD", num, 1);
         return;
     }
@@ -104,6 +104,7 @@ int main(int argc, char *argv[]) {
             detach_teardown();
             rc = cmd(argc - 1, argv + 1);
             say_done(rc);
+            mdk_cli_quiesce();                                   /* no thread of ours is left inside the HIP runtime when the process goes */
             _exit(rc & 0xff);
         }
     }

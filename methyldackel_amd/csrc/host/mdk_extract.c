@@ -49,16 +49,23 @@ MDK_LOCAL void leave_fast(int ret) {
         if(write(fd, &code, 1) != 1) { /* nobody is listening any more */ }
         close(fd);
     }
+    mdk_cli_quiesce();
     _exit(ret & 0xff);
 }
 /* the HIP runtime takes 0.1-0.4 s to come up: start that before anything else (options, BAM header, FASTA), on its own thread */
 static void *hipwarm_main(void *arg) { (void)arg; (void)md_dev_warm(getenv("MDK_DEVICE") ? atoi(getenv("MDK_DEVICE")) : 0); return NULL; }
 /* only in the `MethylDackel` command, which always ends with _exit (leave_fast): a library caller whose bad command line makes
- * us return at once must not find a half-initialised runtime racing its exit handlers */
+ * us return at once must not find a half-initialised runtime racing its exit handlers.  The thread is joined -- and with it the side
+ * threads md_dev_warm starts (md_dev_quiesce) -- before the command leaves: mdk_cli_quiesce, called by leave_fast and by main.c after
+ * the caller has been told that the outputs are closed. */
+static pthread_t g_warm_th; static int g_warm_started = 0;
 MDK_LOCAL void hip_warm_up(void) {
-    pthread_t th;
-    if(!fast_exit_wanted() || pthread_create(&th, NULL, hipwarm_main, NULL)) return;
-    pthread_detach(th);
+    if(!fast_exit_wanted() || g_warm_started) return;
+    if(pthread_create(&g_warm_th, NULL, hipwarm_main, NULL) == 0) g_warm_started = 1;
+}
+void mdk_cli_quiesce(void) {
+    if(g_warm_started) { pthread_join(g_warm_th, NULL); g_warm_started = 0; }
+    md_dev_quiesce();
 }
 /* md_dev_last_error is per thread: keep the text of a failed open for the thread that reports it */
 MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_open(d->device, &d->cfg, &d->dev); if(d->rc) snprintf(d->err, sizeof(d->err), "%s", md_dev_last_error()); return NULL; }

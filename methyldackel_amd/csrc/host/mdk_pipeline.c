@@ -374,6 +374,7 @@ typedef struct pslot {
      * device gives up on is prepared from them by mdk_plan_host_prepare) */
     uint32_t *roff; size_t n_roff, cap_roff; md_raw_range *rr; int cap_rr; int hold_slabs, prepared, n_dev_rg;
     int released;                                         /* the slabs behind the ranges were given back early (mdk_plan_release_records) */
+    int fallback;                                         /* the chunk is being prepared on the host after all (mdk_plan_host_prepare_from): its slabs are not given back early any more */
     int use_tab;                                          /* whole members of host slabs travel with the slab's own record table instead of an entry per record in roff (not perRead: its emitter looks the kept records up in roff) */
 } pslot;
 
@@ -430,7 +431,7 @@ static int dev_member(mdk_plan *p, pslot *sl, mdk_slab *ds, int mi, int32_t tid,
 static int reader_fill(mdk_plan *p, pslot *sl) {
     const opts_t *o = &p->o; mdk_bam *bam = p->bam; uint32_t tid, beg, end, tmp; int rc, fi, collect; mdk_rec r; size_t off; mdk_chunk *c = &sl->c;
     memset(c, 0, sizeof(*c)); sl->raw_len = 0; sl->n_rg = 0; sl->n_stream = 0; sl->win = NULL; sl->woff = sl->wlen = 0;
-    sl->n_roff = 0; sl->cat_len = 0; sl->prepared = 0; sl->released = 0; sl->hold_slabs = p->dev_prep; sl->n_dev_rg = 0; sl->use_tab = p->dev_prep && !o->perread && !getenv("MDK_NO_RECTAB");
+    sl->n_roff = 0; sl->cat_len = 0; sl->prepared = 0; sl->released = 0; sl->fallback = 0; sl->hold_slabs = p->dev_prep; sl->n_dev_rg = 0; sl->use_tab = p->dev_prep && !o->perread && !getenv("MDK_NO_RECTAB");
     /* extract.c:325-350 */
     c->index = p->bin++;
     tid = p->g_tid; beg = p->g_pos; end = (uint32_t)(beg + o->chunk_size);
@@ -806,12 +807,21 @@ int mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c) {
 }
 /* the same for a chunk some of whose records were inflated on the device and so never were in host memory: the records as the
  * device slot holds them (the concatenation of the chunk's ranges) come back first and stand in for the ranges */
+/* The uploader thread gives a chunk's slabs back as soon as its records have crossed the link (mdk_plan_release_records) while the collector
+ * thread may be handed the same chunk back by the device (MDK_ERR_PREP_HOST): the two meet under rel_mu.  Whoever comes first decides --
+ * released: the fallback reads the records back from the device slot; fallback first: the slabs stay referenced until the chunk is recycled
+ * and are parsed where they lie. */
+static pthread_mutex_t rel_mu = PTHREAD_MUTEX_INITIALIZER;
 int mdk_plan_host_prepare_from(mdk_plan *p, mdk_chunk *c, md_dev *dev, int slot) {
-    pslot *sl;
+    pslot *sl; int from_device;
     if(!p || !c || !p->started) return -1;
+    pthread_mutex_lock(&rel_mu);
     sl = held_slot(p, c);
-    if(!sl || !sl->hold_slabs) return -1;
-    if(!sl->prepared && (sl->n_dev_rg || sl->released)) {
+    if(!sl || !sl->hold_slabs) { pthread_mutex_unlock(&rel_mu); return -1; }
+    sl->fallback = 1;
+    from_device = !sl->prepared && (sl->n_dev_rg || sl->released);
+    pthread_mutex_unlock(&rel_mu);
+    if(from_device) {
         uint64_t nb = sl->cat_len + 64; uint32_t nr = (uint32_t)c->raw.n_records + 1; rrange *g;
         if(nb > sl->raw_cap) { if(grow((void **)&sl->raw, nb)) return -5; sl->raw_cap = nb; }
         if(nr > sl->cap_roff) { if(grow((void **)&sl->roff, sizeof(uint32_t) * (size_t)nr)) return -5; sl->cap_roff = nr; }
@@ -825,10 +835,14 @@ int mdk_plan_host_prepare_from(mdk_plan *p, mdk_chunk *c, md_dev *dev, int slot)
 }
 
 int mdk_plan_release_records(mdk_plan *p, const mdk_chunk *c) {
-    pslot *sl;
+    pslot *sl; int rc = -1;
     if(!p || !c || !p->started) return -1;
+    pthread_mutex_lock(&rel_mu);
     sl = held_slot(p, c);
-    if(!sl || !sl->hold_slabs || sl->prepared) return -1;
-    if(sl->n_rg) { slot_release_slabs(p, sl); sl->released = 1; }
-    return 0;
+    if(sl && sl->hold_slabs && !sl->prepared && !sl->fallback) {
+        if(sl->n_rg) { slot_release_slabs(p, sl); sl->released = 1; }
+        rc = 0;
+    }
+    pthread_mutex_unlock(&rel_mu);
+    return rc;
 }

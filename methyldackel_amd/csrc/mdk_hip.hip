@@ -734,7 +734,7 @@ static void launch_pileup_multi(const md_dev *h, int grid, size_t lds, hipStream
 // caller can overlap it with its own start-up; md_dev_open afterwards finds it done.
 // streams made ahead of md_dev_open by md_dev_warm (creating one costs the runtime ~5 ms, and needs nothing the options decide)
 static std::mutex g_stash_mu; static std::vector<hipStream_t> g_stash; static int g_stash_dev = -1;
-static std::atomic<bool> g_warm_reg_stop{false};       // the caller's own registration thread has taken over (md_host_register_all with a handle)
+static std::atomic<bool> g_warm_reg_stop{false};       // the device is open (any command): whoever uploads from a block registers it from here on
 // (Round 4 tried stream priorities -- the consumer's streams high, the device inflate's low, so that kernels of microseconds would not queue
 // behind thousands of members: 512 Mb 1.04 -> 0.99 s and 128 Mb 0.376 -> 0.339 s inside WITHOUT them, gpurun_out r04n; all streams are alike.)
 #define WARM_STREAMS 4
@@ -752,6 +752,35 @@ static hipStream_t stream_take(int device) {
 }
 hipStream_t mdk_stream_take(int device) { return stream_take(device); }
 struct WarmScope { WarmScope() { std::lock_guard<std::mutex> lk(g_stash_mu); g_warm_state = 1; } ~WarmScope() { { std::lock_guard<std::mutex> lk(g_stash_mu); g_warm_state = 2; } g_stash_cv.notify_all(); } };
+// The warm-up's side threads.  They are JOINABLE and md_dev_quiesce joins them: before a handle is closed, before the command leaves with
+// _exit (mdk_extract.c leave_fast) -- no thread of this library is inside the runtime when the process goes (round 4's threads were detached,
+// and a short command could reach _exit while they were still in hipMalloc / hipHostRegister).  None of them touches a kernel symbol: the
+// device library's one code object is loaded by md_dev_warm's own thread, once, before anything is launched from it.
+static std::mutex g_side_mu; static std::vector<std::thread> &g_side = *new std::vector<std::thread>();      // (never destroyed: a joinable std::thread must not meet its destructor at exit)
+static std::atomic<bool> g_side_quit{false};
+extern "C" void md_dev_quiesce(void) {
+    std::vector<std::thread> mine;
+    { std::lock_guard<std::mutex> lk(g_side_mu); g_side_quit.store(true); g_warm_reg_stop.store(true); mine.swap(g_side); }
+    for(std::thread &t : mine) if(t.joinable()) t.join();
+}
+template <typename F> static void side_start(F &&f) {
+    static std::once_flag hook;
+    std::call_once(hook, [] { (void)atexit(md_dev_quiesce); });     // a library caller that never closes a handle: joined before the runtime's own exit handlers run
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if(g_side_quit.load()) return;                       // the process is on its way out (or a handle has been closed): nothing new is started
+    g_side.emplace_back(std::forward<F>(f));
+}
+static std::once_flag g_code_once; static int g_code_rc = 0;
+// the one code object of the library (-fgpu-rdc), loaded by ONE thread; every launch path of the library comes through md_dev_open, which calls this
+static int code_object_load() {
+    std::call_once(g_code_once, [] {
+        hipFuncAttributes fa;
+        if(hipFuncGetAttributes(&fa, pileup_fn(false, false)) != hipSuccess || hipFuncGetAttributes(&fa, (const void *)k_classify) != hipSuccess) { g_code_rc = 1; (void)hipGetLastError(); return; }
+        if(prep_kernels_init()) g_code_rc = 1;          // (same code object: the attribute of the scan kernel, nothing is loaded again)
+        inflate_kernels_warm();
+    });
+    return g_code_rc;
+}
 extern "C" int md_dev_warm(int device) {
     WarmScope warm_scope;
     const double t0 = mdk_now();
@@ -763,38 +792,35 @@ extern "C" int md_dev_warm(int device) {
     const double t2 = mdk_now();
     { std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev != device) { g_stash.clear(); g_stash_dev = device; } }
     // What the first chunk and the first piece would otherwise pay for on the pipeline's critical path (gpurun_out r04p, 3 ms time series: the first
-    // upload took 75 ms and the first group 60 ms, a later group 8): the code objects of the preparation and inflate kernels (every .hip file
-    // is a code object of its own, loaded at the first use of one of its kernels, ~30 ms each) and the copy engines' queues in both directions
-    // (made at the first copy).  On threads of their own, not waited for: whoever needs one of them first waits inside the runtime for that one.
-    if(!getenv("MDK_NO_WARM_SIDE")) {
+    // upload took 75 ms and the first group 60 ms, a later group 8): the copy engines' queues in both directions (made at the first copy), carved
+    // device blocks, the pieces' streams.  On threads of their own; whoever needs one of them first waits inside the runtime for that one.
+    if(!getenv("MDK_NO_WARM_SIDE") && !g_side_quit.load()) {
         // ... and the staging blocks the host's inflate fills while the runtime comes up are made known to it from the moment it IS up, not from the
-        // moment the device handle is open 60-90 ms later (the first chunk's upload waited 50-85 ms for the registration of ~30 blocks, r04q)
+        // moment the device handle is open 60-90 ms later (the first chunk's upload waited 50-85 ms for the registration of ~30 blocks, r04q).
+        // Until the device is open (md_dev_open stops it), not longer.
         if(!getenv("MDK_NO_PIN") && !getenv("MDK_NO_PREREG"))
-            std::thread([device]() {
+            side_start([device]() {
                 if(hipSetDevice(device) != hipSuccess) return;
                 const double t0 = mdk_now();
-                while(!g_warm_reg_stop.load() && mdk_now() - t0 < 1.0) { if(md_host_register_all(nullptr, 1) == 0) std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
-            }).detach();
-        std::thread([device]() { if(hipSetDevice(device) == hipSuccess) (void)prep_kernels_init(); }).detach();
-        std::thread([device]() {          // the device inflate's streams (mdk_inflate.hip piece_stream_of takes them from the stash)
+                while(!g_warm_reg_stop.load() && !g_side_quit.load() && mdk_now() - t0 < 1.0) { if(md_host_register_all(nullptr, 1) == 0) std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+            });
+        side_start([device]() {          // the device inflate's streams (mdk_inflate.hip piece_stream_of takes them from the stash)
             if(hipSetDevice(device) != hipSuccess) return;
-            for(int i = 0; i < 4; i++) { hipStream_t s = nullptr; if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; } std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev == device) g_stash.insert(g_stash.begin(), s); else { (void)hipStreamDestroy(s); return; } }
-        }).detach();
-        std::thread([device]() { if(hipSetDevice(device) == hipSuccess) inflate_kernels_warm(); }).detach();
-        std::thread([device]() {
+            for(int i = 0; i < 4 && !g_side_quit.load(); i++) { hipStream_t s = nullptr; if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; } std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev == device) g_stash.insert(g_stash.begin(), s); else { (void)hipStreamDestroy(s); return; } }
+        });
+        side_start([device]() {
             if(hipSetDevice(device) != hipSuccess) return;
             hipStream_t s = stream_take(device); if(!s) return;
             void *hp = harena_take(1u << 20), *dp = arena_take(1u << 20);
-            if(hp && dp) { memset(hp, 0, 1u << 20); (void)hipMemcpyAsync(dp, hp, 1u << 20, hipMemcpyHostToDevice, s); (void)hipMemcpyAsync(hp, dp, 1u << 20, hipMemcpyDeviceToHost, s); (void)hipStreamSynchronize(s); }
+            if(hp && dp) { memset(hp, 0, 1u << 20); (void)hipMemcpyAsync(dp, hp, 1u << 20, hipMemcpyHostToDevice, s); (void)hipMemcpyAsync(hp, dp, 1u << 20, hipMemcpyDeviceToHost, s); }
+            (void)hipStreamSynchronize(s);
             if(hp) harena_give(hp); if(dp) arena_give(dp);
-            arena_reserve(4);             // (24 slots of a 30x 1 Mb chunk each carve ~2.5 GiB)
+            if(!g_side_quit.load()) arena_reserve(4);             // (24 slots of a 30x 1 Mb chunk each carve ~2.5 GiB)
             (void)hipGetLastError();
             std::lock_guard<std::mutex> lk(g_stash_mu); g_stash.push_back(s);
-        }).detach();
+        });
     }
-    hipFuncAttributes fa;
-    HIPCHK(hipFuncGetAttributes(&fa, pileup_fn(false, false)));
-    HIPCHK(hipFuncGetAttributes(&fa, (const void *)k_classify));
+    if(code_object_load()) return fail(MDK_ERR_HIP, "loading the device library's code object", hipGetLastError());
     const double t3 = mdk_now();
     for(int i = 0; i < WARM_STREAMS; i++) {
         hipStream_t s = nullptr;
@@ -806,7 +832,7 @@ extern "C" int md_dev_warm(int device) {
     }
     const double t4 = mdk_now();
     arena_prime(device);
-    if(mdk_prof_on()) fprintf(stderr, "[mdk hip] warm-up: runtime init + device count %.3fs, context (hipSetDevice + hipFree(0)) %.3fs, code object of the pileup kernels %.3fs, %d streams %.3fs, first blocks of carved device / pinned memory %.3fs\n", t1 - t0, t2 - t1, t3 - t2, WARM_STREAMS, t4 - t3, mdk_now() - t4);
+    if(mdk_prof_on()) fprintf(stderr, "[mdk hip] warm-up: runtime init + device count %.3fs, context (hipSetDevice + hipFree(0)) %.3fs, the library's code object %.3fs, %d streams %.3fs, first blocks of carved device / pinned memory %.3fs\n", t1 - t0, t2 - t1, t3 - t2, WARM_STREAMS, t4 - t3, mdk_now() - t4);
     return 0;
 }
 
@@ -825,6 +851,8 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     if(n <= 0) { if(n == 0) snprintf(g_err, sizeof(g_err), "no HIP device visible"); return MDK_ERR_NODEVICE; }
     if(device < 0 || device >= n) return fail(MDK_ERR_ARG, "md_dev_open: device index", hipSuccess);
     HIPCHK(hipSetDevice(device));
+    g_warm_reg_stop.store(true);                       // from here on, whoever uploads from a staging block registers it (every command, not only extract)
+    if(code_object_load()) return fail(MDK_ERR_HIP, "loading the device library's code object", hipGetLastError());
     md_dev *h = new md_dev();
     h->device = device; h->cfg = *cfg;
     // default tile: 4 positions per thread (2048) for CpG-only runs, 3 (1536) when CHG/CHH are counted: with ~20 sites per
@@ -863,6 +891,7 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
 
 extern "C" void md_dev_close(md_dev *h) {
     if(!h) return;
+    md_dev_quiesce();
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for(auto &s : h->slots) {
@@ -1566,7 +1595,7 @@ extern "C" void md_host_profile(double *seconds, uint64_t *calls, uint64_t *byte
 // every staging block not yet known to the runtime is registered now, by `threads` threads (the caller: a helper thread of the command, once
 // the device is up -- the slabs filled while the runtime was still starting would otherwise be registered one by one by the thread that uploads)
 extern "C" int md_host_register_all(md_dev *h, int threads) {
-    if(h) { (void)hipSetDevice(h->device); g_warm_reg_stop.store(true); }
+    if(h) (void)hipSetDevice(h->device);
     std::vector<char *> todo;
     { std::lock_guard<std::mutex> lk(g_blocks_mu); for(const HostBlock &b : g_blocks) if(b.state == 0) todo.push_back(b.base); }
     if(threads < 1) threads = 1;

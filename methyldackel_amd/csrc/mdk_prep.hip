@@ -27,6 +27,7 @@
 // its window holds, sets a flag and the host prepares that chunk the slow way (mdk_pipeline.c) -- same segments either way.
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include "mdk_hip_internal.hpp"
 #include "mdk_pair_rule.h"          // the pending/pairing machine of the overlap callbacks, shared with its host test
 
@@ -688,8 +689,8 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
 #define PREP_SCAN_LDS ((size_t)(PB / 64) * RAWWIN_LDS)
 static_assert(PREP_SCAN_LDS >= 4 * PB * sizeof(uint4), "the PrepRead stage lives in the windows' memory");
 MDK_HIDDEN int prep_kernels_init() {        // more dynamic LDS than the default window: once per process
-    static int rc = -1;
-    if(rc < 0) rc = hipFuncSetAttribute((const void *)k_prep_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess ? 0 : 1;
+    static std::once_flag once; static int rc = 1;
+    std::call_once(once, [] { rc = hipFuncSetAttribute((const void *)k_prep_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess ? 0 : 1; });
     return rc;
 }
 static uint32_t pow2_at_least(size_t n) { uint32_t p = 1024; while(p < n) p <<= 1; return p; }

@@ -18,6 +18,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The hot path first: under `-x` a failure in a side command (mbias, perRead, bed masks) must not keep the parity matrix of the
+# `extract` path -- BASELINE.json's configs -- from running at all (round 4's driver run stopped at test 91 of 281 and never reached it).
+GPU_ORDER = ["test_gpu_parity", "test_gpu_prep", "test_gpu_scaled_configs", "test_gpu_multi", "test_zoo", "test_gpu_edge_cases", "test_gpu_inflate",
+             "test_gpu_bed", "test_gpu_perread", "test_gpu_mbias", "test_gpu_bench", "test_gpu_stress"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(it):
+        mod = Path(str(it.fspath)).stem
+        return (GPU_ORDER.index(mod) if mod in GPU_ORDER else len(GPU_ORDER), )
+    items.sort(key=key)          # stable: the order inside a module, and of the CPU modules among themselves, is unchanged
+
+
 @pytest.fixture(scope="session", autouse=True)
 def built():
     """Everything is built in-tree by `make` (the GPU box receives the prebuilt .so files; make is then a no-op)."""
