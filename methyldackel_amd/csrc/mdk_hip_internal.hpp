@@ -67,14 +67,18 @@ template <typename T> struct HBuf {
 };
 
 // device chunk preparation (mdk_prep.hip)
-// one admitted read, file order.  64 bytes, so that k_prep_segs meets everything it needs about a read and its mate in four 16-byte
-// loads instead of going back to the record: the name's first 16 bytes (zero-filled past its end; nlen = its strlen), the first
-// three CIGAR operations, and the read's slot in the name table.
+// one candidate record of the chunk, at its index in the chunk's record table (file order).  64 bytes, so that k_prep_segs meets everything it
+// needs about a read and its mate in four 16-byte loads instead of going back to the record: the name's first 16 bytes (zero-filled past
+// its end; nlen = its strlen), the first three CIGAR operations, and the start of the read admitted just before it (what htslib's pileup
+// buffer evicts against, mdk_pair_rule.h).  adm = 0: the record was not admitted (filter_func said no) and nothing else in it means anything.
+// (perRead's selection keeps the admitted reads compacted instead: rd[a] is the a-th kept read, adm = 1 in all of them.)
+#define PREP_PREV_NONE INT32_MIN            // no read was admitted before this one
+#define PREP_PREV_UNKNOWN (INT32_MIN + 1)   // the one before it belongs to an earlier workgroup of k_prep_scan: k_prep_segs looks it up
 struct alignas(16) PrepRead {
-    int32_t pos, rend; uint16_t ncig, flag; uint8_t strand, nlen; uint16_t pad;       // quad 0 + quad 1: what pairing looks at in the OTHER reads of a name
+    int32_t pos, rend; uint16_t ncig, flag; uint8_t strand, nlen, adm, pad;             // quad 0 + quad 1: what pairing looks at in the OTHER reads of a name
     uint32_t name[4];
     uint32_t seq_off, lq, cig_off, qn_off;                                              // quad 2 + quad 3: what the segments of a read (and of its mate) need
-    uint32_t cig[3]; uint32_t slot;
+    uint32_t cig[3]; int32_t prev;
 };
 static_assert(sizeof(PrepRead) == 64, "PrepRead layout");
 struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, max_lq; uint64_t algo_bytes; };      // max_lq: longest admitted read (mbias sizes its histogram by it)

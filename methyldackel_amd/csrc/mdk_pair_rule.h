@@ -23,10 +23,10 @@ MDK_PR bool mdk_pairs(uint32_t flag) { return (flag & 0x1) && !(flag & 12); }
 
 struct MdkPairState { int32_t pending, mate; int32_t live[MDK_MAXLIVE]; int nlive; bool second, overflow; };
 MDK_PR void mdk_pair_init(MdkPairState &S) { S.pending = -1; S.mate = -1; S.nlive = 0; S.second = false; S.overflow = false; }
-/* one read of the name: x its index among the chunk's admitted reads, (flag, rend) its own, prev_pos the start of the read admitted just
- * before it (unused for x == 0); a: the read whose mate is asked for; contig: the chunk's contig index */
-MDK_PR void mdk_pair_step(MdkPairState &S, int32_t contig, uint32_t a, int32_t x, uint32_t flag, int32_t rend, int32_t prev_pos) {
-    const bool first = x == 0;
+/* one read of the name: x its index in the chunk (any numbering that follows file order), (flag, rend) its own, first: no read was admitted
+ * before it, else prev_pos is the start of the read admitted just before it; a: the read whose mate is asked for; contig: the chunk's
+ * contig index */
+MDK_PR void mdk_pair_step(MdkPairState &S, int32_t contig, uint32_t a, int32_t x, uint32_t flag, int32_t rend, bool first, int32_t prev_pos) {
     const bool inserted = first ? (contig > 0 || rend > 0) : (rend > prev_pos);
     if(!inserted) return;
     bool evicted = false; int w = 0;
@@ -47,9 +47,9 @@ MDK_PR void mdk_pair_step(MdkPairState &S, int32_t contig, uint32_t a, int32_t x
 /* the same for a name with exactly two admitted reads f < s (file order), one of which is `a` (and mdk_pairs(a's flag) holds): f enters
  * and becomes pending; s enters, sweeps f out if f ends before the start of the read admitted before s -- which erases the pending
  * entry --, and otherwise is paired with it.  Returns the index of the read `a` is resolved against, or -1. */
-MDK_PR int32_t mdk_pair_two(int32_t contig, uint32_t a, int32_t f, int32_t s, uint32_t flag_f, int32_t rend_f, int32_t prev_f,
+MDK_PR int32_t mdk_pair_two(int32_t contig, uint32_t a, int32_t f, int32_t s, uint32_t flag_f, int32_t rend_f, bool first_f, int32_t prev_f,
                             uint32_t flag_s, int32_t rend_s, int32_t prev_s, bool &second) {
-    const bool in_f = f == 0 ? (contig > 0 || rend_f > 0) : rend_f > prev_f;
+    const bool in_f = first_f ? (contig > 0 || rend_f > 0) : rend_f > prev_f;
     const bool in_s = rend_s > prev_s;
     second = false;
     if(!in_f || !in_s || !mdk_pairs(flag_f) || !mdk_pairs(flag_s) || rend_f < prev_s) return -1;

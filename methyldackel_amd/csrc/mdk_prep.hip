@@ -3,24 +3,25 @@
 // per launch, each over up to 8 chunks at once (a 1 Mb chunk is ~780 workgroups: alone it leaves the machine half empty and every
 // launch boundary is paid per chunk):
 //
-//   k_prep_scan  one lane per BAM record.  A lane walks ITS record, so every load of a wavefront touches 64 different cache lines and
-//                costs that whatever its width: the record is fetched 16 bytes at a time (two loads for the fixed fields, one for the
-//                name's first block, one for the first four CIGAR operations, 8 bytes per aux field) and taken apart in registers:
-//                reference length (bam_cigar2rlen), the aux walk for NH and XG (bam_aux_get), getStrand (common.c:84-116) and
-//                filter_func's admission tests in its order (common.c:416-444: unmapped, MAPQ, -F, -R, duplicates, NH, mappability
-//                windows, singleton, discordant, BED span, conversion efficiency).  The admitted records are compacted IN FILE ORDER
-//                (the order bam_plp_push sees them in) inside the same kernel: a workgroup draws a ticket, publishes its count, and
-//                adds up the counts of the tickets before it -- they all belong to workgroups that are already running, so nobody
-//                waits for a workgroup that has not started.  What later steps need of a read travels in a 64-byte PrepRead (name
-//                head, first CIGAR operations, table slot), and each admitted read goes into a name-keyed hash table (what khash
-//                does in custom_overlap_constructor).
-//   k_prep_segs  one lane per admitted read: the records of its name, in file order, go through the constructor/destructor state
-//                machine of overlaps.c:121-147 *including* htslib's buffer eviction (a read leaves the pileup buffer once a
-//                later read starts beyond its end, and its destructor erases the name) -- every read of a name runs the few
-//                steps of its own group, which is cheaper than a launch of its own; then CIGAR -> gapless runs
-//                (calculate_positions, overlaps.c:27-52; htslib resolve_cigar2), cut where the partner's runs begin and end,
-//                clipped to the chunk: counted, placed by the same ticket scheme, written; every segment also widens the
-//                [first,last) run of the tiles it touches.
+//   k_prep_scan  one lane per BAM record; a wavefront stages the stretch of the record stream that holds its 64 records in LDS with
+//                coalesced loads and every lane takes ITS record apart from there: reference length (bam_cigar2rlen), the aux walk for
+//                NH and XG (bam_aux_get), getStrand (common.c:84-116) and filter_func's admission tests in its order (common.c:416-444:
+//                unmapped, MAPQ, -F, -R, duplicates, NH, mappability windows, singleton, discordant, BED span, conversion efficiency).
+//                What later steps need of a record travels in a 64-byte PrepRead AT THE RECORD'S OWN INDEX (admitted or not, a flag
+//                says which), so a workgroup depends on no other: which records it takes follows from its place in the launch, nothing
+//                is compacted, nobody waits.  The start of the read admitted just before a read -- what htslib's pileup buffer evicts
+//                against -- is found with a ballot inside the wavefront and an exchange inside the workgroup.  Each admitted read goes
+//                into a name-keyed hash table (what khash does in custom_overlap_constructor) whose compare-and-swap returns the name's
+//                previous read: the two are linked both ways (hnext, hfwd), which is all k_prep_segs follows -- it never sees the table.
+//                (perRead's selection keeps the order-preserving compaction of rounds 2-4 in a kernel of its own, k_prep_scan_ordered.)
+//   k_prep_segs  one lane per record: an admitted read and the other read its links lead to (nearly always its mate, a few dozen
+//                records away) go through the constructor/destructor state machine of overlaps.c:121-147 *including* htslib's buffer
+//                eviction (a read leaves the pileup buffer once a later read starts beyond its end, and its destructor erases the
+//                name) in closed form; a name with more reads walks its chain and runs the machine step by step.  Then CIGAR ->
+//                gapless runs (calculate_positions, overlaps.c:27-52; htslib resolve_cigar2), cut where the partner's runs begin and
+//                end, clipped to the chunk: counted, placed IN FILE ORDER (a workgroup draws a ticket, publishes its count and adds up
+//                the counts of the tickets before it -- they all belong to workgroups that are already running, so nobody waits for a
+//                workgroup that has not started), written; every segment also widens the [first,last) run of the tiles it touches.
 //
 // Nothing is copied: segments address sequence and qualities inside the uploaded record bytes (MDK layout 1, see
 // KParams::unit/packed in mdk_hip.hip).  A name with more records than a lane keeps in registers, or more live reads than
@@ -52,8 +53,8 @@ struct PrepParams {
     const uint32_t *mapbits; int64_t maplen;         // 1 bit per base, or NULL
     const md_region *runs; int64_t nruns; int bed_on;
     PrepRead *rd; uint32_t *aidx;    // per admitted read: the read, (perRead) its index among the candidate records
-    unsigned long long *hent; int32_t *hnext; uint32_t hmask;      // name table: (high half of the name's hash) << 32 | (index + 1 of the name's latest read); 0 = empty
-    uint32_t *cntA, *cntS, *ticket; int nblocks;     // per workgroup: published counts of admitted reads / segments; two ticket counters
+    unsigned long long *hent; int32_t *hnext, *hfwd; uint32_t hmask;      // name table: (high half of the name's hash) << 32 | (index + 1 of the name's latest read); 0 = empty.  hnext[i]: the read of i's name that was in the table before i; hfwd[i]: the one that came after
+    uint32_t *cntA, *cntS, *ticket; int nblocks;     // per workgroup: published counts of admitted reads (perRead) / segments; two ticket counters
     md_seg *seg; int64_t cap_seg;
     TileEnt *tiles; int ntiles, tile;
     PrepCounters *cnt;
@@ -66,21 +67,10 @@ struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 // (2 MB) and ticket counters stay in its L2 instead of every L2 thrashing over all eight.  WHICH records of the chunk a workgroup
 // takes is decided by the ticket it draws, not by its index; the launch holds at least as many workgroups per chunk as the chunk has
 // tickets (enqueue_prep_group), and a workgroup that draws a ticket beyond them leaves.
-#ifndef PREP_XCD
-#define PREP_XCD 1
-#endif
 #ifndef PREP_STAGE
 #define PREP_STAGE 1                  // k_prep_scan stages the record stream in LDS (0: every lane reads its record from HBM, round 3's arrangement)
 #endif
-__device__ __forceinline__ int chunk_of_block(const PrepMulti &M) {
-#if PREP_XCD
-    return (int)((blockIdx.x & 7u) % (unsigned)M.n);
-#else
-    int j = 0;
-    while(j + 1 < M.n && (int)blockIdx.x >= M.bstart[j + 1]) j++;
-    return j;
-#endif
-}
+__device__ __forceinline__ int chunk_of_block(const PrepMulti &M) { return (int)((blockIdx.x & 7u) % (unsigned)M.n); }
 // What the workgroups of a chunk tell each other -- tickets, published counts, the name table's compare-and-swaps -- goes through agent-scope
 // atomics.  (Round 4 tried workgroup-scope atomics with a chunk pinned to the XCD s_getreg(XCC_ID) names and workgroups that keep drawing
 // tickets: the ISA is the same but for one cache bit, the gain was 4 %, and with three groups in flight on three streams the launches
@@ -268,6 +258,7 @@ __global__ __launch_bounds__(PB) void k_prep_zero(const PrepMulti M) {
         uint4 *z = (uint4 *)P.zero; const uint64_t n16 = P.zero_bytes >> 4;
         for(uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * PB) z[i] = make_uint4(0, 0, 0, 0);
         for(int t = blockIdx.x * PB + threadIdx.x; t < P.ntiles; t += gridDim.x * PB) { P.tiles[t].first = 0x7fffffff; P.tiles[t].last = 0; }      // the tile runs start empty
+        if(P.hfwd) { uint4 *f = (uint4 *)P.hfwd; const int n16f = (P.n_rec + 3) >> 2; for(int i = blockIdx.x * PB + threadIdx.x; i < n16f; i += gridDim.x * PB) f[i] = make_uint4(~0u, ~0u, ~0u, ~0u); }      // nobody came after anybody yet
         if(blockIdx.x == 0 && threadIdx.x < sizeof(PrepCounters) / 4) ((uint32_t *)P.cnt)[threadIdx.x] = 0;
     }
 }
@@ -328,7 +319,7 @@ __device__ __forceinline__ int scan_record(const PrepParams &P, const V &v, cons
     }
     D.strand = (uint8_t)strand;
     if(!keep) return 0;
-    if(c.no_pairing) { atomicMax(&P.cnt->max_lq, (uint32_t)lq); return 1; }          // mbias: rows of the histogram
+    if(c.no_pairing) return 1;                            // mbias: no names
     // the name as strcmp sees it (its letters up to the first NUL, at most l_read_name - 1 of them), 16 bytes at a time: hashed, and its
     // first block kept in the read
     uint32_t nlen = 0; h = 0x9e3779b97f4a7c15ULL;
@@ -359,20 +350,9 @@ __device__ __forceinline__ int scan_record(const PrepParams &P, const V &v, cons
 #define RAWWIN 18944
 #endif
 #define RAWWIN_LDS (RAWWIN + 32)                      // (+ slack for the word reads of a field that ends at the window's end)
-__global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
-    __shared__ uint32_t s_tk, wcnt[PB / 64], red[PB / 64];
-    extern __shared__ __align__(16) uint4 dyn[];          // PB/64 windows of RAWWIN_LDS bytes; afterwards the workgroup's PrepReads on their way out (64 bytes each)
-    uint4 *const stage = dyn;
-    const PrepParams &P = M.P[chunk_of_block(M)];
-    if(threadIdx.x == 0) s_tk = sync_add(&P.ticket[0], 1u);
-    __syncthreads();
-    const uint32_t tk = s_tk; const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than tickets for this chunk
-    int adm = 0; PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
-    // the wavefront's stretch of the record stream -> LDS, 1 KiB per instruction, straight from HBM (global_load_lds: no registers in between)
-    const int i0 = (int)(tk * PB) + 64 * wave;            // its first record
-    uint32_t wbase = 0, wlen = 0;
-    uint8_t *const win = (uint8_t *)dyn + (size_t)wave * RAWWIN_LDS;
+// the wavefront's stretch of the record stream -> LDS, 1 KiB per instruction, straight from HBM (global_load_lds: no registers in between)
+__device__ __forceinline__ void stage_window(const PrepParams &P, const int i0, const int lane, uint8_t *const win, uint32_t &wbase, uint32_t &wlen) {
+    wbase = 0; wlen = 0;
 #if PREP_STAGE
     if(i0 < P.n_rec) {
         const uint64_t b0 = P.rec_off[i0], b1 = i0 + 64 < P.n_rec ? (uint64_t)P.rec_off[i0 + 64] : P.raw_bytes;
@@ -386,6 +366,10 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     }
     __builtin_amdgcn_wave_barrier();
 #endif
+}
+// record i through the window if it lies inside whole, from HBM otherwise
+__device__ __forceinline__ int scan_one(const PrepParams &P, const int i, const uint8_t *const win, const uint32_t wbase, const uint32_t wlen, PrepRead &D, uint64_t &h) {
+    int adm = 0;
     if(i < P.n_rec) {
         const uint64_t o = P.rec_off[i];
         bool ok = o + 4 + 32 <= P.raw_bytes;
@@ -397,24 +381,56 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
         }
         if(!ok) atomicExch(&P.cnt->malformed, 1u);
     }
-    // file-order compaction: rank inside the workgroup, plus what the earlier tickets admitted
-    const unsigned long long m = __ballot(adm);
-    if(lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0;
-    for(int w = 0; w < PB / 64; w++) { if(w < wave) rank += wcnt[w]; total += wcnt[w]; }
-    if(threadIdx.x == 0) sync_set(&P.cntA[tk], total | CNT_READY);
-    const uint32_t base = tickets_before(P.cntA, tk, red);
-    if((int)tk == P.nblocks - 1 && threadIdx.x == 0) P.cnt->n_adm = base + total;
-    const uint32_t a = base + rank;
+    return adm;
+}
+__device__ __forceinline__ void stage_read(uint4 *st, const PrepRead &D, const int adm) {
+    st[0] = make_uint4((uint32_t)D.pos, (uint32_t)D.rend, (uint32_t)D.ncig | (uint32_t)D.flag << 16, (uint32_t)D.strand | (uint32_t)D.nlen << 8 | (uint32_t)(adm ? 1u : 0u) << 16);
+    st[1] = make_uint4(D.name[0], D.name[1], D.name[2], D.name[3]);
+    st[2] = make_uint4(D.seq_off, D.lq, D.cig_off, D.qn_off);
+    st[3] = make_uint4(D.cig[0], D.cig[1], D.cig[2], (uint32_t)D.prev);
+}
+
+// extract / mbias: every record's PrepRead at the record's own index; no workgroup waits for another.
+// Workgroup b works for chunk (b mod 8) mod n (chunk_of_block) and is the tk-th of the workgroups that do: tk follows from b alone.
+__global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
+    __shared__ uint32_t wcnt[PB / 64]; __shared__ int32_t wlast[PB / 64];
+    extern __shared__ __align__(16) uint4 dyn[];          // PB/64 windows of RAWWIN_LDS bytes; afterwards the workgroup's PrepReads on their way out (64 bytes each)
+    uint4 *const stage = dyn;
+    const int cj = chunk_of_block(M);
+    const PrepParams &P = M.P[cj];
+    const uint32_t xcd = blockIdx.x & 7u, per = (7u - (uint32_t)cj) / (uint32_t)M.n + 1u;       // XCDs that serve this chunk: cj, cj + n, ... (< 8)
+    const uint32_t tk = (blockIdx.x >> 3) * per + xcd / (uint32_t)M.n;
+    if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than this chunk needs
+    const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
+    uint32_t wbase, wlen;
+    uint8_t *const win = (uint8_t *)dyn + (size_t)wave * RAWWIN_LDS;
+    stage_window(P, (int)(tk * PB) + 64 * wave, lane, win, wbase, wlen);
+    const int adm = scan_one(P, i, win, wbase, wlen, D, h);
+    // the start of the read admitted just before this one: the nearest admitted lane below in the wavefront, else the last admitted read of
+    // the nearest wavefront below in the workgroup, else (not the chunk's first workgroup) left to k_prep_segs
+    const unsigned long long m = __ballot(adm), below = m & ((1ull << lane) - 1ull);
+    const int32_t pv_wave = __shfl(D.pos, below ? 63 - __clzll((long long)below) : 0), top = __shfl(D.pos, m ? 63 - __clzll((long long)m) : 0);
+    if(lane == 0) { wcnt[wave] = (uint32_t)__popcll(m); wlast[wave] = top; }
+    if(P.cfg.no_pairing) {                                // mbias: the longest admitted read sizes the histogram rows kept in LDS
+        uint32_t v = adm ? D.lq : 0u;
+#pragma unroll
+        for(int d = 32; d; d >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t > v ? t : v; }
+        if(lane == 0 && v) atomicMax(&P.cnt->max_lq, v);
+    }
+    __syncthreads();                                      // (every wavefront has parsed its records: the windows' memory is free for the stage)
     if(adm) {
-        if(P.aidx) P.aidx[a] = (uint32_t)i;
-        if(!(P.cfg.no_pairing || P.cfg.perread)) {
-            // name table: open addressing; an entry is (high half of the name's hash, the name's latest read), the name's earlier reads hang
-            // off hnext.  One 8-byte word per name, so an insertion touches one line of a 2 MB table: the first read of a name takes an
-            // empty entry with one compare-and-swap, a later one replaces the head with a second (file order is restored by whoever
-            // walks the chain).
-            const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)(a + 1u);
+        int32_t pv = pv_wave;
+        if(!below) {
+            pv = tk == 0 ? PREP_PREV_NONE : PREP_PREV_UNKNOWN;
+            for(int w = wave - 1; w >= 0; w--) if(wcnt[w]) { pv = wlast[w]; break; }
+        }
+        D.prev = pv;
+        if(!P.cfg.no_pairing) {
+            // name table: open addressing; an entry is (high half of the name's hash, the name's latest read).  One 8-byte word per name, so an
+            // insertion touches one line of a 2 MB table: the first read of a name takes an empty entry with one compare-and-swap, a later one
+            // replaces the head with a second -- and learns who was there: the two are linked both ways
+            const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i + 1u);
             uint32_t sl = (uint32_t)h & P.hmask; int32_t before = -1;
             for(;;) {
                 unsigned long long old = sync_cas(&P.hent[sl], 0ull, mine);
@@ -426,78 +442,136 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
                 }
                 sl = (sl + 1) & P.hmask;
             }
-            D.slot = sl;
-            P.hnext[a] = before;
+            P.hnext[i] = before;
+            if(before >= 0) P.hfwd[before] = i;
         }
-        // the PrepRead goes to the workgroup's stage in LDS first: written straight from the lanes, its four quads would leave in four store
-        // instructions of 16 bytes per 64 -- partial lines, which the memory side does not merge (WRITE_SIZE was 2.7x the bytes stored)
-        uint4 *st = stage + 4 * rank;
-        st[0] = make_uint4((uint32_t)D.pos, (uint32_t)D.rend, (uint32_t)D.ncig | (uint32_t)D.flag << 16, (uint32_t)D.strand | (uint32_t)D.nlen << 8);
-        st[1] = make_uint4(D.name[0], D.name[1], D.name[2], D.name[3]);
-        st[2] = make_uint4(D.seq_off, D.lq, D.cig_off, D.qn_off);
-        st[3] = make_uint4(D.cig[0], D.cig[1], D.cig[2], D.slot);
+    }
+    if(threadIdx.x == 0) { uint32_t t = 0; for(int w = 0; w < PB / 64; w++) t += wcnt[w]; if(t) atomicAdd(&P.cnt->n_adm, t); }
+    // the PrepReads go to the workgroup's stage in LDS first and from there to rd[] as whole lines: written straight from the lanes, the four
+    // quads would leave in four store instructions of 16 bytes per 64 -- partial lines, which the memory side does not merge
+    stage_read(stage + 4 * threadIdx.x, D, adm);
+    __syncthreads();
+    {
+        const int first = (int)(tk * PB), cnt = P.n_rec - first < PB ? P.n_rec - first : PB;
+        uint4 *out = (uint4 *)(P.rd + first);
+        for(int q = threadIdx.x; q < 4 * cnt; q += PB) out[q] = stage[q];
+    }
+}
+
+// perRead: the selected reads compacted IN FILE ORDER (rd[a], aidx[a] = the a-th kept record): a workgroup draws a ticket, publishes its
+// count, and adds up the counts of the tickets before it
+__global__ __launch_bounds__(PB) void k_prep_scan_ordered(const PrepMulti M) {
+    __shared__ uint32_t s_tk, wcnt[PB / 64], red[PB / 64];
+    extern __shared__ __align__(16) uint4 dyn[];
+    uint4 *const stage = dyn;
+    const PrepParams &P = M.P[chunk_of_block(M)];
+    if(threadIdx.x == 0) s_tk = sync_add(&P.ticket[0], 1u);
+    __syncthreads();
+    const uint32_t tk = s_tk; const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than tickets for this chunk
+    PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
+    uint32_t wbase, wlen;
+    uint8_t *const win = (uint8_t *)dyn + (size_t)wave * RAWWIN_LDS;
+    stage_window(P, (int)(tk * PB) + 64 * wave, lane, win, wbase, wlen);
+    const int adm = scan_one(P, i, win, wbase, wlen, D, h);
+    const unsigned long long m = __ballot(adm);
+    if(lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), total = 0;
+    for(int w = 0; w < PB / 64; w++) { if(w < wave) rank += wcnt[w]; total += wcnt[w]; }
+    if(threadIdx.x == 0) sync_set(&P.cntA[tk], total | CNT_READY);
+    const uint32_t base = tickets_before(P.cntA, tk, red);
+    if((int)tk == P.nblocks - 1 && threadIdx.x == 0) P.cnt->n_adm = base + total;
+    if(adm) {
+        if(P.aidx) P.aidx[base + rank] = (uint32_t)i;
+        D.prev = PREP_PREV_UNKNOWN;
+        stage_read(stage + 4 * rank, D, 1);
     }
     __syncthreads();
-    {   // ... and from there to rd[base .. base + total) as whole lines
+    {
         uint4 *out = (uint4 *)(P.rd + base);
         for(uint32_t q = threadIdx.x; q < 4 * total; q += PB) out[q] = stage[q];
     }
 }
 
-// what pairing looks at in another read of the name: quad 0 (pos rend ncig|flag strand|nlen) and quad 1 (the name's first 16 bytes) of its
-// PrepRead, taken apart in registers (a PrepRead filled through a pointer would live in scratch)
-struct OtherRead { int32_t rend; uint32_t flag, nlen; uint4 name; };
-__device__ __forceinline__ OtherRead other_read(const PrepParams &P, const int32_t x) {
-    const uint4 *q = (const uint4 *)&P.rd[x]; const uint4 q0 = q[0], q1 = q[1];
-    OtherRead O; O.rend = (int32_t)q0.y; O.flag = q0.z >> 16; O.nlen = (q0.w >> 8) & 255u; O.name = q1;
+// A PrepRead in registers: its four quads as they are loaded, fields picked out with shifts where they are used.  (As a struct copied and
+// zeroed whole, the compiler splits it into BYTES -- one register per byte of every word that holds a byte field -- and k_prep_segs
+// needed 86 VGPRs for two of them.)
+struct RdRegs {
+    uint4 q0, q1, q2, q3;
+    __device__ __forceinline__ int32_t pos() const { return (int32_t)q0.x; }
+    __device__ __forceinline__ int32_t rend() const { return (int32_t)q0.y; }
+    __device__ __forceinline__ uint32_t ncig() const { return q0.z & 0xffffu; }
+    __device__ __forceinline__ uint32_t flag() const { return q0.z >> 16; }
+    __device__ __forceinline__ uint32_t strand() const { return q0.w & 255u; }
+    __device__ __forceinline__ uint32_t nlen() const { return (q0.w >> 8) & 255u; }
+    __device__ __forceinline__ bool adm() const { return (q0.w >> 16) & 1u; }
+    __device__ __forceinline__ uint32_t seq_off() const { return q2.x; }
+    __device__ __forceinline__ uint32_t lq() const { return q2.y; }
+    __device__ __forceinline__ uint32_t cig_off() const { return q2.z; }
+    __device__ __forceinline__ uint32_t qn_off() const { return q2.w; }
+    __device__ __forceinline__ int32_t prev() const { return (int32_t)q3.w; }
+};
+__device__ __forceinline__ RdRegs rd_zero() { RdRegs R; R.q0 = R.q1 = R.q2 = R.q3 = make_uint4(0, 0, 0, 0); return R; }
+__device__ __forceinline__ RdRegs rd_load(const PrepRead *rd, const uint32_t x) { const uint4 *q = (const uint4 *)&rd[x]; RdRegs R; R.q0 = q[0]; R.q1 = q[1]; R.q2 = q[2]; R.q3 = q[3]; return R; }
+
+// what pairing looks at in another read of the name: quad 0 (pos rend ncig|flag strand|nlen|adm), quad 1 (the name's first 16 bytes) and the
+// last word (the start of the read admitted before it) of its PrepRead, taken apart in registers (a PrepRead filled through a pointer would
+// live in scratch)
+struct OtherRead { int32_t rend, prev; uint32_t flag, nlen; uint4 name; };
+__device__ __forceinline__ OtherRead other_read(const PrepRead *rd, const int32_t x) {
+    const uint4 *q = (const uint4 *)&rd[x]; const uint4 q0 = q[0], q1 = q[1]; const uint32_t pv = ((const uint32_t *)q)[15];
+    OtherRead O; O.rend = (int32_t)q0.y; O.flag = q0.z >> 16; O.nlen = (q0.w >> 8) & 255u; O.name = q1; O.prev = (int32_t)pv;
     return O;
 }
-__device__ __forceinline__ bool same_name_as(const PrepParams &P, const PrepRead &x, const OtherRead &y, const int32_t yi) {       // strcmp == 0
-    if(x.nlen != y.nlen || x.name[0] != y.name.x || x.name[1] != y.name.y || x.name[2] != y.name.z || x.name[3] != y.name.w) return false;
-    if(x.nlen <= 16) return true;
-    const uint8_t *p = P.raw + x.qn_off, *q = P.raw + P.rd[yi].qn_off;
-    for(int k = 16; k < x.nlen; k++) if(p[k] != q[k]) return false;
+__device__ __forceinline__ bool same_name(const uint8_t *raw, const uint32_t xnlen, const uint4 xname, const uint32_t xqn_off, const uint32_t ynlen, const uint4 yname, const uint32_t yqn_off) {       // strcmp == 0
+    if(xnlen != ynlen || xname.x != yname.x || xname.y != yname.y || xname.z != yname.z || xname.w != yname.w) return false;
+    if(xnlen <= 16) return true;
+    const uint8_t *p = raw + xqn_off, *q = raw + yqn_off;
+    for(uint32_t k = 16; k < xnlen; k++) if(p[k] != q[k]) return false;
     return true;
 }
-// Returns the read `a` is resolved against (-1: none) and whether `a` is the later of the two (the rule: mdk_pair_rule.h).
-__device__ int32_t pair_of(const PrepParams &P, const uint32_t a, const PrepRead &ra, bool &second) {
-    second = false;
-    if(!mdk_pairs(ra.flag)) return -1;                              // such a read never becomes pending nor pairs (it still occupies the buffer for others)
-    // the name's chain: newest first; nearly always the read and one other
-    const int32_t x1 = (int32_t)(uint32_t)P.hent[ra.slot] - 1;
-    const int32_t x2 = x1 >= 0 ? P.hnext[x1] : -1;
-    if(x2 < 0) return -1;                                           // alone under its name: pending for ever
-    const int32_t x3 = P.hnext[x2];
-    if(x3 < 0) {
-        // two reads f < s, one of them `a`: the rule in closed form (mdk_pair_two)
-        const int32_t f = x1 < x2 ? x1 : x2, sx = x1 < x2 ? x2 : x1, o = (uint32_t)f == a ? sx : f;
-        const OtherRead O = other_read(P, o);
-        const int32_t prev_f = f ? P.rd[f - 1].pos : 0, prev_s = P.rd[sx - 1].pos;
-        if(!same_name_as(P, ra, O, o)) return -1;                   // two names with one hash
-        const bool a_first = (uint32_t)f == a;
-        return mdk_pair_two(P.tid, a, f, sx, a_first ? ra.flag : O.flag, a_first ? ra.rend : O.rend, prev_f,
-                            a_first ? O.flag : ra.flag, a_first ? O.rend : ra.rend, prev_s, second);
+// the start of the read admitted just before read x, when k_prep_scan left that to us: x is the first admitted read of its workgroup
+// there, so the one before it is the nearest admitted record below that workgroup's first
+__device__ __forceinline__ int32_t prev_of(const PrepRead *rd, const int32_t x, const int32_t prev) {
+    if(prev != PREP_PREV_UNKNOWN) return prev;
+    for(int32_t j = (x & ~(PB - 1)) - 1; j >= 0; j--) {
+        const uint4 q0 = *(const uint4 *)&rd[j];
+        if((q0.w >> 16) & 1u) return (int32_t)q0.x;
     }
-    int32_t idx[MAXG]; int k = 0;
-    for(int32_t x = x1; x >= 0; x = P.hnext[x]) { if(k == MAXG) { atomicExch(&P.cnt->fallback, 1u); return -1; } idx[k++] = x; }
-    for(int i = 1; i < k; i++) { const int32_t v = idx[i]; int q = i - 1; while(q >= 0 && idx[q] > v) { idx[q + 1] = idx[q]; q--; } idx[q + 1] = v; }
+    return PREP_PREV_NONE;
+}
+// The reads of a's name, all of them (more than two, or two names with one hash): the chain from its newest read back, taken in file order
+// (the smallest index not done yet, found by walking the chain again: a handful of reads, and no array of them), through the machine step
+// by step.  Returns the read `a` is resolved against, | PAIR_SECOND when `a` is the later of the two; -1: none; -2: the host must prepare
+// this chunk.  A rare path and a real call on purpose -- inlined, its registers would be the kernel's (99 VGPRs instead of 68); it takes
+// what it needs by value, so that nothing of the kernel's arguments has to live in scratch for it.
+#define PAIR_SECOND 0x40000000
+struct PairCtx { const int32_t *hnext, *hfwd; const PrepRead *rd; const uint8_t *raw; int32_t tid; };
+__device__ __attribute__((noinline)) int32_t pair_of_many(const PairCtx X, const uint32_t a, const int32_t a_rend, const int32_t a_prev, const uint32_t a_flag, const uint32_t a_nlen, const uint4 a_name, const uint32_t a_qn_off) {
+    int32_t head = (int32_t)a; int k = 0;
+    for(int guard = 0; X.hfwd[head] >= 0; head = X.hfwd[head]) if(++guard > MAXG) return -2;
+    for(int32_t x = head; x >= 0; x = X.hnext[x]) if(++k > MAXG) return -2;
     MdkPairState S; mdk_pair_init(S);
-    for(int i = 0; i < k; i++) {
-        const int32_t x = idx[i];
-        int32_t rend = ra.rend; uint32_t flag = ra.flag;
-        if((uint32_t)x != a) { const OtherRead O = other_read(P, x); if(!same_name_as(P, ra, O, x)) continue; rend = O.rend; flag = O.flag; }      // (continue: another name with the same hash)
-        mdk_pair_step(S, P.tid, a, x, flag, rend, x == 0 ? 0 : P.rd[x - 1].pos);
-        if(S.overflow) { atomicExch(&P.cnt->fallback, 1u); return -1; }
+    for(int32_t last = -1;;) {
+        int32_t x = 0x7fffffff;
+        for(int32_t y = head; y >= 0; y = X.hnext[y]) if(y > last && y < x) x = y;
+        if(x == 0x7fffffff) break;
+        last = x;
+        int32_t rend = a_rend, prev = a_prev; uint32_t flag = a_flag;
+        if((uint32_t)x != a) { const OtherRead O = other_read(X.rd, x); if(!same_name(X.raw, a_nlen, a_name, a_qn_off, O.nlen, O.name, X.rd[x].qn_off)) continue; rend = O.rend; flag = O.flag; prev = O.prev; }      // (continue: another name with the same hash)
+        prev = prev_of(X.rd, x, prev);
+        mdk_pair_step(S, X.tid, a, x, flag, rend, prev == PREP_PREV_NONE, prev);
+        if(S.overflow) return -2;
     }
-    second = S.second;
-    return S.mate;
+    return S.mate < 0 ? -1 : (S.mate | (S.second ? PAIR_SECOND : 0));
 }
 
 // gapless runs of a CIGAR, one at a time (calculate_positions, overlaps.c:27-52)
 struct RunIt {
     const uint8_t *cig; uint32_t c0, c1, c2; int n, k; int32_t x, y, lq;         // the first three operations travel with the read (PrepRead::cig)
     int32_t rx, ry, rl; bool valid;
-    __device__ void init(const uint8_t *raw, const PrepRead &r) { cig = raw + r.cig_off; c0 = r.cig[0]; c1 = r.cig[1]; c2 = r.cig[2]; n = r.ncig; k = 0; x = r.pos; y = 0; lq = (int32_t)r.lq; valid = false; next(); }
+    __device__ void init(const uint8_t *raw, const RdRegs &r) { cig = raw + r.cig_off(); c0 = r.q3.x; c1 = r.q3.y; c2 = r.q3.z; n = (int)r.ncig(); k = 0; x = r.pos(); y = 0; lq = (int32_t)r.lq(); valid = false; next(); }
     __device__ void next() {
         valid = false;
         while(k < n) {
@@ -516,13 +590,13 @@ struct RunIt {
 
 // lo/hi: reference extent of the pieces written (for the tile runs); untouched when nothing is emitted
 template <bool WRITE>
-__device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const PrepRead &r, const bool has_mate, const PrepRead &m, const bool is_second, md_seg *out, uint32_t base, int64_t &lo, int64_t &hi) {
-    const bool paired = has_mate && (((int)r.strand - (int)m.strand) & 1) == 0;       // overlaps.c:63-65
+__device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const RdRegs &r, const bool has_mate, const RdRegs &m, const bool is_second, md_seg *out, uint32_t base, int32_t &lo, int32_t &hi) {
+    const bool paired = has_mate && (((int)r.strand() - (int)m.strand()) & 1) == 0;       // overlaps.c:63-65
     RunIt own, oth;
     own.init(P.raw, r);
     if(paired) oth.init(P.raw, m); else oth.valid = false;
-    const uint8_t sf = (uint8_t)((r.strand & 7) | ((r.flag & 0x80) ? MDK_SF_READ2 : 0) | (is_second ? MDK_SF_SECOND : 0));
-    const uint8_t msf = paired ? (uint8_t)((m.strand & 7) | ((m.flag & 0x80) ? MDK_SF_READ2 : 0)) : 0;
+    const uint8_t sf = (uint8_t)((r.strand() & 7) | ((r.flag() & 0x80) ? MDK_SF_READ2 : 0) | (is_second ? MDK_SF_SECOND : 0));
+    const uint8_t msf = paired ? (uint8_t)((m.strand() & 7) | ((m.flag() & 0x80) ? MDK_SF_READ2 : 0)) : 0;
     uint32_t n = 0;
     for(; own.valid; own.next()) {
         int32_t cur = own.rx; const int32_t stop = own.rx + own.rl;
@@ -533,9 +607,9 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const Pre
             if(pe - cur > 65535) pe = cur + 65535;
             if((int64_t)pe > P.beg && (int64_t)cur < P.end) {
                 if(WRITE) {
-                    md_seg g; g.rpos = cur; g.off4 = r.seq_off; g.l_qseq = r.lq; g.q0 = (uint32_t)(own.ry + (cur - own.rx)); g.len = (uint16_t)(pe - cur);
+                    md_seg g; g.rpos = cur; g.off4 = r.seq_off(); g.l_qseq = r.lq(); g.q0 = (uint32_t)(own.ry + (cur - own.rx)); g.len = (uint16_t)(pe - cur);
                     g.sf = sf; g.msf = 0; g.m_off4 = 0; g.m_l_qseq = 0; g.m_q0 = 0;
-                    if(covered) { g.sf |= MDK_SF_PARTNER; g.msf = msf; g.m_off4 = m.seq_off; g.m_l_qseq = m.lq; g.m_q0 = (uint32_t)(oth.ry + (cur - oth.rx)); }
+                    if(covered) { g.sf |= MDK_SF_PARTNER; g.msf = msf; g.m_off4 = m.seq_off(); g.m_l_qseq = m.lq(); g.m_q0 = (uint32_t)(oth.ry + (cur - oth.rx)); }
                     const uint32_t o = base + n;
                     if((int64_t)o < P.cap_seg) {
                         out[o] = g;
@@ -556,18 +630,47 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     const PrepParams &P = M.P[chunk_of_block(M)];
     if(threadIdx.x == 0) s_tk = sync_add(&P.ticket[1], 1u);
     __syncthreads();
-    const uint32_t tk = s_tk, n_adm = P.cnt->n_adm;
-    if(tk * PB >= n_adm) return;                          // (a workgroup that leaves here is never waited for: every ticket before an active one is active)
+    const uint32_t tk = s_tk, n_rec = (uint32_t)P.n_rec;
+    if(tk * PB >= n_rec) return;                          // (a workgroup that leaves here is never waited for: every ticket before an active one is active)
     const uint32_t a = tk * PB + threadIdx.x; const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool active = a < n_adm;
-    PrepRead r; memset(&r, 0, sizeof(r)); PrepRead m = r; bool has_mate = false, is_second = false;
+    RdRegs r = rd_zero(), m = rd_zero(); bool has_mate = false, is_second = false;
+    int32_t lnext = -1, lfwd = -1;
+    if(a < n_rec) { r = rd_load(P.rd, a); if(!P.cfg.no_pairing) { lnext = P.hnext[a]; lfwd = P.hfwd[a]; } }      // (hnext of a record that was not admitted is whatever the buffer held: looked at only under adm)
+    const bool active = a < n_rec && r.adm();
     uint32_t n = 0; unsigned long long bytes = 0;
     if(active) {
-        r = P.rd[a];
-        if(!P.cfg.no_pairing) { const int32_t mi = pair_of(P, a, r, is_second); if(mi >= 0) { has_mate = true; m = P.rd[mi]; } }
-        int64_t lo = 0, hi = 0;
+        if(!P.cfg.no_pairing && mdk_pairs(r.flag())) {    // (a read that cannot pair never becomes pending; it still occupies the buffer for the others)
+            const int32_t c = lnext >= 0 ? lnext : lfwd;  // the read that was in the table before this one, else the one that came after
+            if(c >= 0) {
+                // exactly two reads under the name unless the chain goes on at either end: this read has both neighbours, or the other
+                // read has one on its far side
+                const int32_t cn = P.hnext[c], cf = P.hfwd[c];
+                m = rd_load(P.rd, (uint32_t)c);
+                // (a read whose predecessor k_prep_scan left to be looked up -- the first admitted read of a workgroup there -- takes the long way too)
+                const bool more = (lnext >= 0 ? (lfwd >= 0 || cn >= 0) : cf >= 0) || r.prev() == PREP_PREV_UNKNOWN || m.prev() == PREP_PREV_UNKNOWN;
+                int32_t mi = -1;
+                if(!more) {
+                    if(same_name(P.raw, r.nlen(), r.q1, r.qn_off(), m.nlen(), m.q1, m.qn_off())) {       // (else: two names with one hash, each alone)
+                        // two reads f < s, one of them this one: the rule in closed form (mdk_pair_two)
+                        const bool a_first = a < (uint32_t)c;
+                        const int32_t f = a_first ? (int32_t)a : c, sx = a_first ? c : (int32_t)a;
+                        const int32_t prev_f = a_first ? r.prev() : m.prev(), prev_s = a_first ? m.prev() : r.prev();
+                        mi = mdk_pair_two(P.tid, a, f, sx, a_first ? r.flag() : m.flag(), a_first ? r.rend() : m.rend(), prev_f == PREP_PREV_NONE, prev_f,
+                                          a_first ? m.flag() : r.flag(), a_first ? m.rend() : r.rend(), prev_s, is_second);
+                    }
+                } else {
+                    PairCtx X; X.hnext = P.hnext; X.hfwd = P.hfwd; X.rd = P.rd; X.raw = P.raw; X.tid = P.tid;
+                    mi = pair_of_many(X, a, r.rend(), r.prev(), r.flag(), r.nlen(), r.q1, r.qn_off());
+                    if(mi == -2) { atomicExch(&P.cnt->fallback, 1u); mi = -1; }
+                    r = rd_load(P.rd, a);                   // (read again rather than kept in registers across the call: a call leaves the caller a few registers only)
+                    if(mi >= 0) { is_second = (mi & PAIR_SECOND) != 0; mi &= ~PAIR_SECOND; m = rd_load(P.rd, (uint32_t)mi); }
+                }
+                has_mate = mi >= 0;
+            }
+        }
+        int32_t lo = 0, hi = 0;
         n = read_segments<false>(P, r, has_mate, m, is_second, nullptr, 0, lo, hi);
-        bytes = 16ull + 4ull * r.ncig + ((unsigned long long)r.lq + 1) / 2 + r.lq;        // SURVEY.md 8d, per admitted read
+        bytes = 16ull + 4ull * r.ncig() + ((unsigned long long)r.lq() + 1) / 2 + r.lq();        // SURVEY.md 8d, per admitted read
     }
     // where this read's segments go: scan inside the workgroup, plus what the earlier tickets counted
     uint32_t incl = n;
@@ -584,8 +687,8 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
       if(lane == 0 && b) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, b); }
     const uint32_t before = tickets_before(P.cntS, tk, red);
     base += before;
-    if((tk + 1) * PB >= n_adm && threadIdx.x == 0) P.cnt->n_segs = before + total;
-    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    if((tk + 1) * PB >= n_rec && threadIdx.x == 0) P.cnt->n_segs = before + total;
+    int32_t lo = INT32_MAX, hi = INT32_MIN;             // (reference positions are 32 bits: BAM's pos)
     if(n) (void)read_segments<true>(P, r, has_mate, m, is_second, P.seg, base, lo, hi);
     // Tile runs: tile t's run [first, last) must cover every segment touching t.  A lane contributes [base, base + n) to every
     // tile its pieces reach -- a superset, which is all k_pileup needs.  Reads are in coordinate order, so the lanes of a wave
@@ -593,9 +696,8 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     // instead of two contended atomics per segment (275 us -> a few us per 1 Mb chunk).
     int t0 = 0x7fffffff, t1 = -1;
     if(n && hi > lo && (int64_t)base < P.cap_seg) {
-        if(lo < P.beg) lo = P.beg;
-        if(hi > P.end) hi = P.end;
-        t0 = (int)((lo - P.beg) / P.tile); t1 = (int)((hi - 1 - P.beg) / P.tile);
+        const int64_t l = lo < P.beg ? P.beg : (int64_t)lo, u = hi > P.end ? P.end : (int64_t)hi;
+        t0 = (int)((uint32_t)(l - P.beg) / (uint32_t)P.tile); t1 = (int)((uint32_t)(u - 1 - P.beg) / (uint32_t)P.tile);       // (a chunk spans less than 2^31 positions)
     }
     const int p0 = __shfl_up(t0, 1), p1 = __shfl_up(t1, 1), n0 = __shfl_down(t0, 1), n1 = __shfl_down(t1, 1);
     uint32_t top = base + n; if((int64_t)top > P.cap_seg) top = (uint32_t)P.cap_seg;
@@ -609,9 +711,10 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
 __global__ __launch_bounds__(PB) void k_perread_raw(const PrepParams P, const uint8_t *ctxcode, int64_t wend, md_pr_count *out) {
     const uint32_t a = blockIdx.x * PB + threadIdx.x;
     if(a >= P.cnt->n_adm) return;
-    const PrepRead r = P.rd[a];
-    const uint8_t *seq = P.raw + r.seq_off, *qual = seq + ((r.lq + 1) >> 1), *cg = P.raw + r.cig_off;
-    out[a] = perread_walk(seq, qual, r.lq, (int)r.ncig, r.pos, r.strand & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg, &r](int k) { return k < 3 ? r.cig[k] : ld32(cg + 4 * k); });
+    const RdRegs r = rd_load(P.rd, a);
+    const uint8_t *seq = P.raw + r.seq_off(), *qual = seq + ((r.lq() + 1) >> 1), *cg = P.raw + r.cig_off();
+    const uint32_t c0 = r.q3.x, c1 = r.q3.y, c2 = r.q3.z;
+    out[a] = perread_walk(seq, qual, r.lq(), (int)r.ncig(), r.pos(), r.strand() & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg, c0, c1, c2](int k) { return k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : ld32(cg + 4 * k); });
 }
 
 // record offsets of a device-resident range (offsets in the piece it was inflated in) -> offsets in the chunk's concatenation
@@ -690,7 +793,8 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
 static_assert(PREP_SCAN_LDS >= 4 * PB * sizeof(uint4), "the PrepRead stage lives in the windows' memory");
 MDK_HIDDEN int prep_kernels_init() {        // more dynamic LDS than the default window: once per process
     static std::once_flag once; static int rc = 1;
-    std::call_once(once, [] { rc = hipFuncSetAttribute((const void *)k_prep_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess ? 0 : 1; });
+    std::call_once(once, [] { rc = (hipFuncSetAttribute((const void *)k_prep_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess &&
+                                    hipFuncSetAttribute((const void *)k_prep_scan_ordered, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess) ? 0 : 1; });
     return rc;
 }
 static uint32_t pow2_at_least(size_t n) { uint32_t p = 1024; while(p < n) p <<= 1; return p; }
@@ -705,7 +809,9 @@ static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
     P.ref = h->ref[s->tid]; P.reflen = h->reflen[s->tid];
     if(h->prep.map_on && (size_t)s->tid < h->mapbits.size()) { P.mapbits = h->mapbits[s->tid]; P.maplen = h->maplen[s->tid]; }
     P.bed_on = (size_t)s->tid < h->d_runs.size() && h->has_runs[s->tid]; if(P.bed_on) { P.runs = h->d_runs[s->tid]; P.nruns = h->n_runs[s->tid]; }
-    P.rd = s->d_prd.p; P.aidx = h->prep.perread ? s->d_aidx.p : nullptr; P.hnext = s->d_hnext.p; P.hmask = s->hmask;
+    P.rd = s->d_prd.p; P.aidx = h->prep.perread ? s->d_aidx.p : nullptr; P.hmask = s->hmask;
+    const bool links = !h->prep.perread && !h->prep.no_pairing;      // the reads of a name linked both ways: hnext[n_rec], hfwd[n_rec] (16-byte aligned: k_prep_zero fills it with -1)
+    P.hnext = links ? s->d_hnext.p : nullptr; P.hfwd = links ? s->d_hnext.p + (((size_t)n + 4) & ~(size_t)3) : nullptr;
     uint8_t *z = s->d_zero.p;
     P.hent = (unsigned long long *)z; P.cntA = (uint32_t *)(z + H * 8); P.cntS = P.cntA + (nb > 0 ? nb : 1); P.ticket = P.cntS + (nb > 0 ? nb : 1);
     P.nblocks = nb; P.zero = z; P.zero_bytes = zero_bytes_for(s->hmask, nb);
@@ -728,16 +834,14 @@ int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_prep_zero, dim3(zgrid), dim3(PB), 0, st, M);
     if(total > 0) {
         int grid = total;
-#if PREP_XCD
         {   // chunk j is served by the workgroups b with (b mod 8) mod n == j (chunk_of_block): enough of them for its nblocks tickets
             int per8 = 1;
             for(int j = 0; j < n; j++) { int xcds = 0; for(int x = 0; x < 8; x++) if(x % n == j) xcds++; if(xcds) per8 = std::max(per8, (M.P[j].nblocks + xcds - 1) / xcds); else per8 = std::max(per8, M.P[j].nblocks); }
             grid = 8 * per8;
         }
         static_assert(MAXM <= 8, "chunk_of_block deals the chunks of a launch to 8 XCDs");
-#endif
-        hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
-        if(!h->prep.perread) hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M);
+        if(h->prep.perread) hipLaunchKernelGGL(k_prep_scan_ordered, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
+        else { hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M); hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M); }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -774,7 +878,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     static std::atomic<int> first_call{1}; const bool first = mdk_prof_on() && first_call.exchange(0); const double tf0 = first ? mdk_now() : 0; double tf1 = 0;
     {
         ProfScope pf(PF_UP_ALLOC);
-        if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+        if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
            s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
         if(!s->b_site) {
             if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
@@ -828,7 +932,7 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     if(total >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: more than 4 GiB of records in one chunk", hipSuccess);
     const int n = b->n_records, nb = (n + PB - 1) / PB; const size_t nn = (size_t)n + 1;
     s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->hmask = 1023; s->ntiles = 0; s->tile = h->tile;
-    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(nn) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
        s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
     { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
     { int rc = enqueue_prep(h, s); if(rc) return rc; }                 // perread mode: selection + file-order compaction only (k_prep_scan)

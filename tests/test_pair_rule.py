@@ -49,11 +49,11 @@ int main() {
                 std::vector<int> idx; for(int i = 0; i < n; i++) if(R[i].name == R[a].name) idx.push_back(i);
                 if(idx.size() > MDK_MAXLIVE) continue;                 // (the kernel hands such a chunk to the host)
                 MdkPairState S; mdk_pair_init(S);
-                for(int x : idx) mdk_pair_step(S, contig, (uint32_t)a, x, R[x].flag, R[x].rend, x ? R[x - 1].pos : 0);
+                for(int x : idx) mdk_pair_step(S, contig, (uint32_t)a, x, R[x].flag, R[x].rend, x == 0, x ? R[x - 1].pos : 0);
                 got = S.mate; sec = S.second;
                 if(idx.size() == 2) {
                     bool s2 = false; const int f = idx[0], s = idx[1];
-                    const int g2 = mdk_pair_two(contig, (uint32_t)a, f, s, R[f].flag, R[f].rend, f ? R[f - 1].pos : 0, R[s].flag, R[s].rend, R[s - 1].pos, s2);
+                    const int g2 = mdk_pair_two(contig, (uint32_t)a, f, s, R[f].flag, R[f].rend, f == 0, f ? R[f - 1].pos : 0, R[s].flag, R[s].rend, R[s - 1].pos, s2);
                     twos++;
                     if(g2 != got || (got >= 0 && s2 != sec)) bad++;
                 }
