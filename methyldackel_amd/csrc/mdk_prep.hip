@@ -240,13 +240,20 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *red) {
     __syncthreads();
     return t;
 }
-// what the workgroups holding earlier tickets counted, added up (they are running: a ticket is drawn by a workgroup that has started)
+// what the workgroups holding earlier tickets counted, added up (they are running: a ticket is drawn by a workgroup that has started).
+// Every thread asks for four of the counts at once -- a thousand tickets in one round trip -- and only then waits for the ones not yet published.
 __device__ __forceinline__ uint32_t tickets_before(uint32_t *cnt, uint32_t tk, uint32_t *red) {
     uint32_t part = 0;
-    for(uint32_t q = threadIdx.x; q < tk; q += PB) {
-        uint32_t v;
-        while(!((v = sync_peek(&cnt[q])) & CNT_READY)) __builtin_amdgcn_s_sleep(1);
-        part += v & ~CNT_READY;
+    for(uint32_t q0 = threadIdx.x; q0 < tk; q0 += 4 * PB) {
+        uint32_t v[4];
+#pragma unroll
+        for(int u = 0; u < 4; u++) { const uint32_t q = q0 + (uint32_t)u * PB; v[u] = q < tk ? sync_peek(&cnt[q]) : CNT_READY; }
+#pragma unroll
+        for(int u = 0; u < 4; u++) {
+            const uint32_t q = q0 + (uint32_t)u * PB;
+            while(!(v[u] & CNT_READY)) { __builtin_amdgcn_s_sleep(1); v[u] = sync_peek(&cnt[q]); }
+            part += v[u] & ~CNT_READY;
+        }
     }
     return block_sum(part, red);
 }
@@ -350,15 +357,24 @@ __device__ __forceinline__ int scan_record(const PrepParams &P, const V &v, cons
 #define RAWWIN 18944
 #endif
 #define RAWWIN_LDS (RAWWIN + 32)                      // (+ slack for the word reads of a field that ends at the window's end)
+// Where the lane's record starts and where the next one does: two coalesced loads, issued together, before anything depends on them -- the
+// window's bounds are then lane 0's start and lane 63's end, and the lane needs no further load before it can take its record apart.
+struct RecAt { uint32_t o, onext; };
+__device__ __forceinline__ RecAt rec_at(const PrepParams &P, const int i) {
+    RecAt A; A.o = 0; A.onext = 0;
+    if(i < P.n_rec) { A.o = P.rec_off[i]; A.onext = i + 1 < P.n_rec ? P.rec_off[i + 1] : (uint32_t)P.raw_bytes; }
+    return A;
+}
 // the wavefront's stretch of the record stream -> LDS, 1 KiB per instruction, straight from HBM (global_load_lds: no registers in between)
-__device__ __forceinline__ void stage_window(const PrepParams &P, const int i0, const int lane, uint8_t *const win, uint32_t &wbase, uint32_t &wlen) {
+__device__ __forceinline__ void stage_window(const PrepParams &P, const int i0, const RecAt &A, const int lane, uint8_t *const win, uint32_t &wbase, uint32_t &wlen) {
     wbase = 0; wlen = 0;
 #if PREP_STAGE
+    const uint32_t first = (uint32_t)__shfl((int)A.o, 0), last = (uint32_t)__shfl((int)A.onext, 63);       // (every lane takes part)
     if(i0 < P.n_rec) {
-        const uint64_t b0 = P.rec_off[i0], b1 = i0 + 64 < P.n_rec ? (uint64_t)P.rec_off[i0 + 64] : P.raw_bytes;
+        const uint64_t b0 = first, b1 = i0 + 64 <= P.n_rec ? (uint64_t)last : P.raw_bytes;
         wbase = (uint32_t)(b0 & ~15ull);
-        uint64_t l = ((b1 - wbase) + 15) & ~15ull; if(l > RAWWIN) l = RAWWIN;
-        if((uint64_t)wbase + l > ((P.raw_bytes + 15) & ~15ull)) l = ((P.raw_bytes + 15) & ~15ull) - wbase;       // (the buffer is 64 bytes longer than the records)
+        uint64_t l = b1 > wbase ? ((b1 - wbase) + 15) & ~15ull : 0; if(l > RAWWIN) l = RAWWIN;
+        if((uint64_t)wbase + l > ((P.raw_bytes + 15) & ~15ull)) l = (uint64_t)wbase < ((P.raw_bytes + 15) & ~15ull) ? ((P.raw_bytes + 15) & ~15ull) - wbase : 0;       // (the buffer is 64 bytes longer than the records)
         wlen = (uint32_t)l;
         const uint8_t *src = P.raw + wbase + 16 * lane;
         for(uint32_t k = 0; k < wlen; k += 1024) if(k + 16 * lane < wlen) __builtin_amdgcn_global_load_lds((const void *)(src + k), (__attribute__((address_space(3))) void *)(win + k), 16, 0, 0);
@@ -368,10 +384,10 @@ __device__ __forceinline__ void stage_window(const PrepParams &P, const int i0, 
 #endif
 }
 // record i through the window if it lies inside whole, from HBM otherwise
-__device__ __forceinline__ int scan_one(const PrepParams &P, const int i, const uint8_t *const win, const uint32_t wbase, const uint32_t wlen, PrepRead &D, uint64_t &h) {
+__device__ __forceinline__ int scan_one(const PrepParams &P, const int i, const RecAt &A, const uint8_t *const win, const uint32_t wbase, const uint32_t wlen, PrepRead &D, uint64_t &h) {
     int adm = 0;
     if(i < P.n_rec) {
-        const uint64_t o = P.rec_off[i];
+        const uint64_t o = A.o;
         bool ok = o + 4 + 32 <= P.raw_bytes;
         if(ok) {
             uint32_t bs = 0;
@@ -405,8 +421,9 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
     uint32_t wbase, wlen;
     uint8_t *const win = (uint8_t *)dyn + (size_t)wave * RAWWIN_LDS;
-    stage_window(P, (int)(tk * PB) + 64 * wave, lane, win, wbase, wlen);
-    const int adm = scan_one(P, i, win, wbase, wlen, D, h);
+    const RecAt at = rec_at(P, i);
+    stage_window(P, (int)(tk * PB) + 64 * wave, at, lane, win, wbase, wlen);
+    const int adm = scan_one(P, i, at, win, wbase, wlen, D, h);
     // the start of the read admitted just before this one: the nearest admitted lane below in the wavefront, else the last admitted read of
     // the nearest wavefront below in the workgroup, else (not the chunk's first workgroup) left to k_prep_segs
     const unsigned long long m = __ballot(adm), below = m & ((1ull << lane) - 1ull);
@@ -472,8 +489,9 @@ __global__ __launch_bounds__(PB) void k_prep_scan_ordered(const PrepMulti M) {
     PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
     uint32_t wbase, wlen;
     uint8_t *const win = (uint8_t *)dyn + (size_t)wave * RAWWIN_LDS;
-    stage_window(P, (int)(tk * PB) + 64 * wave, lane, win, wbase, wlen);
-    const int adm = scan_one(P, i, win, wbase, wlen, D, h);
+    const RecAt at = rec_at(P, i);
+    stage_window(P, (int)(tk * PB) + 64 * wave, at, lane, win, wbase, wlen);
+    const int adm = scan_one(P, i, at, win, wbase, wlen, D, h);
     const unsigned long long m = __ballot(adm);
     if(lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
@@ -544,11 +562,11 @@ __device__ __forceinline__ int32_t prev_of(const PrepRead *rd, const int32_t x, 
 // The reads of a's name, all of them (more than two, or two names with one hash): the chain from its newest read back, taken in file order
 // (the smallest index not done yet, found by walking the chain again: a handful of reads, and no array of them), through the machine step
 // by step.  Returns the read `a` is resolved against, | PAIR_SECOND when `a` is the later of the two; -1: none; -2: the host must prepare
-// this chunk.  A rare path and a real call on purpose -- inlined, its registers would be the kernel's (99 VGPRs instead of 68); it takes
-// what it needs by value, so that nothing of the kernel's arguments has to live in scratch for it.
+// this chunk.  (As a real call it cost the kernel 52 bytes of scratch per lane -- and every launch ~30 us at each kernel boundary while the
+// runtime found room for it, profiles/r05c_prep_variants.txt; inlined, its state lives in LDS and the kernel needs 57 VGPRs.)
 #define PAIR_SECOND 0x40000000
 struct PairCtx { const int32_t *hnext, *hfwd; const PrepRead *rd; const uint8_t *raw; int32_t tid; };
-__device__ __attribute__((noinline)) int32_t pair_of_many(const PairCtx X, const uint32_t a, const int32_t a_rend, const int32_t a_prev, const uint32_t a_flag, const uint32_t a_nlen, const uint4 a_name, const uint32_t a_qn_off) {
+__device__ __forceinline__ int32_t pair_of_many(const PairCtx X, const uint32_t a, const int32_t a_rend, const int32_t a_prev, const uint32_t a_flag, const uint32_t a_nlen, const uint4 a_name, const uint32_t a_qn_off) {
     int32_t head = (int32_t)a; int k = 0;
     for(int guard = 0; X.hfwd[head] >= 0; head = X.hfwd[head]) if(++guard > MAXG) return -2;
     for(int32_t x = head; x >= 0; x = X.hnext[x]) if(++k > MAXG) return -2;
@@ -625,7 +643,14 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const RdR
     return n;
 }
 
+#ifndef SEGS_SGPRS
+#define SEGS_SGPRS 0                  // > 0: cap the kernel's scalar registers (104 of them cost the eighth wavefront per SIMD; the excess spills into lanes of a VGPR)
+#endif
+#if SEGS_SGPRS
+__global__ __launch_bounds__(PB) __attribute__((amdgpu_num_sgpr(SEGS_SGPRS))) void k_prep_segs(const PrepMulti M) {
+#else
 __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
+#endif
     __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64];
     const PrepParams &P = M.P[chunk_of_block(M)];
     if(threadIdx.x == 0) s_tk = sync_add(&P.ticket[1], 1u);
@@ -662,7 +687,6 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
                     PairCtx X; X.hnext = P.hnext; X.hfwd = P.hfwd; X.rd = P.rd; X.raw = P.raw; X.tid = P.tid;
                     mi = pair_of_many(X, a, r.rend(), r.prev(), r.flag(), r.nlen(), r.q1, r.qn_off());
                     if(mi == -2) { atomicExch(&P.cnt->fallback, 1u); mi = -1; }
-                    r = rd_load(P.rd, a);                   // (read again rather than kept in registers across the call: a call leaves the caller a few registers only)
                     if(mi >= 0) { is_second = (mi & PAIR_SECOND) != 0; mi &= ~PAIR_SECOND; m = rd_load(P.rd, (uint32_t)mi); }
                 }
                 has_mate = mi >= 0;
