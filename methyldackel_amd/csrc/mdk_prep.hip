@@ -67,6 +67,9 @@ struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 // (2 MB) and ticket counters stay in its L2 instead of every L2 thrashing over all eight.  WHICH records of the chunk a workgroup
 // takes is decided by the ticket it draws, not by its index; the launch holds at least as many workgroups per chunk as the chunk has
 // tickets (enqueue_prep_group), and a workgroup that draws a ticket beyond them leaves.
+#ifndef PREP_EXP_NOCAS
+#define PREP_EXP_NOCAS 0
+#endif
 #ifndef PREP_STAGE
 #define PREP_STAGE 1                  // k_prep_scan stages the record stream in LDS (0: every lane reads its record from HBM, round 3's arrangement)
 #endif
@@ -406,6 +409,9 @@ __device__ __forceinline__ void stage_read(uint4 *st, const PrepRead &D, const i
     st[3] = make_uint4(D.cig[0], D.cig[1], D.cig[2], (uint32_t)D.prev);
 }
 
+// barrier that orders LDS traffic only (does not drain this wavefront's outstanding global loads, stores and atomics)
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // extract / mbias: every record's PrepRead at the record's own index; no workgroup waits for another.
 // Workgroup b works for chunk (b mod 8) mod n (chunk_of_block) and is the tk-th of the workgroups that do: tk follows from b alone.
 __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
@@ -435,7 +441,20 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
         for(int d = 32; d; d >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t > v ? t : v; }
         if(lane == 0 && v) atomicMax(&P.cnt->max_lq, v);
     }
-    __syncthreads();                                      // (every wavefront has parsed its records: the windows' memory is free for the stage)
+    // name table: open addressing; an entry is (high half of the name's hash, the name's latest read).  One 8-byte word per name, so an
+    // insertion touches one line of a 2 MB table: the first read of a name takes an empty entry with one compare-and-swap, a later one
+    // replaces the head with a second -- and learns who was there: the two are linked both ways.  The first compare-and-swap is on its way
+    // from here; its answer is looked at only after the PrepReads have left (the barriers below order LDS traffic only).
+    const bool ins = adm && !P.cfg.no_pairing;
+    const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i + 1u);
+    uint32_t sl = (uint32_t)h & P.hmask;
+    unsigned long long old = 0ull;
+#if PREP_EXP_NOCAS                                        // TIMING EXPERIMENT ONLY (wrong results): a plain store where the compare-and-swap is
+    if(ins) P.hent[sl] = mine;
+#else
+    if(ins) old = sync_cas(&P.hent[sl], 0ull, mine);
+#endif
+    lds_only_barrier();                                   // (every wavefront has parsed its records: the windows' memory is free for the stage)
     if(adm) {
         int32_t pv = pv_wave;
         if(!below) {
@@ -443,35 +462,36 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
             for(int w = wave - 1; w >= 0; w--) if(wcnt[w]) { pv = wlast[w]; break; }
         }
         D.prev = pv;
-        if(!P.cfg.no_pairing) {
-            // name table: open addressing; an entry is (high half of the name's hash, the name's latest read).  One 8-byte word per name, so an
-            // insertion touches one line of a 2 MB table: the first read of a name takes an empty entry with one compare-and-swap, a later one
-            // replaces the head with a second -- and learns who was there: the two are linked both ways
-            const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i + 1u);
-            uint32_t sl = (uint32_t)h & P.hmask; int32_t before = -1;
-            for(;;) {
-                unsigned long long old = sync_cas(&P.hent[sl], 0ull, mine);
-                if(old == 0ull) break;
-                if((old >> 32) == (key >> 32)) {
-                    for(;;) { const unsigned long long seen = sync_cas(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
-                    before = (int32_t)(uint32_t)old - 1;
-                    break;
-                }
-                sl = (sl + 1) & P.hmask;
-            }
-            P.hnext[i] = before;
-            if(before >= 0) P.hfwd[before] = i;
-        }
     }
-    if(threadIdx.x == 0) { uint32_t t = 0; for(int w = 0; w < PB / 64; w++) t += wcnt[w]; if(t) atomicAdd(&P.cnt->n_adm, t); }
+    if(threadIdx.x == 0) {
+        uint32_t t = 0; int32_t lastpos = PREP_PREV_NONE;
+        for(int w = 0; w < PB / 64; w++) { t += wcnt[w]; if(wcnt[w]) lastpos = wlast[w]; }
+        if(t) atomicAdd(&P.cnt->n_adm, t);
+        P.cntA[tk] = (uint32_t)lastpos;                    // the start of this workgroup's last admitted read: what the first one of the next workgroup was admitted after (k_prep_segs block_prev)
+    }
     // the PrepReads go to the workgroup's stage in LDS first and from there to rd[] as whole lines: written straight from the lanes, the four
     // quads would leave in four store instructions of 16 bytes per 64 -- partial lines, which the memory side does not merge
     stage_read(stage + 4 * threadIdx.x, D, adm);
-    __syncthreads();
+    lds_only_barrier();
     {
         const int first = (int)(tk * PB), cnt = P.n_rec - first < PB ? P.n_rec - first : PB;
         uint4 *out = (uint4 *)(P.rd + first);
         for(int q = threadIdx.x; q < 4 * cnt; q += PB) out[q] = stage[q];
+    }
+    if(ins) {
+        int32_t before = -1;
+        for(;;) {
+            if(old == 0ull) break;
+            if((old >> 32) == (key >> 32)) {
+                for(;;) { const unsigned long long seen = sync_cas(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
+                before = (int32_t)(uint32_t)old - 1;
+                break;
+            }
+            sl = (sl + 1) & P.hmask;
+            old = sync_cas(&P.hent[sl], 0ull, mine);
+        }
+        P.hnext[i] = before;
+        if(before >= 0) P.hfwd[before] = i;
     }
 }
 
@@ -549,8 +569,15 @@ __device__ __forceinline__ bool same_name(const uint8_t *raw, const uint32_t xnl
     for(uint32_t k = 16; k < xnlen; k++) if(p[k] != q[k]) return false;
     return true;
 }
-// the start of the read admitted just before read x, when k_prep_scan left that to us: x is the first admitted read of its workgroup
-// there, so the one before it is the nearest admitted record below that workgroup's first
+// The start of the read admitted just before the first admitted read of block `blk` (the records one workgroup of k_prep_scan took): the
+// last admitted start of the nearest block below that admitted anything.  v = last[blk - 1], asked for ahead of time by the caller.
+__device__ __forceinline__ int32_t block_prev(const uint32_t *last, int32_t blk, int32_t v) {
+    if(blk <= 0) return PREP_PREV_NONE;
+    while(v == PREP_PREV_NONE && --blk > 0) v = (int32_t)last[blk - 1];
+    return v;
+}
+// the same by walking the records (the rare path's way): x is the first admitted read of its block, so the one before it is the nearest
+// admitted record below that block's first
 __device__ __forceinline__ int32_t prev_of(const PrepRead *rd, const int32_t x, const int32_t prev) {
     if(prev != PREP_PREV_UNKNOWN) return prev;
     for(int32_t j = (x & ~(PB - 1)) - 1; j >= 0; j--) {
@@ -644,7 +671,7 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const RdR
 }
 
 #ifndef SEGS_SGPRS
-#define SEGS_SGPRS 0                  // > 0: cap the kernel's scalar registers (104 of them cost the eighth wavefront per SIMD; the excess spills into lanes of a VGPR)
+#define SEGS_SGPRS 96                 // cap on the kernel's scalar registers: 104 of them cost the eighth wavefront per SIMD; the excess spills into lanes of a VGPR (measured: 172.6 -> 162.6 us per launch, profiles/r05d_prep_variants.txt).  0: no cap
 #endif
 #if SEGS_SGPRS
 __global__ __launch_bounds__(PB) __attribute__((amdgpu_num_sgpr(SEGS_SGPRS))) void k_prep_segs(const PrepMulti M) {
@@ -660,6 +687,7 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     const uint32_t a = tk * PB + threadIdx.x; const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     RdRegs r = rd_zero(), m = rd_zero(); bool has_mate = false, is_second = false;
     int32_t lnext = -1, lfwd = -1;
+    const int32_t mylast = tk > 0 ? (int32_t)P.cntA[tk - 1] : PREP_PREV_NONE;      // (one scalar load, on its way with the rest)
     if(a < n_rec) { r = rd_load(P.rd, a); if(!P.cfg.no_pairing) { lnext = P.hnext[a]; lfwd = P.hfwd[a]; } }      // (hnext of a record that was not admitted is whatever the buffer held: looked at only under adm)
     const bool active = a < n_rec && r.adm();
     uint32_t n = 0; unsigned long long bytes = 0;
@@ -671,15 +699,17 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
                 // read has one on its far side
                 const int32_t cn = P.hnext[c], cf = P.hfwd[c];
                 m = rd_load(P.rd, (uint32_t)c);
-                // (a read whose predecessor k_prep_scan left to be looked up -- the first admitted read of a workgroup there -- takes the long way too)
-                const bool more = (lnext >= 0 ? (lfwd >= 0 || cn >= 0) : cf >= 0) || r.prev() == PREP_PREV_UNKNOWN || m.prev() == PREP_PREV_UNKNOWN;
+                const int32_t cblk = c / PB, clast = cblk > 0 ? (int32_t)P.cntA[cblk - 1] : PREP_PREV_NONE;      // (asked for with the rest, used if c turns out to be its block's first admitted read)
+                const bool more = lnext >= 0 ? (lfwd >= 0 || cn >= 0) : cf >= 0;
+                const int32_t rprev = r.prev() == PREP_PREV_UNKNOWN ? block_prev(P.cntA, (int32_t)tk, mylast) : r.prev();
+                const int32_t mprev = m.prev() == PREP_PREV_UNKNOWN ? block_prev(P.cntA, cblk, clast) : m.prev();
                 int32_t mi = -1;
                 if(!more) {
                     if(same_name(P.raw, r.nlen(), r.q1, r.qn_off(), m.nlen(), m.q1, m.qn_off())) {       // (else: two names with one hash, each alone)
                         // two reads f < s, one of them this one: the rule in closed form (mdk_pair_two)
                         const bool a_first = a < (uint32_t)c;
                         const int32_t f = a_first ? (int32_t)a : c, sx = a_first ? c : (int32_t)a;
-                        const int32_t prev_f = a_first ? r.prev() : m.prev(), prev_s = a_first ? m.prev() : r.prev();
+                        const int32_t prev_f = a_first ? rprev : mprev, prev_s = a_first ? mprev : rprev;
                         mi = mdk_pair_two(P.tid, a, f, sx, a_first ? r.flag() : m.flag(), a_first ? r.rend() : m.rend(), prev_f == PREP_PREV_NONE, prev_f,
                                           a_first ? m.flag() : r.flag(), a_first ? m.rend() : r.rend(), prev_s, is_second);
                     }
