@@ -70,6 +70,12 @@ struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 #ifndef PREP_EXP_NOCAS
 #define PREP_EXP_NOCAS 0
 #endif
+#ifndef PREP_EXP_SEGS
+#define PREP_EXP_SEGS 0               // TIMING EXPERIMENTS ONLY (wrong results), bits: 1 no tile-run atomics, 2 no write pass, 4 no wait for the earlier tickets, 8 the ticket from blockIdx, 16 no byte tally
+#endif
+#ifndef PREP_LOCAL
+#define PREP_LOCAL 1                  // k_prep_scan pairs the reads of a workgroup among themselves in LDS before the chunk's table is asked (0: every read asks the table)
+#endif
 #ifndef PREP_STAGE
 #define PREP_STAGE 1                  // k_prep_scan stages the record stream in LDS (0: every lane reads its record from HBM, round 3's arrangement)
 #endif
@@ -441,20 +447,16 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
         for(int d = 32; d; d >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t > v ? t : v; }
         if(lane == 0 && v) atomicMax(&P.cnt->max_lq, v);
     }
-    // name table: open addressing; an entry is (high half of the name's hash, the name's latest read).  One 8-byte word per name, so an
+    // Name table: open addressing; an entry is (high half of the name's hash, the name's latest read).  One 8-byte word per name, so an
     // insertion touches one line of a 2 MB table: the first read of a name takes an empty entry with one compare-and-swap, a later one
-    // replaces the head with a second -- and learns who was there: the two are linked both ways.  The first compare-and-swap is on its way
-    // from here; its answer is looked at only after the PrepReads have left (the barriers below order LDS traffic only).
+    // replaces the head with a second -- and learns who was there: the two are linked both ways (hnext, hfwd).
+    // A device-scope atomic is 64 bytes of memory traffic and a round trip beyond the L2 (the scan without them: 132 us per launch instead
+    // of 187, profiles/r05e_prep_variants.txt), and a read's mate is nearly always a few dozen records away -- in this very workgroup.  So
+    // the workgroup first groups its own reads by name hash in LDS (a small table, LDS atomics) and links each group among itself; ONE
+    // lane per group then inserts the whole group into the chunk's table as if its reads had arrived one after the other: 0.65 atomics
+    // per read instead of 1.5.
     const bool ins = adm && !P.cfg.no_pairing;
-    const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i + 1u);
-    uint32_t sl = (uint32_t)h & P.hmask;
-    unsigned long long old = 0ull;
-#if PREP_EXP_NOCAS                                        // TIMING EXPERIMENT ONLY (wrong results): a plain store where the compare-and-swap is
-    if(ins) P.hent[sl] = mine;
-#else
-    if(ins) old = sync_cas(&P.hent[sl], 0ull, mine);
-#endif
-    lds_only_barrier();                                   // (every wavefront has parsed its records: the windows' memory is free for the stage)
+    lds_only_barrier();                                   // (every wavefront has parsed its records: the windows' memory is free)
     if(adm) {
         int32_t pv = pv_wave;
         if(!below) {
@@ -469,16 +471,54 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
         if(t) atomicAdd(&P.cnt->n_adm, t);
         P.cntA[tk] = (uint32_t)lastpos;                    // the start of this workgroup's last admitted read: what the first one of the next workgroup was admitted after (k_prep_segs block_prev)
     }
+    const int i0 = (int)(tk * PB);
+    int32_t lprev = -2;                                   // the read of this workgroup linked in front of this one; -1: none, this lane inserts the group; -2: does not take part
+    uint32_t ghead = threadIdx.x;                         // the group's last read (what the chunk's table will name)
+#if PREP_LOCAL
+    {
+        // (behind the PrepRead stage in the windows' memory) lh: every lane's hash; lt: open addressing, 2 PB entries of lane + 1; lhead: per
+        // group -- filed under the lane that took the entry -- the lane that joined last
+        unsigned long long *const lh = (unsigned long long *)(stage + 4 * PB); uint32_t *const lt = (uint32_t *)(lh + PB), *const lhead = lt + 2 * PB;
+        lh[threadIdx.x] = ins ? h : 0ull; lt[threadIdx.x] = 0u; lt[threadIdx.x + PB] = 0u; lhead[threadIdx.x] = 0xffffffffu;
+        lds_only_barrier();
+        uint32_t rep = threadIdx.x;
+        if(ins) {
+            uint32_t e = (uint32_t)(h >> 20) & (2u * PB - 1u);          // (other bits than the chunk table's slot)
+            for(;;) {
+                const uint32_t was = atomicCAS(&lt[e], 0u, threadIdx.x + 1u);
+                if(was == 0u) break;
+                if(lh[was - 1u] == h) { rep = was - 1u; break; }
+                e = (e + 1u) & (2u * PB - 1u);
+            }
+            lprev = (int32_t)atomicExch(&lhead[rep], threadIdx.x);        // 0xffffffff = -1: the first of its group to get here
+        }
+        lds_only_barrier();
+        if(ins && lprev == -1) ghead = lhead[rep];
+    }
+#else
+    if(ins) lprev = -1;
+#endif
+    // the group's compare-and-swap is on its way from here; its answer is looked at only after the PrepReads have left
+    const bool gins = ins && lprev == -1;
+    const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i0 + ghead + 1u);
+    uint32_t sl = (uint32_t)h & P.hmask;
+    unsigned long long old = 0ull;
+#if PREP_EXP_NOCAS                                        // TIMING EXPERIMENT ONLY (wrong results): a plain store where the compare-and-swap is
+    if(gins) P.hent[sl] = mine;
+#else
+    if(gins) old = sync_cas(&P.hent[sl], 0ull, mine);
+#endif
+    if(ins && lprev >= 0) { P.hnext[i] = i0 + lprev; P.hfwd[i0 + lprev] = i; }
     // the PrepReads go to the workgroup's stage in LDS first and from there to rd[] as whole lines: written straight from the lanes, the four
     // quads would leave in four store instructions of 16 bytes per 64 -- partial lines, which the memory side does not merge
     stage_read(stage + 4 * threadIdx.x, D, adm);
     lds_only_barrier();
     {
-        const int first = (int)(tk * PB), cnt = P.n_rec - first < PB ? P.n_rec - first : PB;
-        uint4 *out = (uint4 *)(P.rd + first);
+        const int cnt = P.n_rec - i0 < PB ? P.n_rec - i0 : PB;
+        uint4 *out = (uint4 *)(P.rd + i0);
         for(int q = threadIdx.x; q < 4 * cnt; q += PB) out[q] = stage[q];
     }
-    if(ins) {
+    if(gins) {
         int32_t before = -1;
         for(;;) {
             if(old == 0ull) break;
@@ -680,7 +720,11 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
 #endif
     __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64];
     const PrepParams &P = M.P[chunk_of_block(M)];
+#if PREP_EXP_SEGS & 8
+    if(threadIdx.x == 0) s_tk = (blockIdx.x >> 3) * ((7u - (uint32_t)chunk_of_block(M)) / (uint32_t)M.n + 1u) + (blockIdx.x & 7u) / (uint32_t)M.n;
+#else
     if(threadIdx.x == 0) s_tk = sync_add(&P.ticket[1], 1u);
+#endif
     __syncthreads();
     const uint32_t tk = s_tk, n_rec = (uint32_t)P.n_rec;
     if(tk * PB >= n_rec) return;                          // (a workgroup that leaves here is never waited for: every ticket before an active one is active)
@@ -738,12 +782,12 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     { unsigned long long b = bytes;
 #pragma unroll
       for(int d = 32; d; d >>= 1) b += __shfl_xor(b, d);
-      if(lane == 0 && b) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, b); }
-    const uint32_t before = tickets_before(P.cntS, tk, red);
+      if(!(PREP_EXP_SEGS & 16) && lane == 0 && b) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, b); }
+    const uint32_t before = (PREP_EXP_SEGS & 4) ? tk * 352u : tickets_before(P.cntS, tk, red);
     base += before;
     if((tk + 1) * PB >= n_rec && threadIdx.x == 0) P.cnt->n_segs = before + total;
     int32_t lo = INT32_MAX, hi = INT32_MIN;             // (reference positions are 32 bits: BAM's pos)
-    if(n) (void)read_segments<true>(P, r, has_mate, m, is_second, P.seg, base, lo, hi);
+    if(n && !(PREP_EXP_SEGS & 2)) (void)read_segments<true>(P, r, has_mate, m, is_second, P.seg, base, lo, hi);
     // Tile runs: tile t's run [first, last) must cover every segment touching t.  A lane contributes [base, base + n) to every
     // tile its pieces reach -- a superset, which is all k_pileup needs.  Reads are in coordinate order, so the lanes of a wave
     // touching one tile are (nearly always) consecutive: only the first of them lowers `first`, only the last raises `last`,
@@ -755,7 +799,7 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
     }
     const int p0 = __shfl_up(t0, 1), p1 = __shfl_up(t1, 1), n0 = __shfl_down(t0, 1), n1 = __shfl_down(t1, 1);
     uint32_t top = base + n; if((int64_t)top > P.cap_seg) top = (uint32_t)P.cap_seg;
-    for(int t = t0; t <= t1; t++) {
+    for(int t = t0; t <= t1 && !(PREP_EXP_SEGS & 1); t++) {
         if(lane == 0 || t < p0 || t > p1) atomicMin(&P.tiles[t].first, (int)base);
         if(lane == 63 || t < n0 || t > n1) atomicMax(&P.tiles[t].last, (int)top);
     }
@@ -844,7 +888,7 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
 }
 
 #define PREP_SCAN_LDS ((size_t)(PB / 64) * RAWWIN_LDS)
-static_assert(PREP_SCAN_LDS >= 4 * PB * sizeof(uint4), "the PrepRead stage lives in the windows' memory");
+static_assert(PREP_SCAN_LDS >= 4 * PB * sizeof(uint4) + PB * 8 + 2 * PB * 4 + PB * 4, "the PrepRead stage and the workgroup's name grouping live in the windows' memory");
 MDK_HIDDEN int prep_kernels_init() {        // more dynamic LDS than the default window: once per process
     static std::once_flag once; static int rc = 1;
     std::call_once(once, [] { rc = (hipFuncSetAttribute((const void *)k_prep_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess &&
