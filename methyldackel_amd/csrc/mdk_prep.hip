@@ -633,11 +633,11 @@ __device__ __forceinline__ int32_t prev_of(const PrepRead *rd, const int32_t x, 
 // runtime found room for it, profiles/r05c_prep_variants.txt; inlined, its state lives in LDS and the kernel needs 57 VGPRs.)
 #define PAIR_SECOND 0x40000000
 struct PairCtx { const int32_t *hnext, *hfwd; const PrepRead *rd; const uint8_t *raw; int32_t tid; };
-__device__ __forceinline__ int32_t pair_of_many(const PairCtx X, const uint32_t a, const int32_t a_rend, const int32_t a_prev, const uint32_t a_flag, const uint32_t a_nlen, const uint4 a_name, const uint32_t a_qn_off) {
+__device__ __forceinline__ int32_t pair_of_many(const PairCtx X, MdkPairState &S, const uint32_t a, const int32_t a_rend, const int32_t a_prev, const uint32_t a_flag, const uint32_t a_nlen, const uint4 a_name, const uint32_t a_qn_off) {
     int32_t head = (int32_t)a; int k = 0;
     for(int guard = 0; X.hfwd[head] >= 0; head = X.hfwd[head]) if(++guard > MAXG) return -2;
     for(int32_t x = head; x >= 0; x = X.hnext[x]) if(++k > MAXG) return -2;
-    MdkPairState S; mdk_pair_init(S);
+    mdk_pair_init(S);
     for(int32_t last = -1;;) {
         int32_t x = 0x7fffffff;
         for(int32_t y = head; y >= 0; y = X.hnext[y]) if(y > last && y < x) x = y;
@@ -673,15 +673,18 @@ struct RunIt {
     }
 };
 
-// lo/hi: reference extent of the pieces written (for the tile runs); untouched when nothing is emitted
-template <bool WRITE>
-__device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const RdRegs &r, const bool has_mate, const RdRegs &m, const bool is_second, md_seg *out, uint32_t base, int32_t &lo, int32_t &hi) {
+// lo/hi: reference extent of the pieces written (for the tile runs); untouched when nothing is emitted.  A piece leaves as the two quads of
+// its md_seg through `sink(index, quad0, quad1)` -- into the workgroup's stage in LDS, or (a workgroup with more pieces than the stage holds)
+// straight into the segment array.
+struct NoSink { __device__ __forceinline__ void operator()(uint32_t, uint4, uint4) const {} };
+template <bool WRITE, typename Sink>
+__device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const RdRegs &r, const bool has_mate, const RdRegs &m, const bool is_second, const Sink sink, const uint32_t base, const uint32_t limit, int32_t &lo, int32_t &hi) {
     const bool paired = has_mate && (((int)r.strand() - (int)m.strand()) & 1) == 0;       // overlaps.c:63-65
     RunIt own, oth;
     own.init(P.raw, r);
     if(paired) oth.init(P.raw, m); else oth.valid = false;
-    const uint8_t sf = (uint8_t)((r.strand() & 7) | ((r.flag() & 0x80) ? MDK_SF_READ2 : 0) | (is_second ? MDK_SF_SECOND : 0));
-    const uint8_t msf = paired ? (uint8_t)((m.strand() & 7) | ((m.flag() & 0x80) ? MDK_SF_READ2 : 0)) : 0;
+    const uint32_t sf = (r.strand() & 7) | ((r.flag() & 0x80) ? MDK_SF_READ2 : 0) | (is_second ? MDK_SF_SECOND : 0);
+    const uint32_t msf = paired ? ((m.strand() & 7) | ((m.flag() & 0x80) ? MDK_SF_READ2 : 0)) : 0;
     uint32_t n = 0;
     for(; own.valid; own.next()) {
         int32_t cur = own.rx; const int32_t stop = own.rx + own.rl;
@@ -692,15 +695,14 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const RdR
             if(pe - cur > 65535) pe = cur + 65535;
             if((int64_t)pe > P.beg && (int64_t)cur < P.end) {
                 if(WRITE) {
-                    md_seg g; g.rpos = cur; g.off4 = r.seq_off(); g.l_qseq = r.lq(); g.q0 = (uint32_t)(own.ry + (cur - own.rx)); g.len = (uint16_t)(pe - cur);
-                    g.sf = sf; g.msf = 0; g.m_off4 = 0; g.m_l_qseq = 0; g.m_q0 = 0;
-                    if(covered) { g.sf |= MDK_SF_PARTNER; g.msf = msf; g.m_off4 = m.seq_off(); g.m_l_qseq = m.lq(); g.m_q0 = (uint32_t)(oth.ry + (cur - oth.rx)); }
+                    // md_seg: rpos off4 l_qseq q0 | len sf msf  m_off4 m_l_qseq m_q0
+                    const uint4 g0 = make_uint4((uint32_t)cur, r.seq_off(), r.lq(), (uint32_t)(own.ry + (cur - own.rx)));
+                    uint4 g1 = make_uint4((uint32_t)(pe - cur) & 0xffffu | sf << 16, 0u, 0u, 0u);
+                    if(covered) g1 = make_uint4((uint32_t)(pe - cur) & 0xffffu | (sf | MDK_SF_PARTNER) << 16 | msf << 24, m.seq_off(), m.lq(), (uint32_t)(oth.ry + (cur - oth.rx)));
                     const uint32_t o = base + n;
-                    if((int64_t)o < P.cap_seg) {
-                        out[o] = g;
-                        if(cur < lo) lo = cur;
-                        if(pe > hi) hi = pe;
-                    }
+                    if(o < limit) sink(o, g0, g1);
+                    if(cur < lo) lo = cur;
+                    if(pe > hi) hi = pe;
                 }
                 n++;
             }
@@ -709,7 +711,10 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const RdR
     }
     return n;
 }
+static_assert(sizeof(md_seg) == 32 && offsetof(md_seg, len) == 16 && offsetof(md_seg, sf) == 18 && offsetof(md_seg, msf) == 19 && offsetof(md_seg, m_off4) == 20, "md_seg layout (read_segments builds it as two quads)");
 
+#define SEG_STAGE 512                 // segments of one workgroup staged in LDS (16 KB)
+#define SEG_TSPAN 32                  // tiles a workgroup's reads may reach for their runs to be merged in LDS
 #ifndef SEGS_SGPRS
 #define SEGS_SGPRS 96                 // cap on the kernel's scalar registers: 104 of them cost the eighth wavefront per SIMD; the excess spills into lanes of a VGPR (measured: 172.6 -> 162.6 us per launch, profiles/r05d_prep_variants.txt).  0: no cap
 #endif
@@ -719,17 +724,23 @@ __global__ __launch_bounds__(PB) __attribute__((amdgpu_num_sgpr(SEGS_SGPRS))) vo
 __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
 #endif
     __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64];
+    // the workgroup's segments on their way out (32 bytes each; a workgroup of 256 records makes ~350); before that, the rare path's state
+    __shared__ __align__(16) uint4 sstage[2 * SEG_STAGE];
+    __shared__ int s_tlo, s_thi, tfirst[SEG_TSPAN], tlast[SEG_TSPAN];      // the tiles the workgroup's segments reach, and per tile the run of them (relative to the workgroup's first)
+    static_assert(sizeof(sstage) >= PB * sizeof(MdkPairState), "the rare path keeps a state per thread in the stage's memory");
     const PrepParams &P = M.P[chunk_of_block(M)];
 #if PREP_EXP_SEGS & 8
     if(threadIdx.x == 0) s_tk = (blockIdx.x >> 3) * ((7u - (uint32_t)chunk_of_block(M)) / (uint32_t)M.n + 1u) + (blockIdx.x & 7u) / (uint32_t)M.n;
 #else
     if(threadIdx.x == 0) s_tk = sync_add(&P.ticket[1], 1u);
 #endif
+    if(threadIdx.x == 0) { s_tlo = 0x7fffffff; s_thi = -1; }
+    if(threadIdx.x < SEG_TSPAN) { tfirst[threadIdx.x] = 0x7fffffff; tlast[threadIdx.x] = 0; }
     __syncthreads();
     const uint32_t tk = s_tk, n_rec = (uint32_t)P.n_rec;
     if(tk * PB >= n_rec) return;                          // (a workgroup that leaves here is never waited for: every ticket before an active one is active)
     const uint32_t a = tk * PB + threadIdx.x; const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    RdRegs r = rd_zero(), m = rd_zero(); bool has_mate = false, is_second = false;
+    RdRegs r = rd_zero(), m = rd_zero(); bool has_mate = false, is_second = false; int32_t mate = -1;
     int32_t lnext = -1, lfwd = -1;
     const int32_t mylast = tk > 0 ? (int32_t)P.cntA[tk - 1] : PREP_PREV_NONE;      // (one scalar load, on its way with the rest)
     if(a < n_rec) { r = rd_load(P.rd, a); if(!P.cfg.no_pairing) { lnext = P.hnext[a]; lfwd = P.hfwd[a]; } }      // (hnext of a record that was not admitted is whatever the buffer held: looked at only under adm)
@@ -759,49 +770,84 @@ __global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
                     }
                 } else {
                     PairCtx X; X.hnext = P.hnext; X.hfwd = P.hfwd; X.rd = P.rd; X.raw = P.raw; X.tid = P.tid;
-                    mi = pair_of_many(X, a, r.rend(), r.prev(), r.flag(), r.nlen(), r.q1, r.qn_off());
+                    mi = pair_of_many(X, ((MdkPairState *)sstage)[threadIdx.x], a, r.rend(), r.prev(), r.flag(), r.nlen(), r.q1, r.qn_off());
                     if(mi == -2) { atomicExch(&P.cnt->fallback, 1u); mi = -1; }
                     if(mi >= 0) { is_second = (mi & PAIR_SECOND) != 0; mi &= ~PAIR_SECOND; m = rd_load(P.rd, (uint32_t)mi); }
                 }
-                has_mate = mi >= 0;
+                has_mate = mi >= 0; mate = mi;
             }
         }
         int32_t lo = 0, hi = 0;
-        n = read_segments<false>(P, r, has_mate, m, is_second, nullptr, 0, lo, hi);
+        n = read_segments<false>(P, r, has_mate, m, is_second, NoSink(), 0u, 0u, lo, hi);
         bytes = 16ull + 4ull * r.ncig() + ((unsigned long long)r.lq() + 1) / 2 + r.lq();        // SURVEY.md 8d, per admitted read
     }
-    // where this read's segments go: scan inside the workgroup, plus what the earlier tickets counted
+    // where this read's segments go: scan inside the workgroup (wpos: its place among the workgroup's), plus what the earlier tickets counted
     uint32_t incl = n;
 #pragma unroll
     for(int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if(lane >= d) incl += t; }
     if(lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t base = incl - n, total = 0;
-    for(int w = 0; w < PB / 64; w++) { if(w < wave) base += wsum[w]; total += wsum[w]; }
+    __syncthreads();                                      // (also: nobody is in the rare path any more -- the stage's memory is the stage's)
+    uint32_t wpos = incl - n, total = 0;
+    for(int w = 0; w < PB / 64; w++) { if(w < wave) wpos += wsum[w]; total += wsum[w]; }
     if(threadIdx.x == 0) sync_set(&P.cntS[tk], total | CNT_READY);
     { unsigned long long b = bytes;
 #pragma unroll
       for(int d = 32; d; d >>= 1) b += __shfl_xor(b, d);
       if(!(PREP_EXP_SEGS & 16) && lane == 0 && b) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, b); }
-    const uint32_t before = (PREP_EXP_SEGS & 4) ? tk * 352u : tickets_before(P.cntS, tk, red);
-    base += before;
-    if((tk + 1) * PB >= n_rec && threadIdx.x == 0) P.cnt->n_segs = before + total;
+    // The segments are made while the earlier tickets' counts are on their way: into the stage in LDS, at their place among the workgroup's
+    // (straight from the lanes they would leave as 16-byte stores 32 bytes apart -- partial lines, which the memory side does not merge: the
+    // write pass was 92 of the kernel's 177 us, profiles/r05f_prep_variants.txt), and leave it as whole lines.  A workgroup with more
+    // segments than the stage holds (long CIGARs) goes round again for the next stage-full.
     int32_t lo = INT32_MAX, hi = INT32_MIN;             // (reference positions are 32 bits: BAM's pos)
-    if(n && !(PREP_EXP_SEGS & 2)) (void)read_segments<true>(P, r, has_mate, m, is_second, P.seg, base, lo, hi);
-    // Tile runs: tile t's run [first, last) must cover every segment touching t.  A lane contributes [base, base + n) to every
-    // tile its pieces reach -- a superset, which is all k_pileup needs.  Reads are in coordinate order, so the lanes of a wave
-    // touching one tile are (nearly always) consecutive: only the first of them lowers `first`, only the last raises `last`,
-    // instead of two contended atomics per segment (275 us -> a few us per 1 Mb chunk).
     int t0 = 0x7fffffff, t1 = -1;
-    if(n && hi > lo && (int64_t)base < P.cap_seg) {
+    uint32_t before = 0;
+    const uint32_t cap = P.cap_seg > 0xffffffffll ? 0xffffffffu : (uint32_t)P.cap_seg;
+    uint4 *const st = sstage;
+    if(n && !(PREP_EXP_SEGS & 2))                        // (every lane with segments: lo and hi are wanted of all of them, the stage takes what fits)
+        (void)read_segments<true>(P, r, has_mate, m, is_second, [st](uint32_t o, uint4 g0, uint4 g1) { st[2 * o] = g0; st[2 * o + 1] = g1; }, wpos, (uint32_t)SEG_STAGE, lo, hi);
+    if(n && hi > lo) {
         const int64_t l = lo < P.beg ? P.beg : (int64_t)lo, u = hi > P.end ? P.end : (int64_t)hi;
         t0 = (int)((uint32_t)(l - P.beg) / (uint32_t)P.tile); t1 = (int)((uint32_t)(u - 1 - P.beg) / (uint32_t)P.tile);       // (a chunk spans less than 2^31 positions)
+        atomicMin(&s_tlo, t0); atomicMax(&s_thi, t1);
     }
-    const int p0 = __shfl_up(t0, 1), p1 = __shfl_up(t1, 1), n0 = __shfl_down(t0, 1), n1 = __shfl_down(t1, 1);
-    uint32_t top = base + n; if((int64_t)top > P.cap_seg) top = (uint32_t)P.cap_seg;
-    for(int t = t0; t <= t1 && !(PREP_EXP_SEGS & 1); t++) {
-        if(lane == 0 || t < p0 || t > p1) atomicMin(&P.tiles[t].first, (int)base);
-        if(lane == 63 || t < n0 || t > n1) atomicMax(&P.tiles[t].last, (int)top);
+    before = (PREP_EXP_SEGS & 4) ? tk * 352u : tickets_before(P.cntS, tk, red);       // (two barriers inside: the stage is complete behind it)
+    if((tk + 1) * PB >= n_rec && threadIdx.x == 0) P.cnt->n_segs = before + total;
+    {
+        const uint32_t left = total < SEG_STAGE ? total : SEG_STAGE;
+        const uint32_t avail = cap > before ? (left < cap - before ? left : cap - before) : 0u;
+        uint4 *out = (uint4 *)(P.seg + before);
+        for(uint32_t q = threadIdx.x; q < 2 * avail; q += PB) out[q] = sstage[q];
+    }
+    if(total > SEG_STAGE && n && wpos + n > SEG_STAGE && !(PREP_EXP_SEGS & 2)) {
+        // (rare: what did not fit the stage leaves from the lanes; the reads are loaded again rather than kept in registers across the wait)
+        const RdRegs r2 = rd_load(P.rd, a), m2 = has_mate ? rd_load(P.rd, (uint32_t)mate) : rd_zero();
+        md_seg *const sg = P.seg + before; int32_t lo2 = 0, hi2 = 0;
+        (void)read_segments<true>(P, r2, has_mate, m2, is_second, [sg](uint32_t o, uint4 g0, uint4 g1) { if(o >= SEG_STAGE) { uint4 *q = (uint4 *)(sg + o); q[0] = g0; q[1] = g1; } }, wpos, cap > before ? cap - before : 0u, lo2, hi2);
+    }
+    // Tile runs: tile t's run [first, last) must cover every segment touching t.  A lane contributes [its first, its last + 1) to every
+    // tile its pieces reach -- a superset, which is all k_pileup needs.  Reads are in coordinate order, so the lanes of a wave
+    // touching one tile are (nearly always) consecutive: only the first of them lowers `first`, only the last raises `last`.
+    // The workgroup's reads reach a tile or two: their runs are merged in LDS and a lane per tile tells the chunk (two device-scope
+    // atomics per tile and workgroup instead of two per tile and wavefront).
+    const int tlo = s_tlo, thi = s_thi;
+    if(thi >= tlo && !(PREP_EXP_SEGS & 1)) {
+        if(thi - tlo < SEG_TSPAN) {
+            const int p0 = __shfl_up(t0, 1), p1 = __shfl_up(t1, 1), n0 = __shfl_down(t0, 1), n1 = __shfl_down(t1, 1);
+            for(int t = t0; t <= t1; t++) {
+                if(lane == 0 || t < p0 || t > p1) atomicMin(&tfirst[t - tlo], (int)wpos);
+                if(lane == 63 || t < n0 || t > n1) atomicMax(&tlast[t - tlo], (int)(wpos + n));
+            }
+            __syncthreads();
+            const int k = (int)threadIdx.x;
+            if(k <= thi - tlo && tlast[k] > tfirst[k] && before + (uint32_t)tfirst[k] < cap) {
+                const uint32_t top = before + (uint32_t)tlast[k];
+                atomicMin(&P.tiles[tlo + k].first, (int)(before + (uint32_t)tfirst[k]));
+                atomicMax(&P.tiles[tlo + k].last, (int)(top < cap ? top : cap));
+            }
+        } else {                                          // (reads that skip far: N operations)
+            const uint32_t base = before + wpos; uint32_t top = base + n; if(top > cap) top = cap;
+            if(base < cap) for(int t = t0; t <= t1; t++) { atomicMin(&P.tiles[t].first, (int)base); atomicMax(&P.tiles[t].last, (int)top); }
+        }
     }
 }
 

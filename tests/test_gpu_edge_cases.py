@@ -157,3 +157,49 @@ def test_undeterminable_strand_aborts_like_the_reference(tmp_path):
     rg = mdk.run_cli([str(tmp_path / "e.fa"), str(tmp_path / "e.bam"), "-o", str(tmp_path / "g")], cwd=tmp_path)
     assert ro.returncode == -6 and rg.returncode == -6, (ro.returncode, rg.returncode)
     assert "Can't determine the strand of a read!" in ro.stderr and "Can't determine the strand of a read!" in rg.stderr
+
+
+def test_many_cigar_operations_far_skips_and_a_crowd_of_pairs(tmp_path):
+    """what k_prep_segs keeps per workgroup of 256 records: more segments than its LDS stage holds (reads with ten gapless runs each, and so
+    many of them that the segment array has to grow and the preparation is run again), reads whose N operations reach across dozens of
+    tiles, pairs whose mates sit in different workgroups of the scan (a block of unrelated reads in between) next to pairs that sit side
+    by side, and a name with a read in each of three workgroups"""
+    rng = random.Random(11)
+    L = 260000
+    ref = ref_with_cpgs(L, 9)
+    R = []
+
+    def add(pos, flag, cig, qname, mpos=0, q=35):
+        import re
+        seq, p = [], pos
+        for n, op in re.findall(r"(\d+)([MIDNS])", cig):
+            n = int(n)
+            if op == "M":
+                seq.append(bs_read(ref, p, n, bool(flag & 0x40) != bool(flag & 0x10), rng)); p += n
+            elif op in "IS":
+                seq.append("".join(rng.choice("ACGT") for _ in range(n)))
+            else:
+                p += n
+        s = "".join(seq)
+        R.append((pos, len(R), record(0, pos, flag, cig, s, [rng.choice([12, 23, 37, 41]) for _ in range(len(s))], qname=qname, mpos=mpos)))
+
+    many = "8M1D" * 9 + "8M"                                  # ten runs of 8, 89 reference bases
+    for k in range(1200):                                       # 600 pairs of ten-run reads, mates 40 apart: ~16 segments and more per pair
+        pos = 1000 + 15 * k
+        add(pos, 99, many, f"m{k}", pos + 40); add(pos + 40, 147, many, f"m{k}", pos)
+    for k in range(40):                                         # skips of 1 kb .. 120 kb: up to ~58 tiles of 2048
+        pos = 30000 + 50 * k
+        add(pos, 99, f"30M{1000 + 3000 * k}N30M", f"n{k}", pos + 10); add(pos + 10, 147, "50M", f"n{k}", pos)
+    for k in range(300):                                        # mates 700 records apart (other workgroups of the scan), names shared by three reads for every tenth
+        pos = 150000 + 20 * k
+        add(pos, 99, "60M", f"f{k}", pos + 14000)
+        add(pos + 14000, 147, "60M", f"f{k}", pos)
+        if k % 10 == 0:
+            add(pos + 7000, 99 | 0x800, "40M", f"f{k}", pos)
+    for k in range(700):                                        # the crowd in between, singles
+        add(150010 + 20 * k, 0, "70M", f"s{k}")
+    R.sort(key=lambda x: (x[0], x[1]))
+    write_bam(tmp_path / "m.bam", [("c1", L)], [r for _, _, r in R])
+    write_fasta(tmp_path / "m.fa", [("c1", ref)])
+    for extra in (["--CHG", "--CHH", "-q", "0"], ["-F", "0", "--keepSingleton", "--keepDiscordant", "--chunkSize", "100000", "-q", "0"], ["--chunkSize", "20000", "--mergeContext", "-q", "0"]):
+        compare_cli(tmp_path, [str(tmp_path / "m.fa"), str(tmp_path / "m.bam")] + extra)
