@@ -252,9 +252,11 @@ int  md_dev_set_regions(md_dev *h, int32_t tid, const md_region *runs, int64_t n
  * (memory owned by the handle, valid until the next read/reset/close). */
 typedef struct { int32_t len; const uint32_t *count; } md_mbias;
 int  md_dev_mbias_submit(md_dev *h, int slot, const md_read_batch *b);
-/* the same from the chunk's raw records (md_dev_set_prep with no_pairing = 1 first): H2D + device preparation + the histogram
- * kernel; waits once for the preparation (the longest admitted read sizes the histogram).  The ranges must stay valid until
- * the call returns; MDK_ERR_PREP_HOST is not possible here (no pairing). */
+/* the same from the chunk's raw records (md_dev_set_prep with no_pairing = 1 first): H2D + device preparation are queued and the call
+ * returns; the histogram kernel follows once the preparation has reported the longest admitted read (which sizes the histogram rows
+ * kept in LDS) -- at the next submit on another slot, at md_dev_slot_sync or at md_dev_mbias_read, whichever comes first.  The ranges
+ * must stay valid until md_dev_slot_sync(slot) or the next submit on that slot returns; MDK_ERR_PREP_HOST is not possible here (no
+ * pairing). */
 int  md_dev_mbias_submit_raw(md_dev *h, int slot, const md_raw_batch *b);
 int  md_dev_mbias_read(md_dev *h, md_mbias *out);
 int  md_dev_mbias_reset(md_dev *h);

@@ -102,8 +102,11 @@ int mbias_main(int argc, char *argv[]) {
     dev = dop.dev;
     if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `mbias`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
+    if(p->dev_prep) mdk_plan_attach_device(p, dev);      /* from here on the device inflates pieces of the file too, as in extract */
     for(;; k++) {
-        /* chunk k goes to slot k&1; the batch handed out two calls ago is recycled by the next call, so its upload must be over */
+        /* chunk k goes to slot k&1; the batch handed out two calls ago is recycled by the next call, so its upload must be over.  A submit queues
+         * the chunk's upload and preparation and meanwhile sends the other slot's chunk -- whose preparation has reported by then -- on to the
+         * histogram kernel (md_dev_mbias_submit_raw), so the records of chunk k cross the link while chunk k-1 is counted */
         if((rc = md_dev_slot_sync(dev, k & 1)) != 0) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
         rc = mdk_plan_next_chunk(p, &ch);
         if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
@@ -122,6 +125,7 @@ int mbias_main(int argc, char *argv[]) {
         else if(mdk_mbias_report(&hist, p->o.mb_opref, p->o.svg, p->o.txt, p->o.ctx_on[0] + 2 * p->o.ctx_on[1] + 4 * p->o.ctx_on[2])) ret = -3;
     }
     if(fast_exit_wanted()) leave_fast(ret);
+    mdk_plan_detach_device(p);
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;

@@ -360,7 +360,7 @@ region:
  * from the records on the host.  MDK_HOST_INFLATE=1 keeps every piece on the host's inflate threads. */
 int mdk_plan_attach_device(mdk_plan *p, md_dev *dev) {
     if(!p || !dev || !p->bam) return -1;
-    if(!p->dev_prep || p->o.mbias || p->o.perread || getenv("MDK_HOST_INFLATE")) return 0;
+    if(!p->dev_prep || p->o.perread || getenv("MDK_HOST_INFLATE")) return 0;       /* (perRead prints from the records' bytes on the host: mdk_plan_emit_perread_raw) */
     if(p->bai && p->shard_world > 1) return 0;      /* a rank of a sharded run seeks before every chunk of its own: a 64 MB device piece per seek would be thrown away with the next */
     /* eight teams: a 64 MB piece is ~3,400 members = wavefronts, about half of what the device holds at once, and a team spends a third of its
      * cycle copying the piece into its staging block (512 Mb: 1.23 s inside with 3 teams, 1.04 with 5, 0.96 with 8; 128 Mb: no difference) */

@@ -1176,17 +1176,16 @@ extern "C" int md_dev_mbias_submit(md_dev *h, int slot, const md_read_batch *b) 
     return 0;
 }
 
-// the same from the chunk's raw records: the device prepares them (no pairing: md_prep_cfg.no_pairing) and tells how long the
-// longest admitted read is, which sizes the histogram rows kept in LDS -- one wait for the preparation per chunk
-extern "C" int md_dev_mbias_submit_raw(md_dev *h, int slot, const md_raw_batch *b) {
-    if(!h || !h->prep_set || !h->prep.no_pairing) return fail(MDK_ERR_ARG, "md_dev_mbias_submit_raw: md_dev_set_prep with no_pairing first", hipSuccess);
-    int rc = md_dev_upload_raw(h, slot, b);
-    if(rc) return rc;
-    Slot *s = get_slot(h, slot);
-    { Slot *one[1] = {s}; rc = enqueue_prep_group(h, one, 1, s->stream); if(rc) return rc; }
-    HIPCHK(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, s->stream));
+// The same from the chunk's raw records: the device prepares them (no pairing: md_prep_cfg.no_pairing) and tells how long the longest
+// admitted read is, which sizes the histogram rows kept in LDS.  The histogram kernel of a chunk therefore waits for its preparation's
+// report -- but the host does not wait for it here: a submit queues the chunk's upload, preparation and report, and then sends the OTHER
+// slots' chunks, whose reports have had a whole upload's time to arrive, on to the histogram kernel (round 4 waited for every chunk's
+// preparation before the next chunk's records could start crossing the link).
+static int mbias_finish(md_dev *h, Slot *s) {
+    if(!s->mb_pending) return 0;
+    s->mb_pending = false;
     HIPCHK(hipStreamSynchronize(s->stream));
-    rc = prep_outcome(h, s);
+    int rc = prep_outcome(h, s);
     if(rc == MDK_ERR_PREP_REDO) {
         HIPCHK(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -1205,11 +1204,26 @@ extern "C" int md_dev_mbias_submit_raw(md_dev *h, int slot, const md_raw_batch *
     HIPCHK(hipGetLastError());
     return 0;
 }
+extern "C" int md_dev_mbias_submit_raw(md_dev *h, int slot, const md_raw_batch *b) {
+    if(!h || !h->prep_set || !h->prep.no_pairing) return fail(MDK_ERR_ARG, "md_dev_mbias_submit_raw: md_dev_set_prep with no_pairing first", hipSuccess);
+    Slot *s = get_slot(h, slot);
+    if(!s) return MDK_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = mbias_finish(h, s);                       // (a slot submitted twice in a row: its earlier chunk goes on first)
+    if(rc) return rc;
+    if((rc = md_dev_upload_raw(h, slot, b)) != 0) return rc;
+    { Slot *one[1] = {s}; rc = enqueue_prep_group(h, one, 1, s->stream); if(rc) return rc; }
+    HIPCHK(hipMemcpyAsync(s->h_st.p, h->d_status.p + s->index, sizeof(SlotStatus), hipMemcpyDeviceToHost, s->stream));
+    s->mb_pending = true;
+    for(Slot &o : h->slots) if(&o != s && o.mb_pending && (rc = mbias_finish(h, &o)) != 0) return rc;
+    return 0;
+}
 
 extern "C" int md_dev_slot_sync(md_dev *h, int slot) {
     Slot *s = get_slot(h, slot);
     if(!s) return MDK_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { const int rc = mbias_finish(h, s); if(rc) return rc; }
     HIPCHK(hipStreamSynchronize(s->stream));
     return 0;
 }
@@ -1217,6 +1231,7 @@ extern "C" int md_dev_slot_sync(md_dev *h, int slot) {
 extern "C" int md_dev_mbias_read(md_dev *h, md_mbias *out) {
     if(!h || !out) return fail(MDK_ERR_ARG, "md_dev_mbias_read", hipSuccess);
     HIPCHK(hipSetDevice(h->device));
+    for(Slot &o : h->slots) { const int rc = mbias_finish(h, &o); if(rc) return rc; }
     HIPCHK(hipDeviceSynchronize());
     for(auto &s : h->slots) {
         int err = 0;
@@ -1232,6 +1247,7 @@ extern "C" int md_dev_mbias_read(md_dev *h, md_mbias *out) {
 extern "C" int md_dev_mbias_reset(md_dev *h) {
     if(!h) return MDK_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
+    for(Slot &o : h->slots) { const int rc = mbias_finish(h, &o); if(rc) return rc; }
     HIPCHK(hipDeviceSynchronize());
     if(h->d_hist) { HIPCHK(hipMemset(h->d_hist, 0, (size_t)h->hist_cap * 16 * sizeof(uint32_t))); HIPCHK(hipDeviceSynchronize()); }
     h->hist_len = 0;

@@ -87,7 +87,17 @@ __device__ __forceinline__ int chunk_of_block(const PrepMulti &M) { return (int)
 __device__ __forceinline__ uint32_t sync_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t sync_peek(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sync_set(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long sync_cas(unsigned long long *p, unsigned long long expected, unsigned long long desired) { return atomicCAS(p, expected, desired); }
+#ifndef PREP_CAS_SCOPE
+#define PREP_CAS_SCOPE 0              // EXPERIMENT: 1 = the name table's compare-and-swaps at workgroup scope (resolved in the XCD's own L2; right only while every workgroup of a chunk runs on one XCD)
+#endif
+__device__ __forceinline__ unsigned long long sync_cas(unsigned long long *p, unsigned long long expected, unsigned long long desired) {
+#if PREP_CAS_SCOPE
+    (void)__hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return expected;
+#else
+    return atomicCAS(p, expected, desired);
+#endif
+}
 
 // ---- a record through a view of its bytes; the aux area ----
 struct AuxHit { bool nh, xg; int64_t nh_val; uint8_t xg1; };
