@@ -116,7 +116,7 @@ static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, uint64_t seq) {       
          * consumer still holds keep their slabs until it has been given further chunks -- slabs that only come back if the scanner
          * goes on.  (Slabs delivered out of order by other teams say nothing about that: n_ready > 0 is not "the scanner has work".) */
         if(seq == SEQ_FORCE || b->n_alloc < b->max_alloc || seq == b->pop_seq) { b->n_alloc++; s = calloc(1, sizeof(*s)); break; }
-        pthread_cond_wait(&b->cv_pool, &b->mu);
+        b->n_pool_wait++; pthread_cond_wait(&b->cv_pool, &b->mu); b->n_pool_wait--;
     }
     pthread_mutex_unlock(&b->mu);
     if(!s) return NULL;
@@ -126,6 +126,45 @@ static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, uint64_t seq) {       
     s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM; s->n_mem = 0; s->n_sum = 0;
     return s;
 }
+/* ---- the reaper (see mdk_io.h) ---- */
+#define MDK_POOL_KEEP 2
+static void slab_destroy(mdk_slab *s);
+static void reap_push(mdk_bam *b, mdk_slab *s) {        /* (mu held) */
+    if(b->n_reap == b->cap_reap) { b->cap_reap = b->cap_reap ? b->cap_reap * 2 : 32; b->reap = xrealloc(b->reap, sizeof(mdk_slab *) * b->cap_reap); }
+    b->reap[b->n_reap++] = s; b->n_alloc--;
+    pthread_cond_signal(&b->cv_reap);
+}
+static void *reaper_main(void *arg) {
+    mdk_bam *b = arg;
+    pthread_mutex_lock(&b->mu);
+    for(;;) {
+        while(!b->n_reap && !b->reap_quit) pthread_cond_wait(&b->cv_reap, &b->mu);
+        if(!b->n_reap) break;
+        { mdk_slab *s = b->reap[--b->n_reap]; b->reap_busy = 1; pthread_mutex_unlock(&b->mu); slab_destroy(s); pthread_mutex_lock(&b->mu); b->reap_busy = 0; }
+        if(!b->n_reap) pthread_cond_broadcast(&b->cv_reaped);
+    }
+    pthread_mutex_unlock(&b->mu);
+    return NULL;
+}
+/* the end of the file has been reached: what the pool holds beyond a couple of slabs goes too */
+static void reap_pool(mdk_bam *b) {                       /* (mu held) */
+    if(!b->reap_started || b->n_pool_wait) return;
+    while(b->n_pool > MDK_POOL_KEEP) reap_push(b, b->pool[--b->n_pool]);
+}
+/* wait until the reaper has nothing left to give back (a command about to leave: what it has not unregistered the kernel will, slowly) */
+void mdk_bam_reap_wait(mdk_bam *b) {
+    if(!b || !b->reap_started) return;
+    pthread_mutex_lock(&b->mu);
+    reap_pool(b);
+    while(b->n_reap || b->reap_busy) pthread_cond_wait(&b->cv_reaped, &b->mu);
+    pthread_mutex_unlock(&b->mu);
+}
+static void reaper_stop(mdk_bam *b) {
+    if(!b->reap_started) return;
+    pthread_mutex_lock(&b->mu); b->reap_quit = 1; pthread_cond_broadcast(&b->cv_reap); pthread_mutex_unlock(&b->mu);
+    pthread_join(b->reap_th, NULL);
+    b->reap_started = 0; b->reap_quit = 0;
+}
 void mdk_slab_ref(mdk_bam *b, mdk_slab *s) { pthread_mutex_lock(&b->mu); s->refs++; pthread_mutex_unlock(&b->mu); }
 void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
     pthread_mutex_lock(&b->mu);
@@ -133,6 +172,8 @@ void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
         if(s->piece) {
             if(b->n_dpool == b->cap_dpool) { b->cap_dpool = b->cap_dpool ? b->cap_dpool * 2 : 8; b->dpool = xrealloc(b->dpool, sizeof(mdk_slab *) * b->cap_dpool); }
             b->dpool[b->n_dpool++] = s;
+        } else if(b->io_end && b->reap_started && !b->n_pool_wait && b->n_pool >= MDK_POOL_KEEP) {
+            reap_push(b, s);                              /* nobody will ask for it again (a team still inflating its last piece finds MDK_POOL_KEEP in the pool, or makes one) */
         } else {
             if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = xrealloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); }
             b->pool[b->n_pool++] = s;
@@ -337,11 +378,12 @@ static void *inflater_main(void *arg) {
         /* the end of the file, or an error */
         pthread_mutex_lock(&b->mu);
         if(st < 0) { if(b->inf_done >= 0) b->inf_done = st; }
-        else if(!b->io_end) b->io_end = 1;
+        else if(!b->io_end) { b->io_end = 1; reap_pool(b); }
         pthread_cond_broadcast(&b->cv_q);
         pthread_mutex_unlock(&b->mu);
         break;
     }
+    if(gt >= 0 && !getenv("MDK_NO_REAP")) { md_host_free(b->gpu_stage[gt]); b->gpu_stage[gt] = NULL; b->gpu_stage_cap[gt] = 0; }      /* its last piece has crossed the link (md_piece_wait): the staging block goes now, not at exit */
     free(ta);
     return NULL;
 }
@@ -352,6 +394,7 @@ static void inflaters_start(mdk_bam *b) {
     if(i == 0) { b->io_status = -1; b->inf_done = -1; snprintf(b->err, sizeof(b->err), "cannot create an inflate thread"); }
     b->n_teams = i;
     b->inf_started = 1;
+    if(!b->reap_started && !getenv("MDK_NO_REAP") && pthread_create(&b->reap_th, NULL, reaper_main, b) == 0) b->reap_started = 1;
     if(b->dev && b->n_gpu_teams) { int k; for(k = 0; k < b->n_gpu_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } } b->n_gpu_teams = k; b->gpu_started = 1; }
 }
 static void inflaters_stop(mdk_bam *b) {
@@ -478,7 +521,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
      * teams that find no slab wait; the device inflates what they do not get to. */
     b->max_alloc = b->nthreads >= 8 ? 12 : b->nthreads + 4;
     if(getenv("MDK_SLAB_CAP")) b->max_alloc = atoi(getenv("MDK_SLAB_CAP")) > 1 ? atoi(getenv("MDK_SLAB_CAP")) : 2;
-    pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_mutex_init(&b->life_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL);
+    pthread_mutex_init(&b->mu, NULL); pthread_mutex_init(&b->io_mu, NULL); pthread_mutex_init(&b->life_mu, NULL); pthread_cond_init(&b->cv_q, NULL); pthread_cond_init(&b->cv_pool, NULL); pthread_cond_init(&b->cv_reap, NULL); pthread_cond_init(&b->cv_reaped, NULL);
     b->n_teams = b->nthreads >= 32 ? 4 : b->nthreads >= 8 ? 2 : 1;
     if(getenv("MDK_DEVICE_INFLATE_ONLY")) { b->host_leaves = 1; b->n_teams = 1; }
     b->gpu_piece_bytes = GCHUNK;
@@ -511,6 +554,9 @@ void mdk_bam_close(mdk_bam *b) {
     int i;
     if(!b) return;
     inflaters_stop(b);
+    reaper_stop(b);
+    for(i = 0; i < b->n_reap; i++) slab_destroy(b->reap[i]);
+    free(b->reap);
     if(b->cur) slab_destroy(b->cur);
     for(i = 0; i < MDK_READY; i++) if(b->ready[i]) slab_destroy(b->ready[i]);
     for(i = 0; i < b->n_pool; i++) slab_destroy(b->pool[i]);
@@ -520,7 +566,7 @@ void mdk_bam_close(mdk_bam *b) {
     if(b->f) fclose(b->f);
     if(b->target_name) for(i = 0; i < b->n_targets; i++) free(b->target_name[i]);
     free(b->target_name); free(b->target_len); free(b->text); if(b->map) munmap((void *)b->map, b->map_len); else free(b->cbuf);
-    pthread_mutex_destroy(&b->mu); pthread_mutex_destroy(&b->io_mu); pthread_mutex_destroy(&b->life_mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool);
+    pthread_mutex_destroy(&b->mu); pthread_mutex_destroy(&b->io_mu); pthread_mutex_destroy(&b->life_mu); pthread_cond_destroy(&b->cv_q); pthread_cond_destroy(&b->cv_pool); pthread_cond_destroy(&b->cv_reap); pthread_cond_destroy(&b->cv_reaped);
     free(b);
 }
 

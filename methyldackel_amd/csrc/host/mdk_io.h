@@ -64,6 +64,11 @@ typedef struct mdk_bam {
     struct md_dev *dev; pthread_t gpu_th[MDK_GPU_TEAMS_MAX]; int n_gpu_teams, gpu_started; uint8_t *gpu_stage[MDK_GPU_TEAMS_MAX]; size_t gpu_stage_cap[MDK_GPU_TEAMS_MAX];
     mdk_slab **dpool; int n_dpool, cap_dpool, n_dalloc, max_dalloc; uint64_t n_dev_pieces, n_host_pieces, n_materialized;
     mdk_slab **pool; int n_pool, cap_pool, n_alloc, max_alloc;
+    /* Once the last piece of the file has been handed to a team (io_end), a slab that comes back is not kept for a next piece that will never
+     * come: a reaper thread gives its staging memory back (hipHostUnregister + unmap) while the last chunks are still on their way through
+     * the device -- memory that is still registered when the process ends is taken down by the kernel page by page on one core, 0.3 s for
+     * the ~40 slabs of a 128 Mb run (gpurun_out/r05h/e2e.json: 0.39 s inside the process, 0.67 s for its caller). */
+    mdk_slab **reap; int n_reap, cap_reap, n_pool_wait, reap_started, reap_quit, reap_busy; pthread_t reap_th; pthread_cond_t cv_reap, cv_reaped;
     uint8_t *cbuf; size_t ccap, clen; int file_eof;
     const uint8_t *map; size_t map_len, map_pos;   /* the file mapped read-only: the inflate threads read the compressed bytes where the page cache has them (no copy) */
     /* scanner position */
@@ -91,6 +96,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads);
 mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off);
 void mdk_slab_ref(mdk_bam *b, mdk_slab *s);
 void mdk_slab_unref(mdk_bam *b, mdk_slab *s);
+void mdk_bam_reap_wait(mdk_bam *b);      /* until the slabs given up after the end of the file have been unregistered and unmapped */
 void mdk_bam_close(mdk_bam *b);
 /* from now on, pieces of the file are also inflated on this device (n_teams threads, each with its own device piece); safe while
  * the host teams are running.  mdk_bam_detach_device stops those threads and frees the device pieces: before md_dev_close. */

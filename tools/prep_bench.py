@@ -24,13 +24,13 @@ for i in range(R):
 slots = (C.c_int * R)(*range(R)); ms = C.c_float(0)
 out = {"R": R, "records_per_chunk": recs // R, "record_bytes_per_chunk": rawb // R, "extra": extra}
 import os
-FAST = bool(os.environ.get("PREP_BENCH_FAST"))           # only the 8-chunk launches (per-kernel traces of build variants)
+FAST = bool(os.environ.get("PREP_BENCH_FAST"))           # only the 8-chunk launches (per-kernel traces of build variants); 2: the pileup's 8-chunk launches too (bench.py's counter passes)
 if not FAST:
     assert L.md_dev_bench_prep(dev.h, 0, 3, 30, C.byref(ms)) == 0; out["prep_ms_one_chunk_same_slot"] = ms.value
 for per in ((8,) if FAST else (1, 2, 4, 8)):
     assert L.md_dev_bench_prep_rotate(dev.h, slots, R, per, 2 * (R // per), 20 * (R // per), C.byref(ms)) == 0, L.md_dev_last_error()
     out[f"prep_ms_per_chunk_{per}_per_launch"] = ms.value / per
-for per in (() if FAST else (1, 8)):
+for per in ((8,) if os.environ.get("PREP_BENCH_FAST") == "2" else () if FAST else (1, 8)):
     br = dev.bench_rotate(list(range(R)), 8, 100, per_launch=per)
     out[f"pileup_ms_per_chunk_{per}_per_launch"] = br.ms_pileup / per
 out["prep_GBps_8_per_launch"] = (rawb / R) / (out["prep_ms_per_chunk_8_per_launch"] / 1e3) / 1e9
