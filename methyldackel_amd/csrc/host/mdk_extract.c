@@ -300,6 +300,9 @@ int extract_main(int argc, char *argv[]) {
         pthread_mutex_unlock(&X->mu);
         ta = now_s(); release_uploaded(X, 0); w_rel += now_s() - ta;
     }
+    /* the last groups' records have crossed the link or are about to: their slabs go back too (to the reaper: the file has been read to its end),
+     * instead of staying registered until the process ends */
+    if(!ret) { int guard = 0; for(;;) { int any = 0; for(i = 0; i < MDK_NGROUPS; i++) any |= X->G[i].held; if(!any || ++guard > 2 * MDK_NGROUPS_MAX) break; release_uploaded(X, 1); } }
     if(ret) xp_fail(X, ret);
     pthread_mutex_lock(&X->mu); X->up_done = 1; X->ref_quit = 1; pthread_cond_broadcast(&X->cv); pthread_mutex_unlock(&X->mu);
     if(cth_ok) pthread_join(cth, NULL);

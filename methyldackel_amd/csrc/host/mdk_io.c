@@ -127,6 +127,7 @@ static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, uint64_t seq) {       
     return s;
 }
 /* ---- the reaper (see mdk_io.h) ---- */
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 #define MDK_POOL_KEEP 2
 static void slab_destroy(mdk_slab *s);
 static void reap_push(mdk_bam *b, mdk_slab *s) {        /* (mu held) */
@@ -140,7 +141,7 @@ static void *reaper_main(void *arg) {
     for(;;) {
         while(!b->n_reap && !b->reap_quit) pthread_cond_wait(&b->cv_reap, &b->mu);
         if(!b->n_reap) break;
-        { mdk_slab *s = b->reap[--b->n_reap]; b->reap_busy = 1; pthread_mutex_unlock(&b->mu); slab_destroy(s); pthread_mutex_lock(&b->mu); b->reap_busy = 0; }
+        { mdk_slab *s = b->reap[--b->n_reap]; const double t0 = now_s(); b->reap_busy = 1; pthread_mutex_unlock(&b->mu); slab_destroy(s); pthread_mutex_lock(&b->mu); b->reap_busy = 0; b->n_reaped++; b->t_reap += now_s() - t0; }
         if(!b->n_reap) pthread_cond_broadcast(&b->cv_reaped);
     }
     pthread_mutex_unlock(&b->mu);
@@ -156,7 +157,9 @@ void mdk_bam_reap_wait(mdk_bam *b) {
     if(!b || !b->reap_started) return;
     pthread_mutex_lock(&b->mu);
     reap_pool(b);
-    while(b->n_reap || b->reap_busy) pthread_cond_wait(&b->cv_reaped, &b->mu);
+    { const double t0 = now_s();
+      while(b->n_reap || b->reap_busy) pthread_cond_wait(&b->cv_reaped, &b->mu);
+      if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] reaper: %d slabs given back in %.3fs of its own thread's time, %d left in the pool, %d still referenced; waited for it %.3fs at the end\n", b->n_reaped, b->t_reap, b->n_pool, b->n_alloc - b->n_pool, now_s() - t0); }
     pthread_mutex_unlock(&b->mu);
 }
 static void reaper_stop(mdk_bam *b) {

@@ -664,19 +664,21 @@ __device__ __forceinline__ int32_t pair_of_many(const PairCtx X, MdkPairState &S
 
 // gapless runs of a CIGAR, one at a time (calculate_positions, overlaps.c:27-52)
 struct RunIt {
-    const uint8_t *cig; uint32_t c0, c1, c2; int n, k; int32_t x, y, lq;         // the first three operations travel with the read (PrepRead::cig)
-    int32_t rx, ry, rl; bool valid;
-    __device__ void init(const uint8_t *raw, const RdRegs &r) { cig = raw + r.cig_off(); c0 = r.q3.x; c1 = r.q3.y; c2 = r.q3.z; n = (int)r.ncig(); k = 0; x = r.pos(); y = 0; lq = (int32_t)r.lq(); valid = false; next(); }
-    __device__ void next() {
-        valid = false;
+    uint32_t cig_off, c0, c1, c2; int n, k; int32_t x, y, lq;         // the first three operations travel with the read (PrepRead::cig); the others are read where they lie
+    int32_t rx, ry, rl;                                               // the run at hand: rl > 0 while there is one
+    __device__ __forceinline__ bool valid() const { return rl > 0; }
+    __device__ void init(const uint8_t *raw, const RdRegs &r) { cig_off = r.cig_off(); c0 = r.q3.x; c1 = r.q3.y; c2 = r.q3.z; n = (int)r.ncig(); k = 0; x = r.pos(); y = 0; lq = (int32_t)r.lq(); rx = ry = rl = 0; next(raw); }
+    __device__ void stop() { rl = 0; }
+    __device__ void next(const uint8_t *raw) {
+        rl = 0;
         while(k < n) {
-            const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : ld32(cig + 4 * k); k++;
+            const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : ld32(raw + cig_off + 4 * k); k++;
             const int op = c & 15; const int32_t len = (int32_t)(c >> 4);
             if(op == 0 || op == 7 || op == 8) {
                 int32_t l = len; if(y + l > lq) l = lq - y;          // a CIGAR that consumes more bases than the record stores
                 const int32_t sx = x, sy = y;
                 x += len; y += len;
-                if(l > 0) { rx = sx; ry = sy; rl = l; valid = true; return; }
+                if(l > 0) { rx = sx; ry = sy; rl = l; return; }
             } else if(op == 1 || op == 4) y += len;
             else if(op == 2 || op == 3) x += len;
         }
@@ -692,16 +694,16 @@ __device__ __forceinline__ uint32_t read_segments(const PrepParams &P, const RdR
     const bool paired = has_mate && (((int)r.strand() - (int)m.strand()) & 1) == 0;       // overlaps.c:63-65
     RunIt own, oth;
     own.init(P.raw, r);
-    if(paired) oth.init(P.raw, m); else oth.valid = false;
+    if(paired) oth.init(P.raw, m); else oth.stop();
     const uint32_t sf = (r.strand() & 7) | ((r.flag() & 0x80) ? MDK_SF_READ2 : 0) | (is_second ? MDK_SF_SECOND : 0);
     const uint32_t msf = paired ? ((m.strand() & 7) | ((m.flag() & 0x80) ? MDK_SF_READ2 : 0)) : 0;
     uint32_t n = 0;
-    for(; own.valid; own.next()) {
+    for(; own.valid(); own.next(P.raw)) {
         int32_t cur = own.rx; const int32_t stop = own.rx + own.rl;
         while(cur < stop) {
             int32_t pe = stop; bool covered = false;
-            while(oth.valid && oth.rx + oth.rl <= cur) oth.next();
-            if(oth.valid) { if(oth.rx <= cur) { covered = true; if(oth.rx + oth.rl < pe) pe = oth.rx + oth.rl; } else if(oth.rx < pe) pe = oth.rx; }
+            while(oth.valid() && oth.rx + oth.rl <= cur) oth.next(P.raw);
+            if(oth.valid()) { if(oth.rx <= cur) { covered = true; if(oth.rx + oth.rl < pe) pe = oth.rx + oth.rl; } else if(oth.rx < pe) pe = oth.rx; }
             if(pe - cur > 65535) pe = cur + 65535;
             if((int64_t)pe > P.beg && (int64_t)cur < P.end) {
                 if(WRITE) {
@@ -729,9 +731,9 @@ static_assert(sizeof(md_seg) == 32 && offsetof(md_seg, len) == 16 && offsetof(md
 #define SEGS_SGPRS 96                 // cap on the kernel's scalar registers: 104 of them cost the eighth wavefront per SIMD; the excess spills into lanes of a VGPR (measured: 172.6 -> 162.6 us per launch, profiles/r05d_prep_variants.txt).  0: no cap
 #endif
 #if SEGS_SGPRS
-__global__ __launch_bounds__(PB) __attribute__((amdgpu_num_sgpr(SEGS_SGPRS))) void k_prep_segs(const PrepMulti M) {
+__global__ __launch_bounds__(PB, 8) __attribute__((amdgpu_num_sgpr(SEGS_SGPRS))) void k_prep_segs(const PrepMulti M) {
 #else
-__global__ __launch_bounds__(PB) void k_prep_segs(const PrepMulti M) {
+__global__ __launch_bounds__(PB, 8) void k_prep_segs(const PrepMulti M) {
 #endif
     __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64];
     // the workgroup's segments on their way out (32 bytes each; a workgroup of 256 records makes ~350); before that, the rare path's state
