@@ -80,7 +80,7 @@ static void see_own_device_only(void) {
     if(getenv("MDK_NO_RESTRICT") || getenv("ROCR_VISIBLE_DEVICES") || getenv("HIP_VISIBLE_DEVICES") || getenv("CUDA_VISIBLE_DEVICES") || getenv("GPU_DEVICE_ORDINAL")) return;
     if((w && atoi(w) > 1) || getenv("MDK_TORCHRUN") || d < 0) return;
     snprintf(num, sizeof(num), "%d", d);
-    setenv("ROCR_VISIBLE_DEVICES", num, 1); setenv("MDK_DEVICE", "0", 1);
+    setenv("ROCR_VISIBLE_DEVICES", num, 1); setenv("MDK_DEVICE_USER", num, 1); setenv("MDK_DEVICE", "0", 1);      /* (messages name the device as the user did) */
 }
 int main(int argc, char *argv[]) {
     if(argc == 1) { usage_main(); return 0; }

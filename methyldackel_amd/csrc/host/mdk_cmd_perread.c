@@ -123,7 +123,7 @@ int perRead_main(int argc, char *argv[]) {
     if(!p->started && pipeline_start(p)) { if(dth_ok) pthread_join(dth, NULL); if(dop.dev) md_dev_close(dop.dev); mdk_plan_close(p); return -5; }
     if(dth_ok) pthread_join(dth, NULL); else devopen_main(&dop);
     dev = dop.dev;
-    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `perRead`.\n", dop.device, dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(dop.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `perRead`.\n", user_device(dop.device), dop.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
     while(more || have[0] || have[1]) {       /* two chunks in flight, as in extract_main */
         int cur = k & 1, prev = cur ^ 1;

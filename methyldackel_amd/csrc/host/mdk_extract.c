@@ -230,7 +230,7 @@ int extract_main(int argc, char *argv[]) {
     t_dev = now_s() - T0;
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] resident at device ready %.0f MB\n", rss_mb(0));
     dev = dop.d.dev;
-    if(dop.d.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", dop.d.device, dop.d.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
+    if(dop.d.rc) { fprintf(stderr, "[mdk] cannot open MI355X device %d: %s\n[mdk] this build has no CPU path for `extract`.\n", user_device(dop.d.device), dop.d.err); mdk_plan_close(p); return MDK_RC_NODEVICE; }
     (void)md_dev_reserve_contigs(dev, p->bam->n_targets);
     if(p->dev_prep) { md_prep_cfg pc; mdk_plan_prep_cfg(p, &pc); md_dev_set_prep(dev, &pc); }
     if(p->dev_prep) mdk_plan_attach_device(p, dev);      /* from here on the device inflates pieces of the file too */

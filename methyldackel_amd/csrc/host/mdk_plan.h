@@ -148,6 +148,8 @@ MDK_LOCAL void pipeline_stop(mdk_plan *p);
 MDK_LOCAL int emitter_start(emitter *E, mdk_plan *p, int n_th);
 MDK_LOCAL int emitter_push(emitter *E, const mdk_chunk *c, const md_sites *s);
 MDK_LOCAL void emitter_stop(emitter *E);
+/* the device index as the user gave it (the command narrows the runtime's view to that device, which then is number 0: csrc/host/main.c) */
+static inline int user_device(int d) { const char *u = getenv("MDK_DEVICE_USER"); return u ? atoi(u) : d; }
 MDK_LOCAL int fast_exit_wanted(void);
 MDK_LOCAL void leave_fast(int ret);
 MDK_LOCAL void hip_warm_up(void);
