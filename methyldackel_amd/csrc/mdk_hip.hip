@@ -146,7 +146,6 @@ struct KParams {
     int packed;                   // 0: payload = blob + 4*off4, qualities after the sequence padded to 4 bytes (host-built batches);
                                   // 1: payload = blob + off4 (byte offset into the uploaded BAM records), qualities directly after the sequence
     int mbias; uint32_t *hist; int hist_lq;     // mbias: window-relative contexts at the chunk edges; histogram rows [q][16]; rows kept in LDS
-    uint32_t blob_bytes;          // bytes of `blob` that may be read (the staged dense kernel asks for 16 at a time and must not leave the buffer)
 };
 
 // kept query-index window [lo,hi) of a read after --OT-style and --nOT-style trimming (common.c:137-208)
@@ -404,114 +403,6 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
     }
 }
 
-// The same with the reads' bytes going THROUGH LDS.  Above, a lane asks for the four bytes of a site one by one: ~10 byte loads per lane and
-// segment, each instruction touching the lines of 8 reads, and a lane has the bytes of two sites in flight.  Here the 8 lanes of a segment
-// first bring the stretch of the read that the segment's sites on this tile lie in -- 128 quality bytes and the 64 bytes that hold their
-// bases, 16 + 8 bytes per lane, the partner's the same: four wide loads per lane -- into the wavefront's stage, and the sites then take
-// their bytes from there.  A third of the load instructions, every line asked for once per segment instead of once per few sites, and all of
-// a segment's bytes in flight at once.  QST_W bases per step; a segment that reaches further on the tile goes round again.
-#ifndef QW_STAGE
-#define QW_STAGE 0
-#endif
-#define QST_W 128                                  // bases per step
-#define QST_SEG (QST_W + QST_W / 2)                // bytes of one read's stretch: qualities, then the bytes of its bases
-#define QST_GROUP (2 * QST_SEG)                    // ... own and partner
-#define QST_WAVE ((64 / QL) * QST_GROUP)           // bytes of LDS per wavefront
-template <bool VARIANT>
-__device__ __forceinline__ void quarter_sites_staged(const KParams &P, const SegQ &s, int lane, const uint16_t *listC,
-                                                     uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv, uint8_t *wst) {
-    static_assert(QL == 8, "16 + 8 bytes per lane cover QST_W bases with 8 lanes");
-    const int sub = lane & (QL - 1), qbase = lane & (64 - QL);
-    const uint8_t *const blob = P.blob; const int minPhred = P.minPhred, tile = P.tile;
-    uint8_t *const g = wst + (lane >> 3) * QST_GROUP;     // this segment's stage: [0,128) qualities, [128,192) bases; the partner's behind
-    const uint32_t room = P.blob_bytes;
-#pragma unroll
-    for(int pass = 0; pass < (VARIANT ? 2 : 1); pass++) {
-        const bool callpass = pass == 0;
-        if(__ballot((s.w[pass] >> 18) != 0) == 0) continue;       // no lane of this wavefront has a site in this pass
-        for(int it = 0; it < QL; it++) {
-            const int owner = qbase | it;                          // the lane that prepared the segment this group works on now
-            const uint32_t w = (uint32_t)__shfl((int)s.w[pass], owner);
-            const int n = (int)(w >> 18);
-            if(__ballot(n != 0) == 0) continue;
-            const uint32_t oseq = (uint32_t)__shfl((int)s.oseq, owner), oqual = (uint32_t)__shfl((int)s.oqual, owner), wlen = (uint32_t)__shfl((int)s.wlen, owner);
-            const int cq = __shfl(s.cq, owner), lo = __shfl(s.lo, owner);
-            const bool partner = (w >> 4) & 1;
-            uint32_t mseq = 0, mqual = 0, mwlen = 0; int mcq = 0, mlo = 0;
-            if(__ballot(partner && n != 0) != 0) {
-                mseq = (uint32_t)__shfl((int)s.mseq, owner); mqual = (uint32_t)__shfl((int)s.mqual, owner); mwlen = (uint32_t)__shfl((int)s.mwlen, owner);
-                mcq = __shfl(s.mcq, owner); mlo = __shfl(s.mlo, owner);
-            }
-            const int strand = w & 7; const bool odd = strand & 1, second = (w >> 3) & 1;
-            const int badrs = strand == 0 ? 6 : (odd ? 4 : 2);      // --keepStrand: region strand codes this read is invisible at (bed.c:56-64)
-            const uint16_t *list = listC + ((w >> 5) & 0x1fff);
-            const int mcode = odd ? 2 : 4, ucode = odd ? 8 : 1;
-            bool anyok = false;
-            int j0 = 0;                                            // first site of the segment not done yet (the same in the 8 lanes of a group)
-            while(__ballot(j0 < n) != 0) {
-                // the stretch: QST_W query positions from the first site not done yet
-                // (from an even position: 128 positions are then exactly 64 bytes of bases; own and partner may differ in parity, so a stretch
-                // takes the sites less than QST_W - 1 positions from its first)
-                const int l_first = j0 < n ? (int)(list[j0] & 0x1fffu) : 0, qw0 = (l_first + cq) & ~1, mqw0 = (l_first + mcq) & ~1;
-                if(j0 < n) {
-                    uint4 a = make_uint4(0, 0, 0, 0), ma = a; uint2 b = make_uint2(0, 0), mb = b;
-                    const uint32_t qa = oqual + (uint32_t)qw0 + 16u * (uint32_t)sub, sa = oseq + (uint32_t)(qw0 >> 1) + 8u * (uint32_t)sub;
-                    if(qw0 >= 0 && qa + 16u <= room) __builtin_memcpy(&a, blob + qa, 16);
-                    if(qw0 >= 0 && sa + 8u <= room) __builtin_memcpy(&b, blob + sa, 8);
-                    if(partner && mqw0 >= 0) {
-                        const uint32_t mqa = mqual + (uint32_t)mqw0 + 16u * (uint32_t)sub, msa = mseq + (uint32_t)(mqw0 >> 1) + 8u * (uint32_t)sub;
-                        if(mqa + 16u <= room) __builtin_memcpy(&ma, blob + mqa, 16);
-                        if(msa + 8u <= room) __builtin_memcpy(&mb, blob + msa, 8);
-                    }
-                    *(uint4 *)(g + 16 * sub) = a; *(uint2 *)(g + QST_W + 8 * sub) = b;
-                    if(partner) { *(uint4 *)(g + QST_SEG + 16 * sub) = ma; *(uint2 *)(g + QST_SEG + QST_W + 8 * sub) = mb; }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the group's lanes read what their neighbours wrote: same wavefront, in order)
-                __builtin_amdgcn_wave_barrier();
-                // the sites inside the stretch, two adjacent list entries per lane and step, 16 consecutive sites per group
-                int jn = n;                                                   // first site beyond the stretch
-                if(j0 < n && (int)(list[n - 1] & 0x1fffu) - l_first >= QST_W - 1) {
-                    int a2 = j0, b2 = n;                                      // (rare: a segment longer than a stretch)
-                    while(a2 < b2) { const int mid = (a2 + b2) >> 1; if((int)(list[mid] & 0x1fffu) - l_first < QST_W - 1) a2 = mid + 1; else b2 = mid; }
-                    jn = a2;
-                }
-                for(int j = j0 + 2 * sub; j < jn; j += 2 * QL) {
-                    uint32_t e01; __builtin_memcpy(&e01, list + j, 4);             // (the second entry is whatever follows the list when j + 1 == n)
-                    const uint32_t e0 = e01 & 0xffffu, e1 = e01 >> 16;
-                    const int l0 = (int)(e0 & 0x1fffu), l1 = (int)(e1 & 0x1fffu);
-                    const bool ok0 = !((badrs >> (e0 >> 13)) & 1), ok1 = j + 1 < jn && !((badrs >> (e1 >> 13)) & 1);
-                    const int q0 = l0 + cq, q1 = l1 + cq, mq0 = l0 + mcq, mq1 = l1 + mcq;
-                    uint32_t sb0 = 0xff, qb0 = 0, msb0 = 0xff, mqb0 = 0, sb1 = 0xff, qb1 = 0, msb1 = 0xff, mqb1 = 0;   // a trimmed base needs no byte: it reads as N with quality 0
-                    if(ok0 && (unsigned)(q0 - lo) < wlen) { sb0 = g[QST_W + ((q0 >> 1) - (qw0 >> 1))]; qb0 = g[q0 - qw0]; }
-                    if(ok0 && partner && (unsigned)(mq0 - mlo) < mwlen) { msb0 = g[QST_SEG + QST_W + ((mq0 >> 1) - (mqw0 >> 1))]; mqb0 = g[QST_SEG + (mq0 - mqw0)]; }
-                    if(ok1 && (unsigned)(q1 - lo) < wlen) { sb1 = g[QST_W + ((q1 >> 1) - (qw0 >> 1))]; qb1 = g[q1 - qw0]; }
-                    if(ok1 && partner && (unsigned)(mq1 - mlo) < mwlen) { msb1 = g[QST_SEG + QST_W + ((mq1 >> 1) - (mqw0 >> 1))]; mqb1 = g[QST_SEG + (mq1 - mqw0)]; }
-                    auto use = [&](const bool ok, const int l, const int q, const int mq, const uint32_t sb, const uint32_t qb, const uint32_t msb, const uint32_t mqb) {
-                        if(!ok) return;
-                        const int bq = (int)((sb >> ((~q & 1) << 2)) & 15u); int ql = (int)qb;
-                        if(partner) { const int mb2 = (int)((msb >> ((~mq & 1) << 2)) & 15u); ql = resolve_own(second, bq, ql, mb2, (int)mqb); }
-                        if(callpass) {
-                            if(ql >= minPhred && (bq == mcode || bq == ucode)) atomicAdd(&cm[(bq == ucode ? tile : 0) + l], 1u);     // cu = cm + tile
-                        } else if(VARIANT) {
-                            if(ql >= minPhred) {
-                                atomicAdd(&co[l], 1u);
-                                if(odd ? (bq != 4 && bq != 15) : (bq != 2 && bq != 15)) atomicAdd(&cv[l], 1u);
-                            }
-                        }
-                    };
-                    use(ok0, l0, q0, mq0, sb0, qb0, msb0, mqb0);
-                    use(ok1, l1, q1, mq1, sb1, qb1, msb1, mqb1);
-                    anyok = anyok || ok0 || ok1;
-                }
-                j0 = jn;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the stage is read out before the next stretch overwrites it)
-                __builtin_amdgcn_wave_barrier();
-            }
-            if(callpass && strand == 0 && anyok) atomicExch(P.err, 1);        // a read of unknown strand reached a call; reference: assert(strand != 0) (common.c:122-125)
-        }
-    }
-}
-
 // barrier that orders LDS traffic only (does not drain this wave's outstanding global loads)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -624,11 +515,7 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
             md_seg g = g0;
             if(r0 != first) { g.rpos = 0x7fffffff; g.len = 0; if(r0 + tid < last) g = P.seg[r0 + tid]; }
             const SegQ sq = seg_setup<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, nG, topC, topG);
-#if QW_STAGE
-            quarter_sites_staged<VARIANT>(P, sq, lane, listC, cm, cu, co, cv, (uint8_t *)(lds + (VARIANT ? 5 : 3) * TILE) + wave * QST_WAVE);       // (behind the counters and the two lists: 4 + 2 x 2 bytes per position, twice the counters with VARIANT)
-#else
             quarter_sites<VARIANT>(P, sq, lane, listC, cm, cu, co, cv);
-#endif
         }
     } else {
         if(first + tid < last) lane_seg<VARIANT>(P, g0, (int)T0, (int)T1, listC, nC, listG, nG, cm, cu, co, cv);
@@ -682,7 +569,7 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
 }
 
 template <bool VARIANT, bool QW>
-__global__ __launch_bounds__(WG, (QW && QW_STAGE) ? 6 : PILEUP_WAVES) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
+__global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
     const int b = blockIdx.x;
     const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
     if(t >= P.ntiles) return;
@@ -695,7 +582,7 @@ __global__ __launch_bounds__(WG, (QW && QW_STAGE) ? 6 : PILEUP_WAVES) void k_pil
 // kernel arguments; a workgroup finds its interval from the tile prefix.
 struct KMulti { int n, nper; int tstart[MAXM + 1]; KParams P[MAXM]; };
 template <bool VARIANT, bool QW>
-__global__ __launch_bounds__(WG, (QW && QW_STAGE) ? 6 : PILEUP_WAVES) void k_pileup_multi(const KMulti M) {      // (the staged dense kernel holds 42 KB of LDS: three workgroups per CU, 80 VGPRs)
+__global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup_multi(const KMulti M) {
     const int b = blockIdx.x;
     const int tg = (b & 7) * M.nper + (b >> 3);
     if(tg >= M.tstart[M.n]) return;
@@ -950,7 +837,6 @@ extern "C" int md_dev_warm(int device) {
 }
 
 static int fixed_lds(int tile, bool variant) { return tile * ((variant ? 16 : 8) + 4); }
-int pileup_lds(const md_dev *h, int tile) { return fixed_lds(tile, h->variant) + ((QW_STAGE && h->qw) ? WAVES * QST_WAVE : 0); }       // + the dense kernel's stage
 
 extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     if(!cfg || !out) return fail(MDK_ERR_ARG, "md_dev_open", hipSuccess);
@@ -978,10 +864,10 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     h->n_slots = cfg->n_slots > 0 ? cfg->n_slots : 2;
     h->variant = cfg->minOppositeDepth > 0;
     h->qw = (cfg->keepCHG || cfg->keepCHH) && !getenv("MDK_NO_QW");       // dense contexts: a quarter of a wavefront per segment (MDK_NO_QW: the lane-per-segment kernel, for comparison)
-    while(pileup_lds(h, h->tile) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
-    if(pileup_lds(h, h->tile) > 65536) {    // more than the default dynamic-LDS window: opt in
-        HIPCHK(hipFuncSetAttribute(pileup_fn(h->variant, h->qw), hipFuncAttributeMaxDynamicSharedMemorySize, pileup_lds(h, h->tile)));
-        HIPCHK(hipFuncSetAttribute(pileup_multi_fn(h->variant, h->qw), hipFuncAttributeMaxDynamicSharedMemorySize, pileup_lds(h, h->tile)));
+    while(fixed_lds(h->tile, h->variant) > LDS_LIMIT - 1024 && h->tile > WG) h->tile -= WG;       // stay inside 160 KiB of LDS
+    if(fixed_lds(h->tile, h->variant) > 65536) {    // more than the default dynamic-LDS window: opt in
+        HIPCHK(hipFuncSetAttribute(pileup_fn(h->variant, h->qw), hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, h->variant)));
+        HIPCHK(hipFuncSetAttribute(pileup_multi_fn(h->variant, h->qw), hipFuncAttributeMaxDynamicSharedMemorySize, fixed_lds(h->tile, h->variant)));
     }
     h->slots.resize(h->n_slots);
     if(h->d_status.need((size_t)h->n_slots) || h->h_status.need((size_t)h->n_slots)) return MDK_ERR_NOMEM;
@@ -1126,8 +1012,8 @@ extern "C" int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) {
     const int ntiles = (int)((span + TILE - 1) / TILE);
     if(s->h_tiles.need((size_t)(ntiles > 0 ? ntiles : 1))) return MDK_ERR_NOMEM;
     build_tiles(b, TILE, s->h_tiles.p, ntiles);
-    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = pileup_lds(h, TILE);
-    s->read_bytes = b->algo_bytes; s->blob_bytes = (uint64_t)b->blob_bytes;
+    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = fixed_lds(TILE, h->variant);
+    s->read_bytes = b->algo_bytes;
     size_t ns = (size_t)b->n_segs, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     if(s->d_seg_in.need(ns + 1) || s->d_blob.need((size_t)b->blob_bytes + 64)) return MDK_ERR_NOMEM;
     if(s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
@@ -1157,7 +1043,6 @@ extern "C" int md_dev_bind_output(md_dev *h, int slot, void *d_site, void *d_var
 static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
     memset(&P, 0, sizeof(P));
     P.seg = s->d_seg_in.p; P.blob = s->raw_layout ? s->d_raw.p : s->d_blob.p; P.packed = s->raw_layout ? 1 : 0;
-    P.blob_bytes = (uint32_t)((s->raw_layout ? s->raw_bytes : s->blob_bytes) + 48);      // (the buffers are allocated 64 bytes longer than what they hold)
     P.ctxcode = h->refcode[s->tid]; P.reflen = h->reflen[s->tid];
     P.beg = s->beg; P.end = s->end; P.tile = s->tile; P.ntiles = s->ntiles; P.nper = (s->ntiles + 7) / 8;
     P.tiles = s->d_tiles.p;

@@ -98,7 +98,7 @@ struct Slot {
     hipStream_t run = nullptr; bool fresh = false;       // run: the stream the latest pileup launch went to; fresh: work queued on `stream` that no launch has been ordered after yet
     DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRead> d_prd; DBuf<uint32_t> d_aidx; HBuf<uint32_t> h_aidx; DBuf<int32_t> d_hnext; Ref<PrepCounters> d_pcnt;
     DBuf<uint8_t> d_zero;              // what a preparation launch starts from zeroed: name table (keys, heads), per-workgroup counts, tickets
-    uint32_t hmask = 0; int pr_nrec = 0; uint64_t raw_bytes = 0, blob_bytes = 0; bool raw_layout = false; int64_t woff = 0, wlen = 0;
+    uint32_t hmask = 0; int pr_nrec = 0; uint64_t raw_bytes = 0; bool raw_layout = false; int64_t woff = 0, wlen = 0;
     bool prep_pending = false;         // records uploaded, preparation kernels not yet queued (they go with the launch, several chunks at a time)
     bool mb_pending = false;           // mbias: the chunk's preparation is queued, its histogram kernel not yet (it waits for what the preparation reports: the longest read)
     DBuf<md_pr_read> d_pr; DBuf<uint32_t> d_cig; DBuf<md_pr_count> d_prc; HBuf<md_pr_count> h_prc; int pr_n = -1;      // perRead
@@ -172,7 +172,6 @@ MDK_HIDDEN void mdk_prof_add(int site, double seconds);
 MDK_HIDDEN double mdk_now();
 struct ProfScope { int site; double t0; ProfScope(int s) : site(s), t0(mdk_prof_on() ? mdk_now() : 0.0) {} ~ProfScope() { if(mdk_prof_on()) mdk_prof_add(site, mdk_now() - t0); } };
 MDK_HIDDEN Slot *get_slot(md_dev *h, int slot);
-MDK_HIDDEN int pileup_lds(const md_dev *h, int tile);      // dynamic LDS of a pileup launch
 MDK_HIDDEN void host_block_ensure_registered(const void *ptr);      // a huge-page staging block is registered with the runtime at its first upload
 MDK_HIDDEN int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on = nullptr);
 MDK_HIDDEN int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cross_sync);

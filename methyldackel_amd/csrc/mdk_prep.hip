@@ -67,6 +67,9 @@ struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 // (2 MB) and ticket counters stay in its L2 instead of every L2 thrashing over all eight.  WHICH records of the chunk a workgroup
 // takes is decided by the ticket it draws, not by its index; the launch holds at least as many workgroups per chunk as the chunk has
 // tickets (enqueue_prep_group), and a workgroup that draws a ticket beyond them leaves.
+#ifndef PREP_WIN_AUX
+#define PREP_WIN_AUX 0                // cache policy of the window's loads (2 = nt: the record stream is read once and should not push the name table out of the caches)
+#endif
 #ifndef PREP_EXP_NOCAS
 #define PREP_EXP_NOCAS 0
 #endif
@@ -375,11 +378,7 @@ __device__ __forceinline__ int scan_record(const PrepParams &P, const V &v, cons
 #ifndef RAWWIN
 #define RAWWIN 18944
 #endif
-#if PREP_STAGE == 1
 #define RAWWIN_LDS (RAWWIN + 32)                      // (+ slack for the word reads of a field that ends at the window's end)
-#else
-#define RAWWIN_LDS 1024                               // (EXPERIMENT PREP_STAGE=2: a scratch row the stretch is loaded through, only to bring it into the L2; PREP_STAGE=0: unused)
-#endif
 // Where the lane's record starts and where the next one does: two coalesced loads, issued together, before anything depends on them -- the
 // window's bounds are then lane 0's start and lane 63's end, and the lane needs no further load before it can take its record apart.
 struct RecAt { uint32_t o, onext; };
@@ -391,19 +390,7 @@ __device__ __forceinline__ RecAt rec_at(const PrepParams &P, const int i) {
 // the wavefront's stretch of the record stream -> LDS, 1 KiB per instruction, straight from HBM (global_load_lds: no registers in between)
 __device__ __forceinline__ void stage_window(const PrepParams &P, const int i0, const RecAt &A, const int lane, uint8_t *const win, uint32_t &wbase, uint32_t &wlen) {
     wbase = 0; wlen = 0;
-#if PREP_STAGE == 2
-    {   // EXPERIMENT: the wavefront's stretch of the record stream is read once, coalesced, and thrown away (every KiB over the same scratch
-        // row) -- it is then in the XCD's L2 when the lanes read their records from it one by one, and no LDS is held for it
-        const uint32_t first = (uint32_t)__shfl((int)A.o, 0), last = (uint32_t)__shfl((int)A.onext, 63);
-        if(i0 < P.n_rec) {
-            const uint64_t b0 = first & ~15ull, b1 = i0 + 64 <= P.n_rec ? (uint64_t)last : P.raw_bytes;
-            const uint64_t lim = (P.raw_bytes + 15) & ~15ull;
-            const uint8_t *src = P.raw + b0 + 16 * lane;
-            for(uint64_t k = b0; k < b1 && k + 1024 <= lim; k += 1024, src += 1024) __builtin_amdgcn_global_load_lds((const void *)src, (__attribute__((address_space(3))) void *)win, 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-#elif PREP_STAGE
+#if PREP_STAGE
     const uint32_t first = (uint32_t)__shfl((int)A.o, 0), last = (uint32_t)__shfl((int)A.onext, 63);       // (every lane takes part)
     if(i0 < P.n_rec) {
         const uint64_t b0 = first, b1 = i0 + 64 <= P.n_rec ? (uint64_t)last : P.raw_bytes;
@@ -412,7 +399,7 @@ __device__ __forceinline__ void stage_window(const PrepParams &P, const int i0, 
         if((uint64_t)wbase + l > ((P.raw_bytes + 15) & ~15ull)) l = (uint64_t)wbase < ((P.raw_bytes + 15) & ~15ull) ? ((P.raw_bytes + 15) & ~15ull) - wbase : 0;       // (the buffer is 64 bytes longer than the records)
         wlen = (uint32_t)l;
         const uint8_t *src = P.raw + wbase + 16 * lane;
-        for(uint32_t k = 0; k < wlen; k += 1024) if(k + 16 * lane < wlen) __builtin_amdgcn_global_load_lds((const void *)(src + k), (__attribute__((address_space(3))) void *)(win + k), 16, 0, 0);
+        for(uint32_t k = 0; k < wlen; k += 1024) if(k + 16 * lane < wlen) __builtin_amdgcn_global_load_lds((const void *)(src + k), (__attribute__((address_space(3))) void *)(win + k), 16, 0, PREP_WIN_AUX);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_wave_barrier();
@@ -1043,7 +1030,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     const int64_t span = b->end - b->beg; const int TILE = h->tile;
     const int ntiles = (int)((span + TILE - 1) / TILE), n = b->n_records, nb = (n + PB - 1) / PB;
     s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->woff = b->woff; s->wlen = b->wlen; s->uploaded = false; s->launched = false;
-    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = pileup_lds(h, TILE);
+    s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = TILE * ((h->variant ? 16 : 8) + 4);
     s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->n_segs = -1; s->n_reads = -1; s->read_bytes = 0;
     const size_t nn = (size_t)n + 1, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
