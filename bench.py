@@ -531,11 +531,11 @@ def main():
             (t_all, ts_all), d_all = run_oracle(sp, "allcore", best["threads"], best["chunk_size"], 3)
             same = all((d_single / f).read_bytes() == (d_all / f).read_bytes() for f in os.listdir(d_single))
             calls = calls_of(d_single)
-            # The wall clock on top is the one with the TEARDOWN IN PLACE (MDK_NO_DETACH=1): the process that did the work is the process the caller
-            # waits for -- the CPU baseline's protocol.  By default the command does its work in a child and returns when the child reports its
-            # outputs closed (csrc/host/main.c); that figure is reported next to it as `detached`.
-            t_g, ts_g, d_g, ok_g, in_g = run_ours(sp, "inplace", {"MDK_NO_DETACH": "1"})
-            t_gd, ts_gd, _, ok_gd, _ = run_ours(sp, "default", {})
+            # The wall clock on top is the command as it runs by default: the process that did the work is the process the caller waits for, its
+            # teardown included -- the CPU baseline's protocol.  With MDK_DETACH=1 the command does its work in a child and returns when the child
+            # reports its outputs closed (csrc/host/main.c); that figure is reported next to it as `detached`.
+            t_g, ts_g, d_g, ok_g, in_g = run_ours(sp, "inplace", {})
+            t_gd, ts_gd, _, ok_gd, _ = run_ours(sp, "detached", {"MDK_DETACH": "1"})
             ident = ok_g and ok_gd and all((d_g / f).read_bytes() == (d_single / f).read_bytes() for f in os.listdir(d_single))
             result["cpu_baseline"] = {"value": calls / t_all, "unit": "CpG calls/s", "cores": best["threads"], "kind": "port",
                                       "sample": f"oracle/mdk_oracle extract -@ {best['threads']} --chunkSize {best['chunk_size']} -- the fastest of a sweep over worker threads x chunk size on this box's {ncores} hardware threads "
@@ -548,9 +548,9 @@ def main():
                                  "speedup_vs_cpu_baseline": t_all / t_g, "speedup_vs_single_thread": t_single / t_g, "identical_to_oracle": bool(ident),
                                  "inside_process_runs": in_g, "bam_bytes": os.path.getsize(str(sp) + ".bam"),
                                  "detached": {"seconds": t_gd, "runs": ts_gd, "speedup_vs_cpu_baseline": t_all / t_gd,
-                                              "note": "the command's default: its work is done by a child, the command returns when the child reports its outputs closed and the child's address-space teardown goes on behind the caller"},
+                                              "note": "MDK_DETACH=1 (opt-in): the command's work is done by a child, the command returns when the child reports its outputs closed and the child's address-space teardown goes on behind the caller"},
                                  "note": "`MethylDackel extract` of this build on the same file, one process (start-up, HIP init, inflate on the host's threads and -- once the device is up -- on the device, "
-                                         "chunk preparation, H2D, kernels, D2H, text, teardown).  `seconds` is the caller's wall clock around a process that tears its own address space down (MDK_NO_DETACH=1); "
+                                         "chunk preparation, H2D, kernels, D2H, text, teardown).  `seconds` is the caller's wall clock around a process that tears its own address space down (the default); "
                                          "inside_process_runs = the command's own clock from entry to outputs closed"}
             # the device inflate on the record: the 32 Mb sample's BGZF members through md_piece_* (tools/piece_bench: whole file in 64 MB pieces, three in
             # flight, and the kernels alone on the largest resident piece, HIP events)
@@ -584,9 +584,9 @@ def main():
                 cfg_l = {"threads": best["threads"], "chunk_size": best["chunk_size"]}
                 if t_alt < t_la:
                     (t_la, ts_la), d_la = run_oracle(spl, "large_alt3", alt[0], alt[1], 2); ts_la = ts_la + [t_alt]; t_la = statistics.median(ts_la); cfg_l = {"threads": alt[0], "chunk_size": alt[1]}
-                t_lg, ts_lg, d_lg, ok_lg, in_lg = run_ours(spl, "large_inplace", {"MDK_NO_DETACH": "1"}, runs=5)
-                t_ld, ts_ld, _, ok_ld, _ = run_ours(spl, "large_default", {}, runs=3)
-                t_lq, ts_lq, _, ok_lq, _ = run_ours(spl, "large_queue", {"MDK_NO_DETACH": "1"}, runs=4, gap=0.0)
+                t_lg, ts_lg, d_lg, ok_lg, in_lg = run_ours(spl, "large_inplace", {}, runs=5)
+                t_ld, ts_ld, _, ok_ld, _ = run_ours(spl, "large_detached", {"MDK_DETACH": "1"}, runs=3)
+                t_lq, ts_lq, _, ok_lq, _ = run_ours(spl, "large_queue", {}, runs=4, gap=0.0)
                 ident_l = ok_lg and ok_ld and ok_lq and all((d_lg / f).read_bytes() == (d_la / f).read_bytes() for f in os.listdir(d_la))
                 calls_l = calls_of(d_la)
                 bam_l = os.path.getsize(str(spl) + ".bam")
@@ -595,10 +595,10 @@ def main():
                                        "speedup_vs_cpu_all_cores": t_la / t_lg, "identical_to_oracle": bool(ident_l),
                                        "inside_process_runs": in_lg, "bam_GBps": bam_l / t_lg / 1e9,
                                        "detached": {"seconds": t_ld, "runs": ts_ld, "speedup_vs_cpu_all_cores": t_la / t_ld,
-                                                    "note": "the command's default (work in a child, return at outputs closed, teardown behind the caller): csrc/host/main.c detach_teardown, as the mold linker does"},
+                                                    "note": "MDK_DETACH=1 (opt-in: work in a child, return at outputs closed, teardown behind the caller): csrc/host/main.c detach_teardown, as the mold linker does"},
                                        "queue": {"seconds_per_sample": t_lq, "runs": ts_lq, "speedup_vs_cpu_all_cores": t_la / t_lq,
                                                  "note": "four runs back to back with no pause between them, teardown in place: what a queue of samples gets per sample"},
-                                       "protocol": "CPU: the sweep's best setting and one alternative, the faster of them, median; this build: 5 runs, median; the caller's wall clock around the command with the teardown IN PLACE (MDK_NO_DETACH=1), each run started one second after the previous command's last process has gone"}
+                                       "protocol": "CPU: the sweep's best setting and one alternative, the faster of them, median; this build: 5 runs, median; the caller's wall clock around the command with the teardown in place (the default), each run started one second after the previous command's last process has gone"}
                 if args.xl_copies > 1:
                     # a sample large enough that start-up and exit are a small part of the run: K copies of the large sample as K contigs (tools/mdk_replicate)
                     spx = data / f"xl_{args.large_sample_length}x{args.xl_copies}_{args.coverage}"
@@ -607,8 +607,8 @@ def main():
                         subprocess.run([str(REPO / "tools/_build/mdk_replicate"), str(spl), str(spx), str(args.xl_copies)], check=True, capture_output=True, timeout=600)
                         log(f"[bench] xl sample written in {time.time() - t1:.1f} s")
                     (t_xa, ts_xa), d_xa = run_oracle(spx, "xl_allcore", cfg_l["threads"], cfg_l["chunk_size"], 1)
-                    t_xg, ts_xg, d_xg, ok_xg, in_xg = run_ours(spx, "xl_inplace", {"MDK_NO_DETACH": "1"}, runs=3)
-                    t_xd, ts_xd, _, ok_xd, _ = run_ours(spx, "xl_default", {}, runs=2)
+                    t_xg, ts_xg, d_xg, ok_xg, in_xg = run_ours(spx, "xl_inplace", {}, runs=3)
+                    t_xd, ts_xd, _, ok_xd, _ = run_ours(spx, "xl_detached", {"MDK_DETACH": "1"}, runs=2)
                     ident_x = ok_xg and ok_xd and all((d_xg / f).read_bytes() == (d_xa / f).read_bytes() for f in os.listdir(d_xa))
                     calls_x = calls_of(d_xa); bam_x = os.path.getsize(str(spx) + ".bam")
                     result["e2e_xl"] = {"sample_bp": args.large_sample_length * args.xl_copies, "contigs": args.xl_copies, "bam_bytes": bam_x, "cpg_calls": calls_x,
@@ -634,8 +634,8 @@ def main():
                             subprocess.run([str(REPO / "tools/_build/mdk_replicate"), str(spl), str(spy), str(args.xxl_copies)], check=True, capture_output=True, timeout=900)
                             log(f"[bench] xxl sample written in {time.time() - t1:.1f} s under {xdir}")
                             (t_ya, ts_ya), d_ya = run_oracle(spy, "xxl_allcore", cfg_l["threads"], cfg_l["chunk_size"], 1)
-                            t_yg, ts_yg, d_yg, ok_yg, in_yg = run_ours(spy, "xxl_inplace", {"MDK_NO_DETACH": "1"}, runs=2)
-                            t_yd, ts_yd, _, ok_yd, _ = run_ours(spy, "xxl_default", {}, runs=1)
+                            t_yg, ts_yg, d_yg, ok_yg, in_yg = run_ours(spy, "xxl_inplace", {}, runs=2)
+                            t_yd, ts_yd, _, ok_yd, _ = run_ours(spy, "xxl_detached", {"MDK_DETACH": "1"}, runs=1)
                             ident_y = ok_yg and ok_yd and all((d_yg / f).read_bytes() == (d_ya / f).read_bytes() for f in os.listdir(d_ya))
                             calls_y = calls_of(d_ya); bam_y = os.path.getsize(str(spy) + ".bam")
                             result["e2e_xxl"] = {"sample_bp": args.large_sample_length * args.xxl_copies, "contigs": args.xxl_copies, "bam_bytes": bam_y, "cpg_calls": calls_y, "storage": str(xdir),

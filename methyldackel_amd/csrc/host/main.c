@@ -19,13 +19,14 @@ static void usage_main(void) {
                     "    perRead  Generate a per-read methylation summary (GPU).\n"
                     "    mergeContext   Combine single Cytosine metrics from 'MethylDackel extract' into per-CpG/CHG metrics.\n");
 }
-/* A finished run still holds gigabytes of pinned staging blocks, device memory and queues, and the kernel takes ~0.2 s to take that address space
+/* A finished run still holds pinned staging blocks, device memory and queues, and the kernel takes ~0.2 s to take that address space
  * down (measured: tools/exit_stack_probe.py -- between _exit and the moment the parent can reap, one task is left, the one inside exit_mmap) --
- * AFTER every output is complete and closed.  So, as the mold linker does, the work is done by a child and this process, which holds nothing,
- * waits only for the child's word that its outputs are closed: it returns the child's code at once and the teardown goes on behind it.  The
+ * AFTER every output is complete and closed.  With MDK_DETACH=1, as the mold linker does, the work is done by a child and this process, which holds
+ * nothing, waits only for the child's word that its outputs are closed: it returns the child's code at once and the teardown goes on behind it.  The
  * child says so in leave (below; mdk_extract.c leave_fast) through the descriptor MDK_DONE_FD names, having closed its standard streams first so
  * that a caller reading our stdout/stderr through pipes sees their end when we return.  A child that dies without a word is waited for and
- * its fate is ours.  MDK_NO_DETACH=1, or a profiler in the environment (the tools follow the process they started), runs everything in place. */
+ * its fate is ours.  This is OPT-IN (MDK_DETACH=1): by default -- and under a profiler, which follows the process it started -- everything runs in
+ * place, and the wall clock a caller sees includes the teardown, as the CPU path's does. */
 static pid_t g_child = -1;
 static int open_null(void) { return open("/dev/null", O_RDWR); }
 static void forward_signal(int sig) { if(g_child > 0) kill(g_child, sig); }
@@ -50,7 +51,7 @@ static void say_done(int rc) {              /* the child's last act before it le
 static void detach_teardown(void) {
     int pfd[2]; pid_t c; char num[16]; const pid_t me = getpid();
     static const int sigs[] = {SIGINT, SIGTERM, SIGHUP, SIGQUIT, SIGUSR1, SIGUSR2};
-    if(getenv("MDK_NO_DETACH") || profiler_present() || pipe(pfd)) return;
+    if(!getenv("MDK_DETACH") || getenv("MDK_NO_DETACH") || profiler_present() || pipe(pfd)) return;      /* opt-in since round 5: by default the process that does the work is the one the caller waits for */
     fflush(stdout); fflush(stderr);
     c = fork();
     if(c < 0) { close(pfd[0]); close(pfd[1]); return; }

@@ -68,7 +68,7 @@ struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 // takes is decided by the ticket it draws, not by its index; the launch holds at least as many workgroups per chunk as the chunk has
 // tickets (enqueue_prep_group), and a workgroup that draws a ticket beyond them leaves.
 #ifndef PREP_WIN_AUX
-#define PREP_WIN_AUX 0                // cache policy of the window's loads (2 = nt: the record stream is read once and should not push the name table out of the caches)
+#define PREP_WIN_AUX 2                // cache policy of the window's loads (2 = nt: the record stream is read once and should not push the name table out of the caches)
 #endif
 #ifndef PREP_EXP_NOCAS
 #define PREP_EXP_NOCAS 0

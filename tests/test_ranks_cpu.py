@@ -162,11 +162,11 @@ def test_claimed_chunks_balance_the_work_not_the_count(data, tmp_path):
 
 def test_command_hands_its_teardown_to_a_child_and_stays_the_same_command(data, tmp_path):
     """main.c detach_teardown: the work is done by a child whose word "outputs closed" lets the command return; the command's outputs, return code
-    and fate under a signal are what they are with MDK_NO_DETACH=1"""
+    and fate under a signal are what they are in place (the default; the child is opt-in: MDK_DETACH=1)"""
     import signal, time
     args = [str(data / "s.fa"), str(data / "s.bam"), "-@", "4", "--chunkSize", "20000"]
     od = oracle(tmp_path, args)
-    for tag, extra in (("detached", {}), ("inplace", {"MDK_NO_DETACH": 1})):
+    for tag, extra in (("detached", {"MDK_DETACH": 1}), ("inplace", {})):
         gd = tmp_path / tag; gd.mkdir()
         r = mdk.run_cli(args + ["-o", "out"], cwd=gd, env=standin_env(tmp_path, **extra))
         assert r.returncode == 0 and "[mdk main] leaving" in r.stderr, r.stderr[-800:]      # (stderr through a pipe: complete, and at its end when the command returns)
@@ -175,7 +175,7 @@ def test_command_hands_its_teardown_to_a_child_and_stays_the_same_command(data, 
         assert bad.returncode == 252 and "Couldn't open" in bad.stderr
     # a signal to the command reaches the process that does the work: nothing of it is left behind
     gd = tmp_path / "killed"; gd.mkdir()
-    e = dict(os.environ); e.update(standin_env(tmp_path, MDK_STANDIN_US_PER_KREC=3000000)); e["MDK_NO_RANKS"] = "1"
+    e = dict(os.environ); e.update(standin_env(tmp_path, MDK_STANDIN_US_PER_KREC=3000000, MDK_DETACH=1)); e["MDK_NO_RANKS"] = "1"
     mark = str(gd / "out_marker")
     p = subprocess.Popen([str(mdk.CLI), "extract"] + args + ["-o", mark], cwd=gd, env=e, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     def workers():

@@ -54,15 +54,15 @@ for name, s in (("large", sp),) + ((("xl", sx),) if copies > 1 else ()):
     t = time.perf_counter()
     subprocess.run([str(REPO / "oracle/_build/mdk_oracle"), "extract", str(s) + ".fa", str(s) + ".bam", "-@", "64", "--chunkSize", "50000", "-o", "gpu"], cwd=D, check=True, capture_output=True)
     cpu = time.perf_counter() - t
-    a = ours(s, "extract", ["-o", "gpu"], {"MDK_NO_DETACH": "1"}, 3)
-    b = ours(s, "extract", ["-o", "gpu"], {}, 3)
+    a = ours(s, "extract", ["-o", "gpu"], {}, 3)
+    b = ours(s, "extract", ["-o", "gpu"], {"MDK_DETACH": "1"}, 3)
     ident = all((D / "out" / f"gpu_{c}.bedGraph").read_bytes() == (D / f"gpu_{c}.bedGraph").read_bytes() for c in ("CpG",))
-    q = ours(s, "extract", ["-o", "gpu"], {"MDK_NO_DETACH": "1"}, 4, gap=0.0)          # a queue of samples: back to back, no pause
+    q = ours(s, "extract", ["-o", "gpu"], {}, 4, gap=0.0)          # a queue of samples: back to back, no pause
     res[name] = {"bam_bytes": os.path.getsize(str(s) + ".bam"), "cpu_64x50000_s": round(cpu, 2), "in_place": a, "detached": b, "queue_in_place": q, "identical": ident,
                  "x_in_place": round(cpu / a["median"], 2), "x_detached": round(cpu / b["median"], 2), "x_queue": round(cpu / q["median"], 2)}
     print(name, json.dumps({k: v for k, v in res[name].items() if k not in ("in_place", "detached", "queue_in_place")}), a["runs"], b["runs"], q["runs"], flush=True)
-mb = ours(sp, "mbias", ["--noSVG", "--txt"], {"MDK_NO_DETACH": "1"}, 3)
-mbh = ours(sp, "mbias", ["--noSVG", "--txt"], {"MDK_NO_DETACH": "1", "MDK_HOST_INFLATE": "1"}, 2)
+mb = ours(sp, "mbias", ["--noSVG", "--txt"], {}, 3)
+mbh = ours(sp, "mbias", ["--noSVG", "--txt"], {"MDK_HOST_INFLATE": "1"}, 2)
 res["mbias_large"] = {"in_place": mb, "host_inflate_only": mbh}
 print("mbias", mb["runs"], "host inflate only", mbh["runs"], flush=True)
 (out / "e2e.json").write_text(json.dumps(res, indent=1))
