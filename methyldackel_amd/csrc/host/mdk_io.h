@@ -44,7 +44,7 @@ typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs;
                           uint32_t *off32; size_t cap_off32;        /* off32[i] = sum[i].off: the records' places as one array, which the device takes as it is (md_raw_range.h_rec_off) */
                           struct md_piece *piece; const uint8_t *d_buf; const uint32_t *d_rec_off; uint64_t d_bytes; uint32_t d_records; } mdk_slab;
 
-#define MDK_GPU_TEAMS_MAX 8        /* device inflate teams: a host thread, a pinned staging block and pieces in flight each */
+#define MDK_GPU_TEAMS_MAX 16       /* device inflate teams: a host thread, a pinned staging block and pieces in flight each */
 typedef struct mdk_bam {
     FILE *f;
     int nthreads;

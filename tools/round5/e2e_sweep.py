@@ -12,9 +12,9 @@ if not Path(str(sp) + ".bam.bai").exists():
 if not Path(str(sx) + ".bam").exists():
     subprocess.run([str(REPO / "tools/_build/mdk_replicate"), str(sp), str(sx), "4"], check=True, capture_output=True)
 CLI = REPO / "methyldackel_amd/_build/MethylDackel"
-cfgs = [("default_64", "64", {}), ("t128", "128", {}), ("t128_teams8", "128", {"MDK_INFLATE_TEAMS": "8", "MDK_SLAB_CAP": "24"}), ("t192_teams8", "192", {"MDK_INFLATE_TEAMS": "8", "MDK_SLAB_CAP": "24"}),
-        ("t128_teams8_gpu4", "128", {"MDK_INFLATE_TEAMS": "8", "MDK_SLAB_CAP": "24", "MDK_GPU_INFLATE_TEAMS": "4"}), ("t256_teams8_cap32", "256", {"MDK_INFLATE_TEAMS": "8", "MDK_SLAB_CAP": "32"}),
-        ("t64_gpu12pieces32", "64", {"MDK_GPU_PIECE_MB": "32"}), ("t128_teams6", "128", {"MDK_INFLATE_TEAMS": "6", "MDK_SLAB_CAP": "18"})]
+cfgs = [("default_64", "64", {}), ("gpu12", "64", {"MDK_GPU_INFLATE_TEAMS": "12"}), ("gpu16", "64", {"MDK_GPU_INFLATE_TEAMS": "16"}),
+        ("gpu16_piece32", "64", {"MDK_GPU_INFLATE_TEAMS": "16", "MDK_GPU_PIECE_MB": "32"}), ("gpu12_host2", "64", {"MDK_GPU_INFLATE_TEAMS": "12", "MDK_INFLATE_TEAMS": "2"}),
+        ("gpu16_t96", "96", {"MDK_GPU_INFLATE_TEAMS": "16"})]
 res = {}
 w = D / "out"; w.mkdir(exist_ok=True)
 for name, th, env in cfgs:
