@@ -65,6 +65,7 @@ extern "C" int md_dev_profile_text(char *buf, int cap) {
 // ---- carved device memory (DBuf, mdk_hip_internal.hpp) ----
 struct Arena { std::mutex mu; std::vector<char *> blocks; size_t cur = 0, used = 0; long live = 0; };       // cur: block being carved; used: bytes of it taken
 static Arena g_arena[16];
+static std::atomic<int> g_open_handles{0};       // carved memory starts over only when nothing is carved AND no handle is open (a handle's buffers come and go; its status arrays stay)
 static const bool g_arena_on = getenv("MDK_NO_ARENA") == nullptr;
 void *arena_take(size_t bytes) {
     int dev = 0;
@@ -84,7 +85,7 @@ void arena_give(void *p) {
     for(Arena &A : g_arena) {
         std::lock_guard<std::mutex> lk(A.mu);
         for(char *b : A.blocks) if((char *)p >= b && (char *)p < b + ARENA_BLOCK) {
-            if(--A.live == 0) { A.cur = 0; A.used = 0; while(A.blocks.size() > 2) { (void)hipFree(A.blocks.back()); A.blocks.pop_back(); } }      // nothing carved is in use: start over (a process that opens many handles in turn)
+            if(--A.live == 0 && g_open_handles.load() == 0) { A.cur = 0; A.used = 0; while(A.blocks.size() > 2) { (void)hipFree(A.blocks.back()); A.blocks.pop_back(); } }      // nothing carved is in use and nobody could carve next to a reset: start over (a process that opens many handles in turn)
             return;
         }
     }
@@ -109,7 +110,7 @@ void harena_give(void *p) {
     HArena &A = g_harena;
     std::lock_guard<std::mutex> lk(A.mu);
     for(char *b : A.blocks) if((char *)p >= b && (char *)p < b + HARENA_BLOCK) {
-        if(--A.live == 0) { A.cur = 0; A.used = 0; while(A.blocks.size() > 2) { (void)hipHostFree(A.blocks.back()); A.blocks.pop_back(); } }
+        if(--A.live == 0 && g_open_handles.load() == 0) { A.cur = 0; A.used = 0; while(A.blocks.size() > 2) { (void)hipHostFree(A.blocks.back()); A.blocks.pop_back(); } }
         return;
     }
 }
@@ -287,6 +288,9 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
 // ds_bpermute from the lane that prepared it), so their loads fall into the same one or two cache lines.
 #ifndef PILEUP_WAVES
 #define PILEUP_WAVES 8
+#endif
+#ifndef QW_WAVES
+#define QW_WAVES PILEUP_WAVES   // waves per SIMD the dense-context kernel is compiled for (8: 64 VGPRs and a few spilled dwords; 6: 80 VGPRs, none, three workgroups per CU)
 #endif
 #ifndef QL
 #define QL 8          // lanes per segment
@@ -569,7 +573,7 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
 }
 
 template <bool VARIANT, bool QW>
-__global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
+__global__ __launch_bounds__(WG, QW ? QW_WAVES : PILEUP_WAVES) void k_pileup(const KParams P) {     // 64 VGPRs: four 512-thread workgroups per CU
     const int b = blockIdx.x;
     const int t = (b & 7) * P.nper + (b >> 3);   // XCD-aware: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles
     if(t >= P.ntiles) return;
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup(const KParams P) { 
 // kernel arguments; a workgroup finds its interval from the tile prefix.
 struct KMulti { int n, nper; int tstart[MAXM + 1]; KParams P[MAXM]; };
 template <bool VARIANT, bool QW>
-__global__ __launch_bounds__(WG, PILEUP_WAVES) void k_pileup_multi(const KMulti M) {
+__global__ __launch_bounds__(WG, QW ? QW_WAVES : PILEUP_WAVES) void k_pileup_multi(const KMulti M) {
     const int b = blockIdx.x;
     const int tg = (b & 7) * M.nper + (b >> 3);
     if(tg >= M.tstart[M.n]) return;
@@ -885,6 +889,7 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
         s.run = s.stream;
     }
     if(mdk_prof_on()) fprintf(stderr, "[mdk hip] md_dev_open: %.3fs (of which streams and events of %d slots %.3fs)\n", mdk_now() - t_open0, h->n_slots, mdk_now() - t_open1);
+    g_open_handles.fetch_add(1);
     *out = h;
     return 0;
 }
@@ -906,6 +911,7 @@ extern "C" void md_dev_close(md_dev *h) {
     for(hipStream_t st : h->streams) if(st) (void)hipStreamDestroy(st);
     for(hipStream_t st : h->piece_streams) if(st) (void)hipStreamDestroy(st);
     if(h->ref_stream) (void)hipStreamDestroy(h->ref_stream);
+    g_open_handles.fetch_sub(1);                       // (before the last carved buffers go: the give that brings the count to zero may start the blocks over)
     h->d_status.release(); h->h_status.release();
     if(h->d_crc) (void)hipFree(h->d_crc);
     if(h->d_hist) (void)hipFree(h->d_hist);
