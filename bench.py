@@ -362,7 +362,8 @@ def main():
     # committed summary of a separate profiled run stands in, and the line says which.
     traffic, traffic_info = None, None
     fam_kernels = {"preparation": ["k_prep_zero", "k_prep_scan", "k_prep_segs"], "pileup": ["k_pileup_multi<false,false>"]}
-    if rank == 0 and world == 1 and not args.no_live_traffic and not extra and not args.synth_args and args.length == 1_000_000 and shutil.which("rocprofv3"):
+    under_profiler = any(os.environ.get(k) for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH"))      # (this run is itself being profiled: no profiler inside a profiler)
+    if rank == 0 and world == 1 and not args.no_live_traffic and not under_profiler and not extra and not args.synth_args and args.length == 1_000_000 and shutil.which("rocprofv3"):
         try:
             import csv, glob
             per = {}

@@ -10,7 +10,7 @@ if [ "${2:-tests}" = tests ]; then
 fi
 timeout 1200 python bench.py --data-dir $D > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; echo "bench rc=$?"; cat $O/${TAG}_bench.json; tail -5 $O/${TAG}_bench.err
 cd /tmp; export TMPDIR=/tmp
-B="python $R/bench.py --data-dir $D --no-cpu-baseline"
+B="python $R/bench.py --data-dir $D --no-cpu-baseline --no-live-traffic"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof_kt -o kt -- $B --steps 4 --warmup 1 --passes 16 > $O/${TAG}_bench_under_rocprof.json 2> /dev/null
 P="$B --steps 2 --warmup 1 --passes 4"
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $O/${TAG}_prof_pmc_sq -o p -- $P > /dev/null 2>&1
