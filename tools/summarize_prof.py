@@ -52,13 +52,13 @@ if ktf:
     for r in csv.DictReader(open(ktf)):
         per[canon(r["Kernel_Name"])].append((int(r["Grid_Size_X"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     with open(f"{dst}/{tag}_rocprofv3_kernel_stats_largest_grid.csv", "w") as o:
-        o.write("kernel,grid_size,dispatches,avg_us,min_us,max_us\n")
+        o.write("kernel,grid_size,dispatches,avg_us,median_us,min_us,max_us\n")
         for k, v in sorted(per.items()):
             if not k.startswith("k_"):
                 continue
             gmax = max(g for g, _ in v); t = [x for g, x in v if g >= 0.98 * gmax]
-            dur[k] = {"grid": gmax, "dispatches": len(t), "avg_us": sum(t) / len(t), "min_us": min(t), "max_us": max(t)}
-            o.write(f"\"{k}\",{gmax},{len(t)},{sum(t) / len(t):.2f},{min(t):.2f},{max(t):.2f}\n")
+            dur[k] = {"grid": gmax, "dispatches": len(t), "avg_us": sum(t) / len(t), "median_us": sorted(t)[len(t) // 2], "min_us": min(t), "max_us": max(t)}
+            o.write(f"\"{k}\",{gmax},{len(t)},{sum(t) / len(t):.2f},{sorted(t)[len(t) // 2]:.2f},{min(t):.2f},{max(t):.2f}\n")
 
 kernels = {}
 for name, cs in agg.items():
