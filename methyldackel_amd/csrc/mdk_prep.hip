@@ -53,7 +53,7 @@ struct PrepParams {
     const uint32_t *mapbits; int64_t maplen;         // 1 bit per base, or NULL
     const md_region *runs; int64_t nruns; int bed_on;
     PrepRead *rd; uint32_t *aidx;    // per admitted read: the read, (perRead) its index among the candidate records
-    unsigned long long *hent; int32_t *hnext, *hfwd; uint32_t hmask;      // name table: (high half of the name's hash) << 32 | (index + 1 of the name's latest read); 0 = empty.  hnext[i]: the read of i's name that was in the table before i; hfwd[i]: the one that came after
+    unsigned long long *hent, *hk; int32_t *hnext, *hfwd; uint32_t hmask;      // name table: (high half of the name's hash) << 32 | (index + 1 of the name's latest read); 0 = empty.  hnext[i]: the read of i's name that was in the table before i; hfwd[i]: the one that came after
     uint32_t *cntA, *cntS, *ticket; int nblocks;     // per workgroup: published counts of admitted reads (perRead) / segments; two ticket counters
     md_seg *seg; int64_t cap_seg;
     TileEnt *tiles; int ntiles, tile;
@@ -90,6 +90,9 @@ __device__ __forceinline__ int chunk_of_block(const PrepMulti &M) { return (int)
 __device__ __forceinline__ uint32_t sync_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t sync_peek(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sync_set(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef PREP_LINK
+#define PREP_LINK 0                   // 1: the name table is asked by a kernel of its own (k_prep_link) instead of at the end of k_prep_scan.  Measured (profiles/r05q_prep_variants.txt): scan 177 -> 139 us, the new kernel 52 us at eight wavefronts per SIMD -- the compare-and-swaps cost what they cost wherever they wait
+#endif
 #ifndef PREP_CAS_SCOPE
 #define PREP_CAS_SCOPE 0              // EXPERIMENT: 1 = the name table's compare-and-swaps at workgroup scope (resolved in the XCD's own L2; right only while every workgroup of a chunk runs on one XCD)
 #endif
@@ -282,14 +285,15 @@ __device__ __forceinline__ uint32_t tickets_before(uint32_t *cnt, uint32_t tk, u
 
 // everything a launch starts from zeroed, for all its chunks (one launch instead of two memsets per chunk)
 __global__ __launch_bounds__(PB) void k_prep_zero(const PrepMulti M) {
-    for(int j = 0; j < M.n; j++) {
-        const PrepParams &P = M.P[j];
-        uint4 *z = (uint4 *)P.zero; const uint64_t n16 = P.zero_bytes >> 4;
-        for(uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * PB) z[i] = make_uint4(0, 0, 0, 0);
-        for(int t = blockIdx.x * PB + threadIdx.x; t < P.ntiles; t += gridDim.x * PB) { P.tiles[t].first = 0x7fffffff; P.tiles[t].last = 0; }      // the tile runs start empty
-        if(P.hfwd) { uint4 *f = (uint4 *)P.hfwd; const int n16f = (P.n_rec + 3) >> 2; for(int i = blockIdx.x * PB + threadIdx.x; i < n16f; i += gridDim.x * PB) f[i] = make_uint4(~0u, ~0u, ~0u, ~0u); }      // nobody came after anybody yet
-        if(blockIdx.x == 0 && threadIdx.x < sizeof(PrepCounters) / 4) ((uint32_t *)P.cnt)[threadIdx.x] = 0;
-    }
+    // workgroup b works for chunk b mod n with the b / n-th share of it (the grid is n times a chunk's share: the launches over eight
+    // chunks have a grid of their own, which is how the profiles tell them from the one-chunk launches)
+    const int j = (int)(blockIdx.x % (unsigned)M.n); const uint32_t b = blockIdx.x / (unsigned)M.n, nb = gridDim.x / (unsigned)M.n;
+    const PrepParams &P = M.P[j];
+    uint4 *z = (uint4 *)P.zero; const uint64_t n16 = P.zero_bytes >> 4;
+    for(uint64_t i = (uint64_t)b * PB + threadIdx.x; i < n16; i += (uint64_t)nb * PB) z[i] = make_uint4(0, 0, 0, 0);
+    for(int t = (int)(b * PB + threadIdx.x); t < P.ntiles; t += (int)(nb * PB)) { P.tiles[t].first = 0x7fffffff; P.tiles[t].last = 0; }      // the tile runs start empty
+    if(P.hfwd) { uint4 *f = (uint4 *)P.hfwd; const int n16f = (P.n_rec + 3) >> 2; for(int i = (int)(b * PB + threadIdx.x); i < n16f; i += (int)(nb * PB)) f[i] = make_uint4(~0u, ~0u, ~0u, ~0u); }      // nobody came after anybody yet
+    if(b == 0 && threadIdx.x < sizeof(PrepCounters) / 4) ((uint32_t *)P.cnt)[threadIdx.x] = 0;
 }
 
 // One record: fields, reference length, aux walk, strand, filter_func's tests in its order, name hash.  `v` reads the record's bytes (from HBM
@@ -431,6 +435,29 @@ __device__ __forceinline__ void stage_read(uint4 *st, const PrepRead &D, const i
 // barrier that orders LDS traffic only (does not drain this wavefront's outstanding global loads, stores and atomics)
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// the tk-th of the workgroups that work for chunk cj (chunk_of_block): XCDs cj, cj + n, ... (< 8) serve it
+__device__ __forceinline__ uint32_t static_ticket(const PrepMulti &M, int cj) {
+    const uint32_t xcd = blockIdx.x & 7u, per = (7u - (uint32_t)cj) / (uint32_t)M.n + 1u;
+    return (blockIdx.x >> 3) * per + xcd / (uint32_t)M.n;
+}
+// A group of reads of one name (its first read i, `mine` = the name's key and the group's last read) enters the chunk's table at slot sl;
+// `old` is what its first compare-and-swap against an empty entry saw.  The read that headed the name before is linked to it both ways.
+__device__ __forceinline__ void table_insert(const PrepParams &P, int i, uint32_t sl, unsigned long long key, unsigned long long mine, unsigned long long old) {
+    int32_t before = -1;
+    for(;;) {
+        if(old == 0ull) break;
+        if((old >> 32) == (key >> 32)) {
+            for(;;) { const unsigned long long seen = sync_cas(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
+            before = (int32_t)(uint32_t)old - 1;
+            break;
+        }
+        sl = (sl + 1) & P.hmask;
+        old = sync_cas(&P.hent[sl], 0ull, mine);
+    }
+    P.hnext[i] = before;
+    if(before >= 0) P.hfwd[before] = i;
+}
+
 // extract / mbias: every record's PrepRead at the record's own index; no workgroup waits for another.
 // Workgroup b works for chunk (b mod 8) mod n (chunk_of_block) and is the tk-th of the workgroups that do: tk follows from b alone.
 __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
@@ -439,8 +466,7 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     uint4 *const stage = dyn;
     const int cj = chunk_of_block(M);
     const PrepParams &P = M.P[cj];
-    const uint32_t xcd = blockIdx.x & 7u, per = (7u - (uint32_t)cj) / (uint32_t)M.n + 1u;       // XCDs that serve this chunk: cj, cj + n, ... (< 8)
-    const uint32_t tk = (blockIdx.x >> 3) * per + xcd / (uint32_t)M.n;
+    const uint32_t tk = static_ticket(M, cj);
     if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than this chunk needs
     const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
@@ -513,13 +539,18 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
 #endif
     // the group's compare-and-swap is on its way from here; its answer is looked at only after the PrepReads have left
     const bool gins = ins && lprev == -1;
+#if PREP_LINK
+    // the group's insertion is left to k_prep_link: the name's hash (its low 9 bits make room for the group's last read and a mark)
+    if(i < P.n_rec && P.hk) P.hk[i] = gins ? ((h & ~0x1ffull) | 0x100ull | (unsigned long long)ghead) : 0ull;
+#else
     const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i0 + ghead + 1u);
-    uint32_t sl = (uint32_t)h & P.hmask;
+    uint32_t sl = (uint32_t)(h >> 9) & P.hmask;
     unsigned long long old = 0ull;
 #if PREP_EXP_NOCAS                                        // TIMING EXPERIMENT ONLY (wrong results): a plain store where the compare-and-swap is
     if(gins) P.hent[sl] = mine;
 #else
     if(gins) old = sync_cas(&P.hent[sl], 0ull, mine);
+#endif
 #endif
     if(ins && lprev >= 0) { P.hnext[i] = i0 + lprev; P.hfwd[i0 + lprev] = i; }
     // the PrepReads go to the workgroup's stage in LDS first and from there to rd[] as whole lines: written straight from the lanes, the four
@@ -531,22 +562,28 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
         uint4 *out = (uint4 *)(P.rd + i0);
         for(int q = threadIdx.x; q < 4 * cnt; q += PB) out[q] = stage[q];
     }
-    if(gins) {
-        int32_t before = -1;
-        for(;;) {
-            if(old == 0ull) break;
-            if((old >> 32) == (key >> 32)) {
-                for(;;) { const unsigned long long seen = sync_cas(&P.hent[sl], old, mine); if(seen == old) break; old = seen; }       // (only the reads of this very name compete here)
-                before = (int32_t)(uint32_t)old - 1;
-                break;
-            }
-            sl = (sl + 1) & P.hmask;
-            old = sync_cas(&P.hent[sl], 0ull, mine);
-        }
-        P.hnext[i] = before;
-        if(before >= 0) P.hfwd[before] = i;
-    }
+#if !PREP_LINK
+    if(gins) table_insert(P, i, sl, key, mine, old);
+#endif
 }
+
+#if PREP_LINK
+// The groups k_prep_scan left (hk[i] marked: record i is the first of its workgroup's reads of a name, the low byte names the last) enter
+// the chunk's table, a lane per record, nothing held in LDS: eight wavefronts per SIMD wait for their compare-and-swaps together.
+__global__ __launch_bounds__(PB) void k_prep_link(const PrepMulti M) {
+    const int cj = chunk_of_block(M);
+    const PrepParams &P = M.P[cj];
+    const uint32_t tk = static_ticket(M, cj);
+    if(tk >= (uint32_t)P.nblocks || !P.hk) return;
+    const int i0 = (int)(tk * PB), i = i0 + (int)threadIdx.x;
+    if(i >= P.n_rec) return;
+    const unsigned long long v = P.hk[i];
+    if(!(v & 0x100ull)) return;
+    const unsigned long long key = (v >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i0 + (uint32_t)(v & 0xffull) + 1u);
+    const uint32_t sl = (uint32_t)(v >> 9) & P.hmask;
+    table_insert(P, i, sl, key, mine, sync_cas(&P.hent[sl], 0ull, mine));
+}
+#endif
 
 // perRead: the selected reads compacted IN FILE ORDER (rd[a], aidx[a] = the a-th kept record): a workgroup draws a ticket, publishes its
 // count, and adds up the counts of the tickets before it
@@ -972,6 +1009,7 @@ static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
     P.rd = s->d_prd.p; P.aidx = h->prep.perread ? s->d_aidx.p : nullptr; P.hmask = s->hmask;
     const bool links = !h->prep.perread && !h->prep.no_pairing;      // the reads of a name linked both ways: hnext[n_rec], hfwd[n_rec] (16-byte aligned: k_prep_zero fills it with -1)
     P.hnext = links ? s->d_hnext.p : nullptr; P.hfwd = links ? s->d_hnext.p + (((size_t)n + 4) & ~(size_t)3) : nullptr;
+    P.hk = links && PREP_LINK ? (unsigned long long *)(s->d_hnext.p + 2 * (((size_t)n + 4) & ~(size_t)3)) : nullptr;      // (8 bytes per record behind the two link arrays)
     uint8_t *z = s->d_zero.p;
     P.hent = (unsigned long long *)z; P.cntA = (uint32_t *)(z + H * 8); P.cntS = P.cntA + (nb > 0 ? nb : 1); P.ticket = P.cntS + (nb > 0 ? nb : 1);
     P.nblocks = nb; P.zero = z; P.zero_bytes = zero_bytes_for(s->hmask, nb);
@@ -990,8 +1028,8 @@ int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
     int total = 0; size_t zmax = 0;
     for(int i = 0; i < n; i++) { fill_prep(h, ss[i], M.P[i]); M.bstart[i] = total; total += M.P[i].nblocks; zmax = std::max<size_t>(zmax, (size_t)M.P[i].zero_bytes); ss[i]->prep_pending = false; }
     M.n = n; M.bstart[n] = total;
-    int zgrid = (int)std::min<size_t>(2048, (zmax / 16 + PB - 1) / PB); if(zgrid < 1) zgrid = 1;
-    hipLaunchKernelGGL(k_prep_zero, dim3(zgrid), dim3(PB), 0, st, M);
+    int zgrid = (int)std::min<size_t>(256, (zmax / 16 + PB - 1) / PB); if(zgrid < 1) zgrid = 1;
+    hipLaunchKernelGGL(k_prep_zero, dim3(zgrid * n), dim3(PB), 0, st, M);
     if(total > 0) {
         int grid = total;
         {   // chunk j is served by the workgroups b with (b mod 8) mod n == j (chunk_of_block): enough of them for its nblocks tickets
@@ -1001,7 +1039,13 @@ int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
         }
         static_assert(MAXM <= 8, "chunk_of_block deals the chunks of a launch to 8 XCDs");
         if(h->prep.perread) hipLaunchKernelGGL(k_prep_scan_ordered, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
-        else { hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M); hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M); }
+        else {
+            hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
+#if PREP_LINK
+            if(!h->prep.no_pairing) hipLaunchKernelGGL(k_prep_link, dim3(grid), dim3(PB), 0, st, M);
+#endif
+            hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M);
+        }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1038,7 +1082,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     static std::atomic<int> first_call{1}; const bool first = mdk_prof_on() && first_call.exchange(0); const double tf0 = first ? mdk_now() : 0; double tf1 = 0;
     {
         ProfScope pf(PF_UP_ALLOC);
-        if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+        if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(4 * nn + 16) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
            s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
         if(!s->b_site) {
             if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
@@ -1092,7 +1136,7 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     if(total >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: more than 4 GiB of records in one chunk", hipSuccess);
     const int n = b->n_records, nb = (n + PB - 1) / PB; const size_t nn = (size_t)n + 1;
     s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->hmask = 1023; s->ntiles = 0; s->tile = h->tile;
-    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(4 * nn + 16) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
        s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
     { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
     { int rc = enqueue_prep(h, s); if(rc) return rc; }                 // perread mode: selection + file-order compaction only (k_prep_scan)
