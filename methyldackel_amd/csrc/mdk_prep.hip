@@ -53,7 +53,7 @@ struct PrepParams {
     const uint32_t *mapbits; int64_t maplen;         // 1 bit per base, or NULL
     const md_region *runs; int64_t nruns; int bed_on;
     PrepRead *rd; uint32_t *aidx;    // per admitted read: the read, (perRead) its index among the candidate records
-    unsigned long long *hent, *hk; int32_t *hnext, *hfwd; uint32_t hmask;      // name table: (high half of the name's hash) << 32 | (index + 1 of the name's latest read); 0 = empty.  hnext[i]: the read of i's name that was in the table before i; hfwd[i]: the one that came after
+    unsigned long long *hent; int32_t *hnext, *hfwd; uint32_t hmask;      // name table: (high half of the name's hash) << 32 | (index + 1 of the name's latest read); 0 = empty.  hnext[i]: the read of i's name that was in the table before i; hfwd[i]: the one that came after
     uint32_t *cntA, *cntS, *ticket; int nblocks;     // per workgroup: published counts of admitted reads (perRead) / segments; two ticket counters
     md_seg *seg; int64_t cap_seg;
     TileEnt *tiles; int ntiles, tile;
@@ -90,9 +90,6 @@ __device__ __forceinline__ int chunk_of_block(const PrepMulti &M) { return (int)
 __device__ __forceinline__ uint32_t sync_add(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t sync_peek(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sync_set(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#ifndef PREP_LINK
-#define PREP_LINK 0                   // 1: the name table is asked by a kernel of its own (k_prep_link) instead of at the end of k_prep_scan.  Measured (profiles/r05q_prep_variants.txt): scan 177 -> 139 us, the new kernel 52 us at eight wavefronts per SIMD -- the compare-and-swaps cost what they cost wherever they wait
-#endif
 #ifndef PREP_CAS_SCOPE
 #define PREP_CAS_SCOPE 0              // EXPERIMENT: 1 = the name table's compare-and-swaps at workgroup scope (resolved in the XCD's own L2; right only while every workgroup of a chunk runs on one XCD)
 #endif
@@ -539,18 +536,13 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
 #endif
     // the group's compare-and-swap is on its way from here; its answer is looked at only after the PrepReads have left
     const bool gins = ins && lprev == -1;
-#if PREP_LINK
-    // the group's insertion is left to k_prep_link: the name's hash (its low 9 bits make room for the group's last read and a mark)
-    if(i < P.n_rec && P.hk) P.hk[i] = gins ? ((h & ~0x1ffull) | 0x100ull | (unsigned long long)ghead) : 0ull;
-#else
     const unsigned long long key = (unsigned long long)(uint32_t)(h >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i0 + ghead + 1u);
-    uint32_t sl = (uint32_t)(h >> 9) & P.hmask;
+    uint32_t sl = (uint32_t)h & P.hmask;
     unsigned long long old = 0ull;
 #if PREP_EXP_NOCAS                                        // TIMING EXPERIMENT ONLY (wrong results): a plain store where the compare-and-swap is
     if(gins) P.hent[sl] = mine;
 #else
     if(gins) old = sync_cas(&P.hent[sl], 0ull, mine);
-#endif
 #endif
     if(ins && lprev >= 0) { P.hnext[i] = i0 + lprev; P.hfwd[i0 + lprev] = i; }
     // the PrepReads go to the workgroup's stage in LDS first and from there to rd[] as whole lines: written straight from the lanes, the four
@@ -562,28 +554,8 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
         uint4 *out = (uint4 *)(P.rd + i0);
         for(int q = threadIdx.x; q < 4 * cnt; q += PB) out[q] = stage[q];
     }
-#if !PREP_LINK
     if(gins) table_insert(P, i, sl, key, mine, old);
-#endif
 }
-
-#if PREP_LINK
-// The groups k_prep_scan left (hk[i] marked: record i is the first of its workgroup's reads of a name, the low byte names the last) enter
-// the chunk's table, a lane per record, nothing held in LDS: eight wavefronts per SIMD wait for their compare-and-swaps together.
-__global__ __launch_bounds__(PB) void k_prep_link(const PrepMulti M) {
-    const int cj = chunk_of_block(M);
-    const PrepParams &P = M.P[cj];
-    const uint32_t tk = static_ticket(M, cj);
-    if(tk >= (uint32_t)P.nblocks || !P.hk) return;
-    const int i0 = (int)(tk * PB), i = i0 + (int)threadIdx.x;
-    if(i >= P.n_rec) return;
-    const unsigned long long v = P.hk[i];
-    if(!(v & 0x100ull)) return;
-    const unsigned long long key = (v >> 32) << 32, mine = key | (unsigned long long)((uint32_t)i0 + (uint32_t)(v & 0xffull) + 1u);
-    const uint32_t sl = (uint32_t)(v >> 9) & P.hmask;
-    table_insert(P, i, sl, key, mine, sync_cas(&P.hent[sl], 0ull, mine));
-}
-#endif
 
 // perRead: the selected reads compacted IN FILE ORDER (rd[a], aidx[a] = the a-th kept record): a workgroup draws a ticket, publishes its
 // count, and adds up the counts of the tickets before it
@@ -1009,7 +981,6 @@ static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
     P.rd = s->d_prd.p; P.aidx = h->prep.perread ? s->d_aidx.p : nullptr; P.hmask = s->hmask;
     const bool links = !h->prep.perread && !h->prep.no_pairing;      // the reads of a name linked both ways: hnext[n_rec], hfwd[n_rec] (16-byte aligned: k_prep_zero fills it with -1)
     P.hnext = links ? s->d_hnext.p : nullptr; P.hfwd = links ? s->d_hnext.p + (((size_t)n + 4) & ~(size_t)3) : nullptr;
-    P.hk = links && PREP_LINK ? (unsigned long long *)(s->d_hnext.p + 2 * (((size_t)n + 4) & ~(size_t)3)) : nullptr;      // (8 bytes per record behind the two link arrays)
     uint8_t *z = s->d_zero.p;
     P.hent = (unsigned long long *)z; P.cntA = (uint32_t *)(z + H * 8); P.cntS = P.cntA + (nb > 0 ? nb : 1); P.ticket = P.cntS + (nb > 0 ? nb : 1);
     P.nblocks = nb; P.zero = z; P.zero_bytes = zero_bytes_for(s->hmask, nb);
@@ -1041,9 +1012,6 @@ int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
         if(h->prep.perread) hipLaunchKernelGGL(k_prep_scan_ordered, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
         else {
             hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
-#if PREP_LINK
-            if(!h->prep.no_pairing) hipLaunchKernelGGL(k_prep_link, dim3(grid), dim3(PB), 0, st, M);
-#endif
             hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M);
         }
     }
@@ -1082,7 +1050,7 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     static std::atomic<int> first_call{1}; const bool first = mdk_prof_on() && first_call.exchange(0); const double tf0 = first ? mdk_now() : 0; double tf1 = 0;
     {
         ProfScope pf(PF_UP_ALLOC);
-        if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(4 * nn + 16) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+        if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
            s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
         if(!s->b_site) {
             if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
@@ -1136,7 +1104,7 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     if(total >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: more than 4 GiB of records in one chunk", hipSuccess);
     const int n = b->n_records, nb = (n + PB - 1) / PB; const size_t nn = (size_t)n + 1;
     s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->hmask = 1023; s->ntiles = 0; s->tile = h->tile;
-    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(4 * nn + 16) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+    if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
        s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
     { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
     { int rc = enqueue_prep(h, s); if(rc) return rc; }                 // perread mode: selection + file-order compaction only (k_prep_scan)
