@@ -159,7 +159,8 @@ void mdk_bam_reap_wait(mdk_bam *b) {
     reap_pool(b);
     { const double t0 = now_s();
       while(b->n_reap || b->reap_busy) pthread_cond_wait(&b->cv_reaped, &b->mu);
-      if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] reaper: %d slabs given back in %.3fs of its own thread's time, %d left in the pool, %d still referenced; waited for it %.3fs at the end\n", b->n_reaped, b->t_reap, b->n_pool, b->n_alloc - b->n_pool, now_s() - t0); }
+      if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] reaper: %d slabs given back in %.3fs of its own thread's time, %d left in the pool, %d still referenced; waited for it %.3fs at the end\n", b->n_reaped, b->t_reap, b->n_pool, b->n_alloc - b->n_pool, now_s() - t0);
+      if(getenv("MDK_HOST_PROFILE")) { int k; for(k = 0; k < 2; k++) fprintf(stderr, "[mdk host] %s teams, summed over the teams that have left: %d pieces; waiting for the file's lock + framing %.3fs, inflating %.3fs (device teams: waiting for a device slab %.3fs, staging copy %.3fs, device %.3fs), handing over in file order %.3fs\n", k ? "device" : "host", b->tt_pieces[k], b->tt_next[k], b->tt_host[k], b->tt_slab[k], b->tt_copy[k], b->tt_dev[k], b->tt_deliver[k]); } }
     pthread_mutex_unlock(&b->mu);
 }
 static void reaper_stop(mdk_bam *b) {
@@ -297,14 +298,17 @@ static mdk_slab *dslab_get(mdk_bam *b, uint64_t seq) {          /* a free device
 }
 /* one piece through the device: the compressed bytes are staged in registered memory, md_piece_submit/wait inflates them and frames
  * the records; what comes back to the host is one digest per member */
-static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *status) {
+static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *status, double *tt) {
     blk_t *blk = pc->blk; const int nb = pc->nb; mdk_slab *s; md_inf_member *mt; md_piece_info info; int i; uint64_t o = 0;
     const uint8_t *c0 = blk[0].in; const size_t span = (size_t)((blk[nb - 1].in + blk[nb - 1].in_len) - c0);
+    double t0 = now_s(), t1;
     *status = 0;
     s = dslab_get(b, pc->seq);
+    t1 = now_s(); tt[0] += t1 - t0; t0 = t1;
     if(!s) { *status = b->quit ? 1 : -1; return NULL; }
     if(b->gpu_stage_cap[team] < span + 64) { md_host_free(b->gpu_stage[team]); b->gpu_stage_cap[team] = span + (span >> 3) + (1u << 20); b->gpu_stage[team] = md_host_alloc(b->gpu_stage_cap[team]); if(!b->gpu_stage[team]) { b->gpu_stage_cap[team] = 0; mdk_slab_unref(b, s); *status = -1; return NULL; } }
     memcpy(b->gpu_stage[team], c0, span);
+    t1 = now_s(); tt[1] += t1 - t0; t0 = t1;
     mt = malloc(sizeof(*mt) * (size_t)nb);
     if(!mt) { mdk_slab_unref(b, s); *status = -1; return NULL; }
     for(i = 0; i < nb; i++) { mt[i].in_off = (uint64_t)(blk[i].in - c0); mt[i].in_len = blk[i].in_len; mt[i].out_len = blk[i].out_len; mt[i].out_off = o; mt[i].crc32 = blk[i].crc; mt[i].reserved = 0; o += blk[i].out_len; }
@@ -314,6 +318,7 @@ static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *stat
         pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu);
         free(mt); mdk_slab_unref(b, s); *status = -2; return NULL;
       } }
+    tt[2] += now_s() - t0;
     if(s->cap_mem < nb) { free(s->mem); s->cap_mem = nb + 64; s->mem = malloc(sizeof(mdk_member) * (size_t)s->cap_mem); }
     if(!s->mem) { s->cap_mem = 0; free(mt); mdk_slab_unref(b, s); *status = -1; return NULL; }
     for(i = 0; i < nb; i++) {
@@ -353,17 +358,19 @@ static int deliver(mdk_bam *b, mdk_slab *s, uint64_t seq) {
 typedef struct { mdk_bam *b; int gpu_team; } team_arg;        /* gpu_team < 0: a host team */
 static void *inflater_main(void *arg) {
     team_arg *ta = arg; mdk_bam *b = ta->b; const int gt = ta->gpu_team;
+    double t_next = 0, t_host = 0, t_deliver = 0, td[3] = {0, 0, 0}; int n_pieces = 0;
     for(;;) {
-        piece pc; int st; mdk_slab *s = NULL;
+        piece pc; int st; mdk_slab *s = NULL; double t0 = now_s(), t1;
         pthread_mutex_lock(&b->io_mu);
         if(b->io_status) { pthread_mutex_unlock(&b->io_mu); break; }              /* another team has seen the end (or an error) */
         st = next_piece(b, &pc, gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK);
         if(st == 0) pc.seq = b->next_seq++; else b->io_status = st;
         pthread_mutex_unlock(&b->io_mu);
+        t1 = now_s(); t_next += t1 - t0; t0 = t1;
         if(st == 0) {
             /* a device team's piece goes to the host's inflate after all when it would inflate to more than the device addresses in one piece
              * (4 GiB: a ratio above 64, low-complexity data) or when the device cannot take it for want of a resource (status -1) */
-            if(gt >= 0 && pc.total < 0xfff00000ull) { s = inflate_piece_device(b, &pc, gt, &st); if(!s && st == -1) { pthread_mutex_lock(&b->mu); const int q = b->quit; pthread_mutex_unlock(&b->mu); if(!q) { st = 0; s = inflate_piece(b, &pc, b->team_threads, &st); } } }
+            if(gt >= 0 && pc.total < 0xfff00000ull) { s = inflate_piece_device(b, &pc, gt, &st, td); if(!s && st == -1) { pthread_mutex_lock(&b->mu); const int q = b->quit; pthread_mutex_unlock(&b->mu); if(!q) { st = 0; s = inflate_piece(b, &pc, b->team_threads, &st); } } }
             else s = inflate_piece(b, &pc, b->team_threads, &st);
             free(pc.cbuf); free(pc.blk);
             /* the piece's pages of the file mapping are done with (inflated, or copied to the device's staging block): unmapped here, piece by piece
@@ -371,8 +378,11 @@ static void *inflater_main(void *arg) {
             if(b->map && pc.map_end > pc.map_beg) { const size_t a = (pc.map_beg + 4095) & ~(size_t)4095, e = pc.map_end & ~(size_t)4095; if(e > a) (void)madvise((void *)(b->map + a), e - a, MADV_DONTNEED); }
         }
         if(s && gt < 0 && b->dev) md_host_register(b->dev, s->buf);          /* the device is up: the slab this team has just filled is made known to the runtime here, not by the thread that uploads from it */
+        t1 = now_s(); t_host += t1 - t0; t0 = t1;      /* (a device team: slab wait + copy + device, told apart in td) */
         if(s) {
+            n_pieces++;
             if(deliver(b, s, pc.seq)) break;
+            t_deliver += now_s() - t0;
             /* test hook (MDK_DEVICE_INFLATE_ONLY=1, `extract` only): the host teams leave after the piece that holds the BAM header, so that
              * every other piece is inflated on the device however small the file is */
             if(gt < 0 && b->host_leaves && b->header_done) break;
@@ -386,6 +396,7 @@ static void *inflater_main(void *arg) {
         pthread_mutex_unlock(&b->mu);
         break;
     }
+    { const int k = gt >= 0; pthread_mutex_lock(&b->mu); b->tt_next[k] += t_next; b->tt_host[k] += t_host; b->tt_deliver[k] += t_deliver; b->tt_slab[k] += td[0]; b->tt_copy[k] += td[1]; b->tt_dev[k] += td[2]; b->tt_pieces[k] += n_pieces; pthread_mutex_unlock(&b->mu); }
     if(gt >= 0 && !getenv("MDK_NO_REAP")) { md_host_free(b->gpu_stage[gt]); b->gpu_stage[gt] = NULL; b->gpu_stage_cap[gt] = 0; }      /* its last piece has crossed the link (md_piece_wait): the staging block goes now, not at exit */
     free(ta);
     return NULL;
@@ -414,7 +425,7 @@ int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     if(n_teams < 1) n_teams = 1;
     if(n_teams > MDK_GPU_TEAMS_MAX) n_teams = MDK_GPU_TEAMS_MAX;
     pthread_mutex_lock(&b->life_mu);                              /* (the reader thread may be inside a seek, which stops and restarts every team) */
-    b->dev = dev; b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + 4;
+    b->dev = dev; b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + (getenv("MDK_DSLAB_EXTRA") && atoi(getenv("MDK_DSLAB_EXTRA")) >= 1 ? atoi(getenv("MDK_DSLAB_EXTRA")) : 4);
     if(b->inf_started) {
         for(k = 0; k < n_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } }
         b->n_gpu_teams = k; b->gpu_started = 1;

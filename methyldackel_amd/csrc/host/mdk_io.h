@@ -69,6 +69,7 @@ typedef struct mdk_bam {
      * the device -- memory that is still registered when the process ends is taken down by the kernel page by page on one core, 0.3 s for
      * the ~40 slabs of a 128 Mb run (gpurun_out/r05h/e2e.json: 0.39 s inside the process, 0.67 s for its caller). */
     mdk_slab **reap; int n_reap, cap_reap, n_pool_wait, reap_started, reap_quit, reap_busy; pthread_t reap_th; pthread_cond_t cv_reap, cv_reaped; int n_reaped; double t_reap;
+    double tt_next[2], tt_slab[2], tt_copy[2], tt_dev[2], tt_deliver[2], tt_host[2]; int tt_pieces[2];      /* MDK_HOST_PROFILE: where the inflate teams' time went, summed over the teams ([0] host teams, [1] device teams) */
     uint8_t *cbuf; size_t ccap, clen; int file_eof;
     const uint8_t *map; size_t map_len, map_pos;   /* the file mapped read-only: the inflate threads read the compressed bytes where the page cache has them (no copy) */
     /* scanner position */

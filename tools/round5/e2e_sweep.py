@@ -15,6 +15,7 @@ CLI = REPO / "methyldackel_amd/_build/MethylDackel"
 cfgs = [("default_64", "64", {}), ("gpu12", "64", {"MDK_GPU_INFLATE_TEAMS": "12"}), ("gpu16", "64", {"MDK_GPU_INFLATE_TEAMS": "16"}),
         ("gpu16_piece32", "64", {"MDK_GPU_INFLATE_TEAMS": "16", "MDK_GPU_PIECE_MB": "32"}), ("gpu12_host2", "64", {"MDK_GPU_INFLATE_TEAMS": "12", "MDK_INFLATE_TEAMS": "2"}),
         ("gpu16_t96", "96", {"MDK_GPU_INFLATE_TEAMS": "16"})]
+if os.environ.get("E2E_CFGS"): cfgs = [tuple(c) for c in json.loads(os.environ["E2E_CFGS"])]      # [[name, threads, {env}], ...]
 res = {}
 w = D / "out"; w.mkdir(exist_ok=True)
 for name, th, env in cfgs:
@@ -25,8 +26,8 @@ for name, th, env in cfgs:
         t = time.perf_counter(); r = subprocess.run([str(CLI), "extract", str(sx) + ".fa", str(sx) + ".bam", "-@", th, "-o", "x"], cwd=w, env=e, capture_output=True, text=True, timeout=300); ws.append(time.perf_counter() - t)
         assert r.returncode == 0, r.stderr[-800:]
         ins.append(float(re.search(r"total ([0-9.]+)s; chunks prepared", r.stderr).group(1)))
-        last = [l[:500] for l in r.stderr.splitlines() if "pieces inflated by" in l or "uploader:" in l or "reaper" in l]
+        last = [l[:500] for l in r.stderr.splitlines() if "pieces inflated by" in l or "uploader:" in l or "reaper" in l or "teams, summed" in l]
     res[name] = {"wall": [round(x, 3) for x in ws], "inside": ins, "lines": last}
     print(name, res[name]["wall"], ins, flush=True)
-    for l in last: print("    ", l[:400], flush=True)
+    for l in last: print("    ", l[:500], flush=True)
 (out / "e2e_sweep.json").write_text(json.dumps(res, indent=1))
