@@ -106,6 +106,7 @@ int main(int argc, char *argv[]) {
             rc = cmd(argc - 1, argv + 1);
             say_done(rc);
             mdk_cli_quiesce();                                   /* no thread of ours is left inside the HIP runtime when the process goes */
+            if(profiler_present()) return rc & 0xff;             /* (a profiler writes its files from an exit handler: under one the process leaves the ordinary way) */
             _exit(rc & 0xff);
         }
     }
