@@ -13,7 +13,7 @@
 static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 #define CCHUNK (8u << 20)      /* compressed bytes a host team inflates into one slab */
-#define GCHUNK (64u << 20)     /* compressed bytes of a piece inflated on the device: ~3,400 members, one wavefront each */
+#define GCHUNK (96u << 20)     /* compressed bytes of a piece inflated on the device: ~5,100 members, one wavefront each, on a device that holds ~6,100 (64 MB: ~3,400, whose k_inflate ran mostly alone and left the device under-filled; 512 Mb: 1.22 -> 1.10 s, profiles/r05z_e2e_piece_size.log) */
 
 static inline uint16_t le16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 static inline uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -539,7 +539,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     b->n_teams = b->nthreads >= 32 ? 4 : b->nthreads >= 8 ? 2 : 1;
     if(getenv("MDK_DEVICE_INFLATE_ONLY")) { b->host_leaves = 1; b->n_teams = 1; }
     b->gpu_piece_bytes = GCHUNK;
-    if(getenv("MDK_GPU_PIECE_MB") && atof(getenv("MDK_GPU_PIECE_MB")) >= 0.25 && atof(getenv("MDK_GPU_PIECE_MB")) <= 64) b->gpu_piece_bytes = (size_t)(atof(getenv("MDK_GPU_PIECE_MB")) * 1048576.0);      /* test hook: many small device pieces */
+    if(getenv("MDK_GPU_PIECE_MB") && atof(getenv("MDK_GPU_PIECE_MB")) >= 0.25 && atof(getenv("MDK_GPU_PIECE_MB")) <= 256) b->gpu_piece_bytes = (size_t)(atof(getenv("MDK_GPU_PIECE_MB")) * 1048576.0);      /* test hook: many small device pieces */
     if(getenv("MDK_INFLATE_TEAMS")) { b->n_teams = atoi(getenv("MDK_INFLATE_TEAMS")); if(b->n_teams < 1) b->n_teams = 1; if(b->n_teams > 8) b->n_teams = 8; }
     b->team_threads = (b->nthreads + b->n_teams - 1) / b->n_teams;
     inflaters_start(b);
