@@ -568,13 +568,13 @@ def main():
                                                   "frac": inf_bytes / (kv["inflate_ms"] * 1e6) / HBM_PEAK_GBS, "members_per_launch": pj["kernel_only"]["piece_members"],
                                                   "note": "algorithmic bytes = compressed bytes read + inflated bytes written, one 64 MB piece per launch; the kernel is bound by one lane's dependent symbol decode per member, not by HBM (DESIGN.md 4)"},
                                      "crc32_ms": kv["crc32_ms"], "walk_ms": kv["walk_ms"], "crc32_GBps": kv["out_bytes"] / (kv["crc32_ms"] * 1e6) if kv["crc32_ms"] > 0 else None}
-                # a 64 MB piece is ~3,400 members = wavefronts, about half of what the device holds at once; the command keeps 8 pieces in flight (8 device teams).
+                # a 64 MB piece is ~3,400 members = wavefronts, about half of what the device holds at once; the command keeps 8 pieces (of 96 MB since the end of round 5) in flight (8 device teams).
                 # What the kernel does with the device full: the whole file as one launch
                 pw = subprocess.run([str(REPO / "tools/_build/piece_bench"), str(sp) + ".bam", "1024", "1", "0"], capture_output=True, text=True, timeout=300)
                 kw = json.loads(pw.stdout)["kernel_only"]["v0"]
                 result["inflate"]["device_full"] = {"members_per_launch": json.loads(pw.stdout)["kernel_only"]["piece_members"], "kernel_ms": kw["inflate_ms"], "GBps_compressed": kw["GBps_compressed"], "GBps_inflated": kw["GBps_inflated"],
                                                     "crc32_ms": kw["crc32_ms"], "walk_ms": kw["walk_ms"], "identical_to_zlib": kw.get("identical_to_zlib"),
-                                                    "note": "k_inflate over all members of the file in one launch (what eight 64 MB pieces in flight present to the device); HIP events"}
+                                                    "note": "k_inflate over all members of the file in one launch (what the command's eight pieces in flight present to the device); HIP events"}
             except Exception as ex:
                 result["inflate"] = {"error": repr(ex)[:300]}
             if args.large_sample_length and headline:
