@@ -58,10 +58,12 @@ def same_outputs(od, gd):
 
 @pytest.mark.parametrize("extra,env", [([], {}), (["--chunkSize", "7000", "--mergeContext", "--CHG"], {"MDK_FASTA_THREADS": 5}), (["--chunkSize", "20000"], {"MDK_STANDIN_HANDBACK": 3}),
                                        (["--chunkSize", "333333", "--minOppositeDepth", "2", "--maxVariantFrac", "0.3", "--CHH"], {}), (["--chunkSize", "5000"], {"MDK_DEVICE_INFLATE_ONLY": 1, "MDK_GPU_PIECE_MB": "0.25", "MDK_STANDIN_HANDBACK": 5}),
-                                       (["--chunkSize", "3000", "--CHG"], {"MDK_GROUPS_IN_FLIGHT": 5, "MDK_STANDIN_HANDBACK": 7, "MDK_STANDIN_US_PER_KREC": 20000}), (["--chunkSize", "3000"], {"MDK_GROUPS_IN_FLIGHT": 2})])
+                                       (["--chunkSize", "3000", "--CHG"], {"MDK_GROUPS_IN_FLIGHT": 5, "MDK_STANDIN_HANDBACK": 7, "MDK_STANDIN_US_PER_KREC": 20000}), (["--chunkSize", "3000"], {"MDK_GROUPS_IN_FLIGHT": 2}),
+                                       (["--chunkSize", "5000"], {"MDK_DEVICE_INFLATE_ONLY": 1, "MDK_GPU_PIECE_MB": "0.5", "MDK_DSLAB_EXTRA": 1, "MDK_GPU_INFLATE_TEAMS": 3})])
 def test_extract_main_on_the_standin_equals_oracle(data, tmp_path, extra, env):
     """one process: extract_main's threads, groups of chunks in flight, slabs given back early, chunks handed back to the host preparation, pieces
-    "inflated on the device" (fifth case: every piece after the header's); the last two: five and two groups in flight instead of three"""
+    "inflated on the device" (fifth case: every piece after the header's); then five and two groups in flight instead of three; the last: three device teams with one
+    device slab to spare between them"""
     args = [str(data / "s.fa"), str(data / "s.bam"), "-@", "4"] + extra
     od = oracle(tmp_path, args)
     gd = tmp_path / "gpu"; gd.mkdir()
@@ -72,6 +74,11 @@ def test_extract_main_on_the_standin_equals_oracle(data, tmp_path, extra, env):
         assert int(re.search(r"chunks prepared on the host after all: (\d+)", r.stderr).group(1)) >= 2
     if "MDK_DEVICE_INFLATE_ONLY" in env:
         assert int(re.search(r"on the device (\d+)", r.stderr).group(1)) >= 2
+    # MDK_HOST_PROFILE: where the inflate teams' time went, one line per kind of team (csrc/host/mdk_io.c)
+    teams = dict(re.findall(r"\[mdk host\] (host|device) teams, summed over the teams that have left: (\d+) pieces", r.stderr))
+    assert set(teams) == {"host", "device"} and int(teams["host"]) >= 1, r.stderr[-1500:]
+    if "MDK_DEVICE_INFLATE_ONLY" in env:
+        assert int(teams["device"]) >= 1, r.stderr[-1500:]
 
 
 def run_ranks_cpu(args, n, cwd, env):
