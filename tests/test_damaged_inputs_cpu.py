@@ -36,8 +36,9 @@ def damage(kind, data):
     return {"double_eof": data + data[-28:], "tail_garbage": data + b"xyz" * 10, "no_eof_block": data[:-28], "not_bgzf": b"this is not a BAM file\n" * 500}[kind]
 
 
+@pytest.mark.parametrize("device_pieces", [False, True], ids=["host_inflate", "device_pieces"])
 @pytest.mark.parametrize("kind", ["flip0.001", "flip0.3", "flip0.97", "cut0", "cut10", "cut28", "cut1000", "cut0.4", "cut-29", "cut-1", "double_eof", "tail_garbage", "no_eof_block", "not_bgzf"])
-def test_damaged_bam_ends_as_in_the_oracle(good, tmp_path, kind):
+def test_damaged_bam_ends_as_in_the_oracle(good, tmp_path, kind, device_pieces):
     bam = tmp_path / "d.bam"
     bam.write_bytes(damage(kind, (good / "s.bam").read_bytes()))
     args = [str(good / "s.fa"), str(bam)]
@@ -45,6 +46,8 @@ def test_damaged_bam_ends_as_in_the_oracle(good, tmp_path, kind):
     o = run_oracle(args + ["-o", "out"], cwd=od)
     gd = tmp_path / "gpu"; gd.mkdir()
     env = {"LD_PRELOAD": str(STANDIN), "MDK_STANDIN_DUMP": str(good / "dump.tsv")}
+    if device_pieces:       # test hooks (csrc/host/mdk_io.c): every piece after the header's goes through the device teams (md_piece_*: zlib in the stand-in), 256 KB each
+        env.update({"MDK_DEVICE_INFLATE_ONLY": "1", "MDK_GPU_PIECE_MB": "0.25"})
     try:
         r = mdk.run_cli(args + ["-@", "4", "-o", "out"], cwd=gd, env=env, timeout=120)
     except subprocess.TimeoutExpired:
