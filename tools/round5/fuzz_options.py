@@ -8,9 +8,11 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent.parent
 seed, n = int(sys.argv[1]), int(sys.argv[2]); W = Path(sys.argv[3] if len(sys.argv) > 3 else "/tmp/mdk_fuzz_options"); W.mkdir(parents=True, exist_ok=True)
 rnd = random.Random(seed)
+# the data set follows from the seed too: read length, single or paired ends, Bismark-style records, records split across BGZF members,
+# with or without an index, with mappability tracks
+shape = ["-l", str(rnd.choice([40, 75, 100, 150, 250]))] + [f for f in ("--single", "--bismark", "--split-records", "--no-bai", "--extras") if rnd.random() < 0.35] + ["--bbm", "--bw"]
 if not (W / "s.bam").exists():
-    subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(W / "s"), "-L", "90000,30000", "-c", "14", "-s", "5", "--extras"], check=True, capture_output=True)
-    (W / "r.bed").write_text("chr1\t1000\t30000\nchr1\t45000\t46000\t.\t0\t-\nchr2\t0\t9000\t.\t0\t+\n")
+    subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(W / "s"), "-L", rnd.choice(["90000,30000", "120000", "20000,20000,50000"]), "-c", str(rnd.choice([6, 14, 30])), "-s", str(seed)] + shape, check=True, capture_output=True)
 names = [l[1:].split()[0] for l in open(W / "s.fa") if l.startswith(">")]
 (W / "r.bed").write_text(f"{names[0]}\t1000\t30000\n{names[0]}\t45000\t46000\tx\t0\t-\n{names[-1]}\t0\t9000\tx\t0\t+\n")
 def pick():
@@ -28,6 +30,9 @@ def pick():
     maybe(0.5, "--chunkSize", str(rnd.choice([1, 100, 777, 5000, 33333, 1000000]))); maybe(0.1, "--minConversionEfficiency", str(rnd.choice([0.0, 0.5, 0.9, 1.0])))
     maybe(0.15, "-r", rnd.choice([names[0], f"{names[0]}:2000-40000", f"{names[-1]}:1-5000", f"{names[0]}:50,000", "nosuchcontig", f"{names[0]}:70000-60000"]))
     maybe(0.3, "-@", str(rnd.choice([1, 2, 4, 7])))
+    if rnd.random() < 0.2:
+        a.extend(rnd.choice([["-M", str(W / "s.bw")], ["-B", str(W / "s.bbm")]]))
+        maybe(0.5, "-t", str(rnd.choice([0.01, 0.5, 0.9]))); maybe(0.5, "-b", str(rnd.choice([1, 15, 60])))
     rnd.shuffle(a) if rnd.random() < 0.0 else None
     return a
 env_std = dict(os.environ)
@@ -38,7 +43,9 @@ for it in range(n):
     for d in (od, gd): shutil.rmtree(d, ignore_errors=True); d.mkdir()
     args = a + [str(W / "s.fa"), str(W / "s.bam"), "-o", "out"]
     eo = dict(env_std, MDK_ORACLE_DUMP=str(W / "dump.tsv"))
-    o = subprocess.run([str(REPO / "oracle/_build/mdk_oracle"), "extract"] + args, cwd=od, env=eo, capture_output=True, text=True, timeout=300)
+    # (the oracle reads mappability from a BBM file only -- no libBigWig here --; mdk_synth wrote the same track both ways)
+    oargs = [str(W / "s.bbm") if x == str(W / "s.bw") else "-B" if x == "-M" else x for x in args]
+    o = subprocess.run([str(REPO / "oracle/_build/mdk_oracle"), "extract"] + oargs, cwd=od, env=eo, capture_output=True, text=True, timeout=300)
     eg = dict(env_std, LD_PRELOAD=str(REPO / "tools/_build/libmdk_dev_standin.so"), MDK_STANDIN_DUMP=str(W / "dump.tsv"), HSA_DISABLE_COREDUMP_ON_EXCEPTION="1")
     try:
         g = subprocess.run([str(REPO / "methyldackel_amd/_build/MethylDackel"), "extract"] + args, cwd=gd, env=eg, capture_output=True, text=True, timeout=300); grc = g.returncode; gerr = g.stderr
@@ -53,9 +60,10 @@ for it in range(n):
         for f in fo:
             if (od / f).read_bytes() != (gd / f).read_bytes(): why.append(f"{f} differs")
     # (the oracle abbreviates the usage text: what is compared is the first line either side says)
+    gerr = gerr.replace(str(W / "s.bw"), str(W / "s.bbm"))
     if o.returncode != 0 and isinstance(grc, int) and o.stderr.strip().splitlines()[:1] != [l for l in gerr.strip().splitlines() if not l.startswith("[mdk")][:1]:
         why.append(f"message: {o.stderr.strip().splitlines()[:1]} vs {gerr.strip().splitlines()[:1]}")
     if why:
         bad += 1; print(it, " ".join(a), "->", "; ".join(why)[:600], flush=True)
-print(f"seed {seed}: {n} command lines ({refused} of them refused by the oracle), {bad} differing")
+print(f"seed {seed} (data: {' '.join(shape)}): {n} command lines ({refused} of them refused by the oracle), {bad} differing")
 sys.exit(1 if bad else 0)
