@@ -16,3 +16,11 @@ def test_random_command_lines_equal_the_oracle(tmp_path, seed):
     r = subprocess.run([sys.executable, str(REPO / "tools/round5/fuzz_options.py"), str(seed), "25", str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "25 command lines" in r.stdout and " 0 differing" in r.stdout
+
+
+def test_random_runs_of_the_ranks_driver_equal_the_oracle(tmp_path):
+    """the same for the one-process-per-GPU driver (csrc/host/mdk_ranks.c; tools/round5/fuzz_ranks.py): 2-4 ranks on this host, random chunk sizes
+    and options, chunks dealt or claimed, with or without the index, chunks handed back to the host"""
+    subprocess.run(["make", "-C", str(REPO), "tools/_build/libmdk_dev_standin.so", "tools/_build/mdk_synth"], check=True, capture_output=True)
+    r = subprocess.run([sys.executable, str(REPO / "tools/round5/fuzz_ranks.py"), "13", "10", str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 differing" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
