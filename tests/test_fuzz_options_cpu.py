@@ -24,3 +24,12 @@ def test_random_runs_of_the_ranks_driver_equal_the_oracle(tmp_path):
     subprocess.run(["make", "-C", str(REPO), "tools/_build/libmdk_dev_standin.so", "tools/_build/mdk_synth"], check=True, capture_output=True)
     r = subprocess.run([sys.executable, str(REPO / "tools/round5/fuzz_ranks.py"), "13", "10", str(tmp_path)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " 0 differing" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_random_command_lines_through_the_host_preparation_equal_the_oracles_counters(tmp_path):
+    """the host preparation (the path of a chunk the device hands back, and of MDK_HOST_PREP=1) over a random data shape and random options
+    that bear on the counting: its packed batches, evaluated by tests/batch_eval.py, against the oracle's per-column counters
+    (tools/round5/fuzz_host_prep.py)"""
+    subprocess.run(["make", "-C", str(REPO), "tools/_build/mdk_synth"], check=True, capture_output=True)
+    r = subprocess.run([sys.executable, str(REPO / "tools/round5/fuzz_host_prep.py"), "14", "10", str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 differing" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
