@@ -28,15 +28,15 @@ static void note_records(blk_t *b, sumbuf *sb, const uint8_t *base) {
     const uint8_t *d = b->out; uint32_t L = b->out_len, o = 0;
     b->sum0 = sb->n; b->n_sum = 0; b->ok = 0; b->sorted = 1; b->min_endp = 0x7fffffff; b->max_endp = (int32_t)0x80000000; b->tid0 = b->tidN = -1; b->pos0 = b->posN = -1;
     while(o + 4 <= L) {
-        uint32_t bs = le32(d + o), lq, nc, k; const uint8_t *r = d + o + 4, *c; int32_t rl = 0; mdk_rsum *q;
+        uint32_t bs = le32(d + o), lq, nc, k, rl = 0; const uint8_t *r = d + o + 4, *c; mdk_rsum *q;      /* (rl: unsigned -- a member that starts inside a record is walked as if it started one, and what stands where a CIGAR would adds up to anything) */
         if(bs < 32 || (uint64_t)o + 4 + bs > L) return;
         lq = r[8]; nc = le16(r + 12);
         if(32u + lq + 4u * nc > bs) return;
         c = r + 32 + lq;
-        for(k = 0; k < nc; k++) { uint32_t v = le32(c + 4 * k), op = v & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int32_t)(v >> 4); }
+        for(k = 0; k < nc; k++) { uint32_t v = le32(c + 4 * k), op = v & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += v >> 4; }
         if(sb->n == sb->cap) { sb->cap = sb->cap ? sb->cap * 2 : 4096; sb->v = realloc(sb->v, sizeof(mdk_rsum) * sb->cap); if(!sb->v) { sb->cap = sb->n = 0; return; } }
         q = &sb->v[sb->n++];
-        q->off = (uint32_t)(d + o - base); q->len = bs; q->tid = (int32_t)le32(r); q->pos = (int32_t)le32(r + 4); q->endp = q->pos + (rl > 0 ? rl : 1);
+        q->off = (uint32_t)(d + o - base); q->len = bs; q->tid = (int32_t)le32(r); q->pos = (int32_t)le32(r + 4); q->endp = (int32_t)((uint32_t)q->pos + ((int32_t)rl > 0 ? rl : 1u));
         if(b->n_sum == 0) { b->tid0 = q->tid; b->pos0 = q->pos; }
         else if(q->tid < 0 || q->tid < b->tidN || (q->tid == b->tidN && q->pos < b->posN)) b->sorted = 0;
         if(q->tid < 0) b->sorted = 0;                       /* unplaced records: leave them to the record-by-record path */
@@ -377,7 +377,7 @@ static void *inflater_main(void *arg) {
              * and on many threads, they are not left for the kernel to walk on one core when the process ends (they stay in the page cache) */
             if(b->map && pc.map_end > pc.map_beg) { const size_t a = (pc.map_beg + 4095) & ~(size_t)4095, e = pc.map_end & ~(size_t)4095; if(e > a) (void)madvise((void *)(b->map + a), e - a, MADV_DONTNEED); }
         }
-        if(s && gt < 0 && b->dev) md_host_register(b->dev, s->buf);          /* the device is up: the slab this team has just filled is made known to the runtime here, not by the thread that uploads from it */
+        if(s && gt < 0) { md_dev *dv = __atomic_load_n(&b->dev, __ATOMIC_ACQUIRE); if(dv) md_host_register(dv, s->buf); }          /* the device is up: the slab this team has just filled is made known to the runtime here, not by the thread that uploads from it */
         t1 = now_s(); t_host += t1 - t0; t0 = t1;      /* (a device team: slab wait + copy + device, told apart in td) */
         if(s) {
             n_pieces++;
@@ -385,7 +385,7 @@ static void *inflater_main(void *arg) {
             t_deliver += now_s() - t0;
             /* test hook (MDK_DEVICE_INFLATE_ONLY=1, `extract` only): the host teams leave after the piece that holds the BAM header, so that
              * every other piece is inflated on the device however small the file is */
-            if(gt < 0 && b->host_leaves && b->header_done) break;
+            if(gt < 0 && b->host_leaves) { int hd; pthread_mutex_lock(&b->mu); hd = b->header_done; pthread_mutex_unlock(&b->mu); if(hd) break; }
             continue;
         }
         /* the end of the file, or an error */
@@ -403,7 +403,7 @@ static void *inflater_main(void *arg) {
 }
 static void inflaters_start(mdk_bam *b) {
     int i;
-    b->next_seq = b->pop_seq = 0; b->io_status = 0; b->io_end = 0;
+    pthread_mutex_lock(&b->mu); b->next_seq = b->pop_seq = 0; b->io_status = 0; b->io_end = 0; pthread_mutex_unlock(&b->mu);      /* (no team is running; a thread giving a slab back looks at io_end: mdk_slab_unref) */
     for(i = 0; i < b->n_teams; i++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = -1; if(pthread_create(&b->inf_th[i], NULL, inflater_main, ta)) { free(ta); break; } }
     if(i == 0) { b->io_status = -1; b->inf_done = -1; snprintf(b->err, sizeof(b->err), "cannot create an inflate thread"); }
     b->n_teams = i;
@@ -425,7 +425,8 @@ int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     if(n_teams < 1) n_teams = 1;
     if(n_teams > MDK_GPU_TEAMS_MAX) n_teams = MDK_GPU_TEAMS_MAX;
     pthread_mutex_lock(&b->life_mu);                              /* (the reader thread may be inside a seek, which stops and restarts every team) */
-    b->dev = dev; b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + (getenv("MDK_DSLAB_EXTRA") && atoi(getenv("MDK_DSLAB_EXTRA")) >= 1 ? atoi(getenv("MDK_DSLAB_EXTRA")) : 4);
+    __atomic_store_n(&b->dev, dev, __ATOMIC_RELEASE);             /* (the host teams, already running, look at it without a lock: inflater_main) */
+    b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + (getenv("MDK_DSLAB_EXTRA") && atoi(getenv("MDK_DSLAB_EXTRA")) >= 1 ? atoi(getenv("MDK_DSLAB_EXTRA")) : 4);
     if(b->inf_started) {
         for(k = 0; k < n_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } }
         b->n_gpu_teams = k; b->gpu_started = 1;
@@ -450,7 +451,7 @@ void mdk_bam_detach_device(mdk_bam *b) {
     if(b->cur && b->cur->piece) { slab_destroy(b->cur); b->cur = NULL; }
     pthread_mutex_unlock(&b->mu);
     for(i = 0; i < MDK_GPU_TEAMS_MAX; i++) { md_host_free(b->gpu_stage[i]); b->gpu_stage[i] = NULL; b->gpu_stage_cap[i] = 0; }
-    b->dev = NULL; b->n_gpu_teams = 0;
+    __atomic_store_n(&b->dev, (md_dev *)NULL, __ATOMIC_RELEASE); b->n_gpu_teams = 0;
     pthread_mutex_unlock(&b->life_mu);
 }
 
@@ -542,6 +543,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
     if(getenv("MDK_GPU_PIECE_MB") && atof(getenv("MDK_GPU_PIECE_MB")) >= 0.25 && atof(getenv("MDK_GPU_PIECE_MB")) <= 256) b->gpu_piece_bytes = (size_t)(atof(getenv("MDK_GPU_PIECE_MB")) * 1048576.0);      /* test hook: many small device pieces */
     if(getenv("MDK_INFLATE_TEAMS")) { b->n_teams = atoi(getenv("MDK_INFLATE_TEAMS")); if(b->n_teams < 1) b->n_teams = 1; if(b->n_teams > 8) b->n_teams = 8; }
     b->team_threads = (b->nthreads + b->n_teams - 1) / b->n_teams;
+    (void)crc_wanted();                                           /* (decided here, once, before the threads that ask) */
     inflaters_start(b);
     if((rc = need(b, 12)) <= 0 || memcmp(b->cur->buf + b->off, "BAM\1", 4)) return open_fail(b, fn);
     b->l_text = le32(b->cur->buf + b->off + 4);

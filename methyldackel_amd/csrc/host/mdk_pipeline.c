@@ -796,12 +796,14 @@ static pslot *held_slot(mdk_plan *p, const mdk_chunk *c) {      /* (another thre
     pthread_mutex_unlock(&p->mu);
     return sl;
 }
+static pthread_mutex_t rel_mu = PTHREAD_MUTEX_INITIALIZER;      /* (what it is for: below, at mdk_plan_host_prepare_from) */
 int mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c) {
-    int rc; pslot *sl = NULL;
+    int rc, done; pslot *sl = NULL;
     if(!p || !c || !p->started) return -1;
     sl = held_slot(p, c);
     if(!sl || !sl->hold_slabs) return -1;
-    if(!sl->prepared) { rc = worker_process(p, sl); if(rc < 0) return rc; sl->prepared = 1; }
+    pthread_mutex_lock(&rel_mu); done = sl->prepared; pthread_mutex_unlock(&rel_mu);      /* (mdk_plan_release_records looks at it from the uploader thread) */
+    if(!done) { rc = worker_process(p, sl); if(rc < 0) return rc; pthread_mutex_lock(&rel_mu); sl->prepared = 1; pthread_mutex_unlock(&rel_mu); }
     c->batch = sl->c.batch;
     return 0;
 }
@@ -811,7 +813,6 @@ int mdk_plan_host_prepare(mdk_plan *p, mdk_chunk *c) {
  * thread may be handed the same chunk back by the device (MDK_ERR_PREP_HOST): the two meet under rel_mu.  Whoever comes first decides --
  * released: the fallback reads the records back from the device slot; fallback first: the slabs stay referenced until the chunk is recycled
  * and are parsed where they lie. */
-static pthread_mutex_t rel_mu = PTHREAD_MUTEX_INITIALIZER;
 int mdk_plan_host_prepare_from(mdk_plan *p, mdk_chunk *c, md_dev *dev, int slot) {
     pslot *sl; int from_device;
     if(!p || !c || !p->started) return -1;

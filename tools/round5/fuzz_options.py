@@ -8,6 +8,8 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent.parent
 seed, n = int(sys.argv[1]), int(sys.argv[2]); W = Path(sys.argv[3] if len(sys.argv) > 3 else "/tmp/mdk_fuzz_options"); W.mkdir(parents=True, exist_ok=True)
 rnd = random.Random(seed)
+# MDK_FUZZ_CLI: another build of the command (a sanitizer build with the stand-in linked in: then nothing is preloaded)
+CLI = os.environ.get("MDK_FUZZ_CLI", str(REPO / "methyldackel_amd/_build/MethylDackel"))
 # the data set follows from the seed too: read length, single or paired ends, Bismark-style records, records split across BGZF members,
 # with or without an index, with mappability tracks
 shape = ["-l", str(rnd.choice([40, 75, 100, 150, 250]))] + [f for f in ("--single", "--bismark", "--split-records", "--no-bai", "--extras") if rnd.random() < 0.35] + ["--bbm", "--bw"]
@@ -46,9 +48,9 @@ for it in range(n):
     # (the oracle reads mappability from a BBM file only -- no libBigWig here --; mdk_synth wrote the same track both ways)
     oargs = [str(W / "s.bbm") if x == str(W / "s.bw") else "-B" if x == "-M" else x for x in args]
     o = subprocess.run([str(REPO / "oracle/_build/mdk_oracle"), "extract"] + oargs, cwd=od, env=eo, capture_output=True, text=True, timeout=300)
-    eg = dict(env_std, LD_PRELOAD=str(REPO / "tools/_build/libmdk_dev_standin.so"), MDK_STANDIN_DUMP=str(W / "dump.tsv"), HSA_DISABLE_COREDUMP_ON_EXCEPTION="1")
+    eg = dict(env_std, **({} if os.environ.get("MDK_FUZZ_CLI") else {"LD_PRELOAD": str(REPO / "tools/_build/libmdk_dev_standin.so")}), MDK_STANDIN_DUMP=str(W / "dump.tsv"), HSA_DISABLE_COREDUMP_ON_EXCEPTION="1")
     try:
-        g = subprocess.run([str(REPO / "methyldackel_amd/_build/MethylDackel"), "extract"] + args, cwd=gd, env=eg, capture_output=True, text=True, timeout=300); grc = g.returncode; gerr = g.stderr
+        g = subprocess.run([CLI, "extract"] + args, cwd=gd, env=eg, capture_output=True, text=True, timeout=300); grc = g.returncode; gerr = g.stderr
     except subprocess.TimeoutExpired:
         grc, gerr = "HANG", ""
     why = []

@@ -7,6 +7,8 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent.parent
 seed, n = int(sys.argv[1]), int(sys.argv[2]); W = Path(sys.argv[3] if len(sys.argv) > 3 else f"/tmp/mdk_fuzz_ranks_{seed}"); W.mkdir(parents=True, exist_ok=True)
 rnd = random.Random(seed)
+# MDK_FUZZ_CLI: another build of the command (a sanitizer build with the stand-in linked in: then nothing is preloaded)
+CLI = os.environ.get("MDK_FUZZ_CLI", str(REPO / "methyldackel_amd/_build/MethylDackel"))
 if not (W / "s.bam").exists():
     subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(W / "s"), "-L", rnd.choice(["150000,60000", "90000,30000,30000", "200000"]), "-c", str(rnd.choice([8, 16])), "-s", str(seed), "--extras"] + (["--split-records"] if rnd.random() < 0.4 else []), check=True, capture_output=True)
 bad = 0
@@ -20,7 +22,7 @@ for it in range(n):
     if rnd.random() < 0.2: a += ["--minOppositeDepth", "2", "--maxVariantFrac", "0.3"]
     a += ["--chunkSize", str(rnd.choice([1500, 4000, 9000, 20000, 70000, 1000000]))]
     world = rnd.choice([2, 2, 3, 4])
-    env = {"LD_PRELOAD": str(REPO / "tools/_build/libmdk_dev_standin.so"), "MDK_STANDIN_DUMP": str(W / "dump.tsv"), "HSA_DISABLE_COREDUMP_ON_EXCEPTION": "1"}
+    env = {**({} if os.environ.get("MDK_FUZZ_CLI") else {"LD_PRELOAD": str(REPO / "tools/_build/libmdk_dev_standin.so")}), "MDK_STANDIN_DUMP": str(W / "dump.tsv"), "HSA_DISABLE_COREDUMP_ON_EXCEPTION": "1"}
     if rnd.random() < 0.4: env["MDK_CLAIM"] = "1"
     if rnd.random() < 0.3: env["MDK_NO_INDEX"] = "1"
     if rnd.random() < 0.3: env["MDK_STANDIN_HANDBACK"] = str(rnd.choice([2, 3, 5]))
@@ -35,7 +37,7 @@ for it in range(n):
     procs = []
     for r in range(world):
         e = dict(os.environ); e.update(env); e.update({"MDK_WORLD": str(world), "MDK_RANK": str(r), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
-        procs.append(subprocess.Popen([str(REPO / "methyldackel_amd/_build/MethylDackel"), "extract"] + args, cwd=gd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        procs.append(subprocess.Popen([CLI, "extract"] + args, cwd=gd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     why = []
     try:
         outs = [p.communicate(timeout=300) for p in procs]
