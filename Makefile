@@ -38,7 +38,7 @@ tools/_build/pin_probe: tools/pin_probe.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ tools/pin_probe.hip
 tools/_build/inflate_emu: tools/inflate_emu.cpp methyldackel_amd/csrc/mdk_inflate_core.h methyldackel_amd/csrc/mdk_crc32_core.h
 	@mkdir -p tools/_build
-	g++ -O2 -Wall -o $@ tools/inflate_emu.cpp -Imethyldackel_amd/csrc -lz
+	g++ -O2 -Wall -Wno-unknown-pragmas -o $@ tools/inflate_emu.cpp -Imethyldackel_amd/csrc -lz
 tools/_build/piece_bench: tools/piece_bench.c include/mdk_hip.h $(B)/libmdk_hip.so
 	@mkdir -p tools/_build
 	$(CC) -O2 -g -Wall -Iinclude -o $@ tools/piece_bench.c -L$(B) -lmdk_hip -Wl,-rpath,'$$ORIGIN/../../$(B)' -lz

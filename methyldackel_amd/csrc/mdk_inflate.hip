@@ -1,16 +1,15 @@
 // mdk_inflate.hip -- BGZF inflate and BAM record framing on the device (the step the reference pays for
 // inside htslib's sam_itr_next, common.c:413).
 //
-//   k_inflate     one WAVEFRONT per BGZF member.  Inside a Huffman block every lane decodes the symbol that would start at its bit of the
-//                 stream's next 64 (mdk_inflate_core.h inf_decode_at) and a walk over the results picks the real ones -- ~5 symbols per round
-//                 of table lookups on the bench's BAM (tools/inflate_emu prints the statistics); their output positions are a prefix sum in DPP.  Batches of <= 128 match tokens / 1 KiB of output: literals
-//                 go straight into a 2 KiB output window (INF_WIN) in LDS, matches become tokens.  Between batches all 64 lanes work: (1) top
-//                 up the LDS ring of compressed words with one coalesced load, (2) FAR matches -- source older than the LDS window -- one lane
-//                 per token, bytes from global memory (written by an earlier batch of this wavefront), (3) NEAR matches: every token whose
-//                 source is final is copied at once, a short one by its own lane, a long one by the whole wavefront (a self-overlapping
-//                 match doubles the copied span per round), (4) the batch's bytes leave the window for global memory, coalesced.  A 64 KiB
-//                 member is ~22 k symbols; the file's ~10^4..10^5 members are what fills the machine (one lane per member, round 2's
-//                 experiment, left 434 wavefronts of diverging lanes).
+//   k_inflate     one WAVEFRONT per BGZF member at a time; the wavefronts of a launch draw members from a counter until none is left.  A Huffman
+//                 block is decoded 64 stretches of the stream at once (mdk_inflate_core.h: every lane runs a chain of symbols through its
+//                 stretch, first from a guessed start, then from where its left neighbour's chain ended; two passes settle 19 of 20 batches) and
+//                 leaves TOKENS in a scratch area of the wavefront in global memory, token j of the 64 lanes side by side (one coalesced store per
+//                 step).  The tokens become bytes in batches of <= 2 KiB through a 4 KiB output window in LDS: a prefix sum (DPP) places 64 tokens
+//                 at a time, literals go into the window, and all bytes of the batch's matches are resolved together -- source pointers per byte,
+//                 pointer jumping through the batch's own matches, one gather (a source older than the window comes from global memory, written
+//                 there by an earlier batch of the same wavefront) --, then the batch leaves the window as coalesced dword stores.  A 64 KiB member
+//                 of a BAM file is ~11 k symbols in ~530 chain steps of the wavefront (20 symbols per step) and ~33 batches of output.
 //   k_crc32       one wavefront per member: the CRC32 of the inflated bytes against the member's trailer -- what htslib's bgzf_read_block
 //                 checks for every block the reference reads.  Coalesced 16-byte loads; every lane keeps the CRC of its own column of the
 //                 member (slice-by-4 tables and a "1008 zero bytes" operator in LDS), the 64 columns are merged with GF(2) multiplications.
@@ -24,19 +23,28 @@
 #include "mdk_inflate_core.h"
 #include "mdk_crc32_core.h"
 
-// coherent byte / word loads of what this wavefront stored earlier (plain loads could hit a stale line in the CU's L1)
-__device__ __forceinline__ uint32_t ld_u32_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
+#ifndef INF_EXP
+#define INF_EXP 0
+#endif
 struct InfParams {
     const uint8_t *comp;              // the piece's compressed bytes (device), 4-byte aligned base
     const md_inf_member *mem; int n_mem;
     uint8_t *out;                     // inflated bytes
-    uint32_t *status;                 // [0] = first error: code | member << 8 (0 = none)
+    uint32_t *status;                 // [0] = first error: code | member << 8 (0 = none); [2] = the counter the wavefronts draw members from
+    uint32_t *tok;                    // token scratch: INF_TOK_WORDS words per wavefront of the launch
+#ifdef INF_PROFILE
+    unsigned long long *prof;         // [16] cycles per phase, summed over the wavefronts (experiment builds only)
+#endif
 };
+#ifdef INF_PROFILE
+#define PROF_T(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_acc[k] += now_ - prof_t; prof_t = now_; } while(0)
+enum { PR_STAGE = 0, PR_HEADER, PR_STORED, PR_CHAIN1, PR_CHAIN2, PR_CHAINX, PR_CONFIRM, PR_TOKFETCH, PR_TOKPLACE, PR_SOURCES, PR_JUMP, PR_GATHER, PR_FLUSH, PR_OTHER, PR_N };
+#else
+#define PROF_T(k) do { } while(0)
+#endif
 
 // Inclusive prefix sum over the wavefront's 64 lanes in the VALU's own data paths (DPP: shifts inside the rows of 16, then lane 15 / lane 31
-// broadcast to the rows behind) -- six adds and no trip through LDS; __shfl_up compiles to ds_bpermute_b32, six dependent LDS round trips
-// in the middle of every decode round.
+// broadcast to the rows behind) -- six adds and no trip through LDS.
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1 (a lane without a source adds 0)
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
@@ -46,9 +54,63 @@ __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
     return x;
 }
+// the same with max over signed values (a lane without a source keeps its own)
+__device__ __forceinline__ int wave_incl_max(int x) {
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x111, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x112, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x114, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x118, 0xf, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+__device__ __forceinline__ uint32_t leading_ones(unsigned long long m) { return ~m ? (uint32_t)(__ffsll((long long)~m) - 1) : 64u; }      // lanes 0 .. n-1 all set
+
+// A decode table by the whole wavefront (mdk_inflate_core.h: the pieces): lane i looks after symbols i, i + 64, ...; how many symbols have
+// each length and which rank a symbol has among those of its length are ballots; every symbol then fills its own entries.  0, or
+// inf_code_space's verdict.  Ends with a barrier: the table is complete for every lane.
+template <typename T, int CHUNKS>
+__device__ __forceinline__ int build_table(const uint8_t *lens, const int n, const int tb, T *tab, uint16_t *symtab, InfLong *L, const int kind, const int strict, const int lane) {
+    uint32_t len_c[CHUNKS], count[16], first[16], off[16];
+#pragma unroll
+    for(int c = 0; c < CHUNKS; c++) { const int i = 64 * c + lane; len_c[c] = i < n ? (uint32_t)(lens[i] & 15) : 0u; }
+    count[0] = 0;
+#pragma unroll
+    for(int l = 1; l < 16; l++) {
+        uint32_t k = 0;
+#pragma unroll
+        for(int c = 0; c < CHUNKS; c++) k += (uint32_t)__popcll(__ballot(len_c[c] == (uint32_t)l));
+        count[l] = k;
+    }
+    const int rc = inf_code_space(count, kind, strict);
+    if(rc) return rc;
+    inf_code_layout(count, first, off);
+    inf_table_clear(tab, tb, kind, (uint32_t)lane);
+    if(L && lane == 0) {
+#pragma unroll
+        for(int l = 1; l < 16; l++) inf_long_store(*L, count, first, off, (uint32_t)l);
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for(int c = 0; c < CHUNKS; c++) {
+        uint32_t rank = 0, code = 0;
+#pragma unroll
+        for(int l = 1; l < 16; l++) {
+            const unsigned long long mk = __ballot(len_c[c] == (uint32_t)l);
+            if(len_c[c] == (uint32_t)l) { const uint32_t before = (uint32_t)__popcll(mk & lt); rank = off[l] + before; code = first[l] + before; }
+            // (the next chunk's symbols of this length go on from where this chunk's end, in rank and in code)
+            const uint32_t seen = (uint32_t)__popcll(mk);
+            off[l] += seen; first[l] += seen;
+        }
+        if(len_c[c]) inf_place_symbol(tab, symtab, tb, kind, (uint32_t)(64 * c + lane), len_c[c], code, rank);
+    }
+    __syncthreads();
+    return 0;
+}
 
 // One member by one wavefront.
-__device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S, const int m, const int lane) {
+__device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S, uint32_t *tok, const int m, const int lane) {
     const md_inf_member M = P.mem[m];
     if(M.out_len == 0) return;
     const uint64_t a0 = M.in_off & ~3ull;                               // aligned start of the stream's words
@@ -56,145 +118,179 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
     const uint32_t n_words = (uint32_t)((M.in_off + M.in_len + 3 - a0) >> 2);
     const uint32_t *words = (const uint32_t *)(P.comp + a0);
     uint8_t *out = P.out + M.out_off;
-    uint32_t filled = 0;                                               // stream words put into the ring so far
+    // the member's output as a buffer: a lane that wants no byte of it asks behind its end, which costs no memory access
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, (int)M.out_len, 0x00020000);
     // everything below is wave-uniform: position in the stream (bits), bytes produced, the block the decoder stands in
     uint32_t bitpos = 8u * skip, pos = 0, in_block = 0, last = 0, stored_left = 0;
     auto fail = [&](uint32_t code) { if(lane == 0) atomicCAS(P.status, 0u, code | ((uint32_t)m << 8)); };
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for(;;) {
-        // (1) top up the ring: word w may replace word w-256 once the decoder stands behind that one
-        while(filled + 64 <= (bitpos >> 5) + INF_IN_WORDS) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = w < n_words ? words[w] : 0u; filled += 64; }
+#ifdef INF_PROFILE
+    unsigned long long prof_acc[PR_N] = {0}, prof_t = __builtin_amdgcn_s_memtime();
+    struct ProfOut { const InfParams &P; unsigned long long *acc; int lane; __device__ ~ProfOut() { if(lane == 0) for(int k = 0; k < PR_N; k++) atomicAdd(P.prof + k, acc[k]); } } prof_out{P, prof_acc, lane};
+#endif
+    auto stage = [&](uint32_t wbase, uint32_t count) {                  // words wbase .. of the stream into S.in, coalesced; words behind the stream read as zero
         __syncthreads();
-        const uint32_t beg = pos; uint32_t n_tok = 0, err = 0, fin = 0;
-        if(in_block == 0) {                                            // a block header: one lane, through the bit reader; a batch of its own
-            if(lane == 0) inf_header_batch(S, bitpos);
+        for(uint32_t i = (uint32_t)lane; i < count; i += 64) { const uint32_t w = wbase + i; S.in[i] = w < n_words ? __builtin_nontemporal_load(words + w) : 0u; }
+        __syncthreads();
+    };
+    auto flush = [&](uint32_t beg, uint32_t end) {                      // whole aligned words of the window as dwords (the global address is whatever the member's offset makes it), the edges as bytes
+        const uint32_t p0 = (beg + 3u) & ~3u, p1 = end & ~3u;
+        if(p0 <= p1) {
+            for(uint32_t p = p0 + 4u * lane; p < p1; p += 256) { const uint32_t v = *(const uint32_t *)&S.win[p & (INF_WIN - 1)]; __builtin_memcpy(out + p, &v, 4); }
+            if(beg + lane < p0) out[beg + lane] = S.win[(beg + lane) & (INF_WIN - 1)];
+            if(p1 + lane < end) out[p1 + lane] = S.win[(p1 + lane) & (INF_WIN - 1)];
+        } else for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
+    };
+    for(;;) {
+        const uint32_t wbase = bitpos >> 5, rel = bitpos & 31u;
+        uint32_t fin = 0;
+        if(in_block == 0) {                                            // a block header: one lane reads it, all lanes build its tables
+            PROF_T(PR_OTHER); stage(wbase, INF_HDR_WORDS); PROF_T(PR_STAGE);
+            if(lane == 0) inf_header_open(S, rel);
             __syncthreads();
-            bitpos = S.bitpos; in_block = S.in_block; last = S.last; stored_left = S.stored_left; err = S.err;
-        } else if(in_block == 2) {                                     // a stored block: bytes out of the ring, all lanes
-            const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH;
-            for(uint32_t i = lane; i < n; i += 64) S.win[(pos + i) & (INF_WIN - 1)] = inf_ring_byte(S, bitpos, i);
+            uint32_t err = S.err; const uint32_t type = S.h.type;
+            if(!err && type == 1) { inf_header_fixed_lens(S, (uint32_t)lane); __syncthreads(); }
+            if(!err && type == 2) {
+                if(build_table<inf_dist_t, 1>(S.h.cl, 19, INF_CL_TB, S.dist, nullptr, nullptr, 2, 1, lane)) err = INF_E_CODELEN;
+                if(!err) { if(lane == 0) inf_header_lens(S); __syncthreads(); err = S.err; }
+            }
+            if(!err && type != 0) {
+                const int nlit = (int)S.h.nlit, ndist = (int)S.h.ndist;
+                if(build_table<inf_dist_t, 1>(S.h.lens + nlit, ndist, INF_DIST_TB, S.dist, S.dsym, &S.dl, 1, type == 2, lane)) err = INF_E_DISTTABLE;
+                else if(build_table<inf_lit_t, 5>(S.h.lens, nlit, INF_LIT_TB, S.lit, S.lsym, &S.ll, 0, 1, lane)) err = INF_E_LITTABLE;
+                in_block = 1;
+            } else in_block = S.in_block;
+            bitpos = 32u * wbase + S.bitpos; last = S.last; stored_left = S.stored_left;
+            PROF_T(PR_HEADER);
+            if(err || (bitpos >> 5) > n_words) { fail(err ? err : (uint32_t)INF_E_INPUT); return; }
+            continue;
+        }
+        if(in_block == 2) {                                            // a stored block: bytes out of the staged words, all lanes
+            stage(wbase, INF_STORED_WORDS);
+            const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH, beg = pos;
+            if(pos + n > M.out_len) { fail(INF_E_OVERRUN); return; }
+            for(uint32_t i = lane; i < n; i += 64) S.win[(pos + i) & (INF_WIN - 1)] = inf_ring_byte(S, rel, i);
             pos += n; bitpos += 8u * n; stored_left -= n;
             if(stored_left == 0) { in_block = 0; fin = last; }
-        } else {
-            // a Huffman block, in rounds: every lane decodes the symbol that would start at its bit of the next 64; the walk keeps the real ones
-            const uint32_t lim = beg + (INF_BATCH_BYTES - 258), blim = bitpos + 32u * INF_BATCH_WORDS;
-            for(;;) {
-                const InfSym sy = inf_decode_at(S, bitpos + (uint32_t)lane);
-                // the walk: lane 0's symbol is real, the next real one starts where it ends, ... -- a scalar loop over readlane; adv = the symbol's
-                // bits, with bit 8 set where the walk ends behind this symbol (end of block) and bit 9 where it ends AT it (not a code)
-                const uint32_t adv = sy.kind >= 3 ? 0x200u : sy.kind == 2 ? (sy.nbits | 0x100u) : sy.nbits;
-                // (either stop bit carries the walk past lane 63, so the loop tests one thing; where it really stands is put right behind it)
-                uint32_t off = 0, a = 0, lastl = 0; unsigned long long V = 0;
-                do { lastl = off; V |= 1ull << off; a = (uint32_t)__builtin_amdgcn_readlane((int)adv, (int)off); off += a; } while(off < 64);
-                off = lastl + (a & 0xffu);
-                uint32_t stop = a >= 0x200u ? (uint32_t)__builtin_amdgcn_readlane((int)sy.kind, (int)lastl) : a >= 0x100u ? 2u : 0u;
-                if(stop >= 3) V &= ~(1ull << lastl);
-                bool valid = (V >> lane) & 1ull;
-                const uint32_t olen = !valid ? 0u : sy.kind == 0 ? 1u : sy.kind == 1 ? (sy.val & 0xffffu) : 0u;
-                const uint32_t incl = wave_incl_sum(olen);
-                const uint32_t dst = pos + incl - olen;
-                bool ism = valid && sy.kind == 1;
-                unsigned long long mball = __ballot(ism);
-                // the batch's limits: 64 match tokens, INF_BATCH_BYTES of output -- the first symbol that does not fit ends the round in front of it
-                // (rarely the case: asked of the round as a whole first -- its last real symbol's end, all its matches)
-                const uint32_t vend = V ? (uint32_t)__builtin_amdgcn_readlane((int)(dst + olen), 63 - __clzll((long long)V)) : pos;
-                unsigned long long cm = 0;
-                if(vend > beg + INF_BATCH_BYTES || n_tok + (uint32_t)__popcll(mball) > INF_MAX_TOK)
-                    cm = __ballot(valid && ((ism && n_tok + (uint32_t)__popcll(mball & lt) >= INF_MAX_TOK) || dst + olen > beg + INF_BATCH_BYTES));
-                if(cm) { const int c = __ffsll((long long)cm) - 1; V &= (1ull << c) - 1ull; off = (uint32_t)c; stop = 1; valid = (V >> lane) & 1ull; ism = ism && valid; mball = __ballot(ism); }
-                if(__ballot(ism && (sy.val >> 16) > dst)) { err = INF_E_DIST; break; }
-                if(valid && sy.kind == 0) S.win[dst & (INF_WIN - 1)] = (uint8_t)sy.val;
-                if(ism) { InfToken t; t.dst = dst; t.len_dist = sy.val; S.tok[n_tok + (uint32_t)__popcll(mball & lt)] = t; }
-                n_tok += (uint32_t)__popcll(mball);
-                pos = cm ? (V ? (uint32_t)__builtin_amdgcn_readlane((int)(dst + olen), 63 - __clzll((long long)V)) : pos) : vend;
-                bitpos += off;
-                if(stop >= 3) { err = stop == 3 ? INF_E_SYMBOL : INF_E_DIST; break; }
-                if(stop == 2) { in_block = 0; fin = last; break; }
-                if(stop == 1 || n_tok >= INF_MAX_TOK || pos > lim || bitpos > blim) break;
-            }
-            __syncthreads();                                          // the window and the tokens are in LDS for every lane
+            if(fin && pos != M.out_len) { fail(INF_E_SHORT); return; }
+            if((bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, M.in_len))) { fail(INF_E_INPUT); return; }
+            __syncthreads();
+            flush(beg, pos); PROF_T(PR_STORED);
+            if(fin) return;
+            continue;
         }
-        if(!err && pos > M.out_len) err = INF_E_OVERRUN;
-        if(!err && fin && pos != M.out_len) err = INF_E_SHORT;
-        if(err || (bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, M.in_len))) { fail(err ? err : (uint32_t)INF_E_INPUT); return; }
-        const uint32_t end = pos;
-        // (2) far matches: one lane per token (of each 64 of them); every byte comes from global memory
-        {
-            bool waited = false;
-            for(uint32_t tb = 0; tb < n_tok; tb += 64) {
-                bool far = false;
-                InfToken t; t.dst = 0; t.len_dist = 0;
-                if(tb + (uint32_t)lane < n_tok) { t = S.tok[tb + (uint32_t)lane]; far = inf_tok_far(t, beg); }
-                if(__ballot(far)) {
-                    if(!waited) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); waited = true; }      // the earlier batches' stores have reached L2
-                    if(far) {
-                        // 16 bytes per round trip: the five aligned words that hold them are requested together, then cut to the source's
-                        // byte offset (v_alignbyte) and stored into the window byte by byte (its position there is unaligned too)
-                        const uint32_t len = t.len_dist & 0xffffu; const uint8_t *sp = out + (t.dst - (t.len_dist >> 16));
-                        for(uint32_t i = 0; i < len; i += 16) {
-                            const uintptr_t a = (uintptr_t)(sp + i); const uint32_t *wp = (const uint32_t *)(a & ~(uintptr_t)3); const uint32_t k = (uint32_t)(a & 3u);
-                            const uint32_t n = len - i < 16u ? len - i : 16u;
-                            const uint32_t w0 = ld_u32_l2(wp), w1 = ld_u32_l2(wp + 1), w2 = ld_u32_l2(wp + 2), w3 = ld_u32_l2(wp + 3), w4 = ld_u32_l2(wp + 4);
-                            uint32_t b[4] = {__builtin_amdgcn_alignbyte(w1, w0, k), __builtin_amdgcn_alignbyte(w2, w1, k), __builtin_amdgcn_alignbyte(w3, w2, k), __builtin_amdgcn_alignbyte(w4, w3, k)};
-#pragma unroll
-                            for(uint32_t q = 0; q < 16; q++) if(q < n) S.win[(t.dst + i + q) & (INF_WIN - 1)] = (uint8_t)(b[q >> 2] >> (8 * (q & 3)));
-                        }
-                    }
-                }
-            }
-            if(waited) __syncthreads();
+        // ---- a Huffman batch: 64 stretches of sw words, chains until a prefix of the lanes agrees ----
+        const uint32_t left_words = n_words > wbase ? n_words - wbase : 1u;
+        uint32_t sw = (left_words + 63u) / 64u; sw = sw < INF_SW_MIN ? INF_SW_MIN : sw > INF_SW_MAX ? INF_SW_MAX : sw; sw |= 1u;
+        const uint32_t sub = 32u * sw;
+        PROF_T(PR_OTHER); stage(wbase, 64u * sw + 8u); PROF_T(PR_STAGE);
+        const uint32_t stream_end = 32u * (n_words - wbase) + 64u;      // no true chain gets this far without an error
+        uint32_t start = rel + sub * (uint32_t)lane; const uint32_t sub_end = start + sub;
+        const bool active = lane == 0 || start < stream_end;
+        InfChain c; c.end = start; c.n = 0; c.status = INF_C_BADLIT;
+        bool need = active, written = false; uint32_t passes = 0, nconf = 1, lstat = 0;
+        for(;;) {
+            if(need) c = inf_chain(S, start, sub_end, passes != 0, tok + lane);
+            PROF_T(passes == 0 ? PR_CHAIN1 : passes == 1 ? PR_CHAIN2 : PR_CHAINX);
+            if(passes) written = written || need;
+            passes++;
+            // who goes again: a lane whose left neighbour's chain ended elsewhere than where it started, or whose tokens are not written down yet (the first pass writes nothing)
+            const uint32_t pend = (uint32_t)__shfl_up((int)c.end, 1), pst = (uint32_t)__shfl_up((int)c.status, 1);
+            need = lane == 0 ? !written : (active && pst == INF_C_OK && (start != pend || !written));
+            if(need && lane) start = pend;
+            if(passes == 1) continue;
+            nconf = leading_ones(__ballot(lane == 0 || (active && pst == INF_C_OK && !need)));
+            lstat = (uint32_t)__builtin_amdgcn_readlane((int)c.status, (int)nconf - 1);
+            if(lstat != INF_C_OK || passes >= INF_MAX_PASSES || !__ballot(need)) break;        // (nobody needs to go again = all active lanes agree)
         }
-        // (3) near matches, the tokens in stream order, 64 at a time.  Everything below the first token not yet copied is final (literals were
-        // written while decoding, far matches above, the 64 tokens before these), so every token whose source ends below that mark can be
-        // copied at once -- short ones (most: a BAM field repeated from the record before) each by its own lane, byte by byte, which also gets a
-        // match that overlaps its own output right; a long one, when it is the first, by the whole wavefront (span-doubling rounds).  A handful
-        // of rounds per 64 tokens instead of one per token.
-        for(uint32_t tb = 0; tb < n_tok; tb += 64) {
-            InfToken t; t.dst = 0; t.len_dist = 0; bool mine = false;
-            if(tb + (uint32_t)lane < n_tok) { t = S.tok[tb + (uint32_t)lane]; mine = !inf_tok_far(t, beg); }
-            const uint32_t len = t.len_dist & 0xffffu, dist = t.len_dist >> 16, src = t.dst - dist;
-            unsigned long long pending = __ballot(mine);
-            while(pending) {
-                const int f = __ffsll((long long)pending) - 1;
-                const uint32_t W = (uint32_t)__builtin_amdgcn_readlane((int)t.dst, f), flen = (uint32_t)__builtin_amdgcn_readlane((int)len, f);
-                if(flen > INF_NEAR_LANE_MAX) {
-                    const uint32_t fdist = (uint32_t)__builtin_amdgcn_readlane((int)dist, f);
-                    uint32_t done = 0, span = fdist;
-                    while(done < flen) {
-                        const uint32_t n = span < flen - done ? span : flen - done;
-                        inf_near_round(S.win, W, fdist, done, n, (uint32_t)lane);
-                        __syncthreads();
-                        done += n; span <<= 1;
-                    }
-                    pending &= ~(1ull << f);
-                    continue;
-                }
-                const bool ready = ((pending >> lane) & 1ull) && len <= INF_NEAR_LANE_MAX && (lane == f || src + len <= W);
-                if(ready) for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = S.win[(src + i) & (INF_WIN - 1)];
-                pending &= ~__ballot(ready);
+        if(lstat == INF_C_BADLIT || lstat == INF_C_BADDIST) { fail(lstat == INF_C_BADLIT ? (uint32_t)INF_E_SYMBOL : (uint32_t)INF_E_DIST); return; }
+        const uint32_t cn = (uint32_t)lane < nconf ? c.n : 0u, tincl = wave_incl_sum(cn);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)tincl, 63), lend = (uint32_t)__builtin_amdgcn_readlane((int)c.end, (int)nconf - 1);
+        bitpos = 32u * wbase + lend;
+        if(lstat == INF_C_EOB) { in_block = 0; fin = last; }
+        if((bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, M.in_len))) { fail(INF_E_INPUT); return; }
+        __syncthreads();                                               // the staged words are done with: their memory now holds the output batches' state
+        S.o.tpre[lane] = tincl - cn; if(lane < 2) S.o.tpre[64 + lane] = total;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");             // the tokens are read back by other lanes than wrote them
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads(); PROF_T(PR_CONFIRM);
+        // ---- the tokens into bytes, a batch of output at a time ----
+        uint32_t g = 0;
+        while(g < total) {
+            const uint32_t beg = pos, base0 = beg & ~31u;
+            S.o.starts[lane] = 0;                                        // (INF_BATCH_BYTES / 32 = 64 words)
+            __syncthreads();
+            bool full = false;
+            while(g < total && !full) {
+                const uint32_t gi = g + (uint32_t)lane; const bool has = gi < total;
+                uint32_t t = 0, len = 0;
+                if(has) { const uint32_t col = inf_tok_column(S, gi); t = tok[64u * (gi - S.o.tpre[col]) + col]; len = inf_tok_len(t); }
+                const uint32_t incl = wave_incl_sum(len), at = pos + incl - len; PROF_T(PR_TOKFETCH);
+                const uint32_t take = leading_ones(__ballot(has && at + len <= base0 + INF_BATCH_BYTES));
+                if(take == 0) { full = true; break; }                    // (a token is at most 258 bytes: the first of a batch always fits)
+                bool ok = true;
+                if((uint32_t)lane < take) ok = inf_tok_place(S, t, at, base0);
+                if(__ballot(!ok)) { fail(INF_E_DIST); return; }
+                pos = (uint32_t)__builtin_amdgcn_readlane((int)(at + len), (int)take - 1); g += take;
+                if(take < 64 && g < total) full = true;
+                if(pos > M.out_len) { fail(INF_E_OVERRUN); return; }
+                PROF_T(PR_TOKPLACE);
+            }
+            __syncthreads();
+            const uint32_t end = pos;
+            // matches: every byte's source, pointer jumping through the batch's own matches, one gather
+            {
+                const int lst = inf_lz_last_start(S, (uint32_t)lane);
+                const int run = __shfl_up(wave_incl_max(lst), 1);        // the last start mark in front of the lane's bytes
+                const uint32_t carry = (lane > 0 && run >= 0) ? S.o.aux[run] : 0u;
+                const uint32_t inr = inf_lz_inrange((uint32_t)lane, base0, beg, end);
+                uint32_t q[32];
+                inf_lz_sources(S, (uint32_t)lane, base0, inr, carry, q);
                 __syncthreads();
+                inf_lz_publish(S, (uint32_t)lane, q);
+                __syncthreads(); PROF_T(PR_SOURCES);
+                for(;;) {
+                    const bool moved = inf_lz_jump(S, (uint32_t)lane, base0, beg, inr, q);
+                    if(!__ballot(moved)) break;
+                    __syncthreads();
+                    inf_lz_publish(S, (uint32_t)lane, q);
+                    __syncthreads();
+                }
+                PROF_T(PR_JUMP);
+                bool far = false;
+#pragma unroll
+                for(uint32_t j = 0; j < 32; j++) far = far || (((inr >> j) & 1u) && q[j] + INF_WIN < end);
+#if INF_EXP == 1
+                const bool any_far = false;
+#else
+                const bool any_far = __ballot(far) != 0;
+#endif
+#if INF_EXP != 3
+                if(any_far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the earlier batches' stores have reached L2
+#endif
+                inf_lz_gather(S, (uint32_t)lane, base0, end, inr, q, any_far, [&](uint32_t p, bool wanted) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(out_rsrc, wanted ? p : 0xffffffffu, 0, INF_EXP == 2 ? 0 : 16 /* sc1: past the CU's L1 */); });
+                __syncthreads(); PROF_T(PR_GATHER);
             }
+            flush(beg, end); PROF_T(PR_FLUSH);
         }
-        // (4) the batch leaves the window
-        {   // whole aligned words of the window as dwords (the global address is whatever the member's offset makes it), the edges as bytes
-            const uint32_t p0 = (beg + 3u) & ~3u, p1 = end & ~3u;
-            if(p0 <= p1) {
-                for(uint32_t p = p0 + 4u * lane; p < p1; p += 256) { const uint32_t v = *(const uint32_t *)&S.win[p & (INF_WIN - 1)]; __builtin_memcpy(out + p, &v, 4); }
-                if(beg + lane < p0) out[beg + lane] = S.win[(beg + lane) & (INF_WIN - 1)];
-                if(p1 + lane < end) out[p1 + lane] = S.win[(p1 + lane) & (INF_WIN - 1)];
-            } else for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
-        }
+        if(fin && pos != M.out_len) { fail(INF_E_SHORT); return; }
         if(fin) return;
     }
 }
 #ifndef INF_WAVES
-#define INF_WAVES 6
+#define INF_WAVES 3
 #endif
 __global__ __launch_bounds__(64, INF_WAVES) void k_inflate(const InfParams P) {
     __shared__ InfShared S;
-    const int m = blockIdx.x, lane = threadIdx.x;
-    if(m >= P.n_mem) return;
-    inflate_member(P, S, m, lane);
+    const int lane = threadIdx.x;
+    uint32_t *tok = P.tok + (size_t)blockIdx.x * INF_TOK_WORDS;
+    for(;;) {
+        int m = 0;
+        if(lane == 0) m = (int)atomicAdd(P.status + 2, 1u);
+        m = __builtin_amdgcn_readfirstlane(m);
+        if(m >= P.n_mem) return;
+        inflate_member(P, S, tok, m, lane);
+        __syncthreads();
+    }
 }
 
 // ---- CRC-32 of the inflated members (mdk_crc32_core.h) ----
@@ -294,10 +390,33 @@ __global__ __launch_bounds__(1024) void k_walk_scan(const uint32_t *cnt, uint32_
 // ------------------------------------------------------------------------------------------------
 // host side: pieces
 // ------------------------------------------------------------------------------------------------
-static void launch_inflate(int n_mem, hipStream_t st, const InfParams &IP) { hipLaunchKernelGGL(k_inflate, dim3(n_mem), dim3(64), 0, st, IP); }
+// The wavefronts of a launch: as many as the device holds at once (what the kernel's LDS and registers allow per CU, times the CUs), or the
+// members if they are fewer; each draws members from the counter in status[2] until none is left, so a launch has no second, partly filled
+// generation of wavefronts and the last ones end within one member's time of each other.  MDK_INF_GRID overrides.
+static int inflate_grid_max(int device) {
+    static int cached[64] = {0};
+    const int slot = device >= 0 && device < 64 ? device : 0;
+    if(!cached[slot]) {
+        int per_cu = 0, cus = 0;
+        if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_inflate, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        if(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+        (void)hipGetLastError();
+        int g = per_cu * cus;
+        if(getenv("MDK_INF_GRID") && atoi(getenv("MDK_INF_GRID")) > 0) g = atoi(getenv("MDK_INF_GRID"));
+        cached[slot] = g;
+    }
+    return cached[slot];
+}
+static inline int inflate_grid(int device, int n_mem) { const int g = inflate_grid_max(device); return n_mem < g ? n_mem : g; }
+static hipError_t launch_inflate(int device, int n_mem, hipStream_t st, const InfParams &IP) {
+    hipError_t e = hipMemsetAsync(IP.status + 2, 0, 4, st);
+    if(e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_inflate, dim3(inflate_grid(device, n_mem)), dim3(64), 0, st, IP);
+    return hipGetLastError();
+}
 struct md_piece {
     md_dev *h = nullptr; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
-    DBuf<uint8_t> d_comp, d_out; DBuf<md_inf_member> d_mem; DBuf<uint32_t> d_cnt, d_first, d_recoff, d_status; DBuf<md_inf_digest> d_dig;
+    DBuf<uint8_t> d_comp, d_out; DBuf<md_inf_member> d_mem; DBuf<uint32_t> d_cnt, d_first, d_recoff, d_status, d_tok; DBuf<md_inf_digest> d_dig;
     HBuf<md_inf_digest> h_dig; HBuf<uint32_t> h_status;
     int n_mem = 0; uint64_t out_bytes = 0, comp_bytes = 0; uint32_t n_rec_cap = 0; bool busy = false;
     bool own_stream = false, recorded = false;      // recorded: `done` has been recorded at least once (what waiting for the piece's own work means)
@@ -357,7 +476,7 @@ extern "C" void md_piece_destroy(md_piece *p) {
     (void)piece_sync(p);
     if(p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     if(p->done) (void)hipEventDestroy(p->done);
-    p->d_comp.release(); p->d_out.release(); p->d_mem.release(); p->d_cnt.release(); p->d_first.release(); p->d_recoff.release(); p->d_status.release(); p->d_dig.release();
+    p->d_comp.release(); p->d_out.release(); p->d_mem.release(); p->d_cnt.release(); p->d_first.release(); p->d_recoff.release(); p->d_status.release(); p->d_tok.release(); p->d_dig.release();
     p->h_dig.release(); p->h_status.release();
     delete p;
 }
@@ -378,15 +497,18 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
     if(out_bytes >= (1ull << 32) - 65536) return fail(MDK_ERR_ARG, "md_piece_submit: more than 4 GiB inflated in one piece", hipSuccess);
     const uint32_t rec_cap = (uint32_t)(out_bytes / 36 + 16);          // a BAM record is at least 36 bytes with its block_size word
     if(p->d_comp.need((size_t)comp_bytes + 1024) || p->d_out.need((size_t)out_bytes + 1024) || p->d_mem.need((size_t)n_mem) || p->d_cnt.need((size_t)n_mem) || p->d_first.need((size_t)n_mem) ||
-       p->d_dig.need((size_t)n_mem) || p->h_dig.need((size_t)n_mem) || p->d_recoff.need((size_t)rec_cap)) return MDK_ERR_NOMEM;
+       p->d_dig.need((size_t)n_mem) || p->h_dig.need((size_t)n_mem) || p->d_recoff.need((size_t)rec_cap) || p->d_tok.need((size_t)inflate_grid(h->device, n_mem) * INF_TOK_WORDS)) return MDK_ERR_NOMEM;
     p->n_mem = n_mem; p->out_bytes = out_bytes; p->comp_bytes = comp_bytes; p->n_rec_cap = rec_cap;
     hipStream_t st = p->stream;
     host_block_ensure_registered(comp);
     HIPCHK(hipMemcpyAsync(p->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->d_mem.p, mem, sizeof(md_inf_member) * (size_t)n_mem, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(p->d_status.p, 0, 16, st));
-    InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p;
-    launch_inflate(n_mem, st, IP);
+    InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p; IP.tok = p->d_tok.p;
+#ifdef INF_PROFILE
+    { static unsigned long long *dp = nullptr; if(!dp) { (void)hipMalloc((void **)&dp, 16 * 8); (void)hipMemset(dp, 0, 16 * 8); } IP.prof = dp; }
+#endif
+    HIPCHK(launch_inflate(h->device, n_mem, st, IP));
     if(p->check_crc) launch_crc(h, p, st);
     WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
     hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
@@ -453,11 +575,14 @@ extern "C" int md_piece_bench(md_piece *p, int iters, float *ms_inflate, float *
     HIPCHK(hipSetDevice(p->h->device));
     hipEvent_t e0, e1, e2; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
     hipStream_t st = p->stream; const int n_mem = p->n_mem;
-    InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p;
+    InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p; IP.tok = p->d_tok.p;
+#ifdef INF_PROFILE
+    unsigned long long *dprof = nullptr; HIPCHK(hipMalloc((void **)&dprof, 16 * 8)); HIPCHK(hipMemset(dprof, 0, 16 * 8)); IP.prof = dprof;
+#endif
     WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipEventRecord(e0, st));
-    for(int i = 0; i < iters; i++) launch_inflate(n_mem, st, IP);
+    for(int i = 0; i < iters; i++) HIPCHK(launch_inflate(p->h->device, n_mem, st, IP));
     HIPCHK(hipEventRecord(e1, st));
     for(int i = 0; i < iters; i++) {
         hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
@@ -469,6 +594,13 @@ extern "C" int md_piece_bench(md_piece *p, int iters, float *ms_inflate, float *
     float a = 0, b = 0; HIPCHK(hipEventElapsedTime(&a, e0, e1)); HIPCHK(hipEventElapsedTime(&b, e1, e2));
     if(ms_inflate) *ms_inflate = a / (float)iters;
     if(ms_walk) *ms_walk = b / (float)iters;
+#ifdef INF_PROFILE
+    {   unsigned long long hp[16]; HIPCHK(hipMemcpy(hp, dprof, sizeof hp, hipMemcpyDeviceToHost)); unsigned long long tot = 0; for(int k = 0; k < PR_N; k++) tot += hp[k];
+        static const char *nm[PR_N] = {"stage", "header", "stored", "chain_pass1", "chain_pass2", "chain_more", "confirm", "tok_fetch", "tok_place", "lz_sources", "lz_jump", "lz_gather", "flush", "other"};
+        fprintf(stderr, "[inf profile] %d members x %d launches; share of the wavefronts' time per phase:", n_mem, iters);
+        for(int k = 0; k < PR_N; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)hp[k] / (double)(tot ? tot : 1));
+        fprintf(stderr, "; memtime ticks per member %.0f\n", (double)tot / ((double)n_mem * iters)); (void)hipFree(dprof); }
+#endif
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     return 0;
 }

@@ -15,120 +15,148 @@
 #include "mdk_inflate_core.h"
 #include "mdk_crc32_core.h"
 
-// statistics of the decode rounds (the file mode prints them): rounds, real symbols, literals / matches, near-match rounds, and -- what a round
-// over a 128-bit window would have resolved (the walk carried on over the next 64 bits where nothing but the window's end stopped it)
-static uint64_t g_rounds, g_syms, g_lits, g_matches, g_syms128, g_near_rounds, g_hdr_batches, g_round_cut;
+// statistics of the batches (the file mode prints them)
+static uint64_t g_hbatches, g_passes, g_wave_steps, g_lane_steps, g_syms, g_hdr_batches, g_lanes_taken, g_lanes_active, g_obatches, g_jump_rounds, g_far_bytes, g_match_bytes, g_cut_passes, g_tok_groups, g_pass_hist[INF_MAX_PASSES + 1];
+// the words of the stream from word `wbase` on into S.in (64 lanes, coalesced, on the device); words behind the stream read as zero
+static void emu_stage(InfShared &S, const uint8_t *comp, uint64_t a0, uint32_t n_words, uint32_t wbase, uint32_t count) {
+    for(uint32_t i = 0; i < count; i++) { const uint32_t w = wbase + i; uint32_t v = 0; if(w < n_words) memcpy(&v, comp + a0 + 4ull * w, 4); S.in[i] = v; }      // (the caller pads the buffer)
+}
 // one member, as k_inflate does it; returns 0 or the error code
-static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uint8_t *out, uint32_t out_len, uint64_t *n_far, uint64_t *n_near, uint64_t *n_batches) {
-    static InfShared S;
+static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uint8_t *out, uint32_t out_len, uint64_t *n_batches) {
+    static InfShared S; static uint32_t tok[INF_TOK_WORDS];
     if(out_len == 0) return 0;
     const uint64_t a0 = in_off & ~3ull; const uint32_t skip = (uint32_t)(in_off & 3ull);
     const uint32_t n_words = (uint32_t)((in_off + in_len + 3 - a0) >> 2);
-    auto word = [&](uint32_t w) -> uint32_t { uint32_t v = 0; if(w < n_words) memcpy(&v, comp + a0 + 4ull * w, 4); return v; };   // (the caller pads the buffer)
-    uint32_t filled = 0;
     uint32_t bitpos = 8u * skip, pos = 0, in_block = 0, last = 0, stored_left = 0;
+    auto flush = [&](uint32_t beg, uint32_t end) { for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)]; };
     for(uint64_t turns = 0;; turns++) {
         if(turns > 200000) return 103;                                   // a batch must consume input or produce output: 64 KiB cannot take this long
-        while(filled + 64 <= (bitpos >> 5) + INF_IN_WORDS) { for(uint32_t lane = 0; lane < 64; lane++) { const uint32_t w = filled + lane; S.in[w & (INF_IN_WORDS - 1)] = word(w); } filled += 64; }
         (*n_batches)++;
-        const uint32_t beg = pos; uint32_t n_tok = 0, err = 0, fin = 0;
+        const uint32_t wbase = bitpos >> 5, rel = bitpos & 31u;
+        uint32_t err = 0, fin = 0;
         if(in_block == 0) {
-            inf_header_batch(S, bitpos); g_hdr_batches++;
-            bitpos = S.bitpos; in_block = S.in_block; last = S.last; stored_left = S.stored_left; err = S.err;
-        } else if(in_block == 2) {
-            const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH;
-            for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[(pos + i) & (INF_WIN - 1)] = inf_ring_byte(S, bitpos, i);
+            emu_stage(S, comp, a0, n_words, wbase, INF_HDR_WORDS);
+            inf_header_open(S, rel); g_hdr_batches++;
+            err = S.err; const uint32_t type = S.h.type;
+            if(!err && type == 1) for(uint32_t lane = 0; lane < 64; lane++) inf_header_fixed_lens(S, lane);
+            if(!err && type == 2) {
+                if(inf_build_serial<inf_dist_t>(S.h.cl, 19, INF_CL_TB, S.dist, nullptr, nullptr, 2, 1)) err = INF_E_CODELEN;
+                if(!err) { inf_header_lens(S); err = S.err; }
+            }
+            if(!err && type != 0) {
+                const int nlit = (int)S.h.nlit, ndist = (int)S.h.ndist;
+                if(inf_build_serial<inf_dist_t>(S.h.lens + nlit, ndist, INF_DIST_TB, S.dist, S.dsym, &S.dl, 1, type == 2)) err = INF_E_DISTTABLE;
+                else if(inf_build_serial<inf_lit_t>(S.h.lens, nlit, INF_LIT_TB, S.lit, S.lsym, &S.ll, 0, 1)) err = INF_E_LITTABLE;
+                in_block = 1;
+            } else in_block = S.in_block;
+            bitpos = 32u * wbase + S.bitpos; last = S.last; stored_left = S.stored_left;
+            if(err) return (int)err;
+            if((bitpos >> 5) > n_words) return INF_E_INPUT;
+            continue;
+        }
+        if(in_block == 2) {
+            emu_stage(S, comp, a0, n_words, wbase, INF_STORED_WORDS);
+            const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH, beg = pos;
+            if(pos + n > out_len) return INF_E_OVERRUN;
+            for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[(pos + i) & (INF_WIN - 1)] = inf_ring_byte(S, rel, i);
             pos += n; bitpos += 8u * n; stored_left -= n;
             if(stored_left == 0) { in_block = 0; fin = last; }
-        } else {
-            // the rounds of k_inflate: the per-lane decode is the kernel's code, the cross-lane steps (walk by readlane, scan, ballots) run over arrays
-            const uint32_t lim = beg + (INF_BATCH_BYTES - 258), blim = bitpos + 32u * INF_BATCH_WORDS;
-            for(;;) {
-                InfSym sy[64];
-                for(uint32_t lane = 0; lane < 64; lane++) sy[lane] = inf_decode_at(S, bitpos + lane);
-                uint32_t adv[64]; for(uint32_t lane = 0; lane < 64; lane++) adv[lane] = sy[lane].kind >= 3 ? 0x200u : sy[lane].kind == 2 ? (sy[lane].nbits | 0x100u) : sy[lane].nbits;
-                uint32_t off = 0, a = 0, lastl = 0; uint64_t V = 0;
-                do { lastl = off; V |= 1ull << off; a = adv[off]; off += a; } while(off < 64);
-                off = lastl + (a & 0xffu);
-                uint32_t stop = a >= 0x200u ? sy[lastl].kind : a >= 0x100u ? 2u : 0u;
-                if(stop >= 3) V &= ~(1ull << lastl);
-                uint32_t olen[64], dst[64], mpre[64]; uint32_t run = 0, nm = 0; uint64_t mball = 0, cm = 0;
-                for(uint32_t lane = 0; lane < 64; lane++) {
-                    const bool valid = (V >> lane) & 1ull;
-                    olen[lane] = !valid ? 0u : sy[lane].kind == 0 ? 1u : sy[lane].kind == 1 ? (sy[lane].val & 0xffffu) : 0u;
-                    dst[lane] = pos + run; run += olen[lane];
-                    mpre[lane] = nm; if(valid && sy[lane].kind == 1) { mball |= 1ull << lane; nm++; }
-                }
-                for(uint32_t lane = 0; lane < 64; lane++) { const bool valid = (V >> lane) & 1ull, ism = (mball >> lane) & 1ull; if(valid && ((ism && n_tok + mpre[lane] >= INF_MAX_TOK) || dst[lane] + olen[lane] > beg + INF_BATCH_BYTES)) cm |= 1ull << lane; }
-                if(cm) { const int c = __builtin_ctzll(cm); V &= (1ull << c) - 1ull; off = (uint32_t)c; stop = 1; mball &= V; }
-                bool baddist = false;
-                for(uint32_t lane = 0; lane < 64; lane++) if(((mball >> lane) & 1ull) && (sy[lane].val >> 16) > dst[lane]) baddist = true;
-                if(baddist) { err = INF_E_DIST; break; }
-                for(uint32_t lane = 0; lane < 64; lane++) {
-                    const bool valid = (V >> lane) & 1ull;
-                    if(valid && sy[lane].kind == 0) S.win[dst[lane] & (INF_WIN - 1)] = (uint8_t)sy[lane].val;
-                    if((mball >> lane) & 1ull) { InfToken t; t.dst = dst[lane]; t.len_dist = sy[lane].val; if(n_tok + mpre[lane] >= INF_MAX_TOK) return 104; S.tok[n_tok + mpre[lane]] = t; }
-                }
-                n_tok += (uint32_t)__builtin_popcountll(mball);
-                {   // statistics
-                    const int nv = __builtin_popcountll(V); g_rounds++; g_syms += (uint64_t)nv; g_matches += (uint64_t)__builtin_popcountll(mball); g_lits += (uint64_t)(nv - __builtin_popcountll(mball)); g_syms128 += (uint64_t)nv;
-                    if(stop == 0) { uint32_t o2 = off; while(o2 < 128) { const InfSym y = inf_decode_at(S, bitpos + o2); if(y.kind >= 2) break; g_syms128++; o2 += y.nbits; } } else if(stop == 1) g_round_cut++;
-                }
-                if(V) { const int hi = 63 - __builtin_clzll(V); pos = dst[hi] + olen[hi]; }
-                bitpos += off;
-                if(stop >= 3) { err = stop == 3 ? INF_E_SYMBOL : INF_E_DIST; break; }
-                if(stop == 2) { in_block = 0; fin = last; break; }
-                if(stop == 1 || n_tok >= INF_MAX_TOK || pos > lim || bitpos > blim) break;
-                if(!V) return 105;                                        // a round without progress (cannot happen: the first symbol of a round always fits)
-            }
+            if(fin && pos != out_len) return INF_E_SHORT;
+            if((bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, in_len))) return INF_E_INPUT;
+            flush(beg, pos);
+            if(fin) return 0;
+            continue;
         }
-        if(!err && pos > out_len) err = INF_E_OVERRUN;
-        if(!err && fin && pos != out_len) err = INF_E_SHORT;
-        if(err) return (int)err;
+        // A Huffman batch: chains from guessed starts, then from the neighbours' ends, until a prefix of the lanes agrees (k_inflate; the per-lane
+        // bodies are the kernel's code, the steps across lanes -- shifts, ballots, scans -- run over arrays).  sw words per lane: what is left of the
+        // stream spread over the lanes, within [INF_SW_MIN, INF_SW_MAX], odd.
+        const uint32_t left_words = n_words > wbase ? n_words - wbase : 1u;
+        uint32_t sw = (left_words + 63u) / 64u; sw = sw < INF_SW_MIN ? INF_SW_MIN : sw > INF_SW_MAX ? INF_SW_MAX : sw; sw |= 1u;
+        const uint32_t sub = 32u * sw;
+        emu_stage(S, comp, a0, n_words, wbase, 64u * sw + 8u);
+        g_hbatches++;
+        const uint32_t stream_end = 32u * (n_words - wbase) + 64u;        // (relative) no true chain gets this far without an error
+        uint32_t start[64]; InfChain c[64]; uint64_t need = 0, written = 0; uint32_t nconf = 0, passes = 0, nact = 0;
+        for(uint32_t lane = 0; lane < 64; lane++) { start[lane] = rel + sub * lane; c[lane].status = INF_C_BADLIT; c[lane].n = 0; c[lane].end = start[lane]; if(lane == 0 || start[lane] < stream_end) { need |= 1ull << lane; nact++; } }
+        g_lanes_active += nact;
+        for(;;) {
+            uint32_t mx = 0;
+            for(uint32_t lane = 0; lane < 64; lane++) if((need >> lane) & 1ull) {
+                c[lane] = inf_chain(S, start[lane], rel + sub * (lane + 1), passes != 0, tok + lane);
+                const uint32_t steps = c[lane].n + (c[lane].status >= 2 ? 1u : 0u); if(steps > mx) mx = steps; g_lane_steps += steps;
+            }
+            g_wave_steps += mx; if(passes) written |= need; passes++;
+            // who goes again: a lane whose left neighbour's chain ended elsewhere than where it started, or whose tokens are not written down yet (the first pass writes nothing)
+            need = (written & 1ull) ? 0ull : 1ull;
+            for(uint32_t lane = 63; lane >= 1; lane--) if(lane < nact && c[lane - 1].status == INF_C_OK && (start[lane] != c[lane - 1].end || !((written >> lane) & 1ull))) { start[lane] = c[lane - 1].end; need |= 1ull << lane; }
+            if(passes == 1) continue;
+            nconf = 1; while(nconf < nact && c[nconf - 1].status == INF_C_OK && !((need >> nconf) & 1ull)) nconf++;
+            if(nconf == nact || c[nconf - 1].status != INF_C_OK || passes >= INF_MAX_PASSES) break;
+        }
+        g_passes += passes; g_pass_hist[passes]++;
+        if(nconf < nact && c[nconf - 1].status == INF_C_OK) g_cut_passes++;
+        g_lanes_taken += nconf;
+        const InfChain &L = c[nconf - 1];
+        if(L.status == INF_C_BADLIT) return INF_E_SYMBOL;
+        if(L.status == INF_C_BADDIST) return INF_E_DIST;
+        uint32_t tpre[66], total = 0;
+        for(uint32_t lane = 0; lane < 66; lane++) { tpre[lane] = total; if(lane < nconf) total += c[lane].n; }
+        g_syms += total;
+        if(total == 0 && L.status == INF_C_OK && L.end == start[0]) return 108;           // no progress (cannot happen: a stretch is longer than a symbol)
+        bitpos = 32u * wbase + L.end;
+        if(L.status == INF_C_EOB) { in_block = 0; fin = last; }
         if((bitpos >> 5) > n_words || (fin && inf_overran_input(bitpos, skip, in_len))) return INF_E_INPUT;
-        const uint32_t end = pos;
-        if(end - beg > INF_BATCH_BYTES || n_tok > INF_MAX_TOK) return 100;
-        bool far[INF_MAX_TOK];
-        for(uint32_t k = 0; k < INF_MAX_TOK; k++) {                      // the far phase: every token, 64 at a time on the device
-            far[k] = false;
-            if(k < n_tok) {
-                const InfToken t = S.tok[k]; far[k] = inf_tok_far(t, beg);
-                if(far[k]) {
-                    const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16);
-                    if(src + len > beg) return 101;                       // a far source must lie wholly in what earlier batches wrote
-                    for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = out[src + i];
-                    (*n_far)++;
+        // the tokens into bytes, a batch of output at a time
+        uint32_t g = 0;
+        while(g < total) {
+            g_obatches++;
+            const uint32_t beg = pos, base0 = beg & ~31u;
+            for(uint32_t lane = 0; lane < 66; lane++) S.o.tpre[lane] = tpre[lane];
+            for(uint32_t w = 0; w < INF_BATCH_BYTES / 32; w++) S.o.starts[w] = 0;
+            bool full = false;
+            while(g < total && !full) {
+                g_tok_groups++;
+                uint32_t t[64], len[64], at[64], run = 0, take = 0;
+                for(uint32_t lane = 0; lane < 64; lane++) {
+                    t[lane] = 0; len[lane] = 0;
+                    if(g + lane < total) { const uint32_t col = inf_tok_column(S, g + lane); t[lane] = tok[64u * (g + lane - S.o.tpre[col]) + col]; len[lane] = inf_tok_len(t[lane]); }
+                    at[lane] = pos + run; run += len[lane];
+                    if(g + lane < total && at[lane] + len[lane] <= base0 + INF_BATCH_BYTES && take == lane) take = lane + 1;
                 }
+                if(take == 0) { if(pos == beg) return 105; full = true; break; }           // (a token is at most 258 bytes: the first of a batch always fits)
+                for(uint32_t lane = 0; lane < take; lane++) if(!inf_tok_place(S, t[lane], at[lane], base0)) return INF_E_DIST;
+                pos = at[take - 1] + len[take - 1]; g += take;
+                if(take < 64 && g < total) full = true;
+                if(pos > out_len) return INF_E_OVERRUN;
             }
-        }
-        for(uint32_t tb = 0; tb < n_tok; tb += 64) {   // the near phase of k_inflate: the tokens in stream order, 64 at a time; rounds over those not yet copied
-            uint64_t pending = 0; for(uint32_t k = 0; k < 64 && tb + k < n_tok; k++) if(!far[tb + k]) pending |= 1ull << k;
-            int guard = 0;
-            while(pending) {
-                g_near_rounds++;
-                if(++guard > 200) return 106;
-                const int f = __builtin_ctzll(pending); const InfToken q = S.tok[tb + f];
-                const uint32_t W = q.dst, flen = q.len_dist & 0xffffu;
-                if(q.dst - (q.len_dist >> 16) + INF_WIN < end) return 102;          // a near source must still be in the window at the end of the batch
-                if(flen > INF_NEAR_LANE_MAX) {
-                    const uint32_t fdist = q.len_dist >> 16; uint32_t done = 0, span = fdist;
-                    while(done < flen) {
-                        const uint32_t n = span < flen - done ? span : flen - done;
-                        uint8_t snap[INF_WIN]; memcpy(snap, S.win, INF_WIN);      // all lanes read before any lane's write is seen: the round must not depend on lane order
-                        for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[(W + done + i) & (INF_WIN - 1)] = snap[(W - fdist + i) & (INF_WIN - 1)];
-                        done += n; span <<= 1;
-                    }
-                    pending &= ~(1ull << f); (*n_near)++;
-                    continue;
-                }
-                uint64_t ready = 0;
-                for(uint32_t lane = 0; lane < 64 && tb + lane < n_tok; lane++) { const InfToken t = S.tok[tb + lane]; const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16); if(((pending >> lane) & 1ull) && len <= INF_NEAR_LANE_MAX && ((int)lane == f || src + len <= W)) ready |= 1ull << lane; }
-                // the ready lanes copy at the same time, byte i of every token in step i: run from the LAST lane to the first to show that the order between lanes does not matter
-                for(int lane = 63; lane >= 0; lane--) if((ready >> lane) & 1ull) { const InfToken t = S.tok[tb + lane]; const uint32_t len = t.len_dist & 0xffffu, src = t.dst - (t.len_dist >> 16); for(uint32_t i = 0; i < len; i++) S.win[(t.dst + i) & (INF_WIN - 1)] = S.win[(src + i) & (INF_WIN - 1)]; (*n_near)++; }
-                pending &= ~ready;
+            const uint32_t end = pos;
+            if(end - base0 > INF_BATCH_BYTES) return 100;
+            // matches: sources, pointer jumping, gather
+            uint32_t carry[64]; int32_t run = -1;
+            for(uint32_t lane = 0; lane < 64; lane++) { carry[lane] = run >= 0 ? S.o.aux[run] : 0u; const int32_t l = inf_lz_last_start(S, lane); if(l > run) run = l; }
+            uint32_t q[64][32], inr[64];
+            for(uint32_t lane = 0; lane < 64; lane++) { inr[lane] = inf_lz_inrange(lane, base0, beg, end); inf_lz_sources(S, lane, base0, inr[lane], carry[lane], q[lane]); }
+            for(uint32_t lane = 0; lane < 64; lane++) inf_lz_publish(S, lane, q[lane]);
+            for(int guard = 0;; guard++) {
+                if(guard > 64) return 106;
+                bool moved = false;
+                for(uint32_t lane = 0; lane < 64; lane++) moved |= inf_lz_jump(S, lane, base0, beg, inr[lane], q[lane]);
+                for(uint32_t lane = 0; lane < 64; lane++) inf_lz_publish(S, lane, q[lane]);
+                g_jump_rounds++;
+                if(!moved) break;
             }
+            bool any_far = false;
+            for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t j = 0; j < 32; j++) { const uint32_t p = base0 + 32 * lane + j, src = q[lane][j];
+                if(((inr[lane] >> j) & 1u) != (p >= beg && p < end ? 1u : 0u)) return 110;
+                if(p < beg || p >= end) { if(src != (p & 0xffffu)) return 109; continue; }
+                if(src != p) { g_match_bytes++; if(src + INF_WIN < end) { g_far_bytes++; any_far = true; if(src >= beg) return 101; } if(src >= p) return 102; } }
+            uint8_t snap[INF_WIN]; memcpy(snap, S.win, INF_WIN);      // all lanes read before any lane's write is seen: the gather must not depend on lane order ...
+            for(int lane = 63; lane >= 0; lane--) { InfShared &W = S; uint8_t keep[INF_WIN]; memcpy(keep, W.win, INF_WIN); memcpy(W.win, snap, INF_WIN);      // ... so every lane reads the window as it stood, and its 32 bytes are merged in
+                inf_lz_gather(W, (uint32_t)lane, base0, end, inr[lane], q[lane], any_far, [&](uint32_t at, bool wanted) -> uint32_t { return wanted ? out[at] : 0u; });
+                const uint32_t slot = (base0 + 32u * (uint32_t)lane) & (INF_WIN - 1); memcpy(keep + slot, W.win + slot, 32); memcpy(W.win, keep, INF_WIN); }
+            flush(beg, end);
         }
-        for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
+        if(fin && pos != out_len) return INF_E_SHORT;
         if(fin) return 0;
     }
 }
@@ -139,13 +167,20 @@ static int check_stream(const std::vector<uint8_t> &raw, int level, int strategy
     const int lead = 1 + (int)(raw.size() % 3);                                // an unaligned start, as in a file
     zs.next_in = (Bytef *)raw.data(); zs.avail_in = (uInt)raw.size(); zs.next_out = comp.data() + lead; zs.avail_out = (uInt)(comp.size() - lead - 8);
     deflate(&zs, Z_FINISH); const uint32_t clen = (uint32_t)zs.total_out; deflateEnd(&zs);
-    std::vector<uint8_t> got(raw.size() + 8, 0xEE); uint64_t a = 0, b = 0, c = 0;
-    const int rc = emu_member(comp.data(), (uint64_t)lead, clen, got.data(), (uint32_t)raw.size(), &a, &b, &c);
+    std::vector<uint8_t> got(raw.size() + 8, 0xEE); uint64_t c = 0;
+    const int rc = emu_member(comp.data(), (uint64_t)lead, clen, got.data(), (uint32_t)raw.size(), &c);
     if(rc || (raw.size() && memcmp(got.data(), raw.data(), raw.size()))) { fprintf(stderr, "selftest FAILED: %s level %d strategy %d size %zu: rc %d\n", what, level, strategy, raw.size(), rc); return 1; }
     return 0;
 }
 static int selftest(void) {
-    int bad = 0; uint64_t s = 88172645463325252ull; auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    int bad = 0;
+    {   // the arithmetic entries against RFC 1951 3.2.5's tables
+        const uint16_t LBASE[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258}; const uint8_t LEXT[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+        const uint16_t DBASE[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577}; const uint8_t DEXT[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+        for(uint32_t k = 0; k < 29; k++) if(inf_lit_entry(257 + k) != (INF_L_LEN | ((uint32_t)LEXT[k] << 12) | ((uint32_t)(LBASE[k] - 3) << 4))) { fprintf(stderr, "length symbol %u\n", 257 + k); bad++; }
+        for(uint32_t k = 0; k < 30; k++) if(inf_dist_entry(k) != (((uint32_t)DBASE[k] << 16) | ((uint32_t)DEXT[k] << 8))) { fprintf(stderr, "distance symbol %u\n", k); bad++; }
+        if(inf_lit_entry(65) != (65u << 4) || inf_lit_entry(256) != INF_L_EOB || inf_lit_entry(286) != INF_L_BAD || inf_dist_entry(30) != INF_D_BAD) bad++;
+    } uint64_t s = 88172645463325252ull; auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
     for(int kind = 0; kind < 8; kind++) for(size_t size : {(size_t)0, (size_t)1, (size_t)7, (size_t)300, (size_t)5000, (size_t)65280, (size_t)65536}) {
         std::vector<uint8_t> raw(size);
         for(size_t i = 0; i < size; i++) {
@@ -196,8 +231,8 @@ static int fuzz(long iters) {
         case 3: out_len = (uint32_t)(rnd() & 1 ? rnd() % (size + 1) : size + 1 + rnd() % 300); if(out_len > 65536) out_len = 65536; break;      // wrong ISIZE
         default: comp[lead + rnd() % (clen < 12 ? clen : 12)] ^= (uint8_t)rnd(); break;      // the block header
         }
-        std::vector<uint8_t> got((size_t)out_len + 64, 0xEE); uint64_t a = 0, b = 0, c = 0;
-        const int rc = emu_member(comp.data(), (uint64_t)lead, clen, got.data(), out_len, &a, &b, &c);
+        std::vector<uint8_t> got((size_t)out_len + 64, 0xEE); uint64_t c = 0;
+        const int rc = emu_member(comp.data(), (uint64_t)lead, clen, got.data(), out_len, &c);
         for(size_t i = out_len; i < got.size(); i++) if(got[i] != 0xEE) { fprintf(stderr, "fuzz %ld: a byte was written beyond the announced size (rc %d)\n", it, rc); bad++; break; }
         if(rc == 0 && out_len) {                                                 // accepted: then zlib accepts it too, with the same bytes
             std::vector<uint8_t> ref((size_t)out_len + 8); z_stream zi; memset(&zi, 0, sizeof zi); inflateInit2(&zi, -15);
@@ -245,7 +280,7 @@ int main(int argc, char **argv) {
     fseek(f, 0, SEEK_END); size_t n = (size_t)ftell(f); fseek(f, 0, SEEK_SET);
     std::vector<uint8_t> raw(n + 64, 0); if(fread(raw.data(), 1, n, f) != n) return 2; fclose(f);
     const long maxm = argc > 2 ? atol(argv[2]) : -1;
-    size_t o = 0; long m = 0, bad = 0; uint64_t tot = 0, n_far = 0, n_near = 0, n_batches = 0;
+    size_t o = 0; long m = 0, bad = 0; uint64_t tot = 0, n_batches = 0;
     std::vector<uint8_t> ref(65536 + 64), got(65536 + 64);
     while(o + 18 <= n && (maxm < 0 || m < maxm)) {
         const uint16_t xlen = (uint16_t)(raw[o + 10] | raw[o + 11] << 8); const uint32_t bs = (uint32_t)(raw[o + 16] | raw[o + 17] << 8) + 1; uint32_t isz; memcpy(&isz, &raw[o + bs - 4], 4);
@@ -255,17 +290,21 @@ int main(int argc, char **argv) {
             inflateInit2(&zs, -15); const int zr = inflate(&zs, Z_FINISH); inflateEnd(&zs);
             if(zr != Z_STREAM_END) { fprintf(stderr, "zlib failed on member %ld\n", m); return 2; }
             memset(got.data(), 0xEE, isz);
-            const int rc = emu_member(raw.data(), in_off, in_len, got.data(), isz, &n_far, &n_near, &n_batches);
+            const int rc = emu_member(raw.data(), in_off, in_len, got.data(), isz, &n_batches);
             if(rc || memcmp(got.data(), ref.data(), isz)) { if(bad < 5) { size_t k = 0; while(k < isz && got[k] == ref[k]) k++; fprintf(stderr, "member %ld (file offset %zu): rc %d, first difference at byte %zu of %u\n", m, o, rc, k, isz); } bad++; }
             tot += isz;
         }
         o += bs; m++;
     }
-    printf("{\"members\": %ld, \"inflated_bytes\": %llu, \"mismatching_members\": %ld, \"batches\": %llu, \"far_matches\": %llu, \"near_matches\": %llu, "
-           "\"header_batches\": %llu, \"decode_rounds\": %llu, \"symbols\": %llu, \"literals\": %llu, \"matches\": %llu, \"symbols_per_round\": %.2f, \"rounds_cut_by_batch_limits\": %llu, "
-           "\"symbols_per_round_if_window_were_128_bits\": %.2f, \"near_rounds\": %llu, \"bytes_per_symbol\": %.2f}\n", m, (unsigned long long)tot, bad,
-           (unsigned long long)n_batches, (unsigned long long)n_far, (unsigned long long)n_near, (unsigned long long)g_hdr_batches, (unsigned long long)g_rounds, (unsigned long long)g_syms, (unsigned long long)g_lits,
-           (unsigned long long)g_matches, g_rounds ? (double)g_syms / (double)g_rounds : 0.0, (unsigned long long)g_round_cut, g_rounds ? (double)g_syms128 / (double)g_rounds : 0.0, (unsigned long long)g_near_rounds,
-           g_syms ? (double)tot / (double)g_syms : 0.0);
+    printf("{\"members\": %ld, \"inflated_bytes\": %llu, \"mismatching_members\": %ld, \"batches\": %llu, \"header_batches\": %llu, \"huffman_batches\": %llu, \"stretch_words\": [%d, %d], \"batch_bytes\": %d, "
+           "\"passes_per_huffman_batch\": %.2f, \"wave_steps_per_member\": %.1f, \"symbols\": %llu, \"symbols_per_wave_step\": %.2f, \"lane_steps_per_symbol\": %.2f, \"lanes_active_per_batch\": %.1f, \"lanes_taken_per_batch\": %.1f, "
+           "\"output_batches\": %llu, \"token_groups\": %llu, \"batches_cut_by_passes\": %llu, \"jump_rounds_per_output_batch\": %.2f, \"match_bytes\": %llu, \"far_bytes\": %llu, \"chain_passes_hist\": [",
+           m, (unsigned long long)tot, bad, (unsigned long long)n_batches, (unsigned long long)g_hdr_batches, (unsigned long long)g_hbatches, INF_SW_MIN, INF_SW_MAX, INF_BATCH_BYTES,
+           g_hbatches ? (double)g_passes / (double)g_hbatches : 0.0, m ? (double)g_wave_steps / (double)m : 0.0, (unsigned long long)g_syms,
+           g_wave_steps ? (double)g_syms / (double)g_wave_steps : 0.0, g_syms ? (double)g_lane_steps / (double)g_syms : 0.0, g_hbatches ? (double)g_lanes_active / (double)g_hbatches : 0.0, g_hbatches ? (double)g_lanes_taken / (double)g_hbatches : 0.0,
+           (unsigned long long)g_obatches, (unsigned long long)g_tok_groups, (unsigned long long)g_cut_passes, g_obatches ? (double)g_jump_rounds / (double)g_obatches : 0.0,
+           (unsigned long long)g_match_bytes, (unsigned long long)g_far_bytes);
+    for(int i = 1; i <= INF_MAX_PASSES; i++) printf("%s%llu", i > 1 ? ", " : "", (unsigned long long)g_pass_hist[i]);
+    printf("]}\n");
     return bad ? 1 : 0;
 }
