@@ -155,6 +155,12 @@ int  md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bits, int64_
  * (launch / download / wait / bench work on it).  md_dev_submit_raw = upload_raw + launch.  md_dev_download / md_dev_wait
  * return MDK_ERR_PREP_HOST when the preparation gave up on the chunk (see above). */
 int  md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b);
+/* The same for a caller that can keep its device memory: a batch that is ONE device-resident range (the usual chunk of a file inflated on the
+ * device: a run of members of one piece) is not copied at all -- the preparation and the pileup read the records where md_piece_* left them,
+ * with the piece's own record table.  Returns 1 then, and the range (the piece's buffers) must stay as it is until the slot's results have been
+ * collected (md_dev_download / md_dev_download_group / md_dev_wait); 0 = copied as md_dev_upload_raw does (the memory may be reused after
+ * md_dev_upload_wait); < 0 an error.  MDK_NO_INPLACE=1 in the environment: always copies. */
+int  md_dev_upload_raw_inplace(md_dev *h, int slot, const md_raw_batch *b);
 /* waits until the copies md_dev_upload_raw (or md_dev_upload) queued for the slot have read their host memory, which may then be reused */
 int  md_dev_upload_wait(md_dev *h, int slot);
 /* the same without waiting: 1 = they have, 0 = not yet, < 0 error */
@@ -196,6 +202,9 @@ typedef struct {
     uint32_t n_records; uint64_t out_bytes;
     const uint8_t *d_out; const uint32_t *d_rec_off;  /* DEVICE pointers: inflated bytes; offset (in d_out) of every record's block_size word */
 } md_piece_info;
+/* how many members the device inflates at once (the wavefronts k_inflate keeps resident, each on one member): a piece of a whole multiple of this
+ * many members leaves no last, nearly empty round of them; <= 0: unknown */
+int  md_piece_members_per_round(md_dev *h);
 int  md_piece_create(md_dev *h, md_piece **out);     /* buffers grown on demand; its work is queued on one of a few streams the pieces of a handle share (four; MDK_PIECE_STREAMS=0: a stream of its own) */
 void md_piece_destroy(md_piece *p);
 /* asynchronous: H2D of `comp` (pinned memory makes it a DMA) and the member table, the kernels, D2H of the digests.  The member

@@ -162,10 +162,10 @@ HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_quiesce", "md_dev_open", "
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_dev_download_group", "md_dev_reserve_contigs", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_rank_shared", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_result_header", "md_comm_result_send", "md_comm_result_recv", "md_dev_pci_bus_id",
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned", "md_host_profile", "md_dev_profile_text", "md_host_register", "md_host_register_all",
-               "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_upload_wait", "md_dev_upload_done", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep", "md_dev_bench_prep_rotate", "md_bench_set_prep",
+               "md_dev_set_prep", "md_dev_set_mappability", "md_dev_upload_raw", "md_dev_upload_raw_inplace", "md_dev_upload_wait", "md_dev_upload_done", "md_dev_submit_raw", "md_dev_debug_segments", "md_dev_bench_prep", "md_dev_bench_prep_rotate", "md_bench_set_prep",
                "md_dev_mbias_submit", "md_dev_mbias_submit_raw", "md_dev_mbias_read", "md_dev_mbias_reset", "md_dev_slot_sync",
                "md_dev_perread_submit", "md_dev_perread_download", "md_dev_perread_submit_raw", "md_dev_perread_download_raw", "md_dev_read_raw",
-               "md_piece_create", "md_piece_destroy", "md_piece_submit", "md_piece_wait", "md_piece_read", "md_piece_read_records", "md_piece_bench", "md_piece_bench_crc"]
+               "md_piece_members_per_round", "md_piece_create", "md_piece_destroy", "md_piece_submit", "md_piece_wait", "md_piece_read", "md_piece_read_records", "md_piece_bench", "md_piece_bench_crc"]
 EXTRACT_SYMBOLS = ["extract_main", "mdk_plan_open", "mdk_plan_close", "mdk_plan_dev_cfg", "mdk_plan_ensure_reference",
                    "mdk_plan_next_chunk", "mdk_plan_try_next_chunk", "mdk_plan_emit", "mdk_plan_finish", "mdk_plan_set_shard", "mdk_plan_n_targets", "mdk_plan_target_name",
                    "mdk_plan_target_len", "mdk_plan_regions", "mdk_plan_set_prep", "mdk_plan_set_hold", "mdk_plan_prep_cfg", "mdk_plan_host_prepare",

@@ -83,7 +83,7 @@ MDK_LOCAL void *devopen_main(void *arg) { devopen_t *d = arg; d->rc = md_dev_ope
 static int g_ngroups = 3;            /* groups in flight (MDK_GROUPS_IN_FLIGHT=n, 2..6) */
 #define MDK_NGROUPS g_ngroups
 enum { G_FREE = 0, G_FILL, G_LAUNCHED };
-typedef struct { mdk_chunk ch[MDK_GROUP]; int slot[MDK_GROUP]; int n, launched[MDK_GROUP], state, held, n_held, rel_slot[MDK_GROUP]; mdk_chunk rel_ch[MDK_GROUP]; } cgroup;      /* held: the host memory behind its records has not been given back yet */
+typedef struct { mdk_chunk ch[MDK_GROUP]; int slot[MDK_GROUP]; int n, launched[MDK_GROUP], inplace[MDK_GROUP], state, held, n_held, rel_slot[MDK_GROUP]; mdk_chunk rel_ch[MDK_GROUP]; } cgroup;      /* held: the host memory behind its records has not been given back yet; inplace: the device reads the chunk's records where the piece they were inflated in holds them (md_dev_upload_raw_inplace): that piece goes back when the chunk's results are in */
 typedef struct {
     mdk_plan *p; md_dev *dev; emitter *em; cgroup G[MDK_NGROUPS_MAX];
     pthread_mutex_t mu; pthread_cond_t cv;
@@ -181,6 +181,7 @@ static void *collector_main(void *arg) {
             if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }
             if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); xp_fail(X, MDK_RC_DEVICE); bad = 1; break; }
             sites[k] = st[i];
+            if(g->inplace[k] && !getenv("MDK_NO_EARLY_RELEASE")) (void)mdk_plan_release_records(p, &g->ch[k]);      /* the kernels that read the piece are done: it goes back to the inflate teams */
         }
         X->w_down += now_s() - ta;
         if(bad) break;
@@ -270,11 +271,12 @@ int extract_main(int argc, char *argv[]) {
             if(rc == 2) break;
             if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
             if(rc == 0) { more = 0; break; }
-            g->launched[g->n] = 0;
+            g->launched[g->n] = 0; g->inplace[g->n] = 0;
             if(!c->skipped) {
                 ta = now_s(); rc = c->prep ? 0 : ref_wait(X, c->tid); w_ref += now_s() - ta;       /* (raw records can cross the link before the contig's bases have) */
                 ta = now_s(); g_up_phase = 6;
-                if(!rc) rc = c->prep ? md_dev_upload_raw(dev, g->slot[g->n], &c->raw) : md_dev_upload(dev, g->slot[g->n], &c->batch);
+                g->inplace[g->n] = 0;
+                if(!rc) { if(c->prep) { rc = md_dev_upload_raw_inplace(dev, g->slot[g->n], &c->raw); if(rc > 0) { g->inplace[g->n] = 1; rc = 0; } } else rc = md_dev_upload(dev, g->slot[g->n], &c->batch); }
                 w_sub += now_s() - ta; g_up_phase = 3;
                 if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
                 g->launched[g->n] = 1;
@@ -293,7 +295,7 @@ int extract_main(int argc, char *argv[]) {
             if(nl) { ta = now_s(); rc = md_dev_launch_group(dev, ls, nl); w_sub += now_s() - ta; if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; } }
         }
         g->n_held = g->n; g->held = 0;
-        for(i = 0; i < g->n; i++) { g->rel_slot[i] = (g->launched[i] && g->ch[i].prep) ? g->slot[i] : -1; g->rel_ch[i] = g->ch[i]; if(g->rel_slot[i] >= 0 && !getenv("MDK_NO_EARLY_RELEASE")) g->held = 1; }
+        for(i = 0; i < g->n; i++) { g->rel_slot[i] = (g->launched[i] && g->ch[i].prep && !g->inplace[i]) ? g->slot[i] : -1; g->rel_ch[i] = g->ch[i]; if(g->rel_slot[i] >= 0 && !getenv("MDK_NO_EARLY_RELEASE")) g->held = 1; }
         pthread_mutex_lock(&X->mu);
         if(g->n) { g->state = G_LAUNCHED; X->n_up++; } else g->state = G_FREE;
         pthread_cond_broadcast(&X->cv);

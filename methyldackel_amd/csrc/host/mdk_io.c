@@ -104,6 +104,33 @@ static void *inflate_worker(void *arg) {
     return NULL;
 }
 
+/* ---- the mapped file's pages, ahead of the teams ----
+ * next_piece walks the BGZF headers of a piece under io_mu.  In a fresh mapping every page it touches is a page fault (the pages are in the page
+ * cache, but this process has no entry for them yet): ~0.8 us per member, 0.4 s per 9 GB of BAM, and serial for all teams -- the feed ran at the
+ * speed of that walk (gpurun_out r06r: 0.40 s of a 0.5 s streaming phase inside the lock, teams queueing for it 1.3 s in sum).  So every team,
+ * once it holds a piece and has let go of the lock, makes the entries of ONE block further ahead (MADV_POPULATE_READ, Linux 5.14; by touching a
+ * byte per page where the kernel does not know it): together the teams keep a frontier POP_AHEAD in front of the read position, at ~2 ms of
+ * each piece's team.  (Threads of their own that ran ahead through the whole file held the address space's lock against the runtime's start-up:
+ * the device was usable 0.15 s later, gpurun_out r06n.) */
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+#define POP_BLOCK ((size_t)64 << 20)
+#define POP_AHEAD ((size_t)1 << 30)
+static void populate_ahead(mdk_bam *b) {
+    static int by_touch = 0, off = -1;
+    if(off < 0) off = getenv("MDK_NO_POPULATE") ? 1 : 0;
+    if(off || !b->map) return;
+    { const size_t pos = __atomic_load_n(&b->map_pos, __ATOMIC_RELAXED); size_t at = __atomic_load_n(&b->pop_next, __ATOMIC_RELAXED), len;
+      if(at < pos) { __atomic_compare_exchange_n(&b->pop_next, &at, pos, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED); at = __atomic_load_n(&b->pop_next, __ATOMIC_RELAXED); }      /* (a seek, or readers that overtook the frontier) */
+      if(at >= b->map_len || at > pos + POP_AHEAD) return;
+      at = __atomic_fetch_add(&b->pop_next, POP_BLOCK, __ATOMIC_RELAXED);
+      if(at >= b->map_len) return;
+      at &= ~(size_t)4095; len = at + POP_BLOCK <= b->map_len ? POP_BLOCK : b->map_len - at;
+      if(!__atomic_load_n(&by_touch, __ATOMIC_RELAXED) && madvise((void *)(b->map + at), len, MADV_POPULATE_READ) != 0) __atomic_store_n(&by_touch, 1, __ATOMIC_RELAXED);
+      if(__atomic_load_n(&by_touch, __ATOMIC_RELAXED)) { volatile uint8_t sink = 0; size_t o; for(o = 0; o < len; o += 4096) sink ^= b->map[at + o]; (void)sink; } }
+}
+
 /* ---- slabs ---- */
 #define SEQ_FORCE UINT64_MAX
 static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, uint64_t seq) {          /* a free slab with room for need_cap bytes, for piece `seq`; SEQ_FORCE: never wait for one to come back */
@@ -160,6 +187,7 @@ void mdk_bam_reap_wait(mdk_bam *b) {
     { const double t0 = now_s();
       while(b->n_reap || b->reap_busy) pthread_cond_wait(&b->cv_reaped, &b->mu);
       if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] reaper: %d slabs given back in %.3fs of its own thread's time, %d left in the pool, %d still referenced; waited for it %.3fs at the end\n", b->n_reaped, b->t_reap, b->n_pool, b->n_alloc - b->n_pool, now_s() - t0);
+      if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] framing the pieces (the walk over the BGZF headers, under the file's lock): %.3fs in all\n", b->t_frame);
       if(getenv("MDK_HOST_PROFILE")) { int k; for(k = 0; k < 2; k++) fprintf(stderr, "[mdk host] %s teams, summed over the teams that have left: %d pieces; waiting for the file's lock + framing %.3fs, inflating %.3fs (device teams: waiting for a device slab %.3fs, staging copy %.3fs, device %.3fs), handing over in file order %.3fs\n", k ? "device" : "host", b->tt_pieces[k], b->tt_next[k], b->tt_host[k], b->tt_slab[k], b->tt_copy[k], b->tt_dev[k], b->tt_deliver[k]); } }
     pthread_mutex_unlock(&b->mu);
 }
@@ -192,7 +220,7 @@ typedef struct { uint8_t *cbuf; blk_t *blk; int nb; size_t total; uint64_t seq; 
 
 /* under io_mu: read CCHUNK more compressed bytes, list every complete member; the unfinished tail moves to a fresh window.
  * status: 0 a piece was produced, 1 end of file, <0 error */
-static int next_piece(mdk_bam *b, piece *pc, size_t want) {
+static int next_piece(mdk_bam *b, piece *pc, size_t want, int max_members) {
     size_t n, off = 0, total = 0; blk_t *blk = NULL; int nb = 0, mb = 0;
     memset(pc, 0, sizeof(*pc));
     if(b->map) {        /* mapped file: the window is a view, nothing is read or copied here */
@@ -205,7 +233,7 @@ static int next_piece(mdk_bam *b, piece *pc, size_t want) {
         b->clen += n;
         if(n < want) b->file_eof = 1;
     }
-    while(off + 18 <= b->clen) {
+    while(off + 18 <= b->clen && (max_members <= 0 || nb < max_members)) {
         const uint8_t *p = b->cbuf + off; uint16_t xlen; uint32_t bsize = 0, isize; size_t x; int have = 0;
         if(p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) { snprintf(b->err, sizeof(b->err), "not a BGZF file (bad gzip member header)"); free(blk); return -2; }
         xlen = le16(p + 10);
@@ -363,10 +391,13 @@ static void *inflater_main(void *arg) {
         piece pc; int st; mdk_slab *s = NULL; double t0 = now_s(), t1;
         pthread_mutex_lock(&b->io_mu);
         if(b->io_status) { pthread_mutex_unlock(&b->io_mu); break; }              /* another team has seen the end (or an error) */
-        st = next_piece(b, &pc, gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK);
+        { const double tf = now_s();
+        st = next_piece(b, &pc, gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK, gt >= 0 ? b->gpu_piece_members : 0);
+        b->t_frame += now_s() - tf; }
         if(st == 0) pc.seq = b->next_seq++; else b->io_status = st;
         pthread_mutex_unlock(&b->io_mu);
         t1 = now_s(); t_next += t1 - t0; t0 = t1;
+        if(st == 0) { populate_ahead(b); if(gt >= 0) populate_ahead(b); }       /* (a device team's piece is larger than a block) */
         if(st == 0) {
             /* a device team's piece goes to the host's inflate after all when it would inflate to more than the device addresses in one piece
              * (4 GiB: a ratio above 64, low-complexity data) or when the device cannot take it for want of a resource (status -1) */
@@ -426,7 +457,18 @@ int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     if(n_teams > MDK_GPU_TEAMS_MAX) n_teams = MDK_GPU_TEAMS_MAX;
     pthread_mutex_lock(&b->life_mu);                              /* (the reader thread may be inside a seek, which stops and restarts every team) */
     __atomic_store_n(&b->dev, dev, __ATOMIC_RELEASE);             /* (the host teams, already running, look at it without a lock: inflater_main) */
-    b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + (getenv("MDK_DSLAB_EXTRA") && atoi(getenv("MDK_DSLAB_EXTRA")) >= 1 ? atoi(getenv("MDK_DSLAB_EXTRA")) : 4);
+    /* A device piece is a whole number of the device's ROUNDS of members: k_inflate keeps a fixed number of wavefronts resident, each inflating one member at a
+     * time, so 5,135 members on 2,560 wavefronts took three members' time where 5,120 take two (a 96 MB piece: 3.8 ms instead of 2.6, gpurun_out r06l).
+     * MDK_GPU_PIECE_ROUNDS=n (default 2); a piece size given in bytes (MDK_GPU_PIECE_MB, tests) stands as it is. */
+    if(!getenv("MDK_GPU_PIECE_MB")) {
+        const int per = md_piece_members_per_round(dev); int rounds = getenv("MDK_GPU_PIECE_ROUNDS") ? atoi(getenv("MDK_GPU_PIECE_ROUNDS")) : 2;
+        if(rounds < 1) rounds = 1;
+        if(rounds > 8) rounds = 8;
+        pthread_mutex_lock(&b->io_mu);
+        if(per > 0) { b->gpu_piece_members = per * rounds; b->gpu_piece_bytes = (size_t)b->gpu_piece_members * 28672u; if(b->gpu_piece_bytes > (240u << 20)) b->gpu_piece_bytes = 240u << 20; }
+        pthread_mutex_unlock(&b->io_mu);
+    }
+    b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + (getenv("MDK_DSLAB_EXTRA") && atoi(getenv("MDK_DSLAB_EXTRA")) >= 1 ? atoi(getenv("MDK_DSLAB_EXTRA")) : 8);      /* (a chunk read in place keeps its piece until its results are in: md_dev_upload_raw_inplace) */
     if(b->inf_started) {
         for(k = 0; k < n_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } }
         b->n_gpu_teams = k; b->gpu_started = 1;
@@ -722,7 +764,7 @@ int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
     b->n_ready = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
     pthread_mutex_unlock(&b->mu);
     if(b->cur) { mdk_slab_unref(b, b->cur); b->cur = NULL; }
-    if(b->map) { if((size_t)(voffset >> 16) > b->map_len) { snprintf(b->err, sizeof(b->err), "seek failed"); pthread_mutex_unlock(&b->life_mu); return -2; } b->map_pos = (size_t)(voffset >> 16); }
+    if(b->map) { if((size_t)(voffset >> 16) > b->map_len) { snprintf(b->err, sizeof(b->err), "seek failed"); pthread_mutex_unlock(&b->life_mu); return -2; } b->map_pos = (size_t)(voffset >> 16); __atomic_store_n(&b->pop_next, b->map_pos, __ATOMIC_RELAXED); }
     else if(fseeko(b->f, (off_t)(voffset >> 16), SEEK_SET)) { snprintf(b->err, sizeof(b->err), "seek failed"); pthread_mutex_unlock(&b->life_mu); return -2; }
     inflaters_start(b);
     pthread_mutex_unlock(&b->life_mu);

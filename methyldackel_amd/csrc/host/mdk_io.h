@@ -58,7 +58,7 @@ typedef struct mdk_bam {
      * goes on with its next piece instead of waiting for its turn (device pieces are several times larger than host pieces) */
 #define MDK_READY 64
     mdk_slab *ready[MDK_READY]; int n_ready; uint64_t pop_seq; int io_end;      /* io_end: copy of io_status once non-zero */
-    int inf_done, quit, host_leaves, header_done; size_t gpu_piece_bytes;
+    int inf_done, quit, host_leaves, header_done; size_t gpu_piece_bytes; int gpu_piece_members;      /* gpu_piece_members: a device piece ends after this many members (a whole number of the device's rounds of wavefronts), 0 = by bytes only */
     /* teams that inflate on the device (mdk_bam_attach_device): each stages a piece of the file in registered memory and hands it
      * to the device library (md_piece_*); they share the piece counter with the host teams */
     struct md_dev *dev; pthread_t gpu_th[MDK_GPU_TEAMS_MAX]; int n_gpu_teams, gpu_started; uint8_t *gpu_stage[MDK_GPU_TEAMS_MAX]; size_t gpu_stage_cap[MDK_GPU_TEAMS_MAX];
@@ -72,6 +72,10 @@ typedef struct mdk_bam {
     double tt_next[2], tt_slab[2], tt_copy[2], tt_dev[2], tt_deliver[2], tt_host[2]; int tt_pieces[2];      /* MDK_HOST_PROFILE: where the inflate teams' time went, summed over the teams ([0] host teams, [1] device teams) */
     uint8_t *cbuf; size_t ccap, clen; int file_eof;
     const uint8_t *map; size_t map_len, map_pos;   /* the file mapped read-only: the inflate threads read the compressed bytes where the page cache has them (no copy) */
+    /* the mapping's page-table entries are made AHEAD of the framing (mdk_io.c populate_ahead): the walk over the members' headers runs under io_mu, one team at
+     * a time, and a first touch of a page there costs the whole feed a microsecond per member */
+    double t_frame;                                /* (io_mu) seconds inside next_piece */
+    size_t pop_next;                               /* (atomic) up to where the mapping's entries have been made or are being made */
     /* scanner position */
     mdk_slab *cur; size_t off;
     int mem_i; size_t sum_i, sum_end;        /* next member to look at; records of the current ok member still to hand out */

@@ -1048,7 +1048,7 @@ extern "C" int md_dev_bind_output(md_dev *h, int slot, void *d_site, void *d_var
 
 static int fill_kparams(md_dev *h, Slot *s, KParams &P) {
     memset(&P, 0, sizeof(P));
-    P.seg = s->d_seg_in.p; P.blob = s->raw_layout ? s->d_raw.p : s->d_blob.p; P.packed = s->raw_layout ? 1 : 0;
+    P.seg = s->d_seg_in.p; P.blob = s->raw_layout ? const_cast<uint8_t *>(s->raw_at) : s->d_blob.p; P.packed = s->raw_layout ? 1 : 0;
     P.ctxcode = h->refcode[s->tid]; P.reflen = h->reflen[s->tid];
     P.beg = s->beg; P.end = s->end; P.tile = s->tile; P.ntiles = s->ntiles; P.nper = (s->ntiles + 7) / 8;
     P.tiles = s->d_tiles.p;

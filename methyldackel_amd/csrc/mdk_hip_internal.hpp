@@ -99,6 +99,9 @@ struct Slot {
     DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRead> d_prd; DBuf<uint32_t> d_aidx; HBuf<uint32_t> h_aidx; DBuf<int32_t> d_hnext; Ref<PrepCounters> d_pcnt;
     DBuf<uint8_t> d_zero;              // what a preparation launch starts from zeroed: name table (keys, heads), per-workgroup counts, tickets
     uint32_t hmask = 0; int pr_nrec = 0; uint64_t raw_bytes = 0; bool raw_layout = false; int64_t woff = 0, wlen = 0;
+    // where the kernels find the chunk's records and their table: the slot's own copies (d_raw, d_recoff), or -- md_dev_upload_raw_inplace -- the caller's piece:
+    // raw_at + rec_at[i] is record i; inplace_delta / inplace_bytes: the range inside the piece (md_dev_read_raw hands back the range alone)
+    const uint8_t *raw_at = nullptr; const uint32_t *rec_at = nullptr; uint64_t raw_span = 0; bool inplace = false; uint32_t inplace_delta = 0;
     bool prep_pending = false;         // records uploaded, preparation kernels not yet queued (they go with the launch, several chunks at a time)
     bool mb_pending = false;           // mbias: the chunk's preparation is queued, its histogram kernel not yet (it waits for what the preparation reports: the longest read)
     DBuf<md_pr_read> d_pr; DBuf<uint32_t> d_cig; DBuf<md_pr_count> d_prc; HBuf<md_pr_count> h_prc; int pr_n = -1;      // perRead

@@ -393,6 +393,21 @@ __global__ __launch_bounds__(1024) void k_walk_scan(const uint32_t *cnt, uint32_
 // The wavefronts of a launch: as many as the device holds at once (what the kernel's LDS and registers allow per CU, times the CUs), or the
 // members if they are fewer; each draws members from the counter in status[2] until none is left, so a launch has no second, partly filled
 // generation of wavefronts and the last ones end within one member's time of each other.  MDK_INF_GRID overrides.
+// MDK_PIECE_CU_RESERVE=n (experiment): the pieces' streams leave n of the device's CUs alone (hipExtStreamCreateWithCUMask), so that the kernels of the
+// chunks -- microseconds of work that otherwise waits for a slot until a whole launch of k_inflate has ended -- always find CUs
+static int piece_cu_reserve() { static const int r = getenv("MDK_PIECE_CU_RESERVE") ? atoi(getenv("MDK_PIECE_CU_RESERVE")) : 0; return r > 0 && r < 200 ? r : 0; }
+static hipStream_t piece_stream_make(int device) {
+    hipStream_t s = nullptr; const int r = piece_cu_reserve();
+    if(r > 0) {
+        int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        uint32_t mask[16]; const int words = (cus + 31) / 32; for(int w = 0; w < 16; w++) mask[w] = 0;
+        for(int i = 0; i < cus; i++) mask[i >> 5] |= 1u << (i & 31);
+        for(int k = 0; k < r; k++) { const int i = (int)(((long long)k * cus) / r) + (cus / r) - 1; if(i >= 0 && i < cus) mask[i >> 5] &= ~(1u << (i & 31)); }      // evenly spread
+        if(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) == hipSuccess) return s;
+        (void)hipGetLastError();
+    }
+    return mdk_stream_take(device);
+}
 static int inflate_grid_max(int device) {
     static int cached[64] = {0};
     const int slot = device >= 0 && device < 64 ? device : 0;
@@ -401,7 +416,7 @@ static int inflate_grid_max(int device) {
         if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_inflate, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
         if(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
         (void)hipGetLastError();
-        int g = per_cu * cus;
+        int g = per_cu * (cus - piece_cu_reserve());
         if(getenv("MDK_INF_GRID") && atoi(getenv("MDK_INF_GRID")) > 0) g = atoi(getenv("MDK_INF_GRID"));
         cached[slot] = g;
     }
@@ -454,10 +469,11 @@ static hipStream_t piece_stream_of(md_dev *h, bool *own) {
     *own = false;
     if(want < 1) { hipStream_t s = nullptr; if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr; *own = true; return s; }
     std::lock_guard<std::mutex> lk(h->piece_mu);
-    if((int)h->piece_streams.size() < want) { hipStream_t s = mdk_stream_take(h->device); if(!s) return nullptr; h->piece_streams.push_back(s); return s; }
+    if((int)h->piece_streams.size() < want) { hipStream_t s = piece_stream_make(h->device); if(!s) return nullptr; h->piece_streams.push_back(s); return s; }
     return h->piece_streams[(size_t)(h->piece_rr++ % want)];
 }
 static hipError_t piece_sync(md_piece *p) { return p->recorded ? hipEventSynchronize(p->done) : hipSuccess; }      // the piece's own work, not its stream's
+extern "C" int md_piece_members_per_round(md_dev *h) { if(!h) return 0; if(hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return 0; } return inflate_grid_max(h->device); }
 extern "C" int md_piece_create(md_dev *h, md_piece **out) {
     if(!h || !out) return fail(MDK_ERR_ARG, "md_piece_create", hipSuccess);
     *out = nullptr;

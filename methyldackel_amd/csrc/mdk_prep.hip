@@ -930,8 +930,9 @@ extern "C" int md_dev_read_raw(md_dev *h, int slot, uint8_t *bytes, uint64_t *n_
     if(*n_bytes < s->raw_bytes || *n_records < (uint32_t)s->pr_nrec) { *n_bytes = s->raw_bytes; *n_records = (uint32_t)s->pr_nrec; return fail(MDK_ERR_ARG, "md_dev_read_raw: buffers too small", hipSuccess); }
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if(s->raw_bytes) HIPCHK(hipMemcpy(bytes, s->d_raw.p, (size_t)s->raw_bytes, hipMemcpyDeviceToHost));
-    if(s->pr_nrec) HIPCHK(hipMemcpy(rec_off, s->d_recoff.p, sizeof(uint32_t) * (size_t)s->pr_nrec, hipMemcpyDeviceToHost));
+    if(s->raw_bytes) HIPCHK(hipMemcpy(bytes, s->raw_at + s->inplace_delta, (size_t)s->raw_bytes, hipMemcpyDeviceToHost));
+    if(s->pr_nrec) HIPCHK(hipMemcpy(rec_off, s->rec_at, sizeof(uint32_t) * (size_t)s->pr_nrec, hipMemcpyDeviceToHost));
+    if(s->inplace_delta) for(int i = 0; i < s->pr_nrec; i++) rec_off[i] -= s->inplace_delta;      // (read in place: the table counts from the piece's first byte)
     *n_bytes = s->raw_bytes; *n_records = (uint32_t)s->pr_nrec;
     return 0;
 }
@@ -973,7 +974,7 @@ static size_t zero_bytes_for(uint32_t hmask, int nb) { return (((size_t)hmask + 
 static void fill_prep(md_dev *h, Slot *s, PrepParams &P) {
     memset(&P, 0, sizeof(P));
     const int n = s->pr_nrec, nb = (n + PB - 1) / PB; const size_t H = (size_t)s->hmask + 1;
-    P.raw = s->d_raw.p; P.raw_bytes = s->raw_bytes; P.rec_off = s->d_recoff.p; P.n_rec = n;
+    P.raw = s->raw_at; P.raw_bytes = s->raw_span; P.rec_off = s->rec_at; P.n_rec = n;
     P.cfg = h->prep; P.tid = s->tid; P.beg = s->beg; P.end = s->end; P.woff = s->woff; P.wlen = s->wlen;
     P.ref = h->ref[s->tid]; P.reflen = h->reflen[s->tid];
     if(h->prep.map_on && (size_t)s->tid < h->mapbits.size()) { P.mapbits = h->mapbits[s->tid]; P.maplen = h->maplen[s->tid]; }
@@ -1022,7 +1023,7 @@ static int enqueue_prep(md_dev *h, Slot *s, hipStream_t st = nullptr) { Slot *on
 
 // H2D of the chunk's record bytes and record table, then the preparation kernels: the slot ends up "uploaded", with its
 // segments and tile runs in device memory, exactly as after md_dev_upload of a host-built batch.
-extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
+static int upload_raw(md_dev *h, int slot, const md_raw_batch *b, bool may_stay) {
     Slot *s = get_slot(h, slot);
     if(!s || !b || b->n_records < 0 || b->n_ranges < 0 || b->end < b->beg) return fail(MDK_ERR_ARG, "md_dev_upload_raw", hipSuccess);
     if(!h->prep_set) return fail(MDK_ERR_ARG, "md_dev_upload_raw: md_dev_set_prep was not called", hipSuccess);
@@ -1044,13 +1045,16 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->woff = b->woff; s->wlen = b->wlen; s->uploaded = false; s->launched = false;
     s->tile = TILE; s->ntiles = ntiles; s->lds_bytes = TILE * ((h->variant ? 16 : 8) + 4);
     s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->n_segs = -1; s->n_reads = -1; s->read_bytes = 0;
+    // one device-resident range with its own record table, and a caller that keeps it: nothing is copied
+    static const bool no_inplace = getenv("MDK_NO_INPLACE") != nullptr;
+    const bool inplace = may_stay && !no_inplace && b->n_ranges == 1 && b->range[0].d_rec_off && (uint32_t)n == b->range[0].n_records && n > 0 && b->range[0].bytes + (uint64_t)b->range[0].rec_delta < (1ull << 32) - 64;
     const size_t nn = (size_t)n + 1, nt = (size_t)(ntiles > 0 ? ntiles : 1);
     const size_t segcap = std::max<size_t>(s->d_seg_in.cap, nn * 2 + 4096);
     s->hmask = pow2_at_least(nn + nn / 4) - 1;          // names are at most the records: load factor <= 0.8, ~0.4 for pairs; 2 MB for a 1 Mb chunk at 30x
     static std::atomic<int> first_call{1}; const bool first = mdk_prof_on() && first_call.exchange(0); const double tf0 = first ? mdk_now() : 0; double tf1 = 0;
     {
         ProfScope pf(PF_UP_ALLOC);
-        if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
+        if((!inplace && (s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn))) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
            s->d_seg_in.need(segcap) || s->d_tiles.need(nt) || s->d_seg.need(nt)) return MDK_ERR_NOMEM;
         if(!s->b_site) {
             if(s->d_site.need((size_t)span + 16)) return MDK_ERR_NOMEM;
@@ -1058,12 +1062,15 @@ extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
         }
     }
     if(first) tf1 = mdk_now();
-    { ProfScope pf(PF_UP_COPY); int rcc = copy_ranges(h, s, b); if(rcc) return rcc; HIPCHK(hipEventRecord(s->e1, s->stream)); }
+    if(inplace) { const md_raw_range &r = b->range[0]; s->inplace = true; s->inplace_delta = r.rec_delta; s->raw_at = r.ptr - r.rec_delta; s->rec_at = r.d_rec_off; s->raw_span = (uint64_t)r.rec_delta + r.bytes; HIPCHK(hipEventRecord(s->e1, s->stream)); }
+    else { ProfScope pf(PF_UP_COPY); s->inplace = false; s->inplace_delta = 0; s->raw_at = s->d_raw.p; s->rec_at = s->d_recoff.p; s->raw_span = total; int rcc = copy_ranges(h, s, b); if(rcc) return rcc; HIPCHK(hipEventRecord(s->e1, s->stream)); }
     if(first) fprintf(stderr, "[mdk hip] the first chunk's upload: device buffers %.3fs, registration + copies queued %.3fs\n", tf1 - tf0, mdk_now() - tf1);
     s->prep_pending = true;            // the preparation kernels are queued with the launch: alone (md_dev_launch) or with up to seven other chunks (md_dev_launch_group)
     s->uploaded = true;
-    return 0;
+    return inplace ? 1 : 0;
 }
+extern "C" int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) { return upload_raw(h, slot, b, false); }
+extern "C" int md_dev_upload_raw_inplace(md_dev *h, int slot, const md_raw_batch *b) { return upload_raw(h, slot, b, true); }
 
 extern "C" int md_dev_upload_wait(md_dev *h, int slot) {
     Slot *s = get_slot(h, slot);
@@ -1103,9 +1110,10 @@ extern "C" int md_dev_perread_submit_raw(md_dev *h, int slot, const md_raw_batch
     for(int i = 0; i < b->n_ranges; i++) total += b->range[i].bytes;
     if(total >= (1ull << 32) - 64) return fail(MDK_ERR_ARG, "md_dev_perread_submit_raw: more than 4 GiB of records in one chunk", hipSuccess);
     const int n = b->n_records, nb = (n + PB - 1) / PB; const size_t nn = (size_t)n + 1;
-    s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->hmask = 1023; s->ntiles = 0; s->tile = h->tile;
+    s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->pr_nrec = n; s->raw_bytes = total; s->raw_layout = true; s->hmask = 1023; s->ntiles = 0; s->tile = h->tile; s->inplace = false; s->inplace_delta = 0; s->raw_span = total;
     if(s->d_raw.need((size_t)total + 64) || s->d_recoff.need(nn) || s->d_prd.need(nn) || s->d_hnext.need(2 * nn + 8) || s->d_zero.need(zero_bytes_for(s->hmask, nb)) ||
        s->d_aidx.need(nn) || s->h_aidx.need(nn) || s->d_prc.need(nn) || s->h_prc.need(nn)) return MDK_ERR_NOMEM;
+    s->raw_at = s->d_raw.p; s->rec_at = s->d_recoff.p;
     { int rcc = copy_ranges(h, s, b); if(rcc) return rcc; }
     { int rc = enqueue_prep(h, s); if(rc) return rc; }                 // perread mode: selection + file-order compaction only (k_prep_scan)
     if(n > 0) {

@@ -87,6 +87,7 @@ int md_dev_upload_raw(md_dev *h, int slot, const md_raw_batch *b) {
     pthread_mutex_lock(&h->mu); h->n_up++; if(h->handback > 0 && h->n_up % h->handback == 0) s->handed_back = 1; pthread_mutex_unlock(&h->mu);
     return 0;
 }
+int md_dev_upload_raw_inplace(md_dev *h, int slot, const md_raw_batch *b) { return md_dev_upload_raw(h, slot, b); }      /* (the stand-in always copies) */
 int md_dev_upload_wait(md_dev *h, int slot) { return slot_of(h, slot) ? 0 : MDK_ERR_ARG; }
 int md_dev_upload_done(md_dev *h, int slot) { static __thread unsigned n; return slot_of(h, slot) ? (int)(++n % 3 != 0) : MDK_ERR_ARG; }      /* "not yet" now and then: the caller's waiting path runs too */
 int md_dev_upload(md_dev *h, int slot, const md_read_batch *b) { sslot *s = slot_of(h, slot); if(!s || !b) return MDK_ERR_ARG; s->tid = b->tid; s->beg = b->beg; s->end = b->end; s->used = 1; s->launched = 0; s->handed_back = 0; return 0; }

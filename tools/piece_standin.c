@@ -14,6 +14,7 @@
 struct md_piece { uint8_t *out; uint64_t out_cap; uint32_t *rec; uint64_t rec_cap, n_rec; md_inf_digest *dig; int dig_cap; md_piece_info info; };
 static uint32_t u32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 
+int md_piece_members_per_round(md_dev *h) { (void)h; return getenv("MDK_STANDIN_MEMBERS_PER_ROUND") ? atoi(getenv("MDK_STANDIN_MEMBERS_PER_ROUND")) : 0; }      /* (0: pieces are cut by bytes) */
 int md_piece_create(md_dev *h, md_piece **out) { (void)h; *out = calloc(1, sizeof(**out)); return *out ? 0 : -6; }
 void md_piece_destroy(md_piece *p) { if(!p) return; free(p->out); free(p->rec); free(p->dig); free(p); }
 void md_host_register(md_dev *h, const void *ptr) { (void)h; (void)ptr; }
