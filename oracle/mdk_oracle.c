@@ -55,6 +55,8 @@
 #include <string.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <dlfcn.h>
 #include <time.h>
 
@@ -121,8 +123,11 @@ static int32_t rec_endpos(const brec *r) { return r->pos + (r->rlen > 0 ? r->rle
  * spread over the N threads up front: members are inflated block-parallel, records are decoded range-parallel. */
 static int g_load_threads = 1;
 static double wall_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
-#define PHASE(name) do { if(getenv("MDK_ORACLE_PROFILE")) { double t_ = wall_s(); fprintf(stderr, "[oracle] %-22s %.3f s\n", name, t_ - g_t0); g_t0 = t_; } } while(0)
-static double g_t0;
+/* MDK_ORACLE_PROFILE=1: wall clock per phase on stderr; a phase one thread does alone counts as serial (SERIAL), the others are spread over the -@ N threads */
+static double g_t0, g_t_serial, g_t_all;
+#define PHASE_(name, serial) do { double t_ = wall_s(); g_t_all += t_ - g_t0; if(serial) g_t_serial += t_ - g_t0; if(getenv("MDK_ORACLE_PROFILE")) fprintf(stderr, "[oracle] %-22s %.3f s%s\n", name, t_ - g_t0, serial ? "  (one thread)" : ""); g_t0 = t_; } while(0)
+#define PHASE(name) PHASE_(name, 0)
+#define PHASE_SERIAL(name) PHASE_(name, 1)
 typedef struct { const uint8_t *raw; const size_t *moff, *mout; const uint32_t *mlen, *misz, *mhdr; size_t nm; uint8_t *out; int k, n, bad;
                  size_t *roff; size_t n_roff, cap_roff; uint32_t *mcount; } inflate_job;      /* roff/mcount: the records each member holds when it starts on a record boundary */
 /* htslib never lets a record straddle two BGZF members (bam_write1 flushes first), so a member normally starts on a record
@@ -201,35 +206,81 @@ static void *decode_main(void *arg) {
     }
     return NULL;
 }
+/* the file is mapped, not read: every worker of the reference reads through its own handle (extract.c:283-295), nobody reads the whole file on one
+ * thread first.  The mapping's pages are touched by the -@ N threads, each its share, so that the serial walk over the members' headers finds them */
+#ifndef MADV_POPULATE_READ
+#define MADV_POPULATE_READ 22
+#endif
+typedef struct { const uint8_t *p; size_t len; } touch_job;
+static void *touch_main(void *arg) {
+    touch_job *j = arg; size_t o; volatile uint8_t sink = 0;
+    if(j->len && madvise((void *)j->p, j->len, MADV_POPULATE_READ) != 0) for(o = 0; o < j->len; o += 4096) sink ^= j->p[o];
+    (void)sink;
+    return NULL;
+}
+typedef struct { bamfile *bf; size_t lo, hi; size_t *tlo, *thi; int bad; } range_job;      /* tlo/thi[tid]: first record / one past the last record of the contig inside [lo,hi) */
+static void *range_main(void *arg) {
+    range_job *j = arg; bamfile *bf = j->bf; size_t i; int32_t t;
+    for(t = 0; t < bf->n_targets; t++) { j->tlo[t] = (size_t)-1; j->thi[t] = 0; }
+    for(i = j->lo; i < j->hi; i++) {
+        const brec *b = &bf->rec[i];
+        if(b->tid < 0 || b->tid >= bf->n_targets) continue;
+        if(j->tlo[b->tid] == (size_t)-1) j->tlo[b->tid] = i;
+        else if(j->thi[b->tid] != i) { j->bad = 1; return NULL; }                       /* contigs interleaved */
+        if(i > j->tlo[b->tid] && bf->rec[i - 1].pos > b->pos) { j->bad = 2; return NULL; }
+        j->thi[b->tid] = i + 1;
+    }
+    return NULL;
+}
+typedef struct { size_t *dst; const size_t *first; const uint32_t *mcount; inflate_job *ijob; size_t m0, nm; int k, nt; } gather_job;
+static void *gather_main(void *arg) {      /* thread k's members are i = k, k + nt, ...: their record offsets, noted in that order, go to their places in file order */
+    gather_job *g = arg; size_t i, cur = 0;
+    for(i = (size_t)g->k; i < g->nm; i += (size_t)g->nt) {
+        if(g->mcount[i] == UINT32_MAX) continue;
+        if(i >= g->m0) memcpy(g->dst + g->first[i], g->ijob[g->k].roff + cur, g->mcount[i] * sizeof(size_t));
+        cur += g->mcount[i];
+    }
+    return NULL;
+}
 static int bam_load(const char *fn, bamfile *bf) {
     FILE *f = fopen(fn, "rb");
     uint8_t *raw; size_t rawlen, o = 0, cap, i, nm = 0, mcap = 1024, total = 0, *moff, *mout, *roff; uint32_t *mlen, *misz, *mhdr, *mcount = NULL; inflate_job *ijob = NULL;
-    int nt = g_load_threads < 1 ? 1 : g_load_threads, k, bad = 0;
+    int nt = g_load_threads < 1 ? 1 : g_load_threads, k, bad = 0, mapped = 0;
     memset(bf, 0, sizeof(*bf));
     if(!f) return -1;
     g_t0 = wall_s();
-    fseek(f, 0, SEEK_END); rawlen = ftell(f); fseek(f, 0, SEEK_SET);
-    raw = xmalloc(rawlen);
-    if(fread(raw, 1, rawlen, f) != rawlen) { fclose(f); free(raw); return -1; }
-    fclose(f);
-    PHASE("read file");
+    { struct stat st; void *m;
+      if(fstat(fileno(f), &st) != 0 || st.st_size <= 0) { fclose(f); return -1; }
+      rawlen = (size_t)st.st_size;
+      m = mmap(NULL, rawlen, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+      if(m == MAP_FAILED) { raw = xmalloc(rawlen); if(fread(raw, 1, rawlen, f) != rawlen) { fclose(f); free(raw); return -1; } }       /* (not a mappable file: read it) */
+      else {
+          pthread_t *th = xmalloc(sizeof(pthread_t) * nt); touch_job *tj = xmalloc(sizeof(touch_job) * nt); const size_t per = ((rawlen / (size_t)nt) + 4095) & ~(size_t)4095;
+          raw = m; mapped = 1;
+          for(k = 0; k < nt; k++) { size_t a = per * (size_t)k, e = a + per; if(a > rawlen) a = rawlen; if(e > rawlen || k == nt - 1) e = rawlen; tj[k].p = raw + a; tj[k].len = e - a; if(k) pthread_create(&th[k], NULL, touch_main, &tj[k]); }
+          touch_main(&tj[0]);
+          for(k = 1; k < nt; k++) pthread_join(th[k], NULL);
+          free(th); free(tj);
+      }
+      fclose(f); }
+    PHASE("map file");
     /* member table (BGZF: concatenated gzip members with a 'BC' extra subfield holding the member size) */
     moff = xmalloc(mcap * sizeof(size_t)); mout = xmalloc(mcap * sizeof(size_t)); mlen = xmalloc(mcap * 4); misz = xmalloc(mcap * 4); mhdr = xmalloc(mcap * 4);
     while(o + 18 <= rawlen) {
         uint16_t xlen, bsize = 0; size_t x; int have = 0;
-        if(raw[o] != 0x1f || raw[o + 1] != 0x8b || raw[o + 2] != 8 || !(raw[o + 3] & 4)) { free(raw); return -2; }
+        if(raw[o] != 0x1f || raw[o + 1] != 0x8b || raw[o + 2] != 8 || !(raw[o + 3] & 4)) { if(mapped) munmap(raw, rawlen); else free(raw); return -2; }
         xlen = rd16(raw + o + 10);
         for(x = o + 12; x + 4 <= o + 12 + xlen;) {      /* find the 'BC' extra subfield */
             uint16_t slen = rd16(raw + x + 2);
             if(raw[x] == 'B' && raw[x + 1] == 'C' && slen == 2) { bsize = rd16(raw + x + 4); have = 1; }
             x += 4 + slen;
         }
-        if(!have || o + bsize + 1 > rawlen) { free(raw); return -2; }
+        if(!have || o + bsize + 1 > rawlen) { if(mapped) munmap(raw, rawlen); else free(raw); return -2; }
         if(nm == mcap) { mcap *= 2; moff = xrealloc(moff, mcap * sizeof(size_t)); mout = xrealloc(mout, mcap * sizeof(size_t)); mlen = xrealloc(mlen, mcap * 4); misz = xrealloc(misz, mcap * 4); mhdr = xrealloc(mhdr, mcap * 4); }
         moff[nm] = o; mlen[nm] = (uint32_t)bsize + 1; mhdr[nm] = 12u + xlen; misz[nm] = rd32(raw + o + bsize + 1 - 4); mout[nm] = total; total += misz[nm]; nm++;
         o += (size_t)bsize + 1;
     }
-    PHASE("member table");
+    PHASE_SERIAL("member table");
     bf->data = xmalloc(total + 1);
     bf->len = total;
     if(g_ld_state == 0) ldeflate_init();
@@ -242,7 +293,8 @@ static int bam_load(const char *fn, bamfile *bf) {
         for(k = 0; k < nt; k++) bad |= job[k].bad;
         free(th); ijob = job;
     }
-    free(raw); free(moff); free(mlen); free(mhdr);
+    if(mapped) munmap(raw, rawlen); else free(raw);
+    free(moff); free(mlen); free(mhdr);
     PHASE("inflate");
     if(bad) return -2;
     /* header */
@@ -275,8 +327,14 @@ static int bam_load(const char *fn, bamfile *bf) {
         for(i = 0; i <= im && i < nm; i++) if(mcount[i] != UINT32_MAX) cur[i % (size_t)nt] += mcount[i];      /* what the threads noted for the header members is not used */
         for(i = im + 1; i < nm && ok; i++) { if(mcount[i] == UINT32_MAX) ok = 0; else tot += mcount[i]; }
         if(ok) {
+            size_t *first = xmalloc((nm + 1) * sizeof(size_t)), at = bf->n_rec; pthread_t *th = xmalloc(sizeof(pthread_t) * nt); gather_job *gj = xmalloc(sizeof(gather_job) * nt);
             if(bf->n_rec + tot + 1 > cap) { cap = bf->n_rec + tot + 1; roff = xrealloc(roff, cap * sizeof(size_t)); }
-            for(i = im + 1; i < nm; i++) { const size_t t = i % (size_t)nt; memcpy(roff + bf->n_rec, ijob[t].roff + cur[t], mcount[i] * sizeof(size_t)); cur[t] += mcount[i]; bf->n_rec += mcount[i]; }
+            for(i = 0; i < nm; i++) { first[i] = at; if(i > im) at += mcount[i]; }
+            for(k = 0; k < nt; k++) { gather_job g = {roff, first, mcount, ijob, im + 1, nm, k, nt}; gj[k] = g; if(k) pthread_create(&th[k], NULL, gather_main, &gj[k]); }
+            gather_main(&gj[0]);
+            for(k = 1; k < nt; k++) pthread_join(th[k], NULL);
+            bf->n_rec = at;
+            free(first); free(th); free(gj);
         } else {
             bf->n_rec = 0;
             while(o + 4 <= bf->len) {
@@ -309,13 +367,25 @@ static int bam_load(const char *fn, bamfile *bf) {
     (void)0;
     bf->tid_hi = xmalloc(sizeof(size_t) * (bf->n_targets + 1));
     for(i = 0; i < (size_t)bf->n_targets; i++) bf->tid_lo[i] = bf->tid_hi[i] = 0;
-    for(i = 0; i < bf->n_rec; i++) {
-        brec *b = &bf->rec[i];
-        if(b->tid < 0 || b->tid >= bf->n_targets) continue;
-        if(bf->tid_hi[b->tid] == 0 && bf->tid_lo[b->tid] == 0) bf->tid_lo[b->tid] = i;
-        else if(bf->tid_hi[b->tid] != i) { fprintf(stderr, "oracle: BAM is not coordinate sorted (contigs interleaved)\n"); return -4; }
-        if(i > bf->tid_lo[b->tid] && bf->rec[i - 1].pos > b->pos) { fprintf(stderr, "oracle: BAM is not coordinate sorted\n"); return -4; }
-        bf->tid_hi[b->tid] = i + 1;
+    {   /* every thread its stretch of the records, then the stretches are joined in order */
+        pthread_t *th = xmalloc(sizeof(pthread_t) * nt); range_job *rj = xmalloc(sizeof(range_job) * nt); int32_t t;
+        for(k = 0; k < nt; k++) { range_job j = {bf, bf->n_rec * (size_t)k / nt, bf->n_rec * (size_t)(k + 1) / nt, xmalloc(sizeof(size_t) * (bf->n_targets + 1)), xmalloc(sizeof(size_t) * (bf->n_targets + 1)), 0}; rj[k] = j; if(k) pthread_create(&th[k], NULL, range_main, &rj[k]); }
+        range_main(&rj[0]);
+        for(k = 1; k < nt; k++) pthread_join(th[k], NULL);
+        for(k = 0; k < nt && !bad; k++) {
+            if(rj[k].bad) { bad = rj[k].bad; break; }
+            if(rj[k].lo < rj[k].hi && rj[k].lo > 0) { const brec *a = &bf->rec[rj[k].lo - 1], *b = &bf->rec[rj[k].lo]; if(a->tid == b->tid && a->tid >= 0 && a->tid < bf->n_targets && a->pos > b->pos) { bad = 2; break; } }
+            for(t = 0; t < bf->n_targets; t++) {
+                if(rj[k].tlo[t] == (size_t)-1) continue;
+                if(bf->tid_hi[t] == 0 && bf->tid_lo[t] == 0) bf->tid_lo[t] = rj[k].tlo[t];
+                else if(bf->tid_hi[t] != rj[k].tlo[t]) { bad = 1; break; }
+                bf->tid_hi[t] = rj[k].thi[t];
+            }
+        }
+        for(k = 0; k < nt; k++) { free(rj[k].tlo); free(rj[k].thi); }
+        free(th); free(rj);
+        if(bad == 1) { fprintf(stderr, "oracle: BAM is not coordinate sorted (contigs interleaved)\n"); return -4; }
+        if(bad == 2) { fprintf(stderr, "oracle: BAM is not coordinate sorted\n"); return -4; }
     }
     PHASE("contig ranges");
     return 0;
@@ -369,6 +439,8 @@ static int fasta_load(const char *fn, fasta *fa) {
     free(line); fclose(f);
     return 0;
 }
+typedef struct { const char *fn; fasta *fa; int rc; } fasta_job;
+static void *fasta_bg_main(void *arg) { fasta_job *j = arg; j->rc = fasta_load(j->fn, j->fa); return NULL; }
 /* faidx_fetch_seq(fai, name, beg, end_inclusive, &len): clamped to the contig; len=-2 unknown name */
 static char *fetch_seq(const fasta *fa, const char *name, int64_t beg, int64_t end, int *len) {
     int i; int64_t L; char *s;
@@ -1292,7 +1364,7 @@ static void extract_usage(void) {
 }
 
 static int extract_main(int argc, char *argv[]) {              /* extract.c:706-1514 */
-    char *opref = NULL, *oname, *p; int c, i; Config config; bamfile bf; fasta fa;
+    char *opref = NULL, *oname, *p; int c, i; Config config; bamfile bf; fasta fa; fasta_job fa_job; pthread_t fa_th; int fa_bg = 0;
     FILE *BBM_ptr = NULL; char *BWName = NULL; int outputBB = 0, noBAM = 0; char *bedName = NULL; int keepStrand = 0;
     const char *FastaName, *BAMName;
     static struct option lopts[] = {
@@ -1390,7 +1462,10 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
 
     FastaName = argv[optind]; BAMName = argv[optind + 1];
     g_load_threads = config.nThreads;
-    if((i = bam_load(BAMName, &bf)) != 0) { fprintf(stderr, "Couldn't open %s for reading!\n", BAMName); return -4; }
+    /* (the reference's workers fetch their windows of the FASTA as they go, extract.c:381; this oracle reads it whole -- on a thread of its own, next to the BAM) */
+    fa_job.fn = FastaName; fa_job.fa = &fa; fa_job.rc = 0;
+    fa_bg = config.nThreads > 1 && pthread_create(&fa_th, NULL, fasta_bg_main, &fa_job) == 0;
+    if((i = bam_load(BAMName, &bf)) != 0) { if(fa_bg) pthread_join(fa_th, NULL); fprintf(stderr, "Couldn't open %s for reading!\n", BAMName); return -4; }
     if(config.BBMName && (BBM_ptr = fopen(config.BBMName, "rb")) == NULL) { fprintf(stderr, "Couldn't open %s for reading!\n", config.BBMName); return -8; }
 
     if(BBM_ptr) {                                              /* extract.c:1236-1339 */
@@ -1443,7 +1518,8 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
         fclose(BBM_ptr);
     }
 
-    if(fasta_load(FastaName, &fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", FastaName); return -4; }
+    if(fa_bg) { pthread_join(fa_th, NULL); if(fa_job.rc) { fprintf(stderr, "Couldn't open the index for %s!\n", FastaName); return -4; } }
+    else if(fasta_load(FastaName, &fa) != 0) { fprintf(stderr, "Couldn't open the index for %s!\n", FastaName); return -4; }
 
     /* output files (extract.c:1343-1439) */
     if(opref == NULL) {
@@ -1493,7 +1569,7 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
     if(getenv("MDK_ORACLE_DUMP")) dump_fp = fopen(getenv("MDK_ORACLE_DUMP"), "w");
 
     {   /* extract.c:1479-1486 */
-        PHASE("fasta, outputs");
+        PHASE_SERIAL("fasta, outputs");
         extractArgs ea = {&config, &bf, &fa}; int nt = config.nThreads < 1 ? 1 : config.nThreads; pthread_t *threads = calloc((size_t)nt, sizeof(pthread_t));
         if(dump_fp) nt = 1;      /* the per-column dump is written as columns are finished: one worker keeps it ordered */
         for(i = 1; i < nt; i++) pthread_create(threads + i, NULL, extractCalls, &ea);
@@ -1501,6 +1577,7 @@ static int extract_main(int argc, char *argv[]) {              /* extract.c:706-
         for(i = 1; i < nt; i++) pthread_join(threads[i], NULL);
         free(threads);
         PHASE("chunks (all workers)");
+        if(getenv("MDK_ORACLE_PROFILE")) fprintf(stderr, "[oracle] serial phases %.3f s of %.3f s = %.1f %%\n", g_t_serial, g_t_all, g_t_all > 0 ? 100.0 * g_t_serial / g_t_all : 0.0);
     }
 
     if(dump_fp) { fclose(dump_fp); dump_fp = NULL; }
