@@ -212,85 +212,207 @@ static void emit_read(buf_t *out, const contig_t *ct, int tid, int64_t pos, cons
     free(seq); free(qual);
 }
 
-int main(int argc, char **argv) {
-    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {"no-bai", 0, 0, 7}, {"split-records", 0, 0, 8}, {0, 0, 0, 0}};
-    const char *prefix = NULL, *lens = "1000000"; double cov = 30; uint64_t seed = 0x5EED0001ULL; int level = 1, c, want_bbm = 0;
-    opts_t o = {0, 0, 0, 0, 150}; int want_bw = 0, no_bai = 0, split_records = 0; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
-    buf_t pool = {0, 0, 0}; size_t *offs = NULL; char fn[4096]; uint64_t ord = 0, npairs_total = 0, nbases = 0;
-    while((c = getopt_long(argc, argv, "o:L:c:l:s:z:", lo, NULL)) >= 0) {
-        switch(c) {
-        case 'o': prefix = optarg; break; case 'L': lens = optarg; break; case 'c': cov = atof(optarg); break;
-        case 'l': o.readlen = atoi(optarg); break; case 's': seed = strtoull(optarg, NULL, 0); break; case 'z': level = atoi(optarg); break;
-        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break; case 7: no_bai = 1; break; case 8: split_records = 1; break;
-        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [--bismark] [--extras] [--clean] [--bbm] [--bw] [--single] [--no-bai] [--split-records]\n"); return 1;
-        }
-    }
-    if(!prefix) { fprintf(stderr, "mdk_synth: -o PREFIX is required\n"); return 1; }
-    rg.s = seed ? seed : 1; rr.s = mix64(seed + 1) | 1;
-    { char *s = strdup(lens), *p = strtok(s, ","); while(p) { ct = realloc(ct, sizeof(*ct) * (nct + 1)); memset(&ct[nct], 0, sizeof(*ct)); ct[nct].len = atoll(p); asprintf(&ct[nct].name, nct ? "chrS%d" : "chrS1", nct + 1); nct++; p = strtok(NULL, ","); } free(s); }
-    snprintf(fn, sizeof(fn), "%s.fa", prefix);
-    { FILE *f = fopen(fn, "w"); if(!f) { perror(fn); return 1; }
-      for(t = 0; t < nct; t++) { int64_t j; make_contig(&ct[t], &rg); fprintf(f, ">%s synthetic seed=%" PRIu64 "\n", ct[t].name, seed); for(j = 0; j < ct[t].len; j += 60) { fwrite(ct[t].seq + j, 1, (ct[t].len - j) < 60 ? (ct[t].len - j) : 60, f); fputc('\n', f); } }
-      fclose(f); }
-
-    for(t = 0; t < nct; t++) {
-        int64_t L = ct[t].len; uint64_t npairs = (uint64_t)(L * cov / (2.0 * o.readlen)), pi;
-        if(L < 2 * o.readlen) continue;
-        for(pi = 0; pi < npairs; pi++) {
-            int flen = (int)(300 + 50 * rndn(&rr)), ob, mapq, nh, fl1, fl2, strand1, strand2, single = o.single; int64_t fs; cig_t c1, c2; char qn[64]; uint64_t fragkey;
+/* ---- pairs pi0 .. pi1-1 of contig t: records appended to the context's pool (one random stream: the order of the draws is the data) ---- */
+typedef struct { const contig_t *ct; const opts_t *o; uint64_t seed; rng_t rr; buf_t pool; size_t *offs; rec_t *recs; size_t nrec, mrec; uint64_t ord, npairs_total, nbases; } genctx;
+static void gen_pairs(genctx *G, int t, uint64_t pi0, uint64_t pi1) {
+    const int64_t L = G->ct[t].len; uint64_t pi;
+    for(pi = pi0; pi < pi1; pi++) {
+            int flen = (int)(300 + 50 * rndn(&G->rr)), ob, mapq, nh, fl1, fl2, strand1, strand2, single = G->o->single; int64_t fs; cig_t c1, c2; char qn[64]; uint64_t fragkey;
             int64_t p1, p2; double u; int extraflag = 0, discord = 0, singleton = 0;
-            if(flen < o.readlen) flen = o.readlen; if(flen > 4 * o.readlen) flen = 4 * o.readlen; if(flen > L) flen = (int)L;
-            fs = (int64_t)(rndu(&rr) * (L - flen + 1));
-            ob = rndu(&rr) < 0.5;
-            make_cigar(&c1, o.readlen, &rr, &o); make_cigar(&c2, o.readlen, &rr, &o);
+            if(flen < G->o->readlen) flen = G->o->readlen; if(flen > 4 * G->o->readlen) flen = 4 * G->o->readlen; if(flen > L) flen = (int)L;
+            fs = (int64_t)(rndu(&G->rr) * (L - flen + 1));
+            ob = rndu(&G->rr) < 0.5;
+            make_cigar(&c1, G->o->readlen, &G->rr, G->o); make_cigar(&c2, G->o->readlen, &G->rr, G->o);
             snprintf(qn, sizeof(qn), "f%d_%" PRIu64, t, pi);
-            fragkey = mix64(seed ^ ((uint64_t)t << 48) ^ pi);
-            mapq = 40 + rndi(&rr, 21); nh = 0; fl1 = 0; fl2 = 0;
-            if(!o.clean) {
-                if(rndu(&rr) < 0.02) mapq = rndi(&rr, 10);
-                u = rndu(&rr); if(u < 0.10) nh = 1; else if(u < 0.11) nh = 2;
-                u = rndu(&rr); if(u < 0.03) extraflag = 0x400; else if(u < 0.04) extraflag = 0x200;
-                if(rndu(&rr) < 0.01) discord = 1;
-                if(rndu(&rr) < 0.005) singleton = 1;
+            fragkey = mix64(G->seed ^ ((uint64_t)t << 48) ^ pi);
+            mapq = 40 + rndi(&G->rr, 21); nh = 0; fl1 = 0; fl2 = 0;
+            if(!G->o->clean) {
+                if(rndu(&G->rr) < 0.02) mapq = rndi(&G->rr, 10);
+                u = rndu(&G->rr); if(u < 0.10) nh = 1; else if(u < 0.11) nh = 2;
+                u = rndu(&G->rr); if(u < 0.03) extraflag = 0x400; else if(u < 0.04) extraflag = 0x200;
+                if(rndu(&G->rr) < 0.01) discord = 1;
+                if(rndu(&G->rr) < 0.005) singleton = 1;
             }
             /* left read at fs, right read ends at fs+flen */
             p1 = fs; p2 = fs + flen - c2.rspan; if(p2 < 0) p2 = 0; if(p2 + c2.rspan > L) p2 = L - c2.rspan; if(p1 + c1.rspan > L) p1 = L - c1.rspan;
             if(p2 < p1) p2 = p1;
             if(single) {
                 int rev = ob; strand1 = ob ? 2 : 1; fl1 = (rev ? 0x10 : 0) | extraflag;
-                if(o.bismark && rndu(&rr) < 0.1) { strand1 = ob ? 4 : 3; fl1 ^= 0x10; }
-                if(nrec + 1 > mrec) { mrec = mrec ? mrec * 2 : 1 << 16; offs = realloc(offs, mrec * sizeof(size_t)); recs = realloc(recs, mrec * sizeof(rec_t)); }
-                offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p1, &c1, fl1, mapq, -1, 0, qn, strand1, fragkey, &rr, &o, nh, -1);
-                recs[nrec].tid = t; recs[nrec].pos = (int32_t)p1; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++; nbases += c1.qlen; npairs_total++;
+                if(G->o->bismark && rndu(&G->rr) < 0.1) { strand1 = ob ? 4 : 3; fl1 ^= 0x10; }
+                if(G->nrec + 1 > G->mrec) { G->mrec = G->mrec ? G->mrec * 2 : 1 << 16; G->offs = realloc(G->offs, G->mrec * sizeof(size_t)); G->recs = realloc(G->recs, G->mrec * sizeof(rec_t)); }
+                G->offs[G->nrec] = G->pool.l; emit_read(&G->pool, &G->ct[t], t, p1, &c1, fl1, mapq, -1, 0, qn, strand1, fragkey, &G->rr, G->o, nh, -1);
+                G->recs[G->nrec].tid = t; G->recs[G->nrec].pos = (int32_t)p1; G->recs[G->nrec].ord = G->ord++; G->recs[G->nrec].n = (uint32_t)(G->pool.l - G->offs[G->nrec]); G->nrec++; G->nbases += c1.qlen; G->npairs_total++;
                 continue;
             }
             if(!ob) { fl1 = 0x1 | 0x2 | 0x20 | 0x40; fl2 = 0x1 | 0x2 | 0x10 | 0x80; strand1 = strand2 = 1; }       /* 99 / 147 */
             else { fl1 = 0x1 | 0x2 | 0x20 | 0x80; fl2 = 0x1 | 0x2 | 0x10 | 0x40; strand1 = strand2 = 2; }       /* 163 / 83 */
-            if(o.bismark && rndu(&rr) < 0.1) {      /* non-directional: CTOT / CTOB pairs (read#1/#2 roles swapped) */
+            if(G->o->bismark && rndu(&G->rr) < 0.1) {      /* non-directional: CTOT / CTOB pairs (read#1/#2 roles swapped) */
                 fl1 ^= 0xC0; fl2 ^= 0xC0; strand1 = strand2 = ob ? 4 : 3;
             }
             if(discord) { fl1 &= ~0x2; fl2 &= ~0x2; }
             fl1 |= extraflag; fl2 |= extraflag;
-            if(nrec + 4 > mrec) { mrec = mrec ? mrec * 2 : 1 << 16; offs = realloc(offs, mrec * sizeof(size_t)); recs = realloc(recs, mrec * sizeof(rec_t)); }
+            if(G->nrec + 4 > G->mrec) { G->mrec = G->mrec ? G->mrec * 2 : 1 << 16; G->offs = realloc(G->offs, G->mrec * sizeof(size_t)); G->recs = realloc(G->recs, G->mrec * sizeof(rec_t)); }
             if(singleton) {                          /* mate unmapped: keep only the left read */
                 fl1 = (fl1 | 0x8) & ~0x2 & ~0x20;
-                offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p1, &c1, fl1, mapq, (int32_t)p1, 0, qn, strand1, fragkey, &rr, &o, nh, t);
-                recs[nrec].tid = t; recs[nrec].pos = (int32_t)p1; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++; nbases += c1.qlen; npairs_total++;
+                G->offs[G->nrec] = G->pool.l; emit_read(&G->pool, &G->ct[t], t, p1, &c1, fl1, mapq, (int32_t)p1, 0, qn, strand1, fragkey, &G->rr, G->o, nh, t);
+                G->recs[G->nrec].tid = t; G->recs[G->nrec].pos = (int32_t)p1; G->recs[G->nrec].ord = G->ord++; G->recs[G->nrec].n = (uint32_t)(G->pool.l - G->offs[G->nrec]); G->nrec++; G->nbases += c1.qlen; G->npairs_total++;
                 continue;
             }
-            offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p1, &c1, fl1, mapq, (int32_t)p2, (int32_t)(p2 + c2.rspan - p1), qn, strand1, fragkey, &rr, &o, nh, t);
-            recs[nrec].tid = t; recs[nrec].pos = (int32_t)p1; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++;
-            offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p2, &c2, fl2, mapq, (int32_t)p1, -(int32_t)(p2 + c2.rspan - p1), qn, strand2, fragkey, &rr, &o, nh, t);
-            recs[nrec].tid = t; recs[nrec].pos = (int32_t)p2; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++;
-            nbases += c1.qlen + c2.qlen; npairs_total++;
-            if(o.extras && rndu(&rr) < 0.02) {       /* a secondary or supplementary record sharing the qname */
-                cig_t c3; int64_t p3; int f3 = fl1 | (rndu(&rr) < 0.5 ? 0x100 : 0x800);
-                make_cigar(&c3, o.readlen, &rr, &o); p3 = fs + rndi(&rr, flen); if(p3 + c3.rspan > L) p3 = L - c3.rspan; if(p3 < 0) p3 = 0;
-                offs[nrec] = pool.l; emit_read(&pool, &ct[t], t, p3, &c3, f3, mapq, (int32_t)p2, 0, qn, strand1, fragkey, &rr, &o, nh, t);
-                recs[nrec].tid = t; recs[nrec].pos = (int32_t)p3; recs[nrec].ord = ord++; recs[nrec].n = (uint32_t)(pool.l - offs[nrec]); nrec++;
+            G->offs[G->nrec] = G->pool.l; emit_read(&G->pool, &G->ct[t], t, p1, &c1, fl1, mapq, (int32_t)p2, (int32_t)(p2 + c2.rspan - p1), qn, strand1, fragkey, &G->rr, G->o, nh, t);
+            G->recs[G->nrec].tid = t; G->recs[G->nrec].pos = (int32_t)p1; G->recs[G->nrec].ord = G->ord++; G->recs[G->nrec].n = (uint32_t)(G->pool.l - G->offs[G->nrec]); G->nrec++;
+            G->offs[G->nrec] = G->pool.l; emit_read(&G->pool, &G->ct[t], t, p2, &c2, fl2, mapq, (int32_t)p1, -(int32_t)(p2 + c2.rspan - p1), qn, strand2, fragkey, &G->rr, G->o, nh, t);
+            G->recs[G->nrec].tid = t; G->recs[G->nrec].pos = (int32_t)p2; G->recs[G->nrec].ord = G->ord++; G->recs[G->nrec].n = (uint32_t)(G->pool.l - G->offs[G->nrec]); G->nrec++;
+            G->nbases += c1.qlen + c2.qlen; G->npairs_total++;
+            if(G->o->extras && rndu(&G->rr) < 0.02) {       /* a secondary or supplementary record sharing the qname */
+                cig_t c3; int64_t p3; int f3 = fl1 | (rndu(&G->rr) < 0.5 ? 0x100 : 0x800);
+                make_cigar(&c3, G->o->readlen, &G->rr, G->o); p3 = fs + rndi(&G->rr, flen); if(p3 + c3.rspan > L) p3 = L - c3.rspan; if(p3 < 0) p3 = 0;
+                G->offs[G->nrec] = G->pool.l; emit_read(&G->pool, &G->ct[t], t, p3, &c3, f3, mapq, (int32_t)p2, 0, qn, strand1, fragkey, &G->rr, G->o, nh, t);
+                G->recs[G->nrec].tid = t; G->recs[G->nrec].pos = (int32_t)p3; G->recs[G->nrec].ord = G->ord++; G->recs[G->nrec].n = (uint32_t)(G->pool.l - G->offs[G->nrec]); G->nrec++;
             }
+            }
+}
+
+
+/* ---- -j N: the same kind of data made by N threads (contigs' bases per contig, reads in blocks of pairs with a random stream each, sorting, BGZF members and
+ * the index per contig, compression and the file's writing by all) -- for inputs of human size in a bench's time.  The data differ from what the serial
+ * path makes of the same seed (other random streams) and are as reproducible: a (seed, args, -j) ... the number of threads does not enter the streams. ---- */
+#define PAR_BLOCK 200000u            /* pairs per unit of work */
+typedef struct { int t; uint64_t pi0, pi1; genctx G; } par_unit;
+typedef struct { bgzf_t z; rec_t *recs; size_t nrec; size_t *rm, *em; uint32_t *rw, *ew; uint64_t **lin_; uint64_t *lin, first, last; size_t nlin; uint64_t fpos0, fpos1; uint64_t nbases, npairs; } par_contig;
+typedef struct { contig_t *ct; int nct; const opts_t *o; uint64_t seed; double cov; int split_records;
+                 par_unit *unit; size_t n_unit; size_t next; pthread_mutex_t mu; par_contig *pc; int phase; member_t **mem; size_t n_mem; int level; int fd; } par_ctx;
+static size_t par_take(par_ctx *P, size_t n) { size_t i; pthread_mutex_lock(&P->mu); i = P->next++; pthread_mutex_unlock(&P->mu); return i < n ? i : (size_t)-1; }
+static void par_cut_contig(par_ctx *P, int t) {          /* gather, sort, cut into members (a contig starts a member of its own), note where every record lies */
+    par_contig *c = &P->pc[t]; size_t u, n = 0, i; bgzf_t *z = &c->z;
+    for(u = 0; u < P->n_unit; u++) if(P->unit[u].t == t) n += P->unit[u].G.nrec;
+    c->recs = malloc((n + 1) * sizeof(rec_t)); c->nrec = 0;
+    for(u = 0; u < P->n_unit; u++) if(P->unit[u].t == t) { genctx *G = &P->unit[u].G; for(i = 0; i < G->nrec; i++) { rec_t r = G->recs[i]; r.d = G->pool.p + G->offs[i]; r.ord = ((uint64_t)u << 32) | i; c->recs[c->nrec++] = r; } c->nbases += G->nbases; c->npairs += G->npairs_total; free(G->recs); free(G->offs); G->recs = NULL; G->offs = NULL; }
+    qsort(c->recs, c->nrec, sizeof(rec_t), rec_cmp);
+    c->rm = malloc((c->nrec + 1) * sizeof(size_t)); c->em = malloc((c->nrec + 1) * sizeof(size_t)); c->rw = malloc((c->nrec + 1) * 4); c->ew = malloc((c->nrec + 1) * 4);
+    for(i = 0; i < c->nrec; i++) {
+        if(z->n + 4 > (int)sizeof(z->blk)) bgzf_flush(z);
+        if(!P->split_records && z->n && c->recs[i].n <= sizeof(z->blk) && z->n + c->recs[i].n > sizeof(z->blk)) bgzf_flush(z);
+        c->rm[i] = z->nm; c->rw[i] = (uint32_t)z->n;
+        bgzf_write(z, c->recs[i].d, c->recs[i].n);
+        c->em[i] = z->nm; c->ew[i] = (uint32_t)z->n;
+    }
+    bgzf_flush(z);
+}
+static void par_index_contig(par_ctx *P, int t) {        /* the BAI entries of a contig, once its members' places in the file are known */
+    par_contig *c = &P->pc[t]; size_t i; const int64_t len = P->ct[t].len;
+    c->nlin = (size_t)((len >> 14) + 1); c->lin = calloc(c->nlin, 8);
+    for(i = 0; i < c->nrec; i++) {
+        const uint64_t vo = bgzf_voffset(&c->z, c->fpos1, c->rm[i], c->rw[i]); const int32_t pos = c->recs[i].pos; int64_t w, w1; uint32_t ncig, k, rl = 0; const uint8_t *r = c->recs[i].d + 4;
+        ncig = r[12] | (r[13] << 8);
+        for(k = 0; k < ncig; k++) { const uint8_t *cg = r + 32 + r[8] + 4 * k; uint32_t cv = cg[0] | (cg[1] << 8) | (cg[2] << 16) | ((uint32_t)cg[3] << 24), op = cv & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += cv >> 4; }
+        w1 = ((int64_t)pos + (rl ? rl : 1) - 1) >> 14;
+        for(w = pos >> 14; w <= w1 && w < (int64_t)c->nlin; w++) if(!c->lin[w]) c->lin[w] = vo;
+        if(!c->first) c->first = vo;
+    }
+    free(c->rm); free(c->em); free(c->rw); free(c->ew); free(c->recs);
+}
+static void par_compress(member_t *m, int level, bump_t *mine) {
+    static __thread uint8_t out[70000 + 64]; z_stream zs; uint32_t crc; int clen; uint8_t hdr[18] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0, 0};
+    memset(&zs, 0, sizeof(zs)); deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    zs.next_in = m->raw; zs.avail_in = m->n; zs.next_out = out + 18; zs.avail_out = 70000;
+    deflate(&zs, Z_FINISH); clen = (int)zs.total_out; deflateEnd(&zs);
+    crc = crc32(crc32(0, NULL, 0), m->raw, m->n);
+    { int bsize = clen + 25; hdr[16] = bsize & 0xff; hdr[17] = bsize >> 8; }
+    memcpy(out, hdr, 18);
+    { uint8_t tr[8] = {crc, crc >> 8, crc >> 16, crc >> 24, (uint8_t)m->n, (uint8_t)(m->n >> 8), (uint8_t)(m->n >> 16), (uint8_t)(m->n >> 24)}; memcpy(out + 18 + clen, tr, 8); }
+    m->clen = (uint32_t)(18 + clen + 8); m->comp = bump(mine, m->clen); memcpy(m->comp, out, m->clen); m->raw = NULL;
+}
+static void *par_worker(void *arg) {
+    par_ctx *P = arg; size_t i; bump_t mine = {NULL, 0};
+    if(P->phase == 0) { while((i = par_take(P, (size_t)P->nct)) != (size_t)-1) { rng_t rg; rg.s = mix64(P->seed * 0x9E3779B97F4A7C15ULL + 0x1000 + i) | 1; make_contig(&P->ct[i], &rg); } }
+    else if(P->phase == 1) { while((i = par_take(P, P->n_unit)) != (size_t)-1) { par_unit *u = &P->unit[i]; u->G.ct = P->ct; u->G.o = P->o; u->G.seed = P->seed; u->G.rr.s = mix64(P->seed ^ ((uint64_t)(u->t + 1) << 40) ^ (u->pi0 * 0x9E3779B97F4A7C15ULL)) | 1; gen_pairs(&u->G, u->t, u->pi0, u->pi1); } }
+    else if(P->phase == 2) { while((i = par_take(P, (size_t)P->nct)) != (size_t)-1) par_cut_contig(P, (int)i); }
+    else if(P->phase == 3) { while((i = par_take(P, (P->n_mem + 63) / 64)) != (size_t)-1) { size_t k; for(k = 64 * i; k < 64 * i + 64 && k < P->n_mem; k++) par_compress(P->mem[k], P->level, &mine); } }
+    else if(P->phase == 4) { while((i = par_take(P, (P->n_mem + 255) / 256)) != (size_t)-1) { size_t k; for(k = 256 * i; k < 256 * i + 256 && k < P->n_mem; k++) { member_t *m = P->mem[k]; size_t done = 0; while(done < m->clen) { ssize_t w = pwrite(P->fd, m->comp + done, m->clen - done, (off_t)(m->fpos + done)); if(w <= 0) { perror("pwrite"); exit(1); } done += (size_t)w; } } } }
+    else if(P->phase == 5) { while((i = par_take(P, (size_t)P->nct)) != (size_t)-1) par_index_contig(P, (int)i); }
+    return NULL;
+}
+static void par_run(par_ctx *P, int phase, int nt) {
+    pthread_t th[256]; int k, made = 0;
+    P->phase = phase; P->next = 0;
+    for(k = 0; k < nt - 1 && k < 255; k++) { if(pthread_create(&th[made], NULL, par_worker, P)) break; made++; }
+    par_worker(P);
+    for(k = 0; k < made; k++) pthread_join(th[k], NULL);
+}
+int main(int argc, char **argv) {
+    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {"no-bai", 0, 0, 7}, {"split-records", 0, 0, 8}, {0, 0, 0, 0}};
+    const char *prefix = NULL, *lens = "1000000"; double cov = 30; uint64_t seed = 0x5EED0001ULL; int level = 1, c, want_bbm = 0;
+    opts_t o = {0, 0, 0, 0, 150}; int want_bw = 0, no_bai = 0, split_records = 0, par = 0; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
+    buf_t pool = {0, 0, 0}; size_t *offs = NULL; char fn[4096]; uint64_t ord = 0, npairs_total = 0, nbases = 0;
+    while((c = getopt_long(argc, argv, "o:L:c:l:s:z:j:", lo, NULL)) >= 0) {
+        switch(c) {
+        case 'o': prefix = optarg; break; case 'L': lens = optarg; break; case 'c': cov = atof(optarg); break;
+        case 'l': o.readlen = atoi(optarg); break; case 's': seed = strtoull(optarg, NULL, 0); break; case 'z': level = atoi(optarg); break; case 'j': par = atoi(optarg); break;
+        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break; case 7: no_bai = 1; break; case 8: split_records = 1; break;
+        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [-j threads] [--bismark] [--extras] [--clean] [--bbm] [--bw] [--single] [--no-bai] [--split-records]\n"); return 1;
         }
     }
+    if(!prefix) { fprintf(stderr, "mdk_synth: -o PREFIX is required\n"); return 1; }
+    rg.s = seed ? seed : 1; rr.s = mix64(seed + 1) | 1;
+    { char *s = strdup(lens), *p = strtok(s, ","); while(p) { ct = realloc(ct, sizeof(*ct) * (nct + 1)); memset(&ct[nct], 0, sizeof(*ct)); ct[nct].len = atoll(p); asprintf(&ct[nct].name, nct ? "chrS%d" : "chrS1", nct + 1); nct++; p = strtok(NULL, ","); } free(s); }
+    if(par > 0) {
+        par_ctx P; size_t u = 0, k; uint64_t fpos = 0; bgzf_t zh; buf_t h = {0, 0, 0}; char *txt = malloc(65536 + 64 * (size_t)nct); int n = 0; FILE *f;
+        static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if(par > 256) par = 256;
+        memset(&P, 0, sizeof(P)); P.ct = ct; P.nct = nct; P.o = &o; P.seed = seed; P.cov = cov; P.split_records = split_records; P.level = level; pthread_mutex_init(&P.mu, NULL);
+        par_run(&P, 0, par);                                                          /* the contigs' bases */
+        snprintf(fn, sizeof(fn), "%s.fa", prefix); f = fopen(fn, "w"); if(!f) { perror(fn); return 1; }
+        for(t = 0; t < nct; t++) { int64_t j; char *lines = malloc((size_t)ct[t].len + (size_t)ct[t].len / 60 + 2), *q = lines; fprintf(f, ">%s synthetic seed=%" PRIu64 "\n", ct[t].name, seed);
+            for(j = 0; j < ct[t].len; j += 60) { const size_t w = (size_t)((ct[t].len - j) < 60 ? (ct[t].len - j) : 60); memcpy(q, ct[t].seq + j, w); q += w; *q++ = '\n'; }
+            fwrite(lines, 1, (size_t)(q - lines), f); free(lines); }
+        fclose(f);
+        for(t = 0; t < nct; t++) { const uint64_t np = ct[t].len < 2 * o.readlen ? 0 : (uint64_t)(ct[t].len * cov / (2.0 * o.readlen)); P.n_unit += (size_t)((np + PAR_BLOCK - 1) / PAR_BLOCK); }
+        P.unit = calloc(P.n_unit + 1, sizeof(par_unit));
+        for(t = 0; t < nct; t++) { const uint64_t np = ct[t].len < 2 * o.readlen ? 0 : (uint64_t)(ct[t].len * cov / (2.0 * o.readlen)); uint64_t a; for(a = 0; a < np; a += PAR_BLOCK) { P.unit[u].t = t; P.unit[u].pi0 = a; P.unit[u].pi1 = a + PAR_BLOCK < np ? a + PAR_BLOCK : np; u++; } }
+        par_run(&P, 1, par);                                                          /* the reads */
+        P.pc = calloc((size_t)nct + 1, sizeof(par_contig));
+        par_run(&P, 2, par);                                                          /* per contig: sorted, cut into members */
+        memset(&zh, 0, sizeof(zh));                                                   /* the header's members */
+        n += snprintf(txt + n, 65536, "@HD\tVN:1.6\tSO:coordinate\n");
+        for(t = 0; t < nct; t++) n += snprintf(txt + n, 64, "@SQ\tSN:%s\tLN:%" PRId64 "\n", ct[t].name, ct[t].len);
+        n += snprintf(txt + n, 256, "@PG\tID:mdk_synth\tPN:mdk_synth\tCL:seed=%" PRIu64 " -j\n", seed);
+        bput(&h, "BAM\1", 4); b32(&h, (uint32_t)n); bput(&h, txt, (size_t)n); b32(&h, (uint32_t)nct);
+        for(t = 0; t < nct; t++) { b32(&h, (uint32_t)strlen(ct[t].name) + 1); bput(&h, ct[t].name, strlen(ct[t].name) + 1); b32(&h, (uint32_t)ct[t].len); }
+        bgzf_write(&zh, h.p, h.l); bgzf_flush(&zh);
+        P.n_mem = zh.nm; for(t = 0; t < nct; t++) P.n_mem += P.pc[t].z.nm;
+        P.mem = malloc((P.n_mem + 1) * sizeof(member_t *)); k = 0;
+        { size_t i; for(i = 0; i < zh.nm; i++) P.mem[k++] = &zh.m[i]; for(t = 0; t < nct; t++) for(i = 0; i < P.pc[t].z.nm; i++) P.mem[k++] = &P.pc[t].z.m[i]; }
+        par_run(&P, 3, par);                                                          /* compressed */
+        { size_t i; for(i = 0; i < zh.nm; i++) { zh.m[i].fpos = fpos; fpos += zh.m[i].clen; } for(t = 0; t < nct; t++) { P.pc[t].fpos0 = fpos; for(i = 0; i < P.pc[t].z.nm; i++) { P.pc[t].z.m[i].fpos = fpos; fpos += P.pc[t].z.m[i].clen; } P.pc[t].fpos1 = fpos; } }
+        snprintf(fn, sizeof(fn), "%s.bam", prefix); f = fopen(fn, "wb"); if(!f) { perror(fn); return 1; }
+        P.fd = fileno(f); if(ftruncate(P.fd, (off_t)(fpos + 28)) != 0) { perror("ftruncate"); return 1; }
+        par_run(&P, 4, par);                                                          /* written */
+        if(pwrite(P.fd, eof, 28, (off_t)fpos) != 28) { perror("pwrite"); return 1; }
+        fclose(f);
+        par_run(&P, 5, par);                                                          /* indexed */
+        for(t = 0; t < nct; t++) { nrec += P.pc[t].nrec; npairs_total += P.pc[t].npairs; nbases += P.pc[t].nbases; if(P.pc[t].first) P.pc[t].last = fpos << 16; }
+        if(!no_bai) {
+            buf_t x = {0, 0, 0}; FILE *bf;
+            bput(&x, "BAI\1", 4); b32(&x, (uint32_t)nct);
+            for(t = 0; t < nct; t++) {
+                par_contig *c = &P.pc[t]; size_t w; uint64_t prev = 0;
+                if(c->first) { b32(&x, 1); b32(&x, 0); b32(&x, 1); bput(&x, &c->first, 8); bput(&x, &c->last, 8); } else b32(&x, 0);
+                for(w = 0; w < c->nlin; w++) { if(c->lin[w]) prev = c->lin[w]; else c->lin[w] = prev; }
+                { size_t nn = c->nlin; while(nn && !c->lin[nn - 1]) nn--; b32(&x, (uint32_t)nn); bput(&x, c->lin, 8 * nn); }
+            }
+            snprintf(fn, sizeof(fn), "%s.bam.bai", prefix); bf = fopen(fn, "wb"); if(!bf) { perror(fn); return 1; }
+            fwrite(x.p, 1, x.l, bf); fclose(bf); free(x.p);
+        }
+        goto tracks;
+    }
+    snprintf(fn, sizeof(fn), "%s.fa", prefix);
+    { FILE *f = fopen(fn, "w"); if(!f) { perror(fn); return 1; }
+      for(t = 0; t < nct; t++) { int64_t j; make_contig(&ct[t], &rg); fprintf(f, ">%s synthetic seed=%" PRIu64 "\n", ct[t].name, seed); for(j = 0; j < ct[t].len; j += 60) { fwrite(ct[t].seq + j, 1, (ct[t].len - j) < 60 ? (ct[t].len - j) : 60, f); fputc('\n', f); } }
+      fclose(f); }
+
+    { genctx G; memset(&G, 0, sizeof(G)); G.ct = ct; G.o = &o; G.seed = seed; G.rr = rr;
+      for(t = 0; t < nct; t++) { const int64_t L = ct[t].len; const uint64_t npairs = (uint64_t)(L * cov / (2.0 * o.readlen)); if(L < 2 * o.readlen) continue; gen_pairs(&G, t, 0, npairs); }
+      pool = G.pool; offs = G.offs; recs = G.recs; nrec = G.nrec; mrec = G.mrec; ord = G.ord; npairs_total = G.npairs_total; nbases = G.nbases; rr = G.rr; }
     if(getenv("MDK_SYNTH_PROFILE")) fprintf(stderr, "[synth] reads generated at %.2f s\n", clock() / (double)CLOCKS_PER_SEC);
     for(i = 0; i < nrec; i++) recs[i].d = pool.p + offs[i];
     qsort(recs, nrec, sizeof(rec_t), rec_cmp);
@@ -345,6 +467,7 @@ int main(int argc, char **argv) {
       }
       free(z.m); free(h.p); }
 
+tracks:
     if(want_bbm || want_bw) {     /* synthetic mappability track: values {0, 0.5, 1.0}; written as BBM and/or bigWig (same values) */
         typedef struct { int64_t beg, end; uint8_t val; } mrun; mrun **runs = calloc(nct, sizeof(mrun *)); size_t *nr = calloc(nct, sizeof(size_t));
         for(t = 0; t < nct; t++) {
