@@ -74,6 +74,309 @@ def median_run(fn, runs=3):
     return statistics.median(ts), ts
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The CPU baseline and the end-to-end legs (rank 0 of an N = 1 run).  Every leg has a price in seconds; a leg the run's time budget
+# (--budget-s) no longer holds is left out and named in "legs_skipped" -- the line itself must always come out.
+# ------------------------------------------------------------------------------------------------------------------------------------
+HUMAN_LADDER = [248, 242, 198, 190, 181, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]      # hg38's chr1..22, X, Y in Mb
+
+
+def _wait_gone(limit=8.0):
+    t_end = time.time() + limit
+    while time.time() < t_end:
+        alive = False
+        for pid in os.listdir("/proc"):
+            if not pid.isdigit() or int(pid) == os.getpid():
+                continue
+            try:      # (by name, not by command line: a process that is taking its address space down has none any more)
+                if open(f"/proc/{pid}/comm").read().strip() == "MethylDackel" and open(f"/proc/{pid}/stat").read().rsplit(") ", 1)[1][0] != "Z":
+                    alive = True; break
+            except OSError:
+                pass
+        if not alive:
+            return
+        time.sleep(0.02)
+
+
+def _calls_of(d, name="out_CpG.bedGraph"):
+    n = 0
+    for line in open(Path(d) / name):
+        f = line.split("\t")
+        if len(f) == 6:
+            n += int(f[4]) + int(f[5])
+    return n
+
+
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+class Legs:
+    def __init__(self, args, result, data, work, extra, t_start, mdk):
+        self.args, self.result, self.data, self.work, self.extra, self.t_start, self.mdk = args, result, Path(data), Path(work), extra, t_start, mdk
+        self.oracle = REPO / "oracle/_build/mdk_oracle"
+        self.ncores = os.cpu_count() or 1
+        self.threads = str(min(64, self.ncores))
+        self.skipped = []; self.slow_runs = []; self.n = 0
+
+    def left(self):
+        return self.args.budget_s - (time.time() - self.t_start)
+
+    def fits(self, name, price):
+        if self.left() >= price:
+            return True
+        self.skipped.append({"leg": name, "needs_s": price, "left_s": round(self.left(), 1)})
+        log(f"[bench] leg {name} left out: needs ~{price:.0f} s, {self.left():.0f} s of the budget left")
+        return False
+
+    def synth(self, prefix, lens, cov, seed, par=0, more=()):
+        if not Path(str(prefix) + ".bam.bai").exists():
+            t1 = time.time()
+            subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(prefix), "-L", lens, "-c", str(cov), "-s", str(seed)] + (["-j", str(par)] if par else []) + list(more) + self.args.synth_args.split(),
+                           capture_output=True, text=True, check=True)
+            log(f"[bench] sample {Path(prefix).name} written in {time.time() - t1:.1f} s")
+        return prefix
+
+    def run_oracle(self, sp, name, thr, ck, runs, opts=(), timeout=1800):
+        """-> (median seconds, runs, directory, phases of the last run)"""
+        self.n += 1
+        d = self.work / f"co_{self.n}_{name}"; d.mkdir()
+        o = ["-@", str(thr)] + (["--chunkSize", str(ck)] if ck else [])
+        ts = []; phases = {}
+        for _ in range(runs):
+            t1 = time.perf_counter()
+            r = subprocess.run([str(self.oracle), "extract", str(sp) + ".fa", str(sp) + ".bam"] + o + list(opts) + self.extra + ["-o", "out"], check=True, capture_output=True, text=True, cwd=d, timeout=timeout,
+                               env=dict(os.environ, MDK_ORACLE_PROFILE="1"))
+            ts.append(time.perf_counter() - t1)
+            phases = {}
+            for line in r.stderr.splitlines():
+                m = re.match(r"\[oracle\] (.+?)\s+([0-9.]+) s(\s+\(one thread\))?$", line)
+                if m:
+                    phases[m.group(1).strip()] = {"seconds": float(m.group(2)), "serial": bool(m.group(3))}
+                m = re.match(r"\[oracle\] serial phases ([0-9.]+) s of ([0-9.]+) s", line)
+                if m:
+                    phases["_serial_fraction"] = float(m.group(1)) / max(float(m.group(2)), 1e-9)
+        log(f"[bench] oracle {name}: {[round(t, 3) for t in ts]}")
+        return statistics.median(ts), ts, d, phases
+
+    def run_ours(self, sp, name, env=None, runs=3, gap=1.0, opts=(), ranks=None, timeout=600):
+        """-> (median seconds, runs, directory, all ok, the command's own clock per run)"""
+        self.n += 1
+        d = self.work / f"cg_{self.n}_{name}"; d.mkdir(); rcs = []; ts = []; inner = []; profs = []
+        for _ in range(runs):
+            # (outside the clock) runs are measured in isolation: the next one starts a second after the previous command's last process has gone
+            # (the driver goes on releasing a process's GPU state for a while; gap = 0: a queue of samples, back to back)
+            if gap > 0:
+                _wait_gone(); time.sleep(gap)
+            t1 = time.perf_counter()
+            r = self.mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", self.threads] + list(opts) + self.extra + ["-o", "out"], cwd=d, env=dict(env or {}, MDK_HOST_PROFILE="1"), timeout=timeout, ranks=ranks)
+            ts.append(time.perf_counter() - t1); rcs.append(r.returncode)
+            m = re.search(r"total ([0-9.]+)s; chunks prepared", r.stderr)          # the command's own clock, entry of extract_main to outputs closed
+            inner.append(float(m.group(1)) if m else None)
+            profs.append([l[:400] for l in r.stderr.splitlines() if l.startswith("[mdk")])
+        log(f"[bench] {name}: wall {[round(t, 3) for t in ts]} inside the process {inner}")
+        med = statistics.median(ts)
+        for k, t in enumerate(ts):          # a run far off the others is kept with its own account of where the time went, not just as a number
+            if t > 1.6 * med and t - med > 0.3:
+                self.slow_runs.append({"leg": name, "run": k, "seconds": t, "median": med, "profile": profs[k]})
+        return med, ts, d, all(r == 0 for r in rcs), inner
+
+    @staticmethod
+    def same(d1, d2):
+        fs = sorted(os.listdir(d2))
+        return bool(fs) and all((Path(d1) / f).exists() and (Path(d1) / f).read_bytes() == (Path(d2) / f).read_bytes() for f in fs)
+
+    def cpu_setting_sweep(self, sp, tag, settings, runs_best):
+        """one run per setting, then `runs_best` runs at the fastest -> (median, runs, directory, phases, setting, sweep)"""
+        sweep = []
+        for thr, ck in settings:
+            if thr > self.ncores:
+                continue
+            t1, _, _, _ = self.run_oracle(sp, f"{tag}_sweep_{thr}_{ck}", thr, ck, 1)
+            sweep.append({"threads": thr, "chunk_size": ck, "seconds": t1})
+        best = min(sweep, key=lambda q: q["seconds"])
+        t, ts, d, ph = self.run_oracle(sp, f"{tag}_best", best["threads"], best["chunk_size"], runs_best)
+        ts = ts + [best["seconds"]]
+        return statistics.median(ts), ts, d, ph, {"threads": best["threads"], "chunk_size": best["chunk_size"]}, sweep
+
+    def e2e(self, key, sp, cpu_cfg, note, opts=(), oracle_opts=None, runs=3, cpu_runs=1, extras=None, detached_runs=0, queue_runs=0, price=0.0, out_name="out_CpG.bedGraph"):
+        """one end-to-end comparison: the oracle at cpu_cfg, this build `runs` times (in place); identical outputs asserted into the entry"""
+        t_c, ts_c, d_c, ph = self.run_oracle(sp, key + "_cpu", cpu_cfg["threads"], cpu_cfg["chunk_size"], cpu_runs, opts=oracle_opts if oracle_opts is not None else opts)
+        t_g, ts_g, d_g, ok_g, in_g = self.run_ours(sp, key + "_inplace", {}, runs=runs, opts=opts)
+        calls = _calls_of(d_c, out_name); bam = os.path.getsize(str(sp) + ".bam")
+        e = {"bam_bytes": bam, "calls": calls, "calls_counted_in": out_name, "cpu_all_cores_seconds": t_c, "cpu_runs": ts_c, "cpu_setting": cpu_cfg, "cpu_phases": ph, "cpu_serial_fraction": ph.get("_serial_fraction"),
+             "seconds": t_g, "runs": ts_g, "value": calls / t_g, "unit": "CpG calls/s" if out_name.endswith("CpG.bedGraph") else "calls/s", "speedup_vs_cpu_all_cores": t_c / t_g, "identical_to_oracle": bool(ok_g and self.same(d_g, d_c)),
+             "inside_process_runs": in_g, "bam_GBps": bam / t_g / 1e9, "options": list(opts), "note": note,
+             "protocol": f"CPU: {cpu_runs} run(s) at the setting named, MDK_ORACLE_PROFILE phases of the last; this build: {runs} runs, median; the caller's wall clock around the command, teardown in place, each run a second after the previous command's last process has gone"}
+        if detached_runs:
+            t_d, ts_d, _, ok_d, _ = self.run_ours(sp, key + "_detached", {"MDK_DETACH": "1"}, runs=detached_runs, opts=opts)
+            e["detached"] = {"seconds": t_d, "runs": ts_d, "speedup_vs_cpu_all_cores": t_c / t_d, "ok": bool(ok_d), "note": "MDK_DETACH=1 (opt-in): the work is done by a child, the command returns when the child reports its outputs closed"}
+        if queue_runs:
+            t_q, ts_q, _, ok_q, _ = self.run_ours(sp, key + "_queue", {}, runs=queue_runs, gap=0.0, opts=opts)
+            e["queue"] = {"seconds_per_sample": t_q, "runs": ts_q, "speedup_vs_cpu_all_cores": t_c / t_q, "ok": bool(ok_q), "note": "runs back to back with no pause, teardown in place: what a queue of samples gets per sample"}
+        if extras:
+            e.update(extras)
+        self.result[key] = e
+        return e, d_c
+
+
+def e2e_legs(args, result, data, work, extra, headline, t_start, mdk):
+    G = Legs(args, result, data, work, extra, t_start, mdk)
+    cov = args.coverage
+    # ---- cpu_baseline + e2e_cli on the 32 Mb sample ----
+    sp = G.synth(G.data / f"cpu_sample_{args.cpu_sample_length}_{cov}", str(args.cpu_sample_length), cov, S1_SEED + 1000)
+    t_single, ts_single, d_single, ph_single = G.run_oracle(sp, "single", 1, None, 1)
+    t_all, ts_all, d_all, ph_all, best, sweep = G.cpu_setting_sweep(sp, "small", ((32, 250_000), (64, 50_000), (64, 250_000), (128, 1_000_000), (G.ncores, max(50_000, args.cpu_sample_length // (4 * G.ncores)))), 2)
+    calls = _calls_of(d_single)
+    result["cpu_baseline"] = {"value": calls / t_all, "unit": "CpG calls/s", "cores": best["threads"], "kind": "port",
+                              "sample": f"oracle/mdk_oracle extract -@ {best['threads']} --chunkSize {best['chunk_size']} -- the fastest of a sweep over worker threads x chunk size on this box's {G.ncores} hardware threads "
+                                        f"(C restatement of the reference with its chunk-parallel worker threads, extract.c:325-350,1479-1486; end to end from the BAM file: the file mapped, inflate with CRC32 check by all threads, pileup, text) "
+                                        f"on a {args.cpu_sample_length} bp / {cov}x sample of the same synthetic workload; median of 3 runs {t_all:.2f} s, {calls} CpG calls; the reference binary itself cannot be built here (no htslib)",
+                              "seconds": t_all, "runs": ts_all, "cpg_calls": calls, "identical_to_single_thread": G.same(d_all, d_single), "host_threads": G.ncores, "sweep": sweep,
+                              "phases": ph_all, "serial_fraction": ph_all.get("_serial_fraction"),
+                              "single_thread": {"value": calls / t_single, "seconds": t_single, "runs": ts_single, "cores": 1, "phases": ph_single}}
+    t_g, ts_g, d_g, ok_g, in_g = G.run_ours(sp, "inplace", {})
+    t_gd, ts_gd, _, ok_gd, _ = G.run_ours(sp, "detached", {"MDK_DETACH": "1"}, runs=2)
+    result["e2e_cli"] = {"seconds": t_g, "runs": ts_g, "value": calls / t_g, "unit": "CpG calls/s", "threads": int(G.threads), "protocol": "3 runs, median, whole-process wall clock with the teardown in place (the CPU baseline's protocol)",
+                         "speedup_vs_cpu_baseline": t_all / t_g, "speedup_vs_single_thread": t_single / t_g, "identical_to_oracle": bool(ok_g and ok_gd and G.same(d_g, d_single)),
+                         "inside_process_runs": in_g, "bam_bytes": os.path.getsize(str(sp) + ".bam"),
+                         "detached": {"seconds": t_gd, "runs": ts_gd, "speedup_vs_cpu_baseline": t_all / t_gd, "note": "MDK_DETACH=1 (opt-in): the command's work is done by a child, the command returns when the child reports its outputs closed"},
+                         "note": "`MethylDackel extract` of this build on the same file, one process (start-up, HIP init, inflate on the host's threads and -- once the device is up -- on the device, chunk preparation, kernels, D2H, text, teardown)"}
+    # ---- the device inflate on the record ----
+    try:
+        pb = subprocess.run([str(REPO / "tools/_build/piece_bench"), str(sp) + ".bam", "96", "8", "0"], capture_output=True, text=True, timeout=300)
+        pj = json.loads(pb.stdout); kv = pj["kernel_only"]["v0"]; inf_bytes = kv["comp_bytes"] + kv["out_bytes"]
+        result["inflate"] = {"workload": f"the {args.cpu_sample_length} bp sample's BAM: {pj['members']} BGZF members, {pj['file_MB']:.0f} MB -> {pj['inflated_MB']:.0f} MB",
+                             "pipelined": {"GBps_compressed": pj["pass1"]["GBps_compressed"], "GBps_inflated": pj["pass1"]["GBps_inflated"], "seconds": pj["pass1"]["seconds"],
+                                           "note": "whole file through md_piece_submit / md_piece_wait: staging copy, H2D of the compressed bytes, k_inflate, k_crc32, k_walk, digests back; 96 MB pieces, 8 in flight (what the command keeps)"},
+                             "GBps_compressed": kv["GBps_compressed"], "GBps_inflated": kv["GBps_inflated"],
+                             "roofline": {"kernel": "k_inflate", "bound": "hbm", "kernel_ms": kv["inflate_ms"], "algo_bytes_per_launch": inf_bytes, "achieved": inf_bytes / (kv["inflate_ms"] * 1e6), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": inf_bytes / (kv["inflate_ms"] * 1e6) / HBM_PEAK_GBS, "members_per_launch": pj["kernel_only"]["piece_members"],
+                                          "note": "algorithmic bytes = compressed bytes read + inflated bytes written, one 96 MB piece per launch; the kernel is bound by instruction issue and LDS round trips of its chains and pointer jumps, not by HBM (DESIGN.md 4)"},
+                             "crc32_ms": kv["crc32_ms"], "walk_ms": kv["walk_ms"], "crc32_GBps": kv["out_bytes"] / (kv["crc32_ms"] * 1e6) if kv["crc32_ms"] > 0 else None}
+        pw = subprocess.run([str(REPO / "tools/_build/piece_bench"), str(sp) + ".bam", "4000", "1", "0"], capture_output=True, text=True, timeout=300)
+        kw = json.loads(pw.stdout)["kernel_only"]["v0"]
+        result["inflate"]["device_full"] = {"members_per_launch": json.loads(pw.stdout)["kernel_only"]["piece_members"], "kernel_ms": kw["inflate_ms"], "GBps_compressed": kw["GBps_compressed"], "GBps_inflated": kw["GBps_inflated"],
+                                            "crc32_ms": kw["crc32_ms"], "walk_ms": kw["walk_ms"], "identical_to_zlib": kw.get("identical_to_zlib"),
+                                            "note": "k_inflate over all members of the file in one launch; HIP events"}
+    except Exception as ex:
+        result["inflate"] = {"error": repr(ex)[:300]}
+    if not (args.large_sample_length and headline):
+        return
+    # ---- 128 Mb: the CPU's best setting at this size, the command in place / detached / as a queue ----
+    spl = G.synth(G.data / f"cpu_sample_{args.large_sample_length}_{cov}", str(args.large_sample_length), cov, S1_SEED + 1000)
+    alt = (64, 250_000) if best["threads"] == 32 else (32, 250_000)
+    t_la, ts_la, d_la, ph_la, cfg_l, sweep_l = G.cpu_setting_sweep(spl, "large", ((best["threads"], best["chunk_size"]), alt, (64, 1_000_000)), 1)
+    t_lg, ts_lg, d_lg, ok_lg, in_lg = G.run_ours(spl, "large_inplace", {}, runs=5)
+    t_ld, ts_ld, _, ok_ld, _ = G.run_ours(spl, "large_detached", {"MDK_DETACH": "1"}, runs=2)
+    t_lq, ts_lq, _, ok_lq, _ = G.run_ours(spl, "large_queue", {}, runs=3, gap=0.0)
+    calls_l = _calls_of(d_la); bam_l = os.path.getsize(str(spl) + ".bam")
+    result["e2e_large"] = {"sample_bp": args.large_sample_length, "bam_bytes": bam_l, "cpg_calls": calls_l, "cpu_all_cores_seconds": t_la, "cpu_runs": ts_la, "cpu_setting": cfg_l, "cpu_sweep": sweep_l, "cpu_phases": ph_la,
+                           "cpu_serial_fraction": ph_la.get("_serial_fraction"), "seconds": t_lg, "runs": ts_lg, "value": calls_l / t_lg, "unit": "CpG calls/s", "speedup_vs_cpu_all_cores": t_la / t_lg,
+                           "identical_to_oracle": bool(ok_lg and ok_ld and ok_lq and G.same(d_lg, d_la)), "inside_process_runs": in_lg, "bam_GBps": bam_l / t_lg / 1e9,
+                           "detached": {"seconds": t_ld, "runs": ts_ld, "speedup_vs_cpu_all_cores": t_la / t_ld},
+                           "queue": {"seconds_per_sample": t_lq, "runs": ts_lq, "speedup_vs_cpu_all_cores": t_la / t_lq, "note": "three runs back to back with no pause between them, teardown in place"},
+                           "protocol": "CPU: a sweep of three settings at this size, the fastest once more, median; this build: 5 runs, median; the caller's wall clock around the command with the teardown in place (the default)"}
+    # ---- BASELINE configs[2]: --CHG --CHH with --OT/--OB trimming, end to end (20x the output lines through the host's formatter) ----
+    if G.fits("e2e_cfg3", 45):
+        o3 = ["--CHG", "--CHH", "--OT", "6,146,6,146", "--OB", "6,146,6,146"]
+        G.e2e("e2e_cfg3", spl, cfg_l, "BASELINE.json configs[2] at 128 Mb: all three contexts with mbias trimming; calls = CpG calls (the CHG / CHH files are compared byte for byte as well)", opts=o3, runs=3)
+    # ---- 512 Mb: K copies of the large sample as K contigs ----
+    spx = None
+    if args.xl_copies > 1 and G.fits("e2e_xl", 75):
+        spx = G.data / f"xl_{args.large_sample_length}x{args.xl_copies}_{cov}"
+        if not Path(str(spx) + ".bam").exists():
+            t1 = time.time()
+            subprocess.run([str(REPO / "tools/_build/mdk_replicate"), str(spl), str(spx), str(args.xl_copies)], check=True, capture_output=True, timeout=600)
+            log(f"[bench] xl sample written in {time.time() - t1:.1f} s")
+        alt_x = (64, 250_000) if cfg_l["threads"] == 32 else (32, 250_000)
+        t_x2, _, _, _ = G.run_oracle(spx, "xl_alt", alt_x[0], alt_x[1], 1)
+        e, d_xc = G.e2e("e2e_xl", spx, cfg_l, f"{args.xl_copies} copies of the 128 Mb sample as {args.xl_copies} contigs (tools/mdk_replicate)", runs=3, cpu_runs=2, detached_runs=2,
+                     extras={"sample_bp": args.large_sample_length * args.xl_copies, "contigs": args.xl_copies})
+        if t_x2 < e["cpu_all_cores_seconds"]:       # the other setting was the faster one at this size: the baseline is the faster
+            e["cpu_other_setting"] = {"threads": alt_x[0], "chunk_size": alt_x[1], "seconds": t_x2, "note": "one run; faster than the setting above, and what the speed-up is computed from"}
+            e["cpu_all_cores_seconds"] = t_x2; e["speedup_vs_cpu_all_cores"] = t_x2 / e["seconds"]
+            if "detached" in e:
+                e["detached"]["speedup_vs_cpu_all_cores"] = t_x2 / e["detached"]["seconds"]
+        else:
+            e["cpu_other_setting"] = {"threads": alt_x[0], "chunk_size": alt_x[1], "seconds": t_x2}
+        if args.ranks_leg > 1 and G.fits("e2e_ranks", 20):
+            try:
+                ranks_on_sample(G, result, spx, args.ranks_leg, e, d_xc)
+            except Exception as ex:
+                result["e2e_ranks"] = {"error": repr(ex)[:300]}
+    # ---- the metric's own size: a human-like 30x sample of 24 DISTINCT contigs (mdk_synth -j), as large as this box holds ----
+    shm = Path("/dev/shm")
+    if args.human_gb > 0 and G.fits("e2e_human", 60 + 55 * args.human_gb):
+        scale = asked = args.human_gb / 3.1
+        # what the leg holds at once: the BAM (17.1 MB per Mb), the generator's records (~3.5x that) while it runs, then the oracle's inflated copy + record table (~4.5x)
+        need_gb = 17.1e-3 * 3100 * scale * 6.0
+        room = min(_mem_available_gb(), shutil.disk_usage(shm).free / 1e9 if shm.is_dir() else 0.0)
+        while scale > 0.3 and need_gb > 0.6 * room:
+            scale *= 0.75; need_gb *= 0.75
+        if need_gb <= 0.6 * room:
+            hd = shm / f"mdk_bench_human_{os.getpid()}"; hd.mkdir(exist_ok=True)
+            try:
+                lens = [max(1_000_000, int(m * 1_000_000 * scale)) for m in HUMAN_LADDER]
+                sph = G.synth(hd / "human", ",".join(str(x) for x in lens), cov, S1_SEED + 3000, par=min(96, G.ncores))
+                G.e2e("e2e_human", sph, cfg_l, "24 distinct contigs with hg38's length ladder (tools/mdk_synth -j: every contig its own bases and reads), 30x, in RAM-backed storage; "
+                      + ("the whole ladder: 3.1 Gb" if scale > 0.99 else f"scaled to {sum(lens) / 1e9:.2f} Gb" + (": what this box's memory holds next to the oracle's in-memory copy" if scale < asked else " (--human-gb)")),
+                      runs=2, cpu_runs=1, extras={"sample_bp": sum(lens), "contigs": len(lens), "storage": str(hd)})
+            finally:
+                shutil.rmtree(hd, ignore_errors=True)
+        else:
+            G.skipped.append({"leg": "e2e_human", "why": f"needs ~{need_gb:.0f} GB of memory, {room:.0f} GB available"})
+    # ---- BASELINE configs[4]: 100x with --mergeContext and a bigWig mappability filter ----
+    if args.cfg5_mb > 0 and G.fits("e2e_cfg5", 35 + 0.9 * args.cfg5_mb):
+        per = max(1, args.cfg5_mb // 4) * 1_000_000
+        sp5 = G.synth(G.data / f"cfg5_{args.cfg5_mb}Mb_100x", ",".join([str(per)] * 4), 100.0, S1_SEED + 5000, par=min(64, G.ncores), more=["--bw", "--bbm"])
+        G.e2e("e2e_cfg5", sp5, cfg_l, f"BASELINE.json configs[4] at {4 * per // 1_000_000} Mb: 100x, --mergeContext, the mappability track read as bigWig (-M) by this build and as BBM (-B, the same values) by the oracle, which has no bigWig reader",
+              opts=["--mergeContext", "-M", str(sp5) + ".bw"], oracle_opts=["--mergeContext", "-B", str(sp5) + ".bbm"], runs=3, extras={"sample_bp": 4 * per, "coverage": 100.0})
+    if G.skipped:
+        result["legs_skipped"] = G.skipped
+    if G.slow_runs:
+        result["slow_runs"] = G.slow_runs
+    result["bench_seconds"] = round(time.time() - t_start, 1)
+
+
+def ranks_on_sample(G, result, sp, n_ranks, one, ref_dir, devices=None):
+    """`MethylDackel extract` as n_ranks processes (csrc/host/mdk_ranks.c) on a sample: chunks dealt k mod N, and claimed from rank 0's counter (MDK_CLAIM=1)"""
+    out = {"ranks": n_ranks, "sample_bp": one.get("sample_bp"), "one_rank_seconds": one["seconds"]}
+    for mode, env in (("dealt", {}), ("claimed", {"MDK_CLAIM": "1"})):
+        t, ts, d, ok, _ = G.run_ours(sp, f"ranks{n_ranks}_{mode}", env, runs=2, ranks=n_ranks)
+        same = G.same(d, ref_dir)
+        out[mode] = {"seconds": t, "runs": ts, "ok": bool(ok), "identical_to_oracle": bool(same), "speedup_vs_one_rank": one["seconds"] / t, "value": one["calls"] / t}
+    import torch
+    shared = devices is None and torch.cuda.device_count() < n_ranks
+    out["exchange"] = {"transport": "the ranks share one physical GPU: site buffers travel over the ranks' TCP connections (RCCL refuses two ranks on one device)" if shared
+                       else "ncclSend/ncclRecv of the site buffers to rank 0 (csrc/mdk_comm.hip md_comm_result_send/recv), control over TCP"}
+    result["e2e_ranks"] = out
+
+
+def ranks_leg(args, result, data, work, world, mdk, dist):
+    """--gpus N > 1: the thing that shards -- the command as N ranks, one per GPU, on the XL sample, next to the one-rank run"""
+    G = Legs(args, result, data, work, [], time.time(), mdk)
+    cov = args.coverage
+    spl = G.synth(G.data / f"cpu_sample_{args.large_sample_length}_{cov}", str(args.large_sample_length), cov, S1_SEED + 1000)
+    spx = G.data / f"xl_{args.large_sample_length}x{args.xl_copies}_{cov}"
+    if not Path(str(spx) + ".bam").exists():
+        subprocess.run([str(REPO / "tools/_build/mdk_replicate"), str(spl), str(spx), str(args.xl_copies)], check=True, capture_output=True, timeout=600)
+    t_c, ts_c, d_c, ph = G.run_oracle(spx, "ranks_cpu", 32, 250_000, 1)
+    t1, ts1, d1, ok1, _ = G.run_ours(spx, "ranks_one", {}, runs=2)
+    calls = _calls_of(d_c)
+    one = {"seconds": t1, "calls": calls, "sample_bp": args.large_sample_length * args.xl_copies}
+    ranks_on_sample(G, result, spx, world, one, d_c)
+    result["e2e_ranks"].update({"cpu_all_cores_seconds": t_c, "one_rank_identical_to_oracle": bool(ok1 and G.same(d1, d_c)),
+                                "value_unit": "CpG calls/s of the whole job (the command's wall clock, teardown in place)"})
+
+
+
 def main():
     t_start = time.time()
     ap = argparse.ArgumentParser()
@@ -89,7 +392,10 @@ def main():
     ap.add_argument("--cpu-sample-length", type=int, default=32_000_000, help="bp of the same synthetic workload the CPU oracle is timed on")
     ap.add_argument("--large-sample-length", type=int, default=128_000_000, help="bp of the second, larger end-to-end sample (0 = skip)")
     ap.add_argument("--xl-copies", type=int, default=4, help="the XL end-to-end sample = this many copies of the large sample as that many contigs (<= 1: skip)")
-    ap.add_argument("--xxl-copies", type=int, default=8, help="a third end-to-end sample = this many copies of the large sample (kept in /dev/shm when there is room; <= --xl-copies: skip)")
+    ap.add_argument("--budget-s", type=float, default=420.0, help="seconds the whole run may take: end-to-end legs that no longer fit are left out (and named in legs_skipped)")
+    ap.add_argument("--human-gb", type=float, default=3.1, help="Gb of the human-like 24-contig 30x sample (0: skip); scaled down to what the box's memory holds")
+    ap.add_argument("--cfg5-mb", type=int, default=128, help="Mb of the 100x sample for BASELINE configs[4] (0: skip)")
+    ap.add_argument("--ranks-leg", type=int, default=2, help="N = 1 runs: also run the command as this many ranks sharing the GPU (0/1: skip)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc passes that measure the dominant family's HBM traffic for this line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true", help="the step is the pileup alone over resident segments (round 2's loop; for profiling that kernel)")
@@ -450,209 +756,15 @@ def main():
         log(f"[bench] device legs done in {time.time() - t_start:.0f} s")
         if not args.no_cpu_baseline and world == 1:
           try:
-            oracle = REPO / "oracle/_build/mdk_oracle"
-            ncores = os.cpu_count() or 1
-            threads = str(min(64, ncores))
-
-            def sample(length, tag):
-                sp = data / f"cpu_sample_{length}_{args.coverage}"
-                if not Path(str(sp) + ".bam.bai").exists():
-                    subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(sp), "-L", str(length), "-c", str(args.coverage), "-s", str(S1_SEED + 1000)] + args.synth_args.split(),
-                                   capture_output=True, text=True, check=True)
-                return sp
-
-            def run_oracle(sp, name, thr, ck, runs):
-                d = work / f"co_{name}"; d.mkdir()
-                opts = ["-@", str(thr)] + (["--chunkSize", str(ck)] if ck else [])
-                r = median_run(lambda: subprocess.run([str(oracle), "extract", str(sp) + ".fa", str(sp) + ".bam"] + opts + extra + ["-o", "out"], check=True, capture_output=True, cwd=d, timeout=900), runs), d
-                log(f"[bench] oracle {name}: {r[0][1]}")
-                return r
-
-            def wait_gone(marker, limit=8.0):
-                t_end = time.time() + limit
-                while time.time() < t_end:
-                    alive = False
-                    for pid in os.listdir("/proc"):
-                        if not pid.isdigit() or int(pid) == os.getpid():
-                            continue
-                        try:      # (by name, not by command line: a process that is taking its address space down has none any more)
-                            if open(f"/proc/{pid}/comm").read().strip() == "MethylDackel" and open(f"/proc/{pid}/stat").read().rsplit(") ", 1)[1][0] != "Z":
-                                alive = True; break
-                        except OSError:
-                            pass
-                    if not alive:
-                        return
-                    time.sleep(0.02)
-
-            def run_ours(sp, name, env, runs=3, gap=1.0):
-                d = work / f"cg_{name}"; d.mkdir(); rcs = []; ts = []; inner = []; profs = []
-                for _ in range(runs):
-                    # (outside the clock) the previous command's process -- by default a child the command does not wait for -- is still taking its address
-                    # space down for 0.2-0.4 s after the command has returned; a command started into that shares the driver's locks with it and is
-                    # slower itself, mostly in the time until its device is usable (0.16 -> 0.25-0.45 s; 5 runs 0.3 s apart: 0.40, 0.49, 0.65, 0.75,
-                    # 0.80 s; gpurun_out r04t/r04u).  Runs are measured in isolation: the next one starts a second after the previous one's last
-                    # process has gone
-                    if gap > 0:
-                        wait_gone(str(sp) + ".bam"); time.sleep(gap)        # (the driver goes on releasing a process's GPU resources for a while after the process is gone; gap = 0: a queue of samples, back to back)
-                    t1 = time.perf_counter()
-                    r = mdk.run_cli([str(sp) + ".fa", str(sp) + ".bam", "-@", threads] + extra + ["-o", "out"], cwd=d, env=dict(env, MDK_HOST_PROFILE="1"), timeout=300)
-                    ts.append(time.perf_counter() - t1); rcs.append(r.returncode)
-                    m = re.search(r"total ([0-9.]+)s; chunks prepared", r.stderr)          # the command's own clock, entry of extract_main to outputs closed
-                    inner.append(float(m.group(1)) if m else None)
-                    profs.append([l[:400] for l in r.stderr.splitlines() if l.startswith("[mdk")])
-                log(f"[bench] {name}: wall {ts} inside the process {inner}")
-                # a run far off the others is kept with its own account of where the time went (MDK_HOST_PROFILE lines), not just as a number
-                med = statistics.median(ts)
-                for k, t in enumerate(ts):
-                    if t > 1.6 * med and t - med > 0.3:
-                        slow_runs.append({"leg": name, "run": k, "seconds": t, "median": med, "profile": profs[k]})
-                return med, ts, d, all(r == 0 for r in rcs), inner
-
-            slow_runs = []
-
-            def calls_of(d):
-                n = 0
-                for line in open(d / "out_CpG.bedGraph"):
-                    f = line.split("\t")
-                    if len(f) == 6:
-                        n += int(f[4]) + int(f[5])
-                return n
-
-            sp = sample(args.cpu_sample_length, "small")
-            # the CPU baseline is the BEST the CPU path does over a small sweep of worker threads x chunk size (one run each), then 3 runs at that
-            # setting; the reference's chunk-parallel workers need enough chunks to go round, and outputs do not depend on --chunkSize
-            (t_single, ts_single), d_single = run_oracle(sp, "single", 1, None, 3)
-            sweep = []
-            for thr, ck in ((32, 250_000), (64, 50_000), (64, 250_000), (128, 1_000_000), (ncores, max(50_000, args.cpu_sample_length // (4 * ncores)))):
-                if thr > ncores:
-                    continue
-                (t1, _), _ = run_oracle(sp, f"sweep_{thr}_{ck}", thr, ck, 1)
-                sweep.append({"threads": thr, "chunk_size": ck, "seconds": t1})
-            best = min(sweep, key=lambda q: q["seconds"])
-            (t_all, ts_all), d_all = run_oracle(sp, "allcore", best["threads"], best["chunk_size"], 3)
-            same = all((d_single / f).read_bytes() == (d_all / f).read_bytes() for f in os.listdir(d_single))
-            calls = calls_of(d_single)
-            # The wall clock on top is the command as it runs by default: the process that did the work is the process the caller waits for, its
-            # teardown included -- the CPU baseline's protocol.  With MDK_DETACH=1 the command does its work in a child and returns when the child
-            # reports its outputs closed (csrc/host/main.c); that figure is reported next to it as `detached`.
-            t_g, ts_g, d_g, ok_g, in_g = run_ours(sp, "inplace", {})
-            t_gd, ts_gd, _, ok_gd, _ = run_ours(sp, "detached", {"MDK_DETACH": "1"})
-            ident = ok_g and ok_gd and all((d_g / f).read_bytes() == (d_single / f).read_bytes() for f in os.listdir(d_single))
-            result["cpu_baseline"] = {"value": calls / t_all, "unit": "CpG calls/s", "cores": best["threads"], "kind": "port",
-                                      "sample": f"oracle/mdk_oracle extract -@ {best['threads']} --chunkSize {best['chunk_size']} -- the fastest of a sweep over worker threads x chunk size on this box's {ncores} hardware threads "
-                                                f"(C restatement of the reference with its chunk-parallel worker threads, extract.c:325-350,1479-1486; end to end from the BAM file: inflate with CRC32 check, pileup, text) "
-                                                f"on a {args.cpu_sample_length} bp / {args.coverage}x sample of the same synthetic workload; 3 runs, median "
-                                                f"{t_all:.2f} s, {calls} CpG calls; the reference binary itself cannot be built here (no htslib)",
-                                      "seconds": t_all, "runs": ts_all, "cpg_calls": calls, "identical_to_single_thread": bool(same), "host_threads": ncores, "sweep": sweep,
-                                      "single_thread": {"value": calls / t_single, "seconds": t_single, "runs": ts_single, "cores": 1}}
-            result["e2e_cli"] = {"seconds": t_g, "runs": ts_g, "value": calls / t_g, "unit": "CpG calls/s", "threads": int(threads), "protocol": "3 runs, median, whole-process wall clock with the teardown in place (the CPU baseline's protocol)",
-                                 "speedup_vs_cpu_baseline": t_all / t_g, "speedup_vs_single_thread": t_single / t_g, "identical_to_oracle": bool(ident),
-                                 "inside_process_runs": in_g, "bam_bytes": os.path.getsize(str(sp) + ".bam"),
-                                 "detached": {"seconds": t_gd, "runs": ts_gd, "speedup_vs_cpu_baseline": t_all / t_gd,
-                                              "note": "MDK_DETACH=1 (opt-in): the command's work is done by a child, the command returns when the child reports its outputs closed and the child's address-space teardown goes on behind the caller"},
-                                 "note": "`MethylDackel extract` of this build on the same file, one process (start-up, HIP init, inflate on the host's threads and -- once the device is up -- on the device, "
-                                         "chunk preparation, H2D, kernels, D2H, text, teardown).  `seconds` is the caller's wall clock around a process that tears its own address space down (the default); "
-                                         "inside_process_runs = the command's own clock from entry to outputs closed"}
-            # the device inflate on the record: the 32 Mb sample's BGZF members through md_piece_* (tools/piece_bench: whole file in 64 MB pieces, three in
-            # flight, and the kernels alone on the largest resident piece, HIP events)
-            try:
-                pb = subprocess.run([str(REPO / "tools/_build/piece_bench"), str(sp) + ".bam", "64", "3", "0"], capture_output=True, text=True, timeout=300)
-                pj = json.loads(pb.stdout)
-                kv = pj["kernel_only"]["v0"]
-                inf_bytes = kv["comp_bytes"] + kv["out_bytes"]
-                result["inflate"] = {"workload": f"the {args.cpu_sample_length} bp sample's BAM: {pj['members']} BGZF members, {pj['file_MB']:.0f} MB -> {pj['inflated_MB']:.0f} MB",
-                                     "pipelined": {"GBps_compressed": pj["pass1"]["GBps_compressed"], "GBps_inflated": pj["pass1"]["GBps_inflated"], "seconds": pj["pass1"]["seconds"],
-                                                   "note": "whole file through md_piece_submit / md_piece_wait: staging copy, H2D of the compressed bytes, k_inflate, k_crc32, k_walk, digests back; 64 MB pieces, 3 in flight"},
-                                     "GBps_compressed": kv["GBps_compressed"], "GBps_inflated": kv["GBps_inflated"],
-                                     "roofline": {"kernel": "k_inflate", "bound": "hbm", "kernel_ms": kv["inflate_ms"], "algo_bytes_per_launch": inf_bytes, "achieved": inf_bytes / (kv["inflate_ms"] * 1e6), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                  "frac": inf_bytes / (kv["inflate_ms"] * 1e6) / HBM_PEAK_GBS, "members_per_launch": pj["kernel_only"]["piece_members"],
-                                                  "note": "algorithmic bytes = compressed bytes read + inflated bytes written, one 64 MB piece per launch; the kernel is bound by one lane's dependent symbol decode per member, not by HBM (DESIGN.md 4)"},
-                                     "crc32_ms": kv["crc32_ms"], "walk_ms": kv["walk_ms"], "crc32_GBps": kv["out_bytes"] / (kv["crc32_ms"] * 1e6) if kv["crc32_ms"] > 0 else None}
-                # a 64 MB piece is ~3,400 members = wavefronts, about half of what the device holds at once; the command keeps 8 pieces (of 96 MB since the end of round 5) in flight (8 device teams).
-                # What the kernel does with the device full: the whole file as one launch
-                pw = subprocess.run([str(REPO / "tools/_build/piece_bench"), str(sp) + ".bam", "1024", "1", "0"], capture_output=True, text=True, timeout=300)
-                kw = json.loads(pw.stdout)["kernel_only"]["v0"]
-                result["inflate"]["device_full"] = {"members_per_launch": json.loads(pw.stdout)["kernel_only"]["piece_members"], "kernel_ms": kw["inflate_ms"], "GBps_compressed": kw["GBps_compressed"], "GBps_inflated": kw["GBps_inflated"],
-                                                    "crc32_ms": kw["crc32_ms"], "walk_ms": kw["walk_ms"], "identical_to_zlib": kw.get("identical_to_zlib"),
-                                                    "note": "k_inflate over all members of the file in one launch (what the command's eight pieces in flight present to the device); HIP events"}
-            except Exception as ex:
-                result["inflate"] = {"error": repr(ex)[:300]}
-            if args.large_sample_length and headline:
-                spl = sample(args.large_sample_length, "large")
-                alt = (32, 250_000) if best["threads"] != 32 else (64, 250_000)
-                (t_alt, _), _ = run_oracle(spl, "large_alt", alt[0], alt[1], 1)
-                (t_la, ts_la), d_la = run_oracle(spl, "large_allcore", best["threads"], best["chunk_size"], 2)
-                cfg_l = {"threads": best["threads"], "chunk_size": best["chunk_size"]}
-                if t_alt < t_la:
-                    (t_la, ts_la), d_la = run_oracle(spl, "large_alt3", alt[0], alt[1], 2); ts_la = ts_la + [t_alt]; t_la = statistics.median(ts_la); cfg_l = {"threads": alt[0], "chunk_size": alt[1]}
-                t_lg, ts_lg, d_lg, ok_lg, in_lg = run_ours(spl, "large_inplace", {}, runs=5)
-                t_ld, ts_ld, _, ok_ld, _ = run_ours(spl, "large_detached", {"MDK_DETACH": "1"}, runs=3)
-                t_lq, ts_lq, _, ok_lq, _ = run_ours(spl, "large_queue", {}, runs=4, gap=0.0)
-                ident_l = ok_lg and ok_ld and ok_lq and all((d_lg / f).read_bytes() == (d_la / f).read_bytes() for f in os.listdir(d_la))
-                calls_l = calls_of(d_la)
-                bam_l = os.path.getsize(str(spl) + ".bam")
-                result["e2e_large"] = {"sample_bp": args.large_sample_length, "bam_bytes": bam_l, "cpg_calls": calls_l,
-                                       "cpu_all_cores_seconds": t_la, "cpu_runs": ts_la, "cpu_setting": cfg_l, "seconds": t_lg, "runs": ts_lg, "value": calls_l / t_lg, "unit": "CpG calls/s",
-                                       "speedup_vs_cpu_all_cores": t_la / t_lg, "identical_to_oracle": bool(ident_l),
-                                       "inside_process_runs": in_lg, "bam_GBps": bam_l / t_lg / 1e9,
-                                       "detached": {"seconds": t_ld, "runs": ts_ld, "speedup_vs_cpu_all_cores": t_la / t_ld,
-                                                    "note": "MDK_DETACH=1 (opt-in: work in a child, return at outputs closed, teardown behind the caller): csrc/host/main.c detach_teardown, as the mold linker does"},
-                                       "queue": {"seconds_per_sample": t_lq, "runs": ts_lq, "speedup_vs_cpu_all_cores": t_la / t_lq,
-                                                 "note": "four runs back to back with no pause between them, teardown in place: what a queue of samples gets per sample"},
-                                       "protocol": "CPU: the sweep's best setting and one alternative, the faster of them, median; this build: 5 runs, median; the caller's wall clock around the command with the teardown in place (the default), each run started one second after the previous command's last process has gone"}
-                if args.xl_copies > 1:
-                    # a sample large enough that start-up and exit are a small part of the run: K copies of the large sample as K contigs (tools/mdk_replicate)
-                    spx = data / f"xl_{args.large_sample_length}x{args.xl_copies}_{args.coverage}"
-                    if not Path(str(spx) + ".bam").exists():
-                        t1 = time.time()
-                        subprocess.run([str(REPO / "tools/_build/mdk_replicate"), str(spl), str(spx), str(args.xl_copies)], check=True, capture_output=True, timeout=600)
-                        log(f"[bench] xl sample written in {time.time() - t1:.1f} s")
-                    (t_xa, ts_xa), d_xa = run_oracle(spx, "xl_allcore", cfg_l["threads"], cfg_l["chunk_size"], 1)
-                    t_xg, ts_xg, d_xg, ok_xg, in_xg = run_ours(spx, "xl_inplace", {}, runs=3)
-                    t_xd, ts_xd, _, ok_xd, _ = run_ours(spx, "xl_detached", {"MDK_DETACH": "1"}, runs=2)
-                    ident_x = ok_xg and ok_xd and all((d_xg / f).read_bytes() == (d_xa / f).read_bytes() for f in os.listdir(d_xa))
-                    calls_x = calls_of(d_xa); bam_x = os.path.getsize(str(spx) + ".bam")
-                    result["e2e_xl"] = {"sample_bp": args.large_sample_length * args.xl_copies, "contigs": args.xl_copies, "bam_bytes": bam_x, "cpg_calls": calls_x,
-                                        "cpu_all_cores_seconds": t_xa, "cpu_runs": ts_xa, "cpu_setting": cfg_l, "seconds": t_xg, "runs": ts_xg, "value": calls_x / t_xg, "unit": "CpG calls/s",
-                                        "speedup_vs_cpu_all_cores": t_xa / t_xg, "identical_to_oracle": bool(ident_x), "inside_process_runs": in_xg,
-                                        "detached": {"seconds": t_xd, "runs": ts_xd, "speedup_vs_cpu_all_cores": t_xa / t_xd},
-                                        "bam_GBps": bam_x / t_xg / 1e9, "bam_GBps_inside_process": [bam_x / q / 1e9 if q else None for q in in_xg],
-                                        "protocol": "CPU: one run at the large sample's setting; this build: 3 runs, median; whole-process wall clock, teardown in place"}
-                if args.xxl_copies > max(1, args.xl_copies):
-                    # ... and one where start-up and teardown are a small part of this build's run too: in RAM-backed storage when the box has room for it
-                    shm = Path("/dev/shm")
-                    need = bam_l * (args.xxl_copies + 1)
-                    xdir = data
-                    try:
-                        if shm.is_dir() and shutil.disk_usage(shm).free > 3 * need:
-                            xdir = shm / f"mdk_bench_xxl_{os.getpid()}"; xdir.mkdir(exist_ok=True)
-                    except OSError:
-                        pass
-                    if shutil.disk_usage(xdir).free > 2 * need:
-                        spy = xdir / f"xxl_{args.large_sample_length}x{args.xxl_copies}_{args.coverage}"
-                        try:
-                            t1 = time.time()
-                            subprocess.run([str(REPO / "tools/_build/mdk_replicate"), str(spl), str(spy), str(args.xxl_copies)], check=True, capture_output=True, timeout=900)
-                            log(f"[bench] xxl sample written in {time.time() - t1:.1f} s under {xdir}")
-                            (t_ya, ts_ya), d_ya = run_oracle(spy, "xxl_allcore", cfg_l["threads"], cfg_l["chunk_size"], 1)
-                            t_yg, ts_yg, d_yg, ok_yg, in_yg = run_ours(spy, "xxl_inplace", {}, runs=2)
-                            t_yd, ts_yd, _, ok_yd, _ = run_ours(spy, "xxl_detached", {"MDK_DETACH": "1"}, runs=1)
-                            ident_y = ok_yg and ok_yd and all((d_yg / f).read_bytes() == (d_ya / f).read_bytes() for f in os.listdir(d_ya))
-                            calls_y = calls_of(d_ya); bam_y = os.path.getsize(str(spy) + ".bam")
-                            result["e2e_xxl"] = {"sample_bp": args.large_sample_length * args.xxl_copies, "contigs": args.xxl_copies, "bam_bytes": bam_y, "cpg_calls": calls_y, "storage": str(xdir),
-                                                 "cpu_all_cores_seconds": t_ya, "cpu_runs": ts_ya, "cpu_setting": cfg_l, "seconds": t_yg, "runs": ts_yg, "value": calls_y / t_yg, "unit": "CpG calls/s",
-                                                 "speedup_vs_cpu_all_cores": t_ya / t_yg, "identical_to_oracle": bool(ident_y), "inside_process_runs": in_yg,
-                                                 "detached": {"seconds": t_yd, "runs": ts_yd, "speedup_vs_cpu_all_cores": t_ya / t_yd},
-                                                 "bam_GBps": bam_y / t_yg / 1e9,
-                                                 "protocol": "CPU: one run at the large sample's setting; this build: 2 runs, median; whole-process wall clock, teardown in place"}
-                        finally:
-                            if xdir != data:
-                                shutil.rmtree(xdir, ignore_errors=True)
-            if slow_runs:
-                result["slow_runs"] = slow_runs
+            e2e_legs(args, result, data, work, extra, headline, t_start, mdk)
           except Exception as ex:            # a leg that fails or hangs (timeout) must not take the measured line with it
             result["legs_error"] = repr(ex)[:500]
             log(f"[bench] a CPU/end-to-end leg failed: {ex!r}")
+        if world > 1 and not args.no_cpu_baseline:
+          try:
+            ranks_leg(args, result, data, work, world, mdk, dist)
+          except Exception as ex:
+            result["e2e_ranks"] = {"error": repr(ex)[:300]}
         print(json.dumps(result), flush=True)
     if world > 1:
         L.md_comm_close(comm)

@@ -41,3 +41,22 @@ def test_two_ranks_without_the_exchange():
     j = run_bench("--devices", "0,0", "--no-exchange")
     assert j["n_gpus"] == 2 and j["value"] > 0
     assert j["exchange"]["exchanges"] == 0 and j["exchange"]["transport"].startswith("NONE")
+
+
+def test_the_command_as_two_ranks_leg(tmp_path):
+    """bench.py's e2e_ranks leg (the thing that shards: `MethylDackel extract` as N ranks, csrc/host/mdk_ranks.c) on a small two-contig sample, both ranks
+    on device 0: dealt and claimed, each identical to the oracle's output"""
+    import argparse, time
+    sys.path.insert(0, str(REPO))
+    import bench
+    args = argparse.Namespace(budget_s=600.0, coverage=30.0, synth_args="", large_sample_length=4_000_000, xl_copies=2)
+    result = {}
+    G = bench.Legs(args, result, tmp_path, tmp_path, [], time.time(), mdk)
+    sp = G.synth(tmp_path / "two", "4000000,3000000", 30.0, 11, par=4)
+    t_c, _, d_c, _ = G.run_oracle(sp, "cpu", 8, 250_000, 1)
+    t1, _, d1, ok1, _ = G.run_ours(sp, "one", {}, runs=1)
+    assert ok1 and G.same(d1, d_c)
+    bench.ranks_on_sample(G, result, sp, 2, {"seconds": t1, "calls": bench._calls_of(d_c), "sample_bp": 7_000_000}, d_c)
+    e = result["e2e_ranks"]
+    assert e["ranks"] == 2 and e["dealt"]["ok"] and e["dealt"]["identical_to_oracle"] and e["claimed"]["ok"] and e["claimed"]["identical_to_oracle"]
+    assert "TCP" in e["exchange"]["transport"] or "ncclSend" in e["exchange"]["transport"]
