@@ -230,8 +230,9 @@ int  md_dev_count(void);                                       /* number of HIP 
 /* optional: create the device context and load the kernels ahead of md_dev_open (e.g. on a thread, while options and
  * input headers are still being read) */
 int  md_dev_warm(int device);
-/* joins the helper threads md_dev_warm started (registration of staging blocks, streams and device blocks made ahead); md_dev_close calls
- * it, and a process that leaves without closing its handle (the command's _exit) calls it first.  Idempotent. */
+/* for a process about to leave without closing its handle (the command's _exit; also run at exit): joins the helper threads md_dev_warm started
+ * (registration of staging blocks, streams and device blocks made ahead) and starts none again.  md_dev_close joins them too, but a later
+ * md_dev_warm / md_dev_open in the same process starts its own again.  Idempotent. */
 void md_dev_quiesce(void);
 int  md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out);
 /* room for the references of contigs 0..n-1, so that a thread may upload the next contig (md_dev_set_reference and what goes with it) while

@@ -107,7 +107,10 @@ int mbias_main(int argc, char *argv[]) {
         /* chunk k goes to slot k&1; the batch handed out two calls ago is recycled by the next call, so its upload must be over.  A submit queues
          * the chunk's upload and preparation and meanwhile sends the other slot's chunk -- whose preparation has reported by then -- on to the
          * histogram kernel (md_dev_mbias_submit_raw), so the records of chunk k cross the link while chunk k-1 is counted */
-        if((rc = md_dev_slot_sync(dev, k & 1)) != 0) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break; }
+        if((rc = md_dev_slot_sync(dev, k & 1)) != 0) {
+            if(rc == MDK_ERR_STRAND0) { fprintf(stderr, "Can't determine the strand of a read!\n"); abort(); }       /* (the slot's deferred histogram step reports here when the chunks in between were skipped) */
+            fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; break;
+        }
         rc = mdk_plan_next_chunk(p, &ch);
         if(rc < 0) { ret = rc == -5 ? -5 : -4; break; }
         if(rc == 0) break;
@@ -124,7 +127,7 @@ int mbias_main(int argc, char *argv[]) {
         if(rc) { fprintf(stderr, "[mdk] device error: %s\n", md_dev_last_error()); ret = MDK_RC_DEVICE; }
         else if(mdk_mbias_report(&hist, p->o.mb_opref, p->o.svg, p->o.txt, p->o.ctx_on[0] + 2 * p->o.ctx_on[1] + 4 * p->o.ctx_on[2])) ret = -3;
     }
-    if(fast_exit_wanted()) leave_fast(ret);
+    if(fast_exit_wanted()) leave_fast_plan(p, ret);
     mdk_plan_detach_device(p);
     md_dev_close(dev);
     mdk_plan_close(p);

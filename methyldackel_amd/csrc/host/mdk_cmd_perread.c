@@ -166,7 +166,7 @@ int perRead_main(int argc, char *argv[]) {
         if(!more && !have[0] && !have[1]) break;
     }
     fflush(p->pr_out);
-    if(fast_exit_wanted()) { if(p->pr_out_owned) fclose(p->pr_out); leave_fast(ret); }
+    if(fast_exit_wanted()) { if(p->pr_out_owned) fclose(p->pr_out); leave_fast_plan(p, ret); }
     md_dev_close(dev);
     mdk_plan_close(p);
     return ret;

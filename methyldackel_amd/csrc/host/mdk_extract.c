@@ -64,8 +64,9 @@ MDK_LOCAL void hip_warm_up(void) {
     if(!fast_exit_wanted() || g_warm_started) return;
     if(pthread_create(&g_warm_th, NULL, hipwarm_main, NULL) == 0) g_warm_started = 1;
 }
+MDK_LOCAL void leave_fast_plan(mdk_plan *p, int ret) { g_leaving = p; leave_fast(ret); }      /* every command's way out: the plan's reaper and device teams are waited for */
 void mdk_cli_quiesce(void) {
-    if(g_leaving && g_leaving->bam) mdk_bam_reap_wait(g_leaving->bam);
+    if(g_leaving && g_leaving->bam) { mdk_bam_teams_leave(g_leaving->bam); mdk_bam_reap_wait(g_leaving->bam); }
     if(g_warm_started) { pthread_join(g_warm_th, NULL); g_warm_started = 0; }
     md_dev_quiesce();
 }
@@ -318,7 +319,7 @@ int extract_main(int argc, char *argv[]) {
     if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk main] plan open %.3fs, device ready at %.3fs, uploader: wait-for-chunk %.3fs wait-for-reference %.3fs wait-for-group %.3fs submit %.3fs wait-for-uploads %.3fs; collector: download %.3fs emit %.3fs, total %.3fs; chunks prepared on the host after all: %d\n", t_open, t_dev, w_next, w_ref, w_group, w_sub, w_rel, X->w_down, X->w_emit, now_s() - T0, X->n_host_prep);
     if(ret == 0) mdk_plan_finish(p);
     if(getenv("MDK_HOST_PROFILE")) { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); fprintf(stderr, "[mdk main] leaving at epoch %.3f (resident %.0f MB, of which file-backed/shared %.0f MB)\n", ts.tv_sec + 1e-9 * ts.tv_nsec, rss_mb(0), rss_mb(1)); }
-    if(fast_exit_wanted()) { g_leaving = p; leave_fast(ret); }
+    if(fast_exit_wanted()) leave_fast_plan(p, ret);
     { double tc = now_s(), td;
       pthread_mutex_destroy(&X->mu); pthread_cond_destroy(&X->cv); free(X->ref_state); free(X);
       mdk_plan_detach_device(p);

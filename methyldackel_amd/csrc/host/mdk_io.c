@@ -176,10 +176,20 @@ static void *reaper_main(void *arg) {
 }
 /* the end of the file has been reached: what the pool holds beyond a couple of slabs goes too */
 static void reap_pool(mdk_bam *b) {                       /* (mu held) */
-    if(!b->reap_started || b->n_pool_wait) return;
+    if(!b->reap_started || b->n_pool_wait || b->seeked) return;      /* (a reader that seeks -- a rank of a sharded run, a region list -- reaches the end of the file before every seek: its slabs stay until it is closed) */
     while(b->n_pool > MDK_POOL_KEEP) reap_push(b, b->pool[--b->n_pool]);
 }
 /* wait until the reaper has nothing left to give back (a command about to leave: what it has not unregistered the kernel will, slowly) */
+/* a command about to leave with _exit: the device teams are told to stop and joined -- none of them may be inside the HIP runtime (md_piece_*, md_host_free of
+ * its staging block) when the process goes */
+void mdk_bam_teams_leave(mdk_bam *b) {
+    int i;
+    if(!b || !b->gpu_started) return;
+    pthread_mutex_lock(&b->life_mu);
+    pthread_mutex_lock(&b->mu); b->quit = 1; pthread_cond_broadcast(&b->cv_pool); pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu);
+    if(b->gpu_started) { for(i = 0; i < b->n_gpu_teams; i++) pthread_join(b->gpu_th[i], NULL); b->gpu_started = 0; }
+    pthread_mutex_unlock(&b->life_mu);
+}
 void mdk_bam_reap_wait(mdk_bam *b) {
     if(!b || !b->reap_started) return;
     pthread_mutex_lock(&b->mu);
@@ -204,7 +214,7 @@ void mdk_slab_unref(mdk_bam *b, mdk_slab *s) {
         if(s->piece) {
             if(b->n_dpool == b->cap_dpool) { b->cap_dpool = b->cap_dpool ? b->cap_dpool * 2 : 8; b->dpool = xrealloc(b->dpool, sizeof(mdk_slab *) * b->cap_dpool); }
             b->dpool[b->n_dpool++] = s;
-        } else if(b->io_end && b->reap_started && !b->n_pool_wait && b->n_pool >= MDK_POOL_KEEP) {
+        } else if(b->io_end && !b->seeked && b->reap_started && !b->n_pool_wait && b->n_pool >= MDK_POOL_KEEP) {
             reap_push(b, s);                              /* nobody will ask for it again (a team still inflating its last piece finds MDK_POOL_KEEP in the pool, or makes one) */
         } else {
             if(b->n_pool == b->cap_pool) { b->cap_pool = b->cap_pool ? b->cap_pool * 2 : 16; b->pool = xrealloc(b->pool, sizeof(mdk_slab *) * b->cap_pool); }
@@ -761,7 +771,7 @@ int mdk_bam_seek(mdk_bam *b, uint64_t voffset) {
     inflaters_stop(b);
     pthread_mutex_lock(&b->mu);
     for(i = 0; i < MDK_READY; i++) if(b->ready[i]) { mdk_slab *q = b->ready[i]; b->ready[i] = NULL; q->refs = 1; pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, q); pthread_mutex_lock(&b->mu); }
-    b->n_ready = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0;
+    b->n_ready = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0; b->seeked = 1;
     pthread_mutex_unlock(&b->mu);
     if(b->cur) { mdk_slab_unref(b, b->cur); b->cur = NULL; }
     if(b->map) { if((size_t)(voffset >> 16) > b->map_len) { snprintf(b->err, sizeof(b->err), "seek failed"); pthread_mutex_unlock(&b->life_mu); return -2; } b->map_pos = (size_t)(voffset >> 16); __atomic_store_n(&b->pop_next, b->map_pos, __ATOMIC_RELAXED); }

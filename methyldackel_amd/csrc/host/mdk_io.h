@@ -75,6 +75,7 @@ typedef struct mdk_bam {
     /* the mapping's page-table entries are made AHEAD of the framing (mdk_io.c populate_ahead): the walk over the members' headers runs under io_mu, one team at
      * a time, and a first touch of a page there costs the whole feed a microsecond per member */
     double t_frame;                                /* (io_mu) seconds inside next_piece */
+    int seeked;                                    /* (mu) mdk_bam_seek has been called: the end of the file is not the end of the reading */
     size_t pop_next;                               /* (atomic) up to where the mapping's entries have been made or are being made */
     /* scanner position */
     mdk_slab *cur; size_t off;
@@ -101,7 +102,8 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads);
 mdk_slab *mdk_bam_cur_slab(mdk_bam *b, size_t *off);
 void mdk_slab_ref(mdk_bam *b, mdk_slab *s);
 void mdk_slab_unref(mdk_bam *b, mdk_slab *s);
-void mdk_bam_reap_wait(mdk_bam *b);      /* until the slabs given up after the end of the file have been unregistered and unmapped */
+void mdk_bam_reap_wait(mdk_bam *b);
+void mdk_bam_teams_leave(mdk_bam *b);       /* stop and join the device inflate teams (a command on its way out) */      /* until the slabs given up after the end of the file have been unregistered and unmapped */
 void mdk_bam_close(mdk_bam *b);
 /* from now on, pieces of the file are also inflated on this device (n_teams threads, each with its own device piece); safe while
  * the host teams are running.  mdk_bam_detach_device stops those threads and frees the device pieces: before md_dev_close. */

@@ -356,8 +356,8 @@ region:
     return 0;
 }
 
-/* BGZF inflate on the device as well (mdk_io.c): the `extract` command in device-preparation mode only -- `mbias` and `perRead` format
- * from the records on the host.  MDK_HOST_INFLATE=1 keeps every piece on the host's inflate threads. */
+/* BGZF inflate on the device as well (mdk_io.c): `extract` and `mbias` in device-preparation mode -- `perRead` prints from the records'
+ * bytes on the host.  MDK_HOST_INFLATE=1 keeps every piece on the host's inflate threads. */
 int mdk_plan_attach_device(mdk_plan *p, md_dev *dev) {
     if(!p || !dev || !p->bam) return -1;
     if(!p->dev_prep || p->o.perread || getenv("MDK_HOST_INFLATE")) return 0;       /* (perRead prints from the records' bytes on the host: mdk_plan_emit_perread_raw) */

@@ -152,6 +152,7 @@ MDK_LOCAL void emitter_stop(emitter *E);
 static inline int user_device(int d) { const char *u = getenv("MDK_DEVICE_USER"); return u ? atoi(u) : d; }
 MDK_LOCAL int fast_exit_wanted(void);
 MDK_LOCAL void leave_fast(int ret);
+MDK_LOCAL void leave_fast_plan(struct mdk_plan *p, int ret);      /* the same with the plan whose reaper thread and device inflate teams must have left the HIP runtime first */
 MDK_LOCAL void hip_warm_up(void);
 MDK_LOCAL void *devopen_main(void *arg);
 MDK_LOCAL int ranks_from_env(int *rank, int *world);

@@ -305,7 +305,7 @@ MDK_LOCAL int extract_ranks(int argc, char *argv[], int rank, int world) {
 out:
     if(Q.th_ok) { pthread_mutex_lock(&Q.mu); Q.quit = 1; pthread_cond_broadcast(&Q.cv); pthread_mutex_unlock(&Q.mu); pthread_join(Q.th, NULL); }
     ranks_close(&R);
-    if(fast_exit_wanted() && ret == 0) leave_fast(ret);
+    if(fast_exit_wanted() && ret == 0) leave_fast_plan(p, ret);
     if(hb) { for(i = 0; i < world; i++) { free(hb[i].site); free(hb[i].var); } free(hb); }
     free(ring); free(rslot);
     if(comm) md_comm_close(comm);

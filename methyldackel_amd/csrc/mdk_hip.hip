@@ -761,12 +761,17 @@ struct WarmScope { WarmScope() { std::lock_guard<std::mutex> lk(g_stash_mu); g_w
 // and a short command could reach _exit while they were still in hipMalloc / hipHostRegister).  None of them touches a kernel symbol: the
 // device library's one code object is loaded by md_dev_warm's own thread, once, before anything is launched from it.
 static std::mutex g_side_mu; static std::vector<std::thread> &g_side = *new std::vector<std::thread>();      // (never destroyed: a joinable std::thread must not meet its destructor at exit)
-static std::atomic<bool> g_side_quit{false};
-extern "C" void md_dev_quiesce(void) {
+static std::atomic<bool> g_side_quit{false}, g_side_forever{false};
+// forever: the process is leaving (the command's _exit, atexit) -- nothing is started again.  Otherwise (a handle is being closed in a process that lives
+// on: Python, a test suite, bench.py opening handles in turn) the threads are stopped and joined, and the next md_dev_warm / md_dev_open starts its own.
+static void side_join(bool forever) {
     std::vector<std::thread> mine;
     { std::lock_guard<std::mutex> lk(g_side_mu); g_side_quit.store(true); g_warm_reg_stop.store(true); mine.swap(g_side); }
     for(std::thread &t : mine) if(t.joinable()) t.join();
+    if(!forever) { std::lock_guard<std::mutex> lk(g_side_mu); if(!g_side_forever.load()) g_side_quit.store(false); }
+    else g_side_forever.store(true);
 }
+extern "C" void md_dev_quiesce(void) { side_join(true); }
 template <typename F> static void side_start(F &&f) {
     static std::once_flag hook;
     std::call_once(hook, [] { (void)atexit(md_dev_quiesce); });     // a library caller that never closes a handle: joined before the runtime's own exit handlers run
@@ -787,6 +792,7 @@ static int code_object_load() {
 }
 extern "C" int md_dev_warm(int device) {
     WarmScope warm_scope;
+    if(!g_side_forever.load()) g_warm_reg_stop.store(false);       // (a warm-up after a handle was closed: its side threads run again)
     const double t0 = mdk_now();
     int n = md_dev_count();
     const double t1 = mdk_now();
@@ -896,7 +902,7 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
 
 extern "C" void md_dev_close(md_dev *h) {
     if(!h) return;
-    md_dev_quiesce();
+    side_join(false);
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for(auto &s : h->slots) {
@@ -1650,8 +1656,16 @@ extern "C" void md_host_free(void *q) {
         for(;;) {
             auto it = std::lower_bound(g_blocks.begin(), g_blocks.end(), key, block_less);
             if(it == g_blocks.end() || it->base != p) break;
-            if(it->state == 1) { g_blocks_cv.wait(lk); continue; }          // somebody is registering it right now
-            if(it->state == 2) (void)hipHostUnregister(p);
+            if(it->state == 1) { g_blocks_cv.wait(lk); continue; }          // somebody is registering it (or taking its registration away) right now
+            if(it->state == 2) {                                            // the lock is given up while the runtime unpins the block: uploaders looking their blocks up do not queue behind it
+                it->state = 1; lk.unlock();
+                (void)hipHostUnregister(p);
+                lk.lock();
+                it = std::lower_bound(g_blocks.begin(), g_blocks.end(), key, block_less);
+                if(it != g_blocks.end() && it->base == p) g_blocks.erase(it);
+                g_blocks_cv.notify_all();
+                break;
+            }
             g_blocks.erase(it);
             break;
         }

@@ -40,10 +40,11 @@
 #define INF_DIST_TB   8                    // ... of the distance table
 #define INF_CL_TB     7                    // ... of the code-length alphabet's table (its codes are never longer)
 #ifndef INF_SW_MAX
-#define INF_SW_MAX    31                   // words of the stream per lane and Huffman batch, at most (odd: the lanes' stretches start in different LDS banks)
+#define INF_SW_MAX    19                   // words of the stream per lane and Huffman batch, at most (odd: the lanes' stretches start in different LDS banks).  19: the staged words then fit next to the
+                                           // tables and the window in 12.9 KB, twelve wavefronts per CU instead of ten (31 words: 15.1 ms for the bench's file, 19: 14.3; 608 bits still synchronise 98 % of the chains)
 #endif
 #ifndef INF_SW_MIN
-#define INF_SW_MIN    21                   // ... and at least (a stretch must be long enough for a chain to meet the true decoder inside it: 672 bits, 99 %)
+#define INF_SW_MIN    19                   // ... and at least (a stretch must be long enough for a chain to meet the true decoder inside it)
 #endif
 #define INF_IN_CAP    (64 * INF_SW_MAX + 8)    // staged compressed words of a batch: S.in[0] is word `wbase` of the stream, and every bit position the functions below take counts from ITS bit 0
 #define INF_HDR_WORDS 168                  // what a header batch stages (a dynamic header is at most 14 + 19*3 + 316*14 bits < 160 words)
