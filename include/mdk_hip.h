@@ -234,6 +234,11 @@ int  md_dev_warm(int device);
  * (registration of staging blocks, streams and device blocks made ahead) and starts none again.  md_dev_close joins them too, but a later
  * md_dev_warm / md_dev_open in the same process starts its own again.  Idempotent. */
 void md_dev_quiesce(void);
+/* How much device memory the caller expects to use (inflated pieces, chunk slots, contigs), told as early as it knows (the size of the BAM):
+ * md_dev_warm's helper thread makes that much carved memory ahead, while the copy engines are still idle.  An allocation made later, next to
+ * the pieces' copies, costs its caller 10-30 ms and holds up every other call into the runtime meanwhile (profiles/r06pf_*).  No handle
+ * needed; may be called before, during or after md_dev_warm; without it memory is made when first asked for. */
+void md_dev_reserve_hint(uint64_t device_bytes);
 int  md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out);
 /* room for the references of contigs 0..n-1, so that a thread may upload the next contig (md_dev_set_reference and what goes with it) while
  * others work on slots of contigs already uploaded; without it md_dev_set_reference must not run next to other calls on the handle */

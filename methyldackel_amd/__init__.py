@@ -158,7 +158,7 @@ def raw_record_offsets(raw):
     return out
 
 
-HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_quiesce", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
+HIP_SYMBOLS = ["md_dev_count", "md_dev_warm", "md_dev_quiesce", "md_dev_reserve_hint", "md_dev_open", "md_dev_close", "md_dev_last_error", "md_dev_tile", "md_dev_set_reference", "md_dev_set_regions",
                "md_dev_upload", "md_dev_launch", "md_dev_submit", "md_dev_download", "md_dev_sync", "md_dev_bind_output", "md_dev_wait", "md_sites_order",
                "md_dev_bench", "md_dev_bench_rotate", "md_dev_launch_group", "md_dev_group_max", "md_dev_download_group", "md_dev_reserve_contigs", "md_comm_unique_id", "md_comm_open_rank", "md_comm_open_rank_shared", "md_comm_close", "md_comm_world", "md_comm_gather", "md_comm_wait", "md_comm_result_header", "md_comm_result_send", "md_comm_result_recv", "md_dev_pci_bus_id",
                "md_bench_open", "md_bench_run", "md_bench_verify", "md_bench_region_bytes", "md_bench_close", "md_dev_debug_effective", "md_host_alloc", "md_host_free", "md_host_set_pinned", "md_host_profile", "md_dev_profile_text", "md_host_register", "md_host_register_all",

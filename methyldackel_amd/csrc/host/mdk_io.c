@@ -579,6 +579,10 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
         if(fstat(fileno(b->f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
             void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(b->f), 0);
             if(m != MAP_FAILED) { b->map = m; b->map_len = (size_t)st.st_size; b->map_pos = 0; (void)madvise(m, b->map_len, MADV_SEQUENTIAL); }
+            if(!getenv("MDK_NO_RESERVE_HINT")) {       /* what the device will hold at once: up to 16 pieces being inflated or read in place (0.64 GB each), the chunks' slots and the contigs in use */
+                uint64_t pieces = (uint64_t)st.st_size / (96ull << 20) + 2; if(pieces > 16) pieces = 16;
+                md_dev_reserve_hint(pieces * (640ull << 20) + (6ull << 30));
+            }
         }
     }
     b->nthreads = nthreads < 1 ? 1 : nthreads;

@@ -54,7 +54,7 @@ bool mdk_prof_on() { static const bool on = getenv("MDK_HOST_PROFILE") != nullpt
 double mdk_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 void mdk_prof_add(int site, double seconds) { g_prof_ns[site].fetch_add((uint64_t)(seconds * 1e9), std::memory_order_relaxed); g_prof_calls[site].fetch_add(1, std::memory_order_relaxed); }
 extern "C" int md_dev_profile_text(char *buf, int cap) {
-    static const char *const name[PF_N] = {"upload:wait-for-slot", "upload:alloc", "upload:copies", "launch", "collect:wait", "download:copy", "download:order", "set_reference", "piece:submit", "piece:wait"};
+    static const char *const name[PF_N] = {"upload:wait-for-slot", "upload:alloc", "upload:copies", "launch", "collect:wait", "download:copy", "download:order", "set_reference", "piece:submit", "piece:wait", "group:first-kernel-to-last-on-the-device", "group:launch-call-to-results-on-the-host"};
     int o = 0;
     if(!buf || cap < 1) return MDK_ERR_ARG;
     buf[0] = 0;
@@ -77,6 +77,7 @@ void *arena_take(size_t bytes) {
         if(A.cur < A.blocks.size() && A.used + bytes <= ARENA_BLOCK) { char *p = A.blocks[A.cur] + A.used; A.used += bytes; A.live++; return p; }
         if(A.cur + 1 < A.blocks.size()) { A.cur++; A.used = 0; continue; }
         char *b = nullptr;
+        MarkScope mk("arena hipMalloc 1 GiB");
         if(hipMalloc((void **)&b, ARENA_BLOCK) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         A.blocks.push_back(b); A.cur = A.blocks.size() - 1; A.used = 0;
     }
@@ -90,6 +91,22 @@ void arena_give(void *p) {
         }
     }
 }
+struct CallMark { std::atomic<const char *> what{nullptr}; std::atomic<double> t0{0}; };
+static CallMark g_marks[256]; static std::atomic<int> g_mark_next{0};
+static thread_local int t_mark_base = -1, t_mark_depth = 0;
+int mdk_mark_begin(const char *what) {
+    if(!mdk_prof_on()) return -1;
+    if(t_mark_base < 0) t_mark_base = (g_mark_next.fetch_add(1) & 63) * 4;
+    const int s = t_mark_base + (t_mark_depth < 3 ? t_mark_depth : 3); t_mark_depth++;
+    g_marks[s].t0.store(mdk_now()); g_marks[s].what.store(what);
+    return s;
+}
+void mdk_mark_end(int slot) { if(slot < 0) return; g_marks[slot].what.store(nullptr); if(t_mark_depth > 0) t_mark_depth--; }
+void mdk_marks_dump(const char *why) {
+    const double t = mdk_now(); char buf[1024]; int o = 0;
+    for(int i = 0; i < 256 && o < 900; i++) { const char *w = g_marks[i].what.load(); if(w) o += snprintf(buf + o, sizeof(buf) - (size_t)o, " [%s for %.1f ms]", w, (t - g_marks[i].t0.load()) * 1e3); }
+    fprintf(stderr, "[mdk hip] %s; other threads inside:%s\n", why, o ? buf : " nobody");
+}
 // ... and the same for pinned host memory (HBuf); pinned memory belongs to no device
 struct HArena { std::mutex mu; std::vector<char *> blocks; size_t cur = 0, used = 0; long live = 0; };
 static HArena g_harena;
@@ -102,8 +119,20 @@ void *harena_take(size_t bytes) {
         if(A.cur < A.blocks.size() && A.used + bytes <= HARENA_BLOCK) { char *p = A.blocks[A.cur] + A.used; A.used += bytes; A.live++; return p; }
         if(A.cur + 1 < A.blocks.size()) { A.cur++; A.used = 0; continue; }
         char *b = nullptr;
+        MarkScope mk("harena hipHostMalloc 32 MiB");
         if(hipHostMalloc((void **)&b, HARENA_BLOCK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         A.blocks.push_back(b); A.cur = A.blocks.size() - 1; A.used = 0;
+    }
+}
+static void harena_reserve(size_t n_blocks) {
+    HArena &A = g_harena;
+    if(!g_arena_on) return;
+    for(;;) {
+        { std::lock_guard<std::mutex> lk(A.mu); if(A.blocks.size() >= n_blocks) return; }
+        char *b = nullptr;
+        MarkScope mk("harena_reserve hipHostMalloc 32 MiB");
+        if(hipHostMalloc((void **)&b, HARENA_BLOCK, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return; }
+        std::lock_guard<std::mutex> lk(A.mu); A.blocks.push_back(b);
     }
 }
 void harena_give(void *p) {
@@ -121,9 +150,18 @@ static void arena_reserve(size_t n_blocks) {      // blocks made ahead of their 
     for(;;) {
         { std::lock_guard<std::mutex> lk(A.mu); if(A.blocks.size() >= n_blocks) return; }
         char *b = nullptr;
+        MarkScope mk("arena_reserve hipMalloc 1 GiB");
         if(hipMalloc((void **)&b, ARENA_BLOCK) != hipSuccess) { (void)hipGetLastError(); return; }
         std::lock_guard<std::mutex> lk(A.mu); A.blocks.push_back(b);
     }
+}
+static std::atomic<uint64_t> g_reserve_hint{0};
+static size_t reserve_blocks_wanted() { const uint64_t b = g_reserve_hint.load(); size_t n = (size_t)((b + ARENA_BLOCK - 1) / ARENA_BLOCK); if(n < 4) n = 4; if(n > 40) n = 40; return n; }      // (24 slots of a 30x 1 Mb chunk each carve ~2.5 GiB)
+static std::atomic<int> g_reserve_done{0};      // the warm-up's helper thread has made its blocks: a hint that comes later is acted on by its caller's own helper
+template <typename F> static void side_start(F &&f);
+extern "C" void md_dev_reserve_hint(uint64_t device_bytes) {
+    g_reserve_hint.store(device_bytes);
+    if(g_reserve_done.load()) { int dev = 0; if(hipGetDevice(&dev) == hipSuccess) side_start([dev]() { if(hipSetDevice(dev) == hipSuccess) arena_reserve(reserve_blocks_wanted()); (void)hipGetLastError(); }); }
 }
 static void arena_prime(int device) {          // the first block, while the caller is still starting up (md_dev_warm)
     (void)device;
@@ -595,6 +633,53 @@ __global__ __launch_bounds__(WG, QW ? QW_WAVES : PILEUP_WAVES) void k_pileup_mul
     pileup_tile<VARIANT, QW>(M.P[j], tg - M.tstart[j], b);
 }
 
+// The results of a group launch, put where the host reads them by the device itself: every tile's run of site records is copied to
+// its place in position order (the prefix sum over the tiles' counts: what md_sites_order does on the host) straight into the slot's
+// pinned host buffer, and the slot's status block into the pinned mirror.  The collector then waits for the stream and has everything;
+// the copies it used to queue -- status, then sites, variant counters and tile table of each of eight slots, SDMA and blit kernels by
+// turns on one stream, each hop behind whatever k_inflate had on the device -- took it 5.4 ms per group, three quarters of the streaming
+// phase of a 512 Mb run (profiles/r06i_*).  SlotStatus.pad tells the host what it got: the number of ordered sites, or PACK_NONE when
+// they did not fit the host buffer (or the tile table is inconsistent): that slot is collected by copies as before.
+#define PACK_WG 256
+#define PACK_BLOCKS 8              // workgroups per slot, each copies every eighth tile
+#define PACK_NONE 0xffffffffu
+struct KPackSlot { const md_site *site; const md_site_var *var; const md_tile_seg *tseg; md_site *out; md_site_var *vout; const SlotStatus *d_st; SlotStatus *h_st; int ntiles; uint32_t cap, site_cap; };
+struct KPack { int n; KPackSlot S[MAXM]; };
+__global__ __launch_bounds__(PACK_WG) void k_sites_pack(const KPack K) {
+    const int j = blockIdx.x / PACK_BLOCKS, b = blockIdx.x % PACK_BLOCKS;
+    const KPackSlot &S = K.S[j];
+    __shared__ uint32_t e_off[PACK_WG], e_cnt[PACK_WG], e_dst[PACK_WG], wsum[PACK_WG / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t base = 0; bool bad = false;
+    for(int r0 = 0; r0 < S.ntiles; r0 += PACK_WG) {
+        md_tile_seg sg; sg.off = 0; sg.cnt = 0;
+        if(r0 + tid < S.ntiles) sg = S.tseg[r0 + tid];
+        if((uint64_t)sg.off + sg.cnt > S.site_cap) { bad = true; sg.cnt = 0; }
+        const uint32_t incl = (uint32_t)wave_scan_incl((int)sg.cnt, lane);
+        if(lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t o = base + incl - sg.cnt, tot = 0;
+        for(int w = 0; w < PACK_WG / 64; w++) { if(w < wave) o += wsum[w]; tot += wsum[w]; }
+        e_off[tid] = sg.off; e_cnt[tid] = sg.cnt; e_dst[tid] = o;
+        __syncthreads();
+        const int ne = S.ntiles - r0 < PACK_WG ? S.ntiles - r0 : PACK_WG;
+        if((uint64_t)base + tot <= S.cap)
+            for(int e = b + PACK_BLOCKS * wave; e < ne; e += PACK_BLOCKS * (PACK_WG / 64)) {
+                const uint32_t c = e_cnt[e], src = e_off[e], dst = e_dst[e];
+                for(uint32_t i = lane; i < c; i += 64) { S.out[dst + i] = S.site[src + i]; if(S.var) S.vout[dst + i] = S.var[src + i]; }
+            }
+        base += tot;
+        __syncthreads();
+    }
+    if(b == 0) {
+        const int any_bad = __syncthreads_or(bad ? 1 : 0);
+        const uint32_t *src = (const uint32_t *)S.d_st; uint32_t *dst = (uint32_t *)S.h_st;
+        static_assert(sizeof(SlotStatus) % 4 == 0 && offsetof(SlotStatus, pad) % 4 == 0, "SlotStatus is copied by words");
+        for(int i = tid; i < (int)(sizeof(SlotStatus) / 4); i += PACK_WG)
+            dst[i] = i == (int)(offsetof(SlotStatus, pad) / 4) ? ((any_bad || base > S.cap) ? PACK_NONE : base) : src[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // mbias (MBias.c:57-230): the same admission, segments, context lists and trimming, but no mate-overlap resolution and
 // no per-position counters: every call lands in a histogram over (strand, read number, position in read).
@@ -755,6 +840,28 @@ static hipStream_t stream_take(int device) {
     return s;
 }
 hipStream_t mdk_stream_take(int device) { return stream_take(device); }
+// The device inflate's streams have LOW priority, everybody else's the default.  Not for the order of dispatch in the first place: the runtime keeps a pool
+// of hardware queues PER PRIORITY, so the pieces' streams no longer share hardware queues with the streams the groups of chunks are launched on.
+// With one pool (4 queues for 4 + 3 + 1 streams) a group's five small kernels sat in a queue behind a piece's copy, k_inflate, k_crc32 and walks:
+// 15 ms from the launch call to the results for 0.5-2 ms of kernels, three groups in flight -> a group every 5 ms whatever else got faster
+// (profiles/r06pb_*: MDK_HOST_PROFILE's group lines, the kernel trace: no group kernel runs while pieces are queued).  Round 4's priority experiment
+// (high for the consumer, low for the inflate) predates the group launches and the pieces' shared streams.  MDK_PIECE_PRIO=0: all streams alike.
+static std::vector<hipStream_t> g_stash_piece;      // (g_stash_mu) made by md_dev_warm's side thread
+static bool piece_prio_wanted() { static const bool on = !(getenv("MDK_PIECE_PRIO") && atoi(getenv("MDK_PIECE_PRIO")) == 0); return on; }
+static hipStream_t piece_stream_new() {
+    hipStream_t s = nullptr;
+    if(piece_prio_wanted()) {
+        int least = 0, greatest = 0;
+        if(hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least) == hipSuccess) return s;
+        (void)hipGetLastError(); s = nullptr;
+    }
+    if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
+hipStream_t mdk_piece_stream_take(int device) {
+    { std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev == device && !g_stash_piece.empty()) { hipStream_t s = g_stash_piece.back(); g_stash_piece.pop_back(); return s; } }
+    return piece_stream_new();
+}
 struct WarmScope { WarmScope() { std::lock_guard<std::mutex> lk(g_stash_mu); g_warm_state = 1; } ~WarmScope() { { std::lock_guard<std::mutex> lk(g_stash_mu); g_warm_state = 2; } g_stash_cv.notify_all(); } };
 // The warm-up's side threads.  They are JOINABLE and md_dev_quiesce joins them: before a handle is closed, before the command leaves with
 // _exit (mdk_extract.c leave_fast) -- no thread of this library is inside the runtime when the process goes (round 4's threads were detached,
@@ -800,7 +907,7 @@ extern "C" int md_dev_warm(int device) {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));
     const double t2 = mdk_now();
-    { std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev != device) { g_stash.clear(); g_stash_dev = device; } }
+    { std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev != device) { g_stash.clear(); g_stash_piece.clear(); g_stash_dev = device; } }
     // What the first chunk and the first piece would otherwise pay for on the pipeline's critical path (gpurun_out r04p, 3 ms time series: the first
     // upload took 75 ms and the first group 60 ms, a later group 8): the copy engines' queues in both directions (made at the first copy), carved
     // device blocks, the pieces' streams.  On threads of their own; whoever needs one of them first waits inside the runtime for that one.
@@ -816,7 +923,7 @@ extern "C" int md_dev_warm(int device) {
             });
         side_start([device]() {          // the device inflate's streams (mdk_inflate.hip piece_stream_of takes them from the stash)
             if(hipSetDevice(device) != hipSuccess) return;
-            for(int i = 0; i < 4 && !g_side_quit.load(); i++) { hipStream_t s = nullptr; if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; } std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev == device) g_stash.insert(g_stash.begin(), s); else { (void)hipStreamDestroy(s); return; } }
+            for(int i = 0; i < 6 && !g_side_quit.load(); i++) { hipStream_t s = piece_stream_new(); if(!s) return; std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev == device) g_stash_piece.push_back(s); else { (void)hipStreamDestroy(s); return; } }
         });
         side_start([device]() {
             if(hipSetDevice(device) != hipSuccess) return;
@@ -825,7 +932,8 @@ extern "C" int md_dev_warm(int device) {
             if(hp && dp) { memset(hp, 0, 1u << 20); (void)hipMemcpyAsync(dp, hp, 1u << 20, hipMemcpyHostToDevice, s); (void)hipMemcpyAsync(hp, dp, 1u << 20, hipMemcpyDeviceToHost, s); }
             (void)hipStreamSynchronize(s);
             if(hp) harena_give(hp); if(dp) arena_give(dp);
-            if(!g_side_quit.load()) arena_reserve(4);             // (24 slots of a 30x 1 Mb chunk each carve ~2.5 GiB)
+            if(!g_side_quit.load()) { arena_reserve(reserve_blocks_wanted()); g_reserve_done.store(1); }
+            if(!g_side_quit.load()) harena_reserve(4);            // (the slots' pinned result and table buffers: 2-4 MB each, two dozen slots)
             (void)hipGetLastError();
             std::lock_guard<std::mutex> lk(g_stash_mu); g_stash.push_back(s);
         });
@@ -900,6 +1008,7 @@ extern "C" int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     return 0;
 }
 
+static void ref_release(md_dev *h, size_t tid);
 extern "C" void md_dev_close(md_dev *h) {
     if(!h) return;
     side_join(false);
@@ -908,7 +1017,7 @@ extern "C" void md_dev_close(md_dev *h) {
     for(auto &s : h->slots) {
         s.d_seg_in.release(); s.d_blob.release(); s.d_tiles.release(); s.h_tiles.release();
         s.d_raw.release(); s.d_recoff.release(); s.d_prd.release(); s.d_zero.release();
-        s.d_aidx.release(); s.h_aidx.release(); s.d_hnext.release();
+        s.d_aidx.release(); s.h_aidx.release(); s.d_hnext.release(); s.h_rectab.release();
         s.d_pr.release(); s.d_cig.release(); s.d_prc.release(); s.h_prc.release();
         s.d_site.release(); s.d_var.release(); s.d_seg.release();
         s.h_site.release(); s.h_sorted.release(); s.h_var.release(); s.h_vsorted.release(); s.h_seg.release();
@@ -916,6 +1025,8 @@ extern "C" void md_dev_close(md_dev *h) {
     }
     for(hipStream_t st : h->streams) if(st) (void)hipStreamDestroy(st);
     for(hipStream_t st : h->piece_streams) if(st) (void)hipStreamDestroy(st);
+    if(h->piece_in) (void)hipStreamDestroy(h->piece_in);
+    if(h->piece_inf) (void)hipStreamDestroy(h->piece_inf);
     if(h->ref_stream) (void)hipStreamDestroy(h->ref_stream);
     g_open_handles.fetch_sub(1);                       // (before the last carved buffers go: the give that brings the count to zero may start the blocks over)
     h->d_status.release(); h->h_status.release();
@@ -923,8 +1034,7 @@ extern "C" void md_dev_close(md_dev *h) {
     if(h->d_hist) (void)hipFree(h->d_hist);
     for(uint32_t *p : h->mapbits) if(p) (void)hipFree(p);
     for(md_region *p : h->d_runs) if(p) (void)hipFree(p);
-    for(char *p : h->ref) if(p) (void)hipFree(p);
-    for(uint8_t *p : h->refcode) if(p) (void)hipFree(p);
+    for(size_t t = 0; t < h->ref.size(); t++) ref_release(h, t);
     delete h;
 }
 
@@ -936,23 +1046,34 @@ extern "C" int md_dev_reserve_contigs(md_dev *h, int32_t n) {
     if(!h || n < 0) return fail(MDK_ERR_ARG, "md_dev_reserve_contigs", hipSuccess);
     const size_t k = (size_t)n;
     if(h->ref.size() < k) { h->ref.resize(k, nullptr); h->refcode.resize(k, nullptr); h->reflen.resize(k, 0); }
+    if(h->ref_carved.size() < k) h->ref_carved.resize(k, 0);
     if(h->d_runs.size() < k) { h->d_runs.resize(k, nullptr); h->n_runs.resize(k, 0); h->has_runs.resize(k, 0); }
     if(h->mapbits.size() < k) { h->mapbits.resize(k, nullptr); h->maplen.resize(k, 0); }
     return 0;
 }
 
+static void ref_release(md_dev *h, size_t tid) {
+    const bool carved = tid < h->ref_carved.size() && h->ref_carved[tid];
+    if(h->ref[tid]) { if(carved) arena_give(h->ref[tid]); else (void)hipFree(h->ref[tid]); h->ref[tid] = nullptr; }
+    if(h->refcode[tid]) { if(carved) arena_give(h->refcode[tid]); else (void)hipFree(h->refcode[tid]); h->refcode[tid] = nullptr; }
+    if(tid < h->ref_carved.size()) h->ref_carved[tid] = 0;
+}
 extern "C" int md_dev_set_reference(md_dev *h, int32_t tid, const char *seq, int64_t len) {
     if(!h || tid < 0 || !seq || len < 0) return fail(MDK_ERR_ARG, "md_dev_set_reference", hipSuccess);
-    ProfScope pf(PF_SETREF);
+    ProfScope pf(PF_SETREF); MarkScope mk_ref("md_dev_set_reference");
     HIPCHK(hipSetDevice(h->device));
     if((size_t)tid >= h->ref.size()) { h->ref.resize(tid + 1, nullptr); h->refcode.resize(tid + 1, nullptr); h->reflen.resize(tid + 1, 0); }
-    if(h->ref[tid]) { (void)hipFree(h->ref[tid]); h->ref[tid] = nullptr; }
-    if(h->refcode[tid]) { (void)hipFree(h->refcode[tid]); h->refcode[tid] = nullptr; }
-    char *d = nullptr; uint8_t *c = nullptr;
-    hipError_t e = hipMalloc((void **)&d, (size_t)len + 16);
-    if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(reference)", e);
-    e = hipMalloc((void **)&c, (size_t)len + 16);
-    if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_NOMEM, "hipMalloc(reference codes)", e); }
+    if(h->ref_carved.size() < h->ref.size()) h->ref_carved.resize(h->ref.size(), 0);
+    ref_release(h, tid);
+    char *d = nullptr; uint8_t *c = nullptr; bool carved = false;
+    if((size_t)len + 16 < ARENA_MAX) { d = (char *)arena_take((size_t)len + 16); c = d ? (uint8_t *)arena_take((size_t)len + 16) : nullptr; if(d && !c) { arena_give(d); d = nullptr; } carved = d != nullptr; }      // (made ahead by the warm-up: no allocation next to the pieces' copies)
+    if(!carved) {
+        hipError_t e = hipMalloc((void **)&d, (size_t)len + 16);
+        if(e != hipSuccess) return fail(MDK_ERR_NOMEM, "hipMalloc(reference)", e);
+        e = hipMalloc((void **)&c, (size_t)len + 16);
+        if(e != hipSuccess) { (void)hipFree(d); return fail(MDK_ERR_NOMEM, "hipMalloc(reference codes)", e); }
+    }
+    h->ref_carved[tid] = carved ? 1 : 0;
     // on a stream of its own: a contig can be uploaded (by another thread) while chunks of the contigs before it are worked on, and neither waits for the other
     if(!h->ref_stream && !(h->ref_stream = stream_take(h->device))) return fail(MDK_ERR_HIP, "hipStreamCreateWithFlags", hipGetLastError());
     HIPCHK(hipMemcpyAsync(d, seq, (size_t)len, hipMemcpyHostToDevice, h->ref_stream));
@@ -1075,7 +1196,7 @@ int launch_kernels(md_dev *h, Slot *s, bool time_pileup, hipStream_t on) {
     hipStream_t st = on ? on : s->stream;
     if(s->fresh && st != s->stream) { HIPCHK(hipEventRecord(s->e0, s->stream)); HIPCHK(hipStreamWaitEvent(st, s->e0, 0)); }      // the slot's upload comes first
     if(s->raw_layout && s->prep_pending) { Slot *one[1] = {s}; int rc = enqueue_prep_group(h, one, 1, st); if(rc) return rc; }       // its preparation, then the pileup
-    s->fresh = false; s->run = st;
+    s->fresh = false; s->run = st; s->packed = false;
     s->ring++;                                          // a fresh (already zero) site counter for this launch
     if(s->ntiles > 0) {
         KParams P; int rc = fill_kparams(h, s, P); if(rc) return rc;
@@ -1103,6 +1224,7 @@ extern "C" int md_dev_launch(md_dev *h, int slot) {
 // One kernel launch over up to MAXM uploaded slots (see k_pileup_multi).  The launch goes to the first slot's stream, ordered
 // after whatever the other slots' streams still have queued (their uploads / preparation); every slot's stream then waits
 // for it, so download / wait per slot work as after md_dev_launch.
+static bool pack_wanted() { static const bool on = !getenv("MDK_NO_PACK"); return on; }
 int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cross_sync) {
     if(!h || !slots || n < 1 || n > MAXM) return fail(MDK_ERR_ARG, "md_dev_launch_group: 1..8 slots", hipSuccess);
     static_assert(sizeof(KMulti) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -1123,6 +1245,7 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
         s->fresh = false; s->run = st;
     }
     M.n = n; M.tstart[n] = total; M.nper = (total + 7) / 8;
+    if(mdk_prof_on() && !on) { HIPCHK(hipEventRecord(s0->k0, st)); s0->t_launch = mdk_now(); }      // MDK_HOST_PROFILE: the group's kernels on the device's clock, the launch on the host's
     {   // chunks whose records were uploaded but not prepared yet: their preparation kernels, all chunks per launch
         Slot *pend[MAXM]; int np = 0;
         for(int i = 0; i < n; i++) { Slot *s = get_slot(h, slots[i]); if(s->raw_layout && s->prep_pending) pend[np++] = s; }
@@ -1132,6 +1255,27 @@ int launch_group_on(md_dev *h, const int *slots, int n, hipStream_t on, bool cro
         launch_pileup_multi(h, M.nper * 8, (size_t)s0->lds_bytes, st, M);
         HIPCHK(hipGetLastError());
     }
+    for(int i = 0; i < n; i++) get_slot(h, slots[i])->packed = false;
+    if(pack_wanted() && !on) {      // (not in the benchmarks' resident loops: their step is preparation + pileup) the ordered sites and the status blocks go to pinned host memory by a kernel of the same stream (k_sites_pack)
+        KPack K; memset(&K, 0, sizeof(K)); K.n = n; bool ok = true;
+        for(int i = 0; i < n && ok; i++) {
+            Slot *s = get_slot(h, slots[i]);
+            if(s->b_site) { ok = false; break; }               // caller-bound device output (the exchange between GPUs reads it there)
+            const size_t span = (size_t)(s->end > s->beg ? s->end - s->beg : 0);
+            size_t want = std::max<size_t>(span / 8, 65536); want = std::min(want, span + 16);      // (a slot that met more sites than this before has grown its buffer to fit them: md_dev_download_group)
+            if(s->h_sorted.need(want) || (h->variant && s->h_vsorted.need(s->h_sorted.cap))) { (void)hipGetLastError(); ok = false; break; }
+            KPackSlot &S = K.S[i];
+            S.site = s->d_site.p; S.var = h->variant ? s->d_var.p : nullptr; S.tseg = s->d_seg.p; S.out = s->h_sorted.p; S.vout = h->variant ? s->h_vsorted.p : nullptr;
+            S.d_st = h->d_status.p + s->index; S.h_st = h->h_status.p + s->index; S.ntiles = s->ntiles > 0 ? s->ntiles : 0;
+            S.cap = (uint32_t)std::min<size_t>(h->variant ? std::min(s->h_sorted.cap, s->h_vsorted.cap) : s->h_sorted.cap, 0xfffffff0u); S.site_cap = (uint32_t)std::min<size_t>(s->d_site.cap, 0xfffffff0u);
+        }
+        if(ok) {
+            hipLaunchKernelGGL(k_sites_pack, dim3(n * PACK_BLOCKS), dim3(PACK_WG), 0, st, K);
+            HIPCHK(hipGetLastError());
+            for(int i = 0; i < n; i++) get_slot(h, slots[i])->packed = true;
+        }
+    }
+    if(mdk_prof_on() && !on) HIPCHK(hipEventRecord(s0->k1, st));
     for(int i = 0; i < n; i++) get_slot(h, slots[i])->launched = true;      // collected through each slot's `run` stream (finish_count)
     return 0;
 }
@@ -1142,7 +1286,10 @@ extern "C" int md_dev_launch_group(md_dev *h, const int *slots, int n) {
     if(!h) return fail(MDK_ERR_ARG, "md_dev_launch_group", hipSuccess);
     ProfScope pf(PF_LAUNCH);
     HIPCHK(hipSetDevice(h->device));
-    return launch_group_on(h, slots, n, nullptr, true);
+    const double t0 = mdk_prof_on() ? mdk_now() : 0;
+    int rc; { MarkScope mk("md_dev_launch_group"); rc = launch_group_on(h, slots, n, nullptr, true); }
+    if(mdk_prof_on() && mdk_now() - t0 > 0.004) { char w[96]; snprintf(w, sizeof(w), "slow md_dev_launch_group: %.1f ms", (mdk_now() - t0) * 1e3); mdk_marks_dump(w); }
+    return rc;
 }
 extern "C" int md_dev_group_max(void) { return MAXM; }
 
@@ -1422,33 +1569,46 @@ extern "C" int md_dev_download_group(md_dev *h, const int *slots, int n, md_site
         return 0;
     }
     static std::atomic<int> first_call{1}; const bool first = mdk_prof_on() && first_call.exchange(0); const double tf0 = first ? mdk_now() : 0;
+    bool all_packed = true; for(int i = 0; i < n; i++) all_packed = all_packed && ss[i]->packed;
     {
         ProfScope pf(PF_FIN_WAIT);
-        if(hipMemcpyAsync(h->h_status.p + lo, h->d_status.p + lo, sizeof(SlotStatus) * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MDK_ERR_HIP, "D2H status", hipGetLastError());
+        // (a packed group's status blocks were written into the pinned mirror by k_sites_pack: the wait is all there is)
+        if(!all_packed && hipMemcpyAsync(h->h_status.p + lo, h->d_status.p + lo, sizeof(SlotStatus) * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, st) != hipSuccess) return fail(MDK_ERR_HIP, "D2H status", hipGetLastError());
         hipError_t e = hipStreamSynchronize(st);
         if(e != hipSuccess) return fail(MDK_ERR_HIP, "hipStreamSynchronize", e);
     }
     if(first) fprintf(stderr, "[mdk hip] the first group's results waited for %.3fs\n", mdk_now() - tf0);
-    for(int i = 0; i < n; i++) { cnt[i] = finish_eval(h, ss[i]); if(cnt[i] < 0) rcs[i] = (int)cnt[i]; }      // (a chunk whose segment array had to grow is prepared and piled up again in there)
+    if(mdk_prof_on() && ss[0]->t_launch > 0) { float ms = 0; if(hipEventElapsedTime(&ms, ss[0]->k0, ss[0]->k1) == hipSuccess) mdk_prof_add(PF_GRP_DEV, ms * 1e-3); else (void)hipGetLastError(); mdk_prof_add(PF_GRP_TURN, mdk_now() - ss[0]->t_launch); ss[0]->t_launch = 0; }
+    uint32_t packed_n[MAXM];
+    for(int i = 0; i < n; i++) {
+        packed_n[i] = (all_packed && ss[i]->packed) ? ss[i]->h_st.p->pad : PACK_NONE;
+        cnt[i] = finish_eval(h, ss[i]); if(cnt[i] < 0) rcs[i] = (int)cnt[i];      // (a chunk whose segment array had to grow is prepared and piled up again in there: what was packed is void then)
+        if(!ss[i]->packed) packed_n[i] = PACK_NONE;
+    }
     {
         ProfScope pf(PF_DL_COPY);
+        bool any = false;
         for(int i = 0; i < n; i++) {
-            Slot *s = ss[i]; if(rcs[i] || cnt[i] == 0) continue;
+            Slot *s = ss[i]; if(rcs[i] || cnt[i] == 0 || packed_n[i] != PACK_NONE) continue;
             const size_t nn = (size_t)cnt[i], nt = (size_t)(s->ntiles > 0 ? s->ntiles : 1);
             if(s->h_site.need(nn + 1) || s->h_sorted.need(nn + 1) || s->h_seg.need(nt) || (h->variant && (s->h_var.need(nn + 1) || s->h_vsorted.need(nn + 1)))) { rcs[i] = MDK_ERR_NOMEM; continue; }
             const md_site *d_site = s->b_site ? s->b_site : s->d_site.p; const md_site_var *d_var = s->b_site ? s->b_var : s->d_var.p; const md_tile_seg *d_seg = s->b_site ? s->b_seg : s->d_seg.p;
-            HIPCHK(hipMemcpyAsync(s->h_site.p, d_site, nn * sizeof(md_site), hipMemcpyDeviceToHost, st));
-            if(h->variant) HIPCHK(hipMemcpyAsync(s->h_var.p, d_var, nn * sizeof(md_site_var), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(s->h_seg.p, d_seg, (size_t)s->ntiles * sizeof(md_tile_seg), hipMemcpyDeviceToHost, st));
+            hipStream_t cs = s->run ? s->run : st;
+            HIPCHK(hipMemcpyAsync(s->h_site.p, d_site, nn * sizeof(md_site), hipMemcpyDeviceToHost, cs));
+            if(h->variant) HIPCHK(hipMemcpyAsync(s->h_var.p, d_var, nn * sizeof(md_site_var), hipMemcpyDeviceToHost, cs));
+            HIPCHK(hipMemcpyAsync(s->h_seg.p, d_seg, (size_t)s->ntiles * sizeof(md_tile_seg), hipMemcpyDeviceToHost, cs));
+            if(cs != st) HIPCHK(hipStreamSynchronize(cs));
+            any = true;
         }
-        HIPCHK(hipStreamSynchronize(st));
+        if(any) HIPCHK(hipStreamSynchronize(st));
     }
     for(int i = 0; i < n; i++) ss[i]->busy = false;   // the stream has been waited for and nothing was queued since (a slot that reported an error included)
     ProfScope pf2(PF_DL_ORDER);
     for(int i = 0; i < n; i++) {
         Slot *s = ss[i]; if(rcs[i]) continue;
         int64_t nsites = 0;
-        if(cnt[i]) {
+        if(packed_n[i] != PACK_NONE) nsites = (int64_t)packed_n[i];
+        else if(cnt[i]) {
             nsites = md_sites_order(s->h_site.p, h->variant ? s->h_var.p : nullptr, s->h_seg.p, s->ntiles, cnt[i], s->h_sorted.p, h->variant ? s->h_vsorted.p : nullptr);
             if(nsites < 0) { rcs[i] = fail(MDK_ERR_ARG, "md_dev_download_group: inconsistent tile segments", hipSuccess); continue; }
         }
@@ -1605,7 +1765,7 @@ MDK_HIDDEN void host_block_ensure_registered(const void *ptr) {
         char *const base = it->base; const size_t len = it->len; it->state = 1;
         lk.unlock();
         const auto t0 = std::chrono::steady_clock::now();
-        const bool ok = hipHostRegister(base, len, hipHostRegisterDefault) == hipSuccess;
+        bool ok; { MarkScope mk("hipHostRegister"); ok = hipHostRegister(base, len, hipHostRegisterDefault) == hipSuccess; }
         if(!ok) (void)hipGetLastError();                             // a block that cannot be registered is uploaded pageable
         const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         lk.lock();
@@ -1643,13 +1803,13 @@ extern "C" void *md_host_alloc(uint64_t bytes) {
     static std::once_flag once; static int pinned_ok = 0;          // several chunk workers may be the first caller at the same time
     if(!g_want_pinned.load()) return plain_alloc(n);               // (does not touch the HIP runtime)
     std::call_once(once, [] { int c = 0; pinned_ok = (!getenv("MDK_NO_PIN") && hipGetDeviceCount(&c) == hipSuccess && c > 0) ? 1 : 0; });
-    if(pinned_ok && hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess) { memcpy(p, "MDKPIN", 7); return (char *)p + 64; }
+    if(pinned_ok) { MarkScope mk("md_host_alloc hipHostMalloc"); if(hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess) { memcpy(p, "MDKPIN", 7); return (char *)p + 64; } }
     return plain_alloc(n);
 }
 extern "C" void md_host_free(void *q) {
     if(!q) return;
     char *p = (char *)q - 64;
-    if(!memcmp(p, "MDKPIN", 7)) { (void)hipHostFree(p); return; }
+    if(!memcmp(p, "MDKPIN", 7)) { MarkScope mk("md_host_free hipHostFree"); (void)hipHostFree(p); return; }
     {
         std::unique_lock<std::mutex> lk(g_blocks_mu);
         HostBlock key{p, 0, 0};
@@ -1659,7 +1819,7 @@ extern "C" void md_host_free(void *q) {
             if(it->state == 1) { g_blocks_cv.wait(lk); continue; }          // somebody is registering it (or taking its registration away) right now
             if(it->state == 2) {                                            // the lock is given up while the runtime unpins the block: uploaders looking their blocks up do not queue behind it
                 it->state = 1; lk.unlock();
-                (void)hipHostUnregister(p);
+                { MarkScope mk("hipHostUnregister"); (void)hipHostUnregister(p); }
                 lk.lock();
                 it = std::lower_bound(g_blocks.begin(), g_blocks.end(), key, block_less);
                 if(it != g_blocks.end() && it->base == p) g_blocks.erase(it);

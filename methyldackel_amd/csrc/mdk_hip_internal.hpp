@@ -23,6 +23,12 @@ MDK_HIDDEN char *mdk_err_buf();            // the calling thread's message buffe
 MDK_HIDDEN int fail(int code, const char *what, hipError_t e);
 #define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return fail(MDK_ERR_HIP, #call, e_); } while(0)
 
+// MDK_HOST_PROFILE: which of this library's calls into the runtime are under way, per thread -- when one call takes long, what the others were inside
+// is printed next to it (the runtime serialises more than its interface says: a hipFree waits for the whole device, registrations hold its memory lock)
+MDK_HIDDEN int mdk_mark_begin(const char *what);
+MDK_HIDDEN void mdk_mark_end(int slot);
+MDK_HIDDEN void mdk_marks_dump(const char *why);
+struct MarkScope { int s; MarkScope(const char *w) : s(mdk_mark_begin(w)) {} ~MarkScope() { mdk_mark_end(s); } };
 struct TileEnt { int first, last; };     // segments [first,last) of the batch overlap the tile (one contiguous run: the batch is coordinate sorted)
 
 // Device buffers.  A hipMalloc costs the calling thread ~0.2 ms whatever its size, and a slot needs ten buffers the first time it is used
@@ -30,7 +36,7 @@ struct TileEnt { int first, last; };     // segments [first,last) of the batch o
 // block, per device).  Carved memory is handed back only when the last carved buffer of the device is released -- then the blocks are
 // reused from their start --, and a buffer that grows takes a new piece: 288 GB of HBM make that a fair price.
 #define ARENA_BLOCK (1ull << 30)
-#define ARENA_MAX (256ull << 20)
+#define ARENA_MAX (512ull << 20)      /* (a 96 MB piece's inflated bytes with their headroom are 420 MB) */
 MDK_HIDDEN void *arena_take(size_t bytes);          // NULL: no room could be made (the caller falls back to hipMalloc)
 MDK_HIDDEN void arena_give(void *p);
 template <typename T> struct DBuf {
@@ -40,11 +46,12 @@ template <typename T> struct DBuf {
         release();
         size_t want = n + n / 4 + 64;
         if(want * sizeof(T) < ARENA_MAX) { p = (T *)arena_take(want * sizeof(T)); if(p) { carved = true; cap = want; return 0; } }
+        MarkScope mk("DBuf hipMalloc");
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
         if(e != hipSuccess) { p = nullptr; return fail(MDK_ERR_NOMEM, "hipMalloc", e); }
         cap = want; return 0;
     }
-    void release() { if(p) { if(carved) arena_give(p); else (void)hipFree(p); } p = nullptr; cap = 0; carved = false; }
+    void release() { if(p) { if(carved) arena_give(p); else { MarkScope mk("DBuf hipFree"); (void)hipFree(p); } } p = nullptr; cap = 0; carved = false; }
 };
 // pinned host buffers (results on their way back): a hipHostMalloc costs the calling thread ~1 ms, and every slot needs three the first time
 // its results are collected -- small ones are carved out of 32 MiB pinned blocks the same way
@@ -59,11 +66,12 @@ template <typename T> struct HBuf {
         release();
         size_t want = n + n / 4 + 64;
         if(want * sizeof(T) < HARENA_MAX) { p = (T *)harena_take(want * sizeof(T)); if(p) { carved = true; cap = want; return 0; } }
+        MarkScope mk("HBuf hipHostMalloc");
         hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
         if(e != hipSuccess) { p = nullptr; return fail(MDK_ERR_NOMEM, "hipHostMalloc", e); }
         cap = want; return 0;
     }
-    void release() { if(p) { if(carved) harena_give(p); else (void)hipHostFree(p); } p = nullptr; cap = 0; carved = false; }
+    void release() { if(p) { if(carved) harena_give(p); else { MarkScope mk("HBuf hipHostFree"); (void)hipHostFree(p); } } p = nullptr; cap = 0; carved = false; }
 };
 
 // device chunk preparation (mdk_prep.hip)
@@ -96,7 +104,8 @@ struct Slot {
     DBuf<md_site> d_site; DBuf<md_site_var> d_var; DBuf<md_tile_seg> d_seg; Ref<uint32_t> d_total; Ref<int> d_err;
     HBuf<md_site> h_site, h_sorted; HBuf<md_site_var> h_var, h_vsorted; HBuf<md_tile_seg> h_seg; Ref<SlotStatus> h_st; int index = 0;
     hipStream_t run = nullptr; bool fresh = false;       // run: the stream the latest pileup launch went to; fresh: work queued on `stream` that no launch has been ordered after yet
-    DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; DBuf<PrepRead> d_prd; DBuf<uint32_t> d_aidx; HBuf<uint32_t> h_aidx; DBuf<int32_t> d_hnext; Ref<PrepCounters> d_pcnt;
+    DBuf<uint8_t> d_raw; DBuf<uint32_t> d_recoff; HBuf<uint32_t> h_rectab;      /* h_rectab: the host's record tables on their way to d_recoff, pinned */
+    DBuf<PrepRead> d_prd; DBuf<uint32_t> d_aidx; HBuf<uint32_t> h_aidx; DBuf<int32_t> d_hnext; Ref<PrepCounters> d_pcnt;
     DBuf<uint8_t> d_zero;              // what a preparation launch starts from zeroed: name table (keys, heads), per-workgroup counts, tickets
     uint32_t hmask = 0; int pr_nrec = 0; uint64_t raw_bytes = 0; bool raw_layout = false; int64_t woff = 0, wlen = 0;
     // where the kernels find the chunk's records and their table: the slot's own copies (d_raw, d_recoff), or -- md_dev_upload_raw_inplace -- the caller's piece:
@@ -109,6 +118,8 @@ struct Slot {
     md_site *b_site = nullptr; md_site_var *b_var = nullptr; md_tile_seg *b_seg = nullptr; int64_t b_cap_sites = 0, b_cap_tiles = 0;
     int n_segs = 0, n_reads = 0, ntiles = 0, tid = -1, tile = 0, lds_bytes = 0; int64_t beg = 0, end = 0; uint64_t read_bytes = 0;
     bool uploaded = false, launched = false; unsigned ring = 0;
+    double t_launch = 0;               // MDK_HOST_PROFILE: when the group launch this slot led was issued
+    bool packed = false;               // the latest launch was a group launch that also put the slot's ordered sites and status into pinned host memory (k_sites_pack)
     bool busy = false;                 // work of this slot may still be running on its stream (uploaded or launched, results not collected yet): the next upload waits for the stream first
 };
 
@@ -116,10 +127,10 @@ struct md_dev {
     int device; md_dev_cfg cfg; int tile, n_slots; bool variant; bool qw = false;
     std::vector<hipStream_t> streams;        // the streams the slots work on (cfg.n_streams of them, or one per slot)
     std::mutex crc_mu; void *d_crc = nullptr;   // constants of k_crc32 (mdk_inflate.hip), made by the first piece
-    std::mutex piece_mu; std::vector<hipStream_t> piece_streams; int piece_rr = 0;      // the pieces' streams: a few, shared (mdk_inflate.hip piece_stream_of)
+    std::mutex piece_mu; std::vector<hipStream_t> piece_streams; int piece_rr = 0; hipStream_t piece_in = nullptr, piece_inf = nullptr;      /* the pieces' lanes (mdk_inflate.hip): the stream their compressed bytes cross the link on, the stream k_inflate runs on */      // the pieces' streams: a few, shared (mdk_inflate.hip piece_stream_of)
     hipStream_t ref_stream = nullptr;           // md_dev_set_reference works here, so that it neither waits for nor holds up the slots' streams    /* qw: dense contexts, a quarter of a wavefront per segment */
     std::vector<Slot> slots;
-    std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen;
+    std::vector<char *> ref; std::vector<uint8_t *> refcode; std::vector<int64_t> reflen; std::vector<char> ref_carved;      /* ref_carved[tid]: the contig's two arrays came out of the carved blocks */
     DBuf<SlotStatus> d_status; HBuf<SlotStatus> h_status;
     md_prep_cfg prep; bool prep_set = false; std::vector<uint32_t *> mapbits; std::vector<int64_t> maplen;
     std::vector<md_region *> d_runs; std::vector<int64_t> n_runs; std::vector<char> has_runs;       // -l runs kept for the read prefilter
@@ -169,7 +180,7 @@ __device__ __forceinline__ md_pr_count perread_walk(const uint8_t *seq, const ui
 }
 
 // MDK_HOST_PROFILE=1: where the host threads' time inside the library goes (seconds and calls per site), printed by md_dev_profile_dump
-enum { PF_UP_SYNC = 0, PF_UP_ALLOC, PF_UP_COPY, PF_LAUNCH, PF_FIN_WAIT, PF_DL_COPY, PF_DL_ORDER, PF_SETREF, PF_PIECE_SUBMIT, PF_PIECE_WAIT, PF_N };
+enum { PF_UP_SYNC = 0, PF_UP_ALLOC, PF_UP_COPY, PF_LAUNCH, PF_FIN_WAIT, PF_DL_COPY, PF_DL_ORDER, PF_SETREF, PF_PIECE_SUBMIT, PF_PIECE_WAIT, PF_GRP_DEV, PF_GRP_TURN, PF_N };
 MDK_HIDDEN bool mdk_prof_on();
 MDK_HIDDEN void mdk_prof_add(int site, double seconds);
 MDK_HIDDEN double mdk_now();
@@ -184,6 +195,7 @@ MDK_HIDDEN int finish_group(md_dev *h, const int *slots, int n, int64_t *counts)
 MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s);
 MDK_HIDDEN int prep_kernels_init();           // mdk_prep.hip: its code object loaded, the scan kernel's LDS limit set (once per process)
 MDK_HIDDEN void inflate_kernels_warm();
+MDK_HIDDEN hipStream_t mdk_piece_stream_take(int device);      // a low-priority stream for the device inflate (its own pool of hardware queues)
 MDK_HIDDEN hipStream_t mdk_stream_take(int device);       // a stream made ahead by md_dev_warm, or a new one      // mdk_inflate.hip: its code object loaded
 MDK_HIDDEN int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st);      // preparation kernels of up to MAXM uploaded raw slots, one launch each kernel
 #endif

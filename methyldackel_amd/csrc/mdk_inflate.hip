@@ -406,7 +406,7 @@ static hipStream_t piece_stream_make(int device) {
         if(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask) == hipSuccess) return s;
         (void)hipGetLastError();
     }
-    return mdk_stream_take(device);
+    return mdk_piece_stream_take(device);
 }
 static int inflate_grid_max(int device) {
     static int cached[64] = {0};
@@ -423,14 +423,13 @@ static int inflate_grid_max(int device) {
     return cached[slot];
 }
 static inline int inflate_grid(int device, int n_mem) { const int g = inflate_grid_max(device); return n_mem < g ? n_mem : g; }
-static hipError_t launch_inflate(int device, int n_mem, hipStream_t st, const InfParams &IP) {
-    hipError_t e = hipMemsetAsync(IP.status + 2, 0, 4, st);
-    if(e != hipSuccess) return e;
+static hipError_t launch_inflate(int device, int n_mem, hipStream_t st, const InfParams &IP, bool counter_is_zero = false) {
+    if(!counter_is_zero) { hipError_t e = hipMemsetAsync(IP.status + 2, 0, 4, st); if(e != hipSuccess) return e; }
     hipLaunchKernelGGL(k_inflate, dim3(inflate_grid(device, n_mem)), dim3(64), 0, st, IP);
     return hipGetLastError();
 }
 struct md_piece {
-    md_dev *h = nullptr; hipStream_t stream = nullptr; hipEvent_t done = nullptr;
+    md_dev *h = nullptr; hipStream_t stream = nullptr; hipEvent_t done = nullptr, ev_in = nullptr, ev_inf = nullptr;
     DBuf<uint8_t> d_comp, d_out; DBuf<md_inf_member> d_mem; DBuf<uint32_t> d_cnt, d_first, d_recoff, d_status, d_tok; DBuf<md_inf_digest> d_dig;
     HBuf<md_inf_digest> h_dig; HBuf<uint32_t> h_status;
     int n_mem = 0; uint64_t out_bytes = 0, comp_bytes = 0; uint32_t n_rec_cap = 0; bool busy = false;
@@ -472,6 +471,24 @@ static hipStream_t piece_stream_of(md_dev *h, bool *own) {
     if((int)h->piece_streams.size() < want) { hipStream_t s = piece_stream_make(h->device); if(!s) return nullptr; h->piece_streams.push_back(s); return s; }
     return h->piece_streams[(size_t)(h->piece_rr++ % want)];
 }
+// The pieces' LANES.  A piece's work used to sit on one of four streams from its copy to its digests, so up to four k_inflate ran at a time: each
+// took 4.3-4.8 ms instead of the 2.9 it takes alone, and -- its wavefronts draw members until none is left -- gave its LDS back in 12.9 KB
+// slots that the next launch's wavefronts took at once: a workgroup of k_prep_scan (76 KB) or k_crc32 found room only when all queued pieces
+// had run dry (k_prep_scan 0.9 ms instead of 0.18, k_crc32 1.4 instead of 0.13, the device idle for 10-16 ms at a time while three groups of
+// chunks waited for it: profiles/r06pc_*).  Now every handle has ONE stream the compressed bytes of all pieces cross the link on, in the order
+// submitted and at the link's full rate each, and ONE stream all k_inflate run on, one after the other: a launch has the device to itself,
+// and where its last wavefronts end everybody else's small kernels find the CUs empty.  CRC, record walk and the digests' way back stay on the
+// piece's own (shared) stream, ordered by events.  MDK_PIECE_LANES=0: everything on the piece's stream as before.
+static bool piece_lanes_wanted() { static const bool on = !(getenv("MDK_PIECE_LANES") && atoi(getenv("MDK_PIECE_LANES")) == 0); return on; }
+static bool piece_lanes_of(md_dev *h, hipStream_t *in, hipStream_t *inf) {
+    if(!piece_lanes_wanted()) return false;
+    std::lock_guard<std::mutex> lk(h->piece_mu);
+    if(!h->piece_in) h->piece_in = piece_stream_make(h->device);
+    if(!h->piece_inf) h->piece_inf = piece_stream_make(h->device);
+    if(!h->piece_in || !h->piece_inf) return false;
+    *in = h->piece_in; *inf = h->piece_inf;
+    return true;
+}
 static hipError_t piece_sync(md_piece *p) { return p->recorded ? hipEventSynchronize(p->done) : hipSuccess; }      // the piece's own work, not its stream's
 extern "C" int md_piece_members_per_round(md_dev *h) { if(!h) return 0; if(hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return 0; } return inflate_grid_max(h->device); }
 extern "C" int md_piece_create(md_dev *h, md_piece **out) {
@@ -479,7 +496,7 @@ extern "C" int md_piece_create(md_dev *h, md_piece **out) {
     *out = nullptr;
     HIPCHK(hipSetDevice(h->device));
     md_piece *p = new md_piece(); p->h = h;
-    if(!(p->stream = piece_stream_of(h, &p->own_stream)) || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) { if(p->own_stream && p->stream) (void)hipStreamDestroy(p->stream); delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
+    if(!(p->stream = piece_stream_of(h, &p->own_stream)) || hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&p->ev_inf, hipEventDisableTiming) != hipSuccess) { if(p->own_stream && p->stream) (void)hipStreamDestroy(p->stream); delete p; return fail(MDK_ERR_HIP, "md_piece_create: stream", hipGetLastError()); }
     if(p->d_status.need(4) || p->h_status.need(4)) { delete p; return MDK_ERR_NOMEM; }
     p->check_crc = !getenv("MDK_NO_CRC");
     if(p->check_crc && !crc_const_of(h)) { delete p; return fail(MDK_ERR_NOMEM, "md_piece_create: CRC tables", hipSuccess); }
@@ -492,6 +509,8 @@ extern "C" void md_piece_destroy(md_piece *p) {
     (void)piece_sync(p);
     if(p->own_stream && p->stream) (void)hipStreamDestroy(p->stream);
     if(p->done) (void)hipEventDestroy(p->done);
+    if(p->ev_in) (void)hipEventDestroy(p->ev_in);
+    if(p->ev_inf) (void)hipEventDestroy(p->ev_inf);
     p->d_comp.release(); p->d_out.release(); p->d_mem.release(); p->d_cnt.release(); p->d_first.release(); p->d_recoff.release(); p->d_status.release(); p->d_tok.release(); p->d_dig.release();
     p->h_dig.release(); p->h_status.release();
     delete p;
@@ -501,7 +520,7 @@ extern "C" void md_piece_destroy(md_piece *p) {
 // stream; md_piece_wait returns when it is all done.  comp should be pinned memory (md_host_alloc) for the copy to be a DMA.
 extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_bytes, const md_inf_member *mem, int n_mem) {
     if(!p || !comp || !mem || n_mem < 1) return fail(MDK_ERR_ARG, "md_piece_submit", hipSuccess);
-    ProfScope pf(PF_PIECE_SUBMIT);
+    ProfScope pf(PF_PIECE_SUBMIT); MarkScope mk_sub("md_piece_submit");
     md_dev *h = p->h;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(piece_sync(p));
@@ -515,16 +534,19 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
     if(p->d_comp.need((size_t)comp_bytes + 1024) || p->d_out.need((size_t)out_bytes + 1024) || p->d_mem.need((size_t)n_mem) || p->d_cnt.need((size_t)n_mem) || p->d_first.need((size_t)n_mem) ||
        p->d_dig.need((size_t)n_mem) || p->h_dig.need((size_t)n_mem) || p->d_recoff.need((size_t)rec_cap) || p->d_tok.need((size_t)inflate_grid(h->device, n_mem) * INF_TOK_WORDS)) return MDK_ERR_NOMEM;
     p->n_mem = n_mem; p->out_bytes = out_bytes; p->comp_bytes = comp_bytes; p->n_rec_cap = rec_cap;
-    hipStream_t st = p->stream;
+    hipStream_t st = p->stream, s_in = st, s_inf = st;
+    const bool lanes = piece_lanes_of(h, &s_in, &s_inf);
     host_block_ensure_registered(comp);
-    HIPCHK(hipMemcpyAsync(p->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->d_mem.p, mem, sizeof(md_inf_member) * (size_t)n_mem, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(p->d_status.p, 0, 16, st));
+    HIPCHK(hipMemcpyAsync(p->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, s_in));
+    HIPCHK(hipMemcpyAsync(p->d_mem.p, mem, sizeof(md_inf_member) * (size_t)n_mem, hipMemcpyHostToDevice, s_in));
+    HIPCHK(hipMemsetAsync(p->d_status.p, 0, 16, s_in));          // (error word, record count, the launch's member counter)
+    if(lanes) { HIPCHK(hipEventRecord(p->ev_in, s_in)); HIPCHK(hipStreamWaitEvent(s_inf, p->ev_in, 0)); }
     InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p; IP.tok = p->d_tok.p;
 #ifdef INF_PROFILE
     { static unsigned long long *dp = nullptr; if(!dp) { (void)hipMalloc((void **)&dp, 16 * 8); (void)hipMemset(dp, 0, 16 * 8); } IP.prof = dp; }
 #endif
-    HIPCHK(launch_inflate(h->device, n_mem, st, IP));
+    HIPCHK(launch_inflate(h->device, n_mem, s_inf, IP, true));
+    if(lanes) { HIPCHK(hipEventRecord(p->ev_inf, s_inf)); HIPCHK(hipStreamWaitEvent(st, p->ev_inf, 0)); }
     if(p->check_crc) launch_crc(h, p, st);
     WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
     hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);

@@ -900,6 +900,10 @@ static int copy_ranges(md_dev *h, Slot *s, const md_raw_batch *b) {
     for(int i = 0; i < b->n_ranges; i++) { const md_raw_range &r = b->range[i]; if(r.d_rec_off || r.h_rec_off) any_tab = true; else loose += r.n_records; nrec_sum += r.n_records; }
     if((any_tab ? loose : (uint64_t)b->n_records) && !b->rec_off) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null record table", hipSuccess);
     if(any_tab && nrec_sum != (uint64_t)b->n_records) return fail(MDK_ERR_ARG, "md_dev_upload_raw: with a range that has its own record table every range must carry its record count", hipSuccess);
+    // The host's record tables (a slab's own, or the slot's list) are ordinary memory: copied from there, every table would be a staged copy that
+    // returns when it has been made -- after everything queued on the stream before it, the chunk's 57 MB of records included (the thread that
+    // uploads stood 5-35 ms in such a call, a dozen times per run: profiles/r06pf_*).  They go through a pinned table of the slot instead.
+    if(b->n_records && s->h_rectab.need((size_t)b->n_records + 1)) return MDK_ERR_NOMEM;
     uint64_t o = 0; uint32_t idx = 0, hidx = 0;
     for(int i = 0; i < b->n_ranges; i++) {
         const md_raw_range &r = b->range[i];
@@ -910,17 +914,24 @@ static int copy_ranges(md_dev *h, Slot *s, const md_raw_batch *b) {
             if(r.bytes) { host_block_ensure_registered(r.ptr); HIPCHK(hipMemcpyAsync(s->d_raw.p + o, r.ptr, (size_t)r.bytes, hipMemcpyHostToDevice, s->stream)); }
             if(r.h_rec_off) {          // the range's own table: as it is, then re-based where it lands
                 if(r.n_records) {
-                    HIPCHK(hipMemcpyAsync(s->d_recoff.p + idx, r.h_rec_off, sizeof(uint32_t) * (size_t)r.n_records, hipMemcpyHostToDevice, s->stream));
+                    memcpy(s->h_rectab.p + idx, r.h_rec_off, sizeof(uint32_t) * (size_t)r.n_records);
+                    HIPCHK(hipMemcpyAsync(s->d_recoff.p + idx, s->h_rectab.p + idx, sizeof(uint32_t) * (size_t)r.n_records, hipMemcpyHostToDevice, s->stream));
                     hipLaunchKernelGGL(k_rebase, dim3((r.n_records + 255) / 256), dim3(256), 0, s->stream, s->d_recoff.p + idx, (const uint32_t *)(s->d_recoff.p + idx), r.n_records, (uint32_t)o - r.rec_delta);
                 }
             } else {
-                if(any_tab && r.n_records) HIPCHK(hipMemcpyAsync(s->d_recoff.p + idx, b->rec_off + hidx, sizeof(uint32_t) * (size_t)r.n_records, hipMemcpyHostToDevice, s->stream));
+                if(any_tab && r.n_records) {
+                    memcpy(s->h_rectab.p + idx, b->rec_off + hidx, sizeof(uint32_t) * (size_t)r.n_records);
+                    HIPCHK(hipMemcpyAsync(s->d_recoff.p + idx, s->h_rectab.p + idx, sizeof(uint32_t) * (size_t)r.n_records, hipMemcpyHostToDevice, s->stream));
+                }
                 hidx += r.n_records;
             }
         }
         idx += r.n_records; o += r.bytes;
     }
-    if(!any_tab && b->n_records) { host_block_ensure_registered(b->rec_off); HIPCHK(hipMemcpyAsync(s->d_recoff.p, b->rec_off, sizeof(uint32_t) * (size_t)b->n_records, hipMemcpyHostToDevice, s->stream)); }
+    if(!any_tab && b->n_records) {
+        memcpy(s->h_rectab.p, b->rec_off, sizeof(uint32_t) * (size_t)b->n_records);
+        HIPCHK(hipMemcpyAsync(s->d_recoff.p, s->h_rectab.p, sizeof(uint32_t) * (size_t)b->n_records, hipMemcpyHostToDevice, s->stream));
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1030,11 +1041,14 @@ static int upload_raw(md_dev *h, int slot, const md_raw_batch *b, bool may_stay)
     if(b->n_records && !b->range) return fail(MDK_ERR_ARG, "md_dev_upload_raw: null array", hipSuccess);
     if(b->tid < 0) return fail(MDK_ERR_ARG, "md_dev_upload_raw: contig", hipSuccess);      /* (the contig's reference is needed when the slot is launched, not yet here) */
     HIPCHK(hipSetDevice(h->device));
+    struct SlowCall { double t0, t_sync = 0, t_alloc = 0; const md_raw_batch *b; bool on; SlowCall(const md_raw_batch *bb) : t0(mdk_prof_on() ? mdk_now() : 0), b(bb), on(mdk_prof_on()) {}
+        ~SlowCall() { if(on) { const double t = mdk_now(); if(t - t0 > 0.004) { char w[256]; snprintf(w, sizeof(w), "slow upload_raw: %.1f ms (slot wait %.1f, buffers %.1f, copies %.1f), %d ranges, %d records, first range %s", (t - t0) * 1e3, (t_sync - t0) * 1e3, (t_alloc - t_sync) * 1e3, (t - t_alloc) * 1e3, b->n_ranges, b->n_records, b->n_ranges ? (b->range[0].d_rec_off ? "device" : b->range[0].h_rec_off ? "host+table" : "host") : "-"); mdk_marks_dump(w); } } } } slow(b);
     if(s->busy) {                                    // work of the slot's previous chunk may still be running (its results were not collected)
         ProfScope pf(PF_UP_SYNC);
         HIPCHK(hipStreamSynchronize(s->stream));
         if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));
     }
+    slow.t_sync = slow.on ? mdk_now() : 0;
     s->busy = true;
     s->fresh = true;
     uint64_t total = 0;
@@ -1062,6 +1076,7 @@ static int upload_raw(md_dev *h, int slot, const md_raw_batch *b, bool may_stay)
         }
     }
     if(first) tf1 = mdk_now();
+    slow.t_alloc = slow.on ? mdk_now() : 0;
     if(inplace) { const md_raw_range &r = b->range[0]; s->inplace = true; s->inplace_delta = r.rec_delta; s->raw_at = r.ptr - r.rec_delta; s->rec_at = r.d_rec_off; s->raw_span = (uint64_t)r.rec_delta + r.bytes; HIPCHK(hipEventRecord(s->e1, s->stream)); }
     else { ProfScope pf(PF_UP_COPY); s->inplace = false; s->inplace_delta = 0; s->raw_at = s->d_raw.p; s->rec_at = s->d_recoff.p; s->raw_span = total; int rcc = copy_ranges(h, s, b); if(rcc) return rcc; HIPCHK(hipEventRecord(s->e1, s->stream)); }
     if(first) fprintf(stderr, "[mdk hip] the first chunk's upload: device buffers %.3fs, registration + copies queued %.3fs\n", tf1 - tf0, mdk_now() - tf1);

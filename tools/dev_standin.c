@@ -34,6 +34,7 @@ const char *md_dev_last_error(void) { return t_err; }
 int md_dev_count(void) { return 1; }
 int md_dev_warm(int device) { (void)device; return 0; }
 void md_dev_quiesce(void) { }
+void md_dev_reserve_hint(uint64_t device_bytes) { (void)device_bytes; }
 int md_dev_open(int device, const md_dev_cfg *cfg, md_dev **out) {
     md_dev *h = calloc(1, sizeof(*h)); (void)device;
     pthread_once(&g_once, load_dump);

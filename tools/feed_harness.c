@@ -22,6 +22,7 @@ const char *md_dev_last_error(void) { return "feed_harness stand-in"; }
 void *md_host_alloc(uint64_t bytes) { return malloc((size_t)bytes + 64); }
 void md_host_free(void *p) { free(p); }
 void md_host_register(md_dev *h, const void *ptr) { (void)h; (void)ptr; }
+void md_dev_reserve_hint(uint64_t device_bytes) { (void)device_bytes; }
 int md_piece_members_per_round(md_dev *h) { (void)h; return getenv("MDK_STANDIN_MEMBERS_PER_ROUND") ? atoi(getenv("MDK_STANDIN_MEMBERS_PER_ROUND")) : 0; }      /* (0: pieces are cut by bytes) */
 int md_piece_create(md_dev *h, md_piece **out) { (void)h; *out = calloc(1, sizeof(**out)); return *out ? 0 : -6; }
 void md_piece_destroy(md_piece *p) { if(!p) return; free(p->out); free(p->rec); free(p->dig); free(p); }
