@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 static double io_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 #define CCHUNK (8u << 20)      /* compressed bytes a host team inflates into one slab */
@@ -111,7 +112,9 @@ static void *inflate_worker(void *arg) {
  * once it holds a piece and has let go of the lock, makes the entries of ONE block further ahead (MADV_POPULATE_READ, Linux 5.14; by touching a
  * byte per page where the kernel does not know it): together the teams keep a frontier POP_AHEAD in front of the read position, at ~2 ms of
  * each piece's team.  (Threads of their own that ran ahead through the whole file held the address space's lock against the runtime's start-up:
- * the device was usable 0.15 s later, gpurun_out r06n.) */
+ * the device was usable 0.15 s later, gpurun_out r06n.)
+ * OFF since the end of round 6 (MDK_POPULATE=1 turns it on): measured against each other by interleaved runs on three boxes (profiles/r06_e2e_ab.txt), the 512 Mb
+ * run takes 1.03-1.07 s without it and 1.12-1.16 s with it -- a dozen teams making entries at once fight over the same address-space lock the walk's single faults take. */
 #ifndef MADV_POPULATE_READ
 #define MADV_POPULATE_READ 22
 #endif
@@ -119,7 +122,7 @@ static void *inflate_worker(void *arg) {
 #define POP_AHEAD ((size_t)1 << 30)
 static void populate_ahead(mdk_bam *b) {
     static int by_touch = 0, off = -1;
-    if(off < 0) off = getenv("MDK_NO_POPULATE") ? 1 : 0;
+    if(off < 0) off = getenv("MDK_POPULATE") && !getenv("MDK_NO_POPULATE") ? 0 : 1;      /* off unless asked for: see above */
     if(off || !b->map) return;
     { const size_t pos = __atomic_load_n(&b->map_pos, __ATOMIC_RELAXED); size_t at = __atomic_load_n(&b->pop_next, __ATOMIC_RELAXED), len;
       if(at < pos) { __atomic_compare_exchange_n(&b->pop_next, &at, pos, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED); at = __atomic_load_n(&b->pop_next, __ATOMIC_RELAXED); }      /* (a seek, or readers that overtook the frontier) */
@@ -150,7 +153,7 @@ static mdk_slab *slab_get_ex(mdk_bam *b, size_t need_cap, uint64_t seq) {       
     /* slabs are what the device preparation uploads from: staging memory (pinned for inputs large enough to repay the pinning,
      * md_host_set_pinned in mdk_plan.c), so that the H2D copies of a chunk are asynchronous and run at the link's speed */
     if(s->cap < need_cap) { md_host_free(s->buf); s->cap = need_cap + (need_cap >> 3); s->buf = md_host_alloc(s->cap); if(!s->buf) { free(s); return NULL; } }
-    s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM; s->n_mem = 0; s->n_sum = 0;
+    s->refs = 1; s->beg = s->end = MDK_SLAB_HEADROOM; s->n_mem = 0; s->n_sum = 0; s->spec = s->spec_fail = 0;
     return s;
 }
 /* ---- the reaper (see mdk_io.h) ---- */
@@ -273,6 +276,89 @@ static int next_piece(mdk_bam *b, piece *pc, size_t want, int max_members) {
     return 0;
 }
 
+/* ---- pieces cut without the lock ----
+ * next_piece's walk over the members' headers is a chain (a member's BSIZE says where the next begins), run under io_mu by one team at a time, and in
+ * a mapped file every member costs it a first touch of a page: 0.3-0.4 s for the 460,000 members of a 9 GB BAM, which the whole feed stood behind
+ * (profiles/r06pm_*: the teams queued 1.1-2.1 s in sum for the lock, the thread that uploads waited 0.2 s of a 0.5 s streaming phase for chunks).
+ * Here a team takes a NOMINAL range of the file under the lock (two additions) and finds the members in it by itself, next to the other teams: the first
+ * member that begins at or after a nominal boundary is found by looking for a BGZF header whose BSIZE leads to another header, three times over; the
+ * range's members are then walked exactly, header by header as next_piece does, from that start to the start found the same way at the range's nominal end.
+ * What makes this exact and not merely likely: the scanner takes the pieces in file order and checks that every piece begins where the piece before it ENDED
+ * (the first begins at a boundary known exactly).  By induction every piece it accepts was walked from a true member boundary.  A piece that does not
+ * fit -- a false header inside compressed bytes passing the test, a damaged file -- and a piece its team could not frame or inflate are thrown away with
+ * everything after them, and the rest of the file is framed under the lock as before, from the last verified boundary (spec_redo): errors are found and
+ * reported by that path alone.  MDK_SPEC_FAULT=n (tests): piece n starts one member late.
+ * NOT THE DEFAULT (MDK_SPEC_FRAMING=1 turns it on): measured by interleaved runs (profiles/r06_e2e_ab.txt) the 512 Mb run takes 1.11-1.23 s this way and 1.03-1.07 s
+ * with the walk under the lock.  The streaming phase itself is shorter (the device's inflate lane is full: 8 pieces in flight, 4 ms apart), but with nothing
+ * holding the teams back the runtime's start-up -- which maps and registers memory under the address-space lock the teams' threads keep taking -- needs 0.20 s
+ * instead of 0.07 s for its first step alone, and the device is usable at 0.36 s instead of 0.24 (gpurun_out r06pp); holding all host teams but one back until
+ * the device is attached (MDK_NO_SPEC_HOLD) recovers a third of that.  Kept, with its tests (tests/test_feed_harness.py), for the day the start-up is cheaper. */
+/* `v` is a view of the file: v[y] is the file's byte y for vis_beg <= y < vis_end (the mapped file itself, or a range read into a team's buffer) */
+typedef struct { const uint8_t *v; size_t vis_beg, vis_end, file_len; } fview;
+static int member_at(const fview *f, size_t y, size_t *next) {        /* is there a well-formed BGZF member header at y?  *next = where the member ends */
+    const uint8_t *p = f->v + y; uint16_t xlen; size_t x; uint32_t bsize = 0; int have = 0;
+    if(y < f->vis_beg || y + 18 > f->vis_end || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    xlen = le16(p + 10);
+    if(y + 12 + xlen > f->vis_end) return 0;
+    for(x = 12; x + 4 <= 12u + xlen;) { uint16_t sl = le16(p + x + 2); if(p[x] == 'B' && p[x + 1] == 'C' && sl == 2) { bsize = le16(p + x + 4) + 1u; have = 1; } x += 4 + sl; }
+    if(!have || bsize < 12u + xlen + 8u || y + bsize > f->file_len) return 0;
+    *next = y + bsize;
+    return 1;
+}
+static size_t find_member_start(const fview *f, size_t x) {        /* the first y >= x where a chain of three members (or fewer, up to the file's end) begins; file_len: none up to the file's end; (size_t)-1: none within a member's reach */
+    const size_t len = f->file_len, lim = x + 65536 + 64 < len ? x + 65536 + 64 : len;
+    size_t y;
+    for(y = x; y + 18 <= lim && y + 18 <= f->vis_end; y++) {
+        size_t n1, n2, n3;
+        if(f->v[y] != 0x1f || f->v[y + 1] != 0x8b) continue;
+        if(!member_at(f, y, &n1)) continue;
+        if(n1 != len && (!member_at(f, n1, &n2) || (n2 != len && !member_at(f, n2, &n3)))) continue;
+        return y;
+    }
+    return lim == len ? len : (size_t)-1;
+}
+/* under io_mu: status 0 = a range was handed out, 1 = end of the file */
+static int claim_range(mdk_bam *b, size_t want, size_t *nom_beg, size_t *nom_end, int *first) {
+    if(b->spec_pos >= b->map_len) return 1;
+    *nom_beg = b->spec_pos; *first = b->spec_pos == b->spec_start;
+    *nom_end = b->map_len - b->spec_pos > want + (256u << 10) ? b->spec_pos + want : b->map_len;       /* (no sliver of a last range) */
+    b->spec_pos = *nom_end;
+    return 0;
+}
+#define SPEC_SLACK ((size_t)4 * 65536 + 256)            /* past a range's nominal end: the boundary found there (<= 64 KB on) and the two members its test follows */
+/* outside any lock: the members of the range.  The range's bytes are READ into the team's buffer (pread: no page of the mapped file is touched -- a first
+ * touch there is a page fault under the address space's lock, which scales badly over a dozen teams, and a copy into the staging block was due anyway);
+ * buf == NULL: taken from the mapping.  0 = framed (pc filled; nb may be 0); -9 = it cannot be framed from here (the caller delivers a failed piece) */
+static int frame_range(mdk_bam *b, piece *pc, size_t nom_beg, size_t nom_end, int first, uint64_t seq, uint8_t *buf, size_t cap) {
+    const size_t len = b->map_len; fview f; size_t beg, end, off, total = 0;
+    blk_t *blk = NULL; int nb = 0, mb = 0;
+    static long fault = -2; if(fault == -2) fault = getenv("MDK_SPEC_FAULT") ? atol(getenv("MDK_SPEC_FAULT")) : -1;
+    pc->cbuf = NULL; pc->blk = NULL; pc->nb = 0; pc->total = 0; pc->map_beg = pc->map_end = nom_beg;
+    f.v = b->map; f.vis_beg = 0; f.vis_end = len; f.file_len = len;
+    if(buf) {
+        const size_t want = (nom_end + SPEC_SLACK < len ? nom_end + SPEC_SLACK : len) - nom_beg; size_t got = 0;
+        if(want > cap) return -9;
+        while(got < want) { const ssize_t r = pread(fileno(b->f), buf + got, want - got, (off_t)(nom_beg + got)); if(r <= 0) return -9; got += (size_t)r; }
+        f.v = buf - nom_beg; f.vis_beg = nom_beg; f.vis_end = nom_beg + want;
+    }
+    beg = first ? nom_beg : find_member_start(&f, nom_beg); end = nom_end >= len ? len : find_member_start(&f, nom_end);
+    if(beg == (size_t)-1 || end == (size_t)-1 || beg > end) return -9;
+    pc->map_beg = pc->map_end = beg;
+    if(fault >= 0 && (uint64_t)fault == seq && beg < end) { size_t n1; if(member_at(&f, beg, &n1)) { beg = n1; pc->map_beg = pc->map_end = beg; } }
+    for(off = beg; off < end;) {
+        const uint8_t *p = f.v + off; size_t nx; uint16_t xlen; uint32_t bsize;
+        if(!member_at(&f, off, &nx) || nx > f.vis_end) { free(blk); return -9; }
+        xlen = le16(p + 10); bsize = (uint32_t)(nx - off);
+        if(le32(p + bsize - 4) > 65536u) { free(blk); return -9; }          /* (no BGZF member inflates to more: not a boundary, or a file for the other path to refuse) */
+        if(nb == mb) { blk_t *nw; mb = mb ? mb * 2 : 1024; nw = realloc(blk, sizeof(blk_t) * (size_t)mb); if(!nw) { free(blk); return -9; } blk = nw; }
+        blk[nb].in = p + 12 + xlen; blk[nb].in_len = bsize - 12 - xlen - 8; blk[nb].out = NULL; blk[nb].out_len = le32(p + bsize - 4); blk[nb].crc = le32(p + bsize - 8); nb++;
+        total += le32(p + bsize - 4); off = nx;
+    }
+    if(off != end) { free(blk); return -9; }
+    pc->blk = blk; pc->nb = nb; pc->total = total; pc->map_beg = beg; pc->map_end = end;
+    return 0;
+}
+
 /* inflate the members of a piece into a slab (fanned out to nthreads) and gather the record tables */
 static mdk_slab *inflate_piece(mdk_bam *b, piece *pc, int nthreads, int *status) {
     blk_t *blk = pc->blk; int nb = pc->nb; mdk_slab *s;
@@ -331,7 +417,7 @@ static mdk_slab *dslab_get(mdk_bam *b, uint64_t seq) {          /* a free device
     pthread_mutex_unlock(&b->mu);
     if(!s) return NULL;
     if(!s->piece && md_piece_create(b->dev, &s->piece)) { pthread_mutex_lock(&b->mu); b->n_dalloc--; snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu); free(s); return NULL; }
-    s->refs = 1; s->beg = s->end = 0; s->n_mem = 0; s->n_sum = 0;
+    s->refs = 1; s->beg = s->end = 0; s->n_mem = 0; s->n_sum = 0; s->spec = s->spec_fail = 0;
     return s;
 }
 /* one piece through the device: the compressed bytes are staged in registered memory, md_piece_submit/wait inflates them and frames
@@ -344,13 +430,15 @@ static mdk_slab *inflate_piece_device(mdk_bam *b, piece *pc, int team, int *stat
     s = dslab_get(b, pc->seq);
     t1 = now_s(); tt[0] += t1 - t0; t0 = t1;
     if(!s) { *status = b->quit ? 1 : -1; return NULL; }
-    if(b->gpu_stage_cap[team] < span + 64) { md_host_free(b->gpu_stage[team]); b->gpu_stage_cap[team] = span + (span >> 3) + (1u << 20); b->gpu_stage[team] = md_host_alloc(b->gpu_stage_cap[team]); if(!b->gpu_stage[team]) { b->gpu_stage_cap[team] = 0; mdk_slab_unref(b, s); *status = -1; return NULL; } }
-    memcpy(b->gpu_stage[team], c0, span);
+    const int staged = b->gpu_stage[team] && c0 >= b->gpu_stage[team] && c0 + span <= b->gpu_stage[team] + b->gpu_stage_cap[team];      /* the range was read into the staging block (frame_range): uploaded from where it lies */
+    if(!staged && b->gpu_stage_cap[team] < span + 64) { md_host_free(b->gpu_stage[team]); b->gpu_stage_cap[team] = span + (span >> 3) + (1u << 20); b->gpu_stage[team] = md_host_alloc(b->gpu_stage_cap[team]); if(!b->gpu_stage[team]) { b->gpu_stage_cap[team] = 0; mdk_slab_unref(b, s); *status = -1; return NULL; } }
+    const uint8_t *const src = staged ? c0 : b->gpu_stage[team];
+    if(!staged) memcpy(b->gpu_stage[team], c0, span);
     t1 = now_s(); tt[1] += t1 - t0; t0 = t1;
     mt = malloc(sizeof(*mt) * (size_t)nb);
     if(!mt) { mdk_slab_unref(b, s); *status = -1; return NULL; }
     for(i = 0; i < nb; i++) { mt[i].in_off = (uint64_t)(blk[i].in - c0); mt[i].in_len = blk[i].in_len; mt[i].out_len = blk[i].out_len; mt[i].out_off = o; mt[i].crc32 = blk[i].crc; mt[i].reserved = 0; o += blk[i].out_len; }
-    { int rs = md_piece_submit(s->piece, b->gpu_stage[team], span, mt, nb);
+    { int rs = md_piece_submit(s->piece, src, span, mt, nb);
       if(rs == MDK_ERR_NOMEM) { free(mt); mdk_slab_unref(b, s); *status = -1; return NULL; }      /* no device memory for this piece: the host's inflate takes it */
       if(rs || md_piece_wait(s->piece, &info)) {
         pthread_mutex_lock(&b->mu); snprintf(b->err, sizeof(b->err), "%s", md_dev_last_error()); pthread_mutex_unlock(&b->mu);
@@ -393,27 +481,72 @@ static int deliver(mdk_bam *b, mdk_slab *s, uint64_t seq) {
     pthread_mutex_unlock(&b->mu);
     return 0;
 }
-typedef struct { mdk_bam *b; int gpu_team; } team_arg;        /* gpu_team < 0: a host team */
+typedef struct { mdk_bam *b; int gpu_team, idx; } team_arg;        /* gpu_team < 0: a host team (the idx-th) */
 static void *inflater_main(void *arg) {
     team_arg *ta = arg; mdk_bam *b = ta->b; const int gt = ta->gpu_team;
-    double t_next = 0, t_host = 0, t_deliver = 0, td[3] = {0, 0, 0}; int n_pieces = 0;
+    double t_next = 0, t_host = 0, t_deliver = 0, td[3] = {0, 0, 0}; int n_pieces = 0; uint8_t *hbuf = NULL; size_t hbuf_cap = 0;      /* hbuf: a host team's range of the file (frame_range) */
+    /* While the runtime is starting, ONE host team reads: with the file's lock out of their way four teams took a piece every few milliseconds between them, and
+     * the runtime -- whose start-up maps and registers memory under the same address-space lock their page faults and registrations take -- had the device usable
+     * 0.11 s later (0.36 s instead of 0.25, gpurun_out r06pp).  The others join when the device is attached, or after 0.4 s (a caller that attaches none). */
+    if(gt < 0 && ta->idx > 0 && b->map && b->spec_on && !getenv("MDK_NO_SPEC_HOLD")) {
+        static double th0 = 0; if(th0 == 0) th0 = now_s();      /* (the process's first reading: later restarts -- seeks -- find the 0.4 s over) */
+        for(;;) { int q; if(__atomic_load_n(&b->dev, __ATOMIC_ACQUIRE) || now_s() - th0 > 0.4) break; pthread_mutex_lock(&b->mu); q = b->quit; pthread_mutex_unlock(&b->mu); if(q) break; usleep(1000); }
+    }
     for(;;) {
         piece pc; int st; mdk_slab *s = NULL; double t0 = now_s(), t1;
+        int spec = 0, fr = 0; size_t nom_beg = 0, nom_end = 0; int first = 0;
         pthread_mutex_lock(&b->io_mu);
         if(b->io_status) { pthread_mutex_unlock(&b->io_mu); break; }              /* another team has seen the end (or an error) */
-        { const double tf = now_s();
-        st = next_piece(b, &pc, gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK, gt >= 0 ? b->gpu_piece_members : 0);
-        b->t_frame += now_s() - tf; }
+        spec = b->map && b->spec_on && !b->spec_off;
+        if(spec) {      /* a nominal range, framed below next to the other teams (claim_range / frame_range) */
+            size_t want = gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK;
+            if(gt >= 0 && b->gpu_piece_members > 0) { const size_t avg = __atomic_load_n(&b->spec_avg_member, __ATOMIC_RELAXED); want = (size_t)((double)(avg ? avg : 16384u) * b->gpu_piece_members * 0.985); }      /* (a whole number of the device's rounds of members, a little under) */
+            memset(&pc, 0, sizeof(pc));
+            st = claim_range(b, want, &nom_beg, &nom_end, &first);
+        } else {
+            const double tf = now_s();
+            st = next_piece(b, &pc, gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK, gt >= 0 ? b->gpu_piece_members : 0);
+            b->t_frame += now_s() - tf;
+        }
         if(st == 0) pc.seq = b->next_seq++; else b->io_status = st;
         pthread_mutex_unlock(&b->io_mu);
+        if(spec && st == 0) {      /* the range's bytes into this team's buffer: a device team's staging block (what its piece is uploaded from), a host team's own */
+            uint8_t *rb = NULL; size_t rcap = 0; const size_t need_cap = nom_end - nom_beg + SPEC_SLACK + 64;
+            if(!getenv("MDK_SPEC_MAPPED")) {
+                if(gt >= 0) {
+                    if(b->gpu_stage_cap[gt] < need_cap) { md_host_free(b->gpu_stage[gt]); b->gpu_stage_cap[gt] = need_cap + (need_cap >> 3) + (1u << 20); b->gpu_stage[gt] = md_host_alloc(b->gpu_stage_cap[gt]); if(!b->gpu_stage[gt]) b->gpu_stage_cap[gt] = 0; }
+                    rb = b->gpu_stage[gt]; rcap = b->gpu_stage_cap[gt];
+                } else {
+                    if(hbuf_cap < need_cap) { free(hbuf); hbuf_cap = need_cap + (need_cap >> 3); hbuf = malloc(hbuf_cap); if(!hbuf) hbuf_cap = 0; }
+                    rb = hbuf; rcap = hbuf_cap;
+                }
+            }
+            fr = frame_range(b, &pc, nom_beg, nom_end, first, pc.seq, rb, rcap);
+        }
+        if(spec && st == 0) { if(!fr && pc.nb) __atomic_store_n(&b->spec_avg_member, (pc.map_end - pc.map_beg) / (size_t)pc.nb, __ATOMIC_RELAXED); }
         t1 = now_s(); t_next += t1 - t0; t0 = t1;
-        if(st == 0) { populate_ahead(b); if(gt >= 0) populate_ahead(b); }       /* (a device team's piece is larger than a block) */
+        if(st == 0 && !spec) { populate_ahead(b); if(gt >= 0) populate_ahead(b); }       /* (a device team's piece is larger than a block) */
+        if(st == 0 && spec && (fr || pc.nb == 0)) {      /* nothing to inflate: an empty piece, or one that could not be framed (the scanner starts the other path when it gets there) */
+            s = slab_get_ex(b, MDK_SLAB_HEADROOM + 64, SEQ_FORCE);
+            if(!s) { pthread_mutex_lock(&b->mu); if(!b->quit && b->inf_done >= 0) b->inf_done = -1; pthread_cond_broadcast(&b->cv_q); pthread_mutex_unlock(&b->mu); free(pc.blk); break; }
+            s->spec = 1; s->spec_fail = fr ? 1 : 0; s->file_beg = pc.map_beg; s->file_end = pc.map_end;
+            free(pc.blk);
+            if(deliver(b, s, pc.seq)) break;
+            continue;
+        }
         if(st == 0) {
             /* a device team's piece goes to the host's inflate after all when it would inflate to more than the device addresses in one piece
              * (4 GiB: a ratio above 64, low-complexity data) or when the device cannot take it for want of a resource (status -1) */
             if(gt >= 0 && pc.total < 0xfff00000ull) { s = inflate_piece_device(b, &pc, gt, &st, td); if(!s && st == -1) { pthread_mutex_lock(&b->mu); const int q = b->quit; pthread_mutex_unlock(&b->mu); if(!q) { st = 0; s = inflate_piece(b, &pc, b->team_threads, &st); } } }
             else s = inflate_piece(b, &pc, b->team_threads, &st);
             free(pc.cbuf); free(pc.blk);
+            if(spec) {
+                if(s) { s->spec = 1; s->spec_fail = 0; s->file_beg = pc.map_beg; s->file_end = pc.map_end; }
+                else if(st == -2) {      /* its bytes did not inflate, or failed their CRC: a damaged file, or a piece that does not begin at a member -- the scanner decides (spec_redo) */
+                    s = slab_get_ex(b, MDK_SLAB_HEADROOM + 64, SEQ_FORCE);
+                    if(s) { s->spec = 1; s->spec_fail = 1; s->file_beg = pc.map_beg; s->file_end = pc.map_end; st = 0; pthread_mutex_lock(&b->mu); b->err[0] = 0; pthread_mutex_unlock(&b->mu); }
+                }
+            }
             /* the piece's pages of the file mapping are done with (inflated, or copied to the device's staging block): unmapped here, piece by piece
              * and on many threads, they are not left for the kernel to walk on one core when the process ends (they stay in the page cache) */
             if(b->map && pc.map_end > pc.map_beg) { const size_t a = (pc.map_beg + 4095) & ~(size_t)4095, e = pc.map_end & ~(size_t)4095; if(e > a) (void)madvise((void *)(b->map + a), e - a, MADV_DONTNEED); }
@@ -439,18 +572,20 @@ static void *inflater_main(void *arg) {
     }
     { const int k = gt >= 0; pthread_mutex_lock(&b->mu); b->tt_next[k] += t_next; b->tt_host[k] += t_host; b->tt_deliver[k] += t_deliver; b->tt_slab[k] += td[0]; b->tt_copy[k] += td[1]; b->tt_dev[k] += td[2]; b->tt_pieces[k] += n_pieces; pthread_mutex_unlock(&b->mu); }
     if(gt >= 0 && !getenv("MDK_NO_REAP")) { md_host_free(b->gpu_stage[gt]); b->gpu_stage[gt] = NULL; b->gpu_stage_cap[gt] = 0; }      /* its last piece has crossed the link (md_piece_wait): the staging block goes now, not at exit */
+    free(hbuf);
     free(ta);
     return NULL;
 }
 static void inflaters_start(mdk_bam *b) {
     int i;
     pthread_mutex_lock(&b->mu); b->next_seq = b->pop_seq = 0; b->io_status = 0; b->io_end = 0; pthread_mutex_unlock(&b->mu);      /* (no team is running; a thread giving a slab back looks at io_end: mdk_slab_unref) */
-    for(i = 0; i < b->n_teams; i++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = -1; if(pthread_create(&b->inf_th[i], NULL, inflater_main, ta)) { free(ta); break; } }
+    b->spec_on = b->map && getenv("MDK_SPEC_FRAMING") && !getenv("MDK_SERIAL_FRAMING"); b->spec_pos = b->spec_start = b->spec_verified = b->map_pos;      /* (map_pos: the file's start, or the member a seek went to -- a boundary known exactly) */
+    for(i = 0; i < b->n_teams; i++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = -1; ta->idx = i; if(pthread_create(&b->inf_th[i], NULL, inflater_main, ta)) { free(ta); break; } }
     if(i == 0) { b->io_status = -1; b->inf_done = -1; snprintf(b->err, sizeof(b->err), "cannot create an inflate thread"); }
     b->n_teams = i;
     b->inf_started = 1;
     if(!b->reap_started && !getenv("MDK_NO_REAP") && pthread_create(&b->reap_th, NULL, reaper_main, b) == 0) b->reap_started = 1;
-    if(b->dev && b->n_gpu_teams) { int k; for(k = 0; k < b->n_gpu_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } } b->n_gpu_teams = k; b->gpu_started = 1; }
+    if(b->dev && b->n_gpu_teams) { int k; for(k = 0; k < b->n_gpu_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; ta->idx = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } } b->n_gpu_teams = k; b->gpu_started = 1; }
 }
 static void inflaters_stop(mdk_bam *b) {
     int i;
@@ -480,7 +615,7 @@ int mdk_bam_attach_device(mdk_bam *b, struct md_dev *dev, int n_teams) {
     }
     b->n_gpu_teams = n_teams; b->max_dalloc = n_teams + (getenv("MDK_DSLAB_EXTRA") && atoi(getenv("MDK_DSLAB_EXTRA")) >= 1 ? atoi(getenv("MDK_DSLAB_EXTRA")) : 8);      /* (a chunk read in place keeps its piece until its results are in: md_dev_upload_raw_inplace) */
     if(b->inf_started) {
-        for(k = 0; k < n_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } }
+        for(k = 0; k < n_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; ta->idx = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } }
         b->n_gpu_teams = k; b->gpu_started = 1;
     }
     pthread_mutex_unlock(&b->life_mu);
@@ -532,6 +667,20 @@ static mdk_slab *slab_next(mdk_bam *b) {
 /* make at least n bytes available at the scan position, moving to the next slab when the current one runs out
  * (the unfinished tail is completed in the next slab's headroom); 1 ok, 0 clean end of data, <0 error.
  * A slab inflated on the device becomes current with off == end: the caller sees that through mdk_bam_at_device. */
+/* a piece that does not fit the one before it: everything the teams hold is thrown away and the rest of the file is framed under the lock, from the last boundary verified */
+static void spec_redo(mdk_bam *b) {
+    int i;
+    pthread_mutex_lock(&b->life_mu);
+    inflaters_stop(b);
+    pthread_mutex_lock(&b->mu);
+    for(i = 0; i < MDK_READY; i++) if(b->ready[i]) { mdk_slab *q = b->ready[i]; b->ready[i] = NULL; q->refs = 1; pthread_mutex_unlock(&b->mu); mdk_slab_unref(b, q); pthread_mutex_lock(&b->mu); }
+    b->n_ready = 0; b->quit = 0; b->inf_done = 0; b->clen = 0; b->file_eof = 0; b->err[0] = 0;
+    pthread_mutex_unlock(&b->mu);
+    b->map_pos = b->spec_verified; b->n_spec_redo++; b->spec_off = 1;      /* (no team is running) */
+    inflaters_start(b);
+    pthread_mutex_unlock(&b->life_mu);
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] a piece cut without the lock did not fit at byte %zu of the file: framing under the lock from there\n", b->spec_verified);
+}
 static int slab_all_ok(const mdk_slab *s) { int i; for(i = 0; i < s->n_mem; i++) if(!s->mem[i].ok) return 0; return 1; }
 static int need(mdk_bam *b, size_t n) {
     for(;;) {
@@ -539,6 +688,10 @@ static int need(mdk_bam *b, size_t n) {
         if(b->cur && b->cur->piece) { if(b->mem_i < b->cur->n_mem) return 2; }          /* standing in a device slab: nothing to read through */
         else if(b->cur && b->cur->end - b->off >= n) return 1;
         s = slab_next(b); left = (b->cur && !b->cur->piece) ? b->cur->end - b->off : 0;
+        if(s && s->spec) {      /* a piece cut without the lock is good if it begins where the piece before it ended (claim_range) */
+            if(s->spec_fail || s->file_beg != b->spec_verified) { mdk_slab_unref(b, s); spec_redo(b); continue; }
+            b->spec_verified = s->file_end;
+        }
         if(!s) {
             if(b->inf_done < 0) return b->inf_done;
             if(left == 0) return 0;

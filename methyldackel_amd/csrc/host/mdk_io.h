@@ -42,7 +42,8 @@ struct md_piece;
 typedef struct mdk_slab { uint8_t *buf; size_t cap, beg, end; int refs;
                           mdk_rsum *sum; size_t n_sum, cap_sum; mdk_member *mem; int n_mem, cap_mem;
                           uint32_t *off32; size_t cap_off32;        /* off32[i] = sum[i].off: the records' places as one array, which the device takes as it is (md_raw_range.h_rec_off) */
-                          struct md_piece *piece; const uint8_t *d_buf; const uint32_t *d_rec_off; uint64_t d_bytes; uint32_t d_records; } mdk_slab;
+                          struct md_piece *piece; const uint8_t *d_buf; const uint32_t *d_rec_off; uint64_t d_bytes; uint32_t d_records;
+                          size_t file_beg, file_end; int spec, spec_fail; } mdk_slab;      /* spec: the piece was cut without the file's lock (mdk_io.c claim_range): file_beg/file_end = its members' bytes in the file, checked against the piece before it when the scanner takes it; spec_fail: its team could not frame or inflate it */
 
 #define MDK_GPU_TEAMS_MAX 16       /* device inflate teams: a host thread, a pinned staging block and pieces in flight each */
 typedef struct mdk_bam {
@@ -75,6 +76,10 @@ typedef struct mdk_bam {
     /* the mapping's page-table entries are made AHEAD of the framing (mdk_io.c populate_ahead): the walk over the members' headers runs under io_mu, one team at
      * a time, and a first touch of a page there costs the whole feed a microsecond per member */
     double t_frame;                                /* (io_mu) seconds inside next_piece */
+    /* pieces cut WITHOUT walking the members under the lock (mdk_io.c claim_range): spec_pos = where the next piece nominally starts, spec_start = the exact
+     * member boundary the reading began at (the first piece's start needs no search); spec_verified (scanner) = the end of the last piece taken; spec_off:
+     * a piece did not begin where the one before it ended (or could not be framed): the rest of the file is framed under the lock as before */
+    size_t spec_pos, spec_start, spec_verified; int spec_on, spec_off; size_t spec_avg_member; uint64_t n_spec_redo;
     int seeked;                                    /* (mu) mdk_bam_seek has been called: the end of the file is not the end of the reading */
     size_t pop_next;                               /* (atomic) up to where the mapping's entries have been made or are being made */
     /* scanner position */

@@ -846,6 +846,7 @@ hipStream_t mdk_stream_take(int device) { return stream_take(device); }
 // 15 ms from the launch call to the results for 0.5-2 ms of kernels, three groups in flight -> a group every 5 ms whatever else got faster
 // (profiles/r06pb_*: MDK_HOST_PROFILE's group lines, the kernel trace: no group kernel runs while pieces are queued).  Round 4's priority experiment
 // (high for the consumer, low for the inflate) predates the group launches and the pieces' shared streams.  MDK_PIECE_PRIO=0: all streams alike.
+static std::atomic<int> g_warm_streams_made{0};      // of the WARM_STREAMS the handle's own work runs on
 static std::vector<hipStream_t> g_stash_piece;      // (g_stash_mu) made by md_dev_warm's side thread
 static bool piece_prio_wanted() { static const bool on = !(getenv("MDK_PIECE_PRIO") && atoi(getenv("MDK_PIECE_PRIO")) == 0); return on; }
 static hipStream_t piece_stream_new() {
@@ -911,7 +912,9 @@ extern "C" int md_dev_warm(int device) {
     // What the first chunk and the first piece would otherwise pay for on the pipeline's critical path (gpurun_out r04p, 3 ms time series: the first
     // upload took 75 ms and the first group 60 ms, a later group 8): the copy engines' queues in both directions (made at the first copy), carved
     // device blocks, the pieces' streams.  On threads of their own; whoever needs one of them first waits inside the runtime for that one.
-    if(!getenv("MDK_NO_WARM_SIDE") && !g_side_quit.load()) {
+    const bool side_streams = !getenv("MDK_NO_WARM_SIDE") && !g_side_quit.load();
+    g_warm_streams_made.store(0);
+    if(side_streams) {
         // ... and the staging blocks the host's inflate fills while the runtime comes up are made known to it from the moment it IS up, not from the
         // moment the device handle is open 60-90 ms later (the first chunk's upload waited 50-85 ms for the registration of ~30 blocks, r04q).
         // Until the device is open (md_dev_open stops it), not longer.
@@ -923,6 +926,15 @@ extern "C" int md_dev_warm(int device) {
             });
         side_start([device]() {          // the device inflate's streams (mdk_inflate.hip piece_stream_of takes them from the stash)
             if(hipSetDevice(device) != hipSuccess) return;
+            // the handle's own streams first (the groups', the contigs'): they are wanted the moment the code object is in, and making them next to its load
+            // instead of after it brings the device's first use 30 ms forward; then the pieces'
+            for(int i = 0; i < WARM_STREAMS && !g_side_quit.load(); i++) {
+                hipStream_t s = nullptr;
+                if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+                { std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev == device) g_stash.push_back(s); else { (void)hipStreamDestroy(s); break; } }
+                g_warm_streams_made.fetch_add(1); g_stash_cv.notify_all();
+            }
+            g_warm_streams_made.store(WARM_STREAMS); g_stash_cv.notify_all();
             for(int i = 0; i < 6 && !g_side_quit.load(); i++) { hipStream_t s = piece_stream_new(); if(!s) return; std::lock_guard<std::mutex> lk(g_stash_mu); if(g_stash_dev == device) g_stash_piece.push_back(s); else { (void)hipStreamDestroy(s); return; } }
         });
         side_start([device]() {
@@ -940,7 +952,8 @@ extern "C" int md_dev_warm(int device) {
     }
     if(code_object_load()) return fail(MDK_ERR_HIP, "loading the device library's code object", hipGetLastError());
     const double t3 = mdk_now();
-    for(int i = 0; i < WARM_STREAMS; i++) {
+    if(side_streams) { std::unique_lock<std::mutex> lk(g_stash_mu); g_stash_cv.wait_for(lk, std::chrono::milliseconds(500), [] { return g_warm_streams_made.load() >= WARM_STREAMS; }); }      // (made by the helper thread meanwhile)
+    else for(int i = 0; i < WARM_STREAMS; i++) {
         hipStream_t s = nullptr;
         if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
         { std::lock_guard<std::mutex> lk(g_stash_mu);

@@ -534,12 +534,16 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
     if(p->d_comp.need((size_t)comp_bytes + 1024) || p->d_out.need((size_t)out_bytes + 1024) || p->d_mem.need((size_t)n_mem) || p->d_cnt.need((size_t)n_mem) || p->d_first.need((size_t)n_mem) ||
        p->d_dig.need((size_t)n_mem) || p->h_dig.need((size_t)n_mem) || p->d_recoff.need((size_t)rec_cap) || p->d_tok.need((size_t)inflate_grid(h->device, n_mem) * INF_TOK_WORDS)) return MDK_ERR_NOMEM;
     p->n_mem = n_mem; p->out_bytes = out_bytes; p->comp_bytes = comp_bytes; p->n_rec_cap = rec_cap;
+    const bool prof = mdk_prof_on(); double tq[8]; int nq = 0; auto tick = [&]() { if(prof && nq < 8) tq[nq++] = mdk_now(); };
+    tick();
     hipStream_t st = p->stream, s_in = st, s_inf = st;
     const bool lanes = piece_lanes_of(h, &s_in, &s_inf);
     host_block_ensure_registered(comp);
+    tick();
     HIPCHK(hipMemcpyAsync(p->d_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, s_in));
     HIPCHK(hipMemcpyAsync(p->d_mem.p, mem, sizeof(md_inf_member) * (size_t)n_mem, hipMemcpyHostToDevice, s_in));
     HIPCHK(hipMemsetAsync(p->d_status.p, 0, 16, s_in));          // (error word, record count, the launch's member counter)
+    tick();
     if(lanes) { HIPCHK(hipEventRecord(p->ev_in, s_in)); HIPCHK(hipStreamWaitEvent(s_inf, p->ev_in, 0)); }
     InfParams IP; IP.comp = p->d_comp.p; IP.mem = p->d_mem.p; IP.n_mem = n_mem; IP.out = p->d_out.p; IP.status = p->d_status.p; IP.tok = p->d_tok.p;
 #ifdef INF_PROFILE
@@ -547,6 +551,7 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
 #endif
     HIPCHK(launch_inflate(h->device, n_mem, s_inf, IP, true));
     if(lanes) { HIPCHK(hipEventRecord(p->ev_inf, s_inf)); HIPCHK(hipStreamWaitEvent(st, p->ev_inf, 0)); }
+    tick();
     if(p->check_crc) launch_crc(h, p, st);
     WalkParams W; W.out = p->d_out.p; W.mem = p->d_mem.p; W.n_mem = n_mem; W.count = p->d_cnt.p; W.rec_off = p->d_recoff.p; W.first = p->d_first.p; W.dig = p->d_dig.p;
     hipLaunchKernelGGL(k_walk<false>, dim3((n_mem + 63) / 64), dim3(64), 0, st, W);
@@ -556,6 +561,8 @@ extern "C" int md_piece_submit(md_piece *p, const uint8_t *comp, uint64_t comp_b
     HIPCHK(hipMemcpyAsync(p->h_dig.p, p->d_dig.p, sizeof(md_inf_digest) * (size_t)n_mem, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(p->h_status.p, p->d_status.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(p->done, st));
+    tick();
+    if(prof && nq == 5 && tq[4] - tq[0] > 0.003) { char w[200]; snprintf(w, sizeof(w), "slow md_piece_submit: %.1f ms (registration %.1f, copies in %.1f, inflate launch %.1f, the rest %.1f)", (tq[4] - tq[0]) * 1e3, (tq[1] - tq[0]) * 1e3, (tq[2] - tq[1]) * 1e3, (tq[3] - tq[2]) * 1e3, (tq[4] - tq[3]) * 1e3); mdk_marks_dump(w); }
     p->busy = true; p->recorded = true;
     return 0;
 }

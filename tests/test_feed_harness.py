@@ -73,3 +73,34 @@ def test_fixture_bams(sample):
         ref = run(bam, 0, 0)
         got = run(bam, 1, 2, 8, {"MDK_DEVICE_INFLATE_ONLY": "1", "MDK_GPU_PIECE_MB": "0.25"})
         assert (got["records"], got["digest"]) == (ref["records"], ref["digest"]), bam.name
+
+
+# ---- pieces cut without the file's lock (mdk_io.c claim_range / frame_range; MDK_SPEC_FRAMING=1: measured slower end to end, not the default) ----
+SPEC = [
+    (1, 6, 32, {}),
+    (1, 12, 8, {"MDK_GPU_PIECE_MB": "0.25", "MDK_SLAB_CAP": "2"}),
+    (0, 12, 8, {"MDK_SLAB_CAP": "2", "MDK_INFLATE_TEAMS": "4"}),
+    (1, 40, 8, {"MDK_DEVICE_INFLATE_ONLY": "1", "MDK_GPU_PIECE_MB": "0.25"}),
+]
+
+
+@pytest.mark.parametrize("mode,hold,threads,env", SPEC, ids=[f"spec{i}" for i in range(len(SPEC))])
+def test_pieces_cut_without_the_lock_read_the_same_stream_as_the_serial_walk(sample, mode, hold, threads, env):
+    for bam in ("s.bam", "x.bam"):
+        ref = run(sample / bam, mode, hold, threads, dict(env, MDK_SERIAL_FRAMING="1"))
+        got = run(sample / bam, mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1"))
+        mapped = run(sample / bam, mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1", MDK_SPEC_MAPPED="1"))
+        assert (got["records"], got["bytes"], got["digest"]) == (ref["records"], ref["bytes"], ref["digest"]) == (mapped["records"], mapped["bytes"], mapped["digest"])
+        assert got.get("spec_redo", 0) == 0 and ref.get("spec_redo", 0) == 0
+
+
+@pytest.mark.parametrize("fault", [0, 1, 2, 5, 17, 60])
+def test_a_piece_that_does_not_fit_sends_the_rest_of_the_file_down_the_serial_path(sample, fault):
+    """MDK_SPEC_FAULT=n: piece n begins one member late -- the scanner must notice (it does not begin where piece n-1 ended), throw away
+    what the teams hold and have the rest framed under the lock; the stream read is the same, and the run ends."""
+    ref = run(sample / "s.bam", 0, 0, 8, {"MDK_SERIAL_FRAMING": "1"})
+    for mode, hold, threads, env in ((1, 6, 8, {"MDK_DEVICE_INFLATE_ONLY": "1", "MDK_GPU_PIECE_MB": "0.25"}), (0, 3, 8, {"MDK_INFLATE_TEAMS": "4"})):
+        got = run(sample / "s.bam", mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1", MDK_SPEC_FAULT=str(fault)))
+        assert (got["records"], got["bytes"], got["digest"]) == (ref["records"], ref["bytes"], ref["digest"])
+        if mode == 1 or fault <= 2:          # (the 25 MB file is three or four host pieces, or a hundred small device pieces: a piece number it does not reach meets no fault)
+            assert got["spec_redo"] == 1

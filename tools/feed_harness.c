@@ -99,8 +99,8 @@ int main(int argc, char **argv) {
         if(on_device) mdk_bam_dev_advance(b); else mdk_bam_advance_sum(b, &q);
     }
     for(int i = 0; i < nheld; i++) mdk_slab_unref(b, held[i]);
-    printf("{\"records\": %llu, \"bytes\": %llu, \"digest\": \"%016llx\", \"host_pieces\": %llu, \"device_pieces\": %llu, \"device_members\": %llu, \"read_back\": %llu}\n",
-           (unsigned long long)n, (unsigned long long)bytes, (unsigned long long)h, (unsigned long long)b->n_host_pieces, (unsigned long long)b->n_dev_pieces, (unsigned long long)dev_members, (unsigned long long)b->n_materialized);
+    printf("{\"records\": %llu, \"bytes\": %llu, \"digest\": \"%016llx\", \"host_pieces\": %llu, \"device_pieces\": %llu, \"device_members\": %llu, \"read_back\": %llu, \"spec_redo\": %llu}\n",
+           (unsigned long long)n, (unsigned long long)bytes, (unsigned long long)h, (unsigned long long)b->n_host_pieces, (unsigned long long)b->n_dev_pieces, (unsigned long long)dev_members, (unsigned long long)b->n_materialized, (unsigned long long)b->n_spec_redo);
     if(mode == 1) mdk_bam_detach_device(b);
     mdk_bam_close(b);
     free(held);
