@@ -292,7 +292,10 @@ static int next_piece(mdk_bam *b, piece *pc, size_t want, int max_members) {
  * with the walk under the lock.  The streaming phase itself is shorter (the device's inflate lane is full: 8 pieces in flight, 4 ms apart), but with nothing
  * holding the teams back the runtime's start-up -- which maps and registers memory under the address-space lock the teams' threads keep taking -- needs 0.20 s
  * instead of 0.07 s for its first step alone, and the device is usable at 0.36 s instead of 0.24 (gpurun_out r06pp); holding all host teams but one back until
- * the device is attached (MDK_NO_SPEC_HOLD) recovers a third of that.  Kept, with its tests (tests/test_feed_harness.py), for the day the start-up is cheaper. */
+ * the device is attached (MDK_NO_SPEC_HOLD) recovers a third of that.  Nor does it pay when it only takes over once the device is attached (what
+ * MDK_SPEC_FRAMING=1 does now; MDK_SPEC_AT_ONCE=1: from the file's first byte): 1.09 against 1.05 s at 512 Mb, 1.66 against 1.53 s at 1 Gb (r06pv) -- in the
+ * steady state the device is the limit (a kernel runs 88 % of the streaming phase, profiles/r06pu_trace_summary.txt), and a dozen teams that never wait only
+ * queue more work behind it.  Kept, with its tests (tests/test_feed_harness.py), for a feed that is not device-bound (several GPUs behind one reader). */
 /* `v` is a view of the file: v[y] is the file's byte y for vis_beg <= y < vis_end (the mapped file itself, or a range read into a team's buffer) */
 typedef struct { const uint8_t *v; size_t vis_beg, vis_end, file_len; } fview;
 static int member_at(const fview *f, size_t y, size_t *next) {        /* is there a well-formed BGZF member header at y?  *next = where the member ends */
@@ -488,7 +491,7 @@ static void *inflater_main(void *arg) {
     /* While the runtime is starting, ONE host team reads: with the file's lock out of their way four teams took a piece every few milliseconds between them, and
      * the runtime -- whose start-up maps and registers memory under the same address-space lock their page faults and registrations take -- had the device usable
      * 0.11 s later (0.36 s instead of 0.25, gpurun_out r06pp).  The others join when the device is attached, or after 0.4 s (a caller that attaches none). */
-    if(gt < 0 && ta->idx > 0 && b->map && b->spec_on && !getenv("MDK_NO_SPEC_HOLD")) {
+    if(gt < 0 && ta->idx > 0 && b->map && b->spec_on && getenv("MDK_SPEC_AT_ONCE") && !getenv("MDK_NO_SPEC_HOLD")) {
         static double th0 = 0; if(th0 == 0) th0 = now_s();      /* (the process's first reading: later restarts -- seeks -- find the 0.4 s over) */
         for(;;) { int q; if(__atomic_load_n(&b->dev, __ATOMIC_ACQUIRE) || now_s() - th0 > 0.4) break; pthread_mutex_lock(&b->mu); q = b->quit; pthread_mutex_unlock(&b->mu); if(q) break; usleep(1000); }
     }
@@ -498,6 +501,9 @@ static void *inflater_main(void *arg) {
         pthread_mutex_lock(&b->io_mu);
         if(b->io_status) { pthread_mutex_unlock(&b->io_mu); break; }              /* another team has seen the end (or an error) */
         spec = b->map && b->spec_on && !b->spec_off;
+        /* ... but only once the device is attached: until then the pieces are cut by the walk under the lock, which holds the teams back while the runtime starts
+         * (see above).  The switch: the first range begins where the walk has got to -- a boundary known exactly. */
+        if(spec && !b->spec_active) { if(__atomic_load_n(&b->dev, __ATOMIC_ACQUIRE) || getenv("MDK_SPEC_AT_ONCE")) { b->spec_active = 1; b->spec_pos = b->spec_start = b->map_pos; } else spec = 0; }
         if(spec) {      /* a nominal range, framed below next to the other teams (claim_range / frame_range) */
             size_t want = gt >= 0 ? b->gpu_piece_bytes : b->host_leaves ? (256u << 10) : CCHUNK;
             if(gt >= 0 && b->gpu_piece_members > 0) { const size_t avg = __atomic_load_n(&b->spec_avg_member, __ATOMIC_RELAXED); want = (size_t)((double)(avg ? avg : 16384u) * b->gpu_piece_members * 0.985); }      /* (a whole number of the device's rounds of members, a little under) */
@@ -512,7 +518,7 @@ static void *inflater_main(void *arg) {
         pthread_mutex_unlock(&b->io_mu);
         if(spec && st == 0) {      /* the range's bytes into this team's buffer: a device team's staging block (what its piece is uploaded from), a host team's own */
             uint8_t *rb = NULL; size_t rcap = 0; const size_t need_cap = nom_end - nom_beg + SPEC_SLACK + 64;
-            if(!getenv("MDK_SPEC_MAPPED")) {
+            if(getenv("MDK_SPEC_PREAD")) {
                 if(gt >= 0) {
                     if(b->gpu_stage_cap[gt] < need_cap) { md_host_free(b->gpu_stage[gt]); b->gpu_stage_cap[gt] = need_cap + (need_cap >> 3) + (1u << 20); b->gpu_stage[gt] = md_host_alloc(b->gpu_stage_cap[gt]); if(!b->gpu_stage[gt]) b->gpu_stage_cap[gt] = 0; }
                     rb = b->gpu_stage[gt]; rcap = b->gpu_stage_cap[gt];
@@ -540,6 +546,7 @@ static void *inflater_main(void *arg) {
             if(gt >= 0 && pc.total < 0xfff00000ull) { s = inflate_piece_device(b, &pc, gt, &st, td); if(!s && st == -1) { pthread_mutex_lock(&b->mu); const int q = b->quit; pthread_mutex_unlock(&b->mu); if(!q) { st = 0; s = inflate_piece(b, &pc, b->team_threads, &st); } } }
             else s = inflate_piece(b, &pc, b->team_threads, &st);
             free(pc.cbuf); free(pc.blk);
+            if(!spec && s && b->map && b->spec_on) { s->spec = 1; s->spec_fail = 0; s->file_beg = pc.map_beg; s->file_end = pc.map_end; }      /* (cut by the walk: begins where the piece before it ended by construction; the scanner's frontier moves with it) */
             if(spec) {
                 if(s) { s->spec = 1; s->spec_fail = 0; s->file_beg = pc.map_beg; s->file_end = pc.map_end; }
                 else if(st == -2) {      /* its bytes did not inflate, or failed their CRC: a damaged file, or a piece that does not begin at a member -- the scanner decides (spec_redo) */
@@ -579,7 +586,7 @@ static void *inflater_main(void *arg) {
 static void inflaters_start(mdk_bam *b) {
     int i;
     pthread_mutex_lock(&b->mu); b->next_seq = b->pop_seq = 0; b->io_status = 0; b->io_end = 0; pthread_mutex_unlock(&b->mu);      /* (no team is running; a thread giving a slab back looks at io_end: mdk_slab_unref) */
-    b->spec_on = b->map && getenv("MDK_SPEC_FRAMING") && !getenv("MDK_SERIAL_FRAMING"); b->spec_pos = b->spec_start = b->spec_verified = b->map_pos;      /* (map_pos: the file's start, or the member a seek went to -- a boundary known exactly) */
+    b->spec_on = b->map && getenv("MDK_SPEC_FRAMING") && !getenv("MDK_SERIAL_FRAMING"); b->spec_active = 0; b->spec_pos = b->spec_start = b->spec_verified = b->map_pos;      /* (map_pos: the file's start, or the member a seek went to -- a boundary known exactly) */
     for(i = 0; i < b->n_teams; i++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = -1; ta->idx = i; if(pthread_create(&b->inf_th[i], NULL, inflater_main, ta)) { free(ta); break; } }
     if(i == 0) { b->io_status = -1; b->inf_done = -1; snprintf(b->err, sizeof(b->err), "cannot create an inflate thread"); }
     b->n_teams = i;
@@ -732,7 +739,7 @@ mdk_bam *mdk_bam_open(const char *fn, int nthreads) {
         if(fstat(fileno(b->f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
             void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(b->f), 0);
             if(m != MAP_FAILED) { b->map = m; b->map_len = (size_t)st.st_size; b->map_pos = 0; (void)madvise(m, b->map_len, MADV_SEQUENTIAL); }
-            if(!getenv("MDK_NO_RESERVE_HINT")) {       /* what the device will hold at once: up to 16 pieces being inflated or read in place (0.64 GB each), the chunks' slots and the contigs in use */
+            if(getenv("MDK_RESERVE_HINT")) {      /* (off by default: the allocations it spares the streaming phase -- 10-30 ms calls next to the pieces' copies, profiles/r06pf_slow_calls.txt -- do not show in the wall clock, and 15 GiB made ahead cost the 512 Mb run 0-5 % in three of four interleaved comparisons, profiles/r06_e2e_ab.txt) */       /* what the device will hold at once: up to 16 pieces being inflated or read in place (0.64 GB each), the chunks' slots and the contigs in use */
                 uint64_t pieces = (uint64_t)st.st_size / (96ull << 20) + 2; if(pieces > 16) pieces = 16;
                 md_dev_reserve_hint(pieces * (640ull << 20) + (6ull << 30));
             }

@@ -79,7 +79,7 @@ typedef struct mdk_bam {
     /* pieces cut WITHOUT walking the members under the lock (mdk_io.c claim_range): spec_pos = where the next piece nominally starts, spec_start = the exact
      * member boundary the reading began at (the first piece's start needs no search); spec_verified (scanner) = the end of the last piece taken; spec_off:
      * a piece did not begin where the one before it ended (or could not be framed): the rest of the file is framed under the lock as before */
-    size_t spec_pos, spec_start, spec_verified; int spec_on, spec_off; size_t spec_avg_member; uint64_t n_spec_redo;
+    size_t spec_pos, spec_start, spec_verified; int spec_on, spec_off, spec_active; size_t spec_avg_member; uint64_t n_spec_redo;
     int seeked;                                    /* (mu) mdk_bam_seek has been called: the end of the file is not the end of the reading */
     size_t pop_next;                               /* (atomic) up to where the mapping's entries have been made or are being made */
     /* scanner position */

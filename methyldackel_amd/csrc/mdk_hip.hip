@@ -845,10 +845,12 @@ hipStream_t mdk_stream_take(int device) { return stream_take(device); }
 // With one pool (4 queues for 4 + 3 + 1 streams) a group's five small kernels sat in a queue behind a piece's copy, k_inflate, k_crc32 and walks:
 // 15 ms from the launch call to the results for 0.5-2 ms of kernels, three groups in flight -> a group every 5 ms whatever else got faster
 // (profiles/r06pb_*: MDK_HOST_PROFILE's group lines, the kernel trace: no group kernel runs while pieces are queued).  Round 4's priority experiment
-// (high for the consumer, low for the inflate) predates the group launches and the pieces' shared streams.  MDK_PIECE_PRIO=0: all streams alike.
+// (high for the consumer, low for the inflate) predates the group launches and the pieces' shared streams.
+// OFF again since the pieces have their lanes (mdk_inflate.hip: every k_inflate on one stream of its own, which shares its hardware queue with copies only): with
+// the lanes in, low priority costs the 512 Mb run 4 % (1.044 -> 1.005 s by interleaved runs, profiles/r06_e2e_ab.txt r06pr).  MDK_PIECE_PRIO=1 turns it on.
 static std::atomic<int> g_warm_streams_made{0};      // of the WARM_STREAMS the handle's own work runs on
 static std::vector<hipStream_t> g_stash_piece;      // (g_stash_mu) made by md_dev_warm's side thread
-static bool piece_prio_wanted() { static const bool on = !(getenv("MDK_PIECE_PRIO") && atoi(getenv("MDK_PIECE_PRIO")) == 0); return on; }
+static bool piece_prio_wanted() { static const bool on = getenv("MDK_PIECE_PRIO") && atoi(getenv("MDK_PIECE_PRIO")) != 0; return on; }
 static hipStream_t piece_stream_new() {
     hipStream_t s = nullptr;
     if(piece_prio_wanted()) {

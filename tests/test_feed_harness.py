@@ -75,7 +75,7 @@ def test_fixture_bams(sample):
         assert (got["records"], got["digest"]) == (ref["records"], ref["digest"]), bam.name
 
 
-# ---- pieces cut without the file's lock (mdk_io.c claim_range / frame_range; MDK_SPEC_FRAMING=1: measured slower end to end, not the default) ----
+# ---- pieces cut without the file's lock (mdk_io.c claim_range / frame_range; MDK_SPEC_FRAMING=1 -- measured slower end to end, not the default --: from the moment the device is attached; with MDK_SPEC_AT_ONCE=1 from the file's first byte) ----
 SPEC = [
     (1, 6, 32, {}),
     (1, 12, 8, {"MDK_GPU_PIECE_MB": "0.25", "MDK_SLAB_CAP": "2"}),
@@ -88,8 +88,10 @@ SPEC = [
 def test_pieces_cut_without_the_lock_read_the_same_stream_as_the_serial_walk(sample, mode, hold, threads, env):
     for bam in ("s.bam", "x.bam"):
         ref = run(sample / bam, mode, hold, threads, dict(env, MDK_SERIAL_FRAMING="1"))
-        got = run(sample / bam, mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1"))
-        mapped = run(sample / bam, mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1", MDK_SPEC_MAPPED="1"))
+        got = run(sample / bam, mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1", MDK_SPEC_AT_ONCE="1"))
+        mapped = run(sample / bam, mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1", MDK_SPEC_AT_ONCE="1", MDK_SPEC_PREAD="1"))
+        switch = run(sample / bam, mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1"))          # (cut by the walk until the device is attached, without the lock from then on)
+        assert (switch["records"], switch["bytes"], switch["digest"]) == (ref["records"], ref["bytes"], ref["digest"]) and switch["spec_redo"] == 0
         assert (got["records"], got["bytes"], got["digest"]) == (ref["records"], ref["bytes"], ref["digest"]) == (mapped["records"], mapped["bytes"], mapped["digest"])
         assert got.get("spec_redo", 0) == 0 and ref.get("spec_redo", 0) == 0
 
@@ -100,7 +102,7 @@ def test_a_piece_that_does_not_fit_sends_the_rest_of_the_file_down_the_serial_pa
     what the teams hold and have the rest framed under the lock; the stream read is the same, and the run ends."""
     ref = run(sample / "s.bam", 0, 0, 8, {"MDK_SERIAL_FRAMING": "1"})
     for mode, hold, threads, env in ((1, 6, 8, {"MDK_DEVICE_INFLATE_ONLY": "1", "MDK_GPU_PIECE_MB": "0.25"}), (0, 3, 8, {"MDK_INFLATE_TEAMS": "4"})):
-        got = run(sample / "s.bam", mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1", MDK_SPEC_FAULT=str(fault)))
+        got = run(sample / "s.bam", mode, hold, threads, dict(env, MDK_SPEC_FRAMING="1", MDK_SPEC_AT_ONCE="1", MDK_SPEC_FAULT=str(fault)))
         assert (got["records"], got["bytes"], got["digest"]) == (ref["records"], ref["bytes"], ref["digest"])
         if mode == 1 or fault <= 2:          # (the 25 MB file is three or four host pieces, or a hundred small device pieces: a piece number it does not reach meets no fault)
             assert got["spec_redo"] == 1
