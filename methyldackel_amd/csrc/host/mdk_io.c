@@ -165,6 +165,16 @@ static void reap_push(mdk_bam *b, mdk_slab *s) {        /* (mu held) */
     b->reap[b->n_reap++] = s; b->n_alloc--;
     pthread_cond_signal(&b->cv_reap);
 }
+/* Giving registered memory back while the last chunks are on their way pays for files whose run holds gigabytes of it for seconds; for a small file it
+ * is a loss: a 0.5 GB BAM (32 Mb at 30x) is through in 0.26 s, and the command then left in 0.02 s without the reaper and in 0.24 s with it -- nine
+ * interleaved runs each, 0.257 against 0.523 s for the caller (profiles/r06_e2e_ab.txt r06pw) --, while at 2.2 GB the two are level (0.73 against 0.69 s) and
+ * above that the reaper is ahead.  Below MDK_REAP_MIN_MB (default 1536) of BAM there is none; MDK_NO_REAP=1: never. */
+static int reap_wanted(const mdk_bam *b) {
+    static long min_mb = -1;
+    if(getenv("MDK_NO_REAP")) return 0;
+    if(min_mb < 0) min_mb = getenv("MDK_REAP_MIN_MB") ? atol(getenv("MDK_REAP_MIN_MB")) : 1536;
+    return !b->map || (long)(b->map_len >> 20) >= min_mb;
+}
 static void *reaper_main(void *arg) {
     mdk_bam *b = arg;
     pthread_mutex_lock(&b->mu);
@@ -194,12 +204,13 @@ void mdk_bam_teams_leave(mdk_bam *b) {
     pthread_mutex_unlock(&b->life_mu);
 }
 void mdk_bam_reap_wait(mdk_bam *b) {
-    if(!b || !b->reap_started) return;
+    if(!b) return;
     pthread_mutex_lock(&b->mu);
-    reap_pool(b);
+    if(b->reap_started) reap_pool(b);
     { const double t0 = now_s();
-      while(b->n_reap || b->reap_busy) pthread_cond_wait(&b->cv_reaped, &b->mu);
-      if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] reaper: %d slabs given back in %.3fs of its own thread's time, %d left in the pool, %d still referenced; waited for it %.3fs at the end\n", b->n_reaped, b->t_reap, b->n_pool, b->n_alloc - b->n_pool, now_s() - t0);
+      while(b->reap_started && (b->n_reap || b->reap_busy)) pthread_cond_wait(&b->cv_reaped, &b->mu);
+      if(getenv("MDK_HOST_PROFILE") && !b->reap_started) fprintf(stderr, "[mdk host] reaper: none (a BAM below MDK_REAP_MIN_MB, or MDK_NO_REAP)\n");
+      else if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] reaper: %d slabs given back in %.3fs of its own thread's time, %d left in the pool, %d still referenced; waited for it %.3fs at the end\n", b->n_reaped, b->t_reap, b->n_pool, b->n_alloc - b->n_pool, now_s() - t0);
       if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] framing the pieces (the walk over the BGZF headers, under the file's lock): %.3fs in all\n", b->t_frame);
       if(getenv("MDK_HOST_PROFILE")) { int k; for(k = 0; k < 2; k++) fprintf(stderr, "[mdk host] %s teams, summed over the teams that have left: %d pieces; waiting for the file's lock + framing %.3fs, inflating %.3fs (device teams: waiting for a device slab %.3fs, staging copy %.3fs, device %.3fs), handing over in file order %.3fs\n", k ? "device" : "host", b->tt_pieces[k], b->tt_next[k], b->tt_host[k], b->tt_slab[k], b->tt_copy[k], b->tt_dev[k], b->tt_deliver[k]); } }
     pthread_mutex_unlock(&b->mu);
@@ -578,7 +589,7 @@ static void *inflater_main(void *arg) {
         break;
     }
     { const int k = gt >= 0; pthread_mutex_lock(&b->mu); b->tt_next[k] += t_next; b->tt_host[k] += t_host; b->tt_deliver[k] += t_deliver; b->tt_slab[k] += td[0]; b->tt_copy[k] += td[1]; b->tt_dev[k] += td[2]; b->tt_pieces[k] += n_pieces; pthread_mutex_unlock(&b->mu); }
-    if(gt >= 0 && !getenv("MDK_NO_REAP")) { md_host_free(b->gpu_stage[gt]); b->gpu_stage[gt] = NULL; b->gpu_stage_cap[gt] = 0; }      /* its last piece has crossed the link (md_piece_wait): the staging block goes now, not at exit */
+    if(gt >= 0 && reap_wanted(b)) { md_host_free(b->gpu_stage[gt]); b->gpu_stage[gt] = NULL; b->gpu_stage_cap[gt] = 0; }      /* its last piece has crossed the link (md_piece_wait): the staging block goes now, not at exit */
     free(hbuf);
     free(ta);
     return NULL;
@@ -591,7 +602,7 @@ static void inflaters_start(mdk_bam *b) {
     if(i == 0) { b->io_status = -1; b->inf_done = -1; snprintf(b->err, sizeof(b->err), "cannot create an inflate thread"); }
     b->n_teams = i;
     b->inf_started = 1;
-    if(!b->reap_started && !getenv("MDK_NO_REAP") && pthread_create(&b->reap_th, NULL, reaper_main, b) == 0) b->reap_started = 1;
+    if(!b->reap_started && reap_wanted(b) && pthread_create(&b->reap_th, NULL, reaper_main, b) == 0) b->reap_started = 1;
     if(b->dev && b->n_gpu_teams) { int k; for(k = 0; k < b->n_gpu_teams; k++) { team_arg *ta = malloc(sizeof(*ta)); if(!ta) break; ta->b = b; ta->gpu_team = k; ta->idx = k; if(pthread_create(&b->gpu_th[k], NULL, inflater_main, ta)) { free(ta); break; } } b->n_gpu_teams = k; b->gpu_started = 1; }
 }
 static void inflaters_stop(mdk_bam *b) {

@@ -67,6 +67,7 @@ struct Arena { std::mutex mu; std::vector<char *> blocks; size_t cur = 0, used =
 static Arena g_arena[16];
 static std::atomic<int> g_open_handles{0};       // carved memory starts over only when nothing is carved AND no handle is open (a handle's buffers come and go; its status arrays stay)
 static const bool g_arena_on = getenv("MDK_NO_ARENA") == nullptr;
+size_t mdk_arena_max() { static const size_t v = getenv("MDK_ARENA_MAX_MB") && atol(getenv("MDK_ARENA_MAX_MB")) > 0 ? (size_t)atol(getenv("MDK_ARENA_MAX_MB")) << 20 : ARENA_MAX; return v; }
 void *arena_take(size_t bytes) {
     int dev = 0;
     if(!g_arena_on || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -947,7 +948,7 @@ extern "C" int md_dev_warm(int device) {
             (void)hipStreamSynchronize(s);
             if(hp) harena_give(hp); if(dp) arena_give(dp);
             if(!g_side_quit.load()) { arena_reserve(reserve_blocks_wanted()); g_reserve_done.store(1); }
-            if(!g_side_quit.load()) harena_reserve(4);            // (the slots' pinned result and table buffers: 2-4 MB each, two dozen slots)
+            if(!g_side_quit.load() && !getenv("MDK_NO_HARENA_RESERVE")) harena_reserve(4);            // (the slots' pinned result and table buffers: 2-4 MB each, two dozen slots)
             (void)hipGetLastError();
             std::lock_guard<std::mutex> lk(g_stash_mu); g_stash.push_back(s);
         });

@@ -37,6 +37,7 @@ struct TileEnt { int first, last; };     // segments [first,last) of the batch o
 // reused from their start --, and a buffer that grows takes a new piece: 288 GB of HBM make that a fair price.
 #define ARENA_BLOCK (1ull << 30)
 #define ARENA_MAX (512ull << 20)      /* (a 96 MB piece's inflated bytes with their headroom are 420 MB) */
+MDK_HIDDEN size_t mdk_arena_max();                 // ARENA_MAX, or MDK_ARENA_MAX_MB (experiments)
 MDK_HIDDEN void *arena_take(size_t bytes);          // NULL: no room could be made (the caller falls back to hipMalloc)
 MDK_HIDDEN void arena_give(void *p);
 template <typename T> struct DBuf {
@@ -45,7 +46,7 @@ template <typename T> struct DBuf {
         if(n <= cap) return 0;
         release();
         size_t want = n + n / 4 + 64;
-        if(want * sizeof(T) < ARENA_MAX) { p = (T *)arena_take(want * sizeof(T)); if(p) { carved = true; cap = want; return 0; } }
+        if(want * sizeof(T) < mdk_arena_max()) { p = (T *)arena_take(want * sizeof(T)); if(p) { carved = true; cap = want; return 0; } }
         MarkScope mk("DBuf hipMalloc");
         hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
         if(e != hipSuccess) { p = nullptr; return fail(MDK_ERR_NOMEM, "hipMalloc", e); }

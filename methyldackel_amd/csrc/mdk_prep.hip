@@ -970,7 +970,11 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
 }
 
 #define PREP_SCAN_LDS_MIN ((size_t)(4 * PB * sizeof(uint4) + PB * 8 + 2 * PB * 4 + PB * 4))
+#if PREP_STAGE
 #define PREP_SCAN_LDS (((size_t)(PB / 64) * RAWWIN_LDS) > PREP_SCAN_LDS_MIN ? ((size_t)(PB / 64) * RAWWIN_LDS) : PREP_SCAN_LDS_MIN)
+#else
+#define PREP_SCAN_LDS PREP_SCAN_LDS_MIN              /* no windows: the PrepRead stage and the name grouping only */
+#endif
 static_assert(PREP_SCAN_LDS >= 4 * PB * sizeof(uint4) + PB * 8 + 2 * PB * 4 + PB * 4, "the PrepRead stage and the workgroup's name grouping live in the windows' memory");
 MDK_HIDDEN int prep_kernels_init() {        // more dynamic LDS than the default window: once per process
     static std::once_flag once; static int rc = 1;
