@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <vector>
 #include <mutex>
 #include "mdk_hip.h"
@@ -84,13 +85,15 @@ template <typename T> struct HBuf {
 #define PREP_PREV_NONE INT32_MIN            // no read was admitted before this one
 #define PREP_PREV_UNKNOWN (INT32_MIN + 1)   // the one before it belongs to an earlier workgroup of k_prep_scan: k_prep_segs looks it up
 struct alignas(16) PrepRead {
-    int32_t pos, rend; uint16_t ncig, flag; uint8_t strand, nlen, adm, pad;             // quad 0 + quad 1: what pairing looks at in the OTHER reads of a name
+    int32_t pos, rend; uint16_t ncig, flag; uint8_t strand, nlen, adm, lqn;             // quad 0 + quad 1: what pairing looks at in the OTHER reads of a name (lqn = l_read_name)
     uint32_t name[4];
-    uint32_t seq_off, lq, cig_off, qn_off;                                              // quad 2 + quad 3: what the segments of a read (and of its mate) need
-    uint32_t cig[3]; int32_t prev;
+    uint32_t lq; int32_t prev; uint32_t cig[2];                                         // quad 2: what the segments of a read (and of its mate) need
 };
-static_assert(sizeof(PrepRead) == 64, "PrepRead layout");
-struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, max_lq; uint64_t algo_bytes; };      // max_lq: longest admitted read (mbias sizes its histogram by it)
+// 48 bytes (64 until round 6): where the record's name, CIGAR and sequence lie follows from the record's own offset -- rec_off[i], which
+// k_prep_segs loads coalesced -- with l_read_name and n_cigar_op: name at +36, CIGAR behind the name, sequence behind the CIGAR.  Two CIGAR
+// operations travel with the read (a read with three or more -- an indel, a skip: 2-3 % -- has the others read where they lie).
+static_assert(sizeof(PrepRead) == 48, "PrepRead layout");
+struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, max_lq; uint64_t algo_bytes; uint32_t far, pad; };      // max_lq: longest admitted read (mbias sizes its histogram by it)
 #define MDK_ERR_PREP_REDO (-100)   // internal: the segment array was enlarged and the preparation re-enqueued
 
 // everything the host reads back after a launch, one block per slot inside ONE device array (and its pinned mirror), so that
@@ -136,6 +139,7 @@ struct md_dev {
     md_prep_cfg prep; bool prep_set = false; std::vector<uint32_t *> mapbits; std::vector<int64_t> maplen;
     std::vector<md_region *> d_runs; std::vector<int64_t> n_runs; std::vector<char> has_runs;       // -l runs kept for the read prefilter
     uint32_t *d_hist = nullptr; int hist_cap = 0, hist_len = 0; std::vector<uint32_t> h_hist;      // mbias: rows [q][16], q < hist_cap
+    std::atomic<bool> scan_wide{getenv("MDK_SCAN_WIDE") && atoi(getenv("MDK_SCAN_WIDE")) > 0}; bool scan_wide_fixed = getenv("MDK_SCAN_WIDE") != nullptr;      // k_prep_scan's windows: wide for libraries with long read names (prep_outcome decides from the first chunks unless the environment has)
 };
 
 

@@ -76,11 +76,14 @@ struct PrepMulti { int n; int bstart[MAXM + 1]; PrepParams P[MAXM]; };
 #ifndef PREP_EXP_SEGS
 #define PREP_EXP_SEGS 0               // TIMING EXPERIMENTS ONLY (wrong results), bits: 1 no tile-run atomics, 2 no write pass, 4 no wait for the earlier tickets, 8 the ticket from blockIdx, 16 no byte tally
 #endif
+#ifndef PREP_EXP_SCAN
+#define PREP_EXP_SCAN 0               // TIMING EXPERIMENTS ONLY (wrong results), bits: 1 the PrepReads are not written out
+#endif
 #ifndef PREP_LOCAL
 #define PREP_LOCAL 1                  // k_prep_scan pairs the reads of a workgroup among themselves in LDS before the chunk's table is asked (0: every read asks the table)
 #endif
 #ifndef PREP_STAGE
-#define PREP_STAGE 1                  // k_prep_scan stages the record stream in LDS (0: every lane reads its record from HBM, round 3's arrangement)
+#define PREP_STAGE 2                  // how k_prep_scan gets at the records: 2 = of every record the pieces the scan looks at, gathered in LDS (GatherView: 25 KB per workgroup); 1 = the wavefront's whole stretch of the record stream in LDS (rounds 4-5: 76 KB per workgroup, two workgroups per CU); 0 = every lane reads its record from HBM
 #endif
 __device__ __forceinline__ int chunk_of_block(const PrepMulti &M) { return (int)((blockIdx.x & 7u) % (unsigned)M.n); }
 // What the workgroups of a chunk tell each other -- tickets, published counts, the name table's compare-and-swaps -- goes through agent-scope
@@ -112,11 +115,23 @@ __device__ __forceinline__ int first_zero_byte(uint64_t x, int n) {        // in
 // Where a lane reads ITS record from.  GlobalView: the record bytes in HBM, loads of any alignment (every load of a wavefront then touches 64
 // different lines).  LdsView: the wavefront has staged the stretch of the record stream that holds its 64 records in LDS with coalesced
 // 16-byte loads (k_prep_scan), and the fields are picked out of it: aligned dword reads + v_alignbyte, the record starts at any byte.
+#ifndef PREP_GLOBAL_NT
+#define PREP_GLOBAL_NT 0              // the lanes' own loads of their records non-temporal
+#endif
+typedef uint32_t __attribute__((aligned(1))) u32_any; typedef uint64_t __attribute__((aligned(1))) u64_any;
+typedef uint32_t u32x4_any __attribute__((ext_vector_type(4), aligned(1)));
 struct GlobalView {
     const uint8_t *r;                              // the record's block_size word
+#if PREP_GLOBAL_NT
+    __device__ __forceinline__ uint32_t u32(uint32_t x) const { return __builtin_nontemporal_load((const u32_any *)(r + x)); }
+    __device__ __forceinline__ uint64_t u64(uint32_t x) const { return __builtin_nontemporal_load((const u64_any *)(r + x)); }
+    __device__ __forceinline__ uint4 u128(uint32_t x) const { const u32x4_any v = __builtin_nontemporal_load((const u32x4_any *)(r + x)); return make_uint4(v.x, v.y, v.z, v.w); }
+#else
     __device__ __forceinline__ uint32_t u32(uint32_t x) const { return ld32(r + x); }
     __device__ __forceinline__ uint64_t u64(uint32_t x) const { return ld64(r + x); }
     __device__ __forceinline__ uint4 u128(uint32_t x) const { return ld128(r + x); }
+#endif
+    __device__ __forceinline__ bool fits(uint32_t, uint32_t, uint32_t) { return true; }
 };
 struct LdsView {
     const uint32_t *w; uint32_t b;                 // window words; byte offset of the record's block_size word in the window
@@ -124,6 +139,41 @@ struct LdsView {
     __device__ __forceinline__ uint64_t u64(uint32_t x) const { const uint32_t a = b + x, i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2]; return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, k) | (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, k) << 32; }
     __device__ __forceinline__ uint4 u128(uint32_t x) const { const uint32_t a = b + x, i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2], w3 = w[i + 3], w4 = w[i + 4];
         return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, k), __builtin_amdgcn_alignbyte(w2, w1, k), __builtin_amdgcn_alignbyte(w3, w2, k), __builtin_amdgcn_alignbyte(w4, w3, k)); }
+    __device__ __forceinline__ bool fits(uint32_t, uint32_t, uint32_t) { return true; }
+};
+// GatherView: of every record the wavefront has staged only the stretch that the scan looks at -- GW_NP 16-byte pieces from GW_PRE pieces before
+// the record's (16-byte aligned) start: the END of the record before it, i.e. that record's aux fields, then this record's header, name and CIGAR;
+// three quarters of a record, its sequence and qualities, are never asked for (stage_gather).  A record's bytes are therefore in two places: its
+// head (offsets below `thr`) in its own window, its aux area in the window of the record after it.  fits() says whether both hold what the scan
+// will ask for: a record whose head its window does not hold (a long name, a long CIGAR) is read from HBM by its lane altogether, one whose
+// aux area is longer than what the next window holds of it has its aux fields walked in HBM (`auxg`; scan_aux reads through u64 only).
+#ifndef GW_PRE
+#define GW_PRE 1
+#endif
+#ifndef GW_NP
+#define GW_NP 6                       // 96 bytes: 16-31 of the record before, at least 65 of the record (36 + a name of up to 24 letters + one operation)
+#endif
+#ifndef GW_NP_WIDE
+#define GW_NP_WIDE 8                  // 128 bytes: k_prep_scan_wide, for libraries with long read names (at least 97 bytes of the record: a name of up to 56 letters)
+#endif
+#define GW_LDS(NP) (65 * 16 * (NP) + 32)              // 64 records and the one behind them (+ slack for word reads at the end)
+__device__ __forceinline__ uint32_t gw_start(uint32_t o) { return o >= 16u * GW_PRE ? (o & ~15u) - 16u * GW_PRE : 0u; }
+struct GatherView {
+    const uint32_t *w; const uint8_t *g; bool auxg; uint32_t c1, c2, thr, lim1, onext, ws2, o;      // g: the record in HBM; byte x of the record at c1 + x of the wavefront's LDS (x < thr) or at c2 + x; lim1: bytes of the record its own window holds; ws2: where the next window starts in the record stream
+    __device__ __forceinline__ uint32_t at(uint32_t x) const { return x + (x < thr ? c1 : c2); }
+    __device__ __forceinline__ uint32_t u32(uint32_t x) const { const uint32_t a = at(x), i = a >> 2; return __builtin_amdgcn_alignbyte(w[i + 1], w[i], a & 3u); }
+    __device__ __forceinline__ uint64_t u64(uint32_t x) const {
+        if(auxg && x >= thr) return ld64(g + x);
+        const uint32_t a = at(x), i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2]; return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, k) | (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, k) << 32; }
+    __device__ __forceinline__ uint4 u128(uint32_t x) const { const uint32_t a = at(x), i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2], w3 = w[i + 3], w4 = w[i + 4];
+        return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, k), __builtin_amdgcn_alignbyte(w2, w1, k), __builtin_amdgcn_alignbyte(w3, w2, k), __builtin_amdgcn_alignbyte(w4, w3, k)); }
+    // head: the record's bytes [0, hend) are wanted; aux area [aux, end)
+    __device__ __forceinline__ bool fits(uint32_t hend, uint32_t aux, uint32_t end) {
+        if(hend > lim1) return false;
+        auxg = aux < end && (o + end != onext || o + aux < ws2);
+        thr = aux;
+        return true;
+    }
 };
 // aux area [s, e) (offsets from the record's block_size word): first NH and first XG, as bam_aux_get finds them; a malformed area ends the walk.
 // One 8-byte read per field: tag (2), type (1) and the first five value bytes -- all of a fixed-size value that NH or XG can have, and the first
@@ -297,7 +347,7 @@ __global__ __launch_bounds__(PB) void k_prep_zero(const PrepMulti M) {
 // or from the wavefront's staged window), o = the record's place in the chunk's record bytes.  Returns whether the record is admitted; D and h
 // are what the rest of the kernel needs of it.  ok = false: malformed.
 template <typename V>
-__device__ __forceinline__ int scan_record(const PrepParams &P, const V &v, const uint64_t o, PrepRead &D, uint64_t &h, bool &ok) {
+__device__ __forceinline__ int scan_record(const PrepParams &P, V v, const uint64_t o, PrepRead &D, uint64_t &h, bool &ok, bool &redo) {
     int adm = 0;
     const uint4 h0 = v.u128(0), h1 = v.u128(16);          // block_size refID pos (l_read_name mapq bin) | (n_cigar flag) l_seq next_refID next_pos
     const uint32_t bs = h0.x;
@@ -309,12 +359,12 @@ __device__ __forceinline__ int scan_record(const PrepParams &P, const V &v, cons
     if(!ok) return 0;
     // offsets from the record's block_size word
     const uint32_t qn = 4 + 32, cig = qn + lqn, seq = cig + 4 * ncig, qual = seq + (uint32_t)(lq + 1) / 2, aux = qual + (uint32_t)lq, end = 4 + bs;
+    if(!v.fits(seq, aux, end)) { redo = true; return 0; }       // (a view that holds a part of the record only: not this record's)
     const uint4 cb = v.u128(cig);                         // the first four CIGAR operations
     int32_t rlen = 0;
     for(uint32_t k = 0; k < ncig; k++) { const uint32_t c = k == 0 ? cb.x : k == 1 ? cb.y : k == 2 ? cb.z : k == 3 ? cb.w : v.u32(cig + 4 * k); const int op = c & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t)(c >> 4); }
     D.pos = pos; D.rend = pos + rlen; D.lq = (uint32_t)lq; D.ncig = (uint16_t)ncig; D.flag = (uint16_t)flag;
-    D.seq_off = (uint32_t)(o + seq); D.cig_off = (uint32_t)(o + cig); D.qn_off = (uint32_t)(o + qn);
-    D.cig[0] = cb.x; D.cig[1] = cb.y; D.cig[2] = cb.z;
+    D.lqn = (uint8_t)lqn; D.cig[0] = cb.x; D.cig[1] = cb.y;
     const md_prep_cfg &c = P.cfg;
     if(c.perread) {          // perRead.c:178-183: alignments that start inside the chunk; flag masks and MAPQ only
         bool keepr = (int64_t)pos >= P.beg && (int64_t)pos < P.end;
@@ -406,6 +456,46 @@ __device__ __forceinline__ void stage_window(const PrepParams &P, const int i0, 
     __builtin_amdgcn_wave_barrier();
 #endif
 }
+// PREP_STAGE 2: of each of the wavefront's 64 records, and of the record behind them, NP pieces (GatherView) -> LDS, window w at w * 16 NP.
+// A lane brings piece p = 64 j + lane in round j: the pieces of a window are neighbours in the instruction and fall into one or two lines.
+template <int NP>
+__device__ __forceinline__ void stage_gather(const PrepParams &P, const int i, const RecAt &A, const int lane, uint8_t *const win) {
+    // the start of window `lane`: the lane's record, or -- the lane after the chunk's last record -- the end of the records
+    const uint32_t ow = i < P.n_rec ? A.o : i == P.n_rec ? (uint32_t)P.raw_bytes : 0xffffffffu;
+    const uint32_t o64 = (uint32_t)__shfl((int)(i + 1 < P.n_rec ? A.onext : i + 1 == P.n_rec ? (uint32_t)P.raw_bytes : 0xffffffffu), 63);
+    const uint32_t lim = (uint32_t)((P.raw_bytes + 15) & ~15ull);          // (the buffer is 64 bytes longer than the records)
+#pragma unroll
+    for(int j = 0; j < (65 * NP + 63) / 64; j++) {
+        const uint32_t p = 64u * j + (uint32_t)lane, wdw = p / NP, k = p - wdw * NP;
+        const uint32_t os = (uint32_t)__shfl((int)ow, (int)(wdw & 63u));
+        const uint32_t oo = wdw < 64u ? os : o64;
+        const uint32_t src = gw_start(oo) + 16u * k;
+        if(wdw <= 64u && oo != 0xffffffffu && src < lim)
+            __builtin_amdgcn_global_load_lds((const void *)(P.raw + src), (__attribute__((address_space(3))) void *)(win + 1024 * j), 16, 0, PREP_WIN_AUX);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int NP>
+__device__ __forceinline__ int scan_one_gather(const PrepParams &P, const int i, const RecAt &A, const int lane, const uint8_t *const win, PrepRead &D, uint64_t &h, bool &far) {
+    constexpr uint32_t GW_BYTES = 16 * NP;
+    int adm = 0;
+    if(i < P.n_rec) {
+        const uint64_t o = A.o;
+        bool ok = o + 4 + 32 <= P.raw_bytes, redo = false;
+        if(ok) {
+            const uint32_t ws1 = gw_start(A.o), ws2 = gw_start(A.onext);
+            GatherView v; v.w = (const uint32_t *)win; v.g = P.raw + o; v.auxg = false; v.o = A.o; v.onext = A.onext; v.ws2 = ws2;
+            v.c1 = (uint32_t)lane * GW_BYTES + (A.o - ws1); v.lim1 = GW_BYTES - (A.o - ws1);
+            v.c2 = ((uint32_t)lane + 1u) * GW_BYTES + A.o - ws2;         // (mod 2^32: added to an offset >= ws2 - o it is a place in the next window)
+            v.thr = 0xffffffffu;
+            adm = scan_record(P, v, o, D, h, ok, redo);
+            if(redo) { far = true; redo = false; ok = true; adm = scan_record(P, GlobalView{P.raw + o}, o, D, h, ok, redo); }
+        }
+        if(!ok) atomicExch(&P.cnt->malformed, 1u);
+    }
+    return adm;
+}
 // record i through the window if it lies inside whole, from HBM otherwise
 __device__ __forceinline__ int scan_one(const PrepParams &P, const int i, const RecAt &A, const uint8_t *const win, const uint32_t wbase, const uint32_t wlen, PrepRead &D, uint64_t &h) {
     int adm = 0;
@@ -415,18 +505,43 @@ __device__ __forceinline__ int scan_one(const PrepParams &P, const int i, const 
         if(ok) {
             uint32_t bs = 0;
             const bool inwin = o >= wbase && o + 8 <= (uint64_t)wbase + wlen && (bs = LdsView{(const uint32_t *)win, (uint32_t)(o - wbase)}.u32(0), o + 4 + (uint64_t)bs <= (uint64_t)wbase + wlen);
-            if(inwin) adm = scan_record(P, LdsView{(const uint32_t *)win, (uint32_t)(o - wbase)}, o, D, h, ok);
-            else adm = scan_record(P, GlobalView{P.raw + o}, o, D, h, ok);
+            bool redo = false;
+            if(inwin) adm = scan_record(P, LdsView{(const uint32_t *)win, (uint32_t)(o - wbase)}, o, D, h, ok, redo);
+            else adm = scan_record(P, GlobalView{P.raw + o}, o, D, h, ok, redo);
         }
         if(!ok) atomicExch(&P.cnt->malformed, 1u);
     }
     return adm;
 }
+#if PREP_STAGE == 2
+#define SCAN_WAVE_LDS(NP) GW_LDS(NP)
+#else
+#define SCAN_WAVE_LDS(NP) RAWWIN_LDS
+#endif
+// the wavefront's 64 records from i0: staged as PREP_STAGE says, then every lane takes its own apart
+template <int NP>
+__device__ __forceinline__ int scan_wave(const PrepParams &P, const int i, const int i0, const int lane, uint8_t *const win, PrepRead &D, uint64_t &h) {
+    const RecAt at = rec_at(P, i);
+#if PREP_STAGE == 2
+    (void)i0;
+    stage_gather<NP>(P, i, at, lane, win);
+    bool far = false;
+    const int adm = scan_one_gather<NP>(P, i, at, lane, win, D, h, far);
+    const unsigned long long fm = __ballot(far);          // records whose head the window did not hold: the host widens the windows when they are many (prep_outcome)
+    if(fm && lane == 0) atomicAdd(&P.cnt->far, (uint32_t)__popcll(fm));
+    return adm;
+#else
+    uint32_t wbase, wlen;
+    stage_window(P, i0, at, lane, win, wbase, wlen);
+    return scan_one(P, i, at, win, wbase, wlen, D, h);
+#endif
+}
+#define RDQ 3                         // quads of a PrepRead
+static_assert(sizeof(PrepRead) == RDQ * sizeof(uint4), "PrepRead in quads");
 __device__ __forceinline__ void stage_read(uint4 *st, const PrepRead &D, const int adm) {
-    st[0] = make_uint4((uint32_t)D.pos, (uint32_t)D.rend, (uint32_t)D.ncig | (uint32_t)D.flag << 16, (uint32_t)D.strand | (uint32_t)D.nlen << 8 | (uint32_t)(adm ? 1u : 0u) << 16);
+    st[0] = make_uint4((uint32_t)D.pos, (uint32_t)D.rend, (uint32_t)D.ncig | (uint32_t)D.flag << 16, (uint32_t)D.strand | (uint32_t)D.nlen << 8 | (uint32_t)(adm ? 1u : 0u) << 16 | (uint32_t)D.lqn << 24);
     st[1] = make_uint4(D.name[0], D.name[1], D.name[2], D.name[3]);
-    st[2] = make_uint4(D.seq_off, D.lq, D.cig_off, D.qn_off);
-    st[3] = make_uint4(D.cig[0], D.cig[1], D.cig[2], (uint32_t)D.prev);
+    st[2] = make_uint4(D.lq, (uint32_t)D.prev, D.cig[0], D.cig[1]);
 }
 
 // barrier that orders LDS traffic only (does not drain this wavefront's outstanding global loads, stores and atomics)
@@ -457,7 +572,8 @@ __device__ __forceinline__ void table_insert(const PrepParams &P, int i, uint32_
 
 // extract / mbias: every record's PrepRead at the record's own index; no workgroup waits for another.
 // Workgroup b works for chunk (b mod 8) mod n (chunk_of_block) and is the tk-th of the workgroups that do: tk follows from b alone.
-__global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
+template <int NP>
+__device__ __forceinline__ void prep_scan_body(const PrepMulti &M) {
     __shared__ uint32_t wcnt[PB / 64]; __shared__ int32_t wlast[PB / 64];
     extern __shared__ __align__(16) uint4 dyn[];          // PB/64 windows of RAWWIN_LDS bytes; afterwards the workgroup's PrepReads on their way out (64 bytes each)
     uint4 *const stage = dyn;
@@ -467,11 +583,8 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than this chunk needs
     const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
-    uint32_t wbase, wlen;
-    uint8_t *const win = (uint8_t *)dyn + (size_t)wave * RAWWIN_LDS;
-    const RecAt at = rec_at(P, i);
-    stage_window(P, (int)(tk * PB) + 64 * wave, at, lane, win, wbase, wlen);
-    const int adm = scan_one(P, i, at, win, wbase, wlen, D, h);
+    uint8_t *const win = (uint8_t *)dyn + (size_t)wave * SCAN_WAVE_LDS(NP);
+    const int adm = scan_wave<NP>(P, i, (int)(tk * PB) + 64 * wave, lane, win, D, h);
     // the start of the read admitted just before this one: the nearest admitted lane below in the wavefront, else the last admitted read of
     // the nearest wavefront below in the workgroup, else (not the chunk's first workgroup) left to k_prep_segs
     const unsigned long long m = __ballot(adm), below = m & ((1ull << lane) - 1ull);
@@ -514,7 +627,7 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     {
         // (behind the PrepRead stage in the windows' memory) lh: every lane's hash; lt: open addressing, 2 PB entries of lane + 1; lhead: per
         // group -- filed under the lane that took the entry -- the lane that joined last
-        unsigned long long *const lh = (unsigned long long *)(stage + 4 * PB); uint32_t *const lt = (uint32_t *)(lh + PB), *const lhead = lt + 2 * PB;
+        unsigned long long *const lh = (unsigned long long *)(stage + RDQ * PB); uint32_t *const lt = (uint32_t *)(lh + PB), *const lhead = lt + 2 * PB;
         lh[threadIdx.x] = ins ? h : 0ull; lt[threadIdx.x] = 0u; lt[threadIdx.x + PB] = 0u; lhead[threadIdx.x] = 0xffffffffu;
         lds_only_barrier();
         uint32_t rep = threadIdx.x;
@@ -547,19 +660,27 @@ __global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) {
     if(ins && lprev >= 0) { P.hnext[i] = i0 + lprev; P.hfwd[i0 + lprev] = i; }
     // the PrepReads go to the workgroup's stage in LDS first and from there to rd[] as whole lines: written straight from the lanes, the four
     // quads would leave in four store instructions of 16 bytes per 64 -- partial lines, which the memory side does not merge
-    stage_read(stage + 4 * threadIdx.x, D, adm);
+    stage_read(stage + RDQ * threadIdx.x, D, adm);
     lds_only_barrier();
     {
         const int cnt = P.n_rec - i0 < PB ? P.n_rec - i0 : PB;
         uint4 *out = (uint4 *)(P.rd + i0);
-        for(int q = threadIdx.x; q < 4 * cnt; q += PB) out[q] = stage[q];
+#if !(PREP_EXP_SCAN & 1)
+        for(int q = threadIdx.x; q < RDQ * cnt; q += PB) out[q] = stage[q];
+#else
+        if(cnt < 0) out[threadIdx.x] = stage[threadIdx.x];
+#endif
     }
     if(gins) table_insert(P, i, sl, key, mine, old);
 }
 
+__global__ __launch_bounds__(PB) void k_prep_scan(const PrepMulti M) { prep_scan_body<GW_NP>(M); }
+__global__ __launch_bounds__(PB) void k_prep_scan_wide(const PrepMulti M) { prep_scan_body<GW_NP_WIDE>(M); }       // (the same with wider windows: enqueue_prep_group)
+
 // perRead: the selected reads compacted IN FILE ORDER (rd[a], aidx[a] = the a-th kept record): a workgroup draws a ticket, publishes its
 // count, and adds up the counts of the tickets before it
 __global__ __launch_bounds__(PB) void k_prep_scan_ordered(const PrepMulti M) {
+    constexpr int NP = GW_NP;
     __shared__ uint32_t s_tk, wcnt[PB / 64], red[PB / 64];
     extern __shared__ __align__(16) uint4 dyn[];
     uint4 *const stage = dyn;
@@ -569,11 +690,8 @@ __global__ __launch_bounds__(PB) void k_prep_scan_ordered(const PrepMulti M) {
     const uint32_t tk = s_tk; const int i = (int)(tk * PB + threadIdx.x), lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if(tk >= (uint32_t)P.nblocks) return;                 // more workgroups than tickets for this chunk
     PrepRead D; memset(&D, 0, sizeof(D)); uint64_t h = 0;
-    uint32_t wbase, wlen;
-    uint8_t *const win = (uint8_t *)dyn + (size_t)wave * RAWWIN_LDS;
-    const RecAt at = rec_at(P, i);
-    stage_window(P, (int)(tk * PB) + 64 * wave, at, lane, win, wbase, wlen);
-    const int adm = scan_one(P, i, at, win, wbase, wlen, D, h);
+    uint8_t *const win = (uint8_t *)dyn + (size_t)wave * SCAN_WAVE_LDS(NP);
+    const int adm = scan_wave<NP>(P, i, (int)(tk * PB) + 64 * wave, lane, win, D, h);
     const unsigned long long m = __ballot(adm);
     if(lane == 0) wcnt[wave] = (uint32_t)__popcll(m);
     __syncthreads();
@@ -585,12 +703,12 @@ __global__ __launch_bounds__(PB) void k_prep_scan_ordered(const PrepMulti M) {
     if(adm) {
         if(P.aidx) P.aidx[base + rank] = (uint32_t)i;
         D.prev = PREP_PREV_UNKNOWN;
-        stage_read(stage + 4 * rank, D, 1);
+        stage_read(stage + RDQ * rank, D, 1);
     }
     __syncthreads();
     {
         uint4 *out = (uint4 *)(P.rd + base);
-        for(uint32_t q = threadIdx.x; q < 4 * total; q += PB) out[q] = stage[q];
+        for(uint32_t q = threadIdx.x; q < RDQ * total; q += PB) out[q] = stage[q];
     }
 }
 
@@ -598,7 +716,7 @@ __global__ __launch_bounds__(PB) void k_prep_scan_ordered(const PrepMulti M) {
 // zeroed whole, the compiler splits it into BYTES -- one register per byte of every word that holds a byte field -- and k_prep_segs
 // needed 86 VGPRs for two of them.)
 struct RdRegs {
-    uint4 q0, q1, q2, q3;
+    uint4 q0, q1, q2; uint32_t o;                      // its three quads; o: where its record lies (rec_off)
     __device__ __forceinline__ int32_t pos() const { return (int32_t)q0.x; }
     __device__ __forceinline__ int32_t rend() const { return (int32_t)q0.y; }
     __device__ __forceinline__ uint32_t ncig() const { return q0.z & 0xffffu; }
@@ -606,21 +724,22 @@ struct RdRegs {
     __device__ __forceinline__ uint32_t strand() const { return q0.w & 255u; }
     __device__ __forceinline__ uint32_t nlen() const { return (q0.w >> 8) & 255u; }
     __device__ __forceinline__ bool adm() const { return (q0.w >> 16) & 1u; }
-    __device__ __forceinline__ uint32_t seq_off() const { return q2.x; }
-    __device__ __forceinline__ uint32_t lq() const { return q2.y; }
-    __device__ __forceinline__ uint32_t cig_off() const { return q2.z; }
-    __device__ __forceinline__ uint32_t qn_off() const { return q2.w; }
-    __device__ __forceinline__ int32_t prev() const { return (int32_t)q3.w; }
+    __device__ __forceinline__ uint32_t qn_off() const { return o + 36u; }
+    __device__ __forceinline__ uint32_t cig_off() const { return o + 36u + (q0.w >> 24); }
+    __device__ __forceinline__ uint32_t seq_off() const { return o + 36u + (q0.w >> 24) + 4u * (q0.z & 0xffffu); }
+    __device__ __forceinline__ uint32_t lq() const { return q2.x; }
+    __device__ __forceinline__ int32_t prev() const { return (int32_t)q2.y; }
 };
-__device__ __forceinline__ RdRegs rd_zero() { RdRegs R; R.q0 = R.q1 = R.q2 = R.q3 = make_uint4(0, 0, 0, 0); return R; }
-__device__ __forceinline__ RdRegs rd_load(const PrepRead *rd, const uint32_t x) { const uint4 *q = (const uint4 *)&rd[x]; RdRegs R; R.q0 = q[0]; R.q1 = q[1]; R.q2 = q[2]; R.q3 = q[3]; return R; }
+__device__ __forceinline__ RdRegs rd_zero() { RdRegs R; R.q0 = R.q1 = R.q2 = make_uint4(0, 0, 0, 0); R.o = 0; return R; }
+// rd[x] with the offset of ITS record: record x's (extract, mbias: a PrepRead per record), or -- perRead: rd[] holds the kept reads only -- record aidx[x]'s
+__device__ __forceinline__ RdRegs rd_load(const PrepParams &P, const uint32_t x) { const uint4 *q = (const uint4 *)&P.rd[x]; RdRegs R; R.q0 = q[0]; R.q1 = q[1]; R.q2 = q[2]; R.o = P.rec_off[P.aidx ? P.aidx[x] : x]; return R; }
 
 // what pairing looks at in another read of the name: quad 0 (pos rend ncig|flag strand|nlen|adm), quad 1 (the name's first 16 bytes) and the
 // last word (the start of the read admitted before it) of its PrepRead, taken apart in registers (a PrepRead filled through a pointer would
 // live in scratch)
 struct OtherRead { int32_t rend, prev; uint32_t flag, nlen; uint4 name; };
 __device__ __forceinline__ OtherRead other_read(const PrepRead *rd, const int32_t x) {
-    const uint4 *q = (const uint4 *)&rd[x]; const uint4 q0 = q[0], q1 = q[1]; const uint32_t pv = ((const uint32_t *)q)[15];
+    const uint4 *q = (const uint4 *)&rd[x]; const uint4 q0 = q[0], q1 = q[1]; const uint32_t pv = ((const uint32_t *)q)[9];
     OtherRead O; O.rend = (int32_t)q0.y; O.flag = q0.z >> 16; O.nlen = (q0.w >> 8) & 255u; O.name = q1; O.prev = (int32_t)pv;
     return O;
 }
@@ -654,7 +773,7 @@ __device__ __forceinline__ int32_t prev_of(const PrepRead *rd, const int32_t x, 
 // this chunk.  (As a real call it cost the kernel 52 bytes of scratch per lane -- and every launch ~30 us at each kernel boundary while the
 // runtime found room for it, profiles/r05c_prep_variants.txt; inlined, its state lives in LDS and the kernel needs 57 VGPRs.)
 #define PAIR_SECOND 0x40000000
-struct PairCtx { const int32_t *hnext, *hfwd; const PrepRead *rd; const uint8_t *raw; int32_t tid; };
+struct PairCtx { const int32_t *hnext, *hfwd; const PrepRead *rd; const uint32_t *rec_off; const uint8_t *raw; int32_t tid; };
 __device__ __forceinline__ int32_t pair_of_many(const PairCtx X, MdkPairState &S, const uint32_t a, const int32_t a_rend, const int32_t a_prev, const uint32_t a_flag, const uint32_t a_nlen, const uint4 a_name, const uint32_t a_qn_off) {
     int32_t head = (int32_t)a; int k = 0;
     for(int guard = 0; X.hfwd[head] >= 0; head = X.hfwd[head]) if(++guard > MAXG) return -2;
@@ -666,7 +785,7 @@ __device__ __forceinline__ int32_t pair_of_many(const PairCtx X, MdkPairState &S
         if(x == 0x7fffffff) break;
         last = x;
         int32_t rend = a_rend, prev = a_prev; uint32_t flag = a_flag;
-        if((uint32_t)x != a) { const OtherRead O = other_read(X.rd, x); if(!same_name(X.raw, a_nlen, a_name, a_qn_off, O.nlen, O.name, X.rd[x].qn_off)) continue; rend = O.rend; flag = O.flag; prev = O.prev; }      // (continue: another name with the same hash)
+        if((uint32_t)x != a) { const OtherRead O = other_read(X.rd, x); if(!same_name(X.raw, a_nlen, a_name, a_qn_off, O.nlen, O.name, X.rec_off[x] + 36u)) continue; rend = O.rend; flag = O.flag; prev = O.prev; }      // (continue: another name with the same hash)
         prev = prev_of(X.rd, x, prev);
         mdk_pair_step(S, X.tid, a, x, flag, rend, prev == PREP_PREV_NONE, prev);
         if(S.overflow) return -2;
@@ -676,15 +795,15 @@ __device__ __forceinline__ int32_t pair_of_many(const PairCtx X, MdkPairState &S
 
 // gapless runs of a CIGAR, one at a time (calculate_positions, overlaps.c:27-52)
 struct RunIt {
-    uint32_t cig_off, c0, c1, c2; int n, k; int32_t x, y, lq;         // the first three operations travel with the read (PrepRead::cig); the others are read where they lie
+    uint32_t cig_off, c0, c1; int n, k; int32_t x, y, lq;             // the first two operations travel with the read (PrepRead::cig); the others are read where they lie
     int32_t rx, ry, rl;                                               // the run at hand: rl > 0 while there is one
     __device__ __forceinline__ bool valid() const { return rl > 0; }
-    __device__ void init(const uint8_t *raw, const RdRegs &r) { cig_off = r.cig_off(); c0 = r.q3.x; c1 = r.q3.y; c2 = r.q3.z; n = (int)r.ncig(); k = 0; x = r.pos(); y = 0; lq = (int32_t)r.lq(); rx = ry = rl = 0; next(raw); }
+    __device__ void init(const uint8_t *raw, const RdRegs &r) { cig_off = r.cig_off(); c0 = r.q2.z; c1 = r.q2.w; n = (int)r.ncig(); k = 0; x = r.pos(); y = 0; lq = (int32_t)r.lq(); rx = ry = rl = 0; next(raw); }
     __device__ void stop() { rl = 0; }
     __device__ void next(const uint8_t *raw) {
         rl = 0;
         while(k < n) {
-            const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : ld32(raw + cig_off + 4 * k); k++;
+            const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : ld32(raw + cig_off + 4 * k); k++;
             const int op = c & 15; const int32_t len = (int32_t)(c >> 4);
             if(op == 0 || op == 7 || op == 8) {
                 int32_t l = len; if(y + l > lq) l = lq - y;          // a CIGAR that consumes more bases than the record stores
@@ -767,7 +886,7 @@ __global__ __launch_bounds__(PB, 8) void k_prep_segs(const PrepMulti M) {
     RdRegs r = rd_zero(), m = rd_zero(); bool has_mate = false, is_second = false; int32_t mate = -1;
     int32_t lnext = -1, lfwd = -1;
     const int32_t mylast = tk > 0 ? (int32_t)P.cntA[tk - 1] : PREP_PREV_NONE;      // (one scalar load, on its way with the rest)
-    if(a < n_rec) { r = rd_load(P.rd, a); if(!P.cfg.no_pairing) { lnext = P.hnext[a]; lfwd = P.hfwd[a]; } }      // (hnext of a record that was not admitted is whatever the buffer held: looked at only under adm)
+    if(a < n_rec) { r = rd_load(P, a); if(!P.cfg.no_pairing) { lnext = P.hnext[a]; lfwd = P.hfwd[a]; } }      // (hnext of a record that was not admitted is whatever the buffer held: looked at only under adm)
     const bool active = a < n_rec && r.adm();
     uint32_t n = 0; unsigned long long bytes = 0;
     if(active) {
@@ -777,7 +896,7 @@ __global__ __launch_bounds__(PB, 8) void k_prep_segs(const PrepMulti M) {
                 // exactly two reads under the name unless the chain goes on at either end: this read has both neighbours, or the other
                 // read has one on its far side
                 const int32_t cn = P.hnext[c], cf = P.hfwd[c];
-                m = rd_load(P.rd, (uint32_t)c);
+                m = rd_load(P, (uint32_t)c);
                 const int32_t cblk = c / PB, clast = cblk > 0 ? (int32_t)P.cntA[cblk - 1] : PREP_PREV_NONE;      // (asked for with the rest, used if c turns out to be its block's first admitted read)
                 const bool more = lnext >= 0 ? (lfwd >= 0 || cn >= 0) : cf >= 0;
                 const int32_t rprev = r.prev() == PREP_PREV_UNKNOWN ? block_prev(P.cntA, (int32_t)tk, mylast) : r.prev();
@@ -793,10 +912,10 @@ __global__ __launch_bounds__(PB, 8) void k_prep_segs(const PrepMulti M) {
                                           a_first ? m.flag() : r.flag(), a_first ? m.rend() : r.rend(), prev_s, is_second);
                     }
                 } else {
-                    PairCtx X; X.hnext = P.hnext; X.hfwd = P.hfwd; X.rd = P.rd; X.raw = P.raw; X.tid = P.tid;
+                    PairCtx X; X.hnext = P.hnext; X.hfwd = P.hfwd; X.rd = P.rd; X.rec_off = P.rec_off; X.raw = P.raw; X.tid = P.tid;
                     mi = pair_of_many(X, ((MdkPairState *)sstage)[threadIdx.x], a, r.rend(), r.prev(), r.flag(), r.nlen(), r.q1, r.qn_off());
                     if(mi == -2) { atomicExch(&P.cnt->fallback, 1u); mi = -1; }
-                    if(mi >= 0) { is_second = (mi & PAIR_SECOND) != 0; mi &= ~PAIR_SECOND; m = rd_load(P.rd, (uint32_t)mi); }
+                    if(mi >= 0) { is_second = (mi & PAIR_SECOND) != 0; mi &= ~PAIR_SECOND; m = rd_load(P, (uint32_t)mi); }
                 }
                 has_mate = mi >= 0; mate = mi;
             }
@@ -844,7 +963,7 @@ __global__ __launch_bounds__(PB, 8) void k_prep_segs(const PrepMulti M) {
     }
     if(total > SEG_STAGE && n && wpos + n > SEG_STAGE && !(PREP_EXP_SEGS & 2)) {
         // (rare: what did not fit the stage leaves from the lanes; the reads are loaded again rather than kept in registers across the wait)
-        const RdRegs r2 = rd_load(P.rd, a), m2 = has_mate ? rd_load(P.rd, (uint32_t)mate) : rd_zero();
+        const RdRegs r2 = rd_load(P, a), m2 = has_mate ? rd_load(P, (uint32_t)mate) : rd_zero();
         md_seg *const sg = P.seg + before; int32_t lo2 = 0, hi2 = 0;
         (void)read_segments<true>(P, r2, has_mate, m2, is_second, [sg](uint32_t o, uint4 g0, uint4 g1) { if(o >= SEG_STAGE) { uint4 *q = (uint4 *)(sg + o); q[0] = g0; q[1] = g1; } }, wpos, cap > before ? cap - before : 0u, lo2, hi2);
     }
@@ -879,10 +998,10 @@ __global__ __launch_bounds__(PB, 8) void k_prep_segs(const PrepMulti M) {
 __global__ __launch_bounds__(PB) void k_perread_raw(const PrepParams P, const uint8_t *ctxcode, int64_t wend, md_pr_count *out) {
     const uint32_t a = blockIdx.x * PB + threadIdx.x;
     if(a >= P.cnt->n_adm) return;
-    const RdRegs r = rd_load(P.rd, a);
+    const RdRegs r = rd_load(P, a);
     const uint8_t *seq = P.raw + r.seq_off(), *qual = seq + ((r.lq() + 1) >> 1), *cg = P.raw + r.cig_off();
-    const uint32_t c0 = r.q3.x, c1 = r.q3.y, c2 = r.q3.z;
-    out[a] = perread_walk(seq, qual, r.lq(), (int)r.ncig(), r.pos(), r.strand() & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg, c0, c1, c2](int k) { return k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : ld32(cg + 4 * k); });
+    const uint32_t c0 = r.q2.z, c1 = r.q2.w;
+    out[a] = perread_walk(seq, qual, r.lq(), (int)r.ncig(), r.pos(), r.strand() & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg, c0, c1](int k) { return k == 0 ? c0 : k == 1 ? c1 : ld32(cg + 4 * k); });
 }
 
 // record offsets of a device-resident range (offsets in the piece it was inflated in) -> offsets in the chunk's concatenation
@@ -969,16 +1088,19 @@ extern "C" int md_dev_set_mappability(md_dev *h, int32_t tid, const uint32_t *bi
     return 0;
 }
 
-#define PREP_SCAN_LDS_MIN ((size_t)(4 * PB * sizeof(uint4) + PB * 8 + 2 * PB * 4 + PB * 4))
+#define PREP_SCAN_LDS_MIN ((size_t)(RDQ * PB * sizeof(uint4) + PB * 8 + 2 * PB * 4 + PB * 4))
 #if PREP_STAGE
-#define PREP_SCAN_LDS (((size_t)(PB / 64) * RAWWIN_LDS) > PREP_SCAN_LDS_MIN ? ((size_t)(PB / 64) * RAWWIN_LDS) : PREP_SCAN_LDS_MIN)
+#define PREP_SCAN_LDS_NP(NP) (((size_t)(PB / 64) * SCAN_WAVE_LDS(NP)) > PREP_SCAN_LDS_MIN ? ((size_t)(PB / 64) * SCAN_WAVE_LDS(NP)) : PREP_SCAN_LDS_MIN)
 #else
-#define PREP_SCAN_LDS PREP_SCAN_LDS_MIN              /* no windows: the PrepRead stage and the name grouping only */
+#define PREP_SCAN_LDS_NP(NP) PREP_SCAN_LDS_MIN       /* no windows: the PrepRead stage and the name grouping only */
 #endif
-static_assert(PREP_SCAN_LDS >= 4 * PB * sizeof(uint4) + PB * 8 + 2 * PB * 4 + PB * 4, "the PrepRead stage and the workgroup's name grouping live in the windows' memory");
+#define PREP_SCAN_LDS PREP_SCAN_LDS_NP(GW_NP)
+#define PREP_SCAN_LDS_WIDE PREP_SCAN_LDS_NP(GW_NP_WIDE)
+static_assert(PREP_SCAN_LDS >= RDQ * PB * sizeof(uint4) + PB * 8 + 2 * PB * 4 + PB * 4, "the PrepRead stage and the workgroup's name grouping live in the windows' memory");
 MDK_HIDDEN int prep_kernels_init() {        // more dynamic LDS than the default window: once per process
     static std::once_flag once; static int rc = 1;
     std::call_once(once, [] { rc = (hipFuncSetAttribute((const void *)k_prep_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess &&
+                                    hipFuncSetAttribute((const void *)k_prep_scan_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS_WIDE) == hipSuccess &&
                                     hipFuncSetAttribute((const void *)k_prep_scan_ordered, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PREP_SCAN_LDS) == hipSuccess) ? 0 : 1; });
     return rc;
 }
@@ -1027,7 +1149,8 @@ int enqueue_prep_group(md_dev *h, Slot *const *ss, int n, hipStream_t st) {
         static_assert(MAXM <= 8, "chunk_of_block deals the chunks of a launch to 8 XCDs");
         if(h->prep.perread) hipLaunchKernelGGL(k_prep_scan_ordered, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
         else {
-            hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
+            if(h->scan_wide.load(std::memory_order_relaxed)) hipLaunchKernelGGL(k_prep_scan_wide, dim3(grid), dim3(PB), PREP_SCAN_LDS_WIDE, st, M);
+            else hipLaunchKernelGGL(k_prep_scan, dim3(grid), dim3(PB), PREP_SCAN_LDS, st, M);
             hipLaunchKernelGGL(k_prep_segs, dim3(grid), dim3(PB), 0, st, M);
         }
     }
@@ -1166,6 +1289,9 @@ MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s) {
     if(c.strand0) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "Can't determine the strand of a read!"); return MDK_ERR_STRAND0; }
     if(c.fallback) { snprintf(mdk_err_buf(), MDK_ERR_BYTES, "a read name with more than %d records or %d live reads: this chunk needs the host preparation", MAXG, MDK_MAXLIVE); return MDK_ERR_PREP_HOST; }
     s->n_reads = (int)c.n_adm; s->n_segs = (int)c.n_segs; s->read_bytes = c.algo_bytes;
+    // a library whose records' heads (36 bytes, the name, the CIGAR) do not fit k_prep_scan's windows -- a quarter of a chunk's records read from HBM by
+    // their lanes -- gets the wide windows from here on (same results either way; MDK_SCAN_WIDE=0/1 decides beforehand)
+    if(!h->scan_wide_fixed && (uint64_t)c.far * 4 > (uint64_t)(s->pr_nrec > 0 ? s->pr_nrec : 0)) h->scan_wide.store(true, std::memory_order_relaxed);
     if((size_t)c.n_segs > s->d_seg_in.cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
         if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));

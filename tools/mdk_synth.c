@@ -140,7 +140,7 @@ static int reg2bin(int64_t beg, int64_t end) {
 }
 static const uint8_t nt16[256] = {['A'] = 1, ['C'] = 2, ['G'] = 4, ['T'] = 8, ['N'] = 15, ['a'] = 1, ['c'] = 2, ['g'] = 4, ['t'] = 8, ['n'] = 15};
 
-typedef struct { int clean, bismark, extras, single; int readlen; } opts_t;
+typedef struct { int clean, bismark, extras, single; int readlen; int illumina; } opts_t;       /* illumina: read names and aux fields as long as a sequencer's and a bisulfite aligner's */
 typedef struct { uint32_t op[8]; int n; int rspan, qlen; } cig_t;
 
 /* choose a CIGAR for a read of `L` query bases */
@@ -202,6 +202,7 @@ static void emit_read(buf_t *out, const contig_t *ct, int tid, int64_t pos, cons
     bput(out, seq, (L + 1) / 2); bput(out, qual, L);
     /* aux */
     bput(out, "NMC", 3); b8(out, (uint8_t)rndi(r, 4));
+    if(o->illumina) { int j; bput(out, "ASi", 3); b32(out, (uint32_t)(-(int)rndi(r, 40))); bput(out, "XMZ", 3); for(j = 0; j < L; j++) b8(out, (uint8_t)"..z.h.x.Z"[rndi(r, 9)]); b8(out, 0); }
     if(!o->clean && rndu(r) < 0.3) { bput(out, "MDZ", 3); bput(out, "150", 4); }
     if(o->bismark) { bput(out, "XRZ", 3); bput(out, (flag & 0x80) ? "GA" : "CT", 3); bput(out, "XGZ", 3); bput(out, (strand == 1 || strand == 3) ? "CT" : "GA", 3); }
     if(!o->clean && rndu(r) < 0.02) { bput(out, "XGi", 3); b32(out, (uint32_t)rndi(r, 3)); }      /* non-Bismark XG: must be ignored */
@@ -223,7 +224,8 @@ static void gen_pairs(genctx *G, int t, uint64_t pi0, uint64_t pi1) {
             fs = (int64_t)(rndu(&G->rr) * (L - flen + 1));
             ob = rndu(&G->rr) < 0.5;
             make_cigar(&c1, G->o->readlen, &G->rr, G->o); make_cigar(&c2, G->o->readlen, &G->rr, G->o);
-            snprintf(qn, sizeof(qn), "f%d_%" PRIu64, t, pi);
+            if(G->o->illumina) snprintf(qn, sizeof(qn), "A00%03d:%d:HXXXXXXXX:%d:%04d:%05" PRIu64 ":%05" PRIu64, 123 + t % 7, 45 + t, 1 + (int)(pi & 3), 1101 + (int)(pi % 977), pi % 32749, pi);
+            else snprintf(qn, sizeof(qn), "f%d_%" PRIu64, t, pi);
             fragkey = mix64(G->seed ^ ((uint64_t)t << 48) ^ pi);
             mapq = 40 + rndi(&G->rr, 21); nh = 0; fl1 = 0; fl2 = 0;
             if(!G->o->clean) {
@@ -340,7 +342,7 @@ static void par_run(par_ctx *P, int phase, int nt) {
     for(k = 0; k < made; k++) pthread_join(th[k], NULL);
 }
 int main(int argc, char **argv) {
-    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {"no-bai", 0, 0, 7}, {"split-records", 0, 0, 8}, {0, 0, 0, 0}};
+    static struct option lo[] = {{"bismark", 0, 0, 1}, {"extras", 0, 0, 2}, {"clean", 0, 0, 3}, {"bbm", 0, 0, 4}, {"single", 0, 0, 5}, {"bw", 0, 0, 6}, {"no-bai", 0, 0, 7}, {"split-records", 0, 0, 8}, {"illumina", 0, 0, 9}, {0, 0, 0, 0}};
     const char *prefix = NULL, *lens = "1000000"; double cov = 30; uint64_t seed = 0x5EED0001ULL; int level = 1, c, want_bbm = 0;
     opts_t o = {0, 0, 0, 0, 150}; int want_bw = 0, no_bai = 0, split_records = 0, par = 0; contig_t *ct = NULL; int nct = 0, t; rng_t rr, rg; rec_t *recs = NULL; size_t nrec = 0, mrec = 0, i;
     buf_t pool = {0, 0, 0}; size_t *offs = NULL; char fn[4096]; uint64_t ord = 0, npairs_total = 0, nbases = 0;
@@ -348,8 +350,8 @@ int main(int argc, char **argv) {
         switch(c) {
         case 'o': prefix = optarg; break; case 'L': lens = optarg; break; case 'c': cov = atof(optarg); break;
         case 'l': o.readlen = atoi(optarg); break; case 's': seed = strtoull(optarg, NULL, 0); break; case 'z': level = atoi(optarg); break; case 'j': par = atoi(optarg); break;
-        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break; case 7: no_bai = 1; break; case 8: split_records = 1; break;
-        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [-j threads] [--bismark] [--extras] [--clean] [--bbm] [--bw] [--single] [--no-bai] [--split-records]\n"); return 1;
+        case 1: o.bismark = 1; break; case 2: o.extras = 1; break; case 3: o.clean = 1; break; case 4: want_bbm = 1; break; case 5: o.single = 1; break; case 6: want_bw = 1; break; case 7: no_bai = 1; break; case 8: split_records = 1; break; case 9: o.illumina = 1; break;
+        default: fprintf(stderr, "usage: mdk_synth -o PREFIX [-L len,len..] [-c cov] [-l readlen] [-s seed] [-z level] [-j threads] [--bismark] [--extras] [--clean] [--bbm] [--bw] [--single] [--no-bai] [--split-records] [--illumina]\n"); return 1;
         }
     }
     if(!prefix) { fprintf(stderr, "mdk_synth: -o PREFIX is required\n"); return 1; }
