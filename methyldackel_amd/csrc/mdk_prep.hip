@@ -866,7 +866,7 @@ __global__ __launch_bounds__(PB, 8) __attribute__((amdgpu_num_sgpr(SEGS_SGPRS)))
 #else
 __global__ __launch_bounds__(PB, 8) void k_prep_segs(const PrepMulti M) {
 #endif
-    __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64];
+    __shared__ uint32_t s_tk, wsum[PB / 64], red[PB / 64]; __shared__ unsigned long long wbytes[PB / 64];
     // the workgroup's segments on their way out (32 bytes each; a workgroup of 256 records makes ~350); before that, the rare path's state
     __shared__ __align__(16) uint4 sstage[2 * SEG_STAGE];
     __shared__ int s_tlo, s_thi, tfirst[SEG_TSPAN], tlast[SEG_TSPAN];      // the tiles the workgroup's segments reach, and per tile the run of them (relative to the workgroup's first)
@@ -929,14 +929,15 @@ __global__ __launch_bounds__(PB, 8) void k_prep_segs(const PrepMulti M) {
 #pragma unroll
     for(int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if(lane >= d) incl += t; }
     if(lane == 63) wsum[wave] = incl;
+    { unsigned long long b = bytes;                       // the workgroup's share of the byte tally: one atomic per workgroup (one per wavefront -- 25,000 on one address per launch -- cost the kernel 4 us)
+#pragma unroll
+      for(int d = 32; d; d >>= 1) b += __shfl_xor(b, d);
+      if(lane == 0) wbytes[wave] = b; }
     __syncthreads();                                      // (also: nobody is in the rare path any more -- the stage's memory is the stage's)
     uint32_t wpos = incl - n, total = 0;
     for(int w = 0; w < PB / 64; w++) { if(w < wave) wpos += wsum[w]; total += wsum[w]; }
     if(threadIdx.x == 0) sync_set(&P.cntS[tk], total | CNT_READY);
-    { unsigned long long b = bytes;
-#pragma unroll
-      for(int d = 32; d; d >>= 1) b += __shfl_xor(b, d);
-      if(!(PREP_EXP_SEGS & 16) && lane == 0 && b) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, b); }
+    if(!(PREP_EXP_SEGS & 16) && threadIdx.x == 64) { unsigned long long b = 0; for(int w = 0; w < PB / 64; w++) b += wbytes[w]; if(b) atomicAdd((unsigned long long *)&P.cnt->algo_bytes, b); }
     // The segments are made while the earlier tickets' counts are on their way: into the stage in LDS, at their place among the workgroup's
     // (straight from the lanes they would leave as 16-byte stores 32 bytes apart -- partial lines, which the memory side does not merge: the
     // write pass was 92 of the kernel's 177 us, profiles/r05f_prep_variants.txt), and leave it as whole lines.  A workgroup with more
@@ -1291,7 +1292,8 @@ MDK_HIDDEN int prep_outcome(md_dev *h, Slot *s) {
     s->n_reads = (int)c.n_adm; s->n_segs = (int)c.n_segs; s->read_bytes = c.algo_bytes;
     // a library whose records' heads (36 bytes, the name, the CIGAR) do not fit k_prep_scan's windows -- a quarter of a chunk's records read from HBM by
     // their lanes -- gets the wide windows from here on (same results either way; MDK_SCAN_WIDE=0/1 decides beforehand)
-    if(!h->scan_wide_fixed && (uint64_t)c.far * 4 > (uint64_t)(s->pr_nrec > 0 ? s->pr_nrec : 0)) h->scan_wide.store(true, std::memory_order_relaxed);
+    if(!h->scan_wide_fixed && (uint64_t)c.far * 4 > (uint64_t)(s->pr_nrec > 0 ? s->pr_nrec : 0) && !h->scan_wide.exchange(true, std::memory_order_relaxed) && getenv("MDK_HOST_PROFILE"))
+        fprintf(stderr, "[mdk hip] k_prep_scan: %u of a chunk's %d records did not fit the windows (long read names): wide windows from here on\n", c.far, s->pr_nrec);
     if((size_t)c.n_segs > s->d_seg_in.cap) {
         HIPCHK(hipStreamSynchronize(s->stream));
         if(s->run && s->run != s->stream) HIPCHK(hipStreamSynchronize(s->run));

@@ -83,6 +83,28 @@ def test_device_prep_equals_host_prep(tmp_path, small_synth, which, extra):
     assert n_chunks >= 1 and n_reads > 500 and n_segs >= n_reads
 
 
+@pytest.mark.parametrize("wide", [None, "0", "1"], ids=["adaptive", "narrow", "wide"])
+def test_long_read_names_and_long_aux_fields(tmp_path, wide):
+    """k_prep_scan gathers a window of each record into LDS (GatherView): a sequencer's read names (38 letters) do not fit the default window --
+    the lanes read such records from HBM, and after the first chunk's counters the wide-window kernel takes over -- and a bisulfite aligner's aux
+    fields (XM:Z, 150 letters) are walked in HBM.  The three arrangements (chosen from the counters; MDK_SCAN_WIDE=0; MDK_SCAN_WIDE=1), chunk by
+    chunk against the host preparation, then the command against the oracle."""
+    synth(tmp_path / "il", "-L", "60000", "-c", "25", "-s", "21", "--illumina", "--extras")
+    old = os.environ.get("MDK_SCAN_WIDE")
+    try:
+        if wide is None: os.environ.pop("MDK_SCAN_WIDE", None)
+        else: os.environ["MDK_SCAN_WIDE"] = wide
+        n_chunks, n_reads, n_segs = both_ways([str(tmp_path / "il.fa"), str(tmp_path / "il.bam"), "--chunkSize", "7000", "--CHG", "-o", str(tmp_path / "x")])
+        assert n_chunks >= 8 and n_reads > 5000
+    finally:
+        if old is None: os.environ.pop("MDK_SCAN_WIDE", None)
+        else: os.environ["MDK_SCAN_WIDE"] = old
+    env = {"MDK_HOST_PROFILE": "1"}
+    if wide is not None: env["MDK_SCAN_WIDE"] = wide
+    compare_cli(tmp_path, [str(tmp_path / "il.fa"), str(tmp_path / "il.bam"), "--chunkSize", "9000", "--CHH"], env=env)
+    assert ("wide windows from here on" in (tmp_path / "gpu_stderr.txt").read_text()) == (wide is None)
+
+
 def test_device_prep_on_reference_fixtures(tmp_path):
     for fa, bam, extra in (("cg100.fa", "cg_aln.bam", ["-q", "2"]), ("cg100.fa", "cg_aln.bam", ["--ignoreFlags", "0xD00", "-q", "2"]), ("cg100.fa", "cg_with_variants.bam", ["-p", "1", "-q", "0", "--minOppositeDepth", "3"]),
                            ("chgchh.fa", "chgchh_aln.bam", ["-q", "5", "--minConversionEfficiency", "0.9"]), ("cg100.fa", "NH.bam", ["-q", "1"]), ("cg100.fa", "cg_aln.bam", ["-q", "2", "--chunkSize", "7"])):
