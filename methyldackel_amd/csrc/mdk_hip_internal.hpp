@@ -90,8 +90,9 @@ struct alignas(16) PrepRead {
     uint32_t lq; int32_t prev; uint32_t cig[2];                                         // quad 2: what the segments of a read (and of its mate) need
 };
 // 48 bytes (64 until round 6): where the record's name, CIGAR and sequence lie follows from the record's own offset -- rec_off[i], which
-// k_prep_segs loads coalesced -- with l_read_name and n_cigar_op: name at +36, CIGAR behind the name, sequence behind the CIGAR.  Two CIGAR
-// operations travel with the read (a read with three or more -- an indel, a skip: 2-3 % -- has the others read where they lie).
+// k_prep_segs loads coalesced -- with l_read_name and n_cigar_op: name at +36, CIGAR behind the name, sequence behind the CIGAR.  The first
+// three CIGAR operations travel with the read in cig[] as 21 bits each (length < 2^17 << 4 | operation) under a flag in bit 63 that says they
+// are there; a longer operation, or a fourth one, is read where it lies.
 static_assert(sizeof(PrepRead) == 48, "PrepRead layout");
 struct PrepCounters { uint32_t n_adm, n_segs, malformed, strand0, fallback, max_lq; uint64_t algo_bytes; uint32_t far, pad; };      // max_lq: longest admitted read (mbias sizes its histogram by it)
 #define MDK_ERR_PREP_REDO (-100)   // internal: the segment array was enlarged and the preparation re-enqueued

@@ -364,7 +364,14 @@ __device__ __forceinline__ int scan_record(const PrepParams &P, V v, const uint6
     int32_t rlen = 0;
     for(uint32_t k = 0; k < ncig; k++) { const uint32_t c = k == 0 ? cb.x : k == 1 ? cb.y : k == 2 ? cb.z : k == 3 ? cb.w : v.u32(cig + 4 * k); const int op = c & 15; if(op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int32_t)(c >> 4); }
     D.pos = pos; D.rend = pos + rlen; D.lq = (uint32_t)lq; D.ncig = (uint16_t)ncig; D.flag = (uint16_t)flag;
-    D.lqn = (uint8_t)lqn; D.cig[0] = cb.x; D.cig[1] = cb.y;
+    D.lqn = (uint8_t)lqn;
+    {   // the first three CIGAR operations in 21 bits each (a length below 2^17 and the operation, as BAM packs them) + a flag that they are
+        unsigned long long pk = 0; bool okp = true;
+#pragma unroll
+        for(int k = 0; k < 3; k++) { const uint32_t cc = k == 0 ? cb.x : k == 1 ? cb.y : cb.z; if((uint32_t)k < ncig) { okp = okp && cc < (1u << 21); pk |= (unsigned long long)(cc & 0x1fffffu) << (21 * k); } }
+        if(okp) pk |= 1ull << 63;
+        D.cig[0] = (uint32_t)pk; D.cig[1] = (uint32_t)(pk >> 32);
+    }
     const md_prep_cfg &c = P.cfg;
     if(c.perread) {          // perRead.c:178-183: alignments that start inside the chunk; flag masks and MAPQ only
         bool keepr = (int64_t)pos >= P.beg && (int64_t)pos < P.end;
@@ -795,15 +802,15 @@ __device__ __forceinline__ int32_t pair_of_many(const PairCtx X, MdkPairState &S
 
 // gapless runs of a CIGAR, one at a time (calculate_positions, overlaps.c:27-52)
 struct RunIt {
-    uint32_t cig_off, c0, c1; int n, k; int32_t x, y, lq;             // the first two operations travel with the read (PrepRead::cig); the others are read where they lie
+    uint32_t cig_off; unsigned long long pk; int n, k; int32_t x, y, lq;      // the first three operations travel with the read (PrepRead::cig, 21 bits each); the others are read where they lie
     int32_t rx, ry, rl;                                               // the run at hand: rl > 0 while there is one
     __device__ __forceinline__ bool valid() const { return rl > 0; }
-    __device__ void init(const uint8_t *raw, const RdRegs &r) { cig_off = r.cig_off(); c0 = r.q2.z; c1 = r.q2.w; n = (int)r.ncig(); k = 0; x = r.pos(); y = 0; lq = (int32_t)r.lq(); rx = ry = rl = 0; next(raw); }
+    __device__ void init(const uint8_t *raw, const RdRegs &r) { cig_off = r.cig_off(); pk = (unsigned long long)r.q2.z | (unsigned long long)r.q2.w << 32; n = (int)r.ncig(); k = 0; x = r.pos(); y = 0; lq = (int32_t)r.lq(); rx = ry = rl = 0; next(raw); }
     __device__ void stop() { rl = 0; }
     __device__ void next(const uint8_t *raw) {
         rl = 0;
         while(k < n) {
-            const uint32_t c = k == 0 ? c0 : k == 1 ? c1 : ld32(raw + cig_off + 4 * k); k++;
+            const uint32_t c = (k < 3 && (long long)pk < 0) ? (uint32_t)(pk >> (21 * k)) & 0x1fffffu : ld32(raw + cig_off + 4 * k); k++;
             const int op = c & 15; const int32_t len = (int32_t)(c >> 4);
             if(op == 0 || op == 7 || op == 8) {
                 int32_t l = len; if(y + l > lq) l = lq - y;          // a CIGAR that consumes more bases than the record stores
@@ -1001,8 +1008,8 @@ __global__ __launch_bounds__(PB) void k_perread_raw(const PrepParams P, const ui
     if(a >= P.cnt->n_adm) return;
     const RdRegs r = rd_load(P, a);
     const uint8_t *seq = P.raw + r.seq_off(), *qual = seq + ((r.lq() + 1) >> 1), *cg = P.raw + r.cig_off();
-    const uint32_t c0 = r.q2.z, c1 = r.q2.w;
-    out[a] = perread_walk(seq, qual, r.lq(), (int)r.ncig(), r.pos(), r.strand() & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg, c0, c1](int k) { return k == 0 ? c0 : k == 1 ? c1 : ld32(cg + 4 * k); });
+    const unsigned long long pk = (unsigned long long)r.q2.z | (unsigned long long)r.q2.w << 32;
+    out[a] = perread_walk(seq, qual, r.lq(), (int)r.ncig(), r.pos(), r.strand() & 1, ctxcode, P.reflen, wend, P.cfg.min_phred, [cg, pk](int k) { return (k < 3 && (long long)pk < 0) ? (uint32_t)(pk >> (21 * k)) & 0x1fffffu : ld32(cg + 4 * k); });
 }
 
 // record offsets of a device-resident range (offsets in the piece it was inflated in) -> offsets in the chunk's concatenation
