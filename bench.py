@@ -108,13 +108,23 @@ def _calls_of(d, name="out_CpG.bedGraph"):
 
 
 def _mem_available_gb():
+    """what this process's control group may still take (files in /dev/shm are charged to it as well), or the machine's MemAvailable if that is less:
+    a box with 3 TB of memory ran this under a 300 GiB limit, and a leg sized by MemAvailable alone took the box down"""
+    avail = 0.0
     try:
         for line in open("/proc/meminfo"):
             if line.startswith("MemAvailable:"):
-                return int(line.split()[1]) / 1e6
+                avail = int(line.split()[1]) / 1e6
     except OSError:
         pass
-    return 0.0
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"), ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                avail = min(avail, max(0.0, (int(v) - int(open(cur).read().strip())) / 1e9))
+        except (OSError, ValueError):
+            pass
+    return avail
 
 
 class Legs:
@@ -393,7 +403,7 @@ def main():
     ap.add_argument("--large-sample-length", type=int, default=128_000_000, help="bp of the second, larger end-to-end sample (0 = skip)")
     ap.add_argument("--xl-copies", type=int, default=4, help="the XL end-to-end sample = this many copies of the large sample as that many contigs (<= 1: skip)")
     ap.add_argument("--budget-s", type=float, default=420.0, help="seconds the whole run may take: end-to-end legs that no longer fit are left out (and named in legs_skipped)")
-    ap.add_argument("--human-gb", type=float, default=3.1, help="Gb of the human-like 24-contig 30x sample (0: skip); scaled down to what the box's memory holds")
+    ap.add_argument("--human-gb", type=float, default=0.0, help="Gb of the human-like 24-contig 30x sample (0: skip); scaled down to what the box's memory holds")
     ap.add_argument("--cfg5-mb", type=int, default=128, help="Mb of the 100x sample for BASELINE configs[4] (0: skip)")
     ap.add_argument("--ranks-leg", type=int, default=2, help="N = 1 runs: also run the command as this many ranks sharing the GPU (0/1: skip)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc passes that measure the dominant family's HBM traffic for this line")
@@ -585,9 +595,11 @@ def main():
     assert L.md_dev_bench_prep_rotate(dev.h, slot_arr, R, GROUP, 2 * (R // GROUP), 40 * (R // GROUP), C.byref(prep_ms)) == 0, L.md_dev_last_error()
     assert L.md_dev_bench_prep_rotate(dev.h, slot_arr, R, 1, R, 10 * R, C.byref(prep1_ms)) == 0, L.md_dev_last_error()
     pile_s, prep_s = br.ms_pileup / 1e3, prep_ms.value / 1e3
-    # algorithmic bytes per LAUNCH (GROUP chunks).  Pileup: SURVEY.md 8d (reads' payload + reference + sites).  Preparation: every byte of the
-    # chunk's records once (the fields it needs sit at both ends of a record: every 128-byte line is touched) + the 32-byte segments it
-    # writes; its intermediates (64 B per admitted read, the name table) are overhead, not algorithmic bytes.
+    # algorithmic bytes per LAUNCH (GROUP chunks).  Pileup: SURVEY.md 8d (reads' payload + reference + sites).  Preparation: its input -- every
+    # byte of the chunk's records, once -- + the 32-byte segments it writes; its intermediates (48 B per record, the name table) are overhead,
+    # not algorithmic bytes.  The numerator is the one rounds 3-5 used, so the fractions compare; since round 6 the scan fetches
+    # only the lines its fields lie in (1.7 of a record's 2.2: `traffic` below is what the counters saw), and `step` prices preparation +
+    # pileup with SURVEY.md 8d's own per-chunk figure.
     pile_bytes = int(br.algo_bytes)
     prep_bytes = int((raw_bytes / R + 32.0 * segs / R) * GROUP)
     fam = {
