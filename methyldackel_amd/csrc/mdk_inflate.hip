@@ -135,10 +135,10 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
     auto flush = [&](uint32_t beg, uint32_t end) {                      // whole aligned words of the window as dwords (the global address is whatever the member's offset makes it), the edges as bytes
         const uint32_t p0 = (beg + 3u) & ~3u, p1 = end & ~3u;
         if(p0 <= p1) {
-            for(uint32_t p = p0 + 4u * lane; p < p1; p += 256) { const uint32_t v = *(const uint32_t *)&S.win[p & (INF_WIN - 1)]; __builtin_memcpy(out + p, &v, 4); }
-            if(beg + lane < p0) out[beg + lane] = S.win[(beg + lane) & (INF_WIN - 1)];
-            if(p1 + lane < end) out[p1 + lane] = S.win[(p1 + lane) & (INF_WIN - 1)];
-        } else for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)];
+            for(uint32_t p = p0 + 4u * lane; p < p1; p += 256) { const uint32_t v = *(const inf_u32a *)&S.win[inf_win_at(p)]; __builtin_memcpy(out + p, &v, 4); }
+            if(beg + lane < p0) out[beg + lane] = S.win[inf_win_at(beg + lane)];
+            if(p1 + lane < end) out[p1 + lane] = S.win[inf_win_at(p1 + lane)];
+        } else for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[inf_win_at(p)];
     };
     for(;;) {
         const uint32_t wbase = bitpos >> 5, rel = bitpos & 31u;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
             stage(wbase, INF_STORED_WORDS);
             const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH, beg = pos;
             if(pos + n > M.out_len) { fail(INF_E_OVERRUN); return; }
-            for(uint32_t i = lane; i < n; i += 64) S.win[(pos + i) & (INF_WIN - 1)] = inf_ring_byte(S, rel, i);
+            for(uint32_t i = lane; i < n; i += 64) S.win[inf_win_at(pos + i)] = inf_ring_byte(S, rel, i);
             pos += n; bitpos += 8u * n; stored_left -= n;
             if(stored_left == 0) { in_block = 0; fin = last; }
             if(fin && pos != M.out_len) { fail(INF_E_SHORT); return; }
@@ -241,7 +241,7 @@ __device__ __forceinline__ void inflate_member(const InfParams &P, InfShared &S,
             {
                 const int lst = inf_lz_last_start(S, (uint32_t)lane);
                 const int run = __shfl_up(wave_incl_max(lst), 1);        // the last start mark in front of the lane's bytes
-                const uint32_t carry = (lane > 0 && run >= 0) ? S.o.aux[run] : 0u;
+                const uint32_t carry = (lane > 0 && run >= 0) ? S.o.aux[inf_aux_at((uint32_t)run)] : 0u;
                 const uint32_t inr = inf_lz_inrange((uint32_t)lane, base0, beg, end);
                 uint32_t q[32];
                 inf_lz_sources(S, (uint32_t)lane, base0, inr, carry, q);

@@ -111,6 +111,15 @@ struct InfShared {
     // written by the lane that parsed a block header, read by all lanes after the barrier
     uint32_t bitpos, in_block, last, stored_left, err;
 };
+// Where byte p of the member lives in the window ring, and entry r of a batch's per-byte state in S.o.aux.  In the batch steps lane l owns 32
+// consecutive bytes, so the 64 lanes' accesses of one instruction lie 32 bytes (8 dwords) apart in the window and 64 bytes (16 dwords) apart
+// in aux: straight addressing would put a group of 32 lanes on four (two) of the LDS's 32 banks -- every byte of the gather and every entry
+// of a pointer-jumping round an 8-way (16-way) bank conflict.  So the dword index is XORed with the bits above it that count the lanes: dword
+// bits 0-2 of the window with bits 5-7, dword bits 0-3 of aux with bits 5-8; bytes within a dword stay where they are, which keeps the
+// window's dword accesses (the flush, the gather's write-back) whole.  Every access of either array goes through these two.
+typedef uint32_t __attribute__((may_alias)) inf_u32a;      // (dword views of the byte / halfword arrays: may_alias keeps the compilers' type-based reordering off them)
+MDK_HD uint32_t inf_win_at(uint32_t p) { const uint32_t a = p & (INF_WIN - 1); return a ^ (((a >> 7) & 7u) << 2); }
+MDK_HD uint32_t inf_aux_at(uint32_t r) { return r ^ (((r >> 6) & 15u) << 1); }
 
 // The decoder's registers between batches.  `bb` holds the next `cnt` bits of the stream, least significant first; 32 <= cnt <= 63
 // between any two steps, so a step can look at 32 bits without asking.
@@ -377,8 +386,8 @@ MDK_HD uint32_t inf_tok_column(const InfShared &S, uint32_t g) {
 // mark their start.  false: the match reaches in front of the member's first byte.
 MDK_HD bool inf_tok_place(InfShared &S, uint32_t t, uint32_t at, uint32_t base0) {
     const uint32_t r = at - base0, dist = t >> 16;
-    if(dist == 0) { S.win[at & (INF_WIN - 1)] = (uint8_t)t; S.o.aux[r] = 0; }
-    else { if(dist > at) return false; S.o.aux[r] = (uint16_t)dist; }      // (dist <= 32768)
+    if(dist == 0) { S.win[inf_win_at(at)] = (uint8_t)t; S.o.aux[inf_aux_at(r)] = 0; }
+    else { if(dist > at) return false; S.o.aux[inf_aux_at(r)] = (uint16_t)dist; }      // (dist <= 32768)
     INF_OR_BIT(S.o.starts[r >> 5], 1u << (r & 31u));
     return true;
 }
@@ -399,14 +408,14 @@ MDK_HD uint32_t inf_lz_inrange(uint32_t lane, uint32_t base0, uint32_t beg, uint
     return below_hi & ~below_lo;
 }
 MDK_HD void inf_lz_sources(const InfShared &S, uint32_t lane, uint32_t base0, uint32_t inr, uint32_t carry_dist, uint32_t *q /* [32] */) {
-    InfV4 a[4];
+    uint32_t a[16];                        // the lane's 32 entries, a dword (two entries) at a time
 #pragma unroll
-    for(int k = 0; k < 4; k++) a[k] = *(const InfV4 *)(const void *)&S.o.aux[32u * lane + 8u * (uint32_t)k];
+    for(uint32_t k = 0; k < 16; k++) a[k] = *(const inf_u32a *)(const void *)&S.o.aux[inf_aux_at(32u * lane + 2u * k)];
     const uint32_t w = S.o.starts[lane], p0 = base0 + 32u * lane;
     uint32_t d = carry_dist;
 #pragma unroll
     for(uint32_t j = 0; j < 32; j++) {
-        const uint32_t av = (a[j >> 3].w[(j >> 1) & 3u] >> (16u * (j & 1u))) & 0xffffu;
+        const uint32_t av = (a[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
         d = ((w >> j) & 1u) ? av : d;
         const uint32_t p = p0 + j;
         q[j] = ((inr >> j) & 1u) ? p - d : (p & 0xffffu);       // (a position outside the batch may lie behind the member's 65536th byte: what S.o.aux can hold of it)
@@ -415,12 +424,7 @@ MDK_HD void inf_lz_sources(const InfShared &S, uint32_t lane, uint32_t base0, ui
 // (2) inf_lz_publish: the sources into S.o.aux (after every lane has read the distances it needs).
 MDK_HD void inf_lz_publish(InfShared &S, uint32_t lane, const uint32_t *q) {
 #pragma unroll
-    for(int k = 0; k < 4; k++) {
-        InfV4 v;
-#pragma unroll
-        for(int i = 0; i < 4; i++) v.w[i] = (q[8 * k + 2 * i] & 0xffffu) | (q[8 * k + 2 * i + 1] << 16);
-        *(InfV4 *)(void *)&S.o.aux[32u * lane + 8u * (uint32_t)k] = v;
-    }
+    for(uint32_t k = 0; k < 16; k++) *(inf_u32a *)(void *)&S.o.aux[inf_aux_at(32u * lane + 2u * k)] = (q[2 * k] & 0xffffu) | (q[2 * k + 1] << 16);
 }
 // (3) inf_lz_jump: a source that is itself a byte of one of the batch's matches is replaced by THAT byte's source (read from S.o.aux; the
 // caller publishes the new sources and repeats until nothing moves: every source is then a literal of the batch or a byte in front of it).
@@ -428,7 +432,7 @@ MDK_HD void inf_lz_publish(InfShared &S, uint32_t lane, const uint32_t *q) {
 MDK_HD bool inf_lz_jump(const InfShared &S, uint32_t lane, uint32_t base0, uint32_t beg, uint32_t inr, uint32_t *q) {
     uint32_t t[32];
 #pragma unroll
-    for(uint32_t j = 0; j < 32; j++) t[j] = S.o.aux[(((inr >> j) & 1u) && q[j] >= beg) ? q[j] - base0 : 32u * lane + j];
+    for(uint32_t j = 0; j < 32; j++) t[j] = S.o.aux[inf_aux_at((((inr >> j) & 1u) && q[j] >= beg) ? q[j] - base0 : 32u * lane + j)];
     uint32_t moved = 0;
 #pragma unroll
     for(uint32_t j = 0; j < 32; j++) { moved |= t[j] ^ q[j]; q[j] = t[j]; }
@@ -446,14 +450,14 @@ MDK_HD void inf_lz_gather(InfShared &S, uint32_t lane, uint32_t base0, uint32_t 
 #pragma unroll
         for(uint32_t j = 0; j < 32; j++) b[j] = far(q[j], ((inr >> j) & 1u) && q[j] + INF_WIN < end);
     }
-    InfV4 v[2];
+    uint32_t v[8];
 #pragma unroll
     for(uint32_t j = 0; j < 32; j++) {
-        const uint32_t nb = S.win[q[j] & (INF_WIN - 1)];
+        const uint32_t nb = S.win[inf_win_at(q[j])];
         const uint32_t x = (any_far && ((inr >> j) & 1u) && q[j] + INF_WIN < end) ? b[j] : nb;
-        if((j & 3u) == 0) v[j >> 4].w[(j >> 2) & 3u] = x; else v[j >> 4].w[(j >> 2) & 3u] |= x << (8u * (j & 3u));
+        if((j & 3u) == 0) v[j >> 2] = x; else v[j >> 2] |= x << (8u * (j & 3u));
     }
-    const uint32_t slot = (base0 + 32u * lane) & (INF_WIN - 1);
-    *(InfV4 *)(void *)&S.win[slot] = v[0]; *(InfV4 *)(void *)&S.win[slot + 16] = v[1];
+#pragma unroll
+    for(uint32_t k = 0; k < 8; k++) *(inf_u32a *)(void *)&S.win[inf_win_at(base0 + 32u * lane + 4u * k)] = v[k];       // (every read above has been made: in-order issue of one wavefront)
 }
 #endif

@@ -28,7 +28,7 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
     const uint64_t a0 = in_off & ~3ull; const uint32_t skip = (uint32_t)(in_off & 3ull);
     const uint32_t n_words = (uint32_t)((in_off + in_len + 3 - a0) >> 2);
     uint32_t bitpos = 8u * skip, pos = 0, in_block = 0, last = 0, stored_left = 0;
-    auto flush = [&](uint32_t beg, uint32_t end) { for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[p & (INF_WIN - 1)]; };
+    auto flush = [&](uint32_t beg, uint32_t end) { for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t p = beg + lane; p < end; p += 64) out[p] = S.win[inf_win_at(p)]; };
     for(uint64_t turns = 0;; turns++) {
         if(turns > 200000) return 103;                                   // a batch must consume input or produce output: 64 KiB cannot take this long
         (*n_batches)++;
@@ -58,7 +58,7 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
             emu_stage(S, comp, a0, n_words, wbase, INF_STORED_WORDS);
             const uint32_t n = stored_left < INF_STORED_BATCH ? stored_left : INF_STORED_BATCH, beg = pos;
             if(pos + n > out_len) return INF_E_OVERRUN;
-            for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[(pos + i) & (INF_WIN - 1)] = inf_ring_byte(S, rel, i);
+            for(uint32_t lane = 0; lane < 64; lane++) for(uint32_t i = lane; i < n; i += 64) S.win[inf_win_at(pos + i)] = inf_ring_byte(S, rel, i);
             pos += n; bitpos += 8u * n; stored_left -= n;
             if(stored_left == 0) { in_block = 0; fin = last; }
             if(fin && pos != out_len) return INF_E_SHORT;
@@ -133,7 +133,7 @@ static int emu_member(const uint8_t *comp, uint64_t in_off, uint32_t in_len, uin
             if(end - base0 > INF_BATCH_BYTES) return 100;
             // matches: sources, pointer jumping, gather
             uint32_t carry[64]; int32_t run = -1;
-            for(uint32_t lane = 0; lane < 64; lane++) { carry[lane] = run >= 0 ? S.o.aux[run] : 0u; const int32_t l = inf_lz_last_start(S, lane); if(l > run) run = l; }
+            for(uint32_t lane = 0; lane < 64; lane++) { carry[lane] = run >= 0 ? S.o.aux[inf_aux_at((uint32_t)run)] : 0u; const int32_t l = inf_lz_last_start(S, lane); if(l > run) run = l; }
             uint32_t q[64][32], inr[64];
             for(uint32_t lane = 0; lane < 64; lane++) { inr[lane] = inf_lz_inrange(lane, base0, beg, end); inf_lz_sources(S, lane, base0, inr[lane], carry[lane], q[lane]); }
             for(uint32_t lane = 0; lane < 64; lane++) inf_lz_publish(S, lane, q[lane]);
