@@ -112,13 +112,14 @@ struct InfShared {
     uint32_t bitpos, in_block, last, stored_left, err;
 };
 // Where byte p of the member lives in the window ring, and entry r of a batch's per-byte state in S.o.aux.  In the batch steps lane l owns 32
-// consecutive bytes, so the 64 lanes' accesses of one instruction lie 32 bytes (8 dwords) apart in the window and 64 bytes (16 dwords) apart
-// in aux: straight addressing would put a group of 32 lanes on four (two) of the LDS's 32 banks -- every byte of the gather and every entry
-// of a pointer-jumping round an 8-way (16-way) bank conflict.  So the dword index is XORed with the bits above it that count the lanes: dword
-// bits 0-2 of the window with bits 5-7, dword bits 0-3 of aux with bits 5-8; bytes within a dword stay where they are, which keeps the
-// window's dword accesses (the flush, the gather's write-back) whole.  Every access of either array goes through these two.
+// consecutive bytes, so the 64 lanes' accesses of one instruction lie 64 bytes (16 dwords) apart in aux: straight addressing would put a
+// group of 32 lanes on two of the LDS's 32 banks -- every entry of a pointer-jumping round a 16-way bank conflict.  So aux's dword index is
+// XORed with the bits above it that count the lanes (dword bits 0-3 with bits 5-8: conflict-free for a lane's own entries and for sources at
+// a common distance; the two entries of a dword stay together): k_inflate 14.3 -> 12.8 ms for the bench's file.  The same for the window
+// (bytes 32 apart: 8-way) measured nothing (12.86 against 12.81 ms, gpurun_out/r06i4_*: its gather reads scattered sources anyway) and costs
+// instructions per byte: the window is addressed straight.  Every access of either array goes through these two.
 typedef uint32_t __attribute__((may_alias)) inf_u32a;      // (dword views of the byte / halfword arrays: may_alias keeps the compilers' type-based reordering off them)
-MDK_HD uint32_t inf_win_at(uint32_t p) { const uint32_t a = p & (INF_WIN - 1); return a ^ (((a >> 7) & 7u) << 2); }
+MDK_HD uint32_t inf_win_at(uint32_t p) { return p & (INF_WIN - 1); }
 MDK_HD uint32_t inf_aux_at(uint32_t r) { return r ^ (((r >> 6) & 15u) << 1); }
 
 // The decoder's registers between batches.  `bb` holds the next `cnt` bits of the stream, least significant first; 32 <= cnt <= 63
