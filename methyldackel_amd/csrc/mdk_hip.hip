@@ -398,7 +398,11 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
             if(__ballot(n != 0) == 0) continue;
             const uint32_t oseq = (uint32_t)__shfl((int)s.oseq, owner), oqual = (uint32_t)__shfl((int)s.oqual, owner), wlen = (uint32_t)__shfl((int)s.wlen, owner);
             const int cq = __shfl(s.cq, owner), lo = __shfl(s.lo, owner);
+#ifdef QW_EXP_NO_PARTNER                    // TIMING EXPERIMENT ONLY (wrong results): no segment has a partner
+            const bool partner = false;
+#else
             const bool partner = (w >> 4) & 1;
+#endif
             uint32_t mseq = 0, mqual = 0, mwlen = 0; int mcq = 0, mlo = 0;
             if(__ballot(partner && n != 0) != 0) {
                 mseq = (uint32_t)__shfl((int)s.mseq, owner); mqual = (uint32_t)__shfl((int)s.mqual, owner); mwlen = (uint32_t)__shfl((int)s.mwlen, owner);
