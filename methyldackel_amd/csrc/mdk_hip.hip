@@ -31,6 +31,7 @@
 #include <atomic>
 #include <mutex>
 #include <algorithm>
+#include <type_traits>
 #include <condition_variable>
 #include <thread>
 #include <chrono>
@@ -329,7 +330,7 @@ __device__ __forceinline__ void lane_seg(const KParams &P, const md_seg &g, int 
 #define PILEUP_WAVES 8
 #endif
 #ifndef QW_WAVES
-#define QW_WAVES PILEUP_WAVES   // waves per SIMD the dense-context kernel is compiled for (8: 64 VGPRs and a few spilled dwords; 6: 80 VGPRs, none, three workgroups per CU)
+#define QW_WAVES 6   // waves per SIMD the dense-context kernel is compiled for (6: 72-78 VGPRs, no scratch, three workgroups per CU: 217.6 us per 8-chunk launch; 8: 64 VGPRs and 44-64 bytes of scratch with the two forms of the site loop: 219.9)
 #endif
 #ifndef QL
 #define QL 8          // lanes per segment
@@ -382,6 +383,22 @@ __device__ __forceinline__ SegQ seg_setup(const KParams &P, const md_seg &g, int
     return s;
 }
 
+// The 64 segments a wavefront has prepared, dealt out again so that the eight a step works on (the lanes l with l & 7 == step) are of one
+// kind: first the segments without a partner, then those with one, last those with no site on this tile (their steps are skipped whole).
+// Rank s goes to lane 8 (s & 7) + (s >> 3); ds_permute pushes every field there.
+__device__ __forceinline__ SegQ seg_sort(const SegQ &q, const int lane) {
+    const bool some = ((q.w[0] | q.w[1]) >> 18) != 0, partner = (q.w[0] >> 4) & 1;
+    const unsigned long long below = (1ull << lane) - 1ull, ma = __ballot(some && !partner), mb = __ballot(some && partner), mc = ~(ma | mb);
+    const int s = some ? (partner ? __popcll(ma) + __popcll(mb & below) : __popcll(ma & below)) : __popcll(ma) + __popcll(mb) + __popcll(mc & below);
+    const int to = (8 * (s & 7) + (s >> 3)) << 2;
+    SegQ r;
+    r.oseq = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.oseq); r.oqual = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.oqual);
+    r.mseq = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.mseq); r.mqual = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.mqual);
+    r.cq = __builtin_amdgcn_ds_permute(to, q.cq); r.lo = __builtin_amdgcn_ds_permute(to, q.lo); r.mcq = __builtin_amdgcn_ds_permute(to, q.mcq); r.mlo = __builtin_amdgcn_ds_permute(to, q.mlo);
+    r.wlen = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.wlen); r.mwlen = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.mwlen);
+    r.w[0] = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.w[0]); r.w[1] = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.w[1]);
+    return r;
+}
 template <bool VARIANT>
 __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, int lane, const uint16_t *listC,
                                               uint32_t *cm, uint32_t *cu, uint32_t *co, uint32_t *cv) {
@@ -404,7 +421,8 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
             const bool partner = (w >> 4) & 1;
 #endif
             uint32_t mseq = 0, mqual = 0, mwlen = 0; int mcq = 0, mlo = 0;
-            if(__ballot(partner && n != 0) != 0) {
+            const bool anyp = __ballot(partner && n != 0) != 0;
+            if(anyp) {
                 mseq = (uint32_t)__shfl((int)s.mseq, owner); mqual = (uint32_t)__shfl((int)s.mqual, owner); mwlen = (uint32_t)__shfl((int)s.mwlen, owner);
                 mcq = __shfl(s.mcq, owner); mlo = __shfl(s.mlo, owner);
             }
@@ -416,6 +434,10 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
             const int mcode = odd ? 2 : 4, ucode = odd ? 8 : 1;      // the strand's C read as C (methylated) / as T (unmethylated): BAM codes C=2 T=8, G=4 A=1
             // a lane takes two ADJACENT entries of the list per step (one LDS load), the 8 lanes of a segment 16 consecutive sites
             bool anyok = false;
+            // the loop over the segment's sites, once with and once without the partner's half (the segments of a round are sorted so that
+            // the eight of a step nearly always agree, seg_sort: a step of partner-less segments asks for half the bytes and runs no overlap rule)
+            auto sites = [&](auto has_partner) {
+            constexpr bool HP = decltype(has_partner)::value;
             for(int j = 2 * sub; j < n; j += 2 * QL) {
                 // 1. which sites (no base has been touched yet); 2. every byte they need is requested; 3. they are used
                 uint32_t e01; __builtin_memcpy(&e01, list + j, 4);             // (the second entry is whatever follows the list when j + 1 == n)
@@ -425,13 +447,13 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
                 const int q0 = l0 + cq, q1 = l1 + cq, mq0 = l0 + mcq, mq1 = l1 + mcq;
                 uint32_t sb0 = 0xff, qb0 = 0, msb0 = 0xff, mqb0 = 0, sb1 = 0xff, qb1 = 0, msb1 = 0xff, mqb1 = 0;   // a trimmed base needs no load: it reads as N with quality 0
                 if(ok0 && (unsigned)(q0 - lo) < wlen) { sb0 = blob[oseq + (uint32_t)(q0 >> 1)]; qb0 = blob[oqual + (uint32_t)q0]; }
-                if(ok0 && partner && (unsigned)(mq0 - mlo) < mwlen) { msb0 = blob[mseq + (uint32_t)(mq0 >> 1)]; mqb0 = blob[mqual + (uint32_t)mq0]; }
+                if(HP && ok0 && partner && (unsigned)(mq0 - mlo) < mwlen) { msb0 = blob[mseq + (uint32_t)(mq0 >> 1)]; mqb0 = blob[mqual + (uint32_t)mq0]; }
                 if(ok1 && (unsigned)(q1 - lo) < wlen) { sb1 = blob[oseq + (uint32_t)(q1 >> 1)]; qb1 = blob[oqual + (uint32_t)q1]; }
-                if(ok1 && partner && (unsigned)(mq1 - mlo) < mwlen) { msb1 = blob[mseq + (uint32_t)(mq1 >> 1)]; mqb1 = blob[mqual + (uint32_t)mq1]; }
+                if(HP && ok1 && partner && (unsigned)(mq1 - mlo) < mwlen) { msb1 = blob[mseq + (uint32_t)(mq1 >> 1)]; mqb1 = blob[mqual + (uint32_t)mq1]; }
                 auto use = [&](const bool ok, const int l, const int q, const int mq, const uint32_t sb, const uint32_t qb, const uint32_t msb, const uint32_t mqb) {
                     if(!ok) return;
                     const int bq = (int)((sb >> ((~q & 1) << 2)) & 15u); int ql = (int)qb;
-                    if(partner) { const int mb = (int)((msb >> ((~mq & 1) << 2)) & 15u); ql = resolve_own(second, bq, ql, mb, (int)mqb); }
+                    if(HP && partner) { const int mb = (int)((msb >> ((~mq & 1) << 2)) & 15u); ql = resolve_own(second, bq, ql, mb, (int)mqb); }
                     if(callpass) {
                         if(ql >= minPhred && (bq == mcode || bq == ucode)) atomicAdd(&cm[(bq == ucode ? tile : 0) + l], 1u);     // cu = cm + tile
                     } else if(VARIANT) {
@@ -445,6 +467,8 @@ __device__ __forceinline__ void quarter_sites(const KParams &P, const SegQ &s, i
                 use(ok1, l1, q1, mq1, sb1, qb1, msb1, mqb1);
                 anyok = anyok || ok0 || ok1;
             }
+            };
+            if(anyp) sites(std::true_type{}); else sites(std::false_type{});
             if(callpass && strand == 0 && anyok) atomicExch(P.err, 1);        // a read of unknown strand reached a call; reference: assert(strand != 0) (common.c:122-125)
         }
     }
@@ -561,7 +585,11 @@ __device__ __forceinline__ void pileup_tile(const KParams &P, const int t, const
         for(int r0 = first; r0 < last; r0 += WG) {                 // uniform: every lane takes part in the exchange of every round
             md_seg g = g0;
             if(r0 != first) { g.rpos = 0x7fffffff; g.len = 0; if(r0 + tid < last) g = P.seg[r0 + tid]; }
+#ifndef QW_NO_SORT
+            const SegQ sq = seg_sort(seg_setup<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, nG, topC, topG), lane);
+#else
             const SegQ sq = seg_setup<VARIANT>(P, g, (int)T0, (int)T1, listC, nC, nG, topC, topG);
+#endif
             quarter_sites<VARIANT>(P, sq, lane, listC, cm, cu, co, cv);
         }
     } else {
