@@ -146,7 +146,7 @@ struct LdsView {
 // three quarters of a record, its sequence and qualities, are never asked for (stage_gather).  A record's bytes are therefore in two places: its
 // head (offsets below `thr`) in its own window, its aux area in the window of the record after it.  fits() says whether both hold what the scan
 // will ask for: a record whose head its window does not hold (a long name, a long CIGAR) is read from HBM by its lane altogether, one whose
-// aux area is longer than what the next window holds of it has its aux fields walked in HBM (`auxg`; scan_aux reads through u64 only).
+// aux area is longer than what the next window holds of it has its aux fields walked in HBM (`auxg`; scan_aux reads through u64 and u128).
 #ifndef GW_PRE
 #define GW_PRE 1
 #endif
@@ -165,7 +165,9 @@ struct GatherView {
     __device__ __forceinline__ uint64_t u64(uint32_t x) const {
         if(auxg && x >= thr) return ld64(g + x);
         const uint32_t a = at(x), i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2]; return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, k) | (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, k) << 32; }
-    __device__ __forceinline__ uint4 u128(uint32_t x) const { const uint32_t a = at(x), i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2], w3 = w[i + 3], w4 = w[i + 4];
+    __device__ __forceinline__ uint4 u128(uint32_t x) const {
+        if(auxg && x >= thr) return ld128(g + x);
+        const uint32_t a = at(x), i = a >> 2, k = a & 3u; const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2], w3 = w[i + 3], w4 = w[i + 4];
         return make_uint4(__builtin_amdgcn_alignbyte(w1, w0, k), __builtin_amdgcn_alignbyte(w2, w1, k), __builtin_amdgcn_alignbyte(w3, w2, k), __builtin_amdgcn_alignbyte(w4, w3, k)); }
     // head: the record's bytes [0, hend) are wanted; aux area [aux, end)
     __device__ __forceinline__ bool fits(uint32_t hend, uint32_t aux, uint32_t end) {
@@ -195,7 +197,19 @@ __device__ __forceinline__ AuxHit scan_aux(const V &v, uint32_t s, const uint32_
             else {
                 uint32_t z = vo + 5; bool found = false;
                 if(avail <= 5) return A;
-                while(z < e) { n = e - z < 8 ? (int)(e - z) : 8; k = first_zero_byte(v.u64(z), n); if(k < n) { z += k; found = true; break; } z += 8; }
+                // a long string (a bisulfite aligner's XM:Z holds a letter per base): 32 letters per round trip, two 16-byte reads asked for together
+                // (eight at a time cost a 150-letter string 19 dependent round trips, and the scan of such a library four times its time);
+                // what is read past the area's end lies in the next record or the buffer's 64 spare bytes
+                while(z < e && !found) {
+                    const uint4 b0 = v.u128(z), b1 = v.u128(z + 16);
+                    const uint64_t w4[4] = {(uint64_t)b0.x | (uint64_t)b0.y << 32, (uint64_t)b0.z | (uint64_t)b0.w << 32, (uint64_t)b1.x | (uint64_t)b1.y << 32, (uint64_t)b1.z | (uint64_t)b1.w << 32};
+#pragma unroll
+                    for(int i = 0; i < 4; i++) {
+                        const uint32_t zi = z + 8u * (uint32_t)i;
+                        if(!found && zi < e) { n = e - zi < 8 ? (int)(e - zi) : 8; k = first_zero_byte(w4[i], n); if(k < n) { z = zi + (uint32_t)k; found = true; } }
+                    }
+                    if(!found) z += 32;
+                }
                 if(!found) return A;
                 sz = (size_t)(z - vo) + 1;
             }
@@ -754,7 +768,11 @@ __device__ __forceinline__ bool same_name(const uint8_t *raw, const uint32_t xnl
     if(xnlen != ynlen || xname.x != yname.x || xname.y != yname.y || xname.z != yname.z || xname.w != yname.w) return false;
     if(xnlen <= 16) return true;
     const uint8_t *p = raw + xqn_off, *q = raw + yqn_off;
-    for(uint32_t k = 16; k < xnlen; k++) if(p[k] != q[k]) return false;
+    for(uint32_t k = 16; k < xnlen; k += 8) {             // eight letters at a time (a sequencer's names are ~40 letters: every pair comes through here; the reads past the name stay inside the record, or the buffer's 64 spare bytes)
+        uint64_t a = ld64(p + k), b = ld64(q + k);
+        if(xnlen - k < 8) { const uint64_t m = (1ull << (8 * (xnlen - k))) - 1ull; a &= m; b &= m; }
+        if(a != b) return false;
+    }
     return true;
 }
 // The start of the read admitted just before the first admitted read of block `blk` (the records one workgroup of k_prep_scan took): the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """MEASUREMENT TOOL: the device preparation and the pileup over R resident 1 Mb chunks of the S1 workload, one chunk and eight chunks
 per launch (HIP events inside libmdk_hip).  usage: prep_bench.py [R=16] [extra extract options]"""
-import ctypes as C, json, subprocess, sys, tempfile
+import ctypes as C, json, os, subprocess, sys, tempfile
 from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO))
@@ -11,7 +11,7 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 extra = sys.argv[2:]
 work = Path(tempfile.mkdtemp(prefix="mdk_prepbench_"))
 mdk.build()
-subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(work / "s"), "-L", str(1_000_000 * R), "-c", "30", "-s", str(0x5EED0001)], check=True, capture_output=True)
+subprocess.run([str(REPO / "tools/_build/mdk_synth"), "-o", str(work / "s"), "-L", str(1_000_000 * R), "-c", "30", "-s", str(0x5EED0001)] + os.environ.get("PREP_BENCH_SYNTH", "").split(), check=True, capture_output=True)      # PREP_BENCH_SYNTH: extra generator options (--illumina: long read names and aux fields)
 plan = mdk.Plan([str(work / "s.fa"), str(work / "s.bam"), "--chunkSize", "1000000", "-@", "16"] + extra + ["-o", str(work / "o")])
 plan.set_prep(1)
 cfg = plan.dev_cfg(); cfg.n_slots = R
