@@ -14,7 +14,15 @@ def top_frames(pid, tid=None):
     try:
         with open(p) as f: fr = [l.split()[-1].split("+")[0] for l in f.read().splitlines() if l.strip()]
         return fr
-    except OSError as e: return [f"<{e.__class__.__name__}>"]
+    except OSError as e:
+        # not root: the symbol the task sleeps in (wchan), its state and its name are readable by the owner
+        base = f"/proc/{pid}" if tid is None else f"/proc/{pid}/task/{tid}"
+        try:
+            wch = open(base + "/wchan").read().strip() or "0"
+            st = open(base + "/stat").read(); comm = st[st.index("(") + 1:st.rindex(")")]; state = st[st.rindex(")") + 2]
+            return [f"{comm}:{state}:{wch}"]
+        except OSError:
+            return [f"<{e.__class__.__name__}>"]
 
 def one(args, env, rep):
     e = dict(os.environ); e.update(env); e.setdefault("MDK_FAST_EXIT", "1"); e.update({"MDK_HOST_PROFILE": "1", "MDK_NO_RANKS": "1"})
