@@ -156,6 +156,10 @@ static void *emitter_main(void *arg) {
         if(!j) { pthread_mutex_unlock(&E->mu); break; }
         j->state = EJ_BUSY;
         pthread_mutex_unlock(&E->mu);
+        if(j->need_copy) {                       /* emitter_push_lazy: the copy out of the caller's buffer, by this thread instead of by the caller */
+            memcpy(j->site, j->src_site, sizeof(md_site) * (size_t)j->s.n_sites); if(j->src_var) memcpy(j->var, j->src_var, sizeof(md_site_var) * (size_t)j->s.n_sites);
+            pthread_mutex_lock(&E->mu); j->need_copy = 0; E->n_uncopied--; pthread_cond_broadcast(&E->cv_copied); pthread_mutex_unlock(&E->mu);
+        }
         t0 = now_s();
         emit_format(E->p, &j->c, &j->s, &j->e);
         pthread_mutex_lock(&E->mu);
@@ -184,10 +188,10 @@ static void *emitter_main(void *arg) {
 MDK_LOCAL int emitter_start(emitter *E, mdk_plan *p, int n_th) {
     int i;
     memset(E, 0, sizeof(*E));
-    E->p = p; E->n_th = n_th < 1 ? 1 : n_th; E->n_job = E->n_th + 2; E->next_write = p->next_emit;
+    E->p = p; E->n_th = n_th < 1 ? 1 : n_th; E->n_job = E->n_th + (getenv("MDK_EMIT_JOBS_EXTRA") ? atoi(getenv("MDK_EMIT_JOBS_EXTRA")) : 2); if(E->n_job < E->n_th + 1) E->n_job = E->n_th + 1; E->next_write = p->next_emit;
     E->job = xcalloc((size_t)E->n_job, sizeof(ejob)); E->th = xcalloc((size_t)E->n_th, sizeof(pthread_t));
     if(!E->job || !E->th) return -5;
-    pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv_job, NULL); pthread_cond_init(&E->cv_free, NULL); pthread_cond_init(&E->cv_turn, NULL);
+    pthread_mutex_init(&E->mu, NULL); pthread_cond_init(&E->cv_job, NULL); pthread_cond_init(&E->cv_free, NULL); pthread_cond_init(&E->cv_turn, NULL); pthread_cond_init(&E->cv_copied, NULL);
     {   /* regular output files (what -o makes): what has been written so far (the header lines) is flushed, from here on the
          * emitter threads write at explicit offsets.  Anything else (a FIFO, /dev/null) keeps the ordered stream writes. */
         const int nk = p->o.cytosine_report ? 1 : 3; int k;
@@ -204,25 +208,39 @@ MDK_LOCAL int emitter_start(emitter *E, mdk_plan *p, int n_th) {
     E->n_th = i;            /* fewer than asked for still drain the same queue */
     return 0;
 }
-/* hand a chunk and its sites over (both are copied: the caller's buffers are recycled) */
-MDK_LOCAL int emitter_push(emitter *E, const mdk_chunk *c, const md_sites *s) {
+/* hand a chunk and its sites over (both are copied: the caller's buffers are recycled).  lazy: a large site array is copied by the emitter
+ * thread that takes the job, not here -- the caller hands over all the chunks of a group and then waits for the copies with
+ * emitter_wait_copied before it recycles the buffers: the dense contexts' 6 MB per chunk, copied by the collector alone out of the pinned
+ * buffers the device had just written, were 0.19 s of a 128 Mb run's 0.66 s (profiles/r06c3_profile.txt) */
+static int emitter_push_ex(emitter *E, const mdk_chunk *c, const md_sites *s, int lazy);
+MDK_LOCAL int emitter_push(emitter *E, const mdk_chunk *c, const md_sites *s) { return emitter_push_ex(E, c, s, 0); }
+MDK_LOCAL int emitter_push_lazy(emitter *E, const mdk_chunk *c, const md_sites *s) { return emitter_push_ex(E, c, s, 1); }
+static double g_t_free = 0, g_t_fill = 0, g_t_copied = 0;      /* the collector's time in here by what it waited for (MDK_HOST_PROFILE) */
+MDK_LOCAL void emitter_wait_copied(emitter *E) { const double t0 = now_s(); pthread_mutex_lock(&E->mu); while(E->n_uncopied) pthread_cond_wait(&E->cv_copied, &E->mu); pthread_mutex_unlock(&E->mu); g_t_copied += now_s() - t0; }
+static int emitter_push_ex(emitter *E, const mdk_chunk *c, const md_sites *s, int lazy) {
     ejob *j = NULL; int i;
     if(c->index != E->p->next_emit) { fprintf(stderr, "[mdk] chunks must be emitted in order\n"); return -2; }
     if(E->failed) return -3;                     /* a write has failed (the reason was printed): the caller stops feeding the GPU for a file that cannot be completed */
     E->p->next_emit++;
+    const double tf0 = now_s();
     pthread_mutex_lock(&E->mu);
     for(;;) { for(i = 0; i < E->n_job; i++) if(E->job[i].state == EJ_FREE) { j = &E->job[i]; break; } if(j) break; pthread_cond_wait(&E->cv_free, &E->mu); }
     j->state = EJ_BUSY;                          /* being filled */
     pthread_mutex_unlock(&E->mu);
+    const double tf1 = now_s(); g_t_free += tf1 - tf0;
     j->c = *c; j->s = *s;
     if(s->n_sites > j->cap) {
         j->cap = s->n_sites + s->n_sites / 4 + 1024; free(j->site); free(j->var);
         j->site = malloc(sizeof(md_site) * (size_t)j->cap); j->var = malloc(sizeof(md_site_var) * (size_t)j->cap);
         if(!j->site || !j->var) { fprintf(stderr, "[mdk] out of memory while queueing a chunk for output\n"); abort(); }      /* nothing sensible can be written in order any more */
     }
-    if(s->n_sites) { memcpy(j->site, s->site, sizeof(md_site) * (size_t)s->n_sites); if(s->var) memcpy(j->var, s->var, sizeof(md_site_var) * (size_t)s->n_sites); }
+    { static long lazy_min = -1; if(lazy_min < 0) lazy_min = getenv("MDK_LAZY_COPY_MIN") ? atol(getenv("MDK_LAZY_COPY_MIN")) : 16384;      /* (256 KB: below that the copy is not worth a hand-over; the variable is a test hook) */
+      j->need_copy = lazy && s->n_sites >= lazy_min && s->n_sites > 0; }
+    if(j->need_copy) { j->src_site = s->site; j->src_var = s->var; }
+    else if(s->n_sites) { memcpy(j->site, s->site, sizeof(md_site) * (size_t)s->n_sites); if(s->var) memcpy(j->var, s->var, sizeof(md_site_var) * (size_t)s->n_sites); }
     j->s.site = j->site; j->s.var = s->var ? j->var : NULL;
-    pthread_mutex_lock(&E->mu); j->state = EJ_READY; pthread_cond_signal(&E->cv_job); pthread_mutex_unlock(&E->mu);
+    g_t_fill += now_s() - tf1;
+    pthread_mutex_lock(&E->mu); if(j->need_copy) E->n_uncopied++; j->state = EJ_READY; pthread_cond_signal(&E->cv_job); pthread_mutex_unlock(&E->mu);
     return 0;
 }
 MDK_LOCAL void emitter_stop(emitter *E) {
@@ -236,6 +254,7 @@ MDK_LOCAL void emitter_stop(emitter *E) {
     if(E->pw) { int k; const int nk = E->p->o.cytosine_report ? 1 : 3; for(k = 0; k < nk; k++) if((E->p->o.cytosine_report || E->p->o.ctx_on[k]) && E->p->out[k]) (void)fseeko(E->p->out[k], (off_t)E->woff[k], SEEK_SET); }
     for(i = 0; i < E->n_job; i++) { int k; free(E->job[i].site); free(E->job[i].var); for(k = 0; k < 3; k++) free(E->job[i].e.ob[k].s); }
     E->p->t_emit += E->t_format;
+    if(getenv("MDK_HOST_PROFILE")) fprintf(stderr, "[mdk host] handing chunks to the emitter: waiting for a free job %.3fs, sizing and copying %.3fs, waiting for the emitter threads' copies %.3fs\n", g_t_free, g_t_fill, g_t_copied);
     free(E->job); free(E->th); E->th = NULL;
 }
 

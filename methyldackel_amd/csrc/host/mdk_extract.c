@@ -188,7 +188,8 @@ static void *collector_main(void *arg) {
         if(bad) break;
         ta = now_s();
         g_col_phase = 3;
-        for(i = 0; i < g->n; i++) if(emitter_push(X->em, &g->ch[i], &sites[i])) { xp_fail(X, X->em->failed ? MDK_RC_OUTPUT : MDK_RC_DEVICE); bad = 1; break; }
+        for(i = 0; i < g->n; i++) if(emitter_push_lazy(X->em, &g->ch[i], &sites[i])) { xp_fail(X, X->em->failed ? MDK_RC_OUTPUT : MDK_RC_DEVICE); bad = 1; break; }
+        emitter_wait_copied(X->em);                  /* (the emitter threads copy the group's site arrays side by side; the slots' buffers are the device's again from here) */
         X->w_emit += now_s() - ta;
         if(bad) break;
         g_col_phase = 0;

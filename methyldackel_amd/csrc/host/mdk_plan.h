@@ -125,9 +125,9 @@ struct mdk_plan {
 
 /* extract_main's emitter: chunks are formatted by a few threads and written in chunk order (mdk_emit.c) */
 enum { EJ_FREE = 0, EJ_READY, EJ_BUSY };
-typedef struct { int state; mdk_chunk c; md_sites s; md_site *site; md_site_var *var; int64_t cap; emit_ctx e; } ejob;
+typedef struct { int state; mdk_chunk c; md_sites s; md_site *site; md_site_var *var; int64_t cap; emit_ctx e; const md_site *src_site; const md_site_var *src_var; int need_copy; } ejob;      /* need_copy: the sites still lie in the caller's buffer (emitter_push_lazy): the thread that takes the job copies them first */
 typedef struct {
-    mdk_plan *p; ejob *job; int n_job, n_th; pthread_t *th; pthread_mutex_t mu; pthread_cond_t cv_job, cv_free, cv_turn;
+    mdk_plan *p; ejob *job; int n_job, n_th; pthread_t *th; pthread_mutex_t mu; pthread_cond_t cv_job, cv_free, cv_turn, cv_copied; int n_uncopied;
     uint32_t next_write; int quit; double t_format;
     int pw, fd[3], failed; int64_t woff[3];      /* pw: the outputs are regular files -> a chunk reserves its byte range in turn and is written with pwrite outside the lock */
 } emitter;
@@ -147,6 +147,8 @@ MDK_LOCAL int pipeline_start(mdk_plan *p);
 MDK_LOCAL void pipeline_stop(mdk_plan *p);
 MDK_LOCAL int emitter_start(emitter *E, mdk_plan *p, int n_th);
 MDK_LOCAL int emitter_push(emitter *E, const mdk_chunk *c, const md_sites *s);
+MDK_LOCAL int emitter_push_lazy(emitter *E, const mdk_chunk *c, const md_sites *s);      /* a large site array is copied by the emitter thread that takes the job: ... */
+MDK_LOCAL void emitter_wait_copied(emitter *E);                                              /* ... and the caller waits here before it recycles the buffers it handed over */
 MDK_LOCAL void emitter_stop(emitter *E);
 /* the device index as the user gave it (the command narrows the runtime's view to that device, which then is number 0: csrc/host/main.c) */
 static inline int user_device(int d) { const char *u = getenv("MDK_DEVICE_USER"); return u ? atoi(u) : d; }

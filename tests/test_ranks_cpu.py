@@ -58,7 +58,7 @@ def same_outputs(od, gd):
 
 @pytest.mark.parametrize("extra,env", [([], {}), (["--chunkSize", "7000", "--mergeContext", "--CHG"], {"MDK_FASTA_THREADS": 5}), (["--chunkSize", "20000"], {"MDK_STANDIN_HANDBACK": 3}),
                                        (["--chunkSize", "333333", "--minOppositeDepth", "2", "--maxVariantFrac", "0.3", "--CHH"], {}), (["--chunkSize", "5000"], {"MDK_DEVICE_INFLATE_ONLY": 1, "MDK_GPU_PIECE_MB": "0.25", "MDK_STANDIN_HANDBACK": 5}),
-                                       (["--chunkSize", "3000", "--CHG"], {"MDK_GROUPS_IN_FLIGHT": 5, "MDK_STANDIN_HANDBACK": 7, "MDK_STANDIN_US_PER_KREC": 20000}), (["--chunkSize", "3000"], {"MDK_GROUPS_IN_FLIGHT": 2}),
+                                       (["--chunkSize", "3000", "--CHG"], {"MDK_GROUPS_IN_FLIGHT": 5, "MDK_STANDIN_HANDBACK": 7, "MDK_STANDIN_US_PER_KREC": 20000}), (["--chunkSize", "3000"], {"MDK_GROUPS_IN_FLIGHT": 2, "MDK_LAZY_COPY_MIN": 1}),
                                        (["--chunkSize", "5000"], {"MDK_DEVICE_INFLATE_ONLY": 1, "MDK_GPU_PIECE_MB": "0.5", "MDK_DSLAB_EXTRA": 1, "MDK_GPU_INFLATE_TEAMS": 3})])
 def test_extract_main_on_the_standin_equals_oracle(data, tmp_path, extra, env):
     """one process: extract_main's threads, groups of chunks in flight, slabs given back early, chunks handed back to the host preparation, pieces
