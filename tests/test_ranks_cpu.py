@@ -93,7 +93,8 @@ def run_ranks_cpu(args, n, cwd, env):
 
 
 @pytest.mark.parametrize("world,extra,env", [(2, ["--chunkSize", "9000", "--CHG", "--mergeContext"], {}), (3, ["--chunkSize", "20000"], {"MDK_STANDIN_HANDBACK": 4}), (2, ["--chunkSize", "9000"], {"MDK_NO_INDEX": 1}),
-                                             (3, ["--chunkSize", "9000", "--CHG"], {"MDK_CLAIM": 1}), (2, ["--chunkSize", "20000"], {"MDK_CLAIM": 1, "MDK_NO_INDEX": 1, "MDK_STANDIN_HANDBACK": 3})])
+                                             (3, ["--chunkSize", "9000", "--CHG"], {"MDK_CLAIM": 1}), (2, ["--chunkSize", "20000"], {"MDK_CLAIM": 1, "MDK_NO_INDEX": 1, "MDK_STANDIN_HANDBACK": 3}),
+                                             (8, ["--chunkSize", "2000"], {}), (8, ["--chunkSize", "2000", "--CHH"], {"MDK_CLAIM": 1})])      # (eight ranks: rank 0 collects seven others' chunks in schedule order)
 def test_ranks_driver_on_the_standin_equals_oracle(data, tmp_path, world, extra, env):
     """mdk_ranks.c itself, N processes over its TCP connections: chunks dealt k mod N and claimed (MDK_CLAIM=1), with and without the index, with
     chunks handed back to the host on the rank that holds their records"""
