@@ -120,7 +120,11 @@ struct InfShared {
 // instructions per byte: the window is addressed straight.  Every access of either array goes through these two.
 typedef uint32_t __attribute__((may_alias)) inf_u32a;      // (dword views of the byte / halfword arrays: may_alias keeps the compilers' type-based reordering off them)
 MDK_HD uint32_t inf_win_at(uint32_t p) { return p & (INF_WIN - 1); }
+#ifndef INF_AUX_STRAIGHT
 MDK_HD uint32_t inf_aux_at(uint32_t r) { return r ^ (((r >> 6) & 15u) << 1); }
+#else
+MDK_HD uint32_t inf_aux_at(uint32_t r) { return r; }      /* (counter comparisons: profiles/r06i5_inflate_lds_counters.txt) */
+#endif
 
 // The decoder's registers between batches.  `bb` holds the next `cnt` bits of the stream, least significant first; 32 <= cnt <= 63
 // between any two steps, so a step can look at 32 bits without asking.
